@@ -1,0 +1,189 @@
+"""The oracle (oracle/np_oracle.py) against the golden vectors generated from the reference.
+
+CPU only.  This is what pins the oracle: the reference itself has no tests.
+Tolerances: the goldens are the reference's fp32 outputs, the oracle is fp64 -> a few fp32 ulps
+of headroom relative to the largest element (observed <= 2.4e-7).
+"""
+import numpy as np
+import pytest
+
+from conftest import formula_weights, mlp_formula_params, rel_err
+from oracle import np_oracle as O
+
+TOL = 2e-6
+
+
+def grad_scale(c):
+    """Size of the un-cancelled positive-pair gradient term: (2 alpha / (B tau)) max |d|d|^p/dd|."""
+    m = c["meta"]
+    if "p" not in m:
+        return 0.0
+    p = float(m["p"]); tau = float(m["tau"]); alpha = float(m["alpha"]) if "alpha" in m else 0.5
+    d = np.abs(np.asarray(c["in"]["z1"], np.float64) - np.asarray(c["in"]["z2"], np.float64))
+    if d.size == 0:
+        return 0.0
+    return 2 * alpha / (d.shape[0] * tau) * float((p * np.maximum(d, 1e-12) ** (p - 1)).max())
+
+
+def _check_loss_case(c, out, tol=TOL, grads=("dz1", "dz2", "dz3")):
+    # loss_i = 2(alpha*pos/tau + (1-alpha)*lse) cancels when the positive dominates the
+    # softmax (lse ~ -pos/tau), so "relative" is taken w.r.t. the size of the two summands:
+    # that is the fp32 rounding scale of the reference itself.
+    B3 = c["in"]["z3"].shape[0] if "z3" in c["in"] else c["in"]["z1"].shape[0]
+    comp = max(float(np.abs(out["loss_i"]).max()), float(np.abs(out["lse"]).max()) + np.log(B3 + 1.0), 1e-30)
+    assert abs(float(out["loss_mean"]) - float(c["out"]["loss_mean"])) < tol * comp
+    assert np.abs(out["loss_i"] - c["out"]["loss_i"]).max() < tol * comp
+    if "pos_mean" in c["out"]:
+        assert abs(float(out["pos_mean"]) - float(c["out"]["pos_mean"])) < tol * max(1.0, abs(float(c["out"]["pos_mean"])))
+        assert abs(float(out["neg_mean"]) - float(c["out"]["neg_mean"])) < tol * max(1.0, abs(float(c["out"]["neg_mean"])))
+    for g in grads:
+        ref = c["out"][g]
+        # gradients are a difference of two O(gscale) terms (alignment pull vs softmax push)
+        scale = max(np.abs(ref).max(), grad_scale(c), 1e-30)
+        # softmax weights exp(-neg/tau - lse) inherit the ABSOLUTE fp32 rounding of the exponent,
+        # i.e. a relative error ~ eps * |lse| in the saturated (scale=3, p=3) cases
+        sat = max(1.0, float(np.abs(out["lse"]).max()))
+        assert np.abs(out[g] - ref).max() / scale < 5 * tol * sat, g
+
+
+@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz"])
+def test_lp_loss_goldens(golden, name):
+    G = golden(name)
+    assert G.n_cases > 0
+    for key, c in G.cases():
+        m = c["meta"]
+        out = O.lp_simclr_loss(c["in"]["z1"], c["in"]["z2"], c["in"]["z3"], p=float(m["p"]),
+                               tau=float(m["tau"]), alpha=float(m["alpha"]),
+                               compat=bool(m["compat"]), pow=bool(m["pow"]))
+        _check_loss_case(c, out)
+
+
+def test_lp_loss_roll_goldens(golden):
+    G = golden("g1r_lp_roll.npz")
+    for key, c in G.cases():
+        m = c["meta"]
+        z1, z2 = c["in"]["z1"], c["in"]["z2"]
+        out = O.lp_simclr_loss(z1, z2, np.roll(z1, 1, 0), p=float(m["p"]), tau=float(m["tau"]),
+                               alpha=float(m["alpha"]), compat=True, pow=True)
+        out["dz1"] = out["dz1"] + np.roll(out["dz3"], -1, 0)
+        _check_loss_case(c, out, grads=("dz1", "dz2"))
+
+
+def test_analytic_kats():
+    """All-zero embeddings: compat -> ln(B+1); default -> 0."""
+    for B in (8, 512):
+        z = np.zeros((B, 10))
+        assert abs(O.lp_simclr_loss(z, z, z, 2, compat=True, grad=False)["loss_mean"] - np.log(B + 1)) < 1e-12
+        assert abs(O.lp_simclr_loss(z, z, z, 2, compat=False, grad=False)["loss_mean"]) < 1e-12
+
+
+def test_lp_loss_grad_finite_difference():
+    """Independent check of the analytic backward incl. upstream grads on all four outputs."""
+    rng = np.random.default_rng(0)
+    z1 = rng.normal(size=(7, 3)); z2 = z1 + 0.1 * rng.normal(size=(7, 3)); z3 = rng.normal(size=(9, 3))
+    gi = rng.normal(size=7)
+    for p in (1, 2, 3, 1.5):
+        for compat in (True, False):
+            for pw in (True, False):
+                kw = dict(p=p, tau=0.7, alpha=0.3, compat=compat, pow=pw)
+
+                def scalar(a, b, c):
+                    o = O.lp_simclr_loss(a, b, c, grad=False, **kw)
+                    return 1.3 * o["loss_mean"] + (gi * o["loss_i"]).sum() + 0.4 * o["pos_mean"] - 0.2 * o["neg_mean"]
+                out = O.lp_simclr_loss(z1, z2, z3, g_mean=1.3, g_item=gi, g_pos=0.4, g_neg=-0.2, **kw)
+                for name, arr, idx in (("dz1", z1, 0), ("dz2", z2, 1), ("dz3", z3, 2)):
+                    num = np.zeros_like(arr)
+                    for i in np.ndindex(arr.shape):
+                        args = [z1.copy(), z2.copy(), z3.copy()]
+                        args[idx][i] += 1e-6; up = scalar(*args)
+                        args[idx][i] -= 2e-6; dn = scalar(*args)
+                        num[i] = (up - dn) / 2e-6
+                    assert np.abs(num - out[name]).max() < 1e-6, (p, compat, pw, name)
+
+
+def test_simclr_goldens(golden):
+    G = golden("g5_simclr.npz")
+    for key, c in G.cases():
+        m = c["meta"]
+        out = O.simclr_loss(c["in"]["z1"], c["in"]["z2"], c["in"]["z3"], normalize=bool(m["normalize"]),
+                            tau=float(m["tau"]), alpha=float(m["alpha"]))
+        _check_loss_case(c, out)
+
+
+def test_mlp_goldens(golden):
+    G = golden("g6_mlp.npz")
+    for key, c in G.cases():
+        n = int(c["meta"]["n"]); head = str(c["meta"]["head"]); hidden = [int(h) for h in c["meta"]["hidden"]]
+        head = None if head == "None" else head
+        Ws, bs, hp = mlp_formula_params(n, hidden, head)
+        P = O.MLPParams(Ws, bs, head, hp)
+        y, cache = O.mlp_forward(P, c["in"]["x"])
+        assert rel_err(y, c["out"]["y"]) < 5e-6, key
+        gr = O.mlp_backward(P, cache, c["in"]["gy"])
+        assert rel_err(gr["dx"], c["out"]["dx"]) < 2e-5, key
+        for l in range(len(Ws)):
+            for kind, got in (("weight", gr["dW"][l]), ("bias", gr["db"][l])):
+                nm = f"{2 * l}.{kind}"
+                if f"grad/{nm}" in c["out"]:
+                    assert rel_err(got, c["out"][f"grad/{nm}"]) < 2e-5, (key, nm)
+                else:
+                    sub = np.ascontiguousarray(got.reshape(-1)[::97])
+                    assert rel_err(sub, c["out"][f"gradsub/{nm}"]) < 2e-5, (key, nm)
+                    s = c["out"][f"gradsum/{nm}"]
+                    assert abs(got.sum() - s[0]) < 2e-5 * max(1.0, np.abs(got).sum())
+        last = 2 * len(Ws) - 1
+        if head == "learnable_sphere":
+            assert rel_err(gr["dhead"], c["out"][f"grad/{last}.r"]) < 2e-5
+        if head == "learnable_box":
+            assert rel_err(gr["dhead"], c["out"][f"grad/{last}.max_abs_bound"]) < 2e-5
+        keys = [str(k) for k in c["meta"]["state_keys"]]
+        assert keys[:2] == ["0.weight", "0.bias"]
+
+
+def test_mixing_golden(golden):
+    z = golden("g8_mixing.npz").z
+    y = O.mixing_forward([z["W0"], z["W1"], z["W2"]], z["x"])
+    assert rel_err(y, z["y"]) < 2e-6
+
+
+def test_trainstep_goldens(golden):
+    G = golden("g7_trainstep.npz")
+    for key, c in G.cases():
+        p = int(c["meta"]["p"]); head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]; n = 4
+        Ws, bs, hp = mlp_formula_params(n, hidden, head)
+        P = O.MLPParams(Ws, bs, head, hp)
+        nparam = 2 * len(Ws) + (1 if head in ("learnable_sphere", "learnable_box") else 0)
+        shapes = []
+        for l in range(len(Ws)):
+            shapes += [Ws[l].shape, bs[l].shape]
+        if nparam > 2 * len(Ws):
+            shapes.append(hp.shape)
+        st = dict(step=0, m=[np.zeros(s) for s in shapes], v=[np.zeros(s) for s in shapes])
+        gWs = [c["in"][f"g{i}"] for i in range(3)]
+        for s in range(5):
+            loss, pm, nm = O.train_step(P, gWs, c["in"][f"z1_{s}"], c["in"][f"z2_{s}"], st, p=p,
+                                        lr=float(c["meta"]["lr"]))
+            assert abs(loss - c["out"]["loss"][s]) < 1e-5 * abs(c["out"]["loss"][s]), (key, s)
+            assert abs(pm - c["out"]["pos"][s]) < 1e-5 * max(1.0, abs(c["out"]["pos"][s]))
+            assert abs(nm - c["out"]["neg"][s]) < 1e-5 * max(1.0, abs(c["out"]["neg"][s]))
+        for l in range(len(Ws)):
+            for kind, got in (("weight", P.W[l]), ("bias", P.b[l])):
+                ref = c["out"][f"param5/{2 * l}.{kind}"]
+                got = got if ref.size == got.size else np.ascontiguousarray(got.reshape(-1)[::7])
+                # Adam's first steps move every weight by ~lr regardless of gradient size, so
+                # sign flips of ~0 gradients make a few elements differ by O(lr): compare in bulk
+                diff = np.abs(got.reshape(-1) - ref.reshape(-1))
+                if l == len(Ws) - 1 and kind == "bias" and head is None:
+                    # Lp distances are translation invariant: the exact gradient of the last bias
+                    # is 0, the computed one is rounding noise, and Adam turns noise into +-lr
+                    # steps.  Only a random-walk bound is meaningful here.
+                    assert diff.max() <= 5 * float(c["meta"]["lr"]) * 1.01
+                    continue
+                assert np.median(diff) < 1e-6, (key, l, kind)
+                assert (diff > 2e-4).mean() < 0.01, (key, l, kind, float((diff > 2e-4).mean()))
+
+
+def test_formula_in_sync(golden):
+    c = golden("g6_mlp.npz").case("c000")
+    assert np.array_equal(c["in"]["x"], np.asarray(formula_weights((48, 4), 99) * np.sqrt(4) * 1.5, np.float32))
