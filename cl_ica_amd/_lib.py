@@ -1,0 +1,144 @@
+"""ctypes binding of libclica_hip.so (C ABI: include/clica.h).
+
+The HIP library IS the product path: if it is missing or a call fails this module raises --
+there is no eager/PyTorch fallback anywhere in cl_ica_amd.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libclica_hip.so")
+
+c_f32p = C.c_void_p
+c_i64 = C.c_int64
+c_i32 = C.c_int32
+c_size = C.c_size_t
+
+
+class LpLossDesc(C.Structure):
+    _fields_ = [("B", c_i64), ("B3", c_i64), ("n", c_i32), ("p", C.c_float), ("tau", C.c_float),
+                ("alpha", C.c_float), ("compat", c_i32), ("pow", c_i32)]
+
+
+class DotLossDesc(C.Structure):
+    _fields_ = [("B", c_i64), ("B3", c_i64), ("n", c_i32), ("tau", C.c_float), ("alpha", C.c_float),
+                ("normalize", c_i32)]
+
+
+class SamplerDesc(C.Structure):
+    _fields_ = [("space", c_i32), ("dist", c_i32), ("n", c_i32), ("box_min", C.c_float),
+                ("box_max", C.c_float), ("scale", C.c_float), ("shape_p", C.c_float),
+                ("seed", C.c_uint64), ("stream_id", C.c_uint32)]
+
+
+_LOSS_FWD = [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_size, C.c_void_p]
+_LOSS_BWD = [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+             c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p, c_size, C.c_void_p]
+
+# name -> argtypes (restype is int for all but clica_last_error); mirrors include/clica.h
+SIGNATURES: Dict[str, list] = {
+    "clica_version": [],
+    "clica_lp_loss_workspace_bytes": [C.POINTER(LpLossDesc), C.POINTER(c_size), C.POINTER(c_size)],
+    "clica_lp_loss_fwd": [C.POINTER(LpLossDesc)] + _LOSS_FWD,
+    "clica_lp_loss_bwd": [C.POINTER(LpLossDesc)] + _LOSS_BWD,
+    "clica_dot_loss_workspace_bytes": [C.POINTER(DotLossDesc), C.POINTER(c_size), C.POINTER(c_size)],
+    "clica_dot_loss_fwd": [C.POINTER(DotLossDesc)] + _LOSS_FWD,
+    "clica_dot_loss_bwd": [C.POINTER(DotLossDesc)] + _LOSS_BWD,
+    "clica_linear_fwd": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64, c_i32, C.c_float, C.c_void_p],
+    "clica_linear_dgrad": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_float, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p],
+    "clica_linear_wgrad_workspace_bytes": [c_i64, c_i64, c_i64, C.POINTER(c_size)],
+    "clica_linear_wgrad": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i64, c_i32, C.c_void_p, c_size, C.c_void_p],
+    "clica_rescale_fwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
+    "clica_rescale_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
+    "clica_softclip_fwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],
+    "clica_softclip_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
+    "clica_mixing_fwd": [c_f32p, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],
+    "clica_adam_step": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "clica_tick": [C.c_void_p, C.c_void_p],
+    "clica_sample": [C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class ClicaError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise.  Never falls back to anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ClicaError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cl_ica_amd/csrc -j8`).  cl_ica_amd has no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.clica_last_error.restype = C.c_char_p
+    lib.clica_last_error.argtypes = []
+    missing = []
+    for name, args in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.argtypes = args
+        fn.restype = C.c_int
+    if missing:
+        raise ClicaError(f"{LIB_PATH} does not export {missing}; rebuild it (stale library?)")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().clica_last_error().decode("utf-8", "replace")
+        raise ClicaError(f"{what} failed (rc={rc}): {msg}")
+
+
+def require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise ClicaError(f"{name} must live on the GPU (got device {t.device}); cl_ica_amd runs only "
+                         "through its HIP kernels")
+    if t.dtype != torch.float32:
+        raise ClicaError(f"{name} must be float32 (got {t.dtype})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def rowmajor(t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """Return (tensor usable by the kernels, leading dimension).  Strided row views
+    (mu[::2], z[:, :k]) are passed through without a copy."""
+    assert t.dim() == 2
+    if t.shape[1] == 1 or t.stride(1) == 1:
+        ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+        if ld >= t.shape[1]:
+            return t, ld
+    t = t.contiguous()
+    return t, t.shape[1]
+
+
+# zero-initialised scratch per (device, stream, tag): the loss forward keeps a ticket word in it
+_WS: Dict[Tuple[int, int, str], torch.Tensor] = {}
+
+
+def workspace(tag: str, nbytes: int, device: torch.device) -> torch.Tensor:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(), tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.zeros(max(nbytes, 1024), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf

@@ -1,0 +1,67 @@
+// Fused Adam over one flat parameter arena: torch.optim.Adam(lr, betas, eps) exactly as the
+// reference constructs it (/root/reference/main_mlp.py:312; no weight decay, no amsgrad):
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// HBM-bound: 16 B read + 12 B written per parameter, one launch for all layers.
+#include "common.h"
+
+namespace clica {
+namespace adam {
+constexpr int THREADS = 256;
+
+__global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                 float* __restrict__ v, int64_t count, float lr, float b1, float b2, float eps,
+                                                 float gscale, const int32_t* __restrict__ step_dev) {
+  __shared__ float s_step_size, s_inv_bc2_sqrt;
+  if (threadIdx.x == 0) {
+    const double t = (double)(step_dev[0] + 1);
+    const double bc1 = 1.0 - pow((double)b1, t);
+    const double bc2 = 1.0 - pow((double)b2, t);
+    s_step_size = (float)((double)lr / bc1);
+    s_inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  }
+  __syncthreads();
+  const float step_size = s_step_size, inv_bc2_sqrt = s_inv_bc2_sqrt;
+  const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+  const int64_t n4 = count / 4;
+  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += stride) {
+    float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+    float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float gr = ga[u] * gscale;
+      ma[u] = b1 * ma[u] + omb1 * gr;
+      va[u] = b2 * va[u] + omb2 * gr * gr;
+      pa[u] -= step_size * ma[u] / (sqrtf(va[u]) * inv_bc2_sqrt + eps);
+    }
+    p4[i] = pp; m4[i] = mm; v4[i] = vv;
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * THREADS + threadIdx.x; i < count; i += stride) {
+    const float gr = g[i] * gscale;
+    const float mn = b1 * m[i] + omb1 * gr;
+    const float vn = b2 * v[i] + omb2 * gr * gr;
+    m[i] = mn; v[i] = vn;
+    p[i] -= step_size * mn / (sqrtf(vn) * inv_bc2_sqrt + eps);
+  }
+}
+}  // namespace adam
+}  // namespace clica
+
+using namespace clica;
+
+extern "C" int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                               float lr, float beta1, float beta2, float eps, float grad_scale,
+                               const int32_t* step_dev, clica_stream_t stream) {
+  CLICA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && count > 0, "clica_adam_step: bad argument");
+  CLICA_CHECK_ARG(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
+                  "clica_adam_step: arenas must be 16-byte aligned");
+  int64_t blocks = ceil_div(ceil_div(count, 4), adam::THREADS);
+  if (blocks > kNumCU * 8) blocks = kNumCU * 8;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks), dim3(adam::THREADS), 0, as_stream(stream),
+                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev);
+  return launch_status("clica_adam_step");
+}

@@ -1,0 +1,488 @@
+// C ABI of the Lp InfoNCE loss (include/clica.h) -- planning, workspace carve-up, launches.
+// Kernels: lp_kernels.h; per-exponent instantiations: lp_loss_pk.hip.
+#include "lp_kernels.h"
+
+namespace clica {
+namespace lp {
+
+// ---- positive pair ---------------------------------------------------------------------------
+// returns sum of powers; frac (p<1) branch: (|z1-z2| + 1e-12)^p  (losses.py:439-441)
+__device__ __forceinline__ float pos_sum(const float* a, const float* b, int n, const Params& q, bool frac) {
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) {
+    float d = a[k] - b[k];
+    float t;
+    if (frac) t = exp2f(q.p * log2f(fabsf(d) + 1e-12f));
+    else if (q.p == 2.f) t = d * d;
+    else if (q.p == 1.f) t = fabsf(d);
+    else if (q.p == 3.f) t = fabsf(d) * d * d;
+    else t = fabsf(d) > 0.f ? exp2f(q.p * log2f(fabsf(d))) : 0.f;
+    s += t;
+  }
+  return s;
+}
+
+struct Means {
+  float* blocksums;      // [gridDim.x][3]
+  unsigned int* ticket;  // zero on entry, reset by the last block
+  float* means;          // [3]
+};
+
+// deterministic grid reduction of three per-thread values: block tree -> per-block slot ->
+// last-arriving block sums the slots in index order (release/acquire at agent scope).
+__device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const Means& M, float inv_count) {
+  __shared__ float red[3][THREADS / 64];
+  float v[3] = {v0, v1, v2};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) { red[0][wave] = v[0]; red[1][wave] = v[1]; red[2][wave] = v[2]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int a = 0; a < 3; ++a) {
+      float t = 0.f;
+      for (int w = 0; w < THREADS / 64; ++w) t += red[a][w];
+      M.blocksums[blockIdx.x * 3 + a] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned int prev = __hip_atomic_fetch_add(M.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+      for (unsigned int b = 0; b < gridDim.x; ++b) {
+        t0 += __hip_atomic_load(&M.blocksums[b * 3 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t1 += __hip_atomic_load(&M.blocksums[b * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t2 += __hip_atomic_load(&M.blocksums[b * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      M.means[0] = t0 * inv_count;
+      M.means[1] = t1 * inv_count;
+      M.means[2] = t2 * inv_count;
+      __hip_atomic_store(M.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void fwd_finalize_k(
+    const float2* __restrict__ part, int nsplit, int64_t rows,
+    const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
+    Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
+    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M) {
+  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  float v_loss = 0.f, v_pos = 0.f, v_lse = 0.f;
+  if (i < rows) {
+    float m = -1e30f, s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float2 ps = part[(int64_t)sp * rows + i];
+      const float mn = fmaxf(m, ps.x);
+      s = s * exp2f(m - mn) + ps.y * exp2f(ps.x - mn);
+      m = mn;
+    }
+    float pos, xp;
+    if (dot) {   // SimCLRLoss: pos = <z1, z2> and the logit is +pos/tau (losses.py:188-193)
+      pos = 0.f;
+      for (int k = 0; k < q.n; ++k) pos += z1[i * ld1 + k] * z2[i * ld2 + k];
+      xp = pos * q.kscale;
+      pos = -pos;  // loss_pos = -pos/tau (losses.py:192)
+    } else {
+      const float sp_ = pos_sum(z1 + i * ld1, z2 + i * ld2, q.n, q, frac != 0);
+      pos = root_of(sp_, q);
+      xp = -pos * q.kscale;
+    }
+    if (compat) {  // positive pair joins the softmax denominator (losses.py:459-462)
+      const float mn = fmaxf(m, xp);
+      s = s * exp2f(m - mn) + exp2f(xp - mn);
+      m = mn;
+    }
+    const float lse_raw = (m + log2f(s)) * kLn2;
+    const float lse = compat ? lse_raw : lse_raw - log_b3;   // _logmeanexp, losses.py:506-510
+    const float lp = pos / tau;
+    const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
+    loss_i[i] = li; pos_i[i] = lp; lse_i[i] = lse_raw;
+    v_loss = li; v_pos = lp; v_lse = lse;
+  }
+  reduce_means(v_loss, v_pos, v_lse, M, 1.f / (float)rows);
+}
+
+// ---- backward ------------------------------------------------------------------------------
+// per-row coefficients + the positive-pair gradient
+//   statL[i] = lse_raw[i] * log2(e);  statC[i] = -(C_i / tau)  with C_i the upstream weight of lse_i
+__global__ __launch_bounds__(THREADS) void bwd_coef_k(
+    int64_t rows, const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
+    Params q, float tau, float alpha, int compat, int frac, int dot, const float* __restrict__ lse_i,
+    const float* __restrict__ g_mean, const float* __restrict__ g_item,
+    const float* __restrict__ g_pos, const float* __restrict__ g_neg,
+    float* __restrict__ statL, float* __restrict__ statC,
+    float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2) {
+  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (i >= rows) return;
+  const float inv_rows = 1.f / (float)rows;
+  const float gi = (g_mean ? g_mean[0] : 1.f) * inv_rows + (g_item ? g_item[i] : 0.f);
+  const float A = 2.f * alpha * gi + (g_pos ? g_pos[0] * inv_rows : 0.f);
+  const float C = 2.f * (1.f - alpha) * gi + (g_neg ? g_neg[0] * inv_rows : 0.f);
+  const float L = lse_i[i];
+  statL[i] = L * kLog2e;
+  statC[i] = q.xs * C / tau;
+  if (!dz1 && !dz2) return;
+  const float* a = z1 + i * ld1;
+  const float* b = z2 + i * ld2;
+  if (dot) {
+    float pos = 0.f;
+    for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
+    const float dpos = -A / tau + (C / tau) * exp2f(pos * q.kscale - L * kLog2e);
+    for (int k = 0; k < q.n; ++k) {
+      if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
+      if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
+    }
+    return;
+  }
+  const float sp_ = pos_sum(a, b, q.n, q, frac != 0);
+  const float pos = root_of(sp_, q);
+  float cpos = A / tau;
+  if (compat) cpos -= (C / tau) * exp2f(-pos * q.kscale - L * kLog2e);
+  cpos *= droot_of(sp_, q);  // includes the factor p
+  for (int k = 0; k < q.n; ++k) {
+    const float d = a[k] - b[k];
+    float dt;
+    if (frac) {
+      const float v = exp2f((q.p - 1.f) * log2f(fabsf(d) + 1e-12f));
+      dt = d > 0.f ? v : (d < 0.f ? -v : 0.f);
+    } else if (q.p == 2.f) dt = d;
+    else if (q.p == 1.f) dt = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
+    else if (q.p == 3.f) dt = d * fabsf(d);
+    else {
+      const float ad = fabsf(d);
+      const float v = ad > 0.f ? exp2f((q.p - 1.f) * log2f(ad)) : 0.f;
+      dt = d < 0.f ? -v : v;
+    }
+    const float g = cpos * dt;
+    if (dz1) dz1[i * ldd1 + k] = g;
+    if (dz2) dz2[i * ldd2 + k] = -g;
+  }
+}
+
+// out[i,k] (+)= sum_split part[split][i][k]
+__global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
+                                                       int np, int n, float* __restrict__ out, int64_t ldo,
+                                                       int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= rows * np) return;
+  const int64_t i = idx / np;
+  const int k = (int)(idx - i * np);
+  if (k >= n) return;
+  float t = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) t += part[((int64_t)sp * rows + i) * np + k];
+  float* dst = out + i * ldo + k;
+  *dst = accumulate ? (*dst + t) : t;
+}
+
+static Params make_params(const clica_lp_loss_desc* d, bool frac) {
+  Params q;
+  q.p = d->p; q.inv_p = 1.f / d->p; q.kscale = kLog2e / d->tau;
+  q.sgn = frac ? -1.f : 1.f; q.eps = frac ? 1e-12f : 0.f; q.xs = -1.f;
+  q.pow = d->pow ? 1 : 0; q.n = d->n;
+  return q;
+}
+static int exponent_kind(float p) { return p == 1.f ? 1 : (p == 2.f ? 2 : (p == 3.f ? 3 : 0)); }
+
+static void launch_fwd_partial(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own,
+                               const float* str, int64_t lds, int64_t n_str, const Params& q,
+                               float2* part, hipStream_t st) {
+  switch (pk) {
+    case 1: launch_fwd_partial_pk1(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
+    case 2: launch_fwd_partial_pk2(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
+    case 3: launch_fwd_partial_pk3(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
+    case 4: launch_fwd_partial_pk4(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
+    default: launch_fwd_partial_pk0(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
+  }
+}
+static void launch_bwd_pairs(bool owner_stats, const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own,
+                             const float* str, int64_t lds, int64_t n_str, const Params& q,
+                             const float* statL, const float* statC, float* part, hipStream_t st) {
+  switch (pk) {
+    case 1: launch_bwd_pairs_pk1(P, owner_stats, own, ldo, n_own, str, lds, n_str, q, statL, statC, part, st); break;
+    case 2: launch_bwd_pairs_pk2(P, owner_stats, own, ldo, n_own, str, lds, n_str, q, statL, statC, part, st); break;
+    case 3: launch_bwd_pairs_pk3(P, owner_stats, own, ldo, n_own, str, lds, n_str, q, statL, statC, part, st); break;
+    case 4: launch_bwd_pairs_pk4(P, owner_stats, own, ldo, n_own, str, lds, n_str, q, statL, statC, part, st); break;
+    default: launch_bwd_pairs_pk0(P, owner_stats, own, ldo, n_own, str, lds, n_str, q, statL, statC, part, st); break;
+  }
+}
+
+// workspace carve-up ------------------------------------------------------------------------------
+struct FwdWs { float2* part; float* blocksums; unsigned int* ticket; size_t bytes; };
+struct BwdWs { float* statL; float* statC; float* partR; float* partC; size_t bytes; };
+
+static FwdWs carve_fwd(void* ws, const Plan& P, int64_t rows) {
+  FwdWs w; char* p = (char*)ws; size_t off = 0;
+  w.ticket = (unsigned int*)(p + off); off += 256;   // must be zero before first use (see .h)
+  w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, THREADS) * 3 * sizeof(float), 256);
+  w.part = (float2*)(p + off); off += align_up((size_t)P.nsplit * rows * sizeof(float2), 256);
+  w.bytes = off; return w;
+}
+static BwdWs carve_bwd(void* ws, const Plan& PR, const Plan& PC, int64_t rows, int64_t cols) {
+  BwdWs w; char* p = (char*)ws; size_t off = 256;   // keep clear of the forward's ticket word
+  w.statL = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
+  w.statC = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
+  w.partR = (float*)(p + off); off += align_up((size_t)PR.nsplit * rows * PR.np * sizeof(float), 256);
+  w.partC = (float*)(p + off); off += align_up((size_t)PC.nsplit * cols * PC.np * sizeof(float), 256);
+  w.bytes = off; return w;
+}
+
+static int validate(const clica_lp_loss_desc* d, const char* who) {
+  CLICA_CHECK_ARG(d != nullptr, "%s: desc is NULL", who);
+  CLICA_CHECK_ARG(d->B > 0 && d->B3 > 0, "%s: B=%lld B3=%lld must be positive", who, (long long)d->B, (long long)d->B3);
+  CLICA_CHECK_ARG(d->n >= 1, "%s: n=%d must be >= 1", who, d->n);
+  CLICA_CHECK_ARG(pad_dim(d->n) > 0, "%s: n=%d > 64 is not supported by the register-resident kernels", who, d->n);
+  CLICA_CHECK_ARG(d->p > 0.f, "%s: p=%g must be > 0", who, d->p);
+  CLICA_CHECK_ARG(d->tau > 0.f, "%s: tau=%g must be > 0", who, d->tau);
+  if (d->p < 1.f)
+    CLICA_CHECK_ARG(d->B == d->B3, "%s: p<1 uses the transposed branch (losses.py:433-442) and needs B3 == B", who);
+  return CLICA_OK;
+}
+
+}  // namespace lp
+}  // namespace clica
+
+using namespace clica;
+using namespace clica::lp;
+
+// In the p < 1 branch the pair-matrix rows are z3 rows and the columns z1 rows.
+extern "C" int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t* fwd_bytes, size_t* bwd_bytes) {
+  int rc = validate(d, "clica_lp_loss_workspace_bytes");
+  if (rc) return rc;
+  const bool frac = d->p < 1.f;
+  const int64_t rows = frac ? d->B3 : d->B, cols = frac ? d->B : d->B3;
+  Plan PF = make_plan(rows, cols, d->n, false);
+  Plan PR = make_plan(rows, cols, d->n, true);
+  Plan PC = make_plan(cols, rows, d->n, true);
+  if (fwd_bytes) *fwd_bytes = carve_fwd(nullptr, PF, rows).bytes;
+  if (bwd_bytes) *bwd_bytes = carve_bwd(nullptr, PR, PC, rows, cols).bytes;
+  return CLICA_OK;
+}
+
+extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
+                                 const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                                 const float* z3, int64_t ld3,
+                                 float* loss_i, float* pos_i, float* lse_i, float* means,
+                                 void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_fwd");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && z2 && z3 && loss_i && pos_i && lse_i && means && workspace, "clica_lp_loss_fwd: NULL pointer");
+  CLICA_CHECK_ARG(ld1 >= d->n && ld2 >= d->n && ld3 >= d->n, "clica_lp_loss_fwd: leading dimension < n");
+  const bool frac = d->p < 1.f;
+  const float* rows_p = frac ? z3 : z1; const int64_t ldr = frac ? ld3 : ld1; const int64_t rows = frac ? d->B3 : d->B;
+  const float* cols_p = frac ? z1 : z3; const int64_t ldc = frac ? ld1 : ld3; const int64_t cols = frac ? d->B : d->B3;
+  Plan P = make_plan(rows, cols, d->n, false);
+  FwdWs w = carve_fwd(workspace, P, rows);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  Params q = make_params(d, frac);
+  hipStream_t st = as_stream(stream);
+  launch_fwd_partial(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part, st);
+  Means M{w.blocksums, w.ticket, means};
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st,
+                     (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
+                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M);
+  return launch_status("clica_lp_loss_fwd");
+}
+
+extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
+                                 const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                                 const float* z3, int64_t ld3, const float* lse_i,
+                                 const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
+                                 float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                                 float* dz3, int64_t ldd3, int32_t accumulate_dz3,
+                                 void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_bwd");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && z2 && z3 && lse_i && workspace, "clica_lp_loss_bwd: NULL pointer");
+  const bool frac = d->p < 1.f;
+  const int64_t rows = frac ? d->B3 : d->B, cols = frac ? d->B : d->B3;
+  const float* rows_p = frac ? z3 : z1; const int64_t ldr = frac ? ld3 : ld1;
+  const float* cols_p = frac ? z1 : z3; const int64_t ldc = frac ? ld1 : ld3;
+  // gradient destinations of the pair-matrix rows / columns
+  float* d_rows = frac ? dz3 : dz1; const int64_t ld_dr = frac ? ldd3 : ldd1;
+  float* d_cols = frac ? dz1 : dz3; const int64_t ld_dc = frac ? ldd1 : ldd3;
+  Plan PR = make_plan(rows, cols, d->n, true);
+  Plan PC = make_plan(cols, rows, d->n, true);
+  BwdWs w = carve_bwd(workspace, PR, PC, rows, cols);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_bwd: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  Params q = make_params(d, frac);
+  const int pk = exponent_kind(d->p);
+  hipStream_t st = as_stream(stream);
+  // 1. coefficients + positive-pair gradient: dz1 = gp (assign), dz2 = -gp
+  hipLaunchKernelGGL(bwd_coef_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st,
+                     rows, z1, ld1, z2, ld2, q, d->tau, d->alpha, d->compat ? 1 : 0, frac ? 1 : 0, 0, lse_i,
+                     g_mean, g_item, g_pos, g_neg, w.statL, w.statC, dz1, ldd1, dz2, ldd2);
+  // in the p>=1 branch dz1 receives the positive term (assigned above) plus the row pass;
+  // in the p<1 branch dz1 is the COLUMN gradient: positive term assigned, column pass added.
+  if (d_rows) {
+    launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
+    const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
+                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc);
+  }
+  if (d_cols) {
+    Params qc = q; qc.sgn = -q.sgn;   // e = -(owner - stream) + eps seen from the column side
+    launch_bwd_pairs(false, PC, pk, cols_p, ldc, cols, rows_p, ldr, rows, qc, w.statL, w.statC, w.partC, st);
+    const int acc = frac ? 1 : (accumulate_dz3 ? 1 : 0);
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np, THREADS)), dim3(THREADS), 0, st,
+                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc);
+  }
+  return launch_status("clica_lp_loss_bwd");
+}
+
+// =====================================================================================
+// Dot-product InfoNCE -- SimCLRLoss.loss, /root/reference/losses.py:177-202.
+// Same tiled online-LSE skeleton with the pair term o*s (kind PK_DOT); the optional row
+// L2-normalisation (losses.py:180-185) is a pre-pass into workspace plus its chain rule.
+// =====================================================================================
+namespace clica {
+namespace lp {
+
+// u = z / ||z||_2 ; inv[i] = 1/||z_i||
+__global__ __launch_bounds__(THREADS) void rownorm_fwd_k(const float* __restrict__ z, int64_t ldz, int64_t rows, int n,
+                                                        float* __restrict__ u, int64_t ldu, float* __restrict__ inv) {
+  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (i >= rows) return;
+  float ss = 0.f;
+  for (int k = 0; k < n; ++k) { const float v = z[i * ldz + k]; ss += v * v; }
+  const float r = 1.f / sqrtf(ss);
+  inv[i] = r;
+  for (int k = 0; k < n; ++k) u[i * ldu + k] = z[i * ldz + k] * r;
+}
+// dz (+)= (du - u <du,u>) * inv
+__global__ __launch_bounds__(THREADS) void rownorm_bwd_k(const float* __restrict__ u, const float* __restrict__ du, int64_t ldu,
+                                                        const float* __restrict__ inv, int64_t rows, int n,
+                                                        float* __restrict__ dz, int64_t lddz, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (i >= rows) return;
+  float dot = 0.f;
+  for (int k = 0; k < n; ++k) dot += du[i * ldu + k] * u[i * ldu + k];
+  const float r = inv[i];
+  for (int k = 0; k < n; ++k) {
+    const float g = (du[i * ldu + k] - u[i * ldu + k] * dot) * r;
+    float* dst = dz + i * lddz + k;
+    *dst = accumulate ? (*dst + g) : g;
+  }
+}
+
+struct DotWs {
+  float *u1, *u2, *u3, *i1, *i2, *i3, *du1, *du2, *du3;
+  size_t bytes;
+};
+static DotWs carve_dot(void* ws, size_t off, int64_t B, int64_t B3, int n, bool normalize, bool bwd) {
+  DotWs w{}; char* p = (char*)ws;
+  auto take = [&](size_t count) { float* r = (float*)(p + off); off += align_up(count * sizeof(float), 256); return r; };
+  if (normalize) {
+    w.u1 = take((size_t)B * n); w.u2 = take((size_t)B * n); w.u3 = take((size_t)B3 * n);
+    w.i1 = take(B); w.i2 = take(B); w.i3 = take(B3);
+    if (bwd) { w.du1 = take((size_t)B * n); w.du2 = take((size_t)B * n); w.du3 = take((size_t)B3 * n); }
+  }
+  w.bytes = off; return w;
+}
+static int validate_dot(const clica_dot_loss_desc* d, const char* who) {
+  CLICA_CHECK_ARG(d != nullptr, "%s: desc is NULL", who);
+  CLICA_CHECK_ARG(d->B > 0 && d->B3 > 0, "%s: B=%lld B3=%lld must be positive", who, (long long)d->B, (long long)d->B3);
+  CLICA_CHECK_ARG(d->n >= 1 && pad_dim(d->n) > 0, "%s: n=%d must be in 1..64", who, d->n);
+  CLICA_CHECK_ARG(d->tau > 0.f, "%s: tau=%g must be > 0", who, d->tau);
+  return CLICA_OK;
+}
+static Params dot_params(const clica_dot_loss_desc* d) {
+  Params q;
+  q.p = 1.f; q.inv_p = 1.f; q.kscale = kLog2e / d->tau; q.sgn = 1.f; q.eps = 0.f; q.xs = 1.f; q.pow = 1; q.n = d->n;
+  return q;
+}
+static void normalize_rows(const float* z, int64_t ld, int64_t rows, int n, float* u, float* inv, hipStream_t st) {
+  hipLaunchKernelGGL(rownorm_fwd_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st, z, ld, rows, n, u, (int64_t)n, inv);
+}
+
+}  // namespace lp
+}  // namespace clica
+
+extern "C" int clica_dot_loss_workspace_bytes(const clica_dot_loss_desc* d, size_t* fwd_bytes, size_t* bwd_bytes) {
+  int rc = validate_dot(d, "clica_dot_loss_workspace_bytes");
+  if (rc) return rc;
+  Plan PF = make_plan(d->B, d->B3, d->n, false), PR = make_plan(d->B, d->B3, d->n, true), PC = make_plan(d->B3, d->B, d->n, true);
+  if (fwd_bytes) *fwd_bytes = carve_dot(nullptr, carve_fwd(nullptr, PF, d->B).bytes, d->B, d->B3, d->n, d->normalize, false).bytes;
+  if (bwd_bytes) *bwd_bytes = carve_dot(nullptr, carve_bwd(nullptr, PR, PC, d->B, d->B3).bytes, d->B, d->B3, d->n, d->normalize, true).bytes;
+  return CLICA_OK;
+}
+
+extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
+                                  const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                                  const float* z3, int64_t ld3,
+                                  float* loss_i, float* pos_i, float* lse_i, float* means,
+                                  void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate_dot(d, "clica_dot_loss_fwd");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && z2 && z3 && loss_i && pos_i && lse_i && means && workspace, "clica_dot_loss_fwd: NULL pointer");
+  CLICA_CHECK_ARG(ld1 >= d->n && ld2 >= d->n && ld3 >= d->n, "clica_dot_loss_fwd: leading dimension < n");
+  Plan P = make_plan(d->B, d->B3, d->n, false);
+  FwdWs w = carve_fwd(workspace, P, d->B);
+  DotWs dw = carve_dot(workspace, w.bytes, d->B, d->B3, d->n, d->normalize, false);
+  if (dw.bytes > workspace_bytes) { set_error("clica_dot_loss_fwd: workspace %zu < %zu", workspace_bytes, dw.bytes); return CLICA_E_WORKSPACE; }
+  hipStream_t st = as_stream(stream);
+  Params q = dot_params(d);
+  if (d->normalize) {
+    normalize_rows(z1, ld1, d->B, d->n, dw.u1, dw.i1, st);
+    normalize_rows(z2, ld2, d->B, d->n, dw.u2, dw.i2, st);
+    normalize_rows(z3, ld3, d->B3, d->n, dw.u3, dw.i3, st);
+    z1 = dw.u1; z2 = dw.u2; z3 = dw.u3; ld1 = ld2 = ld3 = d->n;
+  }
+  launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, st);
+  Means M{w.blocksums, w.ticket, means};
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(d->B, THREADS)), dim3(THREADS), 0, st,
+                     (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
+                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M);
+  return launch_status("clica_dot_loss_fwd");
+}
+
+extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
+                                  const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                                  const float* z3, int64_t ld3, const float* lse_i,
+                                  const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
+                                  float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                                  float* dz3, int64_t ldd3, int32_t accumulate_dz3,
+                                  void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate_dot(d, "clica_dot_loss_bwd");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && z2 && z3 && lse_i && workspace, "clica_dot_loss_bwd: NULL pointer");
+  const int64_t B = d->B, B3 = d->B3; const int n = d->n;
+  Plan PR = make_plan(B, B3, n, true), PC = make_plan(B3, B, n, true);
+  BwdWs w = carve_bwd(workspace, PR, PC, B, B3);
+  DotWs dw = carve_dot(workspace, w.bytes, B, B3, n, d->normalize, true);
+  if (dw.bytes > workspace_bytes) { set_error("clica_dot_loss_bwd: workspace %zu < %zu", workspace_bytes, dw.bytes); return CLICA_E_WORKSPACE; }
+  hipStream_t st = as_stream(stream);
+  Params q = dot_params(d);
+  // with normalisation the pair gradients land in du* and go through the chain rule afterwards
+  float *o1 = dz1, *o2 = dz2, *o3 = dz3; int64_t lo1 = ldd1, lo2 = ldd2, lo3 = ldd3; int acc3 = accumulate_dz3 ? 1 : 0;
+  if (d->normalize) {
+    normalize_rows(z1, ld1, B, n, dw.u1, dw.i1, st);
+    normalize_rows(z2, ld2, B, n, dw.u2, dw.i2, st);
+    normalize_rows(z3, ld3, B3, n, dw.u3, dw.i3, st);
+    z1 = dw.u1; z2 = dw.u2; z3 = dw.u3; ld1 = ld2 = ld3 = n;
+    o1 = dz1 ? dw.du1 : nullptr; o2 = dz2 ? dw.du2 : nullptr; o3 = dz3 ? dw.du3 : nullptr; lo1 = lo2 = lo3 = n; acc3 = 0;
+  }
+  hipLaunchKernelGGL(bwd_coef_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st,
+                     B, z1, ld1, z2, ld2, q, d->tau, d->alpha, 1, 0, 1, lse_i,
+                     g_mean, g_item, g_pos, g_neg, w.statL, w.statC, o1, lo1, o2, lo2);
+  if (o1) {
+    launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
+                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1);
+  }
+  if (o3) {
+    launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
+                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3);
+  }
+  if (d->normalize) {
+    if (dz1) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u1, (const float*)dw.du1, (int64_t)n, (const float*)dw.i1, B, n, dz1, ldd1, 0);
+    if (dz2) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u2, (const float*)dw.du2, (int64_t)n, (const float*)dw.i2, B, n, dz2, ldd2, 0);
+    if (dz3) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B3, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u3, (const float*)dw.du3, (int64_t)n, (const float*)dw.i3, B3, n, dz3, ldd3, accumulate_dz3 ? 1 : 0);
+  }
+  return launch_status("clica_dot_loss_bwd");
+}

@@ -1,0 +1,54 @@
+// One exponent kind (CLICA_PK = 0 generic, 1, 2, 3; 4 = dot product) of the pairwise-Lp kernels; compiled four
+// times so the 8 padded dims x 3 kernels x 4 kinds instantiate in parallel.
+#include "lp_kernels.h"
+#ifndef CLICA_PK
+#error "compile with -DCLICA_PK=0|1|2|3|4"
+#endif
+#define CAT_(a, b) a##b
+#define CAT(a, b) CAT_(a, b)
+
+namespace clica {
+namespace lp {
+
+#define LP_FOR_NP(NPV, BODY)                        \
+  switch (NPV) {                                    \
+    case 4: { constexpr int NP = 4; BODY } break;   \
+    case 8: { constexpr int NP = 8; BODY } break;   \
+    case 12: { constexpr int NP = 12; BODY } break; \
+    case 16: { constexpr int NP = 16; BODY } break; \
+    case 24: { constexpr int NP = 24; BODY } break; \
+    case 32: { constexpr int NP = 32; BODY } break; \
+    case 40: { constexpr int NP = 40; BODY } break; \
+    case 64: { constexpr int NP = 64; BODY } break; \
+    default: break;                                 \
+  }
+
+void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64_t ldo, int64_t n_own,
+                                          const float* str, int64_t lds, int64_t n_str, const Params& q,
+                                          float2* part, hipStream_t st) {
+  constexpr int PK = CLICA_PK;
+  dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
+  LP_FOR_NP(P.np, {
+    hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP)>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                       n_str, q, part, P.chunk);
+  })
+}
+
+void CAT(launch_bwd_pairs_pk, CLICA_PK)(const Plan& P, bool owner_stats, const float* own, int64_t ldo,
+                                        int64_t n_own, const float* str, int64_t lds, int64_t n_str,
+                                        const Params& q, const float* statL, const float* statC, float* part,
+                                        hipStream_t st) {
+  constexpr int PK = CLICA_PK;
+  dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
+  LP_FOR_NP(P.np, {
+    if (owner_stats)
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), true>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, part, P.chunk);
+    else
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), false>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, part, P.chunk);
+  })
+}
+
+}  // namespace lp
+}  // namespace clica

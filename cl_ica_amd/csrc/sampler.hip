@@ -1,0 +1,177 @@
+// On-device latent samplers (Philox4x32-10, counter-based: no state, no host sync, graph-replayable)
+// replacing the reference's host RNG + rejection loops:
+//   box    uniform / truncated conditional   /root/reference/spaces.py:273-351 + spaces_utils.py:106-142
+//   sphere uniform / projected conditional   spaces.py:134-231
+//   R^n    normal / laplace / gen. normal    spaces.py:44-119, spaces_utils.py:82-103
+//   von Mises-Fisher (Wood's rejection)      spaces.py:233-257 -> vmf.py:48-134
+// The reference's truncated_rejection_resampling redraws only the out-of-range ELEMENTS each round
+// (with a host sync per round); that is per-element rejection sampling, done here in a register loop.
+// RNG streams cannot match torch/NumPy bit-for-bit: parity is distributional (tests/test_gpu_samplers).
+#include "common.h"
+
+namespace clica {
+namespace rng {
+constexpr int THREADS = 256;
+
+struct Philox {
+  uint32_t key0, key1;
+  uint32_t c0, c1, c2, c3;   // c0 = element index, c1 = draw block, c2 = step, c3 = stream id
+  uint32_t out[4];
+  int have;
+  __device__ Philox(uint64_t seed, uint32_t idx, uint32_t step, uint32_t stream)
+      : key0((uint32_t)seed), key1((uint32_t)(seed >> 32)), c0(idx), c1(0), c2(step), c3(stream), have(0) {}
+  __device__ void refill() {
+    uint32_t a0 = c0, a1 = c1, a2 = c2, a3 = c3, k0 = key0, k1 = key1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      const uint64_t p0 = (uint64_t)0xD2511F53u * a0;
+      const uint64_t p1 = (uint64_t)0xCD9E8D57u * a2;
+      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ a1 ^ k0;
+      const uint32_t n1 = (uint32_t)p1;
+      const uint32_t n2 = (uint32_t)(p0 >> 32) ^ a3 ^ k1;
+      const uint32_t n3 = (uint32_t)p0;
+      a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+    ++c1; have = 4;
+  }
+  __device__ uint32_t next() { if (have == 0) refill(); return out[--have]; }
+  __device__ float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }          // [0,1)
+  __device__ float uniform_open() { return ((float)(next() >> 8) + 1.0f) * (1.0f / 16777216.0f); }  // (0,1]
+  __device__ float normal() {  // Box-Muller, one value per call (the twin is discarded: draws are cheap)
+    const float u1 = uniform_open(), u2 = uniform();
+    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+  }
+  __device__ float laplace() {  // unit-scale Laplace by inverse CDF, as torch.distributions.Laplace.rsample
+    const float u = 2.0f * uniform() - 1.0f;   // [-1,1)
+    const float a = fabsf(u);
+    const float m = -log1pf(-fminf(a, 0.99999994f));
+    return u < 0.f ? -m : m;
+  }
+  __device__ float gamma(float a) {  // Marsaglia-Tsang; shape < 1 via the U^(1/a) boost
+    float boost = 1.f;
+    if (a < 1.f) { boost = powf(uniform_open(), 1.f / a); a += 1.f; }
+    const float d = a - 1.f / 3.f, c = 1.f / sqrtf(9.f * d);
+    for (int it = 0; it < 64; ++it) {
+      const float x = normal();
+      float v = 1.f + c * x;
+      if (v <= 0.f) continue;
+      v = v * v * v;
+      const float u = uniform_open();
+      if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) return d * v * boost;
+    }
+    return d * boost;
+  }
+  __device__ float gennorm(float p) {  // +-Gamma(1/p,1)^(1/p)  (spaces_utils.py:95-102)
+    const float gmm = gamma(1.f / p);
+    const float mag = powf(gmm, 1.f / p);
+    return (next() & 1u) ? mag : -mag;
+  }
+};
+
+struct Desc {
+  int space, dist, n;
+  float box_min, box_max, scale, shape_p;
+  uint64_t seed; uint32_t stream_id;
+};
+
+__device__ __forceinline__ float noise(Philox& g, const Desc& d) {
+  switch (d.dist) {
+    case CLICA_DIST_NORMAL: return d.scale * g.normal();
+    case CLICA_DIST_LAPLACE: return d.scale * g.laplace();
+    case CLICA_DIST_GENNORM: return d.scale * g.gennorm(d.shape_p);
+    default: return 0.f;
+  }
+}
+
+// one thread per sample row
+__global__ __launch_bounds__(THREADS) void sample_k(Desc d, const float* __restrict__ mean, int64_t ldm,
+                                                   float* __restrict__ out, int64_t ldo, int64_t M,
+                                                   const int32_t* __restrict__ step_dev) {
+  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (i >= M) return;
+  const uint32_t step = step_dev ? (uint32_t)step_dev[0] : 0u;
+  Philox g(d.seed, (uint32_t)i, step, d.stream_id);
+  const int n = d.n;
+  float* o = out + i * ldo;
+  const float* mu = mean ? mean + i * ldm : nullptr;   // ldm == 0 broadcasts one row
+
+  if (d.dist == CLICA_DIST_VMF) {
+    // Wood (1994) / Ulrich rejection for w = <x, mu>  (vmf.py:88-114), then a tangent direction (vmf.py:125-134)
+    const float dim = (float)(n - 1), kappa = d.scale;
+    const float b = dim / (sqrtf(4.f * kappa * kappa + dim * dim) + 2.f * kappa);
+    const float x0 = (1.f - b) / (1.f + b);
+    const float c = kappa * x0 + dim * logf(1.f - x0 * x0);
+    float w = 1.f;
+    for (int it = 0; it < 1000; ++it) {
+      const float g1 = g.gamma(0.5f * dim), g2 = g.gamma(0.5f * dim);
+      const float z = g1 / (g1 + g2);                       // Beta(d/2, d/2)
+      w = (1.f - (1.f + b) * z) / (1.f - (1.f - b) * z);
+      const float u = g.uniform_open();
+      if (kappa * w + dim * logf(1.f - x0 * w) - c >= logf(u)) break;
+    }
+    float dot = 0.f, mm = 0.f;
+    for (int k = 0; k < n; ++k) { const float v = g.normal(); o[k] = v; dot += v * mu[k]; mm += mu[k] * mu[k]; }
+    const float coef = dot / sqrtf(mm);                      // mu * <mu,v> / |mu|  (vmf.py:128-132)
+    float ss = 0.f;
+    for (int k = 0; k < n; ++k) { const float t = o[k] - mu[k] * coef; o[k] = t; ss += t * t; }
+    const float sc = sqrtf(fmaxf(1.f - w * w, 0.f)) / sqrtf(ss);
+    for (int k = 0; k < n; ++k) o[k] = o[k] * sc + w * mu[k];
+    return;
+  }
+
+  if (d.space == CLICA_SPACE_BOX) {
+    if (d.dist == CLICA_DIST_UNIFORM) {                      // spaces.py:273-277
+      const float span = d.box_max - d.box_min;
+      for (int k = 0; k < n; ++k) o[k] = g.uniform() * span + d.box_min;
+    } else {                                                 // spaces.py:279-351: truncate per element
+      for (int k = 0; k < n; ++k) {
+        const float m = mu[k];
+        float v = m + noise(g, d);
+        for (int it = 0; it < 4096 && !(v >= d.box_min && v <= d.box_max); ++it) v = m + noise(g, d);
+        o[k] = v;
+      }
+    }
+    return;
+  }
+
+  // sphere / R^n: mean + noise, sphere projects back (the radius is ignored by the reference,
+  // spaces.py:134-138,168: always unit norm)
+  float ss = 0.f;
+  for (int k = 0; k < n; ++k) {
+    float v;
+    if (d.dist == CLICA_DIST_UNIFORM) v = g.normal();        // spaces.py:134-138
+    else v = mu[k] + noise(g, d);
+    o[k] = v; ss += v * v;
+  }
+  if (d.space == CLICA_SPACE_SPHERE) {
+    const float inv = 1.f / sqrtf(ss);
+    for (int k = 0; k < n; ++k) o[k] *= inv;
+  }
+}
+}  // namespace rng
+}  // namespace clica
+
+using namespace clica;
+
+extern "C" int clica_sample(const clica_sampler_desc* d, const float* mean, int64_t ldm,
+                            float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
+                            clica_stream_t stream) {
+  CLICA_CHECK_ARG(d && out && M > 0, "clica_sample: bad argument");
+  CLICA_CHECK_ARG(d->n >= 1 && ldo >= d->n, "clica_sample: n=%d ldo=%lld", d->n, (long long)ldo);
+  CLICA_CHECK_ARG(d->space >= CLICA_SPACE_REAL && d->space <= CLICA_SPACE_SPHERE, "clica_sample: unknown space %d", d->space);
+  CLICA_CHECK_ARG(d->dist >= CLICA_DIST_UNIFORM && d->dist <= CLICA_DIST_VMF, "clica_sample: unknown distribution %d", d->dist);
+  if (d->dist == CLICA_DIST_UNIFORM)
+    CLICA_CHECK_ARG(d->space != CLICA_SPACE_REAL, "clica_sample: uniform is not defined on R^n (spaces.py:44-45)");
+  else
+    CLICA_CHECK_ARG(mean != nullptr && (ldm == 0 || ldm >= d->n), "clica_sample: conditional kinds need `mean`");
+  if (d->dist == CLICA_DIST_VMF)
+    CLICA_CHECK_ARG(d->space == CLICA_SPACE_SPHERE && d->n >= 2 && d->scale > 0.f, "clica_sample: vMF needs the sphere, n >= 2, kappa > 0");
+  if (d->dist == CLICA_DIST_GENNORM) CLICA_CHECK_ARG(d->shape_p > 0.f, "clica_sample: generalized normal needs shape_p > 0");
+  if (d->space == CLICA_SPACE_BOX) CLICA_CHECK_ARG(d->box_max > d->box_min, "clica_sample: empty box");
+  rng::Desc q{d->space, d->dist, d->n, d->box_min, d->box_max, d->scale, d->shape_p, d->seed, d->stream_id};
+  hipLaunchKernelGGL(rng::sample_k, dim3((unsigned)ceil_div(M, rng::THREADS)), dim3(rng::THREADS), 0, as_stream(stream),
+                     q, mean, ldm, out, ldo, M, step_dev);
+  return launch_status("clica_sample");
+}

@@ -1,0 +1,97 @@
+"""Output-normalisation layers with the reference's constructor/attribute surface
+(/root/reference/layers.py:30-91), forward/backward on the HIP head kernels."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+__all__ = ["Lambda", "Flatten", "RescaleLayer", "SoftclipLayer"]
+
+
+class Lambda(nn.Module):
+    """Apply a function to the input (layers.py:30-38)."""
+
+    def __init__(self, f):
+        super().__init__()
+        self.f = f
+
+    def forward(self, *args, **kwargs):
+        return self.f(*args, **kwargs)
+
+
+class Flatten(Lambda):
+    def __init__(self):
+        super().__init__(lambda x: x.view(len(x), -1))
+
+
+class _RescaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r):
+        y, inv = ops.rescale_fwd(x, r)
+        ctx.save_for_backward(x.detach(), r.detach(), inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, r, inv = ctx.saved_tensors
+        dx, dr = ops.rescale_bwd(x, r, inv, gy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, dr
+
+
+class _SoftclipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x.detach(), bound.detach())
+        return ops.softclip_fwd(x, bound)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, bound = ctx.saved_tensors
+        dx, db = ops.softclip_bwd(x, bound, gy, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dx, db
+
+
+class RescaleLayer(nn.Module):
+    """Normalize the data to a hypersphere with fixed/learnable radius: x / ||x|| * r.
+
+    Attribute surface of layers.py:48-61: ``r`` is an ``nn.Parameter`` of shape (1,) when learnable
+    (state-dict key ``<idx>.r``) and a plain tensor -- neither parameter nor buffer -- when fixed.
+    Only ``mode="eq"`` is implemented; the reference never uses "leq" (SURVEY.md section 8 A8).
+    """
+
+    def __init__(self, init_r=1.0, fixed_r=False, mode: Optional[str] = "eq"):
+        super().__init__()
+        self.fixed_r = fixed_r
+        if mode != "eq":
+            raise NotImplementedError("RescaleLayer(mode='leq') is unused by the reference and not built")
+        self.mode = mode
+        if fixed_r:
+            self.r = torch.ones(1, requires_grad=False) * init_r
+        else:
+            self.r = nn.Parameter(torch.ones(1, requires_grad=True) * init_r)
+
+    def forward(self, x):
+        r = self.r.to(x.device)
+        if not r.is_contiguous():
+            r = r.contiguous()
+        return _RescaleFn.apply(x, r)
+
+
+class SoftclipLayer(nn.Module):
+    """Normalize the data to a hyperrectangle with fixed/learnable size: sigmoid(x) * bound
+    (layers.py:74-91; learnable bound has state-dict key ``<idx>.max_abs_bound``)."""
+
+    def __init__(self, n, init_abs_bound=1.0, fixed_abs_bound=True):
+        super().__init__()
+        self.fixed_abs_bound = fixed_abs_bound
+        if fixed_abs_bound:
+            self.max_abs_bound = torch.ones(n, requires_grad=False) * init_abs_bound
+        else:
+            self.max_abs_bound = nn.Parameter(torch.ones(n, requires_grad=True) * init_abs_bound)
+
+    def forward(self, x):
+        return _SoftclipFn.apply(x, self.max_abs_bound.to(x.device).contiguous())

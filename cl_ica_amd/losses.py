@@ -1,0 +1,145 @@
+"""Contrastive losses with the reference's call surface, computed by the HIP kernels.
+
+Drop-in for /root/reference/losses.py: ``LpSimCLRLoss`` (losses.py:405-477) and ``SimCLRLoss``
+(losses.py:162-202) keep constructor arguments, defaults, the 6-argument ``__call__`` protocol of
+``CLLoss`` (losses.py:28-29; the first three arguments are ignored and may be ``None``) and the
+return triple ``(mean, per_item, [pos_mean, neg_mean])``, every element autograd-connected.
+
+Unlike the reference nothing of size B x B3 is ever materialised: forward and backward are tiled
+all-pairs kernels with an online log-sum-exp (cl_ica_amd/csrc/lp_kernels.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from abc import ABC, abstractmethod
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+__all__ = ["CLLoss", "LpSimCLRLoss", "SimCLRLoss"]
+
+
+class CLLoss(ABC):
+    """Loss protocol of the reference (losses.py:11-29): one positive and one negative pair."""
+
+    @abstractmethod
+    def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
+        ...
+
+    def __call__(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
+        return self.loss(z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec)
+
+
+def _prep(name, t):
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D (batch, n), got shape {tuple(t.shape)}")
+    _lib.require_cuda(t, name)
+    return _lib.rowmajor(t.detach())
+
+
+class _PairLossFn(torch.autograd.Function):
+    """autograd bridge to clica_{lp,dot}_loss_{fwd,bwd}; `desc` is the ctypes descriptor."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, z3, kind, desc):
+        lib = _lib.load()
+        (a, lda), (b, ldb), (c, ldc) = _prep("z1_rec", z1), _prep("z2_con_z1_rec", z2), _prep("z3_rec", z3)
+        B = a.shape[0]
+        out = torch.empty(3 * B + 3, dtype=torch.float32, device=a.device)
+        loss_i, pos_i, lse_i, means = out[:B], out[B:2 * B], out[2 * B:3 * B], out[3 * B:]
+        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
+        ws_query = lib.clica_lp_loss_workspace_bytes if kind == "lp" else lib.clica_dot_loss_workspace_bytes
+        _lib.check(ws_query(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), f"clica_{kind}_loss_workspace_bytes")
+        ws = _lib.workspace(f"{kind}_loss", max(fwd_b.value, bwd_b.value), a.device)
+        fwd = lib.clica_lp_loss_fwd if kind == "lp" else lib.clica_dot_loss_fwd
+        _lib.check(fwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
+                       loss_i.data_ptr(), pos_i.data_ptr(), lse_i.data_ptr(), means.data_ptr(),
+                       ws.data_ptr(), ws.numel(), _lib.stream_ptr()), f"clica_{kind}_loss_fwd")
+        ctx.save_for_backward(a, b, c, lse_i)
+        ctx.lds = (lda, ldb, ldc)
+        ctx.kind, ctx.desc = kind, desc
+        ctx.shapes = (z1.shape, z2.shape, z3.shape)
+        mean, pos_mean, neg_mean = means.unbind(0)
+        ctx.mark_non_differentiable()
+        return mean, loss_i, pos_mean, neg_mean
+
+    @staticmethod
+    def backward(ctx, g_mean, g_item, g_pos, g_neg):
+        lib = _lib.load()
+        a, b, c, lse_i = ctx.saved_tensors
+        lda, ldb, ldc = ctx.lds
+        kind, desc = ctx.kind, ctx.desc
+        dev = a.device
+        need1, need2, need3 = ctx.needs_input_grad[:3]
+
+        def scal(g):  # 0-dim upstream gradient -> contiguous fp32 device scalar (None stays None)
+            return None if g is None else g.detach().to(torch.float32).reshape(1).contiguous()
+        g_mean_t = scal(g_mean)
+        if g_mean_t is None:   # the C ABI reads NULL as 1.0; an unused mean output must weigh 0
+            g_mean_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        g_item_t = None if g_item is None else g_item.detach().to(torch.float32).contiguous()
+        g_pos_t, g_neg_t = scal(g_pos), scal(g_neg)
+        n = a.shape[1]
+        dz1 = torch.empty((a.shape[0], n), dtype=torch.float32, device=dev) if (need1 or need2) else None
+        dz2 = torch.empty((b.shape[0], n), dtype=torch.float32, device=dev) if need2 else None
+        dz3 = torch.empty((c.shape[0], n), dtype=torch.float32, device=dev) if need3 else None
+        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
+        ws_query = lib.clica_lp_loss_workspace_bytes if kind == "lp" else lib.clica_dot_loss_workspace_bytes
+        _lib.check(ws_query(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), f"clica_{kind}_loss_workspace_bytes")
+        ws = _lib.workspace(f"{kind}_loss", max(fwd_b.value, bwd_b.value), dev)
+        bwd = lib.clica_lp_loss_bwd if kind == "lp" else lib.clica_dot_loss_bwd
+        _lib.check(bwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc, lse_i.data_ptr(),
+                       _lib.ptr(g_mean_t), _lib.ptr(g_item_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
+                       _lib.ptr(dz1), n, _lib.ptr(dz2), n, _lib.ptr(dz3), n, 0,
+                       ws.data_ptr(), ws.numel(), _lib.stream_ptr()), f"clica_{kind}_loss_bwd")
+        return (dz1 if need1 else None), dz2, dz3, None, None
+
+
+class LpSimCLRLoss(CLLoss):
+    """Extended InfoNCE objective for non-normalized representations based on an Lp norm.
+
+    Same arguments and defaults as the reference (losses.py:416-428):
+        p: exponent of the norm; tau: temperature; alpha: weight between the two summands;
+        simclr_compatibility_mode: logsumexp over [negatives, positive] instead of logmeanexp;
+        pow: use the p-th power of the Lp norm instead of the norm.
+    """
+
+    def __init__(self, p: int, tau: float = 1.0, alpha: float = 0.5,
+                 simclr_compatibility_mode: bool = False, pow: bool = True):
+        self.p = p
+        self.tau = tau
+        self.alpha = alpha
+        self.simclr_compatibility_mode = simclr_compatibility_mode
+        self.pow = pow
+
+    def _desc(self, B, B3, n):
+        return _lib.LpLossDesc(B=B, B3=B3, n=n, p=float(self.p), tau=float(self.tau), alpha=float(self.alpha),
+                               compat=int(bool(self.simclr_compatibility_mode)), pow=int(bool(self.pow)))
+
+    def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
+        del z1, z2_con_z1, z3   # unused by the reference as well (losses.py:431)
+        if z1_rec.shape != z2_con_z1_rec.shape or z1_rec.shape[1] != z3_rec.shape[1]:
+            raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_con_z1_rec.shape)}, {tuple(z3_rec.shape)}")
+        desc = self._desc(z1_rec.shape[0], z3_rec.shape[0], z1_rec.shape[1])
+        mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "lp", desc)
+        return mean, per_item, [pos_mean, neg_mean]
+
+
+class SimCLRLoss(CLLoss):
+    """InfoNCE loss on dot-product similarities, optionally L2-normalised (losses.py:162-202)."""
+
+    def __init__(self, normalize: bool = False, tau: float = 1.0, alpha: float = 0.5):
+        self.normalize = normalize
+        self.tau = tau
+        self.alpha = alpha
+
+    def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
+        del z1, z2_con_z1, z3
+        if z1_rec.shape != z2_con_z1_rec.shape or z1_rec.shape[1] != z3_rec.shape[1]:
+            raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_con_z1_rec.shape)}, {tuple(z3_rec.shape)}")
+        desc = _lib.DotLossDesc(B=z1_rec.shape[0], B3=z3_rec.shape[0], n=z1_rec.shape[1], tau=float(self.tau),
+                                alpha=float(self.alpha), normalize=int(bool(self.normalize)))
+        mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "dot", desc)
+        return mean, per_item, [pos_mean, neg_mean]

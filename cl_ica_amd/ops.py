@@ -1,0 +1,165 @@
+"""Thin functional wrappers over the C ABI (include/clica.h).  Every function launches HIP
+kernels on torch's current stream and returns torch tensors; there is no other code path."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, load, ptr, require_cuda, rowmajor, stream_ptr, workspace
+
+
+def _mat(name: str, t: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D, got {tuple(t.shape)}")
+    require_cuda(t, name)
+    return rowmajor(t.detach())
+
+
+# ------------------------------------------------------------------------------- Linear
+def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], leaky: bool,
+               slope: float = 0.01, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Y = act(x W^T + b); act = LeakyReLU(slope) if `leaky` (encoders.py:38-48)."""
+    (x, ldx), (w, ldw) = _mat("x", x), _mat("weight", weight)
+    M, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"weight {tuple(w.shape)} does not match input {tuple(x.shape)}")
+    if bias is not None:
+        require_cuda(bias, "bias")
+        bias = bias.detach().contiguous()
+    y = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(load().clica_linear_fwd(x.data_ptr(), ldx, w.data_ptr(), ldw, ptr(bias), y.data_ptr(), y.stride(0),
+                                  M, N, K, int(leaky), float(slope), stream_ptr()), "clica_linear_fwd")
+    return y
+
+
+def linear_dgrad(dy: torch.Tensor, weight: torch.Tensor, xact: Optional[torch.Tensor], slope: float = 0.01,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dX = (dY W) * act'(xact)  (xact = saved activation output feeding this layer, or None)."""
+    (dy, lddy), (w, ldw) = _mat("dy", dy), _mat("weight", weight)
+    M, N = dy.shape
+    K = w.shape[1]
+    xa, ldxa = (None, 0)
+    if xact is not None:
+        xa, ldxa = _mat("xact", xact)
+    dx = out if out is not None else torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    check(load().clica_linear_dgrad(dy.data_ptr(), lddy, w.data_ptr(), ldw, ptr(xa), ldxa, float(slope),
+                                    dx.data_ptr(), dx.stride(0), M, N, K, stream_ptr()), "clica_linear_dgrad")
+    return dx
+
+
+def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: Optional[torch.Tensor] = None,
+                 db: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = True):
+    """dW = dY^T X, db = column sums of dY."""
+    (dy, lddy), (x, ldx) = _mat("dy", dy), _mat("x", x)
+    M, N = dy.shape
+    K = x.shape[1]
+    if dW is None:
+        dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
+    if db is None and want_bias:
+        db = torch.empty((N,), dtype=torch.float32, device=dy.device)
+    nbytes = C.c_size_t()
+    check(load().clica_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "clica_linear_wgrad_workspace_bytes")
+    ws = workspace("wgrad", nbytes.value, dy.device)
+    check(load().clica_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dW.data_ptr(), dW.stride(0), ptr(db),
+                                    M, N, K, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
+          "clica_linear_wgrad")
+    return dW, db
+
+
+# ------------------------------------------------------------------------------- heads
+def rescale_fwd(x, r):
+    (x, ldx) = _mat("x", x)
+    M, n = x.shape
+    y = torch.empty((M, n), dtype=torch.float32, device=x.device)
+    inv = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(load().clica_rescale_fwd(x.data_ptr(), ldx, r.data_ptr(), y.data_ptr(), n, inv.data_ptr(), M, n, stream_ptr()),
+          "clica_rescale_fwd")
+    return y, inv
+
+
+def rescale_bwd(x, r, inv, dy, need_dx=True, need_dr=True):
+    (x, ldx), (dy, lddy) = _mat("x", x), _mat("dy", dy)
+    M, n = x.shape
+    dx = torch.empty((M, n), dtype=torch.float32, device=x.device) if need_dx else None
+    part = torch.empty(((M + 255) // 256,), dtype=torch.float32, device=x.device) if need_dr else None
+    check(load().clica_rescale_bwd(x.data_ptr(), ldx, r.data_ptr(), inv.data_ptr(), dy.data_ptr(), lddy, ptr(dx), n,
+                                   ptr(part), M, n, stream_ptr()), "clica_rescale_bwd")
+    return dx, (part.sum().reshape(1) if need_dr else None)
+
+
+def softclip_fwd(x, bound):
+    (x, ldx) = _mat("x", x)
+    M, n = x.shape
+    y = torch.empty((M, n), dtype=torch.float32, device=x.device)
+    check(load().clica_softclip_fwd(x.data_ptr(), ldx, bound.data_ptr(), y.data_ptr(), n, M, n, stream_ptr()),
+          "clica_softclip_fwd")
+    return y
+
+
+def softclip_bwd(x, bound, dy, need_dx=True, need_db=True):
+    (x, ldx), (dy, lddy) = _mat("x", x), _mat("dy", dy)
+    M, n = x.shape
+    dx = torch.empty((M, n), dtype=torch.float32, device=x.device) if need_dx else None
+    part = torch.empty(((M + 255) // 256, n), dtype=torch.float32, device=x.device) if need_db else None
+    check(load().clica_softclip_bwd(x.data_ptr(), ldx, bound.data_ptr(), dy.data_ptr(), lddy, ptr(dx), n, ptr(part),
+                                    M, n, stream_ptr()), "clica_softclip_bwd")
+    return dx, (part.sum(0) if need_db else None)
+
+
+# ------------------------------------------------------------------------------- mixing / adam / sampler
+def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: Optional[torch.Tensor] = None):
+    """x = W_L phi(... phi(W_1 z)); `weights` is a contiguous [L, n, n] stack (nn.Linear layout)."""
+    (z, ldz) = _mat("z", z)
+    require_cuda(weights, "weights")
+    M, n = z.shape
+    if weights.dim() != 3 or weights.shape[1:] != (n, n) or not weights.is_contiguous():
+        raise ValueError(f"weights must be contiguous [L,{n},{n}], got {tuple(weights.shape)}")
+    x = out if out is not None else torch.empty((M, n), dtype=torch.float32, device=z.device)
+    check(load().clica_mixing_fwd(z.data_ptr(), ldz, weights.data_ptr(), weights.shape[0], float(slope), x.data_ptr(),
+                                  x.stride(0), M, n, stream_ptr()), "clica_mixing_fwd")
+    return x
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """In-place Adam on flat fp32 arenas; `step_dev` int32[1] = updates already applied."""
+    for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        require_cuda(t, nm)
+        if not t.is_contiguous():
+            raise ValueError(f"{nm} must be contiguous")
+    check(load().clica_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                 param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                 step_dev.data_ptr(), stream_ptr()), "clica_adam_step")
+
+
+def tick(counter: torch.Tensor):
+    check(load().clica_tick(counter.data_ptr(), stream_ptr()), "clica_tick")
+
+
+SPACE = {"real": 0, "box": 1, "sphere": 2}
+DIST = {"uniform": 0, "normal": 1, "laplace": 2, "gennorm": 3, "vmf": 4}
+
+
+def sample(space: str, dist: str, n: int, size: int, device, mean: Optional[torch.Tensor] = None,
+           scale: float = 1.0, shape_p: float = 2.0, box=(0.0, 1.0), seed: int = 0, stream_id: int = 0,
+           step_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = _lib.SamplerDesc(space=SPACE[space], dist=DIST[dist], n=n, box_min=float(box[0]), box_max=float(box[1]),
+                         scale=float(scale), shape_p=float(shape_p), seed=int(seed) & (2**64 - 1),
+                         stream_id=int(stream_id) & 0xFFFFFFFF)
+    ldm = 0
+    if mean is not None:
+        require_cuda(mean, "mean")
+        if mean.dim() == 1:
+            mean = mean.reshape(1, -1)
+        mean, ldm = rowmajor(mean.detach())
+        if mean.shape[0] == 1:
+            ldm = 0
+        elif mean.shape[0] != size:
+            raise ValueError(f"mean has {mean.shape[0]} rows, expected 1 or {size}")
+    o = out if out is not None else torch.empty((size, n), dtype=torch.float32, device=device)
+    check(load().clica_sample(C.byref(d), ptr(mean), ldm, o.data_ptr(), o.stride(0), size, ptr(step_dev), stream_ptr()),
+          "clica_sample")
+    return o

@@ -1,0 +1,216 @@
+/*
+ * clica.h -- C ABI of libclica_hip.so: the MI355X (gfx950) implementation of cl-ica's
+ * contrastive-training hot path.
+ *
+ * The reference (brendel-group/cl-ica) is pure Python/PyTorch and has NO FFI of its own
+ * (SURVEY.md section 8(b)); this header is the boundary a maintainer would bind with
+ * ctypes.  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - All matrices are row-major fp32 with an explicit leading dimension `ld*` counted in
+ *     ELEMENTS (so strided views such as mu[::2] or z[:, :k] need no copy).
+ *   - All pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - Buffers are allocated and owned by the caller (PyTorch); the library never frees or
+ *     retains them.  `workspace` is caller-provided scratch of at least the size returned
+ *     by the matching *_workspace_bytes query; it needs no initialisation unless stated.
+ *   - Every call is asynchronous: it enqueues kernels on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream) and returns.  No call synchronises the device, so
+ *     all of them may be captured in a HIP graph.
+ *   - Return value: 0 on success, negative on error (CLICA_E_*).  clica_last_error()
+ *     returns a thread-local human-readable message.  No C++ exception crosses the ABI.
+ */
+#ifndef CLICA_H
+#define CLICA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CLICA_OK 0
+#define CLICA_E_INVALID (-1)     /* bad argument (shape, stride, unsupported mode) */
+#define CLICA_E_WORKSPACE (-2)   /* workspace too small */
+#define CLICA_E_HIP (-3)         /* HIP runtime error at launch */
+
+typedef void* clica_stream_t;    /* hipStream_t */
+
+const char* clica_last_error(void);
+int clica_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Lp InfoNCE loss  --  LpSimCLRLoss.loss, /root/reference/losses.py:430-477
+ *   neg[i,j] = sum_k |z1[i,k]-z3[j,k]|^p   (then ^(1/p) unless `pow`)     losses.py:447-454
+ *   pos[i]   = same for (z1[i], z2[i])                                    losses.py:450
+ *   compat:  lse[i] = logsumexp_j(-[neg[i,:], pos[i]]/tau)                losses.py:458-462
+ *   default: lse[i] = logsumexp_j(-neg[i,:]/tau) - log(B3)                losses.py:463-465
+ *   loss[i]  = 2 (alpha pos[i]/tau + (1-alpha) lse[i])                    losses.py:467
+ *   p < 1 uses the reference's eps/transposed branch (losses.py:433-442); it needs B3 == B.
+ * The B x B3 matrix is never materialised (tiled online log-sum-exp).
+ * ---------------------------------------------------------------------------------- */
+typedef struct clica_lp_loss_desc {
+  int64_t B;       /* rows of z1 and z2                                  */
+  int64_t B3;      /* rows of z3                                         */
+  int32_t n;       /* embedding dimension (1..4096)                      */
+  float p;         /* exponent of the norm (1, 2, 3 fast paths; any p>0) */
+  float tau;
+  float alpha;
+  int32_t compat;  /* simclr_compatibility_mode                          */
+  int32_t pow;     /* use p-th power of the norm                         */
+} clica_lp_loss_desc;
+
+/* scratch needed by clica_lp_loss_fwd / _bwd for this problem size */
+int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t* fwd_bytes, size_t* bwd_bytes);
+
+/* Forward.  Outputs (all fp32, device):
+ *   loss_i  [B]  per-item loss                         (2nd return of LpSimCLRLoss.loss)
+ *   pos_i   [B]  pos[i]/tau                            (its mean is the 3rd return's [0])
+ *   lse_i   [B]  RAW logsumexp (without -log B3), saved for the backward
+ *   means   [3]  mean(loss_i), mean(pos_i), mean(lse as the reference defines it)
+ */
+int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
+                      const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                      const float* z3, int64_t ld3,
+                      float* loss_i, float* pos_i, float* lse_i, float* means,
+                      void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
+/* Backward (autograd of the forward; recomputes distances, no B x B3 storage).
+ * Upstream gradients (device pointers, any may be NULL):
+ *   g_mean [1] for means[0] (NULL = 1.0), g_item [B] for loss_i (NULL = 0),
+ *   g_pos [1] / g_neg [1] for means[1] / means[2] (NULL = 0).
+ * Outputs: dz1 [B,n], dz2 [B,n], dz3 [B3,n] (any may be NULL to skip).  If
+ * `accumulate_dz3` != 0 the z3 gradient is ADDED into dz3 (used when z3 aliases z1, i.e.
+ * the reference's z3_rec = roll(z1_rec), main_mlp.py:272, up to a row permutation).
+ */
+int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
+                      const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                      const float* z3, int64_t ld3, const float* lse_i,
+                      const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
+                      float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                      float* dz3, int64_t ldd3, int32_t accumulate_dz3,
+                      void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dot-product InfoNCE  --  SimCLRLoss.loss, /root/reference/losses.py:177-202
+ *   (optional row L2-normalisation is done by the caller-visible wrapper kernels below)
+ *   neg = z1 z3^T, pos = <z1,z2>, lse = logsumexp([neg,pos]/tau),
+ *   loss = 2(alpha(-pos/tau) + (1-alpha) lse)
+ * ---------------------------------------------------------------------------------- */
+typedef struct clica_dot_loss_desc {
+  int64_t B, B3;
+  int32_t n;
+  float tau, alpha;
+  int32_t normalize;   /* losses.py:180-185 */
+} clica_dot_loss_desc;
+
+int clica_dot_loss_workspace_bytes(const clica_dot_loss_desc* d, size_t* fwd_bytes, size_t* bwd_bytes);
+int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
+                       const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                       const float* z3, int64_t ld3,
+                       float* loss_i, float* pos_i, float* lse_i, float* means,
+                       void* workspace, size_t workspace_bytes, clica_stream_t stream);
+int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
+                       const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                       const float* z3, int64_t ld3, const float* lse_i,
+                       const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
+                       float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                       float* dz3, int64_t ldd3, int32_t accumulate_dz3,
+                       void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused Linear (+bias) (+LeakyReLU)  --  the nn.Sequential get_mlp builds,
+ * /root/reference/encoders.py:36-48 (nn.Linear + nn.LeakyReLU(0.01)); fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate).
+ *
+ *   fwd :  Y[M,N]  = act(X[M,K] W[N,K]^T + bias[N])          act = LeakyReLU(slope) or identity
+ *   dgrad: dX[M,K] = (dY[M,N] W[N,K]) * act'(Xact[M,K])      Xact = the saved OUTPUT of the
+ *          previous layer's activation (sign(Xact) == sign(pre-activation) for slope > 0);
+ *          pass Xact = NULL for no activation derivative
+ *   wgrad: dW[N,K] (+)= dY[M,N]^T X[M,K];  db[N] (+)= sum_m dY[m,:]
+ * ---------------------------------------------------------------------------------- */
+int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
+                     float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                     int32_t leaky, float slope, clica_stream_t stream);
+int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W, int64_t ldw,
+                       const float* Xact, int64_t ldxa, float slope,
+                       float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
+                       clica_stream_t stream);
+int clica_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes);
+int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx,
+                       float* dW, int64_t lddw, float* db, int64_t M, int64_t N, int64_t K,
+                       int32_t accumulate, void* workspace, size_t workspace_bytes,
+                       clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Output heads  --  RescaleLayer (mode "eq") layers.py:63-66, SoftclipLayer layers.py:87-91
+ * ---------------------------------------------------------------------------------- */
+int clica_rescale_fwd(const float* X, int64_t ldx, const float* r /*[1]*/, float* Y, int64_t ldy,
+                      float* inv_norm /*[M] saved*/, int64_t M, int32_t n, clica_stream_t stream);
+int clica_rescale_bwd(const float* X, int64_t ldx, const float* r, const float* inv_norm,
+                      const float* dY, int64_t lddy, float* dX, int64_t lddx,
+                      float* dr_partial /*[ceil(M/256)] or NULL*/, int64_t M, int32_t n,
+                      clica_stream_t stream);
+int clica_softclip_fwd(const float* X, int64_t ldx, const float* bound /*[n]*/, float* Y, int64_t ldy,
+                       int64_t M, int32_t n, clica_stream_t stream);
+int clica_softclip_bwd(const float* X, int64_t ldx, const float* bound, const float* dY, int64_t lddy,
+                       float* dX, int64_t lddx, float* dbound_partial /*[ceil(M/256), n] or NULL*/,
+                       int64_t M, int32_t n, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mixing network g  --  construct_invertible_mlp's nn.Sequential forward,
+ * /root/reference/invertible_network_utils.py:87-115: bias-free n x n Linear layers with
+ * LeakyReLU(slope) between them; frozen (no backward).
+ *   W : n_layers contiguous [n,n] row-major matrices (nn.Linear.weight layout)
+ * ---------------------------------------------------------------------------------- */
+int clica_mixing_fwd(const float* Z, int64_t ldz, const float* W, int32_t n_layers, float slope,
+                     float* X, int64_t ldx, int64_t M, int32_t n, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Adam  --  torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) as used at main_mlp.py:312,
+ * over one flat parameter arena.  `step_dev` is a device int32 holding the number of
+ * updates already applied; the call uses t = *step_dev + 1 for the bias corrections and
+ * leaves *step_dev unchanged (advance it with clica_tick so a graph replay stays valid).
+ * ---------------------------------------------------------------------------------- */
+int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                    float lr, float beta1, float beta2, float eps, float grad_scale,
+                    const int32_t* step_dev, clica_stream_t stream);
+/* *counter += 1 (single-thread kernel; keeps step/RNG counters on device for graph replay) */
+int clica_tick(int32_t* counter, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * On-device latent samplers (Philox4x32-10, counter = (element, draw, *step_dev, stream_id))
+ * replacing torch/NumPy host RNG + rejection loops with host syncs:
+ *   spaces.py:273-302 (box uniform / truncated normal via spaces_utils.py:106-142),
+ *   spaces.py:134-170 (sphere uniform / projected normal), spaces.py:44-119 (R^n),
+ *   laplace spaces.py:74-96, generalized normal spaces_utils.py:82-103,
+ *   von Mises-Fisher vmf.py:48-134 (Wood's rejection sampler).
+ * `mean` may be NULL for the marginal kinds; for conditional kinds it is [M,n] (ldm) or, with
+ * ldm == 0, a single row broadcast to all M samples.
+ * ---------------------------------------------------------------------------------- */
+enum clica_space { CLICA_SPACE_REAL = 0, CLICA_SPACE_BOX = 1, CLICA_SPACE_SPHERE = 2 };
+enum clica_dist {
+  CLICA_DIST_UNIFORM = 0,   /* box: U[min,max]^n ; sphere: uniform on S^{n-1}           */
+  CLICA_DIST_NORMAL = 1,    /* N(mean, scale^2); box: per-element truncation; sphere: projected */
+  CLICA_DIST_LAPLACE = 2,   /* Laplace(mean, scale)                                        */
+  CLICA_DIST_GENNORM = 3,   /* generalized normal, exponent shape_p                        */
+  CLICA_DIST_VMF = 4        /* von Mises-Fisher(mean, kappa = scale), sphere only          */
+};
+typedef struct clica_sampler_desc {
+  int32_t space;      /* enum clica_space */
+  int32_t dist;       /* enum clica_dist  */
+  int32_t n;
+  float box_min, box_max;
+  float scale;        /* std / lambda / kappa */
+  float shape_p;      /* exponent for GENNORM */
+  uint64_t seed;
+  uint32_t stream_id; /* distinguishes independent draws inside one step (z, z~, rank...) */
+} clica_sampler_desc;
+int clica_sample(const clica_sampler_desc* d, const float* mean, int64_t ldm,
+                 float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
+                 clica_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLICA_H */

@@ -1,0 +1,137 @@
+"""Fused Linear/LeakyReLU GEMM kernels, heads, mixing net, Adam: HIP vs goldens / oracle / torch fp32."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import formula_weights, mlp_formula_params, rel_err
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a, np.float32), device="cuda")
+
+
+@pytest.mark.parametrize("M,N,K", [(48, 40, 4), (300, 100, 10), (1000, 500, 100), (12288, 500, 500), (257, 10, 100),
+                                   (129, 131, 67), (64, 2000, 400), (5, 3, 1)])
+def test_linear_kernels_vs_fp64(M, N, K):
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    w = (rng.uniform(-1, 1, size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, size=N).astype(np.float32)
+    dy = rng.normal(size=(M, N)).astype(np.float32)
+    z = x.astype(np.float64) @ w.astype(np.float64).T + b
+    for leaky in (True, False):
+        y = ops.linear_fwd(dev(x), dev(w), dev(b), leaky=leaky, slope=0.01).cpu().numpy()
+        ref = np.where(z > 0, z, 0.01 * z) if leaky else z
+        assert rel_err(y, ref) < 2e-6, ("fwd", leaky)
+    xact = rng.normal(size=(M, K)).astype(np.float32)
+    dx = ops.linear_dgrad(dev(dy), dev(w), dev(xact), 0.01).cpu().numpy()
+    ref = (dy.astype(np.float64) @ w.astype(np.float64)) * np.where(xact > 0, 1.0, 0.01)
+    assert rel_err(dx, ref) < 2e-6
+    dx = ops.linear_dgrad(dev(dy), dev(w), None).cpu().numpy()
+    assert rel_err(dx, dy.astype(np.float64) @ w.astype(np.float64)) < 2e-6
+    dW, db = ops.linear_wgrad(dev(dy), dev(x))
+    assert rel_err(dW.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64)) < 3e-6
+    assert rel_err(db.cpu().numpy(), dy.astype(np.float64).sum(0)) < 3e-6
+    # accumulate + asymmetric check (transpose-detecting: M != N != K in several cases)
+    dW2, db2 = ops.linear_wgrad(dev(dy), dev(x), dW=dW.clone(), db=db.clone(), accumulate=True)
+    assert rel_err(dW2.cpu().numpy(), 2 * (dy.astype(np.float64).T @ x.astype(np.float64))) < 3e-6
+    assert rel_err(db2.cpu().numpy(), 2 * dy.astype(np.float64).sum(0)) < 3e-6
+
+
+def test_linear_strided_inputs():
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(1)
+    big = dev(rng.normal(size=(64, 40)))
+    x = big[:, 3:13]              # ld = 40, unaligned start
+    w = dev(rng.normal(size=(7, 10)))
+    y = ops.linear_fwd(x, w, None, leaky=False).cpu().numpy()
+    assert rel_err(y, big.cpu().numpy()[:, 3:13].astype(np.float64) @ w.cpu().numpy().astype(np.float64).T) < 2e-6
+
+
+def _build(n, hidden, head):
+    from cl_ica_amd import encoders
+    f = encoders.get_mlp(n_in=n, n_out=n, layers=list(hidden), output_normalization=head)
+    Ws, bs, hp = mlp_formula_params(n, hidden, head)
+    lin = [m for m in f if isinstance(m, torch.nn.Linear)]
+    for m, W, b in zip(lin, Ws, bs):
+        m.weight.data = torch.tensor(W); m.bias.data = torch.tensor(b)
+    return f.to("cuda"), Ws, bs, hp
+
+
+def test_mlp_goldens(golden):
+    """get_mlp fwd/bwd vs the reference goldens (G6), incl. heads and state-dict keys."""
+    G = golden("g6_mlp.npz")
+    for key, c in G.cases():
+        n = int(c["meta"]["n"]); head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]
+        f, Ws, bs, hp = _build(n, hidden, head)
+        assert list(f.state_dict().keys()) == [str(k) for k in c["meta"]["state_keys"]]
+        x = dev(c["in"]["x"]).requires_grad_(True)
+        y = f(x)
+        y.backward(dev(c["in"]["gy"]))
+        assert rel_err(y.detach().cpu().numpy(), c["out"]["y"]) < 1e-5, key
+        assert rel_err(x.grad.cpu().numpy(), c["out"]["dx"]) < 2e-5, key
+        for name, prm in f.named_parameters():
+            got = prm.grad.cpu().numpy()
+            if f"grad/{name}" in c["out"]:
+                assert rel_err(got, c["out"][f"grad/{name}"]) < 2e-5, (key, name)
+            else:
+                assert rel_err(np.ascontiguousarray(got.reshape(-1)[::97]), c["out"][f"gradsub/{name}"]) < 2e-5, (key, name)
+
+
+def test_mixing_golden(golden):
+    from cl_ica_amd import ops
+    z = golden("g8_mixing.npz").z
+    W = dev(np.stack([z["W0"], z["W1"], z["W2"]]))
+    y = ops.mixing_fwd(dev(z["x"]), W, 0.2).cpu().numpy()
+    assert rel_err(y, z["y"]) < 2e-6
+    rng = np.random.default_rng(0)
+    for n, L in ((40, 3), (3, 1), (64, 2)):
+        Ws = rng.normal(size=(L, n, n)).astype(np.float32) / np.sqrt(n)
+        x = rng.normal(size=(1000, n)).astype(np.float32)
+        assert rel_err(ops.mixing_fwd(dev(x), dev(Ws), 0.2).cpu().numpy(), O.mixing_forward(list(Ws), x)) < 3e-6
+
+
+def test_adam_matches_oracle_and_torch():
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(0)
+    N = 100003
+    p0 = rng.normal(size=N).astype(np.float32)
+    p = dev(p0); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    tp = torch.nn.Parameter(torch.tensor(p0))
+    opt = torch.optim.Adam([tp], lr=1e-3)
+    po, mo, vo = p0.astype(np.float64), np.zeros(N), np.zeros(N)
+    for s in range(1, 6):
+        g = rng.normal(size=N).astype(np.float32) * (10.0 ** rng.integers(-3, 2))
+        ops.adam_step(p, dev(g), m, v, step, lr=1e-3)
+        ops.tick(step)
+        tp.grad = torch.tensor(g); opt.step()
+        po, mo, vo = O.adam_step(po, g.astype(np.float64), mo, vo, s, 1e-3)
+    assert int(step.item()) == 5
+    assert np.abs(p.cpu().numpy() - po).max() < 2e-6
+    assert np.abs(p.cpu().numpy() - tp.detach().numpy()).max() < 2e-6
+
+
+def test_heads_vs_oracle():
+    from cl_ica_amd import layers
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(1000, 10)).astype(np.float32); gy = rng.normal(size=(1000, 10)).astype(np.float32)
+    lay = layers.RescaleLayer(init_r=1.7, fixed_r=False).to("cuda")
+    xt = dev(x).requires_grad_(True); y = lay(xt); y.backward(dev(gy))
+    P = O.MLPParams([np.eye(10)], [np.zeros(10)], "learnable_sphere", np.asarray([1.7]))
+    yo, cache = O.mlp_forward(P, x); gr = O.mlp_backward(P, cache, gy)
+    assert rel_err(y.detach().cpu().numpy(), yo) < 2e-6
+    assert rel_err(xt.grad.cpu().numpy(), gr["dx"]) < 1e-5
+    assert rel_err(lay.r.grad.cpu().numpy(), gr["dhead"]) < 1e-5
+    lay = layers.SoftclipLayer(n=10, init_abs_bound=2.0, fixed_abs_bound=False).to("cuda")
+    xt = dev(x).requires_grad_(True); y = lay(xt); y.backward(dev(gy))
+    P = O.MLPParams([np.eye(10)], [np.zeros(10)], "learnable_box", np.full(10, 2.0))
+    yo, cache = O.mlp_forward(P, x); gr = O.mlp_backward(P, cache, gy)
+    assert rel_err(y.detach().cpu().numpy(), yo) < 2e-6
+    assert rel_err(xt.grad.cpu().numpy(), gr["dx"]) < 1e-5
+    assert rel_err(lay.max_abs_bound.grad.cpu().numpy(), gr["dhead"]) < 1e-5
