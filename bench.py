@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- training steps/sec of the cl-ica contrastive hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], = SURVEY.md M1): main_mlp.py --n 10 --n-mixing-layer 3 --p 2
+--batch-size 6144, box [0,1], uniform marginal, truncated normal conditional sigma=0.05, tau=1,
+compat-mode LpSimCLRLoss, Adam lr=1e-4.  One "step" = one B=6144 batch through
+sample -> g -> f fwd -> loss -> backward -> Adam (main_mlp.py:258-285,328) -- nothing skipped.
+At N GPUs every rank processes its own B=6144 batch per global step against the all-gathered
+N*B negatives pool (weak scaling); `value` counts batches/s over all ranks = N * global_steps/s.
+
+Besides the contract fields the JSON line carries
+  roofline      -- the dominant kernel class (fp32-MFMA Linear GEMMs) timed with HIP events,
+                   algorithmic FLOPs / time vs the 157.3 TFLOP/s fp32 matrix peak
+  cpu_baseline  -- oracle/torch_port.py (the reference's op sequence in PyTorch CPU ops) timed on
+                   this box's host cores, rank 0 at N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_FP32_VALU_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=6144)
+    ap.add_argument("--p", type=int, default=2)
+    ap.add_argument("--space-type", default="box", choices=("box", "sphere"))
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build_trainer(args, device, world):
+    from cl_ica_amd import encoders, invertible_network_utils as inu
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    import contextlib, io
+    n = args.n
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = inu.construct_invertible_mlp(n=n, n_layers=3, act_fct="leaky_relu", cond_thresh_ratio=0.0,
+                                         n_iter_cond_thresh=25000 if n <= 10 else 2000)
+    torch.manual_seed(0)   # identical replicas on every rank
+    f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 50, n * 50, n * 10])
+    spec = SamplerSpec(space=args.space_type, n=n, box=(0.0, 1.0), marginal="uniform", conditional="normal", c_param=0.05, seed=0)
+    return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
+                              device=device, process_group=None if world == 1 else dist.group.WORLD)
+
+
+def roofline_leg(tr, reps=10):
+    """Time every GEMM launch of one step (same shapes, same kernels) with HIP events on the
+    launch stream; aggregate per kernel class.  FLOPs are algorithmic: 2*M*N*K per launch."""
+    from cl_ica_amd import ops
+    R = 2 * tr.B
+    classes = {"linear_fwd": [0.0, 0.0, 0], "linear_dgrad": [0.0, 0.0, 0], "linear_wgrad": [0.0, 0.0, 0]}
+
+    def timed(name, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        return name, flops, s, e
+
+    pending = []
+    for _ in range(reps):
+        cur = tr.x
+        L = len(tr.linears)
+        for l, lin in enumerate(tr.linears):
+            N, K = lin.out_features, lin.in_features
+            pending.append(timed("linear_fwd", 2.0 * R * N * K,
+                                 lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=tr.slope, out=tr.acts[l])))
+            cur = tr.acts[l]
+        g = tr.dy
+        for l in reversed(range(L)):
+            lin = tr.linears[l]
+            N, K = lin.out_features, lin.in_features
+            inp = tr.acts[l - 1] if l > 0 else tr.x
+            pending.append(timed("linear_wgrad", 2.0 * R * N * K,
+                                 lambda g=g, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)], ws=tr.wgrad_ws)))
+            if l > 0:
+                out = tr.dbuf[l & 1][:, :K]
+                pending.append(timed("linear_dgrad", 2.0 * R * N * K,
+                                     lambda g=g, lin=lin, inp=inp, out=out: ops.linear_dgrad(g, lin.weight, inp, tr.slope, out=out)))
+                g = out
+    torch.cuda.synchronize()
+    for name, flops, s, e in pending:
+        c = classes[name]
+        c[0] += flops; c[1] += s.elapsed_time(e) * 1e-3; c[2] += 1
+    rows = []
+    for name, (fl, sec, cnt) in classes.items():
+        rows.append({"kernel": name, "launches_per_step": cnt // reps, "avg_us": 1e6 * sec / cnt,
+                     "tflops": fl / sec / 1e12, "share_s": sec / reps})
+    rows.sort(key=lambda r: -r["share_s"])
+    top = rows[0]
+    roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": round(top["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "avg_launch_us": round(top["avg_us"], 2), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+    return roof, rows
+
+
+def loss_leg(tr, reps=20):
+    """Event-time the tiled Lp-InfoNCE forward and backward (all their kernels) on the step's buffers."""
+    import ctypes as C
+    from cl_ica_amd import _lib
+    lib, st = _lib.load(), _lib.stream_ptr()
+    B, n, o = tr.B, tr.n, tr.loss_out
+    y1, y2 = tr.y[:B], tr.y[B:]
+    z3 = y1 if tr.world == 1 else tr.z_all
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = tb = 0.0
+    for _ in range(reps):
+        ev[0].record()
+        lib.clica_lp_loss_fwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
+                              o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        ev[1].record()
+        lib.clica_lp_loss_bwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                              None, None, None, None, tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n,
+                              (tr.dy[:B] if tr.world == 1 else tr.dz_all).data_ptr(), n, 0, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        ev[2].record()
+        torch.cuda.synchronize()
+        tf += ev[0].elapsed_time(ev[1]) * 1e-3; tb += ev[1].elapsed_time(ev[2]) * 1e-3
+    pairs = float(B) * z3.shape[0] + B
+    cp = {1: 2, 2: 2, 3: 4}.get(int(tr.p), 6)
+    fl_f = pairs * (cp * n + 6)      # P (c_p n + 6); backward = 3x forward
+    return {"fwd_us": 1e6 * tf / reps, "bwd_us": 1e6 * tb / reps, "pairs": pairs,
+            "fwd_gpairs_per_s": pairs / (tf / reps) / 1e9, "fwd_tflops_valu": fl_f / (tf / reps) / 1e12,
+            "bwd_tflops_valu": 3 * fl_f / (tb / reps) / 1e12, "valu_peak_tflops": PEAK_FP32_VALU_TFLOPS,
+            "algorithmic_bytes_fwd": 4 * n * (2 * B + z3.shape[0]) + 12 * B}
+
+
+def main():
+    args = parse()
+    from cl_ica_amd.distributed import init_from_env
+    rank, world, device = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    tr = build_trainer(args, device, world)
+    use_graph = (world == 1) and not args.no_graph
+    if use_graph:
+        tr.capture()
+    for _ in range(args.warmup):
+        tr.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    last = tr.loss_out[3 * tr.B:].clone()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_vals = [float(v) for v in last.cpu()]
+
+    out = {
+        "metric": "training steps/sec (B=6144, n=10 MLP)", "value": world * args.steps / elapsed, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "global_steps_per_s": args.steps / elapsed,
+        "config": {"workload": f"main_mlp.py --n {args.n} --n-mixing-layer 3 --p {args.p} --batch-size {args.batch_size} "
+                               f"--space-type {args.space_type} (unsupervised step: sample->g->f->LpSimCLR->bwd->Adam)",
+                   "batch_per_gpu": args.batch_size, "global_batch": args.batch_size * world,
+                   "negatives_pool": args.batch_size * world, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if use_graph else "eager"},
+        "final_loss": loss_vals[0], "final_pos": loss_vals[1], "final_neg": loss_vals[2],
+    }
+    if rank == 0 and not args.no_roofline:
+        roof, rows = roofline_leg(tr)
+        out["roofline"] = roof
+        out["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+        ll = loss_leg(tr)
+        out["loss_kernel"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ll.items()}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.torch_port import time_reference_step      # checker/baseline leg only
+        threads = torch.get_num_threads()
+        med, _ = time_reference_step(n=args.n, B=args.batch_size, p=args.p, steps=5, warmup=2)
+        out["cpu_baseline"] = {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
+                               "sample": f"5 timed + 2 warm-up full steps at B={args.batch_size}, n={args.n} (median), "
+                                         f"torch {torch.__version__} CPU ops, {os.cpu_count()} host cores visible"}
+        out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

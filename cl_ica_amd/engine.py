@@ -1,0 +1,288 @@
+"""Fused, HBM-resident contrastive train step: the counterpart of ``train_step`` in
+/root/reference/main_mlp.py:258-285 plus the sampling at :328, without autograd and without a
+host sync.
+
+One step enqueues, on one HIP stream:
+    tick -> sample z, z~ (Philox) -> mixing net g -> 7 fused Linear(+LeakyReLU) GEMMs over the
+    stacked 2B rows -> [head] -> tiled Lp-InfoNCE forward -> its backward (dz1 += dz3: the
+    reference's z3_rec = roll(z1_rec) is, up to a row permutation the row-wise log-sum-exp cannot
+    see, "all z1_rec of the batch") -> [head bwd] -> wgrad/dgrad GEMMs into one flat gradient arena
+    -> [bucketed RCCL all-reduce] -> one fused Adam launch over the flat parameter arena.
+All buffers are preallocated, so the whole step can be captured in a HIP graph (``capture()``).
+
+Data parallel (one process per GPU): every rank samples its own B pairs, all-gathers z1_rec
+(B*n*4 bytes per rank) to form the global negatives pool, reduce-scatters d/dz3, and all-reduces the
+flat gradient arena; semantics = the single-process loss on the concatenated batch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import _lib, ops
+from . import layers as ls
+from .distributed import GradBuckets
+
+__all__ = ["SamplerSpec", "ContrastiveTrainer"]
+
+
+@dataclass
+class SamplerSpec:
+    """Ground-truth latent distribution (main_mlp.py:136-200)."""
+    space: str = "box"              # box | sphere | real  (--space-type, "unbounded" -> real)
+    n: int = 10
+    box: tuple = (0.0, 1.0)         # --box-min / --box-max
+    marginal: str = "uniform"       # uniform | normal | laplace | gennorm   (--m-p 0/2/1/k)
+    m_param: float = 1.0
+    m_p: float = 2.0
+    conditional: str = "normal"     # normal | laplace | gennorm | vmf        (--c-p 2/1/k/0)
+    c_param: float = 0.05
+    c_p: float = 2.0
+    seed: int = 0
+
+
+class ContrastiveTrainer:
+    def __init__(self, f: nn.Sequential, g_weights: torch.Tensor, sampler: SamplerSpec, batch_size: int,
+                 p: float = 2, tau: float = 1.0, alpha: float = 0.5, lr: float = 1e-4, g_slope: float = 0.2,
+                 betas=(0.9, 0.999), eps: float = 1e-8, device=None,
+                 process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20):
+        self.device = torch.device(device if device is not None else "cuda")
+        self.f = f.to(self.device)
+        self.B = int(batch_size)
+        self.n = sampler.n
+        self.sampler = sampler
+        self.p, self.tau, self.alpha = float(p), float(tau), float(alpha)
+        self.lr, self.betas, self.eps = float(lr), betas, float(eps)
+        self.g_slope = float(g_slope)
+        self.gW = g_weights.detach().to(self.device, torch.float32).contiguous()
+        assert self.gW.shape[1:] == (self.n, self.n)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        if self.p == 0:
+            raise NotImplementedError("p=0 (SimCLRLoss) runs through cl_ica_amd.losses.SimCLRLoss, not the fused engine")
+
+        mods = list(self.f)
+        self.linears: List[nn.Linear] = [m for m in mods if isinstance(m, nn.Linear)]
+        slopes = {m.negative_slope for m in mods if isinstance(m, nn.LeakyReLU)}
+        self.slope = slopes.pop() if slopes else 0.01
+        heads = [m for m in mods if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer))]
+        self.head = heads[0] if heads else None
+        self._flatten_parameters()
+        self._allocate()
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes) if self.world > 1 else None
+
+    # -------------------------------------------------------------------------------- arenas
+    def _flatten_parameters(self):
+        """Re-point every parameter of f into one 16-byte aligned flat arena (Parameter objects and
+        state-dict keys are unchanged) and create matching grad / exp_avg / exp_avg_sq arenas."""
+        params = list(self.f.parameters())
+        offs, total = [], 0
+        for prm in params:
+            offs.append(total)
+            total += (prm.numel() + 3) // 4 * 4
+        dev = self.device
+        self.param_arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad_arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._views, self._gviews = {}, {}
+        for prm, off in zip(params, offs):
+            view = self.param_arena[off:off + prm.numel()].view(prm.shape)
+            view.copy_(prm.data.to(dev))
+            prm.data = view
+            gview = self.grad_arena[off:off + prm.numel()].view(prm.shape)
+            prm.grad = gview
+            self._views[id(prm)] = view
+            self._gviews[id(prm)] = gview
+        # slices per Linear layer in BACKWARD completion order (last layer first) for bucketing
+        self._layer_slices = []
+        pid = {id(prm): (off, prm.numel()) for prm, off in zip(params, offs)}
+        for lin in reversed(self.linears):
+            o_w, n_w = pid[id(lin.weight)]
+            o_b, n_b = pid[id(lin.bias)]
+            self._layer_slices.append((min(o_w, o_b), max(o_w + n_w, o_b + n_b)))
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def _allocate(self):
+        dev, B, n = self.device, self.B, self.n
+        R = 2 * B
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.z = torch.empty((R, n), **f32)            # rows [0,B): z ; [B,2B): z~
+        self.x = torch.empty((R, n), **f32)            # g(z), g(z~)
+        widths = [lin.out_features for lin in self.linears]
+        self.acts = [torch.empty((R, w), **f32) for w in widths]     # post-activation outputs; last = pre-head
+        self.y = torch.empty((R, n), **f32) if self.head is not None else self.acts[-1]
+        self.inv_norm = torch.empty((R,), **f32) if isinstance(self.head, ls.RescaleLayer) else None
+        wmax = max(widths + [n])
+        self.dbuf = [torch.empty((R, wmax), **f32), torch.empty((R, wmax), **f32)]
+        self.dy = torch.empty((R, n), **f32)
+        self.loss_out = torch.empty(3 * B + 3, **f32)
+        Bg = B * self.world
+        self.z_all = torch.empty((Bg, n), **f32) if self.world > 1 else None
+        self.dz_all = torch.empty((Bg, n), **f32) if self.world > 1 else None
+        self.dz_rs = torch.empty((B, n), **f32) if self.world > 1 else None
+        self.desc = _lib.LpLossDesc(B=B, B3=Bg, n=n, p=self.p, tau=self.tau, alpha=self.alpha, compat=1, pow=1)
+        fb, bb = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(self.desc), C.byref(fb), C.byref(bb)), "workspace")
+        self.loss_ws = torch.zeros(max(fb.value, bb.value), dtype=torch.uint8, device=dev)
+        nb = C.c_size_t(); need = 0
+        for lin in self.linears:
+            _lib.check(_lib.load().clica_linear_wgrad_workspace_bytes(R, lin.out_features, lin.in_features, C.byref(nb)), "wgrad ws")
+            need = max(need, nb.value)
+        self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        if self.head is not None:
+            self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
+            hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
+            self.head_param = hp.data if isinstance(hp, nn.Parameter) else hp.to(dev).contiguous()
+            self.head_learnable = isinstance(hp, nn.Parameter)
+            self.dpre = torch.empty((R, n), **f32)
+
+    # -------------------------------------------------------------------------------- data
+    def sample(self):
+        """z ~ marginal, z~ ~ conditional(z) on device (main_mlp.py:196-200), then x = g(z)."""
+        s, B, n = self.sampler, self.B, self.n
+        z, zt = self.z[:B], self.z[B:]
+        sid = 2 * self.rank
+        if s.marginal == "uniform":
+            ops.sample(s.space, "uniform", n, B, self.device, box=s.box, seed=s.seed, stream_id=sid, step_dev=self.step_dev, out=z)
+        else:
+            if not hasattr(self, "_eta"):
+                self._eta = torch.zeros(1, n, device=self.device)
+                if s.space == "sphere":
+                    self._eta[0, 0] = 1.0                      # main_mlp.py:148-150
+            ops.sample(s.space, s.marginal, n, B, self.device, mean=self._eta, scale=s.m_param, shape_p=s.m_p, box=s.box,
+                       seed=s.seed, stream_id=sid, step_dev=self.step_dev, out=z)
+        ops.sample(s.space, s.conditional, n, B, self.device, mean=z, scale=s.c_param, shape_p=s.c_p, box=s.box,
+                   seed=s.seed, stream_id=sid + 1, step_dev=self.step_dev, out=zt)
+        ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+
+    def inject(self, z1: torch.Tensor, z2: torch.Tensor):
+        """Use caller-provided latents instead of the device sampler (parity tests)."""
+        self.z[:self.B].copy_(z1); self.z[self.B:].copy_(z2)
+        ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+
+    # -------------------------------------------------------------------------------- step pieces
+    def forward(self):
+        cur = self.x
+        L = len(self.linears)
+        for l, lin in enumerate(self.linears):
+            ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=self.slope, out=self.acts[l])
+            cur = self.acts[l]
+        if self.head is not None:
+            lib, st = _lib.load(), _lib.stream_ptr()
+            R, n = cur.shape
+            if isinstance(self.head, ls.RescaleLayer):
+                _lib.check(lib.clica_rescale_fwd(cur.data_ptr(), n, self.head_param.data_ptr(), self.y.data_ptr(), n,
+                                                 self.inv_norm.data_ptr(), R, n, st), "clica_rescale_fwd")
+            else:
+                _lib.check(lib.clica_softclip_fwd(cur.data_ptr(), n, self.head_param.data_ptr(), self.y.data_ptr(), n, R, n, st),
+                           "clica_softclip_fwd")
+
+    def loss_forward_backward(self):
+        lib, st = _lib.load(), _lib.stream_ptr()
+        B, n, o = self.B, self.n, self.loss_out
+        y1, y2 = self.y[:B], self.y[B:]
+        if self.world > 1:
+            dist.all_gather_into_tensor(self.z_all, y1.contiguous(), group=self.pg)
+            z3, dz3, acc = self.z_all, self.dz_all, 0
+        else:
+            z3, dz3, acc = y1, self.dy[:B], 1
+        _lib.check(lib.clica_lp_loss_fwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n,
+                                         o[:B].data_ptr(), o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(),
+                                         self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")
+        _lib.check(lib.clica_lp_loss_bwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n,
+                                         o[2 * B:3 * B].data_ptr(), None, None, None, None,
+                                         self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n, dz3.data_ptr(), n, acc,
+                                         self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd")
+        if self.world > 1:
+            dist.reduce_scatter_tensor(self.dz_rs, self.dz_all, op=dist.ReduceOp.SUM, group=self.pg)
+            self.dy[:B].add_(self.dz_rs)
+
+    def backward(self):
+        lib, st = _lib.load(), _lib.stream_ptr()
+        g = self.dy
+        R, n = g.shape
+        if self.head is not None:
+            pre = self.acts[-1]
+            part = self.head_part if self.head_learnable else None
+            if isinstance(self.head, ls.RescaleLayer):
+                _lib.check(lib.clica_rescale_bwd(pre.data_ptr(), n, self.head_param.data_ptr(), self.inv_norm.data_ptr(),
+                                                 g.data_ptr(), n, self.dpre.data_ptr(), n, _lib.ptr(part), R, n, st), "clica_rescale_bwd")
+            else:
+                _lib.check(lib.clica_softclip_bwd(pre.data_ptr(), n, self.head_param.data_ptr(), g.data_ptr(), n,
+                                                  self.dpre.data_ptr(), n, _lib.ptr(part), R, n, st), "clica_softclip_bwd")
+            if self.head_learnable:
+                hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
+                torch.sum(self.head_part, dim=0, out=self._gviews[id(hp)])
+            g = self.dpre
+        L = len(self.linears)
+        for l in reversed(range(L)):
+            lin = self.linears[l]
+            inp = self.acts[l - 1] if l > 0 else self.x
+            ops.linear_wgrad(g, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)], accumulate=False,
+                             ws=self.wgrad_ws)
+            if self.buckets is not None:
+                self.buckets.layer_done(L - 1 - l)
+            if l > 0:
+                out = self.dbuf[l & 1][:, :lin.in_features]
+                ops.linear_dgrad(g, lin.weight, inp, self.slope, out=out)
+                g = out
+        if self.buckets is not None:
+            self.buckets.wait()
+
+    def optimizer_step(self):
+        ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
+                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world)
+
+    # -------------------------------------------------------------------------------- whole step
+    def _step_body(self, sample: bool):
+        if sample:
+            self.sample()
+        self.forward()
+        self.loss_forward_backward()
+        self.backward()
+        self.optimizer_step()
+        ops.tick(self.step_dev)
+
+    def step(self):
+        """One unsupervised step with on-device sampling.  Returns the device tensor
+        ``[loss_mean, pos_mean, neg_mean]`` of this rank's rows (no host sync)."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body(True)
+        return self.loss_out[3 * self.B:]
+
+    def step_injected(self, z1, z2):
+        self.inject(z1, z2)
+        self._step_body(False)
+        return self.loss_out[3 * self.B:]
+
+    def capture(self, warmup: int = 3):
+        """Capture the step into a HIP graph (single-GPU; counters and RNG offsets live on device,
+        so replays advance them)."""
+        if self.world > 1:
+            raise NotImplementedError("graph capture is single-GPU; the DP path runs eagerly")
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step_body(True)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step_body(True)
+        self.graph = graph
+        return graph
+
+    @property
+    def steps_done(self) -> int:
+        return int(self.step_dev.item())

@@ -1,0 +1,95 @@
+"""Mixing network g (host-side construction, device-side forward).
+
+Counterpart of /root/reference/invertible_network_utils.py:15-123.  Construction is a one-off host
+cost and stays in NumPy on purpose: it consumes ``np.random`` exactly like the reference (a pool of
+column-normalised U(-1,1) matrices ranked by condition number, then per-layer rejection sampling),
+so ``np.random.seed(s)`` reproduces the reference's weights bit-for-bit (KAT: seed 0, n=10, L=3 ->
+threshold 4.085284; tests/test_host_logic.py).  The forward runs in one HIP kernel
+(csrc/mixing.hip) -- g is frozen, so there is no backward.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+
+__all__ = ["construct_invertible_mlp", "MixingMLP"]
+
+_ACT_SLOPES = {"leaky_relu": 0.2, "relu": 0.0}
+
+
+def _column_normalised(n: int) -> np.ndarray:
+    a = np.random.uniform(-1, 1, (n, n))
+    return a / np.sqrt((a * a).sum(0))
+
+
+def mixing_weights(n: int, n_layers: int, n_iter_cond_thresh: int, cond_thresh_ratio: float,
+                   weight_matrix_init: str = "pcl", verbose: bool = True):
+    """NumPy weights of the mixing MLP, same RNG consumption as the reference (:71-102)."""
+    if weight_matrix_init == "rvs":
+        from scipy.stats import ortho_group
+        return [ortho_group.rvs(n).astype(np.float32) for _ in range(n_layers)], 0.0
+    if weight_matrix_init != "pcl":
+        raise ValueError(f"weight matrix {weight_matrix_init} not implemented")
+    conds = np.sort([np.linalg.cond(_column_normalised(n)) for _ in range(n_iter_cond_thresh)])
+    thresh = conds[int(n_iter_cond_thresh * cond_thresh_ratio)]
+    if verbose:
+        print("condition number threshold: {0:f}".format(thresh))
+    mats = []
+    for i in range(n_layers):
+        while True:
+            w = _column_normalised(n)
+            if np.linalg.cond(w) <= thresh:
+                break
+        if verbose:
+            print(f"layer {i + 1}/{n_layers},  condition number: {np.linalg.cond(w)}")
+        mats.append(w.astype(np.float32))
+    return mats, float(thresh)
+
+
+class MixingMLP(nn.Sequential):
+    """``nn.Sequential(Linear(n,n,bias=False), LeakyReLU(0.2), ..., Linear)`` with frozen parameters
+    (same state-dict keys ``0.weight, 2.weight, ...`` as the reference's g.pth) whose forward is the
+    single fused HIP kernel."""
+
+    def __init__(self, mats, slope: float):
+        mods = []
+        for i, w in enumerate(mats):
+            lin = nn.Linear(w.shape[1], w.shape[0], bias=False)
+            lin.weight.data = torch.tensor(w, dtype=torch.float32)
+            mods.append(lin)
+            if i < len(mats) - 1:
+                mods.append(nn.LeakyReLU(negative_slope=slope) if slope > 0 else nn.ReLU())
+        super().__init__(*mods)
+        self.slope = slope
+        for p in self.parameters():
+            p.requires_grad = False
+        self._stack = None
+
+    def weight_stack(self) -> torch.Tensor:
+        ws = [m.weight for m in self if isinstance(m, nn.Linear)]
+        if self._stack is None or self._stack.device != ws[0].device:
+            self._stack = torch.stack([w.detach() for w in ws]).contiguous()
+        return self._stack
+
+    def _apply(self, fn, *a, **k):   # .to(device) invalidates the cached stack
+        self._stack = None
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, z):
+        return ops.mixing_fwd(z, self.weight_stack(), self.slope)
+
+
+def construct_invertible_mlp(n: int = 20, n_layers: int = 2, n_iter_cond_thresh: int = 10000,
+                             cond_thresh_ratio: float = 0.25, weight_matrix_init: str = "pcl",
+                             act_fct: str = "leaky_relu"):
+    """Create an (approximately) invertible mixing network based on an MLP (same arguments as the
+    reference).  Only the piecewise-linear activations have a fused forward ("leaky_relu", the
+    default of every driver, and "relu")."""
+    if act_fct not in _ACT_SLOPES:
+        raise NotImplementedError(f"activation {act_fct!r}: the fused mixing kernel implements leaky_relu/relu "
+                                  "(main_mlp.py uses leaky_relu)")
+    mats, _ = mixing_weights(n, n_layers, n_iter_cond_thresh, cond_thresh_ratio, weight_matrix_init)
+    return MixingMLP(mats, _ACT_SLOPES[act_fct])

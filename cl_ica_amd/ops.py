@@ -52,7 +52,8 @@ def linear_dgrad(dy: torch.Tensor, weight: torch.Tensor, xact: Optional[torch.Te
 
 
 def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: Optional[torch.Tensor] = None,
-                 db: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = True):
+                 db: Optional[torch.Tensor] = None, accumulate: bool = False, want_bias: bool = True,
+                 ws: Optional[torch.Tensor] = None):
     """dW = dY^T X, db = column sums of dY."""
     (dy, lddy), (x, ldx) = _mat("dy", dy), _mat("x", x)
     M, N = dy.shape
@@ -61,9 +62,10 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: Optional[torch.Tensor] =
         dW = torch.empty((N, K), dtype=torch.float32, device=dy.device)
     if db is None and want_bias:
         db = torch.empty((N,), dtype=torch.float32, device=dy.device)
-    nbytes = C.c_size_t()
-    check(load().clica_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "clica_linear_wgrad_workspace_bytes")
-    ws = workspace("wgrad", nbytes.value, dy.device)
+    if ws is None:
+        nbytes = C.c_size_t()
+        check(load().clica_linear_wgrad_workspace_bytes(M, N, K, C.byref(nbytes)), "clica_linear_wgrad_workspace_bytes")
+        ws = workspace("wgrad", nbytes.value, dy.device)
     check(load().clica_linear_wgrad(dy.data_ptr(), lddy, x.data_ptr(), ldx, dW.data_ptr(), dW.stride(0), ptr(db),
                                     M, N, K, int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()),
           "clica_linear_wgrad")

@@ -1,0 +1,94 @@
+"""Fused train step (engine) against the reference's injected-step trajectory (G7), the autograd
+drop-in path, and HIP-graph replay."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import mlp_formula_params
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a, np.float32), device="cuda")
+
+
+def build(n, hidden, head):
+    from cl_ica_amd import encoders
+    f = encoders.get_mlp(n_in=n, n_out=n, layers=list(hidden), output_normalization=head)
+    Ws, bs, hp = mlp_formula_params(n, hidden, head)
+    for m, W, b in zip([m for m in f if isinstance(m, torch.nn.Linear)], Ws, bs):
+        m.weight.data = torch.tensor(W); m.bias.data = torch.tensor(b)
+    return f
+
+
+def test_trainstep_goldens(golden):
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    G = golden("g7_trainstep.npz")
+    for key, c in G.cases():
+        p = int(c["meta"]["p"]); head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]; n = 4
+        f = build(n, hidden, head)
+        gW = dev(np.stack([c["in"][f"g{i}"] for i in range(3)]))
+        tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=64, p=p, lr=float(c["meta"]["lr"]), device="cuda")
+        for s in range(5):
+            out = tr.step_injected(dev(c["in"][f"z1_{s}"]), dev(c["in"][f"z2_{s}"])).cpu().numpy()
+            assert abs(out[0] - c["out"]["loss"][s]) < 1e-5 * abs(c["out"]["loss"][s]), (key, s, out[0], c["out"]["loss"][s])
+            assert abs(out[1] - c["out"]["pos"][s]) < 1e-5 * max(1.0, abs(c["out"]["pos"][s]))
+            assert abs(out[2] - c["out"]["neg"][s]) < 1e-5 * max(1.0, abs(c["out"]["neg"][s]))
+        assert tr.steps_done == 5
+        L = len(tr.linears)
+        for name, prm in f.named_parameters():
+            ref = c["out"][f"param5/{name}"]
+            got = prm.detach().cpu().numpy()
+            got = got if ref.size == got.size else np.ascontiguousarray(got.reshape(-1)[::7])
+            diff = np.abs(got.reshape(-1) - ref.reshape(-1))
+            if name == f"{2 * (L - 1)}.bias" and head is None:
+                assert diff.max() <= 5 * float(c["meta"]["lr"]) * 1.01   # translation-invariant: gradient is noise
+                continue
+            assert np.median(diff) < 2e-6, (key, name)
+            assert (diff > 2e-4).mean() < 0.02, (key, name, float((diff > 2e-4).mean()))
+
+
+def test_engine_matches_autograd_path():
+    """Same batch through (a) the drop-in modules + torch autograd and (b) the fused engine."""
+    from cl_ica_amd import encoders, losses, ops
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(1)
+    n, B = 10, 1024
+    for head in (None, "learnable_box"):
+        f = encoders.get_mlp(n, n, [100, 500, 500, 100], output_normalization=head).to("cuda")
+        gW = torch.randn(3, n, n, device="cuda") / n ** 0.5
+        z1 = torch.rand(B, n, device="cuda"); z2 = (z1 + 0.05 * torch.randn_like(z1)).clamp(0, 1)
+        a, b = f(ops.mixing_fwd(z1, gW)), f(ops.mixing_fwd(z2, gW))
+        tot, _, _ = losses.LpSimCLRLoss(p=2, simclr_compatibility_mode=True)(None, None, None, a, b, torch.roll(a, 1, 0))
+        tot.backward()
+        ref_grads = {k: p.grad.clone() for k, p in f.named_parameters()}
+        tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
+        out = tr.step_injected(z1, z2)
+        assert abs(out[0].item() - tot.item()) < 2e-6 * abs(tot.item())
+        for k, p in f.named_parameters():
+            g = tr._gviews[id(p)]
+            scale = max(ref_grads[k].abs().max().item(), 1e-12)
+            assert (g - ref_grads[k]).abs().max().item() / scale < 2e-4, (head, k)
+
+
+def test_graph_replay_trains():
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(0)
+    n, B = 10, 2048
+    f = encoders.get_mlp(n, n, [100, 500, 500, 100])
+    gW = torch.randn(3, n, n) / n ** 0.5
+    tr = ContrastiveTrainer(f, gW, SamplerSpec(space="box", n=n, seed=3), batch_size=B, p=2, lr=1e-3, device="cuda")
+    first = tr.step().clone()
+    assert abs(first[0].item() - np.log(B + 1)) < 0.05        # fresh f maps everything near 0
+    tr.capture(warmup=2)
+    z_before = tr.z.clone()
+    for _ in range(60):
+        out = tr.step()
+    torch.cuda.synchronize()
+    assert tr.steps_done == 1 + 2 + 1 + 60
+    assert not torch.equal(z_before, tr.z)                     # RNG advanced across replays
+    assert torch.isfinite(out).all() and out[0].item() < first[0].item() - 0.05
+    assert float(tr.z.min()) >= 0.0 and float(tr.z.max()) <= 1.0

@@ -107,7 +107,7 @@ def test_adam_matches_oracle_and_torch():
     opt = torch.optim.Adam([tp], lr=1e-3)
     po, mo, vo = p0.astype(np.float64), np.zeros(N), np.zeros(N)
     for s in range(1, 6):
-        g = rng.normal(size=N).astype(np.float32) * (10.0 ** rng.integers(-3, 2))
+        g = (rng.normal(size=N) * (10.0 ** rng.integers(-3, 2))).astype(np.float32)
         ops.adam_step(p, dev(g), m, v, step, lr=1e-3)
         ops.tick(step)
         tp.grad = torch.tensor(g); opt.step()

@@ -187,3 +187,23 @@ def test_trainstep_goldens(golden):
 def test_formula_in_sync(golden):
     c = golden("g6_mlp.npz").case("c000")
     assert np.array_equal(c["in"]["x"], np.asarray(formula_weights((48, 4), 99) * np.sqrt(4) * 1.5, np.float32))
+
+
+def test_torch_port_goldens(golden):
+    """The cpu_baseline port (oracle/torch_port.py) reproduces the reference's outputs."""
+    import torch
+    from oracle import torch_port as T
+    G = golden("g1_lp_loss.npz")
+    n = 0
+    for key, c in G.cases():
+        m = c["meta"]
+        if c["in"]["z1"].shape[0] > 64:
+            continue
+        a, b, cc = (torch.tensor(c["in"][k], requires_grad=True) for k in ("z1", "z2", "z3"))
+        mean, per, (pm, nm) = T.lp_simclr_loss(a, b, cc, p=int(m["p"]), tau=float(m["tau"]), alpha=float(m["alpha"]),
+                                               compat=bool(m["compat"]), pow=bool(m["pow"]))
+        mean.backward()
+        assert np.array_equal(per.detach().numpy(), c["out"]["loss_i"]) or rel_err(per.detach().numpy(), c["out"]["loss_i"]) < 1e-6
+        assert rel_err(a.grad.numpy(), c["out"]["dz1"]) < 1e-5
+        n += 1
+    assert n > 50
