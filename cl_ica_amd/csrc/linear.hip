@@ -17,16 +17,21 @@
 // LDS double buffer; one barrier per K tile.  wgrad splits the long contraction (Kc = rows of the
 // batch) over blockIdx.z into fp32 slabs that a second tiny kernel sums deterministically.
 #include "common.h"
+#include <stdlib.h>
 
 namespace clica {
 namespace gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int THREADS = 256;
 constexpr int BK = 32;
+constexpr int RED_THREADS = 256;
 
 enum Epi { EPI_BIAS_ACT = 0, EPI_DACT = 1, EPI_SLAB = 2 };
+
+// out-of-range tile pieces load from here: the zero comes straight from memory, so nothing has to
+// touch the loaded registers before the LDS store and the loads stay in flight across the MFMAs
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
 struct Args {
   const float* A; int64_t lda;
@@ -43,7 +48,7 @@ struct Args {
 // ---- tile loaders: global -> registers ------------------------------------------------------
 // CONTIG: operand stored [rows][Kc]; tile = ROWS x BK, float4 along k.
 // !CONTIG: operand stored [Kc][rows]; tile = BK x ROWS, float4 along rows.
-template <int ROWS, bool CONTIG>
+template <int ROWS, bool CONTIG, int THREADS>
 struct Tile {
   static constexpr int UNITS = ROWS * BK / 4;          // float4 units per tile
   static constexpr int PER_THREAD = UNITS / THREADS;
@@ -51,39 +56,35 @@ struct Tile {
   static constexpr int LDS_LD = CONTIG ? (BK + 4) : ROWS;   // +4 floats: conflict-free ds_read_b128
   static constexpr int LDS_FLOATS = CONTIG ? ROWS * (BK + 4) : BK * ROWS;
 
+  // Branch-free: out-of-range pieces read the zero page, so all loads of a tile issue back-to-back
+  // and nothing depends on them until the LDS store after the MFMAs.  VEC needs 16-byte aligned rows and a
+  // contraction/row extent that is a multiple of 4 (every float4 is then fully in or fully out).
   template <bool VEC>
   static __device__ __forceinline__ void load(float4 (&r)[PER_THREAD], const float* __restrict__ src, int64_t ld,
                                               int64_t row0, int64_t nrows, int64_t k0, int64_t kend) {
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
       const int u = threadIdx.x + i * THREADS;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      int64_t off, lim_a, lim_b;   // element offset of .x ; remaining valid elements along the float4
+      bool ok;
       if (CONTIG) {
         const int row = u / (BK / 4), kq = u % (BK / 4);
         const int64_t gr = row0 + row, gk = k0 + 4 * kq;
-        if (gr < nrows) {
-          const float* p = src + gr * ld + gk;
-          if (VEC && gk + 3 < kend) v = *reinterpret_cast<const float4*>(p);
-          else {
-            if (gk < kend) v.x = p[0];
-            if (gk + 1 < kend) v.y = p[1];
-            if (gk + 2 < kend) v.z = p[2];
-            if (gk + 3 < kend) v.w = p[3];
-          }
-        }
+        ok = gr < nrows; off = gr * ld + gk; lim_a = kend - gk;
       } else {
         const int k = u / (ROWS / 4), rq = u % (ROWS / 4);
         const int64_t gk = k0 + k, gr = row0 + 4 * rq;
-        if (gk < kend) {
-          const float* p = src + gk * ld + gr;
-          if (VEC && gr + 3 < nrows) v = *reinterpret_cast<const float4*>(p);
-          else {
-            if (gr < nrows) v.x = p[0];
-            if (gr + 1 < nrows) v.y = p[1];
-            if (gr + 2 < nrows) v.z = p[2];
-            if (gr + 3 < nrows) v.w = p[3];
-          }
-        }
+        ok = gk < kend; off = gk * ld + gr; lim_a = nrows - gr;
+      }
+      (void)lim_b;
+      float4 v;
+      if (VEC) {
+        const bool in = ok && lim_a > 0;
+        v = *reinterpret_cast<const float4*>(in ? src + off : g_zero_page);
+      } else {
+        const bool i0 = ok && lim_a > 0, i1 = ok && lim_a > 1, i2 = ok && lim_a > 2, i3 = ok && lim_a > 3;
+        v = make_float4(*(i0 ? src + off : g_zero_page), *(i1 ? src + off + 1 : g_zero_page),
+                        *(i2 ? src + off + 2 : g_zero_page), *(i3 ? src + off + 3 : g_zero_page));
       }
       r[i] = v;
     }
@@ -116,10 +117,10 @@ struct Tile {
 };
 
 template <int BM, int BN, int WM, int WN, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC>
-__global__ __launch_bounds__(THREADS) void gemm_k(Args g) {
-  using TA = Tile<BM, A_CONTIG>;
-  using TB = Tile<BN, B_CONTIG>;
-  static_assert(WM * WN == THREADS / 64, "4 waves");
+__global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
+  constexpr int THREADS = 64 * WM * WN;
+  using TA = Tile<BM, A_CONTIG, THREADS>;
+  using TB = Tile<BN, B_CONTIG, THREADS>;
   constexpr int TM = BM / WM, TN = BN / WN;        // wave tile
   constexpr int NBM = TM / 32, NBN = TN / 32;      // 32x32 accumulator blocks per wave
   static_assert(TM % 32 == 0 && TN % 32 == 0, "wave tile must be a multiple of 32");
@@ -130,7 +131,17 @@ __global__ __launch_bounds__(THREADS) void gemm_k(Args g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l31 = lane & 31;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  // XCD-aware tile order: the dispatcher places linear block b on XCD b % 8 (speed only, never
+  // correctness).  Re-number so that each XCD walks a CONTIGUOUS range of tiles, N fastest: the
+  // workgroups that share an A row-panel then hit the same XCD-private L2.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int b = by * gx + bx, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    by = id / gx; bx = id - by * gx;
+  }
+  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
   int64_t kbeg = 0, kend = g.Kc;
   if (EPI == EPI_SLAB) {
     kbeg = (int64_t)blockIdx.z * g.k_per_split;
@@ -147,6 +158,10 @@ __global__ __launch_bounds__(THREADS) void gemm_k(Args g) {
 
   float colsum = 0.f;  // wgrad: db partial for A_op row (threadIdx.x < BM), only blockIdx.x == 0
 
+  // Pipeline (2 LDS stages + 1 register stage): at the top of iteration t the registers hold tile
+  // t+1 (loaded during iteration t-1) -> store them into the stage that was last read in iteration
+  // t-1, then issue the global loads of tile t+2, then run the MFMAs of tile t.  Global latency has a
+  // whole iteration to hide in; the barrier at the end only waits for the MFMAs.
   float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
   if (ntiles > 0) {
@@ -154,15 +169,14 @@ __global__ __launch_bounds__(THREADS) void gemm_k(Args g) {
     TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend);
     TA::store(ra, smem);
     TB::store(rb, smem + TA::LDS_FLOATS);
+    if (ntiles > 1) {
+      TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg + BK, kend);
+      TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg + BK, kend);
+    }
   }
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
-    if (t + 1 < ntiles) {
-      const int64_t k0 = kbeg + (int64_t)(t + 1) * BK;
-      TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend);
-      TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend);
-    }
     const float* a_s = smem + cur * STAGE;
     const float* b_s = a_s + TA::LDS_FLOATS;
 #pragma unroll
@@ -179,14 +193,25 @@ __global__ __launch_bounds__(THREADS) void gemm_k(Args g) {
 #pragma unroll
           for (int j = 0; j < NBN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+      if (s == 0) {
+        // staging of the NEXT tiles rides in the shadow of the first k-step's MFMAs (which are
+        // already queued on the matrix pipe) instead of in front of the tile
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) {
+          TA::store(ra, smem + (cur ^ 1) * STAGE);
+          TB::store(rb, smem + (cur ^ 1) * STAGE + TA::LDS_FLOATS);
+        }
+        if (t + 2 < ntiles) {
+          const int64_t k0 = kbeg + (int64_t)(t + 2) * BK;
+          TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend);
+          TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (EPI == EPI_SLAB && g.dbias_slab && blockIdx.x == 0 && !A_CONTIG && threadIdx.x < BM) {
+    if (EPI == EPI_SLAB && g.dbias_slab && bx == 0 && !A_CONTIG && threadIdx.x < BM) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) colsum += a_s[k * TA::LDS_LD + threadIdx.x];
-    }
-    if (t + 1 < ntiles) {
-      TA::store(ra, smem + (cur ^ 1) * STAGE);
-      TB::store(rb, smem + (cur ^ 1) * STAGE + TA::LDS_FLOATS);
     }
     __syncthreads();
   }
@@ -217,20 +242,36 @@ __global__ __launch_bounds__(THREADS) void gemm_k(Args g) {
       }
     }
   }
-  if (EPI == EPI_SLAB && g.dbias_slab && blockIdx.x == 0 && !A_CONTIG && threadIdx.x < BM) {
+  if (EPI == EPI_SLAB && g.dbias_slab && bx == 0 && !A_CONTIG && threadIdx.x < BM) {
     const int64_t row = m0 + threadIdx.x;
     if (row < g.M) g.dbias_slab[(int64_t)blockIdx.z * g.M + row] = colsum;
   }
 }
 
-// dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i]
-__global__ __launch_bounds__(THREADS) void slab_reduce_k(const float* __restrict__ slab, int splits, int64_t M, int64_t N,
-                                                        float* __restrict__ dW, int64_t lddw,
-                                                        const float* __restrict__ dbslab, float* __restrict__ db,
-                                                        int accumulate) {
-  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+// dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i].   float4 per thread when the
+// slab row length allows it (N % 4 == 0 and aligned destination), fixed summation order.
+template <bool VEC4>
+__global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __restrict__ slab, int splits, int64_t M, int64_t N,
+                                                            float* __restrict__ dW, int64_t lddw,
+                                                            const float* __restrict__ dbslab, float* __restrict__ db,
+                                                            int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x;
   const int64_t total = M * N;
-  if (idx < total) {
+  if (VEC4) {
+    const int64_t e = idx * 4;
+    if (e < total) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int s = 0; s < splits; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * total + e);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      const int64_t i = e / N, j = e - i * N;
+      float4* dst = reinterpret_cast<float4*>(dW + i * lddw + j);
+      if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *dst = t;
+    }
+  } else if (idx < total) {
     float t = 0.f;
     for (int s = 0; s < splits; ++s) t += slab[(int64_t)s * total + idx];
     const int64_t i = idx / N, j = idx - i * N;
@@ -244,18 +285,47 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_k(const float* __restrict
   }
 }
 
-template <int BM, int BN, bool A_CONTIG, bool B_CONTIG>
-constexpr size_t lds_bytes() {
-  return 2 * (Tile<BM, A_CONTIG>::LDS_FLOATS + Tile<BN, B_CONTIG>::LDS_FLOATS) * sizeof(float);
-}
-
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- tile configurations ------------------------------------------------------------------------
+// id: BM x BN, waves WM x WN (64*WM*WN threads).  The 8-wave shapes keep two waves per SIMD on a
+// CU that holds ONE workgroup, so LDS/global latency of one wave hides behind the MFMAs of the other.
+struct Cfg { int bm, bn, wm, wn; };
+constexpr Cfg kCfgs[] = {
+    {192, 128, 2, 4},   // 0: 256 workgroups for M = 12288, N = 500 (one per CU, exactly one round)
+    {128, 128, 2, 4},   // 1: wgrad / general
+    {64, 128, 2, 2},    // 2: narrow outputs (N ~ 100): more workgroups along M
+    {128, 128, 2, 2},   // 3: 4-wave fallback
+    {192, 64, 2, 2},    // 4: 512 workgroups for M = 12288, N = 500: two independent 4-wave groups per CU
+    {96, 128, 1, 4},    // 5: same count, other aspect
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+// MFMA-bound cost model: co-resident workgroups share the CU's four matrix pipes, so the time is
+// rounds * (work of one tile); prefer exact fits, then larger tiles (operand reuse).
+static int pick_cfg(int64_t M, int64_t N, int64_t Kc, int splits_hint, const int* allowed, int n_allowed) {
+  int best = allowed[0];
+  double best_cost = 1e300;
+  for (int a = 0; a < n_allowed; ++a) {
+    const Cfg c = kCfgs[allowed[a]];
+    const int64_t tiles = ceil_div(M, c.bm) * ceil_div(N, c.bn) * splits_hint;
+    const int64_t rounds = ceil_div(tiles, kNumCU);
+    double cost = (double)rounds * c.bm * c.bn;
+    cost *= 1.0 + 0.02 * (256.0 * 128.0 / (c.bm * c.bn));   // mild preference for larger tiles
+    if (cost < best_cost) { best_cost = cost; best = allowed[a]; }
+  }
+  (void)Kc;
+  return best;
+}
+
 template <int BM, int BN, int WM, int WN, bool A_CONTIG, bool B_CONTIG, int EPI>
-static int launch(const Args& g, int splits, hipStream_t st, const char* who) {
-  const bool vec = aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);
+static int launch_cfg(const Args& g, int splits, hipStream_t st, const char* who) {
+  constexpr int THREADS = 64 * WM * WN;
+  // float4 loads need aligned rows and extents that keep every float4 fully in or out of range
+  const bool vec = aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
+                   (A_CONTIG ? (g.Kc % 4 == 0) : (g.M % 4 == 0)) && (B_CONTIG ? (g.Kc % 4 == 0) : (g.N % 4 == 0));
   dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits), block(THREADS);
-  constexpr size_t lds = lds_bytes<BM, BN, A_CONTIG, B_CONTIG>();
+  constexpr size_t lds = 2 * (Tile<BM, A_CONTIG, THREADS>::LDS_FLOATS + Tile<BN, B_CONTIG, THREADS>::LDS_FLOATS) * sizeof(float);
   if (vec) {
     auto k = gemm_k<BM, BN, WM, WN, A_CONTIG, B_CONTIG, EPI, true>;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
@@ -270,14 +340,41 @@ static int launch(const Args& g, int splits, hipStream_t st, const char* who) {
   return launch_status(who);
 }
 
-// contraction split for wgrad: enough workgroups for ~2 per CU, each with >= 4 K tiles
-static int wgrad_splits(int64_t M, int64_t N, int64_t Kc, int bm, int bn) {
-  const int64_t tiles = ceil_div(M, bm) * ceil_div(N, bn);
-  int64_t want = ceil_div((int64_t)kNumCU * 2, tiles);
+template <bool A_CONTIG, bool B_CONTIG, int EPI>
+static int launch(int cfg, const Args& g, int splits, hipStream_t st, const char* who) {
+  switch (cfg) {
+    case 0: return launch_cfg<192, 128, 2, 4, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 1: return launch_cfg<128, 128, 2, 4, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 2: return launch_cfg<64, 128, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 4: return launch_cfg<192, 64, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 5: return launch_cfg<96, 128, 1, 4, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    default: return launch_cfg<128, 128, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+  }
+}
+
+static int env_cfg(const char* name) {   // tuning hook: CLICA_GEMM_CFG_{FWD,DGRAD,WGRAD}=id
+  const char* v = getenv(name);
+  return v ? atoi(v) : -1;
+}
+
+// wgrad plan: output tiles x contraction splits ~ one round of workgroups, >= 4 K tiles per split
+struct WgradPlan { int cfg, splits; int64_t k_per_split; };
+static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, int64_t Kc) {
+  WgradPlan p;
+  static const int allowed[] = {1, 2};
+  p.cfg = pick_cfg(M, N, Kc, 1, allowed, 2);
+  if (M * N <= 128 * 128) p.cfg = 1;
+  const int e = env_cfg("CLICA_GEMM_CFG_WGRAD");
+  if (e >= 0 && e < kNumCfgs) p.cfg = e;
+  const Cfg c = kCfgs[p.cfg];
+  const int64_t tiles = ceil_div(M, c.bm) * ceil_div(N, c.bn);
+  int64_t want = kNumCU / tiles; if (want < 1) want = 1;
   const int64_t max_s = ceil_div(Kc, (int64_t)BK * 4);
   if (want > max_s) want = max_s;
   if (want < 1) want = 1;
-  return (int)want;
+  p.k_per_split = ceil_div(ceil_div(Kc, want), (int64_t)BK) * BK;
+  p.splits = (int)ceil_div(Kc, p.k_per_split);
+  return p;
 }
 
 }  // namespace gemm
@@ -294,7 +391,11 @@ extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int
   CLICA_CHECK_ARG(ldx >= K && ldw >= K && ldy >= N, "clica_linear_fwd: leading dimension too small");
   Args g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.Kc = K;
   g.bias = bias; g.slope = slope; g.leaky = leaky;
-  return launch<128, 128, 2, 2, true, true, EPI_BIAS_ACT>(g, 1, as_stream(stream), "clica_linear_fwd");
+  static const int allowed[] = {0, 1, 2};
+  int cfg = pick_cfg(M, N, K, 1, allowed, 3);
+  const int e = env_cfg("CLICA_GEMM_CFG_FWD");
+  if (e >= 0 && e < kNumCfgs) cfg = e;
+  return launch<true, true, EPI_BIAS_ACT>(cfg, g, 1, as_stream(stream), "clica_linear_fwd");
 }
 
 extern "C" int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W, int64_t ldw,
@@ -307,13 +408,21 @@ extern "C" int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W,
   // dX[M,K] = dY[M,N] W[N,K]: contraction over N; B_op[kc=n][j=k] = W[n][k] (Kc strided)
   Args g{}; g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = M; g.N = K; g.Kc = N;
   g.xact = Xact; g.ldxa = ldxa; g.slope = slope;
-  return launch<128, 128, 2, 2, true, false, EPI_DACT>(g, 1, as_stream(stream), "clica_linear_dgrad");
+  static const int allowed[] = {0, 1, 2};
+  int cfg = pick_cfg(M, K, N, 1, allowed, 3);
+  const int e = env_cfg("CLICA_GEMM_CFG_DGRAD");
+  if (e >= 0 && e < kNumCfgs) cfg = e;
+  return launch<true, false, EPI_DACT>(cfg, g, 1, as_stream(stream), "clica_linear_dgrad");
 }
 
 extern "C" int clica_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && M > 0 && N > 0 && K > 0, "clica_linear_wgrad_workspace_bytes: bad argument");
-  const int s = wgrad_splits(N, K, M, 128, 128);
-  *bytes = align_up((size_t)s * N * K * sizeof(float), 256) + align_up((size_t)s * N * sizeof(float), 256);
+  // worst case over the configurations the planner (or the tuning hook) may pick
+  const int64_t max_s = ceil_div(M, (int64_t)BK * 4) < kNumCU ? ceil_div(M, (int64_t)BK * 4) : kNumCU;
+  *bytes = align_up((size_t)max_s * N * K * sizeof(float), 256) + align_up((size_t)max_s * N * sizeof(float), 256);
+  const WgradPlan p = plan_wgrad(N, K, M);
+  const size_t exact = align_up((size_t)p.splits * N * K * sizeof(float), 256) + align_up((size_t)p.splits * N * sizeof(float), 256);
+  if (!getenv("CLICA_GEMM_CFG_WGRAD")) *bytes = exact;
   return CLICA_OK;
 }
 
@@ -324,21 +433,28 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   CLICA_CHECK_ARG(dY && X && dW && workspace, "clica_linear_wgrad: NULL pointer");
   CLICA_CHECK_ARG(M > 0 && N > 0 && K > 0, "clica_linear_wgrad: sizes must be positive");
   CLICA_CHECK_ARG(lddy >= N && ldx >= K && lddw >= K, "clica_linear_wgrad: leading dimension too small");
-  size_t need = 0;
-  clica_linear_wgrad_workspace_bytes(M, N, K, &need);
+  const WgradPlan p = plan_wgrad(N, K, M);
+  const size_t slab_bytes = align_up((size_t)p.splits * N * K * sizeof(float), 256);
+  const size_t need = slab_bytes + align_up((size_t)p.splits * N * sizeof(float), 256);
   if (need > workspace_bytes) { set_error("clica_linear_wgrad: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
-  const int s = wgrad_splits(N, K, M, 128, 128);
   float* slab = (float*)workspace;
-  float* dbslab = (float*)((char*)workspace + align_up((size_t)s * N * K * sizeof(float), 256));
+  float* dbslab = (float*)((char*)workspace + slab_bytes);
   // dW[N,K] = dY[M,N]^T X[M,K]: "M" = N, "N" = K, contraction over the batch rows M
   Args g{}; g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = K; g.M = N; g.N = K; g.Kc = M;
-  g.k_per_split = ceil_div(ceil_div(M, (int64_t)s), (int64_t)BK) * BK;
+  g.k_per_split = p.k_per_split;
   g.dbias_slab = db ? dbslab : nullptr;
   hipStream_t st = as_stream(stream);
-  int rc = launch<128, 128, 2, 2, false, false, EPI_SLAB>(g, s, st, "clica_linear_wgrad");
+  int rc = launch<false, false, EPI_SLAB>(p.cfg, g, p.splits, st, "clica_linear_wgrad");
   if (rc) return rc;
   const int64_t total = N * K;
-  hipLaunchKernelGGL(slab_reduce_k, dim3((unsigned)ceil_div(total > N ? total : N, THREADS)), dim3(THREADS), 0, st,
-                     (const float*)slab, s, N, K, dW, lddw, (const float*)dbslab, db, accumulate ? 1 : 0);
+  const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW);
+  const int64_t work = v4 ? total / 4 : total;
+  const unsigned blocks = (unsigned)ceil_div(work > N ? work : N, RED_THREADS);
+  if (v4)
+    hipLaunchKernelGGL(slab_reduce_k<true>, dim3(blocks), dim3(RED_THREADS), 0, st, (const float*)slab, p.splits, N, K, dW, lddw,
+                       (const float*)dbslab, db, accumulate ? 1 : 0);
+  else
+    hipLaunchKernelGGL(slab_reduce_k<false>, dim3(blocks), dim3(RED_THREADS), 0, st, (const float*)slab, p.splits, N, K, dW, lddw,
+                       (const float*)dbslab, db, accumulate ? 1 : 0);
   return launch_status("clica_linear_wgrad(reduce)");
 }

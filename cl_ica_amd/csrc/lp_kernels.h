@@ -40,110 +40,152 @@ struct Params {
   int n;          // true embedding dim (<= NP)
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// raw v_exp_f32 / v_log_f32 (base 2).  exp2f()/log2f() wrap these in denormal-range fix-ups
+// (compare + select + ldexp per call: 6 instructions instead of 1); a softmax term below 2^-126
+// relative to the row maximum is zero for our purposes.
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x); }
+
 // ---- per-coordinate pair term and its owner-derivative ----------------------------------------
 // PK: 1,2,3 = integer Lp fast paths, 0 = generic p > 0 (incl. the p < 1 eps branch),
 //     4 = dot product (SimCLRLoss, losses.py:187): term = o*s, d/do = s
 constexpr int PK_DOT = 4;
+
+// acc += term(o, s) for two adjacent coordinates (k, k+1); packed fp32 math where the ISA has it
+// (v_pk_add_f32 / v_pk_fma_f32: two lanes of work per issue slot)
 template <int PK>
-__device__ __forceinline__ float pair_e(float o, float s, const Params& q) {
-  if constexpr (PK == 0) return q.sgn * (o - s) + q.eps;
-  return o - s;
+__device__ __forceinline__ void accum2(f32x2& acc, f32x2 o, f32x2 s, const Params& q, int k) {
+  if constexpr (PK == PK_DOT) {
+    acc = __builtin_elementwise_fma(o, s, acc);
+  } else if constexpr (PK == 2) {
+    const f32x2 d = o - s;
+    acc = __builtin_elementwise_fma(d, d, acc);
+  } else if constexpr (PK == 1) {
+    const f32x2 d = o - s;
+    acc.x += fabsf(d.x); acc.y += fabsf(d.y);
+  } else if constexpr (PK == 3) {
+    const f32x2 d = o - s, t = d * d;
+    acc.x = fmaf(fabsf(d.x), t.x, acc.x); acc.y = fmaf(fabsf(d.y), t.y, acc.y);
+  } else {   // generic exponent; zero padding is NOT neutral with the eps of the p < 1 branch
+    if (k < q.n) { const float a = fabsf(q.sgn * (o.x - s.x) + q.eps); acc.x += a > 0.f ? fexp2(q.p * flog2(a)) : 0.f; }
+    if (k + 1 < q.n) { const float a = fabsf(q.sgn * (o.y - s.y) + q.eps); acc.y += a > 0.f ? fexp2(q.p * flog2(a)) : 0.f; }
+  }
 }
+// g += coef * (1/p) d term / d owner.  The factor p lives in the pair coefficient (droot_of), the
+// sign of the generic branch too.  Zero at e == 0 (torch.norm's backward masks the zero-norm
+// entries; sign(0) = 0).
 template <int PK>
-__device__ __forceinline__ float term(float o, float s, const Params& q) {
-  if constexpr (PK == PK_DOT) return o * s;
-  const float e = pair_e<PK>(o, s, q);
-  if constexpr (PK == 1) return fabsf(e);
-  if constexpr (PK == 2) return e * e;
-  if constexpr (PK == 3) return fabsf(e) * e * e;
-  const float a = fabsf(e);
-  return a > 0.f ? exp2f(q.p * log2f(a)) : 0.f;
+__device__ __forceinline__ void gaccum2(f32x2& g, float coef, f32x2 o, f32x2 s, const Params& q, int k) {
+  const f32x2 c2 = {coef, coef};
+  if constexpr (PK == PK_DOT) {
+    g = __builtin_elementwise_fma(c2, s, g);
+  } else if constexpr (PK == 2) {
+    g = __builtin_elementwise_fma(c2, o - s, g);
+  } else if constexpr (PK == 1) {
+    const f32x2 d = o - s;
+    g.x += d.x > 0.f ? coef : (d.x < 0.f ? -coef : 0.f);
+    g.y += d.y > 0.f ? coef : (d.y < 0.f ? -coef : 0.f);
+  } else if constexpr (PK == 3) {
+    const f32x2 d = o - s;
+    const f32x2 t = {d.x * fabsf(d.x), d.y * fabsf(d.y)};
+    g = __builtin_elementwise_fma(c2, t, g);
+  } else {
+    if (k < q.n) {
+      const float e = q.sgn * (o.x - s.x) + q.eps, a = fabsf(e);
+      const float v = a > 0.f ? fexp2((q.p - 1.f) * flog2(a)) : 0.f;
+      g.x += coef * (e < 0.f ? -v : v);
+    }
+    if (k + 1 < q.n) {
+      const float e = q.sgn * (o.y - s.y) + q.eps, a = fabsf(e);
+      const float v = a > 0.f ? fexp2((q.p - 1.f) * flog2(a)) : 0.f;
+      g.y += coef * (e < 0.f ? -v : v);
+    }
+  }
 }
-// (1/p) d term / d owner -- the factor p is folded into the pair coefficient (droot_of), the
-// sign of the generic branch into the coefficient as well.  Zero at e == 0 (torch.norm's backward
-// masks the zero-norm entries; sign(0) = 0).
-template <int PK>
-__device__ __forceinline__ float dterm(float o, float s, const Params& q) {
-  if constexpr (PK == PK_DOT) return s;
-  const float e = pair_e<PK>(o, s, q);
-  if constexpr (PK == 1) return (e > 0.f ? 1.f : 0.f) - (e < 0.f ? 1.f : 0.f);
-  if constexpr (PK == 2) return e;
-  if constexpr (PK == 3) return e * fabsf(e);
-  const float a = fabsf(e);
-  const float v = a > 0.f ? exp2f((q.p - 1.f) * log2f(a)) : 0.f;
-  return e < 0.f ? -v : v;
-}
-// neg value from the sum of powers, and d neg / d sum (times p, see dterm)
+// neg value from the sum of powers, and p * d neg / d sum.  ROOT = false is the reference's default
+// pow=True (neg = sum); ROOT = true takes the 1/p-th root (pow=False).
+template <bool ROOT>
 __device__ __forceinline__ float root_of(float s, const Params& q) {
-  if (q.pow) return s;
+  if constexpr (!ROOT) return s;
   if (q.p == 2.f) return sqrtf(s);
   if (q.p == 1.f) return s;
-  return s > 0.f ? exp2f(q.inv_p * log2f(s)) : 0.f;
+  return s > 0.f ? fexp2(q.inv_p * flog2(s)) : 0.f;
 }
-__device__ __forceinline__ float droot_of(float s, const Params& q) {  // p * d root / d s
-  if (q.pow) return q.p;
+template <bool ROOT>
+__device__ __forceinline__ float droot_of(float s, const Params& q) {
+  if constexpr (!ROOT) return q.p;
   if (q.p == 1.f) return 1.f;
-  return s > 0.f ? exp2f((q.inv_p - 1.f) * log2f(s)) : 0.f;
+  return s > 0.f ? fexp2((q.inv_p - 1.f) * flog2(s)) : 0.f;
 }
 
 // ---- staging -----------------------------------------------------------------------------
+// branch-free: masked-out elements read element 0 and are zeroed by a select
 template <int NP>
 __device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ str, int64_t lds,
                                            int64_t j0, int cnt, int n) {
-  for (int idx = threadIdx.x; idx < TS * NP; idx += THREADS) {
-    int row = idx / NP, k = idx - row * NP;
-    float v = 0.f;
-    if (row < cnt && k < n) v = str[(j0 + row) * lds + k];
-    tile[idx] = v;
+#pragma unroll
+  for (int it = 0; it < (TS * NP + THREADS - 1) / THREADS; ++it) {
+    const int idx = threadIdx.x + it * THREADS;
+    if ((TS * NP) % THREADS != 0 && idx >= TS * NP) break;
+    const int row = idx / NP, k = idx - row * NP;
+    const bool ok = row < cnt && k < n;
+    const float v = str[ok ? (j0 + row) * lds + k : 0];
+    tile[idx] = ok ? v : 0.f;
   }
 }
 
 template <int NP, int R>
-__device__ __forceinline__ void load_owners(float (&o)[R][NP], const float* __restrict__ own, int64_t ldo,
+__device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* __restrict__ own, int64_t ldo,
                                             int64_t own0, int64_t n_own, int n) {
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
-    bool ok = i < n_own;
+    const int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
+    const bool ok = i < n_own;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) o[r][k] = (ok && k < n) ? own[i * ldo + k] : 0.f;
+    for (int k2 = 0; k2 < NP / 2; ++k2) {
+      const bool a = ok && 2 * k2 < n, b = ok && 2 * k2 + 1 < n;
+      const float x = own[a ? i * ldo + 2 * k2 : 0], y = own[b ? i * ldo + 2 * k2 + 1 : 0];
+      o[r][k2].x = a ? x : 0.f; o[r][k2].y = b ? y : 0.f;
+    }
   }
 }
 
-// sum_k |e_k|^p for one owner against JB stream rows of the LDS tile
+// sum_k term for one owner against JB stream rows of the LDS tile (wave-uniform ds_read_b128 broadcasts)
 template <int NP, int PK>
-__device__ __forceinline__ void dist_group(const float (&o)[NP], const float* tile, int jj, const Params& q,
+__device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float* tile, int jj, const Params& q,
                                            float (&acc)[JB]) {
+  f32x2 a2[JB];
 #pragma unroll
-  for (int c = 0; c < JB; ++c) acc[c] = 0.f;
+  for (int c = 0; c < JB; ++c) a2[c] = (f32x2){0.f, 0.f};
 #pragma unroll
   for (int k4 = 0; k4 < NP / 4; ++k4) {
 #pragma unroll
     for (int c = 0; c < JB; ++c) {
       const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-      const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (PK == 0 && 4 * k4 + u >= q.n) continue;  // zero padding is not neutral with eps
-        acc[c] += term<PK>(o[4 * k4 + u], s4[u], q);
-      }
+      accum2<PK>(a2[c], o[2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+      accum2<PK>(a2[c], o[2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
     }
   }
+#pragma unroll
+  for (int c = 0; c < JB; ++c) acc[c] = a2[c].x + a2[c].y;
 }
 
 // ---- forward: per-split (max, sum) partials in the log2 domain -----------------------------
-template <int NP, int PK, int R>
+template <int NP, int PK, int R, bool ROOT>
 __global__ __launch_bounds__(THREADS) void fwd_partial_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, float2* __restrict__ part, int chunk) {
   __shared__ __attribute__((aligned(16))) float tile[TS * NP];
   const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
-  float o[R][NP];
+  f32x2 o[R][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
   float m[R], s[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) { m[r] = -INFINITY; s[r] = 0.f; }
+  const float xk = q.xs * q.kscale;
 
   const int64_t jb = (int64_t)blockIdx.y * chunk;
   const int64_t je = min(n_str, jb + (int64_t)chunk);
@@ -158,18 +200,17 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
         float acc[JB];
         dist_group<NP, PK>(o[r], tile, jj, q, acc);
         float x[JB];
-        float bm = -INFINITY;
 #pragma unroll
         for (int c = 0; c < JB; ++c) {
-          x[c] = (jj + c < cnt) ? q.xs * root_of(acc[c], q) * q.kscale : -INFINITY;
-          bm = fmaxf(bm, x[c]);
+          x[c] = root_of<ROOT>(acc[c], q) * xk;
+          if (jj + c >= cnt) x[c] = -INFINITY;     // ragged tail of the stream (wave-uniform)
         }
         // clamp keeps (-inf) - (-inf) out of the exponent when nothing valid was seen yet
-        const float mn = fmaxf(fmaxf(m[r], bm), -1e30f);
+        const float mn = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(m[r], -1e30f));
         float add = 0.f;
 #pragma unroll
-        for (int c = 0; c < JB; ++c) add += exp2f(x[c] - mn);
-        s[r] = s[r] * exp2f(m[r] - mn) + add;
+        for (int c = 0; c < JB; ++c) add += fexp2(x[c] - mn);
+        s[r] = fmaf(s[r], fexp2(m[r] - mn), add);
         m[r] = mn;
       }
     }
@@ -184,7 +225,7 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 // ---- backward ------------------------------------------------------------------------------
 // Owner-gradient partials.  OWNER_STATS: softmax statistics belong to the owner rows (d/dz1);
 // otherwise to the stream rows (d/dz3: column reduction over row-normalised weights).
-template <int NP, int PK, int R, bool OWNER_STATS>
+template <int NP, int PK, int R, bool OWNER_STATS, bool ROOT>
 __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
@@ -193,7 +234,7 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
   __shared__ __attribute__((aligned(16))) float tile[TS * NP];
   __shared__ float tL[TS], tC[TS];
   const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
-  float o[R][NP], g[R][NP];
+  f32x2 o[R][NP / 2], g[R][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
   float oL[R], oC[R];
 #pragma unroll
@@ -202,8 +243,10 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     oL[r] = 0.f; oC[r] = 0.f;
     if (OWNER_STATS && i < n_own) { oL[r] = statL[i]; oC[r] = statC[i]; }
 #pragma unroll
-    for (int k = 0; k < NP; ++k) g[r][k] = 0.f;
+    for (int k2 = 0; k2 < NP / 2; ++k2) g[r][k2] = (f32x2){0.f, 0.f};
   }
+  const float xk = q.xs * q.kscale;
+  const float csgn = (PK == 0) ? q.sgn : 1.f;
   const int64_t jb = (int64_t)blockIdx.y * chunk;
   const int64_t je = min(n_str, jb + (int64_t)chunk);
   for (int64_t j0 = jb; j0 < je; j0 += TS) {
@@ -212,8 +255,9 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     stage_tile<NP>(tile, str, lds, j0, cnt, q.n);
     if (!OWNER_STATS && threadIdx.x < TS) {
       const bool ok = threadIdx.x < cnt;
-      tL[threadIdx.x] = ok ? statL[j0 + threadIdx.x] : 0.f;
-      tC[threadIdx.x] = ok ? statC[j0 + threadIdx.x] : 0.f;
+      const float l = statL[ok ? j0 + threadIdx.x : 0], c = statC[ok ? j0 + threadIdx.x : 0];
+      tL[threadIdx.x] = ok ? l : 0.f;
+      tC[threadIdx.x] = ok ? c : 0.f;     // zero coefficient masks the ragged tail
     }
     __syncthreads();
     for (int jj = 0; jj < cnt; jj += JB) {
@@ -226,22 +270,19 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
         for (int c = 0; c < JB; ++c) {
           const float L = OWNER_STATS ? oL[r] : tL[jj + c];
           const float C = OWNER_STATS ? oC[r] : tC[jj + c];
-          const float w = exp2f(q.xs * root_of(acc[c], q) * q.kscale - L);
-          float cf = C * w * droot_of(acc[c], q);
-          if (PK == 0) cf *= q.sgn;
-          coef[c] = (jj + c < cnt) ? cf : 0.f;
+          const float w = fexp2(fmaf(root_of<ROOT>(acc[c], q), xk, -L));
+          float cf = C * w * droot_of<ROOT>(acc[c], q) * csgn;
+          if (OWNER_STATS && jj + c >= cnt) cf = 0.f;
+          coef[c] = cf;
         }
+        asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
 #pragma unroll
         for (int k4 = 0; k4 < NP / 4; ++k4) {
 #pragma unroll
           for (int c = 0; c < JB; ++c) {
             const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-            const float s4[4] = {sv.x, sv.y, sv.z, sv.w};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              if (PK == 0 && 4 * k4 + u >= q.n) continue;
-              g[r][4 * k4 + u] += coef[c] * dterm<PK>(o[r][4 * k4 + u], s4[u], q);
-            }
+            gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+            gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
           }
         }
       }
@@ -254,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
       float4* dst = reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * n_own + i) * NP);
 #pragma unroll
       for (int k4 = 0; k4 < NP / 4; ++k4)
-        dst[k4] = make_float4(g[r][4 * k4], g[r][4 * k4 + 1], g[r][4 * k4 + 2], g[r][4 * k4 + 3]);
+        dst[k4] = make_float4(g[r][2 * k4].x, g[r][2 * k4].y, g[r][2 * k4 + 1].x, g[r][2 * k4 + 1].y);
     }
   }
 }

@@ -12,11 +12,11 @@ __device__ __forceinline__ float pos_sum(const float* a, const float* b, int n, 
   for (int k = 0; k < n; ++k) {
     float d = a[k] - b[k];
     float t;
-    if (frac) t = exp2f(q.p * log2f(fabsf(d) + 1e-12f));
+    if (frac) t = fexp2(q.p * flog2(fabsf(d) + 1e-12f));
     else if (q.p == 2.f) t = d * d;
     else if (q.p == 1.f) t = fabsf(d);
     else if (q.p == 3.f) t = fabsf(d) * d * d;
-    else t = fabsf(d) > 0.f ? exp2f(q.p * log2f(fabsf(d))) : 0.f;
+    else t = fabsf(d) > 0.f ? fexp2(q.p * flog2(fabsf(d))) : 0.f;
     s += t;
   }
   return s;
@@ -66,19 +66,34 @@ __device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const
   }
 }
 
+constexpr int FIN_ROWS = 64;   // rows per finalize block; the 4 waves split the per-split partials
+
 __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float2* __restrict__ part, int nsplit, int64_t rows,
     const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
     Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
     float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M) {
-  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-  float v_loss = 0.f, v_pos = 0.f, v_lse = 0.f;
+  __shared__ float sm[THREADS / FIN_ROWS][FIN_ROWS], ss[THREADS / FIN_ROWS][FIN_ROWS];
+  const int lane_row = threadIdx.x & (FIN_ROWS - 1), grp = threadIdx.x / FIN_ROWS;
+  const int64_t i = (int64_t)blockIdx.x * FIN_ROWS + lane_row;
+  float m = -1e30f, s = 0.f;
   if (i < rows) {
-    float m = -1e30f, s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
+    for (int sp = grp; sp < nsplit; sp += THREADS / FIN_ROWS) {
       const float2 ps = part[(int64_t)sp * rows + i];
       const float mn = fmaxf(m, ps.x);
-      s = s * exp2f(m - mn) + ps.y * exp2f(ps.x - mn);
+      s = s * fexp2(m - mn) + ps.y * fexp2(ps.x - mn);
+      m = mn;
+    }
+  }
+  sm[grp][lane_row] = m; ss[grp][lane_row] = s;
+  __syncthreads();
+  float v_loss = 0.f, v_pos = 0.f, v_lse = 0.f;
+  if (grp == 0 && i < rows) {
+#pragma unroll
+    for (int w = 1; w < THREADS / FIN_ROWS; ++w) {
+      const float pm = sm[w][lane_row], psum = ss[w][lane_row];
+      const float mn = fmaxf(m, pm);
+      s = s * fexp2(m - mn) + psum * fexp2(pm - mn);
       m = mn;
     }
     float pos, xp;
@@ -89,15 +104,15 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
       pos = -pos;  // loss_pos = -pos/tau (losses.py:192)
     } else {
       const float sp_ = pos_sum(z1 + i * ld1, z2 + i * ld2, q.n, q, frac != 0);
-      pos = root_of(sp_, q);
+      pos = q.pow ? sp_ : root_of<true>(sp_, q);
       xp = -pos * q.kscale;
     }
     if (compat) {  // positive pair joins the softmax denominator (losses.py:459-462)
       const float mn = fmaxf(m, xp);
-      s = s * exp2f(m - mn) + exp2f(xp - mn);
+      s = s * fexp2(m - mn) + fexp2(xp - mn);
       m = mn;
     }
-    const float lse_raw = (m + log2f(s)) * kLn2;
+    const float lse_raw = (m + flog2(s)) * kLn2;
     const float lse = compat ? lse_raw : lse_raw - log_b3;   // _logmeanexp, losses.py:506-510
     const float lp = pos / tau;
     const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
   if (dot) {
     float pos = 0.f;
     for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
-    const float dpos = -A / tau + (C / tau) * exp2f(pos * q.kscale - L * kLog2e);
+    const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L * kLog2e);
     for (int k = 0; k < q.n; ++k) {
       if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
       if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
@@ -140,22 +155,22 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
     return;
   }
   const float sp_ = pos_sum(a, b, q.n, q, frac != 0);
-  const float pos = root_of(sp_, q);
+  const float pos = q.pow ? sp_ : root_of<true>(sp_, q);
   float cpos = A / tau;
-  if (compat) cpos -= (C / tau) * exp2f(-pos * q.kscale - L * kLog2e);
-  cpos *= droot_of(sp_, q);  // includes the factor p
+  if (compat) cpos -= (C / tau) * fexp2(-pos * q.kscale - L * kLog2e);
+  cpos *= q.pow ? q.p : droot_of<true>(sp_, q);  // includes the factor p
   for (int k = 0; k < q.n; ++k) {
     const float d = a[k] - b[k];
     float dt;
     if (frac) {
-      const float v = exp2f((q.p - 1.f) * log2f(fabsf(d) + 1e-12f));
+      const float v = fexp2((q.p - 1.f) * flog2(fabsf(d) + 1e-12f));
       dt = d > 0.f ? v : (d < 0.f ? -v : 0.f);
     } else if (q.p == 2.f) dt = d;
     else if (q.p == 1.f) dt = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
     else if (q.p == 3.f) dt = d * fabsf(d);
     else {
       const float ad = fabsf(d);
-      const float v = ad > 0.f ? exp2f((q.p - 1.f) * log2f(ad)) : 0.f;
+      const float v = ad > 0.f ? fexp2((q.p - 1.f) * flog2(ad)) : 0.f;
       dt = d < 0.f ? -v : v;
     }
     const float g = cpos * dt;
@@ -164,19 +179,29 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
   }
 }
 
-// out[i,k] (+)= sum_split part[split][i][k]
+// out[i,k] (+)= sum_split part[split][i][k]; one thread per float4 of the padded row
 __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
                                                        int np, int n, float* __restrict__ out, int64_t ldo,
                                                        int accumulate) {
   const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-  if (idx >= rows * np) return;
-  const int64_t i = idx / np;
-  const int k = (int)(idx - i * np);
+  const int q4 = np / 4;
+  if (idx >= rows * q4) return;
+  const int64_t i = idx / q4;
+  const int k = (int)(idx - i * q4) * 4;
   if (k >= n) return;
-  float t = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) t += part[((int64_t)sp * rows + i) * np + k];
+  const int64_t stride = rows * (int64_t)np;
+  const float* src = part + i * np + k;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sp * stride);
+    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  }
   float* dst = out + i * ldo + k;
-  *dst = accumulate ? (*dst + t) : t;
+  const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (k + u < n) dst[u] = accumulate ? (dst[u] + tv[u]) : tv[u];
 }
 
 static Params make_params(const clica_lp_loss_desc* d, bool frac) {
@@ -218,7 +243,7 @@ struct BwdWs { float* statL; float* statC; float* partR; float* partC; size_t by
 static FwdWs carve_fwd(void* ws, const Plan& P, int64_t rows) {
   FwdWs w; char* p = (char*)ws; size_t off = 0;
   w.ticket = (unsigned int*)(p + off); off += 256;   // must be zero before first use (see .h)
-  w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, THREADS) * 3 * sizeof(float), 256);
+  w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
   w.part = (float2*)(p + off); off += align_up((size_t)P.nsplit * rows * sizeof(float2), 256);
   w.bytes = off; return w;
 }
@@ -282,7 +307,7 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   hipStream_t st = as_stream(stream);
   launch_fwd_partial(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part, st);
   Means M{w.blocksums, w.ticket, means};
-  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st,
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(rows, FIN_ROWS)), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M);
   return launch_status("clica_lp_loss_fwd");
@@ -321,14 +346,14 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
   if (d_rows) {
     launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
     const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc);
   }
   if (d_cols) {
     Params qc = q; qc.sgn = -q.sgn;   // e = -(owner - stream) + eps seen from the column side
     launch_bwd_pairs(false, PC, pk, cols_p, ldc, cols, rows_p, ldr, rows, qc, w.statL, w.statC, w.partC, st);
     const int acc = frac ? 1 : (accumulate_dz3 ? 1 : 0);
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np / 4, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc);
   }
   return launch_status("clica_lp_loss_bwd");
@@ -434,7 +459,7 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
   }
   launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, st);
   Means M{w.blocksums, w.ticket, means};
-  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(d->B, THREADS)), dim3(THREADS), 0, st,
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(d->B, FIN_ROWS)), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      1, 0, 1, 0.f, loss_i, pos_i, lse_i, M);
   return launch_status("clica_dot_loss_fwd");
@@ -471,12 +496,12 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
                      g_mean, g_item, g_pos, g_neg, w.statL, w.statC, o1, lo1, o2, lo2);
   if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1);
   }
   if (o3) {
     launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np / 4, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3);
   }
   if (d->normalize) {

@@ -29,8 +29,12 @@ void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64
   constexpr int PK = CLICA_PK;
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
-    hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP)>), grid, block, 0, st, own, ldo, n_own, str, lds,
-                       n_str, q, part, P.chunk);
+    if (q.pow)
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, P.chunk);
+    else
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, P.chunk);
   })
 }
 
@@ -41,11 +45,17 @@ void CAT(launch_bwd_pairs_pk, CLICA_PK)(const Plan& P, bool owner_stats, const f
   constexpr int PK = CLICA_PK;
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
-    if (owner_stats)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), true>), grid, block, 0, st, own, ldo, n_own, str,
+    if (owner_stats && q.pow)
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), true, false>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, part, P.chunk);
+    else if (owner_stats)
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), true, true>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, part, P.chunk);
+    else if (q.pow)
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), false, false>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, statL, statC, part, P.chunk);
     else
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), false>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), false, true>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, statL, statC, part, P.chunk);
   })
 }

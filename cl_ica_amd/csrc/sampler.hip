@@ -85,6 +85,28 @@ __device__ __forceinline__ float noise(Philox& g, const Desc& d) {
   }
 }
 
+// one thread per ELEMENT for the coordinate-wise kinds (box, R^n): B*n threads instead of B
+__global__ __launch_bounds__(THREADS) void sample_elem_k(Desc d, const float* __restrict__ mean, int64_t ldm,
+                                                        float* __restrict__ out, int64_t ldo, int64_t M,
+                                                        const int32_t* __restrict__ step_dev) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= M * d.n) return;
+  const int64_t i = idx / d.n;
+  const int k = (int)(idx - i * d.n);
+  const uint32_t step = step_dev ? (uint32_t)step_dev[0] : 0u;
+  Philox g(d.seed, (uint32_t)idx, step, d.stream_id);
+  float v;
+  if (d.dist == CLICA_DIST_UNIFORM) {                        // spaces.py:273-277
+    v = g.uniform() * (d.box_max - d.box_min) + d.box_min;
+  } else {
+    const float m = mean[i * ldm + k];
+    v = m + noise(g, d);
+    if (d.space == CLICA_SPACE_BOX)                          // spaces.py:279-351: truncate per element
+      for (int it = 0; it < 4096 && !(v >= d.box_min && v <= d.box_max); ++it) v = m + noise(g, d);
+  }
+  out[i * ldo + k] = v;
+}
+
 // one thread per sample row
 __global__ __launch_bounds__(THREADS) void sample_k(Desc d, const float* __restrict__ mean, int64_t ldm,
                                                    float* __restrict__ out, int64_t ldo, int64_t M,
@@ -171,7 +193,12 @@ extern "C" int clica_sample(const clica_sampler_desc* d, const float* mean, int6
   if (d->dist == CLICA_DIST_GENNORM) CLICA_CHECK_ARG(d->shape_p > 0.f, "clica_sample: generalized normal needs shape_p > 0");
   if (d->space == CLICA_SPACE_BOX) CLICA_CHECK_ARG(d->box_max > d->box_min, "clica_sample: empty box");
   rng::Desc q{d->space, d->dist, d->n, d->box_min, d->box_max, d->scale, d->shape_p, d->seed, d->stream_id};
-  hipLaunchKernelGGL(rng::sample_k, dim3((unsigned)ceil_div(M, rng::THREADS)), dim3(rng::THREADS), 0, as_stream(stream),
-                     q, mean, ldm, out, ldo, M, step_dev);
+  const bool rowwise = d->space == CLICA_SPACE_SPHERE || d->dist == CLICA_DIST_VMF;   // need the row norm
+  if (rowwise)
+    hipLaunchKernelGGL(rng::sample_k, dim3((unsigned)ceil_div(M, rng::THREADS)), dim3(rng::THREADS), 0, as_stream(stream),
+                       q, mean, ldm, out, ldo, M, step_dev);
+  else
+    hipLaunchKernelGGL(rng::sample_elem_k, dim3((unsigned)ceil_div(M * d->n, rng::THREADS)), dim3(rng::THREADS), 0,
+                       as_stream(stream), q, mean, ldm, out, ldo, M, step_dev);
   return launch_status("clica_sample");
 }

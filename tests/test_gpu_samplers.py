@@ -86,7 +86,8 @@ def test_real(golden):
     assert np.abs(rn.var(0) - 4.0).max() < 0.08 and np.abs(rn.mean(0)).max() < 0.03
     rl = real.laplace(zero, 0.7, N, device="cuda").cpu().numpy()
     assert np.abs(rl.var(0) - z9["real_laplace/var"]).max() < 0.05
-    assert np.abs(q(rl, qs) - z9["real_laplace/q"]).max() < 0.08
+    assert np.abs(q(rl, qs)[1:-1] - z9["real_laplace/q"][1:-1]).max() < 0.04    # 1%/99% tails are sampling-noise dominated
+    assert np.abs(q(rl, qs) - z9["real_laplace/q"]).max() < 0.2
     rg = real.generalized_normal(zero, 0.7, p=3, size=N, device="cuda").cpu().numpy()
     assert np.abs(rg.var(0) - z9["real_gennorm3/var"]).max() < 0.01
     assert np.abs(q(rg, qs) - z9["real_gennorm3/q"]).max() < 0.02
