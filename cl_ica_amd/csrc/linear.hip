@@ -43,6 +43,7 @@ struct Args {
   float slope; int leaky;
   int64_t k_per_split;    // wgrad: contraction rows per blockIdx.z
   float* dbias_slab;      // wgrad: [splits][M] column sums of A_op rows (db), or nullptr
+  int ablate;             // tuning probe (CLICA_GEMM_ABLATE): 1 no global loads, 2 no LDS stores, 4 no fragment reads, 8 no barrier
 };
 
 // ---- tile loaders: global -> registers ------------------------------------------------------
@@ -116,7 +117,7 @@ struct Tile {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC>
+template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
   constexpr int THREADS = 64 * WM * WN;
   using TA = Tile<BM, A_CONTIG, THREADS>;
@@ -158,10 +159,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
 
   float colsum = 0.f;  // wgrad: db partial for A_op row (threadIdx.x < BM), only blockIdx.x == 0
 
-  // Pipeline (2 LDS stages + 1 register stage): at the top of iteration t the registers hold tile
-  // t+1 (loaded during iteration t-1) -> store them into the stage that was last read in iteration
-  // t-1, then issue the global loads of tile t+2, then run the MFMAs of tile t.  Global latency has a
-  // whole iteration to hide in; the barrier at the end only waits for the MFMAs.
+  // Pipeline: STAGES LDS stages + one register stage for the global loads + double-buffered MFMA
+  // fragments.
+  //   * registers hold tile t+1 at the top of iteration t; they are stored to LDS stage (t+1)%STAGES
+  //     in the shadow of the first k-step's MFMAs, then the global loads of tile t+2 are issued --
+  //     global latency has a whole iteration to hide in.
+  //   * fragments of k-step s+1 are read from LDS while the MFMAs of k-step s run.
+  //   * STAGES == 3: the only barrier of the iteration sits right after the stores; the stage being
+  //     overwritten was last read two iterations ago, so the k-loop runs THROUGH tile boundaries
+  //     (the first fragments of tile t+1 are prefetched during the last k-step of tile t).
+  //   * STAGES == 2 (small-LDS shapes, two workgroups per CU): classic barrier at the end of the tile.
+  static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
+  constexpr int KSTEPS = BK / 8;
   float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
   if (ntiles > 0) {
@@ -175,37 +184,48 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
     }
   }
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    const float* a_s = smem + cur * STAGE;
+
+  float af[2][NBM][4], bf[2][NBN][4];
+  auto load_frags = [&](int buf, const float* a_s, int s) {
     const float* b_s = a_s + TA::LDS_FLOATS;
 #pragma unroll
-    for (int s = 0; s < BK / 8; ++s) {
-      float af[NBM][4], bf[NBN][4];
+    for (int i = 0; i < NBM; ++i) TA::frag(af[buf][i], a_s, wm * TM + i * 32 + l31, s, h);
 #pragma unroll
-      for (int i = 0; i < NBM; ++i) TA::frag(af[i], a_s, wm * TM + i * 32 + l31, s, h);
+    for (int j = 0; j < NBN; ++j) TB::frag(bf[buf][j], b_s, wn * TN + j * 32 + l31, s, h);
+  };
+  if (ntiles > 0) load_frags(0, smem, 0);
+
+  int cur = 0;   // LDS stage of tile t
+  for (int t = 0; t < ntiles; ++t) {
+    const int nxt = (cur + 1 == STAGES) ? 0 : cur + 1;
+    const float* a_s = smem + cur * STAGE;
 #pragma unroll
-      for (int j = 0; j < NBN; ++j) TB::frag(bf[j], b_s, wn * TN + j * 32 + l31, s, h);
+    for (int s = 0; s < KSTEPS; ++s) {
+      // fragments for the NEXT k-step are in flight while this k-step's MFMAs run
+      if (!(g.ablate & 4)) {
+        if (s + 1 < KSTEPS) load_frags((s + 1) & 1, a_s, s + 1);
+        else if (STAGES == 3 && t + 1 < ntiles) load_frags(0, smem + nxt * STAGE, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
         for (int i = 0; i < NBM; ++i)
 #pragma unroll
           for (int j = 0; j < NBN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][tt], bf[j][tt], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][tt], bf[s & 1][j][tt], acc[i][j], 0, 0, 0);
       if (s == 0) {
-        // staging of the NEXT tiles rides in the shadow of the first k-step's MFMAs (which are
-        // already queued on the matrix pipe) instead of in front of the tile
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles) {
-          TA::store(ra, smem + (cur ^ 1) * STAGE);
-          TB::store(rb, smem + (cur ^ 1) * STAGE + TA::LDS_FLOATS);
+        if (t + 1 < ntiles && !(g.ablate & 2)) {
+          TA::store(ra, smem + nxt * STAGE);
+          TB::store(rb, smem + nxt * STAGE + TA::LDS_FLOATS);
         }
-        if (t + 2 < ntiles) {
+        if (t + 2 < ntiles && !(g.ablate & 1)) {
           const int64_t k0 = kbeg + (int64_t)(t + 2) * BK;
           TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend);
           TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend);
         }
+        if (STAGES == 3 && !(g.ablate & 8)) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -213,7 +233,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) colsum += a_s[k * TA::LDS_LD + threadIdx.x];
     }
-    __syncthreads();
+    if (STAGES == 2) {
+      if (!(g.ablate & 8)) __syncthreads();
+      if (t + 1 < ntiles && !(g.ablate & 4)) load_frags(0, smem + nxt * STAGE, 0);
+    }
+    cur = nxt;
   }
 
   // ---- epilogue: C/D layout of 32x32 blocks: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -248,40 +272,52 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
   }
 }
 
-// dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i].   float4 per thread when the
-// slab row length allows it (N % 4 == 0 and aligned destination), fixed summation order.
+// dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i].
+// A block owns 64 consecutive output units (float4 when the row length allows, else float); its
+// four waves each sum a quarter of the splits (s = w, w+4, ...), then wave 0 adds the four partial
+// sums in wave order: fixed summation order, and the split loop is 4x shorter and 4x more parallel.
 template <bool VEC4>
 __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __restrict__ slab, int splits, int64_t M, int64_t N,
                                                             float* __restrict__ dW, int64_t lddw,
                                                             const float* __restrict__ dbslab, float* __restrict__ db,
                                                             int accumulate) {
-  const int64_t idx = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x;
+  __shared__ float4 red[RED_THREADS / 64][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int U = VEC4 ? 4 : 1;
   const int64_t total = M * N;
-  if (VEC4) {
-    const int64_t e = idx * 4;
-    if (e < total) {
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-      for (int s = 0; s < splits; ++s) {
+  const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * U;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total) {
+    for (int s = w; s < splits; s += RED_THREADS / 64) {
+      if (VEC4) {
         const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * total + e);
         t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      } else {
+        t.x += slab[(int64_t)s * total + e];
       }
-      const int64_t i = e / N, j = e - i * N;
+    }
+  }
+  red[w][lane] = t;
+  __syncthreads();
+  if (w == 0 && e < total) {
+#pragma unroll
+    for (int k = 1; k < RED_THREADS / 64; ++k) { const float4 v = red[k][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    const int64_t i = e / N, j = e - i * N;
+    if (VEC4) {
       float4* dst = reinterpret_cast<float4*>(dW + i * lddw + j);
       if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
       *dst = t;
+    } else {
+      float* dst = dW + i * lddw + j;
+      *dst = accumulate ? (*dst + t.x) : t.x;
     }
-  } else if (idx < total) {
-    float t = 0.f;
-    for (int s = 0; s < splits; ++s) t += slab[(int64_t)s * total + idx];
-    const int64_t i = idx / N, j = idx - i * N;
-    float* dst = dW + i * lddw + j;
-    *dst = accumulate ? (*dst + t) : t;
   }
-  if (db && idx < M) {
-    float t = 0.f;
-    for (int s = 0; s < splits; ++s) t += dbslab[(int64_t)s * M + idx];
-    db[idx] = accumulate ? (db[idx] + t) : t;
+  // db: the first blocks also reduce the bias slab (M entries)
+  const int64_t bi = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x;
+  if (db && bi < M) {
+    float tb = 0.f;
+    for (int s = 0; s < splits; ++s) tb += dbslab[(int64_t)s * M + bi];
+    db[bi] = accumulate ? (db[bi] + tb) : tb;
   }
 }
 
@@ -301,38 +337,21 @@ constexpr Cfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-// MFMA-bound cost model: co-resident workgroups share the CU's four matrix pipes, so the time is
-// rounds * (work of one tile); prefer exact fits, then larger tiles (operand reuse).
-static int pick_cfg(int64_t M, int64_t N, int64_t Kc, int splits_hint, const int* allowed, int n_allowed) {
-  int best = allowed[0];
-  double best_cost = 1e300;
-  for (int a = 0; a < n_allowed; ++a) {
-    const Cfg c = kCfgs[allowed[a]];
-    const int64_t tiles = ceil_div(M, c.bm) * ceil_div(N, c.bn) * splits_hint;
-    const int64_t rounds = ceil_div(tiles, kNumCU);
-    double cost = (double)rounds * c.bm * c.bn;
-    cost *= 1.0 + 0.02 * (256.0 * 128.0 / (c.bm * c.bn));   // mild preference for larger tiles
-    if (cost < best_cost) { best_cost = cost; best = allowed[a]; }
-  }
-  (void)Kc;
-  return best;
-}
-
-template <int BM, int BN, int WM, int WN, bool A_CONTIG, bool B_CONTIG, int EPI>
+template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI>
 static int launch_cfg(const Args& g, int splits, hipStream_t st, const char* who) {
   constexpr int THREADS = 64 * WM * WN;
   // float4 loads need aligned rows and extents that keep every float4 fully in or out of range
   const bool vec = aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) &&
                    (A_CONTIG ? (g.Kc % 4 == 0) : (g.M % 4 == 0)) && (B_CONTIG ? (g.Kc % 4 == 0) : (g.N % 4 == 0));
   dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits), block(THREADS);
-  constexpr size_t lds = 2 * (Tile<BM, A_CONTIG, THREADS>::LDS_FLOATS + Tile<BN, B_CONTIG, THREADS>::LDS_FLOATS) * sizeof(float);
+  constexpr size_t lds = STAGES * (Tile<BM, A_CONTIG, THREADS>::LDS_FLOATS + Tile<BN, B_CONTIG, THREADS>::LDS_FLOATS) * sizeof(float);
   if (vec) {
-    auto k = gemm_k<BM, BN, WM, WN, A_CONTIG, B_CONTIG, EPI, true>;
+    auto k = gemm_k<BM, BN, WM, WN, STAGES, A_CONTIG, B_CONTIG, EPI, true>;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, grid, block, lds, st, g);
   } else {
-    auto k = gemm_k<BM, BN, WM, WN, A_CONTIG, B_CONTIG, EPI, false>;
+    auto k = gemm_k<BM, BN, WM, WN, STAGES, A_CONTIG, B_CONTIG, EPI, false>;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
     hipLaunchKernelGGL(k, grid, block, lds, st, g);
@@ -343,12 +362,12 @@ static int launch_cfg(const Args& g, int splits, hipStream_t st, const char* who
 template <bool A_CONTIG, bool B_CONTIG, int EPI>
 static int launch(int cfg, const Args& g, int splits, hipStream_t st, const char* who) {
   switch (cfg) {
-    case 0: return launch_cfg<192, 128, 2, 4, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
-    case 1: return launch_cfg<128, 128, 2, 4, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
-    case 2: return launch_cfg<64, 128, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
-    case 4: return launch_cfg<192, 64, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
-    case 5: return launch_cfg<96, 128, 1, 4, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
-    default: return launch_cfg<128, 128, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 0: return launch_cfg<192, 128, 2, 4, 3, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 1: return launch_cfg<128, 128, 2, 4, 3, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 2: return launch_cfg<64, 128, 2, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 4: return launch_cfg<192, 64, 2, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    case 5: return launch_cfg<96, 128, 1, 4, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
+    default: return launch_cfg<128, 128, 2, 2, 2, A_CONTIG, B_CONTIG, EPI>(g, splits, st, who);
   }
 }
 
@@ -361,9 +380,7 @@ static int env_cfg(const char* name) {   // tuning hook: CLICA_GEMM_CFG_{FWD,DGR
 struct WgradPlan { int cfg, splits; int64_t k_per_split; };
 static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, int64_t Kc) {
   WgradPlan p;
-  static const int allowed[] = {1, 2};
-  p.cfg = pick_cfg(M, N, Kc, 1, allowed, 2);
-  if (M * N <= 128 * 128) p.cfg = 1;
+  p.cfg = (M > 128 && N > 128) ? 1 : 2;   // measured: 8-wave 128x128 wins on the square layers
   const int e = env_cfg("CLICA_GEMM_CFG_WGRAD");
   if (e >= 0 && e < kNumCfgs) p.cfg = e;
   const Cfg c = kCfgs[p.cfg];
@@ -391,8 +408,10 @@ extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int
   CLICA_CHECK_ARG(ldx >= K && ldw >= K && ldy >= N, "clica_linear_fwd: leading dimension too small");
   Args g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.Kc = K;
   g.bias = bias; g.slope = slope; g.leaky = leaky;
-  static const int allowed[] = {0, 1, 2};
-  int cfg = pick_cfg(M, N, K, 1, allowed, 3);
+  { const int ab = env_cfg("CLICA_GEMM_ABLATE"); g.ablate = ab > 0 ? ab : 0; }
+  // measured on MI355X (tools/gemm_bench.py): wide outputs -> 96x128 tiles, two 4-wave workgroups per
+  // CU; narrow outputs (N <= 128, one tile column) -> 64x128 for more workgroups along M
+  int cfg = (N > 128) ? 5 : 2;
   const int e = env_cfg("CLICA_GEMM_CFG_FWD");
   if (e >= 0 && e < kNumCfgs) cfg = e;
   return launch<true, true, EPI_BIAS_ACT>(cfg, g, 1, as_stream(stream), "clica_linear_fwd");
@@ -408,8 +427,7 @@ extern "C" int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W,
   // dX[M,K] = dY[M,N] W[N,K]: contraction over N; B_op[kc=n][j=k] = W[n][k] (Kc strided)
   Args g{}; g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = M; g.N = K; g.Kc = N;
   g.xact = Xact; g.ldxa = ldxa; g.slope = slope;
-  static const int allowed[] = {0, 1, 2};
-  int cfg = pick_cfg(M, K, N, 1, allowed, 3);
+  int cfg = 2;   // measured best for every encoder layer shape (B operand is read with ds_read_b32)
   const int e = env_cfg("CLICA_GEMM_CFG_DGRAD");
   if (e >= 0 && e < kNumCfgs) cfg = e;
   return launch<true, false, EPI_DACT>(cfg, g, 1, as_stream(stream), "clica_linear_dgrad");
@@ -448,8 +466,10 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   if (rc) return rc;
   const int64_t total = N * K;
   const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW);
-  const int64_t work = v4 ? total / 4 : total;
-  const unsigned blocks = (unsigned)ceil_div(work > N ? work : N, RED_THREADS);
+  const int64_t units = v4 ? total / 4 : total;
+  int64_t nb = ceil_div(units, 64);
+  if (db && nb < ceil_div(N, RED_THREADS)) nb = ceil_div(N, RED_THREADS);
+  const unsigned blocks = (unsigned)nb;
   if (v4)
     hipLaunchKernelGGL(slab_reduce_k<true>, dim3(blocks), dim3(RED_THREADS), 0, st, (const float*)slab, p.splits, N, K, dW, lddw,
                        (const float*)dbslab, db, accumulate ? 1 : 0);

@@ -23,14 +23,12 @@ __device__ __forceinline__ float pos_sum(const float* a, const float* b, int n, 
 }
 
 struct Means {
-  float* blocksums;      // [gridDim.x][3]
-  unsigned int* ticket;  // zero on entry, reset by the last block
-  float* means;          // [3]
+  float* blocksums;      // [gridDim.x][3] per-block partial sums
 };
 
-// deterministic grid reduction of three per-thread values: block tree -> per-block slot ->
-// last-arriving block sums the slots in index order (release/acquire at agent scope).
-__device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const Means& M, float inv_count) {
+// block tree -> one slot per block; `means_k` (next launch on the stream) sums the slots in index
+// order, so the three means are deterministic and need no atomics or fences.
+__device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const Means& M) {
   __shared__ float red[3][THREADS / 64];
   float v[3] = {v0, v1, v2};
 #pragma unroll
@@ -41,29 +39,26 @@ __device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) { red[0][wave] = v[0]; red[1][wave] = v[1]; red[2][wave] = v[2]; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int a = 0; a < 3; ++a) {
-      float t = 0.f;
-      for (int w = 0; w < THREADS / 64; ++w) t += red[a][w];
-      M.blocksums[blockIdx.x * 3 + a] = t;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned int prev = __hip_atomic_fetch_add(M.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-      for (unsigned int b = 0; b < gridDim.x; ++b) {
-        t0 += __hip_atomic_load(&M.blocksums[b * 3 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t1 += __hip_atomic_load(&M.blocksums[b * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t2 += __hip_atomic_load(&M.blocksums[b * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      M.means[0] = t0 * inv_count;
-      M.means[1] = t1 * inv_count;
-      M.means[2] = t2 * inv_count;
-      __hip_atomic_store(M.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  if (threadIdx.x < 3) {
+    float t = 0.f;
+    for (int w = 0; w < THREADS / 64; ++w) t += red[threadIdx.x][w];
+    M.blocksums[blockIdx.x * 3 + threadIdx.x] = t;
   }
+}
+
+__global__ __launch_bounds__(64) void means_k(const float* __restrict__ blocksums, int nblocks, float inv_count,
+                                              float* __restrict__ means) {
+  // lane l sums slots l, l+64, ... ; fixed-order shuffle tree afterwards
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < nblocks; b += 64) {
+    v[0] += blocksums[b * 3 + 0]; v[1] += blocksums[b * 3 + 1]; v[2] += blocksums[b * 3 + 2];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
+  }
+  if (threadIdx.x == 0) { means[0] = v[0] * inv_count; means[1] = v[1] * inv_count; means[2] = v[2] * inv_count; }
 }
 
 constexpr int FIN_ROWS = 64;   // rows per finalize block; the 4 waves split the per-split partials
@@ -119,7 +114,7 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     loss_i[i] = li; pos_i[i] = lp; lse_i[i] = lse_raw;
     v_loss = li; v_pos = lp; v_lse = lse;
   }
-  reduce_means(v_loss, v_pos, v_lse, M, 1.f / (float)rows);
+  reduce_means(v_loss, v_pos, v_lse, M);
 }
 
 // ---- backward ------------------------------------------------------------------------------
@@ -237,12 +232,12 @@ static void launch_bwd_pairs(bool owner_stats, const Plan& P, int pk, const floa
 }
 
 // workspace carve-up ------------------------------------------------------------------------------
-struct FwdWs { float2* part; float* blocksums; unsigned int* ticket; size_t bytes; };
+struct FwdWs { float2* part; float* blocksums; size_t bytes; };
 struct BwdWs { float* statL; float* statC; float* partR; float* partC; size_t bytes; };
 
 static FwdWs carve_fwd(void* ws, const Plan& P, int64_t rows) {
   FwdWs w; char* p = (char*)ws; size_t off = 0;
-  w.ticket = (unsigned int*)(p + off); off += 256;   // must be zero before first use (see .h)
+  off += 256;   // reserved header
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
   w.part = (float2*)(p + off); off += align_up((size_t)P.nsplit * rows * sizeof(float2), 256);
   w.bytes = off; return w;
@@ -306,10 +301,12 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   Params q = make_params(d, frac);
   hipStream_t st = as_stream(stream);
   launch_fwd_partial(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part, st);
-  Means M{w.blocksums, w.ticket, means};
-  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(rows, FIN_ROWS)), dim3(THREADS), 0, st,
+  Means M{w.blocksums};
+  const int nfin = (int)ceil_div(rows, FIN_ROWS);
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M);
+  hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)rows, means);
   return launch_status("clica_lp_loss_fwd");
 }
 
@@ -458,10 +455,12 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
     z1 = dw.u1; z2 = dw.u2; z3 = dw.u3; ld1 = ld2 = ld3 = d->n;
   }
   launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, st);
-  Means M{w.blocksums, w.ticket, means};
-  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)ceil_div(d->B, FIN_ROWS)), dim3(THREADS), 0, st,
+  Means M{w.blocksums};
+  const int nfin = (int)ceil_div(d->B, FIN_ROWS);
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      1, 0, 1, 0.f, loss_i, pos_i, lse_i, M);
+  hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
   return launch_status("clica_dot_loss_fwd");
 }
 

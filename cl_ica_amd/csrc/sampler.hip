@@ -16,7 +16,7 @@ constexpr int THREADS = 256;
 struct Philox {
   uint32_t key0, key1;
   uint32_t c0, c1, c2, c3;   // c0 = element index, c1 = draw block, c2 = step, c3 = stream id
-  uint32_t out[4];
+  uint32_t o0, o1, o2, o3;   // named registers: a runtime-indexed array would live in scratch memory
   int have;
   __device__ Philox(uint64_t seed, uint32_t idx, uint32_t step, uint32_t stream)
       : key0((uint32_t)seed), key1((uint32_t)(seed >> 32)), c0(idx), c1(0), c2(step), c3(stream), have(0) {}
@@ -33,10 +33,15 @@ struct Philox {
       a0 = n0; a1 = n1; a2 = n2; a3 = n3;
       k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+    o0 = a0; o1 = a1; o2 = a2; o3 = a3;
     ++c1; have = 4;
   }
-  __device__ uint32_t next() { if (have == 0) refill(); return out[--have]; }
+  __device__ uint32_t next() {
+    if (have == 0) refill();
+    const uint32_t r = o0;
+    o0 = o1; o1 = o2; o2 = o3; --have;
+    return r;
+  }
   __device__ float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }          // [0,1)
   __device__ float uniform_open() { return ((float)(next() >> 8) + 1.0f) * (1.0f / 16777216.0f); }  // (0,1]
   __device__ float normal() {  // Box-Muller, one value per call (the twin is discarded: draws are cheap)
