@@ -49,8 +49,9 @@ class GradBuckets:
     gradient has been written."""
 
     def __init__(self, arena: torch.Tensor, layer_slices: Sequence[Tuple[int, int]], world: int,
-                 group: Optional[dist.ProcessGroup], bucket_bytes: int = 8 << 20):
+                 group: Optional[dist.ProcessGroup], bucket_bytes: int = 8 << 20, force: bool = False):
         self.arena, self.group, self.world = arena, group, world
+        self.force = force
         self.buckets: List[Tuple[int, int]] = []      # (lo, hi) element ranges
         self.trigger: dict = {}                        # layer index (completion order) -> bucket id
         lo = hi = None
@@ -66,7 +67,7 @@ class GradBuckets:
 
     def layer_done(self, i: int):
         b = self.trigger.get(i)
-        if b is None or self.world == 1:
+        if b is None or (self.world == 1 and not self.force):
             return
         lo, hi = self.buckets[b]
         view = self.arena[lo:hi]

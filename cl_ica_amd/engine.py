@@ -50,7 +50,8 @@ class ContrastiveTrainer:
     def __init__(self, f: nn.Sequential, g_weights: torch.Tensor, sampler: SamplerSpec, batch_size: int,
                  p: float = 2, tau: float = 1.0, alpha: float = 0.5, lr: float = 1e-4, g_slope: float = 0.2,
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
-                 process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20):
+                 process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
+                 force_collectives: bool = False):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -64,6 +65,8 @@ class ContrastiveTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
+        # run the collectives even at world size 1 (test hook: exercises the DP code path on one GPU)
+        self.dp = self.world > 1 or (force_collectives and dist.is_initialized())
         if self.p == 0:
             raise NotImplementedError("p=0 (SimCLRLoss) runs through cl_ica_amd.losses.SimCLRLoss, not the fused engine")
 
@@ -76,7 +79,8 @@ class ContrastiveTrainer:
         self._flatten_parameters()
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes) if self.world > 1 else None
+        self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes,
+                                   force=self.dp) if self.dp else None
 
     # -------------------------------------------------------------------------------- arenas
     def _flatten_parameters(self):
@@ -125,9 +129,9 @@ class ContrastiveTrainer:
         self.dy = torch.empty((R, n), **f32)
         self.loss_out = torch.empty(3 * B + 3, **f32)
         Bg = B * self.world
-        self.z_all = torch.empty((Bg, n), **f32) if self.world > 1 else None
-        self.dz_all = torch.empty((Bg, n), **f32) if self.world > 1 else None
-        self.dz_rs = torch.empty((B, n), **f32) if self.world > 1 else None
+        self.z_all = torch.empty((Bg, n), **f32) if self.dp else None
+        self.dz_all = torch.empty((Bg, n), **f32) if self.dp else None
+        self.dz_rs = torch.empty((B, n), **f32) if self.dp else None
         self.desc = _lib.LpLossDesc(B=B, B3=Bg, n=n, p=self.p, tau=self.tau, alpha=self.alpha, compat=1, pow=1)
         fb, bb = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(self.desc), C.byref(fb), C.byref(bb)), "workspace")
@@ -189,7 +193,7 @@ class ContrastiveTrainer:
         lib, st = _lib.load(), _lib.stream_ptr()
         B, n, o = self.B, self.n, self.loss_out
         y1, y2 = self.y[:B], self.y[B:]
-        if self.world > 1:
+        if self.dp:
             dist.all_gather_into_tensor(self.z_all, y1.contiguous(), group=self.pg)
             z3, dz3, acc = self.z_all, self.dz_all, 0
         else:
@@ -201,7 +205,7 @@ class ContrastiveTrainer:
                                          o[2 * B:3 * B].data_ptr(), None, None, None, None,
                                          self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n, dz3.data_ptr(), n, acc,
                                          self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd")
-        if self.world > 1:
+        if self.dp:
             dist.reduce_scatter_tensor(self.dz_rs, self.dz_all, op=dist.ReduceOp.SUM, group=self.pg)
             self.dy[:B].add_(self.dz_rs)
 
@@ -268,7 +272,7 @@ class ContrastiveTrainer:
     def capture(self, warmup: int = 3):
         """Capture the step into a HIP graph (single-GPU; counters and RNG offsets live on device,
         so replays advance them)."""
-        if self.world > 1:
+        if self.dp:
             raise NotImplementedError("graph capture is single-GPU; the DP path runs eagerly")
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))

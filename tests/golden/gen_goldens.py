@@ -18,6 +18,7 @@ test time depends on torch's RNG streams.  Groups follow SURVEY.md section 8(c):
   g8_mixing.npz       construct_invertible_mlp KAT + forward
   g9_samplers.npz     sampler statistics from 1e5 reference draws
   g10_strided.npz     strided / sliced input views
+  g11_metrics.npz     R^2 / MCC evaluation metrics (disentanglement_utils.py)
 """
 import os
 import sys
@@ -444,8 +445,27 @@ def g10():
     save("g10_strided.npz", store)
 
 
+# ----------------------------------------------------------------------------- G11
+def g11():
+    """Evaluation metrics (disentanglement_utils.py): the two calls main_mlp.py makes."""
+    import disentanglement_utils as ref_du
+    store = {}
+    rng = np.random.default_rng(0)
+    for i, (N, n) in enumerate([(2048, 10), (1000, 4), (512, 40)]):
+        z = rng.uniform(size=(N, n)).astype(np.float32)
+        A = rng.normal(size=(n, n))
+        hz = (np.tanh(z @ A) + 0.05 * rng.normal(size=(N, n))).astype(np.float32)[:, rng.permutation(n)]
+        (r2, _), _ = ref_du.linear_disentanglement(torch.tensor(z), torch.tensor(hz), mode="r2")
+        (mcc, corr), _ = ref_du.permutation_disentanglement(torch.tensor(z), torch.tensor(hz), mode="pearson",
+                                                            solver="munkres", rescaling=True)
+        store[f"c{i}/z"] = z; store[f"c{i}/hz"] = hz
+        store[f"c{i}/r2"] = np.asarray(r2); store[f"c{i}/mcc"] = np.asarray(mcc); store[f"c{i}/corr_diag"] = np.diag(corr)
+    store["n_cases"] = np.asarray(3)
+    save("g11_metrics.npz", store)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1r", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10"]
-    table = dict(g1=g1, g1r=g1_roll, g2=g2, g3=g3, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10)
+    which = sys.argv[1:] or ["g1", "g1r", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    table = dict(g1=g1, g1r=g1_roll, g2=g2, g3=g3, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
     for w in which:
         table[w]()

@@ -1,0 +1,67 @@
+"""The C-ABI library loads on a CPU-only host and exports exactly what include/clica.h declares
+(no compute calls: those need the GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "clica.h")
+LIB = os.path.join(ROOT, "cl_ica_amd", "lib", "libclica_hip.so")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(clica_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+def test_header_declares_functions():
+    names = declared_functions()
+    assert len(names) >= 20
+    for must in ("clica_lp_loss_fwd", "clica_lp_loss_bwd", "clica_linear_fwd", "clica_linear_dgrad", "clica_linear_wgrad",
+                 "clica_adam_step", "clica_sample", "clica_mixing_fwd", "clica_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in clica.h but not exported: {missing}"
+
+
+def test_python_binding_matches_header(lib):
+    from cl_ica_amd import _lib
+    declared = set(declared_functions()) - {"clica_last_error"}
+    bound = set(_lib.SIGNATURES)
+    assert bound == declared, (sorted(bound - declared), sorted(declared - bound))
+    assert _lib.load().clica_version() >= 100
+
+
+def test_host_only_entry_points(lib):
+    """Planning/validation entry points are pure host code: they must work (and fail loudly) without a GPU."""
+    from cl_ica_amd import _lib
+    L = _lib.load()
+    d = _lib.LpLossDesc(B=6144, B3=6144, n=10, p=2.0, tau=1.0, alpha=0.5, compat=1, pow=1)
+    fb, bb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.clica_lp_loss_workspace_bytes(ctypes.byref(d), ctypes.byref(fb), ctypes.byref(bb)) == 0
+    assert 0 < fb.value < 64 << 20 and 0 < bb.value < 256 << 20
+    bad = _lib.LpLossDesc(B=4, B3=4, n=100, p=2.0, tau=1.0, alpha=0.5, compat=1, pow=1)
+    assert L.clica_lp_loss_workspace_bytes(ctypes.byref(bad), ctypes.byref(fb), ctypes.byref(bb)) == -1
+    assert b"n=100" in L.clica_last_error()
+    frac = _lib.LpLossDesc(B=4, B3=5, n=3, p=0.5, tau=1.0, alpha=0.5, compat=1, pow=1)
+    assert L.clica_lp_loss_workspace_bytes(ctypes.byref(frac), ctypes.byref(fb), ctypes.byref(bb)) == -1
+    nb = ctypes.c_size_t()
+    assert L.clica_linear_wgrad_workspace_bytes(12288, 500, 500, ctypes.byref(nb)) == 0 and nb.value > 0
+    assert L.clica_linear_fwd(None, 0, None, 0, None, None, 0, 1, 1, 1, 0, 0.0, None) == -1     # NULL pointers rejected
+    with pytest.raises(_lib.ClicaError):
+        _lib.check(-1, "probe")

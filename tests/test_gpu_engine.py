@@ -96,3 +96,51 @@ def test_graph_replay_trains():
     assert not torch.equal(z_before, tr.z)                     # RNG advanced across replays
     assert torch.isfinite(out).all() and out[0].item() < first[0].item() - 0.05
     assert float(tr.z.min()) >= 0.0 and float(tr.z.max()) <= 1.0
+
+
+def test_train_mlp_driver_short_run(tmp_path, capsys):
+    """BASELINE configs[0] shape (n=10, box, p=2, B=512) for a few steps through the CLI driver:
+    step-1 unsupervised loss = ln(513), loss decreases, checkpoints have the reference keys."""
+    from cl_ica_amd import train_mlp
+    res = train_mlp.main(["--n", "10", "--space-type", "box", "--p", "2", "--batch-size", "512", "--n-steps", "40",
+                          "--more-unsupervised", "1", "--n-log-steps", "20", "--seed", "0", "--only-unsupervised",
+                          "--lr", "1e-3", "--num-eval-batches", "2", "--save-dir", str(tmp_path)])
+    out = capsys.readouterr().out
+    assert "Id. Lin. Disentanglement" in out and "Step: 1" in out and "linear mean" in out
+    assert abs(res["losses"][0] - np.log(513)) < 2e-3
+    assert res["losses"][-1] < res["losses"][0] - 0.05
+    sd = torch.load(tmp_path / "unsup_f.pth")
+    assert list(sd.keys()) == [f"{i}.{k}" for i in range(0, 13, 2) for k in ("weight", "bias")]
+    assert list(torch.load(tmp_path / "g.pth").keys()) == ["0.weight", "2.weight", "4.weight"]
+
+
+def test_train_mlp_supervised_and_simclr_paths():
+    from cl_ica_amd import train_mlp
+    r = train_mlp.main(["--n", "4", "--space-type", "sphere", "--p", "0", "--batch-size", "256", "--n-steps", "12",
+                        "--more-unsupervised", "1", "--n-log-steps", "6", "--seed", "1", "--lr", "1e-3", "--num-eval-batches", "1"])
+    assert np.isfinite(r["losses"]).all() and len(r["losses"]) == 12
+
+
+def test_dp_code_path_single_rank():
+    """world_size-1 RCCL group with the collectives forced on: all-gather / reduce-scatter / bucketed
+    all-reduce must reproduce the plain single-GPU step bit-for-bit."""
+    import os
+    import torch.distributed as dist
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = []
+        for force in (False, True):
+            torch.manual_seed(0)
+            f = encoders.get_mlp(10, 10, [100, 500, 100])
+            tr = ContrastiveTrainer(f, torch.eye(10).repeat(3, 1, 1), SamplerSpec(n=10, seed=5), batch_size=1024, p=2,
+                                    lr=1e-3, device="cuda", process_group=dist.group.WORLD, force_collectives=force)
+            for _ in range(3):
+                o = tr.step().clone()
+            outs.append((o, tr.param_arena.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    finally:
+        dist.destroy_process_group()

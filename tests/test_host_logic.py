@@ -1,0 +1,198 @@
+"""Host-side logic that needs no GPU: module structure / state-dict compatibility, mixing-network
+construction KAT, fail-loud behaviour on CPU tensors, arena flattening, gradient bucketing."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+
+def test_get_mlp_structure_and_state_dict(golden):
+    from cl_ica_amd import encoders, layers
+    G = golden("g6_mlp.npz")
+    for key, c in G.cases():
+        n = int(c["meta"]["n"]); head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]
+        arg = list(hidden)
+        f = encoders.get_mlp(n_in=n, n_out=n, layers=arg, output_normalization=head)
+        assert arg == hidden + [n]                      # the reference appends n_out in place (encoders.py:56)
+        assert isinstance(f, torch.nn.Sequential)
+        assert list(f.state_dict().keys()) == [str(k) for k in c["meta"]["state_keys"]]
+        dims = [n] + hidden + [n]
+        lin = [m for m in f if isinstance(m, torch.nn.Linear)]
+        assert [(m.in_features, m.out_features) for m in lin] == list(zip(dims[:-1], dims[1:]))
+        assert all(m.negative_slope == 0.01 for m in f if isinstance(m, torch.nn.LeakyReLU))
+        if head == "learnable_sphere":
+            assert isinstance(f[-1], layers.RescaleLayer) and isinstance(f[-1].r, torch.nn.Parameter) and f[-1].r.shape == (1,)
+        if head == "fixed_sphere":
+            assert not isinstance(f[-1].r, torch.nn.Parameter) and "r" not in dict(f[-1].named_buffers())
+        if head == "learnable_box":
+            assert f[-1].max_abs_bound.shape == (n,)
+        # nn.Linear default init: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight (kaiming a=sqrt(5)) and bias
+        for m in lin:
+            bound = 1.0 / np.sqrt(m.in_features)
+            assert float(m.weight.abs().max()) <= bound + 1e-6 and float(m.bias.abs().max()) <= bound + 1e-6
+
+
+def test_get_mlp_rejects_unbuilt_options():
+    from cl_ica_amd import encoders
+    with pytest.raises(NotImplementedError):
+        encoders.get_mlp(4, 4, [8], layer_normalization="bn")
+    with pytest.raises(ValueError):
+        encoders.get_mlp(4, 4, [8], output_normalization="nope")
+    with pytest.raises(ValueError):
+        encoders.get_mlp(4, 4, [])
+
+
+def test_mixing_constructor_kat(golden):
+    """np.random.seed(0), n=10, L=3 reproduces the reference's g bit-for-bit."""
+    from cl_ica_amd import invertible_network_utils as inu
+    z = golden("g8_mixing.npz").z
+    np.random.seed(3)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        g = inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="leaky_relu", cond_thresh_ratio=0.25, n_iter_cond_thresh=500)
+    assert abs(float(buf.getvalue().splitlines()[0].split(":")[1]) - float(z["small_thresh"])) < 1e-6
+    Ws = [m.weight.detach().numpy() for m in g if isinstance(m, torch.nn.Linear)]
+    assert np.array_equal(Ws[0], z["small_W0"]) and np.array_equal(Ws[1], z["small_W1"])
+    assert list(g.state_dict().keys()) == ["0.weight", "2.weight"]
+    assert all(not p.requires_grad for p in g.parameters())
+    assert isinstance(g[1], torch.nn.LeakyReLU) and g[1].negative_slope == 0.2
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()) as b2:
+        g = inu.construct_invertible_mlp(n=10, n_layers=3, act_fct="leaky_relu", cond_thresh_ratio=0.0, n_iter_cond_thresh=25000)
+    assert abs(float(b2.getvalue().splitlines()[0].split(":")[1]) - 4.085284) < 1e-6
+    for i, m in enumerate([m for m in g if isinstance(m, torch.nn.Linear)]):
+        assert np.array_equal(m.weight.detach().numpy(), z[f"W{i}"])
+    with pytest.raises(NotImplementedError):
+        inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="softplus", n_iter_cond_thresh=10)
+
+
+def test_no_cpu_fallback_anywhere():
+    """CPU tensors must raise, never silently compute (the oracle is test infrastructure only)."""
+    from cl_ica_amd import encoders, layers, losses, spaces
+    from cl_ica_amd._lib import ClicaError
+    z = torch.randn(8, 3)
+    with pytest.raises(ClicaError):
+        losses.LpSimCLRLoss(p=2)(None, None, None, z, z, z)
+    with pytest.raises(ClicaError):
+        losses.SimCLRLoss()(None, None, None, z, z, z)
+    with pytest.raises(ClicaError):
+        encoders.get_mlp(3, 3, [6])(z)
+    with pytest.raises(ClicaError):
+        layers.RescaleLayer()(z)
+    with pytest.raises(RuntimeError):
+        spaces.NSphereSpace(3).uniform(5, device="cpu")
+    import cl_ica_amd
+    import pkgutil
+    for m in pkgutil.iter_modules(cl_ica_amd.__path__):
+        src = open(f"{cl_ica_amd.__path__[0]}/{m.name}.py").read()
+        assert "import oracle" not in src and "from oracle" not in src, m.name
+
+
+def test_loss_ctor_surface():
+    from cl_ica_amd import losses
+    L = losses.LpSimCLRLoss(p=1)
+    assert (L.p, L.tau, L.alpha, L.simclr_compatibility_mode, L.pow) == (1, 1.0, 0.5, False, True)
+    S = losses.SimCLRLoss()
+    assert (S.normalize, S.tau, S.alpha) == (False, 1.0, 0.5)
+    assert isinstance(L, losses.CLLoss) and isinstance(S, losses.CLLoss)
+    with pytest.raises(ValueError):
+        L(None, None, None, torch.zeros(4, 3), torch.zeros(5, 3), torch.zeros(4, 3))
+
+
+def test_latent_space_plumbing():
+    from cl_ica_amd import latent_spaces, spaces
+    calls = []
+
+    class Fake(spaces.Space):
+        dim = 3
+
+        def uniform(self, size, device="cpu"):
+            calls.append(("u", size)); return torch.zeros(size, 3)
+
+        def normal(self, mean, std, size, device="cpu"):
+            calls.append(("n", std)); return mean + 1
+
+        laplace = generalized_normal = normal
+
+    ls = latent_spaces.LatentSpace(Fake(), lambda sp, size, device="cpu": sp.uniform(size, device),
+                                   lambda sp, z, size, device="cpu": sp.normal(z, 0.05, size, device))
+    z = ls.sample_marginal(size=5)
+    zt = ls.sample_conditional(z, size=5)
+    assert calls == [("u", 5), ("n", 0.05)] and ls.dim == 3 and torch.equal(zt, z + 1)
+    prod = latent_spaces.ProductLatentSpace([ls, ls])
+    assert prod.dim == 6 and prod.sample_marginal(size=2).shape == (2, 6)
+    assert prod.sample_conditional(torch.zeros(2, 6), size=2).shape == (2, 6)
+    empty = latent_spaces.LatentSpace(Fake(), None, None)
+    with pytest.raises(RuntimeError):
+        empty.sample_marginal
+
+
+def test_trainer_arena_flattening_cpu():
+    """Arena construction is host logic (no kernel launch): parameters become views of one flat buffer,
+    state-dict keys/values are preserved, layer slices tile the arena in backward order."""
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(0)
+    f = encoders.get_mlp(4, 4, [40, 200, 40], output_normalization="learnable_sphere")
+    before = {k: v.clone() for k, v in f.state_dict().items()}
+    tr = ContrastiveTrainer(f, torch.randn(3, 4, 4), SamplerSpec(n=4), batch_size=64, p=1, device="cpu")
+    after = f.state_dict()
+    assert list(after.keys()) == list(before.keys())
+    for k in before:
+        assert torch.equal(before[k], after[k])
+    base = tr.param_arena.data_ptr()
+    for p in f.parameters():
+        assert base <= p.data_ptr() < base + tr.param_arena.numel() * 4
+        assert (p.data_ptr() - base) % 16 == 0
+        assert p.grad is not None and p.grad.shape == p.shape
+    tr.param_arena.zero_()
+    assert all(float(p.abs().max()) == 0 for p in f.parameters())       # really views
+    sl = tr._layer_slices
+    assert len(sl) == 4 and sl[0][0] > sl[-1][0]                        # last layer first
+    assert all(a < b for a, b in sl)
+
+
+def test_grad_bucket_partition():
+    from cl_ica_amd.distributed import GradBuckets
+    arena = torch.zeros(1000)
+    slices = [(900, 1000), (600, 900), (100, 600), (0, 100)]     # backward completion order
+    gb = GradBuckets(arena, slices, world=2, group=None, bucket_bytes=1200)
+    assert gb.buckets == [(600, 1000), (100, 600), (0, 100)]
+    assert gb.trigger == {1: 0, 2: 1, 3: 2}
+    covered = sorted(gb.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == 1000
+    assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+
+
+def test_metrics_goldens(golden):
+    """R^2 / MCC (torch + scipy assignment) vs the reference's sklearn + Munkres values (G11)."""
+    from cl_ica_amd import disentanglement_utils as du
+    z9 = golden("g11_metrics.npz").z
+    for i in range(int(z9["n_cases"])):
+        z, hz = torch.tensor(z9[f"c{i}/z"]), torch.tensor(z9[f"c{i}/hz"])
+        (r2, none), (z2, pred) = du.linear_disentanglement(z, hz, mode="r2")
+        assert none is None and pred.shape == z.shape
+        assert abs(r2 - float(z9[f"c{i}/r2"])) < 1e-6
+        (mcc, corr), thz = du.permutation_disentanglement(z, hz, mode="pearson", solver="munkres", rescaling=True)
+        assert abs(mcc - float(z9[f"c{i}/mcc"])) < 1e-6
+        assert np.abs(np.abs(np.diag(corr)) - np.abs(z9[f"c{i}/corr_diag"])).max() < 1e-6
+        assert thz.shape == z.shape
+
+
+def test_train_mlp_cli_surface():
+    """Same flags and defaults as main_mlp.py:21-127."""
+    from cl_ica_amd import train_mlp
+    a = train_mlp.parse_args([])
+    assert (a.n, a.p, a.batch_size, a.lr, a.tau, a.c_param, a.m_param, a.c_p, a.m_p) == (10, 2, 6144, 1e-4, 1.0, 0.05, 1.0, 2, 0)
+    assert (a.space_type, a.n_mixing_layer, a.n_log_steps, a.n_steps, a.more_unsupervised, a.num_eval_batches) == ("box", 3, 250, 100001, 3, 10)
+    assert (a.box_min, a.box_max, a.sphere_r, a.act_fct, a.save_dir, a.seed) == (0.0, 1.0, 1.0, "leaky_relu", "", None)
+    assert not (a.sphere_norm or a.box_norm or a.only_supervised or a.only_unsupervised or a.resume_training)
+    s = train_mlp.sampler_spec(train_mlp.parse_args(["--space-type", "sphere", "--c-p", "0", "--m-p", "1"]), 0)
+    assert (s.space, s.conditional, s.marginal) == ("sphere", "vmf", "laplace")
+    s = train_mlp.sampler_spec(train_mlp.parse_args(["--space-type", "unbounded", "--c-p", "3", "--m-p", "2"]), 0)
+    assert (s.space, s.conditional, s.marginal, s.c_p) == ("real", "gennorm", "normal", 3.0)
