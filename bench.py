@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP-graph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (A/B switch)")
     return ap.parse_args()
 
 
@@ -63,55 +64,74 @@ def build_trainer(args, device, world):
     f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 50, n * 50, n * 10])
     spec = SamplerSpec(space=args.space_type, n=n, box=(0.0, 1.0), marginal="uniform", conditional="normal", c_param=0.05, seed=0)
     return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
-                              device=device, process_group=None if world == 1 else dist.group.WORLD)
+                              device=device, process_group=None if world == 1 else dist.group.WORLD,
+                              overlap_backward=not args.no_overlap)
 
 
-def roofline_leg(tr, reps=10):
-    """Time every GEMM launch of one step (same shapes, same kernels) with HIP events on the
-    launch stream; aggregate per kernel class.  FLOPs are algorithmic: 2*M*N*K per launch."""
+def roofline_leg(tr, reps=20):
+    """Per KERNEL INSTANCE (= one symbol in the rocprofv3 summary: layout x tile) timing of the step's
+    GEMM launches.  For each instance the launches of one step are captured into a HIP graph and the
+    graph is replayed `reps` times between two HIP events on the launch stream, so the figure is
+    kernel time (plus the ~1 us in-graph launch boundary), not host launch latency -- comparable with
+    the rocprofv3 average for that symbol (profiles/).  FLOPs are algorithmic: 2*M*N*K per launch.
+    wgrad launches are a GEMM + a slab-reduce kernel, so they are listed but the `roofline` entry is
+    taken from the single-kernel ops (fwd / dgrad)."""
     from cl_ica_amd import ops
     R = 2 * tr.B
-    classes = {"linear_fwd": [0.0, 0.0, 0], "linear_dgrad": [0.0, 0.0, 0], "linear_wgrad": [0.0, 0.0, 0]}
+    groups = {}
 
-    def timed(name, flops, fn):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record(); fn(); e.record()
-        return name, flops, s, e
+    def add(op, N, K, fn):
+        tm, tn, waves, splits = ops.linear_plan(op, R, N, K)
+        vec = (N % 4 == 0 and K % 4 == 0)
+        layout = {"fwd": "true, true, 0", "dgrad": "true, false, 1", "wgrad": "false, false, 2"}[op]
+        key = (op, f"gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>")
+        g = groups.setdefault(key, {"fns": [], "flops": 0.0})
+        g["fns"].append(fn); g["flops"] += 2.0 * R * N * K
 
-    pending = []
-    for _ in range(reps):
-        cur = tr.x
-        L = len(tr.linears)
-        for l, lin in enumerate(tr.linears):
-            N, K = lin.out_features, lin.in_features
-            pending.append(timed("linear_fwd", 2.0 * R * N * K,
-                                 lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=tr.slope, out=tr.acts[l])))
-            cur = tr.acts[l]
-        g = tr.dy
-        for l in reversed(range(L)):
-            lin = tr.linears[l]
-            N, K = lin.out_features, lin.in_features
-            inp = tr.acts[l - 1] if l > 0 else tr.x
-            pending.append(timed("linear_wgrad", 2.0 * R * N * K,
-                                 lambda g=g, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)], ws=tr.wgrad_ws)))
-            if l > 0:
-                out = tr.dbuf[l & 1][:, :K]
-                pending.append(timed("linear_dgrad", 2.0 * R * N * K,
-                                     lambda g=g, lin=lin, inp=inp, out=out: ops.linear_dgrad(g, lin.weight, inp, tr.slope, out=out)))
-                g = out
-    torch.cuda.synchronize()
-    for name, flops, s, e in pending:
-        c = classes[name]
-        c[0] += flops; c[1] += s.elapsed_time(e) * 1e-3; c[2] += 1
+    cur = tr.x
+    L = len(tr.linears)
+    for l, lin in enumerate(tr.linears):
+        N, K = lin.out_features, lin.in_features
+        add("fwd", N, K, lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1),
+                                                                        slope=tr.slope, out=tr.acts[l]))
+        cur = tr.acts[l]
+    g_ = tr.dy
+    for l in reversed(range(L)):
+        lin = tr.linears[l]
+        N, K = lin.out_features, lin.in_features
+        inp = tr.acts[l - 1] if l > 0 else tr.x
+        add("wgrad", N, K, lambda g=g_, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)],
+                                                                           db=tr._gviews[id(lin.bias)], ws=tr.wgrad_ws))
+        if l > 0:
+            out = tr.dbuf[l & 1][:, :K]
+            add("dgrad", N, K, lambda g=g_, lin=lin, inp=inp, out=out: ops.linear_dgrad(g, lin.weight, inp, tr.slope, out=out))
+            g_ = out
     rows = []
-    for name, (fl, sec, cnt) in classes.items():
-        rows.append({"kernel": name, "launches_per_step": cnt // reps, "avg_us": 1e6 * sec / cnt,
-                     "tflops": fl / sec / 1e12, "share_s": sec / reps})
-    rows.sort(key=lambda r: -r["share_s"])
-    top = rows[0]
-    roof = {"kernel": top["kernel"], "bound": "mfma", "achieved": round(top["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-            "avg_launch_us": round(top["avg_us"], 2), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+    for (op, sym), grp in groups.items():
+        for fn in grp["fns"]:
+            fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for fn in grp["fns"]:
+                fn()
+        graph.replay(); torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            graph.replay()
+        e.record(); torch.cuda.synchronize()
+        sec = s.elapsed_time(e) * 1e-3 / reps
+        cnt = len(grp["fns"])
+        rows.append({"op": "linear_" + op, "kernel": sym + (" (+ slab_reduce_k)" if op == "wgrad" else ""),
+                     "launches_per_step": cnt, "avg_us": 1e6 * sec / cnt, "gflop_per_launch": grp["flops"] / cnt / 1e9,
+                     "tflops": grp["flops"] / sec / 1e12, "us_per_step": 1e6 * sec})
+    rows.sort(key=lambda r: -r["us_per_step"])
+    top = [r for r in rows if r["op"] != "linear_wgrad"][0]
+    roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
+            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": None, "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
+            "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
     return roof, rows
 
 

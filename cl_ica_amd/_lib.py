@@ -52,6 +52,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_linear_fwd": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_i64, c_i32, C.c_float, C.c_void_p],
     "clica_linear_dgrad": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, C.c_float, c_f32p, c_i64, c_i64, c_i64, c_i64, C.c_void_p],
     "clica_linear_wgrad_workspace_bytes": [c_i64, c_i64, c_i64, C.POINTER(c_size)],
+    "clica_linear_plan": [c_i32, c_i64, c_i64, c_i64, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)],
     "clica_linear_wgrad": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i64, c_i32, C.c_void_p, c_size, C.c_void_p],
     "clica_rescale_fwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
     "clica_rescale_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],

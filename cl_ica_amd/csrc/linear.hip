@@ -376,6 +376,18 @@ static int env_cfg(const char* name) {   // tuning hook: CLICA_GEMM_CFG_{FWD,DGR
   return v ? atoi(v) : -1;
 }
 
+// measured on MI355X (tools/gemm_bench.py): wide outputs -> 96x128 tiles, two 4-wave workgroups per
+// CU; narrow outputs (N <= 128, one tile column) -> 64x128 for more workgroups along M
+static int cfg_fwd(int64_t N) {
+  const int e = env_cfg("CLICA_GEMM_CFG_FWD");
+  return (e >= 0 && e < kNumCfgs) ? e : ((N > 128) ? 5 : 2);
+}
+// 64x128 measured best for every encoder layer shape (B operand is read with ds_read_b32)
+static int cfg_dgrad() {
+  const int e = env_cfg("CLICA_GEMM_CFG_DGRAD");
+  return (e >= 0 && e < kNumCfgs) ? e : 2;
+}
+
 // wgrad plan: output tiles x contraction splits ~ one round of workgroups, >= 4 K tiles per split
 struct WgradPlan { int cfg, splits; int64_t k_per_split; };
 static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, int64_t Kc) {
@@ -409,11 +421,7 @@ extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int
   Args g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.Kc = K;
   g.bias = bias; g.slope = slope; g.leaky = leaky;
   { const int ab = env_cfg("CLICA_GEMM_ABLATE"); g.ablate = ab > 0 ? ab : 0; }
-  // measured on MI355X (tools/gemm_bench.py): wide outputs -> 96x128 tiles, two 4-wave workgroups per
-  // CU; narrow outputs (N <= 128, one tile column) -> 64x128 for more workgroups along M
-  int cfg = (N > 128) ? 5 : 2;
-  const int e = env_cfg("CLICA_GEMM_CFG_FWD");
-  if (e >= 0 && e < kNumCfgs) cfg = e;
+  const int cfg = cfg_fwd(N);
   return launch<true, true, EPI_BIAS_ACT>(cfg, g, 1, as_stream(stream), "clica_linear_fwd");
 }
 
@@ -427,10 +435,22 @@ extern "C" int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W,
   // dX[M,K] = dY[M,N] W[N,K]: contraction over N; B_op[kc=n][j=k] = W[n][k] (Kc strided)
   Args g{}; g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = M; g.N = K; g.Kc = N;
   g.xact = Xact; g.ldxa = ldxa; g.slope = slope;
-  int cfg = 2;   // measured best for every encoder layer shape (B operand is read with ds_read_b32)
-  const int e = env_cfg("CLICA_GEMM_CFG_DGRAD");
-  if (e >= 0 && e < kNumCfgs) cfg = e;
+  const int cfg = cfg_dgrad();
   return launch<true, false, EPI_DACT>(cfg, g, 1, as_stream(stream), "clica_linear_dgrad");
+}
+
+extern "C" int clica_linear_plan(int32_t op, int64_t M, int64_t N, int64_t K, int32_t* tile_m, int32_t* tile_n,
+                                 int32_t* waves, int32_t* splits) {
+  CLICA_CHECK_ARG(op >= 0 && op <= 2 && M > 0 && N > 0 && K > 0, "clica_linear_plan: bad argument");
+  int cfg, sp = 1;
+  if (op == 0) cfg = cfg_fwd(N);
+  else if (op == 1) cfg = cfg_dgrad();
+  else { const WgradPlan p = plan_wgrad(N, K, M); cfg = p.cfg; sp = p.splits; }
+  if (tile_m) *tile_m = kCfgs[cfg].bm;
+  if (tile_n) *tile_n = kCfgs[cfg].bn;
+  if (waves) *waves = kCfgs[cfg].wm * kCfgs[cfg].wn;
+  if (splits) *splits = sp;
+  return CLICA_OK;
 }
 
 extern "C" int clica_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes) {

@@ -21,6 +21,7 @@
 #pragma once
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace clica {
 namespace lp {
@@ -319,8 +320,12 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
   P.np = pad_dim(n);
   P.R = bwd ? owners_bwd(P.np) : owners_fwd(P.np);
   P.tiles = ceil_div(n_own, (int64_t)THREADS * P.R);
-  // aim for ~4 workgroups per CU; each split covers a whole number of LDS tiles
-  int64_t want = ceil_div((int64_t)kNumCU * 4, P.tiles);
+  // aim for ~8 workgroups per CU (VALU-bound all-pairs loop: needs >= 4 waves per SIMD to cover the
+  // LDS-broadcast and exp latencies); each split covers a whole number of LDS tiles.  Tunable:
+  // CLICA_LP_WG_PER_CU.
+  const char* env = getenv("CLICA_LP_WG_PER_CU");
+  const int per_cu = env ? atoi(env) : 8;
+  int64_t want = ceil_div((int64_t)kNumCU * per_cu, P.tiles);
   int64_t max_split = ceil_div(n_str, (int64_t)TS);
   int64_t ns = want < 1 ? 1 : (want > max_split ? max_split : want);
   if (ns < 1) ns = 1;

@@ -51,7 +51,7 @@ class ContrastiveTrainer:
                  p: float = 2, tau: float = 1.0, alpha: float = 0.5, lr: float = 1e-4, g_slope: float = 0.2,
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, overlap_backward: bool = True):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -60,6 +60,7 @@ class ContrastiveTrainer:
         self.p, self.tau, self.alpha = float(p), float(tau), float(alpha)
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.g_slope = float(g_slope)
+        self.overlap_backward = bool(overlap_backward)
         self.gW = g_weights.detach().to(self.device, torch.float32).contiguous()
         assert self.gW.shape[1:] == (self.n, self.n)
         self.pg = process_group
@@ -125,7 +126,8 @@ class ContrastiveTrainer:
         self.y = torch.empty((R, n), **f32) if self.head is not None else self.acts[-1]
         self.inv_norm = torch.empty((R,), **f32) if isinstance(self.head, ls.RescaleLayer) else None
         wmax = max(widths + [n])
-        self.dbuf = [torch.empty((R, wmax), **f32), torch.empty((R, wmax), **f32)]
+        self.dbuf = [torch.empty((R, wmax), **f32) for _ in range(3)]
+        self.side_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.overlap_backward) else None
         self.dy = torch.empty((R, n), **f32)
         self.loss_out = torch.empty(3 * B + 3, **f32)
         Bg = B * self.world
@@ -226,18 +228,43 @@ class ContrastiveTrainer:
                 hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
                 torch.sum(self.head_part, dim=0, out=self._gviews[id(hp)])
             g = self.dpre
+        # Two streams: wgrad_l (weight/bias gradients into the arena, + bucket all-reduce) runs on the side
+        # stream while the main stream continues the dZ chain with dgrad_l -- the two GEMMs are
+        # independent given dZ_l, and each hides the other's prologue / epilogue-store bubbles.  Three dZ
+        # buffers rotate; a buffer is rewritten only after the wgrad that read it has finished.
         L = len(self.linears)
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        side = self.side_stream
+        two = side is not None and main is not None
+        reader_done = {}        # dZ buffer index -> event of the wgrad that reads it
+        buf_of_g = None         # index into self.dbuf holding the current dZ (None: self.dy / self.dpre)
+        nxt = 0
         for l in reversed(range(L)):
             lin = self.linears[l]
             inp = self.acts[l - 1] if l > 0 else self.x
-            ops.linear_wgrad(g, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)], accumulate=False,
-                             ws=self.wgrad_ws)
-            if self.buckets is not None:
-                self.buckets.layer_done(L - 1 - l)
+            if two:
+                side.wait_stream(main)                      # dZ_l is complete on main
+                with torch.cuda.stream(side):
+                    ops.linear_wgrad(g, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)],
+                                     accumulate=False, ws=self.wgrad_ws)
+                    if self.buckets is not None:
+                        self.buckets.layer_done(L - 1 - l)
+                    if buf_of_g is not None:
+                        ev = torch.cuda.Event(); ev.record(side); reader_done[buf_of_g] = ev
+            else:
+                ops.linear_wgrad(g, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)], accumulate=False,
+                                 ws=self.wgrad_ws)
+                if self.buckets is not None:
+                    self.buckets.layer_done(L - 1 - l)
             if l > 0:
-                out = self.dbuf[l & 1][:, :lin.in_features]
+                if two and nxt in reader_done:
+                    main.wait_event(reader_done.pop(nxt))    # WAR: the wgrad that read this buffer is done
+                out = self.dbuf[nxt][:, :lin.in_features]
                 ops.linear_dgrad(g, lin.weight, inp, self.slope, out=out)
-                g = out
+                g, buf_of_g = out, nxt
+                nxt = (nxt + 1) % len(self.dbuf)
+        if two:
+            main.wait_stream(side)
         if self.buckets is not None:
             self.buckets.wait()
 
@@ -274,6 +301,9 @@ class ContrastiveTrainer:
         so replays advance them)."""
         if self.dp:
             raise NotImplementedError("graph capture is single-GPU; the DP path runs eagerly")
+        # warm-up launches (lazy kernel-attribute setup, allocator) must not count as training: snapshot
+        # and restore parameters, optimizer state and the device step / RNG counter around them
+        snap = [t.clone() for t in (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev)]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -281,6 +311,8 @@ class ContrastiveTrainer:
                 self._step_body(True)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
+        for dst, src in zip((self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev), snap):
+            dst.copy_(src)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             self._step_body(True)

@@ -72,6 +72,13 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: Optional[torch.Tensor] =
     return dW, db
 
 
+def linear_plan(op: str, M: int, N: int, K: int):
+    """(tile_m, tile_n, waves, splits) of the kernel instance a Linear launch of this shape uses."""
+    v = [C.c_int32() for _ in range(4)]
+    check(load().clica_linear_plan({"fwd": 0, "dgrad": 1, "wgrad": 2}[op], M, N, K, *[C.byref(x) for x in v]), "clica_linear_plan")
+    return tuple(x.value for x in v)
+
+
 # ------------------------------------------------------------------------------- heads
 def rescale_fwd(x, r):
     (x, ldx) = _mat("x", x)

@@ -52,7 +52,7 @@ int clica_version(void);
 typedef struct clica_lp_loss_desc {
   int64_t B;       /* rows of z1 and z2                                  */
   int64_t B3;      /* rows of z3                                         */
-  int32_t n;       /* embedding dimension (1..4096)                      */
+  int32_t n;       /* embedding dimension (1..64)                        */
   float p;         /* exponent of the norm (1, 2, 3 fast paths; any p>0) */
   float tau;
   float alpha;
@@ -137,6 +137,11 @@ int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W, int64_t ld
                        float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K,
                        clica_stream_t stream);
 int clica_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes);
+/* Which kernel instance a launch of this shape uses (host-only query for profiling / benches):
+ * op 0 = fwd, 1 = dgrad, 2 = wgrad; returns the workgroup tile, waves per workgroup and, for wgrad,
+ * the number of contraction splits.  The kernel symbol is gemm_k<tile_m, tile_n, ...>. */
+int clica_linear_plan(int32_t op, int64_t M, int64_t N, int64_t K, int32_t* tile_m, int32_t* tile_n,
+                      int32_t* waves, int32_t* splits);
 int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ldx,
                        float* dW, int64_t lddw, float* db, int64_t M, int64_t N, int64_t K,
                        int32_t accumulate, void* workspace, size_t workspace_bytes,

@@ -92,7 +92,7 @@ def test_graph_replay_trains():
     for _ in range(60):
         out = tr.step()
     torch.cuda.synchronize()
-    assert tr.steps_done == 1 + 2 + 60      # the capture pass itself records, it does not execute
+    assert tr.steps_done == 1 + 60          # capture() is side-effect free (warm-up is rolled back)
     assert not torch.equal(z_before, tr.z)                     # RNG advanced across replays
     assert torch.isfinite(out).all() and out[0].item() < first[0].item() - 0.05
     assert float(tr.z.min()) >= 0.0 and float(tr.z.max()) <= 1.0

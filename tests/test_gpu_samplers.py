@@ -27,7 +27,8 @@ def test_box(golden):
     assert np.abs(q(zc, qs) - z9["box_uniform/q"]).max() < 0.012
     d = ztc - zc
     assert np.abs(d.var(0) - z9["box_normal/delta_var"]).max() < 1e-4
-    assert np.abs(q(d, qs) - z9["box_normal/delta_q"]).max() < 3e-3
+    assert np.abs(q(d, qs)[1:-1] - z9["box_normal/delta_q"][1:-1]).max() < 2e-3     # interior quantiles
+    assert np.abs(q(d, qs) - z9["box_normal/delta_q"]).max() < 8e-3                # 1%/99%: sampling noise of two 1e5 draws
     # independence of successive calls and of rows
     z2 = box.uniform(N, device="cuda").cpu().numpy()
     assert abs(np.corrcoef(zc[:, 0], z2[:, 0])[0, 1]) < 0.02

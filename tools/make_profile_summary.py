@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/profile_<tag>/ (rocprofv3 kernel-trace stats + PMC passes, see
+tools/profile_round.sh) into profiles/<tag>_*.{csv,md} -- the committed, judged artefacts."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = f"gpurun_out/profile_{tag}"
+os.makedirs("profiles", exist_ok=True)
+shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        d[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"_n": len(next(iter(cs.values())))} for k, cs in d.items()}
+
+
+pm = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+    p = f"{src}/{name}/p_counter_collection.csv"
+    if os.path.exists(p):
+        for k, v in agg(p).items():
+            pm.setdefault(k, {}).update(v)
+stats = list(csv.DictReader(open(f"{src}/trace/t_kernel_stats.csv")))
+bench = json.load(open(f"{src}/bench_under_rocprof.json"))
+lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline`", "",
+         f"bench line under the profiler: {bench['value']:.1f} steps/s, {bench['ms_per_step']:.3f} ms/step; roofline entry: "
+         f"`{bench['roofline']['kernel']}` {bench['roofline']['achieved']} TFLOP/s ({bench['roofline']['frac']:.3f} of 157.3), "
+         f"avg {bench['roofline']['avg_launch_us']} us/launch (graph replay between HIP events).", "",
+         "PMC columns come from separate `--pmc` passes (FETCH_SIZE / WRITE_SIZE in KB per launch, as reported; per "
+         "MI355X_MICROARCH.md FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 -> `fetch_x2_MB`). "
+         "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs).", "",
+         "| kernel | calls | avg us | % time | fetch_x2 MB | write MB | MfmaUtil | LDS bank conflicts |", "|---|---|---|---|---|---|---|---|"]
+for r in stats:
+    name = r["Name"]
+    c = pm.get(name, {})
+    fetch = f"{2 * c['FETCH_SIZE'] / 1024:.1f}" if "FETCH_SIZE" in c else ""
+    write = f"{c['WRITE_SIZE'] / 1024:.1f}" if "WRITE_SIZE" in c else ""
+    util = ""
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and c.get("GRBM_GUI_ACTIVE", 0) > 0:
+        util = f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.2f}"
+    conf = f"{c['SQ_LDS_BANK_CONFLICT']:.0f}" if "SQ_LDS_BANK_CONFLICT" in c else ""
+    short = name.split("(")[0].replace("void ", "")
+    lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {util} | {conf} |")
+open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:14]))
