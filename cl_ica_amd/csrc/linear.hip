@@ -288,14 +288,27 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
   const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * U;
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < total) {
-    for (int s = w; s < splits; s += RED_THREADS / 64) {
-      if (VEC4) {
-        const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * total + e);
-        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-      } else {
-        t.x += slab[(int64_t)s * total + e];
+    constexpr int W = RED_THREADS / 64;
+    // four loads in flight per thread (independent partial sums), folded in a fixed order
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s0 = w; s0 < splits; s0 += 4 * W) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = s0 + u * W;
+        if (s < splits) {
+          if (VEC4) {
+            const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * total + e);
+            p[u].x += v.x; p[u].y += v.y; p[u].z += v.z; p[u].w += v.w;
+          } else {
+            p[u].x += slab[(int64_t)s * total + e];
+          }
+        }
       }
     }
+    t.x = (p[0].x + p[1].x) + (p[2].x + p[3].x); t.y = (p[0].y + p[1].y) + (p[2].y + p[3].y);
+    t.z = (p[0].z + p[1].z) + (p[2].z + p[3].z); t.w = (p[0].w + p[1].w) + (p[2].w + p[3].w);
   }
   red[w][lane] = t;
   __syncthreads();
@@ -315,8 +328,13 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
   // db: the first blocks also reduce the bias slab (M entries)
   const int64_t bi = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x;
   if (db && bi < M) {
-    float tb = 0.f;
-    for (int s = 0; s < splits; ++s) tb += dbslab[(int64_t)s * M + bi];
+    float pb[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (s0 + u < splits) pb[u] += dbslab[(int64_t)(s0 + u) * M + bi];
+    }
+    const float tb = (pb[0] + pb[1]) + (pb[2] + pb[3]);
     db[bi] = accumulate ? (db[bi] + tb) : tb;
   }
 }

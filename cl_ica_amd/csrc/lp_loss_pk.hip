@@ -1,6 +1,7 @@
 // One exponent kind (CLICA_PK = 0 generic, 1, 2, 3; 4 = dot product) of the pairwise-Lp kernels; compiled four
 // times so the 8 padded dims x 3 kernels x 4 kinds instantiate in parallel.
 #include "lp_kernels.h"
+#include <stdlib.h>
 #ifndef CLICA_PK
 #error "compile with -DCLICA_PK=0|1|2|3|4"
 #endif

@@ -33,9 +33,13 @@ def run(B, B3, n, p, reps=20):
     return res
 
 if __name__ == "__main__":
-    for per_cu in (2, 4, 8, 16):
-        os.environ["CLICA_LP_WG_PER_CU"] = str(per_cu)
-        for (B, B3, n, p) in ((6144, 6144, 10, 2), (6144, 6144, 10, 1), (6144, 49152, 40, 1)):
+    import subprocess
+    if len(sys.argv) > 1 and sys.argv[1] == "one":
+        for (B, B3, n, p) in ((6144, 6144, 10, 2), (6144, 6144, 10, 1), (6144, 49152, 10, 2)):
             f, b = run(B, B3, n, p)
-            pairs = B * B3
-            print(f"wg/cu {per_cu:2d} B={B} B3={B3} n={n} p={p}: fwd {f:8.1f} us ({pairs/f/1e3:7.1f} Gpair/s)  bwd {b:8.1f} us")
+            print(f"SMEM={os.environ.get('CLICA_LP_SMEM','0')} WG/CU={os.environ.get('CLICA_LP_WG_PER_CU','8')} B={B} B3={B3} n={n} p={p}: fwd {f:8.1f} us ({B*B3/f/1e3:7.1f} Gpair/s)  bwd {b:8.1f} us")
+    else:   # the variant switch is read once per process -> one subprocess per setting
+        for smem in ("0", "1", "2", "4"):
+            for per_cu in ("8", "16"):
+                env = dict(os.environ, CLICA_LP_SMEM=smem, CLICA_LP_WG_PER_CU=per_cu)
+                subprocess.run([sys.executable, __file__, "one"], env=env)
