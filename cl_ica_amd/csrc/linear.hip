@@ -20,6 +20,12 @@
 #include <stdlib.h>
 
 namespace clica {
+// skinny.hip: VALU kernels for layers with a tiny contraction or output width
+bool skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* Y, int64_t ldy,
+                int64_t M, int64_t N, int64_t K, int leaky, float slope, hipStream_t st);
+bool skinny_dgrad(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact, int64_t ldxa, float slope,
+                  float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K, hipStream_t st);
+
 namespace gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -274,69 +280,86 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
 
 // dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i].
 // A block owns 64 consecutive output units (float4 when the row length allows, else float); its
-// four waves each sum a quarter of the splits (s = w, w+4, ...), then wave 0 adds the four partial
-// sums in wave order: fixed summation order, and the split loop is 4x shorter and 4x more parallel.
+// four waves each sum a quarter of the splits (s = w, w+4, ...) with four loads in flight, then wave 0
+// adds the four partial sums in wave order: fixed summation order, short dependent-load chains.
 template <bool VEC4>
-__global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __restrict__ slab, int splits, int64_t M, int64_t N,
-                                                            float* __restrict__ dW, int64_t lddw,
-                                                            const float* __restrict__ dbslab, float* __restrict__ db,
-                                                            int accumulate) {
-  __shared__ float4 red[RED_THREADS / 64][64];
+__device__ __forceinline__ void reduce_units(const float* __restrict__ src, int splits, int64_t total, int64_t unit0,
+                                             float4 (*red)[64], float4& t, int64_t& e) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   constexpr int U = VEC4 ? 4 : 1;
-  const int64_t total = M * N;
-  const int64_t e = ((int64_t)blockIdx.x * 64 + lane) * U;
-  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e < total) {
-    constexpr int W = RED_THREADS / 64;
-    // four loads in flight per thread (independent partial sums), folded in a fixed order
-    float4 p[4];
+  constexpr int W = RED_THREADS / 64;
+  e = (unit0 + lane) * U;
+  float4 p[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int u = 0; u < 4; ++u) p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total) {
     for (int s0 = w; s0 < splits; s0 += 4 * W) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int s = s0 + u * W;
         if (s < splits) {
           if (VEC4) {
-            const float4 v = *reinterpret_cast<const float4*>(slab + (int64_t)s * total + e);
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)s * total + e);
             p[u].x += v.x; p[u].y += v.y; p[u].z += v.z; p[u].w += v.w;
           } else {
-            p[u].x += slab[(int64_t)s * total + e];
+            p[u].x += src[(int64_t)s * total + e];
           }
         }
       }
     }
-    t.x = (p[0].x + p[1].x) + (p[2].x + p[3].x); t.y = (p[0].y + p[1].y) + (p[2].y + p[3].y);
-    t.z = (p[0].z + p[1].z) + (p[2].z + p[3].z); t.w = (p[0].w + p[1].w) + (p[2].w + p[3].w);
   }
+  t.x = (p[0].x + p[1].x) + (p[2].x + p[3].x); t.y = (p[0].y + p[1].y) + (p[2].y + p[3].y);
+  t.z = (p[0].z + p[1].z) + (p[2].z + p[3].z); t.w = (p[0].w + p[1].w) + (p[2].w + p[3].w);
   red[w][lane] = t;
   __syncthreads();
-  if (w == 0 && e < total) {
+  if (w == 0) {
 #pragma unroll
-    for (int k = 1; k < RED_THREADS / 64; ++k) { const float4 v = red[k][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-    const int64_t i = e / N, j = e - i * N;
-    if (VEC4) {
-      float4* dst = reinterpret_cast<float4*>(dW + i * lddw + j);
-      if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-      *dst = t;
-    } else {
-      float* dst = dW + i * lddw + j;
-      *dst = accumulate ? (*dst + t.x) : t.x;
-    }
+    for (int k = 1; k < W; ++k) { const float4 v = red[k][lane]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
   }
-  // db: the first blocks also reduce the bias slab (M entries)
-  const int64_t bi = (int64_t)blockIdx.x * RED_THREADS + threadIdx.x;
-  if (db && bi < M) {
-    float pb[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int s0 = 0; s0 < splits; s0 += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (s0 + u < splits) pb[u] += dbslab[(int64_t)(s0 + u) * M + bi];
+  __syncthreads();
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __restrict__ slab, int splits, int64_t M, int64_t N,
+                                                            float* __restrict__ dW, int64_t lddw,
+                                                            const float* __restrict__ dbslab, float* __restrict__ db,
+                                                            int accumulate, int dw_blocks) {
+  __shared__ float4 red[RED_THREADS / 64][64];
+  const int w = threadIdx.x >> 6;
+  float4 t; int64_t e;
+  if ((int)blockIdx.x < dw_blocks) {
+    const int64_t total = M * N;
+    reduce_units<VEC4>(slab, splits, total, (int64_t)blockIdx.x * 64, red, t, e);
+    if (w == 0 && e < total) {
+      const int64_t i = e / N, j = e - i * N;
+      if (VEC4) {
+        float4* dst = reinterpret_cast<float4*>(dW + i * lddw + j);
+        if (accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *dst = t;
+      } else {
+        float* dst = dW + i * lddw + j;
+        *dst = accumulate ? (*dst + t.x) : t.x;
+      }
     }
-    const float tb = (pb[0] + pb[1]) + (pb[2] + pb[3]);
-    db[bi] = accumulate ? (db[bi] + tb) : tb;
+  } else {   // trailing blocks: the bias slab (M entries per split), same scheme
+    reduce_units<false>(dbslab, splits, M, (int64_t)((int)blockIdx.x - dw_blocks) * 64, red, t, e);
+    if (w == 0 && e < M) db[e] = accumulate ? (db[e] + t.x) : t.x;
   }
+}
+
+// one launch: ceil(units/64) blocks for dW followed by ceil(M/64) blocks for db
+static void launch_slab_reduce(const float* slab, const float* dbslab, int splits, int64_t M, int64_t N, float* dW, int64_t lddw,
+                               float* db, int accumulate, hipStream_t st) {
+  const int64_t total = M * N;
+  const bool v4 = (N % 4 == 0) && (lddw % 4 == 0) && ((reinterpret_cast<uintptr_t>(dW) & 15) == 0);
+  const int dw_blocks = (int)ceil_div(v4 ? total / 4 : total, 64);
+  const int db_blocks = db ? (int)ceil_div(M, 64) : 0;
+  if (v4)
+    hipLaunchKernelGGL(slab_reduce_k<true>, dim3((unsigned)(dw_blocks + db_blocks)), dim3(RED_THREADS), 0, st, slab, splits, M, N, dW, lddw,
+                       dbslab, db, accumulate, dw_blocks);
+  else
+    hipLaunchKernelGGL(slab_reduce_k<false>, dim3((unsigned)(dw_blocks + db_blocks)), dim3(RED_THREADS), 0, st, slab, splits, M, N, dW, lddw,
+                       dbslab, db, accumulate, dw_blocks);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -394,6 +417,11 @@ static int env_cfg(const char* name) {   // tuning hook: CLICA_GEMM_CFG_{FWD,DGR
   return v ? atoi(v) : -1;
 }
 
+static bool use_skinny() {   // CLICA_SKINNY=0 forces every shape through the MFMA template (A/B, tests)
+  const char* v = getenv("CLICA_SKINNY");
+  return !(v && atoi(v) == 0);
+}
+
 // measured on MI355X (tools/gemm_bench.py): wide outputs -> 96x128 tiles, two 4-wave workgroups per
 // CU; narrow outputs (N <= 128, one tile column) -> 64x128 for more workgroups along M
 static int cfg_fwd(int64_t N) {
@@ -436,6 +464,8 @@ extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int
   CLICA_CHECK_ARG(X && W && Y, "clica_linear_fwd: NULL pointer");
   CLICA_CHECK_ARG(M > 0 && N > 0 && K > 0, "clica_linear_fwd: M=%lld N=%lld K=%lld must be positive", (long long)M, (long long)N, (long long)K);
   CLICA_CHECK_ARG(ldx >= K && ldw >= K && ldy >= N, "clica_linear_fwd: leading dimension too small");
+  if (use_skinny() && skinny_fwd(X, ldx, W, ldw, bias, Y, ldy, M, N, K, leaky, slope, as_stream(stream)))
+    return launch_status("clica_linear_fwd(skinny)");
   Args g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.Kc = K;
   g.bias = bias; g.slope = slope; g.leaky = leaky;
   { const int ab = env_cfg("CLICA_GEMM_ABLATE"); g.ablate = ab > 0 ? ab : 0; }
@@ -450,6 +480,8 @@ extern "C" int clica_linear_dgrad(const float* dY, int64_t lddy, const float* W,
   CLICA_CHECK_ARG(dY && W && dX, "clica_linear_dgrad: NULL pointer");
   CLICA_CHECK_ARG(M > 0 && N > 0 && K > 0, "clica_linear_dgrad: sizes must be positive");
   CLICA_CHECK_ARG(lddy >= N && ldw >= K && lddx >= K && (!Xact || ldxa >= K), "clica_linear_dgrad: leading dimension too small");
+  if (use_skinny() && skinny_dgrad(dY, lddy, W, ldw, Xact, ldxa, slope, dX, lddx, M, N, K, as_stream(stream)))
+    return launch_status("clica_linear_dgrad(skinny)");
   // dX[M,K] = dY[M,N] W[N,K]: contraction over N; B_op[kc=n][j=k] = W[n][k] (Kc strided)
   Args g{}; g.A = dY; g.lda = lddy; g.B = W; g.ldb = ldw; g.C = dX; g.ldc = lddx; g.M = M; g.N = K; g.Kc = N;
   g.xact = Xact; g.ldxa = ldxa; g.slope = slope;
@@ -489,6 +521,7 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   CLICA_CHECK_ARG(dY && X && dW && workspace, "clica_linear_wgrad: NULL pointer");
   CLICA_CHECK_ARG(M > 0 && N > 0 && K > 0, "clica_linear_wgrad: sizes must be positive");
   CLICA_CHECK_ARG(lddy >= N && ldx >= K && lddw >= K, "clica_linear_wgrad: leading dimension too small");
+  hipStream_t st = as_stream(stream);
   const WgradPlan p = plan_wgrad(N, K, M);
   const size_t slab_bytes = align_up((size_t)p.splits * N * K * sizeof(float), 256);
   const size_t need = slab_bytes + align_up((size_t)p.splits * N * sizeof(float), 256);
@@ -499,20 +532,8 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   Args g{}; g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = K; g.M = N; g.N = K; g.Kc = M;
   g.k_per_split = p.k_per_split;
   g.dbias_slab = db ? dbslab : nullptr;
-  hipStream_t st = as_stream(stream);
   int rc = launch<false, false, EPI_SLAB>(p.cfg, g, p.splits, st, "clica_linear_wgrad");
   if (rc) return rc;
-  const int64_t total = N * K;
-  const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW);
-  const int64_t units = v4 ? total / 4 : total;
-  int64_t nb = ceil_div(units, 64);
-  if (db && nb < ceil_div(N, RED_THREADS)) nb = ceil_div(N, RED_THREADS);
-  const unsigned blocks = (unsigned)nb;
-  if (v4)
-    hipLaunchKernelGGL(slab_reduce_k<true>, dim3(blocks), dim3(RED_THREADS), 0, st, (const float*)slab, p.splits, N, K, dW, lddw,
-                       (const float*)dbslab, db, accumulate ? 1 : 0);
-  else
-    hipLaunchKernelGGL(slab_reduce_k<false>, dim3(blocks), dim3(RED_THREADS), 0, st, (const float*)slab, p.splits, N, K, dW, lddw,
-                       (const float*)dbslab, db, accumulate ? 1 : 0);
+  launch_slab_reduce(slab, dbslab, p.splits, N, K, dW, lddw, db, accumulate ? 1 : 0, st);
   return launch_status("clica_linear_wgrad(reduce)");
 }

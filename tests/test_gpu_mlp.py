@@ -14,9 +14,14 @@ def dev(a):
 
 
 @pytest.mark.parametrize("M,N,K", [(48, 40, 4), (300, 100, 10), (1000, 500, 100), (12288, 500, 500), (257, 10, 100),
-                                   (129, 131, 67), (64, 2000, 400), (5, 3, 1)])
-def test_linear_kernels_vs_fp64(M, N, K):
+                                   (129, 131, 67), (64, 2000, 400), (5, 3, 1), (12288, 100, 10), (12288, 10, 100),
+                                   (777, 16, 16), (1000, 5, 256), (130, 400, 16)])
+@pytest.mark.parametrize("skinny", ["1", "0"])
+def test_linear_kernels_vs_fp64(M, N, K, skinny, monkeypatch):
+    """skinny=1: tiny-K / tiny-N layers take the VALU kernels (csrc/skinny.hip); skinny=0 forces every
+    shape through the MFMA template.  Both must match fp64."""
     from cl_ica_amd import ops
+    monkeypatch.setenv("CLICA_SKINNY", skinny)
     rng = np.random.default_rng(M * 7 + N)
     x = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.uniform(-1, 1, size=(N, K)) / np.sqrt(K)).astype(np.float32)
