@@ -177,9 +177,22 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     tr = build_trainer(args, device, world)
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = not args.no_graph
     if use_graph:
-        tr.capture()
+        try:
+            tr.capture()
+        except Exception as e:   # e.g. a RCCL build that cannot capture collectives: run eagerly, say so
+            if world == 1:
+                raise
+            print(f"[bench] graph capture with collectives failed on rank {rank} ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            use_graph = False
+            tr.graph = None
+        if world > 1:
+            ok = torch.tensor([1 if use_graph else 0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                use_graph = False
+                tr.graph = None
     for _ in range(args.warmup):
         tr.step()
     if world > 1:

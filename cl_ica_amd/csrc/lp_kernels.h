@@ -122,20 +122,31 @@ __device__ __forceinline__ float droot_of(float s, const Params& q) {
 }
 
 // ---- staging -----------------------------------------------------------------------------
-// branch-free: masked-out elements read element 0 and are zeroed by a select
+// Global -> registers -> LDS, split in two so the global loads of tile t+1 are in flight while tile t
+// is being consumed (double-buffered LDS, one barrier per tile).  Branch-free: masked-out elements
+// read element 0 and are zeroed by a select at store time.
 template <int NP>
-__device__ __forceinline__ void stage_tile(float* tile, const float* __restrict__ str, int64_t lds,
-                                           int64_t j0, int cnt, int n) {
+struct Stager {
+  static constexpr int ITERS = (TS * NP + THREADS - 1) / THREADS;
+  float v[ITERS];
+  __device__ __forceinline__ void load(const float* __restrict__ str, int64_t lds, int64_t j0, int cnt, int n) {
 #pragma unroll
-  for (int it = 0; it < (TS * NP + THREADS - 1) / THREADS; ++it) {
-    const int idx = threadIdx.x + it * THREADS;
-    if ((TS * NP) % THREADS != 0 && idx >= TS * NP) break;
-    const int row = idx / NP, k = idx - row * NP;
-    const bool ok = row < cnt && k < n;
-    const float v = str[ok ? (j0 + row) * lds + k : 0];
-    tile[idx] = ok ? v : 0.f;
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = threadIdx.x + it * THREADS;
+      const int row = idx / NP, k = idx - row * NP;
+      const bool ok = idx < TS * NP && row < cnt && k < n;
+      const float x = str[ok ? (j0 + row) * lds + k : 0];
+      v[it] = ok ? x : 0.f;
+    }
   }
-}
+  __device__ __forceinline__ void store(float* tile) const {
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int idx = threadIdx.x + it * THREADS;
+      if ((TS * NP) % THREADS == 0 || idx < TS * NP) tile[idx] = v[it];
+    }
+  }
+};
 
 template <int NP, int R>
 __device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* __restrict__ own, int64_t ldo,
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, float2* __restrict__ part, int chunk) {
-  __shared__ __attribute__((aligned(16))) float tile[TS * NP];
+  __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
   const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
   f32x2 o[R][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
@@ -190,11 +201,18 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 
   const int64_t jb = (int64_t)blockIdx.y * chunk;
   const int64_t je = min(n_str, jb + (int64_t)chunk);
-  for (int64_t j0 = jb; j0 < je; j0 += TS) {
+  Stager<NP> st;
+  if (jb < je) {
+    st.load(str, lds, jb, (int)min((int64_t)TS, je - jb), q.n);
+    st.store(tiles[0]);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t j0 = jb; j0 < je; j0 += TS, cur ^= 1) {
     const int cnt = (int)min((int64_t)TS, je - j0);
-    __syncthreads();
-    stage_tile<NP>(tile, str, lds, j0, cnt, q.n);
-    __syncthreads();
+    const bool more = j0 + TS < je;
+    if (more) st.load(str, lds, j0 + TS, (int)min((int64_t)TS, je - j0 - TS), q.n);   // in flight during the tile
+    const float* tile = tiles[cur];
     for (int jj = 0; jj < cnt; jj += JB) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -215,6 +233,8 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
         m[r] = mn;
       }
     }
+    if (more) st.store(tiles[cur ^ 1]);     // last read one iteration ago, behind the previous barrier
+    __syncthreads();
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -232,8 +252,8 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, const float* __restrict__ statL, const float* __restrict__ statC,
     float* __restrict__ part, int chunk) {
-  __shared__ __attribute__((aligned(16))) float tile[TS * NP];
-  __shared__ float tL[TS], tC[TS];
+  __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
+  __shared__ float tLs[2][TS], tCs[2][TS];
   const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
   f32x2 o[R][NP / 2], g[R][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
@@ -250,17 +270,36 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
   const float csgn = (PK == 0) ? q.sgn : 1.f;
   const int64_t jb = (int64_t)blockIdx.y * chunk;
   const int64_t je = min(n_str, jb + (int64_t)chunk);
-  for (int64_t j0 = jb; j0 < je; j0 += TS) {
-    const int cnt = (int)min((int64_t)TS, je - j0);
-    __syncthreads();
-    stage_tile<NP>(tile, str, lds, j0, cnt, q.n);
+  Stager<NP> st;
+  float rl = 0.f, rc = 0.f;     // staged stream statistics (threads < TS)
+  auto load_stats = [&](int64_t j0, int cnt) {
     if (!OWNER_STATS && threadIdx.x < TS) {
       const bool ok = threadIdx.x < cnt;
       const float l = statL[ok ? j0 + threadIdx.x : 0], c = statC[ok ? j0 + threadIdx.x : 0];
-      tL[threadIdx.x] = ok ? l : 0.f;
-      tC[threadIdx.x] = ok ? c : 0.f;     // zero coefficient masks the ragged tail
+      rl = ok ? l : 0.f;
+      rc = ok ? c : 0.f;         // zero coefficient masks the ragged tail
     }
-    __syncthreads();
+  };
+  auto store_stats = [&](int b) {
+    if (!OWNER_STATS && threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = rc; }
+  };
+  if (jb < je) {
+    const int c0 = (int)min((int64_t)TS, je - jb);
+    st.load(str, lds, jb, c0, q.n); load_stats(jb, c0);
+    st.store(tiles[0]); store_stats(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t j0 = jb; j0 < je; j0 += TS, cur ^= 1) {
+    const int cnt = (int)min((int64_t)TS, je - j0);
+    const bool more = j0 + TS < je;
+    if (more) {
+      const int c1 = (int)min((int64_t)TS, je - j0 - TS);
+      st.load(str, lds, j0 + TS, c1, q.n); load_stats(j0 + TS, c1);
+    }
+    const float* tile = tiles[cur];
+    const float* tL = tLs[cur];
+    const float* tC = tCs[cur];
     for (int jj = 0; jj < cnt; jj += JB) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -288,6 +327,8 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
         }
       }
     }
+    if (more) { st.store(tiles[cur ^ 1]); store_stats(cur ^ 1); }
+    __syncthreads();
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {

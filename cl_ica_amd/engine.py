@@ -297,10 +297,10 @@ class ContrastiveTrainer:
         return self.loss_out[3 * self.B:]
 
     def capture(self, warmup: int = 3):
-        """Capture the step into a HIP graph (single-GPU; counters and RNG offsets live on device,
-        so replays advance them)."""
-        if self.dp:
-            raise NotImplementedError("graph capture is single-GPU; the DP path runs eagerly")
+        """Capture the step into a HIP graph (counters and RNG offsets live on device, so replays
+        advance them).  With data parallelism the RCCL collectives (all-gather, reduce-scatter, bucketed
+        all-reduce on the side stream) are captured into the same graph; every rank must call capture()
+        and then replay in lock-step."""
         # warm-up launches (lazy kernel-attribute setup, allocator) must not count as training: snapshot
         # and restore parameters, optimizer state and the device step / RNG counter around them
         snap = [t.clone() for t in (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev)]

@@ -142,5 +142,19 @@ def test_dp_code_path_single_rank():
                 o = tr.step().clone()
             outs.append((o, tr.param_arena.clone()))
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        # the collectives are graph-capturable: captured replay == eager on the same seed
+        res = []
+        for graph in (False, True):
+            torch.manual_seed(0)
+            f = encoders.get_mlp(10, 10, [100, 500, 100])
+            tr = ContrastiveTrainer(f, torch.eye(10).repeat(3, 1, 1), SamplerSpec(n=10, seed=5), batch_size=1024, p=2,
+                                    lr=1e-3, device="cuda", process_group=dist.group.WORLD, force_collectives=True)
+            if graph:
+                tr.capture(warmup=2)
+            for _ in range(4):
+                o = tr.step().clone()
+            torch.cuda.synchronize()
+            res.append((o, tr.param_arena.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     finally:
         dist.destroy_process_group()

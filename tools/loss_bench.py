@@ -37,9 +37,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
         for (B, B3, n, p) in ((6144, 6144, 10, 2), (6144, 6144, 10, 1), (6144, 49152, 10, 2)):
             f, b = run(B, B3, n, p)
-            print(f"SMEM={os.environ.get('CLICA_LP_SMEM','0')} WG/CU={os.environ.get('CLICA_LP_WG_PER_CU','8')} B={B} B3={B3} n={n} p={p}: fwd {f:8.1f} us ({B*B3/f/1e3:7.1f} Gpair/s)  bwd {b:8.1f} us")
-    else:   # the variant switch is read once per process -> one subprocess per setting
-        for smem in ("0", "1", "2", "4"):
-            for per_cu in ("8", "16"):
-                env = dict(os.environ, CLICA_LP_SMEM=smem, CLICA_LP_WG_PER_CU=per_cu)
-                subprocess.run([sys.executable, __file__, "one"], env=env)
+            print(f"WG/CU={os.environ.get('CLICA_LP_WG_PER_CU','8')} B={B} B3={B3} n={n} p={p}: fwd {f:8.1f} us ({B*B3/f/1e3:7.1f} Gpair/s)  bwd {b:8.1f} us")
+    else:
+        for per_cu in ("8",):
+            env = dict(os.environ, CLICA_LP_WG_PER_CU=per_cu)
+            subprocess.run([sys.executable, __file__, "one"], env=env)
