@@ -151,10 +151,11 @@ def loss_leg(tr, reps=20):
     for _ in range(reps):
         ev[0].record()
         lib.clica_lp_loss_fwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
-                              o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+                              o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), tr.rowgrad.data_ptr(), n,
+                              tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         ev[1].record()
         lib.clica_lp_loss_bwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
-                              None, None, None, None, tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n,
+                              tr.rowgrad.data_ptr(), n, None, None, None, None, tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n,
                               (tr.dy[:B] if tr.world == 1 else tr.dz_all).data_ptr(), n, 0, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         ev[2].record()
         torch.cuda.synchronize()

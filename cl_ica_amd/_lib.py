@@ -36,8 +36,8 @@ class SamplerDesc(C.Structure):
                 ("seed", C.c_uint64), ("stream_id", C.c_uint32)]
 
 
-_LOSS_FWD = [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_size, C.c_void_p]
-_LOSS_BWD = [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+_LOSS_FWD = [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p]
+_LOSS_BWD = [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p,
              c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p, c_size, C.c_void_p]
 
 # name -> argtypes (restype is int for all but clica_last_error); mirrors include/clica.h

@@ -185,16 +185,26 @@ __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float
 }
 
 // ---- forward: per-split (max, sum) partials in the log2 domain -----------------------------
-template <int NP, int PK, int R, bool ROOT>
+// ROWGRAD: also accumulate G_k = sum_j 2^(x_ij - m) * p * droot * (1/p) d term / d owner_k with the same
+// running-max rescaling (the flash-attention forward with "V" = the pair's distance derivative).  After
+// the splits are merged, G / 2^(lse) is the softmax-weighted row gradient sum_j w_ij d neg_ij / d owner_i,
+// so the backward needs NO row pass: dz1 = pos-term + (-C_i / tau) * rowgrad_i for any upstream gradient.
+template <int NP, int PK, int R, bool ROOT, bool ROWGRAD>
 __global__ __launch_bounds__(THREADS) void fwd_partial_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
-    Params q, float2* __restrict__ part, int chunk) {
+    Params q, float2* __restrict__ part, float* __restrict__ part_g, int chunk) {
   __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
   const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
   f32x2 o[R][NP / 2];
+  f32x2 G[ROWGRAD ? R : 1][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
   float m[R], s[R];
+  const float csgn = (PK == 0) ? q.sgn : 1.f;
+#pragma unroll
+  for (int r = 0; r < (ROWGRAD ? R : 1); ++r)
+#pragma unroll
+    for (int k2 = 0; k2 < NP / 2; ++k2) G[r][k2] = (f32x2){0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < R; ++r) { m[r] = -INFINITY; s[r] = 0.f; }
   const float xk = q.xs * q.kscale;
@@ -226,11 +236,28 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
         }
         // clamp keeps (-inf) - (-inf) out of the exponent when nothing valid was seen yet
         const float mn = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(m[r], -1e30f));
-        float add = 0.f;
+        float add = 0.f, e[JB];
 #pragma unroll
-        for (int c = 0; c < JB; ++c) add += fexp2(x[c] - mn);
-        s[r] = fmaf(s[r], fexp2(m[r] - mn), add);
+        for (int c = 0; c < JB; ++c) { e[c] = fexp2(x[c] - mn); add += e[c]; }
+        const float resc = fexp2(m[r] - mn);
+        s[r] = fmaf(s[r], resc, add);
         m[r] = mn;
+        if (ROWGRAD) {
+#pragma unroll
+          for (int c = 0; c < JB; ++c) e[c] *= droot_of<ROOT>(acc[c], q) * csgn;
+          asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
+          const f32x2 r2 = {resc, resc};
+#pragma unroll
+          for (int k4 = 0; k4 < NP / 4; ++k4) {
+            G[r][2 * k4] *= r2; G[r][2 * k4 + 1] *= r2;
+#pragma unroll
+            for (int c = 0; c < JB; ++c) {
+              const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
+              gaccum2<PK>(G[r][2 * k4], e[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+              gaccum2<PK>(G[r][2 * k4 + 1], e[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
+            }
+          }
+        }
       }
     }
     if (more) st.store(tiles[cur ^ 1]);     // last read one iteration ago, behind the previous barrier
@@ -239,7 +266,15 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
-    if (i < n_own) part[(int64_t)blockIdx.y * n_own + i] = make_float2(m[r], s[r]);
+    if (i < n_own) {
+      part[(int64_t)blockIdx.y * n_own + i] = make_float2(m[r], s[r]);
+      if (ROWGRAD) {
+        float4* dst = reinterpret_cast<float4*>(part_g + ((int64_t)blockIdx.y * n_own + i) * NP);
+#pragma unroll
+        for (int k4 = 0; k4 < NP / 4; ++k4)
+          dst[k4] = make_float4(G[r][2 * k4].x, G[r][2 * k4].y, G[r][2 * k4 + 1].x, G[r][2 * k4 + 1].y);
+      }
+    }
   }
 }
 
@@ -382,7 +417,7 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
 #define CLICA_LP_DECLARE(PKV)                                                                          \
   void launch_fwd_partial_pk##PKV(const Plan& P, const float* own, int64_t ldo, int64_t n_own,        \
                                   const float* str, int64_t lds, int64_t n_str, const Params& q,      \
-                                  float2* part, hipStream_t st);                                      \
+                                  float2* part, float* part_g, hipStream_t st);                       \
   void launch_bwd_pairs_pk##PKV(const Plan& P, bool owner_stats, const float* own, int64_t ldo,       \
                                 int64_t n_own, const float* str, int64_t lds, int64_t n_str,          \
                                 const Params& q, const float* statL, const float* statC, float* part, \

@@ -210,14 +210,53 @@ static int exponent_kind(float p) { return p == 1.f ? 1 : (p == 2.f ? 2 : (p == 
 
 static void launch_fwd_partial(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own,
                                const float* str, int64_t lds, int64_t n_str, const Params& q,
-                               float2* part, hipStream_t st) {
+                               float2* part, float* part_g, hipStream_t st) {
   switch (pk) {
-    case 1: launch_fwd_partial_pk1(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
-    case 2: launch_fwd_partial_pk2(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
-    case 3: launch_fwd_partial_pk3(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
-    case 4: launch_fwd_partial_pk4(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
-    default: launch_fwd_partial_pk0(P, own, ldo, n_own, str, lds, n_str, q, part, st); break;
+    case 1: launch_fwd_partial_pk1(P, own, ldo, n_own, str, lds, n_str, q, part, part_g, st); break;
+    case 2: launch_fwd_partial_pk2(P, own, ldo, n_own, str, lds, n_str, q, part, part_g, st); break;
+    case 3: launch_fwd_partial_pk3(P, own, ldo, n_own, str, lds, n_str, q, part, part_g, st); break;
+    case 4: launch_fwd_partial_pk4(P, own, ldo, n_own, str, lds, n_str, q, part, part_g, st); break;
+    default: launch_fwd_partial_pk0(P, own, ldo, n_own, str, lds, n_str, q, part, part_g, st); break;
   }
+}
+
+// rowgrad[i,k] = sum_split G[split][i][k] * 2^(m[split][i] - lse_i*log2e): merge of the flash-style
+// row-gradient partials (fwd_partial_k<..., ROWGRAD>) once the row's log-sum-exp is known
+__global__ __launch_bounds__(THREADS) void rowgrad_combine_k(const float2* __restrict__ part, const float* __restrict__ part_g,
+                                                            int nsplit, int64_t rows, int np, int n,
+                                                            const float* __restrict__ lse_i, float* __restrict__ rowgrad,
+                                                            int64_t ldrg) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  const int q4 = np / 4;
+  if (idx >= rows * q4) return;
+  const int64_t i = idx / q4;
+  const int k = (int)(idx - i * q4) * 4;
+  if (k >= n) return;
+  const float L2 = lse_i[i] * kLog2e;
+  float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const float w = fexp2(part[(int64_t)sp * rows + i].x - L2);
+    const float4 g = *reinterpret_cast<const float4*>(part_g + ((int64_t)sp * rows + i) * np + k);
+    t.x = fmaf(g.x, w, t.x); t.y = fmaf(g.y, w, t.y); t.z = fmaf(g.z, w, t.z); t.w = fmaf(g.w, w, t.w);
+  }
+  const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+    if (k + u < n) rowgrad[i * ldrg + k + u] = tv[u];
+}
+
+// out[i,k] (+)= statC[i] * rowgrad[i,k]   (backward of the row side without a pair pass)
+__global__ __launch_bounds__(THREADS) void rowgrad_apply_k(const float* __restrict__ rowgrad, int64_t ldrg,
+                                                          const float* __restrict__ statC, int64_t rows, int n,
+                                                          float* __restrict__ out, int64_t ldo, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= rows * n) return;
+  const int64_t i = idx / n;
+  const int k = (int)(idx - i * n);
+  const float v = statC[i] * rowgrad[i * ldrg + k];
+  float* dst = out + i * ldo + k;
+  *dst = accumulate ? (*dst + v) : v;
 }
 static void launch_bwd_pairs(bool owner_stats, const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own,
                              const float* str, int64_t lds, int64_t n_str, const Params& q,
@@ -232,15 +271,22 @@ static void launch_bwd_pairs(bool owner_stats, const Plan& P, int pk, const floa
 }
 
 // workspace carve-up ------------------------------------------------------------------------------
-struct FwdWs { float2* part; float* blocksums; size_t bytes; };
+struct FwdWs { float2* part; float* part_g; float* blocksums; size_t bytes; };
 struct BwdWs { float* statL; float* statC; float* partR; float* partC; size_t bytes; };
 
-static FwdWs carve_fwd(void* ws, const Plan& P, int64_t rows) {
+static FwdWs carve_fwd(void* ws, const Plan& P, int64_t rows, bool rowgrad) {
   FwdWs w; char* p = (char*)ws; size_t off = 0;
   off += 256;   // reserved header
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
   w.part = (float2*)(p + off); off += align_up((size_t)P.nsplit * rows * sizeof(float2), 256);
+  w.part_g = nullptr;
+  if (rowgrad) { w.part_g = (float*)(p + off); off += align_up((size_t)P.nsplit * rows * P.np * sizeof(float), 256); }
   w.bytes = off; return w;
+}
+static size_t fwd_carve_max(int64_t rows, int64_t cols, int n) {   // plain vs row-gradient forward, whichever is larger
+  const size_t a = carve_fwd(nullptr, make_plan(rows, cols, n, false), rows, false).bytes;
+  const size_t b = carve_fwd(nullptr, make_plan(rows, cols, n, true), rows, true).bytes;
+  return a > b ? a : b;
 }
 static BwdWs carve_bwd(void* ws, const Plan& PR, const Plan& PC, int64_t rows, int64_t cols) {
   BwdWs w; char* p = (char*)ws; size_t off = 256;   // keep clear of the forward's ticket word
@@ -278,7 +324,8 @@ extern "C" int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t
   Plan PF = make_plan(rows, cols, d->n, false);
   Plan PR = make_plan(rows, cols, d->n, true);
   Plan PC = make_plan(cols, rows, d->n, true);
-  if (fwd_bytes) *fwd_bytes = carve_fwd(nullptr, PF, rows).bytes;
+  if (fwd_bytes) *fwd_bytes = fwd_carve_max(rows, cols, d->n);
+  (void)PF;
   if (bwd_bytes) *bwd_bytes = carve_bwd(nullptr, PR, PC, rows, cols).bytes;
   return CLICA_OK;
 }
@@ -287,6 +334,7 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
                                  const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                                  const float* z3, int64_t ld3,
                                  float* loss_i, float* pos_i, float* lse_i, float* means,
+                                 float* rowgrad, int64_t ldrg,
                                  void* workspace, size_t workspace_bytes, clica_stream_t stream) {
   int rc = validate(d, "clica_lp_loss_fwd");
   if (rc) return rc;
@@ -295,24 +343,29 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   const bool frac = d->p < 1.f;
   const float* rows_p = frac ? z3 : z1; const int64_t ldr = frac ? ld3 : ld1; const int64_t rows = frac ? d->B3 : d->B;
   const float* cols_p = frac ? z1 : z3; const int64_t ldc = frac ? ld1 : ld3; const int64_t cols = frac ? d->B : d->B3;
-  Plan P = make_plan(rows, cols, d->n, false);
-  FwdWs w = carve_fwd(workspace, P, rows);
+  CLICA_CHECK_ARG(!rowgrad || ldrg >= d->n, "clica_lp_loss_fwd: rowgrad leading dimension < n");
+  Plan P = make_plan(rows, cols, d->n, rowgrad != nullptr);
+  FwdWs w = carve_fwd(workspace, P, rows, rowgrad != nullptr);
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, frac);
   hipStream_t st = as_stream(stream);
-  launch_fwd_partial(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part, st);
+  launch_fwd_partial(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part, w.part_g, st);
   Means M{w.blocksums};
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M);
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)rows, means);
+  if (rowgrad)
+    hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(rows * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
+                       (const float2*)w.part, (const float*)w.part_g, P.nsplit, rows, P.np, d->n, (const float*)lse_i, rowgrad, ldrg);
   return launch_status("clica_lp_loss_fwd");
 }
 
 extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
                                  const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                                  const float* z3, int64_t ld3, const float* lse_i,
+                                 const float* rowgrad, int64_t ldrg,
                                  const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
                                  float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
                                  float* dz3, int64_t ldd3, int32_t accumulate_dz3,
@@ -340,7 +393,11 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
                      g_mean, g_item, g_pos, g_neg, w.statL, w.statC, dz1, ldd1, dz2, ldd2);
   // in the p>=1 branch dz1 receives the positive term (assigned above) plus the row pass;
   // in the p<1 branch dz1 is the COLUMN gradient: positive term assigned, column pass added.
-  if (d_rows) {
+  if (d_rows && rowgrad) {   // the forward already produced the softmax-weighted row gradient
+    const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
+    hipLaunchKernelGGL(rowgrad_apply_k, dim3((unsigned)ceil_div(rows * d->n, THREADS)), dim3(THREADS), 0, st,
+                       rowgrad, ldrg, (const float*)w.statC, rows, d->n, d_rows, ld_dr, acc);
+  } else if (d_rows) {
     launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
     const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
@@ -428,7 +485,8 @@ extern "C" int clica_dot_loss_workspace_bytes(const clica_dot_loss_desc* d, size
   int rc = validate_dot(d, "clica_dot_loss_workspace_bytes");
   if (rc) return rc;
   Plan PF = make_plan(d->B, d->B3, d->n, false), PR = make_plan(d->B, d->B3, d->n, true), PC = make_plan(d->B3, d->B, d->n, true);
-  if (fwd_bytes) *fwd_bytes = carve_dot(nullptr, carve_fwd(nullptr, PF, d->B).bytes, d->B, d->B3, d->n, d->normalize, false).bytes;
+  if (fwd_bytes) *fwd_bytes = carve_dot(nullptr, fwd_carve_max(d->B, d->B3, d->n), d->B, d->B3, d->n, d->normalize, false).bytes;
+  (void)PF;
   if (bwd_bytes) *bwd_bytes = carve_dot(nullptr, carve_bwd(nullptr, PR, PC, d->B, d->B3).bytes, d->B, d->B3, d->n, d->normalize, true).bytes;
   return CLICA_OK;
 }
@@ -437,14 +495,18 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
                                   const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                                   const float* z3, int64_t ld3,
                                   float* loss_i, float* pos_i, float* lse_i, float* means,
+                                  float* rowgrad, int64_t ldrg,
                                   void* workspace, size_t workspace_bytes, clica_stream_t stream) {
   int rc = validate_dot(d, "clica_dot_loss_fwd");
   if (rc) return rc;
   CLICA_CHECK_ARG(z1 && z2 && z3 && loss_i && pos_i && lse_i && means && workspace, "clica_dot_loss_fwd: NULL pointer");
   CLICA_CHECK_ARG(ld1 >= d->n && ld2 >= d->n && ld3 >= d->n, "clica_dot_loss_fwd: leading dimension < n");
-  Plan P = make_plan(d->B, d->B3, d->n, false);
-  FwdWs w = carve_fwd(workspace, P, d->B);
-  DotWs dw = carve_dot(workspace, w.bytes, d->B, d->B3, d->n, d->normalize, false);
+  CLICA_CHECK_ARG(!rowgrad || ldrg >= d->n, "clica_dot_loss_fwd: rowgrad leading dimension < n");
+  Plan P = make_plan(d->B, d->B3, d->n, rowgrad != nullptr);
+  // the U/inv buffers sit behind the LARGER forward carve so fwd and bwd agree on their offsets
+  FwdWs w = carve_fwd(workspace, P, d->B, rowgrad != nullptr);
+  const size_t dot_off = fwd_carve_max(d->B, d->B3, d->n);
+  DotWs dw = carve_dot(workspace, dot_off, d->B, d->B3, d->n, d->normalize, false);
   if (dw.bytes > workspace_bytes) { set_error("clica_dot_loss_fwd: workspace %zu < %zu", workspace_bytes, dw.bytes); return CLICA_E_WORKSPACE; }
   hipStream_t st = as_stream(stream);
   Params q = dot_params(d);
@@ -454,19 +516,23 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
     normalize_rows(z3, ld3, d->B3, d->n, dw.u3, dw.i3, st);
     z1 = dw.u1; z2 = dw.u2; z3 = dw.u3; ld1 = ld2 = ld3 = d->n;
   }
-  launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, st);
+  launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, w.part_g, st);
   Means M{w.blocksums};
   const int nfin = (int)ceil_div(d->B, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      1, 0, 1, 0.f, loss_i, pos_i, lse_i, M);
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
+  if (rowgrad)   // gradient w.r.t. the (normalised, if requested) rows
+    hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(d->B * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
+                       (const float2*)w.part, (const float*)w.part_g, P.nsplit, d->B, P.np, d->n, (const float*)lse_i, rowgrad, ldrg);
   return launch_status("clica_dot_loss_fwd");
 }
 
 extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
                                   const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                                   const float* z3, int64_t ld3, const float* lse_i,
+                                  const float* rowgrad, int64_t ldrg,
                                   const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
                                   float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
                                   float* dz3, int64_t ldd3, int32_t accumulate_dz3,
@@ -493,7 +559,10 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
   hipLaunchKernelGGL(bwd_coef_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st,
                      B, z1, ld1, z2, ld2, q, d->tau, d->alpha, 1, 0, 1, lse_i,
                      g_mean, g_item, g_pos, g_neg, w.statL, w.statC, o1, lo1, o2, lo2);
-  if (o1) {
+  if (o1 && rowgrad) {
+    hipLaunchKernelGGL(rowgrad_apply_k, dim3((unsigned)ceil_div(B * n, THREADS)), dim3(THREADS), 0, st,
+                       rowgrad, ldrg, (const float*)w.statC, B, n, o1, lo1, 1);
+  } else if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1);

@@ -24,18 +24,26 @@ namespace lp {
     default: break;                                 \
   }
 
+// part_g != nullptr selects the ROWGRAD variant; its plan must have been made with the backward's
+// owners-per-thread (make_plan(..., bwd = true)): it carries the same register load as bwd_pairs_k.
 void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64_t ldo, int64_t n_own,
                                           const float* str, int64_t lds, int64_t n_str, const Params& q,
-                                          float2* part, hipStream_t st) {
+                                          float2* part, float* part_g, hipStream_t st) {
   constexpr int PK = CLICA_PK;
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
-    if (q.pow)
-      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false>), grid, block, 0, st, own, ldo, n_own, str, lds,
-                         n_str, q, part, P.chunk);
+    if (part_g && q.pow)
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), false, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, part_g, P.chunk);
+    else if (part_g)
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), true, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, part_g, P.chunk);
+    else if (q.pow)
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false, false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, part_g, P.chunk);
     else
-      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), true>), grid, block, 0, st, own, ldo, n_own, str, lds,
-                         n_str, q, part, P.chunk);
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), true, false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, part_g, P.chunk);
   })
 }
 

@@ -130,6 +130,7 @@ class ContrastiveTrainer:
         self.side_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.overlap_backward) else None
         self.dy = torch.empty((R, n), **f32)
         self.loss_out = torch.empty(3 * B + 3, **f32)
+        self.rowgrad = torch.empty((B, n), **f32)      # softmax-weighted row gradient from the forward sweep
         Bg = B * self.world
         self.z_all = torch.empty((Bg, n), **f32) if self.dp else None
         self.dz_all = torch.empty((Bg, n), **f32) if self.dp else None
@@ -202,9 +203,10 @@ class ContrastiveTrainer:
             z3, dz3, acc = y1, self.dy[:B], 1
         _lib.check(lib.clica_lp_loss_fwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n,
                                          o[:B].data_ptr(), o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(),
+                                         self.rowgrad.data_ptr(), n,
                                          self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")
         _lib.check(lib.clica_lp_loss_bwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n,
-                                         o[2 * B:3 * B].data_ptr(), None, None, None, None,
+                                         o[2 * B:3 * B].data_ptr(), self.rowgrad.data_ptr(), n, None, None, None, None,
                                          self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n, dz3.data_ptr(), n, acc,
                                          self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd")
         if self.dp:

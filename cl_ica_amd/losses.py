@@ -54,15 +54,20 @@ class _PairLossFn(torch.autograd.Function):
         _lib.check(ws_query(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), f"clica_{kind}_loss_workspace_bytes")
         ws = _lib.workspace(f"{kind}_loss", max(fwd_b.value, bwd_b.value), a.device)
         fwd = lib.clica_lp_loss_fwd if kind == "lp" else lib.clica_dot_loss_fwd
+        # when z1 will need a gradient, let the forward sweep also accumulate the softmax-weighted row
+        # gradient: the backward then needs only the column sweep
+        n = a.shape[1]
+        want_rg = z1.requires_grad and torch.is_grad_enabled() and not (kind == "lp" and desc.p < 1.0)
+        rowgrad = torch.empty((B, n), dtype=torch.float32, device=a.device) if want_rg else None
         _lib.check(fwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
                        loss_i.data_ptr(), pos_i.data_ptr(), lse_i.data_ptr(), means.data_ptr(),
-                       ws.data_ptr(), ws.numel(), _lib.stream_ptr()), f"clica_{kind}_loss_fwd")
+                       _lib.ptr(rowgrad), n, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), f"clica_{kind}_loss_fwd")
+        ctx.rowgrad = rowgrad
         ctx.save_for_backward(a, b, c, lse_i)
         ctx.lds = (lda, ldb, ldc)
         ctx.kind, ctx.desc = kind, desc
         ctx.shapes = (z1.shape, z2.shape, z3.shape)
         mean, pos_mean, neg_mean = means.unbind(0)
-        ctx.mark_non_differentiable()
         return mean, loss_i, pos_mean, neg_mean
 
     @staticmethod
@@ -82,7 +87,7 @@ class _PairLossFn(torch.autograd.Function):
         g_item_t = None if g_item is None else g_item.detach().to(torch.float32).contiguous()
         g_pos_t, g_neg_t = scal(g_pos), scal(g_neg)
         n = a.shape[1]
-        dz1 = torch.empty((a.shape[0], n), dtype=torch.float32, device=dev) if (need1 or need2) else None
+        dz1 = torch.empty((a.shape[0], n), dtype=torch.float32, device=dev) if need1 else None
         dz2 = torch.empty((b.shape[0], n), dtype=torch.float32, device=dev) if need2 else None
         dz3 = torch.empty((c.shape[0], n), dtype=torch.float32, device=dev) if need3 else None
         fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
@@ -91,7 +96,7 @@ class _PairLossFn(torch.autograd.Function):
         ws = _lib.workspace(f"{kind}_loss", max(fwd_b.value, bwd_b.value), dev)
         bwd = lib.clica_lp_loss_bwd if kind == "lp" else lib.clica_dot_loss_bwd
         _lib.check(bwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc, lse_i.data_ptr(),
-                       _lib.ptr(g_mean_t), _lib.ptr(g_item_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
+                       _lib.ptr(ctx.rowgrad), n, _lib.ptr(g_mean_t), _lib.ptr(g_item_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
                        _lib.ptr(dz1), n, _lib.ptr(dz2), n, _lib.ptr(dz3), n, 0,
                        ws.data_ptr(), ws.numel(), _lib.stream_ptr()), f"clica_{kind}_loss_bwd")
         return (dz1 if need1 else None), dz2, dz3, None, None

@@ -68,14 +68,19 @@ int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t* fwd_bytes
  *   pos_i   [B]  pos[i]/tau                            (its mean is the 3rd return's [0])
  *   lse_i   [B]  RAW logsumexp (without -log B3), saved for the backward
  *   means   [3]  mean(loss_i), mean(pos_i), mean(lse as the reference defines it)
+ *   rowgrad [B,n] (ld `ldrg`) optional, NULL to skip: sum_j softmax_ij * d neg_ij / d z1_i, accumulated
+ *           flash-style inside the same pair sweep.  Handing it to clica_lp_loss_bwd removes the
+ *           backward's row pass (one of its two all-pairs sweeps) for ANY upstream gradient.
  */
 int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
                       const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                       const float* z3, int64_t ld3,
                       float* loss_i, float* pos_i, float* lse_i, float* means,
+                      float* rowgrad, int64_t ldrg,
                       void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* Backward (autograd of the forward; recomputes distances, no B x B3 storage).
+ * `rowgrad` (optional): the forward's row-gradient output; NULL recomputes it with a row pass.
  * Upstream gradients (device pointers, any may be NULL):
  *   g_mean [1] for means[0] (NULL = 1.0), g_item [B] for loss_i (NULL = 0),
  *   g_pos [1] / g_neg [1] for means[1] / means[2] (NULL = 0).
@@ -86,6 +91,7 @@ int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
 int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
                       const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                       const float* z3, int64_t ld3, const float* lse_i,
+                      const float* rowgrad, int64_t ldrg,
                       const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
                       float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
                       float* dz3, int64_t ldd3, int32_t accumulate_dz3,
@@ -109,10 +115,12 @@ int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
                        const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                        const float* z3, int64_t ld3,
                        float* loss_i, float* pos_i, float* lse_i, float* means,
+                       float* rowgrad, int64_t ldrg,
                        void* workspace, size_t workspace_bytes, clica_stream_t stream);
 int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
                        const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                        const float* z3, int64_t ld3, const float* lse_i,
+                       const float* rowgrad, int64_t ldrg,
                        const float* g_mean, const float* g_item, const float* g_pos, const float* g_neg,
                        float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
                        float* dz3, int64_t ldd3, int32_t accumulate_dz3,

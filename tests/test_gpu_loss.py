@@ -182,3 +182,35 @@ def test_error_paths():
         LpSimCLRLoss(p=2)(None, None, None, zc, zc, zc)       # n > 64
     with pytest.raises(ClicaError):
         LpSimCLRLoss(p=0.5)(None, None, None, zc[:, :3], zc[:, :3], torch.zeros(5, 3, device="cuda"))
+
+
+def test_rowgrad_forward_equals_row_pass():
+    """The flash-style row gradient accumulated in the forward sweep equals the backward's recomputing
+    row pass (C ABI called directly both ways, all exponent kinds + dot)."""
+    import ctypes as C
+    from cl_ica_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(3)
+    B, B3, n = 1500, 2100, 10
+    z1 = torch.randn(B, n, device="cuda") * 0.6; z2 = z1 + 0.05 * torch.randn_like(z1); z3 = torch.randn(B3, n, device="cuda") * 0.6
+    for p, pw in ((1, 1), (2, 1), (3, 1), (1.5, 1), (2, 0)):
+        d = _lib.LpLossDesc(B=B, B3=B3, n=n, p=float(p), tau=0.9, alpha=0.4, compat=1, pow=pw)
+        fb, bb = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(d), C.byref(fb), C.byref(bb)), "ws")
+        ws = torch.zeros(max(fb.value, bb.value), dtype=torch.uint8, device="cuda")
+        outs = []
+        for use_rg in (False, True):
+            o = torch.empty(3 * B + 3, device="cuda"); rg = torch.empty(B, n, device="cuda")
+            dz = [torch.empty(B, n, device="cuda"), torch.empty(B, n, device="cuda"), torch.empty(B3, n, device="cuda")]
+            rgp = rg.data_ptr() if use_rg else None
+            _lib.check(lib.clica_lp_loss_fwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
+                                             o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), rgp, n,
+                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "fwd")
+            _lib.check(lib.clica_lp_loss_bwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                                             rgp, n, None, None, None, None, dz[0].data_ptr(), n, dz[1].data_ptr(), n, dz[2].data_ptr(), n, 0,
+                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "bwd")
+            torch.cuda.synchronize()
+            outs.append((o.clone(), [t.clone() for t in dz]))
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-6, atol=1e-6), p
+        for a, b in zip(outs[0][1], outs[1][1]):
+            assert (a - b).abs().max().item() < 2e-6 * max(a.abs().max().item(), 1e-6) + 1e-9, p

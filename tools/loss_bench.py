@@ -12,11 +12,12 @@ def run(B, B3, n, p, reps=20):
     ws = torch.zeros(max(fb.value, bb.value) + (64 << 20), dtype=torch.uint8, device="cuda")
     z1 = torch.randn(B, n, device="cuda") * 0.5; z2 = z1 + 0.05 * torch.randn_like(z1); z3 = torch.randn(B3, n, device="cuda") * 0.5
     o = torch.empty(3 * B + 3, device="cuda"); dz = torch.empty(2 * B + B3, n, device="cuda")
+    rg = torch.empty(B, n, device="cuda"); RG = os.environ.get("LOSS_ROWGRAD", "1") == "1"
     def fwd():
         lib.clica_lp_loss_fwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(), o[B:2*B].data_ptr(),
-                              o[2*B:3*B].data_ptr(), o[3*B:].data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream_ptr())
+                              o[2*B:3*B].data_ptr(), o[3*B:].data_ptr(), (rg.data_ptr() if RG else None), n, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     def bwd():
-        lib.clica_lp_loss_bwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[2*B:3*B].data_ptr(), None, None, None, None,
+        lib.clica_lp_loss_bwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[2*B:3*B].data_ptr(), (rg.data_ptr() if RG else None), n, None, None, None, None,
                               dz[:B].data_ptr(), n, dz[B:2*B].data_ptr(), n, dz[2*B:].data_ptr(), n, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr())
     res = []
     for fn in (fwd, bwd):
@@ -39,6 +40,7 @@ if __name__ == "__main__":
             f, b = run(B, B3, n, p)
             print(f"WG/CU={os.environ.get('CLICA_LP_WG_PER_CU','8')} B={B} B3={B3} n={n} p={p}: fwd {f:8.1f} us ({B*B3/f/1e3:7.1f} Gpair/s)  bwd {b:8.1f} us")
     else:
-        for per_cu in ("8",):
-            env = dict(os.environ, CLICA_LP_WG_PER_CU=per_cu)
+        for rgflag in ("0", "1"):
+            print("row gradient in the forward sweep:", rgflag)
+            env = dict(os.environ, LOSS_ROWGRAD=rgflag)
             subprocess.run([sys.executable, __file__, "one"], env=env)
