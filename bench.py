@@ -151,18 +151,19 @@ def loss_leg(tr, reps=20):
     for _ in range(reps):
         ev[0].record()
         lib.clica_lp_loss_fwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
-                              o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), tr.rowgrad.data_ptr(), n,
+                              o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), None, 0,
                               tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         ev[1].record()
-        lib.clica_lp_loss_bwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
-                              tr.rowgrad.data_ptr(), n, None, None, None, None, tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n,
-                              (tr.dy[:B] if tr.world == 1 else tr.dz_all).data_ptr(), n, 0, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        lib.clica_lp_loss_bwd_sym(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                                  (o[2 * B:3 * B] if tr.world == 1 else tr.lse_all).data_ptr(), None, None, None,
+                                  tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         ev[2].record()
         torch.cuda.synchronize()
         tf += ev[0].elapsed_time(ev[1]) * 1e-3; tb += ev[1].elapsed_time(ev[2]) * 1e-3
     pairs = float(B) * z3.shape[0] + B
     cp = {1: 2, 2: 2, 3: 4}.get(int(tr.p), 6)
-    fl_f = pairs * (cp * n + 6)      # P (c_p n + 6); backward = 3x forward
+    fl_f = pairs * (cp * n + 6)      # P (c_p n + 6); backward contract figure = 3x forward
+    # (the symmetric backward does ONE pair sweep; the contract's 3x is kept as the algorithmic figure)
     return {"fwd_us": 1e6 * tf / reps, "bwd_us": 1e6 * tb / reps, "pairs": pairs,
             "fwd_gpairs_per_s": pairs / (tf / reps) / 1e9, "fwd_tflops_valu": fl_f / (tf / reps) / 1e12,
             "bwd_tflops_valu": 3 * fl_f / (tb / reps) / 1e12, "valu_peak_tflops": PEAK_FP32_VALU_TFLOPS,

@@ -279,14 +279,19 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 }
 
 // ---- backward ------------------------------------------------------------------------------
-// Owner-gradient partials.  OWNER_STATS: softmax statistics belong to the owner rows (d/dz1);
-// otherwise to the stream rows (d/dz3: column reduction over row-normalised weights).
-template <int NP, int PK, int R, bool OWNER_STATS, bool ROOT>
+// Owner-gradient partials.  STATS bit 0: softmax statistics of the OWNER rows weigh the pair (d/dz1: row
+// reduction); bit 1: statistics of the STREAM rows do (d/dz3: column reduction over row-normalised
+// weights); both (3) = the symmetric sweep used when the stream is the pool the owners belong to
+// (z3 = all z1, main_mlp.py:272): d_ij = d_ji, so coef = C_i 2^(x - L_i) + C_j 2^(x - L_j) yields row AND
+// column contributions to dz_i in one pass.
+template <int NP, int PK, int R, int STATS, bool ROOT>
 __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, const float* __restrict__ statL, const float* __restrict__ statC,
+    const float* __restrict__ strL, const float* __restrict__ strC,
     float* __restrict__ part, int chunk) {
+  constexpr bool OWNER_STATS = (STATS & 1) != 0, STREAM_STATS = (STATS & 2) != 0;
   __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
   __shared__ float tLs[2][TS], tCs[2][TS];
   const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
@@ -308,15 +313,15 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
   Stager<NP> st;
   float rl = 0.f, rc = 0.f;     // staged stream statistics (threads < TS)
   auto load_stats = [&](int64_t j0, int cnt) {
-    if (!OWNER_STATS && threadIdx.x < TS) {
+    if (STREAM_STATS && threadIdx.x < TS) {
       const bool ok = threadIdx.x < cnt;
-      const float l = statL[ok ? j0 + threadIdx.x : 0], c = statC[ok ? j0 + threadIdx.x : 0];
+      const float l = strL[ok ? j0 + threadIdx.x : 0], c = strC[ok ? j0 + threadIdx.x : 0];
       rl = ok ? l : 0.f;
       rc = ok ? c : 0.f;         // zero coefficient masks the ragged tail
     }
   };
   auto store_stats = [&](int b) {
-    if (!OWNER_STATS && threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = rc; }
+    if (STREAM_STATS && threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = rc; }
   };
   if (jb < je) {
     const int c0 = (int)min((int64_t)TS, je - jb);
@@ -343,10 +348,11 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
         float coef[JB];
 #pragma unroll
         for (int c = 0; c < JB; ++c) {
-          const float L = OWNER_STATS ? oL[r] : tL[jj + c];
-          const float C = OWNER_STATS ? oC[r] : tC[jj + c];
-          const float w = fexp2(fmaf(root_of<ROOT>(acc[c], q), xk, -L));
-          float cf = C * w * droot_of<ROOT>(acc[c], q) * csgn;
+          const float x = root_of<ROOT>(acc[c], q) * xk;
+          float w = 0.f;
+          if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
+          if (STREAM_STATS) w = fmaf(tC[jj + c], fexp2(x - tL[jj + c]), w);   // tC = 0 masks the ragged tail
+          float cf = w * droot_of<ROOT>(acc[c], q) * csgn;
           if (OWNER_STATS && jj + c >= cnt) cf = 0.f;
           coef[c] = cf;
         }
@@ -421,7 +427,11 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
   void launch_bwd_pairs_pk##PKV(const Plan& P, bool owner_stats, const float* own, int64_t ldo,       \
                                 int64_t n_own, const float* str, int64_t lds, int64_t n_str,          \
                                 const Params& q, const float* statL, const float* statC, float* part, \
-                                hipStream_t st);
+                                hipStream_t st);                                                      \
+  void launch_bwd_sym_pk##PKV(const Plan& P, const float* own, int64_t ldo, int64_t n_own,            \
+                              const float* str, int64_t lds, int64_t n_str, const Params& q,          \
+                              const float* ownL, const float* ownC, const float* strL, const float* strC, \
+                              float* part, hipStream_t st);
 CLICA_LP_DECLARE(0) CLICA_LP_DECLARE(1) CLICA_LP_DECLARE(2) CLICA_LP_DECLARE(3) CLICA_LP_DECLARE(4)
 
 }  // namespace lp

@@ -270,6 +270,32 @@ static void launch_bwd_pairs(bool owner_stats, const Plan& P, int pk, const floa
   }
 }
 
+static void launch_bwd_sym(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own, const float* str, int64_t lds,
+                           int64_t n_str, const Params& q, const float* ownL, const float* ownC, const float* strL,
+                           const float* strC, float* part, hipStream_t st) {
+  switch (pk) {
+    case 1: launch_bwd_sym_pk1(P, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, st); break;
+    case 2: launch_bwd_sym_pk2(P, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, st); break;
+    case 3: launch_bwd_sym_pk3(P, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, st); break;
+    case 4: launch_bwd_sym_pk4(P, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, st); break;
+    default: launch_bwd_sym_pk0(P, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, st); break;
+  }
+}
+
+// statistics of the pool rows for the symmetric sweep: every pool row carries the same upstream weight
+// as the local rows (a mean loss on every rank), i.e. C = 2(1-alpha) g_mean / B + g_neg / B
+__global__ __launch_bounds__(THREADS) void pool_stats_k(int64_t pool_rows, const float* __restrict__ pool_lse, int64_t local_rows,
+                                                       float tau, float alpha, const float* __restrict__ g_mean,
+                                                       const float* __restrict__ g_neg, float xs,
+                                                       float* __restrict__ strL, float* __restrict__ strC) {
+  const int64_t j = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (j >= pool_rows) return;
+  const float inv = 1.f / (float)local_rows;
+  const float C = 2.f * (1.f - alpha) * (g_mean ? g_mean[0] : 1.f) * inv + (g_neg ? g_neg[0] * inv : 0.f);
+  strL[j] = pool_lse[j] * kLog2e;
+  strC[j] = xs * C / tau;
+}
+
 // workspace carve-up ------------------------------------------------------------------------------
 struct FwdWs { float2* part; float* part_g; float* blocksums; size_t bytes; };
 struct BwdWs { float* statL; float* statC; float* partR; float* partC; size_t bytes; };
@@ -411,6 +437,37 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
                        (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc);
   }
   return launch_status("clica_lp_loss_bwd");
+}
+
+extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
+                                     const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                                     const float* pool, int64_t ldp, const float* lse_i, const float* pool_lse,
+                                     const float* g_mean, const float* g_pos, const float* g_neg,
+                                     float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                                     void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_bwd_sym");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && z2 && pool && lse_i && pool_lse && dz1 && workspace, "clica_lp_loss_bwd_sym: NULL pointer");
+  CLICA_CHECK_ARG(d->p >= 1.f, "clica_lp_loss_bwd_sym: the p<1 branch is not symmetric (eps inside the abs, losses.py:436)");
+  CLICA_CHECK_ARG(d->B3 >= d->B, "clica_lp_loss_bwd_sym: the pool (B3=%lld rows) must contain the %lld local rows", (long long)d->B3, (long long)d->B);
+  const int64_t rows = d->B, cols = d->B3;
+  Plan PR = make_plan(rows, cols, d->n, true);
+  Plan PC = make_plan(cols, rows, d->n, true);
+  BwdWs w = carve_bwd(workspace, PR, PC, rows, cols);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_bwd_sym: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  float* strL = w.partC;            // the column-pass slab region is free in this mode (>= 2*cols floats)
+  float* strC = w.partC + cols;
+  Params q = make_params(d, false);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bwd_coef_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st,
+                     rows, z1, ld1, z2, ld2, q, d->tau, d->alpha, d->compat ? 1 : 0, 0, 0, lse_i,
+                     g_mean, (const float*)nullptr, g_pos, g_neg, w.statL, w.statC, dz1, ldd1, dz2, ldd2);
+  hipLaunchKernelGGL(pool_stats_k, dim3((unsigned)ceil_div(cols, THREADS)), dim3(THREADS), 0, st,
+                     cols, pool_lse, rows, d->tau, d->alpha, g_mean, g_neg, q.xs, strL, strC);
+  launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, w.partR, st);
+  hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
+                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1);
+  return launch_status("clica_lp_loss_bwd_sym");
 }
 
 // =====================================================================================

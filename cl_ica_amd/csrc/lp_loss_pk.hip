@@ -55,17 +55,34 @@ void CAT(launch_bwd_pairs_pk, CLICA_PK)(const Plan& P, bool owner_stats, const f
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (owner_stats && q.pow)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), true, false>), grid, block, 0, st, own, ldo, n_own, str,
-                         lds, n_str, q, statL, statC, part, P.chunk);
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 1, false>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
     else if (owner_stats)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), true, true>), grid, block, 0, st, own, ldo, n_own, str,
-                         lds, n_str, q, statL, statC, part, P.chunk);
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 1, true>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
     else if (q.pow)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), false, false>), grid, block, 0, st, own, ldo, n_own, str,
-                         lds, n_str, q, statL, statC, part, P.chunk);
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 2, false>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
     else
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), false, true>), grid, block, 0, st, own, ldo, n_own, str,
-                         lds, n_str, q, statL, statC, part, P.chunk);
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 2, true>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
+  })
+}
+
+// symmetric sweep (stream = the pool the owners belong to): owner AND stream statistics
+void CAT(launch_bwd_sym_pk, CLICA_PK)(const Plan& P, const float* own, int64_t ldo, int64_t n_own,
+                                      const float* str, int64_t lds, int64_t n_str, const Params& q,
+                                      const float* ownL, const float* ownC, const float* strL, const float* strC,
+                                      float* part, hipStream_t st) {
+  constexpr int PK = CLICA_PK;
+  dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
+  LP_FOR_NP(P.np, {
+    if (q.pow)
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, false>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, ownL, ownC, strL, strC, part, P.chunk);
+    else
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, true>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, ownL, ownC, strL, strC, part, P.chunk);
   })
 }
 

@@ -130,11 +130,9 @@ class ContrastiveTrainer:
         self.side_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.overlap_backward) else None
         self.dy = torch.empty((R, n), **f32)
         self.loss_out = torch.empty(3 * B + 3, **f32)
-        self.rowgrad = torch.empty((B, n), **f32)      # softmax-weighted row gradient from the forward sweep
         Bg = B * self.world
         self.z_all = torch.empty((Bg, n), **f32) if self.dp else None
-        self.dz_all = torch.empty((Bg, n), **f32) if self.dp else None
-        self.dz_rs = torch.empty((B, n), **f32) if self.dp else None
+        self.lse_all = torch.empty((Bg,), **f32) if self.dp else None
         self.desc = _lib.LpLossDesc(B=B, B3=Bg, n=n, p=self.p, tau=self.tau, alpha=self.alpha, compat=1, pow=1)
         fb, bb = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(self.desc), C.byref(fb), C.byref(bb)), "workspace")
@@ -193,25 +191,32 @@ class ContrastiveTrainer:
                            "clica_softclip_fwd")
 
     def loss_forward_backward(self):
+        """Loss forward + its backward w.r.t. the embeddings.  The negatives are "all z1_rec of the (global)
+        batch" (the reference's roll, main_mlp.py:272, up to a permutation), so the pair matrix is symmetric
+        and ONE backward sweep with both rows' softmax statistics gives dz1 complete: no row pass, no column
+        pass, and under data parallelism no reduce-scatter of d/dz3 -- only an all-gather of the B
+        log-sum-exp values next to the all-gather of the embeddings."""
         lib, st = _lib.load(), _lib.stream_ptr()
         B, n, o = self.B, self.n, self.loss_out
         y1, y2 = self.y[:B], self.y[B:]
+        lse = o[2 * B:3 * B]
         if self.dp:
             dist.all_gather_into_tensor(self.z_all, y1.contiguous(), group=self.pg)
-            z3, dz3, acc = self.z_all, self.dz_all, 0
+            pool = self.z_all
         else:
-            z3, dz3, acc = y1, self.dy[:B], 1
-        _lib.check(lib.clica_lp_loss_fwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n,
-                                         o[:B].data_ptr(), o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(),
-                                         self.rowgrad.data_ptr(), n,
-                                         self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")
-        _lib.check(lib.clica_lp_loss_bwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n,
-                                         o[2 * B:3 * B].data_ptr(), self.rowgrad.data_ptr(), n, None, None, None, None,
-                                         self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n, dz3.data_ptr(), n, acc,
-                                         self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd")
+            pool = y1
+        _lib.check(lib.clica_lp_loss_fwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, pool.data_ptr(), n,
+                                         o[:B].data_ptr(), o[B:2 * B].data_ptr(), lse.data_ptr(), o[3 * B:].data_ptr(),
+                                         None, 0, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")
         if self.dp:
-            dist.reduce_scatter_tensor(self.dz_rs, self.dz_all, op=dist.ReduceOp.SUM, group=self.pg)
-            self.dy[:B].add_(self.dz_rs)
+            dist.all_gather_into_tensor(self.lse_all, lse, group=self.pg)
+            pool_lse = self.lse_all
+        else:
+            pool_lse = lse
+        _lib.check(lib.clica_lp_loss_bwd_sym(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, pool.data_ptr(), n,
+                                             lse.data_ptr(), pool_lse.data_ptr(), None, None, None,
+                                             self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n,
+                                             self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd_sym")
 
     def backward(self):
         lib, st = _lib.load(), _lib.stream_ptr()

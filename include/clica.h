@@ -97,6 +97,22 @@ int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
                       float* dz3, int64_t ldd3, int32_t accumulate_dz3,
                       void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
+/* Symmetric backward for the reference's training usage z3_rec = roll(z1_rec) (main_mlp.py:272), i.e.
+ * "the negatives are all z1 of the (global) batch".  `pool` [B3,n] holds the z1 rows of every rank in any
+ * order, this rank's B rows included; `pool_lse` [B3] the raw logsumexp of every pool row (all-gather of
+ * lse_i).  Because d(i,j) = d(j,i), one sweep with coefficient C_i w_ij + C_j w_ji yields the complete
+ * gradient of the SUM of all ranks' mean losses w.r.t. this rank's z1 rows -- what the generic backward
+ * delivers as dz1 + (reduce-scatter of dz3) -- with one pair pass and no gradient exchange.
+ * Requirements: p >= 1; every pool row carries the same upstream weight as the local rows (g_mean / g_neg
+ * scalars, no per-item upstream).  dz1 [B,n], dz2 [B,n] (dz2 may be NULL).
+ */
+int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
+                          const float* z1, int64_t ld1, const float* z2, int64_t ld2,
+                          const float* pool, int64_t ldp, const float* lse_i, const float* pool_lse,
+                          const float* g_mean, const float* g_pos, const float* g_neg,
+                          float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                          void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Dot-product InfoNCE  --  SimCLRLoss.loss, /root/reference/losses.py:177-202
  *   (optional row L2-normalisation is done by the caller-visible wrapper kernels below)

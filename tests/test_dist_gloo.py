@@ -93,3 +93,36 @@ def test_gather_negatives_backward_is_reduce_scatter(tmp_path):
     port = _free_port()
     mp.spawn(_worker_plain, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
     assert np.load(tmp_path / "ok.npy")[0] == WORLD
+
+
+def test_symmetric_backward_identity_two_ranks():
+    """The engine's data-parallel backward: with the negatives pool = all ranks' z1 rows, rank r obtains the
+    COMPLETE gradient of sum_q L_q w.r.t. its own rows from one sweep with coefficient
+    C (w_ij + w_ji), given only the all-gathered log-sum-exp values -- no reduce-scatter of d/dz3.
+    Checked in NumPy against the oracle's generic row + column gradients on the concatenated batch."""
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(0)
+    R, B, n, tau, alpha = 2, 24, 5, 0.8, 0.4
+    for p in (1, 2, 3):
+        z1 = rng.normal(size=(R * B, n)); z2 = z1 + 0.1 * rng.normal(size=(R * B, n))
+        # reference semantics on the global batch: z3 = roll(z1); combined gradient on z1
+        ref = O.lp_simclr_loss(z1, z2, np.roll(z1, 1, 0), p=p, tau=tau, alpha=alpha, compat=True)
+        want_dz1 = ref["dz1"] + np.roll(ref["dz3"], -1, 0)
+        lse_all = ref["lse"]                                   # what the ranks all-gather
+        for r in range(R):
+            rows = slice(r * B, (r + 1) * B)
+            loc = O.lp_simclr_loss(z1[rows], z2[rows], z1, p=p, tau=tau, alpha=alpha, compat=True, grad=False)
+            assert np.allclose(loc["lse"], lse_all[rows])      # row statistics do not depend on the row order of the pool
+            # engine convention: every rank differentiates its LOCAL mean (C = 2(1-alpha)/B) and Adam divides by R
+            C = 2 * (1 - alpha) / B
+            d = z1[rows][:, None, :] - z1[None, :, :]
+            neg = (np.abs(d) ** p).sum(-1)
+            w = np.exp(-neg / tau - lse_all[rows][:, None]) + np.exp(-neg / tau - lse_all[None, :])
+            dterm = p * np.abs(d) ** (p - 1) * np.sign(d)
+            dz_neg = (-(C / tau) * w)[:, :, None] * dterm
+            # positive-pair part (local rows only), from the oracle with the negatives' gradient removed
+            pos_only = O.lp_simclr_loss(z1[rows], z2[rows], z1, p=p, tau=tau, alpha=alpha, compat=True)
+            gp = -pos_only["dz2"]
+            got = gp + dz_neg.sum(1)
+            # global-mean gradient = (1/R) sum_q dL_q/dz  ->  compare with R * want (want differentiates the global mean)
+            assert np.abs(got - R * want_dz1[rows]).max() < 1e-10 * max(1.0, np.abs(want_dz1).max() * R), (p, r)
