@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (A/B switch)")
+    ap.add_argument("--no-fused-forward", action="store_true", help="per-layer forward GEMMs instead of the one-launch stack (A/B switch)")
     return ap.parse_args()
 
 
@@ -65,7 +66,7 @@ def build_trainer(args, device, world):
     spec = SamplerSpec(space=args.space_type, n=n, box=(0.0, 1.0), marginal="uniform", conditional="normal", c_param=0.05, seed=0)
     return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
                               device=device, process_group=None if world == 1 else dist.group.WORLD,
-                              overlap_backward=not args.no_overlap)
+                              overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward)
 
 
 def roofline_leg(tr, reps=20):

@@ -1,0 +1,249 @@
+// Whole-encoder forward in ONE launch: the Linear(+bias)(+LeakyReLU) stack of get_mlp
+// (/root/reference/encoders.py:36-48) with the activation panel resident on chip.
+//
+// Why: at n = 10 (widths 10-100-500-500-500-500-100-10, main_mlp.py:297-307) a per-layer GEMM launch
+// pays a fixed ~15 us (first-tile HBM latency, the 24.6 MB epilogue store, the launch boundary) next to
+// ~45 us of MFMA time.  Here every workgroup owns 48 rows of the 2B-row batch for the whole stack:
+//   * the 48 x width activation panel lives in LDS (48 x 520 floats = 100 KB); a layer reads it as the
+//     MFMA A operand and, after a barrier, overwrites it with its own output (accumulators hold the
+//     results meanwhile), which is also streamed to HBM once (coalesced, straight from the panel) because
+//     the backward needs the saved activations;
+//   * weights are the B operand.  A wave owns whole 16-column blocks of the output, so a B fragment is
+//     private to the wave: it is loaded global -> VGPR directly (16 B per lane, L2-resident: every CU
+//     streams the same <= 1 MB matrix), prefetched one 16-deep k-step ahead; no LDS staging, no barrier in
+//     the k-loop;
+//   * math: v_mfma_f32_16x16x4_f32 (exact fp32, same as the tiled GEMMs), 3 row blocks x <= 4 column
+//     blocks per wave, k-permuted so one 16-byte read feeds four MFMAs on both operands.
+// One launch replaces seven; the panel never round-trips through HBM between layers.
+#include "common.h"
+#include <stdlib.h>
+
+namespace clica {
+namespace fmlp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWS = 48;            // rows per workgroup = 3 MFMA row blocks
+constexpr int RB = ROWS / 16;
+constexpr int WAVES = 8;
+constexpr int THREADS = 64 * WAVES;
+constexpr int MAXW = 512;           // widest layer the panel holds
+constexpr int LDP = MAXW + 8;       // panel leading dimension: conflict-free ds_read_b128 of 16 rows x 4 k-groups
+constexpr int CBW = MAXW / 16 / WAVES;   // column blocks per wave (4)
+constexpr int MAXL = 8;
+
+struct Layer {
+  const float* W; int64_t ldw; const float* bias;
+  float* out; int64_t ldo;           // HBM copy of the layer output (saved activation / final result)
+  int N, K, leaky;
+};
+struct Args {
+  const float* X; int64_t ldx; int64_t M; int L; float slope;
+  int ablate;     // tuning probe (CLICA_MLP_ABLATE): 1 no HBM store of activations, 2 weights fetched once per layer, 4 no A prefetch reads
+  Layer layer[MAXL];
+};
+
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+// B fragment of column block `cb` for k in [k0 + 4q, k0 + 4q + 4): W[n = cb*16 + (lane&15)][k..k+3]
+template <bool VEC>
+__device__ __forceinline__ float4 load_b(const Layer& ly, int n, int k) {
+  if (VEC) {
+    const bool in = n < ly.N && k < ly.K;        // K % 4 == 0 on this path: a float4 is fully in or out
+    return *reinterpret_cast<const float4*>(in ? ly.W + (int64_t)n * ly.ldw + k : g_zero_page);
+  }
+  const float* row = ly.W + (int64_t)(n < ly.N ? n : 0) * ly.ldw;
+  const bool r = n < ly.N;
+  return make_float4(*((r && k < ly.K) ? row + k : g_zero_page), *((r && k + 1 < ly.K) ? row + k + 1 : g_zero_page),
+                     *((r && k + 2 < ly.K) ? row + k + 2 : g_zero_page), *((r && k + 3 < ly.K) ? row + k + 3 : g_zero_page));
+}
+
+// One k-iteration covers 32 k: lane group q reads k0+4q..+3 and k0+16+4q..+3, i.e. the two 16-byte loads
+// of a lane group complete a full 128-byte line of each weight row (half-line requests would fetch
+// every L2 line twice: the 32 KB per-step working set of the 8 waves does not survive in L1).
+constexpr int KI = 32;
+// NC = number of 16-column blocks this wave owns in this layer (compile time: the MFMA stream must be
+// branch-free; NC is wave-uniform and selected by a scalar switch in the caller).
+template <bool VEC, int NC>
+__device__ __forceinline__ void layer_gemm(const Layer& ly, const float* panel, int wave, int lane, f32x4 (&acc)[RB][CBW], int ablate) {
+  const int i15 = lane & 15, q = lane >> 4;
+  const int kiters = (ly.K + KI - 1) / KI;
+  int nrow[CBW];
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) nrow[c] = (wave + c * WAVES) * 16 + i15;     // column blocks w, w+8, w+16, w+24
+  float4 bcur[2][CBW], bnxt[2][CBW], acur[2][RB], anxt[2][RB];
+  auto fetch = [&](float4 (&b)[2][CBW], float4 (&a)[2][RB], int k0) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      b[0][c] = load_b<VEC>(ly, nrow[c], k0 + 4 * q);
+      b[1][c] = load_b<VEC>(ly, nrow[c], k0 + 16 + 4 * q);
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      a[0][r] = *reinterpret_cast<const float4*>(&panel[(r * 16 + i15) * LDP + k0 + 4 * q]);
+      a[1][r] = *reinterpret_cast<const float4*>(&panel[(r * 16 + i15) * LDP + k0 + 16 + 4 * q]);
+    }
+  };
+  fetch(bcur, acur, 0);
+  for (int ki = 0; ki < kiters; ++ki) {
+    if (ki + 1 < kiters && !(ablate & 2)) fetch(bnxt, anxt, (ki + 1) * KI);     // in flight behind this iteration's MFMAs
+    else if (ablate & 2) {
+#pragma unroll
+      for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bnxt[hlf][c] = bcur[hlf][c];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) anxt[hlf][r] = acur[hlf][r];
+      }
+    }
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 b4 = bcur[hlf][c];
+          const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const float4 a4 = acur[hlf][r];
+            const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][c], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bcur[hlf][c] = bnxt[hlf][c];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) acur[hlf][r] = anxt[hlf][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
+  extern __shared__ __attribute__((aligned(16))) float panel[];     // [ROWS][LDP]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform: scalar branches
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int nrows = (int)min((int64_t)ROWS, g.M - row0);
+
+  // input panel, zero-padded to a multiple of KI columns (the k-loop runs in KI-deep iterations)
+  {
+    const int K0 = g.layer[0].K, K16 = (K0 + KI - 1) & ~(KI - 1);
+    for (int idx = threadIdx.x; idx < ROWS * K16; idx += THREADS) {
+      const int r = idx / K16, k = idx - r * K16;
+      panel[r * LDP + k] = (r < nrows && k < K0) ? g.X[(row0 + r) * g.ldx + k] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  for (int l = 0; l < g.L; ++l) {
+    const Layer& ly = g.layer[l];
+    f32x4 acc[RB][CBW];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool vec = ((reinterpret_cast<uintptr_t>(ly.W) & 15) == 0) && (ly.ldw % 4 == 0) && (ly.K % 4 == 0);
+    const int ncb_real = (ly.N + 15) / 16;
+    int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
+    nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
+    if (vec) {
+      switch (nc) {
+        case 4: layer_gemm<true, 4>(ly, panel, wave, lane, acc, g.ablate); break;
+        case 3: layer_gemm<true, 3>(ly, panel, wave, lane, acc, g.ablate); break;
+        case 2: layer_gemm<true, 2>(ly, panel, wave, lane, acc, g.ablate); break;
+        case 1: layer_gemm<true, 1>(ly, panel, wave, lane, acc, g.ablate); break;
+        default: break;
+      }
+    } else {
+      switch (nc) {
+        case 4: layer_gemm<false, 4>(ly, panel, wave, lane, acc, g.ablate); break;
+        case 3: layer_gemm<false, 3>(ly, panel, wave, lane, acc, g.ablate); break;
+        case 2: layer_gemm<false, 2>(ly, panel, wave, lane, acc, g.ablate); break;
+        case 1: layer_gemm<false, 1>(ly, panel, wave, lane, acc, g.ablate); break;
+        default: break;
+      }
+    }
+    __syncthreads();                                   // every wave is done reading the input panel
+
+    // epilogue into the panel: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg.
+    // Columns N..round_up(N, KI) are written as zeros: they are the next layer's k-padding.
+    const int ncb = ((ly.N + KI - 1) & ~(KI - 1)) / 16;
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+      const int cb = wave + c * WAVES;
+      if (cb < ncb) {
+        const int col = cb * 16 + (lane & 15);
+        const float bv = (ly.bias && col < ly.N) ? ly.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int row = r * 16 + (lane >> 4) * 4 + e;
+            float v = acc[r][c][e] + bv;
+            if (ly.leaky) v = v > 0.f ? v : v * g.slope;
+            panel[row * LDP + col] = col < ly.N ? v : 0.f;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // stream the new activations to HBM straight from the panel (coalesced rows)
+    const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
+    if (g.ablate & 1) {
+    } else if (ovec) {
+      const int n4 = ly.N / 4;
+      for (int idx = threadIdx.x; idx < nrows * n4; idx += THREADS) {
+        const int r = idx / n4, c4 = idx - r * n4;
+        // streaming store: the saved activations are not read again in this kernel, keep them from
+        // evicting the weight matrix (the B operand every CU re-reads) out of L2
+        const float4 v = *reinterpret_cast<const float4*>(&panel[r * LDP + 4 * c4]);
+        float* dst = ly.out + (row0 + r) * ly.ldo + 4 * c4;
+        __builtin_nontemporal_store(v.x, dst); __builtin_nontemporal_store(v.y, dst + 1);
+        __builtin_nontemporal_store(v.z, dst + 2); __builtin_nontemporal_store(v.w, dst + 3);
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < nrows * ly.N; idx += THREADS) {
+        const int r = idx / ly.N, c = idx - r * ly.N;
+        ly.out[(row0 + r) * ly.ldo + c] = panel[r * LDP + c];
+      }
+    }
+    // no barrier needed here: the next layer only READS the panel until its own post-GEMM barrier
+  }
+}
+
+}  // namespace fmlp
+}  // namespace clica
+
+using namespace clica;
+
+extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
+                             const float* const* W, const int64_t* ldw, const float* const* bias,
+                             float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                             float slope, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(X && W && ldw && bias && out && ldo && N && K && M > 0, "clica_mlp_fwd: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd: %d layers (1..%d supported)", n_layers, MAXL);
+  Args g{};
+  g.X = X; g.ldx = ldx; g.M = M; g.L = n_layers; g.slope = slope;
+  { const char* e = getenv("CLICA_MLP_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(W[l] && out[l] && N[l] >= 1 && K[l] >= 1, "clica_mlp_fwd: layer %d: bad argument", l);
+    CLICA_CHECK_ARG(N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_fwd: layer %d is %d x %d; the on-chip panel holds widths <= %d "
+                    "(use the per-layer clica_linear_fwd for wider encoders)", l, N[l], K[l], MAXW);
+    CLICA_CHECK_ARG(ldw[l] >= K[l] && ldo[l] >= N[l], "clica_mlp_fwd: layer %d: leading dimension too small", l);
+    CLICA_CHECK_ARG(l == 0 || K[l] == N[l - 1], "clica_mlp_fwd: layer %d input width %d != previous output width %d", l, K[l], N[l - 1]);
+    g.layer[l] = Layer{W[l], ldw[l], bias[l], out[l], ldo[l], N[l], K[l], l + 1 < n_layers ? 1 : 0};
+  }
+  CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd: ldx < K[0]");
+  constexpr size_t lds = (size_t)ROWS * LDP * sizeof(float);
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  hipLaunchKernelGGL(mlp_fwd_k, dim3((unsigned)ceil_div(M, ROWS)), dim3(THREADS), lds, as_stream(stream), g);
+  return launch_status("clica_mlp_fwd");
+}

@@ -51,7 +51,7 @@ class ContrastiveTrainer:
                  p: float = 2, tau: float = 1.0, alpha: float = 0.5, lr: float = 1e-4, g_slope: float = 0.2,
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
-                 force_collectives: bool = False, overlap_backward: bool = True):
+                 force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -78,6 +78,7 @@ class ContrastiveTrainer:
         heads = [m for m in mods if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer))]
         self.head = heads[0] if heads else None
         self._flatten_parameters()
+        self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes,
@@ -177,9 +178,14 @@ class ContrastiveTrainer:
     def forward(self):
         cur = self.x
         L = len(self.linears)
-        for l, lin in enumerate(self.linears):
-            ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=self.slope, out=self.acts[l])
-            cur = self.acts[l]
+        if self.fused_forward:
+            # one launch for the whole stack, activation panel resident in LDS (csrc/fused_mlp.hip)
+            ops.mlp_fwd(cur, [lin.weight for lin in self.linears], [lin.bias for lin in self.linears], self.acts, self.slope)
+            cur = self.acts[-1]
+        else:
+            for l, lin in enumerate(self.linears):
+                ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=self.slope, out=self.acts[l])
+                cur = self.acts[l]
         if self.head is not None:
             lib, st = _lib.load(), _lib.stream_ptr()
             R, n = cur.shape

@@ -72,6 +72,35 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: Optional[torch.Tensor] =
     return dW, db
 
 
+MLP_FUSED_MAX_WIDTH = 512
+MLP_FUSED_MAX_LAYERS = 8
+
+
+def mlp_fwd_fusable(weights) -> bool:
+    return len(weights) <= MLP_FUSED_MAX_LAYERS and all(max(w.shape) <= MLP_FUSED_MAX_WIDTH for w in weights)
+
+
+def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01):
+    """Whole Linear(+LeakyReLU) stack in one launch (clica_mlp_fwd); `outs[l]` receives layer l's output
+    (saved activations; the last one is the result).  Widths <= 512, <= 8 layers."""
+    (x, ldx) = _mat("x", x)
+    L = len(weights)
+    ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
+    bs = [None if b is None else b.detach().contiguous() for b in biases]
+    for o in outs:
+        require_cuda(o, "out")
+    VP = C.c_void_p * L
+    I64 = C.c_int64 * L
+    I32 = C.c_int32 * L
+    check(load().clica_mlp_fwd(x.data_ptr(), ldx, x.shape[0], L,
+                               VP(*[w.data_ptr() for w, _ in ws]), I64(*[ld for _, ld in ws]),
+                               VP(*[None if b is None else b.data_ptr() for b in bs]),
+                               VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+                               I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws]),
+                               float(slope), stream_ptr()), "clica_mlp_fwd")
+    return outs[-1]
+
+
 def linear_plan(op: str, M: int, N: int, K: int):
     """(tile_m, tile_n, waves, splits) of the kernel instance a Linear launch of this shape uses."""
     v = [C.c_int32() for _ in range(4)]

@@ -171,6 +171,18 @@ int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ld
                        int32_t accumulate, void* workspace, size_t workspace_bytes,
                        clica_stream_t stream);
 
+/* Whole-stack forward in one launch (csrc/fused_mlp.hip): layer l computes
+ *   out[l] = act(in_l W[l]^T + bias[l]),  in_0 = X, in_l = out[l-1];  act = LeakyReLU(slope) on all but the last
+ * with the activation panel resident in LDS (48 rows per workgroup); every out[l] is also written to HBM
+ * (the backward needs the saved activations).  All widths must be <= 512 and n_layers <= 8 (the n = 10
+ * encoder of main_mlp.py:297-307); otherwise CLICA_E_INVALID -- call clica_linear_fwd per layer instead.
+ * W / ldw / bias / out / ldo / N / K are HOST arrays of n_layers entries (the pointers in them are device
+ * pointers). */
+int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
+                  const float* const* W, const int64_t* ldw, const float* const* bias,
+                  float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                  float slope, clica_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Output heads  --  RescaleLayer (mode "eq") layers.py:63-66, SoftclipLayer layers.py:87-91
  * ---------------------------------------------------------------------------------- */

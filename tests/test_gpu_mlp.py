@@ -140,3 +140,30 @@ def test_heads_vs_oracle():
     assert rel_err(y.detach().cpu().numpy(), yo) < 2e-6
     assert rel_err(xt.grad.cpu().numpy(), gr["dx"]) < 1e-5
     assert rel_err(lay.max_abs_bound.grad.cpu().numpy(), gr["dhead"]) < 1e-5
+
+
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
+                                      ([16, 16], 47), ([3, 500, 3], 49)])
+def test_fused_mlp_forward_matches_per_layer(dims, M):
+    """clica_mlp_fwd (activation panel resident in LDS, one launch) vs the per-layer GEMM path and fp64."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(len(dims) + M)
+    Ws = [(rng.uniform(-1, 1, size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32) for i in range(len(dims) - 1)]
+    bs = [rng.uniform(-0.2, 0.2, size=dims[i + 1]).astype(np.float32) for i in range(len(dims) - 1)]
+    x = rng.normal(size=(M, dims[0])).astype(np.float32)
+    Wd, bd = [dev(w) for w in Ws], [dev(b) for b in bs]
+    outs = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    assert ops.mlp_fwd_fusable(Wd)
+    y = ops.mlp_fwd(dev(x), Wd, bd, outs, 0.01)
+    cur64 = x.astype(np.float64)
+    cur = dev(x)
+    for l in range(len(Ws)):
+        last = l == len(Ws) - 1
+        cur = ops.linear_fwd(cur, Wd[l], bd[l], leaky=not last, slope=0.01)
+        z = cur64 @ Ws[l].astype(np.float64).T + bs[l]
+        cur64 = z if last else np.where(z > 0, z, 0.01 * z)
+        assert rel_err(outs[l].cpu().numpy(), cur64) < 5e-6, ("fp64", l)
+        assert rel_err(outs[l].cpu().numpy(), cur.cpu().numpy()) < 5e-6, ("per-layer", l)
+    assert y.data_ptr() == outs[-1].data_ptr()
+    with pytest.raises(Exception):
+        ops.mlp_fwd(dev(x), [torch.zeros(600, dims[0], device="cuda")], [None], [torch.empty(M, 600, device="cuda")])
