@@ -16,7 +16,6 @@
 //     blocks per wave, k-permuted so one 16-byte read feeds four MFMAs on both operands.
 // One launch replaces seven; the panel never round-trips through HBM between layers.
 #include "common.h"
-#include <stdlib.h>
 
 namespace clica {
 namespace fmlp {
@@ -39,7 +38,8 @@ struct Layer {
 };
 struct Args {
   const float* X; int64_t ldx; int64_t M; int L; float slope;
-  int ablate;     // tuning probe (CLICA_MLP_ABLATE): 1 no HBM store of activations, 2 weights fetched once per layer, 4 no A prefetch reads
+  const float* packed;              // fragment-order weights (clica_mlp_pack) or nullptr
+  int64_t pack_off[MAXL];           // float offset of each layer inside `packed`
   Layer layer[MAXL];
 };
 
@@ -64,8 +64,9 @@ __device__ __forceinline__ float4 load_b(const Layer& ly, int n, int k) {
 constexpr int KI = 32;
 // NC = number of 16-column blocks this wave owns in this layer (compile time: the MFMA stream must be
 // branch-free; NC is wave-uniform and selected by a scalar switch in the caller).
-template <bool VEC, int NC>
-__device__ __forceinline__ void layer_gemm(const Layer& ly, const float* panel, int wave, int lane, f32x4 (&acc)[RB][CBW], int ablate) {
+template <bool VEC, bool PACKED, int NC>
+__device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restrict__ pk, const float* panel, int wave, int lane,
+                                           f32x4 (&acc)[RB][CBW]) {
   const int i15 = lane & 15, q = lane >> 4;
   const int kiters = (ly.K + KI - 1) / KI;
   int nrow[CBW];
@@ -75,8 +76,14 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* panel, 
   auto fetch = [&](float4 (&b)[2][CBW], float4 (&a)[2][RB], int k0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      b[0][c] = load_b<VEC>(ly, nrow[c], k0 + 4 * q);
-      b[1][c] = load_b<VEC>(ly, nrow[c], k0 + 16 + 4 * q);
+      if (PACKED) {   // fragment order: one fully contiguous 1 KB per load instruction, pre-padded with zeros
+        const float* base = pk + ((int64_t)((wave + c * WAVES) * kiters + (k0 >> 5)) * 2 * 64 + lane) * 4;
+        b[0][c] = *reinterpret_cast<const float4*>(base);
+        b[1][c] = *reinterpret_cast<const float4*>(base + 256);
+      } else {
+        b[0][c] = load_b<VEC>(ly, nrow[c], k0 + 4 * q);
+        b[1][c] = load_b<VEC>(ly, nrow[c], k0 + 16 + 4 * q);
+      }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
@@ -86,15 +93,12 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* panel, 
   };
   fetch(bcur, acur, 0);
   for (int ki = 0; ki < kiters; ++ki) {
-    if (ki + 1 < kiters && !(ablate & 2)) fetch(bnxt, anxt, (ki + 1) * KI);     // in flight behind this iteration's MFMAs
-    else if (ablate & 2) {
-#pragma unroll
-      for (int hlf = 0; hlf < 2; ++hlf) {
-#pragma unroll
-        for (int c = 0; c < NC; ++c) bnxt[hlf][c] = bcur[hlf][c];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) anxt[hlf][r] = acur[hlf][r];
-      }
+    // UNCONDITIONAL prefetch of the next iteration's operands (past the end: weights come from the zero
+    // page, the panel offset is clamped): with a conditional issue the compiler cannot count the loads in
+    // flight and drains them all (s_waitcnt vmcnt(0)) in front of the MFMAs, which serialises fetch and math.
+    {
+      const int kn = (ki + 1 < kiters) ? (ki + 1) * KI : ki * KI;     // last iteration: harmless re-read of its own operands
+      fetch(bnxt, anxt, kn);
     }
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
@@ -151,23 +155,19 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     const int ncb_real = (ly.N + 15) / 16;
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
-    if (vec) {
-      switch (nc) {
-        case 4: layer_gemm<true, 4>(ly, panel, wave, lane, acc, g.ablate); break;
-        case 3: layer_gemm<true, 3>(ly, panel, wave, lane, acc, g.ablate); break;
-        case 2: layer_gemm<true, 2>(ly, panel, wave, lane, acc, g.ablate); break;
-        case 1: layer_gemm<true, 1>(ly, panel, wave, lane, acc, g.ablate); break;
-        default: break;
-      }
-    } else {
-      switch (nc) {
-        case 4: layer_gemm<false, 4>(ly, panel, wave, lane, acc, g.ablate); break;
-        case 3: layer_gemm<false, 3>(ly, panel, wave, lane, acc, g.ablate); break;
-        case 2: layer_gemm<false, 2>(ly, panel, wave, lane, acc, g.ablate); break;
-        case 1: layer_gemm<false, 1>(ly, panel, wave, lane, acc, g.ablate); break;
-        default: break;
-      }
+    const float* pk = g.packed ? g.packed + g.pack_off[l] : nullptr;
+#define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                     \
+    switch (nc) {                                                                          \
+      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc); break;           \
+      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc); break;           \
+      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc); break;           \
+      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc); break;           \
+      default: break;                                                                      \
     }
+    if (pk) { CLICA_FMLP_DISPATCH(true, true) }
+    else if (vec) { CLICA_FMLP_DISPATCH(true, false) }
+    else { CLICA_FMLP_DISPATCH(false, false) }
+#undef CLICA_FMLP_DISPATCH
     __syncthreads();                                   // every wave is done reading the input panel
 
     // epilogue into the panel: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg.
@@ -195,8 +195,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
 
     // stream the new activations to HBM straight from the panel (coalesced rows)
     const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
-    if (g.ablate & 1) {
-    } else if (ovec) {
+    if (ovec) {
       const int n4 = ly.N / 4;
       for (int idx = threadIdx.x; idx < nrows * n4; idx += THREADS) {
         const int r = idx / n4, c4 = idx - r * n4;
@@ -217,21 +216,83 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   }
 }
 
+// ---- weight packing: nn.Linear layout -> MFMA fragment order ----------------------------------------------
+// packed[layer][cb][ki][h][lane] (float4) = W[cb*16 + (lane&15)][ki*32 + h*16 + 4*(lane>>4) .. +3], zero padded.
+// A wave's B-fragment load for (cb, ki, h) is then ONE fully contiguous 1 KB request instead of sixteen 64-byte
+// pieces of sixteen different weight rows (which made the fused forward texture-addresser bound).
+struct PackArgs {
+  int L; const float* W[MAXL]; int64_t ldw[MAXL]; int N[MAXL], K[MAXL];
+  int64_t off[MAXL + 1];    // destination offsets, float4 units
+  int64_t src[MAXL + 1];    // source work items: N * ceil(K/4) per layer
+};
+static inline int64_t pack_float4s(int N, int K) { return (int64_t)((N + 15) / 16) * ((K + KI - 1) / KI) * 2 * 64; }
+
+// One thread per SOURCE float4 (row n, k..k+3): coalesced reads of the nn.Linear rows, 16-byte scattered
+// writes.  The zero padding (n >= N inside the last column block, k >= K inside the last k-iteration) is
+// never written here: the caller provides a buffer that was zeroed ONCE (padding float4s have no source
+// element and stay zero across re-packs).
+__global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a, float4* __restrict__ packed) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.src[a.L]) return;
+  int l = 0;
+  while (l + 1 < a.L && idx >= a.src[l + 1]) ++l;
+  const int64_t e = idx - a.src[l];
+  const int K = a.K[l], k4n = (K + 3) / 4;
+  const int n = (int)(e / k4n), k = (int)(e - (int64_t)n * k4n) * 4;
+  const float* row = a.W[l] + (int64_t)n * a.ldw[l] + k;
+  float4 v;
+  if (k + 3 < K && ((reinterpret_cast<uintptr_t>(row) & 15) == 0)) v = *reinterpret_cast<const float4*>(row);
+  else v = make_float4(row[0], k + 1 < K ? row[1] : 0.f, k + 2 < K ? row[2] : 0.f, k + 3 < K ? row[3] : 0.f);
+  const int kiters = (K + KI - 1) / KI;
+  const int cb = n >> 4, i15 = n & 15, ki = k / KI, h = (k % KI) >> 4, q = (k & 15) >> 2;
+  packed[a.off[l] + ((int64_t)(cb * kiters + ki) * 2 + h) * 64 + q * 16 + i15] = v;
+}
+
 }  // namespace fmlp
 }  // namespace clica
 
 using namespace clica;
 
+extern "C" int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(N && K && bytes && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack_bytes: bad argument");
+  int64_t f4 = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_pack_bytes: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
+    f4 += pack_float4s(N[l], K[l]);
+  }
+  *bytes = (size_t)f4 * 16;
+  return CLICA_OK;
+}
+
+extern "C" int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                              float* packed, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(W && ldw && N && K && packed && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_pack: packed buffer must be 16-byte aligned");
+  PackArgs a{};
+  a.L = n_layers; a.off[0] = 0; a.src[0] = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack: layer %d: bad argument", l);
+    a.W[l] = W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l];
+    a.off[l + 1] = a.off[l] + pack_float4s(N[l], K[l]);
+    a.src[l + 1] = a.src[l] + (int64_t)N[l] * ((K[l] + 3) / 4);
+  }
+  hipLaunchKernelGGL(mlp_pack_k, dim3((unsigned)ceil_div(a.src[n_layers], 256)), dim3(256), 0, as_stream(stream), a, reinterpret_cast<float4*>(packed));
+  return launch_status("clica_mlp_pack");
+}
+
 extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                              const float* const* W, const int64_t* ldw, const float* const* bias,
                              float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                             float slope, clica_stream_t stream) {
+                             const float* packed, float slope, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(X && W && ldw && bias && out && ldo && N && K && M > 0, "clica_mlp_fwd: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd: %d layers (1..%d supported)", n_layers, MAXL);
   Args g{};
-  g.X = X; g.ldx = ldx; g.M = M; g.L = n_layers; g.slope = slope;
-  { const char* e = getenv("CLICA_MLP_ABLATE"); g.ablate = e ? atoi(e) : 0; }
+  g.X = X; g.ldx = ldx; g.M = M; g.L = n_layers; g.slope = slope; g.packed = packed;
+  CLICA_CHECK_ARG(!packed || (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_fwd: packed weights must be 16-byte aligned");
+  int64_t poff = 0;
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(W[l] && out[l] && N[l] >= 1 && K[l] >= 1, "clica_mlp_fwd: layer %d: bad argument", l);
     CLICA_CHECK_ARG(N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_fwd: layer %d is %d x %d; the on-chip panel holds widths <= %d "
@@ -239,6 +300,7 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
     CLICA_CHECK_ARG(ldw[l] >= K[l] && ldo[l] >= N[l], "clica_mlp_fwd: layer %d: leading dimension too small", l);
     CLICA_CHECK_ARG(l == 0 || K[l] == N[l - 1], "clica_mlp_fwd: layer %d input width %d != previous output width %d", l, K[l], N[l - 1]);
     g.layer[l] = Layer{W[l], ldw[l], bias[l], out[l], ldo[l], N[l], K[l], l + 1 < n_layers ? 1 : 0};
+    g.pack_off[l] = poff; poff += pack_float4s(N[l], K[l]) * 4;
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd: ldx < K[0]");
   constexpr size_t lds = (size_t)ROWS * LDP * sizeof(float);

@@ -17,6 +17,7 @@ flat gradient arena; semantics = the single-process loss on the concatenated bat
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -79,6 +80,8 @@ class ContrastiveTrainer:
         self.head = heads[0] if heads else None
         self._flatten_parameters()
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
+        self.packed = None
+        self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes,
@@ -180,7 +183,10 @@ class ContrastiveTrainer:
         L = len(self.linears)
         if self.fused_forward:
             # one launch for the whole stack, activation panel resident in LDS (csrc/fused_mlp.hip)
-            ops.mlp_fwd(cur, [lin.weight for lin in self.linears], [lin.bias for lin in self.linears], self.acts, self.slope)
+            ws = [lin.weight for lin in self.linears]
+            if self.pack_weights:
+                self.packed = ops.mlp_pack_weights(ws, self.packed)  # fragment-order copy of the current weights
+            ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed)
             cur = self.acts[-1]
         else:
             for l, lin in enumerate(self.linears):

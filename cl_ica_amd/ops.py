@@ -80,9 +80,26 @@ def mlp_fwd_fusable(weights) -> bool:
     return len(weights) <= MLP_FUSED_MAX_LAYERS and all(max(w.shape) <= MLP_FUSED_MAX_WIDTH for w in weights)
 
 
-def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01):
+def mlp_pack_weights(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weights in MFMA fragment order for `mlp_fwd(..., packed=...)` (clica_mlp_pack).  Re-run after every
+    parameter update; `packed` is reused when given."""
+    L = len(weights)
+    ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
+    I32 = C.c_int32 * L
+    Ns, Ks = I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws])
+    if packed is None:
+        nb = C.c_size_t()
+        check(load().clica_mlp_pack_bytes(L, Ns, Ks, C.byref(nb)), "clica_mlp_pack_bytes")
+        packed = torch.zeros(nb.value // 4, dtype=torch.float32, device=ws[0][0].device)   # zero padding written once
+    check(load().clica_mlp_pack(L, (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws]),
+                                Ns, Ks, packed.data_ptr(), stream_ptr()), "clica_mlp_pack")
+    return packed
+
+
+def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed: Optional[torch.Tensor] = None):
     """Whole Linear(+LeakyReLU) stack in one launch (clica_mlp_fwd); `outs[l]` receives layer l's output
-    (saved activations; the last one is the result).  Widths <= 512, <= 8 layers."""
+    (saved activations; the last one is the result).  Widths <= 512, <= 8 layers.  `packed` = the same
+    weights from `mlp_pack_weights` (faster weight streaming)."""
     (x, ldx) = _mat("x", x)
     L = len(weights)
     ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
@@ -97,7 +114,7 @@ def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01):
                                VP(*[None if b is None else b.data_ptr() for b in bs]),
                                VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
                                I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws]),
-                               float(slope), stream_ptr()), "clica_mlp_fwd")
+                               ptr(packed), float(slope), stream_ptr()), "clica_mlp_fwd")
     return outs[-1]
 
 

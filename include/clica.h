@@ -177,11 +177,19 @@ int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ld
  * (the backward needs the saved activations).  All widths must be <= 512 and n_layers <= 8 (the n = 10
  * encoder of main_mlp.py:297-307); otherwise CLICA_E_INVALID -- call clica_linear_fwd per layer instead.
  * W / ldw / bias / out / ldo / N / K are HOST arrays of n_layers entries (the pointers in them are device
- * pointers). */
+ * pointers).
+ * `packed` (optional, NULL = read W directly): the same weights in MFMA fragment order, produced by
+ * clica_mlp_pack into a buffer of clica_mlp_pack_bytes; a wave's weight fetch is then one contiguous 1 KB
+ * request instead of sixteen 64-byte pieces (re-pack after every optimizer step: ~3.4 MB, a few us).  The
+ * packed buffer must be ZEROED ONCE by the caller before its first clica_mlp_pack (padding entries are never
+ * written). */
 int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                   const float* const* W, const int64_t* ldw, const float* const* bias,
                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                  float slope, clica_stream_t stream);
+                  const float* packed, float slope, clica_stream_t stream);
+int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes);
+int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                   float* packed, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads  --  RescaleLayer (mode "eq") layers.py:63-66, SoftclipLayer layers.py:87-91

@@ -165,5 +165,11 @@ def test_fused_mlp_forward_matches_per_layer(dims, M):
         assert rel_err(outs[l].cpu().numpy(), cur64) < 5e-6, ("fp64", l)
         assert rel_err(outs[l].cpu().numpy(), cur.cpu().numpy()) < 5e-6, ("per-layer", l)
     assert y.data_ptr() == outs[-1].data_ptr()
+    # fragment-order (packed) weights: same arithmetic, so bit-identical to the direct-load variant
+    packed = ops.mlp_pack_weights(Wd)
+    outs2 = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    ops.mlp_fwd(dev(x), Wd, bd, outs2, 0.01, packed=packed)
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
     with pytest.raises(Exception):
         ops.mlp_fwd(dev(x), [torch.zeros(600, dims[0], device="cuda")], [None], [torch.empty(M, 600, device="cuda")])

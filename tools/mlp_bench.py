@@ -29,10 +29,12 @@ def layered():
     for l in range(7):
         ops.linear_fwd(cur, Ws[l], bs[l], leaky=(l < 6), slope=0.01, out=outs[l]); cur = outs[l]
 flops = 2.0 * M * sum(dims[i] * dims[i + 1] for i in range(7))
-for ab in ("0", "1", "2", "3"):
-    os.environ["CLICA_MLP_ABLATE"] = ab
-    tf = replay_time(fused)
-    print(f"fused ablate={ab}: {tf:7.1f} us  {flops/tf/1e6:6.1f} TFLOP/s")
-os.environ["CLICA_MLP_ABLATE"] = "0"
+packed = ops.mlp_pack_weights(Ws)
+def fused_packed(): ops.mlp_fwd(x, Ws, bs, outs, 0.01, packed=packed)
+def pack(): ops.mlp_pack_weights(Ws, packed)
+for name, fn in (("fused (direct W)", fused), ("fused (packed W)", fused_packed)):
+    tf = replay_time(fn)
+    print(f"{name}: {tf:7.1f} us  {flops/tf/1e6:6.1f} TFLOP/s")
+print(f"pack kernel: {replay_time(pack):6.1f} us")
 tl = replay_time(layered)
 print(f"7 layers: {tl:7.1f} us  {flops/tl/1e6:6.1f} TFLOP/s")
