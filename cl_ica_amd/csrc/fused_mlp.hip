@@ -33,8 +33,10 @@ constexpr int MAXL = 8;
 
 struct Layer {
   const float* W; int64_t ldw; const float* bias;
-  float* out; int64_t ldo;           // HBM copy of the layer output (saved activation / final result)
+  float* out; int64_t ldo;           // HBM copy of the layer output (saved activation / final result / dZ)
+  const float* aux; int64_t ldaux;   // dact mode: saved activation [M, N] whose sign gives act'
   int N, K, leaky;
+  int dact;                          // 0: out = act(acc + bias)   1: out = acc * act'(aux)   (backward data chain)
 };
 struct Args {
   const float* X; int64_t ldx; int64_t M; int L; float slope;
@@ -178,14 +180,18 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
       const int cb = wave + c * WAVES;
       if (cb < ncb) {
         const int col = cb * 16 + (lane & 15);
-        const float bv = (ly.bias && col < ly.N) ? ly.bias[col] : 0.f;
+        const float bv = (!ly.dact && ly.bias && col < ly.N) ? ly.bias[col] : 0.f;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int row = r * 16 + (lane >> 4) * 4 + e;
             float v = acc[r][c][e] + bv;
-            if (ly.leaky) v = v > 0.f ? v : v * g.slope;
+            if (ly.dact) {          // dZ_{l-1} = (dZ_l W_l) * LeakyReLU'(a_{l-1}); sign(a) = sign(pre-activation)
+              if (ly.aux && row < nrows && col < ly.N) v *= (ly.aux[(row0 + row) * ly.ldaux + col] > 0.f ? 1.f : g.slope);
+            } else if (ly.leaky) {
+              v = v > 0.f ? v : v * g.slope;
+            }
             panel[row * LDP + col] = col < ly.N ? v : 0.f;
           }
         }
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
 // A wave's B-fragment load for (cb, ki, h) is then ONE fully contiguous 1 KB request instead of sixteen 64-byte
 // pieces of sixteen different weight rows (which made the fused forward texture-addresser bound).
 struct PackArgs {
-  int L; const float* W[MAXL]; int64_t ldw[MAXL]; int N[MAXL], K[MAXL];
+  int L, transpose; const float* W[MAXL]; int64_t ldw[MAXL]; int N[MAXL], K[MAXL];   // stored nn.Linear dims [N, K]
   int64_t off[MAXL + 1];    // destination offsets, float4 units
   int64_t src[MAXL + 1];    // source work items: N * ceil(K/4) per layer
 };
@@ -243,9 +249,22 @@ __global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a, float4* __restrict
   float4 v;
   if (k + 3 < K && ((reinterpret_cast<uintptr_t>(row) & 15) == 0)) v = *reinterpret_cast<const float4*>(row);
   else v = make_float4(row[0], k + 1 < K ? row[1] : 0.f, k + 2 < K ? row[2] : 0.f, k + 3 < K ? row[3] : 0.f);
-  const int kiters = (K + KI - 1) / KI;
-  const int cb = n >> 4, i15 = n & 15, ki = k / KI, h = (k % KI) >> 4, q = (k & 15) >> 2;
-  packed[a.off[l] + ((int64_t)(cb * kiters + ki) * 2 + h) * 64 + q * 16 + i15] = v;
+  if (!a.transpose) {
+    const int kiters = (K + KI - 1) / KI;
+    const int cb = n >> 4, i15 = n & 15, ki = k / KI, h = (k % KI) >> 4, q = (k & 15) >> 2;
+    packed[a.off[l] + ((int64_t)(cb * kiters + ki) * 2 + h) * 64 + q * 16 + i15] = v;
+  } else {
+    // logical matrix = W^T: row n' = k + u (output column of the data-gradient), contraction k' = n
+    float* pf = reinterpret_cast<float*>(packed + a.off[l]);
+    const int kiters = (a.N[l] + KI - 1) / KI;
+    const int ki = n / KI, h = (n % KI) >> 4, q = (n & 15) >> 2, t = n & 3;
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int np = k + u;
+      if (np < K) pf[(((int64_t)((np >> 4) * kiters + ki) * 2 + h) * 64 + q * 16 + (np & 15)) * 4 + t] = vv[u];
+    }
+  }
 }
 
 }  // namespace fmlp
@@ -253,29 +272,29 @@ __global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a, float4* __restrict
 
 using namespace clica;
 
-extern "C" int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes) {
+extern "C" int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes) {
   using namespace fmlp;
   CLICA_CHECK_ARG(N && K && bytes && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack_bytes: bad argument");
   int64_t f4 = 0;
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_pack_bytes: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
-    f4 += pack_float4s(N[l], K[l]);
+    f4 += transpose ? pack_float4s(K[l], N[l]) : pack_float4s(N[l], K[l]);
   }
   *bytes = (size_t)f4 * 16;
   return CLICA_OK;
 }
 
 extern "C" int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
-                              float* packed, clica_stream_t stream) {
+                              int32_t transpose, float* packed, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(W && ldw && N && K && packed && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack: bad argument");
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_pack: packed buffer must be 16-byte aligned");
   PackArgs a{};
-  a.L = n_layers; a.off[0] = 0; a.src[0] = 0;
+  a.L = n_layers; a.transpose = transpose ? 1 : 0; a.off[0] = 0; a.src[0] = 0;
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack: layer %d: bad argument", l);
     a.W[l] = W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l];
-    a.off[l + 1] = a.off[l] + pack_float4s(N[l], K[l]);
+    a.off[l + 1] = a.off[l] + (transpose ? pack_float4s(K[l], N[l]) : pack_float4s(N[l], K[l]));
     a.src[l + 1] = a.src[l] + (int64_t)N[l] * ((K[l] + 3) / 4);
   }
   hipLaunchKernelGGL(mlp_pack_k, dim3((unsigned)ceil_div(a.src[n_layers], 256)), dim3(256), 0, as_stream(stream), a, reinterpret_cast<float4*>(packed));
@@ -299,7 +318,7 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
                     "(use the per-layer clica_linear_fwd for wider encoders)", l, N[l], K[l], MAXW);
     CLICA_CHECK_ARG(ldw[l] >= K[l] && ldo[l] >= N[l], "clica_mlp_fwd: layer %d: leading dimension too small", l);
     CLICA_CHECK_ARG(l == 0 || K[l] == N[l - 1], "clica_mlp_fwd: layer %d input width %d != previous output width %d", l, K[l], N[l - 1]);
-    g.layer[l] = Layer{W[l], ldw[l], bias[l], out[l], ldo[l], N[l], K[l], l + 1 < n_layers ? 1 : 0};
+    g.layer[l] = Layer{W[l], ldw[l], bias[l], out[l], ldo[l], nullptr, 0, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0};
     g.pack_off[l] = poff; poff += pack_float4s(N[l], K[l]) * 4;
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd: ldx < K[0]");
@@ -308,4 +327,35 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
   (void)once;
   hipLaunchKernelGGL(mlp_fwd_k, dim3((unsigned)ceil_div(M, ROWS)), dim3(THREADS), lds, as_stream(stream), g);
   return launch_status("clica_mlp_fwd");
+}
+
+
+// Backward data chain in one launch: for j = 0..n-1   out[j] = (in_j B_j) * LeakyReLU'(act[j]),  in_0 = dY, in_j = out[j-1]
+// where B_j is given ONLY in packed fragment order (clica_mlp_pack(..., transpose = 1) of the layers in chain
+// order, i.e. the encoder's layers L-1 .. 1) and N[j] / K[j] are the logical output / contraction widths of
+// link j (= K_l / N_l of the encoder layer it differentiates).
+extern "C" int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
+                               const int32_t* N, const int32_t* K, const float* packed,
+                               const float* const* act, const int64_t* ldact,
+                               float* const* out, const int64_t* ldo, float slope, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(dY && N && K && packed && act && ldact && out && ldo && M > 0, "clica_mlp_dgrad: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(n_links >= 1 && n_links <= MAXL, "clica_mlp_dgrad: %d links (1..%d supported)", n_links, MAXL);
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_dgrad: packed weights must be 16-byte aligned");
+  Args g{};
+  g.X = dY; g.ldx = lddy; g.M = M; g.L = n_links; g.slope = slope; g.packed = packed;
+  int64_t poff = 0;
+  for (int j = 0; j < n_links; ++j) {
+    CLICA_CHECK_ARG(out[j] && N[j] >= 1 && K[j] >= 1 && N[j] <= MAXW && K[j] <= MAXW, "clica_mlp_dgrad: link %d is %d x %d (max %d)", j, N[j], K[j], MAXW);
+    CLICA_CHECK_ARG(ldo[j] >= N[j] && (!act[j] || ldact[j] >= N[j]), "clica_mlp_dgrad: link %d: leading dimension too small", j);
+    CLICA_CHECK_ARG(j == 0 || K[j] == N[j - 1], "clica_mlp_dgrad: link %d contraction %d != previous width %d", j, K[j], N[j - 1]);
+    g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], act[j], ldact[j], N[j], K[j], 0, 1};
+    g.pack_off[j] = poff; poff += pack_float4s(N[j], K[j]) * 4;
+  }
+  CLICA_CHECK_ARG(lddy >= K[0], "clica_mlp_dgrad: lddy < K[0]");
+  constexpr size_t lds = (size_t)ROWS * LDP * sizeof(float);
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  hipLaunchKernelGGL(mlp_fwd_k, dim3((unsigned)ceil_div(M, ROWS)), dim3(THREADS), lds, as_stream(stream), g);
+  return launch_status("clica_mlp_dgrad");
 }

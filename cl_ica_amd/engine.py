@@ -27,6 +27,8 @@ from torch import nn
 
 from . import _lib, ops
 from . import layers as ls
+from contextlib import nullcontext as _nullctx
+
 from .distributed import GradBuckets
 
 __all__ = ["SamplerSpec", "ContrastiveTrainer"]
@@ -81,6 +83,8 @@ class ContrastiveTrainer:
         self._flatten_parameters()
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
         self.packed = None
+        self.packed_t = None
+        self.fused_backward = self.fused_forward and os.environ.get("CLICA_FUSED_BWD", "1") != "0" and len(self.linears) > 1
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -146,6 +150,8 @@ class ContrastiveTrainer:
             _lib.check(_lib.load().clica_linear_wgrad_workspace_bytes(R, lin.out_features, lin.in_features, C.byref(nb)), "wgrad ws")
             need = max(need, nb.value)
         self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        self.wgrad_ws2 = torch.zeros(need, dtype=torch.uint8, device=dev)    # second stream's slabs
+        self.dz = [torch.empty((R, w), **f32) for w in widths[:-1]] if self.fused_backward else None   # dZ_l for the wgrads
         if self.head is not None:
             self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
             hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
@@ -247,14 +253,42 @@ class ContrastiveTrainer:
                 hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
                 torch.sum(self.head_part, dim=0, out=self._gviews[id(hp)])
             g = self.dpre
-        # Two streams: wgrad_l (weight/bias gradients into the arena, + bucket all-reduce) runs on the side
-        # stream while the main stream continues the dZ chain with dgrad_l -- the two GEMMs are
-        # independent given dZ_l, and each hides the other's prologue / epilogue-store bubbles.  Three dZ
-        # buffers rotate; a buffer is rewritten only after the wgrad that read it has finished.
         L = len(self.linears)
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         side = self.side_stream
         two = side is not None and main is not None
+        if self.fused_backward:
+            # (1) whole data-gradient chain dZ_{L-1} -> ... -> dZ_0 in ONE launch (dZ panel resident in LDS,
+            #     transposed fragment-order weights), every dZ_l also written to HBM;
+            # (2) the weight-gradient GEMMs, independent of each other, alternate between two streams so one's
+            #     prologue / slab reduction hides behind the other's MFMA phase.
+            chain = list(range(L - 1, 0, -1))
+            ws = [self.linears[l].weight for l in chain]
+            self.packed_t = ops.mlp_pack_weights(ws, self.packed_t, transpose=True)
+            ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope)
+            use_two = two and self.buckets is None
+            if use_two:
+                side.wait_stream(main)
+            for i, l in enumerate(reversed(range(L))):
+                lin = self.linears[l]
+                gl = g if l == L - 1 else self.dz[l]
+                inp = self.acts[l - 1] if l > 0 else self.x
+                on_side = use_two and (i & 1)
+                with torch.cuda.stream(side) if on_side else _nullctx():
+                    ops.linear_wgrad(gl, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)], accumulate=False,
+                                     ws=self.wgrad_ws2 if on_side else self.wgrad_ws)
+                if self.buckets is not None:
+                    self.buckets.layer_done(L - 1 - l)
+            if use_two:
+                main.wait_stream(side)
+            if self.buckets is not None:
+                self.buckets.wait()
+            return
+        # Per-layer path (wide encoders).  Two streams: wgrad_l (weight/bias gradients into the arena, + bucket
+        # all-reduce) runs on the side
+        # stream while the main stream continues the dZ chain with dgrad_l -- the two GEMMs are
+        # independent given dZ_l, and each hides the other's prologue / epilogue-store bubbles.  Three dZ
+        # buffers rotate; a buffer is rewritten only after the wgrad that read it has finished.
         reader_done = {}        # dZ buffer index -> event of the wgrad that reads it
         buf_of_g = None         # index into self.dbuf holding the current dZ (None: self.dy / self.dpre)
         nxt = 0

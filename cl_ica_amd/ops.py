@@ -80,19 +80,20 @@ def mlp_fwd_fusable(weights) -> bool:
     return len(weights) <= MLP_FUSED_MAX_LAYERS and all(max(w.shape) <= MLP_FUSED_MAX_WIDTH for w in weights)
 
 
-def mlp_pack_weights(weights, packed: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Weights in MFMA fragment order for `mlp_fwd(..., packed=...)` (clica_mlp_pack).  Re-run after every
-    parameter update; `packed` is reused when given."""
+def mlp_pack_weights(weights, packed: Optional[torch.Tensor] = None, transpose: bool = False) -> torch.Tensor:
+    """Weights in MFMA fragment order for `mlp_fwd(..., packed=...)` (clica_mlp_pack), or -- with
+    ``transpose`` and the layers given in chain order (last layer first) -- for `mlp_dgrad_chain`.
+    Re-run after every parameter update; `packed` is reused when given."""
     L = len(weights)
     ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
     I32 = C.c_int32 * L
     Ns, Ks = I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws])
     if packed is None:
         nb = C.c_size_t()
-        check(load().clica_mlp_pack_bytes(L, Ns, Ks, C.byref(nb)), "clica_mlp_pack_bytes")
+        check(load().clica_mlp_pack_bytes(L, Ns, Ks, int(transpose), C.byref(nb)), "clica_mlp_pack_bytes")
         packed = torch.zeros(nb.value // 4, dtype=torch.float32, device=ws[0][0].device)   # zero padding written once
     check(load().clica_mlp_pack(L, (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws]),
-                                Ns, Ks, packed.data_ptr(), stream_ptr()), "clica_mlp_pack")
+                                Ns, Ks, int(transpose), packed.data_ptr(), stream_ptr()), "clica_mlp_pack")
     return packed
 
 
@@ -116,6 +117,23 @@ def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed:
                                I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws]),
                                ptr(packed), float(slope), stream_ptr()), "clica_mlp_fwd")
     return outs[-1]
+
+
+def mlp_dgrad_chain(dy: torch.Tensor, weights_chain, packed_t: torch.Tensor, acts_chain, outs, slope: float = 0.01):
+    """Backward data chain in one launch (clica_mlp_dgrad).  `weights_chain` = encoder weights in chain order
+    (layer L-1 first ... layer 1), `packed_t` = mlp_pack_weights(weights_chain, transpose=True), `acts_chain[j]`
+    = saved activation that fed layer j of the chain, `outs[j]` = dZ of the layer below (written)."""
+    (dy, lddy) = _mat("dy", dy)
+    n = len(weights_chain)
+    I32, I64, VP = C.c_int32 * n, C.c_int64 * n, C.c_void_p * n
+    acts = [None if a is None else _mat("act", a) for a in acts_chain]
+    check(load().clica_mlp_dgrad(dy.data_ptr(), lddy, dy.shape[0], n,
+                                 I32(*[w.shape[1] for w in weights_chain]), I32(*[w.shape[0] for w in weights_chain]),
+                                 packed_t.data_ptr(),
+                                 VP(*[None if a is None else a[0].data_ptr() for a in acts]), I64(*[0 if a is None else a[1] for a in acts]),
+                                 VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+                                 float(slope), stream_ptr()), "clica_mlp_dgrad")
+    return outs
 
 
 def linear_plan(op: str, M: int, N: int, K: int):

@@ -187,9 +187,19 @@ int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                   const float* const* W, const int64_t* ldw, const float* const* bias,
                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
                   const float* packed, float slope, clica_stream_t stream);
-int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes);
+int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
 int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
-                   float* packed, clica_stream_t stream);
+                   int32_t transpose, float* packed, clica_stream_t stream);
+/* Backward data chain of the same stack in one launch (dZ panel resident in LDS):
+ *   out[j] = (in_j B_j) * LeakyReLU'(act[j]),  in_0 = dY, in_j = out[j-1],  j = 0..n_links-1
+ * B_j only in fragment order: `packed` = clica_mlp_pack(..., transpose = 1, ...) of the encoder layers in CHAIN
+ * order (layer L-1 first, down to layer 1); N[j] / K[j] = output / contraction width of link j (= K_l / N_l of
+ * the layer it differentiates); act[j] = the saved activation that fed that layer (sign -> act'), NULL = none;
+ * out[j] = dZ of the layer below, written to HBM for the weight-gradient GEMMs.  Widths <= 512. */
+int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
+                    const int32_t* N, const int32_t* K, const float* packed,
+                    const float* const* act, const int64_t* ldact,
+                    float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads  --  RescaleLayer (mode "eq") layers.py:63-66, SoftclipLayer layers.py:87-91

@@ -173,3 +173,27 @@ def test_fused_mlp_forward_matches_per_layer(dims, M):
         assert torch.equal(a, b)
     with pytest.raises(Exception):
         ops.mlp_fwd(dev(x), [torch.zeros(600, dims[0], device="cuda")], [None], [torch.empty(M, 600, device="cuda")])
+
+
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
+                                      ([16, 16, 16], 47)])
+def test_fused_dgrad_chain_matches_per_layer(dims, M):
+    """clica_mlp_dgrad (dZ panel resident in LDS, transposed fragment-order weights) vs per-layer dgrad GEMMs."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(len(dims) * 7 + M)
+    L = len(dims) - 1
+    Ws = [dev((rng.uniform(-1, 1, size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(L)]
+    acts = [dev(rng.normal(size=(M, dims[i])).astype(np.float32)) for i in range(L)]      # acts[l] feeds layer l
+    dy = dev(rng.normal(size=(M, dims[-1])).astype(np.float32))
+    chain_w = [Ws[l] for l in range(L - 1, 0, -1)]
+    chain_a = [acts[l] for l in range(L - 1, 0, -1)]
+    outs = [torch.empty(M, dims[l], device="cuda") for l in range(L - 1, 0, -1)]
+    packed_t = ops.mlp_pack_weights(chain_w, transpose=True)
+    ops.mlp_dgrad_chain(dy, chain_w, packed_t, chain_a, outs, 0.01)
+    g = dy
+    g64 = dy.cpu().numpy().astype(np.float64)
+    for j, l in enumerate(range(L - 1, 0, -1)):
+        g = ops.linear_dgrad(g, Ws[l], acts[l], 0.01)
+        g64 = (g64 @ Ws[l].cpu().numpy().astype(np.float64)) * np.where(acts[l].cpu().numpy() > 0, 1.0, 0.01)
+        assert rel_err(outs[j].cpu().numpy(), g64) < 1e-5, ("fp64", l)
+        assert rel_err(outs[j].cpu().numpy(), g.cpu().numpy()) < 1e-5, ("per-layer", l)
