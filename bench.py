@@ -13,8 +13,9 @@ At N GPUs every rank processes its own B=6144 batch per global step against the 
 N*B negatives pool (weak scaling); `value` counts batches/s over all ranks = N * global_steps/s.
 
 Besides the contract fields the JSON line carries
-  roofline      -- the dominant kernel class (fp32-MFMA Linear GEMMs) timed with HIP events,
-                   algorithmic FLOPs / time vs the 157.3 TFLOP/s fp32 matrix peak
+  roofline      -- the step's dominant kernel symbol (the fused fp32-MFMA MLP kernel `mlp_fwd_k`: forward
+                   stack + backward data chain; per-layer `gemm_k` for wide encoders) timed with HIP
+                   events, algorithmic FLOPs / time vs the 157.3 TFLOP/s fp32 matrix peak
   cpu_baseline  -- oracle/torch_port.py (the reference's op sequence in PyTorch CPU ops) timed on
                    this box's host cores, rank 0 at N=1 only
 """
@@ -69,73 +70,114 @@ def build_trainer(args, device, world):
                               overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward)
 
 
+def _graph_time(fns, reps):
+    """Capture the launches `fns` into a HIP graph, replay it `reps` times between two HIP events on the
+    launch stream; returns seconds per replay (kernel time + ~1 us in-graph launch boundary each)."""
+    for fn in fns:
+        fn()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for fn in fns:
+            fn()
+    graph.replay(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        graph.replay()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / reps
+
+
 def roofline_leg(tr, reps=20):
-    """Per KERNEL INSTANCE (= one symbol in the rocprofv3 summary: layout x tile) timing of the step's
-    GEMM launches.  For each instance the launches of one step are captured into a HIP graph and the
-    graph is replayed `reps` times between two HIP events on the launch stream, so the figure is
-    kernel time (plus the ~1 us in-graph launch boundary), not host launch latency -- comparable with
-    the rocprofv3 average for that symbol (profiles/).  FLOPs are algorithmic: 2*M*N*K per launch.
-    The `roofline` entry is the FORWARD GEMM instance with the largest share: the three GEMM classes
-    (fwd / dgrad / wgrad) are within ~20 % of each other per step, but in the real step dgrad and wgrad
-    are co-scheduled on two streams (their in-situ durations in a kernel trace are inflated by sharing
-    the chip) and a wgrad launch is two kernels; the forward kernel runs alone, so its isolated time
-    here and its in-situ average in profiles/ are the same quantity.  All instances are in `kernels`."""
+    """Per KERNEL SYMBOL (= one row of the rocprofv3 summary) timing of the encoder launches the step
+    really issues (same ops, same buffers, same order as ContrastiveTrainer.forward/backward).  For each
+    symbol the step's launches of it are captured into a HIP graph that is replayed `reps` times between
+    two HIP events on the launch stream, so the figure is kernel time, not host launch latency --
+    comparable with the rocprofv3 average for that symbol (profiles/).  FLOPs are algorithmic: 2*M*N*K per
+    Linear application, nothing for the epilogues.
+    Narrow encoders (every width <= 512, the north-star n=10 config) run the whole forward stack and the
+    whole backward data chain as ONE `mlp_fwd_k` launch each; that symbol is then the step's dominant
+    kernel (~43 % of kernel time) and is the `roofline` entry, averaged over its two launches per step
+    exactly as the profiler averages them.  Wide encoders (n=40) run per-layer `gemm_k` launches and the
+    entry is the forward GEMM instance with the largest share.  All symbols are listed in `kernels`."""
     from cl_ica_amd import ops
     R = 2 * tr.B
+    L = len(tr.linears)
     groups = {}
 
-    def add(op, N, K, fn):
+    def add(key, flops, fn):
+        g = groups.setdefault(key, {"fns": [], "flops": 0.0})
+        g["fns"].append(fn); g["flops"] += flops
+
+    def gemm_key(op, N, K):
         tm, tn, waves, splits = ops.linear_plan(op, R, N, K)
         vec = (N % 4 == 0 and K % 4 == 0)
         layout = {"fwd": "true, true, 0", "dgrad": "true, false, 1", "wgrad": "false, false, 2"}[op]
-        key = (op, f"gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>")
-        g = groups.setdefault(key, {"fns": [], "flops": 0.0})
-        g["fns"].append(fn); g["flops"] += 2.0 * R * N * K
+        return ("linear_" + op, f"clica::gemm::gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>"
+                + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 
-    cur = tr.x
-    L = len(tr.linears)
-    for l, lin in enumerate(tr.linears):
-        N, K = lin.out_features, lin.in_features
-        add("fwd", N, K, lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1),
-                                                                        slope=tr.slope, out=tr.acts[l]))
-        cur = tr.acts[l]
-    g_ = tr.dy
-    for l in reversed(range(L)):
-        lin = tr.linears[l]
-        N, K = lin.out_features, lin.in_features
-        inp = tr.acts[l - 1] if l > 0 else tr.x
-        add("wgrad", N, K, lambda g=g_, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)],
-                                                                           db=tr._gviews[id(lin.bias)], ws=tr.wgrad_ws))
-        if l > 0:
-            out = tr.dbuf[l & 1][:, :K]
-            add("dgrad", N, K, lambda g=g_, lin=lin, inp=inp, out=out: ops.linear_dgrad(g, lin.weight, inp, tr.slope, out=out))
-            g_ = out
+    fused_key = ("mlp_fwd+mlp_dgrad", "clica::fmlp::mlp_fwd_k")
+    if tr.fused_forward:
+        ws = [lin.weight for lin in tr.linears]
+        fl = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
+        add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed))
+        add(("mlp_fwd", "clica::fmlp::mlp_fwd_k [forward stack launch]"), fl, groups[fused_key]["fns"][-1])
+    else:
+        cur = tr.x
+        for l, lin in enumerate(tr.linears):
+            N, K = lin.out_features, lin.in_features
+            add(gemm_key("fwd", N, K), 2.0 * R * N * K,
+                lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=tr.slope, out=tr.acts[l]))
+            cur = tr.acts[l]
+    g_top = tr.dy if tr.head is None else tr.dpre
+    if tr.fused_backward:
+        chain = list(range(L - 1, 0, -1))
+        wsT = [tr.linears[l].weight for l in chain]
+        fl = sum(2.0 * R * tr.linears[l].out_features * tr.linears[l].in_features for l in chain)
+        fn = lambda: ops.mlp_dgrad_chain(g_top, wsT, tr.packed_t, [tr.acts[l - 1] for l in chain],
+                                         [tr.dz[l - 1] for l in chain], tr.slope)
+        add(fused_key, fl, fn)
+        add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k [backward data chain launch]"), fl, fn)
+        for l in reversed(range(L)):
+            lin = tr.linears[l]
+            N, K = lin.out_features, lin.in_features
+            gl = g_top if l == L - 1 else tr.dz[l]
+            inp = tr.acts[l - 1] if l > 0 else tr.x
+            add(gemm_key("wgrad", N, K), 2.0 * R * N * K,
+                lambda gl=gl, inp=inp, lin=lin: ops.linear_wgrad(gl, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)],
+                                                                 ws=tr.wgrad_ws))
+    else:
+        g_ = g_top
+        for l in reversed(range(L)):
+            lin = tr.linears[l]
+            N, K = lin.out_features, lin.in_features
+            inp = tr.acts[l - 1] if l > 0 else tr.x
+            add(gemm_key("wgrad", N, K), 2.0 * R * N * K,
+                lambda g=g_, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)],
+                                                                ws=tr.wgrad_ws))
+            if l > 0:
+                out = tr.dbuf[l & 1][:, :K]
+                add(gemm_key("dgrad", N, K), 2.0 * R * N * K,
+                    lambda g=g_, lin=lin, inp=inp, out=out: ops.linear_dgrad(g, lin.weight, inp, tr.slope, out=out))
+                g_ = out
     rows = []
     for (op, sym), grp in groups.items():
-        for fn in grp["fns"]:
-            fn()
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for fn in grp["fns"]:
-                fn()
-        graph.replay(); torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(reps):
-            graph.replay()
-        e.record(); torch.cuda.synchronize()
-        sec = s.elapsed_time(e) * 1e-3 / reps
+        sec = _graph_time(grp["fns"], reps)
         cnt = len(grp["fns"])
-        rows.append({"op": "linear_" + op, "kernel": sym + (" (+ slab_reduce_k)" if op == "wgrad" else ""),
-                     "launches_per_step": cnt, "avg_us": 1e6 * sec / cnt, "gflop_per_launch": grp["flops"] / cnt / 1e9,
-                     "tflops": grp["flops"] / sec / 1e12, "us_per_step": 1e6 * sec})
+        rows.append({"op": op, "kernel": sym, "launches_per_step": cnt, "avg_us": 1e6 * sec / cnt,
+                     "gflop_per_launch": grp["flops"] / cnt / 1e9, "tflops": grp["flops"] / sec / 1e12, "us_per_step": 1e6 * sec})
     rows.sort(key=lambda r: -r["us_per_step"])
-    top = [r for r in rows if r["op"] == "linear_fwd"][0]
+    if fused_key in groups:
+        top = [r for r in rows if r["op"] == fused_key[0]][0]
+        note = "f32 (v_mfma_f32_16x16x4_f32), activation panel resident in LDS"
+    else:
+        top = [r for r in rows if r["op"] == "linear_fwd"][0]
+        note = "f32 (v_mfma_f32_32x32x2_f32)"
     roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
             "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
             "traffic": None, "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
-            "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": "f32 (v_mfma_f32_32x32x2_f32)"}
+            "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": note}
     return roof, rows
 
 
