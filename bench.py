@@ -121,7 +121,8 @@ def roofline_leg(tr, reps=20):
     if tr.fused_forward:
         ws = [lin.weight for lin in tr.linears]
         fl = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
-        add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed))
+        add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed,
+                                               signmasks=tr.signmasks))
         add(("mlp_fwd", "clica::fmlp::mlp_fwd_k [forward stack launch]"), fl, groups[fused_key]["fns"][-1])
     else:
         cur = tr.x
@@ -136,7 +137,8 @@ def roofline_leg(tr, reps=20):
         wsT = [tr.linears[l].weight for l in chain]
         fl = sum(2.0 * R * tr.linears[l].out_features * tr.linears[l].in_features for l in chain)
         fn = lambda: ops.mlp_dgrad_chain(g_top, wsT, tr.packed_t, [tr.acts[l - 1] for l in chain],
-                                         [tr.dz[l - 1] for l in chain], tr.slope)
+                                         [tr.dz[l - 1] for l in chain], tr.slope,
+                                         masks_chain=[tr.signmasks[l - 1] for l in chain])
         add(fused_key, fl, fn)
         add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k [backward data chain launch]"), fl, fn)
         for l in reversed(range(L)):

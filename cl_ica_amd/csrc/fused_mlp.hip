@@ -34,7 +34,9 @@ constexpr int MAXL = 8;
 struct Layer {
   const float* W; int64_t ldw; const float* bias;
   float* out; int64_t ldo;           // HBM copy of the layer output (saved activation / final result / dZ)
-  const float* aux; int64_t ldaux;   // dact mode: saved activation [M, N] whose sign gives act'
+  const float* aux; int64_t ldaux;   // dact mode: saved activation [M, N] whose sign gives act' (slow path, see mask_in)
+  unsigned long long* mask_out;      // forward: per-lane sign bits of this layer's output in accumulator order (or nullptr)
+  const unsigned long long* mask_in; // dact mode: the sign bits the forward stored for the same [M, N] panel (or nullptr)
   int N, K, leaky;
   int dact;                          // 0: out = act(acc + bias)   1: out = acc * act'(aux)   (backward data chain)
 };
@@ -158,6 +160,10 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
     const float* pk = g.packed ? g.packed + g.pack_off[l] : nullptr;
+    // sign bits of the saved activation, one 8-byte word per lane (issued ahead of the k-loop: it is older
+    // than every weight fetch, so the loop's counted waits cover it for free)
+    const int64_t mslot = ((int64_t)blockIdx.x * WAVES + wave) * 64 + lane;
+    unsigned long long mbits = (ly.dact && ly.mask_in) ? ly.mask_in[mslot] : 0ull;
 #define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                     \
     switch (nc) {                                                                          \
       case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc); break;           \
@@ -175,6 +181,8 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     // epilogue into the panel: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg.
     // Columns N..round_up(N, KI) are written as zeros: they are the next layer's k-padding.
     const int ncb = ((ly.N + KI - 1) & ~(KI - 1)) / 16;
+    const bool use_mask = ly.dact && ly.mask_in;
+    unsigned long long obits = 0ull;
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int cb = wave + c * WAVES;
@@ -187,16 +195,20 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
           for (int e = 0; e < 4; ++e) {
             const int row = r * 16 + (lane >> 4) * 4 + e;
             float v = acc[r][c][e] + bv;
+            const int bit = (c * RB + r) * 4 + e;
             if (ly.dact) {          // dZ_{l-1} = (dZ_l W_l) * LeakyReLU'(a_{l-1}); sign(a) = sign(pre-activation)
-              if (ly.aux && row < nrows && col < ly.N) v *= (ly.aux[(row0 + row) * ly.ldaux + col] > 0.f ? 1.f : g.slope);
+              if (use_mask) v *= ((mbits >> bit) & 1ull) ? 1.f : g.slope;
+              else if (ly.aux && row < nrows && col < ly.N) v *= (ly.aux[(row0 + row) * ly.ldaux + col] > 0.f ? 1.f : g.slope);
             } else if (ly.leaky) {
               v = v > 0.f ? v : v * g.slope;
             }
+            obits |= (v > 0.f) ? (1ull << bit) : 0ull;
             panel[row * LDP + col] = col < ly.N ? v : 0.f;
           }
         }
       }
     }
+    if (ly.mask_out) ly.mask_out[mslot] = obits;
     __syncthreads();
 
     // stream the new activations to HBM straight from the panel (coalesced rows)
@@ -207,10 +219,8 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
         const int r = idx / n4, c4 = idx - r * n4;
         // streaming store: the saved activations are not read again in this kernel, keep them from
         // evicting the weight matrix (the B operand every CU re-reads) out of L2
-        const float4 v = *reinterpret_cast<const float4*>(&panel[r * LDP + 4 * c4]);
-        float* dst = ly.out + (row0 + r) * ly.ldo + 4 * c4;
-        __builtin_nontemporal_store(v.x, dst); __builtin_nontemporal_store(v.y, dst + 1);
-        __builtin_nontemporal_store(v.z, dst + 2); __builtin_nontemporal_store(v.w, dst + 3);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&panel[r * LDP + 4 * c4]);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ly.out + (row0 + r) * ly.ldo + 4 * c4));
       }
     } else {
       for (int idx = threadIdx.x; idx < nrows * ly.N; idx += THREADS) {
@@ -284,6 +294,13 @@ extern "C" int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const in
   return CLICA_OK;
 }
 
+extern "C" int clica_mlp_signmask_bytes(int64_t M, size_t* bytes) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(bytes && M > 0, "clica_mlp_signmask_bytes: bad argument");
+  *bytes = (size_t)ceil_div(M, ROWS) * WAVES * 64 * sizeof(uint64_t);
+  return CLICA_OK;
+}
+
 extern "C" int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
                               int32_t transpose, float* packed, clica_stream_t stream) {
   using namespace fmlp;
@@ -304,7 +321,7 @@ extern "C" int clica_mlp_pack(int32_t n_layers, const float* const* W, const int
 extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                              const float* const* W, const int64_t* ldw, const float* const* bias,
                              float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                             const float* packed, float slope, clica_stream_t stream) {
+                             const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(X && W && ldw && bias && out && ldo && N && K && M > 0, "clica_mlp_fwd: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd: %d layers (1..%d supported)", n_layers, MAXL);
@@ -318,7 +335,8 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
                     "(use the per-layer clica_linear_fwd for wider encoders)", l, N[l], K[l], MAXW);
     CLICA_CHECK_ARG(ldw[l] >= K[l] && ldo[l] >= N[l], "clica_mlp_fwd: layer %d: leading dimension too small", l);
     CLICA_CHECK_ARG(l == 0 || K[l] == N[l - 1], "clica_mlp_fwd: layer %d input width %d != previous output width %d", l, K[l], N[l - 1]);
-    g.layer[l] = Layer{W[l], ldw[l], bias[l], out[l], ldo[l], nullptr, 0, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0};
+    unsigned long long* mo = (signmask && signmask[l]) ? reinterpret_cast<unsigned long long*>(signmask[l]) : nullptr;
+    g.layer[l] = Layer{W[l], ldw[l], bias[l], out[l], ldo[l], nullptr, 0, mo, nullptr, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0};
     g.pack_off[l] = poff; poff += pack_float4s(N[l], K[l]) * 4;
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd: ldx < K[0]");
@@ -336,7 +354,7 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
 // link j (= K_l / N_l of the encoder layer it differentiates).
 extern "C" int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
                                const int32_t* N, const int32_t* K, const float* packed,
-                               const float* const* act, const int64_t* ldact,
+                               const float* const* act, const int64_t* ldact, const uint64_t* const* signmask,
                                float* const* out, const int64_t* ldo, float slope, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(dY && N && K && packed && act && ldact && out && ldo && M > 0, "clica_mlp_dgrad: NULL pointer / empty batch");
@@ -349,7 +367,8 @@ extern "C" int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t
     CLICA_CHECK_ARG(out[j] && N[j] >= 1 && K[j] >= 1 && N[j] <= MAXW && K[j] <= MAXW, "clica_mlp_dgrad: link %d is %d x %d (max %d)", j, N[j], K[j], MAXW);
     CLICA_CHECK_ARG(ldo[j] >= N[j] && (!act[j] || ldact[j] >= N[j]), "clica_mlp_dgrad: link %d: leading dimension too small", j);
     CLICA_CHECK_ARG(j == 0 || K[j] == N[j - 1], "clica_mlp_dgrad: link %d contraction %d != previous width %d", j, K[j], N[j - 1]);
-    g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], act[j], ldact[j], N[j], K[j], 0, 1};
+    const unsigned long long* mi = (signmask && signmask[j]) ? reinterpret_cast<const unsigned long long*>(signmask[j]) : nullptr;
+    g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], act[j], ldact[j], nullptr, mi, N[j], K[j], 0, 1};
     g.pack_off[j] = poff; poff += pack_float4s(N[j], K[j]) * 4;
   }
   CLICA_CHECK_ARG(lddy >= K[0], "clica_mlp_dgrad: lddy < K[0]");

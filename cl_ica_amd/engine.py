@@ -152,6 +152,8 @@ class ContrastiveTrainer:
         self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         self.wgrad_ws2 = torch.zeros(need, dtype=torch.uint8, device=dev)    # second stream's slabs
         self.dz = [torch.empty((R, w), **f32) for w in widths[:-1]] if self.fused_backward else None   # dZ_l for the wgrads
+        # sign bits of every hidden activation, written by the fused forward, read by the fused backward chain
+        self.signmasks = (ops.mlp_signmask_alloc(R, len(self.linears) - 1, dev) + [None]) if self.fused_backward else None
         if self.head is not None:
             self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
             hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
@@ -192,7 +194,8 @@ class ContrastiveTrainer:
             ws = [lin.weight for lin in self.linears]
             if self.pack_weights:
                 self.packed = ops.mlp_pack_weights(ws, self.packed)  # fragment-order copy of the current weights
-            ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed)
+            ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
+                        signmasks=self.signmasks)
             cur = self.acts[-1]
         else:
             for l, lin in enumerate(self.linears):
@@ -265,7 +268,8 @@ class ContrastiveTrainer:
             chain = list(range(L - 1, 0, -1))
             ws = [self.linears[l].weight for l in chain]
             self.packed_t = ops.mlp_pack_weights(ws, self.packed_t, transpose=True)
-            ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope)
+            ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
+                                masks_chain=[self.signmasks[l - 1] for l in chain])
             use_two = two and self.buckets is None
             if use_two:
                 side.wait_stream(main)

@@ -97,10 +97,19 @@ def mlp_pack_weights(weights, packed: Optional[torch.Tensor] = None, transpose: 
     return packed
 
 
-def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed: Optional[torch.Tensor] = None):
+def mlp_signmask_alloc(M: int, n_layers: int, device) -> list:
+    """Per-layer opaque sign-bit buffers for mlp_fwd(signmasks=...) / mlp_dgrad_chain(masks_chain=...)."""
+    nbytes = C.c_size_t()
+    check(load().clica_mlp_signmask_bytes(int(M), C.byref(nbytes)), "clica_mlp_signmask_bytes")
+    return [torch.zeros(nbytes.value // 8, dtype=torch.int64, device=device) for _ in range(n_layers)]
+
+
+def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed: Optional[torch.Tensor] = None,
+            signmasks=None):
     """Whole Linear(+LeakyReLU) stack in one launch (clica_mlp_fwd); `outs[l]` receives layer l's output
     (saved activations; the last one is the result).  Widths <= 512, <= 8 layers.  `packed` = the same
-    weights from `mlp_pack_weights` (faster weight streaming)."""
+    weights from `mlp_pack_weights` (faster weight streaming).  `signmasks[l]` (from mlp_signmask_alloc, or
+    None) receives the (out > 0) bits of layer l for the one-launch backward."""
     (x, ldx) = _mat("x", x)
     L = len(weights)
     ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
@@ -115,14 +124,17 @@ def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed:
                                VP(*[None if b is None else b.data_ptr() for b in bs]),
                                VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
                                I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws]),
-                               ptr(packed), float(slope), stream_ptr()), "clica_mlp_fwd")
+                               ptr(packed), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
+                               float(slope), stream_ptr()), "clica_mlp_fwd")
     return outs[-1]
 
 
-def mlp_dgrad_chain(dy: torch.Tensor, weights_chain, packed_t: torch.Tensor, acts_chain, outs, slope: float = 0.01):
+def mlp_dgrad_chain(dy: torch.Tensor, weights_chain, packed_t: torch.Tensor, acts_chain, outs, slope: float = 0.01,
+                    masks_chain=None):
     """Backward data chain in one launch (clica_mlp_dgrad).  `weights_chain` = encoder weights in chain order
     (layer L-1 first ... layer 1), `packed_t` = mlp_pack_weights(weights_chain, transpose=True), `acts_chain[j]`
-    = saved activation that fed layer j of the chain, `outs[j]` = dZ of the layer below (written)."""
+    = saved activation that fed layer j of the chain, `outs[j]` = dZ of the layer below (written).
+    `masks_chain[j]` = that activation's sign bits from mlp_fwd (used instead of re-reading the activation)."""
     (dy, lddy) = _mat("dy", dy)
     n = len(weights_chain)
     I32, I64, VP = C.c_int32 * n, C.c_int64 * n, C.c_void_p * n
@@ -131,6 +143,7 @@ def mlp_dgrad_chain(dy: torch.Tensor, weights_chain, packed_t: torch.Tensor, act
                                  I32(*[w.shape[1] for w in weights_chain]), I32(*[w.shape[0] for w in weights_chain]),
                                  packed_t.data_ptr(),
                                  VP(*[None if a is None else a[0].data_ptr() for a in acts]), I64(*[0 if a is None else a[1] for a in acts]),
+                                 None if masks_chain is None else VP(*[ptr(m) for m in masks_chain]),
                                  VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
                                  float(slope), stream_ptr()), "clica_mlp_dgrad")
     return outs

@@ -186,7 +186,12 @@ int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ld
 int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                   const float* const* W, const int64_t* ldw, const float* const* bias,
                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                  const float* packed, float slope, clica_stream_t stream);
+                  const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream);
+/* signmask (array of n_layers pointers, or NULL; entries may be NULL): per layer an opaque buffer of
+ * clica_mlp_signmask_bytes(M) bytes that receives one bit per output element, (out > 0), in the kernel's
+ * accumulator order.  clica_mlp_dgrad takes it in place of re-reading the saved activation: 8 bytes per lane
+ * instead of 48 strided 4-byte loads in the epilogue of every link. */
+int clica_mlp_signmask_bytes(int64_t M, size_t* bytes);
 int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
 int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
                    int32_t transpose, float* packed, clica_stream_t stream);
@@ -195,10 +200,11 @@ int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, 
  * B_j only in fragment order: `packed` = clica_mlp_pack(..., transpose = 1, ...) of the encoder layers in CHAIN
  * order (layer L-1 first, down to layer 1); N[j] / K[j] = output / contraction width of link j (= K_l / N_l of
  * the layer it differentiates); act[j] = the saved activation that fed that layer (sign -> act'), NULL = none;
+ * signmask[j] (array or NULL) = the sign bits clica_mlp_fwd stored for that same activation: used instead of act[j];
  * out[j] = dZ of the layer below, written to HBM for the weight-gradient GEMMs.  Widths <= 512. */
 int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
                     const int32_t* N, const int32_t* K, const float* packed,
-                    const float* const* act, const int64_t* ldact,
+                    const float* const* act, const int64_t* ldact, const uint64_t* const* signmask,
                     float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -197,3 +197,33 @@ def test_fused_dgrad_chain_matches_per_layer(dims, M):
         g64 = (g64 @ Ws[l].cpu().numpy().astype(np.float64)) * np.where(acts[l].cpu().numpy() > 0, 1.0, 0.01)
         assert rel_err(outs[j].cpu().numpy(), g64) < 1e-5, ("fp64", l)
         assert rel_err(outs[j].cpu().numpy(), g.cpu().numpy()) < 1e-5, ("per-layer", l)
+
+
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([7, 33, 512, 129, 5], 1000), ([16, 16, 16], 47)])
+def test_fused_signmask_path_is_bit_identical(dims, M):
+    """The forward's sign bits (clica_mlp_fwd signmask) drive the backward chain to exactly the same dZ as
+    re-reading the saved activations does, and do not change the forward outputs."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(sum(dims) + M)
+    L = len(dims) - 1
+    Ws = [dev((rng.uniform(-1, 1, size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(L)]
+    bs = [dev(rng.uniform(-0.5, 0.5, size=dims[i + 1]).astype(np.float32)) for i in range(L)]
+    x = dev(rng.normal(size=(M, dims[0])).astype(np.float32))
+    outs_a = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    outs_b = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    packed = ops.mlp_pack_weights(Ws)
+    masks = ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None]
+    ops.mlp_fwd(x, Ws, bs, outs_a, 0.01, packed=packed)
+    ops.mlp_fwd(x, Ws, bs, outs_b, 0.01, packed=packed, signmasks=masks)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
+    dy = dev(rng.normal(size=(M, dims[-1])).astype(np.float32))
+    chain = list(range(L - 1, 0, -1))
+    chain_w = [Ws[l] for l in chain]
+    packed_t = ops.mlp_pack_weights(chain_w, transpose=True)
+    dz_a = [torch.empty(M, dims[l], device="cuda") for l in chain]
+    dz_b = [torch.empty(M, dims[l], device="cuda") for l in chain]
+    ops.mlp_dgrad_chain(dy, chain_w, packed_t, [outs_a[l - 1] for l in chain], dz_a, 0.01)
+    ops.mlp_dgrad_chain(dy, chain_w, packed_t, [outs_a[l - 1] for l in chain], dz_b, 0.01, masks_chain=[masks[l - 1] for l in chain])
+    for a, b in zip(dz_a, dz_b):
+        assert torch.equal(a, b)
