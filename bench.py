@@ -141,14 +141,23 @@ def roofline_leg(tr, reps=20):
                                          masks_chain=[tr.signmasks[l - 1] for l in chain])
         add(fused_key, fl, fn)
         add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k [backward data chain launch]"), fl, fn)
-        for l in reversed(range(L)):
-            lin = tr.linears[l]
-            N, K = lin.out_features, lin.in_features
-            gl = g_top if l == L - 1 else tr.dz[l]
-            inp = tr.acts[l - 1] if l > 0 else tr.x
-            add(gemm_key("wgrad", N, K), 2.0 * R * N * K,
-                lambda gl=gl, inp=inp, lin=lin: ops.linear_wgrad(gl, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)],
-                                                                 ws=tr.wgrad_ws))
+        if tr.grouped_wgrad:
+            order = list(range(L))
+            flw = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
+            add(("mlp_wgrad", "clica::gemm::wgrad_group_k<128, 128, 2, 4, 3> (+ slab_reduce_group_k)"), flw,
+                lambda: ops.mlp_wgrad([g_top if l == L - 1 else tr.dz[l] for l in order],
+                                      [tr.acts[l - 1] if l > 0 else tr.x for l in order],
+                                      [tr._gviews[id(tr.linears[l].weight)] for l in order],
+                                      [tr._gviews[id(tr.linears[l].bias)] for l in order], ws=tr.group_ws))
+        else:
+            for l in reversed(range(L)):
+                lin = tr.linears[l]
+                N, K = lin.out_features, lin.in_features
+                gl = g_top if l == L - 1 else tr.dz[l]
+                inp = tr.acts[l - 1] if l > 0 else tr.x
+                add(gemm_key("wgrad", N, K), 2.0 * R * N * K,
+                    lambda gl=gl, inp=inp, lin=lin: ops.linear_wgrad(gl, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)],
+                                                                     ws=tr.wgrad_ws))
     else:
         g_ = g_top
         for l in reversed(range(L)):

@@ -63,6 +63,10 @@ SIGNATURES: Dict[str, list] = {
     "clica_mlp_pack": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_i32, c_f32p, C.c_void_p],
     "clica_mlp_dgrad": [c_f32p, c_i64, c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, C.POINTER(C.c_void_p), C.POINTER(c_i64),
                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.c_float, C.c_void_p],
+    "clica_mlp_wgrad_workspace_bytes": [c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_size)],
+    "clica_mlp_wgrad": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64),
+                        C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i32), C.POINTER(c_i32), c_i32,
+                        C.c_void_p, c_size, C.c_void_p],
     "clica_rescale_fwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
     "clica_rescale_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
     "clica_softclip_fwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],

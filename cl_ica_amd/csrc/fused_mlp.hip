@@ -70,14 +70,14 @@ constexpr int KI = 32;
 // branch-free; NC is wave-uniform and selected by a scalar switch in the caller).
 template <bool VEC, bool PACKED, int NC>
 __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restrict__ pk, const float* panel, int wave, int lane,
-                                           f32x4 (&acc)[RB][CBW]) {
+                                           f32x4 (&acc)[RB][CBW], const float4 (&bpre)[2][CBW]) {
   const int i15 = lane & 15, q = lane >> 4;
   const int kiters = (ly.K + KI - 1) / KI;
   int nrow[CBW];
 #pragma unroll
   for (int c = 0; c < CBW; ++c) nrow[c] = (wave + c * WAVES) * 16 + i15;     // column blocks w, w+8, w+16, w+24
   float4 bcur[2][CBW], bnxt[2][CBW], acur[2][RB], anxt[2][RB];
-  auto fetch = [&](float4 (&b)[2][CBW], float4 (&a)[2][RB], int k0) {
+  auto fetch_b = [&](float4 (&b)[2][CBW], int k0) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       if (PACKED) {   // fragment order: one fully contiguous 1 KB per load instruction, pre-padded with zeros
@@ -89,21 +89,15 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
         b[1][c] = load_b<VEC>(ly, nrow[c], k0 + 16 + 4 * q);
       }
     }
+  };
+  auto fetch_a = [&](float4 (&a)[2][RB], int k0) {
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
       a[0][r] = *reinterpret_cast<const float4*>(&panel[(r * 16 + i15) * LDP + k0 + 4 * q]);
       a[1][r] = *reinterpret_cast<const float4*>(&panel[(r * 16 + i15) * LDP + k0 + 16 + 4 * q]);
     }
   };
-  fetch(bcur, acur, 0);
-  for (int ki = 0; ki < kiters; ++ki) {
-    // UNCONDITIONAL prefetch of the next iteration's operands (past the end: weights come from the zero
-    // page, the panel offset is clamped): with a conditional issue the compiler cannot count the loads in
-    // flight and drains them all (s_waitcnt vmcnt(0)) in front of the MFMAs, which serialises fetch and math.
-    {
-      const int kn = (ki + 1 < kiters) ? (ki + 1) * KI : ki * KI;     // last iteration: harmless re-read of its own operands
-      fetch(bnxt, anxt, kn);
-    }
+  auto mma_and_rotate = [&]() {
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
 #pragma unroll
@@ -128,8 +122,52 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
 #pragma unroll
       for (int r = 0; r < RB; ++r) acur[hlf][r] = anxt[hlf][r];
     }
+  };
+  if (PACKED) {     // iteration 0's weights were requested before the previous layer's epilogue (see the kernel)
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bcur[hlf][c] = bpre[hlf][c];
+  } else {
+    fetch_b(bcur, 0);
+  }
+  fetch_a(acur, 0);
+  // UNCONDITIONAL prefetch of the next iteration's operands (past the end: a harmless re-read of the last
+  // iteration's own operands): with a conditional issue the compiler cannot count the loads in flight and
+  // drains them all (s_waitcnt vmcnt(0)) in front of the MFMAs, which serialises fetch and math.
+  // Iteration 0 is peeled: the wait in front of ITS MFMAs may leave the previous layer's activation stores
+  // (issued after the early weight request) in flight, which a loop-carried wait count could not express.
+  {
+    const int kn = kiters > 1 ? KI : 0;
+    fetch_b(bnxt, kn);
+    fetch_a(anxt, kn);
+    mma_and_rotate();
+  }
+  for (int ki = 1; ki < kiters; ++ki) {
+    const int kn = (ki + 1 < kiters) ? (ki + 1) * KI : ki * KI;
+    fetch_b(bnxt, kn);
+    fetch_a(anxt, kn);
+    mma_and_rotate();
   }
 }
+
+// iteration-0 weight fragments of a layer, for every column block slot of this wave (slots beyond the layer's
+// last block re-read block 0: unconditional loads, their values are never used)
+__device__ __forceinline__ void request_first_b(const float* __restrict__ pk, int K, int N, int wave, int lane, float4 (&b)[2][CBW]) {
+  const int kiters = (K + KI - 1) / KI, ncb_real = (N + 15) / 16;
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) {
+    const int cb = wave + c * WAVES;
+    const float* base = pk + ((int64_t)((cb < ncb_real ? cb : 0) * kiters) * 2 * 64 + lane) * 4;
+    b[0][c] = *reinterpret_cast<const float4*>(base);
+    b[1][c] = *reinterpret_cast<const float4*>(base + 256);
+  }
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kRsrcWord3 = 0x00020000;       // raw buffer, 32-bit data format (gfx9 family)
+constexpr unsigned kOobOffset = 0x80000000u; // beyond any num_records: the access is dropped / reads zero
 
 __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   extern __shared__ __attribute__((aligned(16))) float panel[];     // [ROWS][LDP]
@@ -137,6 +175,18 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // provably wave-uniform: scalar branches
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int nrows = (int)min((int64_t)ROWS, g.M - row0);
+
+  // Sign bits / first weight fragments of layer 0 (for later layers they are requested ahead of the previous
+  // layer's epilogue).  Raw-buffer accesses with num_records = 0 when the pointer is NULL: unconditional
+  // instructions, so every vector-memory operation of the kernel is statically countable.
+  const int mslot = (wave * 64 + lane) * 8;                       // byte offset inside this workgroup's 4 KB of sign bits
+  auto mask_rsrc = [&](const unsigned long long* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(p) + (p ? (int64_t)blockIdx.x * WAVES * 64 : 0), 0,
+                                             p ? WAVES * 64 * 8 : 0, kRsrcWord3);
+  };
+  float4 bpre[2][CBW];
+  if (g.packed) request_first_b(g.packed + g.pack_off[0], g.layer[0].K, g.layer[0].N, wave, lane, bpre);
+  u32x2 mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(g.layer[0].dact ? g.layer[0].mask_in : nullptr), mslot, 0, 0);
 
   // input panel, zero-padded to a multiple of KI columns (the k-loop runs in KI-deep iterations)
   {
@@ -160,23 +210,29 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
     const float* pk = g.packed ? g.packed + g.pack_off[l] : nullptr;
-    // sign bits of the saved activation, one 8-byte word per lane (issued ahead of the k-loop: it is older
-    // than every weight fetch, so the loop's counted waits cover it for free)
-    const int64_t mslot = ((int64_t)blockIdx.x * WAVES + wave) * 64 + lane;
-    unsigned long long mbits = (ly.dact && ly.mask_in) ? ly.mask_in[mslot] : 0ull;
-#define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                     \
-    switch (nc) {                                                                          \
-      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc); break;           \
-      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc); break;           \
-      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc); break;           \
-      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc); break;           \
-      default: break;                                                                      \
+    const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
+#define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                           \
+    switch (nc) {                                                                                \
+      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      default: break;                                                                            \
     }
     if (pk) { CLICA_FMLP_DISPATCH(true, true) }
     else if (vec) { CLICA_FMLP_DISPATCH(true, false) }
     else { CLICA_FMLP_DISPATCH(false, false) }
 #undef CLICA_FMLP_DISPATCH
     __syncthreads();                                   // every wave is done reading the input panel
+
+    // Request the NEXT layer's first weight fragments and sign bits now: they do not depend on the panel, are
+    // older than the activation stores below, and land while this layer's epilogue runs.
+    if (l + 1 < g.L) {
+      const Layer& nx = g.layer[l + 1];
+      if (g.packed) request_first_b(g.packed + g.pack_off[l + 1], nx.K, nx.N, wave, lane, bpre);
+      mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(nx.dact ? nx.mask_in : nullptr), mslot, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
     // epilogue into the panel: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg.
     // Columns N..round_up(N, KI) are written as zeros: they are the next layer's k-padding.
@@ -208,19 +264,28 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
         }
       }
     }
-    if (ly.mask_out) ly.mask_out[mslot] = obits;
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2){(unsigned)obits, (unsigned)(obits >> 32)}, mask_rsrc(ly.mask_out), mslot, 0, 0);
     __syncthreads();
 
     // stream the new activations to HBM straight from the panel (coalesced rows)
     const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
     if (ovec) {
+      // A FIXED number of unconditional raw-buffer stores (pieces outside the panel get an out-of-range offset
+      // and are dropped by the hardware): the wait in front of the next layer's first MFMAs can then be an
+      // exact count that leaves these stores in flight instead of draining them.  Streaming (nt) stores: the
+      // saved activations are not read again in this kernel, keep them from evicting the weights out of L2.
       const int n4 = ly.N / 4;
-      for (int idx = threadIdx.x; idx < nrows * n4; idx += THREADS) {
+      const __amdgpu_buffer_rsrc_t orsrc =
+          __builtin_amdgcn_make_buffer_rsrc(ly.out + row0 * ly.ldo, 0, (int)(((int64_t)(nrows - 1) * ly.ldo + ly.N) * 4), kRsrcWord3);
+      constexpr int PIECES = (ROWS * (MAXW / 4) + THREADS - 1) / THREADS;
+#pragma unroll
+      for (int it = 0; it < PIECES; ++it) {
+        const int idx = threadIdx.x + it * THREADS;
         const int r = idx / n4, c4 = idx - r * n4;
-        // streaming store: the saved activations are not read again in this kernel, keep them from
-        // evicting the weight matrix (the B operand every CU re-reads) out of L2
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&panel[r * LDP + 4 * c4]);
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(ly.out + (row0 + r) * ly.ldo + 4 * c4));
+        const bool in = r < nrows;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&panel[(in ? r : 0) * LDP + 4 * c4]);
+        const unsigned off = in ? (unsigned)((r * (int)ly.ldo + 4 * c4) * 4) : kOobOffset;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 2);
       }
     } else {
       for (int idx = threadIdx.x; idx < nrows * ly.N; idx += THREADS) {

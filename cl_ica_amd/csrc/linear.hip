@@ -18,6 +18,7 @@
 // batch) over blockIdx.z into fp32 slabs that a second tiny kernel sums deterministically.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace clica {
 // skinny.hip: VALU kernels for layers with a tiny contraction or output width
@@ -123,8 +124,9 @@ struct Tile {
   }
 };
 
+// The workgroup's whole job for output tile (bx, by) and contraction split bz of problem g.
 template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
+__device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int by, const int bz) {
   constexpr int THREADS = 64 * WM * WN;
   using TA = Tile<BM, A_CONTIG, THREADS>;
   using TB = Tile<BN, B_CONTIG, THREADS>;
@@ -138,20 +140,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int h = lane >> 5, l31 = lane & 31;
-  // XCD-aware tile order: the dispatcher places linear block b on XCD b % 8 (speed only, never
-  // correctness).  Re-number so that each XCD walks a CONTIGUOUS range of tiles, N fastest: the
-  // workgroups that share an A row-panel then hit the same XCD-private L2.
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
-    const int gx = gridDim.x, nwg = gridDim.x * gridDim.y;
-    const int b = by * gx + bx, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    by = id / gx; bx = id - by * gx;
-  }
   const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
   int64_t kbeg = 0, kend = g.Kc;
   if (EPI == EPI_SLAB) {
-    kbeg = (int64_t)blockIdx.z * g.k_per_split;
+    kbeg = (int64_t)bz * g.k_per_split;
     kend = min(g.Kc, kbeg + g.k_per_split);
   }
 
@@ -248,7 +240,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
 
   // ---- epilogue: C/D layout of 32x32 blocks: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Cbase = g.C;
-  if (EPI == EPI_SLAB) Cbase += (int64_t)blockIdx.z * g.M * g.ldc;
+  if (EPI == EPI_SLAB) Cbase += (int64_t)bz * g.M * g.ldc;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
 #pragma unroll
@@ -274,8 +266,181 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
   }
   if (EPI == EPI_SLAB && g.dbias_slab && bx == 0 && !A_CONTIG && threadIdx.x < BM) {
     const int64_t row = m0 + threadIdx.x;
-    if (row < g.M) g.dbias_slab[(int64_t)blockIdx.z * g.M + row] = colsum;
+    if (row < g.M) g.dbias_slab[(int64_t)bz * g.M + row] = colsum;
   }
+}
+
+// XCD-aware order: the dispatcher places linear block b on XCD b % 8 (speed only, never correctness).
+// Re-number so that each XCD walks a CONTIGUOUS range of the nwg work items: workgroups that share
+// an operand panel then hit the same XCD-private L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg) {
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_k(Args g) {
+  const int gx = gridDim.x;
+  const int id = xcd_contiguous(blockIdx.y * gx + blockIdx.x, gx * gridDim.y);   // N fastest
+  const int by = id / gx;
+  gemm_body<BM, BN, WM, WN, STAGES, A_CONTIG, B_CONTIG, EPI, VEC>(g, id - by * gx, by, blockIdx.z);
+}
+
+// ---- weight-gradient body with direct global -> LDS tile loads ------------------------------------------
+// Both wgrad operands are [batch rows][features] with the contraction along the batch rows, so a BK x 128
+// tile is BK global row pieces of 512 B and its LDS image [BK][128] is exactly lane-contiguous: one
+// global_load_lds_dwordx4 per wave moves two k-rows (1 KB) HBM/L2 -> LDS without touching a VGPR and
+// without a ds_write.  Four LDS stages: the loads of tile t+3 are issued in iteration t and first
+// waited for in iteration t+2, i.e. two full iterations (~4 us) of MFMA cover their latency; one barrier
+// per iteration, placed after the first k-step so the fragment prefetch runs through tile boundaries.
+// The loads are issued from inline asm: the compiler then does not see an LDS write through VMEM (for which it
+// would insert s_waitcnt vmcnt(0) in front of every later ds_read) and the waits below are the exact ones.
+typedef __attribute__((address_space(3))) float* lds_f32_ptr;
+__device__ __forceinline__ void dma_1k(const float* lane_src, const float* lds_wave_dst) {
+  const unsigned off = (unsigned)(size_t)(lds_f32_ptr)lds_wave_dst;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(lane_src), "s"(off) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcnt(N) only (gfx9 encoding)
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+constexpr int DMA_STAGES = 4;
+template <int WM, int WN>
+__device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, const int by, const int bz) {
+  constexpr int BM = 128, BN = 128, THREADS = 64 * WM * WN, WAVES = WM * WN;
+  static_assert(WAVES == 8, "eight waves: each issues 2 + 2 one-KB loads per 32-deep tile");
+  using TA = Tile<BM, false, THREADS>;
+  using TB = Tile<BN, false, THREADS>;
+  constexpr int TM = BM / WM, TN = BN / WN, NBM = TM / 32, NBN = TN / 32;
+  constexpr int STAGE = TA::LDS_FLOATS + TB::LDS_FLOATS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+  const int64_t kbeg = (int64_t)bz * g.k_per_split, kend = min(g.Kc, kbeg + g.k_per_split);
+  const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
+
+  f32x16 acc[NBM][NBN];
+#pragma unroll
+  for (int i = 0; i < NBM; ++i)
+#pragma unroll
+    for (int j = 0; j < NBN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum = 0.f;
+
+  // this lane's piece of the tile: k-rows 4*wave + 2*j + h (j = 0, 1), columns 4*l31 .. +3
+  const bool a_ok = m0 + 4 * l31 < g.M, b_ok = n0 + 4 * l31 < g.N;      // M, N multiples of 4 on this path
+  const float* a_src = g.A + m0 + 4 * l31;
+  const float* b_src = g.B + n0 + 4 * l31;
+  auto issue = [&](int t) {
+    float* st = smem + (t % DMA_STAGES) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kr = 4 * wave + 2 * j;
+      const int64_t k = kbeg + (int64_t)t * BK + kr + h;
+      const bool kin = k < kend;
+      dma_1k((a_ok && kin) ? a_src + k * g.lda : g_zero_page, st + kr * BM);
+      dma_1k((b_ok && kin) ? b_src + k * g.ldb : g_zero_page, st + TA::LDS_FLOATS + kr * BN);
+    }
+  };
+  constexpr int PER_TILE = 4;     // loads per wave per tile
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+  if (ntiles > 2) issue(2);
+  if (ntiles > 2) wait_vm<2 * PER_TILE>(); else if (ntiles > 1) wait_vm<PER_TILE>(); else wait_vm<0>();
+  __syncthreads();
+
+  constexpr int KSTEPS = BK / 8;
+  float af[2][NBM][4], bf[2][NBN][4];
+  auto load_frags = [&](int buf, const float* a_s, int s) {
+    const float* b_s = a_s + TA::LDS_FLOATS;
+#pragma unroll
+    for (int i = 0; i < NBM; ++i) TA::frag(af[buf][i], a_s, wm * TM + i * 32 + l31, s, h);
+#pragma unroll
+    for (int j = 0; j < NBN; ++j) TB::frag(bf[buf][j], b_s, wn * TN + j * 32 + l31, s, h);
+  };
+  if (ntiles > 0) load_frags(0, smem, 0);
+
+  for (int t = 0; t < ntiles; ++t) {
+    const float* a_s = smem + (t % DMA_STAGES) * STAGE;
+    const float* a_n = smem + ((t + 1) % DMA_STAGES) * STAGE;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 1 < KSTEPS) load_frags((s + 1) & 1, a_s, s + 1);
+      else if (t + 1 < ntiles) load_frags(0, a_n, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < NBM; ++i)
+#pragma unroll
+          for (int j = 0; j < NBN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][tt], bf[s & 1][j][tt], acc[i][j], 0, 0, 0);
+      if (s == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        // tile t+1 must be complete (it is read from the last k-step of this iteration on); tile t+2 may fly
+        if (t + 2 < ntiles) wait_vm<PER_TILE>(); else wait_vm<0>();
+        __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 4
+        if (t + 3 < ntiles) issue(t + 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (g.dbias_slab && bx == 0 && threadIdx.x < BM) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) colsum += a_s[k * TA::LDS_LD + threadIdx.x];
+    }
+  }
+
+  float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+#pragma unroll
+    for (int j = 0; j < NBN; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + l31;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        Cbase[row * g.ldc + col] = acc[i][j][r];
+      }
+    }
+  }
+  if (g.dbias_slab && bx == 0 && threadIdx.x < BM) {
+    const int64_t row = m0 + threadIdx.x;
+    if (row < g.M) g.dbias_slab[(int64_t)bz * g.M + row] = colsum;
+  }
+}
+
+// ---- grouped weight gradients: every layer's dW/db slabs in ONE launch ------------------------------
+// Work item = (problem, contraction split, tile); all items cover the same number of batch rows, so the
+// launch is a few full rounds of equal-length workgroups instead of one ragged launch (+ reduction) per layer.
+constexpr int MAXG = 8;
+struct GroupArgs {
+  int n, total;
+  int first[MAXG + 1];    // first work item of each problem
+  int gx[MAXG], gy[MAXG]; // tiles along N / M
+  int vec[MAXG];
+  Args p[MAXG];
+};
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void wgrad_group_k(GroupArgs G) {
+  const int id = xcd_contiguous(blockIdx.x, G.total);
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MAXG; ++i) q += (i < G.n && id >= G.first[i]) ? 1 : 0;
+  const int local = id - G.first[q];
+  const int gx = G.gx[q], tiles = gx * G.gy[q];
+  const int bz = local / tiles, t = local - bz * tiles;
+  const int by = t / gx, bx = t - by * gx;
+  if (G.vec[q]) wgrad_dma_body<WM, WN>(G.p[q], bx, by, bz);
+  else gemm_body<BM, BN, WM, WN, STAGES, false, false, EPI_SLAB, false>(G.p[q], bx, by, bz);
 }
 
 // dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i].
@@ -344,6 +509,49 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
   } else {   // trailing blocks: the bias slab (M entries per split), same scheme
     reduce_units<false>(dbslab, splits, M, (int64_t)((int)blockIdx.x - dw_blocks) * 64, red, t, e);
     if (w == 0 && e < M) db[e] = accumulate ? (db[e] + t.x) : t.x;
+  }
+}
+
+// grouped variant: the slabs of up to MAXG problems reduced by one launch
+struct ReduceGroupArgs {
+  int n, splits, accumulate;
+  int first[MAXG + 1];      // first block of each problem
+  int dw_blocks[MAXG], vec4[MAXG];
+  const float* slab[MAXG]; const float* dbslab[MAXG];
+  float* dW[MAXG]; float* db[MAXG];
+  int64_t M[MAXG], N[MAXG], lddw[MAXG];
+};
+__global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupArgs G) {
+  __shared__ float4 red[RED_THREADS / 64][64];
+  const int w = threadIdx.x >> 6;
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MAXG; ++i) q += (i < G.n && (int)blockIdx.x >= G.first[i]) ? 1 : 0;
+  const int b = (int)blockIdx.x - G.first[q];
+  const int64_t M = G.M[q], N = G.N[q];
+  float4 t; int64_t e;
+  if (b < G.dw_blocks[q]) {
+    const int64_t total = M * N;
+    if (G.vec4[q]) {
+      reduce_units<true>(G.slab[q], G.splits, total, (int64_t)b * 64, red, t, e);
+      if (w == 0 && e < total) {
+        const int64_t i = e / N, j = e - i * N;
+        float4* dst = reinterpret_cast<float4*>(G.dW[q] + i * G.lddw[q] + j);
+        if (G.accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *dst = t;
+      }
+    } else {
+      reduce_units<false>(G.slab[q], G.splits, total, (int64_t)b * 64, red, t, e);
+      if (w == 0 && e < total) {
+        const int64_t i = e / N, j = e - i * N;
+        float* dst = G.dW[q] + i * G.lddw[q] + j;
+        *dst = G.accumulate ? (*dst + t.x) : t.x;
+      }
+    }
+  } else {
+    reduce_units<false>(G.dbslab[q], G.splits, M, (int64_t)(b - G.dw_blocks[q]) * 64, red, t, e);
+    float* db = G.db[q];
+    if (w == 0 && e < M) db[e] = G.accumulate ? (db[e] + t.x) : t.x;
   }
 }
 
@@ -452,11 +660,104 @@ static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, 
   return p;
 }
 
+// Grouped plan: 128x128 tiles for every layer, one common contraction split count chosen so that
+// (tiles x splits) fills whole rounds of the 256 CUs (one 8-wave workgroup per CU) with few, long items.
+struct GroupPlan { int splits; int64_t k_per_split; int tiles; };
+constexpr int GBM = 128, GBN = 128;
+static GroupPlan plan_wgrad_group(int64_t Mrows, int n, const int32_t* N, const int32_t* K) {
+  GroupPlan p{};
+  for (int l = 0; l < n; ++l) p.tiles += (int)(ceil_div(N[l], GBM) * ceil_div(K[l], GBN));
+  const int64_t max_s = std::max<int64_t>(1, std::min<int64_t>(64, ceil_div(Mrows, (int64_t)BK * 4)));
+  double best = 1e300;
+  for (int64_t s = 1; s <= max_s; ++s) {
+    const int64_t kps = ceil_div(ceil_div(Mrows, s), (int64_t)BK) * BK;
+    const int64_t sp = ceil_div(Mrows, kps);
+    const int64_t rounds = ceil_div((int64_t)p.tiles * sp, kNumCU);
+    // rounds of kps-row items + fixed per-round prologue/epilogue + slab write/read traffic per split
+    // (weights fitted on MI355X, tools/wgrad_bench.py: 13 splits = 3 full rounds wins at M = 12288, n = 10)
+    const double cost = (double)rounds * (kps + 32.0) + 8.0 * sp;
+    if (cost < best) { best = cost; p.splits = (int)sp; p.k_per_split = kps; }
+  }
+  const char* e = getenv("CLICA_WGRAD_GROUP_SPLITS");
+  if (e && atoi(e) > 0) {
+    const int64_t kps = ceil_div(ceil_div(Mrows, (int64_t)atoi(e)), (int64_t)BK) * BK;
+    p.k_per_split = kps; p.splits = (int)ceil_div(Mrows, kps);
+  }
+  return p;
+}
+static size_t group_ws_layout(const GroupPlan& p, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
+  size_t off = 0;
+  for (int l = 0; l < n; ++l) {
+    if (slab_off) slab_off[l] = off;
+    off += align_up((size_t)p.splits * N[l] * K[l] * sizeof(float), 256);
+    if (db_off) db_off[l] = off;
+    off += align_up((size_t)p.splits * N[l] * sizeof(float), 256);
+  }
+  return off;
+}
+
 }  // namespace gemm
 }  // namespace clica
 
 using namespace clica;
 using namespace clica::gemm;
+
+extern "C" int clica_mlp_wgrad_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && N && K && M > 0 && n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_workspace_bytes: bad argument");
+  for (int l = 0; l < n_layers; ++l) CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1, "clica_mlp_wgrad_workspace_bytes: layer %d: bad size", l);
+  *bytes = group_ws_layout(plan_wgrad_group(M, n_layers, N, K), n_layers, N, K, nullptr, nullptr);
+  return CLICA_OK;
+}
+
+extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* dZ, const int64_t* lddz,
+                               const float* const* X, const int64_t* ldx, float* const* dW, const int64_t* lddw,
+                               float* const* db, const int32_t* N, const int32_t* K, int32_t accumulate,
+                               void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dZ && lddz && X && ldx && dW && lddw && db && N && K && workspace && M > 0, "clica_mlp_wgrad: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad: %d layers (1..%d supported)", n_layers, MAXG);
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(dZ[l] && X[l] && dW[l] && N[l] >= 1 && K[l] >= 1, "clica_mlp_wgrad: layer %d: bad argument", l);
+    CLICA_CHECK_ARG(lddz[l] >= N[l] && ldx[l] >= K[l] && lddw[l] >= K[l], "clica_mlp_wgrad: layer %d: leading dimension too small", l);
+  }
+  const GroupPlan p = plan_wgrad_group(M, n_layers, N, K);
+  size_t slab_off[MAXG], db_off[MAXG];
+  const size_t need = group_ws_layout(p, n_layers, N, K, slab_off, db_off);
+  if (need > workspace_bytes) { set_error("clica_mlp_wgrad: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  hipStream_t st = as_stream(stream);
+  GroupArgs G{};
+  ReduceGroupArgs R{};
+  G.n = R.n = n_layers; R.splits = p.splits; R.accumulate = accumulate ? 1 : 0;
+  int item = 0, rblock = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    float* slab = (float*)((char*)workspace + slab_off[l]);
+    float* dbslab = (float*)((char*)workspace + db_off[l]);
+    // dW[N,K] = dZ[M,N]^T X[M,K]: "M" = N, "N" = K, contraction over the batch rows
+    Args& g = G.p[l];
+    g.A = dZ[l]; g.lda = lddz[l]; g.B = X[l]; g.ldb = ldx[l]; g.C = slab; g.ldc = K[l]; g.M = N[l]; g.N = K[l]; g.Kc = M;
+    g.k_per_split = p.k_per_split; g.dbias_slab = db[l] ? dbslab : nullptr;
+    { const int ab = env_cfg("CLICA_GEMM_ABLATE"); g.ablate = ab > 0 ? ab : 0; }
+    G.gx[l] = (int)ceil_div(K[l], GBN); G.gy[l] = (int)ceil_div(N[l], GBM);
+    G.vec[l] = (aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N[l] % 4 == 0 && K[l] % 4 == 0) ? 1 : 0;
+    G.first[l] = item; item += G.gx[l] * G.gy[l] * p.splits;
+    const bool v4 = (K[l] % 4 == 0) && (lddw[l] % 4 == 0) && aligned16(dW[l]);
+    R.vec4[l] = v4 ? 1 : 0;
+    R.dw_blocks[l] = (int)ceil_div(v4 ? (int64_t)N[l] * K[l] / 4 : (int64_t)N[l] * K[l], 64);
+    R.first[l] = rblock; rblock += R.dw_blocks[l] + (db[l] ? (int)ceil_div(N[l], 64) : 0);
+    R.slab[l] = slab; R.dbslab[l] = dbslab; R.dW[l] = dW[l]; R.db[l] = db[l];
+    R.M[l] = N[l]; R.N[l] = K[l]; R.lddw[l] = lddw[l];
+  }
+  G.first[n_layers] = G.total = item; R.first[n_layers] = rblock;
+  constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
+  constexpr size_t lds = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
+  auto k = wgrad_group_k<GBM, GBN, WM, WN, STAGES>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  hipLaunchKernelGGL(k, dim3((unsigned)item), dim3(THREADS), lds, st, G);
+  int rc = launch_status("clica_mlp_wgrad");
+  if (rc) return rc;
+  hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)rblock), dim3(RED_THREADS), 0, st, R);
+  return launch_status("clica_mlp_wgrad(reduce)");
+}
 
 extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,
                                 float* Y, int64_t ldy, int64_t M, int64_t N, int64_t K,

@@ -152,6 +152,9 @@ class ContrastiveTrainer:
         self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         self.wgrad_ws2 = torch.zeros(need, dtype=torch.uint8, device=dev)    # second stream's slabs
         self.dz = [torch.empty((R, w), **f32) for w in widths[:-1]] if self.fused_backward else None   # dZ_l for the wgrads
+        self.grouped_wgrad = self.fused_backward and os.environ.get("CLICA_GROUPED_WGRAD", "1") != "0" and all(
+            lin.bias is not None for lin in self.linears)
+        self.group_ws = ops.mlp_wgrad_workspace(R, [tuple(lin.weight.shape) for lin in self.linears], dev) if self.grouped_wgrad else None
         # sign bits of every hidden activation, written by the fused forward, read by the fused backward chain
         self.signmasks = (ops.mlp_signmask_alloc(R, len(self.linears) - 1, dev) + [None]) if self.fused_backward else None
         if self.head is not None:
@@ -270,6 +273,19 @@ class ContrastiveTrainer:
             self.packed_t = ops.mlp_pack_weights(ws, self.packed_t, transpose=True)
             ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
                                 masks_chain=[self.signmasks[l - 1] for l in chain])
+            if self.grouped_wgrad:
+                # (2) every layer's dW/db in two launches: one grouped split-K GEMM of equal-length work items
+                #     + one grouped slab reduction; under DP a single all-reduce of the flat gradient arena follows
+                order = list(range(L))
+                ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
+                              [self.acts[l - 1] if l > 0 else self.x for l in order],
+                              [self._gviews[id(self.linears[l].weight)] for l in order],
+                              [self._gviews[id(self.linears[l].bias)] for l in order], ws=self.group_ws)
+                if self.buckets is not None:
+                    for i in range(L):
+                        self.buckets.layer_done(i)
+                    self.buckets.wait()
+                return
             use_two = two and self.buckets is None
             if use_two:
                 side.wait_stream(main)

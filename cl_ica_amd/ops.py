@@ -72,6 +72,34 @@ def linear_wgrad(dy: torch.Tensor, x: torch.Tensor, dW: Optional[torch.Tensor] =
     return dW, db
 
 
+def mlp_wgrad_workspace(M: int, shapes, device) -> torch.Tensor:
+    """Workspace for `mlp_wgrad` over layers with weight shapes `shapes` = [(N_l, K_l), ...]."""
+    n = len(shapes)
+    I32 = C.c_int32 * n
+    nbytes = C.c_size_t()
+    check(load().clica_mlp_wgrad_workspace_bytes(int(M), n, I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]), C.byref(nbytes)),
+          "clica_mlp_wgrad_workspace_bytes")
+    return torch.zeros(nbytes.value, dtype=torch.uint8, device=device)
+
+
+def mlp_wgrad(dzs, xs, dWs, dbs, ws: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """All layers' dW[l] = dZ[l]^T X[l], db[l] = column sums of dZ[l] in two launches (clica_mlp_wgrad)."""
+    n = len(dzs)
+    dz = [_mat(f"dz[{l}]", t) for l, t in enumerate(dzs)]
+    xx = [_mat(f"x[{l}]", t) for l, t in enumerate(xs)]
+    M = dz[0][0].shape[0]
+    shapes = [(d.shape[1], x.shape[1]) for (d, _), (x, _) in zip(dz, xx)]
+    if ws is None:
+        ws = mlp_wgrad_workspace(M, shapes, dz[0][0].device)
+    VP, I64, I32 = C.c_void_p * n, C.c_int64 * n, C.c_int32 * n
+    check(load().clica_mlp_wgrad(M, n, VP(*[d.data_ptr() for d, _ in dz]), I64(*[ld for _, ld in dz]),
+                                 VP(*[x.data_ptr() for x, _ in xx]), I64(*[ld for _, ld in xx]),
+                                 VP(*[w.data_ptr() for w in dWs]), I64(*[w.stride(0) for w in dWs]),
+                                 VP(*[ptr(b) for b in dbs]), I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]),
+                                 int(accumulate), ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad")
+    return dWs, dbs
+
+
 MLP_FUSED_MAX_WIDTH = 512
 MLP_FUSED_MAX_LAYERS = 8
 

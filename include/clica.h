@@ -206,6 +206,14 @@ int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
                     const int32_t* N, const int32_t* K, const float* packed,
                     const float* const* act, const int64_t* ldact, const uint64_t* const* signmask,
                     float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
+/* Weight/bias gradients of ALL layers in two launches (one grouped split-K GEMM over equal-length work items
+ * + one grouped deterministic slab reduction):  dW[l] = dZ[l]^T X[l]  ([N_l, K_l]),  db[l] = column sums of dZ[l]
+ * (db[l] may be NULL).  dZ[l] = [M, N_l] gradient at layer l's pre-activation, X[l] = [M, K_l] its input. */
+int clica_mlp_wgrad_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes);
+int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* dZ, const int64_t* lddz,
+                    const float* const* X, const int64_t* ldx, float* const* dW, const int64_t* lddw,
+                    float* const* db, const int32_t* N, const int32_t* K, int32_t accumulate,
+                    void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Output heads  --  RescaleLayer (mode "eq") layers.py:63-66, SoftclipLayer layers.py:87-91

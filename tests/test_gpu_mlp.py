@@ -227,3 +227,30 @@ def test_fused_signmask_path_is_bit_identical(dims, M):
     ops.mlp_dgrad_chain(dy, chain_w, packed_t, [outs_a[l - 1] for l in chain], dz_b, 0.01, masks_chain=[masks[l - 1] for l in chain])
     for a, b in zip(dz_a, dz_b):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
+                                      ([16, 16, 16], 47), ([3, 300], 5000)])
+def test_grouped_wgrad_matches_per_layer(dims, M):
+    """clica_mlp_wgrad (all layers, one grouped split-K launch + one grouped slab reduce) vs fp64 and per-layer wgrad."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(len(dims) * 13 + M)
+    L = len(dims) - 1
+    xs = [dev(rng.normal(size=(M, dims[l])).astype(np.float32)) for l in range(L)]
+    dzs = [dev(rng.normal(size=(M, dims[l + 1])).astype(np.float32)) for l in range(L)]
+    dWs = [torch.full((dims[l + 1], dims[l]), 7.0, device="cuda") for l in range(L)]
+    dbs = [torch.full((dims[l + 1],), 7.0, device="cuda") for l in range(L)]
+    ops.mlp_wgrad(dzs, xs, dWs, dbs)
+    for l in range(L):
+        ref_w = dzs[l].cpu().numpy().astype(np.float64).T @ xs[l].cpu().numpy().astype(np.float64)
+        ref_b = dzs[l].cpu().numpy().astype(np.float64).sum(0)
+        scale_w = np.abs(dzs[l].cpu().numpy().astype(np.float64)).T @ np.abs(xs[l].cpu().numpy().astype(np.float64))
+        assert np.max(np.abs(dWs[l].cpu().numpy() - ref_w) / scale_w) < 1e-5, l
+        assert np.max(np.abs(dbs[l].cpu().numpy() - ref_b)) / np.abs(dzs[l].cpu().numpy()).sum(0).max() < 1e-5, l
+        w1, b1 = ops.linear_wgrad(dzs[l], xs[l])
+        assert rel_err(dWs[l].cpu().numpy(), w1.cpu().numpy()) < 1e-5
+    # accumulate=True adds onto what is there; db = None is allowed
+    before = [w.clone() for w in dWs]
+    ops.mlp_wgrad(dzs, xs, dWs, [None] * L, accumulate=True)
+    for l in range(L):
+        assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
