@@ -117,13 +117,13 @@ def roofline_leg(tr, reps=20):
         return ("linear_" + op, f"clica::gemm::gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>"
                 + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 
-    fused_key = ("mlp_fwd+mlp_dgrad", "clica::fmlp::mlp_fwd_k")
+    fused_key = ("mlp_fwd+mlp_dgrad", "clica::fmlp::mlp_fwd_k<true, false>")
     if tr.fused_forward:
         ws = [lin.weight for lin in tr.linears]
         fl = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
         add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed,
                                                signmasks=tr.signmasks))
-        add(("mlp_fwd", "clica::fmlp::mlp_fwd_k [forward stack launch]"), fl, groups[fused_key]["fns"][-1])
+        add(("mlp_fwd", "clica::fmlp::mlp_fwd_k<true, false> [forward stack launch]"), fl, groups[fused_key]["fns"][-1])
     else:
         cur = tr.x
         for l, lin in enumerate(tr.linears):
@@ -140,7 +140,7 @@ def roofline_leg(tr, reps=20):
                                          [tr.dz[l - 1] for l in chain], tr.slope,
                                          masks_chain=[tr.signmasks[l - 1] for l in chain])
         add(fused_key, fl, fn)
-        add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k [backward data chain launch]"), fl, fn)
+        add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k<true, false> [backward data chain launch]"), fl, fn)
         if tr.grouped_wgrad:
             order = list(range(L))
             flw = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)

@@ -169,6 +169,52 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRsrcWord3 = 0x00020000;       // raw buffer, 32-bit data format (gfx9 family)
 constexpr unsigned kOobOffset = 0x80000000u; // beyond any num_records: the access is dropped / reads zero
 
+// Epilogue of one layer into the panel, specialised at compile time (no scalar branches / kernarg re-reads
+// per element).  C/D layout of the 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg.  Columns
+// N..round_up(N, KI) are written as zeros: they are the next layer's k-padding.  Returns this lane's sign bits.
+enum EpiMode { EPI_BIAS = 0, EPI_BIAS_LEAKY = 1, EPI_DACT_MASK = 2, EPI_DACT_NONE = 3 };
+template <int MODE, bool BITS>
+__device__ __forceinline__ unsigned long long epilogue_to_panel(float* panel, const f32x4 (&acc)[RB][CBW], const float (&bias)[CBW],
+                                                                const unsigned long long mbits, const float slope,
+                                                                const int N, const int wave, const int lane) {
+  const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;
+  unsigned lo = 0u, hi = 0u;
+  const unsigned mlo = (unsigned)mbits, mhi = (unsigned)(mbits >> 32);
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) {
+    const int cb = wave + c * WAVES;
+    if (cb < ncb) {                                   // wave-uniform
+      const int col = cb * 16 + (lane & 15);
+      const bool colin = col < N;
+      float* dst = panel + ((lane >> 4) * 4) * LDP + col;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          constexpr int dummy = 0; (void)dummy;
+          const int bit = (c * RB + r) * 4 + e;       // compile time
+          float v = acc[r][c][e];
+          if (MODE == EPI_BIAS || MODE == EPI_BIAS_LEAKY) v += bias[c];
+          if (MODE == EPI_BIAS_LEAKY) v = v > 0.f ? v : v * slope;
+          if (MODE == EPI_DACT_MASK) {   // dZ_{l-1} = (dZ_l W_l) * LeakyReLU'(a_{l-1}); sign(a) = sign(pre-activation)
+            const unsigned m = bit < 32 ? (mlo >> bit) : (mhi >> (bit - 32));
+            v = (m & 1u) ? v : v * slope;
+          }
+          if (BITS) {
+            if (bit < 32) lo |= (v > 0.f) ? (1u << bit) : 0u;
+            else hi |= (v > 0.f) ? (1u << (bit - 32)) : 0u;
+          }
+          dst[(r * 16 + e) * LDP] = colin ? v : 0.f;
+        }
+      }
+    }
+  }
+  return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+
+// PACKED: weights come in fragment order (g.packed); AUX: some backward link has no sign bits and re-reads its
+// saved activation (slow epilogue).  Separate instantiations keep the hot <true, false> kernel small.
+template <bool PACKED, bool AUX>
 __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   extern __shared__ __attribute__((aligned(16))) float panel[];     // [ROWS][LDP]
   const int lane = threadIdx.x & 63;
@@ -184,9 +230,18 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(p) + (p ? (int64_t)blockIdx.x * WAVES * 64 : 0), 0,
                                              p ? WAVES * 64 * 8 : 0, kRsrcWord3);
   };
+  // bias of this lane's column in each of the wave's column blocks (NULL bias / columns >= N read as 0)
+  auto request_bias = [&](const Layer& ly, float (&b)[CBW]) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ly.bias), 0, ly.bias ? ly.N * 4 : 0, kRsrcWord3);
+#pragma unroll
+    for (int c = 0; c < CBW; ++c)
+      b[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, ((wave + c * WAVES) * 16 + (lane & 15)) * 4, 0, 0));
+  };
   float4 bpre[2][CBW];
-  if (g.packed) request_first_b(g.packed + g.pack_off[0], g.layer[0].K, g.layer[0].N, wave, lane, bpre);
+  float bias[CBW];
+  if (PACKED) request_first_b(g.packed + g.pack_off[0], g.layer[0].K, g.layer[0].N, wave, lane, bpre);
   u32x2 mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(g.layer[0].dact ? g.layer[0].mask_in : nullptr), mslot, 0, 0);
+  request_bias(g.layer[0], bias);
 
   // input panel, zero-padded to a multiple of KI columns (the k-loop runs in KI-deep iterations)
   {
@@ -209,8 +264,11 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     const int ncb_real = (ly.N + 15) / 16;
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
-    const float* pk = g.packed ? g.packed + g.pack_off[l] : nullptr;
+    const float* pk = PACKED ? g.packed + g.pack_off[l] : nullptr;
     const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
+    float bias_l[CBW];
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) bias_l[c] = bias[c];
 #define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                           \
     switch (nc) {                                                                                \
       case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc, bpre); break;           \
@@ -219,7 +277,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
       case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc, bpre); break;           \
       default: break;                                                                            \
     }
-    if (pk) { CLICA_FMLP_DISPATCH(true, true) }
+    if (PACKED) { CLICA_FMLP_DISPATCH(true, true) }
     else if (vec) { CLICA_FMLP_DISPATCH(true, false) }
     else { CLICA_FMLP_DISPATCH(false, false) }
 #undef CLICA_FMLP_DISPATCH
@@ -229,37 +287,45 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     // older than the activation stores below, and land while this layer's epilogue runs.
     if (l + 1 < g.L) {
       const Layer& nx = g.layer[l + 1];
-      if (g.packed) request_first_b(g.packed + g.pack_off[l + 1], nx.K, nx.N, wave, lane, bpre);
+      if (PACKED) request_first_b(g.packed + g.pack_off[l + 1], nx.K, nx.N, wave, lane, bpre);
       mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(nx.dact ? nx.mask_in : nullptr), mslot, 0, 0);
+      request_bias(nx, bias);
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // epilogue into the panel: C/D layout of 16x16 blocks: col = lane & 15, row = (lane >> 4) * 4 + reg.
-    // Columns N..round_up(N, KI) are written as zeros: they are the next layer's k-padding.
-    const int ncb = ((ly.N + KI - 1) & ~(KI - 1)) / 16;
-    const bool use_mask = ly.dact && ly.mask_in;
+    // epilogue into the panel (see epilogue_to_panel); the slow activation-re-reading variant of the backward
+    // chain (no sign bits given) is the only one that touches global memory here
     unsigned long long obits = 0ull;
+    {
+      const int N = ly.N;
+      const float slope = g.slope;
+      const bool bits = ly.mask_out != nullptr;
+      if (!ly.dact) {
+        if (ly.leaky) obits = bits ? epilogue_to_panel<EPI_BIAS_LEAKY, true>(panel, acc, bias_l, 0ull, slope, N, wave, lane)
+                                   : epilogue_to_panel<EPI_BIAS_LEAKY, false>(panel, acc, bias_l, 0ull, slope, N, wave, lane);
+        else obits = bits ? epilogue_to_panel<EPI_BIAS, true>(panel, acc, bias_l, 0ull, slope, N, wave, lane)
+                          : epilogue_to_panel<EPI_BIAS, false>(panel, acc, bias_l, 0ull, slope, N, wave, lane);
+      } else if (ly.mask_in) {
+        epilogue_to_panel<EPI_DACT_MASK, false>(panel, acc, bias_l, mbits, slope, N, wave, lane);
+      } else if (!AUX || !ly.aux) {
+        epilogue_to_panel<EPI_DACT_NONE, false>(panel, acc, bias_l, 0ull, slope, N, wave, lane);
+      } else {
+        const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;
 #pragma unroll
-    for (int c = 0; c < CBW; ++c) {
-      const int cb = wave + c * WAVES;
-      if (cb < ncb) {
-        const int col = cb * 16 + (lane & 15);
-        const float bv = (!ly.dact && ly.bias && col < ly.N) ? ly.bias[col] : 0.f;
+        for (int c = 0; c < CBW; ++c) {
+          const int cb = wave + c * WAVES;
+          if (cb < ncb) {
+            const int col = cb * 16 + (lane & 15);
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
+            for (int r = 0; r < RB; ++r) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int row = r * 16 + (lane >> 4) * 4 + e;
-            float v = acc[r][c][e] + bv;
-            const int bit = (c * RB + r) * 4 + e;
-            if (ly.dact) {          // dZ_{l-1} = (dZ_l W_l) * LeakyReLU'(a_{l-1}); sign(a) = sign(pre-activation)
-              if (use_mask) v *= ((mbits >> bit) & 1ull) ? 1.f : g.slope;
-              else if (ly.aux && row < nrows && col < ly.N) v *= (ly.aux[(row0 + row) * ly.ldaux + col] > 0.f ? 1.f : g.slope);
-            } else if (ly.leaky) {
-              v = v > 0.f ? v : v * g.slope;
+              for (int e = 0; e < 4; ++e) {
+                const int row = r * 16 + (lane >> 4) * 4 + e;
+                float v = acc[r][c][e];
+                if (row < nrows && col < N) v *= (ly.aux[(row0 + row) * ly.ldaux + col] > 0.f ? 1.f : slope);
+                panel[row * LDP + col] = col < N ? v : 0.f;
+              }
             }
-            obits |= (v > 0.f) ? (1ull << bit) : 0ull;
-            panel[row * LDP + col] = col < ly.N ? v : 0.f;
           }
         }
       }
@@ -305,6 +371,8 @@ struct PackArgs {
   int L, transpose; const float* W[MAXL]; int64_t ldw[MAXL]; int N[MAXL], K[MAXL];   // stored nn.Linear dims [N, K]
   int64_t off[MAXL + 1];    // destination offsets, float4 units
   int64_t src[MAXL + 1];    // source work items: N * ceil(K/4) per layer
+  float4* packed_t;         // "both" mode: second destination, transposed layout; off_t[l] < 0 = layer not in the chain
+  int64_t off_t[MAXL];
 };
 static inline int64_t pack_float4s(int N, int K) { return (int64_t)((N + 15) / 16) * ((K + KI - 1) / KI) * 2 * 64; }
 
@@ -328,9 +396,12 @@ __global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a, float4* __restrict
     const int kiters = (K + KI - 1) / KI;
     const int cb = n >> 4, i15 = n & 15, ki = k / KI, h = (k % KI) >> 4, q = (k & 15) >> 2;
     packed[a.off[l] + ((int64_t)(cb * kiters + ki) * 2 + h) * 64 + q * 16 + i15] = v;
-  } else {
+  }
+  float* pf = nullptr;
+  if (a.transpose) pf = reinterpret_cast<float*>(packed + a.off[l]);
+  else if (a.packed_t && a.off_t[l] >= 0) pf = reinterpret_cast<float*>(a.packed_t + a.off_t[l]);
+  if (pf) {
     // logical matrix = W^T: row n' = k + u (output column of the data-gradient), contraction k' = n
-    float* pf = reinterpret_cast<float*>(packed + a.off[l]);
     const int kiters = (a.N[l] + KI - 1) / KI;
     const int ki = n / KI, h = (n % KI) >> 4, q = (n & 15) >> 2, t = n & 3;
     const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -346,6 +417,21 @@ __global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a, float4* __restrict
 }  // namespace clica
 
 using namespace clica;
+
+template <bool PACKED, bool AUX>
+static int launch_mlp_inst(const fmlp::Args& g, hipStream_t st, const char* who) {
+  using namespace fmlp;
+  constexpr size_t lds = (size_t)ROWS * LDP * sizeof(float);
+  auto k = mlp_fwd_k<PACKED, AUX>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  hipLaunchKernelGGL(k, dim3((unsigned)ceil_div(g.M, ROWS)), dim3(THREADS), lds, st, g);
+  return launch_status(who);
+}
+static int launch_mlp(const fmlp::Args& g, bool packed, bool aux, hipStream_t st, const char* who) {
+  if (packed) return aux ? launch_mlp_inst<true, true>(g, st, who) : launch_mlp_inst<true, false>(g, st, who);
+  return launch_mlp_inst<false, false>(g, st, who);
+}
 
 extern "C" int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes) {
   using namespace fmlp;
@@ -383,6 +469,27 @@ extern "C" int clica_mlp_pack(int32_t n_layers, const float* const* W, const int
   return launch_status("clica_mlp_pack");
 }
 
+extern "C" int clica_mlp_pack_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                   float* packed_fwd, float* packed_bwd, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(W && ldw && N && K && packed_fwd && packed_bwd && n_layers >= 2 && n_layers <= MAXL, "clica_mlp_pack_both: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_bwd) & 15) == 0,
+                  "clica_mlp_pack_both: packed buffers must be 16-byte aligned");
+  PackArgs a{};
+  a.L = n_layers; a.transpose = 0; a.off[0] = 0; a.src[0] = 0; a.packed_t = reinterpret_cast<float4*>(packed_bwd);
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack_both: layer %d: bad argument", l);
+    a.W[l] = W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l];
+    a.off[l + 1] = a.off[l] + pack_float4s(N[l], K[l]);
+    a.src[l + 1] = a.src[l] + (int64_t)N[l] * ((K[l] + 3) / 4);
+  }
+  int64_t ot = 0;                      // chain order: layer L-1 first, down to layer 1; layer 0 has no data gradient
+  a.off_t[0] = -1;
+  for (int l = n_layers - 1; l >= 1; --l) { a.off_t[l] = ot; ot += pack_float4s(K[l], N[l]); }
+  hipLaunchKernelGGL(mlp_pack_k, dim3((unsigned)ceil_div(a.src[n_layers], 256)), dim3(256), 0, as_stream(stream), a, reinterpret_cast<float4*>(packed_fwd));
+  return launch_status("clica_mlp_pack_both");
+}
+
 extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                              const float* const* W, const int64_t* ldw, const float* const* bias,
                              float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
@@ -405,11 +512,7 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
     g.pack_off[l] = poff; poff += pack_float4s(N[l], K[l]) * 4;
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd: ldx < K[0]");
-  constexpr size_t lds = (size_t)ROWS * LDP * sizeof(float);
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-  (void)once;
-  hipLaunchKernelGGL(mlp_fwd_k, dim3((unsigned)ceil_div(M, ROWS)), dim3(THREADS), lds, as_stream(stream), g);
-  return launch_status("clica_mlp_fwd");
+  return launch_mlp(g, packed != nullptr, false, as_stream(stream), "clica_mlp_fwd");
 }
 
 
@@ -437,9 +540,7 @@ extern "C" int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t
     g.pack_off[j] = poff; poff += pack_float4s(N[j], K[j]) * 4;
   }
   CLICA_CHECK_ARG(lddy >= K[0], "clica_mlp_dgrad: lddy < K[0]");
-  constexpr size_t lds = (size_t)ROWS * LDP * sizeof(float);
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-  (void)once;
-  hipLaunchKernelGGL(mlp_fwd_k, dim3((unsigned)ceil_div(M, ROWS)), dim3(THREADS), lds, as_stream(stream), g);
-  return launch_status("clica_mlp_dgrad");
+  bool aux = false;
+  for (int j = 0; j < n_links; ++j) aux = aux || (g.layer[j].aux && !g.layer[j].mask_in);
+  return launch_mlp(g, true, aux, as_stream(stream), "clica_mlp_dgrad");
 }

@@ -84,6 +84,7 @@ class ContrastiveTrainer:
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
         self.packed = None
         self.packed_t = None
+        self._packed_current = False
         self.fused_backward = self.fused_forward and os.environ.get("CLICA_FUSED_BWD", "1") != "0" and len(self.linears) > 1
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         self._allocate()
@@ -189,14 +190,27 @@ class ContrastiveTrainer:
         ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
 
     # -------------------------------------------------------------------------------- step pieces
+    def pack(self):
+        """Fragment-order copies of the CURRENT weights for the fused forward / backward-chain kernels (one launch
+        for both layouts when both are used).  Valid until the next optimizer step."""
+        ws = [lin.weight for lin in self.linears]
+        if self.fused_backward and self.pack_weights:
+            self.packed, self.packed_t = ops.mlp_pack_both(ws, self.packed, self.packed_t)
+        elif self.fused_forward and self.pack_weights:
+            self.packed = ops.mlp_pack_weights(ws, self.packed)
+        elif self.fused_backward:
+            chain = [self.linears[l].weight for l in range(len(self.linears) - 1, 0, -1)]
+            self.packed_t = ops.mlp_pack_weights(chain, self.packed_t, transpose=True)
+        self._packed_current = True
+
     def forward(self):
         cur = self.x
         L = len(self.linears)
         if self.fused_forward:
             # one launch for the whole stack, activation panel resident in LDS (csrc/fused_mlp.hip)
             ws = [lin.weight for lin in self.linears]
-            if self.pack_weights:
-                self.packed = ops.mlp_pack_weights(ws, self.packed)  # fragment-order copy of the current weights
+            if not self._packed_current:
+                self.pack()
             ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
                         signmasks=self.signmasks)
             cur = self.acts[-1]
@@ -270,7 +284,8 @@ class ContrastiveTrainer:
             #     prologue / slab reduction hides behind the other's MFMA phase.
             chain = list(range(L - 1, 0, -1))
             ws = [self.linears[l].weight for l in chain]
-            self.packed_t = ops.mlp_pack_weights(ws, self.packed_t, transpose=True)
+            if not self._packed_current:
+                self.pack()
             ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
                                 masks_chain=[self.signmasks[l - 1] for l in chain])
             if self.grouped_wgrad:
@@ -342,12 +357,24 @@ class ContrastiveTrainer:
             self.buckets.wait()
 
     def optimizer_step(self):
+        self._packed_current = False
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                       self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world)
 
     # -------------------------------------------------------------------------------- whole step
     def _step_body(self, sample: bool):
-        if sample:
+        # the fragment-order weight copies only depend on the parameters: pack them on the side stream while the
+        # main stream samples the batch and runs the mixing net
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        side = self.side_stream
+        self._packed_current = False          # a step always re-packs (parameters may have been set from outside)
+        if (self.fused_forward or self.fused_backward) and main is not None and side is not None and sample:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.pack()
+            self.sample()
+            main.wait_stream(side)
+        elif sample:
             self.sample()
         self.forward()
         self.loss_forward_backward()

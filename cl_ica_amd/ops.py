@@ -125,6 +125,30 @@ def mlp_pack_weights(weights, packed: Optional[torch.Tensor] = None, transpose: 
     return packed
 
 
+def mlp_pack_both(weights, packed: Optional[torch.Tensor] = None, packed_t: Optional[torch.Tensor] = None):
+    """Both fragment-order copies a training step needs in ONE launch (clica_mlp_pack_both): `packed` for
+    `mlp_fwd` (layers 0..L-1) and `packed_t` for `mlp_dgrad_chain` (layers L-1..1, transposed)."""
+    L = len(weights)
+    ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
+    I32 = C.c_int32 * L
+    Ns, Ks = I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws])
+    dev = ws[0][0].device
+    if packed is None:
+        nb = C.c_size_t()
+        check(load().clica_mlp_pack_bytes(L, Ns, Ks, 0, C.byref(nb)), "clica_mlp_pack_bytes")
+        packed = torch.zeros(nb.value // 4, dtype=torch.float32, device=dev)
+    if packed_t is None:
+        nb = C.c_size_t()
+        chain = list(range(L - 1, 0, -1))
+        I32c = C.c_int32 * (L - 1)
+        check(load().clica_mlp_pack_bytes(L - 1, I32c(*[ws[l][0].shape[0] for l in chain]), I32c(*[ws[l][0].shape[1] for l in chain]), 1,
+                                          C.byref(nb)), "clica_mlp_pack_bytes")
+        packed_t = torch.zeros(nb.value // 4, dtype=torch.float32, device=dev)
+    check(load().clica_mlp_pack_both(L, (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws]),
+                                     Ns, Ks, packed.data_ptr(), packed_t.data_ptr(), stream_ptr()), "clica_mlp_pack_both")
+    return packed, packed_t
+
+
 def mlp_signmask_alloc(M: int, n_layers: int, device) -> list:
     """Per-layer opaque sign-bit buffers for mlp_fwd(signmasks=...) / mlp_dgrad_chain(masks_chain=...)."""
     nbytes = C.c_size_t()

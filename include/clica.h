@@ -195,6 +195,10 @@ int clica_mlp_signmask_bytes(int64_t M, size_t* bytes);
 int clica_mlp_pack_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
 int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
                    int32_t transpose, float* packed, clica_stream_t stream);
+/* One launch that writes BOTH layouts a training step needs: packed_fwd = clica_mlp_pack(transpose = 0) of layers
+ * 0..L-1 and packed_bwd = clica_mlp_pack(transpose = 1) of layers L-1..1 (the chain order of clica_mlp_dgrad). */
+int clica_mlp_pack_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                        float* packed_fwd, float* packed_bwd, clica_stream_t stream);
 /* Backward data chain of the same stack in one launch (dZ panel resident in LDS):
  *   out[j] = (in_j B_j) * LeakyReLU'(act[j]),  in_0 = dY, in_j = out[j-1],  j = 0..n_links-1
  * B_j only in fragment order: `packed` = clica_mlp_pack(..., transpose = 1, ...) of the encoder layers in CHAIN

@@ -254,3 +254,14 @@ def test_grouped_wgrad_matches_per_layer(dims, M):
     ops.mlp_wgrad(dzs, xs, dWs, [None] * L, accumulate=True)
     for l in range(L):
         assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
+
+
+def test_pack_both_equals_two_packs():
+    from cl_ica_amd import ops
+    dims = [10, 100, 500, 500, 500, 500, 100, 10]
+    rng = np.random.default_rng(5)
+    Ws = [dev(rng.normal(size=(dims[i + 1], dims[i])).astype(np.float32)) for i in range(len(dims) - 1)]
+    p1 = ops.mlp_pack_weights(Ws)
+    pt1 = ops.mlp_pack_weights([Ws[l] for l in range(len(Ws) - 1, 0, -1)], transpose=True)
+    p2, pt2 = ops.mlp_pack_both(Ws)
+    assert torch.equal(p1, p2) and torch.equal(pt1, pt2)
