@@ -73,11 +73,22 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
   const int64_t i = (int64_t)blockIdx.x * FIN_ROWS + lane_row;
   float m = -1e30f, s = 0.f;
   if (i < rows) {
-    for (int sp = grp; sp < nsplit; sp += THREADS / FIN_ROWS) {
-      const float2 ps = part[(int64_t)sp * rows + i];
-      const float mn = fmaxf(m, ps.x);
-      s = s * fexp2(m - mn) + ps.y * fexp2(ps.x - mn);
-      m = mn;
+    // four partials in flight per round (a one-at-a-time loop is a chain of dependent L2 round trips);
+    // missing ones are (m = -1e30, s = 0): they leave the running pair unchanged
+    constexpr int G = THREADS / FIN_ROWS;
+    for (int sp0 = grp; sp0 < nsplit; sp0 += 4 * G) {
+      float2 ps[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sp = sp0 + u * G;
+        ps[u] = sp < nsplit ? part[(int64_t)sp * rows + i] : make_float2(-1e30f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float mn = fmaxf(m, ps[u].x);
+        s = s * fexp2(m - mn) + ps[u].y * fexp2(ps[u].x - mn);
+        m = mn;
+      }
     }
   }
   sm[grp][lane_row] = m; ss[grp][lane_row] = s;
@@ -174,24 +185,35 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
   }
 }
 
-// out[i,k] (+)= sum_split part[split][i][k]; one thread per float4 of the padded row
+// out[i,k] (+)= sum_split part[split][i][k]; FOUR threads per float4 of the padded row (each sums every fourth
+// split with its loads in flight together, then a fixed-order shuffle tree): 4x the parallelism of a
+// launch that is otherwise a few dozen latency-bound workgroups
 __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
                                                        int np, int n, float* __restrict__ out, int64_t ldo,
                                                        int accumulate) {
-  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  const int64_t idx = tid >> 2;
+  const int sub = (int)(tid & 3);
   const int q4 = np / 4;
-  if (idx >= rows * q4) return;
-  const int64_t i = idx / q4;
-  const int k = (int)(idx - i * q4) * 4;
-  if (k >= n) return;
+  const bool live = idx < rows * q4;
+  const int64_t i = live ? idx / q4 : 0;
+  const int k = live ? (int)(idx - i * q4) * 4 : 0;
   const int64_t stride = rows * (int64_t)np;
   const float* src = part + i * np + k;
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-  for (int sp = 0; sp < nsplit; ++sp) {
-    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sp * stride);
-    t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+  if (live && k < n) {
+#pragma unroll 4
+    for (int sp = sub; sp < nsplit; sp += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)sp * stride);
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
   }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    t.x += __shfl_xor(t.x, off, 64); t.y += __shfl_xor(t.y, off, 64);
+    t.z += __shfl_xor(t.z, off, 64); t.w += __shfl_xor(t.w, off, 64);
+  }
+  if (!live || k >= n || sub != 0) return;
   float* dst = out + i * ldo + k;
   const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -426,14 +448,14 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
   } else if (d_rows) {
     launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
     const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc);
   }
   if (d_cols) {
     Params qc = q; qc.sgn = -q.sgn;   // e = -(owner - stream) + eps seen from the column side
     launch_bwd_pairs(false, PC, pk, cols_p, ldc, cols, rows_p, ldr, rows, qc, w.statL, w.statC, w.partC, st);
     const int acc = frac ? 1 : (accumulate_dz3 ? 1 : 0);
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np / 4, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc);
   }
   return launch_status("clica_lp_loss_bwd");
@@ -462,10 +484,14 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
   hipLaunchKernelGGL(bwd_coef_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st,
                      rows, z1, ld1, z2, ld2, q, d->tau, d->alpha, d->compat ? 1 : 0, 0, 0, lse_i,
                      g_mean, (const float*)nullptr, g_pos, g_neg, w.statL, w.statC, dz1, ldd1, dz2, ldd2);
-  hipLaunchKernelGGL(pool_stats_k, dim3((unsigned)ceil_div(cols, THREADS)), dim3(THREADS), 0, st,
-                     cols, pool_lse, rows, d->tau, d->alpha, g_mean, g_neg, q.xs, strL, strC);
+  if (pool_lse == lse_i && cols == rows) {   // single rank: the pool IS the local rows, their statistics are already there
+    strL = w.statL; strC = w.statC;
+  } else {
+    hipLaunchKernelGGL(pool_stats_k, dim3((unsigned)ceil_div(cols, THREADS)), dim3(THREADS), 0, st,
+                       cols, pool_lse, rows, d->tau, d->alpha, g_mean, g_neg, q.xs, strL, strC);
+  }
   launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, w.partR, st);
-  hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
+  hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
                      (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1);
   return launch_status("clica_lp_loss_bwd_sym");
 }
@@ -621,12 +647,12 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
                        rowgrad, ldrg, (const float*)w.statC, B, n, o1, lo1, 1);
   } else if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np / 4, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1);
   }
   if (o3) {
     launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
-    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np / 4, THREADS)), dim3(THREADS), 0, st,
+    hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3);
   }
   if (d->normalize) {

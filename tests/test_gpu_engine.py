@@ -74,7 +74,11 @@ def test_engine_matches_autograd_path():
                 assert g.abs().max().item() < 1e-8     # translation invariance: exact gradient is 0
                 continue
             scale = max(ref_grads[k].abs().max().item(), 1e-12)
-            assert (g - ref_grads[k]).abs().max().item() / scale < 2e-4, (head, k)
+            err = (g - ref_grads[k]).abs().max().item()
+            if k == last_bias:     # nearly translation invariant with a head too: a ~1e-7 residue of +-1e-4 summands,
+                assert err < 1e-8 or err / scale < 2e-4, (head, k)   # only the summation-order noise bound is meaningful
+                continue
+            assert err / scale < 2e-4, (head, k)
 
 
 def test_graph_replay_trains():
