@@ -181,13 +181,33 @@ def roofline_leg(tr, reps=20):
     rows.sort(key=lambda r: -r["us_per_step"])
     if fused_key in groups:
         top = [r for r in rows if r["op"] == fused_key[0]][0]
+        # minimum HBM bytes per launch (average of the two launches): every layer output written once (saved
+        # activations / dZ), the weights once, the sign bits once, the 10-wide input
+        widths = [lin.out_features for lin in tr.linears]
+        nparam = sum(lin.out_features * lin.in_features for lin in tr.linears)
+        mask_b = sum(m.numel() * 8 for m in tr.signmasks if m is not None) if tr.signmasks else 0
+        fwd_b = 4 * R * (tr.linears[0].in_features + sum(widths)) + 4 * nparam + mask_b
+        bwd_b = 4 * R * (widths[-1] + sum(widths[:-1])) + 4 * nparam + mask_b
+        top["alg_bytes"] = (fwd_b + bwd_b) // 2
         note = "f32 (v_mfma_f32_16x16x4_f32), activation panel resident in LDS"
     else:
         top = [r for r in rows if r["op"] == "linear_fwd"][0]
         note = "f32 (v_mfma_f32_32x32x2_f32)"
+    traffic, traffic_src = None, None
+    try:        # HBM-side bytes per launch from the committed PMC passes (cannot be collected from inside this process)
+        here = os.path.dirname(os.path.abspath(__file__))
+        cand = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith("_traffic.json"))
+        if cand:
+            tj = json.load(open(os.path.join(here, "profiles", cand[-1])))
+            ent = tj["kernels"].get(top["kernel"])
+            if ent:
+                traffic = round(ent["fetch_x2_bytes"] + ent["write_bytes"])
+                traffic_src = f"profiles/{cand[-1]}: FETCH_SIZE x2 + WRITE_SIZE per launch (bytes), separate rocprofv3 --pmc passes"
+    except Exception:
+        pass
     roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
             "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": None, "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top.get("alg_bytes"), "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
             "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": note}
     return roof, rows
 

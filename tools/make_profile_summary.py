@@ -50,4 +50,12 @@ for r in stats:
     short = name.split("(")[0].replace("void ", "")
     lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {util} | {conf} |")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
+# per-launch HBM-side traffic (FETCH_SIZE x 2 + WRITE_SIZE, bytes) of every kernel symbol: bench.py's roofline.traffic
+traffic = {}
+for name, c in pm.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic[name.split("(")[0].replace("void ", "")] = {"fetch_x2_bytes": 2 * c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
+                                                            "launches_sampled": c["_n"]}
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/profile_round.sh {tag} (KB as reported; FETCH x2 per "
+                     "MI355X_MICROARCH.md); per-launch averages", "kernels": traffic}, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 print("\n".join(lines[:14]))
