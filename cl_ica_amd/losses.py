@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["CLLoss", "LpSimCLRLoss", "SimCLRLoss"]
+__all__ = ["CLLoss", "ConditionalPairCLLoss", "MarginalPairCLLoss", "LpSimCLRLoss", "SimCLRLoss", "UniformityLoss", "AlignmentLoss"]
 
 
 class CLLoss(ABC):
@@ -148,3 +148,68 @@ class SimCLRLoss(CLLoss):
                                 alpha=float(self.alpha), normalize=int(bool(self.normalize)))
         mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "dot", desc)
         return mean, per_item, [pos_mean, neg_mean]
+
+
+class ConditionalPairCLLoss(ABC):
+    """Loss protocol with one positive pair (reference losses.py:32-46)."""
+
+    @abstractmethod
+    def loss(self, z1_rec, z2_con_z1_rec):
+        ...
+
+    def __call__(self, z1_rec, z2_con_z1_rec):
+        return self.loss(z1_rec, z2_con_z1_rec)
+
+
+class MarginalPairCLLoss(ABC):
+    """Loss protocol with one negative pair (reference losses.py:49-63)."""
+
+    @abstractmethod
+    def loss(self, z1_rec, z3_rec):
+        ...
+
+    def __call__(self, z1_rec, z2_rec):
+        return self.loss(z1_rec, z2_rec)
+
+
+class UniformityLoss(MarginalPairCLLoss):
+    """Loss over the negative pairs only (reference losses.py:205-222):
+    ``per_item[j] = logmeanexp_i( -sum_k |z1_rec[i,k] - z3_rec[j,k]|^p )``, anchored at the rows of ``z3_rec``
+    (the reference builds the pair tensor as ``z1.unsqueeze(0) - z3.unsqueeze(1)`` and reduces its last axis).
+    Computed by the same tiled all-pairs kernel as LpSimCLRLoss: rows = z3_rec, pool = z1_rec, weight of the
+    positive term 0, plain logmeanexp (no positive in the denominator), tau = 1; the kernel's per-row loss is
+    2 * lse, hence the factor 0.5.  Returns ``(mean, per_item, [mean])``."""
+
+    def __init__(self, p: int = 2.0):
+        self.p = p
+
+    def loss(self, z1_rec, z3_rec):
+        if float(self.p) < 1.0:
+            raise NotImplementedError("UniformityLoss: p < 1 is not supported by the HIP kernel (its p < 1 branch follows "
+                                      "LpSimCLRLoss' eps placement, losses.py:433-442, which this loss does not have)")
+        if z1_rec.dim() != 2 or z3_rec.dim() != 2 or z1_rec.shape[1] != z3_rec.shape[1]:
+            raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z3_rec.shape)}")
+        desc = _lib.LpLossDesc(B=z3_rec.shape[0], B3=z1_rec.shape[0], n=z1_rec.shape[1], p=float(self.p), tau=1.0,
+                               alpha=0.0, compat=0, pow=1)
+        mean2, item2, _, _ = _PairLossFn.apply(z3_rec, z3_rec, z1_rec, "lp", desc)
+        loss = 0.5 * mean2
+        return loss, 0.5 * item2, [loss]
+
+
+class AlignmentLoss(ConditionalPairCLLoss):
+    """Loss over the positive pairs only (reference losses.py:225-241): ``per_item[i] = sum_k |z1_rec - z2_rec|^p``.
+    Same kernel with the whole weight on the positive term (alpha = 1) and a one-row negatives pool (its
+    log-sum-exp is finite and weighs 0).  Returns ``(mean, per_item, [mean])``."""
+
+    def __init__(self, p: int = 2.0):
+        self.p = p
+
+    def loss(self, z1_rec, z2_rec):
+        if float(self.p) < 1.0:
+            raise NotImplementedError("AlignmentLoss: p < 1 is not supported by the HIP kernel")
+        if z1_rec.dim() != 2 or z1_rec.shape != z2_rec.shape:
+            raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_rec.shape)}")
+        desc = _lib.LpLossDesc(B=z1_rec.shape[0], B3=1, n=z1_rec.shape[1], p=float(self.p), tau=1.0, alpha=1.0, compat=0, pow=1)
+        mean2, item2, _, _ = _PairLossFn.apply(z1_rec, z2_rec, z1_rec[:1].detach(), "lp", desc)
+        loss = 0.5 * mean2
+        return loss, 0.5 * item2, [loss]

@@ -172,6 +172,35 @@ def lp_simclr_loss(
 # --------------------------------------------------------------------------------------
 # SimCLRLoss  (reference: losses.py:162-202)
 # --------------------------------------------------------------------------------------
+def uniformity_loss(z1, z3, p=2.0, grad=True, dtype=np.float64):
+    """UniformityLoss.loss (losses.py:211-222): pair tensor z1[None] - z3[:, None] -> lp[j, i]; per item j
+    logsumexp_i(-lp[j, i]) - log(#z1 rows) (_logmeanexp, losses.py:506-510); mean over j.  Backward = autograd."""
+    z1 = np.asarray(z1, dtype); z3 = np.asarray(z3, dtype)
+    d = z1[None, :, :] - z3[:, None, :]                 # [j, i, k]
+    lp = _powabs(d, p).sum(-1)
+    lse = _lse(-lp, 1)
+    item = lse - np.log(z1.shape[0])
+    out = dict(loss_mean=item.mean(), loss_i=item)
+    if grad:
+        w = np.exp(-lp - lse[:, None]) / z3.shape[0]    # d mean / d(-lp[j, i])
+        gd = -w[:, :, None] * _dpowabs(d, p)            # d mean / d d[j, i, k]
+        out["dz1"] = gd.sum(0)
+        out["dz3"] = -gd.sum(1)
+    return out
+
+
+def alignment_loss(z1, z2, p=2.0, grad=True, dtype=np.float64):
+    """AlignmentLoss.loss (losses.py:231-241): per item sum_k |z1 - z2|^p, mean over items."""
+    z1 = np.asarray(z1, dtype); z2 = np.asarray(z2, dtype)
+    d = z1 - z2
+    item = _powabs(d, p).sum(-1)
+    out = dict(loss_mean=item.mean(), loss_i=item)
+    if grad:
+        g = _dpowabs(d, p) / z1.shape[0]
+        out["dz1"], out["dz2"] = g, -g
+    return out
+
+
 def simclr_loss(z1, z2, z3, normalize=False, tau=1.0, alpha=0.5, grad=True, dtype=np.float64):
     z1 = np.asarray(z1, dtype); z2 = np.asarray(z2, dtype); z3 = np.asarray(z3, dtype)
     raw = (z1, z2, z3)

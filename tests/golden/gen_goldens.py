@@ -19,6 +19,7 @@ test time depends on torch's RNG streams.  Groups follow SURVEY.md section 8(c):
   g9_samplers.npz     sampler statistics from 1e5 reference draws
   g10_strided.npz     strided / sliced input views
   g11_metrics.npz     R^2 / MCC evaluation metrics (disentanglement_utils.py)
+  g12_align_uniform.npz  UniformityLoss / AlignmentLoss (losses.py:205-241)
 """
 import os
 import sys
@@ -464,8 +465,29 @@ def g11():
     save("g11_metrics.npz", store)
 
 
+def g12():
+    """UniformityLoss / AlignmentLoss (losses.py:205-241).  (AlignmentUniformityLoss raises inside the reference's
+    SplitCombinedCLLoss -- torch.tensor() of a list of (B,) tensors, losses.py:144 -- so there is nothing to pin.)"""
+    store = {}
+    idx = 0
+    for p in (1.0, 2.0, 3.0):
+        for (B, B3, n, scale) in ((8, 8, 3, 1.0), (64, 48, 10, 1.0), (96, 96, 10, 0.3)):
+            z1, z2, z3 = rand_inputs(12000 + idx, B, B3, n, scale)
+            a = torch.tensor(z1, requires_grad=True); c = torch.tensor(z3, requires_grad=True)
+            u, ui, _ = ref_losses.UniformityLoss(p)(a, c)
+            u.backward()
+            put(store, f"u{idx:03d}", dict(z1=z1, z3=z3), dict(loss_mean=t2n(u), loss_i=t2n(ui), dz1=t2n(a.grad), dz3=t2n(c.grad)), p=p)
+            a = torch.tensor(z1, requires_grad=True); b = torch.tensor(z2, requires_grad=True)
+            al, ali, _ = ref_losses.AlignmentLoss(p)(a, b)
+            al.backward()
+            put(store, f"a{idx:03d}", dict(z1=z1, z2=z2), dict(loss_mean=t2n(al), loss_i=t2n(ali), dz1=t2n(a.grad), dz2=t2n(b.grad)), p=p)
+            idx += 1
+    store["n_cases"] = np.asarray(idx)
+    save("g12_align_uniform.npz", store)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g1r", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
-    table = dict(g1=g1, g1r=g1_roll, g2=g2, g3=g3, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11)
+    which = sys.argv[1:] or ["g1", "g1r", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    table = dict(g1=g1, g1r=g1_roll, g2=g2, g3=g3, g5=g5, g6=g6, g7=g7, g8=g8, g9=g9, g10=g10, g11=g11, g12=g12)
     for w in which:
         table[w]()

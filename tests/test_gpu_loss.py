@@ -214,3 +214,30 @@ def test_rowgrad_forward_equals_row_pass():
         assert torch.allclose(outs[0][0], outs[1][0], rtol=2e-6, atol=1e-6), p
         for a, b in zip(outs[0][1], outs[1][1]):
             assert (a - b).abs().max().item() < 2e-6 * max(a.abs().max().item(), 1e-6) + 1e-9, p
+
+
+def test_uniformity_alignment_vs_golden(golden):
+    """UniformityLoss / AlignmentLoss (reference losses.py:205-241) on the all-pairs kernel, against G12."""
+    from cl_ica_amd.losses import AlignmentLoss, UniformityLoss
+    G = golden("g12_align_uniform.npz")
+    for i in range(G.n_cases):
+        u = G.case(f"u{i:03d}"); p = float(u["meta"]["p"])
+        z1 = dev(u["in"]["z1"]).requires_grad_(True); z3 = dev(u["in"]["z3"]).requires_grad_(True)
+        tot, per, extra = UniformityLoss(p)(z1, z3)
+        tot.backward()
+        comp = max(float(np.abs(u["out"]["loss_i"]).max()) + np.log(z1.shape[0]), 1.0)
+        assert abs(tot.item() - float(u["out"]["loss_mean"])) < TOL * comp and extra[0] is tot
+        assert np.abs(per.detach().cpu().numpy() - u["out"]["loss_i"]).max() < TOL * comp
+        for name, t in (("dz1", z1), ("dz3", z3)):
+            d = np.abs(np.asarray(u["in"]["z1"], np.float64)[None] - np.asarray(u["in"]["z3"], np.float64)[:, None])
+            scale = max(np.abs(u["out"][name]).max(), float((p * np.maximum(d, 1e-12) ** (p - 1)).max()) / z3.shape[0])
+            assert np.abs(t.grad.cpu().numpy() - u["out"][name]).max() / scale < TOL * comp, (i, name)
+        a = G.case(f"a{i:03d}")
+        z1 = dev(a["in"]["z1"]).requires_grad_(True); z2 = dev(a["in"]["z2"]).requires_grad_(True)
+        tot, per, _ = AlignmentLoss(p)(z1, z2)
+        tot.backward()
+        assert abs(tot.item() - float(a["out"]["loss_mean"])) < TOL * max(1.0, abs(float(a["out"]["loss_mean"])))
+        assert rel_err(per.detach().cpu().numpy(), a["out"]["loss_i"]) < TOL
+        assert rel_err(z1.grad.cpu().numpy(), a["out"]["dz1"]) < TOL and rel_err(z2.grad.cpu().numpy(), a["out"]["dz2"]) < TOL
+    with pytest.raises(NotImplementedError):
+        UniformityLoss(0.5)(z1, z2)

@@ -207,3 +207,24 @@ def test_torch_port_goldens(golden):
         assert rel_err(a.grad.numpy(), c["out"]["dz1"]) < 1e-5
         n += 1
     assert n > 50
+
+
+def test_uniformity_alignment_oracle_vs_golden(golden):
+    """G12: UniformityLoss / AlignmentLoss (losses.py:205-241)."""
+    G = golden("g12_align_uniform.npz")
+    for i in range(G.n_cases):
+        u = G.case(f"u{i:03d}"); p = float(u["meta"]["p"])
+        out = O.uniformity_loss(u["in"]["z1"], u["in"]["z3"], p)
+        comp = max(float(np.abs(out["loss_i"]).max()) + np.log(u["in"]["z1"].shape[0]), 1.0)
+        assert abs(float(out["loss_mean"]) - float(u["out"]["loss_mean"])) < TOL * comp
+        assert np.abs(out["loss_i"] - u["out"]["loss_i"]).max() < TOL * comp
+        for g in ("dz1", "dz3"):
+            # rows of softmax weights sum to 1/B3: that is the un-cancelled size of a gradient entry
+            scale = max(np.abs(u["out"][g]).max(), float(np.abs(O._dpowabs(u["in"]["z1"][None] - u["in"]["z3"][:, None], p)).max()) / u["in"]["z3"].shape[0])
+            assert np.abs(out[g] - u["out"][g]).max() / scale < 5 * TOL * comp, (i, g)
+        a = G.case(f"a{i:03d}")
+        out = O.alignment_loss(a["in"]["z1"], a["in"]["z2"], p)
+        assert abs(float(out["loss_mean"]) - float(a["out"]["loss_mean"])) < TOL * max(1.0, abs(float(a["out"]["loss_mean"])))
+        assert rel_err(out["loss_i"], a["out"]["loss_i"]) < TOL
+        for g in ("dz1", "dz2"):
+            assert rel_err(out[g], a["out"][g]) < 5 * TOL, (i, g)
