@@ -120,7 +120,13 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
 #pragma unroll
       for (int c = 0; c < NC; ++c) bcur[hlf][c] = bnxt[hlf][c];
 #pragma unroll
-      for (int r = 0; r < RB; ++r) acur[hlf][r] = anxt[hlf][r];
+      for (int r = 0; r < RB; ++r) {
+        // keep the panel fragment ONE 16-byte LDS read: without a whole-vector use the optimiser scalarises it
+        // into four ds_read_b32 (2-way bank conflicts at this row stride) plus an address add each, sunk between the MFMAs
+        f32x4 v = {anxt[hlf][r].x, anxt[hlf][r].y, anxt[hlf][r].z, anxt[hlf][r].w};
+        asm volatile("" : "+v"(v));
+        acur[hlf][r] = make_float4(v[0], v[1], v[2], v[3]);
+      }
     }
   };
   if (PACKED) {     // iteration 0's weights were requested before the previous layer's epilogue (see the kernel)

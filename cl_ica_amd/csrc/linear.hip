@@ -333,20 +333,40 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float colsum = 0.f;
 
-  // this lane's piece of the tile: k-rows 4*wave + 2*j + h (j = 0, 1), columns 4*l31 .. +3
+  // this lane's piece of the tile: k-rows 4*wave + 2*j + h (j = 0, 1), columns 4*l31 .. +3.  The four source
+  // pointers are kept running (one 64-bit add per load and tile; lanes whose columns are out of range sit on
+  // the zero page with stride 0): on this chip fp32 MFMA and the vector ALU share issue, address arithmetic
+  // inside the k-loop is paid for in matrix throughput.
   const bool a_ok = m0 + 4 * l31 < g.M, b_ok = n0 + 4 * l31 < g.N;      // M, N multiples of 4 on this path
-  const float* a_src = g.A + m0 + 4 * l31;
-  const float* b_src = g.B + n0 + 4 * l31;
+  const float* pa[2]; const float* pb[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t k = kbeg + 4 * wave + 2 * j + h;
+    pa[j] = a_ok ? g.A + k * g.lda + m0 + 4 * l31 : g_zero_page;
+    pb[j] = b_ok ? g.B + k * g.ldb + n0 + 4 * l31 : g_zero_page;
+  }
+  const int64_t sa = a_ok ? (int64_t)BK * g.lda : 0, sb = b_ok ? (int64_t)BK * g.ldb : 0;
+  const int full_tiles = (int)((kend - kbeg) / BK);      // tiles with every k-row below kend
   auto issue = [&](int t) {
     float* st = smem + (t % DMA_STAGES) * STAGE;
+    if (t < full_tiles) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kr = 4 * wave + 2 * j;
-      const int64_t k = kbeg + (int64_t)t * BK + kr + h;
-      const bool kin = k < kend;
-      dma_1k((a_ok && kin) ? a_src + k * g.lda : g_zero_page, st + kr * BM);
-      dma_1k((b_ok && kin) ? b_src + k * g.ldb : g_zero_page, st + TA::LDS_FLOATS + kr * BN);
+      for (int j = 0; j < 2; ++j) {
+        const int kr = 4 * wave + 2 * j;
+        dma_1k(pa[j], st + kr * BM);
+        dma_1k(pb[j], st + TA::LDS_FLOATS + kr * BN);
+      }
+    } else {               // the ragged last tile: rows at or beyond kend come from the zero page
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int kr = 4 * wave + 2 * j;
+        const bool kin = kbeg + (int64_t)t * BK + kr + h < kend;
+        dma_1k(kin ? pa[j] : g_zero_page, st + kr * BM);
+        dma_1k(kin ? pb[j] : g_zero_page, st + TA::LDS_FLOATS + kr * BN);
+      }
     }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { pa[j] += sa; pb[j] += sb; }
   };
   constexpr int PER_TILE = 4;     // loads per wave per tile
   if (ntiles > 0) issue(0);
