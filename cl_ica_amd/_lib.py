@@ -74,8 +74,12 @@ SIGNATURES: Dict[str, list] = {
     "clica_softclip_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
     "clica_mixing_fwd": [c_f32p, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],
     "clica_adam_step": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "clica_adam_step_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                             C.c_void_p, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],
     "clica_sample": [C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p],
+    "clica_sample_pair": [C.POINTER(SamplerDesc), C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64,
+                          C.c_void_p, C.c_void_p],
 }
 
 _lib: Optional[C.CDLL] = None

@@ -11,7 +11,7 @@ constexpr int THREADS = 256;
 
 __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, int64_t count, float lr, float b1, float b2, float eps,
-                                                 float gscale, const int32_t* __restrict__ step_dev) {
+                                                 float gscale, int32_t* __restrict__ step_dev, int32_t* __restrict__ ticket) {
   __shared__ float s_step_size, s_inv_bc2_sqrt;
   if (threadIdx.x == 0) {
     const double t = (double)(step_dev[0] + 1);
@@ -46,15 +46,28 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
     m[i] = mn; v[i] = vn;
     p[i] -= step_size * mn / (sqrtf(vn) * inv_bc2_sqrt + eps);
   }
+  // optional fused tick: every workgroup read *step_dev on entry (same thread, earlier in program order than its
+  // arrival below), so the LAST one to arrive may advance it.  Relaxed arrival counter, NO fence: nothing but that
+  // read has to be ordered, and an agent-scope release here would write back the XCD's dirty L2 lines -- the
+  // parameter update itself -- once per workgroup (measured: +20 us).
+  if (ticket) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+        step_dev[0] += 1;
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 }  // namespace adam
 }  // namespace clica
 
 using namespace clica;
 
-extern "C" int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
-                               float lr, float beta1, float beta2, float eps, float grad_scale,
-                               const int32_t* step_dev, clica_stream_t stream) {
+static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                       float lr, float beta1, float beta2, float eps, float grad_scale,
+                       int32_t* step_dev, int32_t* ticket, clica_stream_t stream) {
   CLICA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && count > 0, "clica_adam_step: bad argument");
   CLICA_CHECK_ARG(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
                   "clica_adam_step: arenas must be 16-byte aligned");
@@ -62,6 +75,19 @@ extern "C" int clica_adam_step(float* param, const float* grad, float* exp_avg, 
   if (blocks > kNumCU * 8) blocks = kNumCU * 8;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks), dim3(adam::THREADS), 0, as_stream(stream),
-                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev);
+                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket);
   return launch_status("clica_adam_step");
+}
+
+extern "C" int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                               float lr, float beta1, float beta2, float eps, float grad_scale,
+                               const int32_t* step_dev, clica_stream_t stream) {
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, stream);
+}
+
+extern "C" int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                                    float lr, float beta1, float beta2, float eps, float grad_scale,
+                                    int32_t* step_dev, int32_t* ticket, clica_stream_t stream) {
+  CLICA_CHECK_ARG(ticket != nullptr, "clica_adam_step_tick: ticket is NULL");
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, stream);
 }

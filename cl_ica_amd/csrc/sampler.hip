@@ -112,6 +112,39 @@ __global__ __launch_bounds__(THREADS) void sample_elem_k(Desc d, const float* __
   out[i * ldo + k] = v;
 }
 
+// marginal draw z and conditional draw z~ | z of the same element in one launch (both coordinate-wise kinds):
+// the same Philox counters as two sample_elem_k launches, hence the same numbers
+__global__ __launch_bounds__(THREADS) void sample_pair_elem_k(Desc dm, Desc dc, const float* __restrict__ mmean, int64_t ldmm,
+                                                             float* __restrict__ z, int64_t ldz, float* __restrict__ zt, int64_t ldzt,
+                                                             int64_t M, const int32_t* __restrict__ step_dev) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= M * dm.n) return;
+  const int64_t i = idx / dm.n;
+  const int k = (int)(idx - i * dm.n);
+  const uint32_t step = step_dev ? (uint32_t)step_dev[0] : 0u;
+  float v;
+  {
+    Philox g(dm.seed, (uint32_t)idx, step, dm.stream_id);
+    if (dm.dist == CLICA_DIST_UNIFORM) {
+      v = g.uniform() * (dm.box_max - dm.box_min) + dm.box_min;
+    } else {
+      const float m = mmean[i * ldmm + k];
+      v = m + noise(g, dm);
+      if (dm.space == CLICA_SPACE_BOX)
+        for (int it = 0; it < 4096 && !(v >= dm.box_min && v <= dm.box_max); ++it) v = m + noise(g, dm);
+    }
+    z[i * ldz + k] = v;
+  }
+  {
+    Philox g(dc.seed, (uint32_t)idx, step, dc.stream_id);
+    const float m = v;
+    float w = m + noise(g, dc);
+    if (dc.space == CLICA_SPACE_BOX)
+      for (int it = 0; it < 4096 && !(w >= dc.box_min && w <= dc.box_max); ++it) w = m + noise(g, dc);
+    zt[i * ldzt + k] = w;
+  }
+}
+
 // one thread per sample row
 __global__ __launch_bounds__(THREADS) void sample_k(Desc d, const float* __restrict__ mean, int64_t ldm,
                                                    float* __restrict__ out, int64_t ldo, int64_t M,
@@ -181,6 +214,39 @@ __global__ __launch_bounds__(THREADS) void sample_k(Desc d, const float* __restr
 }  // namespace clica
 
 using namespace clica;
+
+static bool rowwise_kind(const clica_sampler_desc* d) { return d->space == CLICA_SPACE_SPHERE || d->dist == CLICA_DIST_VMF; }
+
+extern "C" int clica_sample_pair(const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
+                                 const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
+                                 int64_t M, const int32_t* step_dev, clica_stream_t stream) {
+  CLICA_CHECK_ARG(marginal && conditional && z && zt && M > 0, "clica_sample_pair: bad argument");
+  CLICA_CHECK_ARG(marginal->n == conditional->n, "clica_sample_pair: the two descriptors disagree on n");
+  CLICA_CHECK_ARG(conditional->dist != CLICA_DIST_UNIFORM, "clica_sample_pair: the second draw must be a conditional kind");
+  if (rowwise_kind(marginal) || rowwise_kind(conditional) || (marginal->dist != CLICA_DIST_UNIFORM && ldmm == 0)) {
+    int rc = clica_sample(marginal, marginal_mean, ldmm, z, ldz, M, step_dev, stream);     // row-wise kinds: two launches
+    if (rc) return rc;
+    return clica_sample(conditional, z, ldz, zt, ldzt, M, step_dev, stream);
+  }
+  // validate through the single-draw entry's rules without launching twice
+  const clica_sampler_desc* both[2] = {marginal, conditional};
+  for (const clica_sampler_desc* d : both) {
+    CLICA_CHECK_ARG(d->n >= 1 && ldz >= d->n && ldzt >= d->n, "clica_sample_pair: leading dimension < n");
+    CLICA_CHECK_ARG(d->space >= CLICA_SPACE_REAL && d->space <= CLICA_SPACE_SPHERE, "clica_sample_pair: unknown space %d", d->space);
+    CLICA_CHECK_ARG(d->dist >= CLICA_DIST_UNIFORM && d->dist <= CLICA_DIST_GENNORM, "clica_sample_pair: unknown distribution %d", d->dist);
+    if (d->dist == CLICA_DIST_UNIFORM) CLICA_CHECK_ARG(d->space != CLICA_SPACE_REAL, "clica_sample_pair: uniform is not defined on R^n");
+    if (d->dist == CLICA_DIST_GENNORM) CLICA_CHECK_ARG(d->shape_p > 0.f, "clica_sample_pair: generalized normal needs shape_p > 0");
+    if (d->space == CLICA_SPACE_BOX) CLICA_CHECK_ARG(d->box_max > d->box_min, "clica_sample_pair: empty box");
+  }
+  if (marginal->dist != CLICA_DIST_UNIFORM) CLICA_CHECK_ARG(marginal_mean != nullptr && ldmm >= marginal->n, "clica_sample_pair: marginal mean missing");
+  rng::Desc qm{marginal->space, marginal->dist, marginal->n, marginal->box_min, marginal->box_max, marginal->scale, marginal->shape_p,
+               marginal->seed, marginal->stream_id};
+  rng::Desc qc{conditional->space, conditional->dist, conditional->n, conditional->box_min, conditional->box_max, conditional->scale,
+               conditional->shape_p, conditional->seed, conditional->stream_id};
+  hipLaunchKernelGGL(rng::sample_pair_elem_k, dim3((unsigned)ceil_div(M * marginal->n, rng::THREADS)), dim3(rng::THREADS), 0,
+                     as_stream(stream), qm, qc, marginal_mean, ldmm, z, ldz, zt, ldzt, M, step_dev);
+  return launch_status("clica_sample_pair");
+}
 
 extern "C" int clica_sample(const clica_sampler_desc* d, const float* mean, int64_t ldm,
                             float* out, int64_t ldo, int64_t M, const int32_t* step_dev,

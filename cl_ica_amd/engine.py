@@ -123,6 +123,11 @@ class ContrastiveTrainer:
             o_b, n_b = pid[id(lin.bias)]
             self._layer_slices.append((min(o_w, o_b), max(o_w + n_w, o_b + n_b)))
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # clica_adam_step_tick's arrival counter
+        # A/B switch: 1 = pair sampler launch (+0.7 %), 2 = tick inside Adam (-0.5 %: 834 same-address atomics cost more
+        # than the 4.6 us single-thread tick launch they replace) -> only the first is on by default
+        fs = int(os.environ.get("CLICA_FUSE_SMALL", "1"))
+        self.fuse_small, self.fuse_tick = bool(fs & 1), bool(fs & 2)
 
     def _allocate(self):
         dev, B, n = self.device, self.B, self.n
@@ -171,17 +176,23 @@ class ContrastiveTrainer:
         s, B, n = self.sampler, self.B, self.n
         z, zt = self.z[:B], self.z[B:]
         sid = 2 * self.rank
-        if s.marginal == "uniform":
-            ops.sample(s.space, "uniform", n, B, self.device, box=s.box, seed=s.seed, stream_id=sid, step_dev=self.step_dev, out=z)
-        else:
+        mean = None
+        if s.marginal != "uniform":
             if not hasattr(self, "_eta"):
                 self._eta = torch.zeros(1, n, device=self.device)
                 if s.space == "sphere":
                     self._eta[0, 0] = 1.0                      # main_mlp.py:148-150
-            ops.sample(s.space, s.marginal, n, B, self.device, mean=self._eta, scale=s.m_param, shape_p=s.m_p, box=s.box,
+            mean = self._eta
+        # both draws in one launch for the coordinate-wise kinds (box, R^n); two for the sphere / vMF
+        if not self.fuse_small:
+            ops.sample(s.space, s.marginal, n, B, self.device, mean=mean, scale=s.m_param, shape_p=s.m_p, box=s.box,
                        seed=s.seed, stream_id=sid, step_dev=self.step_dev, out=z)
-        ops.sample(s.space, s.conditional, n, B, self.device, mean=z, scale=s.c_param, shape_p=s.c_p, box=s.box,
-                   seed=s.seed, stream_id=sid + 1, step_dev=self.step_dev, out=zt)
+            ops.sample(s.space, s.conditional, n, B, self.device, mean=z, scale=s.c_param, shape_p=s.c_p, box=s.box,
+                       seed=s.seed, stream_id=sid + 1, step_dev=self.step_dev, out=zt)
+            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+            return
+        ops.sample_pair(s.space, s.marginal, s.conditional, n, B, z, zt, marginal_mean=mean, m_scale=s.m_param, m_p=s.m_p,
+                        c_scale=s.c_param, c_p=s.c_p, box=s.box, seed=s.seed, stream_id=sid, step_dev=self.step_dev)
         ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
 
     def inject(self, z1: torch.Tensor, z2: torch.Tensor):
@@ -358,8 +369,12 @@ class ContrastiveTrainer:
 
     def optimizer_step(self):
         self._packed_current = False
+        # the last Adam workgroup to finish also advances the device step / RNG counter (no separate tick launch)
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world)
+                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world,
+                      ticket=self.adam_ticket if self.fuse_tick else None)
+        if not self.fuse_tick:
+            ops.tick(self.step_dev)
 
     # -------------------------------------------------------------------------------- whole step
     def _step_body(self, sample: bool):
@@ -380,7 +395,6 @@ class ContrastiveTrainer:
         self.loss_forward_backward()
         self.backward()
         self.optimizer_step()
-        ops.tick(self.step_dev)
 
     def step(self):
         """One unsupervised step with on-device sampling.  Returns the device tensor

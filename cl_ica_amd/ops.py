@@ -262,19 +262,48 @@ def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: 
     return x
 
 
-def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
-    """In-place Adam on flat fp32 arenas; `step_dev` int32[1] = updates already applied."""
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
+              ticket: Optional[torch.Tensor] = None):
+    """In-place Adam on flat fp32 arenas; `step_dev` int32[1] = updates already applied.  With `ticket` (device
+    int32[1], zero) the same launch also advances `step_dev` by one (clica_adam_step_tick)."""
     for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         require_cuda(t, nm)
         if not t.is_contiguous():
             raise ValueError(f"{nm} must be contiguous")
-    check(load().clica_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
-                                 param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
-                                 step_dev.data_ptr(), stream_ptr()), "clica_adam_step")
+    if ticket is None:
+        check(load().clica_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                     param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                     step_dev.data_ptr(), stream_ptr()), "clica_adam_step")
+    else:
+        check(load().clica_adam_step_tick(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                          param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                          step_dev.data_ptr(), ticket.data_ptr(), stream_ptr()), "clica_adam_step_tick")
 
 
 def tick(counter: torch.Tensor):
     check(load().clica_tick(counter.data_ptr(), stream_ptr()), "clica_tick")
+
+
+def sample_pair(space: str, marginal: str, conditional: str, n: int, size: int, z: torch.Tensor, zt: torch.Tensor,
+                marginal_mean: Optional[torch.Tensor] = None, m_scale: float = 1.0, m_p: float = 2.0,
+                c_scale: float = 1.0, c_p: float = 2.0, box=(0.0, 1.0), seed: int = 0, stream_id: int = 0,
+                step_dev: Optional[torch.Tensor] = None):
+    """z ~ marginal, zt ~ conditional(. | z) with Philox stream ids `stream_id` and `stream_id + 1` (clica_sample_pair:
+    one launch for the coordinate-wise kinds; same numbers as two `sample` calls)."""
+    mk = lambda dist, scale, p, sid: _lib.SamplerDesc(space=SPACE[space], dist=DIST[dist], n=n, box_min=float(box[0]), box_max=float(box[1]),
+                                                      scale=float(scale), shape_p=float(p), seed=int(seed) & (2**64 - 1),
+                                                      stream_id=int(sid) & 0xFFFFFFFF)
+    dm, dc = mk(marginal, m_scale, m_p, stream_id), mk(conditional, c_scale, c_p, stream_id + 1)
+    ldmm = 0
+    if marginal_mean is not None:
+        require_cuda(marginal_mean, "marginal_mean")
+        marginal_mean = marginal_mean.reshape(1, -1) if marginal_mean.dim() == 1 else marginal_mean
+        marginal_mean, ldmm = rowmajor(marginal_mean.detach())
+        if marginal_mean.shape[0] == 1:
+            ldmm = 0
+    check(load().clica_sample_pair(C.byref(dm), C.byref(dc), ptr(marginal_mean), ldmm, z.data_ptr(), z.stride(0), zt.data_ptr(),
+                                   zt.stride(0), size, ptr(step_dev), stream_ptr()), "clica_sample_pair")
+    return z, zt
 
 
 SPACE = {"real": 0, "box": 1, "sphere": 2}

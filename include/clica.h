@@ -252,6 +252,11 @@ int clica_mixing_fwd(const float* Z, int64_t ldz, const float* W, int32_t n_laye
 int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                     float lr, float beta1, float beta2, float eps, float grad_scale,
                     const int32_t* step_dev, clica_stream_t stream);
+/* Same update, and the LAST workgroup to finish advances *step_dev by one (replaces the separate clica_tick launch).
+ * `ticket` is a device int32 owned by the caller, zero before the first call; the kernel leaves it at zero. */
+int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                         float lr, float beta1, float beta2, float eps, float grad_scale,
+                         int32_t* step_dev, int32_t* ticket, clica_stream_t stream);
 /* *counter += 1 (single-thread kernel; keeps step/RNG counters on device for graph replay) */
 int clica_tick(int32_t* counter, clica_stream_t stream);
 
@@ -286,6 +291,12 @@ typedef struct clica_sampler_desc {
 int clica_sample(const clica_sampler_desc* d, const float* mean, int64_t ldm,
                  float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
                  clica_stream_t stream);
+/* z ~ marginal and z~ ~ conditional(. | z) (main_mlp.py:196-200) in ONE launch when both kinds are coordinate-wise
+ * (box / R^n); the draws are bit-identical to clica_sample(marginal) followed by clica_sample(conditional, mean = z).
+ * Row-wise kinds (sphere, vMF) fall through to those two launches. */
+int clica_sample_pair(const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
+                      const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
+                      int64_t M, const int32_t* step_dev, clica_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -96,3 +96,34 @@ def test_real(golden):
         real.uniform(4)
     with pytest.raises(RuntimeError):
         spaces.NBoxSpace(3).uniform(4, device="cpu")
+
+
+def test_sample_pair_equals_two_launches():
+    """clica_sample_pair draws the same numbers as clica_sample(marginal) + clica_sample(conditional, mean = z)."""
+    from cl_ica_amd import ops
+    step = torch.full((1,), 7, dtype=torch.int32, device="cuda")
+    for space, marg, cond in (("box", "uniform", "normal"), ("box", "uniform", "laplace"), ("real", "normal", "gennorm"),
+                              ("sphere", "uniform", "normal")):
+        n, B = 10, 4096
+        mean = None if marg == "uniform" else torch.zeros(B, n, device="cuda")
+        z1 = ops.sample(space, marg, n, B, "cuda", mean=mean, scale=1.0, seed=3, stream_id=4, step_dev=step)
+        zt1 = ops.sample(space, cond, n, B, "cuda", mean=z1, scale=0.05, shape_p=3.0, seed=3, stream_id=5, step_dev=step)
+        z2, zt2 = torch.empty_like(z1), torch.empty_like(z1)
+        ops.sample_pair(space, marg, cond, n, B, z2, zt2, marginal_mean=mean, m_scale=1.0, c_scale=0.05, c_p=3.0, seed=3, stream_id=4,
+                        step_dev=step)
+        assert torch.equal(z1, z2) and torch.equal(zt1, zt2), (space, marg, cond)
+
+
+def test_adam_step_tick_advances_counter_once():
+    from cl_ica_amd import ops
+    n = 1 << 20
+    p = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda")
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    p2, m2, v2 = p.clone(), m.clone(), v.clone()
+    step = torch.zeros(1, dtype=torch.int32, device="cuda"); step2 = step.clone()
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for it in range(3):
+        ops.adam_step(p, g, m, v, step, 1e-3, ticket=ticket)
+        ops.adam_step(p2, g, m2, v2, step2, 1e-3); ops.tick(step2)
+        assert int(step.item()) == it + 1 and int(ticket.item()) == 0
+    assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
