@@ -39,6 +39,8 @@ enum Epi { EPI_BIAS_ACT = 0, EPI_DACT = 1, EPI_SLAB = 2 };
 // out-of-range tile pieces load from here: the zero comes straight from memory, so nothing has to
 // touch the loaded registers before the LDS store and the loads stay in flight across the MFMAs
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+// {1, 0, 0, 0}: the first padding column of the wgrad B operand reads this, so the MFMAs produce db = dZ^T 1 there
+__device__ __attribute__((aligned(16))) float g_one_page[4] = {1.f, 0.f, 0.f, 0.f};
 
 struct Args {
   const float* A; int64_t lda;
@@ -338,12 +340,16 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
   // the zero page with stride 0): on this chip fp32 MFMA and the vector ALU share issue, address arithmetic
   // inside the k-loop is paid for in matrix throughput.
   const bool a_ok = m0 + 4 * l31 < g.M, b_ok = n0 + 4 * l31 < g.N;      // M, N multiples of 4 on this path
+  // db for free: when the last column tile has padding, its first padding column (col == N) is fed ones, and
+  // the matrix cores return the column sums of dZ there -- no per-iteration LDS column sum on the vector ALU
+  const bool ones_col = g.dbias_slab && (g.N % BN != 0);
+  const float* b_pad = (ones_col && n0 + 4 * l31 == g.N) ? g_one_page : g_zero_page;
   const float* pa[2]; const float* pb[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t k = kbeg + 4 * wave + 2 * j + h;
     pa[j] = a_ok ? g.A + k * g.lda + m0 + 4 * l31 : g_zero_page;
-    pb[j] = b_ok ? g.B + k * g.ldb + n0 + 4 * l31 : g_zero_page;
+    pb[j] = b_ok ? g.B + k * g.ldb + n0 + 4 * l31 : b_pad;
   }
   const int64_t sa = a_ok ? (int64_t)BK * g.lda : 0, sb = b_ok ? (int64_t)BK * g.ldb : 0;
   const int full_tiles = (int)((kend - kbeg) / BK);      // tiles with every k-row below kend
@@ -410,7 +416,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    if (g.dbias_slab && bx == 0 && threadIdx.x < BM) {
+    if (g.dbias_slab && !ones_col && bx == 0 && threadIdx.x < BM) {     // no padding column to borrow: sum the LDS tile
 #pragma unroll 8
       for (int k = 0; k < BK; ++k) colsum += a_s[k * TA::LDS_LD + threadIdx.x];
     }
@@ -422,16 +428,19 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
 #pragma unroll
     for (int j = 0; j < NBN; ++j) {
       const int64_t col = n0 + wn * TN + j * 32 + l31;
-      if (col >= g.N) continue;
+      const bool is_db = ones_col && col == g.N;
+      if (col >= g.N && !is_db) continue;
+      float* dst = is_db ? g.dbias_slab + (int64_t)bz * g.M : Cbase + col;
+      const int64_t ld = is_db ? 1 : g.ldc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= g.M) continue;
-        Cbase[row * g.ldc + col] = acc[i][j][r];
+        dst[row * ld] = acc[i][j][r];
       }
     }
   }
-  if (g.dbias_slab && bx == 0 && threadIdx.x < BM) {
+  if (g.dbias_slab && !ones_col && bx == 0 && threadIdx.x < BM) {
     const int64_t row = m0 + threadIdx.x;
     if (row < g.M) g.dbias_slab[(int64_t)bz * g.M + row] = colsum;
   }
