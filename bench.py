@@ -114,6 +114,8 @@ def roofline_leg(tr, reps=20):
         tm, tn, waves, splits = ops.linear_plan(op, R, N, K)
         vec = (N % 4 == 0 and K % 4 == 0)
         layout = {"fwd": "true, true, 0", "dgrad": "true, false, 1", "wgrad": "false, false, 2"}[op]
+        if op == "wgrad" and vec and (tm, tn, waves) == (128, 128, 8):     # direct global->LDS body (one-problem group)
+            return ("linear_wgrad", "clica::gemm::wgrad_group_k<128, 128, 2, 4, 3> (+ slab_reduce_k)")
         return ("linear_" + op, f"clica::gemm::gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>"
                 + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 

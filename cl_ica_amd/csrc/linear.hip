@@ -862,7 +862,25 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   Args g{}; g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx; g.C = slab; g.ldc = K; g.M = N; g.N = K; g.Kc = M;
   g.k_per_split = p.k_per_split;
   g.dbias_slab = db ? dbslab : nullptr;
-  int rc = launch<false, false, EPI_SLAB>(p.cfg, g, p.splits, st, "clica_linear_wgrad");
+  int rc;
+  static const bool dma_ok = [] { const char* e = getenv("CLICA_WGRAD_DMA"); return !(e && atoi(e) == 0); }();
+  const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N % 4 == 0 && K % 4 == 0;
+  if (dma_ok && vec && p.cfg == 1) {
+    // 128x128 8-wave tiles: the direct global -> LDS body of the grouped kernel, as a one-problem group
+    GroupArgs G{};
+    G.n = 1; G.p[0] = g; G.vec[0] = 1;
+    G.gx[0] = (int)ceil_div(K, GBN); G.gy[0] = (int)ceil_div(N, GBM);
+    G.first[0] = 0; G.first[1] = G.total = G.gx[0] * G.gy[0] * p.splits;
+    constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
+    constexpr size_t lds = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
+    auto k = wgrad_group_k<GBM, GBN, WM, WN, STAGES>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3((unsigned)G.total), dim3(THREADS), lds, st, G);
+    rc = launch_status("clica_linear_wgrad");
+  } else {
+    rc = launch<false, false, EPI_SLAB>(p.cfg, g, p.splits, st, "clica_linear_wgrad");
+  }
   if (rc) return rc;
   launch_slab_reduce(slab, dbslab, p.splits, N, K, dW, lddw, db, accumulate ? 1 : 0, st);
   return launch_status("clica_linear_wgrad(reduce)");
