@@ -58,6 +58,10 @@ SIGNATURES: Dict[str, list] = {
     "clica_linear_wgrad": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i64, c_i32, C.c_void_p, c_size, C.c_void_p],
     "clica_mlp_fwd": [c_f32p, c_i64, c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                       C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, C.POINTER(C.c_void_p), C.c_float, C.c_void_p],
+    "clica_mlp_fwd_mixed": [c_f32p, c_i64, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i32,
+                            C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
+                            C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, C.POINTER(C.c_void_p),
+                            C.c_float, C.c_void_p],
     "clica_mlp_signmask_bytes": [c_i64, C.POINTER(c_size)],
     "clica_mlp_pack_bytes": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.POINTER(c_size)],
     "clica_mlp_pack": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_i32, c_f32p, C.c_void_p],

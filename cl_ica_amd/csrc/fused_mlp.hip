@@ -44,8 +44,11 @@ struct Args {
   const float* X; int64_t ldx; int64_t M; int L; float slope;
   const float* packed;              // fragment-order weights (clica_mlp_pack) or nullptr
   int64_t pack_off[MAXL];           // float offset of each layer inside `packed`
+  // optional mixing-net prologue (clica_mlp_fwd_mixed): X is the latent block Z, the stack's input is g(Z)
+  const float* mixW; int mixL; float mix_slope; float* xout; int64_t ldxo;
   Layer layer[MAXL];
 };
+constexpr int MIX_MAX_N = 16;       // widest mixing net the prologue handles (ROWS * n values over THREADS threads, <= 2 each)
 
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -250,7 +253,45 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   request_bias(g.layer[0], bias);
 
   // input panel, zero-padded to a multiple of KI columns (the k-loop runs in KI-deep iterations)
-  {
+  if (g.mixW) {
+    // x = g(z): the frozen mixing MLP (n x n bias-free layers, LeakyReLU(mix_slope) between them; same arithmetic
+    // order as clica_mixing_fwd, hence the same bits), computed on this workgroup's 48 latent rows in a corner of
+    // the still empty panel; x goes to the panel AND to HBM (layer 0's weight gradient reads it)
+    const int n = g.layer[0].K, K16 = (n + KI - 1) & ~(KI - 1);
+    float* xa = panel; float* xb = panel + ROWS * MIX_MAX_N;
+    for (int idx = threadIdx.x; idx < ROWS * n; idx += THREADS) {
+      const int r = idx / n, k = idx - r * n;
+      xa[idx] = (r < nrows) ? g.X[(row0 + r) * g.ldx + k] : 0.f;
+    }
+    __syncthreads();
+    for (int l = 0; l < g.mixL; ++l) {
+      const float* wl = g.mixW + l * n * n;
+      for (int idx = threadIdx.x; idx < ROWS * n; idx += THREADS) {
+        const int r = idx / n, j = idx - r * n;
+        float acc = 0.f;
+        for (int k = 0; k < n; ++k) acc = fmaf(xa[r * n + k], wl[j * n + k], acc);
+        if (l < g.mixL - 1) acc = acc > 0.f ? acc : acc * g.mix_slope;
+        xb[idx] = acc;
+      }
+      __syncthreads();
+      float* t = xa; xa = xb; xb = t;
+    }
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int idx = threadIdx.x + u * THREADS; v[u] = idx < ROWS * n ? xa[idx] : 0.f; }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < ROWS * K16; idx += THREADS) { const int r = idx / K16; panel[r * LDP + (idx - r * K16)] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = threadIdx.x + u * THREADS;
+      if (idx < ROWS * n) {
+        const int r = idx / n, k = idx - r * n;
+        panel[r * LDP + k] = v[u];
+        if (r < nrows) g.xout[(row0 + r) * g.ldxo + k] = v[u];
+      }
+    }
+  } else {
     const int K0 = g.layer[0].K, K16 = (K0 + KI - 1) & ~(KI - 1);
     for (int idx = threadIdx.x; idx < ROWS * K16; idx += THREADS) {
       const int r = idx / K16, k = idx - r * K16;
@@ -496,15 +537,17 @@ extern "C" int clica_mlp_pack_both(int32_t n_layers, const float* const* W, cons
   return launch_status("clica_mlp_pack_both");
 }
 
-extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
-                             const float* const* W, const int64_t* ldw, const float* const* bias,
-                             float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                             const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream) {
+static int mlp_fwd_impl(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
+                        const float* const* W, const int64_t* ldw, const float* const* bias,
+                        float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                        const float* packed, uint64_t* const* signmask, float slope,
+                        const float* mixW, int32_t mixL, float mix_slope, float* xout, int64_t ldxo, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(X && W && ldw && bias && out && ldo && N && K && M > 0, "clica_mlp_fwd: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd: %d layers (1..%d supported)", n_layers, MAXL);
   Args g{};
   g.X = X; g.ldx = ldx; g.M = M; g.L = n_layers; g.slope = slope; g.packed = packed;
+  g.mixW = mixW; g.mixL = mixL; g.mix_slope = mix_slope; g.xout = xout; g.ldxo = ldxo;
   CLICA_CHECK_ARG(!packed || (reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_fwd: packed weights must be 16-byte aligned");
   int64_t poff = 0;
   for (int l = 0; l < n_layers; ++l) {
@@ -518,7 +561,27 @@ extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_l
     g.pack_off[l] = poff; poff += pack_float4s(N[l], K[l]) * 4;
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd: ldx < K[0]");
-  return launch_mlp(g, packed != nullptr, false, as_stream(stream), "clica_mlp_fwd");
+  if (mixW) {
+    CLICA_CHECK_ARG(mixL >= 1 && K[0] <= MIX_MAX_N && xout && ldxo >= K[0],
+                    "clica_mlp_fwd_mixed: mixing net of width %d (max %d), %d layers; x_out required", K[0], MIX_MAX_N, mixL);
+  }
+  return launch_mlp(g, packed != nullptr, false, as_stream(stream), mixW ? "clica_mlp_fwd_mixed" : "clica_mlp_fwd");
+}
+
+extern "C" int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
+                             const float* const* W, const int64_t* ldw, const float* const* bias,
+                             float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                             const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream) {
+  return mlp_fwd_impl(X, ldx, M, n_layers, W, ldw, bias, out, ldo, N, K, packed, signmask, slope, nullptr, 0, 0.f, nullptr, 0, stream);
+}
+
+extern "C" int clica_mlp_fwd_mixed(const float* Z, int64_t ldz, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                                   float* x_out, int64_t ldxo, int32_t n_layers,
+                                   const float* const* W, const int64_t* ldw, const float* const* bias,
+                                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                                   const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream) {
+  CLICA_CHECK_ARG(mix_W != nullptr, "clica_mlp_fwd_mixed: mix_W is NULL");
+  return mlp_fwd_impl(Z, ldz, M, n_layers, W, ldw, bias, out, ldo, N, K, packed, signmask, slope, mix_W, mix_layers, mix_slope, x_out, ldxo, stream);
 }
 
 

@@ -82,6 +82,10 @@ class ContrastiveTrainer:
         self.head = heads[0] if heads else None
         self._flatten_parameters()
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
+        # CLICA_FUSE_SMALL bit 4: mixing net g inside the fused forward's prologue (needs the one-launch forward, n <= 16)
+        self.mix_in_forward = bool(getattr(self, "_fuse_flags", int(os.environ.get("CLICA_FUSE_SMALL", "5"))) & 4) \
+            and self.fused_forward and self.n <= 16
+        self._x_pending = False
         self.packed = None
         self.packed_t = None
         self._packed_current = False
@@ -126,8 +130,9 @@ class ContrastiveTrainer:
         self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # clica_adam_step_tick's arrival counter
         # A/B switch: 1 = pair sampler launch (+0.7 %), 2 = tick inside Adam (-0.5 %: 834 same-address atomics cost more
         # than the 4.6 us single-thread tick launch they replace) -> only the first is on by default
-        fs = int(os.environ.get("CLICA_FUSE_SMALL", "1"))
+        fs = int(os.environ.get("CLICA_FUSE_SMALL", "5"))
         self.fuse_small, self.fuse_tick = bool(fs & 1), bool(fs & 2)
+        self._fuse_flags = fs
 
     def _allocate(self):
         dev, B, n = self.device, self.B, self.n
@@ -193,12 +198,18 @@ class ContrastiveTrainer:
             return
         ops.sample_pair(s.space, s.marginal, s.conditional, n, B, z, zt, marginal_mean=mean, m_scale=s.m_param, m_p=s.m_p,
                         c_scale=s.c_param, c_p=s.c_p, box=s.box, seed=s.seed, stream_id=sid, step_dev=self.step_dev)
-        ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+        self._mix()
 
     def inject(self, z1: torch.Tensor, z2: torch.Tensor):
         """Use caller-provided latents instead of the device sampler (parity tests)."""
         self.z[:self.B].copy_(z1); self.z[self.B:].copy_(z2)
-        ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+        self._mix()
+
+    def _mix(self):
+        """x = g(z): its own launch, unless the fused forward runs the mixing net in its prologue."""
+        self._x_pending = self.mix_in_forward
+        if not self.mix_in_forward:
+            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
 
     # -------------------------------------------------------------------------------- step pieces
     def pack(self):
@@ -222,8 +233,11 @@ class ContrastiveTrainer:
             ws = [lin.weight for lin in self.linears]
             if not self._packed_current:
                 self.pack()
+            mix = None
+            if self._x_pending:          # latents in, x = g(z) computed in the kernel prologue and stored to self.x
+                cur, mix, self._x_pending = self.z, (self.gW, self.g_slope, self.x), False
             ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
-                        signmasks=self.signmasks)
+                        signmasks=self.signmasks, mix=mix)
             cur = self.acts[-1]
         else:
             for l, lin in enumerate(self.linears):

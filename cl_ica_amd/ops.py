@@ -157,11 +157,13 @@ def mlp_signmask_alloc(M: int, n_layers: int, device) -> list:
 
 
 def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed: Optional[torch.Tensor] = None,
-            signmasks=None):
+            signmasks=None, mix=None):
     """Whole Linear(+LeakyReLU) stack in one launch (clica_mlp_fwd); `outs[l]` receives layer l's output
     (saved activations; the last one is the result).  Widths <= 512, <= 8 layers.  `packed` = the same
     weights from `mlp_pack_weights` (faster weight streaming).  `signmasks[l]` (from mlp_signmask_alloc, or
-    None) receives the (out > 0) bits of layer l for the one-launch backward."""
+    None) receives the (out > 0) bits of layer l for the one-launch backward.
+    `mix = (gW [L, n, n], slope, x_out)`: `x` holds the LATENTS and the mixing net g runs in the kernel's prologue
+    (clica_mlp_fwd_mixed); x_out receives g(x)."""
     (x, ldx) = _mat("x", x)
     L = len(weights)
     ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
@@ -171,13 +173,19 @@ def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed:
     VP = C.c_void_p * L
     I64 = C.c_int64 * L
     I32 = C.c_int32 * L
-    check(load().clica_mlp_fwd(x.data_ptr(), ldx, x.shape[0], L,
-                               VP(*[w.data_ptr() for w, _ in ws]), I64(*[ld for _, ld in ws]),
-                               VP(*[None if b is None else b.data_ptr() for b in bs]),
-                               VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
-                               I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws]),
-                               ptr(packed), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
-                               float(slope), stream_ptr()), "clica_mlp_fwd")
+    common = (L, VP(*[w.data_ptr() for w, _ in ws]), I64(*[ld for _, ld in ws]),
+              VP(*[None if b is None else b.data_ptr() for b in bs]),
+              VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+              I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws]),
+              ptr(packed), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
+              float(slope), stream_ptr())
+    if mix is None:
+        check(load().clica_mlp_fwd(x.data_ptr(), ldx, x.shape[0], *common), "clica_mlp_fwd")
+    else:
+        gW, gslope, xout = mix
+        gW = gW.detach().contiguous()
+        check(load().clica_mlp_fwd_mixed(x.data_ptr(), ldx, x.shape[0], gW.data_ptr(), gW.shape[0], float(gslope),
+                                         xout.data_ptr(), xout.stride(0), *common), "clica_mlp_fwd_mixed")
     return outs[-1]
 
 

@@ -187,6 +187,14 @@ int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                   const float* const* W, const int64_t* ldw, const float* const* bias,
                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
                   const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream);
+/* Same stack with the mixing network g in the prologue: Z = [M, n] latents, x = g(Z) (clica_mixing_fwd's arithmetic,
+ * n = K[0] <= 16) is computed per 48-row panel on chip, fed to layer 0 and also written to x_out (layer 0's weight
+ * gradient reads it): one launch less per step. */
+int clica_mlp_fwd_mixed(const float* Z, int64_t ldz, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                        float* x_out, int64_t ldxo, int32_t n_layers,
+                        const float* const* W, const int64_t* ldw, const float* const* bias,
+                        float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                        const float* packed, uint64_t* const* signmask, float slope, clica_stream_t stream);
 /* signmask (array of n_layers pointers, or NULL; entries may be NULL): per layer an opaque buffer of
  * clica_mlp_signmask_bytes(M) bytes that receives one bit per output element, (out > 0), in the kernel's
  * accumulator order.  clica_mlp_dgrad takes it in place of re-reading the saved activation: 8 bytes per lane

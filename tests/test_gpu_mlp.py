@@ -265,3 +265,26 @@ def test_pack_both_equals_two_packs():
     pt1 = ops.mlp_pack_weights([Ws[l] for l in range(len(Ws) - 1, 0, -1)], transpose=True)
     p2, pt2 = ops.mlp_pack_both(Ws)
     assert torch.equal(p1, p2) and torch.equal(pt1, pt2)
+
+
+@pytest.mark.parametrize("n,M", [(10, 12288), (4, 100), (16, 1000)])
+def test_fused_forward_with_mixing_prologue_is_bit_identical(n, M):
+    """clica_mlp_fwd_mixed (x = g(z) in the kernel prologue) == clica_mixing_fwd followed by clica_mlp_fwd."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(n * 31 + M)
+    dims = [n, 10 * n, 50 * n if 50 * n <= 512 else 500, 10 * n, n]
+    L = len(dims) - 1
+    Ws = [dev((rng.uniform(-1, 1, size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(L)]
+    bs = [dev(rng.uniform(-0.5, 0.5, size=dims[i + 1]).astype(np.float32)) for i in range(L)]
+    gW = dev((rng.normal(size=(3, n, n)) / np.sqrt(n)).astype(np.float32))
+    z = dev(rng.uniform(size=(M, n)).astype(np.float32))
+    packed = ops.mlp_pack_weights(Ws)
+    x_ref = ops.mixing_fwd(z, gW, 0.2)
+    outs_a = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    outs_b = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    ops.mlp_fwd(x_ref, Ws, bs, outs_a, 0.01, packed=packed)
+    x_out = torch.empty(M, n, device="cuda")
+    ops.mlp_fwd(z, Ws, bs, outs_b, 0.01, packed=packed, mix=(gW, 0.2, x_out))
+    assert torch.equal(x_out, x_ref)
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a, b)
