@@ -414,50 +414,50 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
 // packed[layer][cb][ki][h][lane] (float4) = W[cb*16 + (lane&15)][ki*32 + h*16 + 4*(lane>>4) .. +3], zero padded.
 // A wave's B-fragment load for (cb, ki, h) is then ONE fully contiguous 1 KB request instead of sixteen 64-byte
 // pieces of sixteen different weight rows (which made the fused forward texture-addresser bound).
-struct PackArgs {
-  int L, transpose; const float* W[MAXL]; int64_t ldw[MAXL]; int N[MAXL], K[MAXL];   // stored nn.Linear dims [N, K]
-  int64_t off[MAXL + 1];    // destination offsets, float4 units
-  int64_t src[MAXL + 1];    // source work items: N * ceil(K/4) per layer
-  float4* packed_t;         // "both" mode: second destination, transposed layout; off_t[l] < 0 = layer not in the chain
-  int64_t off_t[MAXL];
-};
 static inline int64_t pack_float4s(int N, int K) { return (int64_t)((N + 15) / 16) * ((K + KI - 1) / KI) * 2 * 64; }
 
-// One thread per SOURCE float4 (row n, k..k+3): coalesced reads of the nn.Linear rows, 16-byte scattered
-// writes.  The zero padding (n >= N inside the last column block, k >= K inside the last k-iteration) is
-// never written here: the caller provides a buffer that was zeroed ONCE (padding float4s have no source
-// element and stay zero across re-packs).
-__global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a, float4* __restrict__ packed) {
+// One thread per DESTINATION float4: a wave writes one whole 1 KB fragment (fully coalesced); its reads are sixteen
+// 64-byte row pieces (plain layout) or 64-byte column pieces of four rows (transposed layout) of an L2-resident
+// matrix.  (The first version went source-parallel: coalesced reads but 213 K scattered 16-byte writes, 11 us.)
+// Padding entries (rows >= N of the last column block, k >= K of the last k-iteration) are written as zeros.
+constexpr int MAXSEG = 2 * MAXL;
+struct PackSeg { const float* W; int64_t ldw; int rows, cols, transposed; };   // logical matrix [rows][cols] = W or W^T
+struct PackArgs {
+  int nseg;
+  int64_t first[MAXSEG + 1];     // first destination float4 of each segment (global numbering over both buffers)
+  float4* dst[MAXSEG];           // destination of the segment's first float4
+  PackSeg seg[MAXSEG];
+};
+
+__global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= a.src[a.L]) return;
-  int l = 0;
-  while (l + 1 < a.L && idx >= a.src[l + 1]) ++l;
-  const int64_t e = idx - a.src[l];
-  const int K = a.K[l], k4n = (K + 3) / 4;
-  const int n = (int)(e / k4n), k = (int)(e - (int64_t)n * k4n) * 4;
-  const float* row = a.W[l] + (int64_t)n * a.ldw[l] + k;
-  float4 v;
-  if (k + 3 < K && ((reinterpret_cast<uintptr_t>(row) & 15) == 0)) v = *reinterpret_cast<const float4*>(row);
-  else v = make_float4(row[0], k + 1 < K ? row[1] : 0.f, k + 2 < K ? row[2] : 0.f, k + 3 < K ? row[3] : 0.f);
-  if (!a.transpose) {
-    const int kiters = (K + KI - 1) / KI;
-    const int cb = n >> 4, i15 = n & 15, ki = k / KI, h = (k % KI) >> 4, q = (k & 15) >> 2;
-    packed[a.off[l] + ((int64_t)(cb * kiters + ki) * 2 + h) * 64 + q * 16 + i15] = v;
-  }
-  float* pf = nullptr;
-  if (a.transpose) pf = reinterpret_cast<float*>(packed + a.off[l]);
-  else if (a.packed_t && a.off_t[l] >= 0) pf = reinterpret_cast<float*>(a.packed_t + a.off_t[l]);
-  if (pf) {
-    // logical matrix = W^T: row n' = k + u (output column of the data-gradient), contraction k' = n
-    const int kiters = (a.N[l] + KI - 1) / KI;
-    const int ki = n / KI, h = (n % KI) >> 4, q = (n & 15) >> 2, t = n & 3;
-    const float vv[4] = {v.x, v.y, v.z, v.w};
+  if (idx >= a.first[a.nseg]) return;
+  int sidx = 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int np = k + u;
-      if (np < K) pf[(((int64_t)((np >> 4) * kiters + ki) * 2 + h) * 64 + q * 16 + (np & 15)) * 4 + t] = vv[u];
+  for (int i = 1; i < MAXSEG; ++i) sidx += (i < a.nseg && idx >= a.first[i]) ? 1 : 0;
+  const PackSeg& sg = a.seg[sidx];
+  const unsigned d = (unsigned)(idx - a.first[sidx]);
+  const unsigned kiters = (unsigned)(sg.cols + KI - 1) / KI;
+  const unsigned lane = d & 63u, h = (d >> 6) & 1u, frag = d >> 7;          // frag = cb * kiters + ki
+  const unsigned cb = frag / kiters, ki = frag - cb * kiters;
+  const int n = (int)(cb * 16u + (lane & 15u)), k = (int)(ki * KI + h * 16u + 4u * (lane >> 4));
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < sg.rows) {
+    if (!sg.transposed) {
+      const float* row = sg.W + (int64_t)n * sg.ldw + k;
+      if (k + 3 < sg.cols && ((reinterpret_cast<uintptr_t>(row) & 15) == 0)) {
+        const float4 t = *reinterpret_cast<const float4*>(row);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (k + u < sg.cols) v[u] = row[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) if (k + u < sg.cols) v[u] = sg.W[(int64_t)(k + u) * sg.ldw + n];
     }
   }
+  a.dst[sidx][d] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 }  // namespace fmlp
@@ -499,21 +499,29 @@ extern "C" int clica_mlp_signmask_bytes(int64_t M, size_t* bytes) {
   return CLICA_OK;
 }
 
+static int launch_pack(fmlp::PackArgs& a, clica_stream_t stream, const char* who) {
+  using namespace fmlp;
+  hipLaunchKernelGGL(mlp_pack_k, dim3((unsigned)ceil_div(a.first[a.nseg], 256)), dim3(256), 0, as_stream(stream), a);
+  return launch_status(who);
+}
+
 extern "C" int clica_mlp_pack(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
                               int32_t transpose, float* packed, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(W && ldw && N && K && packed && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack: bad argument");
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_pack: packed buffer must be 16-byte aligned");
   PackArgs a{};
-  a.L = n_layers; a.transpose = transpose ? 1 : 0; a.off[0] = 0; a.src[0] = 0;
+  a.nseg = n_layers; a.first[0] = 0;
+  int64_t off = 0;
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack: layer %d: bad argument", l);
-    a.W[l] = W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l];
-    a.off[l + 1] = a.off[l] + (transpose ? pack_float4s(K[l], N[l]) : pack_float4s(N[l], K[l]));
-    a.src[l + 1] = a.src[l] + (int64_t)N[l] * ((K[l] + 3) / 4);
+    const int rows = transpose ? K[l] : N[l], cols = transpose ? N[l] : K[l];
+    a.seg[l] = PackSeg{W[l], ldw[l], rows, cols, transpose ? 1 : 0};
+    a.dst[l] = reinterpret_cast<float4*>(packed) + off;
+    const int64_t cnt = pack_float4s(rows, cols);
+    off += cnt; a.first[l + 1] = a.first[l] + cnt;
   }
-  hipLaunchKernelGGL(mlp_pack_k, dim3((unsigned)ceil_div(a.src[n_layers], 256)), dim3(256), 0, as_stream(stream), a, reinterpret_cast<float4*>(packed));
-  return launch_status("clica_mlp_pack");
+  return launch_pack(a, stream, "clica_mlp_pack");
 }
 
 extern "C" int clica_mlp_pack_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
@@ -523,18 +531,25 @@ extern "C" int clica_mlp_pack_both(int32_t n_layers, const float* const* W, cons
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_bwd) & 15) == 0,
                   "clica_mlp_pack_both: packed buffers must be 16-byte aligned");
   PackArgs a{};
-  a.L = n_layers; a.transpose = 0; a.off[0] = 0; a.src[0] = 0; a.packed_t = reinterpret_cast<float4*>(packed_bwd);
+  a.first[0] = 0;
+  int sgi = 0;
+  int64_t off = 0;
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack_both: layer %d: bad argument", l);
-    a.W[l] = W[l]; a.ldw[l] = ldw[l]; a.N[l] = N[l]; a.K[l] = K[l];
-    a.off[l + 1] = a.off[l] + pack_float4s(N[l], K[l]);
-    a.src[l + 1] = a.src[l] + (int64_t)N[l] * ((K[l] + 3) / 4);
+    a.seg[sgi] = PackSeg{W[l], ldw[l], N[l], K[l], 0};
+    a.dst[sgi] = reinterpret_cast<float4*>(packed_fwd) + off;
+    const int64_t cnt = pack_float4s(N[l], K[l]);
+    off += cnt; a.first[sgi + 1] = a.first[sgi] + cnt; ++sgi;
   }
-  int64_t ot = 0;                      // chain order: layer L-1 first, down to layer 1; layer 0 has no data gradient
-  a.off_t[0] = -1;
-  for (int l = n_layers - 1; l >= 1; --l) { a.off_t[l] = ot; ot += pack_float4s(K[l], N[l]); }
-  hipLaunchKernelGGL(mlp_pack_k, dim3((unsigned)ceil_div(a.src[n_layers], 256)), dim3(256), 0, as_stream(stream), a, reinterpret_cast<float4*>(packed_fwd));
-  return launch_status("clica_mlp_pack_both");
+  off = 0;                              // chain order: layer L-1 first, down to layer 1; layer 0 has no data gradient
+  for (int l = n_layers - 1; l >= 1; --l) {
+    a.seg[sgi] = PackSeg{W[l], ldw[l], K[l], N[l], 1};
+    a.dst[sgi] = reinterpret_cast<float4*>(packed_bwd) + off;
+    const int64_t cnt = pack_float4s(K[l], N[l]);
+    off += cnt; a.first[sgi + 1] = a.first[sgi] + cnt; ++sgi;
+  }
+  a.nseg = sgi;
+  return launch_pack(a, stream, "clica_mlp_pack_both");
 }
 
 static int mlp_fwd_impl(const float* X, int64_t ldx, int64_t M, int32_t n_layers,

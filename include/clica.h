@@ -181,8 +181,7 @@ int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X, int64_t ld
  * `packed` (optional, NULL = read W directly): the same weights in MFMA fragment order, produced by
  * clica_mlp_pack into a buffer of clica_mlp_pack_bytes; a wave's weight fetch is then one contiguous 1 KB
  * request instead of sixteen 64-byte pieces (re-pack after every optimizer step: ~3.4 MB, a few us).  The
- * packed buffer must be ZEROED ONCE by the caller before its first clica_mlp_pack (padding entries are never
- * written). */
+ * padding entries (widths that are not multiples of 16 / 32) are written as zeros by every pack. */
 int clica_mlp_fwd(const float* X, int64_t ldx, int64_t M, int32_t n_layers,
                   const float* const* W, const int64_t* ldw, const float* const* bias,
                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
