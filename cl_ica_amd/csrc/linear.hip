@@ -52,7 +52,6 @@ struct Args {
   float slope; int leaky;
   int64_t k_per_split;    // wgrad: contraction rows per blockIdx.z
   float* dbias_slab;      // wgrad: [splits][M] column sums of A_op rows (db), or nullptr
-  int ablate;             // tuning probe (CLICA_GEMM_ABLATE): 1 no global loads, 2 no LDS stores, 4 no fragment reads, 8 no barrier
 };
 
 // ---- tile loaders: global -> registers ------------------------------------------------------
@@ -202,10 +201,8 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
       // fragments for the NEXT k-step are in flight while this k-step's MFMAs run
-      if (!(g.ablate & 4)) {
-        if (s + 1 < KSTEPS) load_frags((s + 1) & 1, a_s, s + 1);
-        else if (STAGES == 3 && t + 1 < ntiles) load_frags(0, smem + nxt * STAGE, 0);
-      }
+      if (s + 1 < KSTEPS) load_frags((s + 1) & 1, a_s, s + 1);
+      else if (STAGES == 3 && t + 1 < ntiles) load_frags(0, smem + nxt * STAGE, 0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
@@ -216,16 +213,16 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][tt], bf[s & 1][j][tt], acc[i][j], 0, 0, 0);
       if (s == 0) {
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < ntiles && !(g.ablate & 2)) {
+        if (t + 1 < ntiles) {
           TA::store(ra, smem + nxt * STAGE);
           TB::store(rb, smem + nxt * STAGE + TA::LDS_FLOATS);
         }
-        if (t + 2 < ntiles && !(g.ablate & 1)) {
+        if (t + 2 < ntiles) {
           const int64_t k0 = kbeg + (int64_t)(t + 2) * BK;
           TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend);
           TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend);
         }
-        if (STAGES == 3 && !(g.ablate & 8)) __syncthreads();
+        if (STAGES == 3) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -234,8 +231,8 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
       for (int k = 0; k < BK; ++k) colsum += a_s[k * TA::LDS_LD + threadIdx.x];
     }
     if (STAGES == 2) {
-      if (!(g.ablate & 8)) __syncthreads();
-      if (t + 1 < ntiles && !(g.ablate & 4)) load_frags(0, smem + nxt * STAGE, 0);
+      __syncthreads();
+      if (t + 1 < ntiles) load_frags(0, smem + nxt * STAGE, 0);
     }
     cur = nxt;
   }
@@ -764,8 +761,7 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
     Args& g = G.p[l];
     g.A = dZ[l]; g.lda = lddz[l]; g.B = X[l]; g.ldb = ldx[l]; g.C = slab; g.ldc = K[l]; g.M = N[l]; g.N = K[l]; g.Kc = M;
     g.k_per_split = p.k_per_split; g.dbias_slab = db[l] ? dbslab : nullptr;
-    { const int ab = env_cfg("CLICA_GEMM_ABLATE"); g.ablate = ab > 0 ? ab : 0; }
-    G.gx[l] = (int)ceil_div(K[l], GBN); G.gy[l] = (int)ceil_div(N[l], GBM);
+      G.gx[l] = (int)ceil_div(K[l], GBN); G.gy[l] = (int)ceil_div(N[l], GBM);
     G.vec[l] = (aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N[l] % 4 == 0 && K[l] % 4 == 0) ? 1 : 0;
     G.first[l] = item; item += G.gx[l] * G.gy[l] * p.splits;
     const bool v4 = (K[l] % 4 == 0) && (lddw[l] % 4 == 0) && aligned16(dW[l]);
@@ -798,7 +794,6 @@ extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int
     return launch_status("clica_linear_fwd(skinny)");
   Args g{}; g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.Kc = K;
   g.bias = bias; g.slope = slope; g.leaky = leaky;
-  { const int ab = env_cfg("CLICA_GEMM_ABLATE"); g.ablate = ab > 0 ? ab : 0; }
   const int cfg = cfg_fwd(N);
   return launch<true, true, EPI_BIAS_ACT>(cfg, g, 1, as_stream(stream), "clica_linear_fwd");
 }
