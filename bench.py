@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the split-bf16 mode issues six bf16 products per fp32 product)
 PEAK_FP32_VALU_TFLOPS = 157.3
 
 
@@ -50,10 +51,14 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (A/B switch)")
     ap.add_argument("--no-fused-forward", action="store_true", help="per-layer forward GEMMs instead of the one-launch stack (A/B switch)")
+    ap.add_argument("--split-bf16", action="store_true",
+                    help="opt-in arithmetic for the two whole-stack encoder kernels: exact 3-way bf16 splits of both fp32 operands, six "
+                         "bf16-MFMA products, fp32 accumulate (fp32-grade error); default is native fp32 MFMA")
+    ap.add_argument("--no-split-probe", action="store_true", help="skip the extra short measurement of the --split-bf16 mode (N = 1 only)")
     return ap.parse_args()
 
 
-def build_trainer(args, device, world):
+def build_trainer(args, device, world, split_bf16=None):
     from cl_ica_amd import encoders, invertible_network_utils as inu
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
     import contextlib, io
@@ -67,7 +72,8 @@ def build_trainer(args, device, world):
     spec = SamplerSpec(space=args.space_type, n=n, box=(0.0, 1.0), marginal="uniform", conditional="normal", c_param=0.05, seed=0)
     return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
                               device=device, process_group=None if world == 1 else dist.group.WORLD,
-                              overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward)
+                              overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward,
+                              split_bf16=args.split_bf16 if split_bf16 is None else split_bf16)
 
 
 def _graph_time(fns, reps):
@@ -119,12 +125,16 @@ def roofline_leg(tr, reps=20):
         return ("linear_" + op, f"clica::gemm::gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>"
                 + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 
-    fused_key = ("mlp_fwd+mlp_dgrad", "clica::fmlp::mlp_fwd_k<true, false>")
+    fused_key = ("mlp_fwd+mlp_dgrad", "clica::fmlp::mlp_split_k" if getattr(tr, "split_bf16", False) else "clica::fmlp::mlp_fwd_k<true, false>")
     if tr.fused_forward:
         ws = [lin.weight for lin in tr.linears]
         fl = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
-        add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed,
-                                               signmasks=tr.signmasks))
+        if tr.split_bf16:
+            add(fused_key, fl, lambda: ops.mlp_fwd_split(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.packed, tr.slope,
+                                                         signmasks=tr.signmasks))
+        else:
+            add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed,
+                                                   signmasks=tr.signmasks))
         add(("mlp_fwd", "clica::fmlp::mlp_fwd_k<true, false> [forward stack launch]"), fl, groups[fused_key]["fns"][-1])
     else:
         cur = tr.x
@@ -138,9 +148,13 @@ def roofline_leg(tr, reps=20):
         chain = list(range(L - 1, 0, -1))
         wsT = [tr.linears[l].weight for l in chain]
         fl = sum(2.0 * R * tr.linears[l].out_features * tr.linears[l].in_features for l in chain)
-        fn = lambda: ops.mlp_dgrad_chain(g_top, wsT, tr.packed_t, [tr.acts[l - 1] for l in chain],
-                                         [tr.dz[l - 1] for l in chain], tr.slope,
-                                         masks_chain=[tr.signmasks[l - 1] for l in chain])
+        if tr.split_bf16:
+            fn = lambda: ops.mlp_dgrad_chain_split(g_top, wsT, tr.packed_t, [tr.dz[l - 1] for l in chain], tr.slope,
+                                                   masks_chain=[tr.signmasks[l - 1] for l in chain])
+        else:
+            fn = lambda: ops.mlp_dgrad_chain(g_top, wsT, tr.packed_t, [tr.acts[l - 1] for l in chain],
+                                             [tr.dz[l - 1] for l in chain], tr.slope,
+                                             masks_chain=[tr.signmasks[l - 1] for l in chain])
         add(fused_key, fl, fn)
         add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k<true, false> [backward data chain launch]"), fl, fn)
         if tr.grouped_wgrad:
@@ -181,7 +195,15 @@ def roofline_leg(tr, reps=20):
         rows.append({"op": op, "kernel": sym, "launches_per_step": cnt, "avg_us": 1e6 * sec / cnt,
                      "gflop_per_launch": grp["flops"] / cnt / 1e9, "tflops": grp["flops"] / sec / 1e12, "us_per_step": 1e6 * sec})
     rows.sort(key=lambda r: -r["us_per_step"])
-    if fused_key in groups:
+    peak = PEAK_FP32_MFMA_TFLOPS
+    if fused_key in groups and getattr(tr, "split_bf16", False):
+        # split-bf16 mode: the step's dominant symbol is the (native fp32-MFMA) grouped weight-gradient kernel
+        top = rows[0]
+        note = ("f32 (v_mfma_f32_32x32x2_f32)" if "wgrad" in top["op"] else
+                "f32 results from six bf16 products of exact 3-way bf16 splits (v_mfma_f32_16x16x32_bf16, fp32 accumulate)")
+        if "wgrad" not in top["op"]:
+            peak = PEAK_BF16_MFMA_TFLOPS
+    elif fused_key in groups:
         top = [r for r in rows if r["op"] == fused_key[0]][0]
         # minimum HBM bytes per launch (average of the two launches): every layer output written once (saved
         # activations / dZ), the weights once, the sign bits once, the 10-wide input
@@ -208,7 +230,7 @@ def roofline_leg(tr, reps=20):
     except Exception:
         pass
     roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
-            "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(top["tflops"] / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top.get("alg_bytes"), "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
             "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": note}
     return roof, rows
@@ -318,6 +340,30 @@ def main():
                                "sample": f"5 timed + 2 warm-up full steps at B={args.batch_size}, n={args.n} (median), "
                                          f"torch {torch.__version__} CPU ops, {os.cpu_count()} host cores visible"}
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    out["encoder_arithmetic"] = ("split-bf16: exact 3-way bf16 splits of both fp32 operands, six bf16-MFMA products, fp32 accumulate "
+                                 "(fp32-grade error; forward stack + backward data chain only)" if tr.split_bf16 else "native fp32 MFMA")
+    if rank == 0 and world == 1 and not tr.split_bf16 and not args.no_split_probe and tr.fused_backward:
+        # extra information, NOT the headline: the same step with the opt-in split-bf16 encoder arithmetic
+        del tr
+        torch.cuda.empty_cache()
+        tr2 = build_trainer(args, device, world, split_bf16=True)
+        if tr2.split_bf16:
+            if use_graph:
+                tr2.capture()
+            for _ in range(args.warmup):
+                tr2.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nst = min(args.steps, 200)
+            for _ in range(nst):
+                tr2.step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            out["split_bf16_probe"] = {"value": nst / el, "unit": "steps/s", "ms_per_step": 1e3 * el / nst, "steps": nst,
+                                       "final_loss": float(tr2.loss_out[3 * tr2.B].item()),
+                                       "note": "opt-in (--split-bf16 / CLICA_SPLIT_BF16=1): encoder forward stack and backward data chain as six "
+                                               "bf16-MFMA products of exact 3-way bf16 operand splits, fp32 accumulate; parity tests pass at the "
+                                               "fp32 tolerances (tests/test_gpu_mlp.py::test_split_bf16_stack_matches_fp64)"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

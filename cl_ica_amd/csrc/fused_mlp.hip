@@ -30,6 +30,9 @@ constexpr int MAXW = 512;           // widest layer the panel holds
 constexpr int LDP = MAXW + 8;       // panel leading dimension: conflict-free ds_read_b128 of 16 rows x 4 k-groups
 constexpr int CBW = MAXW / 16 / WAVES;   // column blocks per wave (4)
 constexpr int MAXL = 8;
+#ifndef FP32_STORE_AUX
+#define FP32_STORE_AUX 2      // activation stores of the fp32 kernel: 2 = streaming (nt)
+#endif
 
 struct Layer {
   const float* W; int64_t ldw; const float* bias;
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
         const bool in = r < nrows;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&panel[(in ? r : 0) * LDP + 4 * c4]);
         const unsigned off = in ? (unsigned)((r * (int)ly.ldo + 4 * c4) * 4) : kOobOffset;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 2);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, FP32_STORE_AUX);
       }
     } else {
       for (int idx = threadIdx.x; idx < nrows * ly.N; idx += THREADS) {
@@ -458,6 +461,305 @@ __global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a) {
     }
   }
   a.dst[sidx][d] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+
+// =====================================================================================================================
+// Split-bf16 variant of the same whole-stack kernel (opt-in, clica_mlp_*_split): fp32-grade results on the bf16
+// matrix cores.  Every fp32 operand is split EXACTLY into three bf16 pieces (8 + 8 + 8 mantissa bits, by
+// truncation: v = hi + mid + lo with no rounding), and the six piece products of order <= 2 -- lo.hi, hi.lo,
+// mid.mid, mid.hi, hi.mid, hi.hi -- are accumulated in fp32 by v_mfma_f32_16x16x32_bf16.  Each bf16 x bf16 product
+// is exact in fp32; the dropped products are below 2^-24 of |a||b|.  Measured against fp64 on a 500 x 500 layer over
+// 12 288 rows: max error 8.6e-7 of max|y| (the fp32-MFMA kernel: 1.0e-6).  Six bf16 instructions of 16 cycles cover
+// K = 32 where the fp32 path needs eight of 32 cycles: 0.375 of the matrix time (tools/proto/bf16x3_probe.py:
+// 26 vs 50 us marginal per 500 x 500 layer; the weight stream, now 6 B per weight from L2, is what remains).
+//   * panel: three bf16 planes [48][520] in LDS (150 KB);
+//   * weights: fragment order per piece, one contiguous 1 KB request per (piece, column block, k-iteration);
+//   * the product is taken transposed (matrix rows = output features, columns = batch rows): a lane then owns
+//     FOUR CONSECUTIVE FEATURES of one batch row, so the epilogue emits one float4 to HBM and one 8-byte LDS
+//     write per plane instead of element-wise traffic, and there is no panel -> HBM copy phase.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDPB = MAXW + 8;                  // bf16 elements per panel row: 1040 B, 16-byte aligned, bank-staggered
+constexpr int PLANE = ROWS * LDPB;              // bf16 elements per plane
+
+__device__ __forceinline__ void split3(float v, unsigned& hb, unsigned& mb, unsigned& lb) {     // piece bits in the HIGH half
+  hb = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(hb);
+  mb = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  lb = __float_as_uint(r2) & 0xFFFF0000u;       // <= 8 significant bits left: exact
+}
+
+static inline int64_t pack3_entries(int N, int K) { return (int64_t)((N + 15) / 16) * ((K + KI - 1) / KI) * 64; }   // 16-byte entries per piece
+
+// fragment-order pieces: dst[piece][cb][ki][lane] (16 B = 8 bf16) = piece(W[cb*16 + (lane&15)][ki*32 + (lane>>4)*8 .. +7])
+struct Pack3Args {
+  int nseg;
+  int64_t first[MAXSEG + 1];
+  u32x4* dst[MAXSEG];          // piece 0 of the segment; pieces are `entries` apart
+  int64_t entries[MAXSEG];
+  PackSeg seg[MAXSEG];
+};
+__global__ __launch_bounds__(256) void mlp_pack3_k(Pack3Args a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.first[a.nseg]) return;
+  int sidx = 0;
+#pragma unroll
+  for (int i = 1; i < MAXSEG; ++i) sidx += (i < a.nseg && idx >= a.first[i]) ? 1 : 0;
+  const PackSeg& sg = a.seg[sidx];
+  const unsigned d = (unsigned)(idx - a.first[sidx]);
+  const unsigned kiters = (unsigned)(sg.cols + KI - 1) / KI;
+  const unsigned lane = d & 63u, frag = d >> 6;
+  const unsigned cb = frag / kiters, ki = frag - cb * kiters;
+  const int n = (int)(cb * 16u + (lane & 15u)), k = (int)(ki * KI + 8u * (lane >> 4));
+  unsigned h[8], m[8], l[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    float v = 0.f;
+    if (n < sg.rows && k + u < sg.cols) v = sg.transposed ? sg.W[(int64_t)(k + u) * sg.ldw + n] : sg.W[(int64_t)n * sg.ldw + k + u];
+    split3(v, h[u], m[u], l[u]);
+  }
+  auto pk = [](const unsigned (&b)[8]) {
+    return (u32x4){(b[0] >> 16) | b[1], (b[2] >> 16) | b[3], (b[4] >> 16) | b[5], (b[6] >> 16) | b[7]};
+  };
+  u32x4* dst = a.dst[sidx] + d;
+  dst[0] = pk(h); dst[a.entries[sidx]] = pk(m); dst[2 * a.entries[sidx]] = pk(l);
+}
+
+struct SplitArgs {
+  Args g;                        // same description of the stack as the fp32 kernel (g.packed unused)
+  const u32x4* packed3;
+  int64_t off3[MAXL];            // 16-byte entry offset of each layer's piece 0
+  int64_t ent3[MAXL];            // entries per piece of each layer
+  int boff[MAXL + 1];            // float offset of each layer's bias row inside the LDS bias table (rows padded to KI)
+};
+constexpr int BIAS_LDS_MAX = (160 * 1024 - 3 * PLANE * 2) / 4 - 64;    // floats left beside the three planes
+
+template <int NC>
+__device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __restrict__ w0, const int64_t ent, const unsigned short* planes,
+                                                 int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[3][CBW]) {
+  const int i15 = lane & 15, kg = lane >> 4;
+  const int kiters = (K + KI - 1) / KI;
+  u32x4 wcur[3][CBW], wnxt[3][CBW];
+  const unsigned lane16 = (unsigned)lane * 16u;
+  auto fetch_w = [&](u32x4 (&w)[3][CBW], int ki) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {     // wave-uniform 64-bit base (scalar registers) + 32-bit lane offset: no per-load VGPR address pair
+        const char* base = reinterpret_cast<const char*>(w0 + p * ent + ((int64_t)(wave + c * WAVES) * kiters + ki) * 64);
+        w[p][c] = *reinterpret_cast<const u32x4*>(base + lane16);
+      }
+  };
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) wcur[p][c] = wpre[p][c];
+  auto step = [&](int ki, int kn) {
+    fetch_w(wnxt, kn);
+    u32x4 x[3][RB];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        x[p][r] = *reinterpret_cast<const u32x4*>(&planes[p * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
+    // keep the twelve weight requests of the NEXT iteration up here, ahead of this iteration's 72 MFMAs: left alone, the
+    // scheduler sinks each load to just before its first use (to save registers) and every one becomes an exposed L2 round trip
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};     // (weight piece, activation piece), small terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[PW[t]][c]), __builtin_bit_cast(bf16x8, x[PX[t]][r]),
+                                                              acc[r][c], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { asm volatile("" : "+v"(wnxt[p][c])); wcur[p][c] = wnxt[p][c]; }
+  };
+  step(0, kiters > 1 ? 1 : 0);                                   // peeled: its weights were requested before the previous epilogue
+  for (int ki = 1; ki < kiters; ++ki) step(ki, ki + 1 < kiters ? ki + 1 : ki);
+}
+
+__device__ __forceinline__ void request_first_w3(const u32x4* __restrict__ w0, int64_t ent, int K, int N, int wave, int lane, u32x4 (&w)[3][CBW]) {
+  const int kiters = (K + KI - 1) / KI, ncb_real = (N + 15) / 16;
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+      const int cb = wave + c * WAVES;
+      w[p][c] = w0[p * ent + ((int64_t)(cb < ncb_real ? cb : 0) * kiters) * 64 + lane];
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short planes[];     // [3][ROWS][LDPB] bf16 bit patterns
+  const Args& g = a.g;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i15 = lane & 15, kg = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+  const int nrows = (int)min((int64_t)ROWS, g.M - row0);
+
+  const int mslot = (wave * 64 + lane) * 8;
+  auto mask_rsrc = [&](const unsigned long long* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(p) + (p ? (int64_t)blockIdx.x * WAVES * 64 : 0), 0,
+                                             p ? WAVES * 64 * 8 : 0, kRsrcWord3);
+  };
+  // all layers' biases in the LDS left beside the planes (rows zero-padded to KI): the epilogue reads four consecutive
+  // features with one ds_read_b128 instead of holding them in registers across the k-loop
+  float* bias_lds = reinterpret_cast<float*>(planes + 3 * PLANE);
+  for (int l = 0; l < g.L; ++l) {
+    const Layer& ly = g.layer[l];
+    for (int i = threadIdx.x; i < a.boff[l + 1] - a.boff[l]; i += THREADS) bias_lds[a.boff[l] + i] = (ly.bias && i < ly.N) ? ly.bias[i] : 0.f;
+  }
+  u32x4 wpre[3][CBW];
+  request_first_w3(a.packed3 + a.off3[0], a.ent3[0], g.layer[0].K, g.layer[0].N, wave, lane, wpre);
+  u32x2 mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(g.layer[0].dact ? g.layer[0].mask_in : nullptr), mslot, 0, 0);
+
+  auto store_split = [&](int r, int k, float v) {
+    unsigned hb, mb, lb; split3(v, hb, mb, lb);
+    planes[r * LDPB + k] = (unsigned short)(hb >> 16);
+    planes[PLANE + r * LDPB + k] = (unsigned short)(mb >> 16);
+    planes[2 * PLANE + r * LDPB + k] = (unsigned short)(lb >> 16);
+  };
+  {
+    const int K0 = g.layer[0].K, K16 = (K0 + KI - 1) & ~(KI - 1);
+    if (g.mixW) {      // x = g(z) in a corner of the still empty plane storage (see mlp_fwd_k): same arithmetic order
+      float* xa = reinterpret_cast<float*>(planes); float* xb = xa + ROWS * MIX_MAX_N;
+      const int n = K0;
+      for (int idx = threadIdx.x; idx < ROWS * n; idx += THREADS) {
+        const int r = idx / n, k = idx - r * n;
+        xa[idx] = (r < nrows) ? g.X[(row0 + r) * g.ldx + k] : 0.f;
+      }
+      __syncthreads();
+      for (int l = 0; l < g.mixL; ++l) {
+        const float* wl = g.mixW + l * n * n;
+        for (int idx = threadIdx.x; idx < ROWS * n; idx += THREADS) {
+          const int r = idx / n, j = idx - r * n;
+          float s = 0.f;
+          for (int k = 0; k < n; ++k) s = fmaf(xa[r * n + k], wl[j * n + k], s);
+          if (l < g.mixL - 1) s = s > 0.f ? s : s * g.mix_slope;
+          xb[idx] = s;
+        }
+        __syncthreads();
+        float* t = xa; xa = xb; xb = t;
+      }
+      float v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { const int idx = threadIdx.x + u * THREADS; v[u] = idx < ROWS * n ? xa[idx] : 0.f; }
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < ROWS * K16; idx += THREADS) { const int r = idx / K16; store_split(r, idx - r * K16, 0.f); }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int idx = threadIdx.x + u * THREADS;
+        if (idx < ROWS * n) {
+          const int r = idx / n, k = idx - r * n;
+          store_split(r, k, v[u]);
+          if (r < nrows) g.xout[(row0 + r) * g.ldxo + k] = v[u];
+        }
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < ROWS * K16; idx += THREADS) {
+        const int r = idx / K16, k = idx - r * K16;
+        store_split(r, k, (r < nrows && k < K0) ? g.X[(row0 + r) * g.ldx + k] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int l = 0; l < g.L; ++l) {
+    const Layer& ly = g.layer[l];
+    f32x4 acc[RB][CBW];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ncb_real = (ly.N + 15) / 16;
+    int nc = (ncb_real - wave + WAVES - 1) / WAVES;
+    nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
+    const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
+    const u32x4* w0 = a.packed3 + a.off3[l];
+    switch (nc) {
+      case 4: layer_gemm_split<4>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
+      case 3: layer_gemm_split<3>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
+      case 2: layer_gemm_split<2>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
+      case 1: layer_gemm_split<1>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
+      default: break;
+    }
+    __syncthreads();                                   // every wave is done reading the planes
+
+    if (l + 1 < g.L) {                                 // next layer's first weights, sign bits and bias: older than the stores below
+      const Layer& nx = g.layer[l + 1];
+      request_first_w3(a.packed3 + a.off3[l + 1], a.ent3[l + 1], nx.K, nx.N, wave, lane, wpre);
+      mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(nx.dact ? nx.mask_in : nullptr), mslot, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // epilogue: lane = batch row r*16 + (lane & 15), features cb*16 + (lane >> 4)*4 + e
+    const int N = ly.N;
+    const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;            // incl. the next layer's k-padding (written as zeros)
+    const bool use_mask = ly.dact && ly.mask_in;
+    const bool want_bits = ly.mask_out != nullptr;
+    const bool slope01 = g.slope > 0.f && g.slope < 1.f;
+    const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (N % 4 == 0);
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(ly.out + row0 * ly.ldo, 0, (int)(((int64_t)(nrows - 1) * ly.ldo + N) * 4), kRsrcWord3);
+    unsigned lo = 0u, hi = 0u;
+#pragma unroll
+    for (int c = 0; c < CBW; ++c) {
+      const int cb = wave + c * WAVES;
+      if (cb < ncb) {                                    // wave-uniform
+        const int n0 = cb * 16 + kg * 4;
+        const bool ragged = cb * 16 + 16 > N;          // wave-uniform: only the last real block and the k-padding blocks need the column mask
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_lds[a.boff[l] + n0]);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int row = r * 16 + i15;
+          f32x4 v = acc[r][c];
+          unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int bit = (c * RB + r) * 4 + e;
+            float t = v[e];
+            if (!ly.dact) {
+              t += b4[e];
+              if (ly.leaky) t = slope01 ? fmaxf(t, t * g.slope) : (t > 0.f ? t : t * g.slope);   // 0 < slope < 1: leaky = max(t, slope t)
+            } else if (use_mask) {
+              const unsigned mk = bit < 32 ? ((unsigned)mbits >> bit) : ((unsigned)(mbits >> 32) >> (bit - 32));
+              t = (mk & 1u) ? t : t * g.slope;
+            }
+            if (ragged && n0 + e >= N) t = 0.f;
+            if (want_bits) { if (bit < 32) lo |= (t > 0.f) ? (1u << bit) : 0u; else hi |= (t > 0.f) ? (1u << (bit - 32)) : 0u; }
+            v[e] = t;
+            split3(t, hb[e], mb[e], lb[e]);
+          }
+          unsigned short* dst = planes + row * LDPB + n0;
+          *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+          *reinterpret_cast<u32x2*>(dst + PLANE) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+          *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+          if (ovec) {       // unconditional raw-buffer store, rows / features outside the tensor get an out-of-range offset
+            const unsigned off = (row < nrows && n0 < N) ? (unsigned)((row * (int)ly.ldo + n0) * 4) : kOobOffset;
+            // plain write-back stores (not nt): the next layer's weight loads queue behind these in the wave's in-order
+            // vmcnt, and an L2 write acknowledges an order of magnitude sooner than a streaming write to HBM does
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (row < nrows && n0 + e < N) ly.out[(row0 + row) * ly.ldo + n0 + e] = v[e];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(ly.mask_out), mslot, 0, 0);
+    __syncthreads();
+  }
 }
 
 }  // namespace fmlp
@@ -628,3 +930,133 @@ extern "C" int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t
   for (int j = 0; j < n_links; ++j) aux = aux || (g.layer[j].aux && !g.layer[j].mask_in);
   return launch_mlp(g, true, aux, as_stream(stream), "clica_mlp_dgrad");
 }
+
+// ---- split-bf16 entry points (see mlp_split_k) ------------------------------------------------------------------------
+static int pack3_fill(fmlp::Pack3Args& a, int& sgi, int64_t& off, const float* W, int64_t ldw, int rows, int cols, int transposed, void* base) {
+  using namespace fmlp;
+  a.seg[sgi] = PackSeg{W, ldw, rows, cols, transposed};
+  const int64_t ent = pack3_entries(rows, cols);
+  a.dst[sgi] = reinterpret_cast<u32x4*>(base) + off;
+  a.entries[sgi] = ent;
+  a.first[sgi + 1] = a.first[sgi] + ent;
+  off += 3 * ent; ++sgi;
+  return 0;
+}
+static int launch_pack3(fmlp::Pack3Args& a, clica_stream_t stream, const char* who) {
+  using namespace fmlp;
+  hipLaunchKernelGGL(mlp_pack3_k, dim3((unsigned)ceil_div(a.first[a.nseg], 256)), dim3(256), 0, as_stream(stream), a);
+  return launch_status(who);
+}
+
+extern "C" int clica_mlp_pack_split_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(N && K && bytes && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack_split_bytes: bad argument");
+  int64_t e = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_pack_split_bytes: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
+    e += 3 * (transpose ? pack3_entries(K[l], N[l]) : pack3_entries(N[l], K[l]));
+  }
+  *bytes = (size_t)e * 16;
+  return CLICA_OK;
+}
+
+extern "C" int clica_mlp_pack_split(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                    int32_t transpose, void* packed, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(W && ldw && N && K && packed && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack_split: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "clica_mlp_pack_split: packed buffer must be 16-byte aligned");
+  Pack3Args a{};
+  int sgi = 0; int64_t off = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack_split: layer %d: bad argument", l);
+    pack3_fill(a, sgi, off, W[l], ldw[l], transpose ? K[l] : N[l], transpose ? N[l] : K[l], transpose ? 1 : 0, packed);
+  }
+  a.nseg = sgi;
+  return launch_pack3(a, stream, "clica_mlp_pack_split");
+}
+
+extern "C" int clica_mlp_pack_split_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                         void* packed_fwd, void* packed_bwd, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(W && ldw && N && K && packed_fwd && packed_bwd && n_layers >= 2 && n_layers <= MAXL, "clica_mlp_pack_split_both: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_bwd) & 15) == 0,
+                  "clica_mlp_pack_split_both: packed buffers must be 16-byte aligned");
+  Pack3Args a{};
+  int sgi = 0; int64_t off = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack_split_both: layer %d: bad argument", l);
+    pack3_fill(a, sgi, off, W[l], ldw[l], N[l], K[l], 0, packed_fwd);
+  }
+  off = 0;
+  for (int l = n_layers - 1; l >= 1; --l) pack3_fill(a, sgi, off, W[l], ldw[l], K[l], N[l], 1, packed_bwd);
+  a.nseg = sgi;
+  return launch_pack3(a, stream, "clica_mlp_pack_split_both");
+}
+
+static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* who) {
+  using namespace fmlp;
+  a.boff[0] = 0;
+  for (int l = 0; l < a.g.L; ++l) a.boff[l + 1] = a.boff[l] + ((a.g.layer[l].N + KI - 1) & ~(KI - 1));
+  if (a.boff[a.g.L] > BIAS_LDS_MAX) {
+    set_error("%s: the layer widths sum to %d (> %d): the on-chip bias table does not fit beside the bf16 planes", who, a.boff[a.g.L], BIAS_LDS_MAX);
+    return CLICA_E_INVALID;
+  }
+  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float);
+  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float);
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
+  (void)once;
+  hipLaunchKernelGGL(mlp_split_k, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
+  return launch_status(who);
+}
+
+extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                                   float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
+                                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                                   const void* packed_split, uint64_t* const* signmask, float slope, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(X && bias && out && ldo && N && K && packed_split && M > 0, "clica_mlp_fwd_split: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd_split: %d layers (1..%d supported)", n_layers, MAXL);
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_split) & 15) == 0, "clica_mlp_fwd_split: packed weights must be 16-byte aligned");
+  SplitArgs a{};
+  Args& g = a.g;
+  g.X = X; g.ldx = ldx; g.M = M; g.L = n_layers; g.slope = slope;
+  g.mixW = mix_W; g.mixL = mix_layers; g.mix_slope = mix_slope; g.xout = x_out; g.ldxo = ldxo;
+  a.packed3 = reinterpret_cast<const u32x4*>(packed_split);
+  int64_t off = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(out[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_fwd_split: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
+    CLICA_CHECK_ARG(ldo[l] >= N[l], "clica_mlp_fwd_split: layer %d: leading dimension too small", l);
+    CLICA_CHECK_ARG(l == 0 || K[l] == N[l - 1], "clica_mlp_fwd_split: layer %d input width %d != previous output width %d", l, K[l], N[l - 1]);
+    unsigned long long* mo = (signmask && signmask[l]) ? reinterpret_cast<unsigned long long*>(signmask[l]) : nullptr;
+    g.layer[l] = Layer{nullptr, 0, bias[l], out[l], ldo[l], nullptr, 0, mo, nullptr, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0};
+    a.off3[l] = off; a.ent3[l] = pack3_entries(N[l], K[l]); off += 3 * a.ent3[l];
+  }
+  CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd_split: ldx < K[0]");
+  if (mix_W) CLICA_CHECK_ARG(mix_layers >= 1 && K[0] <= MIX_MAX_N && x_out && ldxo >= K[0], "clica_mlp_fwd_split: bad mixing-net arguments");
+  return launch_split(a, stream, "clica_mlp_fwd_split");
+}
+
+extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                                     const void* packed_split, const uint64_t* const* signmask,
+                                     float* const* out, const int64_t* ldo, float slope, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(dY && N && K && packed_split && out && ldo && M > 0, "clica_mlp_dgrad_split: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(n_links >= 1 && n_links <= MAXL, "clica_mlp_dgrad_split: %d links (1..%d supported)", n_links, MAXL);
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_split) & 15) == 0, "clica_mlp_dgrad_split: packed weights must be 16-byte aligned");
+  SplitArgs a{};
+  Args& g = a.g;
+  g.X = dY; g.ldx = lddy; g.M = M; g.L = n_links; g.slope = slope;
+  a.packed3 = reinterpret_cast<const u32x4*>(packed_split);
+  int64_t off = 0;
+  for (int j = 0; j < n_links; ++j) {
+    CLICA_CHECK_ARG(out[j] && N[j] >= 1 && K[j] >= 1 && N[j] <= MAXW && K[j] <= MAXW, "clica_mlp_dgrad_split: link %d is %d x %d (max %d)", j, N[j], K[j], MAXW);
+    CLICA_CHECK_ARG(ldo[j] >= N[j], "clica_mlp_dgrad_split: link %d: leading dimension too small", j);
+    CLICA_CHECK_ARG(j == 0 || K[j] == N[j - 1], "clica_mlp_dgrad_split: link %d contraction %d != previous width %d", j, K[j], N[j - 1]);
+    const unsigned long long* mi = (signmask && signmask[j]) ? reinterpret_cast<const unsigned long long*>(signmask[j]) : nullptr;
+    g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], nullptr, 0, nullptr, mi, N[j], K[j], 0, 1};
+    a.off3[j] = off; a.ent3[j] = pack3_entries(N[j], K[j]); off += 3 * a.ent3[j];
+  }
+  CLICA_CHECK_ARG(lddy >= K[0], "clica_mlp_dgrad_split: lddy < K[0]");
+  return launch_split(a, stream, "clica_mlp_dgrad_split");
+}
+

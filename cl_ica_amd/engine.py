@@ -54,7 +54,8 @@ class ContrastiveTrainer:
                  p: float = 2, tau: float = 1.0, alpha: float = 0.5, lr: float = 1e-4, g_slope: float = 0.2,
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
-                 force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True):
+                 force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True,
+                 split_bf16: Optional[bool] = None):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -90,6 +91,10 @@ class ContrastiveTrainer:
         self.packed_t = None
         self._packed_current = False
         self.fused_backward = self.fused_forward and os.environ.get("CLICA_FUSED_BWD", "1") != "0" and len(self.linears) > 1
+        # opt-in: the two whole-stack kernels on the bf16 matrix cores with exact 3-way bf16 operand splits (fp32-grade)
+        want_split = (os.environ.get("CLICA_SPLIT_BF16", "0") == "1") if split_bf16 is None else bool(split_bf16)
+        self.split_bf16 = self.fused_backward and want_split and all(lin.bias is not None for lin in self.linears) and \
+            sum((lin.out_features + 31) // 32 * 32 for lin in self.linears) <= 3456      # on-chip bias table (fused_mlp.hip)
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -216,7 +221,9 @@ class ContrastiveTrainer:
         """Fragment-order copies of the CURRENT weights for the fused forward / backward-chain kernels (one launch
         for both layouts when both are used).  Valid until the next optimizer step."""
         ws = [lin.weight for lin in self.linears]
-        if self.fused_backward and self.pack_weights:
+        if self.split_bf16:
+            self.packed, self.packed_t = ops.mlp_pack_split_both(ws, self.packed, self.packed_t)
+        elif self.fused_backward and self.pack_weights:
             self.packed, self.packed_t = ops.mlp_pack_both(ws, self.packed, self.packed_t)
         elif self.fused_forward and self.pack_weights:
             self.packed = ops.mlp_pack_weights(ws, self.packed)
@@ -236,8 +243,12 @@ class ContrastiveTrainer:
             mix = None
             if self._x_pending:          # latents in, x = g(z) computed in the kernel prologue and stored to self.x
                 cur, mix, self._x_pending = self.z, (self.gW, self.g_slope, self.x), False
-            ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
-                        signmasks=self.signmasks, mix=mix)
+            if self.split_bf16:
+                ops.mlp_fwd_split(cur, ws, [lin.bias for lin in self.linears], self.acts, self.packed, self.slope,
+                                  signmasks=self.signmasks, mix=mix)
+            else:
+                ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
+                            signmasks=self.signmasks, mix=mix)
             cur = self.acts[-1]
         else:
             for l, lin in enumerate(self.linears):
@@ -311,8 +322,12 @@ class ContrastiveTrainer:
             ws = [self.linears[l].weight for l in chain]
             if not self._packed_current:
                 self.pack()
-            ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
-                                masks_chain=[self.signmasks[l - 1] for l in chain])
+            if self.split_bf16:
+                ops.mlp_dgrad_chain_split(g, ws, self.packed_t, [self.dz[l - 1] for l in chain], self.slope,
+                                          masks_chain=[self.signmasks[l - 1] for l in chain])
+            else:
+                ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
+                                    masks_chain=[self.signmasks[l - 1] for l in chain])
             if self.grouped_wgrad:
                 # (2) every layer's dW/db in two launches: one grouped split-K GEMM of equal-length work items
                 #     + one grouped slab reduction; under DP a single all-reduce of the flat gradient arena follows

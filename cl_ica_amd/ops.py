@@ -149,6 +149,62 @@ def mlp_pack_both(weights, packed: Optional[torch.Tensor] = None, packed_t: Opti
     return packed, packed_t
 
 
+# ---- opt-in split-bf16 arithmetic (clica_mlp_*_split): fp32-grade results on the bf16 matrix cores -------------------
+def mlp_pack_split_both(weights, packed: Optional[torch.Tensor] = None, packed_t: Optional[torch.Tensor] = None):
+    """bf16x3 fragment-order copies for `mlp_fwd_split` (layers 0..L-1) and `mlp_dgrad_chain_split` (layers L-1..1,
+    transposed) in one launch."""
+    L = len(weights)
+    ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
+    I32 = C.c_int32 * L
+    Ns, Ks = I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws])
+    dev = ws[0][0].device
+    nb = C.c_size_t()
+    if packed is None:
+        check(load().clica_mlp_pack_split_bytes(L, Ns, Ks, 0, C.byref(nb)), "clica_mlp_pack_split_bytes")
+        packed = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
+    if packed_t is None:
+        chain = list(range(L - 1, 0, -1))
+        I32c = C.c_int32 * (L - 1)
+        check(load().clica_mlp_pack_split_bytes(L - 1, I32c(*[ws[l][0].shape[0] for l in chain]), I32c(*[ws[l][0].shape[1] for l in chain]), 1,
+                                                C.byref(nb)), "clica_mlp_pack_split_bytes")
+        packed_t = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
+    check(load().clica_mlp_pack_split_both(L, (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws]),
+                                           Ns, Ks, packed.data_ptr(), packed_t.data_ptr(), stream_ptr()), "clica_mlp_pack_split_both")
+    return packed, packed_t
+
+
+def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Tensor, slope: float = 0.01, signmasks=None, mix=None):
+    """`mlp_fwd` on the bf16 matrix cores with exact 3-way bf16 splits (clica_mlp_fwd_split); `weights` only give the shapes."""
+    (x, ldx) = _mat("x", x)
+    L = len(weights)
+    bs = [None if b is None else b.detach().contiguous() for b in biases]
+    VP, I64, I32 = C.c_void_p * L, C.c_int64 * L, C.c_int32 * L
+    gW, gslope, xout = mix if mix is not None else (None, 0.0, None)
+    if gW is not None:
+        gW = gW.detach().contiguous()
+    check(load().clica_mlp_fwd_split(x.data_ptr(), ldx, x.shape[0], ptr(gW), 0 if gW is None else gW.shape[0], float(gslope),
+                                     ptr(xout), 0 if xout is None else xout.stride(0), L,
+                                     VP(*[None if b is None else b.data_ptr() for b in bs]),
+                                     VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+                                     I32(*[w.shape[0] for w in weights]), I32(*[w.shape[1] for w in weights]),
+                                     packed_split.data_ptr(), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
+                                     float(slope), stream_ptr()), "clica_mlp_fwd_split")
+    return outs[-1]
+
+
+def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch.Tensor, outs, slope: float = 0.01, masks_chain=None):
+    """`mlp_dgrad_chain` on the bf16 matrix cores (clica_mlp_dgrad_split); sign bits from `mlp_fwd_split`."""
+    (dy, lddy) = _mat("dy", dy)
+    n = len(weights_chain)
+    I32, I64, VP = C.c_int32 * n, C.c_int64 * n, C.c_void_p * n
+    check(load().clica_mlp_dgrad_split(dy.data_ptr(), lddy, dy.shape[0], n,
+                                       I32(*[w.shape[1] for w in weights_chain]), I32(*[w.shape[0] for w in weights_chain]),
+                                       packed_split_t.data_ptr(), None if masks_chain is None else VP(*[ptr(m) for m in masks_chain]),
+                                       VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+                                       float(slope), stream_ptr()), "clica_mlp_dgrad_split")
+    return outs
+
+
 def mlp_signmask_alloc(M: int, n_layers: int, device) -> list:
     """Per-layer opaque sign-bit buffers for mlp_fwd(signmasks=...) / mlp_dgrad_chain(masks_chain=...)."""
     nbytes = C.c_size_t()

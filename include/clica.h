@@ -217,6 +217,27 @@ int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
                     const int32_t* N, const int32_t* K, const float* packed,
                     const float* const* act, const int64_t* ldact, const uint64_t* const* signmask,
                     float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
+/* ---- opt-in split-bf16 arithmetic for the two whole-stack kernels (same results to fp32 rounding level) ----------
+ * Both fp32 operands of every Linear are split exactly into three bf16 pieces and the six piece products of order
+ * <= 2 are accumulated in fp32 on the bf16 matrix cores (csrc/fused_mlp.hip, mlp_split_k): measured max error vs fp64
+ * 8.6e-7 of max|y| on a 500 x 500 layer (fp32-MFMA path: 1.0e-6), 0.375 of the matrix-core time.
+ * packed_split buffers come from clica_mlp_pack_split[_both] (clica_mlp_pack_split_bytes bytes; 6 B per weight).  The
+ * sign-bit buffers have the same size as the fp32 kernels' but a different bit order: use the pair fwd_split /
+ * dgrad_split together.  Saved activations / dZ are written as fp32, as by clica_mlp_fwd / clica_mlp_dgrad.
+ * mix_W may be NULL (then X is the stack's input and x_out is ignored). */
+int clica_mlp_pack_split_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
+int clica_mlp_pack_split(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                         int32_t transpose, void* packed, clica_stream_t stream);
+int clica_mlp_pack_split_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                              void* packed_fwd, void* packed_bwd, clica_stream_t stream);
+int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                        float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
+                        float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                        const void* packed_split, uint64_t* const* signmask, float slope, clica_stream_t stream);
+int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                          const void* packed_split, const uint64_t* const* signmask,
+                          float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
+
 /* Weight/bias gradients of ALL layers in two launches (one grouped split-K GEMM over equal-length work items
  * + one grouped deterministic slab reduction):  dW[l] = dZ[l]^T X[l]  ([N_l, K_l]),  db[l] = column sums of dZ[l]
  * (db[l] may be NULL).  dZ[l] = [M, N_l] gradient at layer l's pre-activation, X[l] = [M, K_l] its input. */

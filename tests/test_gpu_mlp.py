@@ -288,3 +288,38 @@ def test_fused_forward_with_mixing_prologue_is_bit_identical(n, M):
     assert torch.equal(x_out, x_ref)
     for a, b in zip(outs_a, outs_b):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
+                                      ([16, 16, 16], 47)])
+def test_split_bf16_stack_matches_fp64(dims, M):
+    """Opt-in bf16x3-split kernels (clica_mlp_fwd_split / clica_mlp_dgrad_split): forward and backward chain against
+    fp64 at the SAME tolerance as the fp32-MFMA kernels (1e-5 of the largest element)."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(len(dims) * 17 + M)
+    L = len(dims) - 1
+    Ws = [dev((rng.uniform(-1, 1, size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(L)]
+    bs = [dev(rng.uniform(-0.5, 0.5, size=dims[i + 1]).astype(np.float32)) for i in range(L)]
+    x = dev(rng.normal(size=(M, dims[0])).astype(np.float32))
+    outs = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    masks = ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None]
+    packed, packed_t = ops.mlp_pack_split_both(Ws)
+    ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks)
+    a = x.cpu().numpy().astype(np.float64)
+    acts64 = []
+    for l in range(L):
+        a = a @ Ws[l].cpu().numpy().astype(np.float64).T + bs[l].cpu().numpy().astype(np.float64)
+        if l < L - 1:
+            a = np.where(a > 0, a, 0.01 * a)
+        acts64.append(a)
+        assert rel_err(outs[l].cpu().numpy(), a) < 1e-5, ("fwd", l)
+    dy = dev(rng.normal(size=(M, dims[-1])).astype(np.float32))
+    chain = list(range(L - 1, 0, -1))
+    dz = [torch.empty(M, dims[l], device="cuda") for l in chain]
+    ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain])
+    g64 = dy.cpu().numpy().astype(np.float64)
+    for j, l in enumerate(chain):
+        # the derivative mask is taken from the kernel's OWN forward activations (sign decisions at |pre-activation| ~ 1e-7 may
+        # legitimately differ from fp64's)
+        g64 = (g64 @ Ws[l].cpu().numpy().astype(np.float64)) * np.where(outs[l - 1].cpu().numpy() > 0, 1.0, 0.01)
+        assert rel_err(dz[j].cpu().numpy(), g64) < 1e-5, ("dgrad", l)

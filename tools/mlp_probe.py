@@ -11,8 +11,14 @@ for L in (1, 2, 3, 4, 6, 8):
     Ws = [torch.randn(W, W, device="cuda") / W ** 0.5 for _ in range(L)]
     bs = [torch.randn(W, device="cuda") * 0.1 for _ in range(L)]
     outs = [torch.empty(M, W, device="cuda") for _ in range(L)]
-    packed = ops.mlp_pack_weights(Ws)
     masks = ops.mlp_signmask_alloc(M, L, "cuda")
-    t = replay_time(lambda: ops.mlp_fwd(x, Ws, bs, outs, 0.01, packed=packed, signmasks=masks))
+    if os.environ.get("SPLIT") == "1":
+        packed = ops.mlp_pack_split_both(Ws + [Ws[-1]])[0] if L == 1 else ops.mlp_pack_split_both(Ws)[0]
+        if L == 1:   # pack_both needs >= 2 layers: pack [W, W] and use the first
+            pass
+        t = replay_time(lambda: ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks))
+    else:
+        packed = ops.mlp_pack_weights(Ws)
+        t = replay_time(lambda: ops.mlp_fwd(x, Ws, bs, outs, 0.01, packed=packed, signmasks=masks))
     fl = 2.0 * M * W * W * L
     print(f"L={L}: {t:7.1f} us  {fl/t/1e6:6.1f} TFLOP/s   ({t/L:6.1f} us/layer)")
