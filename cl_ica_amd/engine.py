@@ -71,6 +71,7 @@ class ContrastiveTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if self.world > 1 else 0
         # run the collectives even at world size 1 (test hook: exercises the DP code path on one GPU)
+        self.force_collectives = bool(force_collectives)
         self.dp = self.world > 1 or (force_collectives and dist.is_initialized())
         if self.p == 0:
             raise NotImplementedError("p=0 (SimCLRLoss) runs through cl_ica_amd.losses.SimCLRLoss, not the fused engine")
@@ -457,7 +458,10 @@ class ContrastiveTrainer:
         for dst, src in zip((self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev), snap):
             dst.copy_(src)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # with collectives in the step, other threads (the process group's watchdog) may legitimately touch the HIP runtime
+        # during capture: "thread_local" keeps their calls from invalidating it
+        mode = "thread_local" if (self.dp or self.force_collectives) else "global"
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             self._step_body(True)
         self.graph = graph
         return graph
