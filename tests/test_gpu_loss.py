@@ -129,7 +129,8 @@ def test_analytic_kats():
 
 
 @pytest.mark.parametrize("B,B3,n,p", [(6144, 6144, 10, 2), (6144, 6144, 10, 1), (1000, 3001, 7, 3), (6144, 12288, 40, 1),
-                                       (300, 5000, 33, 2), (257, 63, 1, 2), (2048, 2048, 64, 1.5)])
+                                       (300, 5000, 33, 2), (257, 63, 1, 2), (2048, 2048, 64, 1.5), (1, 1, 3, 2), (1, 777, 5, 1),
+                                       (5, 2, 2, 3)])
 def test_full_size_vs_oracle(B, B3, n, p):
     """BASELINE sizes and ragged shapes vs the fp64 oracle; all four upstream gradients exercised."""
     from cl_ica_amd.losses import LpSimCLRLoss
