@@ -13,6 +13,9 @@ src = f"gpurun_out/profile_{tag}"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
+if os.path.exists(f"{src}/trace_split/t_kernel_stats.csv"):       # opt-in split-bf16 mode (kernel trace only)
+    shutil.copy(f"{src}/trace_split/t_kernel_stats.csv", f"profiles/{tag}_split_bf16_kernel_stats.csv")
+    shutil.copy(f"{src}/bench_split_under_rocprof.json", f"profiles/{tag}_split_bf16_bench_under_rocprof.json")
 
 
 def agg(path):
@@ -30,7 +33,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
             pm.setdefault(k, {}).update(v)
 stats = list(csv.DictReader(open(f"{src}/trace/t_kernel_stats.csv")))
 bench = json.load(open(f"{src}/bench_under_rocprof.json"))
-lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline`", "",
+lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-split-probe`", "",
          f"bench line under the profiler: {bench['value']:.1f} steps/s, {bench['ms_per_step']:.3f} ms/step; roofline entry: "
          f"`{bench['roofline']['kernel']}` {bench['roofline']['achieved']} TFLOP/s ({bench['roofline']['frac']:.3f} of 157.3), "
          f"avg {bench['roofline']['avg_launch_us']} us/launch (graph replay between HIP events).", "",
