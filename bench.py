@@ -246,15 +246,26 @@ def loss_leg(tr, reps=20):
     z3 = y1 if tr.world == 1 else tr.z_all
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf = tb = 0.0
+    train = getattr(tr, "loss_train", False)
+    pool_lse = o[2 * B:3 * B] if tr.world == 1 else tr.lse_all
     for _ in range(reps):
         ev[0].record()
-        lib.clica_lp_loss_fwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
-                              o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), None, 0,
-                              tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        if train:      # the fused training pair of entry points the engine calls (coefficient step inside finalize, means inside the reduce)
+            lib.clica_lp_loss_fwd_train(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
+                                        o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n,
+                                        tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        else:
+            lib.clica_lp_loss_fwd(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
+                                  o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), None, 0,
+                                  tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         ev[1].record()
-        lib.clica_lp_loss_bwd_sym(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
-                                  (o[2 * B:3 * B] if tr.world == 1 else tr.lse_all).data_ptr(), None, None, None,
-                                  tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        if train:
+            lib.clica_lp_loss_bwd_sym_train(C.byref(tr.desc), y1.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(), pool_lse.data_ptr(),
+                                            tr.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(), tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+        else:
+            lib.clica_lp_loss_bwd_sym(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                                      pool_lse.data_ptr(), None, None, None,
+                                      tr.dy[:B].data_ptr(), n, tr.dy[B:].data_ptr(), n, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         ev[2].record()
         torch.cuda.synchronize()
         tf += ev[0].elapsed_time(ev[1]) * 1e-3; tb += ev[1].elapsed_time(ev[2]) * 1e-3

@@ -48,6 +48,11 @@ SIGNATURES: Dict[str, list] = {
     "clica_lp_loss_bwd": [C.POINTER(LpLossDesc)] + _LOSS_BWD,
     "clica_lp_loss_bwd_sym": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                               c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],
+    "clica_lp_loss_train_workspace_bytes": [C.POINTER(LpLossDesc), C.POINTER(c_size)],
+    "clica_lp_loss_fwd_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p,
+                                c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],
+    "clica_lp_loss_bwd_sym_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p,
+                                    C.c_void_p, c_size, C.c_void_p],
     "clica_dot_loss_workspace_bytes": [C.POINTER(DotLossDesc), C.POINTER(c_size), C.POINTER(c_size)],
     "clica_dot_loss_fwd": [C.POINTER(DotLossDesc)] + _LOSS_FWD,
     "clica_dot_loss_bwd": [C.POINTER(DotLossDesc)] + _LOSS_BWD,

@@ -61,13 +61,68 @@ __global__ __launch_bounds__(64) void means_k(const float* __restrict__ blocksum
   if (threadIdx.x == 0) { means[0] = v[0] * inv_count; means[1] = v[1] * inv_count; means[2] = v[2] * inv_count; }
 }
 
+// one row of the coefficient step (shared by bwd_coef_k and the training forward's finalize)
+__device__ __forceinline__ void coef_row(
+    const int64_t i, const int64_t rows, const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
+    const Params& q, float tau, float alpha, int compat, int frac, int dot, const float L,
+    const float* __restrict__ g_mean, const float* __restrict__ g_item,
+    const float* __restrict__ g_pos, const float* __restrict__ g_neg,
+    float* __restrict__ statL, float* __restrict__ statC,
+    float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2) {
+  const float inv_rows = 1.f / (float)rows;
+  const float gi = (g_mean ? g_mean[0] : 1.f) * inv_rows + (g_item ? g_item[i] : 0.f);
+  const float A = 2.f * alpha * gi + (g_pos ? g_pos[0] * inv_rows : 0.f);
+  const float C = 2.f * (1.f - alpha) * gi + (g_neg ? g_neg[0] * inv_rows : 0.f);
+  statL[i] = L * kLog2e;
+  statC[i] = q.xs * C / tau;
+  if (!dz1 && !dz2) return;
+  const float* a = z1 + i * ld1;
+  const float* b = z2 + i * ld2;
+  if (dot) {
+    float pos = 0.f;
+    for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
+    const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L * kLog2e);
+    for (int k = 0; k < q.n; ++k) {
+      if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
+      if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
+    }
+    return;
+  }
+  const float sp_ = pos_sum(a, b, q.n, q, frac != 0);
+  const float pos = q.pow ? sp_ : root_of<true>(sp_, q);
+  float cpos = A / tau;
+  if (compat) cpos -= (C / tau) * fexp2(-pos * q.kscale - L * kLog2e);
+  cpos *= q.pow ? q.p : droot_of<true>(sp_, q);  // includes the factor p
+  for (int k = 0; k < q.n; ++k) {
+    const float d = a[k] - b[k];
+    float dt;
+    if (frac) {
+      const float v = fexp2((q.p - 1.f) * flog2(fabsf(d) + 1e-12f));
+      dt = d > 0.f ? v : (d < 0.f ? -v : 0.f);
+    } else if (q.p == 2.f) dt = d;
+    else if (q.p == 1.f) dt = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
+    else if (q.p == 3.f) dt = d * fabsf(d);
+    else {
+      const float ad = fabsf(d);
+      const float v = ad > 0.f ? fexp2((q.p - 1.f) * flog2(ad)) : 0.f;
+      dt = d < 0.f ? -v : v;
+    }
+    const float g = cpos * dt;
+    if (dz1) dz1[i * ldd1 + k] = g;
+    if (dz2) dz2[i * ldd2 + k] = -g;
+  }
+}
+
 constexpr int FIN_ROWS = 64;   // rows per finalize block; the 4 waves split the per-split partials
+// training forward: the finalize thread of a row also does that row's coefficient step (statistics for the pair
+// sweep + the positive-pair gradient, upstream gradient = d(mean loss) = 1), saving the bwd_coef_k launch
+struct TrainOut { float* statL; float* statC; float* dz1; int64_t ldd1; float* dz2; int64_t ldd2; };
 
 __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float2* __restrict__ part, int nsplit, int64_t rows,
     const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
     Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
-    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M) {
+    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T) {
   __shared__ float sm[THREADS / FIN_ROWS][FIN_ROWS], ss[THREADS / FIN_ROWS][FIN_ROWS];
   const int lane_row = threadIdx.x & (FIN_ROWS - 1), grp = threadIdx.x / FIN_ROWS;
   const int64_t i = (int64_t)blockIdx.x * FIN_ROWS + lane_row;
@@ -123,6 +178,9 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float lp = pos / tau;
     const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
     loss_i[i] = li; pos_i[i] = lp; lse_i[i] = lse_raw;
+    if (T.statL)
+      coef_row(i, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, lse_raw, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
+               T.dz1, T.ldd1, T.dz2, T.ldd2);
     v_loss = li; v_pos = lp; v_lse = lse;
   }
   reduce_means(v_loss, v_pos, v_lse, M);
@@ -140,57 +198,31 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
     float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2) {
   const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
   if (i >= rows) return;
-  const float inv_rows = 1.f / (float)rows;
-  const float gi = (g_mean ? g_mean[0] : 1.f) * inv_rows + (g_item ? g_item[i] : 0.f);
-  const float A = 2.f * alpha * gi + (g_pos ? g_pos[0] * inv_rows : 0.f);
-  const float C = 2.f * (1.f - alpha) * gi + (g_neg ? g_neg[0] * inv_rows : 0.f);
-  const float L = lse_i[i];
-  statL[i] = L * kLog2e;
-  statC[i] = q.xs * C / tau;
-  if (!dz1 && !dz2) return;
-  const float* a = z1 + i * ld1;
-  const float* b = z2 + i * ld2;
-  if (dot) {
-    float pos = 0.f;
-    for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
-    const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L * kLog2e);
-    for (int k = 0; k < q.n; ++k) {
-      if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
-      if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
-    }
-    return;
-  }
-  const float sp_ = pos_sum(a, b, q.n, q, frac != 0);
-  const float pos = q.pow ? sp_ : root_of<true>(sp_, q);
-  float cpos = A / tau;
-  if (compat) cpos -= (C / tau) * fexp2(-pos * q.kscale - L * kLog2e);
-  cpos *= q.pow ? q.p : droot_of<true>(sp_, q);  // includes the factor p
-  for (int k = 0; k < q.n; ++k) {
-    const float d = a[k] - b[k];
-    float dt;
-    if (frac) {
-      const float v = fexp2((q.p - 1.f) * flog2(fabsf(d) + 1e-12f));
-      dt = d > 0.f ? v : (d < 0.f ? -v : 0.f);
-    } else if (q.p == 2.f) dt = d;
-    else if (q.p == 1.f) dt = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
-    else if (q.p == 3.f) dt = d * fabsf(d);
-    else {
-      const float ad = fabsf(d);
-      const float v = ad > 0.f ? fexp2((q.p - 1.f) * flog2(ad)) : 0.f;
-      dt = d < 0.f ? -v : v;
-    }
-    const float g = cpos * dt;
-    if (dz1) dz1[i * ldd1 + k] = g;
-    if (dz2) dz2[i * ldd2 + k] = -g;
-  }
+  coef_row(i, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, lse_i[i], g_mean, g_item, g_pos, g_neg, statL, statC,
+           dz1, ldd1, dz2, ldd2);
 }
 
 // out[i,k] (+)= sum_split part[split][i][k]; FOUR threads per float4 of the padded row (each sums every fourth
 // split with its loads in flight together, then a fixed-order shuffle tree): 4x the parallelism of a
 // launch that is otherwise a few dozen latency-bound workgroups
+struct MeansJob { const float* blocksums; int nblocks; float inv_count; float* means; int block; };   // block < 0: none
 __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
                                                        int np, int n, float* __restrict__ out, int64_t ldo,
-                                                       int accumulate) {
+                                                       int accumulate, MeansJob mj) {
+  if ((int)blockIdx.x == mj.block) {        // training step: the forward's three means, off its critical path (see means_k)
+    if (threadIdx.x < 64) {
+      float v[3] = {0.f, 0.f, 0.f};
+      for (int b = threadIdx.x; b < mj.nblocks; b += 64) {
+        v[0] += mj.blocksums[b * 3 + 0]; v[1] += mj.blocksums[b * 3 + 1]; v[2] += mj.blocksums[b * 3 + 2];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
+      if (threadIdx.x == 0) { mj.means[0] = v[0] * mj.inv_count; mj.means[1] = v[1] * mj.inv_count; mj.means[2] = v[2] * mj.inv_count; }
+    }
+    return;
+  }
   const int64_t tid = (int64_t)blockIdx.x * THREADS + threadIdx.x;
   const int64_t idx = tid >> 2;
   const int sub = (int)(tid & 3);
@@ -402,7 +434,7 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M);
+                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{});
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)rows, means);
   if (rowgrad)
     hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(rows * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
@@ -449,14 +481,14 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
     launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
     const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc);
+                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1});
   }
   if (d_cols) {
     Params qc = q; qc.sgn = -q.sgn;   // e = -(owner - stream) + eps seen from the column side
     launch_bwd_pairs(false, PC, pk, cols_p, ldc, cols, rows_p, ldr, rows, qc, w.statL, w.statC, w.partC, st);
     const int acc = frac ? 1 : (accumulate_dz3 ? 1 : 0);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc);
+                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1});
   }
   return launch_status("clica_lp_loss_bwd");
 }
@@ -492,8 +524,89 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
   }
   launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, w.partR, st);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
-                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1);
+                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1});
   return launch_status("clica_lp_loss_bwd_sym");
+}
+
+// ---- training-step pair of entry points: forward with the coefficient step folded into its finalize, symmetric backward
+// with the forward's means folded into its reduction (three launches fewer than fwd + bwd_sym) -------------------------
+struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes; };
+static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols) {
+  TrainWs w; char* p = (char*)ws; size_t off = 256;
+  w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
+  w.statL = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
+  w.statC = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
+  w.strL = (float*)(p + off); off += align_up((size_t)cols * sizeof(float), 256);
+  w.strC = (float*)(p + off); off += align_up((size_t)cols * sizeof(float), 256);
+  w.scratch = p + off;      // forward: per-split (max, sum) partials; backward: per-split gradient partials (the forward's are dead by then)
+  const size_t f = align_up((size_t)PF.nsplit * rows * sizeof(float2), 256);
+  const size_t b = align_up((size_t)PR.nsplit * rows * PR.np * sizeof(float), 256);
+  w.scratch_bytes = f > b ? f : b;
+  w.bytes = off + w.scratch_bytes; return w;
+}
+
+extern "C" int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes) {
+  int rc = validate(d, "clica_lp_loss_train_workspace_bytes");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(bytes != nullptr, "clica_lp_loss_train_workspace_bytes: bytes is NULL");
+  *bytes = carve_train(nullptr, make_plan(d->B, d->B3, d->n, false), make_plan(d->B, d->B3, d->n, true), d->B, d->B3).bytes;
+  return CLICA_OK;
+}
+
+extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
+                                       const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
+                                       float* loss_i, float* pos_i, float* lse_i,
+                                       float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                                       void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_fwd_train");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && z2 && pool && loss_i && pos_i && lse_i && dz1 && dz2 && workspace, "clica_lp_loss_fwd_train: NULL pointer");
+  CLICA_CHECK_ARG(d->p >= 1.f, "clica_lp_loss_fwd_train: the p<1 branch is not symmetric (eps inside the abs, losses.py:436)");
+  CLICA_CHECK_ARG(ld1 >= d->n && ld2 >= d->n && ldp >= d->n && ldd1 >= d->n && ldd2 >= d->n, "clica_lp_loss_fwd_train: leading dimension < n");
+  const int64_t rows = d->B, cols = d->B3;
+  Plan PF = make_plan(rows, cols, d->n, false), PR = make_plan(rows, cols, d->n, true);
+  TrainWs w = carve_train(workspace, PF, PR, rows, cols);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd_train: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  Params q = make_params(d, false);
+  hipStream_t st = as_stream(stream);
+  float2* part = reinterpret_cast<float2*>(w.scratch);
+  launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
+  Means M{w.blocksums};
+  const int nfin = (int)ceil_div(rows, FIN_ROWS);
+  hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
+                     (const float2*)part, PF.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
+                     d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2});
+  return launch_status("clica_lp_loss_fwd_train");
+}
+
+extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
+                                           const float* z1, int64_t ld1, const float* pool, int64_t ldp,
+                                           const float* lse_i, const float* pool_lse,
+                                           float* dz1, int64_t ldd1, float* means,
+                                           void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_bwd_sym_train");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(z1 && pool && lse_i && pool_lse && dz1 && means && workspace, "clica_lp_loss_bwd_sym_train: NULL pointer");
+  CLICA_CHECK_ARG(d->p >= 1.f && d->B3 >= d->B, "clica_lp_loss_bwd_sym_train: needs p >= 1 and a pool that contains the local rows");
+  const int64_t rows = d->B, cols = d->B3;
+  Plan PF = make_plan(rows, cols, d->n, false), PR = make_plan(rows, cols, d->n, true);
+  TrainWs w = carve_train(workspace, PF, PR, rows, cols);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_bwd_sym_train: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  Params q = make_params(d, false);
+  hipStream_t st = as_stream(stream);
+  const float* strL = w.statL; const float* strC = w.statC;
+  if (!(pool_lse == lse_i && cols == rows)) {        // several ranks: statistics of the whole pool from the gathered lse
+    hipLaunchKernelGGL(pool_stats_k, dim3((unsigned)ceil_div(cols, THREADS)), dim3(THREADS), 0, st,
+                       cols, pool_lse, rows, d->tau, d->alpha, (const float*)nullptr, (const float*)nullptr, q.xs, w.strL, w.strC);
+    strL = w.strL; strC = w.strC;
+  }
+  float* partR = reinterpret_cast<float*>(w.scratch);
+  launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
+  const int blocks = (int)ceil_div(rows * PR.np, THREADS);
+  hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,
+                     (const float*)partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1,
+                     MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks});
+  return launch_status("clica_lp_loss_bwd_sym_train");
 }
 
 // =====================================================================================
@@ -604,7 +717,7 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
   const int nfin = (int)ceil_div(d->B, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M);
+                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{});
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
   if (rowgrad)   // gradient w.r.t. the (normalised, if requested) rows
     hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(d->B * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
@@ -648,12 +761,12 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
   } else if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1);
+                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1});
   }
   if (o3) {
     launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3);
+                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3, MeansJob{nullptr, 0, 0.f, nullptr, -1});
   }
   if (d->normalize) {
     if (dz1) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u1, (const float*)dw.du1, (int64_t)n, (const float*)dw.i1, B, n, dz1, ldd1, 0);

@@ -161,7 +161,11 @@ class ContrastiveTrainer:
         self.desc = _lib.LpLossDesc(B=B, B3=Bg, n=n, p=self.p, tau=self.tau, alpha=self.alpha, compat=1, pow=1)
         fb, bb = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(self.desc), C.byref(fb), C.byref(bb)), "workspace")
-        self.loss_ws = torch.zeros(max(fb.value, bb.value), dtype=torch.uint8, device=dev)
+        tb = C.c_size_t()
+        self.loss_train = self.p >= 1 and os.environ.get("CLICA_LOSS_TRAIN", "1") != "0"     # fused training pair of loss entry points
+        if self.loss_train:
+            _lib.check(_lib.load().clica_lp_loss_train_workspace_bytes(C.byref(self.desc), C.byref(tb)), "train workspace")
+        self.loss_ws = torch.zeros(max(fb.value, bb.value, tb.value), dtype=torch.uint8, device=dev)
         nb = C.c_size_t(); need = 0
         for lin in self.linears:
             _lib.check(_lib.load().clica_linear_wgrad_workspace_bytes(R, lin.out_features, lin.in_features, C.byref(nb)), "wgrad ws")
@@ -280,6 +284,20 @@ class ContrastiveTrainer:
             pool = self.z_all
         else:
             pool = y1
+        if self.loss_train:
+            # forward + coefficient step (finalize), then -- after the all-gather of the row statistics under DP -- pair sweep +
+            # reduction (+ the forward's means): 5 launches instead of 8
+            _lib.check(lib.clica_lp_loss_fwd_train(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, pool.data_ptr(), n,
+                                                   o[:B].data_ptr(), o[B:2 * B].data_ptr(), lse.data_ptr(),
+                                                   self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n,
+                                                   self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd_train")
+            if self.dp:
+                dist.all_gather_into_tensor(self.lse_all, lse, group=self.pg)
+            pool_lse = self.lse_all if self.dp else lse
+            _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(self.desc), y1.data_ptr(), n, pool.data_ptr(), n,
+                                                       lse.data_ptr(), pool_lse.data_ptr(), self.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(),
+                                                       self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd_sym_train")
+            return
         _lib.check(lib.clica_lp_loss_fwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, pool.data_ptr(), n,
                                          o[:B].data_ptr(), o[B:2 * B].data_ptr(), lse.data_ptr(), o[3 * B:].data_ptr(),
                                          None, 0, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")

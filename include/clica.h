@@ -112,6 +112,22 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
                           const float* g_mean, const float* g_pos, const float* g_neg,
                           float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
                           void* workspace, size_t workspace_bytes, clica_stream_t stream);
+/* Training-step pair (what the fused engine calls): the same mathematics as clica_lp_loss_fwd + clica_lp_loss_bwd_sym
+ * with the default upstream gradient d(mean loss) = 1, three launches fewer.  fwd_train also writes the positive-pair
+ * part of dz1 / dz2 and keeps the row statistics in the workspace; bwd_sym_train ADDS the pair-sweep gradient to dz1
+ * and delivers means[3] = (loss, pos, neg) of the forward.  Both calls share ONE workspace of
+ * clica_lp_loss_train_workspace_bytes, untouched in between (only the all-gather of lse_i belongs there). */
+int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);
+int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
+                            const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
+                            float* loss_i, float* pos_i, float* lse_i,
+                            float* dz1, int64_t ldd1, float* dz2, int64_t ldd2,
+                            void* workspace, size_t workspace_bytes, clica_stream_t stream);
+int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
+                                const float* z1, int64_t ld1, const float* pool, int64_t ldp,
+                                const float* lse_i, const float* pool_lse,
+                                float* dz1, int64_t ldd1, float* means,
+                                void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Dot-product InfoNCE  --  SimCLRLoss.loss, /root/reference/losses.py:177-202
