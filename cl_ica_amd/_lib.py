@@ -51,7 +51,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_lp_loss_train_workspace_bytes": [C.POINTER(LpLossDesc), C.POINTER(c_size)],
     "clica_lp_loss_fwd_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p,
                                 c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],
-    "clica_lp_loss_bwd_sym_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p,
+    "clica_lp_loss_bwd_sym_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, C.c_void_p,
                                     C.c_void_p, c_size, C.c_void_p],
     "clica_dot_loss_workspace_bytes": [C.POINTER(DotLossDesc), C.POINTER(c_size), C.POINTER(c_size)],
     "clica_dot_loss_fwd": [C.POINTER(DotLossDesc)] + _LOSS_FWD,
@@ -92,6 +92,8 @@ SIGNATURES: Dict[str, list] = {
     "clica_softclip_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
     "clica_mixing_fwd": [c_f32p, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],
     "clica_adam_step": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "clica_adam_step_at": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_i32,
+                           C.c_void_p],
     "clica_adam_step_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                              C.c_void_p, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],

@@ -11,10 +11,10 @@ constexpr int THREADS = 256;
 
 __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, int64_t count, float lr, float b1, float b2, float eps,
-                                                 float gscale, int32_t* __restrict__ step_dev, int32_t* __restrict__ ticket) {
+                                                 float gscale, int32_t* __restrict__ step_dev, int32_t* __restrict__ ticket, int t_offset) {
   __shared__ float s_step_size, s_inv_bc2_sqrt;
   if (threadIdx.x == 0) {
-    const double t = (double)(step_dev[0] + 1);
+    const double t = (double)(step_dev[0] + t_offset);
     const double bc1 = 1.0 - pow((double)b1, t);
     const double bc2 = 1.0 - pow((double)b2, t);
     s_step_size = (float)((double)lr / bc1);
@@ -67,7 +67,7 @@ using namespace clica;
 
 static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                        float lr, float beta1, float beta2, float eps, float grad_scale,
-                       int32_t* step_dev, int32_t* ticket, clica_stream_t stream) {
+                       int32_t* step_dev, int32_t* ticket, int t_offset, clica_stream_t stream) {
   CLICA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && count > 0, "clica_adam_step: bad argument");
   CLICA_CHECK_ARG(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
                   "clica_adam_step: arenas must be 16-byte aligned");
@@ -75,19 +75,26 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
   if (blocks > kNumCU * 8) blocks = kNumCU * 8;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks), dim3(adam::THREADS), 0, as_stream(stream),
-                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket);
+                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, t_offset);
   return launch_status("clica_adam_step");
 }
 
 extern "C" int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                                float lr, float beta1, float beta2, float eps, float grad_scale,
                                const int32_t* step_dev, clica_stream_t stream) {
-  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, stream);
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, 1, stream);
 }
 
 extern "C" int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                                     float lr, float beta1, float beta2, float eps, float grad_scale,
                                     int32_t* step_dev, int32_t* ticket, clica_stream_t stream) {
   CLICA_CHECK_ARG(ticket != nullptr, "clica_adam_step_tick: ticket is NULL");
-  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, stream);
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, 1, stream);
+}
+
+extern "C" int clica_adam_step_at(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                                  float lr, float beta1, float beta2, float eps, float grad_scale,
+                                  const int32_t* step_dev, int32_t t_offset, clica_stream_t stream) {
+  CLICA_CHECK_ARG(t_offset == 0 || t_offset == 1, "clica_adam_step_at: t_offset must be 0 or 1");
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, t_offset, stream);
 }

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
 // out[i,k] (+)= sum_split part[split][i][k]; FOUR threads per float4 of the padded row (each sums every fourth
 // split with its loads in flight together, then a fixed-order shuffle tree): 4x the parallelism of a
 // launch that is otherwise a few dozen latency-bound workgroups
-struct MeansJob { const float* blocksums; int nblocks; float inv_count; float* means; int block; };   // block < 0: none
+struct MeansJob { const float* blocksums; int nblocks; float inv_count; float* means; int block; int32_t* tick; };   // block < 0: none
 __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
                                                        int np, int n, float* __restrict__ out, int64_t ldo,
                                                        int accumulate, MeansJob mj) {
@@ -219,7 +219,10 @@ __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict_
       for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
-      if (threadIdx.x == 0) { mj.means[0] = v[0] * mj.inv_count; mj.means[1] = v[1] * mj.inv_count; mj.means[2] = v[2] * mj.inv_count; }
+      if (threadIdx.x == 0) {
+        mj.means[0] = v[0] * mj.inv_count; mj.means[1] = v[1] * mj.inv_count; mj.means[2] = v[2] * mj.inv_count;
+        if (mj.tick) mj.tick[0] += 1;       // the step's samplers have consumed the counter; whoever reads it later sees step + 1
+      }
     }
     return;
   }
@@ -481,14 +484,14 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
     launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
     const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1});
+                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   }
   if (d_cols) {
     Params qc = q; qc.sgn = -q.sgn;   // e = -(owner - stream) + eps seen from the column side
     launch_bwd_pairs(false, PC, pk, cols_p, ldc, cols, rows_p, ldr, rows, qc, w.statL, w.statC, w.partC, st);
     const int acc = frac ? 1 : (accumulate_dz3 ? 1 : 0);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1});
+                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   }
   return launch_status("clica_lp_loss_bwd");
 }
@@ -524,7 +527,7 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
   }
   launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, w.partR, st);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
-                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1});
+                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   return launch_status("clica_lp_loss_bwd_sym");
 }
 
@@ -582,7 +585,7 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
 extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
                                            const float* z1, int64_t ld1, const float* pool, int64_t ldp,
                                            const float* lse_i, const float* pool_lse,
-                                           float* dz1, int64_t ldd1, float* means,
+                                           float* dz1, int64_t ldd1, float* means, int32_t* tick_counter,
                                            void* workspace, size_t workspace_bytes, clica_stream_t stream) {
   int rc = validate(d, "clica_lp_loss_bwd_sym_train");
   if (rc) return rc;
@@ -605,7 +608,7 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   const int blocks = (int)ceil_div(rows * PR.np, THREADS);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,
                      (const float*)partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1,
-                     MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks});
+                     MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks, tick_counter});
   return launch_status("clica_lp_loss_bwd_sym_train");
 }
 
@@ -761,12 +764,12 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
   } else if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1});
+                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   }
   if (o3) {
     launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3, MeansJob{nullptr, 0, 0.f, nullptr, -1});
+                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   }
   if (d->normalize) {
     if (dz1) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u1, (const float*)dw.du1, (int64_t)n, (const float*)dw.i1, B, n, dz1, ldd1, 0);

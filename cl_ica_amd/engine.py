@@ -85,7 +85,7 @@ class ContrastiveTrainer:
         self._flatten_parameters()
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
         # CLICA_FUSE_SMALL bit 4: mixing net g inside the fused forward's prologue (needs the one-launch forward, n <= 16)
-        self.mix_in_forward = bool(getattr(self, "_fuse_flags", int(os.environ.get("CLICA_FUSE_SMALL", "5"))) & 4) \
+        self.mix_in_forward = bool(getattr(self, "_fuse_flags", int(os.environ.get("CLICA_FUSE_SMALL", "13"))) & 4) \
             and self.fused_forward and self.n <= 16
         self._x_pending = False
         self.packed = None
@@ -134,9 +134,10 @@ class ContrastiveTrainer:
             self._layer_slices.append((min(o_w, o_b), max(o_w + n_w, o_b + n_b)))
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # clica_adam_step_tick's arrival counter
-        # A/B switch: 1 = pair sampler launch (+0.7 %), 2 = tick inside Adam (-0.5 %: 834 same-address atomics cost more
-        # than the 4.6 us single-thread tick launch they replace) -> only the first is on by default
-        fs = int(os.environ.get("CLICA_FUSE_SMALL", "5"))
+        # A/B switch (bits): 1 = pair sampler launch (+0.7 %), 2 = tick inside Adam (-0.5 %: 834 same-address atomics cost more
+        # than the 4.6 us single-thread tick launch they replace; off), 4 = mixing net in the fused forward's prologue,
+        # 8 = step counter advanced by the loss backward's reduction launch (+0.4 %)
+        fs = int(os.environ.get("CLICA_FUSE_SMALL", "13"))
         self.fuse_small, self.fuse_tick = bool(fs & 1), bool(fs & 2)
         self._fuse_flags = fs
 
@@ -166,6 +167,10 @@ class ContrastiveTrainer:
         if self.loss_train:
             _lib.check(_lib.load().clica_lp_loss_train_workspace_bytes(C.byref(self.desc), C.byref(tb)), "train workspace")
         self.loss_ws = torch.zeros(max(fb.value, bb.value, tb.value), dtype=torch.uint8, device=dev)
+        # the step / RNG counter is advanced by the loss backward's reduction launch (all samplers of the step have run by then)
+        # instead of a separate one-thread launch at the end; Adam then takes t = counter
+        self.early_tick = self.loss_train and not self.fuse_tick and bool(self._fuse_flags & 8)
+        self._ticked = False
         nb = C.c_size_t(); need = 0
         for lin in self.linears:
             _lib.check(_lib.load().clica_linear_wgrad_workspace_bytes(R, lin.out_features, lin.in_features, C.byref(nb)), "wgrad ws")
@@ -296,7 +301,9 @@ class ContrastiveTrainer:
             pool_lse = self.lse_all if self.dp else lse
             _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(self.desc), y1.data_ptr(), n, pool.data_ptr(), n,
                                                        lse.data_ptr(), pool_lse.data_ptr(), self.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(),
+                                                       self.step_dev.data_ptr() if self.early_tick else None,
                                                        self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd_sym_train")
+            self._ticked = self.early_tick
             return
         _lib.check(lib.clica_lp_loss_fwd(C.byref(self.desc), y1.data_ptr(), n, y2.data_ptr(), n, pool.data_ptr(), n,
                                          o[:B].data_ptr(), o[B:2 * B].data_ptr(), lse.data_ptr(), o[3 * B:].data_ptr(),
@@ -418,10 +425,11 @@ class ContrastiveTrainer:
     def optimizer_step(self):
         self._packed_current = False
         # the last Adam workgroup to finish also advances the device step / RNG counter (no separate tick launch)
+        ticked, self._ticked = self._ticked, False
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                       self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world,
-                      ticket=self.adam_ticket if self.fuse_tick else None)
-        if not self.fuse_tick:
+                      ticket=self.adam_ticket if (self.fuse_tick and not ticked) else None, t_offset=0 if ticked else 1)
+        if not self.fuse_tick and not ticked:
             ops.tick(self.step_dev)
 
     # -------------------------------------------------------------------------------- whole step

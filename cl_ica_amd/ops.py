@@ -327,14 +327,18 @@ def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: 
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
-              ticket: Optional[torch.Tensor] = None):
+              ticket: Optional[torch.Tensor] = None, t_offset: int = 1):
     """In-place Adam on flat fp32 arenas; `step_dev` int32[1] = updates already applied.  With `ticket` (device
     int32[1], zero) the same launch also advances `step_dev` by one (clica_adam_step_tick)."""
     for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         require_cuda(t, nm)
         if not t.is_contiguous():
             raise ValueError(f"{nm} must be contiguous")
-    if ticket is None:
+    if ticket is None and t_offset != 1:       # the counter was already advanced earlier in the step
+        check(load().clica_adam_step_at(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                        param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                        step_dev.data_ptr(), int(t_offset), stream_ptr()), "clica_adam_step_at")
+    elif ticket is None:
         check(load().clica_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                      param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
                                      step_dev.data_ptr(), stream_ptr()), "clica_adam_step")

@@ -126,7 +126,7 @@ int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
 int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
                                 const float* z1, int64_t ld1, const float* pool, int64_t ldp,
                                 const float* lse_i, const float* pool_lse,
-                                float* dz1, int64_t ldd1, float* means,
+                                float* dz1, int64_t ldd1, float* means, int32_t* tick_counter /* NULL, or a device counter to advance by 1 */,
                                 void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -296,6 +296,11 @@ int clica_mixing_fwd(const float* Z, int64_t ldz, const float* W, int32_t n_laye
 int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                     float lr, float beta1, float beta2, float eps, float grad_scale,
                     const int32_t* step_dev, clica_stream_t stream);
+/* Same update with t = *step_dev + t_offset (t_offset = 0 when the counter was already advanced earlier in the step,
+ * e.g. by clica_lp_loss_bwd_sym_train's tick_counter). */
+int clica_adam_step_at(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                       float lr, float beta1, float beta2, float eps, float grad_scale,
+                       const int32_t* step_dev, int32_t t_offset, clica_stream_t stream);
 /* Same update, and the LAST workgroup to finish advances *step_dev by one (replaces the separate clica_tick launch).
  * `ticket` is a device int32 owned by the caller, zero before the first call; the kernel leaves it at zero. */
 int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
