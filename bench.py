@@ -261,7 +261,7 @@ def loss_leg(tr, reps=20):
         ev[1].record()
         if train:
             lib.clica_lp_loss_bwd_sym_train(C.byref(tr.desc), y1.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(), pool_lse.data_ptr(),
-                                            tr.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(), tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
+                                            tr.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(), None, tr.loss_ws.data_ptr(), tr.loss_ws.numel(), st)
         else:
             lib.clica_lp_loss_bwd_sym(C.byref(tr.desc), y1.data_ptr(), n, y2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
                                       pool_lse.data_ptr(), None, None, None,
