@@ -165,7 +165,10 @@ __device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* 
 }
 
 // sum_k term for one owner against JB stream rows of the LDS tile (wave-uniform ds_read_b128 broadcasts)
-template <int NP, int PK>
+// NQ = number of dimension PAIRS that can hold real data (ceil(n / 2) <= NP / 2): a pair that is all padding
+// (n = 9, 10 in the 12-wide layout) contributes exact zeros and is skipped at compile time -- same bits, two packed
+// instructions fewer per pair and sweep.
+template <int NP, int PK, int NQ = NP / 2>
 __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float* tile, int jj, const Params& q,
                                            float (&acc)[JB]) {
   f32x2 a2[JB];
@@ -176,8 +179,8 @@ __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float
 #pragma unroll
     for (int c = 0; c < JB; ++c) {
       const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-      accum2<PK>(a2[c], o[2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
-      accum2<PK>(a2[c], o[2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
+      if (2 * k4 < NQ) accum2<PK>(a2[c], o[2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+      if (2 * k4 + 1 < NQ) accum2<PK>(a2[c], o[2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
     }
   }
 #pragma unroll
@@ -189,7 +192,7 @@ __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float
 // running-max rescaling (the flash-attention forward with "V" = the pair's distance derivative).  After
 // the splits are merged, G / 2^(lse) is the softmax-weighted row gradient sum_j w_ij d neg_ij / d owner_i,
 // so the backward needs NO row pass: dz1 = pos-term + (-C_i / tau) * rowgrad_i for any upstream gradient.
-template <int NP, int PK, int R, bool ROOT, bool ROWGRAD>
+template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2>
 __global__ __launch_bounds__(THREADS) void fwd_partial_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc[JB];
-        dist_group<NP, PK>(o[r], tile, jj, q, acc);
+        dist_group<NP, PK, NQ>(o[r], tile, jj, q, acc);
         float x[JB];
 #pragma unroll
         for (int c = 0; c < JB; ++c) {
@@ -253,8 +256,8 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 #pragma unroll
             for (int c = 0; c < JB; ++c) {
               const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-              gaccum2<PK>(G[r][2 * k4], e[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
-              gaccum2<PK>(G[r][2 * k4 + 1], e[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
+              if (2 * k4 < NQ) gaccum2<PK>(G[r][2 * k4], e[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+              if (2 * k4 + 1 < NQ) gaccum2<PK>(G[r][2 * k4 + 1], e[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
             }
           }
         }
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 // weights); both (3) = the symmetric sweep used when the stream is the pool the owners belong to
 // (z3 = all z1, main_mlp.py:272): d_ij = d_ji, so coef = C_i 2^(x - L_i) + C_j 2^(x - L_j) yields row AND
 // column contributions to dz_i in one pass.
-template <int NP, int PK, int R, int STATS, bool ROOT>
+template <int NP, int PK, int R, int STATS, bool ROOT, int NQ = NP / 2>
 __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc[JB];
-        dist_group<NP, PK>(o[r], tile, jj, q, acc);
+        dist_group<NP, PK, NQ>(o[r], tile, jj, q, acc);
         float coef[JB];
 #pragma unroll
         for (int c = 0; c < JB; ++c) {
@@ -362,8 +365,8 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
 #pragma unroll
           for (int c = 0; c < JB; ++c) {
             const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-            gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
-            gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
+            if (2 * k4 < NQ) gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+            if (2 * k4 + 1 < NQ) gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
           }
         }
       }

@@ -13,14 +13,15 @@ namespace lp {
 
 #define LP_FOR_NP(NPV, BODY)                        \
   switch (NPV) {                                    \
-    case 4: { constexpr int NP = 4; BODY } break;   \
-    case 8: { constexpr int NP = 8; BODY } break;   \
-    case 12: { constexpr int NP = 12; BODY } break; \
-    case 16: { constexpr int NP = 16; BODY } break; \
-    case 24: { constexpr int NP = 24; BODY } break; \
-    case 32: { constexpr int NP = 32; BODY } break; \
-    case 40: { constexpr int NP = 40; BODY } break; \
-    case 64: { constexpr int NP = 64; BODY } break; \
+    case 4: { constexpr int NP = 4; constexpr int NQ = NP / 2; BODY } break;   \
+    case 8: { constexpr int NP = 8; constexpr int NQ = NP / 2; BODY } break;   \
+    case 12: if (q.n <= 10) { constexpr int NP = 12; constexpr int NQ = 5; BODY }   /* n = 9, 10: the sixth pair is all padding */ \
+             else { constexpr int NP = 12; constexpr int NQ = 6; BODY } break; \
+    case 16: { constexpr int NP = 16; constexpr int NQ = NP / 2; BODY } break; \
+    case 24: { constexpr int NP = 24; constexpr int NQ = NP / 2; BODY } break; \
+    case 32: { constexpr int NP = 32; constexpr int NQ = NP / 2; BODY } break; \
+    case 40: { constexpr int NP = 40; constexpr int NQ = NP / 2; BODY } break; \
+    case 64: { constexpr int NP = 64; constexpr int NQ = NP / 2; BODY } break; \
     default: break;                                 \
   }
 
@@ -33,16 +34,16 @@ void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (part_g && q.pow)
-      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), false, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), false, true, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
     else if (part_g)
-      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), true, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), true, true, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
     else if (q.pow)
-      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false, false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false, false, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
     else
-      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), true, false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), true, false, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
   })
 }
@@ -55,16 +56,16 @@ void CAT(launch_bwd_pairs_pk, CLICA_PK)(const Plan& P, bool owner_stats, const f
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (owner_stats && q.pow)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 1, false>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 1, false, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
     else if (owner_stats)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 1, true>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 1, true, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
     else if (q.pow)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 2, false>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 2, false, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
     else
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 2, true>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 2, true, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, statL, statC, statL, statC, part, P.chunk);
   })
 }
@@ -78,10 +79,10 @@ void CAT(launch_bwd_sym_pk, CLICA_PK)(const Plan& P, const float* own, int64_t l
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (q.pow)
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, false>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, false, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, ownL, ownC, strL, strC, part, P.chunk);
     else
-      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, true>), grid, block, 0, st, own, ldo, n_own, str,
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, true, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, ownL, ownC, strL, strC, part, P.chunk);
   })
 }
