@@ -203,7 +203,6 @@ __device__ __forceinline__ unsigned long long epilogue_to_panel(float* panel, co
       for (int r = 0; r < RB; ++r) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          constexpr int dummy = 0; (void)dummy;
           const int bit = (c * RB + r) * 4 + e;       // compile time
           float v = acc[r][c][e];
           if (MODE == EPI_BIAS || MODE == EPI_BIAS_LEAKY) v += bias[c];
