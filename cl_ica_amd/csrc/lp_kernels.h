@@ -405,19 +405,35 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
   P.np = pad_dim(n);
   P.R = bwd ? owners_bwd(P.np) : owners_fwd(P.np);
   P.tiles = ceil_div(n_own, (int64_t)THREADS * P.R);
-  // aim for ~8 workgroups per CU (VALU-bound all-pairs loop: needs >= 4 waves per SIMD to cover the
-  // LDS-broadcast and exp latencies); each split covers a whole number of LDS tiles.  Tunable:
-  // CLICA_LP_WG_PER_CU.
-  const char* env = getenv("CLICA_LP_WG_PER_CU");
-  const int per_cu = env ? atoi(env) : 8;
-  int64_t want = ceil_div((int64_t)kNumCU * per_cu, P.tiles);
-  int64_t max_split = ceil_div(n_str, (int64_t)TS);
-  int64_t ns = want < 1 ? 1 : (want > max_split ? max_split : want);
-  if (ns < 1) ns = 1;
-  int64_t chunk = ceil_div(ceil_div(n_str, ns), (int64_t)TS) * TS;
-  if (chunk < TS) chunk = TS;
-  P.chunk = (int)chunk;
-  P.nsplit = (int)(n_str > 0 ? ceil_div(n_str, chunk) : 1);
+  // Stream splits.  Every workgroup of a launch is resident at once and the loop is VALU-bound, so a launch lasts as long as
+  // its most loaded CU: ceil(workgroups / 256) x (rows per split + a fixed prologue).  Pick the split count that
+  // minimises that, each split a whole number of TS-row LDS tiles, with 3..10 workgroups per CU (>= 4 waves per SIMD
+  // cover the LDS-broadcast and exp latencies; a mild penalty below 6 per CU).  E.g. B3 = 49 152: 128 splits of 384 rows =
+  // exactly 6 workgroups per CU (-7 % vs the "about 8 per CU" rule, whose 154 splits of 320 rows left a ragged 7.2).
+  // CLICA_LP_WG_PER_CU[_FWD] = <k> forces "about k per CU" instead (tuning).
+  const char* env = getenv(bwd ? "CLICA_LP_WG_PER_CU" : "CLICA_LP_WG_PER_CU_FWD");
+  const int64_t max_split = ceil_div(n_str, (int64_t)TS);
+  auto finish = [&](int64_t ns) {
+    if (ns < 1) ns = 1;
+    if (ns > max_split) ns = max_split;
+    int64_t chunk = ceil_div(ceil_div(n_str, ns), (int64_t)TS) * TS;
+    if (chunk < TS) chunk = TS;
+    P.chunk = (int)chunk;
+    P.nsplit = (int)(n_str > 0 ? ceil_div(n_str, chunk) : 1);
+  };
+  if (env) { finish(ceil_div((int64_t)kNumCU * atoi(env), P.tiles)); return P; }
+  double best = 1e300; int64_t best_ns = 1;
+  const int64_t lo = ceil_div((int64_t)kNumCU * 3, P.tiles), hi = ceil_div((int64_t)kNumCU * 10, P.tiles);
+  const int64_t ns_hi = hi > max_split ? max_split : (hi < 1 ? 1 : hi);
+  const int64_t ns_lo = lo < 1 ? 1 : (lo > ns_hi ? ns_hi : lo);        // short streams: as many splits as there are tiles of rows
+  for (int64_t ns = ns_lo; ns <= ns_hi; ++ns) {
+    const int64_t chunk = ceil_div(ceil_div(n_str, ns), (int64_t)TS) * TS;
+    const int64_t nsp = ceil_div(n_str, chunk);
+    const int64_t rounds = ceil_div(P.tiles * nsp, (int64_t)kNumCU);
+    const double cost = (double)rounds * (double)(chunk + 32) * (1.0 + 0.02 * (rounds < 6 ? 6 - rounds : 0));
+    if (cost < best - 1e-9 || (cost < best + 1e-9 && nsp > best_ns)) { best = cost; best_ns = nsp; }
+  }
+  finish(best_ns);
   return P;
 }
 
