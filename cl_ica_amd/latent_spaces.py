@@ -1,8 +1,19 @@
-"""Spaces combined with marginal / conditional densities (same surface as
-/root/reference/latent_spaces.py:8-75)."""
+"""Latent spaces = a topological space plus the two densities a contrastive step draws from.
+
+Call surface of /root/reference/latent_spaces.py (LatentSpace :8-46, ProductLatentSpace :49-75):
+``LatentSpace(space, sample_marginal, sample_conditional)`` where the two callables take the space as their
+first argument (``lambda space, size, device=...: space.uniform(size, device=device)``), are exposed as
+``ls.sample_marginal(size=..., device=...)`` / ``ls.sample_conditional(z=..., size=..., device=...)`` with the
+space already bound, may be replaced by assignment, and ``ls.dim`` is the space's dimension.  The product space
+concatenates its factors' samples along the feature axis and conditions each factor on its own slice.
+
+The draws themselves come from the on-device samplers behind `cl_ica_amd.spaces`.
+"""
 from __future__ import annotations
 
-from typing import Callable, List
+import functools
+import itertools
+from typing import Callable, Optional, Sequence
 
 import torch
 
@@ -11,59 +22,64 @@ from .spaces import Space
 __all__ = ["LatentSpace", "ProductLatentSpace"]
 
 
-class LatentSpace:
-    """Combines a topological space with a marginal and conditional density to sample from."""
+class _BoundSampler:
+    """Data descriptor: stores a ``fn(space, ...)`` per instance and hands out ``fn`` with the instance's space bound."""
 
-    def __init__(self, space: Space, sample_marginal: Callable, sample_conditional: Callable):
-        self.space = space
-        self._sample_marginal = sample_marginal
-        self._sample_conditional = sample_conditional
+    def __set_name__(self, owner, name):
+        self.public = name
+        self.slot = "_" + name + "_fn"
 
-    def _bound(self, fn, what):
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        fn: Optional[Callable] = getattr(obj, self.slot, None)
         if fn is None:
-            raise RuntimeError(f"{what} was not set")
-        return lambda *args, **kwargs: fn(self.space, *args, **kwargs)
+            raise RuntimeError(f"{self.public} was not set")
+        return functools.partial(fn, obj.space)
+
+    def __set__(self, obj, fn):
+        if fn is not None and not callable(fn):
+            raise TypeError(f"{self.public} must be callable, got {type(fn).__name__}")
+        setattr(obj, self.slot, fn)
+
+
+class LatentSpace:
+    """One space with its marginal p(z) and conditional p(z~ | z) samplers."""
+
+    sample_marginal = _BoundSampler()
+    sample_conditional = _BoundSampler()
+
+    def __init__(self, space: Space, sample_marginal: Optional[Callable], sample_conditional: Optional[Callable]):
+        self.space = space
+        self.sample_marginal = sample_marginal
+        self.sample_conditional = sample_conditional
 
     @property
-    def sample_conditional(self):
-        return self._bound(self._sample_conditional, "sample_conditional")
-
-    @sample_conditional.setter
-    def sample_conditional(self, value: Callable):
-        assert callable(value)
-        self._sample_conditional = value
-
-    @property
-    def sample_marginal(self):
-        return self._bound(self._sample_marginal, "sample_marginal")
-
-    @sample_marginal.setter
-    def sample_marginal(self, value: Callable):
-        assert callable(value)
-        self._sample_marginal = value
-
-    @property
-    def dim(self):
+    def dim(self) -> int:
         return self.space.dim
 
 
 class ProductLatentSpace(LatentSpace):
-    """Cartesian product of latent spaces: samples are concatenated along the feature axis and the
-    conditional is applied block-wise (latent_spaces.py:49-75)."""
+    """Cartesian product of latent spaces (block-wise sampling, feature-axis concatenation)."""
 
-    def __init__(self, spaces: List[LatentSpace]):
-        self.spaces = spaces
+    # plain methods here: the factors already carry their own bound samplers
+    sample_marginal = None
+    sample_conditional = None
 
-    def sample_conditional(self, z, size, **kwargs):
-        parts, n = [], 0
-        for s in self.spaces:
-            parts.append(s.sample_conditional(z=z[..., n:n + s.dim], size=size, **kwargs))
-            n += s.dim
-        return torch.cat(parts, -1)
+    def __init__(self, spaces: Sequence[LatentSpace]):
+        self.spaces = list(spaces)
 
-    def sample_marginal(self, size, **kwargs):
-        return torch.cat([s.sample_marginal(size=size, **kwargs) for s in self.spaces], -1)
+    def _offsets(self):
+        ends = list(itertools.accumulate(s.dim for s in self.spaces))
+        return zip(self.spaces, [0] + ends[:-1], ends)
+
+    def sample_marginal(self, size, **kwargs):  # noqa: F811  (replaces the class attribute above)
+        return torch.cat([s.sample_marginal(size=size, **kwargs) for s in self.spaces], dim=-1)
+
+    def sample_conditional(self, z, size, **kwargs):  # noqa: F811
+        blocks = [s.sample_conditional(z=z[..., lo:hi], size=size, **kwargs) for s, lo, hi in self._offsets()]
+        return torch.cat(blocks, dim=-1)
 
     @property
-    def dim(self):
+    def dim(self) -> int:
         return sum(s.dim for s in self.spaces)

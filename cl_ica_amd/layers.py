@@ -13,19 +13,33 @@ __all__ = ["Lambda", "Flatten", "RescaleLayer", "SoftclipLayer"]
 
 
 class Lambda(nn.Module):
-    """Apply a function to the input (layers.py:30-38)."""
+    """Module wrapper around an arbitrary callable (reference layers.py:30-38): ``Lambda(f)(*a, **k) == f(*a, **k)``."""
 
     def __init__(self, f):
         super().__init__()
         self.f = f
 
-    def forward(self, *args, **kwargs):
-        return self.f(*args, **kwargs)
+    def forward(self, *inputs, **options):
+        fn = self.f
+        return fn(*inputs, **options)
 
 
 class Flatten(Lambda):
+    """Keeps the batch axis, merges all others (reference layers.py:41-45)."""
+
     def __init__(self):
-        super().__init__(lambda x: x.view(len(x), -1))
+        super().__init__(self._merge_trailing_axes)
+
+    @staticmethod
+    def _merge_trailing_axes(batch):
+        return batch.view(batch.shape[0], -1)
+
+
+def _scale_tensor(shape, value, learnable: bool):
+    """The reference keeps a fixed scale as a plain tensor attribute (neither parameter nor buffer, so it is absent from
+    the state dict) and a learnable one as an ``nn.Parameter`` -- checkpoints only interchange if this is reproduced."""
+    t = torch.ones(shape, dtype=torch.float32) * value        # `value` may be a number or a broadcastable tensor
+    return nn.Parameter(t) if learnable else t.detach()
 
 
 class _RescaleFn(torch.autograd.Function):
@@ -69,10 +83,7 @@ class RescaleLayer(nn.Module):
         if mode != "eq":
             raise NotImplementedError("RescaleLayer(mode='leq') is unused by the reference and not built")
         self.mode = mode
-        if fixed_r:
-            self.r = torch.ones(1, requires_grad=False) * init_r
-        else:
-            self.r = nn.Parameter(torch.ones(1, requires_grad=True) * init_r)
+        self.r = _scale_tensor(1, init_r, learnable=not fixed_r)
 
     def forward(self, x):
         r = self.r.to(x.device)
@@ -88,10 +99,7 @@ class SoftclipLayer(nn.Module):
     def __init__(self, n, init_abs_bound=1.0, fixed_abs_bound=True):
         super().__init__()
         self.fixed_abs_bound = fixed_abs_bound
-        if fixed_abs_bound:
-            self.max_abs_bound = torch.ones(n, requires_grad=False) * init_abs_bound
-        else:
-            self.max_abs_bound = nn.Parameter(torch.ones(n, requires_grad=True) * init_abs_bound)
+        self.max_abs_bound = _scale_tensor(n, init_abs_bound, learnable=not fixed_abs_bound)
 
     def forward(self, x):
         return _SoftclipFn.apply(x, self.max_abs_bound.to(x.device).contiguous())
