@@ -87,6 +87,25 @@ __global__ __launch_bounds__(THREADS) void softclip_bwd_k(const float* __restric
     }
   }
 }
+
+// stand-alone LeakyReLU (main_3dident.py:368: the activation BETWEEN the backbone output and the head's Linear, so it
+// cannot ride in a GEMM epilogue).  Backward reads the saved OUTPUT (slope > 0: sign(y) = sign(x)).
+__global__ __launch_bounds__(THREADS) void leaky_fwd_k(const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                      int64_t M, int n, float slope) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= M * n) return;
+  const int64_t i = idx / n; const int k = (int)(idx - i * n);
+  const float v = X[i * ldx + k];
+  Y[i * ldy + k] = v > 0.f ? v : slope * v;
+}
+__global__ __launch_bounds__(THREADS) void leaky_bwd_k(const float* __restrict__ Yact, int64_t ldy, const float* __restrict__ dY, int64_t lddy,
+                                                      float* __restrict__ dX, int64_t lddx, int64_t M, int n, float slope) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= M * n) return;
+  const int64_t i = idx / n; const int k = (int)(idx - i * n);
+  const float g = dY[i * lddy + k];
+  dX[i * lddx + k] = Yact[i * ldy + k] > 0.f ? g : slope * g;
+}
 }  // namespace heads
 }  // namespace clica
 
@@ -118,4 +137,17 @@ extern "C" int clica_softclip_bwd(const float* X, int64_t ldx, const float* boun
   CLICA_CHECK_ARG(X && bound && dY && M > 0 && n > 0 && ldx >= n && lddy >= n && (!dX || lddx >= n), "clica_softclip_bwd: bad argument");
   hipLaunchKernelGGL(softclip_bwd_k, dim3((unsigned)ceil_div(M, THREADS)), dim3(THREADS), 0, as_stream(stream), X, ldx, bound, dY, lddy, dX, lddx, dbound_partial, M, n);
   return launch_status("clica_softclip_bwd");
+}
+extern "C" int clica_leaky_relu_fwd(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t M, int32_t n, float slope,
+                                    clica_stream_t stream) {
+  CLICA_CHECK_ARG(X && Y && M > 0 && n > 0 && ldx >= n && ldy >= n, "clica_leaky_relu_fwd: bad argument");
+  hipLaunchKernelGGL(leaky_fwd_k, dim3((unsigned)ceil_div(M * n, THREADS)), dim3(THREADS), 0, as_stream(stream), X, ldx, Y, ldy, M, n, slope);
+  return launch_status("clica_leaky_relu_fwd");
+}
+extern "C" int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_t lddy, float* dX, int64_t lddx,
+                                    int64_t M, int32_t n, float slope, clica_stream_t stream) {
+  CLICA_CHECK_ARG(Yact && dY && dX && M > 0 && n > 0 && ldy >= n && lddy >= n && lddx >= n, "clica_leaky_relu_bwd: bad argument");
+  CLICA_CHECK_ARG(slope > 0.f, "clica_leaky_relu_bwd: slope=%g must be > 0 (the backward recovers the sign from the output)", slope);
+  hipLaunchKernelGGL(leaky_bwd_k, dim3((unsigned)ceil_div(M * n, THREADS)), dim3(THREADS), 0, as_stream(stream), Yact, ldy, dY, lddy, dX, lddx, M, n, slope);
+  return launch_status("clica_leaky_relu_bwd");
 }

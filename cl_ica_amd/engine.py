@@ -97,6 +97,13 @@ class ContrastiveTrainer:
         self.split_bf16 = self.fused_backward and want_split and all(lin.bias is not None for lin in self.linears) and \
             sum((lin.out_features + 31) // 32 * 32 for lin in self.linears) <= 3456      # on-chip bias table (fused_mlp.hip)
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
+        if self.world > 1:
+            # identical replicas by construction: rank 0's parameters and mixing weights win (callers that seed every rank
+            # identically are unaffected; callers that do not would otherwise train `world` different models silently)
+            dist.broadcast(self.param_arena, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
+            dist.broadcast(self.gW, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
+                           group=process_group)
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes,
@@ -132,6 +139,15 @@ class ContrastiveTrainer:
             o_w, n_w = pid[id(lin.weight)]
             o_b, n_b = pid[id(lin.bias)]
             self._layer_slices.append((min(o_w, o_b), max(o_w + n_w, o_b + n_b)))
+        # parameters that are not Linear weights/biases (a learnable head: RescaleLayer.r / SoftclipLayer.max_abs_bound) get their
+        # gradient at the very start of backward(): they ride in the first slice to complete, so the data-parallel all-reduce
+        # covers them too (otherwise every rank would train its own head parameter)
+        lin_ids = {id(q) for lin in self.linears for q in (lin.weight, lin.bias)}
+        for prm in params:
+            if id(prm) not in lin_ids and self._layer_slices:
+                o, k = pid[id(prm)]
+                lo, hi = self._layer_slices[0]
+                self._layer_slices[0] = (min(lo, o), max(hi, o + (k + 3) // 4 * 4))
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
         self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # clica_adam_step_tick's arrival counter
         # A/B switch (bits): 1 = pair sampler launch (+0.7 %), 2 = tick inside Adam (-0.5 %: 834 same-address atomics cost more

@@ -67,11 +67,17 @@ class MixingMLP(nn.Sequential):
         for p in self.parameters():
             p.requires_grad = False
         self._stack = None
+        self._stack_key = None
 
     def weight_stack(self) -> torch.Tensor:
+        """Contiguous [L, n, n] copy of the layer weights for the fused kernel.  Rebuilt whenever a weight was replaced or
+        written in place (``load_state_dict`` of a reference g.pth, ``.to()``): the key is every weight's storage address and
+        version counter."""
         ws = [m.weight for m in self if isinstance(m, nn.Linear)]
-        if self._stack is None or self._stack.device != ws[0].device:
+        key = tuple((w.data_ptr(), w._version, str(w.device)) for w in ws)
+        if self._stack is None or self._stack_key != key:
             self._stack = torch.stack([w.detach() for w in ws]).contiguous()
+            self._stack_key = key
         return self._stack
 
     def _apply(self, fn, *a, **k):   # .to(device) invalidates the cached stack

@@ -9,7 +9,7 @@ from torch import nn
 
 from . import ops
 
-__all__ = ["Lambda", "Flatten", "RescaleLayer", "SoftclipLayer"]
+__all__ = ["Lambda", "Flatten", "RescaleLayer", "SoftclipLayer", "LeakyReLU"]
 
 
 class Lambda(nn.Module):
@@ -103,3 +103,27 @@ class SoftclipLayer(nn.Module):
 
     def forward(self, x):
         return _SoftclipFn.apply(x, self.max_abs_bound.to(x.device).contiguous())
+
+
+class _LeakyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        y = ops.leaky_relu_fwd(x, slope)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ops.leaky_relu_bwd(y, gy, ctx.slope), None
+
+
+class LeakyReLU(nn.LeakyReLU):
+    """``nn.LeakyReLU`` (same constructor, no parameters) on the HIP element-wise kernel: the activation the 3DIdent encoder
+    puts between the backbone's output and the head's Linear (main_3dident.py:365-370)."""
+
+    def forward(self, x):
+        if x.dim() != 2:
+            return _LeakyFn.apply(x.reshape(-1, x.shape[-1]), float(self.negative_slope)).reshape(x.shape)
+        return _LeakyFn.apply(x, float(self.negative_slope))

@@ -57,7 +57,8 @@ class _PairLossFn(torch.autograd.Function):
         # when z1 will need a gradient, let the forward sweep also accumulate the softmax-weighted row
         # gradient: the backward then needs only the column sweep
         n = a.shape[1]
-        want_rg = z1.requires_grad and torch.is_grad_enabled() and not (kind == "lp" and desc.p < 1.0)
+        # (autograd.Function.forward runs with grad mode off: ask the node, not torch.is_grad_enabled())
+        want_rg = ctx.needs_input_grad[0] and not (kind == "lp" and desc.p < 1.0)
         rowgrad = torch.empty((B, n), dtype=torch.float32, device=a.device) if want_rg else None
         _lib.check(fwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
                        loss_i.data_ptr(), pos_i.data_ptr(), lse_i.data_ptr(), means.data_ptr(),

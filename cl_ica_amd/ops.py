@@ -312,6 +312,23 @@ def softclip_bwd(x, bound, dy, need_dx=True, need_db=True):
     return dx, (part.sum(0) if need_db else None)
 
 
+def leaky_relu_fwd(x, slope: float = 0.01):
+    (x, ldx) = _mat("x", x)
+    M, n = x.shape
+    y = torch.empty((M, n), dtype=torch.float32, device=x.device)
+    check(load().clica_leaky_relu_fwd(x.data_ptr(), ldx, y.data_ptr(), n, M, n, float(slope), stream_ptr()), "clica_leaky_relu_fwd")
+    return y
+
+
+def leaky_relu_bwd(yact, dy, slope: float = 0.01):
+    (yact, ldy), (dy, lddy) = _mat("yact", yact), _mat("dy", dy)
+    M, n = yact.shape
+    dx = torch.empty((M, n), dtype=torch.float32, device=dy.device)
+    check(load().clica_leaky_relu_bwd(yact.data_ptr(), ldy, dy.data_ptr(), lddy, dx.data_ptr(), n, M, n, float(slope), stream_ptr()),
+          "clica_leaky_relu_bwd")
+    return dx
+
+
 # ------------------------------------------------------------------------------- mixing / adam / sampler
 def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: Optional[torch.Tensor] = None):
     """x = W_L phi(... phi(W_1 z)); `weights` is a contiguous [L, n, n] stack (nn.Linear layout)."""

@@ -1,0 +1,99 @@
+"""Adam over ONE flat parameter arena, one HIP launch per step (csrc/adam.hip: ``clica_adam_step``).
+
+Counterpart of the ``torch.optim.Adam(f.parameters(), lr=...)`` the reference's drivers build (main_mlp.py:312,
+main_3dident.py:447-448, kitti_masks/solver.py:36-40) with the same update rule (bias-corrected, eps outside the square
+root, no weight decay / amsgrad) and the same ``state_dict()`` layout (``state[i] = {step, exp_avg, exp_avg_sq}``,
+``param_groups``), so optimizer checkpoints interchange with the reference's.
+
+Construction re-points every parameter's ``.data`` into a 16-byte aligned slice of one contiguous fp32 arena and installs
+``.grad`` views into a matching gradient arena (autograd accumulates into them in place), so ``zero_grad()`` is one memset,
+``step()`` one kernel launch, and a data-parallel run all-reduces ONE buffer (``all_reduce_grads``).
+"""
+from __future__ import annotations
+
+from typing import Iterable, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import require_cuda
+
+__all__ = ["Adam"]
+
+
+class Adam:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 process_group: Optional[dist.ProcessGroup] = None):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("optimizer got an empty parameter list")
+        for p in self.params:
+            require_cuda(p.data, "parameter")
+        dev = self.params[0].device
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        self.param_groups = [dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=0, amsgrad=False,
+                                  params=list(range(len(self.params))))]
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.offsets, self.total = offs, total
+        self.param_arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad_arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        for p, off in zip(self.params, offs):
+            view = self.param_arena[off:off + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+
+    # ------------------------------------------------------------------ torch.optim surface
+    def zero_grad(self, set_to_none: bool = False):
+        """One memset of the gradient arena (the ``.grad`` views stay installed; ``set_to_none`` is ignored on purpose)."""
+        self.grad_arena.zero_()
+        for p, off in zip(self.params, self.offsets):
+            if p.grad is None or p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * off:
+                p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)      # someone set it to None / replaced it
+
+    def all_reduce_grads(self):
+        """Data parallel: sum the gradient arena over the ranks (the 1/world average is applied inside ``step``)."""
+        if self.world > 1:
+            dist.all_reduce(self.grad_arena, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
+                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world)
+        ops.tick(self.step_dev)
+        return loss
+
+    # ------------------------------------------------------------------ checkpoints (torch.optim.Adam layout)
+    def state_dict(self):
+        step = int(self.step_dev.item())
+        state = {}
+        if step > 0:
+            for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+                sl = slice(off, off + p.numel())
+                state[i] = dict(step=torch.tensor(float(step)), exp_avg=self.exp_avg[sl].view(p.shape).clone(),
+                                exp_avg_sq=self.exp_avg_sq[sl].view(p.shape).clone())
+        return dict(state=state, param_groups=[dict(self.param_groups[0])])
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.param_groups[0].update(lr=float(g["lr"]), betas=tuple(g["betas"]), eps=float(g["eps"]))
+        steps = set()
+        for i, st in sd["state"].items():
+            p, off = self.params[int(i)], self.offsets[int(i)]
+            sl = slice(off, off + p.numel())
+            self.exp_avg[sl].view(p.shape).copy_(st["exp_avg"])
+            self.exp_avg_sq[sl].view(p.shape).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ; the flat Adam keeps one step counter")
+        self.step_dev.fill_(steps.pop() if steps else 0)

@@ -21,8 +21,9 @@ import torch.nn.functional as F
 
 from . import disentanglement_utils as du
 from . import encoders, invertible_network_utils, latent_spaces, losses, spaces
-from .distributed import init_from_env
+from .distributed import gather_negatives, init_from_env
 from .engine import ContrastiveTrainer, SamplerSpec
+from .optim import Adam as FlatAdam
 
 # (flag, type, default, help) -- the reference's CLI surface
 _FLAGS = [
@@ -122,6 +123,10 @@ def main(argv=None):
     for k, v in vars(args).items():
         log(f"\t{k}: {v}")
     seed = args.seed if args.seed is not None else int.from_bytes(os.urandom(4), "little")
+    if world > 1:      # without --seed every process would draw its own: rank 0's seed is THE seed (identical g and f everywhere)
+        box = [seed]
+        torch.distributed.broadcast_object_list(box, src=0)
+        seed = int(box[0])
     np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)   # same seeds on every rank: identical g and f
     spaces.manual_seed(seed * 1000003 + rank)
     spec = sampler_spec(args, seed)
@@ -164,7 +169,12 @@ def main(argv=None):
             if world == 1 and not args.no_graph:
                 trainer.capture()
         else:
-            optimizer = torch.optim.Adam(f.parameters(), lr=args.lr)
+            # supervised / p == 0 phases: autograd over the drop-in modules; flat-arena HIP Adam whose gradient arena is
+            # all-reduced under data parallelism (its 1/world average is applied inside the Adam launch)
+            if world > 1:
+                for prm in f.parameters():
+                    torch.distributed.broadcast(prm.data, src=0)
+            optimizer = FlatAdam(f.parameters(), lr=args.lr)
 
         def autograd_step():
             """The reference's train_step verbatim in structure (main_mlp.py:258-285) on the drop-in modules."""
@@ -172,12 +182,14 @@ def main(argv=None):
             z2 = latent_space.sample_conditional(z1, size=args.batch_size)
             optimizer.zero_grad()
             z1_rec, z2_rec = h(z1), h(z2)
-            z3_rec = torch.roll(z1_rec, 1, 0)
+            # negatives = all z1_rec of the (global) batch: roll on one rank, autograd-aware all-gather on several
+            z3_rec = torch.roll(z1_rec, 1, 0) if world == 1 else gather_negatives(z1_rec)
             if supervised:
                 total = F.mse_loss(z1_rec, z1)
             else:
                 total, _, _ = loss(z1, z2, torch.roll(z1, 1, 0), z1_rec, z2_rec, z3_rec)
             total.backward()
+            optimizer.all_reduce_grads()
             optimizer.step()
             return total
 

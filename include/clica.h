@@ -278,6 +278,14 @@ int clica_softclip_bwd(const float* X, int64_t ldx, const float* bound, const fl
                        float* dX, int64_t lddx, float* dbound_partial /*[ceil(M/256), n] or NULL*/,
                        int64_t M, int32_t n, clica_stream_t stream);
 
+/* Stand-alone LeakyReLU between a backbone's output and the encoder head's Linear
+ * (/root/reference/main_3dident.py:365-370: Sequential(backbone, nn.LeakyReLU(), nn.Linear(10 n_lat, n_lat), rescaling)).
+ * The backward takes the saved OUTPUT Yact (slope > 0). */
+int clica_leaky_relu_fwd(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t M, int32_t n, float slope,
+                         clica_stream_t stream);
+int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_t lddy, float* dX, int64_t lddx,
+                         int64_t M, int32_t n, float slope, clica_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Mixing network g  --  construct_invertible_mlp's nn.Sequential forward,
  * /root/reference/invertible_network_utils.py:87-115: bias-free n x n Linear layers with

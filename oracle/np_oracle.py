@@ -29,6 +29,11 @@ __all__ = [
 _CHUNK = 256  # rows per block of the pair matrix (bounds memory at B=6144: 256*6144*n*8 B)
 
 
+def _chunk_rows(cols: int, n: int) -> int:
+    """Rows per block so that one (rows, cols, n) fp64 temporary stays below ~512 MB (pools of 49 152 x 40)."""
+    return int(max(1, min(_CHUNK, (1 << 26) // max(1, cols * n))))
+
+
 # --------------------------------------------------------------------------------------
 # LpSimCLRLoss  (reference: losses.py:405-477, helper _logmeanexp losses.py:506-510)
 # --------------------------------------------------------------------------------------
@@ -109,6 +114,7 @@ def lp_simclr_loss(
 
     lse = np.empty(R, dtype)
     negs = []
+    _CHUNK = _chunk_rows(C, rows.shape[1])
     for r0 in range(0, R, _CHUNK):
         d = sgn * (rows[r0:r0 + _CHUNK, None, :] - cols[None, :, :]) + eps   # eps INSIDE abs (losses.py:436)
         s = _powabs(d, p).sum(-1)
@@ -135,7 +141,7 @@ def lp_simclr_loss(
     lse_raw = lse if compat else lse + math.log(C)
 
     d_rows = np.zeros_like(rows); d_cols = np.zeros_like(cols)
-    for r0 in range(0, R, _CHUNK):
+    for r0 in range(0, R, _CHUNK):        # _CHUNK: the adaptive block size chosen above
         sl = slice(r0, r0 + _CHUNK)
         d = sgn * (rows[sl, None, :] - cols[None, :, :]) + eps
         s = _powabs(d, p).sum(-1)
@@ -167,6 +173,33 @@ def lp_simclr_loss(
         dz1, dz3 = d_rows, d_cols
     out.update(dz1=dz1 + gp, dz2=-gp, dz3=dz3)
     return out
+
+
+def lp_symmetric_row_grads(z1_rows, z2_rows, pool, lse_rows, lse_pool, p, tau=1.0, alpha=0.5, local_rows=None,
+                           dtype=np.float64):
+    """Gradient of the data-parallel objective w.r.t. a set of LOCAL rows when the negatives pool is "all z1_rec of the global
+    batch" (main_mlp.py:272 z3_rec = roll(z1_rec)): with d_ij = d_ji the row part (weights w_ij = softmax of
+    row i) and the column part (w_ji = softmax of row j, from every rank) collapse into one sum over the pool,
+        dz1_i = gp_i - (C / tau) sum_j (w_ij + w_ji) d neg_ij / d z1_i ,    C = 2 (1 - alpha) / B_local   (compat mode, pow=True)
+    given the log-sum-exp of the rows (``lse_rows``) and of every pool row (``lse_pool``).  Returns (dz1, dz2) for the rows.
+    Used to check the engine's symmetric backward sweep at pool sizes where the full fp64 pair matrix is out of reach."""
+    z1 = np.asarray(z1_rows, dtype); z2 = np.asarray(z2_rows, dtype); P = np.asarray(pool, dtype)
+    Ls = np.asarray(lse_rows, dtype); Lp = np.asarray(lse_pool, dtype)
+    Bl = z1.shape[0] if local_rows is None else int(local_rows)
+    A = 2.0 * alpha / Bl; Cc = 2.0 * (1.0 - alpha) / Bl
+    dz1 = np.zeros_like(z1)
+    ch = _chunk_rows(P.shape[0], z1.shape[1])
+    for r0 in range(0, z1.shape[0], ch):
+        sl = slice(r0, r0 + ch)
+        d = z1[sl, None, :] - P[None, :, :]
+        neg = _powabs(d, p).sum(-1)
+        w = np.exp(-neg / tau - Ls[sl, None]) + np.exp(-neg / tau - Lp[None, :])
+        dz1[sl] = ((-(Cc / tau) * w)[:, :, None] * _dpowabs(d, p)).sum(1)
+    dpos = z1 - z2
+    pos = _powabs(dpos, p).sum(-1)
+    cpos = A / tau - Cc * np.exp(-pos / tau - Ls) / tau
+    gp = cpos[:, None] * _dpowabs(dpos, p)
+    return dz1 + gp, -gp
 
 
 # --------------------------------------------------------------------------------------

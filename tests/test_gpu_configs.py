@@ -1,0 +1,335 @@
+"""BASELINE.json configs 3-5 on the GPU:
+  C3  main_mlp.py --n 40 --space-type sphere --p 1 (2000-wide encoder = the engine's per-layer GEMM path; pool of 49 152)
+  C4  main_3dident.py encoder head + loss selection at B = 1024 (backbone features synthetic: torchvision is absent)
+  C5  kitti_masks BetaVAE_H conv encoder + Solver.train body (z_dim 5, p 1), up to the full 2048 x 1 x 64 x 64 batch
+against goldens generated from the imported reference (tests/golden/gen_goldens_r2.py) and the fp64 oracle."""
+import ctypes as C
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PARITY, conv_formula, fill_formula, formula_weights, golden_view, mlp_formula_params
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a, np.float32), device="cuda")
+
+
+def build_mlp(n, hidden, head):
+    from cl_ica_amd import encoders
+    f = encoders.get_mlp(n_in=n, n_out=n, layers=list(hidden), output_normalization=head)
+    Ws, bs, hp = mlp_formula_params(n, hidden, head)
+    for m, W, b in zip([m for m in f if isinstance(m, torch.nn.Linear)], Ws, bs):
+        m.weight.data = torch.tensor(W); m.bias.data = torch.tensor(b)
+    return f
+
+
+# ================================================================================================== C3
+def test_c3_wide_trainstep_goldens(golden):
+    """G13: the reference's train_step on the config-3 architecture (n = 40: 400/2000-wide layers; n = 12 with
+    --sphere-norm), injected sphere batches, p = 1, Adam.  The engine takes its per-layer GEMM path here (widths > 512)."""
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    G = golden("g13_wide_trainstep.npz")
+    for key, c in G.cases():
+        n, B = int(c["meta"]["n"]), int(c["meta"]["B"])
+        head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]; steps = int(c["meta"]["steps"]); stride = int(c["meta"]["stride"])
+        lr = float(c["meta"]["lr"])
+        f = build_mlp(n, hidden, head)
+        gW = dev(np.stack([c["in"][f"g{i}"] for i in range(3)]))
+        tr = ContrastiveTrainer(f, gW, SamplerSpec(space="sphere", n=n), batch_size=B, p=1, lr=lr, device="cuda")
+        assert not tr.fused_forward                                   # 2000 / 600-wide layers: per-layer gemm_k path
+        fam = "c3_wide_trainstep_g13"
+        for s in range(steps):
+            out = tr.step_injected(dev(c["in"][f"z1_{s}"]), dev(c["in"][f"z2_{s}"])).cpu().numpy()
+            PARITY.check(fam, f"{key} n={n} step{s}", "loss", out[0], c["out"]["loss"][s])
+            PARITY.check(fam, f"{key} n={n} step{s}", "pos_mean", out[1], c["out"]["pos"][s])
+            PARITY.check(fam, f"{key} n={n} step{s}", "neg_mean", out[2], c["out"]["neg"][s])
+            if s == 0:
+                PARITY.check(fam, f"{key} n={n} step0", "loss_i", tr.loss_out[:B].cpu().numpy(), c["out"]["loss_i0"])
+                L = len(tr.linears)
+                for name, prm in f.named_parameters():
+                    ref = c["out"][f"grad0/{name}"]
+                    got = golden_view(tr._gviews[id(prm)].cpu().numpy(), ref, stride)
+                    if name == f"{2 * (L - 1)}.bias" and head is None:
+                        # Lp distances are translation invariant: the exact gradient is 0, both sides hold rounding noise
+                        assert np.abs(got).max() < 1e-6 and np.abs(ref).max() < 1e-6
+                        continue
+                    PARITY.check(fam + "/grad", f"{key} n={n}", name, got.reshape(-1), ref.reshape(-1))
+        adam_trajectory_check(fam + "/adam_params", key, f, c["out"], "paramN", stride, lr, steps,
+                              skip=f"{2 * (len(tr.linears) - 1)}.bias" if head is None else None)
+
+
+def adam_trajectory_check(fam, key, module, out, prefix, stride, lr, steps, skip=None):
+    """Parameters after `steps` Adam updates.  Adam divides by sqrt(v): an element whose gradient is below its own fp32
+    rounding noise moves by +-lr per step in BOTH implementations, with a sign either may pick (the reference's own CPU
+    and GPU runs differ the same way).  So the parity statement is two-sided: (1) the norm-wise error of every tensor is
+    within the Adam noise ceiling 2 * lr * steps / max|param|; (2) the MEDIAN element error stays at fp32 resolution,
+    < 1e-6 of max|param|.  Gradients themselves are pinned at 1e-5 by the step-0 check above."""
+    for name, prm in module.named_parameters():
+        ref = out[f"{prefix}/{name}"]
+        got = golden_view(prm.detach().cpu().numpy(), ref, stride).reshape(-1)
+        ref = ref.reshape(-1)
+        scale = max(float(np.abs(ref).max()), 1e-30)
+        diff = np.abs(got.astype(np.float64) - ref)
+        if name == skip:
+            assert diff.max() <= steps * lr * 1.01
+            continue
+        PARITY.check(fam, key, name, got, ref, tol=max(1e-5, 2.0 * lr * steps / scale),
+                     note=f"Adam noise ceiling 2*lr*steps/max|param| (sign of sub-rounding-noise gradients)")
+        PARITY.check(fam + "_median", key, name, [float(np.median(diff))], [0.0], floor=scale, tol=1e-6, note="median element error")
+
+
+def test_c3_loss_pool_49152_sampled_rows_vs_oracle():
+    """Config 3's per-rank loss shape: B = 6144 local rows against the 8-rank pool of 49 152, n = 40, p = 1, through the
+    engine's entry points clica_lp_loss_fwd_train / clica_lp_loss_bwd_sym_train.  The fp64 oracle cannot hold the full
+    pair matrix (2.4e9 pairs), so 96 sampled rows are checked exactly: forward statistics against lp_simclr_loss (rows vs
+    full pool), gradients against lp_symmetric_row_grads given the pool rows' log-sum-exp."""
+    from cl_ica_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+    B, R, n, p, tau, alpha = 6144, 8, 40, 1, 1.0, 0.5
+    Bg = B * R
+    z_all = rng.normal(size=(Bg, n)); z_all /= np.linalg.norm(z_all, axis=1, keepdims=True)
+    zt_all = z_all + 0.05 * rng.normal(size=(Bg, n)); zt_all /= np.linalg.norm(zt_all, axis=1, keepdims=True)
+    z_all = (1.5 * z_all).astype(np.float32); zt_all = (1.5 * zt_all).astype(np.float32)      # encoder outputs are not unit norm
+    pool, pool2 = dev(z_all), dev(zt_all)
+    st = _lib.stream_ptr()
+
+    def fwd_train(rows, rows2, Bl):
+        d = _lib.LpLossDesc(B=Bl, B3=Bg, n=n, p=float(p), tau=tau, alpha=alpha, compat=1, pow=1)
+        nb = C.c_size_t()
+        _lib.check(lib.clica_lp_loss_train_workspace_bytes(C.byref(d), C.byref(nb)), "ws")
+        ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+        o = torch.empty(3 * Bl + 3, device="cuda"); dy = torch.empty(2 * Bl, n, device="cuda")
+        _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), rows.data_ptr(), n, rows2.data_ptr(), n, pool.data_ptr(), n,
+                                               o[:Bl].data_ptr(), o[Bl:2 * Bl].data_ptr(), o[2 * Bl:3 * Bl].data_ptr(),
+                                               dy[:Bl].data_ptr(), n, dy[Bl:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
+        return d, ws, o, dy
+
+    # log-sum-exp of EVERY pool row (what the ranks all-gather), rank by rank
+    lse_all = torch.empty(Bg, device="cuda")
+    for r in range(R):
+        sl = slice(r * B, (r + 1) * B)
+        _, _, o_r, _ = fwd_train(pool[sl], pool2[sl], B)
+        lse_all[sl] = o_r[2 * B:3 * B]
+    d, ws, o, dy = fwd_train(pool[:B], pool2[:B], B)
+    assert torch.equal(o[2 * B:3 * B], lse_all[:B])
+    _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(d), pool[:B].data_ptr(), n, pool.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                                               lse_all.data_ptr(), dy[:B].data_ptr(), n, o[3 * B:].data_ptr(), None,
+                                               ws.data_ptr(), ws.numel(), st), "bwd_sym_train")
+    torch.cuda.synchronize()
+    S = np.sort(rng.choice(B, size=96, replace=False))
+    orc = O.lp_simclr_loss(z_all[S], zt_all[S], z_all, p=p, tau=tau, alpha=alpha, compat=True, grad=False)
+    fam, case = "c3_loss_pool_49152", f"B={B} B3={Bg} n={n} p={p} (96 sampled rows)"
+    oc = o.cpu().numpy()
+    PARITY.check(fam, case, "loss_i", oc[:B][S], orc["loss_i"])
+    PARITY.check(fam, case, "pos_i", oc[B:2 * B][S], orc["pos"] / tau)
+    PARITY.check(fam, case, "lse_i", oc[2 * B:3 * B][S], orc["lse"])
+    # rows from other "ranks" too: their lse enters every local row's gradient
+    S2 = np.sort(rng.choice(Bg, size=64, replace=False))
+    orc2 = O.lp_simclr_loss(z_all[S2], zt_all[S2], z_all, p=p, tau=tau, alpha=alpha, compat=True, grad=False)
+    PARITY.check(fam, case, "lse_pool", lse_all.cpu().numpy()[S2], orc2["lse"])
+    g1, g2 = O.lp_symmetric_row_grads(z_all[S], zt_all[S], z_all, lse_all.cpu().numpy()[S], lse_all.cpu().numpy(), p, tau, alpha,
+                                      local_rows=B)
+    PARITY.check(fam, case, "dz1", dy[:B].cpu().numpy()[S], g1)
+    PARITY.check(fam, case, "dz2", dy[B:].cpu().numpy()[S], g2)
+    # whole-batch means against the per-item values (size-independent property)
+    assert abs(oc[3 * B] - oc[:B].astype(np.float64).mean()) < 1e-6 * abs(oc[3 * B])
+
+
+def test_c3_engine_full_size_vs_oracle():
+    """The n = 40 engine at the real per-rank batch (B = 6144 -> 12 288 stacked rows, 13.6 M parameters, p = 1, sphere
+    latents): loss and the whole gradient arena against the fp64 oracle (mixing net, MLP forward/backward, loss)."""
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(5)
+    n, B = 40, 6144
+    f = encoders.get_mlp(n, n, [n * 10, n * 50, n * 50, n * 50, n * 50, n * 10])
+    rng = np.random.default_rng(11)
+    gW = (rng.normal(size=(3, n, n)) / np.sqrt(n)).astype(np.float32)
+    z1 = rng.normal(size=(B, n)); z1 /= np.linalg.norm(z1, axis=1, keepdims=True)
+    z2 = z1 + 0.05 * rng.normal(size=(B, n)); z2 /= np.linalg.norm(z2, axis=1, keepdims=True)
+    z1 = z1.astype(np.float32); z2 = z2.astype(np.float32)
+    tr = ContrastiveTrainer(f, dev(gW), SamplerSpec(space="sphere", n=n), batch_size=B, p=1, lr=0.0, device="cuda")
+    assert not tr.fused_forward
+    out = tr.step_injected(dev(z1), dev(z2)).cpu().numpy()
+    lin = [m for m in f if isinstance(m, torch.nn.Linear)]
+    P = O.MLPParams([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin],
+                    [m.bias.detach().cpu().numpy().astype(np.float64) for m in lin])
+    xa = np.concatenate([O.mixing_forward(list(gW), z1), O.mixing_forward(list(gW), z2)])
+    y, cache = O.mlp_forward(P, xa)
+    ref = O.lp_simclr_loss(y[:B], y[B:], np.roll(y[:B], 1, 0), p=1, compat=True)
+    fam, case = "c3_engine_full_size", f"n={n} B={B} p=1"
+    PARITY.check(fam, case, "loss_mean", out[0], ref["loss_mean"])
+    PARITY.check(fam, case, "loss_i", tr.loss_out[:B].cpu().numpy(), ref["loss_i"])
+    gy = np.concatenate([ref["dz1"] + np.roll(ref["dz3"], -1, 0), ref["dz2"]])
+    PARITY.check(fam, case, "d_embeddings", tr.dy.cpu().numpy(), gy)
+    gr = O.mlp_backward(P, cache, gy)
+    for l, m in enumerate(lin):
+        PARITY.check(fam, case, f"dW{l}", tr._gviews[id(m.weight)].cpu().numpy(), gr["dW"][l])
+        if l < len(lin) - 1:          # last bias: exact gradient 0 (translation invariance)
+            PARITY.check(fam, case, f"db{l}", tr._gviews[id(m.bias)].cpu().numpy(), gr["db"][l])
+
+
+# ================================================================================================== C5 (KITTI)
+def test_c5_kitti_model_goldens(golden):
+    """G14 (a): BetaVAE_H forward/backward through the loss call of Solver.train -- state-dict layout, mu, loss, dmu and
+    every parameter gradient against the reference (conv stack on MIOpen, Linear / Softclip / loss on the HIP kernels)."""
+    from cl_ica_amd.kitti_masks.model import BetaVAE_H
+    from cl_ica_amd.losses import LpSimCLRLoss
+    G = golden("g14_kitti.npz")
+    for ci in range(int(G.z["n_model_cases"])):
+        c = G.case(f"m{ci:03d}")
+        box = bool(c["meta"]["box_norm"])
+        net = BetaVAE_H(z_dim=5, nc=1, box_norm=box)
+        assert list(net.state_dict().keys()) == [str(k) for k in c["meta"]["state_keys"]]
+        assert [",".join(map(str, v.shape)) for v in net.state_dict().values()] == [str(s) for s in c["meta"]["state_shapes"]]
+        fill_formula(net, conv_formula)
+        net = net.to("cuda")
+        x = dev(c["in"]["x"])
+        mu = net(x); mu.retain_grad()
+        z1, z2 = mu[::2], mu[1::2]
+        tot, per, (pm, nm) = LpSimCLRLoss(p=1, tau=1.0, simclr_compatibility_mode=True)(None, None, None, z1, z2, torch.roll(z1, 1, 0))
+        tot.backward()
+        fam, case = "c5_kitti_model_g14", f"m{ci:03d} box_norm={int(box)}"
+        PARITY.check(fam, case, "mu", mu.detach().cpu().numpy(), c["out"]["mu"])
+        PARITY.check(fam, case, "loss_mean", tot.item(), float(c["out"]["loss_mean"]))
+        PARITY.check(fam, case, "loss_i", per.detach().cpu().numpy(), c["out"]["loss_i"])
+        PARITY.check(fam, case, "pos_mean", pm.item(), float(c["out"]["pos_mean"]))
+        PARITY.check(fam, case, "neg_mean", nm.item(), float(c["out"]["neg_mean"]))
+        PARITY.check(fam, case, "dmu", mu.grad.cpu().numpy(), c["out"]["dmu"])
+        for name, prm in net.named_parameters():
+            ref = c["out"][f"grad/{name}"]
+            PARITY.check(fam + "/grad", case, name, golden_view(prm.grad.cpu().numpy(), ref, 29).reshape(-1), ref.reshape(-1))
+
+
+def test_c5_kitti_solver_goldens(golden, tmp_path):
+    """G14 (b): three iterations of Solver.train (kitti_masks/solver.py:52-96) -- the reference's own loop ran in the build
+    container -- per-iteration loss triple and the parameters after three Adam updates."""
+    from cl_ica_amd.kitti_masks.solver import Solver
+    G = golden("g14_kitti.npz")
+    for si in range(int(G.z["n_solver_cases"])):
+        c = G.case(f"s{si:03d}")
+        p, box, lr = int(c["meta"]["p"]), bool(c["meta"]["box_norm"]), float(c["meta"]["lr"])
+        d = tmp_path / f"s{si}"; d.mkdir()
+        args = types.SimpleNamespace(ckpt_dir=str(d), output_dir=str(d), dataset="kittimasks", cuda=True, max_iter=3, z_dim=5,
+                                     num_channel=1, lr=lr, beta1=0.9, beta2=0.999, box_norm=box, ckpt_name="last", log_step=1,
+                                     save_step=3, p=p)
+        batches = [(torch.tensor(c["in"][f"x_{s}"].astype(np.float32)), None) for s in range(3)]
+        S = Solver(args, data_loader=batches)
+        fill_formula(S.net, conv_formula)
+        rec = []
+        inner = S.loss
+
+        def recording(*a, inner=inner):
+            out = inner(*a)
+            rec.append((out[0].item(), out[2][0].item(), out[2][1].item(), out[1].detach().cpu().numpy()))
+            return out
+        S.loss = recording
+        assert S.train() is False and S.global_iter == 3
+        fam, case = "c5_kitti_solver_g14", f"s{si:03d} p={p} box_norm={int(box)}"
+        for s in range(3):
+            PARITY.check(fam, f"{case} iter{s}", "loss", rec[s][0], c["out"]["loss"][s])
+            PARITY.check(fam, f"{case} iter{s}", "pos_mean", rec[s][1], c["out"]["pos"][s])
+            PARITY.check(fam, f"{case} iter{s}", "neg_mean", rec[s][2], c["out"]["neg"][s])
+        PARITY.check(fam, f"{case} iter0", "loss_i", rec[0][3], c["out"]["loss_i0"])
+        adam_trajectory_check(fam + "/adam_params", case, S.net, c["out"], "param3", 29, lr, 3)
+        # log.csv + checkpoint in the reference's layout
+        lines = open(d / "log.csv").read().split()
+        assert lines[:2] == ["Total", "Loss"] and len(lines) == 5 and abs(float(lines[2]) - c["out"]["loss"][0]) < 1e-4
+        ck = torch.load(d / "last")
+        assert ck["iter"] == 3 and list(ck["model_states"]["net"].keys()) == list(S.net.state_dict().keys())
+        assert set(ck["optim_states"]["optim"]["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+
+
+def test_c5_kitti_full_batch_properties():
+    """Config 5's full shape (2048 x 1 x 64 x 64 images = 1024 pairs, z_dim 5, p 1): no fp64 reference fits the test
+    budget, so size-independent properties: (i) the per-item losses of a batch do not depend on the order of the pairs
+    (permutation equivariance of encoder + loss), (ii) loss mean = mean of items, (iii) the strided-view loss equals the
+    loss on contiguous copies, (iv) one optimizer step lowers the loss on the same batch, (v) finite gradients everywhere."""
+    from cl_ica_amd.kitti_masks.solver import Solver
+    import tempfile
+    d = tempfile.mkdtemp()
+    args = types.SimpleNamespace(ckpt_dir=d, output_dir=d, dataset="kittimasks", cuda=True, max_iter=1, z_dim=5, num_channel=1,
+                                 lr=1e-3, beta1=0.9, beta2=0.999, box_norm=False, ckpt_name="last", log_step=10, save_step=10, p=1)
+    S = Solver(args, data_loader=None)
+    fill_formula(S.net, conv_formula)
+    g = torch.Generator().manual_seed(0)
+    base = (torch.rand(1024, 1, 64, 64, generator=g) < 0.1).float()
+    shift = torch.roll(base, 1, 3)
+    x = torch.stack([base, shift], 1).reshape(2048, 1, 64, 64).cuda()           # interleaved temporal pairs
+    with torch.no_grad():
+        mu = S.net(x)
+        l0 = S.loss(None, None, None, mu[::2], mu[1::2], torch.roll(mu[::2], 1, 0))
+        perm = torch.randperm(1024, generator=g).cuda()
+        xp = x.reshape(1024, 2, 1, 64, 64)[perm].reshape(2048, 1, 64, 64)
+        mup = S.net(xp)
+        l1 = S.loss(None, None, None, mup[::2], mup[1::2], torch.roll(mup[::2], 1, 0))
+        l2 = S.loss(None, None, None, mu[::2].contiguous(), mu[1::2].contiguous(), torch.roll(mu[::2], 1, 0).contiguous())
+    PARITY.check("c5_kitti_full_batch", "2048x1x64x64 permuted pairs", "loss_i", l1[1].cpu().numpy(), l0[1][perm].cpu().numpy())
+    PARITY.check("c5_kitti_full_batch", "2048x1x64x64", "mean_of_items", l0[0].item(), l0[1].double().mean().item())
+    assert torch.equal(l0[1], l2[1])
+    before = S.train_iteration(x).item()
+    assert all(torch.isfinite(p.grad).all() for p in S.net.parameters())
+    with torch.no_grad():
+        mu = S.net(x)
+        after = S.loss(None, None, None, mu[::2], mu[1::2], torch.roll(mu[::2], 1, 0))[0].item()
+    assert abs(before - l0[0].item()) < 1e-6 * abs(before) and after < before
+
+
+# ================================================================================================== C4 (3DIdent)
+def test_c4_3dident_head_and_loss_goldens(golden):
+    """G15: main_3dident.py's head (LeakyReLU -> Linear(10 n_lat, n_lat) -> rescaling) and loss selection at B = 1024 on
+    synthetic backbone features, three Adam steps per mode (position-only l2 / l1+box, periodic rotation+colour, non-periodic
+    rotation+colour, vmf with a fixed sphere).  C4 is exercised at the head / loss boundary: the ResNet itself is
+    torchvision's (absent here) and stays on PyTorch-ROCm."""
+    from cl_ica_amd import threedident as T
+    from cl_ica_amd.optim import Adam
+    G = golden("g15_3dident.npz")
+    B = 1024
+    for ci, (key, c) in enumerate(G.cases()):
+        name = str(c["meta"]["name"]); n_lat = int(c["meta"]["n_lat"]); lr = float(c["meta"]["lr"])
+        a = types.SimpleNamespace(position_only=name.startswith("position_only"),
+                                  rotation_and_color_only="rotation_and_color" in name, rotation_only=False, color_only=False,
+                                  non_periodic_rotation_and_color=name.startswith("non_periodic"),
+                                  box_constraint="learnable" if "box_learnable" in name else None,
+                                  sphere_constraint="fix" if "sphere_fix" in name else None,
+                                  unsupervised_loss={("lp", 1.0): "l1", ("lp", 2.0): "l2", ("dot", 1.0): "vmf", ("dot", 0.0): "l2"}[
+                                      (str(c["meta"]["loss_kind"]), float(c["meta"]["loss_arg"]))],
+                                  identity_solution=False, encoder="rn18")
+        n_non = n_lat if (a.position_only or a.non_periodic_rotation_and_color) else 0
+        f = T.setup_f(a, n_non, n_lat - n_non, base_encoder=lambda pretrained, num_classes: torch.nn.Identity())
+        assert [k for k in f.state_dict().keys()] == ["2." + str(k).split(".", 1)[1] if str(k)[0] == "1" else
+                                                      "3." + str(k).split(".", 1)[1] for k in c["meta"]["state_keys"]]
+        fill_formula(f)
+        f = f.to("cuda")
+        loss = T.make_unsupervised_loss(a, n_non)
+        opt = Adam(f.parameters(), lr=lr)
+        fam = "c4_3dident_head_g15"
+        for s in range(3):
+            h1 = (formula_weights((B, 10 * n_lat), 700 + 10 * ci + s) * np.sqrt(10 * n_lat) * 1.5).astype(np.float32)
+            h2 = (h1 + 0.1 * formula_weights((B, 10 * n_lat), 800 + 10 * ci + s) * np.sqrt(10 * n_lat)).astype(np.float32)
+            t1 = dev(h1).requires_grad_(True); t2 = dev(h2).requires_grad_(True)
+            if s == 0:
+                with torch.no_grad():
+                    PARITY.check(fam, f"{name} step0", "z1_rec", f(t1).cpu().numpy(), c["out"]["z1_rec0"])
+            tot, per, lst = T.train_step(((None, None), (t1, t2)), loss, opt, f, sync=False)
+            PARITY.check(fam, f"{name} step{s}", "loss", tot.item(), c["out"]["loss"][s])
+            PARITY.check(fam, f"{name} step{s}", "pos_mean", lst[0].item(), c["out"]["pos"][s])
+            PARITY.check(fam, f"{name} step{s}", "neg_mean", lst[1].item(), c["out"]["neg"][s])
+            if s == 0:
+                PARITY.check(fam, f"{name} step0", "loss_i", per.detach().cpu().numpy(), c["out"]["loss_i0"])
+                PARITY.check(fam + "/grad", f"{name}", "d_features_1", t1.grad.cpu().numpy(), c["out"]["dh1_0"])
+                PARITY.check(fam + "/grad", f"{name}", "d_features_2", t2.grad.cpu().numpy(), c["out"]["dh2_0"])
+                for k, prm in f.named_parameters():
+                    rk = ("1." if k[0] == "2" else "2.") + k.split(".", 1)[1]
+                    PARITY.check(fam + "/grad", f"{name}", k, prm.grad.cpu().numpy(), c["out"][f"grad0/{rk}"])
+        ref_named = {("2." if k[0] == "1" else "3.") + k.split(".", 1)[1]: v for k, v in
+                     ((str(k)[len("param3/"):], v) for k, v in c["out"].items() if str(k).startswith("param3/"))}
+        adam_trajectory_check(fam + "/adam_params", name, f, {f"p/{k}": v for k, v in ref_named.items()}, "p", 1, lr, 3)

@@ -18,10 +18,14 @@ def free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-@pytest.mark.parametrize("B,n", [(512, 10), (300, 4)])
-def test_two_ranks_match_single_process(tmp_path, B, n):
+@pytest.mark.parametrize("B,n,wide,head", [(512, 10, False, None), (300, 4, False, None), (384, 10, True, None),
+                                            (256, 10, True, "learnable_box"), (256, 10, False, "learnable_sphere")])
+def test_two_ranks_match_single_process(tmp_path, B, n, wide, head):
+    """wide = 600-wide hidden layers: the per-layer GEMM path with the bucketed, two-stream overlapped all-reduce
+    (GradBuckets) under world = 2; head = a learnable output head whose gradient must be all-reduced too."""
     port = free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp2_worker.py"), str(r), str(port), str(tmp_path), str(B), str(n)],
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp2_worker.py"), str(r), str(port), str(tmp_path), str(B), str(n),
+                               "wide" if wide else "narrow", str(head)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
@@ -29,15 +33,25 @@ def test_two_ranks_match_single_process(tmp_path, B, n):
     sys.path.insert(0, HERE)
     from dp2_worker import make_problem
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
-    f, gW, z1, z2 = make_problem(n, 2 * B)
+    f, gW, z1, z2 = make_problem(n, 2 * B, wide, head)
     ref = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=2 * B, p=2, lr=0.0, device="cuda")
     out = ref.step_injected(z1, z2).cpu().numpy()
     r0, r1 = (np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(2))
+    from conftest import PARITY
     means = 0.5 * (r0["means"] + r1["means"])
-    assert np.abs(means - out).max() < 1e-5 * max(1.0, np.abs(out).max()), (means, out)
+    fam, case = "dp2_vs_single_process", f"B={B} n={n} wide={int(wide)} head={head}"
+    for k, nm in enumerate(("loss_mean", "pos_mean", "neg_mean")):
+        PARITY.check(fam, case, nm, means[k], out[k])
     li = np.concatenate([r0["loss_i"], r1["loss_i"]])
-    assert np.abs(li - ref.loss_out[:2 * B].cpu().numpy()).max() < 1e-5 * np.abs(li).max()
-    assert np.array_equal(r0["grad"], r1["grad"])                       # all-reduce: identical on both ranks
+    PARITY.check(fam, case, "loss_i", li, ref.loss_out[:2 * B].cpu().numpy())
+    assert np.array_equal(r0["grad"], r1["grad"])                       # all-reduce: identical on both ranks (incl. the head slot)
     g_ref = 2.0 * ref.grad_arena.cpu().numpy()
-    scale = np.abs(g_ref).max()
-    assert np.abs(r0["grad"] - g_ref).max() / scale < 2e-5, np.abs(r0["grad"] - g_ref).max() / scale
+    # per parameter tensor (the last bias has an exactly-zero gradient without a head: translation invariance)
+    off = 0
+    names = [k for k, _ in f.named_parameters()]
+    for k, prm in f.named_parameters():
+        sl = slice(off, off + prm.numel()); off += (prm.numel() + 3) // 4 * 4
+        if head is None and k == names[-1]:
+            assert np.abs(r0["grad"][sl]).max() < 1e-6
+            continue
+        PARITY.check(fam + "/grad", case, k, r0["grad"][sl], g_ref[sl])

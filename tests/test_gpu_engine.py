@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import mlp_formula_params
+from conftest import PARITY, mlp_formula_params
 
 pytestmark = pytest.mark.gpu
 
@@ -33,21 +33,14 @@ def test_trainstep_goldens(golden):
         tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=64, p=p, lr=float(c["meta"]["lr"]), device="cuda")
         for s in range(5):
             out = tr.step_injected(dev(c["in"][f"z1_{s}"]), dev(c["in"][f"z2_{s}"])).cpu().numpy()
-            assert abs(out[0] - c["out"]["loss"][s]) < 1e-5 * abs(c["out"]["loss"][s]), (key, s, out[0], c["out"]["loss"][s])
-            assert abs(out[1] - c["out"]["pos"][s]) < 1e-5 * max(1.0, abs(c["out"]["pos"][s]))
-            assert abs(out[2] - c["out"]["neg"][s]) < 1e-5 * max(1.0, abs(c["out"]["neg"][s]))
+            PARITY.check("trainstep_g7", f"{key} p={p} head={head} step{s}", "loss", out[0], c["out"]["loss"][s])
+            PARITY.check("trainstep_g7", f"{key} p={p} head={head} step{s}", "pos_mean", out[1], c["out"]["pos"][s])
+            PARITY.check("trainstep_g7", f"{key} p={p} head={head} step{s}", "neg_mean", out[2], c["out"]["neg"][s])
         assert tr.steps_done == 5
+        from test_gpu_configs import adam_trajectory_check
         L = len(tr.linears)
-        for name, prm in f.named_parameters():
-            ref = c["out"][f"param5/{name}"]
-            got = prm.detach().cpu().numpy()
-            got = got if ref.size == got.size else np.ascontiguousarray(got.reshape(-1)[::7])
-            diff = np.abs(got.reshape(-1) - ref.reshape(-1))
-            if name == f"{2 * (L - 1)}.bias" and head is None:
-                assert diff.max() <= 5 * float(c["meta"]["lr"]) * 1.01   # translation-invariant: gradient is noise
-                continue
-            assert np.median(diff) < 2e-6, (key, name)
-            assert (diff > 2e-4).mean() < 0.02, (key, name, float((diff > 2e-4).mean()))
+        adam_trajectory_check("trainstep_g7/adam_params", key, f, c["out"], "param5", 7, float(c["meta"]["lr"]), 5,
+                              skip=f"{2 * (L - 1)}.bias" if head is None else None)
 
 
 def test_engine_matches_autograd_path():
@@ -66,19 +59,16 @@ def test_engine_matches_autograd_path():
         ref_grads = {k: p.grad.clone() for k, p in f.named_parameters()}
         tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
         out = tr.step_injected(z1, z2)
-        assert abs(out[0].item() - tot.item()) < 2e-6 * abs(tot.item())
+        PARITY.check("engine_vs_autograd_dropin", f"head={head}", "loss", out[0].item(), tot.item())
         last_bias = f"{2 * (len(tr.linears) - 1)}.bias"
         for k, p in f.named_parameters():
             g = tr._gviews[id(p)]
-            if k == last_bias and head is None:
-                assert g.abs().max().item() < 1e-8     # translation invariance: exact gradient is 0
+            if k == last_bias:
+                # Lp distances are translation invariant: without a head the exact gradient is 0; with the sigmoid head it is a
+                # ~1e-7 residue of +-1e-4 summands.  Both paths hold summation-order noise there, nothing to compare.
+                assert g.abs().max().item() < (1e-8 if head is None else 1e-6)
                 continue
-            scale = max(ref_grads[k].abs().max().item(), 1e-12)
-            err = (g - ref_grads[k]).abs().max().item()
-            if k == last_bias:     # nearly translation invariant with a head too: a ~1e-7 residue of +-1e-4 summands,
-                assert err < 1e-8 or err / scale < 2e-4, (head, k)   # only the summation-order noise bound is meaningful
-                continue
-            assert err / scale < 2e-4, (head, k)
+            PARITY.check("engine_vs_autograd_dropin", f"head={head}", k, g.cpu().numpy(), ref_grads[k].cpu().numpy())
 
 
 def test_graph_replay_trains():

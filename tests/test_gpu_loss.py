@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import PARITY, rel_err
 from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -36,17 +36,33 @@ def run_hip(loss_obj, z1, z2, z3, roll=False):
     return out
 
 
-def compare(out, ref, lse_scale, gscale, grads, tol=TOL):
-    comp = max(float(np.abs(ref["loss_i"]).max()), lse_scale, 1e-30)
-    assert abs(out["loss_mean"] - float(ref["loss_mean"])) < tol * comp
-    assert np.abs(out["loss_i"] - ref["loss_i"]).max() < tol * comp
+def compare(family, case, out, ref, grads, sat_tol=None, note=None):
+    """Norm-wise relative error of every output against the reference golden, bound 1e-5 (north_star).
+    `sat_tol` (with `note`) is the documented allowance of a saturated case -- see saturation_allowance()."""
+    tol = TOL if sat_tol is None else sat_tol
+    PARITY.check(family, case, "loss_mean", out["loss_mean"], float(ref["loss_mean"]), tol=tol, note=note)
+    PARITY.check(family, case, "loss_i", out["loss_i"], ref["loss_i"], tol=tol, note=note)
     if "pos_mean" in ref:
-        assert abs(out["pos_mean"] - float(ref["pos_mean"])) < tol * max(1.0, abs(float(ref["pos_mean"])))
-        assert abs(out["neg_mean"] - float(ref["neg_mean"])) < tol * max(1.0, abs(float(ref["neg_mean"])), lse_scale)
-    sat = max(1.0, lse_scale)
+        PARITY.check(family, case, "pos_mean", out["pos_mean"], float(ref["pos_mean"]), tol=tol, note=note)
+        PARITY.check(family, case, "neg_mean", out["neg_mean"], float(ref["neg_mean"]), tol=tol, note=note)
     for g in grads:
-        scale = max(float(np.abs(ref[g]).max()), gscale, 1e-30)
-        assert np.abs(out[g] - ref[g]).max() / scale < tol * sat, g
+        PARITY.check(family, case, g, out[g], ref[g], tol=tol, note=note)
+
+
+def saturation_allowance(z1, z2, z3, p, tau, alpha, compat, pw, ref):
+    """Case-specific allowance for SATURATED softmax cases only.  There the per-row loss 2(a pos/tau + (1-a) lse) is a
+    difference of two O(|lse|) numbers and the fp32 REFERENCE golden itself is only accurate to eps32 * |lse| (its own
+    distance from the fp64 oracle is what is measured here).  Returns (tol, note): tol = 1e-5 unless the golden's own
+    fp32-vs-fp64 deviation exceeds 2.5e-6, in which case tol = 1e-5 + 2 x that deviation."""
+    orc = O.lp_simclr_loss(z1, z2, z3, p=p, tau=tau, alpha=alpha, compat=compat, pow=pw)
+    dev_ref = 0.0
+    for k in ("loss_i", "dz1", "dz2", "dz3"):
+        if k in ref and k in orc:
+            den = max(float(np.abs(orc[k]).max()), 1e-30)
+            dev_ref = max(dev_ref, float(np.abs(np.asarray(ref[k], np.float64) - orc[k]).max()) / den)
+    if dev_ref <= 2.5e-6:
+        return None, None
+    return TOL + 2.0 * dev_ref, f"saturated: fp32 reference golden deviates {dev_ref:.1e} from the fp64 oracle"
 
 
 @pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz"])
@@ -59,14 +75,10 @@ def test_lp_goldens(golden, name):
         L = LpSimCLRLoss(p=p, tau=float(m["tau"]), alpha=float(m["alpha"]),
                          simclr_compatibility_mode=bool(m["compat"]), pow=bool(m["pow"]))
         out = run_hip(L, c["in"]["z1"], c["in"]["z2"], c["in"]["z3"])
-        orc = O.lp_simclr_loss(c["in"]["z1"], c["in"]["z2"], c["in"]["z3"], p=float(m["p"]), tau=float(m["tau"]),
-                               alpha=float(m["alpha"]), compat=bool(m["compat"]), pow=bool(m["pow"]), grad=False)
-        lse_scale = float(np.abs(orc["lse"]).max()) + np.log(c["in"]["z3"].shape[0] + 1.0)
-        gs = grad_scale(c["in"]["z1"], c["in"]["z2"], float(m["p"]), float(m["tau"]), float(m["alpha"]))
-        try:
-            compare(out, c["out"], lse_scale, gs, ("dz1", "dz2", "dz3"))
-        except AssertionError as e:
-            raise AssertionError(f"{name}:{key} meta={ {k: v.tolist() for k, v in m.items()} }: {e}")
+        sat_tol, note = saturation_allowance(c["in"]["z1"], c["in"]["z2"], c["in"]["z3"], float(m["p"]), float(m["tau"]),
+                                             float(m["alpha"]), bool(m["compat"]), bool(m["pow"]), c["out"])
+        compare(f"lp_goldens/{name[:-4]}", f"{key} p={float(m['p']):g} tau={float(m['tau']):g} compat={int(m['compat'])} "
+                f"shape={c['in']['z1'].shape}x{c['in']['z3'].shape[0]}", out, c["out"], ("dz1", "dz2", "dz3"), sat_tol, note)
 
 
 def test_lp_roll_goldens(golden):
@@ -77,11 +89,10 @@ def test_lp_roll_goldens(golden):
         L = LpSimCLRLoss(p=int(m["p"]), tau=float(m["tau"]), simclr_compatibility_mode=True)
         out = run_hip(L, c["in"]["z1"], c["in"]["z2"], None, roll=True)
         z1 = c["in"]["z1"]
-        orc = O.lp_simclr_loss(z1, c["in"]["z2"], np.roll(z1, 1, 0), p=float(m["p"]), compat=True, grad=False)
-        lse_scale = float(np.abs(orc["lse"]).max()) + np.log(z1.shape[0] + 1.0)
-        gs = grad_scale(z1, c["in"]["z2"], float(m["p"]), 1.0, 0.5)
         assert not np.isnan(out["dz1"]).any()
-        compare(out, c["out"], lse_scale, gs, ("dz1", "dz2"))
+        sat_tol, note = saturation_allowance(z1, c["in"]["z2"], np.roll(z1, 1, 0), float(m["p"]), float(m["tau"]), 0.5, True, True,
+                                             {"loss_i": c["out"]["loss_i"], "dz2": c["out"]["dz2"]})
+        compare("lp_roll_goldens", f"{key} p={int(m['p'])} shape={z1.shape}", out, c["out"], ("dz1", "dz2"), sat_tol, note)
 
 
 def test_simclr_goldens(golden):
@@ -90,10 +101,7 @@ def test_simclr_goldens(golden):
         m = c["meta"]
         L = SimCLRLoss(normalize=bool(m["normalize"]), tau=float(m["tau"]), alpha=float(m["alpha"]))
         out = run_hip(L, c["in"]["z1"], c["in"]["z2"], c["in"]["z3"])
-        ref = c["out"]
-        lse_scale = float(np.abs(ref["neg_mean"])) + np.log(c["in"]["z3"].shape[0] + 1.0)
-        gscale = float(max(np.abs(c["in"]["z1"]).max(), 1.0)) / (c["in"]["z1"].shape[0] * float(m["tau"]))
-        compare(out, ref, lse_scale, gscale, ("dz1", "dz2", "dz3"))
+        compare("simclr_goldens", f"{key} norm={int(m['normalize'])} tau={float(m['tau']):g}", out, c["out"], ("dz1", "dz2", "dz3"))
 
 
 def test_strided_views(golden):
@@ -105,17 +113,17 @@ def test_strided_views(golden):
     a, b = mu[::2], mu[1::2]
     tot, per, (pm, nm) = LpSimCLRLoss(p=1, tau=1.0, simclr_compatibility_mode=True)(None, None, None, a, b, torch.roll(a, 1, 0))
     tot.backward()
-    assert abs(tot.item() - float(c["out"]["loss_mean"])) < TOL * 8
-    assert rel_err(per.detach().cpu().numpy(), c["out"]["loss_i"]) < TOL
-    assert np.abs(mu.grad.cpu().numpy() - c["out"]["dmu"]).max() < TOL * max(np.abs(c["out"]["dmu"]).max(), 2.0 / 32)
+    PARITY.check("strided_views", "kitti mu[::2]", "loss_mean", tot.item(), float(c["out"]["loss_mean"]))
+    PARITY.check("strided_views", "kitti mu[::2]", "loss_i", per.detach().cpu().numpy(), c["out"]["loss_i"])
+    PARITY.check("strided_views", "kitti mu[::2]", "dmu", mu.grad.cpu().numpy(), c["out"]["dmu"])
     c = G.case("ident")
     za = dev(c["in"]["z"]).requires_grad_(True); zb = dev(c["in"]["z2"]).requires_grad_(True)
     tot, per, _ = LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)(
         None, None, None, za[:, :3], zb[:, :3], torch.roll(za, 1, 0)[:, :3])
     tot.backward()
-    assert rel_err(per.detach().cpu().numpy(), c["out"]["loss_i"]) < TOL
-    assert np.abs(za.grad.cpu().numpy() - c["out"]["dz"]).max() < TOL * max(np.abs(c["out"]["dz"]).max(), 1e-3)
-    assert np.abs(zb.grad.cpu().numpy() - c["out"]["dz2"]).max() < TOL * max(np.abs(c["out"]["dz2"]).max(), 1e-3)
+    PARITY.check("strided_views", "ident z[:, :3]", "loss_i", per.detach().cpu().numpy(), c["out"]["loss_i"])
+    PARITY.check("strided_views", "ident z[:, :3]", "dz", za.grad.cpu().numpy(), c["out"]["dz"])
+    PARITY.check("strided_views", "ident z[:, :3]", "dz2", zb.grad.cpu().numpy(), c["out"]["dz2"])
 
 
 def test_analytic_kats():
@@ -144,16 +152,13 @@ def test_full_size_vs_oracle(B, B3, n, p):
         mean, per, (pm, nm) = LpSimCLRLoss(p=p, tau=0.8, alpha=0.4, simclr_compatibility_mode=compat)(None, None, None, a, b, c)
         (1.3 * mean + (per * dev(gi)).sum() + 0.4 * pm - 0.2 * nm).backward()
         orc = O.lp_simclr_loss(z1, z2, z3, p=p, tau=0.8, alpha=0.4, compat=compat, g_mean=1.3, g_item=gi, g_pos=0.4, g_neg=-0.2)
-        comp = float(np.abs(orc["lse"]).max()) + np.log(B3 + 1.0)
-        assert abs(mean.item() - orc["loss_mean"]) < TOL * comp
-        assert np.abs(per.detach().cpu().numpy() - orc["loss_i"]).max() < TOL * comp
-        assert abs(pm.item() - orc["pos_mean"]) < TOL * max(1.0, abs(orc["pos_mean"]))
-        assert abs(nm.item() - orc["neg_mean"]) < TOL * comp
-        gs = grad_scale(z1, z2, p, 0.8, 0.4) * 2.5
+        fam, case = "full_size_vs_fp64_oracle", f"B={B} B3={B3} n={n} p={p} compat={int(compat)}"
+        PARITY.check(fam, case, "loss_mean", mean.item(), orc["loss_mean"])
+        PARITY.check(fam, case, "loss_i", per.detach().cpu().numpy(), orc["loss_i"])
+        PARITY.check(fam, case, "pos_mean", pm.item(), orc["pos_mean"])
+        PARITY.check(fam, case, "neg_mean", nm.item(), orc["neg_mean"])
         for got, name in ((a.grad, "dz1"), (b.grad, "dz2"), (c.grad, "dz3")):
-            ref = orc[name]
-            scale = max(np.abs(ref).max(), gs if name != "dz3" else 0.0, 1e-30)
-            assert np.abs(got.cpu().numpy() - ref).max() / scale < TOL * max(1.0, comp), (name, compat)
+            PARITY.check(fam, case, name, got.cpu().numpy(), orc[name])
 
 
 def test_permutation_invariance_and_roll_identity():
@@ -226,19 +231,18 @@ def test_uniformity_alignment_vs_golden(golden):
         z1 = dev(u["in"]["z1"]).requires_grad_(True); z3 = dev(u["in"]["z3"]).requires_grad_(True)
         tot, per, extra = UniformityLoss(p)(z1, z3)
         tot.backward()
-        comp = max(float(np.abs(u["out"]["loss_i"]).max()) + np.log(z1.shape[0]), 1.0)
-        assert abs(tot.item() - float(u["out"]["loss_mean"])) < TOL * comp and extra[0] is tot
-        assert np.abs(per.detach().cpu().numpy() - u["out"]["loss_i"]).max() < TOL * comp
+        assert extra[0] is tot
+        PARITY.check("uniformity_goldens", f"u{i:03d} p={p:g}", "loss_mean", tot.item(), float(u["out"]["loss_mean"]))
+        PARITY.check("uniformity_goldens", f"u{i:03d} p={p:g}", "loss_i", per.detach().cpu().numpy(), u["out"]["loss_i"])
         for name, t in (("dz1", z1), ("dz3", z3)):
-            d = np.abs(np.asarray(u["in"]["z1"], np.float64)[None] - np.asarray(u["in"]["z3"], np.float64)[:, None])
-            scale = max(np.abs(u["out"][name]).max(), float((p * np.maximum(d, 1e-12) ** (p - 1)).max()) / z3.shape[0])
-            assert np.abs(t.grad.cpu().numpy() - u["out"][name]).max() / scale < TOL * comp, (i, name)
+            PARITY.check("uniformity_goldens", f"u{i:03d} p={p:g}", name, t.grad.cpu().numpy(), u["out"][name])
         a = G.case(f"a{i:03d}")
         z1 = dev(a["in"]["z1"]).requires_grad_(True); z2 = dev(a["in"]["z2"]).requires_grad_(True)
         tot, per, _ = AlignmentLoss(p)(z1, z2)
         tot.backward()
-        assert abs(tot.item() - float(a["out"]["loss_mean"])) < TOL * max(1.0, abs(float(a["out"]["loss_mean"])))
-        assert rel_err(per.detach().cpu().numpy(), a["out"]["loss_i"]) < TOL
-        assert rel_err(z1.grad.cpu().numpy(), a["out"]["dz1"]) < TOL and rel_err(z2.grad.cpu().numpy(), a["out"]["dz2"]) < TOL
+        PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "loss_mean", tot.item(), float(a["out"]["loss_mean"]))
+        PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "loss_i", per.detach().cpu().numpy(), a["out"]["loss_i"])
+        PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz1", z1.grad.cpu().numpy(), a["out"]["dz1"])
+        PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz2", z2.grad.cpu().numpy(), a["out"]["dz2"])
     with pytest.raises(NotImplementedError):
         UniformityLoss(0.5)(z1, z2)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import formula_weights, mlp_formula_params, rel_err
+from conftest import PARITY, formula_weights, mlp_formula_params, rel_err
 from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -78,14 +78,15 @@ def test_mlp_goldens(golden):
         x = dev(c["in"]["x"]).requires_grad_(True)
         y = f(x)
         y.backward(dev(c["in"]["gy"]))
-        assert rel_err(y.detach().cpu().numpy(), c["out"]["y"]) < 1e-5, key
-        assert rel_err(x.grad.cpu().numpy(), c["out"]["dx"]) < 2e-5, key
+        case = f"{key} n={n} head={head} hidden={hidden}"
+        PARITY.check("mlp_goldens_g6", case, "y", y.detach().cpu().numpy(), c["out"]["y"])
+        PARITY.check("mlp_goldens_g6", case, "dx", x.grad.cpu().numpy(), c["out"]["dx"])
         for name, prm in f.named_parameters():
             got = prm.grad.cpu().numpy()
             if f"grad/{name}" in c["out"]:
-                assert rel_err(got, c["out"][f"grad/{name}"]) < 2e-5, (key, name)
+                PARITY.check("mlp_goldens_g6/grad", case, name, got, c["out"][f"grad/{name}"])
             else:
-                assert rel_err(np.ascontiguousarray(got.reshape(-1)[::97]), c["out"][f"gradsub/{name}"]) < 2e-5, (key, name)
+                PARITY.check("mlp_goldens_g6/grad", case, name, np.ascontiguousarray(got.reshape(-1)[::97]), c["out"][f"gradsub/{name}"])
 
 
 def test_mixing_golden(golden):

@@ -1,0 +1,130 @@
+"""SURVEY.md 8(f) "next" rows on the GPU: N3 checkpoint compatibility with reference-written state dicts (G16), N2 evaluation
+metrics on device tensors (G11), plus regression tests for round-1 advisor findings."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PARITY
+
+pytestmark = pytest.mark.gpu
+CKPT = os.path.join(GOLDEN, "g16_ckpt")
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a, np.float32), device="cuda")
+
+
+def test_n3_reference_checkpoints_load_and_reproduce(golden, tmp_path):
+    """unsup_f.pth-style state dicts torch.save'd BY THE REFERENCE's get_mlp modules (every head) and its g.pth load into
+    FusedMLP / MixingMLP with strict key matching and reproduce the reference's forward on the GPU; saving them again gives
+    a file with identical keys, shapes and bits (main_mlp.py:245-248, 373-381)."""
+    from cl_ica_amd import encoders, invertible_network_utils as inu
+    z = golden("g16_ckpt.npz").z
+    x = dev(z["x"])
+    for tag in [str(t) for t in z["names"]]:
+        head = tag[2:]; head = None if head == "None" else head
+        hidden = [int(h) for h in z[f"{tag}/hidden"]]
+        sd = torch.load(os.path.join(CKPT, tag + ".pth"), map_location="cpu")
+        f = encoders.get_mlp(4, 4, list(hidden), output_normalization=head)
+        missing = f.load_state_dict(sd, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        f = f.to("cuda")
+        PARITY.check("n3_checkpoints_g16", tag, "forward", f(x).detach().cpu().numpy(), z[f"{tag}/y"])
+        out = tmp_path / (tag + "_resaved.pth")
+        torch.save(f.state_dict(), out)
+        sd2 = torch.load(out, map_location="cpu")
+        assert list(sd2.keys()) == list(sd.keys())
+        for k in sd:
+            assert sd2[k].shape == sd[k].shape and torch.equal(sd2[k], sd[k]), (tag, k)
+    # g.pth into a freshly constructed mixing net AFTER its stack cache was built (advisor finding: stale cache)
+    np.random.seed(0)
+    g = inu.construct_invertible_mlp(n=4, n_layers=3, act_fct="leaky_relu", cond_thresh_ratio=0.0, n_iter_cond_thresh=50).to("cuda")
+    before = g(x).clone()
+    sd = torch.load(os.path.join(CKPT, "g.pth"), map_location="cpu")
+    assert list(sd.keys()) == list(g.state_dict().keys())
+    g.load_state_dict(sd, strict=True)
+    y = g(x)
+    assert not torch.allclose(before, y)
+    PARITY.check("n3_checkpoints_g16", "g.pth", "forward", y.cpu().numpy(), z["g/y"])
+    # the trainer's view of g is the same stack
+    assert torch.equal(g.weight_stack().cpu(), torch.stack([sd[k] for k in sd]))
+
+
+def test_n2_metrics_on_device(golden):
+    """R^2 / MCC of the periodic evaluation (disentanglement_utils.py:63-221) with DEVICE tensors in, against the
+    reference's sklearn + Munkres values (G11)."""
+    from cl_ica_amd import disentanglement_utils as du
+    z9 = golden("g11_metrics.npz").z
+    for i in range(int(z9["n_cases"])):
+        z, hz = dev(z9[f"c{i}/z"]), dev(z9[f"c{i}/hz"])
+        (r2, none), (z2, pred) = du.linear_disentanglement(z, hz, mode="r2")
+        assert none is None and pred.shape == z.shape and pred.is_cuda
+        PARITY.check("n2_metrics_g11", f"c{i}", "r2", r2, float(z9[f"c{i}/r2"]))
+        (mcc, corr), thz = du.permutation_disentanglement(z, hz, mode="pearson", solver="munkres", rescaling=True)
+        PARITY.check("n2_metrics_g11", f"c{i}", "mcc", mcc, float(z9[f"c{i}/mcc"]))
+        PARITY.check("n2_metrics_g11", f"c{i}", "corr_diag", np.abs(np.diag(corr)), np.abs(z9[f"c{i}/corr_diag"]))
+        assert thz.shape == z.shape and thz.is_cuda
+
+
+def test_autograd_loss_uses_forward_rowgrad_and_matches_row_pass():
+    """Advisor finding: the flash-style row gradient of the forward sweep was never requested from losses.py.  Now it is
+    whenever z1_rec needs a gradient; the result must equal the recomputing row pass of clica_lp_loss_bwd (rowgrad = NULL)."""
+    import ctypes as C
+    from cl_ica_amd import _lib
+    from cl_ica_amd.losses import LpSimCLRLoss, SimCLRLoss, _PairLossFn
+    torch.manual_seed(0)
+    B, B3, n = 700, 900, 10
+    z1 = torch.randn(B, n, device="cuda") * 0.7; z2 = z1 + 0.05 * torch.randn_like(z1); z3 = torch.randn(B3, n, device="cuda") * 0.7
+    lib = _lib.load()
+    for p in (1, 2, 3):
+        a = z1.clone().requires_grad_(True); b = z2.clone().requires_grad_(True); c = z3.clone().requires_grad_(True)
+        L = LpSimCLRLoss(p=p, tau=0.9, alpha=0.4, simclr_compatibility_mode=True)
+        tot, per, _ = L(None, None, None, a, b, c)
+        assert tot.grad_fn.rowgrad is not None            # the forward accumulated the row gradient
+        tot.backward()
+        d = L._desc(B, B3, n)
+        fb, bb = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(d), C.byref(fb), C.byref(bb)), "ws")
+        ws = torch.zeros(max(fb.value, bb.value), dtype=torch.uint8, device="cuda")
+        o = torch.empty(3 * B + 3, device="cuda")
+        dz = [torch.empty(B, n, device="cuda"), torch.empty(B, n, device="cuda"), torch.empty(B3, n, device="cuda")]
+        _lib.check(lib.clica_lp_loss_fwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
+                                         o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), None, n,
+                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "fwd")
+        _lib.check(lib.clica_lp_loss_bwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                                         None, n, None, None, None, None, dz[0].data_ptr(), n, dz[1].data_ptr(), n, dz[2].data_ptr(), n, 0,
+                                         ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "bwd")
+        torch.cuda.synchronize()
+        for got, ref, nm in ((a.grad, dz[0], "dz1"), (b.grad, dz[1], "dz2"), (c.grad, dz[2], "dz3")):
+            PARITY.check("rowgrad_vs_row_pass", f"p={p}", nm, got.cpu().numpy(), ref.cpu().numpy(), tol=3e-6, note="HIP vs HIP")
+    # z1 without gradient: no row gradient is requested
+    tot, _, _ = LpSimCLRLoss(p=2)(None, None, None, z1, z2.clone().requires_grad_(True), z3)
+    assert tot.grad_fn.rowgrad is None
+
+
+def test_flat_adam_matches_torch_adam():
+    """cl_ica_amd.optim.Adam (one HIP launch over a flat arena) against torch.optim.Adam on the same gradients, and its
+    state_dict in torch's layout."""
+    from cl_ica_amd.optim import Adam
+    torch.manual_seed(0)
+    mk = lambda: torch.nn.Sequential(torch.nn.Linear(7, 13), torch.nn.Linear(13, 5)).cuda()   # noqa: E731
+    a, b = mk(), mk()
+    b.load_state_dict(a.state_dict())
+    oa, ob = Adam(a.parameters(), lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    for s in range(6):
+        x = torch.randn(32, 7, device="cuda")
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            (m(x) ** 2).mean().backward()
+            o.step()
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        PARITY.check("flat_adam_vs_torch", "6 steps", k, p.detach().cpu().numpy(), q.detach().cpu().numpy(), tol=2e-6, note="vs torch.optim.Adam")
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys() and int(sa["state"][0]["step"]) == 6
+    for i in sa["state"]:
+        assert torch.allclose(sa["state"][i]["exp_avg"], sb["state"][i]["exp_avg"], rtol=1e-5, atol=1e-8)
+    oc = Adam(mk().parameters(), lr=1.0)
+    oc.load_state_dict(sa)
+    assert oc.param_groups[0]["lr"] == 1e-2 and int(oc.step_dev.item()) == 6 and torch.equal(oc.exp_avg, oa.exp_avg)

@@ -2,12 +2,13 @@
 construction KAT, fail-loud behaviour on CPU tensors, arena flattening, gradient bucketing."""
 import contextlib
 import io
+import os
 
 import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import ROOT as ROOT_DIR, rel_err
 
 
 def test_get_mlp_structure_and_state_dict(golden):
@@ -87,10 +88,12 @@ def test_no_cpu_fallback_anywhere():
     with pytest.raises(RuntimeError):
         spaces.NSphereSpace(3).uniform(5, device="cpu")
     import cl_ica_amd
-    import pkgutil
-    for m in pkgutil.iter_modules(cl_ica_amd.__path__):
-        src = open(f"{cl_ica_amd.__path__[0]}/{m.name}.py").read()
-        assert "import oracle" not in src and "from oracle" not in src, m.name
+    import glob
+    srcs = glob.glob(f"{cl_ica_amd.__path__[0]}/**/*.py", recursive=True)
+    assert len(srcs) >= 15
+    for path in srcs:      # every module of the package, sub-packages included
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path
 
 
 def test_loss_ctor_surface():
@@ -196,3 +199,47 @@ def test_train_mlp_cli_surface():
     assert (s.space, s.conditional, s.marginal) == ("sphere", "vmf", "laplace")
     s = train_mlp.sampler_spec(train_mlp.parse_args(["--space-type", "unbounded", "--c-p", "3", "--m-p", "2"]), 0)
     assert (s.space, s.conditional, s.marginal, s.c_p) == ("real", "gennorm", "normal", 3.0)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_n3_our_checkpoints_load_into_the_reference():
+    """The reverse direction of tests/test_gpu_next_rows.py::test_n3_*: state dicts saved from cl_ica_amd's get_mlp /
+    MixingMLP / BetaVAE_H load into the REFERENCE's modules with strict key matching (same keys, shapes, values)."""
+    import subprocess, sys, tempfile, textwrap
+    code = textwrap.dedent('''
+        import sys, io, contextlib, warnings
+        warnings.filterwarnings("ignore")
+        import numpy as np, torch
+        sys.path.insert(0, "%s")
+        from cl_ica_amd import encoders as E, invertible_network_utils as I
+        from cl_ica_amd.kitti_masks.model import BetaVAE_H as K
+        ours = {}
+        for head in (None, "learnable_sphere", "learnable_box", "fixed_sphere", "fixed_box"):
+            ours["f_%%s" %% head] = E.get_mlp(4, 4, [12, 20, 12], output_normalization=head).state_dict()
+        np.random.seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ours["g"] = I.construct_invertible_mlp(n=4, n_layers=3, cond_thresh_ratio=0.0, n_iter_cond_thresh=50).state_dict()
+        ours["kitti"] = K(z_dim=5, nc=1, box_norm=True).state_dict()
+        torch.save(ours, sys.argv[1])
+        for m in [k for k in sys.modules if k.split(".")[0] == "cl_ica_amd"]:
+            del sys.modules[m]
+        sys.path.insert(0, "/root/reference")
+        import encoders as RE, invertible_network_utils as RI
+        from kitti_masks.model import BetaVAE_H as RK
+        ours = torch.load(sys.argv[1])
+        for head in (None, "learnable_sphere", "learnable_box", "fixed_sphere", "fixed_box"):
+            r = RE.get_mlp(4, 4, [12, 20, 12], output_normalization=head)
+            res = r.load_state_dict(ours["f_%%s" %% head], strict=True)
+            assert not res.missing_keys and not res.unexpected_keys
+            for k, v in r.state_dict().items():
+                assert torch.equal(v, ours["f_%%s" %% head][k])
+        with contextlib.redirect_stdout(io.StringIO()):
+            rg = RI.construct_invertible_mlp(n=4, n_layers=3, cond_thresh_ratio=0.0, n_iter_cond_thresh=50)
+        rg.load_state_dict(ours["g"], strict=True)
+        RK(z_dim=5, nc=1, box_norm=True).load_state_dict(ours["kitti"], strict=True)
+        print("ok")
+    ''') % ROOT_DIR
+    with tempfile.TemporaryDirectory() as d:
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "ours.pth")], capture_output=True, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
