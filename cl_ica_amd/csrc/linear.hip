@@ -443,15 +443,178 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
   }
 }
 
+// ---- weight gradient of a layer with one TINY dimension (the n-wide first / last encoder layer) on the vector ALU ----
+// dW[N,K] = dZ^T X with S = min(N, K) <= 16 and Lg = max(N, K) <= THREADS.  As a 128 x 128 MFMA tile such a layer is
+// > 90 % padding AND takes the slow register-staged body (its rows are not 16-byte aligned), which made its items the
+// tail of the grouped launch (+37 us of 244 at n = 10).  Here: thread (group gq, large index l) keeps the S outputs
+// (l, 0..S-1) in registers; per batch row it reads its own large-operand element and the row's S small-operand elements
+// (wave-uniform ds_read_b128 broadcasts) and does S FMAs; the THREADS / Lg groups take interleaved rows and are summed
+// through LDS in fixed order at the end.  Row tiles are register-prefetched one tile ahead.  A work item covers
+// k_per_split batch rows and writes one slab, exactly like the MFMA items (same deterministic slab reduction).
+constexpr int MAXG = 8;            // problems (layers) per grouped launch
+constexpr int TINY_MAX_S = 16;
+constexpr int TINY_ROWS = 64;       // batch rows per LDS tile
+// global -> LDS copy of `count` floats of a row block: flat float4 when the block is contiguous and aligned (the
+// encoder's activations / gradients are), element-wise otherwise.  Eight loads are in flight per thread and pass.
+template <int THREADS>
+__device__ __forceinline__ void tiny_stage(float* dst, int dst_ld, const float* __restrict__ src, int64_t ld, int width,
+                                           int64_t r0, int rows_valid, int rows_tile) {
+  const bool flat = ld == width && dst_ld == width && ((reinterpret_cast<uintptr_t>(src + r0 * ld) & 15) == 0) && ((rows_valid * width) % 4 == 0);
+  if (flat) {
+    const float4* s4 = reinterpret_cast<const float4*>(src + r0 * ld);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    const int n4 = rows_valid * width / 4, t4 = rows_tile * width / 4;
+    for (int i0 = threadIdx.x; i0 < t4; i0 += 8 * THREADS) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * THREADS; v[u] = i < n4 ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * THREADS; if (i < t4) d4[i] = v[u]; }
+    }
+    // a tile whose float count is not a multiple of 4 past n4 * 4: covered by rows_valid * width % 4 == 0 above
+  } else {
+    const int nt = rows_tile * width;
+    for (int i0 = threadIdx.x; i0 < nt; i0 += 8 * THREADS) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * THREADS;
+        const int r = i / width, c = i - r * width;
+        const bool ok = i < nt && r < rows_valid;
+        const float x = src[ok ? (r0 + r) * ld + c : 0];
+        v[u] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * THREADS;
+        if (i < nt) { const int r = i / width, c = i - r * width; dst[r * dst_ld + c] = v[u]; }
+      }
+    }
+  }
+}
+template <int THREADS>
+__device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = (int)g.M, K = (int)g.N;               // dW is [N][K]; A = dZ [rows][N], B = X [rows][K]
+  const bool a_large = N >= K;                          // large operand: A (outputs (l, u) = dW[l][u]) or B (dW[u][l])
+  const int Lg = a_large ? N : K, S = a_large ? K : N;
+  const float* Lp = a_large ? g.A : g.B; const int64_t ldl = a_large ? g.lda : g.ldb;
+  const float* Sp = a_large ? g.B : g.A; const int64_t lds_ = a_large ? g.ldb : g.lda;
+  const int G = THREADS / Lg;                           // row-interleaved thread groups
+  const int gq = threadIdx.x / Lg, l = threadIdx.x - gq * Lg;
+  const bool active = gq < G;
+  float* Ls = smem;                                     // [TINY_ROWS][Lg]
+  float* Ss = smem + TINY_ROWS * Lg;                    // [TINY_ROWS][S]  (S padded to 16 for the broadcast reads below)
+  const int64_t kbeg = (int64_t)bz * g.k_per_split, kend = min(g.Kc, kbeg + g.k_per_split);
+  float acc[TINY_MAX_S];
+#pragma unroll
+  for (int u = 0; u < TINY_MAX_S; ++u) acc[u] = 0.f;
+  float accl = 0.f;                                     // column sum of the large operand (db when A is large)
+  float accs[TINY_MAX_S];                               // column sums of the small operand (db when A is small), thread l == 0
+#pragma unroll
+  for (int u = 0; u < TINY_MAX_S; ++u) accs[u] = 0.f;
+  const bool want_db = g.dbias_slab != nullptr;
+  const bool small_db = want_db && !a_large && l == 0;
+  for (int64_t r0 = kbeg; r0 < kend; r0 += TINY_ROWS) {
+    const int rv = (int)min((int64_t)TINY_ROWS, kend - r0);
+    __syncthreads();                                    // every thread is done with the previous tile
+    tiny_stage<THREADS>(Ls, Lg, Lp, ldl, Lg, r0, rv, TINY_ROWS);
+    {   // small operand: 16 threads per row (division-free), THREADS / 16 rows per pass
+      const int c = threadIdx.x & (TINY_MAX_S - 1);
+      constexpr int RPP = THREADS / TINY_MAX_S;
+      float sv[TINY_ROWS / RPP];
+#pragma unroll
+      for (int ps = 0; ps < TINY_ROWS / RPP; ++ps) {
+        const int r = (threadIdx.x >> 4) + ps * RPP;
+        const bool ok = c < S && r < rv;
+        const float x = Sp[ok ? (r0 + r) * lds_ + c : 0];
+        sv[ps] = ok ? x : 0.f;
+      }
+#pragma unroll
+      for (int ps = 0; ps < TINY_ROWS / RPP; ++ps) Ss[((threadIdx.x >> 4) + ps * RPP) * TINY_MAX_S + c] = sv[ps];
+    }
+    __syncthreads();
+    if (active) {
+      for (int r = gq; r < rv; r += G) {
+        const float v = Ls[r * Lg + l];
+        const float4* sr = reinterpret_cast<const float4*>(&Ss[r * TINY_MAX_S]);
+        accl += v;
+#pragma unroll
+        for (int u4 = 0; u4 < TINY_MAX_S / 4; ++u4) {
+          if (4 * u4 < S) {                             // columns S .. 4*ceil(S/4)-1 of Ss hold stale data: masked below
+            const float4 sv = sr[u4];
+            acc[4 * u4 + 0] = fmaf(v, sv.x, acc[4 * u4 + 0]); acc[4 * u4 + 1] = fmaf(v, sv.y, acc[4 * u4 + 1]);
+            acc[4 * u4 + 2] = fmaf(v, sv.z, acc[4 * u4 + 2]); acc[4 * u4 + 3] = fmaf(v, sv.w, acc[4 * u4 + 3]);
+            if (small_db) {
+              accs[4 * u4 + 0] += sv.x; accs[4 * u4 + 1] += sv.y; accs[4 * u4 + 2] += sv.z; accs[4 * u4 + 3] += sv.w;
+            }
+          }
+        }
+      }
+    }
+  }
+  // fixed-order sum over the G groups through LDS: red[gq][l][0..16]  (17 floats per (gq, l): conflict-free stride)
+  __syncthreads();
+  constexpr int RS = TINY_MAX_S + 1;
+  float* red = smem;
+  if (active) {
+#pragma unroll
+    for (int u = 0; u < TINY_MAX_S; ++u) red[(gq * Lg + l) * RS + u] = acc[u];
+    red[(gq * Lg + l) * RS + TINY_MAX_S] = accl;
+  }
+  float* red2 = smem + (size_t)G * Lg * RS;             // [G][16] small-operand column sums
+  if (active && l == 0) {
+#pragma unroll
+    for (int u = 0; u < TINY_MAX_S; ++u) red2[gq * TINY_MAX_S + u] = accs[u];
+  }
+  __syncthreads();
+  float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+  for (int o = threadIdx.x; o < Lg * S; o += THREADS) {
+    const int ll = o / S, u = o - ll * S;
+    float t = 0.f;
+    for (int q = 0; q < G; ++q) t += red[(q * Lg + ll) * RS + u];
+    if (a_large) Cbase[(int64_t)ll * g.ldc + u] = t; else Cbase[(int64_t)u * g.ldc + ll] = t;
+  }
+  if (want_db) {
+    float* dbs = g.dbias_slab + (int64_t)bz * g.M;
+    if (a_large) {
+      for (int ll = threadIdx.x; ll < Lg; ll += THREADS) {
+        float t = 0.f;
+        for (int q = 0; q < G; ++q) t += red[(q * Lg + ll) * RS + TINY_MAX_S];
+        dbs[ll] = t;
+      }
+    } else {
+      for (int u = threadIdx.x; u < S; u += THREADS) {
+        float t = 0.f;
+        for (int q = 0; q < G; ++q) t += red2[q * TINY_MAX_S + u];
+        dbs[u] = t;
+      }
+    }
+  }
+}
+// One launch for all tiny-dimension layers of a group, BEFORE the grouped MFMA launch: grid (row chunks, problems).  The body is
+// latency-bound per tile (a 64-row tile is ~0.2 us of FMAs behind a ~1-2 us fetch), so the rows are cut into many short
+// chunks that all run at once on the otherwise idle chip (~5 us) -- as long items inside the MFMA launch they crawled
+// behind its HBM traffic and became its tail.
+constexpr int TINY_THREADS = 256;
+struct TinyArgs { int n; Args p[MAXG]; };
+__global__ __launch_bounds__(TINY_THREADS) void wgrad_tiny_k(TinyArgs T) {
+  wgrad_tiny_body<TINY_THREADS>(T.p[blockIdx.y], (int)blockIdx.x);
+}
+constexpr int TINY_MAX_LG = 128;    // LDS tile [TINY_ROWS][Lg] = 64 KB
+static bool tiny_eligible(int64_t N, int64_t K, int threads) {
+  const int64_t S = N < K ? N : K, Lg = N < K ? K : N;
+  return S <= TINY_MAX_S && Lg <= TINY_MAX_LG && Lg <= threads;
+}
+
 // ---- grouped weight gradients: every layer's dW/db slabs in ONE launch ------------------------------
 // Work item = (problem, contraction split, tile); all items cover the same number of batch rows, so the
 // launch is a few full rounds of equal-length workgroups instead of one ragged launch (+ reduction) per layer.
-constexpr int MAXG = 8;
 struct GroupArgs {
   int n, total;
   int first[MAXG + 1];    // first work item of each problem
   int gx[MAXG], gy[MAXG]; // tiles along N / M
-  int vec[MAXG];
+  int vec[MAXG];          // 1: direct global -> LDS MFMA body; 0: register-staged MFMA body
   Args p[MAXG];
 };
 
@@ -465,7 +628,7 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_group_k(GroupArgs G) {
   const int gx = G.gx[q], tiles = gx * G.gy[q];
   const int bz = local / tiles, t = local - bz * tiles;
   const int by = t / gx, bx = t - by * gx;
-  if (G.vec[q]) wgrad_dma_body<WM, WN>(G.p[q], bx, by, bz);
+  if (G.vec[q] == 1) wgrad_dma_body<WM, WN>(G.p[q], bx, by, bz);
   else gemm_body<BM, BN, WM, WN, STAGES, false, false, EPI_SLAB, false>(G.p[q], bx, by, bz);
 }
 
@@ -540,7 +703,8 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
 
 // grouped variant: the slabs of up to MAXG problems reduced by one launch
 struct ReduceGroupArgs {
-  int n, splits, accumulate;
+  int n, accumulate;
+  int splits[MAXG];
   int first[MAXG + 1];      // first block of each problem
   int dw_blocks[MAXG], vec4[MAXG];
   const float* slab[MAXG]; const float* dbslab[MAXG];
@@ -559,7 +723,7 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupAr
   if (b < G.dw_blocks[q]) {
     const int64_t total = M * N;
     if (G.vec4[q]) {
-      reduce_units<true>(G.slab[q], G.splits, total, (int64_t)b * 64, red, t, e);
+      reduce_units<true>(G.slab[q], G.splits[q], total, (int64_t)b * 64, red, t, e);
       if (w == 0 && e < total) {
         const int64_t i = e / N, j = e - i * N;
         float4* dst = reinterpret_cast<float4*>(G.dW[q] + i * G.lddw[q] + j);
@@ -567,7 +731,7 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupAr
         *dst = t;
       }
     } else {
-      reduce_units<false>(G.slab[q], G.splits, total, (int64_t)b * 64, red, t, e);
+      reduce_units<false>(G.slab[q], G.splits[q], total, (int64_t)b * 64, red, t, e);
       if (w == 0 && e < total) {
         const int64_t i = e / N, j = e - i * N;
         float* dst = G.dW[q] + i * G.lddw[q] + j;
@@ -575,7 +739,7 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupAr
       }
     }
   } else {
-    reduce_units<false>(G.dbslab[q], G.splits, M, (int64_t)(b - G.dw_blocks[q]) * 64, red, t, e);
+    reduce_units<false>(G.dbslab[q], G.splits[q], M, (int64_t)(b - G.dw_blocks[q]) * 64, red, t, e);
     float* db = G.db[q];
     if (w == 0 && e < M) db[e] = G.accumulate ? (db[e] + t.x) : t.x;
   }
@@ -688,36 +852,51 @@ static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, 
 
 // Grouped plan: 128x128 tiles for every layer, one common contraction split count chosen so that
 // (tiles x splits) fills whole rounds of the 256 CUs (one 8-wave workgroup per CU) with few, long items.
-struct GroupPlan { int splits; int64_t k_per_split; int tiles; };
+struct GroupPlan { int splits; int64_t k_per_split; int tiles; int tiny_splits; int64_t tiny_kps; int n_tiny; };
 constexpr int GBM = 128, GBN = 128;
 static GroupPlan plan_wgrad_group(int64_t Mrows, int n, const int32_t* N, const int32_t* K) {
   GroupPlan p{};
-  for (int l = 0; l < n; ++l) p.tiles += (int)(ceil_div(N[l], GBM) * ceil_div(K[l], GBN));
+  static const bool tiny_on = [] { const char* e = getenv("CLICA_WGRAD_TINY"); return !(e && atoi(e) == 0); }();
+  for (int l = 0; l < n; ++l) {
+    if (tiny_on && tiny_eligible(N[l], K[l], TINY_THREADS)) { ++p.n_tiny; continue; }
+    p.tiles += (int)(ceil_div(N[l], GBM) * ceil_div(K[l], GBN));
+  }
   const int64_t max_s = std::max<int64_t>(1, std::min<int64_t>(64, ceil_div(Mrows, (int64_t)BK * 4)));
   double best = 1e300;
-  for (int64_t s = 1; s <= max_s; ++s) {
+  p.splits = 1; p.k_per_split = ceil_div(Mrows, (int64_t)BK) * BK;
+  for (int64_t s = 1; s <= max_s && p.tiles > 0; ++s) {
     const int64_t kps = ceil_div(ceil_div(Mrows, s), (int64_t)BK) * BK;
     const int64_t sp = ceil_div(Mrows, kps);
     const int64_t rounds = ceil_div((int64_t)p.tiles * sp, kNumCU);
     // rounds of kps-row items + fixed per-round prologue/epilogue + slab write/read traffic per split
-    // (weights fitted on MI355X, tools/wgrad_bench.py: 13 splits = 3 full rounds wins at M = 12288, n = 10)
+    // (weights fitted on MI355X, tools/wgrad_probe.py)
     const double cost = (double)rounds * (kps + 32.0) + 8.0 * sp;
     if (cost < best) { best = cost; p.splits = (int)sp; p.k_per_split = kps; }
   }
-  const char* e = getenv("CLICA_WGRAD_GROUP_SPLITS");
-  if (e && atoi(e) > 0) {
-    const int64_t kps = ceil_div(ceil_div(Mrows, (int64_t)atoi(e)), (int64_t)BK) * BK;
+  static const int forced = [] { const char* e = getenv("CLICA_WGRAD_GROUP_SPLITS"); return e ? atoi(e) : 0; }();
+  if (forced > 0) {
+    const int64_t kps = ceil_div(ceil_div(Mrows, (int64_t)forced), (int64_t)BK) * BK;
     p.k_per_split = kps; p.splits = (int)ceil_div(Mrows, kps);
+  }
+  // tiny-dimension layers: their own short launch, ~one workgroup per CU over all of them, 1..2 row tiles each
+  if (p.n_tiny > 0) {
+    int64_t ts = std::max<int64_t>(1, kNumCU / p.n_tiny);
+    const int64_t cap = std::max<int64_t>(1, Mrows / (2 * TINY_ROWS));
+    if (ts > cap) ts = cap;
+    p.tiny_kps = ceil_div(ceil_div(Mrows, ts), (int64_t)TINY_ROWS) * TINY_ROWS;
+    p.tiny_splits = (int)ceil_div(Mrows, p.tiny_kps);
   }
   return p;
 }
+static bool group_is_tiny(const GroupPlan& p, int32_t N, int32_t K) { return p.n_tiny > 0 && tiny_eligible(N, K, TINY_THREADS); }
 static size_t group_ws_layout(const GroupPlan& p, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
   size_t off = 0;
   for (int l = 0; l < n; ++l) {
+    const size_t sp = group_is_tiny(p, N[l], K[l]) ? p.tiny_splits : p.splits;
     if (slab_off) slab_off[l] = off;
-    off += align_up((size_t)p.splits * N[l] * K[l] * sizeof(float), 256);
+    off += align_up(sp * N[l] * K[l] * sizeof(float), 256);
     if (db_off) db_off[l] = off;
-    off += align_up((size_t)p.splits * N[l] * sizeof(float), 256);
+    off += align_up(sp * N[l] * sizeof(float), 256);
   }
   return off;
 }
@@ -752,34 +931,53 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
   hipStream_t st = as_stream(stream);
   GroupArgs G{};
   ReduceGroupArgs R{};
-  G.n = R.n = n_layers; R.splits = p.splits; R.accumulate = accumulate ? 1 : 0;
-  int item = 0, rblock = 0;
+  TinyArgs T{};
+  R.n = n_layers; R.accumulate = accumulate ? 1 : 0;
+  int item = 0, rblock = 0, ng = 0;
   for (int l = 0; l < n_layers; ++l) {
+    const bool tiny = group_is_tiny(p, N[l], K[l]);
+    const int sp = tiny ? p.tiny_splits : p.splits;
     float* slab = (float*)((char*)workspace + slab_off[l]);
     float* dbslab = (float*)((char*)workspace + db_off[l]);
     // dW[N,K] = dZ[M,N]^T X[M,K]: "M" = N, "N" = K, contraction over the batch rows
-    Args& g = G.p[l];
+    Args g{};
     g.A = dZ[l]; g.lda = lddz[l]; g.B = X[l]; g.ldb = ldx[l]; g.C = slab; g.ldc = K[l]; g.M = N[l]; g.N = K[l]; g.Kc = M;
-    g.k_per_split = p.k_per_split; g.dbias_slab = db[l] ? dbslab : nullptr;
-      G.gx[l] = (int)ceil_div(K[l], GBN); G.gy[l] = (int)ceil_div(N[l], GBM);
-    G.vec[l] = (aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N[l] % 4 == 0 && K[l] % 4 == 0) ? 1 : 0;
-    G.first[l] = item; item += G.gx[l] * G.gy[l] * p.splits;
+    g.k_per_split = tiny ? p.tiny_kps : p.k_per_split; g.dbias_slab = db[l] ? dbslab : nullptr;
+    if (tiny) {
+      T.p[T.n++] = g;
+    } else {
+      G.p[ng] = g;
+      G.gx[ng] = (int)ceil_div(K[l], GBN); G.gy[ng] = (int)ceil_div(N[l], GBM);
+      G.vec[ng] = (aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N[l] % 4 == 0 && K[l] % 4 == 0) ? 1 : 0;
+      G.first[ng] = item; item += G.gx[ng] * G.gy[ng] * sp;
+      ++ng;
+    }
     const bool v4 = (K[l] % 4 == 0) && (lddw[l] % 4 == 0) && aligned16(dW[l]);
-    R.vec4[l] = v4 ? 1 : 0;
+    R.vec4[l] = v4 ? 1 : 0; R.splits[l] = sp;
     R.dw_blocks[l] = (int)ceil_div(v4 ? (int64_t)N[l] * K[l] / 4 : (int64_t)N[l] * K[l], 64);
     R.first[l] = rblock; rblock += R.dw_blocks[l] + (db[l] ? (int)ceil_div(N[l], 64) : 0);
     R.slab[l] = slab; R.dbslab[l] = dbslab; R.dW[l] = dW[l]; R.db[l] = db[l];
     R.M[l] = N[l]; R.N[l] = K[l]; R.lddw[l] = lddw[l];
   }
-  G.first[n_layers] = G.total = item; R.first[n_layers] = rblock;
-  constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
-  constexpr size_t lds = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
-  auto k = wgrad_group_k<GBM, GBN, WM, WN, STAGES>;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
-  (void)once;
-  hipLaunchKernelGGL(k, dim3((unsigned)item), dim3(THREADS), lds, st, G);
-  int rc = launch_status("clica_mlp_wgrad");
-  if (rc) return rc;
+  G.n = ng; G.first[ng] = G.total = item; R.first[n_layers] = rblock;
+  if (T.n > 0) {
+    constexpr size_t tiny_lds = (size_t)(TINY_ROWS * TINY_MAX_LG + TINY_ROWS * TINY_MAX_S) * sizeof(float) + 1024;
+    static bool once_t = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tiny_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiny_lds), true);
+    (void)once_t;
+    hipLaunchKernelGGL(wgrad_tiny_k, dim3((unsigned)p.tiny_splits, (unsigned)T.n), dim3(TINY_THREADS), tiny_lds, st, T);
+    int rct = launch_status("clica_mlp_wgrad(tiny)");
+    if (rct) return rct;
+  }
+  if (ng > 0) {
+    constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
+    constexpr size_t lds = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
+    auto k = wgrad_group_k<GBM, GBN, WM, WN, STAGES>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3((unsigned)item), dim3(THREADS), lds, st, G);
+    int rc = launch_status("clica_mlp_wgrad");
+    if (rc) return rc;
+  }
   hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)rblock), dim3(RED_THREADS), 0, st, R);
   return launch_status("clica_mlp_wgrad(reduce)");
 }

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void means_k(const float* __restrict__ blocksum
 // one row of the coefficient step (shared by bwd_coef_k and the training forward's finalize)
 __device__ __forceinline__ void coef_row(
     const int64_t i, const int64_t rows, const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
-    const Params& q, float tau, float alpha, int compat, int frac, int dot, const float L,
+    const Params& q, float tau, float alpha, int compat, int frac, int dot, const float L2,
     const float* __restrict__ g_mean, const float* __restrict__ g_item,
     const float* __restrict__ g_pos, const float* __restrict__ g_neg,
     float* __restrict__ statL, float* __restrict__ statC,
@@ -73,7 +73,8 @@ __device__ __forceinline__ void coef_row(
   const float gi = (g_mean ? g_mean[0] : 1.f) * inv_rows + (g_item ? g_item[i] : 0.f);
   const float A = 2.f * alpha * gi + (g_pos ? g_pos[0] * inv_rows : 0.f);
   const float C = 2.f * (1.f - alpha) * gi + (g_neg ? g_neg[0] * inv_rows : 0.f);
-  statL[i] = L * kLog2e;
+  statL[i] = L2;      // row statistic stays in the log2 domain end to end: no ln <-> log2 round trip of a number that is
+                      // ~10^3 in saturated rows (each rounding of it is a 1e-4 relative error on every weight of the row)
   statC[i] = q.xs * C / tau;
   if (!dz1 && !dz2) return;
   const float* a = z1 + i * ld1;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void coef_row(
   if (dot) {
     float pos = 0.f;
     for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
-    const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L * kLog2e);
+    const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L2);
     for (int k = 0; k < q.n; ++k) {
       if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
       if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
@@ -91,7 +92,7 @@ __device__ __forceinline__ void coef_row(
   const float sp_ = pos_sum(a, b, q.n, q, frac != 0);
   const float pos = q.pow ? sp_ : root_of<true>(sp_, q);
   float cpos = A / tau;
-  if (compat) cpos -= (C / tau) * fexp2(-pos * q.kscale - L * kLog2e);
+  if (compat) cpos -= (C / tau) * fexp2(-pos * q.kscale - L2);
   cpos *= q.pow ? q.p : droot_of<true>(sp_, q);  // includes the factor p
   for (int k = 0; k < q.n; ++k) {
     const float d = a[k] - b[k];
@@ -173,13 +174,14 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
       s = s * fexp2(m - mn) + fexp2(xp - mn);
       m = mn;
     }
-    const float lse_raw = (m + flog2(s)) * kLn2;
+    const float L2 = m + flog2(s);                // log2-domain log-sum-exp of the scaled logits: THE saved row statistic
+    const float lse_raw = L2 * kLn2;
     const float lse = compat ? lse_raw : lse_raw - log_b3;   // _logmeanexp, losses.py:506-510
     const float lp = pos / tau;
     const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
-    loss_i[i] = li; pos_i[i] = lp; lse_i[i] = lse_raw;
+    loss_i[i] = li; pos_i[i] = lp; lse_i[i] = L2;
     if (T.statL)
-      coef_row(i, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, lse_raw, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
+      coef_row(i, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, L2, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
                T.dz1, T.ldd1, T.dz2, T.ldd2);
     v_loss = li; v_pos = lp; v_lse = lse;
   }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
 
 // ---- backward ------------------------------------------------------------------------------
 // per-row coefficients + the positive-pair gradient
-//   statL[i] = lse_raw[i] * log2(e);  statC[i] = -(C_i / tau)  with C_i the upstream weight of lse_i
+//   statL[i] = lse_i[i] (log2 domain);  statC[i] = -(C_i / tau)  with C_i the upstream weight of the row's log-sum-exp
 __global__ __launch_bounds__(THREADS) void bwd_coef_k(
     int64_t rows, const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
     Params q, float tau, float alpha, int compat, int frac, int dot, const float* __restrict__ lse_i,
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(THREADS) void rowgrad_combine_k(const float2* __res
   const int64_t i = idx / q4;
   const int k = (int)(idx - i * q4) * 4;
   if (k >= n) return;
-  const float L2 = lse_i[i] * kLog2e;
+  const float L2 = lse_i[i];
   float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
   for (int sp = 0; sp < nsplit; ++sp) {
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(THREADS) void pool_stats_k(int64_t pool_rows, const
   if (j >= pool_rows) return;
   const float inv = 1.f / (float)local_rows;
   const float C = 2.f * (1.f - alpha) * (g_mean ? g_mean[0] : 1.f) * inv + (g_neg ? g_neg[0] * inv : 0.f);
-  strL[j] = pool_lse[j] * kLog2e;
+  strL[j] = pool_lse[j];
   strC[j] = xs * C / tau;
 }
 

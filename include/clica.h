@@ -66,7 +66,10 @@ int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t* fwd_bytes
 /* Forward.  Outputs (all fp32, device):
  *   loss_i  [B]  per-item loss                         (2nd return of LpSimCLRLoss.loss)
  *   pos_i   [B]  pos[i]/tau                            (its mean is the 3rd return's [0])
- *   lse_i   [B]  RAW logsumexp (without -log B3), saved for the backward
+ *   lse_i   [B]  row statistic saved for the backward: the RAW log-sum-exp (without -log B3) of the row's logits in LOG2
+ *                units, log2(sum_j 2^(log2(e) * logit_ij)) = natural-log lse * log2(e).  Opaque to callers (the natural-log
+ *                mean is means[2]); kept in the kernels' own exponent domain so that saturated rows (|lse| ~ 10^3) are not
+ *                rounded twice on the way to the backward
  *   means   [3]  mean(loss_i), mean(pos_i), mean(lse as the reference defines it)
  *   rowgrad [B,n] (ld `ldrg`) optional, NULL to skip: sum_j softmax_ij * d neg_ij / d z1_i, accumulated
  *           flash-style inside the same pair sweep.  Handing it to clica_lp_loss_bwd removes the

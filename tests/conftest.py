@@ -169,6 +169,38 @@ def golden_view(got, ref, stride):
     return got if ref.size == got.size else np.ascontiguousarray(got.reshape(-1)[::stride])
 
 
+def p1_tie_analysis(z1, z2, tau=1.0, alpha=0.5, thr=None):
+    """p = 1 makes the loss gradient DISCONTINUOUS: d|d|/dd = sign(d), so an embedding coordinate pair that is equal to
+    within the forward's own rounding (|z_ik - z_jk| <= thr) may get sign +1 from one fp32 implementation and -1 / 0 from
+    another (the reference's CPU and GPU runs differ the same way).  For the compat-mode mean loss with z3 = roll(z1)
+    (all z1 rows are the negatives) this returns
+        near_rows : bool mask of rows taking part in such a near-tie (negatives or their positive pair)
+        quantum   : sum over the near-ties of the gradient change one flip can cause, 2 (C / tau)(w_ij + w_ji) resp.
+                    2 |A / tau - C w_pos / tau| for a positive pair  (A = 2 alpha / B, C = 2 (1 - alpha) / B)
+    so that a test can compare row-wise gradients on the other rows at 1e-5 and bound the effect on sums over rows."""
+    z1 = np.asarray(z1, np.float64); z2 = np.asarray(z2, np.float64)
+    B = z1.shape[0]
+    if thr is None:
+        thr = 8.0 * np.finfo(np.float32).eps * max(float(np.abs(z1).max()), float(np.abs(z2).max()))
+    d = z1[:, None, :] - z1[None, :, :]
+    neg = np.abs(d).sum(-1)
+    pos = np.abs(z1 - z2).sum(-1)
+    x = np.concatenate([-neg / tau, (-pos / tau)[:, None]], 1)
+    m = x.max(1, keepdims=True)
+    lse = (np.log(np.exp(x - m).sum(1, keepdims=True)) + m)[:, 0]
+    w = np.exp(-neg / tau - lse[:, None])
+    near = (np.abs(d) <= thr) & (d != 0.0) & ~np.eye(B, dtype=bool)[:, :, None]     # exact ties (saturated heads) agree: sign(0) = 0
+    A, C = 2.0 * alpha / B, 2.0 * (1.0 - alpha) / B
+    q = float((2.0 * (C / tau) * (w + w.T))[near.any(-1)].sum()) if near.any() else 0.0
+    rows = near.any(-1).any(1)
+    pnear = (np.abs(z1 - z2) <= thr) & (z1 != z2)
+    if pnear.any():
+        wpos = np.exp(-pos / tau - lse)
+        q += float((2.0 * np.abs(A / tau - C * wpos / tau))[pnear.any(1)].sum())
+        rows = rows | pnear.any(1)
+    return rows, q
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     den = max(float(np.max(np.abs(b))), 1e-30)

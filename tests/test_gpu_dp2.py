@@ -49,9 +49,16 @@ def test_two_ranks_match_single_process(tmp_path, B, n, wide, head):
     # per parameter tensor (the last bias has an exactly-zero gradient without a head: translation invariance)
     off = 0
     names = [k for k, _ in f.named_parameters()]
+    lin_last = [m for m in f if isinstance(m, torch.nn.Linear)][-1]
+    last_w_scale = float(2.0 * ref._gviews[id(lin_last.weight)].abs().max().item())
     for k, prm in f.named_parameters():
         sl = slice(off, off + prm.numel()); off += (prm.numel() + 3) // 4 * 4
         if head is None and k == names[-1]:
             assert np.abs(r0["grad"][sl]).max() < 1e-6
             continue
-        PARITY.check(fam + "/grad", case, k, r0["grad"][sl], g_ref[sl])
+        floor = 0.0
+        if k.endswith(".bias") and k.split(".")[0] == names[-2 if head else -1].split(".")[0]:
+            # last Linear's bias under a head: nearly translation invariant (a ~1e-7 residue of +-1e-4 summands, the same dY
+            # rows that make up the weight gradient of that layer): measured relative to that weight gradient
+            floor = last_w_scale
+        PARITY.check(fam + "/grad", case, k, r0["grad"][sl], g_ref[sl], floor=floor)

@@ -231,7 +231,7 @@ def test_fused_signmask_path_is_bit_identical(dims, M):
 
 
 @pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
-                                      ([16, 16, 16], 47), ([3, 300], 5000)])
+                                      ([16, 16, 16], 47), ([3, 300], 5000), ([10, 256, 10], 3001), ([1, 8, 1], 129), ([13, 100, 16, 100], 6144)])
 def test_grouped_wgrad_matches_per_layer(dims, M):
     """clica_mlp_wgrad (all layers, one grouped split-K launch + one grouped slab reduce) vs fp64 and per-layer wgrad."""
     from cl_ica_amd import ops
