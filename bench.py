@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median window is reported")
     ap.add_argument("--n", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=6144)
     ap.add_argument("--p", type=int, default=2)
@@ -55,6 +56,7 @@ def parse():
                     help="opt-in arithmetic for the two whole-stack encoder kernels: exact 3-way bf16 splits of both fp32 operands, six "
                          "bf16-MFMA products, fp32 accumulate (fp32-grade error); default is native fp32 MFMA")
     ap.add_argument("--no-split-probe", action="store_true", help="skip the extra short measurement of the --split-bf16 mode (N = 1 only)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
 
@@ -226,7 +228,11 @@ def roofline_leg(tr, reps=20):
             ent = tj["kernels"].get(top["kernel"])
             if ent:
                 traffic = round(ent["fetch_x2_bytes"] + ent["write_bytes"])
-                traffic_src = f"profiles/{cand[-1]}: FETCH_SIZE x2 + WRITE_SIZE per launch (bytes), separate rocprofv3 --pmc passes"
+                import hashlib
+                digest = hashlib.sha256(open(os.path.join(here, "profiles", cand[-1]), "rb").read()).hexdigest()[:12]
+                traffic_src = (f"NOT measured by this run: copied from the committed PMC profile profiles/{cand[-1]} (sha256 {digest}; "
+                               "FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of tools/profile_round.sh) -- "
+                               "stale if the kernel changed after that profile was taken")
     except Exception:
         pass
     roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
@@ -279,6 +285,59 @@ def loss_leg(tr, reps=20):
             "algorithmic_bytes_fwd": 4 * n * (2 * B + z3.shape[0]) + 12 * B}
 
 
+def dropin_leg(args, device, steps=40, warmup=8):
+    """The INTEGRATION.md import swap, measured: the reference's own `train_step` structure (main_mlp.py:258-285 -- two h(z)
+    passes, roll inside the graph, loss(...), backward(), optimizer.step(), `.item()` host syncs) and its sampling call
+    (:196-200, :328) with `import cl_ica_amd.{losses,encoders,latent_spaces,spaces,invertible_network_utils}` in place of the
+    reference's modules; torch autograd drives the HIP kernels through the drop-in modules.  Reported next to the fused engine:
+    `torch_adam` keeps the reference's `torch.optim.Adam` line, `flat_adam` swaps that one line for `cl_ica_amd.optim.Adam`."""
+    import contextlib, io, types
+    from cl_ica_amd import encoders, invertible_network_utils as inu, losses, optim, train_mlp
+    n, B = args.n, args.batch_size
+    a = types.SimpleNamespace(n=n, box_min=0.0, box_max=1.0, sphere_r=1.0, m_param=1.0, m_p=0, c_param=0.05, c_p=2,
+                              space_type=args.space_type)
+    latent_space = train_mlp.build_latent_space(a, train_mlp.sampler_spec(a, 0))
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        g = inu.construct_invertible_mlp(n=n, n_layers=3, act_fct="leaky_relu", cond_thresh_ratio=0.0,
+                                         n_iter_cond_thresh=25000 if n <= 10 else 2000).to(device)
+    loss = losses.LpSimCLRLoss(p=args.p, tau=1.0, simclr_compatibility_mode=True)
+    res = {}
+    for name in ("torch_adam", "flat_adam"):
+        torch.manual_seed(0)
+        f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 50, n * 50, n * 10]).to(device)
+        optimizer = torch.optim.Adam(f.parameters(), lr=1e-4) if name == "torch_adam" else optim.Adam(f.parameters(), lr=1e-4)
+        h = lambda z: f(g(z))   # noqa: E731
+
+        def train_step(data, loss, optimizer):
+            z1, z2_con_z1 = data
+            z3 = torch.roll(z1, 1, 0)
+            optimizer.zero_grad()
+            z1_rec = h(z1)
+            z2_con_z1_rec = h(z2_con_z1)
+            z3_rec = torch.roll(z1_rec, 1, 0)
+            total_loss_value, _, losses_value = loss(z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec)
+            total_loss_value.backward()
+            optimizer.step()
+            return total_loss_value.item(), [v.item() for v in losses_value]
+
+        def one():
+            z = latent_space.sample_marginal(B)
+            return train_step((z, latent_space.sample_conditional(z, B)), loss, optimizer)
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lv, _ = one()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        res[name] = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "final_loss": lv}
+    res["what"] = ("reference train_step structure (main_mlp.py:258-285, 3 host syncs per step, eager launches, torch autograd) on the "
+                   "drop-in modules: FusedMLP routes to the one-launch clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad kernels")
+    return res
+
+
 def main():
     args = parse()
     from cl_ica_amd.distributed import init_from_env
@@ -306,21 +365,28 @@ def main():
                 tr.graph = None
     for _ in range(args.warmup):
         tr.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    # `--windows` timed windows of EXACTLY `--steps` steps each, every window bracketed by barrier + synchronize on both sides and
+    # reduced with MAX over the ranks; the line reports the MEDIAN window ("median of 5 windows"), so a short
+    # driver run (--steps 20 = 16 ms of GPU time per window) is not at the mercy of one scheduling hiccup.
+    window_s = []
+    for _ in range(max(1, args.windows)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        window_s.append(el)
+    elapsed = float(np.median(window_s))
     last = tr.loss_out[3 * tr.B:].clone()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
     loss_vals = [float(v) for v in last.cpu()]
 
     out = {
@@ -328,6 +394,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "global_steps_per_s": args.steps / elapsed,
+        "windows": len(window_s), "timed_steps_total": args.steps * len(window_s), "timing": "median window of `windows` x `steps` steps",
+        "window_ms_per_step": [round(1e3 * w / args.steps, 4) for w in window_s],
         "config": {"workload": f"main_mlp.py --n {args.n} --n-mixing-layer 3 --p {args.p} --batch-size {args.batch_size} "
                                f"--space-type {args.space_type} (unsupervised step: sample->g->f->LpSimCLR->bwd->Adam)",
                    "batch_per_gpu": args.batch_size, "global_batch": args.batch_size * world,
@@ -351,6 +419,8 @@ def main():
                                "sample": f"5 timed + 2 warm-up full steps at B={args.batch_size}, n={args.n} (median), "
                                          f"torch {torch.__version__} CPU ops, {os.cpu_count()} host cores visible"}
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    if rank == 0 and world == 1 and not args.no_dropin:
+        out["dropin"] = dropin_leg(args, device)
     out["encoder_arithmetic"] = ("split-bf16: exact 3-way bf16 splits of both fp32 operands, six bf16-MFMA products, fp32 accumulate "
                                  "(fp32-grade error; forward stack + backward data chain only)" if tr.split_bf16 else "native fp32 MFMA")
     if rank == 0 and world == 1 and not tr.split_bf16 and not args.no_split_probe and tr.fused_backward:

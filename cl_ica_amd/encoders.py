@@ -57,6 +57,90 @@ class _MLPStackFn(torch.autograd.Function):
         return (g, None, *grads)
 
 
+class _MLPFusedFn(torch.autograd.Function):
+    """The same stack on the WHOLE-ENCODER kernels the training engine uses (csrc/fused_mlp.hip, csrc/linear.hip): one
+    launch for the forward (activation panel resident in LDS, sign bits of every hidden activation saved), one for the
+    backward data chain, one grouped launch (+ one slab reduction) for every layer's dW / db.  Taken when every width is
+    <= 512 (``ops.mlp_fwd_fusable``) and the batch is large enough to fill the chip (see ``_use_fused``)."""
+
+    _pack_cache = {}      # device -> dict(key, shapes, packed, packed_t): fragment-order copies of the CURRENT weights
+
+    @staticmethod
+    def _weights_key(ws):
+        return (ops.PARAM_EPOCH,) + tuple((w.data_ptr(), w._version, tuple(w.shape)) for w in ws)
+
+    @staticmethod
+    def _packed(params_w):
+        """Fragment-order weight copies for the forward (``packed``) and the backward chain (``packed_t``), re-packed (one
+        launch) only when a weight changed: the reference's train_step calls the encoder twice per step on the same weights."""
+        key = _MLPFusedFn._weights_key(params_w)
+        dev = params_w[0].device
+        c = _MLPFusedFn._pack_cache.get(dev)
+        if c is not None and c["key"] == key:
+            return c["packed"], c["packed_t"], key
+        shapes = [tuple(w.shape) for w in params_w]
+        reuse = c is not None and c["shapes"] == shapes
+        packed, packed_t = ops.mlp_pack_both([w.detach() for w in params_w], c["packed"] if reuse else None, c["packed_t"] if reuse else None)
+        _MLPFusedFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t)
+        return packed, packed_t, key
+
+    @staticmethod
+    def forward(ctx, x, slope, *params):
+        L = len(params) // 2
+        ws, bs = [p.detach() for p in params[0::2]], [p.detach() for p in params[1::2]]
+        x = x.detach()
+        M, dev = x.shape[0], x.device
+        packed, packed_t, key = _MLPFusedFn._packed(params[0::2])
+        outs = [torch.empty((M, w.shape[0]), dtype=torch.float32, device=dev) for w in ws]
+        masks = ops.mlp_signmask_alloc(M, L - 1, dev) + [None]
+        ops.mlp_fwd(x, ws, bs, outs, slope, packed=packed, signmasks=masks)
+        ctx.slope, ctx.L = slope, L
+        ctx.pack_key = key
+        ctx.save_for_backward(x, *outs[:-1], *[m for m in masks[:-1]], *ws)
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        L, slope = ctx.L, ctx.slope
+        saved = ctx.saved_tensors
+        x, acts, masks, ws = saved[0], list(saved[1:L]), list(saved[L:2 * L - 1]), list(saved[2 * L - 1:])
+        gy = gy.contiguous()
+        M, dev = gy.shape[0], gy.device
+        # the fragment-order transposed weights must still describe the weights of the forward (they do unless a parameter was
+        # written between forward and backward, which autograd itself would reject)
+        cur = _MLPFusedFn._pack_cache.get(dev)
+        if cur is not None and cur["key"] == ctx.pack_key:
+            packed_t = cur["packed_t"]
+        else:
+            _, packed_t = ops.mlp_pack_both(ws)          # another model's forward re-packed the cache in between: rebuild
+        chain = list(range(L - 1, 0, -1))
+        dz = [torch.empty((M, ws[l].shape[1]), dtype=torch.float32, device=dev) for l in chain]     # dZ of layer l-1
+        ops.mlp_dgrad_chain(gy, [ws[l] for l in chain], packed_t, [acts[l - 1] for l in chain], dz, slope,
+                            masks_chain=[masks[l - 1] for l in chain])
+        dz_of = {l - 1: dz[j] for j, l in enumerate(chain)}
+        dz_of[L - 1] = gy
+        need = ctx.needs_input_grad
+        dWs = [torch.empty_like(w) for w in ws]
+        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) if need[3 + 2 * l] else None for l, w in enumerate(ws)]
+        ops.mlp_wgrad([dz_of[l] for l in range(L)], [acts[l - 1] if l > 0 else x for l in range(L)], dWs, dbs)
+        grads = []
+        for l in range(L):
+            grads += [dWs[l] if need[2 + 2 * l] else None, dbs[l]]
+        dx = ops.linear_dgrad(dz_of[0], ws[0], None, slope) if need[0] else None
+        return (dx, None, *grads)
+
+
+def _use_fused(linears, M: int) -> bool:
+    """Whole-encoder kernels for the autograd path?  They own 48 rows per workgroup for the whole stack, so they want
+    >= ~3/4 of the 256 CUs busy; smaller batches (and wide encoders) take the per-layer GEMMs.  CLICA_DROPIN_FUSED=0/1 forces."""
+    import os
+    e = os.environ.get("CLICA_DROPIN_FUSED", "auto")
+    ok = len(linears) > 1 and all(lin.bias is not None for lin in linears) and ops.mlp_fwd_fusable([lin.weight for lin in linears])
+    if not ok or e == "0":
+        return False
+    return True if e == "1" else (M + 47) // 48 >= 192
+
+
 class FusedMLP(nn.Sequential):
     """``nn.Sequential`` whose forward runs the fused HIP path (same modules, same state dict)."""
 
@@ -70,7 +154,8 @@ class FusedMLP(nn.Sequential):
         params = []
         for lin in linears:
             params += [lin.weight, lin.bias]
-        y = _MLPStackFn.apply(x, slope, *params)
+        fn = _MLPFusedFn if _use_fused(linears, x.shape[0]) else _MLPStackFn
+        y = fn.apply(x, slope, *params)
         for m in mods:
             if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
                 y = m(y)

@@ -343,10 +343,16 @@ def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: 
     return x
 
 
+PARAM_EPOCH = 0     # bumped by every raw-pointer parameter update (adam_step): caches derived from weights (fragment-order packs) key on it,
+                    # because a kernel writing through data_ptr() does not advance torch's per-tensor version counters
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
               ticket: Optional[torch.Tensor] = None, t_offset: int = 1):
     """In-place Adam on flat fp32 arenas; `step_dev` int32[1] = updates already applied.  With `ticket` (device
     int32[1], zero) the same launch also advances `step_dev` by one (clica_adam_step_tick)."""
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
     for nm, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         require_cuda(t, nm)
         if not t.is_contiguous():

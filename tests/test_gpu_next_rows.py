@@ -128,3 +128,39 @@ def test_flat_adam_matches_torch_adam():
     oc = Adam(mk().parameters(), lr=1.0)
     oc.load_state_dict(sa)
     assert oc.param_groups[0]["lr"] == 1e-2 and int(oc.step_dev.item()) == 6 and torch.equal(oc.exp_avg, oa.exp_avg)
+
+
+@pytest.mark.parametrize("opt_kind", ["torch", "flat"])
+def test_dropin_fused_path_matches_per_layer_path(opt_kind, monkeypatch):
+    """FusedMLP under autograd: the whole-encoder kernels (clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad, taken for large
+    batches) against the per-layer GEMM path on the same data, through two optimizer steps (the fragment-order weight cache
+    must follow the parameter updates of torch.optim.Adam AND of the raw-pointer cl_ica_amd.optim.Adam), with the reference's
+    two-calls-per-step structure and an input that needs a gradient."""
+    from cl_ica_amd import encoders, losses, optim
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CLICA_DROPIN_FUSED", fused)
+        torch.manual_seed(0)
+        f = encoders.get_mlp(10, 10, [100, 500, 500, 100]).cuda()
+        opt = torch.optim.Adam(f.parameters(), lr=1e-3) if opt_kind == "torch" else optim.Adam(f.parameters(), lr=1e-3)
+        L = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
+        g = torch.Generator().manual_seed(1)
+        outs = []
+        for s in range(3):
+            x1 = torch.rand(1000, 10, generator=g).cuda().requires_grad_(True)
+            x2 = (x1.detach() + 0.05 * torch.randn(1000, 10, generator=g).cuda())
+            opt.zero_grad()
+            a, b = f(x1), f(x2)
+            tot, _, _ = L(None, None, None, a, b, torch.roll(a, 1, 0))
+            tot.backward()
+            outs.append((tot.item(), x1.grad.clone(), [p.grad.clone() for p in f.parameters()]))
+            opt.step()
+        res[fused] = (outs, [p.detach().clone() for p in f.parameters()])
+    for s in range(3):
+        (la, dxa, ga), (lb, dxb, gb) = res["1"][0][s], res["0"][0][s]
+        PARITY.check("dropin_fused_vs_per_layer", f"{opt_kind} step{s}", "loss", la, lb, tol=2e-6 * (10 ** s), note="HIP vs HIP")
+        if s == 0:
+            PARITY.check("dropin_fused_vs_per_layer", f"{opt_kind} step0", "dx", dxa.cpu().numpy(), dxb.cpu().numpy(), tol=3e-6, note="HIP vs HIP")
+            for k, (u, v) in enumerate(zip(ga[:-1], gb[:-1])):     # last bias: exact gradient 0
+                PARITY.check("dropin_fused_vs_per_layer", f"{opt_kind} step0", f"grad{k}", u.cpu().numpy(), v.cpu().numpy(), tol=3e-6, note="HIP vs HIP")
+    assert res["1"][0][2][0] < res["1"][0][0][0]          # it trains: the packs followed the weights
