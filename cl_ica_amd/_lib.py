@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libclica_hip.so")
+LIB_PATH = os.environ.get("CLICA_LIB") or os.path.join(_HERE, "lib", "libclica_hip.so")     # CLICA_LIB: debug builds (tools/fmlp_trace.py)
 
 c_f32p = C.c_void_p
 c_i64 = C.c_int64

@@ -16,6 +16,7 @@
 //     blocks per wave, k-permuted so one 16-byte read feeds four MFMAs on both operands.
 // One launch replaces seven; the panel never round-trips through HBM between layers.
 #include "common.h"
+#include <stdlib.h>
 
 namespace clica {
 namespace fmlp {
@@ -49,11 +50,20 @@ struct Args {
   int64_t pack_off[MAXL];           // float offset of each layer inside `packed`
   // optional mixing-net prologue (clica_mlp_fwd_mixed): X is the latent block Z, the stack's input is g(Z)
   const float* mixW; int mixL; float mix_slope; float* xout; int64_t ldxo;
+  int prio_mode;                    // issue-priority policy of the k-loop (see layer_gemm); set by launch_mlp
   Layer layer[MAXL];
 };
 constexpr int MIX_MAX_N = 16;       // widest mixing net the prologue handles (ROWS * n values over THREADS threads, <= 2 each)
 
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Debug build only (-DCLICA_FMLP_TRACE, tools/fmlp_trace.py): s_memtime stamps per (workgroup, wave, layer, phase).
+#ifdef CLICA_FMLP_TRACE
+__device__ unsigned long long* g_trace = nullptr;
+#define FMLP_STAMP(l, ph) do { if (g_trace && lane == 0) g_trace[(((size_t)blockIdx.x * WAVES + wave) * (MAXL + 1) + (l)) * 8 + (ph)] = clock64(); } while (0)
+#else
+#define FMLP_STAMP(l, ph) do { } while (0)
+#endif
 
 // B fragment of column block `cb` for k in [k0 + 4q, k0 + 4q + 4): W[n = cb*16 + (lane&15)][k..k+3]
 template <bool VEC>
@@ -76,9 +86,12 @@ constexpr int KI = 32;
 // branch-free; NC is wave-uniform and selected by a scalar switch in the caller).
 template <bool VEC, bool PACKED, int NC>
 __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restrict__ pk, const float* panel, int wave, int lane,
-                                           f32x4 (&acc)[RB][CBW], const float4 (&bpre)[2][CBW]) {
+                                           f32x4 (&acc)[RB][CBW], const float4 (&bpre)[2][CBW], const int rot, const int prio_mode) {
   const int i15 = lane & 15, q = lane >> 4;
   const int kiters = (ly.K + KI - 1) / KI;
+  // `rot`: this workgroup walks the contraction starting at k-iteration rot (and wraps): every CU streams the SAME weight
+  // matrix; rotated starts spread the requests over the L2 slices (-1.5 % per 500 x 500 layer, tools/fmlp_trace.py)
+  auto kof = [&](int ki) { int kk = ki + rot; kk = kk >= kiters ? kk - kiters : kk; return kk * KI; };
   int nrow[CBW];
 #pragma unroll
   for (int c = 0; c < CBW; ++c) nrow[c] = (wave + c * WAVES) * 16 + i15;     // column blocks w, w+8, w+16, w+24
@@ -141,36 +154,52 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
 #pragma unroll
       for (int c = 0; c < NC; ++c) bcur[hlf][c] = bpre[hlf][c];
   } else {
-    fetch_b(bcur, 0);
+    fetch_b(bcur, kof(0));
   }
-  fetch_a(acur, 0);
+  fetch_a(acur, kof(0));
   // UNCONDITIONAL prefetch of the next iteration's operands (past the end: a harmless re-read of the last
   // iteration's own operands): with a conditional issue the compiler cannot count the loads in flight and
   // drains them all (s_waitcnt vmcnt(0)) in front of the MFMAs, which serialises fetch and math.
   // Iteration 0 is peeled: the wait in front of ITS MFMAs may leave the previous layer's activation stores
   // (issued after the early weight request) in flight, which a loop-carried wait count could not express.
+  // The two waves of a SIMD (w and w + 4) share its matrix pipe; arbitration is priority, then AGE: left alone waves 0-3 take
+  // ~60 % of the pipe, end their k-loop at 0.84 of the loop time and leave waves 4-7 to finish alone, where a single wave's
+  // own load issue and LDS waits are exposed (measured, tools/fmlp_trace.py: k-loop ends at 82.5k / 107.7k cycles for the two
+  // halves, ideal 98.3k).  Experiments kept behind CLICA_FMLP_PRIO (default 0 = none; none of them shortened the pair's total):
+  // 1 = static priority for the younger half (swaps winner and loser: 112k / 86k), 4 = the younger half holds priority 1 for
+  // the FIRST half of the loop (halves end at 106k / 114k: the pair still needs ~111k for 98.3k cycles of MFMA, i.e. the
+  // loop's own load-issue / wait overhead is ~12 % with both waves live -- the arbitration only decides who shows it).
+  const bool young = wave >= WAVES / 2;
+  if (prio_mode == 4 && young) __builtin_amdgcn_s_setprio(1);
   {
-    const int kn = kiters > 1 ? KI : 0;
+    const int kn = kof(kiters > 1 ? 1 : 0);
     fetch_b(bnxt, kn);
     fetch_a(anxt, kn);
     mma_and_rotate();
   }
   for (int ki = 1; ki < kiters; ++ki) {
-    const int kn = (ki + 1 < kiters) ? (ki + 1) * KI : ki * KI;
+    if (prio_mode == 4 && young && ki == (kiters >> 1)) __builtin_amdgcn_s_setprio(0);
+    const int kn = kof((ki + 1 < kiters) ? ki + 1 : ki);
     fetch_b(bnxt, kn);
     fetch_a(anxt, kn);
     mma_and_rotate();
   }
+  if (prio_mode == 4 && young) __builtin_amdgcn_s_setprio(0);
 }
 
 // iteration-0 weight fragments of a layer, for every column block slot of this wave (slots beyond the layer's
 // last block re-read block 0: unconditional loads, their values are never used)
+__device__ __forceinline__ int k_rotation(int K) {       // same for every wave of a workgroup; workgroups b, b+8, ... share an XCD
+  const int kiters = (K + KI - 1) / KI;
+  return (int)((blockIdx.x >> 3) % (unsigned)kiters);
+}
 __device__ __forceinline__ void request_first_b(const float* __restrict__ pk, int K, int N, int wave, int lane, float4 (&b)[2][CBW]) {
   const int kiters = (K + KI - 1) / KI, ncb_real = (N + 15) / 16;
+  const int rot = k_rotation(K);
 #pragma unroll
   for (int c = 0; c < CBW; ++c) {
     const int cb = wave + c * WAVES;
-    const float* base = pk + ((int64_t)((cb < ncb_real ? cb : 0) * kiters) * 2 * 64 + lane) * 4;
+    const float* base = pk + ((int64_t)((cb < ncb_real ? cb : 0) * kiters + rot) * 2 * 64 + lane) * 4;
     b[0][c] = *reinterpret_cast<const float4*>(base);
     b[1][c] = *reinterpret_cast<const float4*>(base + 256);
   }
@@ -302,8 +331,11 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   }
   __syncthreads();
 
+  FMLP_STAMP(MAXL, 0);
+  if (g.prio_mode == 1 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
   for (int l = 0; l < g.L; ++l) {
     const Layer& ly = g.layer[l];
+    FMLP_STAMP(l, 0);
     f32x4 acc[RB][CBW];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -314,23 +346,26 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
     const float* pk = PACKED ? g.packed + g.pack_off[l] : nullptr;
+    const int krot = k_rotation(ly.K);
     const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
     float bias_l[CBW];
 #pragma unroll
     for (int c = 0; c < CBW; ++c) bias_l[c] = bias[c];
 #define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                           \
     switch (nc) {                                                                                \
-      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc, bpre); break;           \
-      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc, bpre); break;           \
-      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc, bpre); break;           \
-      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
+      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
+      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
+      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
       default: break;                                                                            \
     }
     if (PACKED) { CLICA_FMLP_DISPATCH(true, true) }
     else if (vec) { CLICA_FMLP_DISPATCH(true, false) }
     else { CLICA_FMLP_DISPATCH(false, false) }
 #undef CLICA_FMLP_DISPATCH
+    FMLP_STAMP(l, 1);
     __syncthreads();                                   // every wave is done reading the input panel
+    FMLP_STAMP(l, 2);
 
     // Request the NEXT layer's first weight fragments and sign bits now: they do not depend on the panel, are
     // older than the activation stores below, and land while this layer's epilogue runs.
@@ -380,7 +415,9 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
       }
     }
     __builtin_amdgcn_raw_buffer_store_b64((u32x2){(unsigned)obits, (unsigned)(obits >> 32)}, mask_rsrc(ly.mask_out), mslot, 0, 0);
+    FMLP_STAMP(l, 3);
     __syncthreads();
+    FMLP_STAMP(l, 4);
 
     // stream the new activations to HBM straight from the panel (coalesced rows)
     const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
@@ -409,8 +446,14 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
       }
     }
     // no barrier needed here: the next layer only READS the panel until its own post-GEMM barrier
+    FMLP_STAMP(l, 5);
   }
 }
+#ifdef CLICA_FMLP_TRACE
+extern "C" int clica_debug_fmlp_trace(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(clica::fmlp::g_trace), &buf, sizeof(buf));
+}
+#endif
 
 // ---- weight packing: nn.Linear layout -> MFMA fragment order ----------------------------------------------
 // packed[layer][cb][ki][h][lane] (float4) = W[cb*16 + (lane&15)][ki*32 + h*16 + 4*(lane>>4) .. +3], zero padded.
@@ -776,7 +819,10 @@ static int launch_mlp_inst(const fmlp::Args& g, hipStream_t st, const char* who)
   hipLaunchKernelGGL(k, dim3((unsigned)ceil_div(g.M, ROWS)), dim3(THREADS), lds, st, g);
   return launch_status(who);
 }
-static int launch_mlp(const fmlp::Args& g, bool packed, bool aux, hipStream_t st, const char* who) {
+static int launch_mlp(const fmlp::Args& g_in, bool packed, bool aux, hipStream_t st, const char* who) {
+  static const int prio = [] { const char* e = getenv("CLICA_FMLP_PRIO"); return e ? atoi(e) : 0; }();
+  fmlp::Args g = g_in;
+  g.prio_mode = prio;
   if (packed) return aux ? launch_mlp_inst<true, true>(g, st, who) : launch_mlp_inst<true, false>(g, st, who);
   return launch_mlp_inst<false, false>(g, st, who);
 }
