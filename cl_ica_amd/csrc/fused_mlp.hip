@@ -50,7 +50,6 @@ struct Args {
   int64_t pack_off[MAXL];           // float offset of each layer inside `packed`
   // optional mixing-net prologue (clica_mlp_fwd_mixed): X is the latent block Z, the stack's input is g(Z)
   const float* mixW; int mixL; float mix_slope; float* xout; int64_t ldxo;
-  int prio_mode;                    // issue-priority policy of the k-loop (see layer_gemm); set by launch_mlp
   Layer layer[MAXL];
 };
 constexpr int MIX_MAX_N = 16;       // widest mixing net the prologue handles (ROWS * n values over THREADS threads, <= 2 each)
@@ -84,14 +83,27 @@ __device__ __forceinline__ float4 load_b(const Layer& ly, int n, int k) {
 constexpr int KI = 32;
 // NC = number of 16-column blocks this wave owns in this layer (compile time: the MFMA stream must be
 // branch-free; NC is wave-uniform and selected by a scalar switch in the caller).
+// Measured with the -DCLICA_FMLP_TRACE build (tools/fmlp_trace.py, s_memtime per wave / layer / phase) on a 500 x 500 layer:
+// ideal MFMA time 98.3k cycles per SIMD; the k-loop of waves 0-3 ends at 82.5k, of waves 4-7 at 107.7k (the two waves of a SIMD
+// share its matrix pipe, arbitration is priority then AGE: the older wave takes ~60 % of it and the younger finishes alone),
+// then barrier 1.2k + epilogue 5.1k + barrier 1.2k + activation-store issue 3.6k = 120k per layer (82 % of ideal).
+// Tried and NOT kept (each re-measured with the trace and with back-to-back launches):
+//   * s_setprio for the younger half (static: swaps winner and loser, 112k / 86k; alternating per k-iteration: 102k / 115k;
+//     first half of the loop only: 106k / 114k) -- the pair needs ~111k either way: the loop's own load-issue / wait overhead
+//     is ~12 % with both waves live, arbitration only decides which wave shows it;
+//   * weight fragments two k-iterations ahead (winner 75k, loser still 114k);
+//   * pinning the eight weight loads + six panel reads to the FRONT of the MFMA block (sched_barrier / sched_group_barrier):
+//     130k-150k -- issuing 8 x 1 KB loads back to back stalls the wave's own MFMA issue for ~1000 cycles, the compiler's
+//     placement (loads spread over the LAST third of the block) is the better one;
+//   * a rotated k-start per workgroup (spread the 256 CUs' requests for the same weight line): -1.5 % cycles inside the
+//     kernel, +2..9 % wall on back-to-back launches.
+// The chip holds 2.37 GHz under this load (tools/clock_probe.py) and the bare instruction pattern issues at 95-99 % of the
+// 157.3 TFLOP/s peak (tools/proto/mfma_rate.hip), so the remaining ~30 % is this kernel's structure, not a clock ceiling.
 template <bool VEC, bool PACKED, int NC>
 __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restrict__ pk, const float* panel, int wave, int lane,
-                                           f32x4 (&acc)[RB][CBW], const float4 (&bpre)[2][CBW], const int rot, const int prio_mode) {
+                                           f32x4 (&acc)[RB][CBW], const float4 (&bpre)[2][CBW]) {
   const int i15 = lane & 15, q = lane >> 4;
   const int kiters = (ly.K + KI - 1) / KI;
-  // `rot`: this workgroup walks the contraction starting at k-iteration rot (and wraps): every CU streams the SAME weight
-  // matrix; rotated starts spread the requests over the L2 slices (-1.5 % per 500 x 500 layer, tools/fmlp_trace.py)
-  auto kof = [&](int ki) { int kk = ki + rot; kk = kk >= kiters ? kk - kiters : kk; return kk * KI; };
   int nrow[CBW];
 #pragma unroll
   for (int c = 0; c < CBW; ++c) nrow[c] = (wave + c * WAVES) * 16 + i15;     // column blocks w, w+8, w+16, w+24
@@ -154,52 +166,36 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
 #pragma unroll
       for (int c = 0; c < NC; ++c) bcur[hlf][c] = bpre[hlf][c];
   } else {
-    fetch_b(bcur, kof(0));
+    fetch_b(bcur, 0);
   }
-  fetch_a(acur, kof(0));
+  fetch_a(acur, 0);
   // UNCONDITIONAL prefetch of the next iteration's operands (past the end: a harmless re-read of the last
   // iteration's own operands): with a conditional issue the compiler cannot count the loads in flight and
   // drains them all (s_waitcnt vmcnt(0)) in front of the MFMAs, which serialises fetch and math.
   // Iteration 0 is peeled: the wait in front of ITS MFMAs may leave the previous layer's activation stores
   // (issued after the early weight request) in flight, which a loop-carried wait count could not express.
-  // The two waves of a SIMD (w and w + 4) share its matrix pipe; arbitration is priority, then AGE: left alone waves 0-3 take
-  // ~60 % of the pipe, end their k-loop at 0.84 of the loop time and leave waves 4-7 to finish alone, where a single wave's
-  // own load issue and LDS waits are exposed (measured, tools/fmlp_trace.py: k-loop ends at 82.5k / 107.7k cycles for the two
-  // halves, ideal 98.3k).  Experiments kept behind CLICA_FMLP_PRIO (default 0 = none; none of them shortened the pair's total):
-  // 1 = static priority for the younger half (swaps winner and loser: 112k / 86k), 4 = the younger half holds priority 1 for
-  // the FIRST half of the loop (halves end at 106k / 114k: the pair still needs ~111k for 98.3k cycles of MFMA, i.e. the
-  // loop's own load-issue / wait overhead is ~12 % with both waves live -- the arbitration only decides who shows it).
-  const bool young = wave >= WAVES / 2;
-  if (prio_mode == 4 && young) __builtin_amdgcn_s_setprio(1);
   {
-    const int kn = kof(kiters > 1 ? 1 : 0);
+    const int kn = kiters > 1 ? KI : 0;
     fetch_b(bnxt, kn);
     fetch_a(anxt, kn);
     mma_and_rotate();
   }
   for (int ki = 1; ki < kiters; ++ki) {
-    if (prio_mode == 4 && young && ki == (kiters >> 1)) __builtin_amdgcn_s_setprio(0);
-    const int kn = kof((ki + 1 < kiters) ? ki + 1 : ki);
+    const int kn = (ki + 1 < kiters) ? (ki + 1) * KI : ki * KI;
     fetch_b(bnxt, kn);
     fetch_a(anxt, kn);
     mma_and_rotate();
   }
-  if (prio_mode == 4 && young) __builtin_amdgcn_s_setprio(0);
 }
 
 // iteration-0 weight fragments of a layer, for every column block slot of this wave (slots beyond the layer's
 // last block re-read block 0: unconditional loads, their values are never used)
-__device__ __forceinline__ int k_rotation(int K) {       // same for every wave of a workgroup; workgroups b, b+8, ... share an XCD
-  const int kiters = (K + KI - 1) / KI;
-  return (int)((blockIdx.x >> 3) % (unsigned)kiters);
-}
 __device__ __forceinline__ void request_first_b(const float* __restrict__ pk, int K, int N, int wave, int lane, float4 (&b)[2][CBW]) {
   const int kiters = (K + KI - 1) / KI, ncb_real = (N + 15) / 16;
-  const int rot = k_rotation(K);
 #pragma unroll
   for (int c = 0; c < CBW; ++c) {
     const int cb = wave + c * WAVES;
-    const float* base = pk + ((int64_t)((cb < ncb_real ? cb : 0) * kiters + rot) * 2 * 64 + lane) * 4;
+    const float* base = pk + ((int64_t)((cb < ncb_real ? cb : 0) * kiters) * 2 * 64 + lane) * 4;
     b[0][c] = *reinterpret_cast<const float4*>(base);
     b[1][c] = *reinterpret_cast<const float4*>(base + 256);
   }
@@ -332,7 +328,6 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
   __syncthreads();
 
   FMLP_STAMP(MAXL, 0);
-  if (g.prio_mode == 1 && wave >= WAVES / 2) __builtin_amdgcn_s_setprio(1);
   for (int l = 0; l < g.L; ++l) {
     const Layer& ly = g.layer[l];
     FMLP_STAMP(l, 0);
@@ -346,17 +341,16 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;        // column blocks wave, wave+8, ... below ncb_real
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
     const float* pk = PACKED ? g.packed + g.pack_off[l] : nullptr;
-    const int krot = k_rotation(ly.K);
     const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
     float bias_l[CBW];
 #pragma unroll
     for (int c = 0; c < CBW; ++c) bias_l[c] = bias[c];
 #define CLICA_FMLP_DISPATCH(VECV, PACKV)                                                           \
     switch (nc) {                                                                                \
-      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
-      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
-      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
-      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc, bpre, krot, g.prio_mode); break; \
+      case 4: layer_gemm<VECV, PACKV, 4>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 3: layer_gemm<VECV, PACKV, 3>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 2: layer_gemm<VECV, PACKV, 2>(ly, pk, panel, wave, lane, acc, bpre); break;           \
+      case 1: layer_gemm<VECV, PACKV, 1>(ly, pk, panel, wave, lane, acc, bpre); break;           \
       default: break;                                                                            \
     }
     if (PACKED) { CLICA_FMLP_DISPATCH(true, true) }
@@ -819,10 +813,7 @@ static int launch_mlp_inst(const fmlp::Args& g, hipStream_t st, const char* who)
   hipLaunchKernelGGL(k, dim3((unsigned)ceil_div(g.M, ROWS)), dim3(THREADS), lds, st, g);
   return launch_status(who);
 }
-static int launch_mlp(const fmlp::Args& g_in, bool packed, bool aux, hipStream_t st, const char* who) {
-  static const int prio = [] { const char* e = getenv("CLICA_FMLP_PRIO"); return e ? atoi(e) : 0; }();
-  fmlp::Args g = g_in;
-  g.prio_mode = prio;
+static int launch_mlp(const fmlp::Args& g, bool packed, bool aux, hipStream_t st, const char* who) {
   if (packed) return aux ? launch_mlp_inst<true, true>(g, st, who) : launch_mlp_inst<true, false>(g, st, who);
   return launch_mlp_inst<false, false>(g, st, who);
 }

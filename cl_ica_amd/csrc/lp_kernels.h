@@ -3,13 +3,17 @@
 // The reference materialises the (B, B3, n) broadcast difference and the (B, B3) distance
 // matrix (1.5 GB + 151 MB at B = 6144, n = 10).  Here the pair space is tiled flash-style:
 //
-//   forward : grid (owner tiles) x (stream splits).  A thread OWNS R rows ("owners") whose n
-//             coordinates live in registers; the other operand ("stream") is staged through
-//             LDS 64 rows at a time and read with wave-uniform (broadcast) ds_read_b128.
-//             Each thread keeps a running (max, sum) in the log2 domain per owner; per-split
-//             partials go to a small workspace and `finalize` merges them, adds the positive
-//             pair, and emits loss_i / pos_i / lse_i and the three means (deterministic
-//             last-block reduction, no float atomics).
+//   forward : grid (owner tiles) x (stream splits).  A workgroup owns 32 R rows ("owners") whose n coordinates
+//             live in registers; the other operand ("stream") is staged through LDS TS rows at a time.  The
+//             workgroup's stream chunk is cut into PARTS = 8 partitions on chip: wave w, half-wave h works on
+//             rows [q TS/8, (q+1) TS/8) of every tile (q = 2w + h) -- lanes l and l + 32 hold the SAME owner and
+//             read DIFFERENT stream rows (one ds_read_b128 serves both halves: two broadcast addresses cost the
+//             same four LDS cycles as one).  Each lane keeps a running (max, sum) in the log2 domain per owner;
+//             the eight partitions are merged with one shuffle + one pass through LDS, so only
+//             (stream splits) = ~8 partials per row reach HBM (the first version kept 512 owners per workgroup
+//             and needed ~85 HBM-level splits to fill the chip: 15-39x the algorithmic bytes in partial traffic
+//             and two latency-bound merge kernels).  `finalize` merges the splits, adds the positive pair, and
+//             emits loss_i / pos_i / lse_i and the three means (deterministic, no float atomics).
 //   backward: distances are recomputed.  d/dz1 is a row reduction (owners = z1 rows, softmax
 //             statistics per owner); d/dz3 is a column reduction over the ROW-normalised
 //             weights (owners = z3 rows, statistics per stream row).  Same kernel, roles
@@ -27,8 +31,18 @@ namespace clica {
 namespace lp {
 
 constexpr int THREADS = 256;
-constexpr int TS = 64;  // stream rows per LDS tile
-constexpr int JB = 4;   // stream rows processed together (independent FMA chains)
+constexpr int WAVES = THREADS / 64;
+constexpr int HALF = 32;            // owner rows per wave: lanes l and l + 32 share an owner and split the stream
+constexpr int PARTS = 2 * WAVES;    // stream partitions inside a workgroup (merged on chip, never through HBM)
+constexpr int JB = 4;               // stream rows processed together (independent FMA chains)
+// stream rows per LDS tile: every partition gets TS / PARTS of them (32 / 16 / 8 rows)
+#ifndef CLICA_LP_TS16
+#define CLICA_LP_TS16 128      // measured (tools/loss_train_probe.py): 128 beats 256 by 14 % on the backward sweep (registers: the
+#endif                        // staging prefetch holds TS NP / 256 values per thread across the tile's arithmetic)
+#ifndef CLICA_LP_TS40
+#define CLICA_LP_TS40 128
+#endif
+constexpr int tile_rows(int np) { return np <= 16 ? CLICA_LP_TS16 : (np <= 40 ? CLICA_LP_TS40 : 64); }
 
 struct Params {
   float p;        // exponent
@@ -127,33 +141,34 @@ __device__ __forceinline__ float droot_of(float s, const Params& q) {
 // read element 0 and are zeroed by a select at store time.
 template <int NP>
 struct Stager {
-  static constexpr int ITERS = (TS * NP + THREADS - 1) / THREADS;
+  static constexpr int TS = tile_rows(NP);
+  static constexpr int ITERS = TS * NP / THREADS;
+  static_assert((TS * NP) % THREADS == 0, "tile must divide over the workgroup");
   float v[ITERS];
   __device__ __forceinline__ void load(const float* __restrict__ str, int64_t lds, int64_t j0, int cnt, int n) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int idx = threadIdx.x + it * THREADS;
       const int row = idx / NP, k = idx - row * NP;
-      const bool ok = idx < TS * NP && row < cnt && k < n;
+      const bool ok = row < cnt && k < n;
       const float x = str[ok ? (j0 + row) * lds + k : 0];
       v[it] = ok ? x : 0.f;
     }
   }
   __device__ __forceinline__ void store(float* tile) const {
 #pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-      const int idx = threadIdx.x + it * THREADS;
-      if ((TS * NP) % THREADS == 0 || idx < TS * NP) tile[idx] = v[it];
-    }
+    for (int it = 0; it < ITERS; ++it) tile[threadIdx.x + it * THREADS] = v[it];
   }
 };
 
+// owner r of this lane: row own0 + r * HALF + (lane & 31) -- both half-waves load the same rows
 template <int NP, int R>
 __device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* __restrict__ own, int64_t ldo,
                                             int64_t own0, int64_t n_own, int n) {
+  const int li = threadIdx.x & (HALF - 1);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
+    const int64_t i = own0 + (int64_t)r * HALF + li;
     const bool ok = i < n_own;
 #pragma unroll
     for (int k2 = 0; k2 < NP / 2; ++k2) {
@@ -192,13 +207,23 @@ __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float
 // running-max rescaling (the flash-attention forward with "V" = the pair's distance derivative).  After
 // the splits are merged, G / 2^(lse) is the softmax-weighted row gradient sum_j w_ij d neg_ij / d owner_i,
 // so the backward needs NO row pass: dz1 = pos-term + (-C_i / tau) * rowgrad_i for any upstream gradient.
+// register budget hints (minimum waves per SIMD the kernel should fit): the sweeps are latency-tolerant only with >= 3-4 waves
+constexpr int fwd_min_waves(int np, bool rowgrad) { return rowgrad ? (np <= 16 ? 3 : 2) : (np <= 16 ? 4 : (np <= 24 ? 3 : 2)); }
+constexpr int bwd_min_waves(int np) { return np <= 16 ? 3 : 2; }
+
 template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2>
-__global__ __launch_bounds__(THREADS) void fwd_partial_k(
+__global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_partial_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, float2* __restrict__ part, float* __restrict__ part_g, int chunk) {
+  constexpr int TS = tile_rows(NP), RPP = TS / PARTS;
+  static_assert(RPP % JB == 0, "partition rows must be whole JB groups");
+  static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");
   __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
-  const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
+  __shared__ float2 wred[WAVES][HALF * R];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (HALF - 1), hf = lane >> 5;
+  const int pq = wave * 2 + hf;                       // this half-wave's partition of every tile
+  const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
   f32x2 o[R][NP / 2];
   f32x2 G[ROWGRAD ? R : 1][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
@@ -225,8 +250,9 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
     const int cnt = (int)min((int64_t)TS, je - j0);
     const bool more = j0 + TS < je;
     if (more) st.load(str, lds, j0 + TS, (int)min((int64_t)TS, je - j0 - TS), q.n);   // in flight during the tile
-    const float* tile = tiles[cur];
-    for (int jj = 0; jj < cnt; jj += JB) {
+    const float* tile = tiles[cur] + pq * RPP * NP;
+    const int cq = min(RPP, max(0, cnt - pq * RPP));    // valid rows of this partition (ragged last tile only)
+    for (int jj = 0; jj < cq; jj += JB) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc[JB];
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 #pragma unroll
         for (int c = 0; c < JB; ++c) {
           x[c] = root_of<ROOT>(acc[c], q) * xk;
-          if (jj + c >= cnt) x[c] = -INFINITY;     // ragged tail of the stream (wave-uniform)
+          if (jj + c >= cq) x[c] = -INFINITY;      // ragged tail of the stream
         }
         // clamp keeps (-inf) - (-inf) out of the exponent when nothing valid was seen yet
         const float mn = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(m[r], -1e30f));
@@ -266,16 +292,60 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
     if (more) st.store(tiles[cur ^ 1]);     // last read one iteration ago, behind the previous barrier
     __syncthreads();
   }
+  // ---- merge the workgroup's eight partitions on chip: half-waves by shuffle, waves through LDS (fixed order) ----
+  float* gred = &tiles[0][0];               // [WAVES][HALF * R][NP]; every wave is past its last tile read (barrier above)
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
-    if (i < n_own) {
-      part[(int64_t)blockIdx.y * n_own + i] = make_float2(m[r], s[r]);
+    const float mo = __shfl_xor(m[r], HALF, 64), so = __shfl_xor(s[r], HALF, 64);
+    const float mn = fmaxf(fmaxf(m[r], mo), -1e30f);
+    const float fa = fexp2(m[r] - mn), fb = fexp2(mo - mn);
+    // both halves compute the same merged value, in the same operand order (lower half first)
+    const float s_lo = hf ? so : s[r], s_hi = hf ? s[r] : so, f_lo = hf ? fb : fa, f_hi = hf ? fa : fb;
+    s[r] = fmaf(s_lo, f_lo, s_hi * f_hi);
+    if (ROWGRAD) {
+#pragma unroll
+      for (int k2 = 0; k2 < NP / 2; ++k2) {
+        const float gxo = __shfl_xor(G[r][k2].x, HALF, 64), gyo = __shfl_xor(G[r][k2].y, HALF, 64);
+        const float gx_lo = hf ? gxo : G[r][k2].x, gx_hi = hf ? G[r][k2].x : gxo;
+        const float gy_lo = hf ? gyo : G[r][k2].y, gy_hi = hf ? G[r][k2].y : gyo;
+        G[r][k2].x = fmaf(gx_lo, f_lo, gx_hi * f_hi); G[r][k2].y = fmaf(gy_lo, f_lo, gy_hi * f_hi);
+      }
+    }
+    m[r] = mn;
+    if (hf == 0) {
+      wred[wave][r * HALF + li] = make_float2(m[r], s[r]);
       if (ROWGRAD) {
-        float4* dst = reinterpret_cast<float4*>(part_g + ((int64_t)blockIdx.y * n_own + i) * NP);
+        float4* dst = reinterpret_cast<float4*>(gred + ((size_t)wave * (HALF * R) + r * HALF + li) * NP);
 #pragma unroll
         for (int k4 = 0; k4 < NP / 4; ++k4)
           dst[k4] = make_float4(G[r][2 * k4].x, G[r][2 * k4].y, G[r][2 * k4 + 1].x, G[r][2 * k4 + 1].y);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < HALF * R) {
+    const int t = threadIdx.x;
+    const int64_t i = own0 + t;
+    float mm = -1e30f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) mm = fmaxf(mm, wred[w][t].x);
+    float ss = 0.f, f[WAVES];
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { f[w] = fexp2(wred[w][t].x - mm); ss = fmaf(wred[w][t].y, f[w], ss); }
+    if (i < n_own) {
+      part[(int64_t)blockIdx.y * n_own + i] = make_float2(mm, ss);
+      if (ROWGRAD) {
+        float4* dst = reinterpret_cast<float4*>(part_g + ((int64_t)blockIdx.y * n_own + i) * NP);
+#pragma unroll
+        for (int k4 = 0; k4 < NP / 4; ++k4) {
+          float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int w = 0; w < WAVES; ++w) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gred + ((size_t)w * (HALF * R) + t) * NP + 4 * k4);
+            a4.x = fmaf(g4.x, f[w], a4.x); a4.y = fmaf(g4.y, f[w], a4.y); a4.z = fmaf(g4.z, f[w], a4.z); a4.w = fmaf(g4.w, f[w], a4.w);
+          }
+          dst[k4] = a4;
+        }
       }
     }
   }
@@ -286,24 +356,30 @@ __global__ __launch_bounds__(THREADS) void fwd_partial_k(
 // reduction); bit 1: statistics of the STREAM rows do (d/dz3: column reduction over row-normalised
 // weights); both (3) = the symmetric sweep used when the stream is the pool the owners belong to
 // (z3 = all z1, main_mlp.py:272): d_ij = d_ji, so coef = C_i 2^(x - L_i) + C_j 2^(x - L_j) yields row AND
-// column contributions to dz_i in one pass.
+// column contributions to dz_i in one pass.  Same owner / partition layout as the forward; the eight partitions'
+// gradient partials are summed on chip (shuffle, then LDS in wave order) before one NP-float row per owner and
+// stream split goes to HBM.
 template <int NP, int PK, int R, int STATS, bool ROOT, int NQ = NP / 2>
-__global__ __launch_bounds__(THREADS) void bwd_pairs_k(
+__global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, const float* __restrict__ statL, const float* __restrict__ statC,
     const float* __restrict__ strL, const float* __restrict__ strC,
     float* __restrict__ part, int chunk) {
   constexpr bool OWNER_STATS = (STATS & 1) != 0, STREAM_STATS = (STATS & 2) != 0;
+  constexpr int TS = tile_rows(NP), RPP = TS / PARTS;
+  static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");
   __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
   __shared__ float tLs[2][TS], tCs[2][TS];
-  const int64_t own0 = (int64_t)blockIdx.x * (THREADS * R);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (HALF - 1), hf = lane >> 5;
+  const int pq = wave * 2 + hf;
+  const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
   f32x2 o[R][NP / 2], g[R][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
   float oL[R], oC[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
+    const int64_t i = own0 + (int64_t)r * HALF + li;
     oL[r] = 0.f; oC[r] = 0.f;
     if (OWNER_STATS && i < n_own) { oL[r] = statL[i]; oC[r] = statC[i]; }
 #pragma unroll
@@ -316,15 +392,15 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
   Stager<NP> st;
   float rl = 0.f, rc = 0.f;     // staged stream statistics (threads < TS)
   auto load_stats = [&](int64_t j0, int cnt) {
-    if (STREAM_STATS && threadIdx.x < TS) {
-      const bool ok = threadIdx.x < cnt;
+    if (STREAM_STATS && (int)threadIdx.x < TS) {
+      const bool ok = (int)threadIdx.x < cnt;
       const float l = strL[ok ? j0 + threadIdx.x : 0], c = strC[ok ? j0 + threadIdx.x : 0];
       rl = ok ? l : 0.f;
       rc = ok ? c : 0.f;         // zero coefficient masks the ragged tail
     }
   };
   auto store_stats = [&](int b) {
-    if (STREAM_STATS && threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = rc; }
+    if (STREAM_STATS && (int)threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = rc; }
   };
   if (jb < je) {
     const int c0 = (int)min((int64_t)TS, je - jb);
@@ -340,10 +416,11 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
       const int c1 = (int)min((int64_t)TS, je - j0 - TS);
       st.load(str, lds, j0 + TS, c1, q.n); load_stats(j0 + TS, c1);
     }
-    const float* tile = tiles[cur];
-    const float* tL = tLs[cur];
-    const float* tC = tCs[cur];
-    for (int jj = 0; jj < cnt; jj += JB) {
+    const float* tile = tiles[cur] + pq * RPP * NP;
+    const float* tL = tLs[cur] + pq * RPP;
+    const float* tC = tCs[cur] + pq * RPP;
+    const int cq = min(RPP, max(0, cnt - pq * RPP));
+    for (int jj = 0; jj < cq; jj += JB) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         float acc[JB];
@@ -356,7 +433,7 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
           if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
           if (STREAM_STATS) w = fmaf(tC[jj + c], fexp2(x - tL[jj + c]), w);   // tC = 0 masks the ragged tail
           float cf = w * droot_of<ROOT>(acc[c], q) * csgn;
-          if (OWNER_STATS && jj + c >= cnt) cf = 0.f;
+          if (OWNER_STATS && jj + c >= cq) cf = 0.f;
           coef[c] = cf;
         }
         asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
@@ -374,15 +451,36 @@ __global__ __launch_bounds__(THREADS) void bwd_pairs_k(
     if (more) { st.store(tiles[cur ^ 1]); store_stats(cur ^ 1); }
     __syncthreads();
   }
+  // ---- sum the eight partitions on chip (fixed order: lower half + upper half, then waves 0..3) ----
+  float* gred = &tiles[0][0];               // [WAVES][HALF * R][NP]
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    int64_t i = own0 + (int64_t)r * THREADS + threadIdx.x;
-    if (i < n_own) {
-      float4* dst = reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * n_own + i) * NP);
+#pragma unroll
+    for (int k2 = 0; k2 < NP / 2; ++k2) {
+      const float gxo = __shfl_xor(g[r][k2].x, HALF, 64), gyo = __shfl_xor(g[r][k2].y, HALF, 64);
+      g[r][k2].x = hf ? gxo + g[r][k2].x : g[r][k2].x + gxo;
+      g[r][k2].y = hf ? gyo + g[r][k2].y : g[r][k2].y + gyo;
+    }
+    if (hf == 0) {
+      float4* dst = reinterpret_cast<float4*>(gred + ((size_t)wave * (HALF * R) + r * HALF + li) * NP);
 #pragma unroll
       for (int k4 = 0; k4 < NP / 4; ++k4)
         dst[k4] = make_float4(g[r][2 * k4].x, g[r][2 * k4].y, g[r][2 * k4 + 1].x, g[r][2 * k4 + 1].y);
     }
+  }
+  __syncthreads();
+  constexpr int Q4 = NP / 4;
+  for (int u = threadIdx.x; u < HALF * R * Q4; u += THREADS) {
+    const int t = u / Q4, k4 = u - t * Q4;
+    const int64_t i = own0 + t;
+    if (i >= n_own) continue;
+    float4 a4 = *reinterpret_cast<const float4*>(gred + (size_t)t * NP + 4 * k4);
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gred + ((size_t)w * (HALF * R) + t) * NP + 4 * k4);
+      a4.x += g4.x; a4.y += g4.y; a4.z += g4.z; a4.w += g4.w;
+    }
+    *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * n_own + i) * NP + 4 * k4) = a4;
   }
 }
 
@@ -397,41 +495,46 @@ constexpr int owners_bwd(int np) { return np <= 16 ? 2 : 1; }
 
 struct Plan {
   int np, R;
-  int64_t tiles;  // owner tiles
+  int64_t tiles;  // owner tiles (32 R owners each)
   int nsplit, chunk;
 };
 inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
   Plan P;
   P.np = pad_dim(n);
   P.R = bwd ? owners_bwd(P.np) : owners_fwd(P.np);
-  P.tiles = ceil_div(n_own, (int64_t)THREADS * P.R);
-  // Stream splits.  Every workgroup of a launch is resident at once and the loop is VALU-bound, so a launch lasts as long as
-  // its most loaded CU: ceil(workgroups / 256) x (rows per split + a fixed prologue).  Pick the split count that
-  // minimises that, each split a whole number of TS-row LDS tiles, with 3..10 workgroups per CU (>= 4 waves per SIMD
-  // cover the LDS-broadcast and exp latencies; a mild penalty below 6 per CU).  E.g. B3 = 49 152: 128 splits of 384 rows =
-  // exactly 6 workgroups per CU (-7 % vs the "about 8 per CU" rule, whose 154 splits of 320 rows left a ragged 7.2).
-  // CLICA_LP_WG_PER_CU[_FWD] = <k> forces "about k per CU" instead (tuning).
-  const char* env = getenv(bwd ? "CLICA_LP_WG_PER_CU" : "CLICA_LP_WG_PER_CU_FWD");
-  const int64_t max_split = ceil_div(n_str, (int64_t)TS);
+  P.tiles = ceil_div(n_own, (int64_t)HALF * P.R);
+  const int64_t TS = tile_rows(P.np);
+  // HBM-level stream splits.  A workgroup already cuts its chunk eight ways on chip, so only enough splits are needed to
+  // give every CU a few whole workgroups: all workgroups of a launch are resident at once and the loop is VALU-bound, so the
+  // launch lasts as long as its most loaded CU, ceil(workgroups / 256) x (rows per split + a fixed prologue / merge cost).
+  // Splits are whole LDS tiles; 2..6 workgroups per CU (8..24 waves).  E.g. B = B3 = 6144, n = 10: 96 tiles x 8 splits of
+  // 768 rows = exactly 3 per CU; the 8-rank pool (B3 = 49 152): 96 x 8 splits of 6144 rows.
+  // CLICA_LP_WG_PER_CU[_FWD] = <k> forces "about k per CU" instead (tuning; read once).
+  static const int env_b = [] { const char* e = getenv("CLICA_LP_WG_PER_CU"); return e ? atoi(e) : 0; }();
+  static const int env_f = [] { const char* e = getenv("CLICA_LP_WG_PER_CU_FWD"); return e ? atoi(e) : 0; }();
+  const int env = bwd ? env_b : env_f;
+  const int64_t max_split = ceil_div(n_str, TS);
   auto finish = [&](int64_t ns) {
     if (ns < 1) ns = 1;
     if (ns > max_split) ns = max_split;
-    int64_t chunk = ceil_div(ceil_div(n_str, ns), (int64_t)TS) * TS;
+    int64_t chunk = ceil_div(ceil_div(n_str, ns), TS) * TS;
     if (chunk < TS) chunk = TS;
     P.chunk = (int)chunk;
     P.nsplit = (int)(n_str > 0 ? ceil_div(n_str, chunk) : 1);
   };
-  if (env) { finish(ceil_div((int64_t)kNumCU * atoi(env), P.tiles)); return P; }
+  if (env > 0) { finish(ceil_div((int64_t)kNumCU * env, P.tiles)); return P; }
   double best = 1e300; int64_t best_ns = 1;
-  const int64_t lo = ceil_div((int64_t)kNumCU * 3, P.tiles), hi = ceil_div((int64_t)kNumCU * 10, P.tiles);
+  const int64_t lo = ceil_div((int64_t)kNumCU * 2, P.tiles), hi = ceil_div((int64_t)kNumCU * 6, P.tiles);
   const int64_t ns_hi = hi > max_split ? max_split : (hi < 1 ? 1 : hi);
   const int64_t ns_lo = lo < 1 ? 1 : (lo > ns_hi ? ns_hi : lo);        // short streams: as many splits as there are tiles of rows
   for (int64_t ns = ns_lo; ns <= ns_hi; ++ns) {
-    const int64_t chunk = ceil_div(ceil_div(n_str, ns), (int64_t)TS) * TS;
+    const int64_t chunk = ceil_div(ceil_div(n_str, ns), TS) * TS;
     const int64_t nsp = ceil_div(n_str, chunk);
     const int64_t rounds = ceil_div(P.tiles * nsp, (int64_t)kNumCU);
-    const double cost = (double)rounds * (double)(chunk + 32) * (1.0 + 0.02 * (rounds < 6 ? 6 - rounds : 0));
-    if (cost < best - 1e-9 || (cost < best + 1e-9 && nsp > best_ns)) { best = cost; best_ns = nsp; }
+    // per-workgroup fixed cost (owner load, first tile, on-chip merge, partial store) ~ 192 stream rows' worth; a mild
+    // penalty below 3 workgroups per CU (fewer than 12 waves leave LDS-broadcast and exp latency exposed)
+    const double cost = (double)rounds * (double)(chunk + 192) * (1.0 + 0.03 * (rounds < 3 ? 3 - rounds : 0)) + 4.0 * (double)nsp;
+    if (cost < best - 1e-9) { best = cost; best_ns = nsp; }
   }
   finish(best_ns);
   return P;
