@@ -92,6 +92,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_softclip_bwd": [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i32, C.c_void_p],
     "clica_leaky_relu_fwd": [c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i32, C.c_float, C.c_void_p],
     "clica_leaky_relu_bwd": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i32, C.c_float, C.c_void_p],
+    "clica_mixing_fwd_act": [c_f32p, c_i64, c_f32p, c_i32, c_i32, C.c_float, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],
     "clica_mixing_fwd": [c_f32p, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i64, c_i32, C.c_void_p],
     "clica_adam_step": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
     "clica_adam_step_at": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_i32,

@@ -454,6 +454,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
 constexpr int MAXG = 8;            // problems (layers) per grouped launch
 constexpr int TINY_MAX_S = 16;
 constexpr int TINY_ROWS = 64;       // batch rows per LDS tile
+constexpr int TINY_MAX_LG = 128;    // widest large dimension: LDS tile [TINY_ROWS][Lg] = 32 KB
 // global -> LDS copy of `count` floats of a row block: flat float4 when the block is contiguous and aligned (the
 // encoder's activations / gradients are), element-wise otherwise.  Eight loads are in flight per thread and pass.
 template <int THREADS>
@@ -492,7 +493,9 @@ __device__ __forceinline__ void tiny_stage(float* dst, int dst_ld, const float* 
     }
   }
 }
-template <int THREADS>
+// S4 = ceil(S / 4): the small dimension in float4 units, a compile-time constant so that the row loop is branch-free and its
+// LDS reads can be batched four rows deep (the first version waited for every ds_read_b128 in turn: ~11 of its 19 us).
+template <int THREADS, int S4>
 __device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = (int)g.M, K = (int)g.N;               // dW is [N][K]; A = dZ [rows][N], B = X [rows][K]
@@ -504,53 +507,90 @@ __device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
   const int gq = threadIdx.x / Lg, l = threadIdx.x - gq * Lg;
   const bool active = gq < G;
   float* Ls = smem;                                     // [TINY_ROWS][Lg]
-  float* Ss = smem + TINY_ROWS * Lg;                    // [TINY_ROWS][S]  (S padded to 16 for the broadcast reads below)
+  float* Ss = smem + TINY_ROWS * Lg;                    // [TINY_ROWS][16]: columns >= S and rows beyond the chunk are zeros
   const int64_t kbeg = (int64_t)bz * g.k_per_split, kend = min(g.Kc, kbeg + g.k_per_split);
-  float acc[TINY_MAX_S];
+  float4 acc[S4];
 #pragma unroll
-  for (int u = 0; u < TINY_MAX_S; ++u) acc[u] = 0.f;
+  for (int u = 0; u < S4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   float accl = 0.f;                                     // column sum of the large operand (db when A is large)
-  float accs[TINY_MAX_S];                               // column sums of the small operand (db when A is small), thread l == 0
-#pragma unroll
-  for (int u = 0; u < TINY_MAX_S; ++u) accs[u] = 0.f;
+  float accs = 0.f;                                     // column sum of the small operand, thread u < S (db when A is small)
   const bool want_db = g.dbias_slab != nullptr;
-  const bool small_db = want_db && !a_large && l == 0;
-  for (int64_t r0 = kbeg; r0 < kend; r0 += TINY_ROWS) {
+  const int nit = (TINY_ROWS + G - 1) / G;              // row iterations per tile and thread group
+  // register prefetch of the NEXT tile (issued before this tile's arithmetic): the large operand's tile when it is one flat,
+  // 16-byte aligned block (the encoder's activations / gradients are), and the small operand always
+  constexpr int LQ = (TINY_ROWS * TINY_MAX_LG / 4 + THREADS - 1) / THREADS;        // float4 per thread
+  constexpr int RPP = THREADS / TINY_MAX_S, SQ = TINY_ROWS / RPP;
+  float4 lq[LQ]; float sq[SQ];
+  const bool flat = ldl == Lg && ((reinterpret_cast<uintptr_t>(Lp) & 15) == 0) && (((int64_t)Lg * kbeg) % 4 == 0) &&
+                    ((Lg * TINY_ROWS) % 4 == 0);
+  const int t4 = TINY_ROWS * Lg / 4;
+  const int sc = threadIdx.x & (TINY_MAX_S - 1), sr0 = threadIdx.x >> 4;
+  auto fetch = [&](int64_t r0) {
     const int rv = (int)min((int64_t)TINY_ROWS, kend - r0);
-    __syncthreads();                                    // every thread is done with the previous tile
-    tiny_stage<THREADS>(Ls, Lg, Lp, ldl, Lg, r0, rv, TINY_ROWS);
-    {   // small operand: 16 threads per row (division-free), THREADS / 16 rows per pass
-      const int c = threadIdx.x & (TINY_MAX_S - 1);
-      constexpr int RPP = THREADS / TINY_MAX_S;
-      float sv[TINY_ROWS / RPP];
+    if (flat) {
+      const float4* s4 = reinterpret_cast<const float4*>(Lp + r0 * ldl);
+      const int n4 = rv * Lg / 4;          // rv * Lg is a multiple of 4 for full tiles; a ragged last tile takes the tail below
 #pragma unroll
-      for (int ps = 0; ps < TINY_ROWS / RPP; ++ps) {
-        const int r = (threadIdx.x >> 4) + ps * RPP;
-        const bool ok = c < S && r < rv;
-        const float x = Sp[ok ? (r0 + r) * lds_ + c : 0];
-        sv[ps] = ok ? x : 0.f;
+      for (int i = 0; i < LQ; ++i) {
+        const int idx = threadIdx.x + i * THREADS;
+        lq[i] = idx < n4 ? s4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-#pragma unroll
-      for (int ps = 0; ps < TINY_ROWS / RPP; ++ps) Ss[((threadIdx.x >> 4) + ps * RPP) * TINY_MAX_S + c] = sv[ps];
     }
-    __syncthreads();
-    if (active) {
-      for (int r = gq; r < rv; r += G) {
-        const float v = Ls[r * Lg + l];
-        const float4* sr = reinterpret_cast<const float4*>(&Ss[r * TINY_MAX_S]);
-        accl += v;
 #pragma unroll
-        for (int u4 = 0; u4 < TINY_MAX_S / 4; ++u4) {
-          if (4 * u4 < S) {                             // columns S .. 4*ceil(S/4)-1 of Ss hold stale data: masked below
-            const float4 sv = sr[u4];
-            acc[4 * u4 + 0] = fmaf(v, sv.x, acc[4 * u4 + 0]); acc[4 * u4 + 1] = fmaf(v, sv.y, acc[4 * u4 + 1]);
-            acc[4 * u4 + 2] = fmaf(v, sv.z, acc[4 * u4 + 2]); acc[4 * u4 + 3] = fmaf(v, sv.w, acc[4 * u4 + 3]);
-            if (small_db) {
-              accs[4 * u4 + 0] += sv.x; accs[4 * u4 + 1] += sv.y; accs[4 * u4 + 2] += sv.z; accs[4 * u4 + 3] += sv.w;
-            }
+    for (int ps = 0; ps < SQ; ++ps) {
+      const int r = sr0 + ps * RPP;
+      const bool ok = sc < S && r < rv;
+      const float x = Sp[ok ? (r0 + r) * lds_ + sc : 0];
+      sq[ps] = ok ? x : 0.f;
+    }
+  };
+  auto stash = [&](int64_t r0) {
+    const int rv = (int)min((int64_t)TINY_ROWS, kend - r0);
+    if (flat && (rv * Lg) % 4 == 0) {
+#pragma unroll
+      for (int i = 0; i < LQ; ++i) {
+        const int idx = threadIdx.x + i * THREADS;
+        if (idx < t4) reinterpret_cast<float4*>(Ls)[idx] = lq[i];
+      }
+    } else {
+      tiny_stage<THREADS>(Ls, Lg, Lp, ldl, Lg, r0, rv, TINY_ROWS);
+    }
+#pragma unroll
+    for (int ps = 0; ps < SQ; ++ps) Ss[(sr0 + ps * RPP) * TINY_MAX_S + sc] = sq[ps];
+  };
+  if (kbeg < kend) fetch(kbeg);
+  for (int64_t r0 = kbeg; r0 < kend; r0 += TINY_ROWS) {
+    __syncthreads();                                    // every thread is done with the previous tile
+    stash(r0);
+    __syncthreads();
+    if (r0 + TINY_ROWS < kend) fetch(r0 + TINY_ROWS);   // in flight during this tile's arithmetic
+    if (active) {
+      for (int i0 = 0; i0 < nit; i0 += 4) {             // four rows per pass: 4 + 4 S4 LDS reads issued before the FMAs
+        float v[4]; float4 sv[4][S4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = gq + (i0 + j) * G;
+          const bool ok = (i0 + j) < nit && r < TINY_ROWS;
+          const int rc = ok ? r : 0;
+          const float x = Ls[rc * Lg + l];
+          v[j] = ok ? x : 0.f;
+#pragma unroll
+          for (int u = 0; u < S4; ++u) sv[j][u] = *reinterpret_cast<const float4*>(&Ss[rc * TINY_MAX_S + 4 * u]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          accl += v[j];
+#pragma unroll
+          for (int u = 0; u < S4; ++u) {
+            acc[u].x = fmaf(v[j], sv[j][u].x, acc[u].x); acc[u].y = fmaf(v[j], sv[j][u].y, acc[u].y);
+            acc[u].z = fmaf(v[j], sv[j][u].z, acc[u].z); acc[u].w = fmaf(v[j], sv[j][u].w, acc[u].w);
           }
         }
       }
+    }
+    if (want_db && !a_large && (int)threadIdx.x < S) {  // db = column sums of the small operand (rows beyond the chunk are zeros)
+#pragma unroll 8
+      for (int r = 0; r < TINY_ROWS; ++r) accs += Ss[r * TINY_MAX_S + threadIdx.x];
     }
   }
   // fixed-order sum over the G groups through LDS: red[gq][l][0..16]  (17 floats per (gq, l): conflict-free stride)
@@ -559,13 +599,11 @@ __device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
   float* red = smem;
   if (active) {
 #pragma unroll
-    for (int u = 0; u < TINY_MAX_S; ++u) red[(gq * Lg + l) * RS + u] = acc[u];
+    for (int u = 0; u < S4; ++u) {
+      float* d = &red[(gq * Lg + l) * RS + 4 * u];
+      d[0] = acc[u].x; d[1] = acc[u].y; d[2] = acc[u].z; d[3] = acc[u].w;
+    }
     red[(gq * Lg + l) * RS + TINY_MAX_S] = accl;
-  }
-  float* red2 = smem + (size_t)G * Lg * RS;             // [G][16] small-operand column sums
-  if (active && l == 0) {
-#pragma unroll
-    for (int u = 0; u < TINY_MAX_S; ++u) red2[gq * TINY_MAX_S + u] = accs[u];
   }
   __syncthreads();
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
@@ -583,12 +621,8 @@ __device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
         for (int q = 0; q < G; ++q) t += red[(q * Lg + ll) * RS + TINY_MAX_S];
         dbs[ll] = t;
       }
-    } else {
-      for (int u = threadIdx.x; u < S; u += THREADS) {
-        float t = 0.f;
-        for (int q = 0; q < G; ++q) t += red2[q * TINY_MAX_S + u];
-        dbs[u] = t;
-      }
+    } else if ((int)threadIdx.x < S) {
+      dbs[threadIdx.x] = accs;
     }
   }
 }
@@ -599,9 +633,15 @@ __device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
 constexpr int TINY_THREADS = 256;
 struct TinyArgs { int n; Args p[MAXG]; };
 __global__ __launch_bounds__(TINY_THREADS) void wgrad_tiny_k(TinyArgs T) {
-  wgrad_tiny_body<TINY_THREADS>(T.p[blockIdx.y], (int)blockIdx.x);
+  const Args& g = T.p[blockIdx.y];
+  const int S = (int)(g.M < g.N ? g.M : g.N);
+  switch ((S + 3) / 4) {
+    case 1: wgrad_tiny_body<TINY_THREADS, 1>(g, (int)blockIdx.x); break;
+    case 2: wgrad_tiny_body<TINY_THREADS, 2>(g, (int)blockIdx.x); break;
+    case 3: wgrad_tiny_body<TINY_THREADS, 3>(g, (int)blockIdx.x); break;
+    default: wgrad_tiny_body<TINY_THREADS, 4>(g, (int)blockIdx.x); break;
+  }
 }
-constexpr int TINY_MAX_LG = 128;    // LDS tile [TINY_ROWS][Lg] = 64 KB
 static bool tiny_eligible(int64_t N, int64_t K, int threads) {
   const int64_t S = N < K ? N : K, Lg = N < K ? K : N;
   return S <= TINY_MAX_S && Lg <= TINY_MAX_LG && Lg <= threads;
@@ -646,7 +686,26 @@ __device__ __forceinline__ void reduce_units(const float* __restrict__ src, int 
   float4 p[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e < total) {
+  if (e < total && splits > 32) {
+    // many short slabs (the tiny-dimension layers: ~100 row chunks): eight loads in flight per wave and pass; the partial sums
+    // keep a fixed association ((u, u + 4) pairs into p[u]) so the result does not depend on timing
+    for (int s0 = w; s0 < splits; s0 += 8 * W) {
+      float4 q8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * W;
+        q8[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < splits) {
+          if (VEC4) q8[u] = *reinterpret_cast<const float4*>(src + (int64_t)s * total + e);
+          else q8[u].x = src[(int64_t)s * total + e];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u].x += q8[u].x + q8[u + 4].x; p[u].y += q8[u].y + q8[u + 4].y; p[u].z += q8[u].z + q8[u + 4].z; p[u].w += q8[u].w + q8[u + 4].w;
+      }
+    }
+  } else if (e < total) {
     for (int s0 = w; s0 < splits; s0 += 4 * W) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -55,7 +55,7 @@ class ContrastiveTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
                  force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True,
-                 split_bf16: Optional[bool] = None):
+                 split_bf16: Optional[bool] = None, g_act_kind: int = 0):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -64,6 +64,7 @@ class ContrastiveTrainer:
         self.p, self.tau, self.alpha = float(p), float(tau), float(alpha)
         self.lr, self.betas, self.eps = float(lr), betas, float(eps)
         self.g_slope = float(g_slope)
+        self.g_act_kind = int(g_act_kind)     # hidden activation of g (ops.MIX_ACT); the fused prologue handles LeakyReLU / ReLU only
         self.overlap_backward = bool(overlap_backward)
         self.gW = g_weights.detach().to(self.device, torch.float32).contiguous()
         assert self.gW.shape[1:] == (self.n, self.n)
@@ -86,7 +87,7 @@ class ContrastiveTrainer:
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
         # CLICA_FUSE_SMALL bit 4: mixing net g inside the fused forward's prologue (needs the one-launch forward, n <= 16)
         self.mix_in_forward = bool(getattr(self, "_fuse_flags", int(os.environ.get("CLICA_FUSE_SMALL", "13"))) & 4) \
-            and self.fused_forward and self.n <= 16
+            and self.fused_forward and self.n <= 16 and self.g_act_kind == 0
         self._x_pending = False
         self.packed = None
         self.packed_t = None
@@ -225,7 +226,7 @@ class ContrastiveTrainer:
                        seed=s.seed, stream_id=sid, step_dev=self.step_dev, out=z)
             ops.sample(s.space, s.conditional, n, B, self.device, mean=z, scale=s.c_param, shape_p=s.c_p, box=s.box,
                        seed=s.seed, stream_id=sid + 1, step_dev=self.step_dev, out=zt)
-            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x, act_kind=self.g_act_kind)
             return
         ops.sample_pair(s.space, s.marginal, s.conditional, n, B, z, zt, marginal_mean=mean, m_scale=s.m_param, m_p=s.m_p,
                         c_scale=s.c_param, c_p=s.c_p, box=s.box, seed=s.seed, stream_id=sid, step_dev=self.step_dev)
@@ -240,7 +241,7 @@ class ContrastiveTrainer:
         """x = g(z): its own launch, unless the fused forward runs the mixing net in its prologue."""
         self._x_pending = self.mix_in_forward
         if not self.mix_in_forward:
-            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x)
+            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x, act_kind=self.g_act_kind)
 
     # -------------------------------------------------------------------------------- step pieces
     def pack(self):

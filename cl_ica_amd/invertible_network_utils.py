@@ -17,7 +17,21 @@ from . import ops
 
 __all__ = ["construct_invertible_mlp", "MixingMLP"]
 
-_ACT_SLOPES = {"leaky_relu": 0.2, "relu": 0.0}
+# act_fct -> (kernel activation kind, its parameter, the nn.Module the reference puts between the Linear layers)
+class SmoothLeakyReLU(nn.Module):
+    """alpha x + (1 - alpha) log(1 + e^x) (reference invertible_network_utils.py:43-49); parameter-free."""
+
+    def __init__(self, alpha=0.2):
+        super().__init__()
+        self.alpha = alpha
+
+    def forward(self, x):
+        return self.alpha * x + (1 - self.alpha) * torch.log(1 + torch.exp(x))
+
+
+_ACTS = {"leaky_relu": (0, 0.2, lambda: nn.LeakyReLU(negative_slope=0.2)), "relu": (0, 0.0, lambda: nn.ReLU()),
+         "elu": (1, 1.0, lambda: nn.ELU(alpha=1.0)), "smooth_leaky_relu": (2, 0.2, lambda: SmoothLeakyReLU(alpha=0.2)),
+         "softplus": (3, 1.0, lambda: nn.Softplus(beta=1))}
 
 
 def _column_normalised(n: int) -> np.ndarray:
@@ -54,16 +68,22 @@ class MixingMLP(nn.Sequential):
     (same state-dict keys ``0.weight, 2.weight, ...`` as the reference's g.pth) whose forward is the
     single fused HIP kernel."""
 
-    def __init__(self, mats, slope: float):
+    def __init__(self, mats, slope: float = 0.2, act_fct: str = None):
+        if act_fct is None:
+            act_fct = "leaky_relu" if slope > 0 else "relu"
+        kind, param, make = _ACTS[act_fct]
+        if act_fct == "leaky_relu":
+            param, make = slope, (lambda: nn.LeakyReLU(negative_slope=slope))
         mods = []
         for i, w in enumerate(mats):
             lin = nn.Linear(w.shape[1], w.shape[0], bias=False)
             lin.weight.data = torch.tensor(w, dtype=torch.float32)
             mods.append(lin)
             if i < len(mats) - 1:
-                mods.append(nn.LeakyReLU(negative_slope=slope) if slope > 0 else nn.ReLU())
+                mods.append(make())
         super().__init__(*mods)
-        self.slope = slope
+        self.act_fct, self.act_kind = act_fct, kind
+        self.slope = param          # the activation's parameter (negative slope / alpha / beta)
         for p in self.parameters():
             p.requires_grad = False
         self._stack = None
@@ -85,17 +105,17 @@ class MixingMLP(nn.Sequential):
         return super()._apply(fn, *a, **k)
 
     def forward(self, z):
-        return ops.mixing_fwd(z, self.weight_stack(), self.slope)
+        return ops.mixing_fwd(z, self.weight_stack(), self.slope, act_kind=self.act_kind)
 
 
 def construct_invertible_mlp(n: int = 20, n_layers: int = 2, n_iter_cond_thresh: int = 10000,
                              cond_thresh_ratio: float = 0.25, weight_matrix_init: str = "pcl",
                              act_fct: str = "leaky_relu"):
     """Create an (approximately) invertible mixing network based on an MLP (same arguments as the
-    reference).  Only the piecewise-linear activations have a fused forward ("leaky_relu", the
-    default of every driver, and "relu")."""
-    if act_fct not in _ACT_SLOPES:
-        raise NotImplementedError(f"activation {act_fct!r}: the fused mixing kernel implements leaky_relu/relu "
-                                  "(main_mlp.py uses leaky_relu)")
+    reference: "relu", "leaky_relu", "elu", "smooth_leaky_relu", "softplus"; "max_out" raises there as well)."""
+    if act_fct == "max_out":
+        raise NotImplementedError("max_out is not implemented by the reference either (invertible_network_utils.py:58-59)")
+    if act_fct not in _ACTS:
+        raise Exception(f"activation function {act_fct} not defined.")
     mats, _ = mixing_weights(n, n_layers, n_iter_cond_thresh, cond_thresh_ratio, weight_matrix_init)
-    return MixingMLP(mats, _ACT_SLOPES[act_fct])
+    return MixingMLP(mats, act_fct=act_fct)

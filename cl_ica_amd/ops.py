@@ -330,16 +330,20 @@ def leaky_relu_bwd(yact, dy, slope: float = 0.01):
 
 
 # ------------------------------------------------------------------------------- mixing / adam / sampler
-def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: Optional[torch.Tensor] = None):
-    """x = W_L phi(... phi(W_1 z)); `weights` is a contiguous [L, n, n] stack (nn.Linear layout)."""
+MIX_ACT = {"leaky_relu": 0, "relu": 0, "elu": 1, "smooth_leaky_relu": 2, "softplus": 3}
+
+
+def mixing_fwd(z: torch.Tensor, weights: torch.Tensor, slope: float = 0.2, out: Optional[torch.Tensor] = None, act_kind: int = 0):
+    """x = W_L phi(... phi(W_1 z)); `weights` is a contiguous [L, n, n] stack (nn.Linear layout).  `act_kind` / `slope`:
+    0 LeakyReLU(slope) (slope 0 = ReLU), 1 ELU(alpha = slope), 2 SmoothLeakyReLU(alpha = slope), 3 Softplus(beta = slope)."""
     (z, ldz) = _mat("z", z)
     require_cuda(weights, "weights")
     M, n = z.shape
     if weights.dim() != 3 or weights.shape[1:] != (n, n) or not weights.is_contiguous():
         raise ValueError(f"weights must be contiguous [L,{n},{n}], got {tuple(weights.shape)}")
     x = out if out is not None else torch.empty((M, n), dtype=torch.float32, device=z.device)
-    check(load().clica_mixing_fwd(z.data_ptr(), ldz, weights.data_ptr(), weights.shape[0], float(slope), x.data_ptr(),
-                                  x.stride(0), M, n, stream_ptr()), "clica_mixing_fwd")
+    check(load().clica_mixing_fwd_act(z.data_ptr(), ldz, weights.data_ptr(), weights.shape[0], int(act_kind), float(slope), x.data_ptr(),
+                                      x.stride(0), M, n, stream_ptr()), "clica_mixing_fwd_act")
     return x
 
 

@@ -164,7 +164,7 @@ def main(argv=None):
         fused = (not supervised) and args.p != 0
         if fused:
             trainer = ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=args.tau,
-                                         lr=args.lr, g_slope=g.slope, device=device,
+                                         lr=args.lr, g_slope=g.slope, g_act_kind=g.act_kind, device=device,
                                          process_group=None if world == 1 else torch.distributed.group.WORLD)
             if world == 1 and not args.no_graph:
                 trainer.capture()

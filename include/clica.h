@@ -297,6 +297,11 @@ int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_
  * ---------------------------------------------------------------------------------- */
 int clica_mixing_fwd(const float* Z, int64_t ldz, const float* W, int32_t n_layers, float slope,
                      float* X, int64_t ldx, int64_t M, int32_t n, clica_stream_t stream);
+/* The other hidden activations construct_invertible_mlp offers (invertible_network_utils.py:44-66, --act-fct):
+ *   act_kind 0: LeakyReLU(act_param) [0.2; act_param = 0 is ReLU]   1: ELU(alpha = act_param)
+ *            2: SmoothLeakyReLU, a x + (1 - a) log(1 + e^x)         3: Softplus(beta = act_param, threshold 20) */
+int clica_mixing_fwd_act(const float* Z, int64_t ldz, const float* W, int32_t n_layers, int32_t act_kind, float act_param,
+                         float* X, int64_t ldx, int64_t M, int32_t n, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Adam  --  torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) as used at main_mlp.py:312,

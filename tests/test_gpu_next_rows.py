@@ -164,3 +164,31 @@ def test_dropin_fused_path_matches_per_layer_path(opt_kind, monkeypatch):
             for k, (u, v) in enumerate(zip(ga[:-1], gb[:-1])):     # last bias: exact gradient 0
                 PARITY.check("dropin_fused_vs_per_layer", f"{opt_kind} step0", f"grad{k}", u.cpu().numpy(), v.cpu().numpy(), tol=3e-6, note="HIP vs HIP")
     assert res["1"][0][2][0] < res["1"][0][0][0]          # it trains: the packs followed the weights
+
+
+def test_mixing_net_activations_goldens(golden):
+    """Every hidden activation construct_invertible_mlp offers (--act-fct relu | leaky_relu | elu | smooth_leaky_relu | softplus,
+    invertible_network_utils.py:51-66): the reference's weights loaded into MixingMLP, forward on the HIP kernel vs G17; the
+    module list (state-dict layout) matches; the engine takes a non-piecewise-linear g through its separate mixing launch."""
+    from cl_ica_amd import invertible_network_utils as inu, encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    z = golden("g17_mixing_acts.npz").z
+    for act in [str(a) for a in z["acts"]]:
+        Ws = [z[f"{act}/W{l}"] for l in range(3)]
+        g = inu.MixingMLP(Ws, act_fct=act).to("cuda")
+        assert [type(m).__name__ for m in g] == [str(m) for m in z[f"{act}/modules"]]
+        y = g(dev(z[f"{act}/x"]))
+        PARITY.check("mixing_activations_g17", act, "forward", y.cpu().numpy(), z[f"{act}/y"])
+        import contextlib, io
+        np.random.seed(1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g2 = inu.construct_invertible_mlp(n=6, n_layers=3, act_fct=act, cond_thresh_ratio=0.0, n_iter_cond_thresh=50).to("cuda")
+        assert g2.act_fct == act
+        f = encoders.get_mlp(6, 6, [12, 24, 12])
+        tr = ContrastiveTrainer(f, g2.weight_stack(), SamplerSpec(n=6), batch_size=256, p=2, lr=1e-3, g_slope=g2.slope,
+                                g_act_kind=g2.act_kind, device="cuda")
+        out = tr.step()
+        assert torch.isfinite(out).all()
+        assert torch.allclose(tr.x, g2(tr.z), rtol=1e-6, atol=1e-6)          # the engine's x = g(z) is the module's forward
+    with pytest.raises(Exception):
+        inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="tanh")

@@ -68,8 +68,12 @@ def test_mixing_constructor_kat(golden):
     assert abs(float(b2.getvalue().splitlines()[0].split(":")[1]) - 4.085284) < 1e-6
     for i, m in enumerate([m for m in g if isinstance(m, torch.nn.Linear)]):
         assert np.array_equal(m.weight.detach().numpy(), z[f"W{i}"])
-    with pytest.raises(NotImplementedError):
-        inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="softplus", n_iter_cond_thresh=10)
+    with pytest.raises(NotImplementedError):       # the reference raises for max_out as well (invertible_network_utils.py:58-59)
+        inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="max_out", n_iter_cond_thresh=10)
+    np.random.seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gs = inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="softplus", n_iter_cond_thresh=10)
+    assert isinstance(gs[1], torch.nn.Softplus) and gs.act_kind == 3 and list(gs.state_dict().keys()) == ["0.weight", "2.weight"]
 
 
 def test_no_cpu_fallback_anywhere():

@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 src = f"gpurun_out/profile_{tag}"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
@@ -26,7 +26,7 @@ def agg(path):
 
 
 pm = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_valu"):
     p = f"{src}/{name}/p_counter_collection.csv"
     if os.path.exists(p):
         for k, v in agg(p).items():
@@ -40,7 +40,11 @@ lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py
          "PMC columns come from separate `--pmc` passes (FETCH_SIZE / WRITE_SIZE in KB per launch, as reported; per "
          "MI355X_MICROARCH.md FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 -> `fetch_x2_MB`). "
          "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs).", "",
-         "| kernel | calls | avg us | % time | fetch_x2 MB | write MB | MfmaUtil | LDS bank conflicts |", "|---|---|---|---|---|---|---|---|"]
+         "VALU busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles -> cycles) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of SIMD cycles "
+         "in which the vector ALU is executing; VALU/wave = SQ_INSTS_VALU / SQ_WAVES; wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt / "
+         "barrier), issue-stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.", "",
+         "| kernel | calls | avg us | % time | fetch_x2 MB | write MB | MfmaUtil | VALU busy | VALU inst/launch | LDS inst/launch | wait | issue-stall | LDS bank conflicts |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for r in stats:
     name = r["Name"]
     c = pm.get(name, {})
@@ -51,7 +55,13 @@ for r in stats:
         util = f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.2f}"
     conf = f"{c['SQ_LDS_BANK_CONFLICT']:.0f}" if "SQ_LDS_BANK_CONFLICT" in c else ""
     short = name.split("(")[0].replace("void ", "")
-    lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {util} | {conf} |")
+    vbusy = f"{4 * c['SQ_ACTIVE_INST_VALU'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.2f}" if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE") else ""
+    vinst = f"{c['SQ_INSTS_VALU']:.0f}" if "SQ_INSTS_VALU" in c else ""
+    linst = f"{c['SQ_INSTS_LDS']:.0f}" if "SQ_INSTS_LDS" in c else ""
+    wait = f"{c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.2f}" if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else ""
+    stall = f"{c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.2f}" if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c else ""
+    lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {util} | {vbusy} | "
+                 f"{vinst} | {linst} | {wait} | {stall} | {conf} |")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 # per-launch HBM-side traffic (FETCH_SIZE x 2 + WRITE_SIZE, bytes) of every kernel symbol: bench.py's roofline.traffic
 traffic = {}
