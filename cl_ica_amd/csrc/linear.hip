@@ -306,9 +306,17 @@ template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcn
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
+// Debug build only (-DCLICA_WGRAD_TRACE, tools/wgrad_trace.py): s_memtime stamps per (workgroup, wave, phase).
+#ifdef CLICA_WGRAD_TRACE
+__device__ unsigned long long* g_wtrace = nullptr;
+#define WG_STAMP(ph) do { if (g_wtrace && (threadIdx.x & 63) == 0) g_wtrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (ph)] = clock64(); } while (0)
+#else
+#define WG_STAMP(ph) do { } while (0)
+#endif
 constexpr int DMA_STAGES = 4;
 template <int WM, int WN>
 __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, const int by, const int bz) {
+  WG_STAMP(0);
   constexpr int BM = 128, BN = 128, THREADS = 64 * WM * WN, WAVES = WM * WN;
   static_assert(WAVES == 8, "eight waves: each issues 2 + 2 one-KB loads per 32-deep tile");
   using TA = Tile<BM, false, THREADS>;
@@ -377,6 +385,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
   if (ntiles > 2) issue(2);
   if (ntiles > 2) wait_vm<2 * PER_TILE>(); else if (ntiles > 1) wait_vm<PER_TILE>(); else wait_vm<0>();
   __syncthreads();
+  WG_STAMP(1);
 
   constexpr int KSTEPS = BK / 8;
   float af[2][NBM][4], bf[2][NBN][4];
@@ -409,6 +418,8 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
         // tile t+1 must be complete (it is read from the last k-step of this iteration on); tile t+2 may fly
         if (t + 2 < ntiles) wait_vm<PER_TILE>(); else wait_vm<0>();
         __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 4
+        // (tried: the four DMAs spread over k-steps 1..3, the two waves of a SIMD one step apart -- k-loop 218.9k vs 214.6k
+        // cycles per 43-tile item, tools/wgrad_trace.py: issuing them together right behind the barrier is the better place)
         if (t + 3 < ntiles) issue(t + 3);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -419,6 +430,7 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
     }
   }
 
+  WG_STAMP(2);
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
@@ -441,7 +453,13 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
     const int64_t row = m0 + threadIdx.x;
     if (row < g.M) g.dbias_slab[(int64_t)bz * g.M + row] = colsum;
   }
+  WG_STAMP(3);
 }
+#ifdef CLICA_WGRAD_TRACE
+extern "C" int clica_debug_wgrad_trace(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(clica::gemm::g_wtrace), &buf, sizeof(buf));
+}
+#endif
 
 // ---- weight gradient of a layer with one TINY dimension (the n-wide first / last encoder layer) on the vector ALU ----
 // dW[N,K] = dZ^T X with S = min(N, K) <= 16 and Lg = max(N, K) <= THREADS.  As a 128 x 128 MFMA tile such a layer is
