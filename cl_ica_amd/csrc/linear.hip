@@ -403,6 +403,11 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
     const float* a_n = smem + ((t + 1) % DMA_STAGES) * STAGE;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
+#ifdef CLICA_WGRAD_TRACE
+      if (t == 20 && s == 0) WG_STAMP(4);
+      if (t == 20 && s == 1) WG_STAMP(7);
+      if (t == 21 && s == 0) { if (g_wtrace && (threadIdx.x & 63) == 0) g_wtrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 0] = clock64() - g_wtrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + 4]; }
+#endif
       if (s + 1 < KSTEPS) load_frags((s + 1) & 1, a_s, s + 1);
       else if (t + 1 < ntiles) load_frags(0, a_n, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -415,9 +420,15 @@ __device__ __forceinline__ void wgrad_dma_body(const Args& g, const int bx, cons
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][tt], bf[s & 1][j][tt], acc[i][j], 0, 0, 0);
       if (s == 0) {
         __builtin_amdgcn_sched_barrier(0);
+#ifdef CLICA_WGRAD_TRACE
+        if (t == 20) WG_STAMP(5);
+#endif
         // tile t+1 must be complete (it is read from the last k-step of this iteration on); tile t+2 may fly
         if (t + 2 < ntiles) wait_vm<PER_TILE>(); else wait_vm<0>();
         __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 4
+#ifdef CLICA_WGRAD_TRACE
+        if (t == 20) WG_STAMP(6);
+#endif
         // (tried: the four DMAs spread over k-steps 1..3, the two waves of a SIMD one step apart -- k-loop 218.9k vs 214.6k
         // cycles per 43-tile item, tools/wgrad_trace.py: issuing them together right behind the barrier is the better place)
         if (t + 3 < ntiles) issue(t + 3);
@@ -460,6 +471,144 @@ extern "C" int clica_debug_wgrad_trace(unsigned long long* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(clica::gemm::g_wtrace), &buf, sizeof(buf));
 }
 #endif
+
+// ---- the same direct global -> LDS scheme on a 256 x 128 (A_WIDE) or 128 x 256 output tile ------------------------------------
+// Why a second tile shape: the 128 x 128 item spends ~18 % of its k-loop outside MFMA issue (tools/wgrad_trace.py: 4992 cycles
+// per 32-deep tile vs 4096), and what it pays per tile -- 32 one-KB DMA pieces, 12 LDS fragment dwords per 8 MFMAs, one
+// workgroup barrier -- does not grow with the tile's area.  A 256 x 128 tile does 2x the MFMAs per barrier with 1.5x the DMA
+// pieces and 1.33x the fragment reads (16 dwords per 16 MFMAs), and the n = 10 encoder's 28 such tiles x 9 contraction splits
+// are 252 equal items = ONE round of the 256 CUs (the 128 x 128 plan needs two rounds of 504, i.e. two prologues / epilogues
+// per CU).  Eight waves, wave tile 64 x 64 (2 x 2 accumulator blocks of 32 x 32), three 48 KB LDS stages: the loads of tile
+// t + 2 are issued behind the barrier of iteration t (their stage was read in iteration t - 1) and first waited for in t + 1.
+// DMA piece layout: the wide operand's k-row is 256 floats = one 1 KB piece (lane l -> columns 4 l .. 4 l + 3); the narrow
+// operand's piece is two k-rows of 128 floats (lanes 32..63 = the second row), as in wgrad_dma_body.
+template <bool A_WIDE>
+__device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, const int by, const int bz) {
+  constexpr int BM = A_WIDE ? 256 : 128, BN = A_WIDE ? 128 : 256;
+  constexpr int WN = BN / 64, NBM = 2, NBN = 2, TM = 64, TN = 64;
+  constexpr int STG = 3, STAGE = BK * (BM + BN);        // floats per stage: [A: BK x BM][B: BK x BN]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
+  const int64_t kbeg = (int64_t)bz * g.k_per_split, kend = min(g.Kc, kbeg + g.k_per_split);
+  const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
+  f32x16 acc[NBM][NBN];
+#pragma unroll
+  for (int i = 0; i < NBM; ++i)
+#pragma unroll
+    for (int j = 0; j < NBN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // source pointers of this lane's pieces.  Wide operand: k-rows 4 wave + j (j = 0..3), columns 4 lane ..; narrow operand:
+  // k-rows 4 wave + 2 j + h (j = 0, 1), columns 4 l31 ...  Lanes whose columns are out of range sit on the zero page (stride 0);
+  // the B lane whose first column is exactly N sits on {1, 0, 0, 0}: the matrix cores return db = dZ^T 1 in that padding column.
+  const bool ones_col = g.dbias_slab && (g.N % BN != 0);
+  const float* wide = A_WIDE ? g.A : g.B; const int64_t ldw = A_WIDE ? g.lda : g.ldb;
+  const float* narr = A_WIDE ? g.B : g.A; const int64_t ldn = A_WIDE ? g.ldb : g.lda;
+  const int64_t w0 = (A_WIDE ? m0 : n0) + 4 * lane, wlim = A_WIDE ? g.M : g.N;
+  const int64_t q0 = (A_WIDE ? n0 : m0) + 4 * l31, qlim = A_WIDE ? g.N : g.M;
+  const bool w_ok = w0 < wlim, q_ok = q0 < qlim;
+  const float* w_pad = (!A_WIDE && ones_col && w0 == g.N) ? g_one_page : g_zero_page;     // the wide operand is B when !A_WIDE
+  const float* q_pad = (A_WIDE && ones_col && q0 == g.N) ? g_one_page : g_zero_page;
+  const float* pw[4]; const float* pn[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pw[j] = w_ok ? wide + (kbeg + 4 * wave + j) * ldw + w0 : w_pad;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) pn[j] = q_ok ? narr + (kbeg + 4 * wave + 2 * j + h) * ldn + q0 : q_pad;
+  const int64_t sw = w_ok ? (int64_t)BK * ldw : 0, sn = q_ok ? (int64_t)BK * ldn : 0;
+  constexpr int WOFF = A_WIDE ? 0 : BK * BM;            // float offset of the wide / narrow operand inside a stage
+  constexpr int NOFF = A_WIDE ? BK * BM : 0;
+  constexpr int WLD = A_WIDE ? BM : BN, NLD = A_WIDE ? BN : BM;
+  const int full_tiles = (int)((kend - kbeg) / BK);
+  auto issue = [&](int t) {
+    float* st = smem + (t % STG) * STAGE;
+    const bool full = t < full_tiles;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kr = 4 * wave + j;
+      const bool kin = full || kbeg + (int64_t)t * BK + kr < kend;
+      dma_1k(kin ? pw[j] : g_zero_page, st + WOFF + kr * WLD);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kr = 4 * wave + 2 * j;
+      const bool kin = full || kbeg + (int64_t)t * BK + kr + h < kend;
+      dma_1k(kin ? pn[j] : g_zero_page, st + NOFF + kr * NLD);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pw[j] += sw;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) pn[j] += sn;
+  };
+  constexpr int PER_TILE = 6;     // loads per wave per tile
+  if (ntiles > 0) issue(0);
+  if (ntiles > 1) issue(1);
+  if (ntiles > 1) wait_vm<PER_TILE>(); else wait_vm<0>();
+  __syncthreads();
+
+  constexpr int KSTEPS = BK / 8;
+  float af[2][NBM][4], bf[2][NBN][4];
+  auto load_frags = [&](int buf, const float* st, int s) {
+    const float* a_s = st;                   // [BK][BM]
+    const float* b_s = st + BK * BM;         // [BK][BN]
+#pragma unroll
+    for (int i = 0; i < NBM; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[buf][i][t] = a_s[(8 * s + 4 * h + t) * BM + wm * TM + i * 32 + l31];
+#pragma unroll
+    for (int j = 0; j < NBN; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bf[buf][j][t] = b_s[(8 * s + 4 * h + t) * BN + wn * TN + j * 32 + l31];
+  };
+  if (ntiles > 0) load_frags(0, smem, 0);
+  for (int t = 0; t < ntiles; ++t) {
+    const float* st_c = smem + (t % STG) * STAGE;
+    const float* st_n = smem + ((t + 1) % STG) * STAGE;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+      if (s + 1 < KSTEPS) load_frags((s + 1) & 1, st_c, s + 1);
+      else if (t + 1 < ntiles) load_frags(0, st_n, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int i = 0; i < NBM; ++i)
+#pragma unroll
+          for (int j = 0; j < NBN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][tt], bf[s & 1][j][tt], acc[i][j], 0, 0, 0);
+      if (s == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        // tile t+1 must be complete (read from the last k-step of this iteration on): it is the only one in flight here
+        wait_vm<0>();
+        __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 3
+        if (t + 2 < ntiles) issue(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+#pragma unroll
+  for (int i = 0; i < NBM; ++i) {
+#pragma unroll
+    for (int j = 0; j < NBN; ++j) {
+      const int64_t col = n0 + wn * TN + j * 32 + l31;
+      const bool is_db = ones_col && col == g.N;
+      if (col >= g.N && !is_db) continue;
+      float* dst = is_db ? g.dbias_slab + (int64_t)bz * g.M : Cbase + col;
+      const int64_t ld = is_db ? 1 : g.ldc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        dst[row * ld] = acc[i][j][r];
+      }
+    }
+  }
+}
+constexpr size_t kBody2LdsBytes = (size_t)3 * BK * (256 + 128) * sizeof(float);
 
 // ---- weight gradient of a layer with one TINY dimension (the n-wide first / last encoder layer) on the vector ALU ----
 // dW[N,K] = dZ^T X with S = min(N, K) <= 16 and Lg = max(N, K) <= THREADS.  As a 128 x 128 MFMA tile such a layer is
@@ -672,7 +821,7 @@ struct GroupArgs {
   int n, total;
   int first[MAXG + 1];    // first work item of each problem
   int gx[MAXG], gy[MAXG]; // tiles along N / M
-  int vec[MAXG];          // 1: direct global -> LDS MFMA body; 0: register-staged MFMA body
+  int vec[MAXG];          // 1: direct global -> LDS 128 x 128 body; 3 / 4: its 256 x 128 / 128 x 256 variant; 0: register-staged body
   Args p[MAXG];
 };
 
@@ -687,6 +836,8 @@ __global__ __launch_bounds__(64 * WM * WN) void wgrad_group_k(GroupArgs G) {
   const int bz = local / tiles, t = local - bz * tiles;
   const int by = t / gx, bx = t - by * gx;
   if (G.vec[q] == 1) wgrad_dma_body<WM, WN>(G.p[q], bx, by, bz);
+  else if (G.vec[q] == 3) wgrad_dma_body2<true>(G.p[q], bx, by, bz);
+  else if (G.vec[q] == 4) wgrad_dma_body2<false>(G.p[q], bx, by, bz);
   else gemm_body<BM, BN, WM, WN, STAGES, false, false, EPI_SLAB, false>(G.p[q], bx, by, bz);
 }
 
@@ -931,12 +1082,27 @@ static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, 
 // (tiles x splits) fills whole rounds of the 256 CUs (one 8-wave workgroup per CU) with few, long items.
 struct GroupPlan { int splits; int64_t k_per_split; int tiles; int tiny_splits; int64_t tiny_kps; int n_tiny; };
 constexpr int GBM = 128, GBN = 128;
+// body of a problem from its shape alone (the workspace query and the launch must agree): 2 = tiny-dimension VALU kernel,
+// 3 / 4 = 256 x 128 / 128 x 256 DMA tiles (a dimension beyond 128), 1 = 128 x 128 DMA tiles, 0 = register-staged (odd widths).
+// Every MFMA item of a launch should cover the same work; mixed 128 x 128 and big-tile problems are legal, just not balanced.
+static int group_kind(int32_t N, int32_t K) {
+  static const bool tiny_on = [] { const char* e = getenv("CLICA_WGRAD_TINY"); return !(e && atoi(e) == 0); }();
+  static const bool big_on = [] { const char* e = getenv("CLICA_WGRAD_BIG"); return !(e && atoi(e) == 0); }();
+  if (tiny_on && tiny_eligible(N, K, TINY_THREADS)) return 2;
+  if (N % 4 != 0 || K % 4 != 0) return 0;
+  if (big_on && (N > 128 || K > 128)) return N >= K ? 3 : 4;
+  return 1;
+}
+static void group_tile(int kind, int* bm, int* bn) {
+  *bm = kind == 3 ? 256 : 128; *bn = kind == 4 ? 256 : 128;
+}
 static GroupPlan plan_wgrad_group(int64_t Mrows, int n, const int32_t* N, const int32_t* K) {
   GroupPlan p{};
-  static const bool tiny_on = [] { const char* e = getenv("CLICA_WGRAD_TINY"); return !(e && atoi(e) == 0); }();
   for (int l = 0; l < n; ++l) {
-    if (tiny_on && tiny_eligible(N[l], K[l], TINY_THREADS)) { ++p.n_tiny; continue; }
-    p.tiles += (int)(ceil_div(N[l], GBM) * ceil_div(K[l], GBN));
+    const int kind = group_kind(N[l], K[l]);
+    if (kind == 2) { ++p.n_tiny; continue; }
+    int bm, bn; group_tile(kind, &bm, &bn);
+    p.tiles += (int)(ceil_div(N[l], bm) * ceil_div(K[l], bn));
   }
   const int64_t max_s = std::max<int64_t>(1, std::min<int64_t>(64, ceil_div(Mrows, (int64_t)BK * 4)));
   double best = 1e300;
@@ -965,7 +1131,7 @@ static GroupPlan plan_wgrad_group(int64_t Mrows, int n, const int32_t* N, const 
   }
   return p;
 }
-static bool group_is_tiny(const GroupPlan& p, int32_t N, int32_t K) { return p.n_tiny > 0 && tiny_eligible(N, K, TINY_THREADS); }
+static bool group_is_tiny(const GroupPlan& p, int32_t N, int32_t K) { return p.n_tiny > 0 && group_kind(N, K) == 2; }
 static size_t group_ws_layout(const GroupPlan& p, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
   size_t off = 0;
   for (int l = 0; l < n; ++l) {
@@ -1024,8 +1190,13 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
       T.p[T.n++] = g;
     } else {
       G.p[ng] = g;
-      G.gx[ng] = (int)ceil_div(K[l], GBN); G.gy[ng] = (int)ceil_div(N[l], GBM);
-      G.vec[ng] = (aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N[l] % 4 == 0 && K[l] % 4 == 0) ? 1 : 0;
+      int kind = group_kind(N[l], K[l]);
+      int bm, bn; group_tile(kind, &bm, &bn);              // the tile shape follows the SHAPE (it fixed the plan); a problem whose
+      if (!(aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0)) kind = (bm == 128 && bn == 128) ? 0 : -1;
+      CLICA_CHECK_ARG(kind >= 0, "clica_mlp_wgrad: layer %d: operands of a %d x %d layer must be 16-byte aligned with leading "
+                      "dimensions that are multiples of 4", l, N[l], K[l]);   // pointers are unaligned can only take the 128 x 128 register-staged body
+      G.gx[ng] = (int)ceil_div(K[l], bn); G.gy[ng] = (int)ceil_div(N[l], bm);
+      G.vec[ng] = kind;
       G.first[ng] = item; item += G.gx[ng] * G.gy[ng] * sp;
       ++ng;
     }
@@ -1047,7 +1218,8 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
   }
   if (ng > 0) {
     constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
-    constexpr size_t lds = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
+    constexpr size_t lds1 = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
+    constexpr size_t lds = lds1 > kBody2LdsBytes ? lds1 : kBody2LdsBytes;
     auto k = wgrad_group_k<GBM, GBN, WM, WN, STAGES>;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
     (void)once;
@@ -1143,8 +1315,9 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
     G.first[0] = 0; G.first[1] = G.total = G.gx[0] * G.gy[0] * p.splits;
     constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
     constexpr size_t lds = DMA_STAGES * (Tile<GBM, false, THREADS>::LDS_FLOATS + Tile<GBN, false, THREADS>::LDS_FLOATS) * sizeof(float);
+    constexpr size_t lds_max = lds > kBody2LdsBytes ? lds : kBody2LdsBytes;      // one attribute value for every call site of this kernel
     auto k = wgrad_group_k<GBM, GBN, WM, WN, STAGES>;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
     (void)once;
     hipLaunchKernelGGL(k, dim3((unsigned)G.total), dim3(THREADS), lds, st, G);
     rc = launch_status("clica_linear_wgrad");

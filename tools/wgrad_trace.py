@@ -39,3 +39,9 @@ print(f"k-loop by wave id (median): {np.round(np.median(loop, 0)).astype(int).to
 order = np.argsort(start)
 print("item start times (cycles, sorted): first round", np.round(np.percentile(start, [0, 25, 49]), 0).tolist(), " second round", np.round(np.percentile(start, [51, 75, 100]), 0).tolist())
 print(f"kernel span: {end.max():.0f} cycles; last first-round end {np.sort(end)[255]:.0f}")
+# one tile in detail (t = 20): stamp4 = tile start, 5 = k-step 0's MFMAs issued, 6 = past wait + barrier, 7 = k-step 1 start (DMA issued)
+fine = t[:, :, 5:8] - t[:, :, 4:5]
+print("tile 20, cycles since its start (median by wave id):")
+for nm, k in (("k-step 0 MFMAs issued", 0), ("past vmcnt wait + barrier", 1), ("k-step 1 starts (4 DMAs issued)", 2)):
+    print(f"  {nm:34s}", np.round(np.median(fine[:, :, k], 0)).astype(int).tolist())
+print("  whole tile 20 (start of 21 - start of 20):", np.round(np.median(t[:, :, 0], 0)).astype(int).tolist(), " [slot 0 overwritten: item start unavailable in this build]")
