@@ -22,7 +22,7 @@ c_size = C.c_size_t
 
 class LpLossDesc(C.Structure):
     _fields_ = [("B", c_i64), ("B3", c_i64), ("n", c_i32), ("p", C.c_float), ("tau", C.c_float),
-                ("alpha", C.c_float), ("compat", c_i32), ("pow", c_i32)]
+                ("alpha", C.c_float), ("compat", c_i32), ("pow", c_i32), ("no_eps", c_i32)]
 
 
 class DotLossDesc(C.Structure):

@@ -389,7 +389,7 @@ static int validate(const clica_lp_loss_desc* d, const char* who) {
   CLICA_CHECK_ARG(pad_dim(d->n) > 0, "%s: n=%d > 64 is not supported by the register-resident kernels", who, d->n);
   CLICA_CHECK_ARG(d->p > 0.f, "%s: p=%g must be > 0", who, d->p);
   CLICA_CHECK_ARG(d->tau > 0.f, "%s: tau=%g must be > 0", who, d->tau);
-  if (d->p < 1.f)
+  if (d->p < 1.f && !d->no_eps)
     CLICA_CHECK_ARG(d->B == d->B3, "%s: p<1 uses the transposed branch (losses.py:433-442) and needs B3 == B", who);
   return CLICA_OK;
 }
@@ -404,7 +404,7 @@ using namespace clica::lp;
 extern "C" int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t* fwd_bytes, size_t* bwd_bytes) {
   int rc = validate(d, "clica_lp_loss_workspace_bytes");
   if (rc) return rc;
-  const bool frac = d->p < 1.f;
+  const bool frac = d->p < 1.f && !d->no_eps;
   const int64_t rows = frac ? d->B3 : d->B, cols = frac ? d->B : d->B3;
   Plan PF = make_plan(rows, cols, d->n, false);
   Plan PR = make_plan(rows, cols, d->n, true);
@@ -425,7 +425,7 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   if (rc) return rc;
   CLICA_CHECK_ARG(z1 && z2 && z3 && loss_i && pos_i && lse_i && means && workspace, "clica_lp_loss_fwd: NULL pointer");
   CLICA_CHECK_ARG(ld1 >= d->n && ld2 >= d->n && ld3 >= d->n, "clica_lp_loss_fwd: leading dimension < n");
-  const bool frac = d->p < 1.f;
+  const bool frac = d->p < 1.f && !d->no_eps;
   const float* rows_p = frac ? z3 : z1; const int64_t ldr = frac ? ld3 : ld1; const int64_t rows = frac ? d->B3 : d->B;
   const float* cols_p = frac ? z1 : z3; const int64_t ldc = frac ? ld1 : ld3; const int64_t cols = frac ? d->B : d->B3;
   CLICA_CHECK_ARG(!rowgrad || ldrg >= d->n, "clica_lp_loss_fwd: rowgrad leading dimension < n");
@@ -458,7 +458,7 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
   int rc = validate(d, "clica_lp_loss_bwd");
   if (rc) return rc;
   CLICA_CHECK_ARG(z1 && z2 && z3 && lse_i && workspace, "clica_lp_loss_bwd: NULL pointer");
-  const bool frac = d->p < 1.f;
+  const bool frac = d->p < 1.f && !d->no_eps;
   const int64_t rows = frac ? d->B3 : d->B, cols = frac ? d->B : d->B3;
   const float* rows_p = frac ? z3 : z1; const int64_t ldr = frac ? ld3 : ld1;
   const float* cols_p = frac ? z1 : z3; const int64_t ldc = frac ? ld1 : ld3;
@@ -507,7 +507,7 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
   int rc = validate(d, "clica_lp_loss_bwd_sym");
   if (rc) return rc;
   CLICA_CHECK_ARG(z1 && z2 && pool && lse_i && pool_lse && dz1 && workspace, "clica_lp_loss_bwd_sym: NULL pointer");
-  CLICA_CHECK_ARG(d->p >= 1.f, "clica_lp_loss_bwd_sym: the p<1 branch is not symmetric (eps inside the abs, losses.py:436)");
+  CLICA_CHECK_ARG(d->p >= 1.f || d->no_eps, "clica_lp_loss_bwd_sym: the p<1 branch is not symmetric (eps inside the abs, losses.py:436)");
   CLICA_CHECK_ARG(d->B3 >= d->B, "clica_lp_loss_bwd_sym: the pool (B3=%lld rows) must contain the %lld local rows", (long long)d->B3, (long long)d->B);
   const int64_t rows = d->B, cols = d->B3;
   Plan PR = make_plan(rows, cols, d->n, true);

@@ -58,7 +58,7 @@ class _PairLossFn(torch.autograd.Function):
         # gradient: the backward then needs only the column sweep
         n = a.shape[1]
         # (autograd.Function.forward runs with grad mode off: ask the node, not torch.is_grad_enabled())
-        want_rg = ctx.needs_input_grad[0] and not (kind == "lp" and desc.p < 1.0)
+        want_rg = ctx.needs_input_grad[0] and not (kind == "lp" and desc.p < 1.0 and not desc.no_eps)
         rowgrad = torch.empty((B, n), dtype=torch.float32, device=a.device) if want_rg else None
         _lib.check(fwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc,
                        loss_i.data_ptr(), pos_i.data_ptr(), lse_i.data_ptr(), means.data_ptr(),
@@ -185,13 +185,10 @@ class UniformityLoss(MarginalPairCLLoss):
         self.p = p
 
     def loss(self, z1_rec, z3_rec):
-        if float(self.p) < 1.0:
-            raise NotImplementedError("UniformityLoss: p < 1 is not supported by the HIP kernel (its p < 1 branch follows "
-                                      "LpSimCLRLoss' eps placement, losses.py:433-442, which this loss does not have)")
         if z1_rec.dim() != 2 or z3_rec.dim() != 2 or z1_rec.shape[1] != z3_rec.shape[1]:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z3_rec.shape)}")
         desc = _lib.LpLossDesc(B=z3_rec.shape[0], B3=z1_rec.shape[0], n=z1_rec.shape[1], p=float(self.p), tau=1.0,
-                               alpha=0.0, compat=0, pow=1)
+                               alpha=0.0, compat=0, pow=1, no_eps=1)        # plain sum |d|^p for every p (no eps branch here)
         mean2, item2, _, _ = _PairLossFn.apply(z3_rec, z3_rec, z1_rec, "lp", desc)
         loss = 0.5 * mean2
         return loss, 0.5 * item2, [loss]
@@ -206,11 +203,10 @@ class AlignmentLoss(ConditionalPairCLLoss):
         self.p = p
 
     def loss(self, z1_rec, z2_rec):
-        if float(self.p) < 1.0:
-            raise NotImplementedError("AlignmentLoss: p < 1 is not supported by the HIP kernel")
         if z1_rec.dim() != 2 or z1_rec.shape != z2_rec.shape:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_rec.shape)}")
-        desc = _lib.LpLossDesc(B=z1_rec.shape[0], B3=1, n=z1_rec.shape[1], p=float(self.p), tau=1.0, alpha=1.0, compat=0, pow=1)
+        desc = _lib.LpLossDesc(B=z1_rec.shape[0], B3=1, n=z1_rec.shape[1], p=float(self.p), tau=1.0, alpha=1.0, compat=0, pow=1,
+                               no_eps=1)
         mean2, item2, _, _ = _PairLossFn.apply(z1_rec, z2_rec, z1_rec[:1].detach(), "lp", desc)
         loss = 0.5 * mean2
         return loss, 0.5 * item2, [loss]

@@ -58,6 +58,9 @@ typedef struct clica_lp_loss_desc {
   float alpha;
   int32_t compat;  /* simclr_compatibility_mode                          */
   int32_t pow;     /* use p-th power of the norm                         */
+  int32_t no_eps;  /* 0: LpSimCLRLoss semantics -- p < 1 takes the reference's eps branch (|z1 - z3 + 1e-12|, transposed pair
+                      orientation, losses.py:433-442).  1: plain sum_k |d_k|^p for every p > 0, no eps, no transposition: the
+                      pair term of UniformityLoss / AlignmentLoss (losses.py:211-221, 231-237)                              */
 } clica_lp_loss_desc;
 
 /* scratch needed by clica_lp_loss_fwd / _bwd for this problem size */

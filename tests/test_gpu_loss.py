@@ -257,10 +257,12 @@ def test_rowgrad_forward_equals_row_pass():
             assert (a - b).abs().max().item() < 2e-6 * max(a.abs().max().item(), 1e-6) + 1e-9, p
 
 
-def test_uniformity_alignment_vs_golden(golden):
-    """UniformityLoss / AlignmentLoss (reference losses.py:205-241) on the all-pairs kernel, against G12."""
+@pytest.mark.parametrize("gname", ["g12_align_uniform.npz", "g18_align_uniform_frac.npz"])
+def test_uniformity_alignment_vs_golden(golden, gname):
+    """UniformityLoss / AlignmentLoss (reference losses.py:205-241) on the all-pairs kernel, against G12 (p = 1, 2, 3) and
+    G18 (fractional exponents 0.5, 0.75, 1.5: plain sum |d|^p, no eps branch)."""
     from cl_ica_amd.losses import AlignmentLoss, UniformityLoss
-    G = golden("g12_align_uniform.npz")
+    G = golden(gname)
     for i in range(G.n_cases):
         u = G.case(f"u{i:03d}"); p = float(u["meta"]["p"])
         z1 = dev(u["in"]["z1"]).requires_grad_(True); z3 = dev(u["in"]["z3"]).requires_grad_(True)
@@ -279,5 +281,3 @@ def test_uniformity_alignment_vs_golden(golden):
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "loss_i", per.detach().cpu().numpy(), a["out"]["loss_i"])
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz1", z1.grad.cpu().numpy(), a["out"]["dz1"])
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz2", z2.grad.cpu().numpy(), a["out"]["dz2"])
-    with pytest.raises(NotImplementedError):
-        UniformityLoss(0.5)(z1, z2)
