@@ -100,7 +100,9 @@ SIGNATURES: Dict[str, list] = {
     "clica_adam_step_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                              C.c_void_p, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],
+    "clica_reload_env": [],
     "clica_sample": [C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p],
+    "clica_sample_scaled": [C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p],
     "clica_sample_pair": [C.POINTER(SamplerDesc), C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64,
                           C.c_void_p, C.c_void_p],
 }

@@ -1038,25 +1038,27 @@ static int launch(int cfg, const Args& g, int splits, hipStream_t st, const char
   }
 }
 
-static int env_cfg(const char* name) {   // tuning hook: CLICA_GEMM_CFG_{FWD,DGRAD,WGRAD}=id
-  const char* v = getenv(name);
-  return v ? atoi(v) : -1;
+// Tuning switches from the environment, read ONCE (first launch) and again only on clica_reload_env(): the launch path
+// of the per-layer entry points is called from autograd nodes in eager mode, where a getenv per call is measurable.
+//   CLICA_GEMM_CFG_{FWD,DGRAD,WGRAD}=id  tile configuration override;  CLICA_SKINNY=0 forces every shape through the MFMA template
+struct Tuning { int cfg_fwd, cfg_dgrad, cfg_wgrad; bool skinny; };
+static Tuning read_tuning() {
+  auto num = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; };
+  const char* sk = getenv("CLICA_SKINNY");
+  return Tuning{num("CLICA_GEMM_CFG_FWD"), num("CLICA_GEMM_CFG_DGRAD"), num("CLICA_GEMM_CFG_WGRAD"), !(sk && atoi(sk) == 0)};
 }
-
-static bool use_skinny() {   // CLICA_SKINNY=0 forces every shape through the MFMA template (A/B, tests)
-  const char* v = getenv("CLICA_SKINNY");
-  return !(v && atoi(v) == 0);
-}
+static Tuning& tuning() { static Tuning t = read_tuning(); return t; }
+static bool use_skinny() { return tuning().skinny; }
 
 // measured on MI355X (tools/gemm_bench.py): wide outputs -> 96x128 tiles, two 4-wave workgroups per
 // CU; narrow outputs (N <= 128, one tile column) -> 64x128 for more workgroups along M
 static int cfg_fwd(int64_t N) {
-  const int e = env_cfg("CLICA_GEMM_CFG_FWD");
+  const int e = tuning().cfg_fwd;
   return (e >= 0 && e < kNumCfgs) ? e : ((N > 128) ? 5 : 2);
 }
 // 64x128 measured best for every encoder layer shape (B operand is read with ds_read_b32)
 static int cfg_dgrad() {
-  const int e = env_cfg("CLICA_GEMM_CFG_DGRAD");
+  const int e = tuning().cfg_dgrad;
   return (e >= 0 && e < kNumCfgs) ? e : 2;
 }
 
@@ -1065,7 +1067,7 @@ struct WgradPlan { int cfg, splits; int64_t k_per_split; };
 static WgradPlan plan_wgrad(int64_t M /*rows of dW*/, int64_t N /*cols of dW*/, int64_t Kc) {
   WgradPlan p;
   p.cfg = (M > 128 && N > 128) ? 1 : 2;   // measured: 8-wave 128x128 wins on the square layers
-  const int e = env_cfg("CLICA_GEMM_CFG_WGRAD");
+  const int e = tuning().cfg_wgrad;
   if (e >= 0 && e < kNumCfgs) p.cfg = e;
   const Cfg c = kCfgs[p.cfg];
   const int64_t tiles = ceil_div(M, c.bm) * ceil_div(N, c.bn);
@@ -1275,6 +1277,11 @@ extern "C" int clica_linear_plan(int32_t op, int64_t M, int64_t N, int64_t K, in
   return CLICA_OK;
 }
 
+extern "C" int clica_reload_env(void) {
+  gemm::tuning() = gemm::read_tuning();
+  return CLICA_OK;
+}
+
 extern "C" int clica_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t K, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && M > 0 && N > 0 && K > 0, "clica_linear_wgrad_workspace_bytes: bad argument");
   // worst case over the configurations the planner (or the tuning hook) may pick
@@ -1282,7 +1289,7 @@ extern "C" int clica_linear_wgrad_workspace_bytes(int64_t M, int64_t N, int64_t 
   *bytes = align_up((size_t)max_s * N * K * sizeof(float), 256) + align_up((size_t)max_s * N * sizeof(float), 256);
   const WgradPlan p = plan_wgrad(N, K, M);
   const size_t exact = align_up((size_t)p.splits * N * K * sizeof(float), 256) + align_up((size_t)p.splits * N * sizeof(float), 256);
-  if (!getenv("CLICA_GEMM_CFG_WGRAD")) *bytes = exact;
+  if (tuning().cfg_wgrad < 0) *bytes = exact;
   return CLICA_OK;
 }
 

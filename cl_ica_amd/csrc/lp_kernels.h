@@ -484,10 +484,144 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
   }
 }
 
+// ---- wide rows: 64 < n <= 512 ------------------------------------------------------------------
+// The kernels above keep an owner's n coordinates (and its n gradient accumulators) in one lane's registers, which stops
+// paying at n = 64.  Wider rows use a different cut of the same sweep: a workgroup owns W_OWN = 16 rows, SIXTEEN lanes
+// share an owner and each holds every sixteenth coordinate (KC = 8 / 16 / 32 registers for n <= 128 / 256 / 512), the
+// per-pair sum is closed with a four-step xor butterfly inside the 16-lane group (fixed order: deterministic), and every
+// lane then updates its own slice of the gradient.  Stream rows are staged through LDS a tile at a time and read
+// conflict-free (the 16 coordinate lanes hit 16 consecutive banks, the four owner groups of a wave broadcast).  One
+// kernel template covers the five sweeps; the partial formats are those of fwd_partial_k / bwd_pairs_k, so finalize,
+// rowgrad_combine_k and bwd_reduce_k are shared.  None of the reference's configurations is this wide (n <= 40 there);
+// the path exists so that the loss has no dimension cliff, and is sized for correctness first.
+constexpr int W_OWN = 16, W_KL = 16;
+constexpr int kMaxWideN = 512;
+constexpr int wide_kc(int n) { return n <= 128 ? 8 : (n <= 256 ? 16 : 32); }
+constexpr int wide_ts(int kc) { return kc == 32 ? 16 : 32; }            // 32 KB tile at KC >= 16
+enum WideMode { W_FWD = 0, W_FWD_ROWGRAD = 1, W_BWD_OWNER = 2, W_BWD_STREAM = 3, W_BWD_SYM = 4 };
+
+template <int PK>
+__device__ __forceinline__ float term1(float o, float s, const Params& q) {
+  if constexpr (PK == PK_DOT) return o * s;
+  else if constexpr (PK == 2) { const float d = o - s; return d * d; }
+  else if constexpr (PK == 1) return fabsf(o - s);
+  else if constexpr (PK == 3) { const float d = o - s; return fabsf(d) * d * d; }
+  else { const float a = fabsf(q.sgn * (o - s) + q.eps); return a > 0.f ? fexp2(q.p * flog2(a)) : 0.f; }
+}
+// (1/p) d term / d owner, sign of the generic branch's `sgn` left to the pair coefficient (as in gaccum2)
+template <int PK>
+__device__ __forceinline__ float dterm1(float o, float s, const Params& q) {
+  if constexpr (PK == PK_DOT) return s;
+  else if constexpr (PK == 2) return o - s;
+  else if constexpr (PK == 1) { const float d = o - s; return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+  else if constexpr (PK == 3) { const float d = o - s; return d * fabsf(d); }
+  else {
+    const float e = q.sgn * (o - s) + q.eps, a = fabsf(e);
+    const float v = a > 0.f ? fexp2((q.p - 1.f) * flog2(a)) : 0.f;
+    return e < 0.f ? -v : v;
+  }
+}
+
+template <int KC, int PK, int MODE>
+__global__ __launch_bounds__(THREADS) void wide_k(
+    const float* __restrict__ own, int64_t ldo, int64_t n_own,
+    const float* __restrict__ str, int64_t lds, int64_t n_str, Params q,
+    const float* __restrict__ ownL, const float* __restrict__ ownC,
+    const float* __restrict__ strL, const float* __restrict__ strC,
+    float2* __restrict__ part, float* __restrict__ part_g, int np, int chunk) {
+  constexpr bool FWD = MODE == W_FWD || MODE == W_FWD_ROWGRAD, ROWGRAD = MODE == W_FWD_ROWGRAD;
+  constexpr bool OWNER_STATS = MODE == W_BWD_OWNER || MODE == W_BWD_SYM, STREAM_STATS = MODE == W_BWD_STREAM || MODE == W_BWD_SYM;
+  constexpr bool GRAD = MODE != W_FWD;
+  constexpr int TS = wide_ts(KC), LDT = KC * W_KL;
+  __shared__ __attribute__((aligned(16))) float tile[TS * LDT];
+  __shared__ float tL[TS], tC[TS];
+  const int oi = threadIdx.x >> 4, kl = threadIdx.x & (W_KL - 1);
+  const int64_t i = (int64_t)blockIdx.x * W_OWN + oi;
+  const bool own_ok = i < n_own;
+  float o[KC], g[GRAD ? KC : 1];
+#pragma unroll
+  for (int c = 0; c < KC; ++c) {
+    const int k = kl + W_KL * c;
+    const bool ok = own_ok && k < q.n;
+    const float x = own[ok ? i * ldo + k : 0];
+    o[c] = ok ? x : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < (GRAD ? KC : 1); ++c) g[c] = 0.f;
+  float oL = 0.f, oC = 0.f;
+  if (OWNER_STATS && own_ok) { oL = ownL[i]; oC = ownC[i]; }
+  float m = -INFINITY, s = 0.f;
+  const float xk = q.xs * q.kscale;
+  const float csgn = (PK == 0) ? q.sgn : 1.f;
+  const bool root = !q.pow;
+  const int64_t jb = (int64_t)blockIdx.y * chunk;
+  const int64_t je = min(n_str, jb + (int64_t)chunk);
+  for (int64_t j0 = jb; j0 < je; j0 += TS) {
+    const int cnt = (int)min((int64_t)TS, je - j0);
+    __syncthreads();                                  // the previous tile has been consumed
+    for (int idx = threadIdx.x; idx < TS * LDT; idx += THREADS) {
+      const int row = idx / LDT, k = idx - row * LDT;
+      const bool ok = row < cnt && k < q.n;
+      const float x = str[ok ? (j0 + row) * lds + k : 0];
+      tile[idx] = ok ? x : 0.f;
+    }
+    if (STREAM_STATS && (int)threadIdx.x < TS) {
+      const bool ok = (int)threadIdx.x < cnt;
+      const float l = strL[ok ? j0 + threadIdx.x : 0], c = strC[ok ? j0 + threadIdx.x : 0];
+      tL[threadIdx.x] = ok ? l : 0.f; tC[threadIdx.x] = ok ? c : 0.f;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < cnt; ++jj) {
+      const float* row = tile + jj * LDT + kl;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c)
+        if (PK != 0 || kl + W_KL * c < q.n) acc += term1<PK>(o[c], row[W_KL * c], q);   // zero padding is neutral except with eps
+#pragma unroll
+      for (int off = W_KL / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      const float x = (root ? root_of<true>(acc, q) : acc) * xk;
+      const float dr = (root ? droot_of<true>(acc, q) : q.p) * csgn;
+      float cf;
+      if (FWD) {
+        const float mn = fmaxf(x, fmaxf(m, -1e30f));
+        const float e = fexp2(x - mn), resc = fexp2(m - mn);
+        s = fmaf(s, resc, e);
+        m = mn;
+        cf = e * dr;
+        if (ROWGRAD) {
+#pragma unroll
+          for (int c = 0; c < KC; ++c) g[c] *= resc;
+        }
+      } else {
+        float w = 0.f;
+        if (OWNER_STATS) w = oC * fexp2(x - oL);
+        if (STREAM_STATS) w = fmaf(tC[jj], fexp2(x - tL[jj]), w);
+        cf = w * dr;
+      }
+      if (GRAD) {
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+          if (PK != 0 || kl + W_KL * c < q.n) g[c] = fmaf(cf, dterm1<PK>(o[c], row[W_KL * c], q), g[c]);
+      }
+    }
+  }
+  if (!own_ok) return;
+  const int64_t slot = (int64_t)blockIdx.y * n_own + i;
+  if (FWD && kl == 0) part[slot] = make_float2(fmaxf(m, -1e30f), s);
+  if (GRAD) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const int k = kl + W_KL * c;
+      if (k < np) part_g[slot * np + k] = k < q.n ? g[c] : 0.f;
+    }
+  }
+}
+
 // ---- host-side planning -----------------------------------------------------------------------
 inline int pad_dim(int n) {
   static const int dims[] = {4, 8, 12, 16, 24, 32, 40, 64};
   for (int d : dims) if (n <= d) return d;
+  if (n <= kMaxWideN) return (n + 3) / 4 * 4;      // wide rows (wide_k): partial rows padded to whole float4s
   return -1;
 }
 constexpr int owners_fwd(int np) { return np <= 24 ? 2 : 1; }
@@ -501,6 +635,19 @@ struct Plan {
 inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
   Plan P;
   P.np = pad_dim(n);
+  if (P.np > 64) {          // wide rows: 16 owners per workgroup, about four workgroups per CU, splits in whole LDS tiles
+    const int64_t TSW = wide_ts(wide_kc(n));
+    P.R = 0;
+    P.tiles = ceil_div(n_own, (int64_t)W_OWN);
+    int64_t ns = ceil_div((int64_t)kNumCU * 4, P.tiles);
+    const int64_t cap = ceil_div(n_str, TSW);
+    if (ns > cap) ns = cap;
+    if (ns < 1) ns = 1;
+    const int64_t chunk = ceil_div(ceil_div(n_str, ns), TSW) * TSW;
+    P.chunk = (int)chunk;
+    P.nsplit = (int)ceil_div(n_str, chunk);
+    return P;
+  }
   P.R = bwd ? owners_bwd(P.np) : owners_fwd(P.np);
   P.tiles = ceil_div(n_own, (int64_t)HALF * P.R);
   const int64_t TS = tile_rows(P.np);

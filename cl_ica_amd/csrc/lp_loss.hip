@@ -386,7 +386,7 @@ static int validate(const clica_lp_loss_desc* d, const char* who) {
   CLICA_CHECK_ARG(d != nullptr, "%s: desc is NULL", who);
   CLICA_CHECK_ARG(d->B > 0 && d->B3 > 0, "%s: B=%lld B3=%lld must be positive", who, (long long)d->B, (long long)d->B3);
   CLICA_CHECK_ARG(d->n >= 1, "%s: n=%d must be >= 1", who, d->n);
-  CLICA_CHECK_ARG(pad_dim(d->n) > 0, "%s: n=%d > 64 is not supported by the register-resident kernels", who, d->n);
+  CLICA_CHECK_ARG(pad_dim(d->n) > 0, "%s: n=%d > %d (register-resident kernels to 64, wide-row kernels beyond)", who, d->n, kMaxWideN);
   CLICA_CHECK_ARG(d->p > 0.f, "%s: p=%g must be > 0", who, d->p);
   CLICA_CHECK_ARG(d->tau > 0.f, "%s: tau=%g must be > 0", who, d->tau);
   if (d->p < 1.f && !d->no_eps)
@@ -666,7 +666,7 @@ static DotWs carve_dot(void* ws, size_t off, int64_t B, int64_t B3, int n, bool 
 static int validate_dot(const clica_dot_loss_desc* d, const char* who) {
   CLICA_CHECK_ARG(d != nullptr, "%s: desc is NULL", who);
   CLICA_CHECK_ARG(d->B > 0 && d->B3 > 0, "%s: B=%lld B3=%lld must be positive", who, (long long)d->B, (long long)d->B3);
-  CLICA_CHECK_ARG(d->n >= 1 && pad_dim(d->n) > 0, "%s: n=%d must be in 1..64", who, d->n);
+  CLICA_CHECK_ARG(d->n >= 1 && pad_dim(d->n) > 0, "%s: n=%d must be in 1..%d", who, d->n, kMaxWideN);
   CLICA_CHECK_ARG(d->tau > 0.f, "%s: tau=%g must be > 0", who, d->tau);
   return CLICA_OK;
 }

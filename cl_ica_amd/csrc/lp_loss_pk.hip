@@ -25,12 +25,30 @@ namespace lp {
     default: break;                                 \
   }
 
+// wide rows (n > 64): one kernel template, instantiated per coordinate-register count
+template <int PK, int MODE>
+static void launch_wide(const Plan& P, const float* own, int64_t ldo, int64_t n_own, const float* str, int64_t lds, int64_t n_str,
+                        const Params& q, const float* ownL, const float* ownC, const float* strL, const float* strC,
+                        float2* part, float* part_g, hipStream_t st) {
+  dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
+  switch (wide_kc(q.n)) {
+    case 8: hipLaunchKernelGGL((wide_k<8, PK, MODE>), grid, block, 0, st, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, part_g, P.np, P.chunk); break;
+    case 16: hipLaunchKernelGGL((wide_k<16, PK, MODE>), grid, block, 0, st, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, part_g, P.np, P.chunk); break;
+    default: hipLaunchKernelGGL((wide_k<32, PK, MODE>), grid, block, 0, st, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, part, part_g, P.np, P.chunk); break;
+  }
+}
+
 // part_g != nullptr selects the ROWGRAD variant; its plan must have been made with the backward's
 // owners-per-thread (make_plan(..., bwd = true)): it carries the same register load as bwd_pairs_k.
 void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64_t ldo, int64_t n_own,
                                           const float* str, int64_t lds, int64_t n_str, const Params& q,
                                           float2* part, float* part_g, hipStream_t st) {
   constexpr int PK = CLICA_PK;
+  if (P.np > 64) {
+    if (part_g) launch_wide<PK, W_FWD_ROWGRAD>(P, own, ldo, n_own, str, lds, n_str, q, nullptr, nullptr, nullptr, nullptr, part, part_g, st);
+    else launch_wide<PK, W_FWD>(P, own, ldo, n_own, str, lds, n_str, q, nullptr, nullptr, nullptr, nullptr, part, part_g, st);
+    return;
+  }
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (part_g && q.pow)
@@ -53,6 +71,11 @@ void CAT(launch_bwd_pairs_pk, CLICA_PK)(const Plan& P, bool owner_stats, const f
                                         const Params& q, const float* statL, const float* statC, float* part,
                                         hipStream_t st) {
   constexpr int PK = CLICA_PK;
+  if (P.np > 64) {
+    if (owner_stats) launch_wide<PK, W_BWD_OWNER>(P, own, ldo, n_own, str, lds, n_str, q, statL, statC, nullptr, nullptr, nullptr, part, st);
+    else launch_wide<PK, W_BWD_STREAM>(P, own, ldo, n_own, str, lds, n_str, q, nullptr, nullptr, statL, statC, nullptr, part, st);
+    return;
+  }
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (owner_stats && q.pow)
@@ -76,6 +99,10 @@ void CAT(launch_bwd_sym_pk, CLICA_PK)(const Plan& P, const float* own, int64_t l
                                       const float* ownL, const float* ownC, const float* strL, const float* strC,
                                       float* part, hipStream_t st) {
   constexpr int PK = CLICA_PK;
+  if (P.np > 64) {
+    launch_wide<PK, W_BWD_SYM>(P, own, ldo, n_own, str, lds, n_str, q, ownL, ownC, strL, strC, nullptr, part, st);
+    return;
+  }
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
     if (q.pow)

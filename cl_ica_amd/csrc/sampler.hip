@@ -79,13 +79,18 @@ struct Desc {
   int space, dist, n;
   float box_min, box_max, scale, shape_p;
   uint64_t seed; uint32_t stream_id;
+  const float* svec; int64_t lds;     // optional per-coordinate scale (spaces.py:60-72: `std` may be a tensor), row stride 0 = one row
 };
 
-__device__ __forceinline__ float noise(Philox& g, const Desc& d) {
+// scale of coordinate k of row i: the descriptor's scalar, times the per-coordinate tensor when there is one
+__device__ __forceinline__ float scale_of(const Desc& d, int64_t i, int k) {
+  return d.svec ? d.scale * d.svec[i * d.lds + k] : d.scale;
+}
+__device__ __forceinline__ float noise(Philox& g, const Desc& d, float sc) {
   switch (d.dist) {
-    case CLICA_DIST_NORMAL: return d.scale * g.normal();
-    case CLICA_DIST_LAPLACE: return d.scale * g.laplace();
-    case CLICA_DIST_GENNORM: return d.scale * g.gennorm(d.shape_p);
+    case CLICA_DIST_NORMAL: return sc * g.normal();
+    case CLICA_DIST_LAPLACE: return sc * g.laplace();
+    case CLICA_DIST_GENNORM: return sc * g.gennorm(d.shape_p);
     default: return 0.f;
   }
 }
@@ -104,10 +109,10 @@ __global__ __launch_bounds__(THREADS) void sample_elem_k(Desc d, const float* __
   if (d.dist == CLICA_DIST_UNIFORM) {                        // spaces.py:273-277
     v = g.uniform() * (d.box_max - d.box_min) + d.box_min;
   } else {
-    const float m = mean[i * ldm + k];
-    v = m + noise(g, d);
+    const float m = mean[i * ldm + k], sc = scale_of(d, i, k);
+    v = m + noise(g, d, sc);
     if (d.space == CLICA_SPACE_BOX)                          // spaces.py:279-351: truncate per element
-      for (int it = 0; it < 4096 && !(v >= d.box_min && v <= d.box_max); ++it) v = m + noise(g, d);
+      for (int it = 0; it < 4096 && !(v >= d.box_min && v <= d.box_max); ++it) v = m + noise(g, d, sc);
   }
   out[i * ldo + k] = v;
 }
@@ -129,18 +134,18 @@ __global__ __launch_bounds__(THREADS) void sample_pair_elem_k(Desc dm, Desc dc, 
       v = g.uniform() * (dm.box_max - dm.box_min) + dm.box_min;
     } else {
       const float m = mmean[i * ldmm + k];
-      v = m + noise(g, dm);
+      v = m + noise(g, dm, dm.scale);
       if (dm.space == CLICA_SPACE_BOX)
-        for (int it = 0; it < 4096 && !(v >= dm.box_min && v <= dm.box_max); ++it) v = m + noise(g, dm);
+        for (int it = 0; it < 4096 && !(v >= dm.box_min && v <= dm.box_max); ++it) v = m + noise(g, dm, dm.scale);
     }
     z[i * ldz + k] = v;
   }
   {
     Philox g(dc.seed, (uint32_t)idx, step, dc.stream_id);
     const float m = v;
-    float w = m + noise(g, dc);
+    float w = m + noise(g, dc, dc.scale);
     if (dc.space == CLICA_SPACE_BOX)
-      for (int it = 0; it < 4096 && !(w >= dc.box_min && w <= dc.box_max); ++it) w = m + noise(g, dc);
+      for (int it = 0; it < 4096 && !(w >= dc.box_min && w <= dc.box_max); ++it) w = m + noise(g, dc, dc.scale);
     zt[i * ldzt + k] = w;
   }
 }
@@ -187,9 +192,9 @@ __global__ __launch_bounds__(THREADS) void sample_k(Desc d, const float* __restr
       for (int k = 0; k < n; ++k) o[k] = g.uniform() * span + d.box_min;
     } else {                                                 // spaces.py:279-351: truncate per element
       for (int k = 0; k < n; ++k) {
-        const float m = mu[k];
-        float v = m + noise(g, d);
-        for (int it = 0; it < 4096 && !(v >= d.box_min && v <= d.box_max); ++it) v = m + noise(g, d);
+        const float m = mu[k], sc = scale_of(d, i, k);
+        float v = m + noise(g, d, sc);
+        for (int it = 0; it < 4096 && !(v >= d.box_min && v <= d.box_max); ++it) v = m + noise(g, d, sc);
         o[k] = v;
       }
     }
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(THREADS) void sample_k(Desc d, const float* __restr
   for (int k = 0; k < n; ++k) {
     float v;
     if (d.dist == CLICA_DIST_UNIFORM) v = g.normal();        // spaces.py:134-138
-    else v = mu[k] + noise(g, d);
+    else v = mu[k] + noise(g, d, scale_of(d, i, k));
     o[k] = v; ss += v * v;
   }
   if (d.space == CLICA_SPACE_SPHERE) {
@@ -240,9 +245,9 @@ extern "C" int clica_sample_pair(const clica_sampler_desc* marginal, const clica
   }
   if (marginal->dist != CLICA_DIST_UNIFORM) CLICA_CHECK_ARG(marginal_mean != nullptr && ldmm >= marginal->n, "clica_sample_pair: marginal mean missing");
   rng::Desc qm{marginal->space, marginal->dist, marginal->n, marginal->box_min, marginal->box_max, marginal->scale, marginal->shape_p,
-               marginal->seed, marginal->stream_id};
+               marginal->seed, marginal->stream_id, nullptr, 0};
   rng::Desc qc{conditional->space, conditional->dist, conditional->n, conditional->box_min, conditional->box_max, conditional->scale,
-               conditional->shape_p, conditional->seed, conditional->stream_id};
+               conditional->shape_p, conditional->seed, conditional->stream_id, nullptr, 0};
   hipLaunchKernelGGL(rng::sample_pair_elem_k, dim3((unsigned)ceil_div(M * marginal->n, rng::THREADS)), dim3(rng::THREADS), 0,
                      as_stream(stream), qm, qc, marginal_mean, ldmm, z, ldz, zt, ldzt, M, step_dev);
   return launch_status("clica_sample_pair");
@@ -251,7 +256,17 @@ extern "C" int clica_sample_pair(const clica_sampler_desc* marginal, const clica
 extern "C" int clica_sample(const clica_sampler_desc* d, const float* mean, int64_t ldm,
                             float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
                             clica_stream_t stream) {
+  return clica_sample_scaled(d, mean, ldm, nullptr, 0, out, ldo, M, step_dev, stream);
+}
+
+extern "C" int clica_sample_scaled(const clica_sampler_desc* d, const float* mean, int64_t ldm,
+                                   const float* scale_vec, int64_t lds,
+                                   float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
+                                   clica_stream_t stream) {
   CLICA_CHECK_ARG(d && out && M > 0, "clica_sample: bad argument");
+  if (scale_vec)
+    CLICA_CHECK_ARG((lds == 0 || lds >= d->n) && d->dist >= CLICA_DIST_NORMAL && d->dist <= CLICA_DIST_GENNORM,
+                    "clica_sample_scaled: a per-coordinate scale needs a location-scale kind (normal / laplace / gennorm) and lds = 0 or >= n");
   CLICA_CHECK_ARG(d->n >= 1 && ldo >= d->n, "clica_sample: n=%d ldo=%lld", d->n, (long long)ldo);
   CLICA_CHECK_ARG(d->space >= CLICA_SPACE_REAL && d->space <= CLICA_SPACE_SPHERE, "clica_sample: unknown space %d", d->space);
   CLICA_CHECK_ARG(d->dist >= CLICA_DIST_UNIFORM && d->dist <= CLICA_DIST_VMF, "clica_sample: unknown distribution %d", d->dist);
@@ -263,7 +278,7 @@ extern "C" int clica_sample(const clica_sampler_desc* d, const float* mean, int6
     CLICA_CHECK_ARG(d->space == CLICA_SPACE_SPHERE && d->n >= 2 && d->scale > 0.f, "clica_sample: vMF needs the sphere, n >= 2, kappa > 0");
   if (d->dist == CLICA_DIST_GENNORM) CLICA_CHECK_ARG(d->shape_p > 0.f, "clica_sample: generalized normal needs shape_p > 0");
   if (d->space == CLICA_SPACE_BOX) CLICA_CHECK_ARG(d->box_max > d->box_min, "clica_sample: empty box");
-  rng::Desc q{d->space, d->dist, d->n, d->box_min, d->box_max, d->scale, d->shape_p, d->seed, d->stream_id};
+  rng::Desc q{d->space, d->dist, d->n, d->box_min, d->box_max, d->scale, d->shape_p, d->seed, d->stream_id, scale_vec, lds};
   const bool rowwise = d->space == CLICA_SPACE_SPHERE || d->dist == CLICA_DIST_VMF;   // need the row norm
   if (rowwise)
     hipLaunchKernelGGL(rng::sample_k, dim3((unsigned)ceil_div(M, rng::THREADS)), dim3(rng::THREADS), 0, as_stream(stream),

@@ -17,7 +17,7 @@ from torch import nn
 from . import layers as ls
 from . import ops
 
-__all__ = ["get_mlp", "FusedMLP"]
+__all__ = ["get_mlp", "FusedMLP", "NormedMLP"]
 
 
 class _MLPStackFn(torch.autograd.Function):
@@ -162,6 +162,23 @@ class FusedMLP(nn.Sequential):
         return y
 
 
+class NormedMLP(nn.Sequential):
+    """get_mlp(layer_normalization="bn" | "gn"): same modules and state dict as the reference's Sequential; Linear and
+    LeakyReLU run on the HIP kernels (per layer), the normalisation modules are torch's."""
+
+    def forward(self, x):
+        if x.dim() != 2:
+            x = x.reshape(-1, x.shape[-1])
+        for m in self:
+            if isinstance(m, nn.Linear):
+                x = _MLPStackFn.apply(x, 0.01, m.weight, m.bias)       # one-layer stack: no activation
+            elif isinstance(m, nn.LeakyReLU):
+                x = ls._LeakyFn.apply(x.contiguous(), float(m.negative_slope))
+            else:
+                x = m(x)
+        return x
+
+
 def get_mlp(n_in: int, n_out: int, layers: List[int], layer_normalization: Optional[str] = None,
             output_normalization: Optional[str] = None, output_normalization_kwargs=None):
     """Creates an MLP (same arguments as encoders.py:10-23).
@@ -171,14 +188,15 @@ def get_mlp(n_in: int, n_out: int, layers: List[int], layer_normalization: Optio
         n_out: dimensionality of the output data
         layers: number of neurons for each hidden layer (the reference appends ``n_out`` to the
             caller's list in place, encoders.py:56; reproduced)
-        layer_normalization: must be None -- "bn"/"gn" are never used by the reference's drivers
-            and have no fused kernel here
+        layer_normalization: None | "bn" | "gn" (encoders.py:41-44).  With a normalisation between the layers the
+            stack cannot run as one fused kernel: every Linear runs on the HIP GEMM kernels, the activation on the HIP
+            elementwise kernel, and BatchNorm1d / GroupNorm(1, .) are torch's own device modules (none of the reference's
+            drivers passes this argument, so it is outside the measured hot path)
         output_normalization: None | "fixed_sphere" | "learnable_sphere" | "fixed_box" | "learnable_box"
         output_normalization_kwargs: forwarded to the head (e.g. ``init_r`` for the sphere)
     """
-    if layer_normalization is not None:
-        raise NotImplementedError("layer_normalization (bn/gn) is outside the fused hot path; "
-                                  "no main_*.py driver of the reference uses it")
+    if layer_normalization not in (None, "bn", "gn"):
+        raise ValueError("layer_normalization")
     if len(layers) == 0:
         raise ValueError("get_mlp needs at least one hidden layer (the reference's empty-layers "
                          "branch raises as well, encoders.py:54)")
@@ -188,6 +206,10 @@ def get_mlp(n_in: int, n_out: int, layers: List[int], layer_normalization: Optio
     for i, l in enumerate(layers):
         modules.append(nn.Linear(width, l))
         if i < len(layers) - 1:
+            if layer_normalization == "bn":
+                modules.append(nn.BatchNorm1d(l))
+            elif layer_normalization == "gn":
+                modules.append(nn.GroupNorm(1, l))
             modules.append(nn.LeakyReLU())
         width = l
     kw = output_normalization_kwargs or {}
@@ -201,4 +223,4 @@ def get_mlp(n_in: int, n_out: int, layers: List[int], layer_normalization: Optio
         modules.append(ls.SoftclipLayer(n=n_out, fixed_abs_bound=False, **kw))
     elif output_normalization is not None:
         raise ValueError("output_normalization")
-    return FusedMLP(*modules)
+    return (NormedMLP if layer_normalization else FusedMLP)(*modules)

@@ -407,7 +407,9 @@ DIST = {"uniform": 0, "normal": 1, "laplace": 2, "gennorm": 3, "vmf": 4}
 
 def sample(space: str, dist: str, n: int, size: int, device, mean: Optional[torch.Tensor] = None,
            scale: float = 1.0, shape_p: float = 2.0, box=(0.0, 1.0), seed: int = 0, stream_id: int = 0,
-           step_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           step_dev: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           scale_vec: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`scale_vec`: optional (n,), (1, n) or (size, n) tensor of per-coordinate scales multiplying `scale` (clica_sample_scaled)."""
     d = _lib.SamplerDesc(space=SPACE[space], dist=DIST[dist], n=n, box_min=float(box[0]), box_max=float(box[1]),
                          scale=float(scale), shape_p=float(shape_p), seed=int(seed) & (2**64 - 1),
                          stream_id=int(stream_id) & 0xFFFFFFFF)
@@ -422,6 +424,16 @@ def sample(space: str, dist: str, n: int, size: int, device, mean: Optional[torc
         elif mean.shape[0] != size:
             raise ValueError(f"mean has {mean.shape[0]} rows, expected 1 or {size}")
     o = out if out is not None else torch.empty((size, n), dtype=torch.float32, device=device)
+    if scale_vec is not None:
+        require_cuda(scale_vec, "scale_vec")
+        sv = scale_vec.detach().to(torch.float32)
+        sv = sv.reshape(1, -1) if sv.dim() == 1 else sv
+        if sv.dim() != 2 or sv.shape[1] != n or sv.shape[0] not in (1, size):
+            raise ValueError(f"scale tensor of shape {tuple(scale_vec.shape)}: expected ({n},), (1, {n}) or ({size}, {n})")
+        sv, lds = rowmajor(sv)
+        check(load().clica_sample_scaled(C.byref(d), ptr(mean), ldm, sv.data_ptr(), 0 if sv.shape[0] == 1 else lds, o.data_ptr(),
+                                         o.stride(0), size, ptr(step_dev), stream_ptr()), "clica_sample_scaled")
+        return o
     check(load().clica_sample(C.byref(d), ptr(mean), ldm, o.data_ptr(), o.stride(0), size, ptr(step_dev), stream_ptr()),
           "clica_sample")
     return o

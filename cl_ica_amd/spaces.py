@@ -75,8 +75,11 @@ class _Base(Space):
         return self.n
 
     def _cond(self, dist, mean, scale, size, device, shape_p=2.0):
-        if torch.is_tensor(scale):
-            raise NotImplementedError("per-dimension scale tensors are not used by the reference's drivers")
+        if torch.is_tensor(scale) and scale.numel() > 1:
+            # spaces.py:60-72, 157-166, 297: `std` of normal() may be a (n,), (1, n) or (size, n) tensor (laplace and
+            # generalized_normal assert a float there, spaces.py:87, 112; accepted here for all three location-scale kinds)
+            return _draw(self.kind, dist, self.n, size, device, mean=_mean2d(mean, self.n, size, device), scale=1.0,
+                         shape_p=float(shape_p), box=self.box, scale_vec=scale.to(device=device, dtype=torch.float32))
         return _draw(self.kind, dist, self.n, size, device, mean=_mean2d(mean, self.n, size, device), scale=float(scale),
                      shape_p=float(shape_p), box=self.box)
 

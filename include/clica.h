@@ -37,6 +37,9 @@ extern "C" {
 typedef void* clica_stream_t;    /* hipStream_t */
 
 const char* clica_last_error(void);
+/* The library reads its tuning switches (CLICA_GEMM_CFG_*, CLICA_SKINNY) from the environment once, at the first launch;
+ * call this after changing them inside a running process (tests, tuning sweeps). */
+int clica_reload_env(void);
 int clica_version(void);
 
 /* ------------------------------------------------------------------------------------
@@ -52,7 +55,7 @@ int clica_version(void);
 typedef struct clica_lp_loss_desc {
   int64_t B;       /* rows of z1 and z2                                  */
   int64_t B3;      /* rows of z3                                         */
-  int32_t n;       /* embedding dimension (1..64)                        */
+  int32_t n;       /* embedding dimension (1..512; register-resident kernels to 64, wide-row kernels beyond) */
   float p;         /* exponent of the norm (1, 2, 3 fast paths; any p>0) */
   float tau;
   float alpha;
@@ -359,6 +362,13 @@ typedef struct clica_sampler_desc {
 int clica_sample(const clica_sampler_desc* d, const float* mean, int64_t ldm,
                  float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
                  clica_stream_t stream);
+/* Same draw with a per-coordinate scale tensor: coordinate k of row i uses d->scale * scale_vec[i * lds + k] (lds = 0: one
+ * row for every sample).  spaces.py:60-72, 157-166, 297: `std` of normal() may be a tensor of shape (n,), (1, n) or (size, n).
+ * scale_vec = NULL is clica_sample. */
+int clica_sample_scaled(const clica_sampler_desc* d, const float* mean, int64_t ldm,
+                        const float* scale_vec, int64_t lds,
+                        float* out, int64_t ldo, int64_t M, const int32_t* step_dev,
+                        clica_stream_t stream);
 /* z ~ marginal and z~ ~ conditional(. | z) (main_mlp.py:196-200) in ONE launch when both kinds are coordinate-wise
  * (box / R^n); the draws are bit-identical to clica_sample(marginal) followed by clica_sample(conditional, mean = z).
  * Row-wise kinds (sphere, vMF) fall through to those two launches. */

@@ -55,9 +55,9 @@ def test_host_only_entry_points(lib):
     fb, bb = ctypes.c_size_t(), ctypes.c_size_t()
     assert L.clica_lp_loss_workspace_bytes(ctypes.byref(d), ctypes.byref(fb), ctypes.byref(bb)) == 0
     assert 0 < fb.value < 64 << 20 and 0 < bb.value < 256 << 20
-    bad = _lib.LpLossDesc(B=4, B3=4, n=100, p=2.0, tau=1.0, alpha=0.5, compat=1, pow=1)
+    bad = _lib.LpLossDesc(B=4, B3=4, n=513, p=2.0, tau=1.0, alpha=0.5, compat=1, pow=1)
     assert L.clica_lp_loss_workspace_bytes(ctypes.byref(bad), ctypes.byref(fb), ctypes.byref(bb)) == -1
-    assert b"n=100" in L.clica_last_error()
+    assert b"n=513" in L.clica_last_error()
     frac = _lib.LpLossDesc(B=4, B3=5, n=3, p=0.5, tau=1.0, alpha=0.5, compat=1, pow=1)
     assert L.clica_lp_loss_workspace_bytes(ctypes.byref(frac), ctypes.byref(fb), ctypes.byref(bb)) == -1
     nb = ctypes.c_size_t()

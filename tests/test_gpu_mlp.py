@@ -13,15 +13,28 @@ def dev(a):
     return torch.tensor(np.asarray(a, np.float32), device="cuda")
 
 
+@pytest.fixture
+def tuning_env(monkeypatch):
+    """Set a library tuning switch for one test: the library caches them, so re-read after setting AND after restoring."""
+    from cl_ica_amd import _lib
+
+    def set_(name, value):
+        monkeypatch.setenv(name, value)
+        assert _lib.load().clica_reload_env() == 0
+    yield set_
+    monkeypatch.undo()
+    assert _lib.load().clica_reload_env() == 0
+
+
 @pytest.mark.parametrize("M,N,K", [(48, 40, 4), (300, 100, 10), (1000, 500, 100), (12288, 500, 500), (257, 10, 100),
                                    (129, 131, 67), (64, 2000, 400), (5, 3, 1), (12288, 100, 10), (12288, 10, 100),
                                    (777, 16, 16), (1000, 5, 256), (130, 400, 16)])
 @pytest.mark.parametrize("skinny", ["1", "0"])
-def test_linear_kernels_vs_fp64(M, N, K, skinny, monkeypatch):
+def test_linear_kernels_vs_fp64(M, N, K, skinny, tuning_env):
     """skinny=1: tiny-K / tiny-N layers take the VALU kernels (csrc/skinny.hip); skinny=0 forces every
     shape through the MFMA template.  Both must match fp64."""
     from cl_ica_amd import ops
-    monkeypatch.setenv("CLICA_SKINNY", skinny)
+    tuning_env("CLICA_SKINNY", skinny)
     rng = np.random.default_rng(M * 7 + N)
     x = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.uniform(-1, 1, size=(N, K)) / np.sqrt(K)).astype(np.float32)
@@ -87,6 +100,36 @@ def test_mlp_goldens(golden):
                 PARITY.check("mlp_goldens_g6/grad", case, name, got, c["out"][f"grad/{name}"])
             else:
                 PARITY.check("mlp_goldens_g6/grad", case, name, np.ascontiguousarray(got.reshape(-1)[::97]), c["out"][f"gradsub/{name}"])
+
+
+@pytest.mark.parametrize("mode", ["bn", "gn"])
+def test_mlp_layer_normalization_goldens(golden, mode):
+    """get_mlp(layer_normalization=...) (encoders.py:41-44) against G20: train / eval forward, gradients, running stats,
+    state-dict layout."""
+    from conftest import fill_formula, formula_weights
+    from cl_ica_amd import encoders
+    z = golden("g20_mlp_layernorm.npz").z
+    n = 6
+    f = encoders.get_mlp(n_in=n, n_out=n, layers=[24, 40, 24], layer_normalization=mode)
+    fill_formula(f)
+    for m in f:
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.GroupNorm)):
+            m.weight.data += 1.0
+    f = f.to("cuda").train()
+    x = dev(z["x"]).requires_grad_(True)
+    y = f(x)
+    (y * dev(z["c"])).sum().backward()
+    PARITY.check("mlp_layernorm_g20", mode, "y", y.detach().cpu().numpy(), z[f"{mode}/y"])
+    PARITY.check("mlp_layernorm_g20", mode, "dx", x.grad.cpu().numpy(), z[f"{mode}/dx"])
+    names = [k for k, _ in f.named_parameters()]
+    assert [f"{mode}/grad/{k}" in z.files for k in names] == [True] * len(names)
+    for name, prm in f.named_parameters():
+        PARITY.check("mlp_layernorm_g20/grad", mode, name, prm.grad.cpu().numpy(), z[f"{mode}/grad/{name}"])
+    for name, buf in f.named_buffers():
+        PARITY.check("mlp_layernorm_g20/buf", mode, name, buf.float().cpu().numpy(), z[f"{mode}/buf/{name}"].astype(np.float32))
+    f.eval()
+    with torch.no_grad():
+        PARITY.check("mlp_layernorm_g20", mode, "y_eval", f(dev(z["x"])).cpu().numpy(), z[f"{mode}/y_eval"])
 
 
 def test_mixing_golden(golden):

@@ -40,8 +40,11 @@ def test_get_mlp_structure_and_state_dict(golden):
 
 def test_get_mlp_rejects_unbuilt_options():
     from cl_ica_amd import encoders
-    with pytest.raises(NotImplementedError):
-        encoders.get_mlp(4, 4, [8], layer_normalization="bn")
+    f = encoders.get_mlp(4, 4, [8, 6], layer_normalization="bn")       # reference module order: Linear, norm, activation
+    assert [type(m).__name__ for m in f] == ["Linear", "BatchNorm1d", "LeakyReLU", "Linear", "BatchNorm1d", "LeakyReLU", "Linear"]
+    assert isinstance(encoders.get_mlp(4, 4, [8], layer_normalization="gn")[1], torch.nn.GroupNorm)
+    with pytest.raises(ValueError):
+        encoders.get_mlp(4, 4, [8], layer_normalization="ln")
     with pytest.raises(ValueError):
         encoders.get_mlp(4, 4, [8], output_normalization="nope")
     with pytest.raises(ValueError):

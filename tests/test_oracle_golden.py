@@ -16,6 +16,10 @@ TOL = 2e-6
 def grad_scale(c):
     """Size of the un-cancelled positive-pair gradient term: (2 alpha / (B tau)) max |d|d|^p/dd|."""
     m = c["meta"]
+    if "normalize" in m:      # dot-product InfoNCE: pull = (2 alpha / (B tau)) z2 (through d u / d z ~ 1 / |z| when normalised)
+        z1 = np.asarray(c["in"]["z1"], np.float64); z2 = np.asarray(c["in"]["z2"], np.float64)
+        mag = 1.0 / np.linalg.norm(z1, axis=1).min() if bool(m["normalize"]) else np.abs(z2).max()
+        return 2 * float(m["alpha"]) / (z1.shape[0] * float(m["tau"])) * float(mag)
     if "p" not in m:
         return 0.0
     p = float(m["p"]); tau = float(m["tau"]); alpha = float(m["alpha"]) if "alpha" in m else 0.5
@@ -46,7 +50,7 @@ def _check_loss_case(c, out, tol=TOL, grads=("dz1", "dz2", "dz3")):
         assert np.abs(out[g] - ref).max() / scale < 5 * tol * sat, g
 
 
-@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz"])
+@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz", "g19_wide_lp.npz"])
 def test_lp_loss_goldens(golden, name):
     G = golden(name)
     assert G.n_cases > 0
@@ -101,8 +105,9 @@ def test_lp_loss_grad_finite_difference():
                     assert np.abs(num - out[name]).max() < 1e-6, (p, compat, pw, name)
 
 
-def test_simclr_goldens(golden):
-    G = golden("g5_simclr.npz")
+@pytest.mark.parametrize("name", ["g5_simclr.npz", "g19_wide_simclr.npz"])
+def test_simclr_goldens(golden, name):
+    G = golden(name)
     for key, c in G.cases():
         m = c["meta"]
         out = O.simclr_loss(c["in"]["z1"], c["in"]["z2"], c["in"]["z3"], normalize=bool(m["normalize"]),
@@ -209,9 +214,10 @@ def test_torch_port_goldens(golden):
     assert n > 50
 
 
-def test_uniformity_alignment_oracle_vs_golden(golden):
-    """G12: UniformityLoss / AlignmentLoss (losses.py:205-241)."""
-    G = golden("g12_align_uniform.npz")
+@pytest.mark.parametrize("gname", ["g12_align_uniform.npz", "g18_align_uniform_frac.npz"])
+def test_uniformity_alignment_oracle_vs_golden(golden, gname):
+    """G12 / G18 (fractional exponents): UniformityLoss / AlignmentLoss (losses.py:205-241)."""
+    G = golden(gname)
     for i in range(G.n_cases):
         u = G.case(f"u{i:03d}"); p = float(u["meta"]["p"])
         out = O.uniformity_loss(u["in"]["z1"], u["in"]["z3"], p)

@@ -6,7 +6,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cl_ica_amd import ops  # noqa: E402
+from cl_ica_amd import _lib, ops  # noqa: E402
 
 SHAPES = [(12288, 500, 500), (12288, 100, 500), (12288, 500, 100), (12288, 100, 10), (12288, 10, 100)]
 if len(sys.argv) > 1 and sys.argv[1] == "n40":
@@ -42,6 +42,7 @@ def main():
                     os.environ.pop(var, None)
                 else:
                     os.environ[var] = str(cfg)
+            _lib.load().clica_reload_env()          # the library caches its tuning switches
             y = ops.linear_fwd(x, w, b, True); dx = ops.linear_dgrad(dy, w, xa); dw, db = ops.linear_wgrad(dy, x)
             errs = [float((y - ref_y).abs().max() / ref_y.abs().max()), float((dx - ref_dx).abs().max() / ref_dx.abs().max()),
                     float((dw - ref_dw).abs().max() / ref_dw.abs().max())]
