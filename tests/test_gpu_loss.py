@@ -141,8 +141,13 @@ def test_simclr_goldens(golden, name):
         z1 = np.asarray(c["in"]["z1"], np.float64)
         mag = 1.0 / np.linalg.norm(z1, axis=1).min() if bool(m["normalize"]) else float(np.abs(c["in"]["z2"]).max())
         gf = 2 * float(m["alpha"]) / (z1.shape[0] * float(m["tau"])) * mag
+        # loss_i = 2 (alpha (-pos / tau) + (1 - alpha) lse) cancels the same way: relative to the larger summand
+        orc = O.simclr_loss(c["in"]["z1"], c["in"]["z2"], c["in"]["z3"], normalize=bool(m["normalize"]), tau=float(m["tau"]),
+                            alpha=float(m["alpha"]), grad=False)
+        pos_mag = float(np.abs(orc["lse"] - orc["loss_i"] / 2.0).max())       # ~ alpha |pos| / tau + alpha |lse|: size of the summands
+        lf = 2.0 * max(pos_mag, (1.0 - float(m["alpha"])) * float(np.abs(orc["lse"]).max()))
         compare(f"simclr_goldens/{name[:-4]}", f"{key} norm={int(m['normalize'])} tau={float(m['tau']):g} n={z1.shape[1]}", out,
-                c["out"], ("dz1", "dz2", "dz3"), grad_floor=gf)
+                c["out"], ("dz1", "dz2", "dz3"), loss_floor=lf, grad_floor=gf, means_floor=(float(np.abs(orc["lse"]).max()),) * 2)
 
 
 def test_strided_views(golden):
