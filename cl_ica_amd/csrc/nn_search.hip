@@ -1,0 +1,197 @@
+// Exact nearest neighbours in squared L2 over a latent table resident in HBM -- the lookup
+// /root/reference/datasets/threedident_dataset.py:64-83, 104-116 does with faiss.IndexFlatL2 (host, one query per
+// __getitem__): sampled latents z, z~ are snapped to the closest rendered grid point of raw_latents.npy.
+//
+// Same all-pairs sweep as the loss (lp_kernels.h): a workgroup owns 32 R queries whose coordinates live in registers, the
+// table streams through LDS a tile at a time, the workgroup's chunk is cut into eight on-chip partitions, and what a lane
+// keeps per query is a sorted list of the K best (distance, row) pairs instead of a running (max, sum).  Partitions are
+// merged on chip, table splits by a small second launch.  Ties go to the lower row (deterministic).  HBM traffic is the
+// table once per query tile: N n 4 B x ceil(Q / 64) (L2-resident for the 3DIdent table: 250 000 x 10 floats = 10 MB).
+#include "lp_kernels.h"
+#include <limits.h>
+
+namespace clica {
+namespace nn {
+using namespace clica::lp;
+
+__device__ __forceinline__ bool before(float d, int j, float d2, int j2) { return d < d2 || (d == d2 && j < j2); }
+
+template <int K>
+__device__ __forceinline__ void insert(float (&bd)[K], int (&bi)[K], float d, int j) {
+  if (!before(d, j, bd[K - 1], bi[K - 1])) return;
+  bd[K - 1] = d; bi[K - 1] = j;
+#pragma unroll
+  for (int c = K - 1; c > 0; --c) {
+    if (before(bd[c], bi[c], bd[c - 1], bi[c - 1])) {
+      const float td = bd[c]; bd[c] = bd[c - 1]; bd[c - 1] = td;
+      const int ti = bi[c]; bi[c] = bi[c - 1]; bi[c - 1] = ti;
+    }
+  }
+}
+
+struct Cand { float d; int i; };
+
+template <int NP, int R, int K, int NQ = NP / 2>
+__global__ __launch_bounds__(THREADS) void nn_partial_k(const float* __restrict__ qry, int64_t ldq, int64_t n_q,
+                                                       const float* __restrict__ tab, int64_t ldt, int64_t n_tab,
+                                                       Params q, Cand* __restrict__ part, int chunk) {
+  constexpr int TS = tile_rows(NP), RPP = TS / PARTS;
+  __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
+  __shared__ Cand wred[WAVES][HALF * R][K];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (HALF - 1), hf = lane >> 5;
+  const int pq = wave * 2 + hf;
+  const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
+  f32x2 o[R][NP / 2];
+  load_owners<NP, R>(o, qry, ldq, own0, n_q, q.n);
+  float bd[R][K]; int bi[R][K];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < K; ++c) { bd[r][c] = INFINITY; bi[r][c] = INT_MAX; }
+
+  const int64_t jb = (int64_t)blockIdx.y * chunk;
+  const int64_t je = min(n_tab, jb + (int64_t)chunk);
+  Stager<NP> st;
+  if (jb < je) {
+    st.load(tab, ldt, jb, (int)min((int64_t)TS, je - jb), q.n);
+    st.store(tiles[0]);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t j0 = jb; j0 < je; j0 += TS, cur ^= 1) {
+    const int cnt = (int)min((int64_t)TS, je - j0);
+    const bool more = j0 + TS < je;
+    if (more) st.load(tab, ldt, j0 + TS, (int)min((int64_t)TS, je - j0 - TS), q.n);
+    const float* tile = tiles[cur] + pq * RPP * NP;
+    const int cq = min(RPP, max(0, cnt - pq * RPP));
+    const int row0 = (int)j0 + pq * RPP;
+    for (int jj = 0; jj < cq; jj += JB) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float acc[JB];
+        dist_group<NP, 2, NQ>(o[r], tile, jj, q, acc);
+        // a lane meets its rows in increasing order, so "strictly closer than the current K-th" keeps the lower row on ties
+        const float worst = bd[r][K - 1];
+        const float best4 = fminf(fminf(acc[0], acc[1]), fminf(acc[2], acc[3]));
+        if (best4 < worst || jj + JB > cq) {
+#pragma unroll
+          for (int c = 0; c < JB; ++c)
+            if (jj + c < cq) insert<K>(bd[r], bi[r], acc[c], row0 + jj + c);
+        }
+      }
+    }
+    if (more) st.store(tiles[cur ^ 1]);
+    __syncthreads();
+  }
+  // merge the two half-waves (shuffle), then the four waves (LDS), fixed order
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float od[K]; int oi[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) { od[c] = __shfl_xor(bd[r][c], HALF, 64); oi[c] = __shfl_xor(bi[r][c], HALF, 64); }
+#pragma unroll
+    for (int c = 0; c < K; ++c) insert<K>(bd[r], bi[r], od[c], oi[c]);
+    if (hf == 0) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) wred[wave][r * HALF + li][c] = Cand{bd[r][c], bi[r][c]};
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < HALF * R) {
+    const int t = threadIdx.x;
+    const int64_t i = own0 + t;
+    float md[K]; int mi[K];
+#pragma unroll
+    for (int c = 0; c < K; ++c) { md[c] = wred[0][t][c].d; mi[c] = wred[0][t][c].i; }
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w)
+#pragma unroll
+      for (int c = 0; c < K; ++c) insert<K>(md, mi, wred[w][t][c].d, wred[w][t][c].i);
+    if (i < n_q) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) part[((int64_t)blockIdx.y * n_q + i) * K + c] = Cand{md[c], mi[c]};
+    }
+  }
+}
+
+// merge the table splits of one query; emits k <= K columns
+template <int K>
+__global__ __launch_bounds__(THREADS) void nn_merge_k(const Cand* __restrict__ part, int nsplit, int64_t n_q, int k,
+                                                     int64_t* __restrict__ idx, float* __restrict__ dist) {
+  const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (i >= n_q) return;
+  float md[K]; int mi[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) { md[c] = INFINITY; mi[c] = INT_MAX; }
+  for (int sp = 0; sp < nsplit; ++sp)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      const Cand v = part[((int64_t)sp * n_q + i) * K + c];
+      insert<K>(md, mi, v.d, v.i);
+    }
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+    if (c < k) {
+      idx[i * k + c] = mi[c] == INT_MAX ? -1 : (int64_t)mi[c];        // fewer than k rows in the table: faiss pads with -1
+      if (dist) dist[i * k + c] = md[c];
+    }
+}
+
+template <int K>
+static void launch(const Plan& P, const float* qry, int64_t ldq, int64_t n_q, const float* tab, int64_t ldt, int64_t n_tab,
+                   const Params& q, Cand* part, int k, int64_t* idx, float* dist, hipStream_t st) {
+  dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
+#define NN_CASE(NPV, NQV)                                                                                              \
+  hipLaunchKernelGGL((nn_partial_k<NPV, owners_fwd(NPV), K, NQV>), grid, block, 0, st, qry, ldq, n_q, tab, ldt, n_tab, q, part, P.chunk)
+  switch (P.np) {
+    case 4: NN_CASE(4, 2); break;
+    case 8: NN_CASE(8, 4); break;
+    case 12: if (q.n <= 10) NN_CASE(12, 5); else NN_CASE(12, 6); break;
+    case 16: NN_CASE(16, 8); break;
+    case 24: NN_CASE(24, 12); break;
+    case 32: NN_CASE(32, 16); break;
+    case 40: NN_CASE(40, 20); break;
+    default: NN_CASE(64, 32); break;
+  }
+#undef NN_CASE
+  hipLaunchKernelGGL((nn_merge_k<K>), dim3((unsigned)ceil_div(n_q, THREADS)), dim3(THREADS), 0, st, (const Cand*)part, P.nsplit,
+                     n_q, k, idx, dist);
+}
+
+constexpr int kMaxK = 4;
+static int kcap(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : 4); }
+}  // namespace nn
+}  // namespace clica
+
+using namespace clica;
+
+extern "C" int clica_nn_search_workspace_bytes(int64_t n_query, int64_t n_table, int32_t n, int32_t k, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && n_query > 0 && n_table > 0 && n >= 1 && n <= 64 && k >= 1 && k <= nn::kMaxK,
+                  "clica_nn_search_workspace_bytes: need n_query, n_table > 0, 1 <= n <= 64, 1 <= k <= %d", nn::kMaxK);
+  const lp::Plan P = lp::make_plan(n_query, n_table, n, false);
+  *bytes = align_up((size_t)P.nsplit * n_query * nn::kcap(k) * sizeof(nn::Cand), 256);
+  return CLICA_OK;
+}
+
+extern "C" int clica_nn_search(const float* table, int64_t ldt, int64_t n_table, const float* query, int64_t ldq, int64_t n_query,
+                               int32_t n, int32_t k, int64_t* idx, float* dist, void* workspace, size_t workspace_bytes,
+                               clica_stream_t stream) {
+  CLICA_CHECK_ARG(table && query && idx && workspace && n_query > 0 && n_table > 0, "clica_nn_search: bad argument");
+  CLICA_CHECK_ARG(n >= 1 && n <= 64 && ldt >= n && ldq >= n, "clica_nn_search: n=%d must be in 1..64 and <= the leading dimensions", n);
+  CLICA_CHECK_ARG(k >= 1 && k <= nn::kMaxK, "clica_nn_search: k=%d must be in 1..%d", k, nn::kMaxK);
+  CLICA_CHECK_ARG(n_table < (int64_t)INT_MAX, "clica_nn_search: table rows are indexed with 32 bits on chip");
+  size_t need = 0;
+  clica_nn_search_workspace_bytes(n_query, n_table, n, k, &need);
+  if (need > workspace_bytes) { set_error("clica_nn_search: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  const lp::Plan P = lp::make_plan(n_query, n_table, n, false);
+  lp::Params q;
+  q.p = 2.f; q.inv_p = 0.5f; q.kscale = 1.f; q.sgn = 1.f; q.eps = 0.f; q.xs = -1.f; q.pow = 1; q.n = n;
+  hipStream_t st = as_stream(stream);
+  nn::Cand* part = reinterpret_cast<nn::Cand*>(workspace);
+  switch (nn::kcap(k)) {
+    case 1: nn::launch<1>(P, query, ldq, n_query, table, ldt, n_table, q, part, k, idx, dist, st); break;
+    case 2: nn::launch<2>(P, query, ldq, n_query, table, ldt, n_table, q, part, k, idx, dist, st); break;
+    default: nn::launch<4>(P, query, ldq, n_query, table, ldt, n_table, q, part, k, idx, dist, st); break;
+  }
+  return launch_status("clica_nn_search");
+}

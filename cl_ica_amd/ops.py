@@ -401,6 +401,25 @@ def sample_pair(space: str, marginal: str, conditional: str, n: int, size: int, 
     return z, zt
 
 
+# ------------------------------------------------------------------------------- nearest neighbours
+def nn_search(table: torch.Tensor, query: torch.Tensor, k: int = 1, want_dist: bool = True):
+    """Exact k nearest table rows of every query row in squared L2 (clica_nn_search; faiss.IndexFlatL2.search semantics:
+    ascending distances, int64 labels).  Returns (dist (Q, k) float32 | None, idx (Q, k) int64)."""
+    (tab, ldt), (qry, ldq) = _mat("table", table), _mat("query", query)
+    N, n = tab.shape
+    Q = qry.shape[0]
+    if qry.shape[1] != n:
+        raise ValueError(f"query {tuple(qry.shape)} does not match the table {tuple(tab.shape)}")
+    nbytes = C.c_size_t()
+    check(load().clica_nn_search_workspace_bytes(Q, N, n, int(k), C.byref(nbytes)), "clica_nn_search_workspace_bytes")
+    ws = workspace("nn_search", nbytes.value, tab.device)
+    idx = torch.empty((Q, k), dtype=torch.int64, device=tab.device)
+    dist = torch.empty((Q, k), dtype=torch.float32, device=tab.device) if want_dist else None
+    check(load().clica_nn_search(tab.data_ptr(), ldt, N, qry.data_ptr(), ldq, Q, n, int(k), idx.data_ptr(), ptr(dist),
+                                 ws.data_ptr(), ws.numel(), stream_ptr()), "clica_nn_search")
+    return dist, idx
+
+
 SPACE = {"real": 0, "box": 1, "sphere": 2}
 DIST = {"uniform": 0, "normal": 1, "laplace": 2, "gennorm": 3, "vmf": 4}
 

@@ -310,6 +310,18 @@ int clica_mixing_fwd_act(const float* Z, int64_t ldz, const float* W, int32_t n_
                          float* X, int64_t ldx, int64_t M, int32_t n, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Exact k-nearest-neighbour search in squared L2 over a latent table in HBM  --  the lookup
+ * datasets/threedident_dataset.py:71, 83, 104-105 does on the host with faiss.IndexFlatL2 (`index.add(latents)`,
+ * `index.search(z, 1)`, `index.search(z_tilde, 2)`): dist[i, c] = |query_i - table_idx[i, c]|^2 ascending in c, ties to the
+ * lower row; idx is int64 like faiss' labels (-1 where the table has fewer than k rows); dist may be NULL.
+ * 1 <= n <= 64, 1 <= k <= 4.
+ * ---------------------------------------------------------------------------------- */
+int clica_nn_search_workspace_bytes(int64_t n_query, int64_t n_table, int32_t n, int32_t k, size_t* bytes);
+int clica_nn_search(const float* table, int64_t ldt, int64_t n_table, const float* query, int64_t ldq, int64_t n_query,
+                    int32_t n, int32_t k, int64_t* idx, float* dist, void* workspace, size_t workspace_bytes,
+                    clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Adam  --  torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) as used at main_mlp.py:312,
  * over one flat parameter arena.  `step_dev` is a device int32 holding the number of
  * updates already applied; the call uses t = *step_dev + 1 for the bias corrections and

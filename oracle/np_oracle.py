@@ -400,3 +400,30 @@ def train_step(P: MLPParams, gWs, z1, z2, state, p=2, tau=1.0, lr=1e-4):
         else:
             P.head_param = newp
     return float(out["loss_mean"]), float(out["pos_mean"]), float(out["neg_mean"])
+
+
+def flat_l2_search(table, query, k, chunk=256):
+    """Exact k nearest rows in squared L2, ascending, ties to the lower row -- what faiss.IndexFlatL2.search returns at
+    /root/reference/datasets/threedident_dataset.py:104-105 (faiss itself is not in the image: exact search is its
+    definition; this function is pinned by construction on known-answer grids, tests/test_oracle_golden.py).
+    Returns (D (Q, k) float64, I (Q, k) int64)."""
+    table = np.asarray(table, np.float64); query = np.asarray(query, np.float64)
+    Q = query.shape[0]
+    D = np.empty((Q, k)); I = np.empty((Q, k), np.int64)
+    for a in range(0, Q, chunk):
+        q = query[a:a + chunk]
+        d = np.zeros((q.shape[0], table.shape[0]))
+        for c in range(table.shape[1]):                    # coordinate by coordinate: no (Q, N, n) temporary
+            d += (q[:, c:c + 1] - table[None, :, c]) ** 2
+        order = np.argsort(d, axis=1, kind="stable")[:, :k]
+        I[a:a + chunk] = order
+        D[a:a + chunk] = np.take_along_axis(d, order, 1)
+    return D, I
+
+
+def threedident_snap(table, z, z_tilde):
+    """threedident_dataset.py:104-116: nearest grid row of z, nearest of z~ that differs from it."""
+    _, iz = flat_l2_search(table, z, 1)
+    _, izt = flat_l2_search(table, z_tilde, 2)
+    iz = iz[:, 0]
+    return iz, np.where(izt[:, 0] != iz, izt[:, 0], izt[:, 1])

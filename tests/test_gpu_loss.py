@@ -230,9 +230,9 @@ def test_error_paths():
     z = torch.zeros(4, 3)
     with pytest.raises(ClicaError):
         LpSimCLRLoss(p=2)(None, None, None, z, z, z)          # CPU tensors: no fallback
-    zc = torch.zeros(4, 70, device="cuda")
+    zc = torch.zeros(4, 513, device="cuda")
     with pytest.raises(ClicaError):
-        LpSimCLRLoss(p=2)(None, None, None, zc, zc, zc)       # n > 64
+        LpSimCLRLoss(p=2)(None, None, None, zc, zc, zc)       # n > 512 (register kernels to 64, wide-row kernels to 512)
     with pytest.raises(ClicaError):
         LpSimCLRLoss(p=0.5)(None, None, None, zc[:, :3], zc[:, :3], torch.zeros(5, 3, device="cuda"))
 

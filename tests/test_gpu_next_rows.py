@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN, PARITY
+from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
 CKPT = os.path.join(GOLDEN, "g16_ckpt")
@@ -192,3 +193,81 @@ def test_mixing_net_activations_goldens(golden):
         assert torch.allclose(tr.x, g2(tr.z), rtol=1e-6, atol=1e-6)          # the engine's x = g(z) is the module's forward
     with pytest.raises(Exception):
         inu.construct_invertible_mlp(n=4, n_layers=2, act_fct="tanh")
+
+
+# ---------------------------------------------------------------------------------------------- N4: latent lookup
+@pytest.mark.parametrize("N,Q,n,k", [(60000, 700, 10, 2), (5000, 33, 3, 1), (4097, 257, 17, 4), (300, 64, 64, 2), (3, 5, 7, 4)])
+def test_nn_search_vs_oracle(N, Q, n, k):
+    """clica_nn_search (exact squared-L2 k-NN, the faiss.IndexFlatL2 lookup of threedident_dataset.py:104-105) against the
+    fp64 oracle: same rows wherever the fp64 gap to the next candidate is resolvable in fp32, distances to 1e-5."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(N + Q)
+    tab = rng.uniform(-1, 1, size=(N, n)).astype(np.float32)
+    qry = rng.uniform(-1, 1, size=(Q, n)).astype(np.float32)
+    dist, idx = ops.nn_search(torch.tensor(tab, device="cuda"), torch.tensor(qry, device="cuda"), k)
+    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+    D, I = O.flat_l2_search(tab, qry, min(k + 1, N))
+    kk = min(k, N)
+    assert (idx[:, kk:] == -1).all()                                    # fewer rows than k: padded like faiss
+    scale = float(n)                                                    # |q - t|^2 <= 4 n; fp32 sum of n terms
+    gap_ok = np.ones((Q, kk), bool)
+    for c in range(kk):                                                 # column c is decided if its fp64 neighbours are not near-ties
+        if c + 1 < D.shape[1]:
+            gap_ok[:, c] &= (D[:, c + 1] - D[:, c]) > 1e-6 * scale
+        if c > 0:
+            gap_ok[:, c] &= (D[:, c] - D[:, c - 1]) > 1e-6 * scale
+    assert gap_ok.mean() > 0.95
+    assert (idx[:, :kk][gap_ok] == I[:, :kk][gap_ok]).all()
+    PARITY.check("nn_search", f"N={N} Q={Q} n={n} k={k}", "dist", dist[:, :kk], D[:, :kk], floor=1e-3 * scale)
+    # every returned row really is at the returned distance, and the columns ascend
+    got = ((qry[:, None, :].astype(np.float64) - tab[idx[:, :kk]].astype(np.float64)) ** 2).sum(-1)
+    assert np.abs(got - dist[:, :kk]).max() <= 1e-5 * max(got.max(), 1e-3 * scale)
+    assert (np.diff(dist[:, :kk], axis=1) >= 0).all()
+
+
+def test_nn_search_ties_and_errors():
+    from cl_ica_amd import ops
+    from cl_ica_amd._lib import ClicaError
+    g = np.stack(np.meshgrid(np.arange(6), np.arange(5), np.arange(4), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    tab = np.concatenate([g, g])                                        # every row twice: the earlier copy wins
+    d, i = ops.nn_search(torch.tensor(tab, device="cuda"), torch.tensor(g + 0.25, device="cuda"), 2)
+    assert (i[:, 0].cpu().numpy() == np.arange(len(g))).all() and (i[:, 1].cpu().numpy() == np.arange(len(g)) + len(g)).all()
+    assert torch.allclose(d, torch.full_like(d, 3 * 0.25 ** 2))
+    with pytest.raises(ClicaError):
+        ops.nn_search(torch.zeros(8, 65, device="cuda"), torch.zeros(2, 65, device="cuda"), 1)
+    with pytest.raises(ClicaError):
+        ops.nn_search(torch.zeros(8, 4, device="cuda"), torch.zeros(2, 4, device="cuda"), 5)
+    with pytest.raises(ClicaError):
+        ops.nn_search(torch.zeros(8, 4), torch.zeros(2, 4), 1)          # host tensors: no fallback
+
+
+def test_threedident_latent_pairs_full_size():
+    """ThreeDIdentDataset.__getitem__'s latent lookup (threedident_dataset.py:96-116) for a batch of 1024 pairs over a table
+    of the dataset's size (250 000 x 10): properties at full size + the oracle on a sample of the batch."""
+    from cl_ica_amd import latent_spaces, spaces
+    from cl_ica_amd.datasets import IndexFlatL2, ThreeDIdentLatentPairs
+    rng = np.random.default_rng(7)
+    N, n, B = 250000, 10, 1024
+    table = rng.uniform(-1, 1, size=(N, n)).astype(np.float32)
+    space = spaces.NBoxSpace(n, -1.0, 1.0)
+    ls = latent_spaces.LatentSpace(space, lambda sp, size, device="cuda": sp.uniform(size, device=device),
+                                   lambda sp, z, size, device="cuda": sp.normal(z, 0.05, size, device=device))
+    spaces.manual_seed(3)
+    ds = ThreeDIdentLatentPairs(table, ls)
+    assert len(ds) == N
+    iz, izt, z, zt = ds.sample(B)
+    assert iz.shape == (B,) and iz.dtype == torch.int64 and (iz != izt).all()
+    assert torch.equal(z, ds.latents[iz]) and torch.equal(zt, ds.latents[izt])
+    # rows of the table find themselves at distance 0 (encode -> lookup round trip at full size)
+    pick = torch.tensor(rng.choice(N, 2048, replace=False), device="cuda")
+    index = IndexFlatL2(n); index.add(table)
+    assert index.ntotal == N
+    D, I = index.search(ds.latents[pick], 2)
+    assert torch.equal(I[:, 0], pick) and (D[:, 0] == 0).all() and (I[:, 1] != pick).all() and (D[:, 1] > 0).all()
+    # the snapping rule against the oracle on a sample (fresh draws with a known pre-image)
+    zq = torch.tensor(rng.uniform(-1, 1, size=(48, n)).astype(np.float32), device="cuda")
+    ztq = (zq + 0.01 * torch.tensor(rng.normal(size=(48, n)).astype(np.float32), device="cuda")).clamp(-1, 1)
+    a, b, _, _ = ds.snap(zq, ztq)
+    oa, ob = O.threedident_snap(table, zq.cpu().numpy(), ztq.cpu().numpy())
+    assert (a.cpu().numpy() == oa).all() and (b.cpu().numpy() == ob).all()
+    assert (a == b).sum() == 0 and (torch.tensor(oa) == O.flat_l2_search(table, ztq.cpu().numpy(), 1)[1][:, 0]).any()   # the exclusion rule fired

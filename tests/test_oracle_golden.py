@@ -234,3 +234,21 @@ def test_uniformity_alignment_oracle_vs_golden(golden, gname):
         assert rel_err(out["loss_i"], a["out"]["loss_i"]) < TOL
         for g in ("dz1", "dz2"):
             assert rel_err(out[g], a["out"][g]) < 5 * TOL, (i, g)
+
+
+def test_flat_l2_search_known_answers():
+    """oracle.flat_l2_search on a lattice where the answers are known by construction (faiss.IndexFlatL2 semantics:
+    ascending squared distances, positions in add order; ties to the lower row)."""
+    g = np.stack(np.meshgrid(np.arange(5), np.arange(4), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    q = g[[7, 31, 59]] + np.array([[0.1, -0.2, 0.05], [0.3, 0.1, -0.1], [-0.2, -0.3, 0.1]])
+    D, I = O.flat_l2_search(g, q, 2)
+    assert I[:, 0].tolist() == [7, 31, 59]
+    assert np.allclose(D[:, 0], [0.1 ** 2 + 0.2 ** 2 + 0.05 ** 2, 0.3 ** 2 + 0.1 ** 2 + 0.1 ** 2, 0.2 ** 2 + 0.3 ** 2 + 0.1 ** 2])
+    assert np.all(D[:, 1] >= D[:, 0])
+    # a query in the middle of a lattice edge: both ends at distance 0.25, the lower row first
+    D, I = O.flat_l2_search(g, np.array([[1.0, 1.0, 0.5]]), 2)
+    a, b = int(np.where((g == [1, 1, 0]).all(1))[0][0]), int(np.where((g == [1, 1, 1]).all(1))[0][0])
+    assert I[0].tolist() == [min(a, b), max(a, b)] and np.allclose(D[0], 0.25)
+    # the dataset rule (threedident_dataset.py:108-113): z~ snapping onto z's grid point takes its second neighbour
+    iz, izt = O.threedident_snap(g, g[[7]] + 0.01, g[[7]] + 0.02)
+    assert iz[0] == 7 and izt[0] != 7
