@@ -1152,19 +1152,6 @@ static size_t group_ws_layout(const GroupPlan& p, int n, const int32_t* N, const
 using namespace clica;
 using namespace clica::gemm;
 
-// side stream of the library (one process drives one GPU): created on first use, never destroyed
-struct SideStream { hipStream_t stream; hipEvent_t fork, join; bool ok, tried; };
-static SideStream g_side{};
-static bool side_stream_ready() {
-  if (!g_side.tried) {
-    g_side.tried = true;
-    g_side.ok = hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) == hipSuccess &&
-                hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) == hipSuccess &&
-                hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) == hipSuccess;
-  }
-  return g_side.ok;
-}
-
 extern "C" int clica_mlp_wgrad_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && N && K && M > 0 && n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_workspace_bytes: bad argument");
   for (int l = 0; l < n_layers; ++l) CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1, "clica_mlp_wgrad_workspace_bytes: layer %d: bad size", l);
@@ -1223,26 +1210,15 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
     R.M[l] = N[l]; R.N[l] = K[l]; R.lddw[l] = lddw[l];
   }
   G.n = ng; G.first[ng] = G.total = item; R.first[n_layers] = rblock;
-  bool tiny_forked = false;
   if (T.n > 0) {
     constexpr size_t tiny_lds = (size_t)(TINY_ROWS * TINY_MAX_LG + TINY_ROWS * TINY_MAX_S) * sizeof(float) + 1024;
     static bool once_t = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tiny_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiny_lds), true);
     (void)once_t;
-    // The tiny layers' launch is a few latency-bound workgroups (12 us alone): fork it onto a side stream so that it runs
-    // under the grouped GEMM launch instead of in front of it, and join before the slab reduction.  Event fork / join is
-    // legal under stream capture (it becomes two graph edges).  CLICA_WGRAD_TINY_SIDE=0: same stream, back to back.
-    static const bool side_on = [] { const char* e = getenv("CLICA_WGRAD_TINY_SIDE"); return !(e && atoi(e) == 0); }();
-    hipStream_t ts = st;
-    if (side_on && ng > 0 && side_stream_ready()) {
-      (void)hipEventRecord(g_side.fork, st);
-      (void)hipStreamWaitEvent(g_side.stream, g_side.fork, 0);
-      ts = g_side.stream;
-    }
-    hipLaunchKernelGGL(wgrad_tiny_k, dim3((unsigned)p.tiny_splits, (unsigned)T.n), dim3(TINY_THREADS), tiny_lds, ts, T);
+    // (forking this launch onto a side stream so that it runs UNDER the grouped launch instead of in front of it was measured:
+    //  the grouped kernel slows down by more than the 12 us the fork hides, 1329 vs 1334 steps/s -- not kept)
+    hipLaunchKernelGGL(wgrad_tiny_k, dim3((unsigned)p.tiny_splits, (unsigned)T.n), dim3(TINY_THREADS), tiny_lds, st, T);
     int rct = launch_status("clica_mlp_wgrad(tiny)");
-    if (ts != st) (void)hipEventRecord(g_side.join, ts);
-    if (rct) { if (ts != st) (void)hipStreamWaitEvent(st, g_side.join, 0); return rct; }
-    tiny_forked = ts != st;
+    if (rct) return rct;
   }
   if (ng > 0) {
     constexpr int WM = 2, WN = 4, STAGES = 3, THREADS = 64 * WM * WN;
@@ -1253,9 +1229,8 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
     (void)once;
     hipLaunchKernelGGL(k, dim3((unsigned)item), dim3(THREADS), lds, st, G);
     int rc = launch_status("clica_mlp_wgrad");
-    if (rc) { if (tiny_forked) (void)hipStreamWaitEvent(st, g_side.join, 0); return rc; }
+    if (rc) return rc;
   }
-  if (tiny_forked) (void)hipStreamWaitEvent(st, g_side.join, 0);
   hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)rblock), dim3(RED_THREADS), 0, st, R);
   return launch_status("clica_mlp_wgrad(reduce)");
 }
