@@ -81,6 +81,9 @@ __device__ __forceinline__ float4 load_b(const Layer& ly, int n, int k) {
 // of a lane group complete a full 128-byte line of each weight row (half-line requests would fetch
 // every L2 line twice: the 32 KB per-step working set of the 8 waves does not survive in L1).
 constexpr int KI = 32;
+#ifndef CLICA_FMLP_PINGPONG
+#define CLICA_FMLP_PINGPONG 1
+#endif
 // NC = number of 16-column blocks this wave owns in this layer (compile time: the MFMA stream must be
 // branch-free; NC is wave-uniform and selected by a scalar switch in the caller).
 // Measured with the -DCLICA_FMLP_TRACE build (tools/fmlp_trace.py, s_memtime per wave / layer / phase) on a 500 x 500 layer:
@@ -128,7 +131,7 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
       a[1][r] = *reinterpret_cast<const float4*>(&panel[(r * 16 + i15) * LDP + k0 + 16 + 4 * q]);
     }
   };
-  auto mma_and_rotate = [&]() {
+  [[maybe_unused]] auto mma_and_rotate = [&]() {
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
 #pragma unroll
@@ -169,6 +172,53 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
     fetch_b(bcur, 0);
   }
   fetch_a(acur, 0);
+#if CLICA_FMLP_PINGPONG
+  // Ping-pong form: the k-loop is unrolled by two with the roles of the two operand buffers swapped, so there is no
+  // register rotation at the end of an iteration (the rotation's moves made the compiler wait for ALL of the next
+  // iteration's loads, vmcnt(0) / lgkmcnt(0), a few MFMAs after issuing them: the whole L2 / LDS round trip was exposed
+  // in every iteration and only the SIMD's other wave covered it).  sched_group_barrier pins one weight load behind
+  // every sixth MFMA of the first half of the block and one panel read behind every 2 NC-th MFMA of the second half.
+  auto mma = [&](const float4 (&b)[2][CBW], const float4 (&a)[2][RB]) {
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float4 b4 = b[hlf][c];
+          const float bv = t == 0 ? b4.x : (t == 1 ? b4.y : (t == 2 ? b4.z : b4.w));
+#pragma unroll
+          for (int r = 0; r < RB; ++r) {
+            const float4 a4 = a[hlf][r];
+            const float av = t == 0 ? a4.x : (t == 1 ? a4.y : (t == 2 ? a4.z : a4.w));
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[r][c], 0, 0, 0);
+          }
+        }
+  };
+  auto pin = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2 * NC; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);      // 6 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * RB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NC, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+    }
+  };
+  auto kof = [&](int ki) { return (ki < kiters ? ki : kiters - 1) * KI; };
+  int ki = 0;
+  for (; ki + 1 < kiters; ki += 2) {
+    fetch_b(bnxt, kof(ki + 1)); fetch_a(anxt, kof(ki + 1));
+    mma(bcur, acur);
+    pin();
+    fetch_b(bcur, kof(ki + 2)); fetch_a(acur, kof(ki + 2));
+    mma(bnxt, anxt);
+    pin();
+  }
+  if (ki < kiters) mma(bcur, acur);
+#else
   // UNCONDITIONAL prefetch of the next iteration's operands (past the end: a harmless re-read of the last
   // iteration's own operands): with a conditional issue the compiler cannot count the loads in flight and
   // drains them all (s_waitcnt vmcnt(0)) in front of the MFMAs, which serialises fetch and math.
@@ -186,6 +236,7 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
     fetch_a(anxt, kn);
     mma_and_rotate();
   }
+#endif
 }
 
 // iteration-0 weight fragments of a layer, for every column block slot of this wave (slots beyond the layer's
@@ -246,6 +297,29 @@ __device__ __forceinline__ unsigned long long epilogue_to_panel(float* panel, co
     }
   }
   return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+
+#ifndef CLICA_FMLP_DEFER_STORE
+#define CLICA_FMLP_DEFER_STORE 1
+#endif
+// panel -> HBM copy of one layer's output by a subset of the workgroup's threads (tid in [0, nthreads))
+__device__ __forceinline__ void store_panel(const float* panel, const Layer& ly, int64_t row0, int nrows, int tid, int nthreads) {
+  const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
+  if (ovec) {
+    const int n4 = ly.N / 4;
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(ly.out + row0 * ly.ldo, 0, (int)(((int64_t)(nrows - 1) * ly.ldo + ly.N) * 4), kRsrcWord3);
+    for (int idx = tid; idx < nrows * n4; idx += nthreads) {
+      const int r = idx / n4, c4 = idx - r * n4;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&panel[r * LDP + 4 * c4]);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, (unsigned)((r * (int)ly.ldo + 4 * c4) * 4), 0, FP32_STORE_AUX);
+    }
+  } else {
+    for (int idx = tid; idx < nrows * ly.N; idx += nthreads) {
+      const int r = idx / ly.N, c = idx - r * ly.N;
+      ly.out[(row0 + r) * ly.ldo + c] = panel[r * LDP + c];
+    }
+  }
 }
 
 // PACKED: weights come in fragment order (g.packed); AUX: some backward link has no sign bits and re-reads its
@@ -358,6 +432,12 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     else { CLICA_FMLP_DISPATCH(false, false) }
 #undef CLICA_FMLP_DISPATCH
     FMLP_STAMP(l, 1);
+#if CLICA_FMLP_DEFER_STORE
+    // The HBM copy of the PREVIOUS layer's output (this layer's input panel, still intact until the barrier below) is
+    // issued here by the waves whose k-loop ends first: the two waves of a SIMD share its matrix pipe with age-priority
+    // arbitration, waves 0..3 leave the loop ~20 % earlier than waves 4..7 and would only wait at the barrier.
+    if (l > 0 && wave < WAVES / 2) store_panel(panel, g.layer[l - 1], row0, nrows, (wave * 64 + lane), 64 * (WAVES / 2));
+#endif
     __syncthreads();                                   // every wave is done reading the input panel
     FMLP_STAMP(l, 2);
 
@@ -413,6 +493,9 @@ __global__ __launch_bounds__(THREADS) void mlp_fwd_k(Args g) {
     __syncthreads();
     FMLP_STAMP(l, 4);
 
+#if CLICA_FMLP_DEFER_STORE
+    if (l + 1 < g.L) { FMLP_STAMP(l, 5); continue; }    // stored by the early waves at the end of the next layer's k-loop
+#endif
     // stream the new activations to HBM straight from the panel (coalesced rows)
     const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
     if (ovec) {
