@@ -195,19 +195,41 @@ __device__ __forceinline__ void layer_gemm(const Layer& ly, const float* __restr
           }
         }
   };
+#ifndef CLICA_FMLP_LOAD_GAP
+#define CLICA_FMLP_LOAD_GAP 6
+#endif
+#ifndef CLICA_FMLP_DS_GAP
+#define CLICA_FMLP_DS_GAP (2 * NC)
+#endif
+#ifndef CLICA_FMLP_DS_FIRST
+#define CLICA_FMLP_DS_FIRST 0
+#endif
   auto pin = [&]() {
+    if (CLICA_FMLP_DS_FIRST) {
 #pragma unroll
-    for (int i = 0; i < 2 * NC; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);      // 6 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+      for (int i = 0; i < 2 * RB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, CLICA_FMLP_DS_GAP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 2 * RB; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NC, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+    for (int i = 0; i < 2 * NC; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, CLICA_FMLP_LOAD_GAP, 0);      // MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+    }
+    if (!CLICA_FMLP_DS_FIRST) {
+#pragma unroll
+      for (int i = 0; i < 2 * RB; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, CLICA_FMLP_DS_GAP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+      }
     }
   };
   auto kof = [&](int ki) { return (ki < kiters ? ki : kiters - 1) * KI; };
+  // (Measured on this loop: the older wave of a SIMD wins the matrix-pipe arbitration, leaves the loop at ~70 k cycles of a
+  //  500 x 500 layer and the younger one follows at ~107 k.  Raising the younger wave's priority for the first 9/16 .. 13/16 of
+  //  its iterations makes both finish together -- 99 k / 105 k, 104 k / 101 k -- but the LAST wave still arrives at ~105 k:
+  //  the pair needs ~105 k cycles for 98.3 k of MFMA work however the pipe is shared; s_setprio not kept.)
   int ki = 0;
   for (; ki + 1 < kiters; ki += 2) {
     fetch_b(bnxt, kof(ki + 1)); fetch_a(anxt, kof(ki + 1));
