@@ -202,46 +202,13 @@ __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float
   for (int c = 0; c < JB; ++c) acc[c] = a2[c].x + a2[c].y;
 }
 
-// JB stream rows of an LDS tile held in registers (float4 pieces), and dist_group on them.  The forward sweep keeps TWO of
-// these (ping-pong): the rows of group g+1 are requested before group g's arithmetic starts, so the LDS round trip that
-// used to sit in front of every group (ten ds_read_b128 + s_waitcnt lgkmcnt(0) at the top of the loop) is paid once per tile.
-template <int NP>
-struct RowGroup {
-  float4 v[JB][NP / 4];
-  __device__ __forceinline__ void load(const float* tile, int jj) {
-#pragma unroll
-    for (int c = 0; c < JB; ++c)
-#pragma unroll
-      for (int k4 = 0; k4 < NP / 4; ++k4) v[c][k4] = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-  }
-};
-template <int NP, int PK, int NQ = NP / 2>
-__device__ __forceinline__ void dist_group_reg(const f32x2 (&o)[NP / 2], const RowGroup<NP>& g, const Params& q, float (&acc)[JB]) {
-  f32x2 a2[JB];
-#pragma unroll
-  for (int c = 0; c < JB; ++c) a2[c] = (f32x2){0.f, 0.f};
-#pragma unroll
-  for (int k4 = 0; k4 < NP / 4; ++k4) {
-#pragma unroll
-    for (int c = 0; c < JB; ++c) {
-      const float4 sv = g.v[c][k4];
-      if (2 * k4 < NQ) accum2<PK>(a2[c], o[2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
-      if (2 * k4 + 1 < NQ) accum2<PK>(a2[c], o[2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < JB; ++c) acc[c] = a2[c].x + a2[c].y;
-}
-// rows of a group in registers cost 2 JB NP / 4 float4s: affordable (3 waves per SIMD) up to the 16-wide layout
-constexpr bool fwd_pipelined(int np, bool rowgrad) { return np <= 16 && !rowgrad; }
-
 // ---- forward: per-split (max, sum) partials in the log2 domain -----------------------------
 // ROWGRAD: also accumulate G_k = sum_j 2^(x_ij - m) * p * droot * (1/p) d term / d owner_k with the same
 // running-max rescaling (the flash-attention forward with "V" = the pair's distance derivative).  After
 // the splits are merged, G / 2^(lse) is the softmax-weighted row gradient sum_j w_ij d neg_ij / d owner_i,
 // so the backward needs NO row pass: dz1 = pos-term + (-C_i / tau) * rowgrad_i for any upstream gradient.
 // register budget hints (minimum waves per SIMD the kernel should fit): the sweeps are latency-tolerant only with >= 3-4 waves
-constexpr int fwd_min_waves(int np, bool rowgrad) { return rowgrad ? (np <= 16 ? 3 : 2) : (np <= 24 ? 3 : 2); }
+constexpr int fwd_min_waves(int np, bool rowgrad) { return rowgrad ? (np <= 16 ? 3 : 2) : (np <= 16 ? 4 : (np <= 24 ? 3 : 2)); }
 constexpr int bwd_min_waves(int np) { return np <= 16 ? 3 : 2; }
 
 template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2>
@@ -285,37 +252,6 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
     if (more) st.load(str, lds, j0 + TS, (int)min((int64_t)TS, je - j0 - TS), q.n);   // in flight during the tile
     const float* tile = tiles[cur] + pq * RPP * NP;
     const int cq = min(RPP, max(0, cnt - pq * RPP));    // valid rows of this partition (ragged last tile only)
-    if constexpr (fwd_pipelined(NP, ROWGRAD)) {
-      auto process = [&](const RowGroup<NP>& grp, int jj) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          float acc[JB];
-          dist_group_reg<NP, PK, NQ>(o[r], grp, q, acc);
-          float x[JB];
-#pragma unroll
-          for (int c = 0; c < JB; ++c) {
-            x[c] = root_of<ROOT>(acc[c], q) * xk;
-            if (jj + c >= cq) x[c] = -INFINITY;
-          }
-          const float mn = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(m[r], -1e30f));
-          float add = 0.f;
-#pragma unroll
-          for (int c = 0; c < JB; ++c) add += fexp2(x[c] - mn);
-          s[r] = fmaf(s[r], fexp2(m[r] - mn), add);
-          m[r] = mn;
-        }
-      };
-      RowGroup<NP> g0, g1;
-      if (cq > 0) g0.load(tile, 0);
-      for (int jj = 0; jj < cq; jj += 2 * JB) {
-        g1.load(tile, min(jj + JB, RPP - JB));          // past the partition's end: a harmless re-read of its last group
-        process(g0, jj);
-        if (jj + JB < cq) {
-          g0.load(tile, min(jj + 2 * JB, RPP - JB));
-          process(g1, jj + JB);
-        }
-      }
-    } else
     for (int jj = 0; jj < cq; jj += JB) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
