@@ -28,7 +28,10 @@ constexpr int RB = ROWS / 16;
 constexpr int WAVES = 8;
 constexpr int THREADS = 64 * WAVES;
 constexpr int MAXW = 512;           // widest layer the panel holds
-constexpr int LDP = MAXW + 8;       // panel leading dimension: conflict-free ds_read_b128 of 16 rows x 4 k-groups
+#ifndef CLICA_FMLP_LDPAD
+#define CLICA_FMLP_LDPAD 8
+#endif
+constexpr int LDP = MAXW + CLICA_FMLP_LDPAD;       // panel leading dimension: conflict-free ds_read_b128 of 16 rows x 4 k-groups
 constexpr int CBW = MAXW / 16 / WAVES;   // column blocks per wave (4)
 constexpr int MAXL = 8;
 #ifndef FP32_STORE_AUX

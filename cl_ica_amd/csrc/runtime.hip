@@ -32,3 +32,19 @@ extern "C" int clica_tick(int32_t* counter, clica_stream_t stream) {
   hipLaunchKernelGGL(clica::tick_k, dim3(1), dim3(1), 0, clica::as_stream(stream), counter);
   return clica::launch_status("clica_tick");
 }
+
+// After a failed stream capture (e.g. a collective backend that cannot be captured) the stream may still be in capture
+// mode and the runtime's per-thread "last error" holds the capture error, which the next launch_status() would report for
+// an innocent kernel.  Ends the capture if one is active on `stream`, waits for the device and clears the error state.
+extern "C" int clica_abort_capture(clica_stream_t stream) {
+  hipStream_t s = clica::as_stream(stream);
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(s, &g);       // returns the invalidation error; the stream leaves capture mode
+    if (g) (void)hipGraphDestroy(g);
+  }
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 8 && hipGetLastError() != hipSuccess; ++i) {}
+  return CLICA_OK;
+}

@@ -92,6 +92,11 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tools/dp_bench_smoke.sh: the multi-rank control flow of bench.py on a ONE-GPU box): every rank on cuda:0,
+    # collectives over gloo
+    if os.environ.get("CLICA_SHARE_DEVICE") == "1":
+        local = 0
+    backend = backend or os.environ.get("CLICA_DIST_BACKEND") or None
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
@@ -101,5 +106,5 @@ def init_from_env(backend: Optional[str] = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend or ("nccl" if device.type == "cuda" else "gloo"), rank=rank, world_size=world,
-                                device_id=device if device.type == "cuda" else None)
+                                device_id=device if (device.type == "cuda" and (backend or "nccl") == "nccl") else None)
     return rank, world, device

@@ -49,6 +49,18 @@ class SamplerSpec:
     seed: int = 0
 
 
+def _abort_capture(graph, stream, others=()) -> None:
+    """Leave stream-capture mode after a failed capture, whatever state torch's CUDAGraph object is in (clica_abort_capture
+    runs inside the HIP runtime instance torch and the kernels share; a ctypes handle to libamdhip64 may be another copy)."""
+    try:
+        graph.capture_end()
+    except Exception:
+        pass
+    lib = _lib.load()
+    for st in (stream,) + tuple(o for o in others if o is not None):       # the origin stream first, then forked side streams
+        lib.clica_abort_capture(C.c_void_p(st.cuda_stream))
+
+
 class ContrastiveTrainer:
     def __init__(self, f: nn.Sequential, g_weights: torch.Tensor, sampler: SamplerSpec, batch_size: int,
                  p: float = 2, tau: float = 1.0, alpha: float = 0.5, lr: float = 1e-4, g_slope: float = 0.2,
@@ -504,8 +516,26 @@ class ContrastiveTrainer:
         # with collectives in the step, other threads (the process group's watchdog) may legitimately touch the HIP runtime
         # during capture: "thread_local" keeps their calls from invalidating it
         mode = "thread_local" if (self.dp or self.force_collectives) else "global"
-        with torch.cuda.graph(graph, capture_error_mode=mode):
-            self._step_body(True)
+        # Explicit begin / end instead of the `torch.cuda.graph` context manager: when the body fails (a collective backend that
+        # cannot be captured), that manager raises from capture_end() inside its __exit__ and never restores the stream -- the
+        # process is left on a stream that is still capturing and every later CUDA call fails.  Here a failed capture is always
+        # terminated (through the HIP runtime if torch refuses), the stream context is always left, and the caller gets the
+        # original exception with the device in a usable state (bench.py / train_mlp then run eager launches).
+        cap = torch.cuda.Stream(device=self.device)
+        cap.wait_stream(torch.cuda.current_stream(self.device))
+        try:
+            with torch.cuda.stream(cap):
+                graph.capture_begin(capture_error_mode=mode)
+                try:
+                    self._step_body(True)
+                    graph.capture_end()
+                except BaseException:
+                    _abort_capture(graph, cap, (self.side_stream,))
+                    if self.side_stream is not None:      # a forked stream cannot be taken out of an invalidated capture: drop it
+                        self.side_stream = torch.cuda.Stream(device=self.device)
+                    raise
+        finally:
+            torch.cuda.current_stream(self.device).wait_stream(cap)
         self.graph = graph
         return graph
 

@@ -40,6 +40,10 @@ const char* clica_last_error(void);
 /* The library reads its tuning switches (CLICA_GEMM_CFG_*, CLICA_SKINNY) from the environment once, at the first launch;
  * call this after changing them inside a running process (tests, tuning sweeps). */
 int clica_reload_env(void);
+/* After a FAILED stream capture on `stream` (e.g. a collective that cannot be captured): end the capture if the stream is
+ * still capturing, wait for the device and clear the runtime's pending error, so that later launches report their own
+ * status.  Harmless when nothing failed. */
+int clica_abort_capture(clica_stream_t stream);
 int clica_version(void);
 
 /* ------------------------------------------------------------------------------------

@@ -155,3 +155,19 @@ def test_dp_code_path_single_rank():
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_failed_capture_leaves_the_engine_usable():
+    """capture() of a step whose collectives cannot be captured (gloo on device tensors) must raise and leave the process able
+    to run the same steps eagerly (bench.py / train_mlp fall back to eager launches when a RCCL build refuses capture).
+    Runs in a subprocess: a failed capture must not leak into this session either way."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "failed_capture_worker.py")
+    r = subprocess.run([sys.executable, worker, str(port)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FAILED_CAPTURE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "capture failed as expected" in r.stdout
