@@ -632,7 +632,7 @@ struct Plan {
   int64_t tiles;  // owner tiles (32 R owners each)
   int nsplit, chunk;
 };
-inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
+inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd, int resident = 0) {
   Plan P;
   P.np = pad_dim(n);
   if (P.np > 64) {          // wide rows: 16 owners per workgroup, about four workgroups per CU, splits in whole LDS tiles
@@ -651,11 +651,9 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
   P.R = bwd ? owners_bwd(P.np) : owners_fwd(P.np);
   P.tiles = ceil_div(n_own, (int64_t)HALF * P.R);
   const int64_t TS = tile_rows(P.np);
-  // HBM-level stream splits.  A workgroup already cuts its chunk eight ways on chip, so only enough splits are needed to
-  // give every CU a few whole workgroups: all workgroups of a launch are resident at once and the loop is VALU-bound, so the
-  // launch lasts as long as its most loaded CU, ceil(workgroups / 256) x (rows per split + a fixed prologue / merge cost).
-  // Splits are whole LDS tiles; 2..6 workgroups per CU (8..24 waves).  E.g. B = B3 = 6144, n = 10: 96 tiles x 8 splits of
-  // 768 rows = exactly 3 per CU; the 8-rank pool (B3 = 49 152): 96 x 8 splits of 6144 rows.
+  // HBM-level stream splits.  A workgroup already cuts its chunk eight ways on chip, so HBM-level splits only exist to fill
+  // the chip (cost model below).  Splits are whole LDS tiles.  E.g. B = B3 = 6144, n = 10: 96 tiles x 8 splits of 768 rows
+  // = exactly 3 workgroups per CU; the 8-rank pool (B3 = 49 152): 96 x 24 splits of 2048 rows = three rounds of that.
   // CLICA_LP_WG_PER_CU[_FWD] = <k> forces "about k per CU" instead (tuning; read once).
   static const int env_b = [] { const char* e = getenv("CLICA_LP_WG_PER_CU"); return e ? atoi(e) : 0; }();
   static const int env_f = [] { const char* e = getenv("CLICA_LP_WG_PER_CU_FWD"); return e ? atoi(e) : 0; }();
@@ -670,17 +668,40 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd) {
     P.nsplit = (int)(n_str > 0 ? ceil_div(n_str, chunk) : 1);
   };
   if (env > 0) { finish(ceil_div((int64_t)kNumCU * env, P.tiles)); return P; }
+  // Cost model (fitted to tools/loss_train_probe.py sweeps, B = 6144, pools of 6144 and 49 152 rows, n = 10 and n = 40):
+  // a CU holds RES workgroups at a time (register-limited: 3 waves per SIMD up to the 16-wide layout, 2 above), which share
+  // it, so a "round" of RES workgroups per CU lasts RES x (rows per split + a fixed prologue / merge cost of ~192 rows'
+  // worth).  Workgroups do not leave a round together -- the CU runs under-occupied while the stragglers finish -- which
+  // costs about a quarter of a round per launch however many rounds there are: more, shorter rounds amortise it (pool of
+  // 49 152 rows: 24 splits of 2048 rows instead of 8 of 6144 is 7 % / 5 % faster forward / backward), until the fixed
+  // cost per workgroup wins (pool of 6144 rows: 8 splits of 768 stay best).
   double best = 1e300; int64_t best_ns = 1;
-  const int64_t lo = ceil_div((int64_t)kNumCU * 2, P.tiles), hi = ceil_div((int64_t)kNumCU * 6, P.tiles);
+  if (resident < 0) {
+    // one-round model (the nearest-neighbour sweep, nn_search.hip: few query tiles, a very long stream): every workgroup of
+    // the launch is taken as resident, 2..6 per CU, the launch lasts as long as its most loaded CU
+    const int64_t lo1 = ceil_div((int64_t)kNumCU * 2, P.tiles), hi1 = ceil_div((int64_t)kNumCU * 6, P.tiles);
+    const int64_t h1 = hi1 > max_split ? max_split : (hi1 < 1 ? 1 : hi1);
+    const int64_t l1 = lo1 < 1 ? 1 : (lo1 > h1 ? h1 : lo1);
+    for (int64_t ns = l1; ns <= h1; ++ns) {
+      const int64_t chunk = ceil_div(ceil_div(n_str, ns), TS) * TS;
+      const int64_t nsp = ceil_div(n_str, chunk);
+      const int64_t rounds = ceil_div(P.tiles * nsp, (int64_t)kNumCU);
+      const double cost = (double)rounds * (double)(chunk + 192) * (1.0 + 0.03 * (rounds < 3 ? 3 - rounds : 0)) + 4.0 * (double)nsp;
+      if (cost < best - 1e-9) { best = cost; best_ns = nsp; }
+    }
+    finish(best_ns);
+    return P;
+  }
+  const int64_t RES = resident > 0 ? resident : (P.np <= 16 ? 3 : 2);
+  const int64_t slots = (int64_t)kNumCU * RES;
+  const int64_t lo = ceil_div(slots, P.tiles), hi = ceil_div(slots * 6, P.tiles);
   const int64_t ns_hi = hi > max_split ? max_split : (hi < 1 ? 1 : hi);
   const int64_t ns_lo = lo < 1 ? 1 : (lo > ns_hi ? ns_hi : lo);        // short streams: as many splits as there are tiles of rows
   for (int64_t ns = ns_lo; ns <= ns_hi; ++ns) {
     const int64_t chunk = ceil_div(ceil_div(n_str, ns), TS) * TS;
     const int64_t nsp = ceil_div(n_str, chunk);
-    const int64_t rounds = ceil_div(P.tiles * nsp, (int64_t)kNumCU);
-    // per-workgroup fixed cost (owner load, first tile, on-chip merge, partial store) ~ 192 stream rows' worth; a mild
-    // penalty below 3 workgroups per CU (fewer than 12 waves leave LDS-broadcast and exp latency exposed)
-    const double cost = (double)rounds * (double)(chunk + 192) * (1.0 + 0.03 * (rounds < 3 ? 3 - rounds : 0)) + 4.0 * (double)nsp;
+    const int64_t rounds = ceil_div(P.tiles * nsp, slots);
+    const double cost = ((double)rounds + 0.25) * (double)RES * (double)(chunk + 192) + 4.0 * (double)nsp;
     if (cost < best - 1e-9) { best = cost; best_ns = nsp; }
   }
   finish(best_ns);

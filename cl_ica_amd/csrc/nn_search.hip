@@ -159,6 +159,7 @@ static void launch(const Plan& P, const float* qry, int64_t ldq, int64_t n_q, co
 }
 
 constexpr int kMaxK = 4;
+constexpr int kResident = -1;       // planner: the one-round model (measured better here than the loss sweeps' multi-round model)
 static int kcap(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : 4); }
 }  // namespace nn
 }  // namespace clica
@@ -168,7 +169,7 @@ using namespace clica;
 extern "C" int clica_nn_search_workspace_bytes(int64_t n_query, int64_t n_table, int32_t n, int32_t k, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && n_query > 0 && n_table > 0 && n >= 1 && n <= 64 && k >= 1 && k <= nn::kMaxK,
                   "clica_nn_search_workspace_bytes: need n_query, n_table > 0, 1 <= n <= 64, 1 <= k <= %d", nn::kMaxK);
-  const lp::Plan P = lp::make_plan(n_query, n_table, n, false);
+  const lp::Plan P = lp::make_plan(n_query, n_table, n, false, nn::kResident);
   *bytes = align_up((size_t)P.nsplit * n_query * nn::kcap(k) * sizeof(nn::Cand), 256);
   return CLICA_OK;
 }
@@ -183,7 +184,7 @@ extern "C" int clica_nn_search(const float* table, int64_t ldt, int64_t n_table,
   size_t need = 0;
   clica_nn_search_workspace_bytes(n_query, n_table, n, k, &need);
   if (need > workspace_bytes) { set_error("clica_nn_search: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
-  const lp::Plan P = lp::make_plan(n_query, n_table, n, false);
+  const lp::Plan P = lp::make_plan(n_query, n_table, n, false, nn::kResident);
   lp::Params q;
   q.p = 2.f; q.inv_p = 0.5f; q.kscale = 1.f; q.sgn = 1.f; q.eps = 0.f; q.xs = -1.f; q.pow = 1; q.n = n;
   hipStream_t st = as_stream(stream);
