@@ -494,6 +494,7 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
   const int64_t m0 = (int64_t)by * BM, n0 = (int64_t)bx * BN;
   const int64_t kbeg = (int64_t)bz * g.k_per_split, kend = min(g.Kc, kbeg + g.k_per_split);
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
+  WG_STAMP(0);
   f32x16 acc[NBM][NBN];
 #pragma unroll
   for (int i = 0; i < NBM; ++i)
@@ -564,11 +565,14 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
       for (int t = 0; t < 4; ++t) bf[buf][j][t] = b_s[(8 * s + 4 * h + t) * BN + wn * TN + j * 32 + l31];
   };
   if (ntiles > 0) load_frags(0, smem, 0);
+  WG_STAMP(1);
   for (int t = 0; t < ntiles; ++t) {
     const float* st_c = smem + (t % STG) * STAGE;
     const float* st_n = smem + ((t + 1) % STG) * STAGE;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
+      if (t == 20 && s == 0) WG_STAMP(4);
+      if (t == 20 && s == 1) WG_STAMP(7);
       if (s + 1 < KSTEPS) load_frags((s + 1) & 1, st_c, s + 1);
       else if (t + 1 < ntiles) load_frags(0, st_n, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -581,14 +585,17 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][i][tt], bf[s & 1][j][tt], acc[i][j], 0, 0, 0);
       if (s == 0) {
         __builtin_amdgcn_sched_barrier(0);
+        if (t == 20) WG_STAMP(5);
         // tile t+1 must be complete (read from the last k-step of this iteration on): it is the only one in flight here
         wait_vm<0>();
         __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 3
+        if (t == 20) WG_STAMP(6);
         if (t + 2 < ntiles) issue(t + 2);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+  WG_STAMP(2);
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
 #pragma unroll
   for (int i = 0; i < NBM; ++i) {
@@ -607,6 +614,7 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
       }
     }
   }
+  WG_STAMP(3);
 }
 constexpr size_t kBody2LdsBytes = (size_t)3 * BK * (256 + 128) * sizeof(float);
 

@@ -34,7 +34,7 @@ t0 = t[:, :, 0].min()
 start = t[:, :, 0].min(1) - t0
 pro, loop, epi = t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2]
 end = t[:, :, 3].max(1) - t0
-print(f"median cycles per wave: prologue {np.median(pro):.0f}  k-loop {np.median(loop):.0f}  epilogue {np.median(epi):.0f}   (ideal k-loop: 43 tiles x 4096 = 176128)")
+print(f"median cycles per wave: prologue {np.median(pro):.0f}  k-loop {np.median(loop):.0f}  epilogue {np.median(epi):.0f}   (ideal k-loop of a 256 x 128 item: 43 tiles x 8192 = 352256 per SIMD pair of waves, i.e. 4096 MFMA cycles per wave and tile)")
 print(f"k-loop by wave id (median): {np.round(np.median(loop, 0)).astype(int).tolist()}")
 order = np.argsort(start)
 print("item start times (cycles, sorted): first round", np.round(np.percentile(start, [0, 25, 49]), 0).tolist(), " second round", np.round(np.percentile(start, [51, 75, 100]), 0).tolist())
