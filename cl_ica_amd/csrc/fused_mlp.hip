@@ -25,14 +25,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int ROWS = 48;            // rows per workgroup = 3 MFMA row blocks
 constexpr int RB = ROWS / 16;
-constexpr int WAVES = 8;
+#ifndef CLICA_FMLP_WAVES
+#define CLICA_FMLP_WAVES 8
+#endif
+constexpr int WAVES = CLICA_FMLP_WAVES;
 constexpr int THREADS = 64 * WAVES;
 constexpr int MAXW = 512;           // widest layer the panel holds
 #ifndef CLICA_FMLP_LDPAD
 #define CLICA_FMLP_LDPAD 8
 #endif
 constexpr int LDP = MAXW + CLICA_FMLP_LDPAD;       // panel leading dimension: conflict-free ds_read_b128 of 16 rows x 4 k-groups
-constexpr int CBW = MAXW / 16 / WAVES;   // column blocks per wave (4)
+constexpr int CBW = (MAXW / 16 + WAVES - 1) / WAVES;   // column blocks per wave (4)
 constexpr int MAXL = 8;
 #ifndef FP32_STORE_AUX
 #define FP32_STORE_AUX 2      // activation stores of the fp32 kernel: 2 = streaming (nt)
