@@ -482,6 +482,9 @@ extern "C" int clica_debug_wgrad_trace(unsigned long long* buf) {
 // t + 2 are issued behind the barrier of iteration t (their stage was read in iteration t - 1) and first waited for in t + 1.
 // DMA piece layout: the wide operand's k-row is 256 floats = one 1 KB piece (lane l -> columns 4 l .. 4 l + 3); the narrow
 // operand's piece is two k-rows of 128 floats (lanes 32..63 = the second row), as in wgrad_dma_body.
+#ifndef CLICA_WGRAD_STAGGER
+#define CLICA_WGRAD_STAGGER 1
+#endif
 template <bool A_WIDE>
 __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, const int by, const int bz) {
   constexpr int BM = A_WIDE ? 256 : 128, BN = A_WIDE ? 128 : 256;
@@ -590,9 +593,24 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
         wait_vm<0>();
         __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 3
         if (t == 20) WG_STAMP(6);
+#if CLICA_WGRAD_STAGGER
+        if (wave < 4 && t + 2 < ntiles) issue(t + 2);
+#else
         if (t + 2 < ntiles) issue(t + 2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
+#if CLICA_WGRAD_STAGGER
+      // The six DMA requests of a wave take 1600-2000 cycles to issue (tools/wgrad_trace.py: the texture path moves 48 KB per
+      // tile and a wave issues in order), and right behind the barrier BOTH waves of every SIMD were in that phase together:
+      // the matrix pipe idled for ~15 % of every tile.  Waves 0..3 still issue there; waves 4..7 (the other wave of each
+      // SIMD) run k-step 1 first and issue afterwards, so one wave per SIMD always has MFMAs to issue.
+      if (s == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (wave >= 4 && t + 2 < ntiles) issue(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
   }
   WG_STAMP(2);

@@ -38,7 +38,7 @@ print(f"median cycles per wave: prologue {np.median(pro):.0f}  k-loop {np.median
 print(f"k-loop by wave id (median): {np.round(np.median(loop, 0)).astype(int).tolist()}")
 order = np.argsort(start)
 print("item start times (cycles, sorted): first round", np.round(np.percentile(start, [0, 25, 49]), 0).tolist(), " second round", np.round(np.percentile(start, [51, 75, 100]), 0).tolist())
-print(f"kernel span: {end.max():.0f} cycles; last first-round end {np.sort(end)[255]:.0f}")
+print(f"kernel span: {end.max():.0f} cycles; last first-round end {np.sort(end)[min(255, len(end) - 1)]:.0f}")
 # one tile in detail (t = 20): stamp4 = tile start, 5 = k-step 0's MFMAs issued, 6 = past wait + barrier, 7 = k-step 1 start (DMA issued)
 fine = t[:, :, 5:8] - t[:, :, 4:5]
 print("tile 20, cycles since its start (median by wave id):")
