@@ -485,6 +485,9 @@ extern "C" int clica_debug_wgrad_trace(unsigned long long* buf) {
 #ifndef CLICA_WGRAD_STAGGER
 #define CLICA_WGRAD_STAGGER 1
 #endif
+#ifndef CLICA_WGRAD_ABLATE      // timing ablations (WRONG results): 1 no DMA in the loop, 2 no barrier, 4 no fragment reads
+#define CLICA_WGRAD_ABLATE 0
+#endif
 template <bool A_WIDE>
 __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, const int by, const int bz) {
   constexpr int BM = A_WIDE ? 256 : 128, BN = A_WIDE ? 128 : 256;
@@ -576,8 +579,10 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
     for (int s = 0; s < KSTEPS; ++s) {
       if (t == 20 && s == 0) WG_STAMP(4);
       if (t == 20 && s == 1) WG_STAMP(7);
+#if !(CLICA_WGRAD_ABLATE & 4)
       if (s + 1 < KSTEPS) load_frags((s + 1) & 1, st_c, s + 1);
       else if (t + 1 < ntiles) load_frags(0, st_n, 0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
@@ -590,10 +595,15 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
         __builtin_amdgcn_sched_barrier(0);
         if (t == 20) WG_STAMP(5);
         // tile t+1 must be complete (read from the last k-step of this iteration on): it is the only one in flight here
+#if !(CLICA_WGRAD_ABLATE & 1)
         wait_vm<0>();
+#endif
+#if !(CLICA_WGRAD_ABLATE & 2)
         __syncthreads();            // ... for every wave; and every wave is done with stage (t-1) % 3
+#endif
         if (t == 20) WG_STAMP(6);
-#if CLICA_WGRAD_STAGGER
+#if CLICA_WGRAD_ABLATE & 1
+#elif CLICA_WGRAD_STAGGER
         if (wave < 4 && t + 2 < ntiles) issue(t + 2);
 #else
         if (t + 2 < ntiles) issue(t + 2);
@@ -607,7 +617,9 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
       // SIMD) run k-step 1 first and issue afterwards, so one wave per SIMD always has MFMAs to issue.
       if (s == 1) {
         __builtin_amdgcn_sched_barrier(0);
+#if !(CLICA_WGRAD_ABLATE & 1)
         if (wave >= 4 && t + 2 < ntiles) issue(t + 2);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
 #endif
