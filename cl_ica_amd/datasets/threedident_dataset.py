@@ -73,6 +73,8 @@ class ThreeDIdentLatentPairs:
         self.unfiltered_latents = latents
         if latent_dimensions_to_use is not None:
             latents = np.ascontiguousarray(latents[:, list(latent_dimensions_to_use)])
+        if latents.ndim != 2 or latents.shape[0] < 2:
+            raise ValueError("ThreeDIdentLatentPairs needs a table of at least two latents (z and z~ are snapped to DIFFERENT rows)")
         if latents.shape[1] != latent_space.dim:
             raise AssertionError(f"Shapes do not match, i.e. {latent_space.dim} vs. {latents.shape}")   # as :50-52
         self.latent_space = latent_space
