@@ -10,8 +10,8 @@
 //     the backward needs the saved activations;
 //   * weights are the B operand.  A wave owns whole 16-column blocks of the output, so a B fragment is
 //     private to the wave: it is loaded global -> VGPR directly (16 B per lane, L2-resident: every CU
-//     streams the same <= 1 MB matrix), prefetched one 16-deep k-step ahead; no LDS staging, no barrier in
-//     the k-loop;
+//     streams the same <= 1 MB matrix) in fragment order, requested one 32-deep k-iteration ahead into the other of two
+//     register buffers (ping-pong, see layer_gemm); no LDS staging, no barrier in the k-loop;
 //   * math: v_mfma_f32_16x16x4_f32 (exact fp32, same as the tiled GEMMs), 3 row blocks x <= 4 column
 //     blocks per wave, k-permuted so one 16-byte read feeds four MFMAs on both operands.
 // One launch replaces seven; the panel never round-trips through HBM between layers.
