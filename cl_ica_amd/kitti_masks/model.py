@@ -21,9 +21,11 @@ __all__ = ["BetaVAE_H", "View", "kaiming_init"]
 
 
 class View(nn.Module):
+    """Reshape stage between the conv stack and the Linear (a module so that the Sequential indices match the reference's)."""
+
     def __init__(self, size):
         super().__init__()
-        self.size = size
+        self.size = tuple(size)
 
     def forward(self, tensor):
         return tensor.view(self.size)
@@ -36,39 +38,35 @@ class _HipLinear(nn.Linear):
         return _MLPStackFn.apply(x.contiguous(), 0.0, self.weight, self.bias)
 
 
+# (out_channels, kernel, stride, padding) of the five conv stages, model.py:42-51; spatial size 64 -> 32 -> 16 -> 8 -> 4 -> 1
+_CONV_STAGES = ((32, 4, 2, 1), (32, 4, 2, 1), (64, 4, 2, 1), (64, 4, 2, 1), (256, 4, 1, 0))
+
+
 class BetaVAE_H(nn.Module):
     """Encoder half of the beta-VAE architecture (Higgins et al., ICLR 2017) used as contrastive encoder."""
 
     def __init__(self, z_dim=10, nc=3, box_norm=False):
         super().__init__()
-        self.z_dim = z_dim
-        self.nc = nc
-        if box_norm:
-            non_periodic_rescale_layer = layers.SoftclipLayer(n=z_dim, init_abs_bound=1.0, fixed_abs_bound=False)
-        else:
-            non_periodic_rescale_layer = layers.Lambda(_identity)
-        self.encoder = nn.Sequential(
-            nn.Conv2d(nc, 32, 4, 2, 1), nn.ReLU(True),        # B,  32, 32, 32
-            nn.Conv2d(32, 32, 4, 2, 1), nn.ReLU(True),        # B,  32, 16, 16
-            nn.Conv2d(32, 64, 4, 2, 1), nn.ReLU(True),        # B,  64,  8,  8
-            nn.Conv2d(64, 64, 4, 2, 1), nn.ReLU(True),        # B,  64,  4,  4
-            nn.Conv2d(64, 256, 4, 1), nn.ReLU(True),          # B, 256,  1,  1
-            View((-1, 256 * 1 * 1)),                          # B, 256
-            _HipLinear(256, z_dim),                           # B, z_dim        (HIP)
-            non_periodic_rescale_layer,                       # identity | learnable Softclip (HIP)
-        )
+        self.z_dim, self.nc = z_dim, nc
+        stages, width = [], nc
+        for out_ch, kernel, stride, pad in _CONV_STAGES:          # indices 0..9: Conv2d, ReLU alternating (MIOpen)
+            stages += [nn.Conv2d(width, out_ch, kernel, stride, pad), nn.ReLU(True)]
+            width = out_ch
+        head = layers.SoftclipLayer(n=z_dim, init_abs_bound=1.0, fixed_abs_bound=False) if box_norm else layers.Lambda(_identity)
+        # index 10: (B, 256, 1, 1) -> (B, 256); 11: Linear on the HIP GEMMs; 12: identity | learnable Softclip (HIP)
+        self.encoder = nn.Sequential(*stages, View((-1, width)), _HipLinear(width, z_dim), head)
         self.weight_init()
 
     def weight_init(self):
-        for block in self._modules:
-            for m in self._modules[block]:
-                kaiming_init(m)
-
-    def forward(self, x, return_z=False):
-        return self._encode(x)
+        # module order = the reference's loop over self._modules blocks (:76-79): same RNG consumption, same initial weights
+        for m in self.encoder:
+            kaiming_init(m)
 
     def _encode(self, x):
         return self.encoder(x)
+
+    def forward(self, x, return_z=False):
+        return self._encode(x)
 
 
 def _identity(x):
@@ -76,11 +74,12 @@ def _identity(x):
 
 
 def kaiming_init(m):
-    if isinstance(m, (nn.Linear, nn.Conv2d)):
+    """model.py:102-110: Kaiming-normal weights and zero biases for Linear / Conv2d, unit scale for batch norms."""
+    if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+        nn.init.ones_(m.weight)
+    elif isinstance(m, (nn.Linear, nn.Conv2d)):
         nn.init.kaiming_normal_(m.weight)
-        if m.bias is not None:
-            m.bias.data.fill_(0)
-    elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
-        m.weight.data.fill_(1)
-        if m.bias is not None:
-            m.bias.data.fill_(0)
+    else:
+        return
+    if m.bias is not None:
+        nn.init.zeros_(m.bias)
