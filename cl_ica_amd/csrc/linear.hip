@@ -513,6 +513,10 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
   // k-rows 4 wave + 2 j + h (j = 0, 1), columns 4 l31 ...  Lanes whose columns are out of range sit on the zero page (stride 0);
   // the B lane whose first column is exactly N sits on {1, 0, 0, 0}: the matrix cores return db = dZ^T 1 in that padding column.
   const bool ones_col = g.dbias_slab && (g.N % BN != 0);
+  // no padding column to carry the ones (the layer's input width is a multiple of the tile: 128, 256, 512 ...): the first
+  // column tile sums dZ's columns from the staged A tile instead, one output feature per thread
+  const bool need_colsum = g.dbias_slab && !ones_col && bx == 0 && (int)threadIdx.x < BM;
+  float colsum = 0.f;
   const float* wide = A_WIDE ? g.A : g.B; const int64_t ldw = A_WIDE ? g.lda : g.ldb;
   const float* narr = A_WIDE ? g.B : g.A; const int64_t ldn = A_WIDE ? g.ldb : g.lda;
   const int64_t w0 = (A_WIDE ? m0 : n0) + 4 * lane, wlim = A_WIDE ? g.M : g.N;
@@ -624,6 +628,10 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
       }
 #endif
     }
+    if (need_colsum) {
+#pragma unroll 8
+      for (int k = 0; k < BK; ++k) colsum += st_c[k * BM + threadIdx.x];      // rows past kend were staged as zeros
+    }
   }
   WG_STAMP(2);
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
@@ -643,6 +651,10 @@ __device__ __forceinline__ void wgrad_dma_body2(const Args& g, const int bx, con
         dst[row * ld] = acc[i][j][r];
       }
     }
+  }
+  if (need_colsum) {
+    const int64_t row = m0 + threadIdx.x;
+    if (row < g.M) g.dbias_slab[(int64_t)bz * g.M + row] = colsum;
   }
   WG_STAMP(3);
 }

@@ -293,3 +293,34 @@ def test_uniformity_alignment_vs_golden(golden, gname):
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "loss_i", per.detach().cpu().numpy(), a["out"]["loss_i"])
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz1", z1.grad.cpu().numpy(), a["out"]["dz1"])
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz2", z2.grad.cpu().numpy(), a["out"]["dz2"])
+
+
+def test_lp_loss_seeded_sweep_vs_oracle():
+    """Forty seeded random shapes / parameters around the kernels' internal boundaries (owner tiles of 64, LDS tiles of 128
+    rows, on-chip partitions of 16 rows, the planner's split lengths, the 64-coordinate switch to the wide-row kernels)
+    against the fp64 oracle: loss_i and all three embedding gradients at 1e-5 of the un-cancelled summands."""
+    from cl_ica_amd.losses import LpSimCLRLoss
+    rng = np.random.default_rng(2024)
+    edges_b = [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 200, 511, 640]
+    edges_b3 = [1, 15, 16, 17, 127, 128, 129, 255, 257, 1000, 1023, 1025, 1537]
+    dims = [1, 2, 3, 4, 5, 9, 10, 11, 12, 13, 16, 17, 24, 33, 40, 41, 64, 65, 70, 129]
+    for case in range(40):
+        B, B3, n = int(rng.choice(edges_b)), int(rng.choice(edges_b3)), int(rng.choice(dims))
+        p = float(rng.choice([1.0, 2.0, 3.0, 1.5, 2.5]))
+        tau, alpha = float(rng.choice([0.5, 1.0, 2.0])), float(rng.choice([0.5, 0.3, 0.8]))
+        compat, pw = bool(rng.integers(2)), bool(rng.integers(2))
+        scale = 0.7 / np.sqrt(n)                       # summed distances stay O(1): unsaturated rows
+        z1 = (rng.normal(size=(B, n)) * scale).astype(np.float32)
+        z2 = (z1 + 0.1 * scale * rng.normal(size=(B, n))).astype(np.float32)
+        z3 = (rng.normal(size=(B3, n)) * scale).astype(np.float32)
+        L = LpSimCLRLoss(p=int(p) if p == int(p) else p, tau=tau, alpha=alpha, simclr_compatibility_mode=compat, pow=pw)
+        out = run_hip(L, z1, z2, z3)
+        orc = O.lp_simclr_loss(z1, z2, z3, p=p, tau=tau, alpha=alpha, compat=compat, pow=pw)
+        lf, gf = summand_floors(orc, alpha, tau, grad_scale(z1, z2, p, tau, alpha))
+        if not pw:        # pow=False: d|x|/dx of the root at a near-zero positive pair is O(1) whatever p is
+            gf = max(gf, 2 * alpha / (B * tau))
+        case_id = f"#{case} B={B} B3={B3} n={n} p={p:g} tau={tau:g} alpha={alpha:g} compat={int(compat)} pow={int(pw)}"
+        PARITY.check("lp_sweep_vs_oracle", case_id, "loss_i", out["loss_i"], orc["loss_i"], floor=lf)
+        PARITY.check("lp_sweep_vs_oracle", case_id, "loss_mean", out["loss_mean"], float(orc["loss_mean"]), floor=lf)
+        for g in ("dz1", "dz2", "dz3"):
+            PARITY.check("lp_sweep_vs_oracle", case_id, g, out[g], orc[g], floor=gf if g != "dz3" else float(np.abs(orc["dz3"]).max()))

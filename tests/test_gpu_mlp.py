@@ -279,7 +279,9 @@ def test_fused_signmask_path_is_bit_identical(dims, M):
 
 
 @pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
-                                      ([16, 16, 16], 47), ([3, 300], 5000), ([10, 256, 10], 3001), ([1, 8, 1], 129), ([13, 100, 16, 100], 6144)])
+                                      ([16, 16, 16], 47), ([3, 300], 5000), ([10, 256, 10], 3001), ([1, 8, 1], 129), ([13, 100, 16, 100], 6144),
+                                      # input widths that are whole tiles (no padding column for the bias gradient's ones)
+                                      ([512, 16, 17], 1), ([256, 512, 256, 128], 4096), ([128, 128, 128], 1000), ([48, 1, 512, 16, 17, 3], 1)])
 def test_grouped_wgrad_matches_per_layer(dims, M):
     """clica_mlp_wgrad (all layers, one grouped split-K launch + one grouped slab reduce) vs fp64 and per-layer wgrad."""
     from cl_ica_amd import ops
@@ -372,3 +374,42 @@ def test_split_bf16_stack_matches_fp64(dims, M):
         # legitimately differ from fp64's)
         g64 = (g64 @ Ws[l].cpu().numpy().astype(np.float64)) * np.where(outs[l - 1].cpu().numpy() > 0, 1.0, 0.01)
         assert rel_err(dz[j].cpu().numpy(), g64) < 1e-5, ("dgrad", l)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_get_mlp_autograd_seeded_sweep_vs_fp64(fused, monkeypatch):
+    """Twelve seeded random encoders (1-7 layers, widths 1..512, batch sizes around the 48-row panels) through the drop-in
+    module under torch autograd -- whole-encoder kernels (fused=1) and per-layer kernels (fused=0) -- against the same
+    network in fp64 torch ops: output, input gradient and every parameter gradient at 1e-5."""
+    from cl_ica_amd import encoders
+    monkeypatch.setenv("CLICA_DROPIN_FUSED", fused)
+    rng = np.random.default_rng(77)
+    widths = [1, 2, 3, 10, 16, 17, 48, 100, 130, 256, 500, 512]
+    for case in range(12):
+        L = int(rng.integers(1, 7))
+        n_in, n_out = int(rng.choice(widths[:8])), int(rng.choice(widths[:8]))
+        hidden = [int(rng.choice(widths)) for _ in range(L)]
+        M = int(rng.choice([1, 5, 47, 48, 49, 96, 1000, 3001]))
+        torch.manual_seed(case)
+        f = encoders.get_mlp(n_in, n_out, list(hidden)).to("cuda")
+        x = torch.randn(M, n_in, device="cuda", requires_grad=True)
+        gy = torch.randn(M, n_out, device="cuda")
+        y = f(x)
+        y.backward(gy)
+        # fp64 twin
+        x64 = x.detach().double().requires_grad_(True)
+        cur = x64
+        prm64 = []
+        lin = [m for m in f if isinstance(m, torch.nn.Linear)]
+        for i, m in enumerate(lin):
+            W = m.weight.detach().double().requires_grad_(True); b = m.bias.detach().double().requires_grad_(True)
+            prm64 += [W, b]
+            cur = cur @ W.T + b
+            if i < len(lin) - 1:
+                cur = torch.nn.functional.leaky_relu(cur, 0.01)
+        cur.backward(gy.double())
+        cid = f"#{case} fused={fused} dims={[n_in] + hidden + [n_out]} M={M}"
+        PARITY.check("get_mlp_sweep_vs_fp64", cid, "y", y.detach().cpu().numpy(), cur.detach().cpu().numpy())
+        PARITY.check("get_mlp_sweep_vs_fp64", cid, "dx", x.grad.cpu().numpy(), x64.grad.cpu().numpy())
+        for (name, prm), ref in zip(f.named_parameters(), prm64):
+            PARITY.check("get_mlp_sweep_vs_fp64/grad", cid, name, prm.grad.cpu().numpy(), ref.grad.cpu().numpy())
