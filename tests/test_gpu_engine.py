@@ -74,6 +74,48 @@ def test_engine_matches_autograd_path():
             PARITY.check("engine_vs_autograd_dropin", f"head={head}", k, g.cpu().numpy(), ref_grads[k].cpu().numpy())
 
 
+def test_engine_seeded_sweep_vs_autograd_path():
+    """Ten seeded random trainers -- latent dimension, encoder widths (whole-tile widths 128 / 256 / 512 included), batch
+    size, head, exponent, space -- through the fused engine (one step with lr = 0 on an injected batch) against the drop-in
+    modules under torch autograd on the same batch: loss and every parameter gradient at 1e-5."""
+    from cl_ica_amd import encoders, losses, ops
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    rng = np.random.default_rng(11)
+    widths = [16, 64, 100, 128, 256, 300, 512, 600]
+    for case in range(10):
+        n = int(rng.choice([2, 3, 5, 10, 16]))
+        hidden = [int(rng.choice(widths)) for _ in range(int(rng.integers(1, 5)))]
+        B = int(rng.choice([64, 200, 1024]))
+        head = [None, "learnable_sphere", "learnable_box", "fixed_sphere", "fixed_box"][int(rng.integers(5))]
+        p = int(rng.choice([1, 2, 3]))
+        torch.manual_seed(100 + case)
+        f = encoders.get_mlp(n, n, list(hidden), output_normalization=head).to("cuda")
+        gW = torch.randn(3, n, n, device="cuda") / n ** 0.5
+        z1 = torch.rand(B, n, device="cuda"); z2 = (z1 + 0.05 * torch.randn_like(z1)).clamp(0, 1)
+        a, b = f(ops.mixing_fwd(z1, gW)), f(ops.mixing_fwd(z2, gW))
+        tot, _, _ = losses.LpSimCLRLoss(p=p, simclr_compatibility_mode=True)(None, None, None, a, b, torch.roll(a, 1, 0))
+        tot.backward()
+        ref = {k: q.grad.clone() for k, q in f.named_parameters()}
+        tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=p, lr=0.0, device="cuda")
+        out = tr.step_injected(z1, z2)
+        cid = f"#{case} n={n} hidden={hidden} B={B} head={head} p={p} fused={tr.fused_forward}"
+        PARITY.check("engine_sweep_vs_autograd", cid, "loss", out[0].item(), tot.item())
+        gmax = max(float(v.abs().max()) for v in ref.values())
+        last_bias = f"{2 * (len(tr.linears) - 1)}.bias"
+        for k, q in f.named_parameters():
+            g = tr._gviews[id(q)]
+            if k == last_bias and (head is None or "box" in head):
+                # Lp distances are translation invariant: without a head the exact gradient is 0, behind the sigmoid-shaped box head
+                # it is a small residue of a column sum of cancelling terms; a backward-stable fp32 sum is accurate relative to
+                # the summands, whose scale is that of the other gradients built from the same dZ
+                PARITY.check("engine_sweep_vs_autograd", cid, k + " (cancelling column sum)", g.cpu().numpy(), ref[k].cpu().numpy(), floor=gmax)
+                continue
+            # p = 1: the two paths run different forward kernels (one 2B-row fused pass vs two B-row calls), their embeddings
+            # differ in the last bits, and sign(z1_k - z3_k) of a coordinate pair closer than that flips a whole 1 / B term
+            tol, note = (5e-5, "p = 1: sign ties between two fp32 forwards") if p == 1 else (1e-5, None)
+            PARITY.check("engine_sweep_vs_autograd", cid, k, g.cpu().numpy(), ref[k].cpu().numpy(), floor=1e-3 * gmax, tol=tol, note=note)
+
+
 def test_graph_replay_trains():
     from cl_ica_amd import encoders
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
