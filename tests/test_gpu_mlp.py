@@ -413,3 +413,29 @@ def test_get_mlp_autograd_seeded_sweep_vs_fp64(fused, monkeypatch):
         PARITY.check("get_mlp_sweep_vs_fp64", cid, "dx", x.grad.cpu().numpy(), x64.grad.cpu().numpy())
         for (name, prm), ref in zip(f.named_parameters(), prm64):
             PARITY.check("get_mlp_sweep_vs_fp64/grad", cid, name, prm.grad.cpu().numpy(), ref.grad.cpu().numpy())
+
+
+def test_linear_kernels_seeded_sweep_vs_fp64():
+    """Thirty seeded random (M, N, K) for the per-layer Linear kernels -- widths around and on the tile sizes (16, 32, 64,
+    128, 256, 512) -- forward, data gradient, weight and bias gradient against fp64."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(5)
+    sizes = [1, 3, 15, 16, 17, 31, 32, 33, 64, 100, 127, 128, 129, 255, 256, 257, 500, 512, 640, 1024]
+    for case in range(30):
+        M = int(rng.choice([1, 7, 63, 64, 65, 500, 2048, 4097]))
+        N, K = int(rng.choice(sizes)), int(rng.choice(sizes))
+        x = rng.normal(size=(M, K)).astype(np.float32)
+        w = (rng.uniform(-1, 1, size=(N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.uniform(-0.1, 0.1, size=N).astype(np.float32)
+        dy = rng.normal(size=(M, N)).astype(np.float32)
+        z = x.astype(np.float64) @ w.astype(np.float64).T + b
+        cid = f"#{case} M={M} N={N} K={K}"
+        y = ops.linear_fwd(dev(x), dev(w), dev(b), leaky=True, slope=0.01).cpu().numpy()
+        PARITY.check("linear_sweep_vs_fp64", cid, "y", y, np.where(z > 0, z, 0.01 * z))
+        xa = rng.normal(size=(M, K)).astype(np.float32)
+        dx = ops.linear_dgrad(dev(dy), dev(w), dev(xa), 0.01).cpu().numpy()
+        PARITY.check("linear_sweep_vs_fp64", cid, "dx", dx, (dy.astype(np.float64) @ w.astype(np.float64)) * np.where(xa > 0, 1.0, 0.01))
+        dw, db = ops.linear_wgrad(dev(dy), dev(x))
+        PARITY.check("linear_sweep_vs_fp64", cid, "dW", dw.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64))
+        # a column sum of M signed terms: relative to the summands' scale
+        PARITY.check("linear_sweep_vs_fp64", cid, "db", db.cpu().numpy(), dy.astype(np.float64).sum(0), floor=float(np.abs(dy).sum(0).max()) * 0.05)
