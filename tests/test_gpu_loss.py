@@ -324,3 +324,62 @@ def test_lp_loss_seeded_sweep_vs_oracle():
         PARITY.check("lp_sweep_vs_oracle", case_id, "loss_mean", out["loss_mean"], float(orc["loss_mean"]), floor=lf)
         for g in ("dz1", "dz2", "dz3"):
             PARITY.check("lp_sweep_vs_oracle", case_id, g, out[g], orc[g], floor=gf if g != "dz3" else float(np.abs(orc["dz3"]).max()))
+
+
+def test_other_losses_seeded_sweep_vs_oracle():
+    """Seeded random shapes for the remaining loss kinds against the fp64 oracle: SimCLRLoss with and without row
+    normalisation (incl. rows wider than 64), LpSimCLRLoss in its p < 1 eps branch (B3 = B), UniformityLoss / AlignmentLoss
+    with fractional and integer exponents."""
+    from cl_ica_amd.losses import AlignmentLoss, LpSimCLRLoss, SimCLRLoss, UniformityLoss
+    rng = np.random.default_rng(31)
+    shapes_b = [1, 2, 33, 64, 65, 130, 400]
+    shapes_b3 = [1, 16, 17, 129, 300, 1025]
+    dims = [2, 3, 10, 13, 40, 64, 65, 128]
+    for case in range(16):                                           # dot-product InfoNCE
+        B, B3, n = int(rng.choice(shapes_b)), int(rng.choice(shapes_b3)), int(rng.choice(dims))
+        normalize = bool(rng.integers(2)); tau = float(rng.choice([0.2, 0.5, 1.0])); alpha = float(rng.choice([0.5, 0.3]))
+        sc = 1.0 if normalize else 1.0 / np.sqrt(n)
+        z1 = (rng.normal(size=(B, n)) * sc).astype(np.float32); z2 = (z1 + 0.2 * sc * rng.normal(size=(B, n))).astype(np.float32)
+        z3 = (rng.normal(size=(B3, n)) * sc).astype(np.float32)
+        out = run_hip(SimCLRLoss(normalize=normalize, tau=tau, alpha=alpha), z1, z2, z3)
+        orc = O.simclr_loss(z1, z2, z3, normalize=normalize, tau=tau, alpha=alpha)
+        mag = 1.0 / np.linalg.norm(z1.astype(np.float64), axis=1).min() if normalize else float(np.abs(z2).max())
+        gf = 2 * alpha / (B * tau) * mag
+        lf = 2.0 * max(float(np.abs(orc["lse"] - orc["loss_i"] / 2.0).max()), (1.0 - alpha) * float(np.abs(orc["lse"]).max()))
+        cid = f"dot #{case} B={B} B3={B3} n={n} norm={int(normalize)} tau={tau:g}"
+        PARITY.check("other_losses_sweep", cid, "loss_i", out["loss_i"], orc["loss_i"], floor=lf)
+        for g in ("dz1", "dz2", "dz3"):
+            PARITY.check("other_losses_sweep", cid, g, out[g], orc[g], floor=gf if g != "dz3" else float(np.abs(orc["dz3"]).max()))
+    for case in range(8):                                            # p < 1: eps inside the abs, transposed pair orientation
+        B, n = int(rng.choice([2, 33, 64, 130])), int(rng.choice([2, 5, 10, 17]))
+        p = float(rng.choice([0.5, 0.75])); tau = float(rng.choice([0.5, 1.0]))
+        z1 = rng.normal(size=(B, n)).astype(np.float32) * 0.5; z2 = (z1 + 0.05 * rng.normal(size=(B, n))).astype(np.float32)
+        z3 = rng.normal(size=(B, n)).astype(np.float32) * 0.5
+        out = run_hip(LpSimCLRLoss(p=p, tau=tau, simclr_compatibility_mode=True), z1, z2, z3)
+        orc = O.lp_simclr_loss(z1, z2, z3, p=p, tau=tau, alpha=0.5, compat=True, pow=True)
+        lf, gf = summand_floors(orc, 0.5, tau, grad_scale(z1, z2, p, tau, 0.5))
+        cid = f"frac #{case} B={B} n={n} p={p:g} tau={tau:g}"
+        PARITY.check("other_losses_sweep", cid, "loss_i", out["loss_i"], orc["loss_i"], floor=lf)
+        for g in ("dz1", "dz2", "dz3"):
+            # pull and push cancel when the positive dominates the softmax (n = 17, p = 0.5: the fp32 reference returns loss 0
+            # and dz2 = 0 exactly there, the fp64 oracle 1e-8 and 3e-7): relative to the pull's scale, as everywhere else
+            PARITY.check("other_losses_sweep", cid, g, out[g], orc[g], floor=gf if g != "dz3" else max(float(np.abs(orc["dz3"]).max()), 1e-3 * gf))
+    for case in range(8):                                            # uniformity / alignment
+        B, B3, n = int(rng.choice(shapes_b[1:])), int(rng.choice(shapes_b3[1:])), int(rng.choice(dims[:6]))
+        p = float(rng.choice([0.5, 1.0, 1.5, 2.0, 3.0]))
+        z1 = (rng.normal(size=(B, n)) / np.sqrt(n)).astype(np.float32); z3 = (rng.normal(size=(B3, n)) / np.sqrt(n)).astype(np.float32)
+        z2 = (z1 + 0.1 * rng.normal(size=(B, n)) / np.sqrt(n)).astype(np.float32)
+        a = dev(z1).requires_grad_(True); c = dev(z3).requires_grad_(True)
+        u, ui, _ = UniformityLoss(p)(a, c); u.backward()
+        ou = O.uniformity_loss(z1, z3, p)
+        cid = f"unif #{case} B={B} B3={B3} n={n} p={p:g}"
+        comp = max(float(np.abs(ou["loss_i"]).max()) + np.log(B3), 1.0)
+        PARITY.check("other_losses_sweep", cid, "loss_i", ui.detach().cpu().numpy(), ou["loss_i"], floor=comp)
+        wscale = float(np.abs(O._dpowabs(z1[None].astype(np.float64) - z3[:, None].astype(np.float64), p)).max()) / B3
+        PARITY.check("other_losses_sweep", cid, "dz1", a.grad.cpu().numpy(), ou["dz1"], floor=wscale)
+        PARITY.check("other_losses_sweep", cid, "dz3", c.grad.cpu().numpy(), ou["dz3"], floor=wscale)
+        a = dev(z1).requires_grad_(True); b = dev(z2).requires_grad_(True)
+        al, ali, _ = AlignmentLoss(p)(a, b); al.backward()
+        oa = O.alignment_loss(z1, z2, p)
+        PARITY.check("other_losses_sweep", "align" + cid[4:], "loss_i", ali.detach().cpu().numpy(), oa["loss_i"])
+        PARITY.check("other_losses_sweep", "align" + cid[4:], "dz1", a.grad.cpu().numpy(), oa["dz1"], floor=1e-3 * float(np.abs(oa["dz1"]).max()))
