@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void means_k(const float* __restrict__ blocksum
 
 // one row of the coefficient step (shared by bwd_coef_k and the training forward's finalize)
 __device__ __forceinline__ void coef_row(
-    const int64_t i, const int64_t rows, const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
+    const int64_t i, const int64_t rows, const float* a /* row i of z1 */, const float* b /* row i of z2 */,
     const Params& q, float tau, float alpha, int compat, int frac, int dot, const float L2,
     const float* __restrict__ g_mean, const float* __restrict__ g_item,
     const float* __restrict__ g_pos, const float* __restrict__ g_neg,
@@ -77,8 +77,6 @@ __device__ __forceinline__ void coef_row(
                       // ~10^3 in saturated rows (each rounding of it is a 1e-4 relative error on every weight of the row)
   statC[i] = q.xs * C / tau;
   if (!dz1 && !dz2) return;
-  const float* a = z1 + i * ld1;
-  const float* b = z2 + i * ld2;
   if (dot) {
     float pos = 0.f;
     for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
@@ -125,8 +123,22 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
     float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T) {
   __shared__ float sm[THREADS / FIN_ROWS][FIN_ROWS], ss[THREADS / FIN_ROWS][FIN_ROWS];
+  // the block's z1 / z2 rows, staged by all 256 threads (coalesced) while the partials are in flight: the finishing
+  // threads then read their row's coordinates from LDS instead of starting two more dependent global round trips
+  constexpr int FIN_MAXN = 64;
+  __shared__ float zrows[2][FIN_ROWS * FIN_MAXN];
   const int lane_row = threadIdx.x & (FIN_ROWS - 1), grp = threadIdx.x / FIN_ROWS;
   const int64_t i = (int64_t)blockIdx.x * FIN_ROWS + lane_row;
+  const bool staged = q.n <= FIN_MAXN;
+  if (staged) {
+    const int64_t r0 = (int64_t)blockIdx.x * FIN_ROWS;
+    const int cnt = (int)min((int64_t)FIN_ROWS, rows - r0) * q.n;
+    for (int idx = threadIdx.x; idx < cnt; idx += THREADS) {
+      const int r = idx / q.n, k = idx - r * q.n;
+      zrows[0][idx] = z1[(r0 + r) * ld1 + k];
+      zrows[1][idx] = z2[(r0 + r) * ld2 + k];
+    }
+  }
   float m = -1e30f, s = 0.f;
   if (i < rows) {
     // four partials in flight per round (a one-at-a-time loop is a chain of dependent L2 round trips);
@@ -159,13 +171,15 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
       m = mn;
     }
     float pos, xp;
+    const float* ra = staged ? &zrows[0][lane_row * q.n] : z1 + i * ld1;
+    const float* rb = staged ? &zrows[1][lane_row * q.n] : z2 + i * ld2;
     if (dot) {   // SimCLRLoss: pos = <z1, z2> and the logit is +pos/tau (losses.py:188-193)
       pos = 0.f;
-      for (int k = 0; k < q.n; ++k) pos += z1[i * ld1 + k] * z2[i * ld2 + k];
+      for (int k = 0; k < q.n; ++k) pos += ra[k] * rb[k];
       xp = pos * q.kscale;
       pos = -pos;  // loss_pos = -pos/tau (losses.py:192)
     } else {
-      const float sp_ = pos_sum(z1 + i * ld1, z2 + i * ld2, q.n, q, frac != 0);
+      const float sp_ = pos_sum(ra, rb, q.n, q, frac != 0);
       pos = q.pow ? sp_ : root_of<true>(sp_, q);
       xp = -pos * q.kscale;
     }
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
     loss_i[i] = li; pos_i[i] = lp; lse_i[i] = L2;
     if (T.statL)
-      coef_row(i, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, L2, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
+      coef_row(i, rows, ra, rb, q, tau, alpha, compat, frac, dot, L2, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
                T.dz1, T.ldd1, T.dz2, T.ldd2);
     v_loss = li; v_pos = lp; v_lse = lse;
   }
@@ -200,7 +214,7 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
     float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2) {
   const int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x;
   if (i >= rows) return;
-  coef_row(i, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, lse_i[i], g_mean, g_item, g_pos, g_neg, statL, statC,
+  coef_row(i, rows, z1 + i * ld1, z2 + i * ld2, q, tau, alpha, compat, frac, dot, lse_i[i], g_mean, g_item, g_pos, g_neg, statL, statC,
            dz1, ldd1, dz2, ldd2);
 }
 
