@@ -91,7 +91,7 @@ def saturation_allowance(z1, z2, z3, p, tau, alpha, compat, pw, ref, loss_floor=
         "saturated golden: tol = 1e-5 + max(2 x fp32 reference's own deviation from the fp64 oracle, 8 eps32 max|lse|)"
 
 
-@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz", "g19_wide_lp.npz"])
+@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz", "g19_wide_lp.npz", "g22_lp_loss_large.npz"])
 def test_lp_goldens(golden, name):
     from cl_ica_amd.losses import LpSimCLRLoss
     G = golden(name)

@@ -50,7 +50,7 @@ def _check_loss_case(c, out, tol=TOL, grads=("dz1", "dz2", "dz3")):
         assert np.abs(out[g] - ref).max() / scale < 5 * tol * sat, g
 
 
-@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz", "g19_wide_lp.npz"])
+@pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz", "g19_wide_lp.npz", "g22_lp_loss_large.npz"])
 def test_lp_loss_goldens(golden, name):
     G = golden(name)
     assert G.n_cases > 0
