@@ -36,6 +36,10 @@ constexpr int WAVES = THREADS / 64;
 constexpr int HALF = 32;            // owner rows per wave: lanes l and l + 32 share an owner and split the stream
 constexpr int PARTS = 2 * WAVES;    // stream partitions inside a workgroup (merged on chip, never through HBM)
 constexpr int JB = 4;               // stream rows processed together (independent FMA chains)
+#ifndef CLICA_LP_JBW
+#define CLICA_LP_JBW 2      // measured (tools/loss_train_probe.py): 2 beats 4 by 3 % (n = 10) to 7 % (n = 40), 1 and 8 are slower
+#endif
+constexpr int JBW = CLICA_LP_JBW;   // the same for the backward sweep (RPP = 16 rows per partition and tile: 2, 4, 8 or 16)
 // stream rows per LDS tile: every partition gets TS / PARTS of them (32 / 16 / 8 rows)
 #ifndef CLICA_LP_TS16
 #define CLICA_LP_TS16 128      // measured (tools/loss_train_probe.py): 128 beats 256 by 14 % on the backward sweep (registers: the
@@ -184,23 +188,23 @@ __device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* 
 // NQ = number of dimension PAIRS that can hold real data (ceil(n / 2) <= NP / 2): a pair that is all padding
 // (n = 9, 10 in the 12-wide layout) contributes exact zeros and is skipped at compile time -- same bits, two packed
 // instructions fewer per pair and sweep.
-template <int NP, int PK, int NQ = NP / 2>
+template <int NP, int PK, int NQ = NP / 2, int JBT = JB>
 __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float* tile, int jj, const Params& q,
-                                           float (&acc)[JB]) {
-  f32x2 a2[JB];
+                                           float (&acc)[JBT]) {
+  f32x2 a2[JBT];
 #pragma unroll
-  for (int c = 0; c < JB; ++c) a2[c] = (f32x2){0.f, 0.f};
+  for (int c = 0; c < JBT; ++c) a2[c] = (f32x2){0.f, 0.f};
 #pragma unroll
   for (int k4 = 0; k4 < NP / 4; ++k4) {
 #pragma unroll
-    for (int c = 0; c < JB; ++c) {
+    for (int c = 0; c < JBT; ++c) {
       const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
       if (2 * k4 < NQ) accum2<PK>(a2[c], o[2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
       if (2 * k4 + 1 < NQ) accum2<PK>(a2[c], o[2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
     }
   }
 #pragma unroll
-  for (int c = 0; c < JB; ++c) acc[c] = a2[c].x + a2[c].y;
+  for (int c = 0; c < JBT; ++c) acc[c] = a2[c].x + a2[c].y;
 }
 
 // ---- forward: per-split (max, sum) partials in the log2 domain -----------------------------
@@ -427,14 +431,14 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     const float* tC = tCs[cur] + pq * RPP;
     const int cq = min(RPP, max(0, cnt - pq * RPP));
     // (a tail-mask-free copy of this loop for full partitions, as in the forward, was measured 4 % SLOWER here: not kept)
-    for (int jj = 0; jj < cq; jj += JB) {
+    for (int jj = 0; jj < cq; jj += JBW) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float acc[JB];
-        dist_group<NP, PK, NQ>(o[r], tile, jj, q, acc);
-        float coef[JB];
+        float acc[JBW];
+        dist_group<NP, PK, NQ, JBW>(o[r], tile, jj, q, acc);
+        float coef[JBW];
 #pragma unroll
-        for (int c = 0; c < JB; ++c) {
+        for (int c = 0; c < JBW; ++c) {
           const float x = root_of<ROOT>(acc[c], q) * xk;
           float w = 0.f;
           if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
@@ -447,7 +451,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
 #pragma unroll
         for (int k4 = 0; k4 < NP / 4; ++k4) {
 #pragma unroll
-          for (int c = 0; c < JB; ++c) {
+          for (int c = 0; c < JBW; ++c) {
             const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
             if (2 * k4 < NQ) gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
             if (2 * k4 + 1 < NQ) gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
