@@ -39,6 +39,9 @@ constexpr int JB = 4;               // stream rows processed together (independe
 #ifndef CLICA_LP_JBW
 #define CLICA_LP_JBW 2      // measured (tools/loss_train_probe.py): 2 beats 4 by 3 % (n = 10) to 7 % (n = 40), 1 and 8 are slower
 #endif
+// ... and for the forward sweep: four up to the 16-wide layout, two above (measured at n = 10: 44 / 47 / 76 us for 4 / 2 / 8 rows,
+// at n = 40: 180 / 168 us for 4 / 2)
+constexpr int jb_fwd(int np) { return np <= 16 ? 4 : 2; }
 constexpr int JBW = CLICA_LP_JBW;   // the same for the backward sweep (RPP = 16 rows per partition and tile: 2, 4, 8 or 16)
 // stream rows per LDS tile: every partition gets TS / PARTS of them (32 / 16 / 8 rows)
 #ifndef CLICA_LP_TS16
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, float2* __restrict__ part, float* __restrict__ part_g, int chunk) {
-  constexpr int TS = tile_rows(NP), RPP = TS / PARTS;
-  static_assert(RPP % JB == 0, "partition rows must be whole JB groups");
+  constexpr int TS = tile_rows(NP), RPP = TS / PARTS, JBF = jb_fwd(NP);
+  static_assert(RPP % JBF == 0, "partition rows must be whole JB groups");
   static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");
   __shared__ __attribute__((aligned(16))) float tiles[2][TS * NP];
   __shared__ float2 wred[WAVES][HALF * R];
@@ -260,35 +263,38 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
     // full partitions (every tile but a ragged last one) skip the per-row tail mask: same values, two instructions fewer per pair
     auto sweep = [&](auto ragged_tag) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
-    for (int jj = 0; jj < cq; jj += JB) {
+    for (int jj = 0; jj < cq; jj += JBF) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float acc[JB];
-        dist_group<NP, PK, NQ>(o[r], tile, jj, q, acc);
-        float x[JB];
+        float acc[JBF];
+        dist_group<NP, PK, NQ, JBF>(o[r], tile, jj, q, acc);
+        float x[JBF];
 #pragma unroll
-        for (int c = 0; c < JB; ++c) {
+        for (int c = 0; c < JBF; ++c) {
           x[c] = root_of<ROOT>(acc[c], q) * xk;
           if (RAGGED && jj + c >= cq) x[c] = -INFINITY;      // ragged tail of the stream
         }
         // clamp keeps (-inf) - (-inf) out of the exponent when nothing valid was seen yet
-        const float mn = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(m[r], -1e30f));
-        float add = 0.f, e[JB];
+        float xm = x[0];
 #pragma unroll
-        for (int c = 0; c < JB; ++c) { e[c] = fexp2(x[c] - mn); add += e[c]; }
+        for (int c = 1; c < JBF; ++c) xm = fmaxf(xm, x[c]);
+        const float mn = fmaxf(xm, fmaxf(m[r], -1e30f));
+        float add = 0.f, e[JBF];
+#pragma unroll
+        for (int c = 0; c < JBF; ++c) { e[c] = fexp2(x[c] - mn); add += e[c]; }
         const float resc = fexp2(m[r] - mn);
         s[r] = fmaf(s[r], resc, add);
         m[r] = mn;
         if (ROWGRAD) {
 #pragma unroll
-          for (int c = 0; c < JB; ++c) e[c] *= droot_of<ROOT>(acc[c], q) * csgn;
+          for (int c = 0; c < JBF; ++c) e[c] *= droot_of<ROOT>(acc[c], q) * csgn;
           asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
           const f32x2 r2 = {resc, resc};
 #pragma unroll
           for (int k4 = 0; k4 < NP / 4; ++k4) {
             G[r][2 * k4] *= r2; G[r][2 * k4 + 1] *= r2;
 #pragma unroll
-            for (int c = 0; c < JB; ++c) {
+            for (int c = 0; c < JBF; ++c) {
               const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
               if (2 * k4 < NQ) gaccum2<PK>(G[r][2 * k4], e[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
               if (2 * k4 + 1 < NQ) gaccum2<PK>(G[r][2 * k4 + 1], e[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
