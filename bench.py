@@ -12,10 +12,18 @@ sample -> g -> f fwd -> loss -> backward -> Adam (main_mlp.py:258-285,328) -- no
 At N GPUs every rank processes its own B=6144 batch per global step against the all-gathered
 N*B negatives pool (weak scaling); `value` counts batches/s over all ranks = N * global_steps/s.
 
+Encoder arithmetic (round 3): the headline runs the split-bf16 mode -- fp32 EMULATION on the bf16 matrix cores (every fp32
+operand split exactly into three bf16 pieces, six piece products, fp32 accumulate; measured error vs fp64 at the native fp32
+kernels' level) for the forward stack, the backward data chain and the weight gradients.  `dtype` says so; the `native_fp32`
+leg is the same step on the fp32-MFMA kernels (`--native-fp32` makes that the headline instead).
+
 Besides the contract fields the JSON line carries
-  roofline      -- the step's dominant kernel symbol (the fused fp32-MFMA MLP kernel `mlp_fwd_k`: forward
-                   stack + backward data chain; per-layer `gemm_k` for wide encoders) timed with HIP
-                   events, algorithmic FLOPs / time vs the 157.3 TFLOP/s fp32 matrix peak
+  roofline      -- the step's dominant kernel symbol (the whole-stack kernel `mlp_split_k` / `mlp_fwd_k`: forward
+                   stack + backward data chain; per-layer `gemm_k` for wide encoders) timed with HIP events inside
+                   training steps: ISSUED bf16 flops (6 x algorithmic) / time vs the 2.5 PFLOP/s dense bf16 peak, with
+                   `fp32_equivalent` = algorithmic flops / time vs the 157.3 TFLOP/s fp32 matrix peak next to it
+  native_fp32   -- value + roofline of the same step on the native fp32-MFMA kernels
+  ranks         -- N > 1: per rank the world size it saw and the wall time of each collective of the step
   cpu_baseline  -- oracle/torch_port.py (the reference's op sequence in PyTorch CPU ops) timed on
                    this box's host cores, rank 0 at N=1 only
 """
@@ -52,10 +60,12 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="single-stream backward (A/B switch)")
     ap.add_argument("--no-fused-forward", action="store_true", help="per-layer forward GEMMs instead of the one-launch stack (A/B switch)")
-    ap.add_argument("--split-bf16", action="store_true",
-                    help="opt-in arithmetic for the two whole-stack encoder kernels: exact 3-way bf16 splits of both fp32 operands, six "
-                         "bf16-MFMA products, fp32 accumulate (fp32-grade error); default is native fp32 MFMA")
-    ap.add_argument("--no-split-probe", action="store_true", help="skip the extra short measurement of the --split-bf16 mode (N = 1 only)")
+    ap.add_argument("--native-fp32", action="store_true",
+                    help="headline on the native fp32-MFMA encoder kernels instead of the default split-bf16 arithmetic (exact 3-way "
+                         "bf16 splits of both fp32 operands, six bf16-MFMA products, fp32 accumulate: fp32 emulation, fp32-grade error)")
+    ap.add_argument("--split-bf16", action="store_true", help="(default since round 3; accepted for compatibility)")
+    ap.add_argument("--no-native-leg", "--no-split-probe", dest="no_native_leg", action="store_true",
+                    help="skip the `native_fp32` leg (the same step on the fp32-MFMA kernels, N = 1 only)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
@@ -75,7 +85,7 @@ def build_trainer(args, device, world, split_bf16=None):
     return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
                               device=device, process_group=None if world == 1 else dist.group.WORLD,
                               overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward,
-                              split_bf16=args.split_bf16 if split_bf16 is None else split_bf16)
+                              split_bf16=(not args.native_fp32) if split_bf16 is None else split_bf16)
 
 
 def _graph_time(fns, reps):
@@ -135,17 +145,17 @@ def roofline_leg(tr, reps=20):
         return ("linear_" + op, f"clica::gemm::gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>"
                 + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 
-    fused_key = ("mlp_fwd+mlp_dgrad", "clica::fmlp::mlp_split_k" if getattr(tr, "split_bf16", False) else "clica::fmlp::mlp_fwd_k<true, false>")
+    split = bool(getattr(tr, "split_bf16", False))
+    fused_sym = "clica::fmlp::mlp_split_k" if split else "clica::fmlp::mlp_fwd_k<true, false>"
+    fused_key = ("mlp_fwd+mlp_dgrad", fused_sym)
     if tr.fused_forward:
-        ws = [lin.weight for lin in tr.linears]
         fl = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
-        if tr.split_bf16:
-            add(fused_key, fl, lambda: ops.mlp_fwd_split(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.packed, tr.slope,
-                                                         signmasks=tr.signmasks))
-        else:
-            add(fused_key, fl, lambda: ops.mlp_fwd(tr.x, ws, [lin.bias for lin in tr.linears], tr.acts, tr.slope, packed=tr.packed,
-                                                   signmasks=tr.signmasks))
-        add(("mlp_fwd", "clica::fmlp::mlp_fwd_k<true, false> [forward stack launch]"), fl, groups[fused_key]["fns"][-1])
+
+        def fwd_fn():
+            tr._packed_current = True          # the fragment-order copies of the last step are still valid (lr = whatever: same layout)
+            tr.forward()
+        add(fused_key, fl, fwd_fn)
+        add(("mlp_fwd", fused_sym + " [forward stack launch]"), fl, fwd_fn)
     else:
         cur = tr.x
         for l, lin in enumerate(tr.linears):
@@ -156,25 +166,18 @@ def roofline_leg(tr, reps=20):
     g_top = tr.dy if tr.head is None else tr.dpre
     if tr.fused_backward:
         chain = list(range(L - 1, 0, -1))
-        wsT = [tr.linears[l].weight for l in chain]
         fl = sum(2.0 * R * tr.linears[l].out_features * tr.linears[l].in_features for l in chain)
-        if tr.split_bf16:
-            fn = lambda: ops.mlp_dgrad_chain_split(g_top, wsT, tr.packed_t, [tr.dz[l - 1] for l in chain], tr.slope,
-                                                   masks_chain=[tr.signmasks[l - 1] for l in chain])
-        else:
-            fn = lambda: ops.mlp_dgrad_chain(g_top, wsT, tr.packed_t, [tr.acts[l - 1] for l in chain],
-                                             [tr.dz[l - 1] for l in chain], tr.slope,
-                                             masks_chain=[tr.signmasks[l - 1] for l in chain])
-        add(fused_key, fl, fn)
-        add(("mlp_dgrad", "clica::fmlp::mlp_fwd_k<true, false> [backward data chain launch]"), fl, fn)
+
+        def chain_fn():
+            tr._packed_current = True
+            tr.backward_chain(g_top)
+        add(fused_key, fl, chain_fn)
+        add(("mlp_dgrad", fused_sym + " [backward data chain launch]"), fl, chain_fn)
         if tr.grouped_wgrad:
-            order = list(range(L))
             flw = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
-            add(("mlp_wgrad", "clica::gemm::wgrad_group_k<128, 128, 2, 4, 3> (+ slab_reduce_group_k)"), flw,
-                lambda: ops.mlp_wgrad([g_top if l == L - 1 else tr.dz[l] for l in order],
-                                      [tr.acts[l - 1] if l > 0 else tr.x for l in order],
-                                      [tr._gviews[id(tr.linears[l].weight)] for l in order],
-                                      [tr._gviews[id(tr.linears[l].bias)] for l in order], ws=tr.group_ws))
+            wsym = ("clica::wsplit::wgrad_split_k (+ wgrad_tiny_k + slab_reduce_group_k)" if getattr(tr, "split_wgrad", False)
+                    else "clica::gemm::wgrad_group_k<128, 128, 2, 4, 3> (+ wgrad_tiny_k + slab_reduce_group_k)")
+            add(("mlp_wgrad", wsym), flw, lambda: tr.weight_grads(g_top))
         else:
             for l in reversed(range(L)):
                 lin = tr.linears[l]
@@ -206,7 +209,6 @@ def roofline_leg(tr, reps=20):
     instep = {}
     if tr.fused_forward and tr.fused_backward and tr.grouped_wgrad and tr.head is None and not tr.dp:
         names = ("mlp_fwd", "mlp_dgrad", "mlp_wgrad")
-        fns_by = {op: grp["fns"][-1] for (op, _), grp in groups.items() if op in names}
         # one event set per repetition and NO host sync inside the loop: the host runs ahead of the GPU (a step is ~0.77 ms of GPU
         # work, ~0.3 ms of eager launch work), so every bracket opens while the GPU is still busy and measures kernel time
         WARM = 60      # ~45 ms of untimed steps first (sustained clock, see _graph_time)
@@ -218,12 +220,10 @@ def roofline_leg(tr, reps=20):
             tr._packed_current = False
             tr.sample()
             tr.pack()
-            if tr._x_pending:       # the mixing net rides in the forward's prologue in the real step; here the forward is launched
-                ops.mixing_fwd(tr.z, tr.gW, tr.g_slope, out=tr.x); tr._x_pending = False     # through ops.mlp_fwd on tr.x
-            ev[0].record(); fns_by["mlp_fwd"](); ev[1].record()
+            ev[0].record(); tr.forward(); ev[1].record()
             tr.loss_forward_backward()
-            ev[2].record(); fns_by["mlp_dgrad"](); ev[3].record()
-            fns_by["mlp_wgrad"](); ev[4].record()
+            ev[2].record(); tr.backward_chain(g_top); ev[3].record()
+            tr.weight_grads(g_top); ev[4].record()
             tr.optimizer_step()
         torch.cuda.synchronize()
         for rep in range(WARM, reps + WARM):
@@ -251,20 +251,28 @@ def roofline_leg(tr, reps=20):
                 r["timing"] = "HIP events around the two launches inside eager training steps (see roofline_leg)"
     rows.sort(key=lambda r: -r["us_per_step"])
     peak = PEAK_FP32_MFMA_TFLOPS
-    if fused_key in groups and getattr(tr, "split_bf16", False):
-        # split-bf16 mode: the step's dominant symbol is the (native fp32-MFMA) grouped weight-gradient kernel
-        top = rows[0]
-        note = ("f32 (v_mfma_f32_32x32x2_f32)" if "wgrad" in top["op"] else
-                "f32 results from six bf16 products of exact 3-way bf16 splits (v_mfma_f32_16x16x32_bf16, fp32 accumulate)")
-        if "wgrad" not in top["op"]:
-            peak = PEAK_BF16_MFMA_TFLOPS
+    issued_factor = 1.0
+    widths = [lin.out_features for lin in tr.linears]
+    nparam = sum(lin.out_features * lin.in_features for lin in tr.linears)
+    mask_b = (sum(m.numel() * 8 for m in tr.signmasks if m is not None) if tr.signmasks else 0)
+    if fused_key in groups and split:
+        # split-bf16 mode: the dominant symbol is the whole-stack kernel on the bf16 matrix cores (two launches per step).  Every
+        # fp32 product is SIX bf16 MFMA products: `achieved` counts the bf16 flops the kernel ISSUES (6 x algorithmic) against the
+        # dense bf16 peak; `fp32_equivalent` is the algorithmic 2MNK against the fp32 matrix peak the native kernel is bound by.
+        top = [r for r in rows if r["op"] == fused_key[0]][0]
+        peak, issued_factor = PEAK_BF16_MFMA_TFLOPS, 6.0
+        pl = getattr(tr, "split_wgrad", False)
+        per = lambda l, planes: (6 if (pl and planes[l] is not None) else 0) + (4 if (not pl or tr.acts_out[l] is not None) else 0)   # noqa: E731
+        fwd_b = 4 * R * tr.linears[0].in_features * 2 + R * sum(widths[l] * per(l, tr.act_planes) for l in range(L)) + 6 * nparam + mask_b
+        perz = lambda l: (6 if (pl and tr.dz_planes[l] is not None) else 0) + (4 if (not pl or tr.dz_out[l] is not None) else 0)         # noqa: E731
+        bwd_b = 4 * R * widths[-1] + R * sum(widths[l] * perz(l) for l in range(L - 1)) + 6 * (nparam - widths[0] * tr.linears[0].in_features) + mask_b
+        top["alg_bytes"] = (fwd_b + bwd_b) // 2
+        note = ("f32 results from six bf16 products of exact 3-way bf16 operand splits (v_mfma_f32_16x16x32_bf16, fp32 accumulate); "
+                "activation planes resident in LDS")
     elif fused_key in groups:
         top = [r for r in rows if r["op"] == fused_key[0]][0]
         # minimum HBM bytes per launch (average of the two launches): every layer output written once (saved
         # activations / dZ), the weights once, the sign bits once, the 10-wide input
-        widths = [lin.out_features for lin in tr.linears]
-        nparam = sum(lin.out_features * lin.in_features for lin in tr.linears)
-        mask_b = sum(m.numel() * 8 for m in tr.signmasks if m is not None) if tr.signmasks else 0
         fwd_b = 4 * R * (tr.linears[0].in_features + sum(widths)) + 4 * nparam + mask_b
         bwd_b = 4 * R * (widths[-1] + sum(widths[:-1])) + 4 * nparam + mask_b
         top["alg_bytes"] = (fwd_b + bwd_b) // 2
@@ -288,10 +296,15 @@ def roofline_leg(tr, reps=20):
                                "stale if the kernel changed after that profile was taken")
     except Exception:
         pass
-    roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(top["tflops"] / peak, 4),
+    roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(issued_factor * top["tflops"], 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(issued_factor * top["tflops"] / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top.get("alg_bytes"), "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
             "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": note}
+    if issued_factor != 1.0:
+        roof["flops_counted"] = "issued bf16 flops = 6 x algorithmic 2MNK (six piece products per fp32 product), against the dense bf16 MFMA peak"
+        roof["fp32_equivalent"] = {"achieved": round(top["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                                   "what": "algorithmic 2MNK per launch / launch time, against the fp32 matrix peak that bounds the native-fp32 kernel"}
     return roof, rows
 
 
@@ -395,15 +408,8 @@ def dropin_leg(args, device, steps=40, warmup=8):
     return res
 
 
-def main():
-    args = parse()
-    from cl_ica_amd.distributed import init_from_env
-    rank, world, device = init_from_env()
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    tr = build_trainer(args, device, world)
+def capture_or_eager(tr, args, rank, world, device):
+    """HIP-graph capture of the step (all ranks agree on the outcome); returns whether replays are in use."""
     use_graph = not args.no_graph
     if use_graph:
         try:
@@ -420,10 +426,15 @@ def main():
             if int(ok.item()) == 0:
                 use_graph = False
                 tr.graph = None
-    for _ in range(args.warmup):
+    return use_graph
+
+
+def timed_windows(tr, steps, warmup, windows, world, device):
+    """`warmup` untimed steps (+ >= 60 ms of continuous work: the chip settles at its sustained clock only after tens of
+    milliseconds, see _graph_time), then `windows` windows of EXACTLY `steps` steps, every window bracketed by barrier +
+    synchronize on both sides and reduced with MAX over the ranks.  Returns (window seconds, extra warm-up steps)."""
+    for _ in range(warmup):
         tr.step()
-    # the chip settles at its sustained clock only after tens of milliseconds of continuous work (see _graph_time): keep stepping,
-    # untimed, until >= 60 ms have gone by since the warm-up began (nothing at --warmup >= ~80; the count is reported)
     torch.cuda.synchronize()
     extra_warm = 0
     if world == 1:
@@ -434,19 +445,16 @@ def main():
             extra_warm += 10
             torch.cuda.synchronize()
     else:               # a FIXED count under data parallelism: every rank must run the same number of collective-bearing steps
-        extra_warm = max(0, 80 - args.warmup)
+        extra_warm = max(0, 80 - warmup)
         for _ in range(extra_warm):
             tr.step()
-    # `--windows` timed windows of EXACTLY `--steps` steps each, every window bracketed by barrier + synchronize on both sides and
-    # reduced with MAX over the ranks; the line reports the MEDIAN window ("median of 5 windows"), so a short
-    # driver run (--steps 20 = 16 ms of GPU time per window) is not at the mercy of one scheduling hiccup.
     window_s = []
-    for _ in range(max(1, args.windows)):
+    for _ in range(max(1, windows)):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             tr.step()
         torch.cuda.synchronize()
         if world > 1:
@@ -457,24 +465,83 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         window_s.append(el)
+    return window_s, extra_warm
+
+
+def comm_leg(tr, rank, world, device, reps=20):
+    """N > 1 only: what every rank saw of the job -- RCCL world size, and the wall time of each collective of the step in
+    isolation (HIP events on the launch stream, barrier in front of every repetition): the all-gather of the embeddings, the
+    all-gather of the row statistics, the all-reduce of the flat gradient arena.  Gathered to rank 0 so that the first real
+    multi-GPU run explains its own scaling curve."""
+    B, n = tr.B, tr.n
+    y1 = tr.y[:B].contiguous()
+    lse = tr.loss_out[2 * B:3 * B]
+    legs = {"all_gather_embeddings": lambda: dist.all_gather_into_tensor(tr.z_all, y1, group=tr.pg),
+            "all_gather_row_lse": lambda: dist.all_gather_into_tensor(tr.lse_all, lse, group=tr.pg),
+            "all_reduce_grad_arena": lambda: dist.all_reduce(tr.grad_arena, group=tr.pg)}
+    mine = {"rank": rank, "world_size_seen": dist.get_world_size(), "backend": dist.get_backend(), "device": torch.cuda.get_device_name(device)}
+    grad_snapshot = tr.grad_arena.clone()
+    for name, fn in legs.items():
+        for _ in range(3):
+            fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * reps)]
+        for r in range(reps):
+            dist.barrier()
+            ev[2 * r].record(); fn(); ev[2 * r + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(ev[2 * r].elapsed_time(ev[2 * r + 1]) * 1e3 for r in range(reps))
+        mine[name + "_us"] = round(ts[len(ts) // 2], 1)
+    tr.grad_arena.copy_(grad_snapshot)
+    mine["bytes"] = {"all_gather_embeddings": 4 * B * n, "all_gather_row_lse": 4 * B, "all_reduce_grad_arena": 4 * tr.grad_arena.numel()}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    return allr
+
+
+def main():
+    args = parse()
+    from cl_ica_amd.distributed import init_from_env
+    rank, world, device = init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    tr = build_trainer(args, device, world)
+    use_graph = capture_or_eager(tr, args, rank, world, device)
+    # SURVEY.md 8(d): "median of 5 windows" -- a short driver run (--steps 20 = ~11 ms of GPU time per window) is then not at the
+    # mercy of one scheduling hiccup
+    window_s, extra_warm = timed_windows(tr, args.steps, args.warmup, args.windows, world, device)
     elapsed = float(np.median(window_s))
     last = tr.loss_out[3 * tr.B:].clone()
     loss_vals = [float(v) for v in last.cpu()]
+    split = bool(tr.split_bf16)
+    enc = "10n-50n-50n-50n-50n-10n"
 
     out = {
-        "metric": "training steps/sec (B=6144, n=10 MLP)", "value": world * args.steps / elapsed, "unit": "steps/s",
+        "metric": f"training steps/sec (B={args.batch_size}, n={args.n} MLP)", "value": world * args.steps / elapsed, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)" if split else "f32"), "data": "synthetic",
         "global_steps_per_s": args.steps / elapsed,
         "warmup_extra_steps": extra_warm, "windows": len(window_s), "timed_steps_total": args.steps * len(window_s), "timing": "median window of `windows` x `steps` steps",
         "window_ms_per_step": [round(1e3 * w / args.steps, 4) for w in window_s],
         "config": {"workload": f"main_mlp.py --n {args.n} --n-mixing-layer 3 --p {args.p} --batch-size {args.batch_size} "
-                               f"--space-type {args.space_type} (unsupervised step: sample->g->f->LpSimCLR->bwd->Adam)",
+                               f"--space-type {args.space_type} (unsupervised step: sample->g->f->LpSimCLR->bwd->Adam; encoder {enc})",
                    "batch_per_gpu": args.batch_size, "global_batch": args.batch_size * world,
                    "negatives_pool": args.batch_size * world, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if use_graph else "eager"},
         "final_loss": loss_vals[0], "final_pos": loss_vals[1], "final_neg": loss_vals[2],
     }
+    out["encoder_arithmetic"] = (
+        "split-bf16 (fp32 emulation): both fp32 operands of every encoder GEMM -- forward stack, backward data chain AND weight "
+        "gradients -- are split exactly into three bf16 pieces, the six piece products of order <= 2 run on the bf16 matrix cores "
+        "with fp32 accumulation (max error vs fp64 8.6e-7 of max|y|, native fp32 MFMA 1.0e-6); every -m gpu engine test runs in "
+        "this mode and in native fp32 against the same goldens / tolerances (tests/conftest.py: encoder_arith)"
+        if split else "native fp32 MFMA" + ("" if tr.fused_forward else " (per-layer kernels: a width beyond 512)"))
+    if world > 1:
+        comm = comm_leg(tr, rank, world, device)
+        if rank == 0:
+            out["ranks"] = comm
     if rank == 0 and not args.no_roofline:
         roof, rows = roofline_leg(tr)
         out["roofline"] = roof
@@ -493,30 +560,22 @@ def main():
         out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0 and world == 1 and not args.no_dropin:
         out["dropin"] = dropin_leg(args, device)
-    out["encoder_arithmetic"] = ("split-bf16: exact 3-way bf16 splits of both fp32 operands, six bf16-MFMA products, fp32 accumulate "
-                                 "(fp32-grade error; forward stack + backward data chain only)" if tr.split_bf16 else "native fp32 MFMA")
-    if rank == 0 and world == 1 and not tr.split_bf16 and not args.no_split_probe and tr.fused_backward:
-        # extra information, NOT the headline: the same step with the opt-in split-bf16 encoder arithmetic
+    if rank == 0 and world == 1 and split and not args.no_native_leg:
+        # the same step on the native fp32-MFMA kernels: its own value, its own roofline entry (fp32 flops / fp32 matrix peak)
         del tr
         torch.cuda.empty_cache()
-        tr2 = build_trainer(args, device, world, split_bf16=True)
-        if tr2.split_bf16:
-            if use_graph:
-                tr2.capture()
-            for _ in range(args.warmup):
-                tr2.step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            nst = min(args.steps, 200)
-            for _ in range(nst):
-                tr2.step()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            out["split_bf16_probe"] = {"value": nst / el, "unit": "steps/s", "ms_per_step": 1e3 * el / nst, "steps": nst,
-                                       "final_loss": float(tr2.loss_out[3 * tr2.B].item()),
-                                       "note": "opt-in (--split-bf16 / CLICA_SPLIT_BF16=1): encoder forward stack and backward data chain as six "
-                                               "bf16-MFMA products of exact 3-way bf16 operand splits, fp32 accumulate; parity tests pass at the "
-                                               "fp32 tolerances (tests/test_gpu_mlp.py::test_split_bf16_stack_matches_fp64)"}
+        tr2 = build_trainer(args, device, world, split_bf16=False)
+        capture_or_eager(tr2, args, rank, world, device)
+        w2, _ = timed_windows(tr2, min(args.steps, 200), args.warmup, 3, world, device)
+        el = float(np.median(w2)); nst = min(args.steps, 200)
+        leg = {"value": nst / el, "unit": "steps/s", "ms_per_step": 1e3 * el / nst, "steps": nst, "windows": len(w2), "dtype": "f32",
+               "final_loss": float(tr2.loss_out[3 * tr2.B].item()),
+               "what": "identical step, encoder GEMMs on v_mfma_f32_16x16x4_f32 / 32x32x2_f32 (split_bf16=False / CLICA_SPLIT_BF16=0)"}
+        if not args.no_roofline:
+            roof2, _ = roofline_leg(tr2, reps=10)
+            leg["roofline"] = {k: roof2[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
+                                                     "algorithmic_gflop_per_launch", "dtype")}
+        out["native_fp32"] = leg
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

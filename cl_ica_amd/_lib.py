@@ -72,11 +72,17 @@ SIGNATURES: Dict[str, list] = {
     "clica_mlp_pack_split": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, C.c_void_p],
     "clica_mlp_pack_split_both": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.c_void_p,
                                   C.c_void_p],
+    "clica_mlp_planes_bytes": [c_i64, c_i32, c_i32, C.POINTER(c_size)],
     "clica_mlp_fwd_split": [c_f32p, c_i64, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i32, C.POINTER(C.c_void_p),
                             C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(C.c_void_p),
-                            C.c_float, C.c_void_p],
+                            C.POINTER(C.c_void_p), C.c_float, C.c_void_p],
     "clica_mlp_dgrad_split": [c_f32p, c_i64, c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(C.c_void_p),
-                              C.POINTER(C.c_void_p), C.POINTER(c_i64), C.c_float, C.c_void_p],
+                              C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.c_float, C.c_void_p],
+    "clica_mlp_wgrad_split_kind": [c_i32, c_i32, C.POINTER(c_i32)],
+    "clica_mlp_wgrad_split_workspace_bytes": [c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_size)],
+    "clica_mlp_wgrad_split": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
+                              C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
+                              C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, c_size, C.c_void_p],
     "clica_mlp_pack_bytes": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.POINTER(c_size)],
     "clica_mlp_pack": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_i32, c_f32p, C.c_void_p],
     "clica_mlp_pack_both": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, c_f32p, C.c_void_p],

@@ -16,6 +16,7 @@
 //     blocks per wave, k-permuted so one 16-byte read feeds four MFMAs on both operands.
 // One launch replaces seven; the panel never round-trips through HBM between layers.
 #include "common.h"
+#include "planes.h"
 #include <stdlib.h>
 
 namespace clica {
@@ -49,6 +50,9 @@ struct Layer {
   const unsigned long long* mask_in; // dact mode: the sign bits the forward stored for the same [M, N] panel (or nullptr)
   int N, K, leaky;
   int dact;                          // 0: out = act(acc + bias)   1: out = acc * act'(aux)   (backward data chain)
+  // split-bf16 kernel only: HBM copy of the layer output as three bf16 planes in the weight-gradient kernel's operand
+  // format (wgrad_split.hip, clica_mlp_planes_bytes), or nullptr; `out` may then be nullptr (no fp32 copy)
+  unsigned short* planes; int pl_units; int pl_ones;
 };
 struct Args {
   const float* X; int64_t ldx; int64_t M; int L; float slope;
@@ -855,9 +859,20 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     const bool use_mask = ly.dact && ly.mask_in;
     const bool want_bits = ly.mask_out != nullptr;
     const bool slope01 = g.slope > 0.f && g.slope < 1.f;
-    const bool ovec = ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (N % 4 == 0);
+    const bool has_out = ly.out != nullptr;
+    const bool ovec = has_out && ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (N % 4 == 0);
     const __amdgpu_buffer_rsrc_t orsrc =
-        __builtin_amdgcn_make_buffer_rsrc(ly.out + row0 * ly.ldo, 0, (int)(((int64_t)(nrows - 1) * ly.ldo + N) * 4), kRsrcWord3);
+        __builtin_amdgcn_make_buffer_rsrc(has_out ? ly.out + row0 * ly.ldo : nullptr, 0,
+                                          has_out ? (int)(((int64_t)(nrows - 1) * ly.ldo + N) * 4) : 0, kRsrcWord3);
+    // bf16-plane copy for the weight-gradient kernel: this workgroup's 48 rows are three 16-row groups of `pl_units` 32-feature
+    // units, 3 KB (three 1 KB plane pieces) each; a lane's four features of one row are 8 bytes of a piece.  ALL 48 rows are
+    // written (rows beyond the batch hold finite values that meet zero rows of the other operand).
+    const bool has_pl = ly.planes != nullptr;
+    const int pl_group_bytes = ly.pl_units * 3 * 1024;
+    const __amdgpu_buffer_rsrc_t prsrc =
+        __builtin_amdgcn_make_buffer_rsrc(has_pl ? reinterpret_cast<char*>(ly.planes) + (int64_t)blockIdx.x * RB * pl_group_bytes : nullptr, 0,
+                                          has_pl ? RB * pl_group_bytes : 0, kRsrcWord3);
+    const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
     unsigned lo = 0u, hi = 0u;
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
@@ -866,6 +881,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
         const int n0 = cb * 16 + kg * 4;
         const bool ragged = cb * 16 + 16 > N;          // wave-uniform: only the last real block and the k-padding blocks need the column mask
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_lds[a.boff[l] + n0]);
+        const unsigned pl_cb = (unsigned)((cb >> 1) * 3 * 1024 + (cb & 1) * 128) + pl_lane;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
           const int row = r * 16 + i15;
@@ -888,21 +904,50 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
             split3(t, hb[e], mb[e], lb[e]);
           }
           unsigned short* dst = planes + row * LDPB + n0;
-          *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
-          *reinterpret_cast<u32x2*>(dst + PLANE) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
-          *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+          const u32x2 ph = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+          const u32x2 pm = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+          const u32x2 pl = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+          *reinterpret_cast<u32x2*>(dst) = ph;
+          *reinterpret_cast<u32x2*>(dst + PLANE) = pm;
+          *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = pl;
+          if (has_pl) {                                  // wave-uniform
+            u32x2 phg = ph;
+            // feature N of the HBM copy is the constant 1 (the weight-gradient GEMM returns db = dZ^T 1 in that column);
+            // the on-chip panel keeps its zero there
+            if (ragged && ly.pl_ones) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n0 + e == N) phg[e >> 1] |= (e & 1) ? 0x3F800000u : 0x00003F80u;
+            }
+            const unsigned po = (unsigned)(r * pl_group_bytes) + pl_cb;
+            __builtin_amdgcn_raw_buffer_store_b64(phg, prsrc, po, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(pm, prsrc, po + 1024u, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(pl, prsrc, po + 2048u, 0, 0);
+          }
           if (ovec) {       // unconditional raw-buffer store, rows / features outside the tensor get an out-of-range offset
             const unsigned off = (row < nrows && n0 < N) ? (unsigned)((row * (int)ly.ldo + n0) * 4) : kOobOffset;
             // plain write-back stores (not nt): the next layer's weight loads queue behind these in the wave's in-order
             // vmcnt, and an L2 write acknowledges an order of magnitude sooner than a streaming write to HBM does
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
-          } else {
+          } else if (has_out) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               if (row < nrows && n0 + e < N) ly.out[(row0 + row) * ly.ldo + n0 + e] = v[e];
           }
         }
       }
+    }
+    if (has_pl && ly.pl_ones && (N & 31) == 0 && wave == 0) {
+      // N is a whole number of units: the ones column lives in an extra unit (feature 0 of unit N / 32) that no accumulator
+      // block covers -- wave 0 writes it (hi plane: 1.0 at feature 0 of every row, everything else zero)
+      const bool first = (lane & 1) == 0 && ((lane >> 3) & 1) == 0;      // this lane's 16 bytes start at feature 0 of the unit
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+          const u32x4 v4 = (u32x4){(pp == 0 && first) ? 0x00003F80u : 0u, 0u, 0u, 0u};
+          __builtin_amdgcn_raw_buffer_store_b128(v4, prsrc, (unsigned)(r * pl_group_bytes + ((N >> 5) * 3 + pp) * 1024 + lane * 16), 0, 0);
+        }
     }
     __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(ly.mask_out), mslot, 0, 0);
     __syncthreads();
@@ -1140,6 +1185,12 @@ extern "C" int clica_mlp_pack_split_both(int32_t n_layers, const float* const* W
   return launch_pack3(a, stream, "clica_mlp_pack_split_both");
 }
 
+extern "C" int clica_mlp_planes_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && M > 0 && width >= 1, "clica_mlp_planes_bytes: bad argument");
+  *bytes = planes::bytes(M, width, ones_column);
+  return CLICA_OK;
+}
+
 static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* who) {
   using namespace fmlp;
   a.boff[0] = 0;
@@ -1159,7 +1210,8 @@ static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* w
 extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
                                    float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
                                    float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                                   const void* packed_split, uint64_t* const* signmask, float slope, clica_stream_t stream) {
+                                   const void* packed_split, uint64_t* const* signmask, void* const* planes, float slope,
+                                   clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(X && bias && out && ldo && N && K && packed_split && M > 0, "clica_mlp_fwd_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd_split: %d layers (1..%d supported)", n_layers, MAXL);
@@ -1171,11 +1223,14 @@ extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const
   a.packed3 = reinterpret_cast<const u32x4*>(packed_split);
   int64_t off = 0;
   for (int l = 0; l < n_layers; ++l) {
-    CLICA_CHECK_ARG(out[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_fwd_split: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
-    CLICA_CHECK_ARG(ldo[l] >= N[l], "clica_mlp_fwd_split: layer %d: leading dimension too small", l);
+    void* pl = planes ? planes[l] : nullptr;
+    CLICA_CHECK_ARG((out[l] || pl) && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_fwd_split: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
+    CLICA_CHECK_ARG(!out[l] || ldo[l] >= N[l], "clica_mlp_fwd_split: layer %d: leading dimension too small", l);
     CLICA_CHECK_ARG(l == 0 || K[l] == N[l - 1], "clica_mlp_fwd_split: layer %d input width %d != previous output width %d", l, K[l], N[l - 1]);
+    CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(pl) & 15) == 0, "clica_mlp_fwd_split: layer %d: plane buffer must be 16-byte aligned", l);
     unsigned long long* mo = (signmask && signmask[l]) ? reinterpret_cast<unsigned long long*>(signmask[l]) : nullptr;
-    g.layer[l] = Layer{nullptr, 0, bias[l], out[l], ldo[l], nullptr, 0, mo, nullptr, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0};
+    g.layer[l] = Layer{nullptr, 0, bias[l], out[l], ldo[l], nullptr, 0, mo, nullptr, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0,
+                       reinterpret_cast<unsigned short*>(pl), planes::units(N[l], 1), 1};
     a.off3[l] = off; a.ent3[l] = pack3_entries(N[l], K[l]); off += 3 * a.ent3[l];
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd_split: ldx < K[0]");
@@ -1185,7 +1240,7 @@ extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const
 
 extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
                                      const void* packed_split, const uint64_t* const* signmask,
-                                     float* const* out, const int64_t* ldo, float slope, clica_stream_t stream) {
+                                     float* const* out, const int64_t* ldo, void* const* planes, float slope, clica_stream_t stream) {
   using namespace fmlp;
   CLICA_CHECK_ARG(dY && N && K && packed_split && out && ldo && M > 0, "clica_mlp_dgrad_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_links >= 1 && n_links <= MAXL, "clica_mlp_dgrad_split: %d links (1..%d supported)", n_links, MAXL);
@@ -1196,11 +1251,14 @@ extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, i
   a.packed3 = reinterpret_cast<const u32x4*>(packed_split);
   int64_t off = 0;
   for (int j = 0; j < n_links; ++j) {
-    CLICA_CHECK_ARG(out[j] && N[j] >= 1 && K[j] >= 1 && N[j] <= MAXW && K[j] <= MAXW, "clica_mlp_dgrad_split: link %d is %d x %d (max %d)", j, N[j], K[j], MAXW);
-    CLICA_CHECK_ARG(ldo[j] >= N[j], "clica_mlp_dgrad_split: link %d: leading dimension too small", j);
+    void* pl = planes ? planes[j] : nullptr;
+    CLICA_CHECK_ARG((out[j] || pl) && N[j] >= 1 && K[j] >= 1 && N[j] <= MAXW && K[j] <= MAXW, "clica_mlp_dgrad_split: link %d is %d x %d (max %d)", j, N[j], K[j], MAXW);
+    CLICA_CHECK_ARG(!out[j] || ldo[j] >= N[j], "clica_mlp_dgrad_split: link %d: leading dimension too small", j);
     CLICA_CHECK_ARG(j == 0 || K[j] == N[j - 1], "clica_mlp_dgrad_split: link %d contraction %d != previous width %d", j, K[j], N[j - 1]);
+    CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(pl) & 15) == 0, "clica_mlp_dgrad_split: link %d: plane buffer must be 16-byte aligned", j);
     const unsigned long long* mi = (signmask && signmask[j]) ? reinterpret_cast<const unsigned long long*>(signmask[j]) : nullptr;
-    g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], nullptr, 0, nullptr, mi, N[j], K[j], 0, 1};
+    g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], nullptr, 0, nullptr, mi, N[j], K[j], 0, 1,
+                       reinterpret_cast<unsigned short*>(pl), planes::units(N[j], 0), 0};
     a.off3[j] = off; a.ent3[j] = pack3_entries(N[j], K[j]); off += 3 * a.ent3[j];
   }
   CLICA_CHECK_ARG(lddy >= K[0], "clica_mlp_dgrad_split: lddy < K[0]");

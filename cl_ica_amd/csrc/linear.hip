@@ -17,6 +17,7 @@
 // LDS double buffer; one barrier per K tile.  wgrad splits the long contraction (Kc = rows of the
 // batch) over blockIdx.z into fp32 slabs that a second tiny kernel sums deterministically.
 #include "common.h"
+#include "wgrad_shared.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -41,18 +42,6 @@ enum Epi { EPI_BIAS_ACT = 0, EPI_DACT = 1, EPI_SLAB = 2 };
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 // {1, 0, 0, 0}: the first padding column of the wgrad B operand reads this, so the MFMAs produce db = dZ^T 1 there
 __device__ __attribute__((aligned(16))) float g_one_page[4] = {1.f, 0.f, 0.f, 0.f};
-
-struct Args {
-  const float* A; int64_t lda;
-  const float* B; int64_t ldb;
-  float* C; int64_t ldc;
-  int64_t M, N, Kc;
-  const float* bias;      // fwd: [N]
-  const float* xact; int64_t ldxa;  // dgrad: saved activation [M][N]
-  float slope; int leaky;
-  int64_t k_per_split;    // wgrad: contraction rows per blockIdx.z
-  float* dbias_slab;      // wgrad: [splits][M] column sums of A_op rows (db), or nullptr
-};
 
 // ---- tile loaders: global -> registers ------------------------------------------------------
 // CONTIG: operand stored [rows][Kc]; tile = ROWS x BK, float4 along k.
@@ -668,10 +657,7 @@ constexpr size_t kBody2LdsBytes = (size_t)3 * BK * (256 + 128) * sizeof(float);
 // (wave-uniform ds_read_b128 broadcasts) and does S FMAs; the THREADS / Lg groups take interleaved rows and are summed
 // through LDS in fixed order at the end.  Row tiles are register-prefetched one tile ahead.  A work item covers
 // k_per_split batch rows and writes one slab, exactly like the MFMA items (same deterministic slab reduction).
-constexpr int MAXG = 8;            // problems (layers) per grouped launch
-constexpr int TINY_MAX_S = 16;
-constexpr int TINY_ROWS = 64;       // batch rows per LDS tile
-constexpr int TINY_MAX_LG = 128;    // widest large dimension: LDS tile [TINY_ROWS][Lg] = 32 KB
+// (MAXG, TINY_MAX_S, TINY_ROWS, TINY_MAX_LG: wgrad_shared.h)
 // global -> LDS copy of `count` floats of a row block: flat float4 when the block is contiguous and aligned (the
 // encoder's activations / gradients are), element-wise otherwise.  Eight loads are in flight per thread and pass.
 template <int THREADS>
@@ -847,8 +833,6 @@ __device__ __forceinline__ void wgrad_tiny_body(const Args& g, const int bz) {
 // latency-bound per tile (a 64-row tile is ~0.2 us of FMAs behind a ~1-2 us fetch), so the rows are cut into many short
 // chunks that all run at once on the otherwise idle chip (~5 us) -- as long items inside the MFMA launch they crawled
 // behind its HBM traffic and became its tail.
-constexpr int TINY_THREADS = 256;
-struct TinyArgs { int n; Args p[MAXG]; };
 __global__ __launch_bounds__(TINY_THREADS) void wgrad_tiny_k(TinyArgs T) {
   const Args& g = T.p[blockIdx.y];
   const int S = (int)(g.M < g.N ? g.M : g.N);
@@ -980,15 +964,7 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
 }
 
 // grouped variant: the slabs of up to MAXG problems reduced by one launch
-struct ReduceGroupArgs {
-  int n, accumulate;
-  int splits[MAXG];
-  int first[MAXG + 1];      // first block of each problem
-  int dw_blocks[MAXG], vec4[MAXG];
-  const float* slab[MAXG]; const float* dbslab[MAXG];
-  float* dW[MAXG]; float* db[MAXG];
-  int64_t M[MAXG], N[MAXG], lddw[MAXG];
-};
+// (struct ReduceGroupArgs: wgrad_shared.h)
 __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupArgs G) {
   __shared__ float4 red[RED_THREADS / 64][64];
   const int w = threadIdx.x >> 6;
@@ -1173,14 +1149,7 @@ static GroupPlan plan_wgrad_group(int64_t Mrows, int n, const int32_t* N, const 
     const int64_t kps = ceil_div(ceil_div(Mrows, (int64_t)forced), (int64_t)BK) * BK;
     p.k_per_split = kps; p.splits = (int)ceil_div(Mrows, kps);
   }
-  // tiny-dimension layers: their own short launch, ~one workgroup per CU over all of them, 1..2 row tiles each
-  if (p.n_tiny > 0) {
-    int64_t ts = std::max<int64_t>(1, kNumCU / p.n_tiny);
-    const int64_t cap = std::max<int64_t>(1, Mrows / (2 * TINY_ROWS));
-    if (ts > cap) ts = cap;
-    p.tiny_kps = ceil_div(ceil_div(Mrows, ts), (int64_t)TINY_ROWS) * TINY_ROWS;
-    p.tiny_splits = (int)ceil_div(Mrows, p.tiny_kps);
-  }
+  if (p.n_tiny > 0) wgrad_tiny_plan(Mrows, p.n_tiny, &p.tiny_splits, &p.tiny_kps);
   return p;
 }
 static bool group_is_tiny(const GroupPlan& p, int32_t N, int32_t K) { return p.n_tiny > 0 && group_kind(N, K) == 2; }
@@ -1194,6 +1163,41 @@ static size_t group_ws_layout(const GroupPlan& p, int n, const int32_t* N, const
     off += align_up(sp * N[l] * sizeof(float), 256);
   }
   return off;
+}
+
+
+// ---- host-side launchers shared with wgrad_split.hip (wgrad_shared.h) ----------------------------------------------------
+bool wgrad_tiny_shape(int32_t N, int32_t K) { return group_kind(N, K) == 2; }
+void wgrad_tiny_plan(int64_t Mrows, int n_tiny, int* splits, int64_t* k_per_split) {
+  // tiny-dimension layers: their own short launch, ~one workgroup per CU over all of them, 1..2 row tiles each
+  int64_t ts = std::max<int64_t>(1, kNumCU / std::max(1, n_tiny));
+  const int64_t cap = std::max<int64_t>(1, Mrows / (2 * TINY_ROWS));
+  if (ts > cap) ts = cap;
+  *k_per_split = ceil_div(ceil_div(Mrows, ts), (int64_t)TINY_ROWS) * TINY_ROWS;
+  *splits = (int)ceil_div(Mrows, *k_per_split);
+}
+int launch_wgrad_tiny(const TinyArgs& T, int splits, hipStream_t st) {
+  constexpr size_t tiny_lds = (size_t)(TINY_ROWS * TINY_MAX_LG + TINY_ROWS * TINY_MAX_S) * sizeof(float) + 1024;
+  static bool once_t = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tiny_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiny_lds), true);
+  (void)once_t;
+  // (forking this launch onto a side stream so that it runs UNDER the grouped launch instead of in front of it was measured:
+  //  the grouped kernel slows down by more than the 12 us the fork hides, 1329 vs 1334 steps/s -- not kept)
+  hipLaunchKernelGGL(wgrad_tiny_k, dim3((unsigned)splits, (unsigned)T.n), dim3(TINY_THREADS), tiny_lds, st, T);
+  return launch_status("clica_mlp_wgrad(tiny)");
+}
+int launch_slab_reduce_group(const ReduceGroupArgs& R, int blocks, hipStream_t st) {
+  hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)blocks), dim3(RED_THREADS), 0, st, R);
+  return launch_status("clica_mlp_wgrad(reduce)");
+}
+int slab_reduce_entry(ReduceGroupArgs& R, int l, int first_block, int sp, const float* slab, const float* dbslab,
+                      float* dW, int64_t lddw, float* db, int32_t N, int32_t K) {
+  const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW);
+  R.vec4[l] = v4 ? 1 : 0; R.splits[l] = sp;
+  R.dw_blocks[l] = (int)ceil_div(v4 ? (int64_t)N * K / 4 : (int64_t)N * K, 64);
+  R.first[l] = first_block;
+  R.slab[l] = slab; R.dbslab[l] = dbslab; R.dW[l] = dW; R.db[l] = db;
+  R.M[l] = N; R.N[l] = K; R.lddw[l] = lddw;
+  return R.dw_blocks[l] + (db ? (int)ceil_div(N, 64) : 0);
 }
 
 }  // namespace gemm
@@ -1252,22 +1256,11 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
       G.first[ng] = item; item += G.gx[ng] * G.gy[ng] * sp;
       ++ng;
     }
-    const bool v4 = (K[l] % 4 == 0) && (lddw[l] % 4 == 0) && aligned16(dW[l]);
-    R.vec4[l] = v4 ? 1 : 0; R.splits[l] = sp;
-    R.dw_blocks[l] = (int)ceil_div(v4 ? (int64_t)N[l] * K[l] / 4 : (int64_t)N[l] * K[l], 64);
-    R.first[l] = rblock; rblock += R.dw_blocks[l] + (db[l] ? (int)ceil_div(N[l], 64) : 0);
-    R.slab[l] = slab; R.dbslab[l] = dbslab; R.dW[l] = dW[l]; R.db[l] = db[l];
-    R.M[l] = N[l]; R.N[l] = K[l]; R.lddw[l] = lddw[l];
+    rblock += slab_reduce_entry(R, l, rblock, sp, slab, dbslab, dW[l], lddw[l], db[l], N[l], K[l]);
   }
   G.n = ng; G.first[ng] = G.total = item; R.first[n_layers] = rblock;
   if (T.n > 0) {
-    constexpr size_t tiny_lds = (size_t)(TINY_ROWS * TINY_MAX_LG + TINY_ROWS * TINY_MAX_S) * sizeof(float) + 1024;
-    static bool once_t = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_tiny_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tiny_lds), true);
-    (void)once_t;
-    // (forking this launch onto a side stream so that it runs UNDER the grouped launch instead of in front of it was measured:
-    //  the grouped kernel slows down by more than the 12 us the fork hides, 1329 vs 1334 steps/s -- not kept)
-    hipLaunchKernelGGL(wgrad_tiny_k, dim3((unsigned)p.tiny_splits, (unsigned)T.n), dim3(TINY_THREADS), tiny_lds, st, T);
-    int rct = launch_status("clica_mlp_wgrad(tiny)");
+    int rct = launch_wgrad_tiny(T, p.tiny_splits, st);
     if (rct) return rct;
   }
   if (ng > 0) {
@@ -1281,8 +1274,7 @@ extern "C" int clica_mlp_wgrad(int64_t M, int32_t n_layers, const float* const* 
     int rc = launch_status("clica_mlp_wgrad");
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)rblock), dim3(RED_THREADS), 0, st, R);
-  return launch_status("clica_mlp_wgrad(reduce)");
+  return launch_slab_reduce_group(R, rblock, st);
 }
 
 extern "C" int clica_linear_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* bias,

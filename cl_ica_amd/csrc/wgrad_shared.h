@@ -1,0 +1,51 @@
+// Pieces of the grouped weight-gradient path shared by linear.hip (fp32 MFMA bodies, tiny-dimension VALU kernel, deterministic
+// slab reduction) and wgrad_split.hip (the split-bf16 MFMA body): argument blocks and the host-side launchers of the two
+// helper kernels, which both arithmetic modes use unchanged.
+#pragma once
+#include "common.h"
+
+namespace clica {
+namespace gemm {
+
+// One GEMM problem C[M,N] = A_op[M,Kc] * B_op[Kc,N] (see linear.hip for the three operand layouts).
+struct Args {
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int64_t M, N, Kc;
+  const float* bias;      // fwd: [N]
+  const float* xact; int64_t ldxa;  // dgrad: saved activation [M][N]
+  float slope; int leaky;
+  int64_t k_per_split;    // wgrad: contraction rows per blockIdx.z
+  float* dbias_slab;      // wgrad: [splits][M] column sums of A_op rows (db), or nullptr
+};
+
+constexpr int MAXG = 8;             // problems (layers) per grouped launch
+constexpr int TINY_MAX_S = 16;
+constexpr int TINY_ROWS = 64;       // batch rows per LDS tile
+constexpr int TINY_MAX_LG = 128;    // widest large dimension: LDS tile [TINY_ROWS][Lg] = 32 KB
+constexpr int TINY_THREADS = 256;
+struct TinyArgs { int n; Args p[MAXG]; };
+
+// grouped slab reduction: dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i]  for up to MAXG problems
+struct ReduceGroupArgs {
+  int n, accumulate;
+  int splits[MAXG];
+  int first[MAXG + 1];      // first block of each problem
+  int dw_blocks[MAXG], vec4[MAXG];
+  const float* slab[MAXG]; const float* dbslab[MAXG];
+  float* dW[MAXG]; float* db[MAXG];
+  int64_t M[MAXG], N[MAXG], lddw[MAXG];
+};
+
+// host side (defined in linear.hip)
+bool wgrad_tiny_shape(int32_t N, int32_t K);                                    // the layer takes the tiny-dimension VALU kernel
+void wgrad_tiny_plan(int64_t Mrows, int n_tiny, int* splits, int64_t* k_per_split);
+int launch_wgrad_tiny(const TinyArgs& T, int splits, hipStream_t st);
+int launch_slab_reduce_group(const ReduceGroupArgs& R, int blocks, hipStream_t st);
+// fills the reduction entry of problem l (dW [N][K], `sp` slabs) and returns the number of blocks it adds
+int slab_reduce_entry(ReduceGroupArgs& R, int l, int first_block, int sp, const float* slab, const float* dbslab,
+                      float* dW, int64_t lddw, float* db, int32_t N, int32_t K);
+
+}  // namespace gemm
+}  // namespace clica

@@ -1,0 +1,367 @@
+// Weight gradients of the MLP encoder (get_mlp, /root/reference/encoders.py:36-48: the dW / db that autograd's
+// nn.Linear backward produces) on the bf16 matrix cores with EXACT 3-way operand splits -- the weight-gradient half of the
+// split-bf16 mode (fused_mlp.hip: mlp_split_k is the forward / backward-chain half).
+//
+//   dW_l[N, K] = dZ_l^T X_l,   db_l = dZ_l^T 1          (contraction over the 2B batch rows)
+//
+// Arithmetic: every fp32 operand value v is hi + mid + lo (three bf16 pieces, 8 + 8 + 8 mantissa bits by truncation, exact),
+// and a product a.b is taken as the six piece products of order <= 2 (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi), each
+// exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the dropped products are below 2^-24 |a||b|.  fp32
+// emulation, not reduced precision (same scheme and error as mlp_split_k: 8.6e-7 of max|y| against fp64, the fp32-MFMA
+// kernels 1.0e-6).  Six 8-pass bf16 instructions cover K = 16 where fp32 MFMA needs eight 16-pass ones: 0.375 of the matrix time.
+//
+// Operands: both have the contraction along the batch rows, i.e. a bf16 MFMA operand (eight consecutive k per lane) is a
+// TRANSPOSED read of the row-major tensors.  The producers (mlp_split_k epilogues, which hold the three pieces of every
+// output value in registers anyway) therefore write the operands as bf16 planes in 16-row x 32-feature units (planes.h);
+// a 1 KB piece goes HBM/L2 -> LDS with one global_load_lds_dwordx4 per wave (no VGPRs, no ds_write) and an operand
+// fragment is two ds_read_b64_tr_b16 (the LDS transposing read of gfx950).  The fp32 copies of the hidden activations /
+// gradients are not written at all in this mode (6 B instead of 4 B per element, but read by nobody else).
+//
+// Work decomposition = the fp32 grouped kernel's (linear.hip: wgrad_group_k): items (layer, contraction split, 256 x 128 or
+// 128 x 256 output tile) of equal length, one 8-wave workgroup per CU, fp32 slabs + the shared deterministic slab reduction;
+// db comes out of the matrix cores through the constant-1 feature the producer appends to X (planes.h).  Layers with a
+// tiny dimension (the n-wide first / last layer) keep the fp32 VALU kernel (wgrad_tiny_k) on fp32 operands.
+#include "common.h"
+#include "planes.h"
+#include "wgrad_shared.h"
+#include <algorithm>
+#include <stdlib.h>
+
+namespace clica {
+namespace wsplit {
+
+using gemm::MAXG;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int STG = 4;                      // LDS stages of one 16-row step each
+constexpr int UW = 8, UN = 4;               // 32-feature units of the wide / narrow side of a tile (256 / 128 features)
+constexpr int PIECES = 3 * (UW + UN);       // one-KB pieces per step (36 KB)
+constexpr int STAGE_BYTES = PIECES * 1024;
+constexpr int THREADS = 512;
+constexpr size_t kLdsBytes = (size_t)STG * STAGE_BYTES;      // 144 KB
+
+struct Prob {
+  const char* A; const char* B;   // plane buffers of dZ_l (rows of dW) and X_l (columns of dW)
+  int fuA, fuB;                   // 32-feature units per 16-row group
+  float* C; int64_t ldc;          // slabs [splits][M][ldc]
+  float* dbslab;                  // [splits][M] or nullptr
+  int M, N;                       // dW rows (N_l) and columns (K_l)
+  int groups, gps;                // 16-row groups of the batch; groups per contraction split
+  int gx, gy, a_wide;             // tiles along the columns / rows; 1: 256 x 128 tiles, 0: 128 x 256
+};
+struct GroupArgs { int n, total; int first[MAXG + 1]; Prob p[MAXG]; };
+
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) char* lds_ptr;
+// one wave instruction: 64 lanes x 16 B from per-lane global addresses to the lane-linear 1 KB at LDS offset `lds_off`.
+// Issued from inline asm: the compiler does not see an LDS write through VMEM (it would serialise every later ds_read
+// behind vmcnt(0)); the waits in the loop below are the exact ones.
+__device__ __forceinline__ void dma_1k(const char* lane_src, unsigned lds_off) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(lane_src), "s"(lds_off) : "memory", "m0");
+#pragma clang diagnostic pop
+}
+template <int N> __device__ __forceinline__ void wait_vm() {   // s_waitcnt vmcnt(N) only (gfx9 encoding)
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+// A fragment is kept as four 32-bit registers (not as eight bf16 values: across the loop's back edge the optimiser would
+// split a bf16 vector into 16-bit scalars and re-pack it with v_perm_b32 in front of every MFMA).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x4 frag_t;
+__device__ __forceinline__ frag_t read_frag(const char* p) {   // keys 8h .. 8h+3 and 8h+4 .. 8h+7 of this lane's feature (planes.h)
+  const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds_ptr)p));
+  const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds_ptr)(p + 256)));
+  return (frag_t){a.x, a.y, b.x, b.y};
+}
+
+// Debug build only (-DCLICA_WSPLIT_TRACE): s_memtime stamps per (workgroup, wave, phase)
+#ifdef CLICA_WSPLIT_TRACE
+__device__ unsigned long long* g_wstrace = nullptr;
+#define WS_STAMP(ph) do { if (g_wstrace && (threadIdx.x & 63) == 0) g_wstrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (ph)] = clock64(); } while (0)
+#else
+#define WS_STAMP(ph) do { } while (0)
+#endif
+
+// One work item: output tile (bx, by) of problem g over the row groups of contraction split bz.
+// Eight waves, wave tile 64 x 64 = 2 x 2 accumulator blocks of 32 x 32 (64 registers); per 16-row step a wave reads
+// 2 + 2 unit fragments x 3 planes (24 transposing reads of 512 B) and issues 24 MFMAs (768 matrix cycles).
+// Pipeline: four 36 KB stages; the pieces of step t + 3 are requested behind the barrier of step t, the fragments of
+// step t + 1 are read during the MFMAs of step t (two register sets, ping-pong), one barrier per step.
+template <bool A_WIDE>
+__device__ __forceinline__ void body(const Prob& g, const int bx, const int by, const int bz) {
+  constexpr int UA = A_WIDE ? UW : UN, UB = A_WIDE ? UN : UW;
+  constexpr int BM = UA * 32, BN = UB * 32;
+  constexpr int WN = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
+  const int g0 = bz * g.gps;
+  const int nt = min(g.groups, g0 + g.gps) - g0;
+  WS_STAMP(0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // this wave's DMA pieces: piece pi = wave + 8 j of the stage image [A: UA units x 3 planes][B: UB units x 3 planes];
+  // units beyond the tensor (a tile that sticks out) are read from a 16-byte page of zeros with stride 0
+  const bool five = wave < PIECES - 32;                      // waves 0..3 move five pieces per step, waves 4..7 four
+  const char* src[5]; int stride[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const int pi = wave + 8 * j;
+    const bool is_a = pi < 3 * UA;
+    const int q = is_a ? pi : pi - 3 * UA;
+    const int unit = q / 3, plane = q - 3 * unit;
+    const int u = (is_a ? by * UA : bx * UB) + unit, fu = is_a ? g.fuA : g.fuB;
+    const bool ok = pi < PIECES && u < fu;
+    const char* base = is_a ? g.A : g.B;
+    src[j] = ok ? base + (((int64_t)g0 * fu + u) * 3 + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
+    stride[j] = ok ? fu * planes::kUnitBytes : 0;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+  auto issue = [&](int t) {
+    const unsigned st = lds0 + (unsigned)((t % STG) * STAGE_BYTES + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dma_1k(src[j], st + 8192u * j); src[j] += stride[j]; }
+    if (five) { dma_1k(src[4], st + 8192u * 4); src[4] += stride[4]; }
+  };
+  // at most `k` of the most recently requested steps may still be in flight
+  auto wait_steps = [&](int k) {
+    if (k <= 0) wait_vm<0>();
+    else if (five) { if (k == 1) wait_vm<5>(); else wait_vm<10>(); }
+    else { if (k == 1) wait_vm<4>(); else wait_vm<8>(); }
+  };
+
+  const int lane_off = h * 512 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+  const char* fa_base = smem + lane_off + (wm * 2) * 3 * 1024;
+  const char* fb_base = smem + lane_off + (UA + wn * 2) * 3 * 1024;
+  frag_t fa0[3][2], fb0[3][2], fa1[3][2], fb1[3][2];
+  auto load_frags = [&](frag_t (&fa)[3][2], frag_t (&fb)[3][2], int t) {
+    const int so = (t % STG) * STAGE_BYTES;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[p][i] = read_frag(fa_base + so + (3 * i + p) * 1024);
+        fb[p][i] = read_frag(fb_base + so + (3 * i + p) * 1024);
+      }
+  };
+  auto mma = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // (dZ piece, X piece), small terms first
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]), acc[i][j], 0, 0, 0);
+  };
+  // step t: [tile t + 1 landed for every wave] -> request tile t + 3 -> read the fragments of t + 1 under the MFMAs of t
+  auto step = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], frag_t (&na)[3][2], frag_t (&nb)[3][2], int t) {
+    if (t + 1 < nt) {
+      wait_steps(t + 2 < nt ? 1 : 0);
+      __syncthreads();               // ... and every wave has read what it needs of stage (t - 1) % STG (the fragments of step t - 1)
+      if (t + 3 < nt) issue(t + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      load_frags(na, nb, t + 1);
+    }
+    mma(fa, fb);
+  };
+
+  if (nt > 0) issue(0);
+  if (nt > 1) issue(1);
+  if (nt > 2) issue(2);
+  wait_steps(nt > 2 ? 2 : nt - 1);
+  __syncthreads();
+  WS_STAMP(1);
+  if (nt > 0) load_frags(fa0, fb0, 0);
+  int t = 0;
+  for (; t + 1 < nt; t += 2) {
+    step(fa0, fb0, fa1, fb1, t);
+    step(fa1, fb1, fa0, fb0, t + 1);
+  }
+  if (t < nt) step(fa0, fb0, fa1, fb1, t);
+  WS_STAMP(2);
+
+  // slab epilogue (same layout as the fp32 kernel: accumulator row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31)
+  const int m0 = by * BM, n0 = bx * BN;
+  float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      const bool is_db = g.dbslab && col == g.N;          // the constant-1 feature of X: db = dZ^T 1
+      if (col >= g.N && !is_db) continue;
+      float* dst = is_db ? g.dbslab + (int64_t)bz * g.M : Cbase + col;
+      const int64_t ld = is_db ? 1 : g.ldc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        dst[row * ld] = acc[i][j][r];
+      }
+    }
+  }
+  WS_STAMP(3);
+}
+
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg) {     // each XCD walks a contiguous range of the work items
+  const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+__global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
+  const int id = xcd_contiguous(blockIdx.x, G.total);
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < MAXG; ++i) q += (i < G.n && id >= G.first[i]) ? 1 : 0;
+  const Prob& g = G.p[q];
+  const int local = id - G.first[q];
+  const int tiles = g.gx * g.gy;
+  const int bz = local / tiles, t = local - bz * tiles;
+  const int by = t / g.gx, bx = t - by * g.gx;
+  if (g.a_wide) body<true>(g, bx, by, bz); else body<false>(g, bx, by, bz);
+}
+
+#ifdef CLICA_WSPLIT_TRACE
+extern "C" int clica_debug_wsplit_trace(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(clica::wsplit::g_wstrace), &buf, sizeof(buf));
+}
+#endif
+
+// ---- plan: which body per layer, how many contraction splits -----------------------------------------------------------------
+struct Plan { int splits, gps, groups, tiles, n_tiny, tiny_splits; int64_t tiny_kps; };
+static void tile_shape(int32_t N, int32_t K, int* a_wide, int* gx, int* gy, bool with_db) {
+  *a_wide = N >= K ? 1 : 0;
+  const int bm = *a_wide ? 256 : 128, bn = *a_wide ? 128 : 256;
+  *gy = (int)ceil_div(N, bm);
+  *gx = (int)ceil_div(K + (with_db ? 1 : 0), bn);
+}
+static Plan make_plan(int64_t Mrows, int n, const int32_t* N, const int32_t* K) {
+  Plan p{};
+  p.groups = (int)planes::groups_used(Mrows);
+  for (int l = 0; l < n; ++l) {
+    if (gemm::wgrad_tiny_shape(N[l], K[l])) { ++p.n_tiny; continue; }
+    int aw, gx, gy; tile_shape(N[l], K[l], &aw, &gx, &gy, true);
+    p.tiles += gx * gy;
+  }
+  // rounds of (gps x 16)-row items + a fixed prologue / slab epilogue per round + slab traffic per split (same cost model
+  // as the fp32 plan, linear.hip: plan_wgrad_group)
+  const int max_s = std::max(1, std::min(64, p.groups / 8));
+  double best = 1e300;
+  p.splits = 1; p.gps = p.groups;
+  for (int s = 1; s <= max_s && p.tiles > 0; ++s) {
+    const int gps = (int)ceil_div(p.groups, s), sp = (int)ceil_div(p.groups, gps);
+    const int64_t rounds = ceil_div((int64_t)p.tiles * sp, kNumCU);
+    const double cost = (double)rounds * (16.0 * gps + 48.0) + 8.0 * sp;
+    if (cost < best) { best = cost; p.splits = sp; p.gps = gps; }
+  }
+  static const int forced = [] { const char* e = getenv("CLICA_WSPLIT_SPLITS"); return e ? atoi(e) : 0; }();
+  if (forced > 0) { p.gps = (int)ceil_div(p.groups, forced); p.splits = (int)ceil_div(p.groups, p.gps); }
+  if (p.n_tiny > 0) gemm::wgrad_tiny_plan(Mrows, p.n_tiny, &p.tiny_splits, &p.tiny_kps);
+  return p;
+}
+static size_t ws_layout(const Plan& p, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
+  size_t off = 0;
+  for (int l = 0; l < n; ++l) {
+    const size_t sp = gemm::wgrad_tiny_shape(N[l], K[l]) ? p.tiny_splits : p.splits;
+    if (slab_off) slab_off[l] = off;
+    off += align_up(sp * N[l] * K[l] * sizeof(float), 256);
+    if (db_off) db_off[l] = off;
+    off += align_up(sp * N[l] * sizeof(float), 256);
+  }
+  return off;
+}
+
+}  // namespace wsplit
+}  // namespace clica
+
+using namespace clica;
+using namespace clica::wsplit;
+
+extern "C" int clica_mlp_wgrad_split_kind(int32_t N, int32_t K, int32_t* kind) {
+  CLICA_CHECK_ARG(kind && N >= 1 && K >= 1, "clica_mlp_wgrad_split_kind: bad argument");
+  *kind = gemm::wgrad_tiny_shape(N, K) ? 1 : 0;
+  return CLICA_OK;
+}
+
+extern "C" int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && N && K && M > 0 && n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_split_workspace_bytes: bad argument");
+  for (int l = 0; l < n_layers; ++l) CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1, "clica_mlp_wgrad_split_workspace_bytes: layer %d: bad size", l);
+  *bytes = ws_layout(make_plan(M, n_layers, N, K), n_layers, N, K, nullptr, nullptr);
+  return CLICA_OK;
+}
+
+extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                     const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                     float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                     int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dZ_planes && X_planes && dZ && lddz && X && ldx && dW && lddw && db && N && K && workspace && M > 0,
+                  "clica_mlp_wgrad_split: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_split: %d layers (1..%d supported)", n_layers, MAXG);
+  const Plan p = make_plan(M, n_layers, N, K);
+  size_t slab_off[MAXG], db_off[MAXG];
+  const size_t need = ws_layout(p, n_layers, N, K, slab_off, db_off);
+  if (need > workspace_bytes) { set_error("clica_mlp_wgrad_split: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  hipStream_t st = as_stream(stream);
+  GroupArgs G{};
+  gemm::ReduceGroupArgs R{};
+  gemm::TinyArgs T{};
+  R.n = n_layers; R.accumulate = accumulate ? 1 : 0;
+  int item = 0, rblock = 0, ng = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(dW[l] && N[l] >= 1 && K[l] >= 1 && lddw[l] >= K[l], "clica_mlp_wgrad_split: layer %d: bad argument", l);
+    const bool tiny = gemm::wgrad_tiny_shape(N[l], K[l]);
+    const int sp = tiny ? p.tiny_splits : p.splits;
+    float* slab = (float*)((char*)workspace + slab_off[l]);
+    float* dbslab = (float*)((char*)workspace + db_off[l]);
+    if (tiny) {
+      CLICA_CHECK_ARG(dZ[l] && X[l] && lddz[l] >= N[l] && ldx[l] >= K[l],
+                      "clica_mlp_wgrad_split: layer %d (%d x %d) takes the fp32 tiny-dimension kernel: fp32 operands required", l, N[l], K[l]);
+      gemm::Args g{};
+      g.A = dZ[l]; g.lda = lddz[l]; g.B = X[l]; g.ldb = ldx[l]; g.C = slab; g.ldc = K[l]; g.M = N[l]; g.N = K[l]; g.Kc = M;
+      g.k_per_split = p.tiny_kps; g.dbias_slab = db[l] ? dbslab : nullptr;
+      T.p[T.n++] = g;
+    } else {
+      CLICA_CHECK_ARG(dZ_planes[l] && X_planes[l], "clica_mlp_wgrad_split: layer %d (%d x %d) needs the bf16 plane copies of both "
+                      "operands (clica_mlp_fwd_split / clica_mlp_dgrad_split with a plane buffer)", l, N[l], K[l]);
+      CLICA_CHECK_ARG(((reinterpret_cast<uintptr_t>(dZ_planes[l]) | reinterpret_cast<uintptr_t>(X_planes[l])) & 15) == 0,
+                      "clica_mlp_wgrad_split: layer %d: plane buffers must be 16-byte aligned", l);
+      Prob& g = G.p[ng];
+      g.A = reinterpret_cast<const char*>(dZ_planes[l]); g.fuA = planes::units(N[l], 0);
+      g.B = reinterpret_cast<const char*>(X_planes[l]); g.fuB = planes::units(K[l], 1);
+      g.C = slab; g.ldc = K[l]; g.dbslab = db[l] ? dbslab : nullptr; g.M = N[l]; g.N = K[l];
+      g.groups = p.groups; g.gps = p.gps;
+      tile_shape(N[l], K[l], &g.a_wide, &g.gx, &g.gy, db[l] != nullptr);
+      G.first[ng] = item; item += g.gx * g.gy * sp;
+      ++ng;
+    }
+    rblock += gemm::slab_reduce_entry(R, l, rblock, sp, slab, dbslab, dW[l], lddw[l], db[l], N[l], K[l]);
+  }
+  G.n = ng; G.first[ng] = G.total = item; R.first[n_layers] = rblock;
+  if (T.n > 0) {
+    int rct = gemm::launch_wgrad_tiny(T, p.tiny_splits, st);
+    if (rct) return rct;
+  }
+  if (ng > 0) {
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
+    (void)once;
+    hipLaunchKernelGGL(wgrad_split_k, dim3((unsigned)item), dim3(THREADS), kLdsBytes, st, G);
+    int rc = launch_status("clica_mlp_wgrad_split");
+    if (rc) return rc;
+  }
+  return gemm::launch_slab_reduce_group(R, rblock, st);
+}

@@ -105,8 +105,10 @@ class ContrastiveTrainer:
         self.packed_t = None
         self._packed_current = False
         self.fused_backward = self.fused_forward and os.environ.get("CLICA_FUSED_BWD", "1") != "0" and len(self.linears) > 1
-        # opt-in: the two whole-stack kernels on the bf16 matrix cores with exact 3-way bf16 operand splits (fp32-grade)
-        want_split = (os.environ.get("CLICA_SPLIT_BF16", "0") == "1") if split_bf16 is None else bool(split_bf16)
+        # encoder arithmetic: the whole-stack kernels and the weight gradients on the bf16 matrix cores with exact 3-way bf16
+        # operand splits (fp32 emulation: six bf16 products per fp32 product, fp32 accumulate, fp32-grade error) --
+        # the default where the encoder fits the whole-stack kernels; split_bf16=False / CLICA_SPLIT_BF16=0 = native fp32 MFMA
+        want_split = (os.environ.get("CLICA_SPLIT_BF16", "1") == "1") if split_bf16 is None else bool(split_bf16)
         self.split_bf16 = self.fused_backward and want_split and all(lin.bias is not None for lin in self.linears) and \
             sum((lin.out_features + 31) // 32 * 32 for lin in self.linears) <= 3456      # on-chip bias table (fused_mlp.hip)
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
@@ -212,6 +214,29 @@ class ContrastiveTrainer:
         self.group_ws = ops.mlp_wgrad_workspace(R, [tuple(lin.weight.shape) for lin in self.linears], dev) if self.grouped_wgrad else None
         # sign bits of every hidden activation, written by the fused forward, read by the fused backward chain
         self.signmasks = (ops.mlp_signmask_alloc(R, len(self.linears) - 1, dev) + [None]) if self.fused_backward else None
+        # split-bf16 weight gradients (csrc/wgrad_split.hip): the MFMA-sized layers read BOTH operands as bf16 planes that the
+        # split forward / backward-chain kernels write instead of the fp32 copies (nobody else reads a hidden activation or
+        # dZ); the tiny first / last layer keeps the fp32 VALU kernel, so the tensors next to them stay fp32 as well.
+        L = len(self.linears)
+        kinds = [ops.mlp_wgrad_split_kind(lin.out_features, lin.in_features) for lin in self.linears] if self.split_bf16 else []
+        self.split_wgrad = bool(self.split_bf16 and self.grouped_wgrad and L >= 3 and kinds[0] == 1 and kinds[-1] == 1
+                                and os.environ.get("CLICA_SPLIT_WGRAD", "1") != "0")
+        self.act_planes = [None] * L
+        self.dz_planes = [None] * L
+        self.acts_out = list(self.acts)                      # what the forward writes as fp32 (None: planes only)
+        self.dz_out = list(self.dz) if self.dz is not None else None
+        if self.split_wgrad:
+            keep = os.environ.get("CLICA_SPLIT_KEEP_FP32", "0") == "1"      # debug: also write every fp32 copy
+            for l in range(L):
+                if kinds[l] == 0:                            # dW_l = dZ_l^T acts_{l-1} on the bf16 matrix cores
+                    self.act_planes[l - 1] = ops.mlp_planes_alloc(R, widths[l - 1], True, dev)
+                    self.dz_planes[l] = ops.mlp_planes_alloc(R, widths[l], False, dev)
+            for l in range(L - 1):
+                if not keep and kinds[l + 1] == 0:           # acts[l] feeds only an MFMA-sized weight gradient
+                    self.acts_out[l] = None
+                if not keep and kinds[l] == 0:
+                    self.dz_out[l] = None
+            self.group_ws = ops.mlp_wgrad_split_workspace(R, [tuple(lin.weight.shape) for lin in self.linears], dev)
         if self.head is not None:
             self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
             hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
@@ -283,8 +308,8 @@ class ContrastiveTrainer:
             if self._x_pending:          # latents in, x = g(z) computed in the kernel prologue and stored to self.x
                 cur, mix, self._x_pending = self.z, (self.gW, self.g_slope, self.x), False
             if self.split_bf16:
-                ops.mlp_fwd_split(cur, ws, [lin.bias for lin in self.linears], self.acts, self.packed, self.slope,
-                                  signmasks=self.signmasks, mix=mix)
+                ops.mlp_fwd_split(cur, ws, [lin.bias for lin in self.linears], self.acts_out, self.packed, self.slope,
+                                  signmasks=self.signmasks, mix=mix, planes=self.act_planes if self.split_wgrad else None)
             else:
                 ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
                             signmasks=self.signmasks, mix=mix)
@@ -347,7 +372,8 @@ class ContrastiveTrainer:
                                              self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n,
                                              self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd_sym")
 
-    def backward(self):
+    def _head_backward(self):
+        """d loss / d (pre-head output): the head's backward (and its parameter gradient), or dy itself."""
         lib, st = _lib.load(), _lib.stream_ptr()
         g = self.dy
         R, n = g.shape
@@ -364,33 +390,51 @@ class ContrastiveTrainer:
                 hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
                 torch.sum(self.head_part, dim=0, out=self._gviews[id(hp)])
             g = self.dpre
+        return g
+
+    def backward_chain(self, g):
+        """Whole data-gradient chain dZ_{L-1} -> ... -> dZ_0 in ONE launch (dZ panel resident in LDS, transposed
+        fragment-order weights); every dZ_l is also written to HBM (fp32 and / or bf16 planes) for the weight gradients."""
+        L = len(self.linears)
+        chain = list(range(L - 1, 0, -1))
+        ws = [self.linears[l].weight for l in chain]
+        if not self._packed_current:
+            self.pack()
+        if self.split_bf16:
+            ops.mlp_dgrad_chain_split(g, ws, self.packed_t, [self.dz_out[l - 1] for l in chain], self.slope,
+                                      masks_chain=[self.signmasks[l - 1] for l in chain],
+                                      planes=[self.dz_planes[l - 1] for l in chain] if self.split_wgrad else None)
+        else:
+            ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
+                                masks_chain=[self.signmasks[l - 1] for l in chain])
+
+    def weight_grads(self, g):
+        """Every layer's dW / db: tiny-layer launch + one grouped split-K GEMM of equal-length work items + one grouped slab
+        reduction (fp32 MFMA on the fp32 copies, or bf16x3 MFMA on the plane copies in split mode)."""
+        L = len(self.linears)
+        R = g.shape[0]
+        order = list(range(L))
+        dWs = [self._gviews[id(self.linears[l].weight)] for l in order]
+        dbs = [self._gviews[id(self.linears[l].bias)] for l in order]
+        if self.split_wgrad:
+            ops.mlp_wgrad_split(R, self.dz_planes, [self.act_planes[l - 1] if l > 0 else None for l in order],
+                                [g if l == L - 1 else self.dz_out[l] for l in order],
+                                [self.acts_out[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
+        else:
+            ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
+                          [self.acts[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
+
+    def backward(self):
+        g = self._head_backward()
         L = len(self.linears)
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         side = self.side_stream
         two = side is not None and main is not None
         if self.fused_backward:
-            # (1) whole data-gradient chain dZ_{L-1} -> ... -> dZ_0 in ONE launch (dZ panel resident in LDS,
-            #     transposed fragment-order weights), every dZ_l also written to HBM;
-            # (2) the weight-gradient GEMMs, independent of each other, alternate between two streams so one's
-            #     prologue / slab reduction hides behind the other's MFMA phase.
-            chain = list(range(L - 1, 0, -1))
-            ws = [self.linears[l].weight for l in chain]
-            if not self._packed_current:
-                self.pack()
-            if self.split_bf16:
-                ops.mlp_dgrad_chain_split(g, ws, self.packed_t, [self.dz[l - 1] for l in chain], self.slope,
-                                          masks_chain=[self.signmasks[l - 1] for l in chain])
-            else:
-                ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
-                                    masks_chain=[self.signmasks[l - 1] for l in chain])
+            # (1) the data-gradient chain in one launch; (2) the weight-gradient GEMMs
+            self.backward_chain(g)
             if self.grouped_wgrad:
-                # (2) every layer's dW/db in two launches: one grouped split-K GEMM of equal-length work items
-                #     + one grouped slab reduction; under DP a single all-reduce of the flat gradient arena follows
-                order = list(range(L))
-                ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
-                              [self.acts[l - 1] if l > 0 else self.x for l in order],
-                              [self._gviews[id(self.linears[l].weight)] for l in order],
-                              [self._gviews[id(self.linears[l].bias)] for l in order], ws=self.group_ws)
+                self.weight_grads(g)
                 if self.buckets is not None:
                     for i in range(L):
                         self.buckets.layer_done(i)
@@ -486,6 +530,9 @@ class ContrastiveTrainer:
         ``[loss_mean, pos_mean, neg_mean]`` of this rank's rows (no host sync)."""
         if self.graph is not None:
             self.graph.replay()
+            # a replay updates the parameter arena without passing through ops.adam_step: caches derived from the weights
+            # (the drop-in encoder's fragment-order packs, encoders._MLPFusedFn) key on this epoch and must see the change
+            ops.PARAM_EPOCH += 1
         else:
             self._step_body(True)
         return self.loss_out[3 * self.B:]
@@ -493,6 +540,7 @@ class ContrastiveTrainer:
     def step_injected(self, z1, z2):
         self.inject(z1, z2)
         self._step_body(False)
+        ops.PARAM_EPOCH += 1
         return self.loss_out[3 * self.B:]
 
     def capture(self, warmup: int = 3):

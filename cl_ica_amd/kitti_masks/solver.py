@@ -15,6 +15,7 @@ flat gradient arena is all-reduced once per step -- the single-process loss on t
 """
 from __future__ import annotations
 
+import contextlib
 import itertools
 import os
 
@@ -62,6 +63,7 @@ class Solver(object):
         self.global_iter = 0
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
 
         self.net = BetaVAE_H(self.z_dim, self.nc, args.box_norm).to(self.device)
         if self.world > 1:          # replicas start identical whatever each rank's RNG state was
@@ -99,17 +101,27 @@ class Solver(object):
         """Runs until ``max_iter`` iterations have been done; returns False (the reference's `failure` flag, never set there)."""
         self.net_mode(train=True)
         window = _WindowMean(self.log_step)
-        with open(os.path.join(self.output_dir, "log.csv"), "a", 1) as log:
-            log.write("Total Loss\n")
+        # data parallel: rank 0 alone owns log.csv and the checkpoints (replicas are identical after every step); the logged
+        # value is the mean over the ranks' row blocks = the loss of the global batch
+        writer = self.rank == 0
+        with (open(os.path.join(self.output_dir, "log.csv"), "a", 1) if writer else contextlib.nullcontext()) as log:
+            if writer:
+                log.write("Total Loss\n")
             for images in self._batches():
-                mean = window.push(self.train_iteration(images).item())
+                total = self.train_iteration(images).detach()
+                if self.world > 1:
+                    total = total.clone()
+                    dist.all_reduce(total, op=dist.ReduceOp.SUM)
+                    total /= self.world
+                mean = window.push(total.item())
                 self.global_iter += 1
-                if mean is not None:
-                    log.write("%.6f\n" % mean)
-                if self.global_iter % self.save_step == 0:
-                    self.save_checkpoint("last")
-                if self.global_iter % _MILESTONE == 0:
-                    self.save_checkpoint(str(self.global_iter))
+                if writer:
+                    if mean is not None:
+                        log.write("%.6f\n" % mean)
+                    if self.global_iter % self.save_step == 0:
+                        self.save_checkpoint("last")
+                    if self.global_iter % _MILESTONE == 0:
+                        self.save_checkpoint(str(self.global_iter))
                 if self.global_iter >= self.max_iter:
                     break
         return False

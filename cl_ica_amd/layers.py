@@ -121,7 +121,15 @@ class _LeakyFn(torch.autograd.Function):
 
 class LeakyReLU(nn.LeakyReLU):
     """``nn.LeakyReLU`` (same constructor, no parameters) on the HIP element-wise kernel: the activation the 3DIdent encoder
-    puts between the backbone's output and the head's Linear (main_3dident.py:365-370)."""
+    puts between the backbone's output and the head's Linear (main_3dident.py:365-370).  The backward recovers the sign of
+    the input from the saved OUTPUT, which needs a strictly positive slope; other slopes (``nn.LeakyReLU`` accepts them) are
+    refused at construction instead of failing at the first backward."""
+
+    def __init__(self, negative_slope: float = 0.01, inplace: bool = False):
+        if not float(negative_slope) > 0.0:
+            raise ValueError(f"cl_ica_amd.layers.LeakyReLU needs negative_slope > 0 (got {negative_slope}); use torch.nn.ReLU / "
+                             "torch.nn.LeakyReLU for a zero or negative slope")
+        super().__init__(negative_slope, inplace)
 
     def forward(self, x):
         if x.dim() != 2:

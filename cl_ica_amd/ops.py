@@ -173,8 +173,25 @@ def mlp_pack_split_both(weights, packed: Optional[torch.Tensor] = None, packed_t
     return packed, packed_t
 
 
-def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Tensor, slope: float = 0.01, signmasks=None, mix=None):
-    """`mlp_fwd` on the bf16 matrix cores with exact 3-way bf16 splits (clica_mlp_fwd_split); `weights` only give the shapes."""
+def mlp_planes_alloc(M: int, width: int, ones: bool, device) -> torch.Tensor:
+    """Opaque buffer for the bf16-plane copy of an [M, width] layer output (operand format of `mlp_wgrad_split`)."""
+    nb = C.c_size_t()
+    check(load().clica_mlp_planes_bytes(int(M), int(width), 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
+    return torch.zeros(nb.value, dtype=torch.uint8, device=device)
+
+
+def mlp_wgrad_split_kind(N: int, K: int) -> int:
+    """0: the layer's weight gradient runs on the bf16 matrix cores from plane copies; 1: fp32 tiny-dimension kernel."""
+    k = C.c_int32()
+    check(load().clica_mlp_wgrad_split_kind(int(N), int(K), C.byref(k)), "clica_mlp_wgrad_split_kind")
+    return int(k.value)
+
+
+def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Tensor, slope: float = 0.01, signmasks=None, mix=None,
+                  planes=None):
+    """`mlp_fwd` on the bf16 matrix cores with exact 3-way bf16 splits (clica_mlp_fwd_split); `weights` only give the shapes.
+    `planes[l]` (from mlp_planes_alloc(M, width_l, True), or None) receives layer l's output as bf16 planes for
+    `mlp_wgrad_split`; `outs[l]` may then be None (no fp32 copy of that hidden activation)."""
     (x, ldx) = _mat("x", x)
     L = len(weights)
     bs = [None if b is None else b.detach().contiguous() for b in biases]
@@ -185,24 +202,56 @@ def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Te
     check(load().clica_mlp_fwd_split(x.data_ptr(), ldx, x.shape[0], ptr(gW), 0 if gW is None else gW.shape[0], float(gslope),
                                      ptr(xout), 0 if xout is None else xout.stride(0), L,
                                      VP(*[None if b is None else b.data_ptr() for b in bs]),
-                                     VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+                                     VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
                                      I32(*[w.shape[0] for w in weights]), I32(*[w.shape[1] for w in weights]),
                                      packed_split.data_ptr(), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
+                                     None if planes is None else VP(*[ptr(q) for q in planes]),
                                      float(slope), stream_ptr()), "clica_mlp_fwd_split")
     return outs[-1]
 
 
-def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch.Tensor, outs, slope: float = 0.01, masks_chain=None):
-    """`mlp_dgrad_chain` on the bf16 matrix cores (clica_mlp_dgrad_split); sign bits from `mlp_fwd_split`."""
+def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch.Tensor, outs, slope: float = 0.01, masks_chain=None,
+                          planes=None):
+    """`mlp_dgrad_chain` on the bf16 matrix cores (clica_mlp_dgrad_split); sign bits from `mlp_fwd_split`.  `planes[j]`
+    (mlp_planes_alloc(M, width, False) or None) receives link j's dZ as bf16 planes; `outs[j]` may then be None."""
     (dy, lddy) = _mat("dy", dy)
     n = len(weights_chain)
     I32, I64, VP = C.c_int32 * n, C.c_int64 * n, C.c_void_p * n
     check(load().clica_mlp_dgrad_split(dy.data_ptr(), lddy, dy.shape[0], n,
                                        I32(*[w.shape[1] for w in weights_chain]), I32(*[w.shape[0] for w in weights_chain]),
                                        packed_split_t.data_ptr(), None if masks_chain is None else VP(*[ptr(m) for m in masks_chain]),
-                                       VP(*[o.data_ptr() for o in outs]), I64(*[o.stride(0) for o in outs]),
+                                       VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
+                                       None if planes is None else VP(*[ptr(q) for q in planes]),
                                        float(slope), stream_ptr()), "clica_mlp_dgrad_split")
     return outs
+
+
+def mlp_wgrad_split_workspace(M: int, shapes, device) -> torch.Tensor:
+    L = len(shapes)
+    I32 = C.c_int32 * L
+    nb = C.c_size_t()
+    check(load().clica_mlp_wgrad_split_workspace_bytes(int(M), L, I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]), C.byref(nb)),
+          "clica_mlp_wgrad_split_workspace_bytes")
+    return torch.zeros(nb.value, dtype=torch.uint8, device=device)
+
+
+def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """Every layer's dW / db in the split-bf16 arithmetic (clica_mlp_wgrad_split).  Per layer EITHER the two plane buffers
+    (`dz_planes[l]`, `x_planes[l]`: layers with `mlp_wgrad_split_kind` 0) OR the fp32 operands (`dzs[l]`, `xs[l]`: kind 1)."""
+    L = len(dWs)
+    VP, I64, I32 = C.c_void_p * L, C.c_int64 * L, C.c_int32 * L
+    dzm = [None if t is None else _mat("dz", t) for t in dzs]
+    xm = [None if t is None else _mat("x", t) for t in xs]
+    shapes = [tuple(w.shape) for w in dWs]
+    if ws is None:
+        ws = mlp_wgrad_split_workspace(M, shapes, dWs[0].device)
+    check(load().clica_mlp_wgrad_split(int(M), L, VP(*[ptr(q) for q in dz_planes]), VP(*[ptr(q) for q in x_planes]),
+                                       VP(*[None if m is None else m[0].data_ptr() for m in dzm]), I64(*[0 if m is None else m[1] for m in dzm]),
+                                       VP(*[None if m is None else m[0].data_ptr() for m in xm]), I64(*[0 if m is None else m[1] for m in xm]),
+                                       VP(*[w.data_ptr() for w in dWs]), I64(*[w.stride(0) for w in dWs]),
+                                       VP(*[ptr(b) for b in dbs]), I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]),
+                                       1 if accumulate else 0, ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split")
+    return ws
 
 
 def mlp_signmask_alloc(M: int, n_layers: int, device) -> list:

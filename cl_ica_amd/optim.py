@@ -65,8 +65,29 @@ class Adam:
         if self.world > 1:
             dist.all_reduce(self.grad_arena, op=dist.ReduceOp.SUM, group=self.pg)
 
+    def _adopt_foreign_grads(self):
+        """``nn.Module.zero_grad()`` / ``zero_grad(set_to_none=True)`` drop the arena views, after which autograd allocates
+        fresh ``.grad`` tensors outside the arena.  Bring those back (copy + re-install the view) so the launch below
+        reads the gradients autograd produced; a parameter that received no gradient this step contributes zeros."""
+        base = self.grad_arena.data_ptr()
+        for p, off in zip(self.params, self.offsets):
+            view = self.grad_arena[off:off + p.numel()].view(p.shape)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != base + 4 * off:
+                view.copy_(p.grad)
+            else:
+                continue
+            p.grad = view
+
     def step(self, closure=None):
+        """One launch over the whole arena.  Differences from ``torch.optim.Adam`` (none of the reference's drivers can
+        observe them): ONE parameter group; one global step count; a parameter without a gradient is updated with g = 0
+        (its moments decay) where torch would skip it."""
         loss = closure() if closure is not None else None
+        if len(self.param_groups) != 1:
+            raise ValueError("the flat Adam supports exactly one parameter group")
+        self._adopt_foreign_grads()
         g = self.param_groups[0]
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
                       float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world)

@@ -246,14 +246,19 @@ int clica_mlp_dgrad(const float* dY, int64_t lddy, int64_t M, int32_t n_links,
                     const int32_t* N, const int32_t* K, const float* packed,
                     const float* const* act, const int64_t* ldact, const uint64_t* const* signmask,
                     float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
-/* ---- opt-in split-bf16 arithmetic for the two whole-stack kernels (same results to fp32 rounding level) ----------
+/* ---- split-bf16 arithmetic for the whole-stack kernels and the weight gradients (same results to fp32 rounding level) ----
  * Both fp32 operands of every Linear are split exactly into three bf16 pieces and the six piece products of order
  * <= 2 are accumulated in fp32 on the bf16 matrix cores (csrc/fused_mlp.hip, mlp_split_k): measured max error vs fp64
  * 8.6e-7 of max|y| on a 500 x 500 layer (fp32-MFMA path: 1.0e-6), 0.375 of the matrix-core time.
  * packed_split buffers come from clica_mlp_pack_split[_both] (clica_mlp_pack_split_bytes bytes; 6 B per weight).  The
  * sign-bit buffers have the same size as the fp32 kernels' but a different bit order: use the pair fwd_split /
- * dgrad_split together.  Saved activations / dZ are written as fp32, as by clica_mlp_fwd / clica_mlp_dgrad.
+ * dgrad_split together.  Layer outputs (saved activations / dZ) are written as fp32 (`out[l]`, as by clica_mlp_fwd /
+ * clica_mlp_dgrad) and / or as three bf16 PLANES in the operand format of clica_mlp_wgrad_split (`planes[l]`, a buffer of
+ * clica_mlp_planes_bytes(M, N_l, ones) bytes; ones = 1 for the forward's activations -- they carry the constant-1 feature
+ * that makes the weight-gradient GEMM return db -- and 0 for the backward chain's dZ).  `planes` may be NULL (no planes
+ * at all); out[l] may be NULL when planes[l] is given (a hidden activation / dZ that only the weight gradients read).
  * mix_W may be NULL (then X is the stack's input and x_out is ignored). */
+int clica_mlp_planes_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes);
 int clica_mlp_pack_split_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
 int clica_mlp_pack_split(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
                          int32_t transpose, void* packed, clica_stream_t stream);
@@ -262,10 +267,23 @@ int clica_mlp_pack_split_both(int32_t n_layers, const float* const* W, const int
 int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
                         float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
                         float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                        const void* packed_split, uint64_t* const* signmask, float slope, clica_stream_t stream);
+                        const void* packed_split, uint64_t* const* signmask, void* const* planes, float slope,
+                        clica_stream_t stream);
 int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
                           const void* packed_split, const uint64_t* const* signmask,
-                          float* const* out, const int64_t* ldo, float slope, clica_stream_t stream);
+                          float* const* out, const int64_t* ldo, void* const* planes, float slope, clica_stream_t stream);
+/* clica_mlp_wgrad in the split-bf16 arithmetic (csrc/wgrad_split.hip): the autograd of nn.Linear.weight / .bias over the whole
+ * encoder (/root/reference/encoders.py:36-48, main_mlp.py:282) with both operands of every MFMA-sized layer taken from the
+ * bf16 plane copies the split kernels above wrote (dZ_planes[l], X_planes[l]; X_planes[l] with the constant-1 feature).
+ * Layers with a tiny dimension (clica_mlp_wgrad_split_kind -> 1: min(N, K) <= 16 and max(N, K) <= 128, the n-wide first /
+ * last encoder layer) run the fp32 VALU kernel of clica_mlp_wgrad on the fp32 operands dZ[l] / X[l]; the other layers'
+ * fp32 pointers may be NULL.  Same slab workspace scheme and deterministic reduction as clica_mlp_wgrad. */
+int clica_mlp_wgrad_split_kind(int32_t N, int32_t K, int32_t* kind);
+int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes);
+int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                          const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                          float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                          int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* Weight/bias gradients of ALL layers in two launches (one grouped split-K GEMM over equal-length work items
  * + one grouped deterministic slab reduction):  dW[l] = dZ[l]^T X[l]  ([N_l, K_l]),  db[l] = column sums of dZ[l]

@@ -1,4 +1,4 @@
-"""bench.py end to end on the GPU (short run): the contract JSON line with its roofline / kernels / loss legs and the split probe."""
+"""bench.py end to end on the GPU (short run): the contract JSON line with its roofline / kernels / loss legs and the native-fp32 leg."""
 import json
 import os
 import subprocess
@@ -16,10 +16,14 @@ def test_bench_emits_contract_line():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "kernels", "loss_kernel", "split_bf16_probe"):
+              "data", "config", "roofline", "kernels", "loss_kernel", "native_fp32"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["value"] > 100
-    rf = line["roofline"]
-    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["peak"] == 157.3 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert line["split_bf16_probe"]["value"] > 100
-    assert abs(line["final_loss"]) < 20 and abs(line["split_bf16_probe"]["final_loss"]) < 20
+    assert line["metric"] == "training steps/sec (B=6144, n=10 MLP)" and "bf16x3 split" in line["dtype"]
+    rf = line["roofline"]      # headline mode: issued bf16 flops against the dense bf16 peak, fp32-equivalent figure next to it
+    assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    fe = rf["fp32_equivalent"]
+    assert fe["peak"] == 157.3 and 0 < fe["frac"] < 1.05 and abs(6 * fe["achieved"] - rf["achieved"]) < 0.05 * rf["achieved"]
+    nat = line["native_fp32"]
+    assert nat["value"] > 100 and nat["dtype"] == "f32" and nat["roofline"]["peak"] == 157.3 and 0 < nat["roofline"]["frac"] < 1
+    assert abs(line["final_loss"]) < 20 and abs(nat["final_loss"]) < 20

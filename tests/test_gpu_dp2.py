@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("encoder_arith")]   # every test in both encoder arithmetics
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 

@@ -6,7 +6,7 @@ import torch
 
 from conftest import PARITY, mlp_formula_params
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("encoder_arith")]   # every test in both encoder arithmetics
 
 
 def dev(a):

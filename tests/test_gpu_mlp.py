@@ -376,6 +376,63 @@ def test_split_bf16_stack_matches_fp64(dims, M):
         assert rel_err(dz[j].cpu().numpy(), g64) < 1e-5, ("dgrad", l)
 
 
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 64, 5], 1000),
+                                      ([10, 64, 128, 256, 96, 10], 3001), ([16, 16, 16], 47), ([12, 120, 500, 17, 300, 96, 3], 6144),
+                                      ([5, 100, 320, 100, 5], 16), ([5, 100, 320, 100, 5], 1)])
+def test_split_bf16_wgrad_matches_fp64(dims, M):
+    """clica_mlp_wgrad_split: dW / db of every layer from the bf16-plane copies the split forward / backward-chain kernels
+    write (csrc/wgrad_split.hip; tiny first / last layer on the fp32 VALU kernel) against fp64 products of the SAME kernels'
+    fp32 outputs -- the planes must hold exactly those values -- at the tolerance of the fp32 grouped kernel's test.  Widths
+    cover ragged units (100, 500, 129, 17), whole units (64, 128, 256, 512: the constant-1 feature lives in an extra
+    unit) and batches that are not whole 16-row groups / 48-row producer panels."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(len(dims) * 19 + M)
+    L = len(dims) - 1
+    Ws = [dev((rng.uniform(-1, 1, size=(dims[i + 1], dims[i])) / np.sqrt(dims[i])).astype(np.float32)) for i in range(L)]
+    bs = [dev(rng.uniform(-0.5, 0.5, size=dims[i + 1]).astype(np.float32)) for i in range(L)]
+    x = dev(rng.normal(size=(M, dims[0])).astype(np.float32))
+    outs = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+    masks = ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None]
+    kinds = [ops.mlp_wgrad_split_kind(dims[l + 1], dims[l]) for l in range(L)]
+    assert kinds[0] == 1 and kinds[-1] == 1
+    act_pl = [ops.mlp_planes_alloc(M, dims[l + 1], True, "cuda") if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
+    dz_pl = [ops.mlp_planes_alloc(M, dims[l + 1], False, "cuda") if kinds[l] == 0 else None for l in range(L)]
+    for t in act_pl + dz_pl:
+        if t is not None:
+            t.fill_(0xFF)          # NaN patterns: every piece the consumer reads must have been written by the producer
+    packed, packed_t = ops.mlp_pack_split_both(Ws)
+    ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks, planes=act_pl)
+    dy = dev(rng.normal(size=(M, dims[-1])).astype(np.float32))
+    chain = list(range(L - 1, 0, -1))
+    dz = [torch.empty(M, dims[l], device="cuda") for l in chain]                 # dz[j] = dZ of layer chain[j] - 1
+    ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain],
+                              planes=[dz_pl[l - 1] for l in chain])
+    dz_of = {l - 1: dz[j] for j, l in enumerate(chain)}
+    dz_of[L - 1] = dy
+    dWs = [torch.full((dims[l + 1], dims[l]), 7.0, device="cuda") for l in range(L)]
+    dbs = [torch.full((dims[l + 1],), 7.0, device="cuda") for l in range(L)]
+    xs = [x] + outs[:-1]
+    # fp32 operands only where the tiny kernel needs them: the MFMA-sized layers must come from the planes alone
+    ops.mlp_wgrad_split(M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)],
+                        [dz_of[l] if kinds[l] == 1 else None for l in range(L)], [xs[l] if kinds[l] == 1 else None for l in range(L)], dWs, dbs)
+    cid = f"dims={dims} M={M}"
+    for l in range(L):
+        d64, x64 = dz_of[l].cpu().numpy().astype(np.float64), xs[l].cpu().numpy().astype(np.float64)
+        ref_w, ref_b = d64.T @ x64, d64.sum(0)
+        scale_w = np.abs(d64).T @ np.abs(x64)
+        err_w = float(np.max(np.abs(dWs[l].cpu().numpy() - ref_w) / np.maximum(scale_w, 1e-30)))
+        err_b = float(np.max(np.abs(dbs[l].cpu().numpy() - ref_b)) / max(np.abs(d64).sum(0).max(), 1e-30))
+        assert err_w < 1e-5 and err_b < 1e-5, (cid, l, kinds[l], err_w, err_b)
+        PARITY.check("split_bf16_wgrad_vs_fp64", cid, f"dW{l}", dWs[l].cpu().numpy(), ref_w)
+        PARITY.check("split_bf16_wgrad_vs_fp64", cid, f"db{l}", dbs[l].cpu().numpy(), ref_b, floor=float(np.abs(d64).sum(0).max()) * 0.05)
+    before = [w.clone() for w in dWs]
+    ops.mlp_wgrad_split(M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)],
+                        [dz_of[l] if kinds[l] == 1 else None for l in range(L)], [xs[l] if kinds[l] == 1 else None for l in range(L)],
+                        dWs, [None] * L, accumulate=True)
+    for l in range(L):
+        assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_get_mlp_autograd_seeded_sweep_vs_fp64(fused, monkeypatch):
     """Twelve seeded random encoders (1-7 layers, widths 1..512, batch sizes around the 48-row panels) through the drop-in
