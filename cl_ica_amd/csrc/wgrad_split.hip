@@ -36,6 +36,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef CLICA_WSPLIT_ABLATE      // timing ablations (WRONG results): 1 no DMA in the loop, 2 every step re-reads tile 0 (L2-hot), 4 no fragment reads
+#define CLICA_WSPLIT_ABLATE 0
+#endif
 constexpr int STG = 4;                      // LDS stages of one 16-row step each
 constexpr int UW = 8, UN = 4;               // 32-feature units of the wide / narrow side of a tile (256 / 128 features)
 constexpr int PIECES = 3 * (UW + UN);       // one-KB pieces per step (36 KB)
@@ -80,19 +83,27 @@ __device__ __forceinline__ frag_t read_frag(const char* p) {   // keys 8h .. 8h+
   return (frag_t){a.x, a.y, b.x, b.y};
 }
 
-// Debug build only (-DCLICA_WSPLIT_TRACE): s_memtime stamps per (workgroup, wave, phase)
+// Debug build only (-DCLICA_WSPLIT_TRACE, tools/wsplit_trace.py): s_memtime stamps per (workgroup, wave, phase), kept in
+// scalar registers and written once at the end of the item (a store or a pointer load inside the loop would enter the
+// wave's in-order vmcnt queue and change the very waits that are being measured)
 #ifdef CLICA_WSPLIT_TRACE
 __device__ unsigned long long* g_wstrace = nullptr;
-#define WS_STAMP(ph) do { if (g_wstrace && (threadIdx.x & 63) == 0) g_wstrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (ph)] = clock64(); } while (0)
+#define WS_DECL unsigned long long ws_ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define WS_STAMP(ph) do { ws_ts[ph] = __builtin_readcyclecounter(); } while (0)
+#define WS_STEP_STAMP(t, ph) do { if ((t) == 30) WS_STAMP(ph); } while (0)
+#define WS_FLUSH do { if (g_wstrace && (threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 16; ++q_) g_wstrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + q_] = ws_ts[q_]; } } while (0)
 #else
+#define WS_DECL do { } while (0)
 #define WS_STAMP(ph) do { } while (0)
+#define WS_STEP_STAMP(t, ph) do { } while (0)
+#define WS_FLUSH do { } while (0)
 #endif
 
 // One work item: output tile (bx, by) of problem g over the row groups of contraction split bz.
 // Eight waves, wave tile 64 x 64 = 2 x 2 accumulator blocks of 32 x 32 (64 registers); per 16-row step a wave reads
 // 2 + 2 unit fragments x 3 planes (24 transposing reads of 512 B) and issues 24 MFMAs (768 matrix cycles).
-// Pipeline: four 36 KB stages; the pieces of step t + 3 are requested behind the barrier of step t, the fragments of
-// step t + 1 are read during the MFMAs of step t (two register sets, ping-pong), one barrier per step.
+// Pipeline: four 36 KB stages; the pieces of step t + 3 are requested during the first half of step t, the fragments of
+// step t + 1 are read during its second half (two register sets, ping-pong), one barrier per step (in the middle).
 template <bool A_WIDE>
 __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, const int bz) {
   constexpr int UA = A_WIDE ? UW : UN, UB = A_WIDE ? UN : UW;
@@ -104,6 +115,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
   const int g0 = bz * g.gps;
   const int nt = min(g.groups, g0 + g.gps) - g0;
+  WS_DECL;
   WS_STAMP(0);
 
   f32x16 acc[2][2];
@@ -128,7 +140,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
     const bool ok = pi < PIECES && u < fu;
     const char* base = is_a ? g.A : g.B;
     src[j] = ok ? base + (((int64_t)g0 * fu + u) * 3 + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
-    stride[j] = ok ? fu * planes::kUnitBytes : 0;
+    stride[j] = (ok && !(CLICA_WSPLIT_ABLATE & 2)) ? fu * planes::kUnitBytes : 0;
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   auto issue = [&](int t) {
@@ -148,36 +160,62 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   const char* fa_base = smem + lane_off + (wm * 2) * 3 * 1024;
   const char* fb_base = smem + lane_off + (UA + wn * 2) * 3 * 1024;
   frag_t fa0[3][2], fb0[3][2], fa1[3][2], fb1[3][2];
-  auto load_frags = [&](frag_t (&fa)[3][2], frag_t (&fb)[3][2], int t) {
+  auto load_frags_of = [&](frag_t (&f)[3][2], const char* base, int t) {
     const int so = (t % STG) * STAGE_BYTES;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[p][i] = read_frag(fa_base + so + (3 * i + p) * 1024);
-        fb[p][i] = read_frag(fb_base + so + (3 * i + p) * 1024);
-      }
+      for (int i = 0; i < 2; ++i) f[p][i] = read_frag(base + so + (3 * i + p) * 1024);
   };
-  auto mma = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2]) {
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // (dZ piece, X piece), small terms first
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]), acc[i][j], 0, 0, 0);
+  auto load_frags = [&](frag_t (&fa)[3][2], frag_t (&fb)[3][2], int t) { load_frags_of(fa, fa_base, t); load_frags_of(fb, fb_base, t); };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // (dZ piece, X piece) of the six products, small terms first
+  auto mfma1 = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], int m) {      // MFMA m = 0..23 of a step: product m / 4, block ((m % 4) / 2, m % 2)
+    const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]),
+                                                        acc[i][j], 0, 0, 0);
   };
-  // step t: [tile t + 1 landed for every wave] -> request tile t + 3 -> read the fragments of t + 1 under the MFMAs of t
+  auto issue_one = [&](int t, int j) { dma_1k(src[j], lds0 + (unsigned)((t % STG) * STAGE_BYTES + (wave + 8 * j) * 1024)); src[j] += stride[j]; };
+  // Step t (all eight waves run the same schedule; a wave issues in order):
+  //   phase 1: MFMAs 0..11 of step t; the wave's 4..5 DMA requests for tile t + 3 go out ONE behind every second MFMA -- a request
+  //            costs the wave ~15..60 issue cycles, which the 32-cycle MFMA in front of it covers; issued as one block behind the
+  //            barrier they kept every wave off the matrix pipe for ~300 cycles per step (tools/wsplit_trace.py);
+  //   middle : tile t + 1 has landed (own pieces: vmcnt; everybody's: barrier);
+  //   phase 2: MFMAs 12..23 of step t with the 24 transposing reads of step t + 1's fragments pinned two behind each MFMA (one
+  //            burst of 24 fills the LDS queue of all eight waves at once and stalls every wave's MFMA issue behind its own reads).
+  // Stage (t + 3) % STG was last read in phase 2 of step t - 2, which every wave has left before anyone passes the barrier of t - 1.
   auto step = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], frag_t (&na)[3][2], frag_t (&nb)[3][2], int t) {
-    if (t + 1 < nt) {
-      wait_steps(t + 2 < nt ? 1 : 0);
-      __syncthreads();               // ... and every wave has read what it needs of stage (t - 1) % STG (the fragments of step t - 1)
-      if (t + 3 < nt) issue(t + 3);
+    const bool more = t + 3 < nt && !(CLICA_WSPLIT_ABLATE & 1);
+    WS_STEP_STAMP(t, 4); WS_STEP_STAMP(t - 1, 10);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      mfma1(fa, fb, 2 * q); mfma1(fa, fb, 2 * q + 1);
       __builtin_amdgcn_sched_barrier(0);
-      load_frags(na, nb, t + 1);
+      if (q < 4) { if (more) issue_one(t + 3, q); }
+      else if (q == 4) { if (more && five) issue_one(t + 3, 4); }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    mma(fa, fb);
+    WS_STEP_STAMP(t, 5);
+    if (t + 1 < nt) {
+      wait_steps((CLICA_WSPLIT_ABLATE & 1) ? 0 : min(t + 3, nt - 1) - (t + 1));
+      WS_STEP_STAMP(t, 6);
+      __syncthreads();
+      WS_STEP_STAMP(t, 7);
+#if !(CLICA_WSPLIT_ABLATE & 4)
+      load_frags(na, nb, t + 1);
+#endif
+#pragma unroll
+      for (int m = 12; m < 24; ++m) mfma1(fa, fb, m);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int m = 12; m < 24; ++m) mfma1(fa, fb, m);
+    }
+    WS_STEP_STAMP(t, 8);
   };
 
   if (nt > 0) issue(0);
@@ -216,6 +254,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
     }
   }
   WS_STAMP(3);
+  WS_FLUSH;
 }
 
 __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {     // each XCD walks a contiguous range of the work items

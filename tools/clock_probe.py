@@ -28,23 +28,37 @@ def measure(fn, reps, label):
 
 
 import bench
-args = bench.parse()
-tr = bench.build_trainer(args, torch.device("cuda"), 1)
-tr.capture()
-measure(tr.step, 600, "whole step (graph replay)")
-from cl_ica_amd import ops
-R = 2 * tr.B
-ws = [lin.weight for lin in tr.linears]; bs = [lin.bias for lin in tr.linears]
-def g(fn):
-    fn(); torch.cuda.synchronize()
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        fn()
-    return gr.replay
-measure(g(lambda: ops.mlp_fwd(tr.x, ws, bs, tr.acts, tr.slope, packed=tr.packed, signmasks=tr.signmasks)), 600, "mlp_fwd_k only")
-L = len(tr.linears); order = list(range(L)); g_top = tr.dy
-measure(g(lambda: ops.mlp_wgrad([g_top if l == L - 1 else tr.dz[l] for l in order], [tr.acts[l - 1] if l > 0 else tr.x for l in order],
-                                [tr._gviews[id(tr.linears[l].weight)] for l in order], [tr._gviews[id(tr.linears[l].bias)] for l in order], ws=tr.group_ws)), 600, "grouped wgrad only")
-z = torch.zeros_like(tr.x)
-x0 = tr.x.clone(); tr.x.zero_()
-measure(g(lambda: ops.mlp_fwd(tr.x, ws, bs, tr.acts, tr.slope, packed=tr.packed, signmasks=tr.signmasks)), 600, "mlp_fwd_k, zero input")
+rs = subprocess.run("rocm-smi --showpower --showclocks --showmaxpower 2>&1 | grep -v '^=' | head -30", shell=True, capture_output=True, text=True)
+print(rs.stdout)
+for native in (False, True):
+    sys.argv = [sys.argv[0]] + (["--native-fp32"] if native else [])
+    args = bench.parse()
+    tr = bench.build_trainer(args, torch.device("cuda"), 1)
+    tr.capture()
+    tag = "native fp32" if native else "split-bf16"
+    measure(tr.step, 800, f"[{tag}] whole step (graph replay)")
+    g_top = tr.dy
+
+    def g(fn):
+        fn(); torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fn()
+        return gr.replay
+
+    def fwd():
+        tr._packed_current = True
+        tr.forward()
+
+    def chain():
+        tr._packed_current = True
+        tr.backward_chain(g_top)
+    measure(g(fwd), 800, f"[{tag}] forward stack only")
+    measure(g(chain), 800, f"[{tag}] backward chain only")
+    measure(g(lambda: tr.weight_grads(g_top)), 800, f"[{tag}] weight gradients only")
+    measure(g(tr.loss_forward_backward), 800, f"[{tag}] loss fwd + bwd only")
+    measure(tr.step, 800, f"[{tag}] whole step again")
+    del tr
+    torch.cuda.empty_cache()
+rs = subprocess.run("rocm-smi --showpower --showclocks 2>&1 | grep -v '^=' | head -30", shell=True, capture_output=True, text=True)
+print(rs.stdout)

@@ -8,14 +8,14 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src = f"gpurun_out/profile_{tag}"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{tag}_bench_under_rocprof.json")
-if os.path.exists(f"{src}/trace_split/t_kernel_stats.csv"):       # opt-in split-bf16 mode (kernel trace only)
-    shutil.copy(f"{src}/trace_split/t_kernel_stats.csv", f"profiles/{tag}_split_bf16_kernel_stats.csv")
-    shutil.copy(f"{src}/bench_split_under_rocprof.json", f"profiles/{tag}_split_bf16_bench_under_rocprof.json")
+if os.path.exists(f"{src}/trace_native/t_kernel_stats.csv"):       # native fp32-MFMA mode (kernel trace only)
+    shutil.copy(f"{src}/trace_native/t_kernel_stats.csv", f"profiles/{tag}_native_fp32_kernel_stats.csv")
+    shutil.copy(f"{src}/bench_native_under_rocprof.json", f"profiles/{tag}_native_fp32_bench_under_rocprof.json")
 
 
 def agg(path):
@@ -26,25 +26,26 @@ def agg(path):
 
 
 pm = {}
-for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_valu"):
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds", "pmc_valu", "pmc_l2"):
     p = f"{src}/{name}/p_counter_collection.csv"
     if os.path.exists(p):
         for k, v in agg(p).items():
             pm.setdefault(k, {}).update(v)
 stats = list(csv.DictReader(open(f"{src}/trace/t_kernel_stats.csv")))
 bench = json.load(open(f"{src}/bench_under_rocprof.json"))
-lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-split-probe`", "",
-         f"bench line under the profiler: {bench['value']:.1f} steps/s, {bench['ms_per_step']:.3f} ms/step; roofline entry: "
-         f"`{bench['roofline']['kernel']}` {bench['roofline']['achieved']} TFLOP/s ({bench['roofline']['frac']:.3f} of 157.3), "
-         f"avg {bench['roofline']['avg_launch_us']} us/launch (graph replay between HIP events).", "",
+lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-native-leg --no-dropin`", "",
+         f"bench line under the profiler: {bench['value']:.1f} steps/s, {bench['ms_per_step']:.3f} ms/step ({bench['dtype']}); roofline entry: "
+         f"`{bench['roofline']['kernel']}` {bench['roofline']['achieved']} TFLOP/s ({bench['roofline']['frac']:.3f} of {bench['roofline']['peak']}), "
+         f"avg {bench['roofline']['avg_launch_us']} us/launch (HIP events inside training steps).", "",
          "PMC columns come from separate `--pmc` passes (FETCH_SIZE / WRITE_SIZE in KB per launch, as reported; per "
          "MI355X_MICROARCH.md FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 -> `fetch_x2_MB`). "
          "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs).", "",
          "VALU busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles -> cycles) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the share of SIMD cycles "
          "in which the vector ALU is executing; VALU/wave = SQ_INSTS_VALU / SQ_WAVES; wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt / "
          "barrier), issue-stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.", "",
-         "| kernel | calls | avg us | % time | fetch_x2 MB | write MB | MfmaUtil | VALU busy | VALU inst/launch | LDS inst/launch | wait | issue-stall | LDS bank conflicts |",
-         "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+         "L2 hit = TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum) over the eight per-XCD L2s.", "",
+         "| kernel | calls | avg us | % time | fetch_x2 MB | write MB | L2 hit | MfmaUtil | VALU busy | VALU inst/launch | LDS inst/launch | wait | issue-stall | LDS bank conflicts |",
+         "|---|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
 for r in stats:
     name = r["Name"]
     c = pm.get(name, {})
@@ -60,7 +61,8 @@ for r in stats:
     linst = f"{c['SQ_INSTS_LDS']:.0f}" if "SQ_INSTS_LDS" in c else ""
     wait = f"{c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.2f}" if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c else ""
     stall = f"{c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.2f}" if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_INST_ANY" in c else ""
-    lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {util} | {vbusy} | "
+    l2 = f"{c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.2f}" if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0 else ""
+    lines.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {l2} | {util} | {vbusy} | "
                  f"{vinst} | {linst} | {wait} | {stall} | {conf} |")
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 # per-launch HBM-side traffic (FETCH_SIZE x 2 + WRITE_SIZE, bytes) of every kernel symbol: bench.py's roofline.traffic

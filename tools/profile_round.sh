@@ -2,23 +2,25 @@
 # Round profile on the GPU box: kernel-trace stats of the bench command + separate PMC passes.
 # usage (via gpurun): bash tools/profile_round.sh r1
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 100 --warmup 10 --windows 1 --no-cpu-baseline --no-split-probe --no-dropin"
+CMD="python $ROOT/bench.py --steps 100 --warmup 10 --windows 1 --no-cpu-baseline --no-native-leg --no-dropin"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-CMD2="python $ROOT/bench.py --steps 10 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-split-probe --no-dropin"
+CMD2="python $ROOT/bench.py --steps 10 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-native-leg --no-dropin"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/pmc_sq -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_sq.err
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS -d $OUT/pmc_lds -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_lds.err
 # vector-ALU occupancy of the pair sweeps: busy / wave cycles, instruction mix
 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM_RD -d $OUT/pmc_valu -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_valu.err
-# the opt-in split-bf16 mode, kernel trace only
-rocprofv3 --kernel-trace --stats -d $OUT/trace_split -o t --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --windows 1 --no-cpu-baseline --no-roofline --no-dropin --split-bf16 > $OUT/bench_split_under_rocprof.json 2> $OUT/trace_split.err
-rm -f $OUT/trace_split/*agent_info.csv $OUT/trace_split/*kernel_trace.csv
+# L2 hit rate (per-XCD L2: do the tiles that share an operand find it there?)
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum -d $OUT/pmc_l2 -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_l2.err
+# the native fp32-MFMA mode (bench.py --native-fp32), kernel trace only
+rocprofv3 --kernel-trace --stats -d $OUT/trace_native -o t --output-format csv -- python $ROOT/bench.py --steps 100 --warmup 10 --windows 1 --no-cpu-baseline --no-roofline --no-dropin --native-fp32 > $OUT/bench_native_under_rocprof.json 2> $OUT/trace_native.err
+rm -f $OUT/trace_native/*agent_info.csv $OUT/trace_native/*kernel_trace.csv
 ls -la $OUT $OUT/trace | head -30
 # keep only the small summaries (trace CSV of every dispatch can be large)
 rm -f $OUT/trace/*agent_info.csv
