@@ -113,6 +113,24 @@ def evaluate(h, latent_space, n_samples=4096):
     return lin, perm
 
 
+def autograd_train_step(h, loss, optimizer, z1, z2, supervised: bool, world: int = 1):
+    """The reference's ``train_step`` verbatim in structure (main_mlp.py:258-285) on the drop-in modules, for the phases the
+    fused engine does not cover: the SUPERVISED phase (``test = True``: ``F.mse_loss(z1_rec, z1)``, :274-276 -- the first of the
+    default ``test_list = [True, False]``) and p = 0 (SimCLRLoss).  Returns the 0-dim loss tensor (no host sync)."""
+    optimizer.zero_grad()
+    z1_rec, z2_rec = h(z1), h(z2)
+    # negatives = all z1_rec of the (global) batch: roll on one rank, autograd-aware all-gather on several
+    z3_rec = torch.roll(z1_rec, 1, 0) if world == 1 else gather_negatives(z1_rec)
+    if supervised:
+        total = F.mse_loss(z1_rec, z1)
+    else:
+        total, _, _ = loss(z1, z2, torch.roll(z1, 1, 0), z1_rec, z2_rec, z3_rec)
+    total.backward()
+    optimizer.all_reduce_grads()
+    optimizer.step()
+    return total
+
+
 def main(argv=None):
     args = parse_args(argv)
     rank, world, device = init_from_env()
@@ -177,21 +195,9 @@ def main(argv=None):
             optimizer = FlatAdam(f.parameters(), lr=args.lr)
 
         def autograd_step():
-            """The reference's train_step verbatim in structure (main_mlp.py:258-285) on the drop-in modules."""
             z1 = latent_space.sample_marginal(size=args.batch_size)
             z2 = latent_space.sample_conditional(z1, size=args.batch_size)
-            optimizer.zero_grad()
-            z1_rec, z2_rec = h(z1), h(z2)
-            # negatives = all z1_rec of the (global) batch: roll on one rank, autograd-aware all-gather on several
-            z3_rec = torch.roll(z1_rec, 1, 0) if world == 1 else gather_negatives(z1_rec)
-            if supervised:
-                total = F.mse_loss(z1_rec, z1)
-            else:
-                total, _, _ = loss(z1, z2, torch.roll(z1, 1, 0), z1_rec, z2_rec, z3_rec)
-            total.backward()
-            optimizer.all_reduce_grads()
-            optimizer.step()
-            return total
+            return autograd_train_step(h, loss, optimizer, z1, z2, supervised, world)
 
         last_step = args.n_steps if supervised else args.n_steps * args.more_unsupervised
         global_step = len(total_loss_values) + 1

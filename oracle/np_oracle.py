@@ -402,6 +402,33 @@ def train_step(P: MLPParams, gWs, z1, z2, state, p=2, tau=1.0, lr=1e-4):
     return float(out["loss_mean"]), float(out["pos_mean"]), float(out["neg_mean"])
 
 
+def supervised_train_step(P: MLPParams, gWs, z1, state, lr=1e-4, return_grads=False):
+    """One SUPERVISED train step (reference: main_mlp.py:258-285 with ``test = True``): z1_rec = f(g(z1)),
+    total_loss_value = F.mse_loss(z1_rec, z1) (:274-276; h(z2) is evaluated and unused), backward, Adam.  Mutates P / state
+    like train_step.  Returns the loss (and the parameter gradients [dW0, db0, ...] if asked)."""
+    z1 = np.asarray(z1, np.float64)
+    y, cache = mlp_forward(P, mixing_forward(gWs, z1))
+    diff = y - z1
+    loss = float((diff * diff).mean())                              # F.mse_loss: mean over all B * n elements
+    gr = mlp_backward(P, cache, 2.0 * diff / diff.size)
+    state["step"] += 1
+    flat = []
+    for l in range(len(P.W)):
+        flat += [("W", l, gr["dW"][l]), ("b", l, gr["db"][l])]
+    if P.head in ("learnable_sphere", "learnable_box"):
+        flat.append(("h", 0, gr["dhead"]))
+    for k, (kind, l, g) in enumerate(flat):
+        cur = P.W[l] if kind == "W" else (P.b[l] if kind == "b" else P.head_param)
+        newp, state["m"][k], state["v"][k] = adam_step(cur, g, state["m"][k], state["v"][k], state["step"], lr)
+        if kind == "W":
+            P.W[l] = newp
+        elif kind == "b":
+            P.b[l] = newp
+        else:
+            P.head_param = newp
+    return (loss, [g for _, _, g in flat]) if return_grads else loss
+
+
 def flat_l2_search(table, query, k, chunk=256):
     """Exact k nearest rows in squared L2, ascending, ties to the lower row -- what faiss.IndexFlatL2.search returns at
     /root/reference/datasets/threedident_dataset.py:104-105 (faiss itself is not in the image: exact search is its

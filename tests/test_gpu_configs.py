@@ -68,7 +68,7 @@ def test_c3_wide_trainstep_goldens(golden):
                         continue
                     PARITY.check(fam + "/grad", f"{key} n={n}", name, got.reshape(-1), ref.reshape(-1))
         adam_trajectory_check(fam + "/adam_params", key, f, c["out"], "paramN", stride, lr, steps,
-                              skip=f"{2 * (len(tr.linears) - 1)}.bias" if head is None else None)
+                              skip=f"{2 * (len(tr.linears) - 1)}.bias" if head is None else None, masks=adam_masks(golden, "g13", key))
 
 
 def traj_tol(s):
@@ -78,12 +78,30 @@ def traj_tol(s):
     return (1e-5, None) if s == 0 else ((s + 1) * 1e-5, "trajectory: (s + 1) x 1e-5 after s optimizer updates")
 
 
-def adam_trajectory_check(fam, key, module, out, prefix, stride, lr, steps, skip=None):
-    """Parameters after `steps` Adam updates.  Adam divides by sqrt(v): an element whose gradient is below its own fp32
-    rounding noise moves by +-lr per step in BOTH implementations, with a sign either may pick (the reference's own CPU
-    and GPU runs differ the same way).  So the parity statement is two-sided: (1) the norm-wise error of every tensor is
-    within the Adam noise ceiling 2 * lr * steps / max|param|; (2) the MEDIAN element differs by < 2 % of the distance an
-    element travels in those updates (lr x steps).  Gradients themselves are pinned at 1e-5 by the step-0 check above."""
+ADAM_MASK_THETA = 0.01     # an element belongs to the strictly checked set if |gradient| > 1 % of the tensor's largest at EVERY step
+
+
+def adam_masks(golden, tag, key, rename=None):
+    """(gmin, gmax) dicts of trajectory `tag/key` from g23_adam_masks.npz (tests/golden/gen_goldens_r3.py): per parameter the
+    smallest |gradient| each element saw over the trajectory's optimizer steps and the tensor's largest |gradient|, recorded
+    while RE-RUNNING the reference trajectory the golden holds."""
+    z = golden("g23_adam_masks.npz").z
+    pre_min, pre_max = f"{tag}/{key}/gmin/", f"{tag}/{key}/gmax/"
+    ren = rename or (lambda k: k)
+    return ({ren(k[len(pre_min):]): z[k] for k in z.files if k.startswith(pre_min)},
+            {ren(k[len(pre_max):]): float(z[k]) for k in z.files if k.startswith(pre_max)})
+
+
+def adam_trajectory_check(fam, key, module, out, prefix, stride, lr, steps, skip=None, masks=None):
+    """Parameters after `steps` Adam updates.  Adam divides by sqrt(v): an element whose gradient is at its own fp32 rounding
+    level moves by +-lr per step in BOTH implementations, with a sign either may pick (the reference's own CPU and GPU runs
+    differ the same way) -- such elements say nothing about an implementation.  The golden's recorded gradient magnitudes
+    (`masks`, see adam_masks) separate them:
+      * STRICT set -- |gradient| stayed above 1 % of the tensor's largest at every step: held to (steps + 1) x 1e-5 of
+        max|param| (one 1e-5 quantum per update, as for the losses along the trajectory);
+      * the rest (gradients near rounding level at some step): bounded by the random walk they can do, 2 lr steps, and
+        recorded under that allowance.  Gradients themselves are pinned at 1e-5 by the step-0 checks."""
+    gmin, gmax = masks if masks is not None else ({}, {})
     for name, prm in module.named_parameters():
         ref = out[f"{prefix}/{name}"]
         got = golden_view(prm.detach().cpu().numpy(), ref, stride).reshape(-1)
@@ -93,10 +111,16 @@ def adam_trajectory_check(fam, key, module, out, prefix, stride, lr, steps, skip
         if name == skip:        # exactly-zero true gradient: a +-lr random walk on BOTH sides
             assert diff.max() <= 2 * steps * lr * 1.01
             continue
-        PARITY.check(fam, key, name, got, ref, tol=max(1e-5, 2.0 * lr * steps / scale),
-                     note=f"Adam noise ceiling 2*lr*steps/max|param| (sign of sub-rounding-noise gradients)")
-        PARITY.check(fam + "_median", key, name, [float(np.median(diff))], [0.0], floor=lr * steps, tol=0.02,
-                     note="median element drift after the Adam steps, relative to the distance an element travels (lr x steps)")
+        assert name in gmin, f"no gradient-magnitude record for {key}:{name} in g23_adam_masks.npz"
+        strict = gmin[name].reshape(-1) > ADAM_MASK_THETA * gmax[name]
+        assert strict.shape == ref.shape
+        if strict.any():
+            PARITY.check(fam, key, f"{name} [{int(strict.sum())}/{strict.size} elements with |grad| > 1 % of max at every step]",
+                         got[strict], ref[strict], tol=(steps + 1) * 1e-5, floor=scale,
+                         note="trajectory: (steps + 1) x 1e-5 of max|param| after the Adam updates, elements with gradients above rounding level")
+        if (~strict).any():
+            PARITY.check(fam + "_noise_elements", key, name, got[~strict], ref[~strict], tol=2.0 * lr * steps / scale * 1.01, floor=scale,
+                         note="elements whose gradient came within 1 % of rounding-level at some step: bounded by their +-lr random walk, 2 lr steps")
 
 
 def test_c3_loss_pool_49152_sampled_rows_vs_oracle():
@@ -279,7 +303,7 @@ def test_c5_kitti_solver_goldens(golden, tmp_path):
             PARITY.check(fam, f"{case} iter{s}", "neg_mean", rec[s][2], c["out"]["neg"][s], floor=lossv, tol=tl, note=tn)
         PARITY.check(fam, f"{case} iter0", "loss_i", rec[0][3], c["out"]["loss_i0"])
         adam_trajectory_check(fam + "/adam_params", case, S.net, c["out"], "param3", 29, lr, 3,
-                              skip=None if box else "encoder.11.bias")
+                              skip=None if box else "encoder.11.bias", masks=adam_masks(golden, "g14", f"s{si:03d}"))
         # log.csv + checkpoint in the reference's layout
         lines = open(d / "log.csv").read().split()
         assert lines[:2] == ["Total", "Loss"] and len(lines) == 5 and abs(float(lines[2]) - c["out"]["loss"][0]) < 1e-4
@@ -394,4 +418,108 @@ def test_c4_3dident_head_and_loss_goldens(golden):
         ref_named = {("2." if k[0] == "1" else "3.") + k.split(".", 1)[1]: v for k, v in
                      ((str(k)[len("param3/"):], v) for k, v in c["out"].items() if str(k).startswith("param3/"))}
         adam_trajectory_check(fam + "/adam_params", name, f, {f"p/{k}": v for k, v in ref_named.items()}, "p", 1, lr, 3,
+                              masks=adam_masks(golden, "g15", key, rename=lambda k: ("2." if k[0] == "1" else "3.") + k.split(".", 1)[1]),
                               skip="2.bias" if (a.unsupervised_loss in ("l1", "l2", "l3") and isinstance(f[3], T.layers.Lambda)) else None)
+
+
+# ================================================================================================== C4 with a real conv backbone
+class _BasicBlock(torch.nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        nn = torch.nn
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(cout)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = torch.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return torch.relu(y + (x if self.down is None else self.down(x)))
+
+
+class _ResNet18(torch.nn.Module):
+    """The ResNet-18 architecture (7x7 stem, max-pool, four stages of two basic blocks, global average pool, fc) in plain
+    torch.nn -- torchvision is not in the image.  Stands in for torchvision.models.resnet18(num_classes=...) of
+    main_3dident.py:287-292; runs on PyTorch-ROCm / MIOpen as BASELINE config 4 prescribes."""
+
+    def __init__(self, num_classes):
+        super().__init__()
+        nn = torch.nn
+        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
+        cfg = [(64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2), (512, 512, 1)]
+        self.blocks = nn.Sequential(*[_BasicBlock(a, b, s) for a, b, s in cfg])
+        self.fc = nn.Linear(512, num_classes)
+
+    def forward(self, x):
+        return self.fc(torch.flatten(torch.nn.functional.adaptive_avg_pool2d(self.blocks(self.stem(x)), 1), 1))
+
+
+@pytest.mark.parametrize("mode", ["position_only_l2", "rotation_and_color_only_periodic"])
+def test_c4_resnet18_backbone_feeds_the_hip_head(mode):
+    """BASELINE config 4 end to end at its real shape: (1024, 3, 64, 64) images x 2 views -> ResNet-18 (plain torch.nn, MIOpen;
+    channels-last activations as a conv net on ROCm produces them) -> HIP LeakyReLU / Linear / rescaling -> HIP loss on column
+    slices -> backward through the backbone -> flat HIP Adam (main_3dident.py:365-371, 467-503).  Checks: one train_step
+    gives finite gradients in every backbone parameter; the loss / per-item losses / head gradients equal the SAME step fed
+    the detached backbone features (the head and loss do not care where their input came from, nor about its strides)."""
+    from cl_ica_amd import threedident as T
+    from cl_ica_amd.optim import Adam
+    B = 1024
+    if mode == "position_only_l2":
+        a = types.SimpleNamespace(position_only=True, rotation_and_color_only=False, rotation_only=False, color_only=False,
+                                  non_periodic_rotation_and_color=False, box_constraint=None, sphere_constraint=None,
+                                  unsupervised_loss="l2", identity_solution=False, encoder="rn18")
+        n_non, n_ang = 3, 0
+    else:            # the 7 angular latents: learnable-radius RescaleLayer + spherical SimCLRLoss(normalize=False) (:311, :407).  (The
+        # combined 10-latent objective cannot run in the reference either: its closure returns a 2-tuple that train_step unpacks
+        # into three names, main_3dident.py:424-441 vs :490.)
+        a = types.SimpleNamespace(position_only=False, rotation_and_color_only=True, rotation_only=False, color_only=False,
+                                  non_periodic_rotation_and_color=False, box_constraint=None, sphere_constraint=None,
+                                  unsupervised_loss="l2", identity_solution=False, encoder="rn18")
+        n_non, n_ang = 0, 7
+    torch.manual_seed(0)
+    f = T.setup_f(a, n_non, n_ang, base_encoder=lambda pretrained, num_classes: _ResNet18(num_classes)).to("cuda")
+    f = f.to(memory_format=torch.channels_last)
+    f.train()                                   # BatchNorm on batch statistics, as during the reference's training
+    loss = T.make_unsupervised_loss(a, n_non)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x1 = torch.randn(B, 3, 64, 64, generator=g).to("cuda").contiguous(memory_format=torch.channels_last)
+    x2 = (x1.cpu() + 0.1 * torch.randn(B, 3, 64, 64, generator=g)).to("cuda").contiguous(memory_format=torch.channels_last)
+    head_names = [k for k, _ in f.named_parameters() if not k.startswith("0.")]
+
+    # (a) the real graph: images -> backbone -> head -> loss, gradients through everything
+    feats = []
+    hook = f[0].register_forward_hook(lambda m, i, o: (o.retain_grad(), feats.append(o)))
+    z1, z2 = f(x1), f(x2)
+    hook.remove()
+    la = loss(None, None, None, z1, z2, torch.roll(z1, 1, 0))
+    la[0].backward()
+    for name, prm in f[0].named_parameters():
+        assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), name
+    assert float(f[0].stem[0].weight.grad.abs().max()) > 0 and float(f[0].fc.weight.grad.abs().max()) > 0
+    ga = {k: prm.grad.clone() for k, prm in f.named_parameters() if k in head_names}
+    dfa = [t.grad.clone() for t in feats]
+    # (b) the same head and loss fed the DETACHED backbone features (what G15 pins against the reference)
+    for prm in f.parameters():
+        prm.grad = None
+    t1, t2 = (t.detach().clone().requires_grad_(True) for t in feats)
+    y1, y2 = f[1:](t1), f[1:](t2)
+    lb = loss(None, None, None, y1, y2, torch.roll(y1, 1, 0))
+    lb[0].backward()
+    fam = "c4_resnet18_backbone"
+    PARITY.check(fam, mode, "loss", la[0].item(), lb[0].item())
+    assert la[1].shape[0] == B
+    PARITY.check(fam, mode, "loss_i", la[1].detach().cpu().numpy(), lb[1].detach().cpu().numpy())
+    PARITY.check(fam, mode, "d_features_1", dfa[0].cpu().numpy(), t1.grad.cpu().numpy())
+    PARITY.check(fam, mode, "d_features_2", dfa[1].cpu().numpy(), t2.grad.cpu().numpy())
+    for k, prm in f.named_parameters():
+        if k in head_names:
+            PARITY.check(fam, mode, k, ga[k].cpu().numpy(), prm.grad.cpu().numpy())
+    # (c) one whole train_step (main_3dident.py:467-503) with the flat HIP Adam over backbone + head parameters
+    opt = Adam(f.parameters(), lr=1e-4)
+    before = {k: v.detach().clone() for k, v in f.named_parameters()}
+    tot, per, lst = T.train_step(((None, None), (x1, x2)), loss, opt, f, sync=True)
+    assert np.isfinite(tot) and abs(tot - la[0].item()) < 1e-4 * abs(tot)
+    moved = [float((prm.detach() - before[k]).abs().max()) for k, prm in f.named_parameters()]
+    assert all(np.isfinite(m) for m in moved) and max(moved) <= 1.0001e-4 and min(moved) >= 0.0 and np.median(moved) > 5e-5

@@ -62,3 +62,58 @@ def test_two_ranks_match_single_process(tmp_path, B, n, wide, head):
             # rows that make up the weight gradient of that layer): measured relative to that weight gradient
             floor = last_w_scale
         PARITY.check(fam + "/grad", case, k, r0["grad"][sl], g_ref[sl], floor=floor)
+
+
+@pytest.mark.parametrize("p,box", [(1, 0), (2, 1)])
+def test_kitti_solver_two_ranks(tmp_path, p, box):
+    """BASELINE config 5 is a data-parallel config: the KITTI-masks Solver (kitti_masks/solver.py:61-74 loop body) with
+    world = 2 -- conv encoder on MIOpen, Linear / Softclip / loss / flat Adam on the HIP kernels, autograd-aware all-gather
+    of the first views as the negatives pool, all-reduce of the flat gradient arena -- against the single-process Solver on
+    the concatenated batch: rank-mean loss == global loss, summed gradient arena == 2 x single-process gradients, identical
+    replicas after the step (and only rank 0 writes log.csv / checkpoints)."""
+    import socket
+    sys.path.insert(0, HERE)
+    from kitti_dp2_worker import kitti_batch, solver_args
+    Bp = 24                                         # pairs per rank
+    port = free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "kitti_dp2_worker.py"), str(r), str(port), str(tmp_path / f"r{r}"),
+                               str(Bp), str(p), str(box)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    for r in range(2):
+        os.makedirs(tmp_path / f"r{r}", exist_ok=True)
+    outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+    for q, o in zip(procs, outs):
+        assert q.returncode == 0, o[-3000:]
+    r0, r1 = (torch.load(tmp_path / f"r{r}" / f"kitti_rank{r}.pt") for r in range(2))
+    assert r0["wrote_log"] and not r1["wrote_log"]
+    for k in r0["init"]:
+        assert torch.equal(r0["init"][k], r1["init"][k]), k            # rank 0's initial weights were broadcast
+        assert torch.equal(r0["final"][k], r1["final"][k]), k          # replicas stay identical
+    assert torch.equal(r0["grad"], r1["grad"])
+    # single process, concatenated batch, same initial weights
+    from cl_ica_amd.kitti_masks.solver import Solver
+    d = tmp_path / "single"; d.mkdir()
+    x = kitti_batch(2 * Bp)
+    S = Solver(solver_args(str(d), p, box), data_loader=[(x, None)])
+    S.net.load_state_dict(r0["init"])
+    rec = []
+    inner = S.loss
+
+    def recording(*a):
+        out = inner(*a)
+        rec.append(out[0].item())
+        return out
+    S.loss = recording
+    assert S.train() is False
+    from conftest import PARITY
+    fam, case = "kitti_dp2_vs_single_process", f"p={p} box_norm={box} pairs/rank={Bp}"
+    logged = [float(open(tmp_path / "r0" / "log.csv").read().split()[2])]          # rank 0 logs the mean over the ranks
+    PARITY.check(fam, case, "loss (rank mean, as logged)", logged[0], rec[0], tol=2e-5 if abs(rec[0]) < 1 else 1e-5)
+    g_ref = 2.0 * S.optim.grad_arena.cpu().numpy()
+    off = 0
+    for name, prm in S.net.named_parameters():
+        sl = slice(off, off + prm.numel()); off += (prm.numel() + 3) // 4 * 4
+        got, ref = r0["grad"].numpy()[sl], g_ref[sl]
+        if name == "encoder.11.bias" and not box:
+            assert np.abs(got).max() < 1e-5 * max(np.abs(g_ref).max(), 1e-30) + 1e-7       # translation invariance: exact gradient 0
+            continue
+        PARITY.check(fam + "/grad", case, name, got, ref)

@@ -9,6 +9,7 @@ from oracle import np_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5   # north_star: loss value and embedding gradients within 1e-5 relative fp32
+SAT_CAP = 3e-5   # hard ceiling of the saturated-row allowance (saturation_allowance)
 
 
 def dev(a):
@@ -71,7 +72,12 @@ def saturation_allowance(z1, z2, z3, p, tau, alpha, compat, pw, ref, loss_floor=
     |lse| ~ 10^2 the fp32 REFERENCE golden itself is only accurate to eps32 * |lse| relative to the summands; its own
     distance `dev` from the fp64 oracle is measured here with the same denominators the comparison uses.  Returns
     (tol, note): tol = 1e-5 unless dev > 2.5e-6, in which case tol = 1e-5 + 2 dev (the HIP result may sit on the other side
-    of the fp64 truth)."""
+    of the fp64 truth) -- CAPPED at SAT_CAP = 3e-5 whatever the formula gives (an allowance that scales with the
+    golden's own error must not be able to hide a regression; the largest error ever measured under it is 2.9e-5).
+    Why these few rows cannot be held to 1e-5 at all: one ulp of a logit of magnitude 300 is 3e-5, and a softmax weight
+    inherits the logit's ABSOLUTE error as a relative error, so two correct fp32 evaluations of the same row -- this one and
+    the reference's, whose torch.norm accumulates in fp64 but then rounds to fp32 and takes ** p and / tau in fp32 -- differ
+    by that much unless they share pow / exp bit for bit."""
     orc = O.lp_simclr_loss(z1, z2, z3, p=p, tau=tau, alpha=alpha, compat=compat, pow=pw)
     dev_ref = 0.0
     for k in ("loss_i", "dz1", "dz2", "dz3"):
@@ -87,8 +93,8 @@ def saturation_allowance(z1, z2, z3, p, tau, alpha, compat, pw, ref, loss_floor=
     logit_tol = 8.0 * float(np.finfo(np.float32).eps) * lse_mag if lse_mag > 20.0 else 0.0
     if dev_ref <= 2.5e-6 and logit_tol == 0.0:
         return None, None
-    return TOL + max(2.0 * dev_ref if dev_ref > 2.5e-6 else 0.0, logit_tol), \
-        "saturated golden: tol = 1e-5 + max(2 x fp32 reference's own deviation from the fp64 oracle, 8 eps32 max|lse|)"
+    return min(SAT_CAP, TOL + max(2.0 * dev_ref if dev_ref > 2.5e-6 else 0.0, logit_tol)), \
+        "saturated golden (|lse| > 20): tol = min(3e-5, 1e-5 + max(2 x fp32 reference's own deviation from the fp64 oracle, 8 eps32 max|lse|))"
 
 
 @pytest.mark.parametrize("name", ["g1_lp_loss.npz", "g2_rect.npz", "g3_misc.npz", "g19_wide_lp.npz", "g22_lp_loss_large.npz"])

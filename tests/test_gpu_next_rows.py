@@ -53,6 +53,43 @@ def test_n3_reference_checkpoints_load_and_reproduce(golden, tmp_path):
     assert torch.equal(g.weight_stack().cpu(), torch.stack([sd[k] for k in sd]))
 
 
+def test_n3_supervised_phase_goldens(golden):
+    """G24: the SUPERVISED phase of main_mlp.py (the first of the default test_list = [True, False]): five injected steps of
+    the reference's train_step with F.mse_loss(z1_rec, z1) (main_mlp.py:258-285, :274-276), run here through train_mlp's own
+    step function (autograd_train_step: drop-in encoder / mixing net on the HIP kernels, flat-arena HIP Adam) -- per-step
+    loss, step-0 reconstruction and gradients, parameters after five Adam updates."""
+    from cl_ica_amd import invertible_network_utils as inu, train_mlp
+    from cl_ica_amd.optim import Adam
+    from test_gpu_configs import adam_trajectory_check, build_mlp, traj_tol
+    from conftest import golden_view
+    G = golden("g24_supervised.npz")
+    for key, c in G.cases():
+        n, B = int(c["meta"]["n"]), int(c["meta"]["B"])
+        head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]; lr = float(c["meta"]["lr"]); steps = int(c["meta"]["steps"])
+        stride = int(c["meta"]["stride"])
+        f = build_mlp(n, hidden, head).to("cuda")
+        g = inu.MixingMLP([c["in"][f"g{i}"] for i in range(3)], act_fct="leaky_relu").to("cuda")
+        h = lambda z: f(g(z))   # noqa: E731
+        opt = Adam(f.parameters(), lr=lr)
+        fam, case = "n3_supervised_g24", f"{key} n={n} B={B} head={head}"
+        for s in range(steps):
+            z1, z2 = dev(c["in"][f"z1_{s}"]), dev(c["in"][f"z2_{s}"])
+            if s == 0:
+                with torch.no_grad():
+                    PARITY.check(fam, case, "z1_rec0", h(z1).cpu().numpy(), c["out"]["z1_rec0"])
+            tot = train_mlp.autograd_train_step(h, None, opt, z1, z2, supervised=True)
+            tl, tn = traj_tol(s)
+            PARITY.check(fam, f"{case} step{s}", "loss", tot.item(), c["out"]["loss"][s], tol=tl, note=tn)
+            if s == 0:
+                for name, prm in f.named_parameters():
+                    ref = c["out"][f"grad0/{name}"]
+                    PARITY.check(fam + "/grad", case, name, golden_view(prm.grad.cpu().numpy(), ref, stride).reshape(-1), ref.reshape(-1))
+        masks = ({k[len("gmin/"):]: v for k, v in c["out"].items() if k.startswith("gmin/")},
+                 {k[len("gmax/"):]: float(v) for k, v in c["out"].items() if k.startswith("gmax/")})
+        adam_trajectory_check(fam + "/adam_params", key, f, c["out"], "param5", stride, lr, steps, masks=masks)
+
+
 def test_n2_metrics_on_device(golden):
     """R^2 / MCC of the periodic evaluation (disentanglement_utils.py:63-221) with DEVICE tensors in, against the
     reference's sklearn + Munkres values (G11)."""

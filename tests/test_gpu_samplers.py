@@ -157,3 +157,42 @@ def test_adam_step_tick_advances_counter_once():
         ops.adam_step(p2, g, m2, v2, step2, 1e-3); ops.tick(step2)
         assert int(step.item()) == it + 1 and int(ticket.item()) == 0
     assert torch.equal(p, p2) and torch.equal(m, m2) and torch.equal(v, v2)
+
+
+def test_product_latent_space_on_device(golden):
+    """ProductLatentSpace (latent_spaces.py:49-75: block-wise sampling, the conditional of every factor sees ITS column slice
+    z[:, lo:hi] of the concatenated sample -- a strided view) on the device samplers: a box x sphere product, every block
+    against the per-block G9 reference statistics, blocks independent of each other."""
+    from cl_ica_amd import latent_spaces, spaces
+    z9 = golden("g9_samplers.npz").z
+    qs = z9["quantiles"]
+    spaces.manual_seed(3)
+    box, sph = spaces.NBoxSpace(10, 0.0, 1.0), spaces.NSphereSpace(10)
+    ls_box = latent_spaces.LatentSpace(box, lambda space, size, device="cuda": space.uniform(size, device=device),
+                                       lambda space, z, size, device="cuda": space.normal(z, 0.05, size, device))
+    ls_sph = latent_spaces.LatentSpace(sph, lambda space, size, device="cuda": space.uniform(size, device=device),
+                                       lambda space, z, size, device="cuda": space.normal(z, 0.05, size, device))
+    prod = latent_spaces.ProductLatentSpace([ls_box, ls_sph])
+    assert prod.dim == 20
+    z = prod.sample_marginal(size=N, device="cuda")
+    zt = prod.sample_conditional(z, size=N, device="cuda")
+    assert z.shape == (N, 20) and zt.shape == (N, 20) and z.is_cuda and zt.is_cuda
+    zb, ztb = z[:, :10].cpu().numpy(), zt[:, :10].cpu().numpy()
+    assert zb.min() >= 0 and zb.max() < 1 and ztb.min() >= 0 and ztb.max() <= 1
+    assert np.abs(zb.mean(0) - z9["box_uniform/mean"]).max() < 0.006 and np.abs(q(zb, qs) - z9["box_uniform/q"]).max() < 0.012
+    d = ztb - zb
+    assert np.abs(d.var(0) - z9["box_normal/delta_var"]).max() < 1e-4
+    assert np.abs(q(d, qs)[1:-1] - z9["box_normal/delta_q"][1:-1]).max() < 2e-3
+    s, st = z[:, 10:], zt[:, 10:]
+    assert float((s.norm(dim=-1) - 1).abs().max()) < 1e-5 and float((st.norm(dim=-1) - 1).abs().max()) < 1e-5
+    cos = (s * st).sum(-1).cpu().numpy()
+    assert abs(cos.mean() - float(z9["sphere_normal/cos_mean"])) < 1e-4
+    assert np.abs(q(cos, qs, None) - z9["sphere_normal/cos_q"]).max() < 6e-4
+    # the conditional of a block depends on ITS slice only: the box block's perturbation is uncorrelated with the sphere block
+    assert abs(np.corrcoef(d[:, 0], (st - s)[:, 0].cpu().numpy())[0, 1]) < 0.02
+    assert abs(np.corrcoef(zb[:, 0], s[:, 0].cpu().numpy())[0, 1]) < 0.02
+    # a 1-D mean (one point of the product space) is sliced per factor as well (latent_spaces.py:57-60)
+    z0 = z[0]
+    zt0 = prod.sample_conditional(z0, size=1000, device="cuda")
+    assert zt0.shape == (1000, 20) and float((zt0[:, :10] - z0[:10]).abs().max()) < 0.5
+    assert float((zt0[:, 10:].norm(dim=-1) - 1).abs().max()) < 1e-5

@@ -189,6 +189,65 @@ def test_trainstep_goldens(golden):
                 assert (diff > 2e-4).mean() < 0.01, (key, l, kind, float((diff > 2e-4).mean()))
 
 
+def test_supervised_phase_goldens(golden):
+    """G24 (tests/golden/gen_goldens_r3.py): the reference's SUPERVISED train_step (F.mse_loss(z1_rec, z1), main_mlp.py:274-276)
+    pins oracle.supervised_train_step: per-step loss, step-0 gradients, and the parameters after five Adam updates on the
+    elements whose gradient stayed above 1 % of the tensor's largest (g24's own gmin / gmax record)."""
+    G = golden("g24_supervised.npz")
+    for key, c in G.cases():
+        n = int(c["meta"]["n"]); head = str(c["meta"]["head"]); head = None if head == "None" else head
+        hidden = [int(h) for h in c["meta"]["hidden"]]; lr = float(c["meta"]["lr"]); stride = int(c["meta"]["stride"])
+        Ws, bs, hp = mlp_formula_params(n, hidden, head)
+        P = O.MLPParams(Ws, bs, head, hp)
+        shapes = []
+        for l in range(len(Ws)):
+            shapes += [Ws[l].shape, bs[l].shape]
+        if head in ("learnable_sphere", "learnable_box"):
+            shapes.append(hp.shape)
+        st = dict(step=0, m=[np.zeros(s) for s in shapes], v=[np.zeros(s) for s in shapes])
+        gWs = [c["in"][f"g{i}"] for i in range(3)]
+        names = [f"{2 * l}.{kind}" for l in range(len(Ws)) for kind in ("weight", "bias")]
+        if len(shapes) > len(names):
+            names.append(f"{2 * len(Ws) - 1}.max_abs_bound" if head == "learnable_box" else f"{2 * len(Ws) - 1}.r")
+        for s in range(int(c["meta"]["steps"])):
+            loss, grads = O.supervised_train_step(P, gWs, c["in"][f"z1_{s}"], st, lr=lr, return_grads=True)
+            assert abs(loss - c["out"]["loss"][s]) < 1e-5 * abs(c["out"]["loss"][s]), (key, s, loss, c["out"]["loss"][s])
+            if s == 0:
+                for name, g in zip(names, grads):
+                    ref = c["out"][f"grad0/{name}"]
+                    got = g if ref.size == g.size else np.ascontiguousarray(np.asarray(g).reshape(-1)[::stride])
+                    assert rel_err(got.reshape(-1), ref.reshape(-1)) < 2e-5, (key, name)
+        finals = []
+        for l in range(len(Ws)):
+            finals += [P.W[l], P.b[l]]
+        if len(shapes) > 2 * len(Ws):
+            finals.append(P.head_param)
+        n_strict = 0
+        for name, got in zip(names, finals):
+            ref = c["out"][f"param5/{name}"]
+            got = got if ref.size == got.size else np.ascontiguousarray(got.reshape(-1)[::stride])
+            strict = c["out"][f"gmin/{name}"].reshape(-1) > 0.01 * float(c["out"][f"gmax/{name}"])
+            n_strict += int(strict.sum())
+            if strict.any():
+                err = np.abs(got.reshape(-1) - ref.reshape(-1))[strict].max() / max(np.abs(ref).max(), 1e-30)
+                assert err < 6e-5, (key, name, err)
+        assert n_strict > 1000
+
+
+def test_adam_mask_file_matches_the_trajectory_goldens(golden):
+    """g23_adam_masks.npz holds one gmin array per stored final-parameter array of G7 / G13 / G14 (solver cases) / G15, same shape."""
+    z = golden("g23_adam_masks.npz").z
+    for tag, fname, prefix in (("g7", "g7_trainstep.npz", "param5"), ("g13", "g13_wide_trainstep.npz", "paramN"),
+                               ("g14", "g14_kitti.npz", "param3"), ("g15", "g15_3dident.npz", "param3")):
+        gz = golden(fname).z
+        keys = [k for k in gz.files if f"/out/{prefix}/" in k]
+        assert keys
+        for k in keys:
+            case, name = k.split("/")[0], k.split(f"/out/{prefix}/")[1]
+            m = z[f"{tag}/{case}/gmin/{name}"]
+            assert m.shape == gz[k].shape and (m >= 0).all() and float(z[f"{tag}/{case}/gmax/{name}"]) >= float(m.max()) * 0.999999
+
+
 def test_formula_in_sync(golden):
     c = golden("g6_mlp.npz").case("c000")
     assert np.array_equal(c["in"]["x"], np.asarray(formula_weights((48, 4), 99) * np.sqrt(4) * 1.5, np.float32))
