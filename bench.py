@@ -66,11 +66,14 @@ def parse():
     ap.add_argument("--split-bf16", action="store_true", help="(default since round 3; accepted for compatibility)")
     ap.add_argument("--no-native-leg", "--no-split-probe", dest="no_native_leg", action="store_true",
                     help="skip the `native_fp32` leg (the same step on the fp32-MFMA kernels, N = 1 only)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the `secondary` leg (BASELINE config 3 on one rank: n = 40, sphere, p = 1, B = 6144, with the local pool and with "
+                         "the emulated 49 152-row pool of the 8-GPU job; N = 1 only)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
 
-def build_trainer(args, device, world, split_bf16=None):
+def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1):
     from cl_ica_amd import encoders, invertible_network_utils as inu
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
     import contextlib, io
@@ -85,7 +88,8 @@ def build_trainer(args, device, world, split_bf16=None):
     return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
                               device=device, process_group=None if world == 1 else dist.group.WORLD,
                               overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward,
-                              split_bf16=(not args.native_fp32) if split_bf16 is None else split_bf16)
+                              split_bf16=(not args.native_fp32) if split_bf16 is None else split_bf16,
+                              emulate_pool_ranks=emulate_pool_ranks)
 
 
 def _graph_time(fns, reps):
@@ -498,6 +502,37 @@ def comm_leg(tr, rank, world, device, reps=20):
     return allr
 
 
+def secondary_leg(args, device, steps=20, windows=3):
+    """BASELINE config 3 on ONE rank (main_mlp.py --n 40 --space-type sphere --p 1 --batch-size 6144: 13.6 M parameters, 1.005
+    TFLOP of encoder GEMMs per step, 2000-wide layers -> the per-layer fp32-MFMA kernels): step rate with the local negatives
+    pool (B3 = 6144) and with the pool of the 8-GPU job emulated on this GPU (B3 = 49 152: the local embeddings replicated eight
+    times, device copies in place of the two all-gathers -- this rank's compute of the data-parallel job, no communication)."""
+    import copy
+    a = copy.copy(args)
+    a.n, a.space_type, a.p = 40, "sphere", 1
+    res = {"workload": "main_mlp.py --n 40 --space-type sphere --p 1 --batch-size 6144 (BASELINE configs[2], one rank's work)",
+           "encoder_gflop_per_step": round(3 * 2 * 13632000 * 2 * a.batch_size / 1e9, 1), "dtype": "f32 (native fp32 MFMA, per-layer kernels)"}
+    for name, ranks in (("pool_6144", 1), ("pool_49152_emulated_8_ranks", 8)):
+        tr = build_trainer(a, device, 1, emulate_pool_ranks=ranks)
+        capture_or_eager(tr, a, 0, 1, device)
+        w, _ = timed_windows(tr, steps, 5, windows, 1, device)
+        el = float(np.median(w))
+        ent = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": len(w),
+               "negatives_pool": a.batch_size * ranks, "final_loss": float(tr.loss_out[3 * tr.B].item()),
+               "whole_step_encoder_tflops": round(3 * 2 * 13632000 * 2 * a.batch_size / (el / steps) / 1e12, 1)}
+        if ranks == 1 and not args.no_roofline:
+            roof, rows = roofline_leg(tr, reps=5)
+            ent["roofline"] = {k: roof[k] for k in ("kernel", "op", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
+                                                    "algorithmic_gflop_per_launch", "dtype")}
+            ent["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+            ll = loss_leg(tr, reps=5)
+            ent["loss_kernel"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ll.items()}
+        res[name] = ent
+        del tr
+        torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse()
     from cl_ica_amd.distributed import init_from_env
@@ -576,6 +611,8 @@ def main():
             leg["roofline"] = {k: roof2[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
                                                      "algorithmic_gflop_per_launch", "dtype")}
         out["native_fp32"] = leg
+    if rank == 0 and world == 1 and not args.no_secondary and (args.n, args.space_type, args.p) == (10, "box", 2):
+        out["secondary"] = secondary_leg(args, device)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

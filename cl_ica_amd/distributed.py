@@ -49,7 +49,8 @@ class GradBuckets:
     gradient has been written."""
 
     def __init__(self, arena: torch.Tensor, layer_slices: Sequence[Tuple[int, int]], world: int,
-                 group: Optional[dist.ProcessGroup], bucket_bytes: int = 8 << 20, force: bool = False):
+                 group: Optional[dist.ProcessGroup], bucket_bytes: int = 8 << 20, force: bool = False,
+                 boundaries: Sequence[int] = ()):
         self.arena, self.group, self.world = arena, group, world
         self.force = force
         self.buckets: List[Tuple[int, int]] = []      # (lo, hi) element ranges
@@ -58,7 +59,9 @@ class GradBuckets:
         for i, (a, b) in enumerate(layer_slices):
             lo = a if lo is None else min(lo, a)
             hi = b if hi is None else max(hi, b)
-            if (hi - lo) * 4 >= bucket_bytes or i == len(layer_slices) - 1:
+            # `boundaries`: completion indices after which a bucket closes whatever its size (the engine's two-half weight-gradient
+            # launch: the first half's all-reduce then runs under the second half's GEMMs)
+            if (hi - lo) * 4 >= bucket_bytes or i == len(layer_slices) - 1 or i in boundaries:
                 self.trigger[i] = len(self.buckets)
                 self.buckets.append((lo, hi))
                 lo = hi = None

@@ -67,7 +67,7 @@ class ContrastiveTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
                  force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True,
-                 split_bf16: Optional[bool] = None, g_act_kind: int = 0):
+                 split_bf16: Optional[bool] = None, g_act_kind: int = 0, emulate_pool_ranks: int = 1):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -86,6 +86,10 @@ class ContrastiveTrainer:
         # run the collectives even at world size 1 (test hook: exercises the DP code path on one GPU)
         self.force_collectives = bool(force_collectives)
         self.dp = self.world > 1 or (force_collectives and dist.is_initialized())
+        # measurement aid (bench.py `secondary` leg): ONE rank's compute of an R-rank data-parallel job on one GPU -- the negatives
+        # pool holds R copies of the local embeddings (R x B rows, device-to-device copies stand in for the two all-gathers), so
+        # the pair sweeps do the work they do on an R-GPU node.  Not a training mode: every negative counts R times.
+        self.emulate_pool = int(emulate_pool_ranks) if (self.world == 1 and not self.dp) else 1
         if self.p == 0:
             raise NotImplementedError("p=0 (SimCLRLoss) runs through cl_ica_amd.losses.SimCLRLoss, not the fused engine")
 
@@ -121,8 +125,14 @@ class ContrastiveTrainer:
                            group=process_group)
         self._allocate()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes,
-                                   force=self.dp) if self.dp else None
+        # data parallel + grouped weight gradients: the grouped launch is issued in TWO halves (layers L-1 .. h, then h-1 .. 0) and
+        # the first half's slice of the gradient arena is all-reduced on the communication stream while the second half's GEMMs run
+        L = len(self.linears)
+        self.wgrad_halves = bool(self.dp and self.fused_backward and self.grouped_wgrad and L >= 4
+                                 and os.environ.get("CLICA_WGRAD_HALVES", "1") != "0")
+        self._half = L // 2
+        self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes, force=self.dp,
+                                   boundaries=(L - 1 - self._half,) if self.wgrad_halves else ()) if self.dp else None
 
     # -------------------------------------------------------------------------------- arenas
     def _flatten_parameters(self):
@@ -187,9 +197,10 @@ class ContrastiveTrainer:
         self.side_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.overlap_backward) else None
         self.dy = torch.empty((R, n), **f32)
         self.loss_out = torch.empty(3 * B + 3, **f32)
-        Bg = B * self.world
-        self.z_all = torch.empty((Bg, n), **f32) if self.dp else None
-        self.lse_all = torch.empty((Bg,), **f32) if self.dp else None
+        Bg = B * self.world * self.emulate_pool
+        pooled = self.dp or self.emulate_pool > 1
+        self.z_all = torch.empty((Bg, n), **f32) if pooled else None
+        self.lse_all = torch.empty((Bg,), **f32) if pooled else None
         self.desc = _lib.LpLossDesc(B=B, B3=Bg, n=n, p=self.p, tau=self.tau, alpha=self.alpha, compat=1, pow=1)
         fb, bb = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(self.desc), C.byref(fb), C.byref(bb)), "workspace")
@@ -338,8 +349,12 @@ class ContrastiveTrainer:
         B, n, o = self.B, self.n, self.loss_out
         y1, y2 = self.y[:B], self.y[B:]
         lse = o[2 * B:3 * B]
+        emu = self.emulate_pool > 1
         if self.dp:
             dist.all_gather_into_tensor(self.z_all, y1.contiguous(), group=self.pg)
+            pool = self.z_all
+        elif emu:
+            self.z_all.view(self.emulate_pool, B, n).copy_(y1.unsqueeze(0))
             pool = self.z_all
         else:
             pool = y1
@@ -352,7 +367,9 @@ class ContrastiveTrainer:
                                                    self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd_train")
             if self.dp:
                 dist.all_gather_into_tensor(self.lse_all, lse, group=self.pg)
-            pool_lse = self.lse_all if self.dp else lse
+            elif emu:
+                self.lse_all.view(self.emulate_pool, B).copy_(lse.unsqueeze(0))
+            pool_lse = self.lse_all if (self.dp or emu) else lse
             _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(self.desc), y1.data_ptr(), n, pool.data_ptr(), n,
                                                        lse.data_ptr(), pool_lse.data_ptr(), self.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(),
                                                        self.step_dev.data_ptr() if self.early_tick else None,
@@ -364,6 +381,9 @@ class ContrastiveTrainer:
                                          None, 0, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")
         if self.dp:
             dist.all_gather_into_tensor(self.lse_all, lse, group=self.pg)
+            pool_lse = self.lse_all
+        elif emu:
+            self.lse_all.view(self.emulate_pool, B).copy_(lse.unsqueeze(0))
             pool_lse = self.lse_all
         else:
             pool_lse = lse
@@ -408,16 +428,16 @@ class ContrastiveTrainer:
             ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
                                 masks_chain=[self.signmasks[l - 1] for l in chain])
 
-    def weight_grads(self, g):
-        """Every layer's dW / db: tiny-layer launch + one grouped split-K GEMM of equal-length work items + one grouped slab
-        reduction (fp32 MFMA on the fp32 copies, or bf16x3 MFMA on the plane copies in split mode)."""
+    def weight_grads(self, g, layers=None):
+        """dW / db of `layers` (default: every layer): tiny-layer launch + one grouped split-K GEMM of equal-length work items +
+        one grouped slab reduction (fp32 MFMA on the fp32 copies, or bf16x3 MFMA on the plane copies in split mode)."""
         L = len(self.linears)
         R = g.shape[0]
-        order = list(range(L))
+        order = list(range(L)) if layers is None else list(layers)
         dWs = [self._gviews[id(self.linears[l].weight)] for l in order]
         dbs = [self._gviews[id(self.linears[l].bias)] for l in order]
         if self.split_wgrad:
-            ops.mlp_wgrad_split(R, self.dz_planes, [self.act_planes[l - 1] if l > 0 else None for l in order],
+            ops.mlp_wgrad_split(R, [self.dz_planes[l] for l in order], [self.act_planes[l - 1] if l > 0 else None for l in order],
                                 [g if l == L - 1 else self.dz_out[l] for l in order],
                                 [self.acts_out[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
         else:
@@ -434,6 +454,16 @@ class ContrastiveTrainer:
             # (1) the data-gradient chain in one launch; (2) the weight-gradient GEMMs
             self.backward_chain(g)
             if self.grouped_wgrad:
+                if self.buckets is not None and self.wgrad_halves:
+                    h = self._half
+                    self.weight_grads(g, layers=range(h, L))          # the head parameter's slot rides in the first slice
+                    for i in range(0, L - h):
+                        self.buckets.layer_done(i)                    # completion index i = layer L - 1 - i: all-reduce starts now ...
+                    self.weight_grads(g, layers=range(0, h))          # ... and runs under this launch
+                    for i in range(L - h, L):
+                        self.buckets.layer_done(i)
+                    self.buckets.wait()
+                    return
                 self.weight_grads(g)
                 if self.buckets is not None:
                     for i in range(L):

@@ -43,6 +43,9 @@ def main():
     assert tr.world == 2 and tr.dp
     if wide:
         assert not tr.fused_forward and len(tr.buckets.buckets) >= 3          # bucketed, overlapped all-reduce path
+    else:
+        # grouped weight gradients in two halves, the first half's all-reduce under the second half's launch
+        assert tr.fused_forward and tr.wgrad_halves and len(tr.buckets.buckets) == 2
     out = tr.step_injected(z1[rank * B:(rank + 1) * B], z2[rank * B:(rank + 1) * B])
     torch.cuda.synchronize()
     np.savez(os.path.join(outdir, f"rank{rank}.npz"), means=out.cpu().numpy(), grad=tr.grad_arena.cpu().numpy(),
