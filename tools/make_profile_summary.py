@@ -74,3 +74,33 @@ for name, c in pm.items():
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of tools/profile_round.sh {tag} (KB as reported; FETCH x2 per "
                      "MI355X_MICROARCH.md); per-launch averages", "kernels": traffic}, open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 print("\n".join(lines[:14]))
+
+# ---- BASELINE config 3 (n = 40) profile: kernel stats + traffic + MFMA busy
+if os.path.exists(f"{src}/trace_c3/t_kernel_stats.csv"):
+    shutil.copy(f"{src}/trace_c3/t_kernel_stats.csv", f"profiles/{tag}_c3_kernel_stats.csv")
+    shutil.copy(f"{src}/bench_c3_under_rocprof.json", f"profiles/{tag}_c3_bench_under_rocprof.json")
+    pm3 = {}
+    for name in ("pmc_c3_fetch", "pmc_c3_write", "pmc_c3_sq"):
+        p_ = f"{src}/{name}/p_counter_collection.csv"
+        if os.path.exists(p_):
+            for k, v in agg(p_).items():
+                pm3.setdefault(k, {}).update(v)
+    b3 = json.load(open(f"{src}/bench_c3_under_rocprof.json"))
+    out3 = [f"# Profile {tag}, BASELINE config 3 on one rank: `bench.py --n 40 --space-type sphere --p 1` (B = 6144, 13.6 M parameters, 1.005 TFLOP of encoder GEMMs per step)", "",
+            f"bench line under the profiler: {b3['value']:.1f} steps/s, {b3['ms_per_step']:.3f} ms/step ({b3['dtype']}); roofline entry `{b3['roofline']['kernel']}` "
+            f"{b3['roofline']['achieved']} TFLOP/s = {b3['roofline']['frac']:.3f} of {b3['roofline']['peak']}.", "",
+            "| kernel | calls | avg us | % time | fetch_x2 MB | write MB | MfmaUtil |", "|---|---|---|---|---|---|---|"]
+    tr3 = {}
+    for r in csv.DictReader(open(f"{src}/trace_c3/t_kernel_stats.csv")):
+        c = pm3.get(r["Name"], {})
+        fetch = f"{2 * c['FETCH_SIZE'] / 1024:.1f}" if "FETCH_SIZE" in c else ""
+        write = f"{c['WRITE_SIZE'] / 1024:.1f}" if "WRITE_SIZE" in c else ""
+        util = f"{c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] / 8 * 1024):.2f}" if c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and c.get("GRBM_GUI_ACTIVE", 0) > 0 else ""
+        short = r["Name"].split("(")[0].replace("void ", "")
+        out3.append(f"| `{short}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | {float(r['Percentage']):.2f} | {fetch} | {write} | {util} |")
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            tr3[short] = {"fetch_x2_bytes": 2 * c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024, "launches_sampled": c["_n"]}
+    open(f"profiles/{tag}_c3_summary.md", "w").write("\n".join(out3) + "\n")
+    json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh {tag} on bench.py --n 40 --space-type sphere --p 1", "kernels": tr3},
+              open(f"profiles/{tag}_c3_traffic.json", "w"), indent=1)
+    print("\n".join(out3[:12]))
