@@ -288,16 +288,22 @@ def roofline_leg(tr, reps=20):
     try:        # HBM-side bytes per launch from the committed PMC passes (cannot be collected from inside this process)
         here = os.path.dirname(os.path.abspath(__file__))
         cand = sorted(f for f in os.listdir(os.path.join(here, "profiles")) if f.endswith("_traffic.json"))
-        if cand:
-            tj = json.load(open(os.path.join(here, "profiles", cand[-1])))
-            ent = tj["kernels"].get(top["kernel"])
+        for fname in reversed(cand):             # newest round first; the file that knows this kernel symbol (headline / config-3 profiles)
+            tj = json.load(open(os.path.join(here, "profiles", fname)))
+            ent = tj["kernels"].get(top["kernel"].split(" (+")[0].split(" [")[0])
+            if ent is None:         # per-layer symbols are abbreviated in the bench line ("...4 waves..."): match on the tile shape prefix
+                pre = top["kernel"].split("...")[0]
+                tail = top["kernel"].split("...")[-1].rstrip(">").strip(", ")
+                hits = [v for k, v in tj["kernels"].items() if k.startswith(pre) and tail and k.rstrip(">").endswith(tail)] if "..." in top["kernel"] else []
+                ent = hits[0] if len(hits) == 1 else None
             if ent:
                 traffic = round(ent["fetch_x2_bytes"] + ent["write_bytes"])
                 import hashlib
-                digest = hashlib.sha256(open(os.path.join(here, "profiles", cand[-1]), "rb").read()).hexdigest()[:12]
-                traffic_src = (f"NOT measured by this run: copied from the committed PMC profile profiles/{cand[-1]} (sha256 {digest}; "
+                digest = hashlib.sha256(open(os.path.join(here, "profiles", fname), "rb").read()).hexdigest()[:12]
+                traffic_src = (f"NOT measured by this run: copied from the committed PMC profile profiles/{fname} (sha256 {digest}; "
                                "FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 --pmc passes of tools/profile_round.sh) -- "
                                "stale if the kernel changed after that profile was taken")
+                break
     except Exception:
         pass
     roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(issued_factor * top["tflops"], 2),
@@ -511,7 +517,8 @@ def secondary_leg(args, device, steps=20, windows=3):
     a = copy.copy(args)
     a.n, a.space_type, a.p = 40, "sphere", 1
     res = {"workload": "main_mlp.py --n 40 --space-type sphere --p 1 --batch-size 6144 (BASELINE configs[2], one rank's work)",
-           "encoder_gflop_per_step": round(3 * 2 * 13632000 * 2 * a.batch_size / 1e9, 1), "dtype": "f32 (native fp32 MFMA, per-layer kernels)"}
+           "encoder_gflop_per_step": round(3 * 2 * 13632000 * 2 * a.batch_size / 1e9, 1),
+           "dtype": "f32: forward / data-gradient GEMMs native fp32 MFMA (per-layer kernels), weight gradients via bf16x3 split"}
     for name, ranks in (("pool_6144", 1), ("pool_49152_emulated_8_ranks", 8)):
         tr = build_trainer(a, device, 1, emulate_pool_ranks=ranks)
         capture_or_eager(tr, a, 0, 1, device)
@@ -550,13 +557,15 @@ def main():
     last = tr.loss_out[3 * tr.B:].clone()
     loss_vals = [float(v) for v in last.cpu()]
     split = bool(tr.split_bf16)
+    wide_split = bool(getattr(tr, "split_wgrad_wide", False))
     enc = "10n-50n-50n-50n-50n-10n"
 
     out = {
         "metric": f"training steps/sec (B={args.batch_size}, n={args.n} MLP)", "value": world * args.steps / elapsed, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)" if split else "f32"), "data": "synthetic",
+        "dtype": ("f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)" if split else
+                  ("f32 (forward / data gradients native fp32 MFMA; weight gradients via bf16x3 split)" if wide_split else "f32")), "data": "synthetic",
         "global_steps_per_s": args.steps / elapsed,
         "warmup_extra_steps": extra_warm, "windows": len(window_s), "timed_steps_total": args.steps * len(window_s), "timing": "median window of `windows` x `steps` steps",
         "window_ms_per_step": [round(1e3 * w / args.steps, 4) for w in window_s],
@@ -572,7 +581,9 @@ def main():
         "gradients -- are split exactly into three bf16 pieces, the six piece products of order <= 2 run on the bf16 matrix cores "
         "with fp32 accumulation (max error vs fp64 8.6e-7 of max|y|, native fp32 MFMA 1.0e-6); every -m gpu engine test runs in "
         "this mode and in native fp32 against the same goldens / tolerances (tests/conftest.py: encoder_arith)"
-        if split else "native fp32 MFMA" + ("" if tr.fused_forward else " (per-layer kernels: a width beyond 512)"))
+        if split else ("native fp32 MFMA per-layer kernels for the forward and the data gradients (a width beyond 512); weight gradients of the "
+                       "MFMA-sized layers in the split-bf16 arithmetic on plane copies made by clica_mlp_planes_from_f32" if wide_split else
+                       "native fp32 MFMA" + ("" if tr.fused_forward else " (per-layer kernels: a width beyond 512)")))
     if world > 1:
         comm = comm_leg(tr, rank, world, device)
         if rank == 0:

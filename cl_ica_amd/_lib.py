@@ -79,6 +79,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_mlp_dgrad_split": [c_f32p, c_i64, c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(C.c_void_p),
                               C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.c_float, C.c_void_p],
     "clica_mlp_wgrad_split_kind": [c_i32, c_i32, C.POINTER(c_i32)],
+    "clica_mlp_planes_from_f32": [c_f32p, c_i64, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p],
     "clica_mlp_wgrad_split_workspace_bytes": [c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_size)],
     "clica_mlp_wgrad_split": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
                               C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),

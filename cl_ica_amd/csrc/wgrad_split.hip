@@ -281,6 +281,52 @@ extern "C" int clica_debug_wsplit_trace(unsigned long long* buf) {
 }
 #endif
 
+// ---- fp32 [M][F] -> bf16 planes (planes.h) -------------------------------------------------------------------------------
+// For operands no split whole-stack kernel produced: the per-layer fp32 kernels of wide encoders (a width beyond 512: BASELINE
+// config 3's 2000-wide layers), the encoder input x, the loss gradient dY.  One thread = four consecutive features of one row
+// (one float4 in, three 8-byte pieces out -- the store pattern of the mlp_split_k epilogue); HBM-bound, 4 B read + 6 B
+// written per element.  Rows beyond M and features beyond F are written as zeros (feature F as 1 when `ones`).
+__device__ __forceinline__ void split3_hi(float v, unsigned& hb, unsigned& mb, unsigned& lb) {     // piece bits in the HIGH half
+  hb = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(hb);
+  mb = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  lb = __float_as_uint(r2) & 0xFFFF0000u;
+}
+__global__ __launch_bounds__(256) void planes_from_f32_k(const float* __restrict__ X, int64_t ldx, int64_t M, int F, int ones, int units,
+                                                         char* __restrict__ out, int64_t groups) {
+  // thread -> (group g, unit u, key k, feature quad q): 16 keys x 8 quads = 128 threads per unit, two units per workgroup
+  const int64_t wu = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
+  if (wu >= groups * units) return;
+  const int64_t g = wu / units; const int u = (int)(wu - g * units);
+  const int t = threadIdx.x & 127, k = t >> 3, q = t & 7;
+  const int64_t row = g * 16 + k;
+  const int f0 = u * 32 + q * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (row < M) {
+    const float* src = X + row * ldx + f0;
+    if (f0 + 3 < F && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+      const float4 x4 = *reinterpret_cast<const float4*>(src);
+      v[0] = x4.x; v[1] = x4.y; v[2] = x4.z; v[3] = x4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (f0 + e < F) v[e] = src[e];
+    }
+  }
+  if (ones) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (f0 + e == F) v[e] = 1.f;       // every row of the group, padded rows included (they meet zero rows)
+  }
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3_hi(v[e], hb[e], mb[e], lb[e]);
+  const int s = q >> 2, c = (q & 3) * 4;                           // 16-feature half of the unit, first feature inside it
+  char* dst = out + ((g * units + u) * 3) * 1024 + (k >> 2) * 256 + s * 128 + (k & 3) * 32 + c * 2;
+  *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+  *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+  *reinterpret_cast<u32x2*>(dst + 2048) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+}
+
 // ---- plan: which body per layer, how many contraction splits -----------------------------------------------------------------
 struct Plan { int splits, gps, groups, tiles, n_tiny, tiny_splits; int64_t tiny_kps; };
 static void tile_shape(int32_t N, int32_t K, int* a_wide, int* gx, int* gy, bool with_db) {
@@ -330,6 +376,17 @@ static size_t ws_layout(const Plan& p, int n, const int32_t* N, const int32_t* K
 
 using namespace clica;
 using namespace clica::wsplit;
+
+extern "C" int clica_mlp_planes_from_f32(const float* X, int64_t ldx, int64_t M, int32_t width, int32_t ones_column, void* planes_out,
+                                         clica_stream_t stream) {
+  CLICA_CHECK_ARG(X && planes_out && M > 0 && width >= 1 && ldx >= width, "clica_mlp_planes_from_f32: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(planes_out) & 15) == 0, "clica_mlp_planes_from_f32: plane buffer must be 16-byte aligned");
+  const int units = planes::units(width, ones_column);
+  const int64_t groups = planes::groups_alloc(M);      // every group of the buffer is written (groups beyond the batch: zeros)
+  hipLaunchKernelGGL(planes_from_f32_k, dim3((unsigned)ceil_div(groups * units, 2)), dim3(256), 0, as_stream(stream),
+                     X, ldx, M, (int)width, ones_column ? 1 : 0, units, reinterpret_cast<char*>(planes_out), groups);
+  return launch_status("clica_mlp_planes_from_f32");
+}
 
 extern "C" int clica_mlp_wgrad_split_kind(int32_t N, int32_t K, int32_t* kind) {
   CLICA_CHECK_ARG(kind && N >= 1 && K >= 1, "clica_mlp_wgrad_split_kind: bad argument");

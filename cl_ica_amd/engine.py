@@ -113,6 +113,7 @@ class ContrastiveTrainer:
         # operand splits (fp32 emulation: six bf16 products per fp32 product, fp32 accumulate, fp32-grade error) --
         # the default where the encoder fits the whole-stack kernels; split_bf16=False / CLICA_SPLIT_BF16=0 = native fp32 MFMA
         want_split = (os.environ.get("CLICA_SPLIT_BF16", "1") == "1") if split_bf16 is None else bool(split_bf16)
+        self._want_split = want_split
         self.split_bf16 = self.fused_backward and want_split and all(lin.bias is not None for lin in self.linears) and \
             sum((lin.out_features + 31) // 32 * 32 for lin in self.linears) <= 3456      # on-chip bias table (fused_mlp.hip)
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
@@ -248,6 +249,20 @@ class ContrastiveTrainer:
                 if not keep and kinds[l] == 0:
                     self.dz_out[l] = None
             self.group_ws = ops.mlp_wgrad_split_workspace(R, [tuple(lin.weight.shape) for lin in self.linears], dev)
+        # Wide encoders (a width beyond 512: the per-layer fp32 GEMM path, BASELINE config 3): forward and data gradients stay on
+        # the fp32-MFMA kernels, the WEIGHT gradients of the MFMA-sized layers run in the split-bf16 arithmetic on plane copies
+        # that an HBM-bound conversion kernel makes of the fp32 activations / gradients (clica_mlp_planes_from_f32)
+        self.split_wgrad_wide = bool(self._want_split and not self.fused_forward and not self.fused_backward
+                                     and all(lin.bias is not None for lin in self.linears)
+                                     and os.environ.get("CLICA_SPLIT_WGRAD_WIDE", "1") != "0")
+        if self.split_wgrad_wide:
+            self.wide_kinds = [ops.mlp_wgrad_split_kind(lin.out_features, lin.in_features) for lin in self.linears]
+            in_w = [lin.in_features for lin in self.linears]
+            self.xin_planes = [ops.mlp_planes_alloc(R, in_w[l], True, dev) if self.wide_kinds[l] == 0 else None for l in range(L)]
+            self.dzw_planes = [ops.mlp_planes_alloc(R, widths[l], False, dev) if self.wide_kinds[l] == 0 else None for l in range(L)]
+            shapes = [tuple(lin.weight.shape) for lin in self.linears]
+            self.wide_ws = max((ops.mlp_wgrad_split_workspace(R, [shapes[l]], dev) for l in range(L) if self.wide_kinds[l] == 0),
+                               key=lambda t: t.numel(), default=None)
         if self.head is not None:
             self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
             hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
@@ -326,7 +341,10 @@ class ContrastiveTrainer:
                             signmasks=self.signmasks, mix=mix)
             cur = self.acts[-1]
         else:
+            wide = getattr(self, "split_wgrad_wide", False)
             for l, lin in enumerate(self.linears):
+                if wide and self.wide_kinds[l] == 0:        # this layer's input as bf16 planes for its weight gradient
+                    ops.mlp_planes_from_f32(cur, True, out=self.xin_planes[l])
                 ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=self.slope, out=self.acts[l])
                 cur = self.acts[l]
         if self.head is not None:
@@ -444,6 +462,17 @@ class ContrastiveTrainer:
             ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
                           [self.acts[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
 
+    def _wgrad_layer(self, l, g, inp, ws):
+        """dW_l / db_l of one layer on the per-layer path: fp32 MFMA GEMM, or -- wide encoders in split mode -- the split-bf16
+        kernel on plane copies (dZ converted here, the layer input converted in forward())."""
+        lin = self.linears[l]
+        dW, db = self._gviews[id(lin.weight)], self._gviews[id(lin.bias)]
+        if getattr(self, "split_wgrad_wide", False) and self.wide_kinds[l] == 0:
+            ops.mlp_planes_from_f32(g, False, out=self.dzw_planes[l])
+            ops.mlp_wgrad_split(g.shape[0], [self.dzw_planes[l]], [self.xin_planes[l]], [None], [None], [dW], [db], ws=self.wide_ws)
+        else:
+            ops.linear_wgrad(g, inp, dW=dW, db=db, accumulate=False, ws=ws)
+
     def backward(self):
         g = self._head_backward()
         L = len(self.linears)
@@ -502,15 +531,13 @@ class ContrastiveTrainer:
             if two:
                 side.wait_stream(main)                      # dZ_l is complete on main
                 with torch.cuda.stream(side):
-                    ops.linear_wgrad(g, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)],
-                                     accumulate=False, ws=self.wgrad_ws)
+                    self._wgrad_layer(l, g, inp, self.wgrad_ws)
                     if self.buckets is not None:
                         self.buckets.layer_done(L - 1 - l)
                     if buf_of_g is not None:
                         ev = torch.cuda.Event(); ev.record(side); reader_done[buf_of_g] = ev
             else:
-                ops.linear_wgrad(g, inp, dW=self._gviews[id(lin.weight)], db=self._gviews[id(lin.bias)], accumulate=False,
-                                 ws=self.wgrad_ws)
+                self._wgrad_layer(l, g, inp, self.wgrad_ws)
                 if self.buckets is not None:
                     self.buckets.layer_done(L - 1 - l)
             if l > 0:

@@ -180,6 +180,16 @@ def mlp_planes_alloc(M: int, width: int, ones: bool, device) -> torch.Tensor:
     return torch.zeros(nb.value, dtype=torch.uint8, device=device)
 
 
+def mlp_planes_from_f32(x: torch.Tensor, ones: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 plane copy (operand format of `mlp_wgrad_split`) of a fp32 [M, width] tensor (clica_mlp_planes_from_f32)."""
+    (x, ldx) = _mat("x", x)
+    M, width = x.shape
+    if out is None:
+        out = mlp_planes_alloc(M, width, ones, x.device)
+    check(load().clica_mlp_planes_from_f32(x.data_ptr(), ldx, M, width, 1 if ones else 0, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32")
+    return out
+
+
 def mlp_wgrad_split_kind(N: int, K: int) -> int:
     """0: the layer's weight gradient runs on the bf16 matrix cores from plane copies; 1: fp32 tiny-dimension kernel."""
     k = C.c_int32()

@@ -279,6 +279,11 @@ int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_li
  * last encoder layer) run the fp32 VALU kernel of clica_mlp_wgrad on the fp32 operands dZ[l] / X[l]; the other layers'
  * fp32 pointers may be NULL.  Same slab workspace scheme and deterministic reduction as clica_mlp_wgrad. */
 int clica_mlp_wgrad_split_kind(int32_t N, int32_t K, int32_t* kind);
+/* fp32 [M, width] (ld `ldx`) -> the bf16 plane copy clica_mlp_wgrad_split reads (buffer of clica_mlp_planes_bytes(M, width, ones)
+ * bytes): for operands that no split whole-stack kernel wrote -- the activations / gradients of the per-layer kernels of wide
+ * encoders (BASELINE config 3's 2000-wide layers), the encoder input, the loss gradient.  HBM-bound (4 B in, 6 B out per element). */
+int clica_mlp_planes_from_f32(const float* X, int64_t ldx, int64_t M, int32_t width, int32_t ones_column, void* planes_out,
+                              clica_stream_t stream);
 int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes);
 int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
                           const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,

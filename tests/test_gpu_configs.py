@@ -32,6 +32,7 @@ def build_mlp(n, hidden, head, gain=1.0):
 
 
 # ================================================================================================== C3
+@pytest.mark.usefixtures("encoder_arith")      # wide encoders: split mode = fp32 fwd / dgrad kernels + split-bf16 weight gradients
 def test_c3_wide_trainstep_goldens(golden):
     """G13: the reference's train_step on the config-3 architecture (n = 40: 400/2000-wide layers; n = 12 with
     --sphere-norm), injected sphere batches, p = 1, Adam.  The engine takes its per-layer GEMM path here (widths > 512)."""
@@ -112,7 +113,7 @@ def adam_trajectory_check(fam, key, module, out, prefix, stride, lr, steps, skip
     pre-activation within rounding of 0 flips a whole gradient term in one fp32 implementation and not in the other (the
     reference's own CPU and GPU runs differ the same way); the p = 1 gradient checks use the same 5e-5.  Such a flip moves every
     gradient element below it by ~1 % of the tensor's TYPICAL magnitude, which is a 10 % change for an element at 1 % of the
-    largest: p = 1 trajectories therefore take the strict set at |gradient| > 10 % of the largest (`theta`)."""
+    largest: p = 1 trajectories therefore take the strict set at |gradient| > 10 % of the largest (`theta`).
     `feedback_frac` (G13 only: 13.6 M / 1.2 M-parameter encoders, p = 1): in a net this large the noise elements are the
     overwhelming majority, their +-lr walks differ between ANY two implementations from the first update on, and that
     difference feeds back through the next forward pass into every gradient (measured: the strict elements end 3 % of their
@@ -206,6 +207,7 @@ def test_c3_loss_pool_49152_sampled_rows_vs_oracle():
     assert abs(oc[3 * B] - oc[:B].astype(np.float64).mean()) < 1e-6 * abs(oc[3 * B])
 
 
+@pytest.mark.usefixtures("encoder_arith")
 def test_c3_engine_full_size_vs_oracle():
     """The n = 40 engine at the real per-rank batch (B = 6144 -> 12 288 stacked rows, 13.6 M parameters, p = 1, sphere
     latents, formula weights so the outputs are not collapsed) against the fp64 oracle, STAGE BY STAGE:

@@ -433,6 +433,24 @@ def test_split_bf16_wgrad_matches_fp64(dims, M):
         assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(12288, 2000, 2000), (12288, 400, 40), (1000, 40, 400), (777, 129, 513), (16, 33, 17), (5000, 600, 120)])
+def test_planes_from_f32_feeds_split_wgrad(M, N, K):
+    """clica_mlp_planes_from_f32 (fp32 -> bf16 planes, for operands of the per-layer kernels of wide encoders) + clica_mlp_wgrad_split
+    on one layer: dW = dZ^T X, db = dZ^T 1 against fp64 -- the weight-gradient path of BASELINE config 3's 2000-wide layers."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(M + 3 * N + 7 * K)
+    x = dev(rng.normal(size=(M, K + 5)).astype(np.float32))[:, :K]          # a column-sliced view: leading dimension > width
+    dz = dev(rng.normal(size=(M, N)).astype(np.float32))
+    xp, dzp = ops.mlp_planes_from_f32(x, True), ops.mlp_planes_from_f32(dz, False)
+    dW, db = torch.full((N, K), 7.0, device="cuda"), torch.full((N,), 7.0, device="cuda")
+    ops.mlp_wgrad_split(M, [dzp], [xp], [None], [None], [dW], [db])
+    d64, x64 = dz.cpu().numpy().astype(np.float64), x.cpu().numpy().astype(np.float64)
+    cid = f"M={M} N={N} K={K}"
+    PARITY.check("planes_from_f32_wgrad_vs_fp64", cid, "dW", dW.cpu().numpy(), d64.T @ x64)
+    PARITY.check("planes_from_f32_wgrad_vs_fp64", cid, "db", db.cpu().numpy(), d64.sum(0), floor=float(np.abs(d64).sum(0).max()) * 0.05)
+    assert np.max(np.abs(dW.cpu().numpy() - d64.T @ x64) / (np.abs(d64).T @ np.abs(x64))) < 1e-5
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_get_mlp_autograd_seeded_sweep_vs_fp64(fused, monkeypatch):
     """Twelve seeded random encoders (1-7 layers, widths 1..512, batch sizes around the 48-row panels) through the drop-in
