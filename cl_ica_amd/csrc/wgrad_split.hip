@@ -53,7 +53,7 @@ struct Prob {
   float* dbslab;                  // [splits][M] or nullptr
   int M, N;                       // dW rows (N_l) and columns (K_l)
   int groups, gps;                // 16-row groups of the batch; groups per contraction split
-  int gx, gy, a_wide;             // tiles along the columns / rows; 1: 256 x 128 tiles, 0: 128 x 256
+  int gx, gy, a_wide;             // tiles along the columns / rows; tile shape 1: 256 x 128, 0: 128 x 256, 2: 256 x 256 (body_big)
 };
 struct GroupArgs { int n, total; int first[MAXG + 1]; Prob p[MAXG]; };
 
@@ -257,6 +257,152 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   WS_FLUSH;
 }
 
+// ---- 256 x 256 output tile (problems with both dimensions beyond 128) -------------------------------------------------------------
+// Why: both bodies move their operands L2 -> LDS at the rate the memory side delivers to a CU (measured ~17 B/clk/CU with all 256 CUs
+// pulling: 36 KB per 16-row step of the 256 x 128 tile = ~2100 cycles for 1536 cycles of MFMA work, tools/wsplit_trace.py); a
+// 256 x 256 tile does twice the MFMAs on 48 KB, i.e. 2/3 of the bytes per flop.
+// Eight waves as 2 (rows) x 4 (columns), wave tile 128 x 64 = 4 x 2 accumulator blocks (128 registers), so the fragments of a
+// whole step no longer fit twice: a step is two halves over the wave's A units {0, 1} and {2, 3} with the same B fragments:
+//   H0(t): 24 MFMAs on A-half 0 / B(t), reading A-half 1 of tile t;   [tile t + 1 landed: vmcnt + barrier]
+//   H1(t): 24 MFMAs on A-half 1 / B(t), requesting tile t + 3 (6 pieces per wave) and reading A-half 0 and B of tile t + 1.
+// Registers: 128 accumulators + 2 x 24 (A halves) + 2 x 24 (B, ping-pong across steps).  Three 48 KB stages: stage t % 3 is last
+// read in H0(t), free behind barrier(t), refilled by the requests of H1(t) with tile t + 3, first needed at barrier(t + 2).
+constexpr int STG2 = 3, PIECES2 = 3 * (UW + UW), STAGE2_BYTES = PIECES2 * 1024;
+static_assert((size_t)STG2 * STAGE2_BYTES <= kLdsBytes, "the big-tile stages must fit the launch's LDS");
+__device__ __forceinline__ void body_big(const Prob& g, const int bx, const int by, const int bz) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
+  const int g0 = bz * g.gps;
+  const int nt = min(g.groups, g0 + g.gps) - g0;
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // six DMA pieces per wave and step: piece pi = wave + 8 j of the stage image [A: 8 units x 3 planes][B: 8 units x 3 planes]
+  const char* src[6]; int stride[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int pi = wave + 8 * j;
+    const bool is_a = pi < 3 * UW;
+    const int q = is_a ? pi : pi - 3 * UW;
+    const int unit = q / 3, plane = q - 3 * unit;
+    const int u = (is_a ? by : bx) * UW + unit, fu = is_a ? g.fuA : g.fuB;
+    const bool ok = u < fu;
+    const char* base = is_a ? g.A : g.B;
+    src[j] = ok ? base + (((int64_t)g0 * fu + u) * 3 + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
+    stride[j] = ok ? fu * planes::kUnitBytes : 0;
+  }
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
+  auto issue_one = [&](int t, int j) { dma_1k(src[j], lds0 + (unsigned)((t % STG2) * STAGE2_BYTES + (wave + 8 * j) * 1024)); src[j] += stride[j]; };
+  const int lane_off = h * 512 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
+  const char* fa_base = smem + lane_off + (wm * 4) * 3 * 1024;
+  const char* fb_base = smem + lane_off + (UW + wn * 2) * 3 * 1024;
+  frag_t a0[3][2], a1[3][2], b0[3][2], b1[3][2];            // [plane][unit of the half / of the wave's two B units]
+  auto load_a = [&](frag_t (&f)[3][2], int t, int half) {
+    const int so = (t % STG2) * STAGE2_BYTES;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) f[p][i] = read_frag(fa_base + so + (3 * (2 * half + i) + p) * 1024);
+  };
+  auto load_b = [&](frag_t (&f)[3][2], int t) {
+    const int so = (t % STG2) * STAGE2_BYTES;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) f[p][j] = read_frag(fb_base + so + (3 * j + p) * 1024);
+  };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  auto mfma1 = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], int half, int m) {     // m = 0..23 of a half
+    const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
+    acc[2 * half + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]),
+                                                                   acc[2 * half + i][j], 0, 0, 0);
+  };
+  auto wait_tiles = [&](int k) {            // at most k of the most recently requested tiles (6 pieces each) may be in flight
+    if (k <= 0) wait_vm<0>(); else if (k == 1) wait_vm<6>(); else wait_vm<12>();
+  };
+  auto step = [&](const frag_t (&fb)[3][2], frag_t (&nb)[3][2], int t) {
+    load_a(a1, t, 1);
+#pragma unroll
+    for (int m = 0; m < 24; ++m) mfma1(a0, fb, 0, m);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool next = t + 1 < nt;
+    if (next) {
+      wait_tiles(min(t + 2, nt - 1) - (t + 1));
+      __syncthreads();
+    }
+    const bool more = t + 3 < nt;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      if (next) {
+        if (q < 3) {                                        // A-half 0 of tile t + 1: two fragments (four reads) per group
+#pragma unroll
+          for (int i = 0; i < 2; ++i) a0[q][i] = read_frag(fa_base + ((t + 1) % STG2) * STAGE2_BYTES + (3 * i + q) * 1024);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) nb[q - 3][j] = read_frag(fb_base + ((t + 1) % STG2) * STAGE2_BYTES + (3 * j + (q - 3)) * 1024);
+        }
+      }
+#pragma unroll
+      for (int m = 4 * q; m < 4 * q + 4; ++m) mfma1(a1, fb, 1, m);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) issue_one(t + 3, q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // note: a0 of step t + 1 is loaded in H1(t) while H1(t) computes on a1 -- a0 (tile t) is dead behind H0(t)
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt)
+    if (tt < nt) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) issue_one(tt, j);
+    }
+  wait_tiles(nt > 2 ? 2 : nt - 1);
+  __syncthreads();
+  if (nt > 0) { load_a(a0, 0, 0); load_b(b0, 0); }
+  int t = 0;
+  for (; t + 1 < nt; t += 2) { step(b0, b1, t); step(b1, b0, t + 1); }
+  if (t < nt) step(b0, b1, t);
+
+  const int m0 = by * 256, n0 = bx * 256;
+  float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      const bool is_db = g.dbslab && col == g.N;
+      if (col >= g.N && !is_db) continue;
+      float* dst = is_db ? g.dbslab + (int64_t)bz * g.M : Cbase + col;
+      const int64_t ld = is_db ? 1 : g.ldc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= g.M) continue;
+        dst[row * ld] = acc[i][j][r];
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {     // each XCD walks a contiguous range of the work items
   const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
@@ -272,7 +418,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
   const int tiles = g.gx * g.gy;
   const int bz = local / tiles, t = local - bz * tiles;
   const int by = t / g.gx, bx = t - by * g.gx;
-  if (g.a_wide) body<true>(g, bx, by, bz); else body<false>(g, bx, by, bz);
+  if (g.a_wide == 2) body_big(g, bx, by, bz); else if (g.a_wide) body<true>(g, bx, by, bz); else body<false>(g, bx, by, bz);
 }
 
 #ifdef CLICA_WSPLIT_TRACE
@@ -328,41 +474,63 @@ __global__ __launch_bounds__(256) void planes_from_f32_k(const float* __restrict
 }
 
 // ---- plan: which body per layer, how many contraction splits -----------------------------------------------------------------
-struct Plan { int splits, gps, groups, tiles, n_tiny, tiny_splits; int64_t tiny_kps; };
-static void tile_shape(int32_t N, int32_t K, int* a_wide, int* gx, int* gy, bool with_db) {
-  *a_wide = N >= K ? 1 : 0;
-  const int bm = *a_wide ? 256 : 128, bn = *a_wide ? 128 : 256;
+struct Plan { int splits, gps, groups, tiles, n_tiny, tiny_splits; int64_t tiny_kps; int big_tiles; };
+static bool big_on() { static const bool on = [] { const char* e = getenv("CLICA_WSPLIT_BIG"); return !(e && atoi(e) == 0); }(); return on; }
+// tile shape of a problem: 2 = 256 x 256 when both dimensions need more than one 128-wide tile, else 256 x 128 / 128 x 256 along
+// the longer side
+static void tile_shape(int32_t N, int32_t K, int* kind, int* gx, int* gy, bool with_db) {
+  const int cols = K + (with_db ? 1 : 0);
+  if (big_on() && N > 128 && cols > 128) { *kind = 2; *gy = (int)ceil_div(N, 256); *gx = (int)ceil_div(cols, 256); return; }
+  *kind = N >= K ? 1 : 0;
+  const int bm = *kind ? 256 : 128, bn = *kind ? 128 : 256;
   *gy = (int)ceil_div(N, bm);
-  *gx = (int)ceil_div(K + (with_db ? 1 : 0), bn);
+  *gx = (int)ceil_div(cols, bn);
 }
+// A 256 x 256 item does twice the MFMAs of a 256 x 128 item per 16-row step: big-tile problems get TWICE the contraction splits
+// (half the steps), so that every item of the launch carries the same matrix work.  `splits` / `gps` are the small-tile figures.
+static int problem_splits(const Plan& p, int kind) { return kind == 2 ? (int)ceil_div(p.groups, (int64_t)std::max(1, p.gps / 2)) : p.splits; }
+static int problem_gps(const Plan& p, int kind) { return kind == 2 ? std::max(1, p.gps / 2) : p.gps; }
 static Plan make_plan(int64_t Mrows, int n, const int32_t* N, const int32_t* K) {
   Plan p{};
   p.groups = (int)planes::groups_used(Mrows);
   for (int l = 0; l < n; ++l) {
     if (gemm::wgrad_tiny_shape(N[l], K[l])) { ++p.n_tiny; continue; }
-    int aw, gx, gy; tile_shape(N[l], K[l], &aw, &gx, &gy, true);
-    p.tiles += gx * gy;
+    int kind, gx, gy; tile_shape(N[l], K[l], &kind, &gx, &gy, true);
+    if (kind == 2) p.big_tiles += gx * gy; else p.tiles += gx * gy;
   }
-  // rounds of (gps x 16)-row items + a fixed prologue / slab epilogue per round + slab traffic per split (same cost model
-  // as the fp32 plan, linear.hip: plan_wgrad_group)
-  const int max_s = std::max(1, std::min(64, p.groups / 8));
+  // rounds of equal items (gps x 16 rows of a small tile = gps / 2 x 16 rows of a big tile) + a fixed prologue / slab epilogue
+  // per round + slab traffic per split (same cost model as the fp32 plan, linear.hip: plan_wgrad_group)
+  const int max_s = std::max(1, std::min(64, p.groups / (p.big_tiles ? 16 : 8)));
   double best = 1e300;
   p.splits = 1; p.gps = p.groups;
-  for (int s = 1; s <= max_s && p.tiles > 0; ++s) {
-    const int gps = (int)ceil_div(p.groups, s), sp = (int)ceil_div(p.groups, gps);
-    const int64_t rounds = ceil_div((int64_t)p.tiles * sp, kNumCU);
-    const double cost = (double)rounds * (16.0 * gps + 48.0) + 8.0 * sp;
+  for (int s = 1; s <= max_s && (p.tiles + p.big_tiles) > 0; ++s) {
+    int gps = (int)ceil_div(p.groups, s);
+    if (p.big_tiles) gps = (gps + 1) & ~1;                    // even: the big tiles take exactly half
+    const int sp = (int)ceil_div(p.groups, gps);
+    const int sp_big = p.big_tiles ? (int)ceil_div(p.groups, gps / 2) : 0;
+    const int64_t items = (int64_t)p.tiles * sp + (int64_t)p.big_tiles * sp_big;
+    const int64_t rounds = ceil_div(items, kNumCU);
+    const double cost = (double)rounds * (16.0 * gps + 48.0) + 8.0 * sp + (p.big_tiles ? 4.0 * sp_big : 0.0);
     if (cost < best) { best = cost; p.splits = sp; p.gps = gps; }
   }
   static const int forced = [] { const char* e = getenv("CLICA_WSPLIT_SPLITS"); return e ? atoi(e) : 0; }();
-  if (forced > 0) { p.gps = (int)ceil_div(p.groups, forced); p.splits = (int)ceil_div(p.groups, p.gps); }
+  if (forced > 0) {
+    p.gps = (int)ceil_div(p.groups, forced);
+    if (p.big_tiles) p.gps = std::max(2, (p.gps + 1) & ~1);
+    p.splits = (int)ceil_div(p.groups, p.gps);
+  }
   if (p.n_tiny > 0) gemm::wgrad_tiny_plan(Mrows, p.n_tiny, &p.tiny_splits, &p.tiny_kps);
   return p;
+}
+static int layer_splits(const Plan& p, int32_t N, int32_t K) {
+  if (gemm::wgrad_tiny_shape(N, K)) return p.tiny_splits;
+  int kind, gx, gy; tile_shape(N, K, &kind, &gx, &gy, true);
+  return problem_splits(p, kind);
 }
 static size_t ws_layout(const Plan& p, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
   size_t off = 0;
   for (int l = 0; l < n; ++l) {
-    const size_t sp = gemm::wgrad_tiny_shape(N[l], K[l]) ? p.tiny_splits : p.splits;
+    const size_t sp = (size_t)layer_splits(p, N[l], K[l]);
     if (slab_off) slab_off[l] = off;
     off += align_up(sp * N[l] * K[l] * sizeof(float), 256);
     if (db_off) db_off[l] = off;
@@ -421,7 +589,7 @@ extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* co
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(dW[l] && N[l] >= 1 && K[l] >= 1 && lddw[l] >= K[l], "clica_mlp_wgrad_split: layer %d: bad argument", l);
     const bool tiny = gemm::wgrad_tiny_shape(N[l], K[l]);
-    const int sp = tiny ? p.tiny_splits : p.splits;
+    const int sp = layer_splits(p, N[l], K[l]);
     float* slab = (float*)((char*)workspace + slab_off[l]);
     float* dbslab = (float*)((char*)workspace + db_off[l]);
     if (tiny) {
@@ -440,8 +608,10 @@ extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* co
       g.A = reinterpret_cast<const char*>(dZ_planes[l]); g.fuA = planes::units(N[l], 0);
       g.B = reinterpret_cast<const char*>(X_planes[l]); g.fuB = planes::units(K[l], 1);
       g.C = slab; g.ldc = K[l]; g.dbslab = db[l] ? dbslab : nullptr; g.M = N[l]; g.N = K[l];
-      g.groups = p.groups; g.gps = p.gps;
-      tile_shape(N[l], K[l], &g.a_wide, &g.gx, &g.gy, db[l] != nullptr);
+      // the tile shape follows the SHAPE (with the bias column: it fixed the plan and the workspace); without a bias the last
+      // column tile may simply have nothing to store
+      tile_shape(N[l], K[l], &g.a_wide, &g.gx, &g.gy, true);
+      g.groups = p.groups; g.gps = problem_gps(p, g.a_wide);
       G.first[ng] = item; item += g.gx * g.gy * sp;
       ++ng;
     }
