@@ -965,6 +965,12 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
 
 // grouped variant: the slabs of up to MAXG problems reduced by one launch
 // (struct ReduceGroupArgs: wgrad_shared.h)
+// Few, large slabs (wide layers: <= 8 contraction splits of a 2000 x 2000 gradient = 16 MB each): one thread per float4 of the
+// result, all its <= 8 slab loads in flight at once, summed in split order (deterministic).  The 64-units-per-block scheme above
+// is built for many short slabs and spends a whole workgroup (and an LDS pass) on 64 float4s: 138 us for a 2000 x 2000 layer with
+// four splits (80 MB, 0.6 TB/s) against ~30 us here.
+constexpr int FLAT_MAX_SPLITS = 8;
+static inline bool reduce_flat(int splits, bool v4) { return v4 && splits <= FLAT_MAX_SPLITS; }
 __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupArgs G) {
   __shared__ float4 red[RED_THREADS / 64][64];
   const int w = threadIdx.x >> 6;
@@ -976,6 +982,23 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupAr
   float4 t; int64_t e;
   if (b < G.dw_blocks[q]) {
     const int64_t total = M * N;
+    if (G.vec4[q] && G.splits[q] <= FLAT_MAX_SPLITS) {       // flat: RED_THREADS float4 units per block (see slab_reduce_entry)
+      e = ((int64_t)b * RED_THREADS + threadIdx.x) * 4;
+      if (e >= total) return;
+      const float* src = G.slab[q] + e;
+      float4 v[FLAT_MAX_SPLITS];
+#pragma unroll
+      for (int sIdx = 0; sIdx < FLAT_MAX_SPLITS; ++sIdx)
+        v[sIdx] = sIdx < G.splits[q] ? *reinterpret_cast<const float4*>(src + (int64_t)sIdx * total) : make_float4(0.f, 0.f, 0.f, 0.f);
+      t = v[0];
+#pragma unroll
+      for (int sIdx = 1; sIdx < FLAT_MAX_SPLITS; ++sIdx) { t.x += v[sIdx].x; t.y += v[sIdx].y; t.z += v[sIdx].z; t.w += v[sIdx].w; }
+      const int64_t i = e / N, j = e - i * N;
+      float4* dst = reinterpret_cast<float4*>(G.dW[q] + i * G.lddw[q] + j);
+      if (G.accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      *dst = t;
+      return;
+    }
     if (G.vec4[q]) {
       reduce_units<true>(G.slab[q], G.splits[q], total, (int64_t)b * 64, red, t, e);
       if (w == 0 && e < total) {
@@ -1193,7 +1216,7 @@ int slab_reduce_entry(ReduceGroupArgs& R, int l, int first_block, int sp, const 
                       float* dW, int64_t lddw, float* db, int32_t N, int32_t K) {
   const bool v4 = (K % 4 == 0) && (lddw % 4 == 0) && aligned16(dW);
   R.vec4[l] = v4 ? 1 : 0; R.splits[l] = sp;
-  R.dw_blocks[l] = (int)ceil_div(v4 ? (int64_t)N * K / 4 : (int64_t)N * K, 64);
+  R.dw_blocks[l] = (int)ceil_div(v4 ? (int64_t)N * K / 4 : (int64_t)N * K, reduce_flat(sp, v4) ? RED_THREADS : 64);
   R.first[l] = first_block;
   R.slab[l] = slab; R.dbslab[l] = dbslab; R.dW[l] = dW; R.db[l] = db;
   R.M[l] = N; R.N[l] = K; R.lddw[l] = lddw;
