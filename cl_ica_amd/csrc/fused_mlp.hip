@@ -631,6 +631,12 @@ __global__ __launch_bounds__(256) void mlp_pack_k(PackArgs a) {
 //     write per plane instead of element-wise traffic, and there is no panel -> HBM copy phase.
 // =====================================================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef CLICA_SPLIT_PINGPONG
+#define CLICA_SPLIT_PINGPONG 1
+#endif
+#ifndef CLICA_SPLIT_LOAD_GAP
+#define CLICA_SPLIT_LOAD_GAP 4
+#endif
 constexpr int LDPB = MAXW + 8;                  // bf16 elements per panel row: 1040 B, 16-byte aligned, bank-staggered
 constexpr int PLANE = ROWS * LDPB;              // bf16 elements per plane
 
@@ -733,9 +739,63 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
 #pragma unroll
       for (int c = 0; c < NC; ++c) { asm volatile("" : "+v"(wnxt[p][c])); wcur[p][c] = wnxt[p][c]; }
   };
+#if CLICA_SPLIT_PINGPONG
+  // Ping-pong form (round 3; the fp32 kernel's k-loop got the same treatment in round 2): two weight sets AND two activation
+  // fragment sets with swapped roles in a loop unrolled by two -- no rotation copies (the 12 x 4 v_mov per iteration above),
+  // the activation fragments of iteration ki + 1 are read from the panel during the MFMAs of ki instead of in front of them,
+  // and sched_group_barrier pins one weight request behind every third MFMA of the first half of the block and one panel read
+  // behind every NC-th MFMA of the second half (requests bunched at the head of the block keep the wave off the matrix pipe).
+  // (Two activation-fragment sets as well -- reading iteration ki + 1's fragments during the MFMAs of ki -- does not fit: 96 + 72 +
+  //  48 registers plus the epilogue's live values spill 71 VGPRs.  The fragments stay single-buffered, read at the head of the
+  //  block in the order hi, lo, mid = the order the six products first need them.)
+  auto fetch_x = [&](u32x4 (&x)[3][RB], int ki) {
+    constexpr int ORDER[3] = {0, 2, 1};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        x[ORDER[q]][r] = *reinterpret_cast<const u32x4*>(&planes[ORDER[q] * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
+  };
+  auto mma = [&](const u32x4 (&w)[3][CBW], const u32x4 (&x)[3][RB]) {
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[PW[t]][c]), __builtin_bit_cast(bf16x8, x[PX[t]][r]),
+                                                              acc[r][c], 0, 0, 0);
+  };
+  auto pin = [&]() {        // one weight request behind every CLICA_SPLIT_LOAD_GAP-th MFMA, the rest of the MFMAs behind the last one
+#pragma unroll
+    for (int i = 0; i < 3 * NC; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, CLICA_SPLIT_LOAD_GAP, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
+    }
+  };
+  auto kof = [&](int ki) { return ki < kiters ? ki : kiters - 1; };      // past the end: a harmless re-read of the last iteration's operands
+  u32x4 x[3][RB];
+  int ki = 0;
+  for (; ki + 1 < kiters; ki += 2) {
+    fetch_x(x, ki);
+    fetch_w(wnxt, kof(ki + 1));
+    mma(wcur, x);
+    pin();
+    __builtin_amdgcn_sched_barrier(0);
+    fetch_x(x, ki + 1);
+    fetch_w(wcur, kof(ki + 2));
+    mma(wnxt, x);
+    pin();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (ki < kiters) { fetch_x(x, ki); mma(wcur, x); }
+}
+#else
   step(0, kiters > 1 ? 1 : 0);                                   // peeled: its weights were requested before the previous epilogue
   for (int ki = 1; ki < kiters; ++ki) step(ki, ki + 1 < kiters ? ki + 1 : ki);
 }
+#endif
 
 __device__ __forceinline__ void request_first_w3(const u32x4* __restrict__ w0, int64_t ent, int K, int N, int wave, int lane, u32x4 (&w)[3][CBW]) {
   const int kiters = (K + KI - 1) / KI, ncb_real = (N + 15) / 16;
