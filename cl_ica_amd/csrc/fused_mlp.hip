@@ -637,6 +637,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef CLICA_SPLIT_LOAD_GAP
 #define CLICA_SPLIT_LOAD_GAP 4
 #endif
+#ifndef CLICA_SPLIT_FAST_EPI
+#define CLICA_SPLIT_FAST_EPI 1
+#endif
 constexpr int LDPB = MAXW + 8;                  // bf16 elements per panel row: 1040 B, 16-byte aligned, bank-staggered
 constexpr int PLANE = ROWS * LDPB;              // bf16 elements per plane
 
@@ -683,6 +686,20 @@ __global__ __launch_bounds__(256) void mlp_pack3_k(Pack3Args a) {
   u32x4* dst = a.dst[sidx] + d;
   dst[0] = pk(h); dst[a.entries[sidx]] = pk(m); dst[2 * a.entries[sidx]] = pk(l);
 }
+
+// Debug build only (-DCLICA_SPLIT_TRACE, tools/split_trace.py): s_memtime stamps per (workgroup, wave, layer, phase), kept in
+// registers and written once at the end of the kernel
+#ifdef CLICA_SPLIT_TRACE
+__device__ unsigned long long* g_strace = nullptr;
+#define ST_DECL unsigned long long st_ts[MAXL][4] = {}
+#define ST_STAMP(l, ph) do { st_ts[l][ph] = __builtin_readcyclecounter(); } while (0)
+#define ST_FLUSH(L) do { if (g_strace && lane == 0) { for (int l_ = 0; l_ < (L); ++l_) for (int q_ = 0; q_ < 4; ++q_) \
+      g_strace[(((size_t)blockIdx.x * WAVES + wave) * MAXL + l_) * 4 + q_] = st_ts[l_][q_]; } } while (0)
+#else
+#define ST_DECL do { } while (0)
+#define ST_STAMP(l, ph) do { } while (0)
+#define ST_FLUSH(L) do { } while (0)
+#endif
 
 struct SplitArgs {
   Args g;                        // same description of the stack as the fp32 kernel (g.packed unused)
@@ -790,6 +807,10 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
     __builtin_amdgcn_sched_barrier(0);
   }
   if (ki < kiters) { fetch_x(x, ki); mma(wcur, x); }
+  // The last pass's look-ahead request (kof) is dead but still counted: without this the compiler protects its target
+  // registers with an s_waitcnt vmcnt(0) wherever the epilogue first reuses one of them -- in the middle of the epilogue's
+  // stores, behind the next layer's weight requests.  Here it only waits for loads issued a whole MFMA block ago.
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
 }
 #else
   step(0, kiters > 1 ? 1 : 0);                                   // peeled: its weights were requested before the previous epilogue
@@ -808,12 +829,101 @@ __device__ __forceinline__ void request_first_w3(const u32x4* __restrict__ w0, i
     }
 }
 
+// ---- epilogue of one layer of mlp_split_k, specialised at compile time ------------------------------------------------------
+// The generic epilogue inside the kernel decides per element between bias / LeakyReLU / sign-bit derivative, sign-bit
+// collection, plane copy, fp32 copy (vector or scalar) ... at run time: 3 900 instructions for twelve accumulator blocks, a
+// third of them scalar branches and kernarg re-loads, 15.8 k cycles per 500 x 500 layer next to a 43 k-cycle k-loop
+// (tools/split_trace.py).  The combinations the training step actually runs are instantiated here without a single
+// data-dependent branch; everything else (odd alignments, no sign bits, slope outside (0, 1), debug copies) keeps the generic code.
+//   ACT: 1 = bias + LeakyReLU (forward, hidden layer)   2 = x LeakyReLU'(sign bits)  (backward chain)
+//   BITS: collect the (y > 0) bits of this layer's output;  PL: write the bf16-plane copy;  OUTV: write the fp32 copy (16-byte stores)
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) {     // {a.hi16, b.hi16} -> one dword (a in the low half)
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
+}
+template <int ACT, bool BITS, bool PL, bool OUTV>
+__device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW], unsigned short* planes, const float* bias_row, const float slope,
+                                                    const unsigned long long mbits, const int N, const int ncb, const int wave, const int lane,
+                                                    const __amdgpu_buffer_rsrc_t orsrc, const int ldo, const int nrows,
+                                                    const __amdgpu_buffer_rsrc_t prsrc, const int pl_group_bytes, const int pl_ones,
+                                                    unsigned& lo_bits, unsigned& hi_bits) {
+  const int i15 = lane & 15, kg = lane >> 4;
+  const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
+  unsigned lo = 0u, hi = 0u;
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) {
+    const int cb = wave + c * WAVES;
+    if (cb < ncb) {                                    // wave-uniform
+      const int n0 = cb * 16 + kg * 4;
+      const bool ragged = cb * 16 + 16 > N;            // wave-uniform: the last real block and the k-padding blocks
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (ACT == 1) b4 = *reinterpret_cast<const f32x4*>(&bias_row[n0]);
+      const unsigned pl_cb = (unsigned)((cb >> 1) * 3 * 1024 + (cb & 1) * 128) + pl_lane;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int row = r * 16 + i15;
+        f32x4 v = acc[r][c];
+        unsigned hb[4], mb[4], r2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int bit = (c * RB + r) * 4 + e;        // compile time
+          float t = v[e];
+          if (ACT == 1) { t += b4[e]; t = fmaxf(t, t * slope); }
+          if (ACT == 2) {
+            const unsigned mk = bit < 32 ? ((unsigned)mbits >> bit) : ((unsigned)(mbits >> 32) >> (bit - 32));
+            t = (mk & 1u) ? t : t * slope;
+          }
+          if (ragged) t = (n0 + e >= N) ? 0.f : t;
+          if (BITS) {      // shifted in from the right (inline constants only; `1u << bit` selects cost one VGPR per constant)
+            if (bit < 32) lo = (lo << 1) | (unsigned)(t > 0.f); else hi = (hi << 1) | (unsigned)(t > 0.f);
+          }
+          v[e] = t;
+          hb[e] = __float_as_uint(t) & 0xFFFF0000u;                 // exact 3-way split by truncation: 4 ops per element,
+          const float r1 = t - __uint_as_float(hb[e]);               // the low piece is the high half of the second residual
+          mb[e] = __float_as_uint(r1) & 0xFFFF0000u;                 // (<= 8 significant bits: taking its top 16 bits is exact)
+          r2[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+        }
+        const u32x2 ph = (u32x2){pack_hi(hb[0], hb[1]), pack_hi(hb[2], hb[3])};
+        const u32x2 pm = (u32x2){pack_hi(mb[0], mb[1]), pack_hi(mb[2], mb[3])};
+        const u32x2 pl = (u32x2){pack_hi(r2[0], r2[1]), pack_hi(r2[2], r2[3])};
+        unsigned short* dst = planes + row * LDPB + n0;
+        *reinterpret_cast<u32x2*>(dst) = ph;
+        *reinterpret_cast<u32x2*>(dst + PLANE) = pm;
+        *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = pl;
+        if (PL) {
+          u32x2 phg = ph;
+          if (ragged && pl_ones) {                     // feature N of the HBM copy is the constant 1 (see the generic epilogue)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n0 + e == N) phg[e >> 1] |= (e & 1) ? 0x3F800000u : 0x00003F80u;
+          }
+          const unsigned po = (unsigned)(r * pl_group_bytes) + pl_cb;
+          __builtin_amdgcn_raw_buffer_store_b64(phg, prsrc, po, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(pm, prsrc, po + 1024u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(pl, prsrc, po + 2048u, 0, 0);
+        }
+        if (OUTV) {
+          const unsigned off = (row < nrows && n0 < N) ? (unsigned)((row * ldo + n0) * 4) : kOobOffset;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+        }
+      }
+    } else if (BITS) {                                 // keep the bit positions of the blocks that follow
+#pragma unroll
+      for (int r = 0; r < RB; ++r) { if ((c * RB + r) * 4 < 32) lo <<= 4; else hi <<= 4; }
+    }
+  }
+  if (BITS) {        // first value shifted in = bit 0: reverse.  lo took 32 values, hi the remaining CBW * RB * 4 - 32
+    lo = __builtin_bitreverse32(lo);
+    hi = __builtin_bitreverse32(hi) >> (64 - CBW * RB * 4);
+  }
+  lo_bits = lo; hi_bits = hi;
+}
+
 __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short planes[];     // [3][ROWS][LDPB] bf16 bit patterns
   const Args& g = a.g;
   const int lane = threadIdx.x & 63;
+  const int lane_id = lane;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int i15 = lane & 15, kg = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * ROWS;
   const int nrows = (int)min((int64_t)ROWS, g.M - row0);
 
@@ -885,8 +995,11 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   }
   __syncthreads();
 
+  ST_DECL;
+#pragma unroll 1
   for (int l = 0; l < g.L; ++l) {
     const Layer& ly = g.layer[l];
+    ST_STAMP(l, 0);
     f32x4 acc[RB][CBW];
 #pragma unroll
     for (int r = 0; r < RB; ++r)
@@ -904,8 +1017,11 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       case 1: layer_gemm_split<1>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
       default: break;
     }
+    ST_STAMP(l, 1);
     __syncthreads();                                   // every wave is done reading the planes
+    ST_STAMP(l, 2);
 
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): nothing of this layer's k-loop is still in flight (see layer_gemm_split)
     if (l + 1 < g.L) {                                 // next layer's first weights, sign bits and bias: older than the stores below
       const Layer& nx = g.layer[l + 1];
       request_first_w3(a.packed3 + a.off3[l + 1], a.ent3[l + 1], nx.K, nx.N, wave, lane, wpre);
@@ -914,6 +1030,13 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
     // epilogue: lane = batch row r*16 + (lane & 15), features cb*16 + (lane >> 4)*4 + e
+    // Everything the epilogue derives from the lane id is recomputed here from an opaque copy: left to itself the compiler
+    // hoists those layer-invariant addresses out of the layer loop, they stay live across the k-loop (which needs every
+    // register it can get), spill, and their scratch re-loads then force vmcnt waits in the middle of the epilogue's stores.
+    int lane = lane_id;
+    asm volatile("" : "+v"(lane));
+    const int i15 = lane & 15, kg = lane >> 4;
+    const int mslot = (wave * 64 + lane) * 8;
     const int N = ly.N;
     const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;            // incl. the next layer's k-padding (written as zeros)
     const bool use_mask = ly.dact && ly.mask_in;
@@ -934,6 +1057,17 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
                                           has_pl ? RB * pl_group_bytes : 0, kRsrcWord3);
     const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
     unsigned lo = 0u, hi = 0u;
+    // fast, fully specialised epilogues for what the training step runs (split_epilogue_fast); wave-uniform dispatch
+    const bool fastable = slope01 && (!has_out || ovec) && (has_pl || has_out) && !(has_pl && has_out);
+    const float* bias_row = &bias_lds[a.boff[l]];
+    int fast_kind = 0;
+    if (CLICA_SPLIT_FAST_EPI && fastable) {
+      if (!ly.dact && ly.leaky && want_bits && has_pl) fast_kind = 1;
+      else if (use_mask && !want_bits && has_pl) fast_kind = 3;
+    }
+    if (fast_kind == 1) split_epilogue_fast<1, true, true, false>(acc, planes, bias_row, g.slope, mbits, N, ncb, wave, lane, orsrc, (int)ly.ldo, nrows, prsrc, pl_group_bytes, ly.pl_ones, lo, hi);
+    else if (fast_kind == 3) split_epilogue_fast<2, false, true, false>(acc, planes, bias_row, g.slope, mbits, N, ncb, wave, lane, orsrc, (int)ly.ldo, nrows, prsrc, pl_group_bytes, ly.pl_ones, lo, hi);
+    else
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int cb = wave + c * WAVES;
@@ -959,7 +1093,9 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
               t = (mk & 1u) ? t : t * g.slope;
             }
             if (ragged && n0 + e >= N) t = 0.f;
-            if (want_bits) { if (bit < 32) lo |= (t > 0.f) ? (1u << bit) : 0u; else hi |= (t > 0.f) ? (1u << (bit - 32)) : 0u; }
+            // sign bits are shifted in from the right and reversed once at the end: `(t > 0) ? 1u << bit : 0` costs a VGPR per
+            // constant (no literal operand in v_cndmask), and the compiler keeps all 48 of them live across the k-loop
+            if (bit < 32) lo = (lo << 1) | (unsigned)(t > 0.f); else hi = (hi << 1) | (unsigned)(t > 0.f);
             v[e] = t;
             split3(t, hb[e], mb[e], lb[e]);
           }
@@ -995,8 +1131,12 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
               if (row < nrows && n0 + e < N) ly.out[(row0 + row) * ly.ldo + n0 + e] = v[e];
           }
         }
+      } else {                                           // keep the bit positions of the blocks that follow
+#pragma unroll
+        for (int r = 0; r < RB; ++r) { if ((c * RB + r) * 4 < 32) lo <<= 4; else hi <<= 4; }
       }
     }
+    if (fast_kind == 0) { lo = __builtin_bitreverse32(lo); hi = __builtin_bitreverse32(hi) >> (64 - CBW * RB * 4); }
     if (has_pl && ly.pl_ones && (N & 31) == 0 && wave == 0) {
       // N is a whole number of units: the ones column lives in an extra unit (feature 0 of unit N / 32) that no accumulator
       // block covers -- wave 0 writes it (hi plane: 1.0 at feature 0 of every row, everything else zero)
@@ -1010,9 +1150,16 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
         }
     }
     __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(ly.mask_out), mslot, 0, 0);
+    ST_STAMP(l, 3);
     __syncthreads();
   }
+  ST_FLUSH(g.L);
 }
+#ifdef CLICA_SPLIT_TRACE
+extern "C" int clica_debug_split_trace(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(clica::fmlp::g_strace), &buf, sizeof(buf));
+}
+#endif
 
 }  // namespace fmlp
 }  // namespace clica
