@@ -1344,8 +1344,10 @@ extern "C" int clica_linear_plan(int32_t op, int64_t M, int64_t N, int64_t K, in
   return CLICA_OK;
 }
 
+namespace clica { namespace lp { void reload_dot_env(); } }      // lp_loss.hip: CLICA_DOT_MFMA
 extern "C" int clica_reload_env(void) {
   gemm::tuning() = gemm::read_tuning();
+  clica::lp::reload_dot_env();
   return CLICA_OK;
 }
 

@@ -61,6 +61,11 @@ struct Params {
   float xs;       // logit = xs * neg * kscale : -1 for Lp distances, +1 for the dot-product kind
   int pow;        // 1: use sum |e|^p ; 0: its 1/p-th root
   int n;          // true embedding dim (<= NP)
+  // dot kind, wide rows (n >= 64) only: <z1_i, z2_i> computed beforehand by a wave-per-row kernel (the finishing kernels run one
+  // THREAD per row and would walk 512 strided coordinates each), and where the coefficient step leaves d loss / d pos_i for
+  // an element-wise kernel instead of writing the two gradient rows itself
+  const float* posdot = nullptr;
+  float* dpos = nullptr;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));

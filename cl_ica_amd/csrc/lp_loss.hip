@@ -79,8 +79,10 @@ __device__ __forceinline__ void coef_row(
   if (!dz1 && !dz2) return;
   if (dot) {
     float pos = 0.f;
-    for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
+    if (q.posdot) pos = q.posdot[i];
+    else for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
     const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L2);
+    if (q.dpos) { q.dpos[i] = dpos; return; }       // wide rows: dpos_apply_k writes dz1 = dpos z2, dz2 = dpos z1
     for (int k = 0; k < q.n; ++k) {
       if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
       if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
@@ -175,7 +177,8 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float* rb = staged ? &zrows[1][lane_row * q.n] : z2 + i * ld2;
     if (dot) {   // SimCLRLoss: pos = <z1, z2> and the logit is +pos/tau (losses.py:188-193)
       pos = 0.f;
-      for (int k = 0; k < q.n; ++k) pos += ra[k] * rb[k];
+      if (q.posdot) pos = q.posdot[i];
+      else for (int k = 0; k < q.n; ++k) pos += ra[k] * rb[k];
       xp = pos * q.kscale;
       pos = -pos;  // loss_pos = -pos/tau (losses.py:192)
     } else {
@@ -663,8 +666,65 @@ __global__ __launch_bounds__(THREADS) void rownorm_bwd_k(const float* __restrict
   }
 }
 
+// wide rows (n >= 64): one WAVE per row, coalesced, shuffle-reduced -- the thread-per-row kernels above walk n strided
+// coordinates per thread (2.4 ms of a 2.5 ms SimCLRLoss step at n = 512, B = 1024)
+constexpr int kWideRowN = 64;
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__global__ __launch_bounds__(256) void rownorm_fwd_wide_k(const float* __restrict__ z, int64_t ldz, int64_t rows, int n,
+                                                         float* __restrict__ u, int64_t ldu, float* __restrict__ inv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  float ss = 0.f;
+  for (int k = lane; k < n; k += 64) { const float v = z[i * ldz + k]; ss = fmaf(v, v, ss); }
+  const float r = 1.f / sqrtf(wave_sum(ss));
+  if (lane == 0) inv[i] = r;
+  for (int k = lane; k < n; k += 64) u[i * ldu + k] = z[i * ldz + k] * r;
+}
+__global__ __launch_bounds__(256) void rownorm_bwd_wide_k(const float* __restrict__ u, const float* __restrict__ du, int64_t ldu,
+                                                         const float* __restrict__ inv, int64_t rows, int n,
+                                                         float* __restrict__ dz, int64_t lddz, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  float dot = 0.f;
+  for (int k = lane; k < n; k += 64) dot = fmaf(du[i * ldu + k], u[i * ldu + k], dot);
+  dot = wave_sum(dot);
+  const float r = inv[i];
+  for (int k = lane; k < n; k += 64) {
+    const float g = (du[i * ldu + k] - u[i * ldu + k] * dot) * r;
+    float* dst = dz + i * lddz + k;
+    *dst = accumulate ? (*dst + g) : g;
+  }
+}
+__global__ __launch_bounds__(256) void rowdot_wide_k(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                                    int64_t rows, int n, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  float s = 0.f;
+  for (int k = lane; k < n; k += 64) s = fmaf(a[i * lda + k], b[i * ldb + k], s);
+  s = wave_sum(s);
+  if (lane == 0) out[i] = s;
+}
+// dz1[i,:] = dpos_i z2[i,:],  dz2[i,:] = dpos_i z1[i,:]   (positive-pair gradient of the dot kind, losses.py:188)
+__global__ __launch_bounds__(THREADS) void dpos_apply_k(const float* __restrict__ dpos, const float* __restrict__ a, int64_t lda,
+                                                       const float* __restrict__ b, int64_t ldb, int64_t rows, int n,
+                                                       float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= rows * n) return;
+  const int64_t i = idx / n; const int k = (int)(idx - i * n);
+  const float g = dpos[i];
+  if (dz1) dz1[i * ldd1 + k] = g * b[i * ldb + k];
+  if (dz2) dz2[i * ldd2 + k] = g * a[i * lda + k];
+}
+
 struct DotWs {
-  float *u1, *u2, *u3, *i1, *i2, *i3, *du1, *du2, *du3;
+  float *u1, *u2, *u3, *i1, *i2, *i3, *du1, *du2, *du3, *pd, *dp;
   size_t bytes;
 };
 static DotWs carve_dot(void* ws, size_t off, int64_t B, int64_t B3, int n, bool normalize, bool bwd) {
@@ -675,6 +735,7 @@ static DotWs carve_dot(void* ws, size_t off, int64_t B, int64_t B3, int n, bool 
     w.i1 = take(B); w.i2 = take(B); w.i3 = take(B3);
     if (bwd) { w.du1 = take((size_t)B * n); w.du2 = take((size_t)B * n); w.du3 = take((size_t)B3 * n); }
   }
+  if (n >= kWideRowN) { w.pd = take(B); w.dp = take(B); }
   w.bytes = off; return w;
 }
 static int validate_dot(const clica_dot_loss_desc* d, const char* who) {
@@ -690,7 +751,115 @@ static Params dot_params(const clica_dot_loss_desc* d) {
   return q;
 }
 static void normalize_rows(const float* z, int64_t ld, int64_t rows, int n, float* u, float* inv, hipStream_t st) {
-  hipLaunchKernelGGL(rownorm_fwd_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st, z, ld, rows, n, u, (int64_t)n, inv);
+  if (n >= kWideRowN)
+    hipLaunchKernelGGL(rownorm_fwd_wide_k, dim3((unsigned)ceil_div(rows, (int64_t)4)), dim3(256), 0, st, z, ld, rows, n, u, (int64_t)n, inv);
+  else
+    hipLaunchKernelGGL(rownorm_fwd_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st, z, ld, rows, n, u, (int64_t)n, inv);
+}
+static void normalize_rows_bwd(const float* u, const float* du, const float* inv, int64_t rows, int n, float* dz, int64_t lddz, int acc,
+                               hipStream_t st) {
+  if (n >= kWideRowN)
+    hipLaunchKernelGGL(rownorm_bwd_wide_k, dim3((unsigned)ceil_div(rows, (int64_t)4)), dim3(256), 0, st, u, du, (int64_t)n, inv, rows, n, dz, lddz, acc);
+  else
+    hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(rows, THREADS)), dim3(THREADS), 0, st, u, du, (int64_t)n, inv, rows, n, dz, lddz, acc);
+}
+static void row_dots(const float* a, int64_t lda, const float* b, int64_t ldb, int64_t rows, int n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(rowdot_wide_k, dim3((unsigned)ceil_div(rows, (int64_t)4)), dim3(256), 0, st, a, lda, b, ldb, rows, n, out);
+}
+
+// ---- SimCLRLoss on the matrix cores for wide rows (n >= 96) ------------------------------------------------------------
+// losses.py:187 is a contraction, neg = z1 z3^T.  The pair sweep above evaluates it on the vector ALU (n FMAs per pair, fine at
+// n = 10, 512 deep at the widths G19 covers); from n = 96 on the three products of the loss are GEMMs on the fp32 MFMA kernels
+// of linear.hip, with the B x B3 logit matrix materialised ONCE per pass in the workspace (4 B B3 bytes against 2 B B3 n flops:
+// 48 flops per byte at n = 96, compute-bound on the matrix pipe):
+//   forward   S = U1 U3^T                  clica_linear_fwd   (M = B,  N = B3, K = n)
+//             (max, sum 2^(. - max)) of S * log2(e)/tau per row and 2048-column chunk -> the partial format of fwd_partial_k,
+//             finished by the SAME fwd_finalize_k (positive pair, loss, means)
+//   backward  S again, then in place  W_ij = statC_i 2^(S_ij log2(e)/tau - statL_i)   (bwd_coef_k's row statistics)
+//             dU1 += W U3                  clica_linear_dgrad (M = B,  N = B3, K = n)
+//             dU3 (+)= W^T U1              clica_linear_wgrad (M = B,  N = B3, K = n)
+// CLICA_DOT_MFMA=0 keeps the pair sweep at every width.
+constexpr int kDotMfmaMinN = 96;      // measured crossover (tools/simclr_bench.py, B = 4096): n = 64 472 vs 512 us, n = 128 925 vs 554 us
+constexpr int DOT_CHUNK = 2048;            // columns per (max, sum) partial: 32 values per lane
+static int read_dot_env() { const char* e = getenv("CLICA_DOT_MFMA"); return !(e && atoi(e) == 0); }
+static int& dot_mfma_switch() { static int on = read_dot_env(); return on; }
+void reload_dot_env() { dot_mfma_switch() = read_dot_env(); }       // clica_reload_env (linear.hip)
+static bool dot_mfma(const clica_dot_loss_desc* d) { return dot_mfma_switch() && d->n >= kDotMfmaMinN; }
+struct DotMfmaWs { float* S; int64_t ldS; float2* part; int nchunk; float* T; void* wg; size_t wg_bytes; size_t bytes; };
+static DotMfmaWs carve_dot_mfma(void* ws, size_t off, int64_t B, int64_t B3, int n, bool bwd) {
+  DotMfmaWs w{}; char* p = (char*)ws;
+  auto take = [&](size_t bytes) { void* r = p + off; off += align_up(bytes, 256); return r; };
+  w.ldS = (B3 + 3) & ~(int64_t)3;
+  w.nchunk = (int)ceil_div(B3, (int64_t)DOT_CHUNK);
+  w.S = (float*)take((size_t)B * w.ldS * sizeof(float));
+  w.part = (float2*)take((size_t)w.nchunk * B * sizeof(float2));
+  if (bwd) {
+    w.T = (float*)take((size_t)B * n * sizeof(float));
+    size_t wb = 0;
+    (void)clica_linear_wgrad_workspace_bytes(B, B3, n, &wb);
+    w.wg_bytes = wb; w.wg = take(wb);
+  }
+  w.bytes = off; return w;
+}
+// one wave per (row, chunk): the row's logits of the chunk stay in registers between the max and the sum
+__global__ __launch_bounds__(256) void dot_rows_partial_k(const float* __restrict__ S, int64_t ldS, int64_t rows, int64_t cols,
+                                                         float kscale, float2* __restrict__ part) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= rows) return;
+  const int64_t c0 = (int64_t)blockIdx.y * DOT_CHUNK;
+  const float* row = S + i * ldS;
+  float x[DOT_CHUNK / 64];
+  float m = -1e30f;
+#pragma unroll
+  for (int u = 0; u < DOT_CHUNK / 256; ++u) {
+    const int64_t c = c0 + u * 256 + lane * 4;
+    float4 v = make_float4(-1e30f, -1e30f, -1e30f, -1e30f);
+    if (c + 3 < cols) v = *reinterpret_cast<const float4*>(row + c);        // ldS and c are multiples of 4
+    else { if (c < cols) v.x = row[c]; if (c + 1 < cols) v.y = row[c + 1]; if (c + 2 < cols) v.z = row[c + 2]; }
+    const bool ok[4] = {c < cols, c + 1 < cols, c + 2 < cols, c + 3 < cols};
+    const float t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[u * 4 + e] = ok[e] ? t[e] * kscale : -1e30f; m = fmaxf(m, x[u * 4 + e]); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < DOT_CHUNK / 64; ++u) s += fexp2(x[u] - m);          // 2^(-1e30 - m) = 0 for the padding
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) part[(int64_t)blockIdx.y * rows + i] = make_float2(m, s);
+}
+// S_ij <- c_i 2^(S_ij kscale - L_i) in place; c_i = statC[i] (backward) or 1 (forward-time row gradient)
+__global__ __launch_bounds__(256) void dot_weights_k(float* __restrict__ S, int64_t ldS, int64_t rows, int64_t cols, float kscale,
+                                                    const float* __restrict__ statL, const float* __restrict__ statC) {
+  const int64_t i = blockIdx.x;
+  const int64_t c = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c >= cols) return;
+  const float L = statL[i], cf = statC ? statC[i] : 1.f;
+  float* p = S + i * ldS + c;
+  float4 v = *reinterpret_cast<float4*>(p);                                  // the row is padded to ldS: whole float4s are in range
+  v.x = c < cols ? cf * fexp2(v.x * kscale - L) : 0.f;
+  v.y = c + 1 < cols ? cf * fexp2(v.y * kscale - L) : 0.f;
+  v.z = c + 2 < cols ? cf * fexp2(v.z * kscale - L) : 0.f;
+  v.w = c + 3 < cols ? cf * fexp2(v.w * kscale - L) : 0.f;
+  *reinterpret_cast<float4*>(p) = v;
+}
+__global__ __launch_bounds__(THREADS) void add_rows_k(const float* __restrict__ T, int64_t ldt, int64_t rows, int n,
+                                                     float* __restrict__ out, int64_t ldo) {
+  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
+  if (idx >= rows * n) return;
+  const int64_t i = idx / n; const int k = (int)(idx - i * n);
+  out[i * ldo + k] += T[i * ldt + k];
+}
+static int dot_logits(const float* u1, int64_t ld1, const float* u3, int64_t ld3, const DotMfmaWs& mw, int64_t B, int64_t B3, int n,
+                      clica_stream_t stream) {
+  return clica_linear_fwd(u1, ld1, u3, ld3, nullptr, mw.S, mw.ldS, B, B3, n, 0, 0.f, stream);
+}
+static void dot_weights(const DotMfmaWs& mw, int64_t B, int64_t B3, float kscale, const float* statL, const float* statC, hipStream_t st) {
+  hipLaunchKernelGGL(dot_weights_k, dim3((unsigned)B, (unsigned)ceil_div(B3, (int64_t)1024)), dim3(256), 0, st,
+                     mw.S, mw.ldS, B, B3, kscale, statL, statC);
 }
 
 }  // namespace lp
@@ -703,6 +872,10 @@ extern "C" int clica_dot_loss_workspace_bytes(const clica_dot_loss_desc* d, size
   if (fwd_bytes) *fwd_bytes = carve_dot(nullptr, fwd_carve_max(d->B, d->B3, d->n), d->B, d->B3, d->n, d->normalize, false).bytes;
   (void)PF;
   if (bwd_bytes) *bwd_bytes = carve_dot(nullptr, carve_bwd(nullptr, PR, PC, d->B, d->B3).bytes, d->B, d->B3, d->n, d->normalize, true).bytes;
+  if (dot_mfma(d)) {      // logit matrix (+ backward: row-gradient staging and the split-K slabs of the column GEMM) behind everything else
+    if (fwd_bytes) *fwd_bytes = carve_dot_mfma(nullptr, *fwd_bytes, d->B, d->B3, d->n, false).bytes;
+    if (bwd_bytes) *bwd_bytes = carve_dot_mfma(nullptr, *bwd_bytes, d->B, d->B3, d->n, true).bytes;
+  }
   return CLICA_OK;
 }
 
@@ -731,9 +904,28 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
     normalize_rows(z3, ld3, d->B3, d->n, dw.u3, dw.i3, st);
     z1 = dw.u1; z2 = dw.u2; z3 = dw.u3; ld1 = ld2 = ld3 = d->n;
   }
-  launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, w.part_g, st);
+  if (dw.pd) { row_dots(z1, ld1, z2, ld2, d->B, d->n, dw.pd, st); q.posdot = dw.pd; }
   Means M{w.blocksums};
   const int nfin = (int)ceil_div(d->B, FIN_ROWS);
+  if (dot_mfma(d)) {
+    const DotMfmaWs mw = carve_dot_mfma(workspace, dw.bytes, d->B, d->B3, d->n, false);
+    if (mw.bytes > workspace_bytes) { set_error("clica_dot_loss_fwd: workspace %zu < %zu", workspace_bytes, mw.bytes); return CLICA_E_WORKSPACE; }
+    rc = dot_logits(z1, ld1, z3, ld3, mw, d->B, d->B3, d->n, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dot_rows_partial_k, dim3((unsigned)ceil_div(d->B, (int64_t)4), (unsigned)mw.nchunk), dim3(256), 0, st,
+                       (const float*)mw.S, mw.ldS, d->B, d->B3, q.kscale, mw.part);
+    hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
+                       (const float2*)mw.part, mw.nchunk, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
+                       1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{});
+    hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
+    if (rowgrad) {          // softmax-weighted sum of the z3 rows: one more GEMM on the weights (coefficient 1)
+      dot_weights(mw, d->B, d->B3, q.kscale, lse_i, nullptr, st);
+      rc = clica_linear_dgrad(mw.S, mw.ldS, z3, ld3, nullptr, 0, 0.f, rowgrad, ldrg, d->B, d->B3, d->n, stream);
+      if (rc) return rc;
+    }
+    return launch_status("clica_dot_loss_fwd(mfma)");
+  }
+  launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, w.part_g, st);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{});
@@ -771,26 +963,46 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
     z1 = dw.u1; z2 = dw.u2; z3 = dw.u3; ld1 = ld2 = ld3 = n;
     o1 = dz1 ? dw.du1 : nullptr; o2 = dz2 ? dw.du2 : nullptr; o3 = dz3 ? dw.du3 : nullptr; lo1 = lo2 = lo3 = n; acc3 = 0;
   }
+  if (dw.pd) { row_dots(z1, ld1, z2, ld2, B, n, dw.pd, st); q.posdot = dw.pd; q.dpos = dw.dp; }
   hipLaunchKernelGGL(bwd_coef_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st,
                      B, z1, ld1, z2, ld2, q, d->tau, d->alpha, 1, 0, 1, lse_i,
                      g_mean, g_item, g_pos, g_neg, w.statL, w.statC, o1, lo1, o2, lo2);
+  if (dw.pd && (o1 || o2))
+    hipLaunchKernelGGL(dpos_apply_k, dim3((unsigned)ceil_div(B * n, THREADS)), dim3(THREADS), 0, st,
+                       (const float*)dw.dp, z1, ld1, z2, ld2, B, n, o1, lo1, o2, lo2);
+  const bool mfma = dot_mfma(d) && ((o1 && !rowgrad) || o3);
+  DotMfmaWs mw{};
+  if (mfma) {
+    mw = carve_dot_mfma(workspace, dw.bytes, B, B3, n, true);
+    if (mw.bytes > workspace_bytes) { set_error("clica_dot_loss_bwd: workspace %zu < %zu", workspace_bytes, mw.bytes); return CLICA_E_WORKSPACE; }
+    rc = dot_logits(z1, ld1, z3, ld3, mw, B, B3, n, stream);
+    if (rc) return rc;
+    dot_weights(mw, B, B3, q.kscale, w.statL, w.statC, st);
+  }
   if (o1 && rowgrad) {
     hipLaunchKernelGGL(rowgrad_apply_k, dim3((unsigned)ceil_div(B * n, THREADS)), dim3(THREADS), 0, st,
                        rowgrad, ldrg, (const float*)w.statC, B, n, o1, lo1, 1);
+  } else if (o1 && mfma) {
+    rc = clica_linear_dgrad(mw.S, mw.ldS, z3, ld3, nullptr, 0, 0.f, mw.T, n, B, B3, n, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(add_rows_k, dim3((unsigned)ceil_div(B * n, THREADS)), dim3(THREADS), 0, st, (const float*)mw.T, (int64_t)n, B, n, o1, lo1);
   } else if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   }
-  if (o3) {
+  if (o3 && mfma) {
+    rc = clica_linear_wgrad(mw.S, mw.ldS, z1, ld1, o3, lo3, nullptr, B, B3, n, acc3, mw.wg, mw.wg_bytes, stream);
+    if (rc) return rc;
+  } else if (o3) {
     launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
                        (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
   }
   if (d->normalize) {
-    if (dz1) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u1, (const float*)dw.du1, (int64_t)n, (const float*)dw.i1, B, n, dz1, ldd1, 0);
-    if (dz2) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u2, (const float*)dw.du2, (int64_t)n, (const float*)dw.i2, B, n, dz2, ldd2, 0);
-    if (dz3) hipLaunchKernelGGL(rownorm_bwd_k, dim3((unsigned)ceil_div(B3, THREADS)), dim3(THREADS), 0, st, (const float*)dw.u3, (const float*)dw.du3, (int64_t)n, (const float*)dw.i3, B3, n, dz3, ldd3, accumulate_dz3 ? 1 : 0);
+    if (dz1) normalize_rows_bwd(dw.u1, dw.du1, dw.i1, B, n, dz1, ldd1, 0, st);
+    if (dz2) normalize_rows_bwd(dw.u2, dw.du2, dw.i2, B, n, dz2, ldd2, 0, st);
+    if (dz3) normalize_rows_bwd(dw.u3, dw.du3, dw.i3, B3, n, dz3, ldd3, accumulate_dz3 ? 1 : 0, st);
   }
   return launch_status("clica_dot_loss_bwd");
 }

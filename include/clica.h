@@ -37,7 +37,7 @@ extern "C" {
 typedef void* clica_stream_t;    /* hipStream_t */
 
 const char* clica_last_error(void);
-/* The library reads its tuning switches (CLICA_GEMM_CFG_*, CLICA_SKINNY) from the environment once, at the first launch;
+/* The library reads its tuning switches (CLICA_GEMM_CFG_*, CLICA_SKINNY, CLICA_DOT_MFMA) from the environment once, at the first launch;
  * call this after changing them inside a running process (tests, tuning sweeps). */
 int clica_reload_env(void);
 /* After a FAILED stream capture on `stream` (e.g. a collective that cannot be captured): end the capture if the stream is
@@ -147,6 +147,9 @@ int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
  *   (optional row L2-normalisation is done by the caller-visible wrapper kernels below)
  *   neg = z1 z3^T, pos = <z1,z2>, lse = logsumexp([neg,pos]/tau),
  *   loss = 2(alpha(-pos/tau) + (1-alpha) lse)
+ * n < 96: the tiled pair sweep (vector ALU, no B x B3 matrix).  n >= 96: the three contractions
+ * (z1 z3^T, W z3, W^T z1) run on the fp32 MFMA GEMMs with the logit matrix in the workspace
+ * (4 B B3 bytes more; clica_dot_loss_workspace_bytes accounts for it; CLICA_DOT_MFMA=0 disables).
  * ---------------------------------------------------------------------------------- */
 typedef struct clica_dot_loss_desc {
   int64_t B, B3;

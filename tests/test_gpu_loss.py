@@ -135,9 +135,28 @@ def test_lp_roll_goldens(golden):
         compare("lp_roll_goldens", f"{key} p={int(m['p'])} shape={z1.shape}", out, c["out"], ("dz1", "dz2"), sat_tol, note, lf, gf, mf)
 
 
+@pytest.fixture
+def dot_path(request):
+    """SimCLRLoss contraction path: "mfma" (default from n = 96: fp32 MFMA GEMMs over a materialised logit matrix) or "valu" (pair sweep)."""
+    import os
+    from cl_ica_amd import _lib
+    old = os.environ.get("CLICA_DOT_MFMA")
+    os.environ["CLICA_DOT_MFMA"] = "1" if request.param == "mfma" else "0"
+    assert _lib.load().clica_reload_env() == 0
+    yield request.param
+    if old is None:
+        os.environ.pop("CLICA_DOT_MFMA", None)
+    else:
+        os.environ["CLICA_DOT_MFMA"] = old
+    assert _lib.load().clica_reload_env() == 0
+
+
+@pytest.mark.parametrize("dot_path", ["mfma", "valu"], indirect=True)
 @pytest.mark.parametrize("name", ["g5_simclr.npz", "g19_wide_simclr.npz"])
-def test_simclr_goldens(golden, name):
+def test_simclr_goldens(golden, name, dot_path):
     from cl_ica_amd.losses import SimCLRLoss
+    if dot_path == "valu" and name.startswith("g5"):
+        pytest.skip("n < 96 takes the pair sweep in both settings")
     for key, c in golden(name).cases():
         m = c["meta"]
         L = SimCLRLoss(normalize=bool(m["normalize"]), tau=float(m["tau"]), alpha=float(m["alpha"]))
@@ -152,7 +171,7 @@ def test_simclr_goldens(golden, name):
                             alpha=float(m["alpha"]), grad=False)
         pos_mag = float(np.abs(orc["lse"] - orc["loss_i"] / 2.0).max())       # ~ alpha |pos| / tau + alpha |lse|: size of the summands
         lf = 2.0 * max(pos_mag, (1.0 - float(m["alpha"])) * float(np.abs(orc["lse"]).max()))
-        compare(f"simclr_goldens/{name[:-4]}", f"{key} norm={int(m['normalize'])} tau={float(m['tau']):g} n={z1.shape[1]}", out,
+        compare(f"simclr_goldens/{name[:-4]}" + ("/valu" if dot_path == "valu" else ""), f"{key} norm={int(m['normalize'])} tau={float(m['tau']):g} n={z1.shape[1]}", out,
                 c["out"], ("dz1", "dz2", "dz3"), loss_floor=lf, grad_floor=gf, means_floor=(float(np.abs(orc["lse"]).max()),) * 2)
 
 
@@ -389,3 +408,33 @@ def test_other_losses_seeded_sweep_vs_oracle():
         oa = O.alignment_loss(z1, z2, p)
         PARITY.check("other_losses_sweep", "align" + cid[4:], "loss_i", ali.detach().cpu().numpy(), oa["loss_i"])
         PARITY.check("other_losses_sweep", "align" + cid[4:], "dz1", a.grad.cpu().numpy(), oa["dz1"], floor=1e-3 * float(np.abs(oa["dz1"]).max()))
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_simclr_mfma_matches_pair_sweep(normalize):
+    """SimCLRLoss (losses.py:162-202) at n = 192, B = 1000, B3 = 2501 (ragged chunk, B3 % 4 != 0): the MFMA path (logit matrix +
+    three fp32-MFMA GEMMs) against the pair sweep and the fp64 oracle, with gradients flowing into every output."""
+    import os
+    from cl_ica_amd import _lib
+    from cl_ica_amd.losses import SimCLRLoss
+    rng = np.random.default_rng(5)
+    B, B3, n = 1000, 2501, 192
+    z1 = rng.standard_normal((B, n)).astype(np.float32) * 0.3
+    z2 = (z1 + 0.1 * rng.standard_normal((B, n))).astype(np.float32)
+    z3 = rng.standard_normal((B3, n)).astype(np.float32) * 0.3
+    gi = rng.standard_normal(B).astype(np.float32)
+    res = {}
+    for path in ("1", "0"):
+        os.environ["CLICA_DOT_MFMA"] = path
+        assert _lib.load().clica_reload_env() == 0
+        a, b, c = (dev(x).requires_grad_(True) for x in (z1, z2, z3))
+        tot, per, (pm, nm) = SimCLRLoss(normalize=normalize, tau=0.7, alpha=0.4)(None, None, None, a, b, c)
+        (tot + (per * dev(gi)).sum() * 1e-3 + 0.5 * pm - 0.25 * nm).backward()
+        res[path] = [t.detach().cpu().numpy().astype(np.float64) for t in (tot, per, pm, nm, a.grad, b.grad, c.grad)]
+    os.environ.pop("CLICA_DOT_MFMA", None)
+    assert _lib.load().clica_reload_env() == 0
+    orc = O.simclr_loss(z1, z2, z3, normalize=normalize, tau=0.7, alpha=0.4, grad=False)
+    for name, x, y in zip(("loss", "loss_i", "pos", "neg", "dz1", "dz2", "dz3"), res["1"], res["0"]):
+        PARITY.check("simclr_mfma_vs_sweep", f"norm={int(normalize)}", name, x, y)
+    for path in ("1", "0"):
+        PARITY.check("simclr_mfma_vs_sweep", f"norm={int(normalize)} path={path} vs fp64 oracle", "loss_i", res[path][1], orc["loss_i"])
