@@ -149,6 +149,9 @@ def roofline_leg(tr, reps=20):
         return ("linear_" + op, f"clica::gemm::gemm_k<{tm}, {tn}, ...{waves} waves..., {layout}, {'true' if vec else 'false'}>"
                 + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 
+    chain = getattr(tr, "chain", set())
+    chain_key = ("linear_fwd+linear_dgrad (wide layers)", "clica::wsplit::gemm_split_k")
+    wide_w = bool(getattr(tr, "split_wgrad_wide", False))
     split = bool(getattr(tr, "split_bf16", False))
     fused_sym = "clica::fmlp::mlp_split_k" if split else "clica::fmlp::mlp_fwd_k<true, false>"
     fused_key = ("mlp_fwd+mlp_dgrad", fused_sym)
@@ -164,8 +167,16 @@ def roofline_leg(tr, reps=20):
         cur = tr.x
         for l, lin in enumerate(tr.linears):
             N, K = lin.out_features, lin.in_features
-            add(gemm_key("fwd", N, K), 2.0 * R * N * K,
-                lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=tr.slope, out=tr.acts[l]))
+            if l in chain:        # wide on both sides: split-bf16 GEMM with fused epilogue (forward and data gradient share the symbol)
+                nxt = (l + 1) in chain
+                add(chain_key, 2.0 * R * N * K,
+                    lambda lin=lin, l=l, nxt=nxt: ops.linear_split_fwd(
+                        tr.xT[l], tr.wT[l], lin.bias, R, lin.out_features, lin.in_features, l < L - 1, tr.slope,
+                        yT=tr.xT[l + 1] if nxt else None, yN=tr.xin_planes[l + 1] if (l + 1 < L and tr.wide_kinds[l + 1] == 0) else None,
+                        yN_ones=True, y=None if nxt else tr.acts[l]))
+            else:
+                add(gemm_key("fwd", N, K), 2.0 * R * N * K,
+                    lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=tr.slope, out=tr.acts[l]))
             cur = tr.acts[l]
     g_top = tr.dy if tr.head is None else tr.dpre
     if tr.fused_backward:
@@ -197,10 +208,22 @@ def roofline_leg(tr, reps=20):
             lin = tr.linears[l]
             N, K = lin.out_features, lin.in_features
             inp = tr.acts[l - 1] if l > 0 else tr.x
-            add(gemm_key("wgrad", N, K), 2.0 * R * N * K,
-                lambda g=g_, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)],
-                                                                ws=tr.wgrad_ws))
-            if l > 0:
+            if wide_w and tr.wide_kinds[l] == 0:       # split-bf16 weight gradient on the plane copies the step left in place
+                add(("linear_wgrad (wide layers)", "clica::wsplit::wgrad_split_k (+ slab_reduce_group_k)"), 2.0 * R * N * K,
+                    lambda l=l: tr._wgrad_layer(l, None, None, tr.wgrad_ws, planes_ready=True))
+            else:
+                add(gemm_key("wgrad", N, K), 2.0 * R * N * K,
+                    lambda g=g_, inp=inp, lin=lin: ops.linear_wgrad(g, inp, dW=tr._gviews[id(lin.weight)], db=tr._gviews[id(lin.bias)],
+                                                                    ws=tr.wgrad_ws))
+            if l > 0 and l in chain:
+                prev = (l - 1) in chain
+                out = None if prev else tr.dbuf[l & 1][:, :K]
+                add(chain_key, 2.0 * R * N * K,
+                    lambda lin=lin, l=l, prev=prev, out=out: ops.linear_split_dgrad(
+                        tr.dzT[l], tr.wN[l], tr.xT[l], tr.slope, R, lin.out_features, lin.in_features,
+                        dxT=tr.dzT[l - 1] if prev else None, dxN=tr.dzw_planes[l - 1] if tr.wide_kinds[l - 1] == 0 else None, dx=out))
+                g_ = out if out is not None else g_
+            elif l > 0:
                 out = tr.dbuf[l & 1][:, :K]
                 add(gemm_key("dgrad", N, K), 2.0 * R * N * K,
                     lambda g=g_, lin=lin, inp=inp, out=out: ops.linear_dgrad(g, lin.weight, inp, tr.slope, out=out))
@@ -281,6 +304,12 @@ def roofline_leg(tr, reps=20):
         bwd_b = 4 * R * (widths[-1] + sum(widths[:-1])) + 4 * nparam + mask_b
         top["alg_bytes"] = (fwd_b + bwd_b) // 2
         note = "f32 (v_mfma_f32_16x16x4_f32), activation panel resident in LDS"
+    elif chain_key in groups:
+        # wide encoder with the split chain: the symbol with the largest share is the split GEMM of the 2000 x 2000 layers
+        top = [r for r in rows if r["op"] == chain_key[0]][0]
+        peak, issued_factor = PEAK_BF16_MFMA_TFLOPS, 6.0
+        note = ("f32 results from six bf16 products of exact 3-way bf16 operand splits (v_mfma_f32_32x32x16_bf16, fp32 accumulate); "
+                "operands as bf16 planes of the transposed tensors, fused bias / LeakyReLU / gate / re-split epilogue")
     else:
         top = [r for r in rows if r["op"] == "linear_fwd"][0]
         note = "f32 (v_mfma_f32_32x32x2_f32)"
@@ -565,7 +594,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)" if split else
-                  ("f32 (forward / data gradients native fp32 MFMA; weight gradients via bf16x3 split)" if wide_split else "f32")), "data": "synthetic",
+                  (("f32 via bf16x3 split on the 2000-wide layers (forward, data and weight gradients); native fp32 MFMA on the narrow ones"
+                    if getattr(tr, "chain", None) else "f32 (forward / data gradients native fp32 MFMA; weight gradients via bf16x3 split)")
+                   if wide_split else "f32")), "data": "synthetic",
         "global_steps_per_s": args.steps / elapsed,
         "warmup_extra_steps": extra_warm, "windows": len(window_s), "timed_steps_total": args.steps * len(window_s), "timing": "median window of `windows` x `steps` steps",
         "window_ms_per_step": [round(1e3 * w / args.steps, 4) for w in window_s],
@@ -581,8 +612,12 @@ def main():
         "gradients -- are split exactly into three bf16 pieces, the six piece products of order <= 2 run on the bf16 matrix cores "
         "with fp32 accumulation (max error vs fp64 8.6e-7 of max|y|, native fp32 MFMA 1.0e-6); every -m gpu engine test runs in "
         "this mode and in native fp32 against the same goldens / tolerances (tests/conftest.py: encoder_arith)"
-        if split else ("native fp32 MFMA per-layer kernels for the forward and the data gradients (a width beyond 512); weight gradients of the "
-                       "MFMA-sized layers in the split-bf16 arithmetic on plane copies made by clica_mlp_planes_from_f32" if wide_split else
+        if split else (("per-layer kernels (a width beyond 512).  Layers wide on both sides (>= 1024: the 2000 x 2000 ones): forward, data "
+                        "gradient and weight gradient in the split-bf16 arithmetic (gemm_split_k / wgrad_split_k on bf16-plane operands, fused "
+                        "epilogues); the narrow layers: native fp32 MFMA forward / data gradient, split-bf16 weight gradient on converted planes"
+                        if getattr(tr, "chain", None) else
+                        "native fp32 MFMA per-layer kernels for the forward and the data gradients (a width beyond 512); weight gradients of the "
+                        "MFMA-sized layers in the split-bf16 arithmetic on plane copies made by clica_mlp_planes_from_f32") if wide_split else
                        "native fp32 MFMA" + ("" if tr.fused_forward else " (per-layer kernels: a width beyond 512)")))
     if world > 1:
         comm = comm_leg(tr, rank, world, device)

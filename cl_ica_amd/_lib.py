@@ -80,6 +80,11 @@ SIGNATURES: Dict[str, list] = {
                               C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.c_float, C.c_void_p],
     "clica_mlp_wgrad_split_kind": [c_i32, c_i32, C.POINTER(c_i32)],
     "clica_mlp_planes_from_f32": [c_f32p, c_i64, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p],
+    "clica_mlp_planes_from_f32_t": [c_f32p, c_i64, c_i64, c_i32, C.c_void_p, C.c_void_p],
+    "clica_linear_split_fwd": [C.c_void_p, C.c_void_p, c_f32p, c_i64, c_i32, c_i32, c_i32, C.c_float, C.c_void_p, C.c_void_p, c_i32,
+                               c_f32p, c_i64, C.c_void_p],
+    "clica_linear_split_dgrad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p,
+                                 c_f32p, c_i64, C.c_void_p],
     "clica_mlp_wgrad_split_workspace_bytes": [c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_size)],
     "clica_mlp_wgrad_split": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
                               C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),

@@ -54,6 +54,14 @@ struct Prob {
   int M, N;                       // dW rows (N_l) and columns (K_l)
   int groups, gps;                // 16-row groups of the batch; groups per contraction split
   int gx, gy, a_wide;             // tiles along the columns / rows; tile shape 1: 256 x 128, 0: 128 x 256, 2: 256 x 256 (body_big)
+  // fused epilogues of gemm_split_k (forward / data gradient of a wide layer, see below); unused (zero) in the weight-gradient launch
+  int epi;                        // 1: + bias, LeakyReLU   2: x LeakyReLU'(sign of the layer's input activation)
+  int leaky; float slope;
+  const float* bias;              // [N] or nullptr
+  const char* signT; int fuS;     // epi 2: T-planes of the activation whose sign gates the gradient (rows = C column, features = C row)
+  char* outT; int fuT;            // output as planes of C^T (rows = C column, features = C row) or nullptr
+  char* outN; int fuN;            // output as planes of C   (rows = C row, features = C column) or nullptr
+  float* outF; int64_t ldf;       // output as fp32 C[row][column] or nullptr
 };
 struct GroupArgs { int n, total; int first[MAXG + 1]; Prob p[MAXG]; };
 
@@ -99,12 +107,92 @@ __device__ unsigned long long* g_wstrace = nullptr;
 #define WS_FLUSH do { } while (0)
 #endif
 
+// ---- fused epilogue of the forward / data-gradient GEMMs of a wide layer (gemm_split_k) ------------------------------------------
+// The accumulator block (i, j) of a wave holds C[row0 + 32 i + 8 q + 4 h + e][col0 + 32 j + (lane & 31)], q, e = 0..3: per lane FOUR
+// CONSECUTIVE ROWS of one column.  With C = Y (rows = batch row m, columns = output feature n) that is
+//   * 8 contiguous bytes per plane of the T-planes of Y (planes of Y^T: rows = n, features = m) -- the operand format of the NEXT
+//     layer's forward and of this layer's sign gate in the backward chain;
+//   * four 2-byte stores, 32 B apart, per plane of the N-planes of Y (rows = m, features = n; 16 lanes x 2 B = one 32-byte sector
+//     per store instruction and row) -- the X operand of the next layer's weight gradient;
+//   * four 4-byte stores of the fp32 copy (lanes = consecutive columns: 128 contiguous bytes), only where an fp32 consumer follows.
+// A 2000-deep contraction amortises all of it: ~500 stores per wave behind ~6000 MFMAs.
+__device__ __forceinline__ void split3_hi(float v, unsigned& hb, unsigned& mb, unsigned& lb);
+template <int NI>
+__device__ __forceinline__ void fused_epilogue(const Prob& g, const f32x16 (&acc)[NI][2], const int row0, const int col0, int lane) {
+  // the lane-derived addresses are recomputed from an opaque copy of the lane id: hoisted above the k-loop by the compiler they
+  // would be live across it and spill (the 256 x 256 body has 14 registers to spare)
+  asm volatile("" : "+v"(lane));
+  const int h = lane >> 5, l31 = lane & 31;
+  const bool fwd = g.epi == 1;
+  const bool slope01 = g.slope > 0.f && g.slope < 1.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + j * 32 + l31;
+    if (col >= g.N) continue;
+    const float b = (fwd && g.bias) ? g.bias[col] : 0.f;
+    // byte offset of (row = col, feature 0) inside T-planes with fu units per group; of (row 0, feature = col) inside N-planes
+    const size_t t_grp = (size_t)(col >> 4) * 3072, t_in = (size_t)(((col & 15) >> 2) * 256 + (col & 3) * 32);
+    const size_t n_col = (size_t)(col >> 5) * 3072 + (size_t)(((col >> 4) & 1) * 128 + (col & 15) * 2);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = row0 + i * 32 + 8 * q + 4 * h;          // rows m .. m + 3
+        if (m >= g.M) continue;
+        const size_t t_feat = (size_t)(m >> 5) * 3072 + (size_t)(((m >> 4) & 1) * 128 + (m & 15) * 2);
+        unsigned sgn[2] = {0x3F803F80u, 0x3F803F80u};           // "positive" when there is no gate
+        if (!fwd && g.signT) {
+          const u32x2 sv = *reinterpret_cast<const u32x2*>(g.signT + t_grp * g.fuS + t_in + t_feat);
+          sgn[0] = sv.x; sgn[1] = sv.y;
+        }
+        unsigned hb[4], mb[4], lb[4];
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][4 * q + e];
+          if (fwd) {
+            t += b;
+            if (g.leaky) t = slope01 ? fmaxf(t, t * g.slope) : (t > 0.f ? t : t * g.slope);
+          } else {
+            const unsigned hbits = (e & 1) ? (sgn[e >> 1] >> 16) : (sgn[e >> 1] & 0xFFFFu);      // hi piece of the activation (bf16)
+            const bool pos = (hbits & 0x8000u) == 0u && (hbits & 0x7FFFu) != 0u;
+            t = pos ? t : t * g.slope;
+          }
+          if (m + e >= g.M) t = 0.f;
+          v[e] = t;
+          split3_hi(t, hb[e], mb[e], lb[e]);
+        }
+        if (g.outT) {
+          char* dst = g.outT + t_grp * g.fuT + t_in + t_feat;
+          *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+          *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+          *reinterpret_cast<u32x2*>(dst + 2048) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+        }
+        if (g.outN) {
+          char* dst = g.outN + (size_t)(m >> 4) * 3072 * g.fuN + (size_t)(((m & 15) >> 2) * 256) + n_col;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (m + e >= g.M) continue;
+            unsigned short* d2 = reinterpret_cast<unsigned short*>(dst + e * 32);
+            d2[0] = (unsigned short)(hb[e] >> 16); d2[512] = (unsigned short)(mb[e] >> 16); d2[1024] = (unsigned short)(lb[e] >> 16);
+          }
+        }
+        if (g.outF) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < g.M) g.outF[(int64_t)(m + e) * g.ldf + col] = v[e];
+        }
+      }
+    }
+  }
+}
+
 // One work item: output tile (bx, by) of problem g over the row groups of contraction split bz.
 // Eight waves, wave tile 64 x 64 = 2 x 2 accumulator blocks of 32 x 32 (64 registers); per 16-row step a wave reads
 // 2 + 2 unit fragments x 3 planes (24 transposing reads of 512 B) and issues 24 MFMAs (768 matrix cycles).
 // Pipeline: four 36 KB stages; the pieces of step t + 3 are requested during the first half of step t, the fragments of
 // step t + 1 are read during its second half (two register sets, ping-pong), one barrier per step (in the middle).
-template <bool A_WIDE>
+template <bool A_WIDE, bool FUSED>
 __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, const int bz) {
   constexpr int UA = A_WIDE ? UW : UN, UB = A_WIDE ? UN : UW;
   constexpr int BM = UA * 32, BN = UB * 32;
@@ -235,6 +323,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
 
   // slab epilogue (same layout as the fp32 kernel: accumulator row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31)
   const int m0 = by * BM, n0 = bx * BN;
+  if constexpr (FUSED) { fused_epilogue<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane); return; }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -269,6 +358,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
 // read in H0(t), free behind barrier(t), refilled by the requests of H1(t) with tile t + 3, first needed at barrier(t + 2).
 constexpr int STG2 = 3, PIECES2 = 3 * (UW + UW), STAGE2_BYTES = PIECES2 * 1024;
 static_assert((size_t)STG2 * STAGE2_BYTES <= kLdsBytes, "the big-tile stages must fit the launch's LDS");
+template <bool FUSED>
 __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int by, const int bz) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -383,6 +473,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
   if (t < nt) step(b0, b1, t);
 
   const int m0 = by * 256, n0 = bx * 256;
+  if constexpr (FUSED) { fused_epilogue<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane); return; }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -418,7 +509,21 @@ __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
   const int tiles = g.gx * g.gy;
   const int bz = local / tiles, t = local - bz * tiles;
   const int by = t / g.gx, bx = t - by * g.gx;
-  if (g.a_wide == 2) body_big(g, bx, by, bz); else if (g.a_wide) body<true>(g, bx, by, bz); else body<false>(g, bx, by, bz);
+  if (g.a_wide == 2) body_big<false>(g, bx, by, bz); else if (g.a_wide) body<true, false>(g, bx, by, bz); else body<false, false>(g, bx, by, bz);
+}
+
+// ---- forward / data gradient of ONE wide layer on the same bodies -------------------------------------------------------------------
+// BASELINE config 3 (n = 40: 2000-wide layers, main_mlp.py:297-307) does not fit the whole-stack kernel (mlp_split_k keeps a 48-row
+// activation panel of <= 512 features in LDS); its per-layer GEMMs ran on the fp32 matrix cores (linear.hip: gemm_k, 0.70-0.76 of
+// the 157 TFLOP/s fp32 peak).  Both are contractions this file's bodies already do when the operands are given TRANSPOSED:
+//   forward   Y[m][n]  = sum_k X[m][k] W[n][k]  : A = planes of X^T (rows = k, features = m),  B = planes of W^T (rows = k, features = n)
+//   backward  dX[m][k] = sum_n dZ[m][n] W[n][k] : A = planes of dZ^T (rows = n, features = m), B = planes of W   (rows = n, features = k)
+// no contraction split (K = 400..2000 is 25..125 steps of a 256 x 256 tile), fused_epilogue instead of the slab.
+__global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
+  const int id = xcd_contiguous(blockIdx.x, G.total);
+  const Prob& g = G.p[0];
+  const int by = id / g.gx, bx = id - by * g.gx;
+  if (g.a_wide == 2) body_big<true>(g, bx, by, 0); else if (g.a_wide) body<true, true>(g, bx, by, 0); else body<false, true>(g, bx, by, 0);
 }
 
 #ifdef CLICA_WSPLIT_TRACE
@@ -468,6 +573,46 @@ __global__ __launch_bounds__(256) void planes_from_f32_k(const float* __restrict
   for (int e = 0; e < 4; ++e) split3_hi(v[e], hb[e], mb[e], lb[e]);
   const int s = q >> 2, c = (q & 3) * 4;                           // 16-feature half of the unit, first feature inside it
   char* dst = out + ((g * units + u) * 3) * 1024 + (k >> 2) * 256 + s * 128 + (k & 3) * 32 + c * 2;
+  *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+  *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+  *reinterpret_cast<u32x2*>(dst + 2048) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+}
+
+// fp32 X[M][F] -> planes of X^T (rows = feature index of X, features = row index of X): the A operand of the first split
+// forward / backward GEMM of a chain whose producer was an fp32 kernel.  One 16 x 32 unit per 128 threads through a padded
+// LDS tile: reads are 64-byte row segments of X, writes the usual 8 bytes per plane and thread.
+__global__ __launch_bounds__(256) void planes_from_f32_t_k(const float* __restrict__ X, int64_t ldx, int64_t M, int F, int units,
+                                                           char* __restrict__ out, int64_t groups) {
+  __shared__ float tile[2][16][33];
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const int64_t wu = (int64_t)blockIdx.x * 2 + half;
+  const bool live = wu < groups * units;
+  const int64_t g = live ? wu / units : 0; const int u = live ? (int)(wu - g * units) : 0;
+  {
+    const int phi = t >> 2, c = (t & 3) * 4;                      // row of X inside the unit, first of four features
+    const int64_t row = (int64_t)u * 32 + phi; const int64_t f0 = g * 16 + c;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live && row < M) {
+      const float* src = X + row * ldx + f0;
+      if (f0 + 3 < F && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4 x4 = *reinterpret_cast<const float4*>(src);
+        v[0] = x4.x; v[1] = x4.y; v[2] = x4.z; v[3] = x4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (f0 + e < F) v[e] = src[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[half][c + e][phi] = v[e];
+  }
+  __syncthreads();
+  if (!live) return;
+  const int k = t >> 3, q = t & 7;
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3_hi(tile[half][k][q * 4 + e], hb[e], mb[e], lb[e]);
+  const int sidx = q >> 2, c = (q & 3) * 4;
+  char* dst = out + ((g * units + u) * 3) * 1024 + (k >> 2) * 256 + sidx * 128 + (k & 3) * 32 + c * 2;
   *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
   *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
   *reinterpret_cast<u32x2*>(dst + 2048) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
@@ -630,4 +775,75 @@ extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* co
     if (rc) return rc;
   }
   return gemm::launch_slab_reduce_group(R, rblock, st);
+}
+
+
+// ---- wide layers: forward / data gradient on the split bodies (gemm_split_k) ------------------------------------------------------
+extern "C" int clica_mlp_planes_from_f32_t(const float* X, int64_t ldx, int64_t M, int32_t width, void* planes_out, clica_stream_t stream) {
+  CLICA_CHECK_ARG(X && planes_out && M > 0 && width >= 1 && ldx >= width, "clica_mlp_planes_from_f32_t: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(planes_out) & 15) == 0, "clica_mlp_planes_from_f32_t: plane buffer must be 16-byte aligned");
+  CLICA_CHECK_ARG(M < ((int64_t)1 << 31) - 64, "clica_mlp_planes_from_f32_t: M too large");
+  const int units = planes::units((int)M, 0);
+  const int64_t groups = planes::groups_alloc(width);
+  hipLaunchKernelGGL(planes_from_f32_t_k, dim3((unsigned)ceil_div(groups * units, 2)), dim3(256), 0, as_stream(stream),
+                     X, ldx, M, (int)width, units, reinterpret_cast<char*>(planes_out), groups);
+  return launch_status("clica_mlp_planes_from_f32_t");
+}
+
+static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, const char* who) {
+  static const int forced = [] { const char* e = getenv("CLICA_SPLIT_GEMM_TILE"); return e ? atoi(e) : -1; }();     // 0 / 1 / 2 (tuning)
+  // 128 x 256 tiles when the output is wide enough, else 256 x 128.  (The 256 x 256 body, the better one for the weight gradients, is
+  // not here: 12288 x 2000 makes 384 of them = 1.5 rounds of the 256 CUs; measured 572 us against 511 us for 768 small tiles.)
+  g.a_wide = forced >= 0 && forced <= 2 ? forced : (cols >= 256 ? 0 : 1);
+  const int bm = g.a_wide == 0 ? 128 : 256, bn = g.a_wide == 1 ? 128 : 256;
+  g.gy = (int)ceil_div(M, (int64_t)bm); g.gx = (int)ceil_div((int64_t)cols, (int64_t)bn);
+  g.gps = g.groups;
+  GroupArgs G{};
+  G.n = 1; G.p[0] = g; G.first[0] = 0; G.first[1] = G.total = g.gx * g.gy;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
+  (void)once;
+  hipLaunchKernelGGL(gemm_split_k, dim3((unsigned)G.total), dim3(THREADS), kLdsBytes, st, G);
+  return launch_status(who);
+}
+static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int clica_linear_split_fwd(const void* xT_planes, const void* wT_planes, const float* bias, int64_t M, int32_t N, int32_t K,
+                                      int32_t leaky, float slope, void* yT_planes, void* yN_planes, int32_t yN_ones,
+                                      float* Y, int64_t ldy, clica_stream_t stream) {
+  CLICA_CHECK_ARG(xT_planes && wT_planes && M > 0 && N >= 1 && K >= 1, "clica_linear_split_fwd: bad argument");
+  CLICA_CHECK_ARG(M < ((int64_t)1 << 31) - 512, "clica_linear_split_fwd: M too large");
+  CLICA_CHECK_ARG(yT_planes || yN_planes || Y, "clica_linear_split_fwd: no output");
+  CLICA_CHECK_ARG(!Y || ldy >= N, "clica_linear_split_fwd: leading dimension too small");
+  CLICA_CHECK_ARG(aligned16p(xT_planes) && aligned16p(wT_planes) && aligned16p(yT_planes) && aligned16p(yN_planes),
+                  "clica_linear_split_fwd: plane buffers must be 16-byte aligned");
+  Prob g{};
+  g.A = reinterpret_cast<const char*>(xT_planes); g.fuA = planes::units((int)M, 0);
+  g.B = reinterpret_cast<const char*>(wT_planes); g.fuB = planes::units(N, 0);
+  g.M = (int)M; g.N = N; g.groups = (int)planes::groups_used(K);
+  g.epi = 1; g.leaky = leaky ? 1 : 0; g.slope = slope; g.bias = bias;
+  g.outT = reinterpret_cast<char*>(yT_planes); g.fuT = planes::units((int)M, 0);
+  g.outN = reinterpret_cast<char*>(yN_planes); g.fuN = planes::units(N, yN_ones ? 1 : 0);
+  g.outF = Y; g.ldf = ldy;
+  return launch_gemm_split(g, M, N, as_stream(stream), "clica_linear_split_fwd");
+}
+
+extern "C" int clica_linear_split_dgrad(const void* dzT_planes, const void* wN_planes, const void* actT_planes, float slope,
+                                        int64_t M, int32_t N, int32_t K, void* dxT_planes, void* dxN_planes,
+                                        float* dX, int64_t lddx, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dzT_planes && wN_planes && M > 0 && N >= 1 && K >= 1, "clica_linear_split_dgrad: bad argument");
+  CLICA_CHECK_ARG(M < ((int64_t)1 << 31) - 512, "clica_linear_split_dgrad: M too large");
+  CLICA_CHECK_ARG(dxT_planes || dxN_planes || dX, "clica_linear_split_dgrad: no output");
+  CLICA_CHECK_ARG(!dX || lddx >= K, "clica_linear_split_dgrad: leading dimension too small");
+  CLICA_CHECK_ARG(aligned16p(dzT_planes) && aligned16p(wN_planes) && aligned16p(actT_planes) && aligned16p(dxT_planes) && aligned16p(dxN_planes),
+                  "clica_linear_split_dgrad: plane buffers must be 16-byte aligned");
+  Prob g{};
+  g.A = reinterpret_cast<const char*>(dzT_planes); g.fuA = planes::units((int)M, 0);
+  g.B = reinterpret_cast<const char*>(wN_planes); g.fuB = planes::units(K, 0);
+  g.M = (int)M; g.N = K; g.groups = (int)planes::groups_used(N);
+  g.epi = 2; g.slope = slope;
+  g.signT = reinterpret_cast<const char*>(actT_planes); g.fuS = planes::units((int)M, 0);
+  g.outT = reinterpret_cast<char*>(dxT_planes); g.fuT = planes::units((int)M, 0);
+  g.outN = reinterpret_cast<char*>(dxN_planes); g.fuN = planes::units(K, 0);
+  g.outF = dX; g.ldf = lddx;
+  return launch_gemm_split(g, M, K, as_stream(stream), "clica_linear_split_dgrad");
 }

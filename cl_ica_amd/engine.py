@@ -263,6 +263,25 @@ class ContrastiveTrainer:
             shapes = [tuple(lin.weight.shape) for lin in self.linears]
             self.wide_ws = max((ops.mlp_wgrad_split_workspace(R, [shapes[l]], dev) for l in range(L) if self.wide_kinds[l] == 0),
                                key=lambda t: t.numel(), default=None)
+        # ... and, for the layers that are wide on BOTH sides (>= 1024: config 3's three 2000 x 2000 layers), forward and data
+        # gradient too: split-bf16 GEMMs with fused epilogues on T-plane operands (csrc/wgrad_split.hip: gemm_split_k; 1.7x the
+        # fp32-MFMA kernels at 12288 x 2000 x 2000).  A chain layer reads its input as T-planes (planes of the transposed
+        # activation), written by the previous chain layer's epilogue or converted from fp32 at the chain's head, and writes
+        # T-planes for the next chain layer, N-planes for the next layer's weight gradient, fp32 only where an fp32 kernel follows.
+        self.chain = set()
+        if self.split_wgrad_wide and os.environ.get("CLICA_SPLIT_WIDE_CHAIN", "1") != "0":
+            in_w = [lin.in_features for lin in self.linears]
+            self.chain = {l for l in range(1, L - 1) if self.wide_kinds[l] == 0 and in_w[l] >= 1024 and widths[l] >= 1024}
+        if self.chain:
+            in_w = [lin.in_features for lin in self.linears]
+            self.wT = {l: ops.mlp_planes_alloc(in_w[l], widths[l], False, dev) for l in self.chain}      # planes of W^T
+            self.wN = {l: ops.mlp_planes_alloc(widths[l], in_w[l], False, dev) for l in self.chain}      # planes of W
+            self.xT = {l: ops.mlp_planes_alloc(in_w[l], R, False, dev) for l in self.chain}              # T-planes of the layer input
+            self.dzT = {l: ops.mlp_planes_alloc(widths[l], R, False, dev) for l in self.chain}           # T-planes of dZ_l
+            for l in self.chain:                              # the epilogues never touch the ones column of the N-planes they fill
+                if l + 1 < L and self.wide_kinds[l + 1] == 0:
+                    ops.mlp_planes_from_f32(torch.zeros((R, widths[l]), **f32), True, out=self.xin_planes[l + 1])
+            self._wide_packed = False
         if self.head is not None:
             self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
             hp = self.head.r if isinstance(self.head, ls.RescaleLayer) else self.head.max_abs_bound
@@ -342,9 +361,27 @@ class ContrastiveTrainer:
             cur = self.acts[-1]
         else:
             wide = getattr(self, "split_wgrad_wide", False)
+            chain = getattr(self, "chain", set())
+            if chain and not (self._wide_packed and self._packed_current):
+                for l in chain:                             # plane copies of the CURRENT weights, both orientations
+                    ops.mlp_planes_from_f32_t(self.linears[l].weight, out=self.wT[l])
+                    ops.mlp_planes_from_f32(self.linears[l].weight, False, out=self.wN[l])
+                self._wide_packed = self._packed_current = True
+            R = self.x.shape[0]
             for l, lin in enumerate(self.linears):
-                if wide and self.wide_kinds[l] == 0:        # this layer's input as bf16 planes for its weight gradient
+                fed = (l - 1) in chain                      # the previous layer's epilogue already wrote this layer's plane operands
+                if wide and self.wide_kinds[l] == 0 and not fed:        # this layer's input as bf16 planes for its weight gradient
                     ops.mlp_planes_from_f32(cur, True, out=self.xin_planes[l])
+                if l in chain:
+                    if not fed:
+                        ops.mlp_planes_from_f32_t(cur, out=self.xT[l])
+                    nxt = (l + 1) in chain
+                    out = None if nxt else self.acts[l]
+                    ops.linear_split_fwd(self.xT[l], self.wT[l], lin.bias, R, lin.out_features, lin.in_features, l < L - 1, self.slope,
+                                         yT=self.xT[l + 1] if nxt else None,
+                                         yN=self.xin_planes[l + 1] if (l + 1 < L and self.wide_kinds[l + 1] == 0) else None, yN_ones=True, y=out)
+                    cur = out
+                    continue
                 ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=self.slope, out=self.acts[l])
                 cur = self.acts[l]
         if self.head is not None:
@@ -462,14 +499,26 @@ class ContrastiveTrainer:
             ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
                           [self.acts[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
 
-    def _wgrad_layer(self, l, g, inp, ws):
+    def saved_activation(self, l):
+        """fp32 values of layer l's output as saved for the backward pass.  Where a split-bf16 kernel wrote the activation only as
+        bf16 planes (no fp32 copy: nobody but the matrix cores reads it) the planes are decoded -- exactly, hi + mid + lo is the
+        fp32 value.  Inspection / tests."""
+        R, w = self.x.shape[0], self.linears[l].out_features
+        if l in getattr(self, "chain", set()) and (l + 1) in self.chain:
+            return ops.mlp_planes_to_f32(self.xin_planes[l + 1], R, w, True)
+        if self.acts_out[l] is None:
+            return ops.mlp_planes_to_f32(self.act_planes[l], R, w, True)
+        return self.acts[l]
+
+    def _wgrad_layer(self, l, g, inp, ws, planes_ready=False):
         """dW_l / db_l of one layer on the per-layer path: fp32 MFMA GEMM, or -- wide encoders in split mode -- the split-bf16
         kernel on plane copies (dZ converted here, the layer input converted in forward())."""
         lin = self.linears[l]
         dW, db = self._gviews[id(lin.weight)], self._gviews[id(lin.bias)]
         if getattr(self, "split_wgrad_wide", False) and self.wide_kinds[l] == 0:
-            ops.mlp_planes_from_f32(g, False, out=self.dzw_planes[l])
-            ops.mlp_wgrad_split(g.shape[0], [self.dzw_planes[l]], [self.xin_planes[l]], [None], [None], [dW], [db], ws=self.wide_ws)
+            if not planes_ready:                            # (a split data-gradient epilogue has written dZ_l's planes already)
+                ops.mlp_planes_from_f32(g, False, out=self.dzw_planes[l])
+            ops.mlp_wgrad_split(self.x.shape[0], [self.dzw_planes[l]], [self.xin_planes[l]], [None], [None], [dW], [db], ws=self.wide_ws)
         else:
             ops.linear_wgrad(g, inp, dW=dW, db=db, accumulate=False, ws=ws)
 
@@ -523,30 +572,55 @@ class ContrastiveTrainer:
         # independent given dZ_l, and each hides the other's prologue / epilogue-store bubbles.  Three dZ
         # buffers rotate; a buffer is rewritten only after the wgrad that read it has finished.
         reader_done = {}        # dZ buffer index -> event of the wgrad that reads it
-        buf_of_g = None         # index into self.dbuf holding the current dZ (None: self.dy / self.dpre)
+        buf_of_g = None         # index into self.dbuf holding the current dZ (None: self.dy / self.dpre, or planes only)
         nxt = 0
+        chain = getattr(self, "chain", set())
+        R = self.x.shape[0]
+        dzN_ready = dzT_ready = False       # dZ_l already sits in dzw_planes[l] / dzT[l] (written by a split data-gradient epilogue)
         for l in reversed(range(L)):
             lin = self.linears[l]
             inp = self.acts[l - 1] if l > 0 else self.x
             if two:
                 side.wait_stream(main)                      # dZ_l is complete on main
                 with torch.cuda.stream(side):
-                    self._wgrad_layer(l, g, inp, self.wgrad_ws)
+                    self._wgrad_layer(l, g, inp, self.wgrad_ws, planes_ready=dzN_ready)
                     if self.buckets is not None:
                         self.buckets.layer_done(L - 1 - l)
                     if buf_of_g is not None:
                         ev = torch.cuda.Event(); ev.record(side); reader_done[buf_of_g] = ev
             else:
-                self._wgrad_layer(l, g, inp, self.wgrad_ws)
+                self._wgrad_layer(l, g, inp, self.wgrad_ws, planes_ready=dzN_ready)
                 if self.buckets is not None:
                     self.buckets.layer_done(L - 1 - l)
-            if l > 0:
+            if l > 0 and l in chain:
+                # dZ_{l-1} = (dZ_l W_l) * LeakyReLU'(acts_{l-1}) on the split bodies: T-planes in, gate from the T-planes of the
+                # layer input, T-planes out for the next chain layer, N-planes out for the weight gradient of layer l - 1
+                if not dzT_ready:
+                    ops.mlp_planes_from_f32_t(g, out=self.dzT[l])
+                prev = (l - 1) in chain
+                out = None
+                if not prev:
+                    if two and nxt in reader_done:
+                        main.wait_event(reader_done.pop(nxt))
+                    out = self.dbuf[nxt][:, :lin.in_features]
+                dxN = self.dzw_planes[l - 1] if self.wide_kinds[l - 1] == 0 else None
+                ops.linear_split_dgrad(self.dzT[l], self.wN[l], self.xT[l], self.slope, R, lin.out_features, lin.in_features,
+                                       dxT=self.dzT[l - 1] if prev else None, dxN=dxN, dx=out)
+                dzT_ready, dzN_ready = prev, dxN is not None
+                g = out
+                if out is not None:
+                    buf_of_g = nxt
+                    nxt = (nxt + 1) % len(self.dbuf)
+                else:
+                    buf_of_g = None
+            elif l > 0:
                 if two and nxt in reader_done:
                     main.wait_event(reader_done.pop(nxt))    # WAR: the wgrad that read this buffer is done
                 out = self.dbuf[nxt][:, :lin.in_features]
                 ops.linear_dgrad(g, lin.weight, inp, self.slope, out=out)
                 g, buf_of_g = out, nxt
                 nxt = (nxt + 1) % len(self.dbuf)
+                dzN_ready = dzT_ready = False
         if two:
             main.wait_stream(side)
         if self.buckets is not None:

@@ -190,6 +190,56 @@ def mlp_planes_from_f32(x: torch.Tensor, ones: bool, out: Optional[torch.Tensor]
     return out
 
 
+def mlp_planes_to_f32(buf: torch.Tensor, rows: int, feats: int, ones: bool) -> torch.Tensor:
+    """Decode a bf16 plane buffer (csrc/planes.h) back into the fp32 [rows, feats] matrix it holds (hi + mid + lo is exact in fp32).
+    Inspection / tests only -- plain tensor ops, no kernel of ours."""
+    units = (feats + (1 if ones else 0) + 31) // 32
+    raw = buf.view(torch.int16)
+    groups = raw.numel() // (units * 3 * 512)
+    a = (raw.view(groups, units, 3, 4, 2, 4, 16).to(torch.int32) << 16).view(torch.float32)      # [g][u][plane][k/4][f/16][k%4][f%16]
+    v = (a[:, :, 0] + a[:, :, 1]) + a[:, :, 2]
+    return v.permute(0, 2, 4, 1, 3, 5).reshape(groups * 16, units * 32)[:rows, :feats].contiguous()
+
+
+def mlp_planes_from_f32_t(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """T-planes of a fp32 [M, width] tensor = bf16 planes of its transpose (rows = feature, features = batch row): the A operand of
+    `linear_split_fwd` / `linear_split_dgrad` (clica_mlp_planes_from_f32_t)."""
+    (x, ldx) = _mat("x", x)
+    M, width = x.shape
+    if out is None:
+        out = mlp_planes_alloc(width, M, False, x.device)
+    check(load().clica_mlp_planes_from_f32_t(x.data_ptr(), ldx, M, width, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32_t")
+    return out
+
+
+def _pp(t):
+    return t.data_ptr() if t is not None else None
+
+
+def linear_split_fwd(xT, wT, bias, M: int, N: int, K: int, leaky: bool, slope: float, yT=None, yN=None, yN_ones: bool = True, y=None):
+    """One wide nn.Linear (+ LeakyReLU) forward in split-bf16 arithmetic from T-plane operands (clica_linear_split_fwd)."""
+    ldy = 0
+    if y is not None:
+        require_cuda(y, "y")
+        if y.dim() != 2 or y.stride(1) != 1:
+            raise ValueError("y must be a 2-D tensor with contiguous rows")
+        ldy = y.stride(0)
+    check(load().clica_linear_split_fwd(xT.data_ptr(), wT.data_ptr(), _pp(bias), int(M), int(N), int(K), 1 if leaky else 0, float(slope),
+                                        _pp(yT), _pp(yN), 1 if yN_ones else 0, _pp(y), ldy, stream_ptr()), "clica_linear_split_fwd")
+
+
+def linear_split_dgrad(dzT, wN, actT, slope: float, M: int, N: int, K: int, dxT=None, dxN=None, dx=None):
+    """dX = (dZ W) * LeakyReLU'(layer input) of one wide layer in split-bf16 arithmetic (clica_linear_split_dgrad)."""
+    ldd = 0
+    if dx is not None:
+        require_cuda(dx, "dx")
+        if dx.dim() != 2 or dx.stride(1) != 1:
+            raise ValueError("dx must be a 2-D tensor with contiguous rows")
+        ldd = dx.stride(0)
+    check(load().clica_linear_split_dgrad(dzT.data_ptr(), wN.data_ptr(), _pp(actT), float(slope), int(M), int(N), int(K),
+                                          _pp(dxT), _pp(dxN), _pp(dx), ldd, stream_ptr()), "clica_linear_split_dgrad")
+
+
 def mlp_wgrad_split_kind(N: int, K: int) -> int:
     """0: the layer's weight gradient runs on the bf16 matrix cores from plane copies; 1: fp32 tiny-dimension kernel."""
     k = C.c_int32()

@@ -287,6 +287,27 @@ int clica_mlp_wgrad_split_kind(int32_t N, int32_t K, int32_t* kind);
  * encoders (BASELINE config 3's 2000-wide layers), the encoder input, the loss gradient.  HBM-bound (4 B in, 6 B out per element). */
 int clica_mlp_planes_from_f32(const float* X, int64_t ldx, int64_t M, int32_t width, int32_t ones_column, void* planes_out,
                               clica_stream_t stream);
+/* Wide layers (a width beyond the 512 the whole-stack kernel holds on chip: BASELINE config 3, main_mlp.py:297-307 with --n 40):
+ * forward and data gradient of ONE nn.Linear (+ LeakyReLU, encoders.py:36-48) in the same split-bf16 arithmetic, on the bodies of
+ * the weight-gradient GEMM.  Operands are bf16 planes (clica_mlp_planes_bytes) of the TRANSPOSED tensors -- "T-planes of X" =
+ * planes of X^T: rows = feature index of X, features = batch row -- so that the contraction runs along plane rows:
+ *   clica_linear_split_fwd    Y = leaky(X W^T + b):  xT = T-planes of X [M, K], wT = T-planes of W [N, K] (planes of W^T);
+ *                             writes any of: yT (T-planes of Y: next layer's xT / the sign gate of its backward), yN (planes of Y,
+ *                             rows = batch row: X operand of the next layer's clica_mlp_wgrad_split; yN_ones = that buffer was
+ *                             allocated with the ones column, which this call leaves untouched), Y (fp32).
+ *   clica_linear_split_dgrad  dX = (dZ W) * leaky'(act):  dzT = T-planes of dZ [M, N], wN = planes of W [N, K] (rows = N),
+ *                             actT = T-planes of the layer's INPUT activation [M, K] (sign gate; NULL: no gate);
+ *                             writes any of dxT (T-planes of dX), dxN (planes of dX: dZ operand of the previous layer's
+ *                             weight gradient), dX (fp32).
+ *   clica_mlp_planes_from_f32_t  fp32 X [M, width] -> T-planes of X (buffer of clica_mlp_planes_bytes(width, M, 0) bytes).
+ * Plane buffers must be zero-initialised once (padding rows / features are never written and must read as zero). */
+int clica_mlp_planes_from_f32_t(const float* X, int64_t ldx, int64_t M, int32_t width, void* planes_out, clica_stream_t stream);
+int clica_linear_split_fwd(const void* xT_planes, const void* wT_planes, const float* bias, int64_t M, int32_t N, int32_t K,
+                           int32_t leaky, float slope, void* yT_planes, void* yN_planes, int32_t yN_ones,
+                           float* Y, int64_t ldy, clica_stream_t stream);
+int clica_linear_split_dgrad(const void* dzT_planes, const void* wN_planes, const void* actT_planes, float slope,
+                             int64_t M, int32_t N, int32_t K, void* dxT_planes, void* dxN_planes,
+                             float* dX, int64_t lddx, clica_stream_t stream);
 int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes);
 int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
                           const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,

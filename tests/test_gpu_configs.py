@@ -249,7 +249,8 @@ def test_c3_engine_full_size_vs_oracle():
     # (3) the oracle's backward on the ENGINE's saved activations (fp32 -> fp64: same LeakyReLU branch per element; a unit whose
     # pre-activation is within rounding of 0 would otherwise take slope 1 on one side and 0.01 on the other, and one such flip
     # moves an element of dW by ~1 % -- it is 1 of 12 288 summands of random sign) and the engine's d loss / d y
-    cache_e = dict(acts=[tr.x.cpu().numpy().astype(np.float64)] + [a.cpu().numpy().astype(np.float64) for a in tr.acts])
+    cache_e = dict(acts=[tr.x.cpu().numpy().astype(np.float64)] +
+                   [tr.saved_activation(l).cpu().numpy().astype(np.float64) for l in range(len(tr.acts))])
     for l, (ae, ao) in enumerate(zip(cache_e["acts"][1:], cache["acts"][1:])):
         PARITY.check(fam, case, f"act{l}", ae, ao)
     gr = O.mlp_backward(P, cache_e, dye.astype(np.float64))

@@ -514,3 +514,69 @@ def test_linear_kernels_seeded_sweep_vs_fp64():
         PARITY.check("linear_sweep_vs_fp64", cid, "dW", dw.cpu().numpy(), dy.astype(np.float64).T @ x.astype(np.float64))
         # a column sum of M signed terms: relative to the summands' scale
         PARITY.check("linear_sweep_vs_fp64", cid, "db", db.cpu().numpy(), dy.astype(np.float64).sum(0), floor=float(np.abs(dy).sum(0).max()) * 0.05)
+
+
+def _planes_to_f64(buf, rows, feats, ones=False):
+    """Decode a bf16 plane buffer (csrc/planes.h) back to the [rows, feats] matrix it holds (hi + mid + lo), on the host."""
+    units = (feats + (1 if ones else 0) + 31) // 32
+    raw = buf.cpu().numpy().view(np.uint16)
+    groups = raw.size // (units * 3 * 512)
+    a = raw.reshape(groups, units, 3, 4, 2, 4, 16).astype(np.uint32) << 16          # [g][u][plane][k/4][f/16][k%4][f%16]
+    v = a.view(np.float32).astype(np.float64).sum(2)                                  # [g][u][k/4][f/16][k%4][f%16]
+    v = v.transpose(0, 2, 4, 1, 3, 5).reshape(groups * 16, units * 32)                # row = g*16 + (k/4)*4 + k%4, feat = u*32 + (f/16)*16 + f%16
+    return v[:rows, :feats], v
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 400, 2000), (500, 333, 130), (256, 129, 64), (1000, 2000, 400)])
+def test_linear_split_wide_fwd_dgrad_match_fp64(M, N, K):
+    """Forward and data gradient of ONE wide nn.Linear + LeakyReLU (encoders.py:36-48) in split-bf16 arithmetic from T-plane
+    operands (clica_linear_split_fwd / _dgrad, BASELINE config 3's layers) against fp64: fp32 copy, T-planes and N-planes of the
+    output, ragged sizes, untouched ones column, zero padding."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    slope = 0.01
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).cuda()
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32) * 0.1).cuda()
+    xT = ops.mlp_planes_from_f32_t(x)                       # planes of x^T: rows = K, features = M
+    dec, _ = _planes_to_f64(xT, K, M)
+    assert np.array_equal(dec, x.cpu().numpy().astype(np.float64).T)
+    wT = ops.mlp_planes_from_f32_t(w)                       # planes of w^T: rows = K, features = N
+    wN = ops.mlp_planes_from_f32(w, False)                  # planes of w:   rows = N, features = K
+    yT = ops.mlp_planes_alloc(N, M, False, x.device)
+    yN = ops.mlp_planes_from_f32(torch.zeros(M, N, device=x.device), True)       # zeros + the ones column, as the engine initialises it
+    y = torch.full((M, N + 3), 7.0, device=x.device)
+    ops.linear_split_fwd(xT, wT, b, M, N, K, True, slope, yT=yT, yN=yN, yN_ones=True, y=y[:, :N])
+    pre = x.double().cpu().numpy() @ w.double().cpu().numpy().T + b.double().cpu().numpy()
+    ref = np.where(pre > 0, pre, slope * pre)
+    got = y[:, :N].double().cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() / scale < 2e-6
+    assert (y[:, N:] == 7.0).all()
+    dT, fullT = _planes_to_f64(yT, N, M)
+    assert np.array_equal(dT, got.T)                        # the three pieces add up to the fp32 value exactly
+    assert np.count_nonzero(fullT[N:, :]) == 0 and np.count_nonzero(fullT[:, M:]) == 0
+    dN, fullN = _planes_to_f64(yN, M, N, ones=True)
+    assert np.array_equal(dN, got)
+    assert np.all(fullN[:, N] == 1.0) and np.count_nonzero(fullN[M:, :N]) == 0
+    # backward: dX = (dZ W) * leaky'(x_act) with the gate taken from T-planes of the layer's input activation
+    act = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+    act[0, :5] = 0.0                                        # LeakyReLU'(0) = slope
+    actT = ops.mlp_planes_from_f32_t(act)
+    dz = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).cuda()
+    dzT = ops.mlp_planes_from_f32_t(dz)
+    dxT = ops.mlp_planes_alloc(K, M, False, x.device)
+    dxN = ops.mlp_planes_alloc(M, K, False, x.device)
+    dx = torch.empty(M, K, device=x.device)
+    ops.linear_split_dgrad(dzT, wN, actT, slope, M, N, K, dxT=dxT, dxN=dxN, dx=dx)
+    gate = np.where(act.cpu().numpy() > 0, 1.0, slope)
+    refd = (dz.double().cpu().numpy() @ w.double().cpu().numpy()) * gate
+    gotd = dx.double().cpu().numpy()
+    assert np.abs(gotd - refd).max() / np.abs(refd).max() < 2e-6
+    assert np.array_equal(_planes_to_f64(dxT, K, M)[0], gotd.T)
+    assert np.array_equal(_planes_to_f64(dxN, M, K)[0], gotd)
+    # no gate, fp32 output only
+    dx2 = torch.empty(M, K, device=x.device)
+    ops.linear_split_dgrad(dzT, wN, None, slope, M, N, K, dx=dx2)
+    ref2 = dz.double().cpu().numpy() @ w.double().cpu().numpy()
+    assert np.abs(dx2.double().cpu().numpy() - ref2).max() / np.abs(ref2).max() < 2e-6
