@@ -539,7 +539,7 @@ def comm_leg(tr, rank, world, device, reps=20):
 
 def secondary_leg(args, device, steps=20, windows=3):
     """BASELINE config 3 on ONE rank (main_mlp.py --n 40 --space-type sphere --p 1 --batch-size 6144: 13.6 M parameters, 1.005
-    TFLOP of encoder GEMMs per step, 2000-wide layers -> the per-layer fp32-MFMA kernels): step rate with the local negatives
+    TFLOP of encoder GEMMs per step, 2000-wide layers -> per-layer kernels, the 2000 x 2000 layers in split-bf16): step rate with the local negatives
     pool (B3 = 6144) and with the pool of the 8-GPU job emulated on this GPU (B3 = 49 152: the local embeddings replicated eight
     times, device copies in place of the two all-gathers -- this rank's compute of the data-parallel job, no communication)."""
     import copy
@@ -547,7 +547,8 @@ def secondary_leg(args, device, steps=20, windows=3):
     a.n, a.space_type, a.p = 40, "sphere", 1
     res = {"workload": "main_mlp.py --n 40 --space-type sphere --p 1 --batch-size 6144 (BASELINE configs[2], one rank's work)",
            "encoder_gflop_per_step": round(3 * 2 * 13632000 * 2 * a.batch_size / 1e9, 1),
-           "dtype": "f32: forward / data-gradient GEMMs native fp32 MFMA (per-layer kernels), weight gradients via bf16x3 split"}
+           "dtype": ("f32: the 2000 x 2000 layers via bf16x3 split (forward, data and weight gradients: gemm_split_k / wgrad_split_k); narrow "
+                     "layers native fp32 MFMA forward / data gradient, bf16x3 split weight gradients")}
     for name, ranks in (("pool_6144", 1), ("pool_49152_emulated_8_ranks", 8)):
         tr = build_trainer(a, device, 1, emulate_pool_ranks=ranks)
         capture_or_eager(tr, a, 0, 1, device)
