@@ -132,13 +132,15 @@ class _MLPFusedFn(torch.autograd.Function):
 
 def _use_fused(linears, M: int) -> bool:
     """Whole-encoder kernels for the autograd path?  They own 48 rows per workgroup for the whole stack, so they want
-    >= ~3/4 of the 256 CUs busy; smaller batches (and wide encoders) take the per-layer GEMMs.  CLICA_DROPIN_FUSED=0/1 forces."""
+    half of the 256 CUs busy (measured at 128 workgroups = one B = 6144 encoder call of the reference's train_step: 645 against
+    594 steps/s through the per-layer GEMMs); smaller batches (and wide encoders) take the per-layer GEMMs.
+    CLICA_DROPIN_FUSED=0/1 forces."""
     import os
     e = os.environ.get("CLICA_DROPIN_FUSED", "auto")
     ok = len(linears) > 1 and all(lin.bias is not None for lin in linears) and ops.mlp_fwd_fusable([lin.weight for lin in linears])
     if not ok or e == "0":
         return False
-    return True if e == "1" else (M + 47) // 48 >= 192
+    return True if e == "1" else (M + 47) // 48 >= 128
 
 
 class FusedMLP(nn.Sequential):
