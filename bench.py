@@ -234,8 +234,38 @@ def roofline_leg(tr, reps=20):
     # symbol back to back sees a different L2 / Infinity-Cache state (its own 108 MB output is still resident) and the
     # forward / backward-chain pair alone thrashes differently again (measured 208 / 201 / 215 us for the three variants).
     instep = {}
-    if tr.fused_forward and tr.fused_backward and tr.grouped_wgrad and tr.head is None and not tr.dp:
+    instep_how = None
+    if tr.fused_forward and tr.fused_backward and tr.grouped_wgrad and tr.head is None and not tr.dp and tr.graph is not None:
+        # Preferred: the launches INSIDE the replayed step graph -- what the timed loop runs and what the rocprofv3 kernel trace
+        # averages -- bracketed by device-side time stamps (clica_stamp: one-thread kernels writing the 100 MHz wall clock; event
+        # records cannot be timed inside a captured graph).  The stamped graph is a second capture used for this leg only.
         names = ("mlp_fwd", "mlp_dgrad", "mlp_wgrad")
+        WARM = 100
+        snap = [t.clone() for t in (tr.param_arena, tr.exp_avg, tr.exp_avg_sq, tr.step_dev)]
+        keep = tr.graph
+        try:
+            tr.stamps = {k: torch.zeros(1 + 2 * reps, dtype=torch.int64, device=tr.device) for k in names + ("null",)}
+            tr.graph = None
+            tr.capture()
+            for _ in range(WARM + reps):
+                tr.graph.replay()
+            torch.cuda.synchronize()
+            iv = {k: ops.stamp_intervals_us(tr.stamps[k]) for k in names + ("null",)}
+            if all(len(v) == reps for v in iv.values()):
+                null_us = float(np.median(iv["null"]))       # begin stamp's run time + one launch boundary
+                instep = {k: float(np.median(iv[k])) - null_us for k in names}
+                instep_how = ("device time stamps (clica_stamp, 100 MHz wall clock) around the launch inside %d replays of the captured "
+                              "training step, median, minus the %.2f us an empty stamp pair measures" % (reps, null_us))
+        except Exception:
+            instep = {}
+        finally:
+            tr.stamps = None
+            tr.graph = keep
+            for dst, src in zip((tr.param_arena, tr.exp_avg, tr.exp_avg_sq, tr.step_dev), snap):
+                dst.copy_(src)
+    if not instep and tr.fused_forward and tr.fused_backward and tr.grouped_wgrad and tr.head is None and not tr.dp:
+        names = ("mlp_fwd", "mlp_dgrad", "mlp_wgrad")
+        instep_how = "HIP events around the two launches inside eager training steps (see roofline_leg)"
         # one event set per repetition and NO host sync inside the loop: the host runs ahead of the GPU (a step is ~0.77 ms of GPU
         # work, ~0.3 ms of eager launch work), so every bracket opens while the GPU is still busy and measures kernel time
         WARM = 60      # ~45 ms of untimed steps first (sustained clock, see _graph_time)
@@ -261,8 +291,13 @@ def roofline_leg(tr, reps=20):
         instep = {k: 1e3 * v / reps for k, v in acc.items()}       # us per launch (wgrad: its three launches together)
     rows = []
     for (op, sym), grp in groups.items():
-        sec = _graph_time(grp["fns"], reps)
         cnt = len(grp["fns"])
+        if instep_how and instep_how.startswith("device time stamps") and (op in instep or op == fused_key[0]):
+            # timed inside the replayed step: no isolated replays of these symbols (they would also enter the rocprofv3 average of
+            # this command, which is meant to be the training loop's)
+            sec = (instep[op] if op in instep else instep["mlp_fwd"] + instep["mlp_dgrad"]) * 1e-6
+        else:
+            sec = _graph_time(grp["fns"], reps)
         rows.append({"op": op, "kernel": sym, "launches_per_step": cnt, "avg_us": 1e6 * sec / cnt,
                      "gflop_per_launch": grp["flops"] / cnt / 1e9, "tflops": grp["flops"] / sec / 1e12, "us_per_step": 1e6 * sec})
     for r in rows:
@@ -271,11 +306,12 @@ def roofline_leg(tr, reps=20):
     if instep:       # the dominant symbol's entry: average of its two in-step launches (forward stack + backward chain)
         for r in rows:
             if r["op"] == fused_key[0]:
-                r["isolated_pair_avg_us"] = r["avg_us"]
+                if not (instep_how or "").startswith("device time stamps"):
+                    r["isolated_pair_avg_us"] = r["avg_us"]
                 r["avg_us"] = 0.5 * (instep["mlp_fwd"] + instep["mlp_dgrad"])
                 r["us_per_step"] = 2.0 * r["avg_us"]
                 r["tflops"] = 2.0 * r["gflop_per_launch"] * 1e9 / (r["us_per_step"] * 1e-6) / 1e12
-                r["timing"] = "HIP events around the two launches inside eager training steps (see roofline_leg)"
+                r["timing"] = instep_how
     rows.sort(key=lambda r: -r["us_per_step"])
     peak = PEAK_FP32_MFMA_TFLOPS
     issued_factor = 1.0

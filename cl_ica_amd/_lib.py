@@ -112,6 +112,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_adam_step_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                              C.c_void_p, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],
+    "clica_stamp": [C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_reload_env": [],
     "clica_abort_capture": [C.c_void_p],
     "clica_nn_search_workspace_bytes": [c_i64, c_i64, c_i32, c_i32, C.POINTER(c_size)],

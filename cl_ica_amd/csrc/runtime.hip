@@ -22,10 +22,23 @@ int launch_status(const char* what) {
 }
 
 __global__ void tick_k(int32_t* c) { *c += 1; }
+// slot[0] += 1; slot[1 + 2 * (old count % cap) + which] = wall clock (100 MHz constant-rate counter, s_memrealtime).  See clica_stamp.
+__global__ void stamp_k(unsigned long long* slot, int which, int cap) {
+  const unsigned long long t = wall_clock64();
+  const unsigned long long c = which ? slot[0] - 1 : slot[0];
+  slot[1 + 2 * (c % (unsigned long long)cap) + which] = t;
+  if (!which) slot[0] = c + 1;
+}
 }  // namespace clica
 
 extern "C" const char* clica_last_error(void) { return clica::g_err; }
 extern "C" int clica_version(void) { return 100; }
+
+extern "C" int clica_stamp(unsigned long long* slot, int32_t which, int32_t capacity, clica_stream_t stream) {
+  CLICA_CHECK_ARG(slot != nullptr && capacity >= 1 && (which == 0 || which == 1), "clica_stamp: bad argument");
+  hipLaunchKernelGGL(clica::stamp_k, dim3(1), dim3(1), 0, clica::as_stream(stream), slot, (int)which, (int)capacity);
+  return clica::launch_status("clica_stamp");
+}
 
 extern "C" int clica_tick(int32_t* counter, clica_stream_t stream) {
   CLICA_CHECK_ARG(counter != nullptr, "clica_tick: counter is NULL");

@@ -530,7 +530,17 @@ class ContrastiveTrainer:
         two = side is not None and main is not None
         if self.fused_backward:
             # (1) the data-gradient chain in one launch; (2) the weight-gradient GEMMs
+            st = getattr(self, "stamps", None)
+            if st:
+                ops.stamp(st["mlp_dgrad"], 0)
             self.backward_chain(g)
+            if st:
+                ops.stamp(st["mlp_dgrad"], 1)
+                if self.grouped_wgrad and self.buckets is None:
+                    ops.stamp(st["mlp_wgrad"], 0)
+                    self.weight_grads(g)
+                    ops.stamp(st["mlp_wgrad"], 1)
+                    return
             if self.grouped_wgrad:
                 if self.buckets is not None and self.wgrad_halves:
                     h = self._half
@@ -651,7 +661,13 @@ class ContrastiveTrainer:
             main.wait_stream(side)
         elif sample:
             self.sample()
+        st = getattr(self, "stamps", None)         # bench.py: device time stamps around the encoder launches, valid inside the graph
+        if st:
+            ops.stamp(st["null"], 0); ops.stamp(st["null"], 1)      # empty bracket: the stamp pair's own cost, subtracted by the reader
+            ops.stamp(st["mlp_fwd"], 0)
         self.forward()
+        if st:
+            ops.stamp(st["mlp_fwd"], 1)
         self.loss_forward_backward()
         self.backward()
         self.optimizer_step()

@@ -484,6 +484,18 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
                                           step_dev.data_ptr(), ticket.data_ptr(), stream_ptr()), "clica_adam_step_tick")
 
 
+def stamp(slot: torch.Tensor, which: int):
+    """Device-side begin (0) / end (1) time stamp into `slot` (int64 [1 + 2 * capacity], zeros): usable inside graph capture."""
+    check(load().clica_stamp(slot.data_ptr(), int(which), (slot.numel() - 1) // 2, stream_ptr()), "clica_stamp")
+
+
+def stamp_intervals_us(slot: torch.Tensor):
+    """Completed (begin, end) pairs of a stamp slot as microseconds (100 MHz counter)."""
+    v = slot.cpu()
+    n = min(int(v[0]), (v.numel() - 1) // 2)
+    return [(int(v[2 + 2 * i]) - int(v[1 + 2 * i])) / 100.0 for i in range(n)]
+
+
 def tick(counter: torch.Tensor):
     check(load().clica_tick(counter.data_ptr(), stream_ptr()), "clica_tick")
 

@@ -393,6 +393,11 @@ int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float*
                          int32_t* step_dev, int32_t* ticket, clica_stream_t stream);
 /* *counter += 1 (single-thread kernel; keeps step/RNG counters on device for graph replay) */
 int clica_tick(int32_t* counter, clica_stream_t stream);
+/* Measurement aid (bench.py): device-side interval stamps that work INSIDE a captured graph, where event records cannot be timed.
+ * `slot` = 1 + 2 * capacity device uint64, zero-initialised: a one-thread kernel writes the 100 MHz wall clock (s_memrealtime) to
+ * begin (which = 0) / end (which = 1) entry (count % capacity) and the begin stamp advances the count in slot[0].  Launched on the
+ * stream right before / after the kernel of interest, the pair brackets it exactly as the in-order stream executes it. */
+int clica_stamp(unsigned long long* slot, int32_t which, int32_t capacity, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * On-device latent samplers (Philox4x32-10, counter = (element, draw, *step_dev, stream_id))
