@@ -730,6 +730,7 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
   for (int p = 0; p < 3; ++p)
 #pragma unroll
     for (int c = 0; c < NC; ++c) wcur[p][c] = wpre[p][c];
+#if !CLICA_SPLIT_PINGPONG
   auto step = [&](int ki, int kn) {
     fetch_w(wnxt, kn);
     u32x4 x[3][RB];
@@ -756,6 +757,7 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
 #pragma unroll
       for (int c = 0; c < NC; ++c) { asm volatile("" : "+v"(wnxt[p][c])); wcur[p][c] = wnxt[p][c]; }
   };
+#endif
 #if CLICA_SPLIT_PINGPONG
   // Ping-pong form (round 3; the fp32 kernel's k-loop got the same treatment in round 2): two weight sets AND two activation
   // fragment sets with swapped roles in a loop unrolled by two -- no rotation copies (the 12 x 4 v_mov per iteration above),

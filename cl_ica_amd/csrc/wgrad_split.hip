@@ -112,11 +112,23 @@ __device__ unsigned long long* g_wstrace = nullptr;
 // CONSECUTIVE ROWS of one column.  With C = Y (rows = batch row m, columns = output feature n) that is
 //   * 8 contiguous bytes per plane of the T-planes of Y (planes of Y^T: rows = n, features = m) -- the operand format of the NEXT
 //     layer's forward and of this layer's sign gate in the backward chain;
-//   * four 2-byte stores, 32 B apart, per plane of the N-planes of Y (rows = m, features = n; 16 lanes x 2 B = one 32-byte sector
-//     per store instruction and row) -- the X operand of the next layer's weight gradient;
+//   * after a 4 x 4 transpose inside each lane quad (quad_transpose16: a lane then holds ONE row of the quad's four columns), 8
+//     contiguous bytes per plane of the N-planes of Y (rows = m, features = n) -- the X operand of the next layer's weight gradient;
 //   * four 4-byte stores of the fp32 copy (lanes = consecutive columns: 128 contiguous bytes), only where an fp32 consumer follows.
 // A 2000-deep contraction amortises all of it: ~500 stores per wave behind ~6000 MFMAs.
 __device__ __forceinline__ void split3_hi(float v, unsigned& hb, unsigned& mb, unsigned& lb);
+// 4 x 4 transpose of 16-bit values inside a lane quad (lanes 4a .. 4a + 3): in, lane j holds rows 0..3 of its column as
+// w0 = [row 0 | row 1 << 16], w1 = [row 2 | row 3 << 16]; out, lane j holds ROW j of the quad's four columns, two per word.
+// Two exchange steps on the data-parallel-primitive path (no LDS): partner j ^ 1 with a byte permute, partner j ^ 2 with a select.
+__device__ __forceinline__ u32x2 quad_transpose16(unsigned w0, unsigned w1, const unsigned sel, const bool upper) {
+  const unsigned p0 = (unsigned)__builtin_amdgcn_mov_dpp((int)w0, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+  const unsigned p1 = (unsigned)__builtin_amdgcn_mov_dpp((int)w1, 0xB1, 0xF, 0xF, true);
+  const unsigned a0 = __builtin_amdgcn_perm(p0, w0, sel);       // even lane: rows 0 of (j, j + 1); odd lane: rows 1 of (j - 1, j)
+  const unsigned a1 = __builtin_amdgcn_perm(p1, w1, sel);       // rows 2 / rows 3
+  const unsigned q = upper ? a0 : a1;
+  const unsigned r = (unsigned)__builtin_amdgcn_mov_dpp((int)q, 0x4E, 0xF, 0xF, true);        // quad_perm [2, 3, 0, 1]
+  return upper ? (u32x2){r, a1} : (u32x2){a0, r};
+}
 template <int NI>
 __device__ __forceinline__ void fused_epilogue(const Prob& g, const f32x16 (&acc)[NI][2], const int row0, const int col0, int lane) {
   // the lane-derived addresses are recomputed from an opaque copy of the lane id: hoisted above the k-loop by the compiler they
@@ -125,23 +137,31 @@ __device__ __forceinline__ void fused_epilogue(const Prob& g, const f32x16 (&acc
   const int h = lane >> 5, l31 = lane & 31;
   const bool fwd = g.epi == 1;
   const bool slope01 = g.slope > 0.f && g.slope < 1.f;
+  const int j4 = lane & 3;                                     // position inside the lane quad = column inside a group of four
+  const unsigned sel = (j4 & 1) ? 0x03020706u : 0x05040100u;
+  const bool upper = (j4 & 2) != 0;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = col0 + j * 32 + l31;
-    if (col >= g.N) continue;
-    const float b = (fwd && g.bias) ? g.bias[col] : 0.f;
+    const bool col_ok = col < g.N;                             // (no early exit: every lane of a quad takes part in the transposes)
+    const int colc = col_ok ? col : 0;
+    const float b = (fwd && g.bias && col_ok) ? g.bias[colc] : 0.f;
     // byte offset of (row = col, feature 0) inside T-planes with fu units per group; of (row 0, feature = col) inside N-planes
-    const size_t t_grp = (size_t)(col >> 4) * 3072, t_in = (size_t)(((col & 15) >> 2) * 256 + (col & 3) * 32);
-    const size_t n_col = (size_t)(col >> 5) * 3072 + (size_t)(((col >> 4) & 1) * 128 + (col & 15) * 2);
+    const size_t t_grp = (size_t)(colc >> 4) * 3072, t_in = (size_t)(((colc & 15) >> 2) * 256 + (colc & 3) * 32);
+    const size_t n_col = (size_t)(colc >> 5) * 3072 + (size_t)(((colc >> 4) & 1) * 128 + (colc & 15) * 2);
+    const int c0 = col & ~3;
+    const bool quad_full = c0 + 3 < g.N;                       // the four columns of this quad are all real features
+    const size_t n_c0 = (size_t)(c0 >> 5) * 3072 + (size_t)(((c0 >> 4) & 1) * 128 + (c0 & 15) * 2);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int m = row0 + i * 32 + 8 * q + 4 * h;          // rows m .. m + 3
-        if (m >= g.M) continue;
-        const size_t t_feat = (size_t)(m >> 5) * 3072 + (size_t)(((m >> 4) & 1) * 128 + (m & 15) * 2);
+        const int m = row0 + i * 32 + 8 * q + 4 * h;          // rows m .. m + 3 (the same for the four lanes of a quad)
+        const bool m_ok = m < g.M;
+        const int mc = m_ok ? m : 0;
+        const size_t t_feat = (size_t)(mc >> 5) * 3072 + (size_t)(((mc >> 4) & 1) * 128 + (mc & 15) * 2);
         unsigned sgn[2] = {0x3F803F80u, 0x3F803F80u};           // "positive" when there is no gate
-        if (!fwd && g.signT) {
+        if (!fwd && g.signT && col_ok && m_ok) {
           const u32x2 sv = *reinterpret_cast<const u32x2*>(g.signT + t_grp * g.fuS + t_in + t_feat);
           sgn[0] = sv.x; sgn[1] = sv.y;
         }
@@ -158,26 +178,43 @@ __device__ __forceinline__ void fused_epilogue(const Prob& g, const f32x16 (&acc
             const bool pos = (hbits & 0x8000u) == 0u && (hbits & 0x7FFFu) != 0u;
             t = pos ? t : t * g.slope;
           }
-          if (m + e >= g.M) t = 0.f;
+          if (m + e >= g.M || !col_ok) t = 0.f;
           v[e] = t;
           split3_hi(t, hb[e], mb[e], lb[e]);
         }
-        if (g.outT) {
+        const u32x2 ph = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
+        const u32x2 pm = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
+        const u32x2 pl = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+        if (g.outT && col_ok && m_ok) {
           char* dst = g.outT + t_grp * g.fuT + t_in + t_feat;
-          *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
-          *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
-          *reinterpret_cast<u32x2*>(dst + 2048) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+          *reinterpret_cast<u32x2*>(dst) = ph;
+          *reinterpret_cast<u32x2*>(dst + 1024) = pm;
+          *reinterpret_cast<u32x2*>(dst + 2048) = pl;
         }
         if (g.outN) {
-          char* dst = g.outN + (size_t)(m >> 4) * 3072 * g.fuN + (size_t)(((m & 15) >> 2) * 256) + n_col;
+          // this lane's four rows of ONE column -> one row (m + j4) of the quad's FOUR columns: 8 contiguous bytes per plane
+          const u32x2 th = quad_transpose16(ph.x, ph.y, sel, upper);
+          const u32x2 tm = quad_transpose16(pm.x, pm.y, sel, upper);
+          const u32x2 tl = quad_transpose16(pl.x, pl.y, sel, upper);
+          const int row = m + j4;
+          if (quad_full) {
+            if (row < g.M) {
+              char* dst = g.outN + (size_t)(row >> 4) * 3072 * g.fuN + (size_t)(((row & 15) >> 2) * 256 + (row & 3) * 32) + n_c0;
+              *reinterpret_cast<u32x2*>(dst) = th;
+              *reinterpret_cast<u32x2*>(dst + 1024) = tm;
+              *reinterpret_cast<u32x2*>(dst + 2048) = tl;
+            }
+          } else if (col_ok && m_ok) {      // ragged last quad of the feature range: element stores (the ones column next to it stays)
+            char* dst = g.outN + (size_t)(m >> 4) * 3072 * g.fuN + (size_t)(((m & 15) >> 2) * 256) + n_col;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (m + e >= g.M) continue;
-            unsigned short* d2 = reinterpret_cast<unsigned short*>(dst + e * 32);
-            d2[0] = (unsigned short)(hb[e] >> 16); d2[512] = (unsigned short)(mb[e] >> 16); d2[1024] = (unsigned short)(lb[e] >> 16);
+            for (int e = 0; e < 4; ++e) {
+              if (m + e >= g.M) continue;
+              unsigned short* d2 = reinterpret_cast<unsigned short*>(dst + e * 32);
+              d2[0] = (unsigned short)(hb[e] >> 16); d2[512] = (unsigned short)(mb[e] >> 16); d2[1024] = (unsigned short)(lb[e] >> 16);
+            }
           }
         }
-        if (g.outF) {
+        if (g.outF && col_ok) {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (m + e < g.M) g.outF[(int64_t)(m + e) * g.ldf + col] = v[e];
