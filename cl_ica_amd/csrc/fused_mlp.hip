@@ -707,8 +707,80 @@ struct SplitArgs {
   int64_t off3[MAXL];            // 16-byte entry offset of each layer's piece 0
   int64_t ent3[MAXL];            // entries per piece of each layer
   int boff[MAXL + 1];            // float offset of each layer's bias row inside the LDS bias table (rows padded to KI)
+  int warm_next;                 // L2 warm-up of the layer that follows a wide one: at most this many KB per early wave (see mlp_split_k)
 };
+#ifndef CLICA_SPLIT_WARM_NEXT
+#define CLICA_SPLIT_WARM_NEXT 12                 // 12: also a 500 x 500 layer that follows directly (1.5 MB per XCD); 3: short layers only
+#endif
+constexpr int WARM_LOADS = CLICA_SPLIT_WARM_NEXT;   // L2 warm-up: 1 KB slices of the NEXT layer's weights per participating wave (see mlp_split_k)
+constexpr int WARM_LOADS2 = 3;                      // ... of the layer after it (short layers only)
 constexpr int BIAS_LDS_MAX = (160 * 1024 - 3 * PLANE * 2) / 4 - 64;    // floats left beside the three planes
+
+// Narrow layers (ONE column block per wave: the 100- and 10-wide layers).  The wide loop below keeps ONE k-iteration of
+// weights in flight, enough when 72 MFMAs (1 152+ cycles) cover an L2 miss.  Here an iteration is 18 or 36 MFMAs, and in the
+// training step the packed weights are COLD (mlp_pack3_k rewrote them a moment ago on another XCD: the first touch per XCD comes
+// from HBM): the trace showed the 500 -> 100 layer at 29.9 k cycles for 16 iterations cold against 15.8 k warm, i.e. one exposed
+// memory round trip per iteration.  So: a ring of FOUR weight sets (three iterations in flight, the registers the wide loop
+// spends on its four column blocks) and two activation-fragment sets (the LDS reads of iteration i + 1 under the MFMAs of i).
+template <int NC>
+__device__ __forceinline__ void layer_gemm_split_narrow(const int K, const u32x4* __restrict__ w0, const int64_t ent, const unsigned short* planes,
+                                                        int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[3][CBW]) {
+  static_assert(NC == 1, "narrow variant: with two column blocks the ring (96) + both fragment sets (72) + accumulators spill");
+  const int i15 = lane & 15, kg = lane >> 4;
+  const int kiters = (K + KI - 1) / KI;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  u32x4 w[4][3][NC];
+  u32x4 x[2][3][RB];
+  auto kof = [&](int ki) { return ki < kiters ? ki : kiters - 1; };      // past the end: a harmless re-read of the last iteration's operands
+  auto fetch_w = [&](u32x4 (&d)[3][NC], int ki) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const char* base = reinterpret_cast<const char*>(w0 + p * ent + ((int64_t)(wave + c * WAVES) * kiters + ki) * 64);
+        d[p][c] = *reinterpret_cast<const u32x4*>(base + lane16);
+      }
+  };
+  auto fetch_x = [&](u32x4 (&d)[3][RB], int ki) {
+    constexpr int ORDER[3] = {0, 2, 1};
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        d[ORDER[q]][r] = *reinterpret_cast<const u32x4*>(&planes[ORDER[q] * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
+  };
+  auto mma = [&](const u32x4 (&ww)[3][NC], const u32x4 (&xx)[3][RB]) {
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ww[PW[t]][c]), __builtin_bit_cast(bf16x8, xx[PX[t]][r]),
+                                                              acc[r][c], 0, 0, 0);
+  };
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) w[0][p][c] = wpre[p][c];
+  fetch_w(w[1], kof(1));
+  fetch_w(w[2], kof(2));
+  fetch_x(x[0], 0);
+  for (int ki = 0; ki < kiters; ki += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ki + u < kiters) {                           // wave-uniform
+        fetch_w(w[(u + 3) & 3], kof(ki + u + 3));
+        fetch_x(x[(u + 1) & 1], kof(ki + u + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        mma(w[u], x[u & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the dead look-ahead requests (see layer_gemm_split)
+}
 
 template <int NC>
 __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __restrict__ w0, const int64_t ent, const unsigned short* planes,
@@ -920,6 +992,26 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
   lo_bits = lo; hi_bits = hi;
 }
 
+// One wave's share of the L2 warm-up of layer `lt` (only if it fits: at most NL KB per participating wave of the XCD): plain
+// 16-byte loads of this wave's 1 KB slices of the packed weights, values discarded by the caller once they have landed.
+template <int NL>
+__device__ __forceinline__ void warm_up_l2(const SplitArgs& a, const int L, const int lt, const int limit, const int wave, const int lane, u32x4 (&warm)[NL]) {
+  constexpr int WW = WAVES / 2;                                               // participating waves per workgroup (the early half)
+  const int nwx = (((int)gridDim.x + 7) >> 3) * WW;                           // ... per XCD (workgroups go round-robin over the eight)
+  const int xw = ((int)blockIdx.x >> 3) * WW + wave;
+  if (lt >= L) return;
+  const int64_t loads = (3 * a.ent3[lt] + 63) >> 6;                            // 64 entries of 16 B per wave instruction
+  if (loads > (int64_t)(limit < NL ? limit : NL) * nwx) return;
+#pragma unroll
+  for (int u = 0; u < NL; ++u) {
+    const int64_t idx = xw + (int64_t)u * nwx;
+    if (idx < loads) {
+      const int64_t e = idx * 64 + lane;
+      warm[u] = a.packed3[a.off3[lt] + (e < 3 * a.ent3[lt] ? e : 0)];
+    }
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short planes[];     // [3][ROWS][LDPB] bf16 bit patterns
   const Args& g = a.g;
@@ -944,7 +1036,6 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   u32x4 wpre[3][CBW];
   request_first_w3(a.packed3 + a.off3[0], a.ent3[0], g.layer[0].K, g.layer[0].N, wave, lane, wpre);
   u32x2 mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(g.layer[0].dact ? g.layer[0].mask_in : nullptr), mslot, 0, 0);
-
   auto store_split = [&](int r, int k, float v) {
     unsigned hb, mb, lb; split3(v, hb, mb, lb);
     planes[r * LDPB + k] = (unsigned short)(hb >> 16);
@@ -1016,14 +1107,37 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       case 4: layer_gemm_split<4>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
       case 3: layer_gemm_split<3>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
       case 2: layer_gemm_split<2>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
-      case 1: layer_gemm_split<1>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
+      case 1: layer_gemm_split_narrow<1>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
       default: break;
     }
     ST_STAMP(l, 1);
+    // L2 warm-up for the SHORT layers ahead.  In the training step the packed weights are cold in this XCD's L2 (mlp_pack3_k rewrote
+    // them a moment ago), and a layer with one column block per wave has nothing to hide the first touch behind: the trace shows the
+    // 500 -> 100 layer at 29.9 k cycles cold against 15.8 k with the weights resident, and the misses queue behind this kernel's own
+    // plane stores (> 10 k cycles: look-ahead inside the k-loop does not cover them, and a wave that issues such a load anywhere
+    // else stalls its NEXT k-loop behind it in the in-order vmcnt).  The one place where they cost nothing: the older wave of
+    // each SIMD leaves a wide layer's k-loop ~16 k cycles before the younger one and only waits at the barrier -- there it
+    // touches its 1 KB slices of the next two layers' weights if those are short; the values are discarded below.  In the backward
+    // chain the WIDE layers are cold as well (packed a forward and a loss ago: layers 3 / 4 of the chain ran their k-loops at
+    // 40 k / 51 k cycles per wave pair instead of 25 k / 42 k), so there the next layer is touched whatever its size (12 KB per early
+    // wave for 500 x 500): chain launch 138 -> 125 us in the step; in the forward the same costs 3 us (a.warm_next).
+    u32x4 warm[WARM_LOADS], warm2[WARM_LOADS2];
+#pragma unroll
+    for (int u = 0; u < WARM_LOADS; ++u) warm[u] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < WARM_LOADS2; ++u) warm2[u] = (u32x4){0u, 0u, 0u, 0u};
+    if (nc >= 3 && wave < WAVES / 2) {
+      warm_up_l2<WARM_LOADS>(a, g.L, l + 1, a.warm_next, wave, lane, warm);
+      warm_up_l2<WARM_LOADS2>(a, g.L, l + 2, WARM_LOADS2, wave, lane, warm2);
+    }
     __syncthreads();                                   // every wave is done reading the planes
     ST_STAMP(l, 2);
 
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): nothing of this layer's k-loop is still in flight (see layer_gemm_split)
+#pragma unroll
+    for (int u = 0; u < WARM_LOADS; ++u) asm volatile("" ::"v"(warm[u]));
+#pragma unroll
+    for (int u = 0; u < WARM_LOADS2; ++u) asm volatile("" ::"v"(warm2[u]));
     if (l + 1 < g.L) {                                 // next layer's first weights, sign bits and bias: older than the stores below
       const Layer& nx = g.layer[l + 1];
       request_first_w3(a.packed3 + a.off3[l + 1], a.ent3[l + 1], nx.K, nx.N, wave, lane, wpre);
@@ -1426,6 +1540,7 @@ extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd_split: %d layers (1..%d supported)", n_layers, MAXL);
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_split) & 15) == 0, "clica_mlp_fwd_split: packed weights must be 16-byte aligned");
   SplitArgs a{};
+  a.warm_next = fmlp::WARM_LOADS2;      // forward: short layers only (its wide layers' weights are fresh out of mlp_pack3_k: not cold-sensitive)
   Args& g = a.g;
   g.X = X; g.ldx = ldx; g.M = M; g.L = n_layers; g.slope = slope;
   g.mixW = mix_W; g.mixL = mix_layers; g.mix_slope = mix_slope; g.xout = x_out; g.ldxo = ldxo;
@@ -1455,6 +1570,7 @@ extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, i
   CLICA_CHECK_ARG(n_links >= 1 && n_links <= MAXL, "clica_mlp_dgrad_split: %d links (1..%d supported)", n_links, MAXL);
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_split) & 15) == 0, "clica_mlp_dgrad_split: packed weights must be 16-byte aligned");
   SplitArgs a{};
+  a.warm_next = fmlp::WARM_LOADS;       // backward chain: every layer (its weights were packed a forward + a loss ago: HBM-cold by now)
   Args& g = a.g;
   g.X = dY; g.ldx = lddy; g.M = M; g.L = n_links; g.slope = slope;
   a.packed3 = reinterpret_cast<const u32x4*>(packed_split);

@@ -25,6 +25,8 @@ for which in ("forward", "chain"):
     tr._packed_current = False
     tr.sample(); tr.pack()
     if which == "forward":
+        if os.environ.get("TRACE_WARM_ICACHE") == "1":      # the same launch right before the traced one: warm instruction cache / TLBs
+            tr.forward()
         assert lib.clica_debug_split_trace(buf.data_ptr()) == 0
         tr.forward(); torch.cuda.synchronize()
         lib.clica_debug_split_trace(None)
