@@ -45,4 +45,11 @@ for which in ("forward", "chain"):
         nxt = (t[:, :, l + 1, 0] - t[:, :, l, 3]) if l + 1 < L else np.zeros_like(kl)
         print(f"  layer {l}: k-loop by wave {np.round(np.median(kl, 0)).astype(int).tolist()}  barrier wait {np.round(np.median(b1, 0)).astype(int).tolist()}"
               f"  epilogue {int(np.median(ep))}  barrier 2 {int(np.median(nxt))}   layer total {int(np.median(t[:, :, l, 3].max(1) - t[:, :, l, 0].min(1)))}")
-    print(f"  whole kernel (first stamp to last): {int(np.median(t[:, :, L - 1, 3].max(1) - t[:, :, 0, 0].min(1)))} cycles")
+    e0 = t[:, :, MAXL - 1, 0].min(1)
+    pro = [int(np.median(t[:, :, MAXL - 1, q].max(1) - e0)) for q in (1, 2, 3)]
+    print(f"  prologue phases from the workgroup's first entry (last wave): loads consumed {pro[0]}, first barrier passed {pro[1]}, mixing done {pro[2]}, "
+          f"first layer starts {int(np.median(t[:, :, 0, 0].min(1) - e0))}; entry skew of the eight waves {int(np.median(t[:, :, MAXL - 1, 0].max(1) - e0))}")
+    print(f"  whole kernel (first stamp to last): {int(np.median(t[:, :, L - 1, 3].max(1) - t[:, :, 0, 0].min(1)))} cycles;  prologue (kernel entry -> "
+          f"first layer: bias table, input staging / mixing net, zero fill): {int(np.median(t[:, :, 0, 0].min(1) - t[:, :, MAXL - 1, 0].min(1)))} cycles;  "
+          f"spread of the workgroups' entry times: {int(t[:, :, MAXL - 1, 0].min(1).max() - t[:, :, MAXL - 1, 0].min(1).min())} cycles;  "
+          f"first entry -> last exit over all workgroups: {int(t[:, :, L - 1, 3].max() - t[:, :, MAXL - 1, 0].min())} cycles")
