@@ -23,7 +23,8 @@ def test_bench_emits_contract_line():
     rf = line["roofline"]      # headline mode: issued bf16 flops against the dense bf16 peak, fp32-equivalent figure next to it
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     fe = rf["fp32_equivalent"]
-    assert fe["peak"] == 157.3 and 0 < fe["frac"] < 1.05 and abs(6 * fe["achieved"] - rf["achieved"]) < 0.05 * rf["achieved"]
+    # (the fp32-EQUIVALENT rate may exceed the fp32 matrix peak: the six bf16 products of one fp32 product cost 0.375 of its matrix time)
+    assert fe["peak"] == 157.3 and 0 < fe["frac"] < 2.5 and abs(6 * fe["achieved"] - rf["achieved"]) < 0.05 * rf["achieved"]
     nat = line["native_fp32"]
     assert nat["value"] > 100 and nat["dtype"] == "f32" and nat["roofline"]["peak"] == 157.3 and 0 < nat["roofline"]["frac"] < 1
     assert abs(line["final_loss"]) < 20 and abs(nat["final_loss"]) < 20

@@ -36,7 +36,7 @@ bench = json.load(open(f"{src}/bench_under_rocprof.json"))
 lines = [f"# Profile {tag}: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-native-leg --no-dropin`", "",
          f"bench line under the profiler: {bench['value']:.1f} steps/s, {bench['ms_per_step']:.3f} ms/step ({bench['dtype']}); roofline entry: "
          f"`{bench['roofline']['kernel']}` {bench['roofline']['achieved']} TFLOP/s ({bench['roofline']['frac']:.3f} of {bench['roofline']['peak']}), "
-         f"avg {bench['roofline']['avg_launch_us']} us/launch (HIP events inside training steps).", "",
+         f"avg {bench['roofline']['avg_launch_us']} us/launch (device time stamps around the launches inside the replayed step graph, bench.py roofline leg).", "",
          "PMC columns come from separate `--pmc` passes (FETCH_SIZE / WRITE_SIZE in KB per launch, as reported; per "
          "MI355X_MICROARCH.md FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950 -> `fetch_x2_MB`). "
          "MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 XCDs * 1024 SIMDs).", "",
