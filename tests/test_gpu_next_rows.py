@@ -308,3 +308,27 @@ def test_threedident_latent_pairs_full_size():
     oa, ob = O.threedident_snap(table, zq.cpu().numpy(), ztq.cpu().numpy())
     assert (a.cpu().numpy() == oa).all() and (b.cpu().numpy() == ob).all()
     assert (a == b).sum() == 0 and (torch.tensor(oa) == O.flat_l2_search(table, ztq.cpu().numpy(), 1)[1][:, 0]).any()   # the exclusion rule fired
+
+
+def test_device_time_stamps_inside_a_graph():
+    """clica_stamp (bench.py's in-graph timing): begin / end stamps around a known amount of work inside a captured graph give
+    one completed interval per replay, in the ring order, of plausible length (the work is ~100 us of matmuls)."""
+    from cl_ica_amd import ops
+    dev = torch.device("cuda")
+    slot = torch.zeros(1 + 2 * 4, dtype=torch.int64, device=dev)
+    a = torch.randn(2048, 2048, device=dev)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        (a @ a).sum().item()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            ops.stamp(slot, 0)
+            b = a @ a
+            b = b @ a
+            ops.stamp(slot, 1)
+        for _ in range(6):          # six replays into a ring of four: the last four survive
+            g.replay()
+    torch.cuda.synchronize()
+    iv = ops.stamp_intervals_us(slot)
+    assert int(slot[0].item()) == 6 and len(iv) == 4
+    assert all(20.0 < v < 20000.0 for v in iv), iv
