@@ -54,6 +54,7 @@ struct Prob {
   int M, N;                       // dW rows (N_l) and columns (K_l)
   int groups, gps;                // 16-row groups of the batch; groups per contraction split
   int gx, gy, a_wide;             // tiles along the columns / rows; tile shape 1: 256 x 128, 0: 128 x 256, 2: 256 x 256 (body_big)
+  int n_big, rows_big;            // gemm_split_k, a_wide == 3 (mixed): the first n_big items are 256 x 256 tiles over rows [0, rows_big), the rest 128 x 256
   // fused epilogues of gemm_split_k (forward / data gradient of a wide layer, see below); unused (zero) in the weight-gradient launch
   int epi;                        // 1: + bias, LeakyReLU   2: x LeakyReLU'(sign of the layer's input activation)
   int leaky; float slope;
@@ -556,9 +557,26 @@ __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
 //   forward   Y[m][n]  = sum_k X[m][k] W[n][k]  : A = planes of X^T (rows = k, features = m),  B = planes of W^T (rows = k, features = n)
 //   backward  dX[m][k] = sum_n dZ[m][n] W[n][k] : A = planes of dZ^T (rows = n, features = m), B = planes of W   (rows = n, features = k)
 // no contraction split (K = 400..2000 is 25..125 steps of a 256 x 256 tile), fused_epilogue instead of the slab.
+// Mixed tiling (a_wide == 3): 12288 x 2000 is 384 tiles of 256 x 256 -- 1.5 rounds of the 256 CUs, and the half-empty second round
+// costs more than the big tile's 2/3 bytes per flop save (572 us against 511 us for 768 tiles of 128 x 256).  So ONE full round of big
+// tiles over the first rows_big rows (the first 256 workgroups, one per CU) and the remaining rows as 128 x 256 tiles, picked up as
+// the CUs come free: 286 + 170 us of work per CU instead of 3 x 170.
 __global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
-  const int id = xcd_contiguous(blockIdx.x, G.total);
   const Prob& g = G.p[0];
+  if (g.a_wide == 3) {
+    const int b = (int)blockIdx.x;
+    if (b < g.n_big) {
+      const int id = xcd_contiguous(b, g.n_big);
+      const int by = id / g.gx, bx = id - by * g.gx;
+      body_big<true>(g, bx, by, 0);
+    } else {
+      const int id = xcd_contiguous(b - g.n_big, G.total - g.n_big);
+      const int by = id / g.gx, bx = id - by * g.gx;
+      body<false, true>(g, bx, g.rows_big / 128 + by, 0);
+    }
+    return;
+  }
+  const int id = xcd_contiguous(blockIdx.x, G.total);
   const int by = id / g.gx, bx = id - by * g.gx;
   if (g.a_wide == 2) body_big<true>(g, bx, by, 0); else if (g.a_wide) body<true, true>(g, bx, by, 0); else body<false, true>(g, bx, by, 0);
 }
@@ -829,14 +847,30 @@ extern "C" int clica_mlp_planes_from_f32_t(const float* X, int64_t ldx, int64_t 
 
 static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, const char* who) {
   static const int forced = [] { const char* e = getenv("CLICA_SPLIT_GEMM_TILE"); return e ? atoi(e) : -1; }();     // 0 / 1 / 2 (tuning)
-  // 128 x 256 tiles when the output is wide enough, else 256 x 128.  (The 256 x 256 body, the better one for the weight gradients, is
-  // not here: 12288 x 2000 makes 384 of them = 1.5 rounds of the 256 CUs; measured 572 us against 511 us for 768 small tiles.)
-  g.a_wide = forced >= 0 && forced <= 2 ? forced : (cols >= 256 ? 0 : 1);
-  const int bm = g.a_wide == 0 ? 128 : 256, bn = g.a_wide == 1 ? 128 : 256;
-  g.gy = (int)ceil_div(M, (int64_t)bm); g.gx = (int)ceil_div((int64_t)cols, (int64_t)bn);
+  // 128 x 256 tiles when the output is wide enough, else 256 x 128; with whole rounds of 256 x 256 tiles in front where they fit
+  // (mixed tiling, see gemm_split_k).  CLICA_SPLIT_GEMM_TILE = 0 / 1 / 2 forces one shape, 3 / unset = this rule.
+  g.a_wide = forced >= 0 && forced <= 3 ? forced : (cols >= 256 ? 0 : 1);
+  int total;
+  const int gx256 = (int)ceil_div((int64_t)cols, (int64_t)256);
+  // mixed: whole rounds of 256 x 256 tiles (kNumCU / gx row tiles each) while a full round fits, 128 x 256 tiles for the rest
+  const int64_t rows_per_big_round = (int64_t)(kNumCU / gx256) * 256;
+  const int64_t big_rounds = (gx256 <= kNumCU && forced != 0 && forced != 1 && forced != 2 && cols >= 256) ? M / rows_per_big_round : 0;
+  if ((forced == 3 || forced < 0) && big_rounds >= 1 && M - big_rounds * rows_per_big_round > 0) {
+    g.a_wide = 3;
+    g.gx = gx256;
+    g.rows_big = (int)(big_rounds * rows_per_big_round);
+    g.n_big = (int)(g.rows_big / 256) * g.gx;
+    total = g.n_big + (int)ceil_div(M - g.rows_big, (int64_t)128) * g.gx;
+    g.gy = 0;
+  } else {
+    if (g.a_wide == 3) g.a_wide = cols >= 256 ? 0 : 1;
+    const int bm = g.a_wide == 0 ? 128 : 256, bn = g.a_wide == 1 ? 128 : 256;
+    g.gy = (int)ceil_div(M, (int64_t)bm); g.gx = (int)ceil_div((int64_t)cols, (int64_t)bn);
+    total = g.gx * g.gy;
+  }
   g.gps = g.groups;
   GroupArgs G{};
-  G.n = 1; G.p[0] = g; G.first[0] = 0; G.first[1] = G.total = g.gx * g.gy;
+  G.n = 1; G.p[0] = g; G.first[0] = 0; G.first[1] = G.total = total;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
   (void)once;
   hipLaunchKernelGGL(gemm_split_k, dim3((unsigned)G.total), dim3(THREADS), kLdsBytes, st, G);

@@ -527,7 +527,8 @@ def _planes_to_f64(buf, rows, feats, ones=False):
     return v[:rows, :feats], v
 
 
-@pytest.mark.parametrize("M,N,K", [(768, 400, 2000), (500, 333, 130), (256, 129, 64), (1000, 2000, 400)])
+@pytest.mark.parametrize("M,N,K", [(768, 400, 2000), (500, 333, 130), (256, 129, 64), (1000, 2000, 400),
+                                   (8192 + 333, 1999, 48)])      # the last: mixed tiling (one round of 256 x 256 tiles + 128 x 256 remainder)
 def test_linear_split_wide_fwd_dgrad_match_fp64(M, N, K):
     """Forward and data gradient of ONE wide nn.Linear + LeakyReLU (encoders.py:36-48) in split-bf16 arithmetic from T-plane
     operands (clica_linear_split_fwd / _dgrad, BASELINE config 3's layers) against fp64: fp32 copy, T-planes and N-planes of the

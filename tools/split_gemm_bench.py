@@ -44,4 +44,4 @@ rows = [
 print(f"M = {M}, N = {N}, K = {K}: {gf:.1f} GFLOP per GEMM; tile = {os.environ.get('CLICA_SPLIT_GEMM_TILE', 'auto')}")
 for name, fn in rows:
     us = timeit(fn)
-    print(f"  {name:34s} {us:8.1f} us   {gf / us * 1e-3:7.1f} TFLOP/s (fp32-equivalent)" if "conversion" not in name else f"  {name:34s} {us:8.1f} us")
+    print(f"  {name:34s} {us:8.1f} us   {gf / us * 1e3:7.1f} TFLOP/s (fp32-equivalent)" if "conversion" not in name else f"  {name:34s} {us:8.1f} us")
