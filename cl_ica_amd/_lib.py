@@ -172,7 +172,9 @@ def require_cuda(t: torch.Tensor, name: str) -> None:
 
 
 def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of the current stream of the current device: what torch.cuda.current_stream().cuda_stream returns, without building
+    # the Python Stream object (11 us per call, eleven calls per drop-in training step)
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

@@ -92,7 +92,7 @@ class _MLPFusedFn(torch.autograd.Function):
         M, dev = x.shape[0], x.device
         packed, packed_t, key = _MLPFusedFn._packed(params[0::2])
         outs = [torch.empty((M, w.shape[0]), dtype=torch.float32, device=dev) for w in ws]
-        masks = ops.mlp_signmask_alloc(M, L - 1, dev) + [None]
+        masks = ops.mlp_signmask_alloc(M, L - 1, dev, zero=False) + [None]
         ops.mlp_fwd(x, ws, bs, outs, slope, packed=packed, signmasks=masks)
         ctx.slope, ctx.L = slope, L
         ctx.pack_key = key

@@ -314,11 +314,14 @@ def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional
     return ws
 
 
-def mlp_signmask_alloc(M: int, n_layers: int, device) -> list:
-    """Per-layer opaque sign-bit buffers for mlp_fwd(signmasks=...) / mlp_dgrad_chain(masks_chain=...)."""
+def mlp_signmask_alloc(M: int, n_layers: int, device, zero: bool = True) -> list:
+    """Per-layer opaque sign-bit buffers for mlp_fwd(signmasks=...) / mlp_dgrad_chain(masks_chain=...).  The forward writes every
+    word of a buffer it is given (all waves and lanes of every workgroup), so `zero=False` (no fill launches) is safe for a buffer
+    that goes straight into a forward call."""
     nbytes = C.c_size_t()
     check(load().clica_mlp_signmask_bytes(int(M), C.byref(nbytes)), "clica_mlp_signmask_bytes")
-    return [torch.zeros(nbytes.value // 8, dtype=torch.int64, device=device) for _ in range(n_layers)]
+    mk = torch.zeros if zero else torch.empty
+    return [mk(nbytes.value // 8, dtype=torch.int64, device=device) for _ in range(n_layers)]
 
 
 def mlp_fwd(x: torch.Tensor, weights, biases, outs, slope: float = 0.01, packed: Optional[torch.Tensor] = None,
