@@ -64,6 +64,18 @@ class _MLPFusedFn(torch.autograd.Function):
     <= 512 (``ops.mlp_fwd_fusable``) and the batch is large enough to fill the chip (see ``_use_fused``)."""
 
     _pack_cache = {}      # device -> dict(key, shapes, packed, packed_t): fragment-order copies of the CURRENT weights
+    _ws_cache = {}        # (device, rows, shapes) -> split-K slab workspace of the grouped weight-gradient launch (reused: every call
+                          #   runs on the caller's stream, in order; allocating it per call was a 30 MB memset per backward)
+
+    @staticmethod
+    def _wgrad_ws(dev, M, shapes):
+        key = (dev, M, tuple(shapes))
+        ws = _MLPFusedFn._ws_cache.get(key)
+        if ws is None:
+            if len(_MLPFusedFn._ws_cache) > 8:
+                _MLPFusedFn._ws_cache.clear()
+            ws = _MLPFusedFn._ws_cache[key] = ops.mlp_wgrad_workspace(M, shapes, dev)
+        return ws
 
     @staticmethod
     def _weights_key(ws):
@@ -96,6 +108,7 @@ class _MLPFusedFn(torch.autograd.Function):
         ops.mlp_fwd(x, ws, bs, outs, slope, packed=packed, signmasks=masks)
         ctx.slope, ctx.L = slope, L
         ctx.pack_key = key
+        ctx.params = params            # the leaf Parameters (for the in-place gradient accumulation of the flat optimizer, see backward)
         ctx.save_for_backward(x, *outs[:-1], *[m for m in masks[:-1]], *ws)
         return outs[-1]
 
@@ -120,12 +133,27 @@ class _MLPFusedFn(torch.autograd.Function):
         dz_of = {l - 1: dz[j] for j, l in enumerate(chain)}
         dz_of[L - 1] = gy
         need = ctx.needs_input_grad
-        dWs = [torch.empty_like(w) for w in ws]
-        dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) if need[3 + 2 * l] else None for l, w in enumerate(ws)]
-        ops.mlp_wgrad([dz_of[l] for l in range(L)], [acts[l - 1] if l > 0 else x for l in range(L)], dWs, dbs)
-        grads = []
-        for l in range(L):
-            grads += [dWs[l] if need[2 + 2 * l] else None, dbs[l]]
+        # cl_ica_amd.optim.Adam keeps every .grad as a view into its (zeroed) gradient arena: add dW / db into those views here
+        # (one grouped launch, accumulate) and return None -- autograd then neither allocates fourteen gradient tensors per
+        # encoder call nor launches an AccumulateGrad add per parameter (what Megatron's main_grad accumulation does)
+        prm = ctx.params
+
+        def arena_view(q):
+            v = getattr(q, "_clica_grad_view", None)
+            return v is not None and q.grad is not None and q.grad.data_ptr() == v.data_ptr() and q.grad.is_contiguous()
+        in_place = all(need[2:]) and all(arena_view(q) for q in prm)
+        wws = _MLPFusedFn._wgrad_ws(dev, M, [tuple(w.shape) for w in ws])
+        if in_place:
+            ops.mlp_wgrad([dz_of[l] for l in range(L)], [acts[l - 1] if l > 0 else x for l in range(L)],
+                          [prm[2 * l].grad for l in range(L)], [prm[2 * l + 1].grad for l in range(L)], ws=wws, accumulate=True)
+            grads = [None] * (2 * L)
+        else:
+            dWs = [torch.empty_like(w) for w in ws]
+            dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) if need[3 + 2 * l] else None for l, w in enumerate(ws)]
+            ops.mlp_wgrad([dz_of[l] for l in range(L)], [acts[l - 1] if l > 0 else x for l in range(L)], dWs, dbs, ws=wws)
+            grads = []
+            for l in range(L):
+                grads += [dWs[l] if need[2 + 2 * l] else None, dbs[l]]
         dx = ops.linear_dgrad(dz_of[0], ws[0], None, slope) if need[0] else None
         return (dx, None, *grads)
 

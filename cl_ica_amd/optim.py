@@ -49,6 +49,9 @@ class Adam:
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)
+            # the drop-in encoder's backward (encoders._MLPFusedFn) adds its dW / db straight into this view (and hands autograd
+            # None) when it finds it installed: no per-parameter gradient tensors, no AccumulateGrad launches
+            p._clica_grad_view = p.grad
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
@@ -59,6 +62,7 @@ class Adam:
         for p, off in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * off:
                 p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)      # someone set it to None / replaced it
+                p._clica_grad_view = p.grad
 
     def all_reduce_grads(self):
         """Data parallel: sum the gradient arena over the ranks (the 1/world average is applied inside ``step``)."""
@@ -79,6 +83,7 @@ class Adam:
             else:
                 continue
             p.grad = view
+            p._clica_grad_view = view
 
     def step(self, closure=None):
         """One launch over the whole arena.  Differences from ``torch.optim.Adam`` (none of the reference's drivers can

@@ -332,3 +332,33 @@ def test_device_time_stamps_inside_a_graph():
     iv = ops.stamp_intervals_us(slot)
     assert int(slot[0].item()) == 6 and len(iv) == 4
     assert all(20.0 < v < 20000.0 for v in iv), iv
+
+
+def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
+    """The reference's train_step structure (two encoder calls per step, main_mlp.py:258-285) on the drop-in modules with
+    cl_ica_amd.optim.Adam: the fused encoder backward adds dW / db straight into the optimizer's gradient arena (autograd gets
+    None).  Three steps against the same loop with torch.optim.Adam (ordinary autograd accumulation): parameters agree."""
+    from cl_ica_amd import encoders, losses, optim
+    monkeypatch.setenv("CLICA_DROPIN_FUSED", "1")
+    n, B = 10, 1536
+    loss = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
+    outs = {}
+    for kind in ("flat", "torch"):
+        torch.manual_seed(3)
+        f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 10]).to("cuda")
+        opt = optim.Adam(f.parameters(), lr=1e-3) if kind == "flat" else torch.optim.Adam(f.parameters(), lr=1e-3)
+        g = torch.Generator(device="cuda").manual_seed(11)
+        for _ in range(3):
+            z1 = torch.rand(B, n, device="cuda", generator=g); z2 = (z1 + 0.05 * torch.randn(B, n, device="cuda", generator=g)).clamp(0, 1)
+            opt.zero_grad()
+            a, b = f(z1), f(z2)
+            tot, _, _ = loss(z1, z2, torch.roll(z1, 1, 0), a, b, torch.roll(a, 1, 0))
+            tot.backward()
+            if kind == "flat":
+                assert all(p.grad.data_ptr() == p._clica_grad_view.data_ptr() for p in f.parameters())
+            opt.step()
+        outs[kind] = [p.detach().clone() for p in f.parameters()] + [tot.detach().clone()]
+    # (two Adam implementations, three steps at lr = 1e-3: rounding-level gradient differences move an element by << lr)
+    for a, b in zip(outs["flat"][:-1], outs["torch"][:-1]):
+        assert float((a - b).abs().max()) <= 1e-4, float((a - b).abs().max())      # 10 % of lr: an element whose gradient is at rounding level
+    assert abs(float(outs["flat"][-1]) - float(outs["torch"][-1])) <= 1e-5 * abs(float(outs["torch"][-1]))
