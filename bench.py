@@ -475,7 +475,11 @@ def dropin_leg(args, device, steps=40, warmup=8):
         el = time.perf_counter() - t0
         res[name] = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "final_loss": lv}
     fused = encoders._use_fused([m for m in f if isinstance(m, torch.nn.Linear)], B)
-    res["encoder_path"] = ("whole-encoder kernels (clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad)" if fused else
+    lin_ = [m for m in f if isinstance(m, torch.nn.Linear)]
+    res["encoder_path"] = (("whole-encoder kernels in the split-bf16 arithmetic (clica_mlp_fwd_split / clica_mlp_dgrad_split / "
+                            "clica_mlp_wgrad_split; weight gradients added into the flat optimizer's gradient arena in place)"
+                            if encoders._dropin_split(lin_) else
+                            "whole-encoder kernels (clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad)") if fused else
                            "per-layer GEMM kernels (clica_linear_*): a %d-row encoder call is %d workgroups of 48 rows, below the 128 the "
                            "whole-encoder kernels need to beat them" % (B, (B + 47) // 48))
     res["what"] = ("reference train_step structure (main_mlp.py:258-285: two encoder calls of B rows, 3 host syncs per step, eager "

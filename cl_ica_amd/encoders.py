@@ -158,6 +158,115 @@ class _MLPFusedFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class _MLPFusedSplitFn(torch.autograd.Function):
+    """``_MLPFusedFn`` in the split-bf16 arithmetic the training engine uses by default (fp32 results from six bf16 products of
+    exact 3-way operand splits: csrc/fused_mlp.hip mlp_split_k, csrc/wgrad_split.hip): forward stack, backward data chain and the
+    grouped weight gradients, with hidden activations / dZ handed from kernel to kernel as bf16 planes where a matrix-core weight
+    gradient is their only reader.  ``CLICA_SPLIT_BF16=0`` / ``CLICA_DROPIN_SPLIT=0`` keep the fp32-MFMA kernels."""
+
+    _pack_cache = {}
+    _ws_cache = {}
+
+    @staticmethod
+    def _packed(params_w):
+        key = _MLPFusedFn._weights_key(params_w)
+        dev = params_w[0].device
+        c = _MLPFusedSplitFn._pack_cache.get(dev)
+        if c is not None and c["key"] == key:
+            return c["packed"], c["packed_t"], key
+        shapes = [tuple(w.shape) for w in params_w]
+        reuse = c is not None and c["shapes"] == shapes
+        packed, packed_t = ops.mlp_pack_split_both([w.detach() for w in params_w], c["packed"] if reuse else None, c["packed_t"] if reuse else None)
+        _MLPFusedSplitFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t)
+        return packed, packed_t, key
+
+    @staticmethod
+    def _wgrad_ws(dev, M, shapes):
+        key = (dev, M, tuple(shapes))
+        ws = _MLPFusedSplitFn._ws_cache.get(key)
+        if ws is None:
+            if len(_MLPFusedSplitFn._ws_cache) > 8:
+                _MLPFusedSplitFn._ws_cache.clear()
+            ws = _MLPFusedSplitFn._ws_cache[key] = ops.mlp_wgrad_split_workspace(M, shapes, dev)
+        return ws
+
+    @staticmethod
+    def forward(ctx, x, slope, *params):
+        L = len(params) // 2
+        ws, bs = [p.detach() for p in params[0::2]], [p.detach() for p in params[1::2]]
+        x = x.detach()
+        M, dev = x.shape[0], x.device
+        packed, _, key = _MLPFusedSplitFn._packed(params[0::2])
+        kinds = [ops.mlp_wgrad_split_kind(w.shape[0], w.shape[1]) for w in ws]       # 0: matrix-core weight gradient from planes
+        # layer l's output: as planes (with the ones column) if the NEXT layer's weight gradient reads planes, as fp32 if it reads
+        # fp32 (tiny-dimension layer) or if it is the result
+        planes = [ops.mlp_planes_alloc(M, ws[l].shape[0], True, dev) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
+        outs = [torch.empty((M, ws[l].shape[0]), dtype=torch.float32, device=dev) if (l == L - 1 or kinds[l + 1] == 1) else None
+                for l in range(L)]
+        masks = ops.mlp_signmask_alloc(M, L - 1, dev, zero=False) + [None]
+        ops.mlp_fwd_split(x, ws, bs, outs, packed, slope, signmasks=masks, planes=planes)
+        ctx.slope, ctx.L, ctx.kinds = slope, L, kinds
+        ctx.pack_key = key
+        ctx.params = params
+        ctx.save_for_backward(x, *outs[:-1], *planes[:-1], *masks[:-1], *ws)
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, gy):
+        L, slope, kinds = ctx.L, ctx.slope, ctx.kinds
+        sv = ctx.saved_tensors
+        x = sv[0]
+        acts, planes, masks, ws = list(sv[1:L]), list(sv[L:2 * L - 1]), list(sv[2 * L - 1:3 * L - 2]), list(sv[3 * L - 2:])
+        gy = gy.contiguous()
+        M, dev = gy.shape[0], gy.device
+        need = ctx.needs_input_grad
+        cur = _MLPFusedSplitFn._pack_cache.get(dev)
+        if cur is not None and cur["key"] == ctx.pack_key:
+            packed_t = cur["packed_t"]
+        else:
+            _, packed_t = ops.mlp_pack_split_both(ws)
+        chain = list(range(L - 1, 0, -1))
+        # dZ of layer j = l - 1: planes for a matrix-core weight gradient, fp32 for a tiny-dimension one (and for d loss / d input)
+        want_f32 = {j: (kinds[j] == 1 or (j == 0 and need[0])) for j in range(L - 1)}
+        dz_f32 = {j: (torch.empty((M, ws[j].shape[0]), dtype=torch.float32, device=dev) if want_f32[j] else None) for j in range(L - 1)}
+        dz_pl = {j: (ops.mlp_planes_alloc(M, ws[j].shape[0], False, dev) if kinds[j] == 0 else None) for j in range(L - 1)}
+        if L > 1:
+            ops.mlp_dgrad_chain_split(gy, [ws[l] for l in chain], packed_t, [dz_f32[l - 1] for l in chain], slope,
+                                      masks_chain=[masks[l - 1] for l in chain], planes=[dz_pl[l - 1] for l in chain])
+        dz_f32[L - 1] = gy
+        dz_pl[L - 1] = ops.mlp_planes_from_f32(gy, False) if kinds[L - 1] == 0 else None
+        xin_f32 = [x] + acts                                   # fp32 input of layer l (None where only planes were written)
+        xin_pl = [ops.mlp_planes_from_f32(x, True) if kinds[0] == 0 else None] + planes
+        prm = ctx.params
+
+        def arena_view(q):
+            v = getattr(q, "_clica_grad_view", None)
+            return v is not None and q.grad is not None and q.grad.data_ptr() == v.data_ptr() and q.grad.is_contiguous()
+        in_place = all(need[2:]) and all(arena_view(q) for q in prm)
+        if in_place:
+            dWs, dbs, acc = [prm[2 * l].grad for l in range(L)], [prm[2 * l + 1].grad for l in range(L)], True
+        else:
+            dWs = [torch.empty_like(w) for w in ws]
+            dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in ws]
+            acc = False
+        ops.mlp_wgrad_split(M, [dz_pl[l] for l in range(L)], [xin_pl[l] if kinds[l] == 0 else None for l in range(L)],
+                            [dz_f32[l] if kinds[l] == 1 else None for l in range(L)], [xin_f32[l] if kinds[l] == 1 else None for l in range(L)],
+                            dWs, dbs, ws=_MLPFusedSplitFn._wgrad_ws(dev, M, [tuple(w.shape) for w in ws]), accumulate=acc)
+        grads = [None] * (2 * L)
+        if not in_place:
+            for l in range(L):
+                grads[2 * l] = dWs[l] if need[2 + 2 * l] else None
+                grads[2 * l + 1] = dbs[l] if need[3 + 2 * l] else None
+        dx = ops.linear_dgrad(dz_f32[0], ws[0], None, slope) if need[0] else None
+        return (dx, None, *grads)
+
+
+def _dropin_split(linears) -> bool:
+    import os
+    fits = sum((lin.out_features + 31) // 32 * 32 for lin in linears) <= 3456        # on-chip bias table of mlp_split_k (fused_mlp.hip)
+    return fits and os.environ.get("CLICA_SPLIT_BF16", "1") != "0" and os.environ.get("CLICA_DROPIN_SPLIT", "1") != "0"
+
+
 def _use_fused(linears, M: int) -> bool:
     """Whole-encoder kernels for the autograd path?  They own 48 rows per workgroup for the whole stack, so they want
     half of the 256 CUs busy (measured at 128 workgroups = one B = 6144 encoder call of the reference's train_step: 645 against
@@ -184,7 +293,7 @@ class FusedMLP(nn.Sequential):
         params = []
         for lin in linears:
             params += [lin.weight, lin.bias]
-        fn = _MLPFusedFn if _use_fused(linears, x.shape[0]) else _MLPStackFn
+        fn = (_MLPFusedSplitFn if _dropin_split(linears) else _MLPFusedFn) if _use_fused(linears, x.shape[0]) else _MLPStackFn
         y = fn.apply(x, slope, *params)
         for m in mods:
             if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
