@@ -132,6 +132,15 @@ class ContrastiveTrainer:
         self.wgrad_halves = bool(self.dp and self.fused_backward and self.grouped_wgrad and L >= 4
                                  and os.environ.get("CLICA_WGRAD_HALVES", "1") != "0")
         self._half = L // 2
+        if self.wgrad_halves and self.group_ws is not None:
+            # each half's launch plans its own contraction splits (fewer tiles -> more splits per layer -> larger slabs than in the
+            # all-layer plan the workspace was sized for: 59.3 MB against 58.5 MB for the n = 10 stack at B = 6144)
+            shapes = [tuple(lin.weight.shape) for lin in self.linears]
+            mk = ops.mlp_wgrad_split_workspace if self.split_wgrad else ops.mlp_wgrad_workspace
+            for part in (shapes[self._half:], shapes[:self._half]):
+                w = mk(2 * self.B, part, self.device)
+                if w.numel() > self.group_ws.numel():
+                    self.group_ws = w
         self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes, force=self.dp,
                                    boundaries=(L - 1 - self._half,) if self.wgrad_halves else ()) if self.dp else None
 

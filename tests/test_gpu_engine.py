@@ -196,6 +196,27 @@ def test_dp_code_path_single_rank():
             torch.cuda.synchronize()
             res.append((o, tr.param_arena.clone()))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        # the headline architecture at the full batch: the grouped weight gradients go out in two halves under data parallelism and
+        # each half's launch plans its own contraction splits -- its slabs must fit the workspace (they did not: 59.3 MB against the
+        # 58.5 MB of the all-layer plan; found by tools/dp_bench_smoke.sh, not by the smaller two-rank tests)
+        torch.manual_seed(0)
+        f = encoders.get_mlp(10, 10, [100, 500, 500, 500, 500, 100])
+        tr = ContrastiveTrainer(f, torch.eye(10).repeat(3, 1, 1), SamplerSpec(n=10, seed=5), batch_size=6144, p=2, lr=1e-3,
+                                device="cuda", process_group=dist.group.WORLD, force_collectives=True)
+        assert tr.wgrad_halves
+        ref = None
+        for _ in range(3):
+            o = tr.step().clone()
+        torch.cuda.synchronize()
+        torch.manual_seed(0)
+        f2 = encoders.get_mlp(10, 10, [100, 500, 500, 500, 500, 100])
+        tr2 = ContrastiveTrainer(f2, torch.eye(10).repeat(3, 1, 1), SamplerSpec(n=10, seed=5), batch_size=6144, p=2, lr=1e-3, device="cuda")
+        for _ in range(3):
+            o2 = tr2.step().clone()
+        # (a collapsed random encoder: the gradients are at rounding level, so Adam moves an element by up to +-lr per step whichever
+        #  summation order produced it -- the loss is what is compared; the parameters only have to stay within 3 steps x lr)
+        assert float((o - o2).abs().max()) <= 1e-5 * float(o2.abs().max())
+        assert float((tr.param_arena - tr2.param_arena).abs().max()) <= 3.1e-3 and bool(torch.isfinite(tr.param_arena).all())
     finally:
         dist.destroy_process_group()
 
