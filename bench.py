@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each; the median window is reported")
-    ap.add_argument("--n", type=int, default=10)
+    ap.add_argument("--n", "--latent-dim", dest="n", type=int, default=10)
     ap.add_argument("--batch-size", type=int, default=6144)
     ap.add_argument("--p", type=int, default=2)
     ap.add_argument("--space-type", default="box", choices=("box", "sphere"))
