@@ -221,6 +221,53 @@ __device__ __forceinline__ void dist_group(const f32x2 (&o)[NP / 2], const float
   for (int c = 0; c < JBT; ++c) acc[c] = a2[c].x + a2[c].y;
 }
 
+// The same, KEEPING the coordinate differences d = o - s of the JBT pairs in registers for the gradient pass of the backward sweep
+// (difference-based kinds 1, 2, 3 only): the second pass then neither re-reads the stream rows from LDS nor repeats the packed
+// subtraction -- 5 of the ~42 vector instructions per pair at n = 10.  2 * JBT * NQ more registers: narrow layouts only.
+template <int NP, int PK, int NQ = NP / 2, int JBT = JB>
+__device__ __forceinline__ void dist_group_keep(const f32x2 (&o)[NP / 2], const float* tile, int jj, float (&acc)[JBT], f32x2 (&d)[JBT][NQ]) {
+  static_assert(PK >= 1 && PK <= 3, "difference-based pair kinds");
+  f32x2 a2[JBT];
+#pragma unroll
+  for (int c = 0; c < JBT; ++c) a2[c] = (f32x2){0.f, 0.f};
+#pragma unroll
+  for (int k4 = 0; k4 < NP / 4; ++k4) {
+#pragma unroll
+    for (int c = 0; c < JBT; ++c) {
+      const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        const int k2 = 2 * k4 + h2;
+        if (k2 < NQ) {
+          const f32x2 dd = o[k2] - (h2 ? (f32x2){sv.z, sv.w} : (f32x2){sv.x, sv.y});
+          d[c][k2] = dd;
+          if constexpr (PK == 2) a2[c] = __builtin_elementwise_fma(dd, dd, a2[c]);
+          else if constexpr (PK == 1) { a2[c].x += fabsf(dd.x); a2[c].y += fabsf(dd.y); }
+          else { const f32x2 t = dd * dd; a2[c].x = fmaf(fabsf(dd.x), t.x, a2[c].x); a2[c].y = fmaf(fabsf(dd.y), t.y, a2[c].y); }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < JBT; ++c) acc[c] = a2[c].x + a2[c].y;
+}
+// g += coef * (1/p) d term / d owner from the kept difference (same arithmetic as gaccum2 behind its subtraction)
+template <int PK>
+__device__ __forceinline__ void gaccum2_d(f32x2& g, float coef, f32x2 d) {
+  const f32x2 c2 = {coef, coef};
+  if constexpr (PK == 2) {
+    g = __builtin_elementwise_fma(c2, d, g);
+  } else if constexpr (PK == 1) {
+    const f32x2 big = {0x1p126f, 0x1p126f};
+    f32x2 t = d * big;
+    t.x = __builtin_amdgcn_fmed3f(t.x, -1.f, 1.f); t.y = __builtin_amdgcn_fmed3f(t.y, -1.f, 1.f);
+    g = __builtin_elementwise_fma(c2, t, g);
+  } else {
+    const f32x2 t = {d.x * fabsf(d.x), d.y * fabsf(d.y)};
+    g = __builtin_elementwise_fma(c2, t, g);
+  }
+}
+
 // ---- forward: per-split (max, sum) partials in the log2 domain -----------------------------
 // ROWGRAD: also accumulate G_k = sum_j 2^(x_ij - m) * p * droot * (1/p) d term / d owner_k with the same
 // running-max rescaling (the flash-attention forward with "V" = the pair's distance derivative).  After
@@ -451,8 +498,11 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     for (int jj = 0; jj < cq; jj += JBW) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
+        constexpr bool KEEPD = NP <= 16 && PK >= 1 && PK <= 3;      // (n = 40 is at 255 registers already: keeping 80 more spills)
         float acc[JBW];
-        dist_group<NP, PK, NQ, JBW>(o[r], tile, jj, q, acc);
+        f32x2 dk[JBW][KEEPD ? NQ : 1];
+        if constexpr (KEEPD) dist_group_keep<NP, PK, NQ, JBW>(o[r], tile, jj, acc, dk);
+        else dist_group<NP, PK, NQ, JBW>(o[r], tile, jj, q, acc);
         float coef[JBW];
 #pragma unroll
         for (int c = 0; c < JBW; ++c) {
@@ -464,14 +514,21 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
           if (OWNER_STATS && jj + c >= cq) cf = 0.f;
           coef[c] = cf;
         }
-        asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
+        if constexpr (KEEPD) {           // narrow rows: the differences of the JBW pairs are still in registers
 #pragma unroll
-        for (int k4 = 0; k4 < NP / 4; ++k4) {
+          for (int k2 = 0; k2 < NQ; ++k2)
 #pragma unroll
-          for (int c = 0; c < JBW; ++c) {
-            const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
-            if (2 * k4 < NQ) gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
-            if (2 * k4 + 1 < NQ) gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
+            for (int c = 0; c < JBW; ++c) gaccum2_d<PK>(g[r][k2], coef[c], dk[c][k2]);
+        } else {
+          asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
+#pragma unroll
+          for (int k4 = 0; k4 < NP / 4; ++k4) {
+#pragma unroll
+            for (int c = 0; c < JBW; ++c) {
+              const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
+              if (2 * k4 < NQ) gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
+              if (2 * k4 + 1 < NQ) gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
+            }
           }
         }
       }
