@@ -495,17 +495,24 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     const float* tC = tCs[cur] + pq * RPP;
     const int cq = min(RPP, max(0, cnt - pq * RPP));
     // (a tail-mask-free copy of this loop for full partitions, as in the forward, was measured 4 % SLOWER here: not kept)
-    for (int jj = 0; jj < cq; jj += JBW) {
+#ifndef CLICA_LP_KEEPD_WIDE
+#define CLICA_LP_KEEPD_WIDE 1
+#endif
+    // keep the coordinate differences for the gradient pass (dist_group_keep): narrow rows with JBW pairs in flight; wider rows
+    // (n = 40 sits at 255 registers with two pairs in flight) with ONE pair in flight -- measured 337 -> 243 us for the n = 40
+    // symmetric sweep: the gradient pass's LDS re-read + second subtraction cost far more than the second pair in flight hid
+    constexpr bool KEEPD = PK >= 1 && PK <= 3 && (NP <= 16 || (CLICA_LP_KEEPD_WIDE && NP <= 40));
+    constexpr int JW = (KEEPD && NP > 16) ? 1 : JBW;
+    for (int jj = 0; jj < cq; jj += JW) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        constexpr bool KEEPD = NP <= 16 && PK >= 1 && PK <= 3;      // (n = 40 is at 255 registers already: keeping 80 more spills)
-        float acc[JBW];
-        f32x2 dk[JBW][KEEPD ? NQ : 1];
-        if constexpr (KEEPD) dist_group_keep<NP, PK, NQ, JBW>(o[r], tile, jj, acc, dk);
-        else dist_group<NP, PK, NQ, JBW>(o[r], tile, jj, q, acc);
-        float coef[JBW];
+        float acc[JW];
+        f32x2 dk[JW][KEEPD ? NQ : 1];
+        if constexpr (KEEPD) dist_group_keep<NP, PK, NQ, JW>(o[r], tile, jj, acc, dk);
+        else dist_group<NP, PK, NQ, JW>(o[r], tile, jj, q, acc);
+        float coef[JW];
 #pragma unroll
-        for (int c = 0; c < JBW; ++c) {
+        for (int c = 0; c < JW; ++c) {
           const float x = root_of<ROOT>(acc[c], q) * xk;
           float w = 0.f;
           if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
@@ -514,17 +521,17 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
           if (OWNER_STATS && jj + c >= cq) cf = 0.f;
           coef[c] = cf;
         }
-        if constexpr (KEEPD) {           // narrow rows: the differences of the JBW pairs are still in registers
+        if constexpr (KEEPD) {           // narrow rows: the differences of the JW pairs are still in registers
 #pragma unroll
           for (int k2 = 0; k2 < NQ; ++k2)
 #pragma unroll
-            for (int c = 0; c < JBW; ++c) gaccum2_d<PK>(g[r][k2], coef[c], dk[c][k2]);
+            for (int c = 0; c < JW; ++c) gaccum2_d<PK>(g[r][k2], coef[c], dk[c][k2]);
         } else {
           asm volatile("" ::: "memory");   // re-read the tile for the second sweep instead of keeping it in VGPRs
 #pragma unroll
           for (int k4 = 0; k4 < NP / 4; ++k4) {
 #pragma unroll
-            for (int c = 0; c < JBW; ++c) {
+            for (int c = 0; c < JW; ++c) {
               const float4 sv = *reinterpret_cast<const float4*>(&tile[(jj + c) * NP + 4 * k4]);
               if (2 * k4 < NQ) gaccum2<PK>(g[r][2 * k4], coef[c], o[r][2 * k4], (f32x2){sv.x, sv.y}, q, 4 * k4);
               if (2 * k4 + 1 < NQ) gaccum2<PK>(g[r][2 * k4 + 1], coef[c], o[r][2 * k4 + 1], (f32x2){sv.z, sv.w}, q, 4 * k4 + 2);
