@@ -81,6 +81,15 @@ __device__ __forceinline__ float flog2(float x) { return __builtin_amdgcn_logf(x
 //     4 = dot product (SimCLRLoss, losses.py:187): term = o*s, d/do = s
 constexpr int PK_DOT = 4;
 
+// acc + |d| as ONE instruction (the source-modifier form of v_add_f32).  Written out because the compiler prefers to clear the sign
+// bits with v_and_b32 (one slot per element) and add the pair with v_pk_add_f32 (half a slot): 1.5 slots per element instead of
+// 1 -- 40 of the ~175 issue slots per pair of the n = 40, p = 1 forward sweep.
+__device__ __forceinline__ float add_abs(float acc, float d) {
+  float r;
+  asm("v_add_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(acc), "v"(d));
+  return r;
+}
+
 // acc += term(o, s) for two adjacent coordinates (k, k+1); packed fp32 math where the ISA has it
 // (v_pk_add_f32 / v_pk_fma_f32: two lanes of work per issue slot)
 template <int PK>
@@ -92,7 +101,7 @@ __device__ __forceinline__ void accum2(f32x2& acc, f32x2 o, f32x2 s, const Param
     acc = __builtin_elementwise_fma(d, d, acc);
   } else if constexpr (PK == 1) {
     const f32x2 d = o - s;
-    acc.x += fabsf(d.x); acc.y += fabsf(d.y);
+    acc.x = add_abs(acc.x, d.x); acc.y = add_abs(acc.y, d.y);
   } else if constexpr (PK == 3) {
     const f32x2 d = o - s, t = d * d;
     acc.x = fmaf(fabsf(d.x), t.x, acc.x); acc.y = fmaf(fabsf(d.y), t.y, acc.y);
@@ -242,7 +251,7 @@ __device__ __forceinline__ void dist_group_keep(const f32x2 (&o)[NP / 2], const 
           const f32x2 dd = o[k2] - (h2 ? (f32x2){sv.z, sv.w} : (f32x2){sv.x, sv.y});
           d[c][k2] = dd;
           if constexpr (PK == 2) a2[c] = __builtin_elementwise_fma(dd, dd, a2[c]);
-          else if constexpr (PK == 1) { a2[c].x += fabsf(dd.x); a2[c].y += fabsf(dd.y); }
+          else if constexpr (PK == 1) { a2[c].x = add_abs(a2[c].x, dd.x); a2[c].y = add_abs(a2[c].y, dd.y); }
           else { const f32x2 t = dd * dd; a2[c].x = fmaf(fabsf(dd.x), t.x, a2[c].x); a2[c].y = fmaf(fabsf(dd.y), t.y, a2[c].y); }
         }
       }
