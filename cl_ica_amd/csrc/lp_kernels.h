@@ -507,11 +507,11 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
 #ifndef CLICA_LP_KEEPD_WIDE
 #define CLICA_LP_KEEPD_WIDE 1
 #endif
-    // keep the coordinate differences for the gradient pass (dist_group_keep): narrow rows with JBW pairs in flight; wider rows
-    // (n = 40 sits at 255 registers with two pairs in flight) with ONE pair in flight -- measured 337 -> 243 us for the n = 40
-    // symmetric sweep: the gradient pass's LDS re-read + second subtraction cost far more than the second pair in flight hid
+    // keep the coordinate differences for the gradient pass (dist_group_keep), ONE pair in flight (n = 40 sits at 255 registers with
+    // two) -- measured 337 -> 243 us for the n = 40 symmetric sweep: the gradient pass's LDS re-read + second subtraction cost far
+    // more than the second pair in flight hid
     constexpr bool KEEPD = PK >= 1 && PK <= 3 && (NP <= 16 || (CLICA_LP_KEEPD_WIDE && NP <= 40));
-    constexpr int JW = (KEEPD && NP > 16) ? 1 : JBW;
+    constexpr int JW = KEEPD ? 1 : JBW;      // (narrow rows with kept differences: 1 / 2 / 4 pairs in flight = 50.5 / 51.2 / 57.8 us at n = 10)
     for (int jj = 0; jj < cq; jj += JW) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
