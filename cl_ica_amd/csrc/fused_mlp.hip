@@ -946,7 +946,8 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
             const unsigned mk = bit < 32 ? ((unsigned)mbits >> bit) : ((unsigned)(mbits >> 32) >> (bit - 32));
             t = (mk & 1u) ? t : t * slope;
           }
-          if (ragged) t = (n0 + e >= N) ? 0.f : t;
+          // (no column mask here: features >= N have all-zero fragment-order weights and a zero-padded bias row, so their
+          //  accumulators and activations ARE zero -- the generic epilogue's explicit mask cost two selects per value)
           if (BITS) {      // shifted in from the right (inline constants only; `1u << bit` selects cost one VGPR per constant)
             if (bit < 32) lo = (lo << 1) | (unsigned)(t > 0.f); else hi = (hi << 1) | (unsigned)(t > 0.f);
           }
