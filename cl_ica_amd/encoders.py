@@ -141,7 +141,7 @@ class _MLPFusedFn(torch.autograd.Function):
         def arena_view(q):
             v = getattr(q, "_clica_grad_view", None)
             return v is not None and q.grad is not None and q.grad.data_ptr() == v.data_ptr() and q.grad.is_contiguous()
-        in_place = all(need[2:]) and all(arena_view(q) for q in prm)
+        in_place = _inplace_grads() and all(need[2:]) and all(arena_view(q) for q in prm)
         wws = _MLPFusedFn._wgrad_ws(dev, M, [tuple(w.shape) for w in ws])
         if in_place:
             ops.mlp_wgrad([dz_of[l] for l in range(L)], [acts[l - 1] if l > 0 else x for l in range(L)],
@@ -242,7 +242,7 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         def arena_view(q):
             v = getattr(q, "_clica_grad_view", None)
             return v is not None and q.grad is not None and q.grad.data_ptr() == v.data_ptr() and q.grad.is_contiguous()
-        in_place = all(need[2:]) and all(arena_view(q) for q in prm)
+        in_place = _inplace_grads() and all(need[2:]) and all(arena_view(q) for q in prm)
         if in_place:
             dWs, dbs, acc = [prm[2 * l].grad for l in range(L)], [prm[2 * l + 1].grad for l in range(L)], True
         else:
@@ -265,6 +265,14 @@ def _dropin_split(linears) -> bool:
     import os
     fits = sum((lin.out_features + 31) // 32 * 32 for lin in linears) <= 3456        # on-chip bias table of mlp_split_k (fused_mlp.hip)
     return fits and os.environ.get("CLICA_SPLIT_BF16", "1") != "0" and os.environ.get("CLICA_DROPIN_SPLIT", "1") != "0"
+
+
+def _inplace_grads() -> bool:
+    """Add the encoder's weight gradients straight into the flat optimizer's `.grad` views (and hand autograd None)?  Right for
+    `loss.backward()`, which is all the reference's drivers do; `torch.autograd.grad(loss, params)` on such parameters would see
+    None -- set CLICA_DROPIN_INPLACE_GRAD=0 for that."""
+    import os
+    return os.environ.get("CLICA_DROPIN_INPLACE_GRAD", "1") != "0"
 
 
 def _use_fused(linears, M: int) -> bool:
