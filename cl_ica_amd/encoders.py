@@ -138,10 +138,7 @@ class _MLPFusedFn(torch.autograd.Function):
         # encoder call nor launches an AccumulateGrad add per parameter (what Megatron's main_grad accumulation does)
         prm = ctx.params
 
-        def arena_view(q):
-            v = getattr(q, "_clica_grad_view", None)
-            return v is not None and q.grad is not None and q.grad.data_ptr() == v.data_ptr() and q.grad.is_contiguous()
-        in_place = _inplace_grads() and all(need[2:]) and all(arena_view(q) for q in prm)
+        in_place = _inplace_ok(prm, need)
         wws = _MLPFusedFn._wgrad_ws(dev, M, [tuple(w.shape) for w in ws])
         if in_place:
             ops.mlp_wgrad([dz_of[l] for l in range(L)], [acts[l - 1] if l > 0 else x for l in range(L)],
@@ -239,10 +236,7 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         xin_pl = [ops.mlp_planes_from_f32(x, True) if kinds[0] == 0 else None] + planes
         prm = ctx.params
 
-        def arena_view(q):
-            v = getattr(q, "_clica_grad_view", None)
-            return v is not None and q.grad is not None and q.grad.data_ptr() == v.data_ptr() and q.grad.is_contiguous()
-        in_place = _inplace_grads() and all(need[2:]) and all(arena_view(q) for q in prm)
+        in_place = _inplace_ok(prm, need)
         if in_place:
             dWs, dbs, acc = [prm[2 * l].grad for l in range(L)], [prm[2 * l + 1].grad for l in range(L)], True
         else:
@@ -268,11 +262,40 @@ def _dropin_split(linears) -> bool:
 
 
 def _inplace_grads() -> bool:
-    """Add the encoder's weight gradients straight into the flat optimizer's `.grad` views (and hand autograd None)?  Right for
-    `loss.backward()`, which is all the reference's drivers do; `torch.autograd.grad(loss, params)` on such parameters would see
-    None -- set CLICA_DROPIN_INPLACE_GRAD=0 for that."""
+    """Master switch of the in-place weight-gradient accumulation (`_inplace_ok`); CLICA_DROPIN_INPLACE_GRAD=0 turns it off."""
     import os
     return os.environ.get("CLICA_DROPIN_INPLACE_GRAD", "1") != "0"
+
+
+def _inplace_ok(prm, need) -> bool:
+    """May this backward add dW / db straight into the flat optimizer's `.grad` views and hand autograd None?
+
+    Only when that is indistinguishable from what autograd itself would do with the returned gradients:
+      * every parameter's `.grad` IS the view `cl_ica_amd.optim.Adam` installed into its gradient arena;
+      * this backward pass really accumulates into the leaves -- i.e. it is `loss.backward()`, not
+        `torch.autograd.grad(y, x)` / `autograd.functional.jacobian` (reference losses.py:279) / `backward(inputs=[...])`, in which
+        the parameters' AccumulateGrad nodes do not run: `ctx.needs_input_grad` cannot tell (it reflects `requires_grad` at
+        forward time), the engine's own execution plan can (`torch._C._will_engine_execute_node`);
+      * no tensor hook / post-accumulate-grad hook is registered on a parameter (they would never fire).
+    Otherwise the gradients are returned to autograd as ordinary tensors."""
+    if not (_inplace_grads() and all(need[2:])):
+        return False
+    for q in prm:
+        v = getattr(q, "_clica_grad_view", None)
+        if v is None or q.grad is None or q.grad.data_ptr() != v.data_ptr() or not q.grad.is_contiguous():
+            return False
+        if q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None):
+            return False
+    try:
+        for q in prm:
+            node = getattr(q, "_clica_acc_node", None)
+            if node is None:
+                node = q._clica_acc_node = torch.autograd.graph.get_gradient_edge(q).node     # the leaf's AccumulateGrad node
+            if not torch._C._will_engine_execute_node(node):
+                return False
+    except RuntimeError:          # autograd.grad(loss, params): the engine CAPTURES the leaf gradients -- they must be returned
+        return False
+    return True
 
 
 def _use_fused(linears, M: int) -> bool:

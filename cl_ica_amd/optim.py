@@ -66,7 +66,8 @@ class Adam:
 
     def all_reduce_grads(self):
         """Data parallel: sum the gradient arena over the ranks (the 1/world average is applied inside ``step``)."""
-        if self.world > 1:
+        self._adopt_foreign_grads()      # `model.zero_grad()` (set_to_none) makes autograd allocate .grad OUTSIDE the arena: bring
+        if self.world > 1:               # those back BEFORE the exchange, or the stale arena is what gets summed (ADVICE r3)
             dist.all_reduce(self.grad_arena, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _adopt_foreign_grads(self):
@@ -75,13 +76,14 @@ class Adam:
         reads the gradients autograd produced; a parameter that received no gradient this step contributes zeros."""
         base = self.grad_arena.data_ptr()
         for p, off in zip(self.params, self.offsets):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * off:
+                continue                                   # the installed view (the common case: no tensor is built for it)
             view = self.grad_arena[off:off + p.numel()].view(p.shape)
-            if p.grad is None:
+            if g is None:
                 view.zero_()
-            elif p.grad.data_ptr() != base + 4 * off:
-                view.copy_(p.grad)
             else:
-                continue
+                view.copy_(g)
             p.grad = view
             p._clica_grad_view = view
 
