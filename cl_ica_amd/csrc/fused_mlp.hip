@@ -691,10 +691,11 @@ __global__ __launch_bounds__(256) void mlp_pack3_k(Pack3Args a) {
 // registers and written once at the end of the kernel
 #ifdef CLICA_SPLIT_TRACE
 __device__ unsigned long long* g_strace = nullptr;
-#define ST_DECL unsigned long long st_ts[MAXL][4] = {}
+#define ST_NS 8
+#define ST_DECL unsigned long long st_ts[MAXL][ST_NS] = {}
 #define ST_STAMP(l, ph) do { st_ts[l][ph] = __builtin_readcyclecounter(); } while (0)
-#define ST_FLUSH(L) do { if (g_strace && lane == 0) { for (int l_ = 0; l_ < MAXL; ++l_) for (int q_ = 0; q_ < 4; ++q_) \
-      g_strace[(((size_t)blockIdx.x * WAVES + wave) * MAXL + l_) * 4 + q_] = st_ts[l_][q_]; } } while (0)
+#define ST_FLUSH(L) do { if (g_strace && lane == 0) { for (int l_ = 0; l_ < MAXL; ++l_) for (int q_ = 0; q_ < ST_NS; ++q_) \
+      g_strace[(((size_t)blockIdx.x * WAVES + wave) * MAXL + l_) * ST_NS + q_] = st_ts[l_][q_]; } } while (0)
 #else
 #define ST_DECL do { } while (0)
 #define ST_STAMP(l, ph) do { } while (0)
@@ -914,6 +915,21 @@ __device__ __forceinline__ void request_first_w3(const u32x4* __restrict__ w0, i
 __device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) {     // {a.hi16, b.hi16} -> one dword (a in the low half)
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
+// Round 4: rewritten around what one instruction can do for TWO values (ISA count: ~63 -> ~33 vector instructions per accumulator
+// block of four values): bias add, slope product and the first residual subtraction of the exact 3-way split as packed fp32
+// (v_pk_add_f32 / v_pk_mul_f32, the subtraction through the neg modifier); the bf16 pieces are cut out of the UNMASKED words by
+// the packing v_perm_b32 (only the subtrahends need the mask); the sign bit of a value enters its lane register as the carry of
+// v_addc_co_u32 (compare + add-with-carry instead of compare + select + shift-or); the backward gate is v_bfe_i32 (bit -> 0 / ~0)
+// + v_bfi_b32 (bitwise select of t and slope t) instead of and + compare + select; the constant-1 feature of the plane copy is
+// patched by a 2-byte store behind the block's own 8-byte store (same lane, program order) instead of four compare + select
+// pairs per block in the common path.  (Worth 1 % of the launch: the epilogue is not bound by its vector instructions, see DESIGN.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef CLICA_EPI_ABLATE
+#define CLICA_EPI_ABLATE 0      // measurement builds only (tools/ab.sh): 1 = no plane stores to HBM in the fast epilogues (WRONG results)
+#endif
+__device__ __forceinline__ void shift_in_positive(unsigned& bits, float t) {      // bits = 2 * bits + (t > 0)
+  asm("v_cmp_lt_f32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(t) : "vcc");
+}
 template <int ACT, bool BITS, bool PL, bool OUTV>
 __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW], unsigned short* planes, const float* bias_row, const float slope,
                                                     const unsigned long long mbits, const int N, const int ncb, const int wave, const int lane,
@@ -922,64 +938,85 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
                                                     unsigned& lo_bits, unsigned& hi_bits) {
   const int i15 = lane & 15, kg = lane >> 4;
   const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
+  const f32x2 slope2 = {slope, slope};
+  const int mlo = (int)(unsigned)mbits, mhi = (int)(unsigned)(mbits >> 32);
   unsigned lo = 0u, hi = 0u;
 #pragma unroll
   for (int c = 0; c < CBW; ++c) {
     const int cb = wave + c * WAVES;
     if (cb < ncb) {                                    // wave-uniform
       const int n0 = cb * 16 + kg * 4;
-      const bool ragged = cb * 16 + 16 > N;            // wave-uniform: the last real block and the k-padding blocks
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (ACT == 1) b4 = *reinterpret_cast<const f32x4*>(&bias_row[n0]);
+      f32x2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+      if (ACT == 1) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_row[n0]); b01 = (f32x2){b4[0], b4[1]}; b23 = (f32x2){b4[2], b4[3]}; }
       const unsigned pl_cb = (unsigned)((cb >> 1) * 3 * 1024 + (cb & 1) * 128) + pl_lane;
+      unsigned short* const dst0 = planes + i15 * LDPB + n0;
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
         const int row = r * 16 + i15;
-        f32x4 v = acc[r][c];
-        unsigned hb[4], mb[4], r2[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int bit = (c * RB + r) * 4 + e;        // compile time
-          float t = v[e];
-          if (ACT == 1) { t += b4[e]; t = fmaxf(t, t * slope); }
-          if (ACT == 2) {
-            const unsigned mk = bit < 32 ? ((unsigned)mbits >> bit) : ((unsigned)(mbits >> 32) >> (bit - 32));
-            t = (mk & 1u) ? t : t * slope;
-          }
-          // (no column mask here: features >= N have all-zero fragment-order weights and a zero-padded bias row, so their
-          //  accumulators and activations ARE zero -- the generic epilogue's explicit mask cost two selects per value)
-          if (BITS) {      // shifted in from the right (inline constants only; `1u << bit` selects cost one VGPR per constant)
-            if (bit < 32) lo = (lo << 1) | (unsigned)(t > 0.f); else hi = (hi << 1) | (unsigned)(t > 0.f);
-          }
-          v[e] = t;
-          hb[e] = __float_as_uint(t) & 0xFFFF0000u;                 // exact 3-way split by truncation: 4 ops per element,
-          const float r1 = t - __uint_as_float(hb[e]);               // the low piece is the high half of the second residual
-          mb[e] = __float_as_uint(r1) & 0xFFFF0000u;                 // (<= 8 significant bits: taking its top 16 bits is exact)
-          r2[e] = __float_as_uint(r1 - __uint_as_float(mb[e]));
+        const f32x4 v = acc[r][c];
+        f32x2 t[2] = {(f32x2){v[0], v[1]}, (f32x2){v[2], v[3]}};
+        if (ACT == 1) {
+          t[0] += b01; t[1] += b23;
+          const f32x2 s0 = t[0] * slope2, s1 = t[1] * slope2;
+          t[0] = (f32x2){fmaxf(t[0][0], s0[0]), fmaxf(t[0][1], s0[1])};
+          t[1] = (f32x2){fmaxf(t[1][0], s1[0]), fmaxf(t[1][1], s1[1])};
         }
-        const u32x2 ph = (u32x2){pack_hi(hb[0], hb[1]), pack_hi(hb[2], hb[3])};
-        const u32x2 pm = (u32x2){pack_hi(mb[0], mb[1]), pack_hi(mb[2], mb[3])};
-        const u32x2 pl = (u32x2){pack_hi(r2[0], r2[1]), pack_hi(r2[2], r2[3])};
-        unsigned short* dst = planes + row * LDPB + n0;
+        if (ACT == 2) {
+          const f32x2 s[2] = {t[0] * slope2, t[1] * slope2};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int bit = (c * RB + r) * 4 + e;      // compile time
+            // (inline asm: written as C the optimiser canonicalises the pair back into and + compare + select)
+            int sel; float tv = t[e >> 1][e & 1];
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(bit < 32 ? mlo : mhi), "n"(bit & 31));      // 0 or ~0
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(tv) : "v"(sel), "v"(tv), "v"(s[e >> 1][e & 1]));       // bit ? t : slope t
+            t[e >> 1][e & 1] = tv;
+          }
+        }
+        // (no column mask here: features >= N have all-zero fragment-order weights and a zero-padded bias row, so their
+        //  accumulators and activations ARE zero -- the generic epilogue's explicit mask cost two selects per value)
+        if (BITS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int bit = (c * RB + r) * 4 + e;
+            if (bit < 32) shift_in_positive(lo, t[e >> 1][e & 1]); else shift_in_positive(hi, t[e >> 1][e & 1]);
+          }
+        }
+        // exact 3-way split by truncation, two values per subtraction; each piece is the high half of t, r1, r2
+        f32x2 r1[2], r2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 hm = {__uint_as_float(__float_as_uint(t[h][0]) & 0xFFFF0000u), __uint_as_float(__float_as_uint(t[h][1]) & 0xFFFF0000u)};
+          r1[h] = t[h] - hm;
+          const f32x2 mm = {__uint_as_float(__float_as_uint(r1[h][0]) & 0xFFFF0000u), __uint_as_float(__float_as_uint(r1[h][1]) & 0xFFFF0000u)};
+          r2[h] = r1[h] - mm;                          // <= 8 significant bits left: its top 16 bits are exact
+        }
+        const u32x2 ph = (u32x2){pack_hi(__float_as_uint(t[0][0]), __float_as_uint(t[0][1])), pack_hi(__float_as_uint(t[1][0]), __float_as_uint(t[1][1]))};
+        const u32x2 pm = (u32x2){pack_hi(__float_as_uint(r1[0][0]), __float_as_uint(r1[0][1])), pack_hi(__float_as_uint(r1[1][0]), __float_as_uint(r1[1][1]))};
+        const u32x2 pl = (u32x2){pack_hi(__float_as_uint(r2[0][0]), __float_as_uint(r2[0][1])), pack_hi(__float_as_uint(r2[1][0]), __float_as_uint(r2[1][1]))};
+        unsigned short* dst = dst0 + r * 16 * LDPB;
         *reinterpret_cast<u32x2*>(dst) = ph;
         *reinterpret_cast<u32x2*>(dst + PLANE) = pm;
         *reinterpret_cast<u32x2*>(dst + 2 * PLANE) = pl;
-        if (PL) {
-          u32x2 phg = ph;
-          if (ragged && pl_ones) {                     // feature N of the HBM copy is the constant 1 (see the generic epilogue)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (n0 + e == N) phg[e >> 1] |= (e & 1) ? 0x3F800000u : 0x00003F80u;
-          }
+        if (PL && !(CLICA_EPI_ABLATE & 1)) {
           const unsigned po = (unsigned)(r * pl_group_bytes) + pl_cb;
-          __builtin_amdgcn_raw_buffer_store_b64(phg, prsrc, po, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(ph, prsrc, po, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(pm, prsrc, po + 1024u, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(pl, prsrc, po + 2048u, 0, 0);
         }
         if (OUTV) {
           const unsigned off = (row < nrows && n0 < N) ? (unsigned)((row * ldo + n0) * 4) : kOobOffset;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), orsrc, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(t[0][0]), __float_as_uint(t[0][1]), __float_as_uint(t[1][0]), __float_as_uint(t[1][1])},
+                                                 orsrc, off, 0, 0);
         }
+      }
+      if (PL && pl_ones && cb == (N >> 4) && (N & 31) != 0) {     // wave-uniform: feature N of the HBM copy is the constant 1 (see the generic epilogue)
+        // the owning lane overwrites the (zero) hi piece of feature N behind its own 8-byte store: same lane, same address, program order
+        const bool owner = N >= n0 && N < n0 + 4;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          __builtin_amdgcn_raw_buffer_store_b16((unsigned short)0x3F80u, prsrc,
+                                                owner ? (unsigned)(r * pl_group_bytes) + pl_cb + (unsigned)((N - n0) * 2) : kOobOffset, 0, 0);
       }
     } else if (BITS) {                                 // keep the bit positions of the blocks that follow
 #pragma unroll
