@@ -709,6 +709,15 @@ struct SplitArgs {
   int64_t ent3[MAXL];            // entries per piece of each layer
   int boff[MAXL + 1];            // float offset of each layer's bias row inside the LDS bias table (rows padded to KI)
   int warm_next;                 // L2 warm-up of the layer that follows a wide one: at most this many KB per early wave (see mlp_split_k)
+  // Round 4: what the training step's epilogues need of a layer, in ONE 64-byte record (one s_load_dwordx16 at the top of the layer).
+  // Reading the same facts field by field from g.layer[l] behind the k-loop was a chain of ~10 DEPENDENT scalar loads, each with its
+  // own s_waitcnt lgkmcnt(0) (flag -> branch -> next flag) in front of the epilogue, with the matrix pipe idle (tools/split_trace.py).
+  struct alignas(64) LayerQ {
+    unsigned short* planes; unsigned long long* mask_out;
+    int N, pl_units, pl_ones, fast_kind;          // fast_kind: 0 generic epilogue, 1 forward hidden layer, 3 backward link (split_epilogue_fast)
+    int boff, K; long long off3, ent3;
+    int pad[2];
+  } q[MAXL];
 };
 #ifndef CLICA_SPLIT_WARM_NEXT
 #define CLICA_SPLIT_WARM_NEXT 12                 // 12: also a 500 x 500 layer that follows directly (1.5 MB per XCD); 3: short layers only
@@ -1184,18 +1193,23 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     for (int r = 0; r < RB; ++r)
 #pragma unroll
       for (int c = 0; c < CBW; ++c) acc[r][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int ncb_real = (ly.N + 15) / 16;
+    SplitArgs::LayerQ q = a.q[l];                      // this layer's quick record: one wide scalar load, complete long before the k-loop ends
+    const bool has_next = l + 1 < g.L;
+    const int ncb_real = (q.N + 15) / 16;
     int nc = (ncb_real - wave + WAVES - 1) / WAVES;
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
     const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
-    const u32x4* w0 = a.packed3 + a.off3[l];
+    const u32x4* w0 = a.packed3 + q.off3;
     switch (nc) {
-      case 4: layer_gemm_split<4>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
-      case 3: layer_gemm_split<3>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
-      case 2: layer_gemm_split<2>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
-      case 1: layer_gemm_split_narrow<1>(ly.K, w0, a.ent3[l], planes, wave, lane, acc, wpre); break;
+      case 4: layer_gemm_split<4>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
+      case 3: layer_gemm_split<3>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
+      case 2: layer_gemm_split<2>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
+      case 1: layer_gemm_split_narrow<1>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
       default: break;
     }
+    // pin the record in scalar registers HERE (one wait, behind the k-loop's own work): read lazily it was a chain of dependent
+    // scalar loads in front of the epilogue
+    asm volatile("" : "+s"(q.planes), "+s"(q.mask_out), "+s"(q.N), "+s"(q.pl_units), "+s"(q.pl_ones), "+s"(q.fast_kind), "+s"(q.boff));
     ST_STAMP(l, 1);
     // L2 warm-up for the SHORT layers ahead.  In the training step the packed weights are cold in this XCD's L2 (mlp_pack3_k rewrote
     // them a moment ago), and a layer with one column block per wave has nothing to hide the first touch behind: the trace shows the
@@ -1216,20 +1230,59 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       warm_up_l2<WARM_LOADS>(a, g.L, l + 1, a.warm_next, wave, lane, warm);
       warm_up_l2<WARM_LOADS2>(a, g.L, l + 2, WARM_LOADS2, wave, lane, warm2);
     }
-    __syncthreads();                                   // every wave is done reading the planes
-    ST_STAMP(l, 2);
-
-    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): nothing of this layer's k-loop is still in flight (see layer_gemm_split)
-#pragma unroll
-    for (int u = 0; u < WARM_LOADS; ++u) asm volatile("" ::"v"(warm[u]));
-#pragma unroll
-    for (int u = 0; u < WARM_LOADS2; ++u) asm volatile("" ::"v"(warm2[u]));
-    if (l + 1 < g.L) {                                 // next layer's first weights, sign bits and bias: older than the stores below
+    // Round 4: the next layer's first weights (read-only: no need to wait for the barrier) and sign bits are requested HERE.  Behind
+    // the barrier all eight waves' 104 requests of 1 KB arrived at the CU's 64 B/clk address path at once and took ~1.7 k cycles to
+    // get through with the matrix pipe idle (tools/split_trace.py, "request"); the four early waves of a wide layer reach this point
+    // ~17 k cycles before the late ones, so their half is through long before the barrier opens.
+    if (has_next) {
       const Layer& nx = g.layer[l + 1];
       request_first_w3(a.packed3 + a.off3[l + 1], a.ent3[l + 1], nx.K, nx.N, wave, lane, wpre);
       mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(nx.dact ? nx.mask_in : nullptr), mslot, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                                   // every wave is done reading the planes
+    ST_STAMP(l, 2);
+    // the warm-up values are dead; consuming them costs a vmcnt(0) (the compiler cannot order the conditional loads against the weight
+    // requests), so only the waves that issued them do it -- they were here ~17 k cycles early and everything of theirs has landed;
+    // the late waves must NOT wait for the weight requests they issued a moment ago
+    if (nc >= 3 && wave < WAVES / 2) {
+#pragma unroll
+      for (int u = 0; u < WARM_LOADS; ++u) asm volatile("" ::"v"(warm[u]));
+#pragma unroll
+      for (int u = 0; u < WARM_LOADS2; ++u) asm volatile("" ::"v"(warm2[u]));
+    }
+    ST_STAMP(l, 4);
+    __builtin_amdgcn_sched_barrier(0);
+    ST_STAMP(l, 5);
+    if (CLICA_SPLIT_FAST_EPI && q.fast_kind != 0) {
+      // the training step's epilogues, from the quick record alone
+      int lane = lane_id;
+      asm volatile("" : "+v"(lane));
+      const int N = q.N;
+      const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;
+      const int pl_group_bytes = q.pl_units * 3 * 1024;
+      const __amdgpu_buffer_rsrc_t prsrc =
+          __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(q.planes) + (int64_t)blockIdx.x * RB * pl_group_bytes, 0, RB * pl_group_bytes, kRsrcWord3);
+      const __amdgpu_buffer_rsrc_t no_out = __builtin_amdgcn_make_buffer_rsrc(static_cast<float*>(nullptr), 0, 0, kRsrcWord3);
+      unsigned lo = 0u, hi = 0u;
+      if (q.fast_kind == 1) split_epilogue_fast<1, true, true, false>(acc, planes, &bias_lds[q.boff], g.slope, mbits, N, ncb, wave, lane, no_out, 0, nrows, prsrc, pl_group_bytes, q.pl_ones, lo, hi);
+      else split_epilogue_fast<2, false, true, false>(acc, planes, &bias_lds[q.boff], g.slope, mbits, N, ncb, wave, lane, no_out, 0, nrows, prsrc, pl_group_bytes, q.pl_ones, lo, hi);
+      ST_STAMP(l, 6);
+      if (q.pl_ones && (N & 31) == 0 && wave == 0) {   // the ones column in an extra unit (see the generic path below)
+        const bool first = (lane & 1) == 0 && ((lane >> 3) & 1) == 0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+          for (int pp = 0; pp < 3; ++pp) {
+            const u32x4 v4 = (u32x4){(pp == 0 && first) ? 0x00003F80u : 0u, 0u, 0u, 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(v4, prsrc, (unsigned)(r * pl_group_bytes + ((N >> 5) * 3 + pp) * 1024 + lane * 16), 0, 0);
+          }
+      }
+      __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(q.mask_out), (wave * 64 + lane) * 8, 0, 0);
+      ST_STAMP(l, 3);
+      __syncthreads();
+      continue;
+    }
 
     // epilogue: lane = batch row r*16 + (lane & 15), features cb*16 + (lane >> 4)*4 + e
     // Everything the epilogue derives from the lane id is recomputed here from an opaque copy: left to itself the compiler
@@ -1242,7 +1295,6 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     const int N = ly.N;
     const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;            // incl. the next layer's k-padding (written as zeros)
     const bool use_mask = ly.dact && ly.mask_in;
-    const bool want_bits = ly.mask_out != nullptr;
     const bool slope01 = g.slope > 0.f && g.slope < 1.f;
     const bool has_out = ly.out != nullptr;
     const bool ovec = has_out && ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (N % 4 == 0);
@@ -1259,17 +1311,6 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
                                           has_pl ? RB * pl_group_bytes : 0, kRsrcWord3);
     const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
     unsigned lo = 0u, hi = 0u;
-    // fast, fully specialised epilogues for what the training step runs (split_epilogue_fast); wave-uniform dispatch
-    const bool fastable = slope01 && (!has_out || ovec) && (has_pl || has_out) && !(has_pl && has_out);
-    const float* bias_row = &bias_lds[a.boff[l]];
-    int fast_kind = 0;
-    if (CLICA_SPLIT_FAST_EPI && fastable) {
-      if (!ly.dact && ly.leaky && want_bits && has_pl) fast_kind = 1;
-      else if (use_mask && !want_bits && has_pl) fast_kind = 3;
-    }
-    if (fast_kind == 1) split_epilogue_fast<1, true, true, false>(acc, planes, bias_row, g.slope, mbits, N, ncb, wave, lane, orsrc, (int)ly.ldo, nrows, prsrc, pl_group_bytes, ly.pl_ones, lo, hi);
-    else if (fast_kind == 3) split_epilogue_fast<2, false, true, false>(acc, planes, bias_row, g.slope, mbits, N, ncb, wave, lane, orsrc, (int)ly.ldo, nrows, prsrc, pl_group_bytes, ly.pl_ones, lo, hi);
-    else
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int cb = wave + c * WAVES;
@@ -1338,7 +1379,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
         for (int r = 0; r < RB; ++r) { if ((c * RB + r) * 4 < 32) lo <<= 4; else hi <<= 4; }
       }
     }
-    if (fast_kind == 0) { lo = __builtin_bitreverse32(lo); hi = __builtin_bitreverse32(hi) >> (64 - CBW * RB * 4); }
+    lo = __builtin_bitreverse32(lo); hi = __builtin_bitreverse32(hi) >> (64 - CBW * RB * 4);
     if (has_pl && ly.pl_ones && (N & 31) == 0 && wave == 0) {
       // N is a whole number of units: the ones column lives in an extra unit (feature 0 of unit N / 32) that no accumulator
       // block covers -- wave 0 writes it (hi plane: 1.0 at feature 0 of every row, everything else zero)
@@ -1607,6 +1648,20 @@ static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* w
   if (a.boff[a.g.L] > BIAS_LDS_MAX) {
     set_error("%s: the layer widths sum to %d (> %d): the on-chip bias table does not fit beside the bf16 planes", who, a.boff[a.g.L], BIAS_LDS_MAX);
     return CLICA_E_INVALID;
+  }
+  const bool slope01 = a.g.slope > 0.f && a.g.slope < 1.f;
+  for (int l = 0; l < a.g.L; ++l) {
+    const Layer& ly = a.g.layer[l];
+    SplitArgs::LayerQ& q = a.q[l];
+    q.planes = ly.planes; q.mask_out = ly.mask_out; q.N = ly.N; q.K = ly.K; q.pl_units = ly.pl_units; q.pl_ones = ly.pl_ones;
+    q.boff = a.boff[l]; q.off3 = a.off3[l]; q.ent3 = a.ent3[l];
+    // the combinations the training step runs (see split_epilogue_fast): plane copy only, slope in (0, 1), and either
+    // bias + LeakyReLU + sign bits (forward hidden layer) or the sign-bit gate (backward link)
+    q.fast_kind = 0;
+    if (slope01 && ly.planes && !ly.out) {
+      if (!ly.dact && ly.leaky && ly.mask_out) q.fast_kind = 1;
+      else if (ly.dact && ly.mask_in && !ly.mask_out) q.fast_kind = 3;
+    }
   }
   const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float);
   constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float);

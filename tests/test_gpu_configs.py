@@ -31,6 +31,73 @@ def build_mlp(n, hidden, head, gain=1.0):
     return f
 
 
+# ================================================================================================== C2 (the benched config)
+def test_c2_engine_full_size_vs_oracle(encoder_arith):
+    """BASELINE config 2 -- the configuration bench.py's number is quoted on -- through the ENGINE at the benched size (VERDICT r3
+    item 2): n = 10, hidden 100-500-500-500-500-100, B = 6144 (12 288 stacked rows), p = 2, box latents, formula weights (gain 2.2:
+    the outputs are not collapsed), main_mlp.py:258-285 / 297-307.  Same stages as test_c3_engine_full_size_vs_oracle, each at 1e-5 on
+    identical inputs, in both encoder arithmetics (fp32 MFMA and the split-bf16 default):
+      (1) embeddings y = f(g(z)) from the ONE-launch whole-stack forward (mixing net in its prologue; asserted on)
+      (2) loss, per-row loss, pos / neg means, d loss / d y from clica_lp_loss_fwd_train / clica_lp_loss_bwd_sym_train at n = 10
+      (3) every saved activation and every dW / db (training epilogues of mlp_split_k / mlp_fwd_k, the backward chain, the grouped and
+          the two tiny weight-gradient launches) against the oracle's backward on the engine's activations and d loss / d y
+      (4) a captured HIP graph replays the same steps BIT FOR BIT (what bench.py times is the replay)."""
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    n, B = 10, 6144
+    hidden = [n * 10, n * 50, n * 50, n * 50, n * 50, n * 10]
+    f = build_mlp(n, hidden, None, gain=2.2)
+    rng = np.random.default_rng(21)
+    gW = np.stack([formula_weights((n, n), 50 + i) * np.sqrt(n) for i in range(3)]).astype(np.float32)
+    z1 = rng.uniform(size=(B, n))
+    z2 = np.clip(z1 + 0.05 * rng.normal(size=(B, n)), 0.0, 1.0)
+    z1 = z1.astype(np.float32); z2 = z2.astype(np.float32)
+    tr = ContrastiveTrainer(f, dev(gW), SamplerSpec(space="box", n=n), batch_size=B, p=2, lr=0.0, device="cuda")
+    assert tr.fused_forward and tr.fused_backward           # the whole-stack kernels, not the per-layer GEMMs
+    assert bool(tr.split_bf16) == (encoder_arith == "split_bf16")
+    out = tr.step_injected(dev(z1), dev(z2)).cpu().numpy()
+    lin = [m for m in f if isinstance(m, torch.nn.Linear)]
+    P = O.MLPParams([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin],
+                    [m.bias.detach().cpu().numpy().astype(np.float64) for m in lin])
+    xa = np.concatenate([O.mixing_forward(list(gW), z1), O.mixing_forward(list(gW), z2)])
+    y, cache = O.mlp_forward(P, xa)
+    fam, case = "c2_engine_full_size", f"n={n} B={B} p=2"
+    ye = tr.y.cpu().numpy().astype(np.float64)
+    PARITY.check(fam, case, "mixing_net", tr.x.cpu().numpy(), xa)
+    PARITY.check(fam, case, "embeddings", ye, y)                                                     # (1)
+    assert float(np.std(y[:B], 0).mean()) > 0.05 * float(np.abs(y).max())                           # not collapsed
+    ref = O.lp_simclr_loss(ye[:B], ye[B:], np.roll(ye[:B], 1, 0), p=2, compat=True)                  # (2)
+    PARITY.check(fam, case, "loss_mean", out[0], ref["loss_mean"])
+    PARITY.check(fam, case, "pos_mean", out[1], ref["pos_mean"], floor=abs(ref["loss_mean"]))
+    PARITY.check(fam, case, "neg_mean", out[2], ref["neg_mean"], floor=abs(ref["loss_mean"]))
+    PARITY.check(fam, case, "loss_i", tr.loss_out[:B].cpu().numpy(), ref["loss_i"])
+    gy = np.concatenate([ref["dz1"] + np.roll(ref["dz3"], -1, 0), ref["dz2"]])
+    dye = tr.dy.cpu().numpy()
+    PARITY.check(fam, case, "d_embeddings", dye, gy)
+    cache_e = dict(acts=[tr.x.cpu().numpy().astype(np.float64)] +                                     # (3)
+                   [tr.saved_activation(l).cpu().numpy().astype(np.float64) for l in range(len(tr.acts))])
+    for l, (ae, ao) in enumerate(zip(cache_e["acts"][1:], cache["acts"][1:])):
+        PARITY.check(fam, case, f"act{l}", ae, ao)
+    gr = O.mlp_backward(P, cache_e, dye.astype(np.float64))
+    for l, m in enumerate(lin):
+        PARITY.check(fam, case, f"dW{l}", tr._gviews[id(m.weight)].cpu().numpy(), gr["dW"][l])
+        PARITY.check(fam, case, f"db{l}", tr._gviews[id(m.bias)].cpu().numpy(), gr["db"][l],
+                     floor=float(np.abs(gr["dW"][l]).max()) if l == len(lin) - 1 else 0.0)   # last bias: exact gradient 0
+    # (4) eager steps vs graph replays with on-device sampling, three Adam updates, bit for bit
+    res = []
+    for graph in (False, True):
+        f2 = build_mlp(n, hidden, None, gain=2.2)
+        t2 = ContrastiveTrainer(f2, dev(gW), SamplerSpec(space="box", n=n, seed=3), batch_size=B, p=2, lr=1e-4, device="cuda")
+        if graph:
+            t2.capture(warmup=2)
+        outs = []
+        for _ in range(3):
+            outs.append(t2.step().clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(outs), t2.param_arena.clone(), t2.loss_out.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    assert bool(torch.isfinite(res[1][1]).all()) and float(res[1][0][0, 0]) > 1.0
+
+
 # ================================================================================================== C3
 @pytest.mark.usefixtures("encoder_arith")      # wide encoders: split mode = fp32 fwd / dgrad kernels + split-bf16 weight gradients
 def test_c3_wide_trainstep_goldens(golden):

@@ -21,7 +21,8 @@ for _ in range(30):
 torch.cuda.synchronize()
 NWG, WAVES, MAXL = 256, 8, 8
 for which in ("forward", "chain"):
-    buf = torch.zeros(NWG * WAVES * MAXL * 4, dtype=torch.int64, device="cuda")
+    NS = 8
+    buf = torch.zeros(NWG * WAVES * MAXL * NS, dtype=torch.int64, device="cuda")
     tr._packed_current = False
     tr.sample(); tr.pack()
     if which == "forward":
@@ -36,7 +37,7 @@ for which in ("forward", "chain"):
         assert lib.clica_debug_split_trace(buf.data_ptr()) == 0
         tr.backward_chain(tr.dy); torch.cuda.synchronize()
         lib.clica_debug_split_trace(None)
-    t = buf.cpu().numpy().reshape(NWG, WAVES, MAXL, 4).astype(np.float64)
+    t = buf.cpu().numpy().reshape(NWG, WAVES, MAXL, NS).astype(np.float64)
     L = 7 if which == "forward" else 6
     print(f"== {which}: cycles per layer (median over workgroups); ideal MFMA cycles of a 500 x 500 layer: 16 iterations x 72 x 16 = 18432 per wave, 36864 per SIMD pair")
     t0 = t[:, :, 0, 0].min(1, keepdims=True)
@@ -44,7 +45,7 @@ for which in ("forward", "chain"):
         kl = t[:, :, l, 1] - t[:, :, l, 0]; b1 = t[:, :, l, 2] - t[:, :, l, 1]; ep = t[:, :, l, 3] - t[:, :, l, 2]
         nxt = (t[:, :, l + 1, 0] - t[:, :, l, 3]) if l + 1 < L else np.zeros_like(kl)
         print(f"  layer {l}: k-loop by wave {np.round(np.median(kl, 0)).astype(int).tolist()}  barrier wait {np.round(np.median(b1, 0)).astype(int).tolist()}"
-              f"  epilogue {int(np.median(ep))}  barrier 2 {int(np.median(nxt))}   layer total {int(np.median(t[:, :, l, 3].max(1) - t[:, :, l, 0].min(1)))}")
+              f"  epilogue {int(np.median(ep))} [drain {np.round(np.median(t[:, :, l, 4] - t[:, :, l, 2], 0)).astype(int).tolist()} request {int(np.median(t[:, :, l, 5] - t[:, :, l, 4]))} body {np.round(np.median(t[:, :, l, 6] - t[:, :, l, 5], 0)).astype(int).tolist()} tail {int(np.median(t[:, :, l, 3] - t[:, :, l, 6]))}]  barrier 2 {int(np.median(nxt))}   layer total {int(np.median(t[:, :, l, 3].max(1) - t[:, :, l, 0].min(1)))}")
     e0 = t[:, :, MAXL - 1, 0].min(1)
     pro = [int(np.median(t[:, :, MAXL - 1, q].max(1) - e0)) for q in (1, 2, 3)]
     print(f"  prologue phases from the workgroup's first entry (last wave): loads consumed {pro[0]}, first barrier passed {pro[1]}, mixing done {pro[2]}, "
