@@ -637,6 +637,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #ifndef CLICA_SPLIT_LOAD_GAP
 #define CLICA_SPLIT_LOAD_GAP 4
 #endif
+#ifndef CLICA_SPLIT_BALANCE
+#define CLICA_SPLIT_BALANCE 0     // 1: keep the two waves of a SIMD in step (LDS progress words + s_setprio); measured, no gain -- see layer_gemm_split
+#endif
 #ifndef CLICA_SPLIT_FAST_EPI
 #define CLICA_SPLIT_FAST_EPI 1
 #endif
@@ -794,7 +797,7 @@ __device__ __forceinline__ void layer_gemm_split_narrow(const int K, const u32x4
 
 template <int NC>
 __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __restrict__ w0, const int64_t ent, const unsigned short* planes,
-                                                 int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[3][CBW]) {
+                                                 int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[3][CBW], volatile int* prog) {
   const int i15 = lane & 15, kg = lane >> 4;
   const int kiters = (K + KI - 1) / KI;
   u32x4 wcur[3][CBW], wnxt[3][CBW];
@@ -879,6 +882,19 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
   u32x4 x[3][RB];
   int ki = 0;
   for (; ki + 1 < kiters; ki += 2) {
+#if CLICA_SPLIT_BALANCE
+    // Round 4: keep the two waves of a SIMD in step.  The issue arbiter prefers the OLDER wave whenever both want the matrix pipe;
+    // the older wave of each pair left a 500 x 500 layer's k-loop after ~25.8 k cycles, the younger ran the remaining ~17 k cycles
+    // alone at 68 % of the pipe's rate (one wave cannot cover its own weight-stream latency): 42-43 k cycles for 36.9 k of matrix
+    // work.  Each wave publishes its progress in LDS and the one that is BEHIND its partner (wave ^ 4: same SIMD) raises its priority.
+    // MEASURED (tools/split_trace.py): the pair then runs 39.7 k / 41.4 k cycles -- in step, but no faster than the unbalanced
+    // younger wave (43.3 k): two waves together reach ~0.89 of the pipe's rate, which is what the CU's 64 B/clk vector-memory path
+    // leaves when the weight stream needs 43 of the ~51 B/clk it delivers (tools/l2_stream_bench.hip); and the early waves' idle
+    // window (L2 warm-up, next layer's requests) is gone.  Launch time unchanged (127.8 vs 127.4 us): off by default.
+    const int partner = __builtin_amdgcn_readfirstlane(prog[wave ^ 4]);
+    prog[wave] = ki + 2;
+    if (partner > ki) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+#endif
     fetch_x(x, ki);
     fetch_w(wnxt, kof(ki + 1));
     mma(wcur, x);
@@ -890,6 +906,9 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
     pin();
     __builtin_amdgcn_sched_barrier(0);
   }
+#if CLICA_SPLIT_BALANCE
+  __builtin_amdgcn_s_setprio(0);
+#endif
   if (ki < kiters) { fetch_x(x, ki); mma(wcur, x); }
   // The last pass's look-ahead request (kof) is dead but still counted: without this the compiler protects its target
   // registers with an s_waitcnt vmcnt(0) wherever the epilogue first reuses one of them -- in the middle of the epilogue's
@@ -1085,6 +1104,8 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   // all layers' biases in the LDS left beside the planes (rows zero-padded to KI): the epilogue reads four consecutive
   // features with one ds_read_b128 instead of holding them in registers across the k-loop
   float* bias_lds = reinterpret_cast<float*>(planes + 3 * PLANE);
+  volatile int* prog = reinterpret_cast<volatile int*>(bias_lds + a.boff[g.L]);      // k-loop progress of the eight waves (layer_gemm_split)
+  if (lane == 0) prog[wave] = 0;
   constexpr int BIAS_IT = (BIAS_LDS_MAX + THREADS - 1) / THREADS;
   float bv[BIAS_IT];
   const int btotal = a.boff[g.L];
@@ -1201,9 +1222,9 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
     const u32x4* w0 = a.packed3 + q.off3;
     switch (nc) {
-      case 4: layer_gemm_split<4>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
-      case 3: layer_gemm_split<3>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
-      case 2: layer_gemm_split<2>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
+      case 4: layer_gemm_split<4>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
+      case 3: layer_gemm_split<3>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
+      case 2: layer_gemm_split<2>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
       case 1: layer_gemm_split_narrow<1>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
       default: break;
     }
@@ -1279,6 +1300,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
           }
       }
       __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(q.mask_out), (wave * 64 + lane) * 8, 0, 0);
+      if (lane == 0) prog[wave] = 0;
       ST_STAMP(l, 3);
       __syncthreads();
       continue;
@@ -1393,6 +1415,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
         }
     }
     __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(ly.mask_out), mslot, 0, 0);
+    if (lane == 0) prog[wave] = 0;
     ST_STAMP(l, 3);
     __syncthreads();
   }
@@ -1663,8 +1686,8 @@ static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* w
       else if (ly.dact && ly.mask_in && !ly.mask_out) q.fast_kind = 3;
     }
   }
-  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float);
-  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float);
+  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 64;      // + the waves' progress words
+  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 64;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
   (void)once;
   hipLaunchKernelGGL(mlp_split_k, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
