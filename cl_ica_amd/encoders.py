@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import layers as ls
+from . import lazy
 from . import ops
 
 __all__ = ["get_mlp", "FusedMLP", "NormedMLP"]
@@ -315,6 +316,7 @@ class FusedMLP(nn.Sequential):
     """``nn.Sequential`` whose forward runs the fused HIP path (same modules, same state dict)."""
 
     def forward(self, x):
+        x = lazy.plain(x)
         mods = list(self)
         linears = [m for m in mods if isinstance(m, nn.Linear)]
         slopes = {m.negative_slope for m in mods if isinstance(m, nn.LeakyReLU)}
@@ -324,12 +326,22 @@ class FusedMLP(nn.Sequential):
         params = []
         for lin in linears:
             params += [lin.weight, lin.bias]
-        fn = (_MLPFusedSplitFn if _dropin_split(linears) else _MLPFusedFn) if _use_fused(linears, x.shape[0]) else _MLPStackFn
-        y = fn.apply(x, slope, *params)
-        for m in mods:
-            if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
-                y = m(y)
-        return y
+
+        def compute(xx):
+            fn = (_MLPFusedSplitFn if _dropin_split(linears) else _MLPFusedFn) if _use_fused(linears, xx.shape[0]) else _MLPStackFn
+            y = fn.apply(xx, slope, *params)
+            for m in mods:
+                if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
+                    y = m(y)
+            return y
+        # The reference's train_step calls the encoder twice per step (main_mlp.py:270-271).  A training call that does not fill the
+        # chip on its own (fewer than 256 panels of 48 rows) is DEFERRED: if the same module is called again before anything uses the
+        # result, both batches run as one stacked launch per phase (cl_ica_amd/lazy.py); any other use computes it right away.
+        if (lazy.enabled() and torch.is_grad_enabled() and x.is_cuda and (x.shape[0] + 47) // 48 < 256
+                and any(p.requires_grad for p in params if p is not None)):
+            every = [p for p in self.parameters()]
+            return lazy.defer(self, x, compute, (x.shape[0], linears[-1].out_features), every)
+        return compute(x)
 
 
 class NormedMLP(nn.Sequential):
@@ -337,6 +349,7 @@ class NormedMLP(nn.Sequential):
     LeakyReLU run on the HIP kernels (per layer), the normalisation modules are torch's."""
 
     def forward(self, x):
+        x = lazy.plain(x)
         if x.dim() != 2:
             x = x.reshape(-1, x.shape[-1])
         for m in self:

@@ -7,7 +7,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from . import ops
+from . import lazy, ops
 
 __all__ = ["Lambda", "Flatten", "RescaleLayer", "SoftclipLayer", "LeakyReLU"]
 
@@ -86,6 +86,7 @@ class RescaleLayer(nn.Module):
         self.r = _scale_tensor(1, init_r, learnable=not fixed_r)
 
     def forward(self, x):
+        x = lazy.plain(x)
         r = self.r.to(x.device)
         if not r.is_contiguous():
             r = r.contiguous()
@@ -102,6 +103,7 @@ class SoftclipLayer(nn.Module):
         self.max_abs_bound = _scale_tensor(n, init_abs_bound, learnable=not fixed_abs_bound)
 
     def forward(self, x):
+        x = lazy.plain(x)
         return _SoftclipFn.apply(x, self.max_abs_bound.to(x.device).contiguous())
 
 
@@ -132,6 +134,7 @@ class LeakyReLU(nn.LeakyReLU):
         super().__init__(negative_slope, inplace)
 
     def forward(self, x):
+        x = lazy.plain(x)
         if x.dim() != 2:
             return _LeakyFn.apply(x.reshape(-1, x.shape[-1]), float(self.negative_slope)).reshape(x.shape)
         return _LeakyFn.apply(x, float(self.negative_slope))

@@ -16,7 +16,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, lazy
 
 __all__ = ["CLLoss", "ConditionalPairCLLoss", "MarginalPairCLLoss", "LpSimCLRLoss", "SimCLRLoss", "UniformityLoss", "AlignmentLoss"]
 
@@ -103,6 +103,84 @@ class _PairLossFn(torch.autograd.Function):
         return (dz1 if need1 else None), dz2, dz3, None, None
 
 
+def _rolled_rows_of(z3, z1) -> bool:
+    """Is `z3` the autograd result of ``torch.roll(z1, s, 0)`` (the reference's ``z3_rec = torch.roll(z1_rec, 1, 0)``,
+    main_mlp.py:272)?  Read off the graph: z3's node is RollBackward0 along dim 0 and its input edge is z1's own gradient edge."""
+    fn = getattr(z3, "grad_fn", None)
+    if fn is None or z3.shape != z1.shape or fn.name() != "RollBackward0":
+        return False
+    try:
+        if tuple(fn._saved_dims) != (0,):
+            return False
+        src, nr = fn.next_functions[0]
+        if z1.grad_fn is not None:
+            return src is z1.grad_fn and nr == z1.output_nr
+        return z1.requires_grad and src is not None and getattr(src, "variable", None) is z1       # a leaf: its AccumulateGrad node
+    except (AttributeError, IndexError):
+        return False
+
+
+class _PairLossSymFn(torch.autograd.Function):
+    """LpSimCLRLoss when the negatives ARE the anchors in another order (``z3_rec = roll(z1_rec)``): the row-wise log-sum-exp does
+    not depend on the order of the negatives, so the forward reads z1 as the pool (no rolled copy), and the backward is ONE pair sweep
+    (clica_lp_loss_bwd_sym: d_ij = d_ji, coefficient C_i w_ij + C_j w_ji) that delivers the complete d loss / d z1 -- the row part, the
+    column part AND what autograd would have routed back through the roll.  What the training engine does, behind the reference's call."""
+
+    @staticmethod
+    def forward(ctx, z1, z2, desc):
+        lib = _lib.load()
+        (a, lda), (b, ldb) = _prep("z1_rec", z1), _prep("z2_con_z1_rec", z2)
+        B = a.shape[0]
+        out = torch.empty(3 * B + 3, dtype=torch.float32, device=a.device)
+        loss_i, pos_i, lse_i, means = out[:B], out[B:2 * B], out[2 * B:3 * B], out[3 * B:]
+        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), "clica_lp_loss_workspace_bytes")
+        ws = _lib.workspace("lp_loss", max(fwd_b.value, bwd_b.value), a.device)
+        _lib.check(lib.clica_lp_loss_fwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, a.data_ptr(), lda,
+                                         loss_i.data_ptr(), pos_i.data_ptr(), lse_i.data_ptr(), means.data_ptr(),
+                                         None, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "clica_lp_loss_fwd")
+        ctx.save_for_backward(a, b, lse_i)
+        ctx.lds, ctx.desc = (lda, ldb), desc
+        mean, pos_mean, neg_mean = means.unbind(0)
+        return mean, loss_i, pos_mean, neg_mean
+
+    @staticmethod
+    def backward(ctx, g_mean, g_item, g_pos, g_neg):
+        lib = _lib.load()
+        a, b, lse_i = ctx.saved_tensors
+        (lda, ldb), desc, dev, n = ctx.lds, ctx.desc, a.device, a.shape[1]
+        need1, need2 = ctx.needs_input_grad[:2]
+
+        def scal(g):
+            return None if g is None else g.detach().to(torch.float32).reshape(1).contiguous()
+        g_mean_t = scal(g_mean)
+        if g_mean_t is None:
+            g_mean_t = torch.zeros(1, dtype=torch.float32, device=dev)
+        g_pos_t, g_neg_t = scal(g_pos), scal(g_neg)
+        dz1 = torch.empty((a.shape[0], n), dtype=torch.float32, device=dev)
+        dz2 = torch.empty((b.shape[0], n), dtype=torch.float32, device=dev) if need2 else None
+        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), "clica_lp_loss_workspace_bytes")
+        ws = _lib.workspace("lp_loss", max(fwd_b.value, bwd_b.value), dev)
+        if g_item is None and desc.p >= 1.0:
+            _lib.check(lib.clica_lp_loss_bwd_sym(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, a.data_ptr(), lda,
+                                                 lse_i.data_ptr(), lse_i.data_ptr(), _lib.ptr(g_mean_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
+                                                 dz1.data_ptr(), n, _lib.ptr(dz2), n, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                       "clica_lp_loss_bwd_sym")
+        else:     # a per-item upstream gradient or p < 1: the generic two-sweep backward with z3 aliasing z1 (column part ADDED into dz1)
+            g_item_t = None if g_item is None else g_item.detach().to(torch.float32).contiguous()
+            _lib.check(lib.clica_lp_loss_bwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, a.data_ptr(), lda, lse_i.data_ptr(),
+                                             None, n, _lib.ptr(g_mean_t), _lib.ptr(g_item_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
+                                             dz1.data_ptr(), n, _lib.ptr(dz2), n, dz1.data_ptr(), n, 1,
+                                             ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "clica_lp_loss_bwd")
+        return (dz1 if need1 else None), dz2, None
+
+
+def _sym_enabled() -> bool:
+    import os
+    return os.environ.get("CLICA_DROPIN_SYM", "1") != "0"
+
+
 class LpSimCLRLoss(CLLoss):
     """Extended InfoNCE objective for non-normalized representations based on an Lp norm.
 
@@ -126,10 +204,14 @@ class LpSimCLRLoss(CLLoss):
 
     def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
         del z1, z2_con_z1, z3   # unused by the reference as well (losses.py:431)
+        z1_rec, z2_con_z1_rec, z3_rec = lazy.plain(z1_rec), lazy.plain(z2_con_z1_rec), lazy.plain(z3_rec)
         if z1_rec.shape != z2_con_z1_rec.shape or z1_rec.shape[1] != z3_rec.shape[1]:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_con_z1_rec.shape)}, {tuple(z3_rec.shape)}")
         desc = self._desc(z1_rec.shape[0], z3_rec.shape[0], z1_rec.shape[1])
-        mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "lp", desc)
+        if _sym_enabled() and z1_rec.dim() == 2 and _rolled_rows_of(z3_rec, z1_rec):
+            mean, per_item, pos_mean, neg_mean = _PairLossSymFn.apply(z1_rec, z2_con_z1_rec, desc)
+        else:
+            mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "lp", desc)
         return mean, per_item, [pos_mean, neg_mean]
 
 
@@ -143,6 +225,7 @@ class SimCLRLoss(CLLoss):
 
     def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
         del z1, z2_con_z1, z3
+        z1_rec, z2_con_z1_rec, z3_rec = lazy.plain(z1_rec), lazy.plain(z2_con_z1_rec), lazy.plain(z3_rec)
         if z1_rec.shape != z2_con_z1_rec.shape or z1_rec.shape[1] != z3_rec.shape[1]:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_con_z1_rec.shape)}, {tuple(z3_rec.shape)}")
         desc = _lib.DotLossDesc(B=z1_rec.shape[0], B3=z3_rec.shape[0], n=z1_rec.shape[1], tau=float(self.tau),
@@ -185,6 +268,7 @@ class UniformityLoss(MarginalPairCLLoss):
         self.p = p
 
     def loss(self, z1_rec, z3_rec):
+        z1_rec, z3_rec = lazy.plain(z1_rec), lazy.plain(z3_rec)
         if z1_rec.dim() != 2 or z3_rec.dim() != 2 or z1_rec.shape[1] != z3_rec.shape[1]:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z3_rec.shape)}")
         desc = _lib.LpLossDesc(B=z3_rec.shape[0], B3=z1_rec.shape[0], n=z1_rec.shape[1], p=float(self.p), tau=1.0,
@@ -203,6 +287,7 @@ class AlignmentLoss(ConditionalPairCLLoss):
         self.p = p
 
     def loss(self, z1_rec, z2_rec):
+        z1_rec, z2_rec = lazy.plain(z1_rec), lazy.plain(z2_rec)
         if z1_rec.dim() != 2 or z1_rec.shape != z2_rec.shape:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_rec.shape)}")
         desc = _lib.LpLossDesc(B=z1_rec.shape[0], B3=1, n=z1_rec.shape[1], p=float(self.p), tau=1.0, alpha=1.0, compat=0, pow=1,

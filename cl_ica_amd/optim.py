@@ -16,7 +16,7 @@ from typing import Iterable, Optional
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import lazy, ops
 from ._lib import require_cuda
 
 __all__ = ["Adam"]
@@ -92,6 +92,7 @@ class Adam:
         observe them): ONE parameter group; one global step count; a parameter without a gradient is updated with g = 0
         (its moments decay) where torch would skip it."""
         loss = closure() if closure is not None else None
+        lazy.flush_all()          # a deferred encoder call (cl_ica_amd/lazy.py) is computed with the parameters it was made with
         if len(self.param_groups) != 1:
             raise ValueError("the flat Adam supports exactly one parameter group")
         self._adopt_foreign_grads()

@@ -18,7 +18,7 @@ from typing import Callable, Optional
 import torch
 from torch import nn
 
-from . import layers, losses
+from . import layers, lazy, losses
 from .encoders import _MLPStackFn
 
 __all__ = ["setup_f", "make_unsupervised_loss", "train_step", "HipLinear", "unpack_item_list"]
@@ -28,6 +28,7 @@ class HipLinear(nn.Linear):
     """``nn.Linear`` (same parameters / state-dict entries / default init) computed by the HIP GEMM kernels."""
 
     def forward(self, x):
+        x = lazy.plain(x)
         return _MLPStackFn.apply(x if x.is_contiguous() else x.contiguous(), 0.0, self.weight, self.bias)
 
 

@@ -18,7 +18,11 @@ def pytest_configure(config):
 # Every GPU parity comparison goes through PARITY.check(): it computes the NORM-WISE relative error
 #     err = max|got - ref| / max(max|ref|, floor)
 # asserts err < tol (north_star: 1e-5 relative fp32) and records the measured value per test family.  At session end
-# the table is written to gpurun_out/r3_parity_errors.json (copied to profiles/ after a GPU run).
+# the table is written to gpurun_out/r4_parity_errors.json (copied to profiles/ after a GPU run).
+# Next to the max-norm figure every family carries an ELEMENT-WISE statistic: the 99.9th percentile of
+# |got - ref| / |ref| over the elements with |ref| > 1e-3 max|ref| (elements the max-norm cannot hide behind a large neighbour),
+# worst case per family (`p999_elem_rel_err`).  It is logged, not asserted: cancellation (loss_i = 2(a pos + (1-a) lse), embedding
+# gradients) legitimately puts single elements above 1e-5 relative to THEMSELVES while they are exact relative to their summands.
 # CLICA_PARITY_RECORD_ONLY=1 is a SURVEY mode, not a kill switch: every check is still evaluated, the per-check rows are
 # written next to the table, and the session is forced to FAIL at the end (exit status 1) however the checks went, so a
 # run with the variable set can never be mistaken for a green suite.
@@ -42,8 +46,19 @@ class ParityLog:
         if not np.isfinite(err):
             err = float("inf")
         f = self.fam.setdefault(family, {"n_checks": 0, "max_rel_err": 0.0, "worst": None, "tol": tol, "n_over_1e-5": 0,
-                                         "allowances": {}})
+                                         "allowances": {}, "p999_elem_rel_err": 0.0, "p999_worst": None})
         f["n_checks"] += 1
+        if ref.size:
+            big = np.abs(ref) > 1e-3 * float(np.max(np.abs(ref)))
+            if big.any():
+                with np.errstate(all="ignore"):
+                    er = np.abs(got[big] - ref[big]) / np.abs(ref[big])
+                er = er[np.isfinite(er)]
+                if er.size:
+                    kth = min(er.size - 1, int(np.ceil(0.999 * er.size)) - 1)
+                    p999 = float(np.partition(er, kth)[kth])
+                    if p999 >= f["p999_elem_rel_err"]:
+                        f["p999_elem_rel_err"] = p999; f["p999_worst"] = f"{case}:{what}"
         if err >= TOL:
             f["n_over_1e-5"] += 1
         if tol != TOL:      # a documented, case-specific allowance: keep its reason and the largest error seen under it
@@ -60,7 +75,7 @@ class ParityLog:
     def dump(self):
         if not self.fam:
             return
-        out = os.environ.get("CLICA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r3_parity_errors.json"))
+        out = os.environ.get("CLICA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r4_parity_errors.json"))
         os.makedirs(os.path.dirname(out), exist_ok=True)
         import json
         prev = {}
@@ -71,13 +86,28 @@ class ParityLog:
                 prev = {}
         prev.update(self.fam)
         json.dump({"definition": "max|got-ref| / max(max|ref|, floor); got = HIP path through the C ABI, ref = reference golden "
-                                 "(fp32, tests/golden) or fp64 oracle; bound 1e-5 unless an allowance is listed",
+                                 "(fp32, tests/golden) or fp64 oracle; bound 1e-5 unless an allowance is listed.  p999_elem_rel_err: 99.9th "
+                                 "percentile of the ELEMENT-wise |got-ref|/|ref| over elements with |ref| > 1e-3 max|ref|, worst check of the "
+                                 "family (logged, not asserted)",
                    "families": prev}, open(out, "w"), indent=1, sort_keys=True)
         if self.rows:
             json.dump(self.rows, open(out.replace(".json", "_rows.json"), "w"))
 
 
 PARITY = ParityLog()
+
+
+def recorded_r3_error(family):
+    """max_rel_err the round-3 GPU run recorded for `family` (profiles/r3_parity_errors.json; the [split_bf16] suffix is added here as
+    in ParityLog.check), or None.  Used to cap allowances at 10 x what was measured."""
+    import json
+    if PARITY.mode == "split_bf16":
+        family = family + "[split_bf16]"
+    try:
+        fam = json.load(open(os.path.join(ROOT, "profiles", "r3_parity_errors.json")))["families"]
+    except Exception:
+        return None
+    return float(fam[family]["max_rel_err"]) if family in fam else None
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import PARITY, conv_formula, fill_formula, formula_weights, golden_view, mlp_formula_params, p1_tie_analysis
+from conftest import PARITY, recorded_r3_error, conv_formula, fill_formula, formula_weights, golden_view, mlp_formula_params, p1_tie_analysis
 from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -211,8 +211,14 @@ def adam_trajectory_check(fam, key, module, out, prefix, stride, lr, steps, skip
                          got[strict], ref[strict], tol=(steps + 1) * quantum, floor=scale,
                          note=f"trajectory: (steps + 1) x {quantum:g} of max|param| after the Adam updates, elements with gradients above rounding level")
         if (~strict).any():
-            PARITY.check(fam + "_noise_elements", key, name, got[~strict], ref[~strict], tol=2.0 * lr * steps / scale * 1.01, floor=scale,
-                         note="elements whose gradient came within 1 % of rounding-level at some step: bounded by their +-lr random walk, 2 lr steps")
+            # the random-walk bound alone is vacuous where the walk is small against the parameter (0.14 of max|param| for G7 against an
+            # observed 1.7e-4): capped at 10 x the family's worst error in the round-3 GPU run, never below the
+            # strict set's own bound
+            walk = 2.0 * lr * steps / scale * 1.01
+            rec = recorded_r3_error(fam + "_noise_elements")
+            tol_n = walk if rec is None else min(walk, max(10.0 * rec, (steps + 1) * quantum))
+            PARITY.check(fam + "_noise_elements", key, name, got[~strict], ref[~strict], tol=tol_n, floor=scale,
+                         note="elements whose gradient came within 1 % of rounding-level at some step: min(+-lr random walk over the steps, 10 x the round-3 recorded error)")
 
 
 def test_c3_loss_pool_49152_sampled_rows_vs_oracle():

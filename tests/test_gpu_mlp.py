@@ -433,6 +433,137 @@ def test_split_bf16_wgrad_matches_fp64(dims, M):
         assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
 
 
+def _stack64(x, Ws, bs, slope):
+    a = np.asarray(x, np.float64)
+    outs = []
+    with np.errstate(all="ignore"):
+        for l, (W, b) in enumerate(zip(Ws, bs)):
+            a = a @ np.asarray(W, np.float64).T + np.asarray(b, np.float64)
+            if l < len(Ws) - 1:
+                a = np.where(a > 0, a, slope * a)
+            outs.append(a)
+    return outs
+
+
+def _run_both_stacks(x, Ws, bs, slope):
+    """The same [M, K] -> ... stack through the split-bf16 and the native fp32-MFMA whole-stack kernels."""
+    from cl_ica_amd import ops
+    dW, db, dx = [dev(w) for w in Ws], [dev(b) for b in bs], dev(x)
+    M, L = x.shape[0], len(Ws)
+    o_split = [torch.empty(M, w.shape[0], device="cuda") for w in Ws]
+    o_native = [torch.empty(M, w.shape[0], device="cuda") for w in Ws]
+    packed3, _ = ops.mlp_pack_split_both(dW)
+    ops.mlp_fwd_split(dx, dW, db, o_split, packed3, slope, signmasks=ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None])
+    ops.mlp_fwd(dx, dW, db, o_native, slope, packed=ops.mlp_pack_weights(dW))
+    torch.cuda.synchronize()
+    return [o.cpu().numpy() for o in o_split], [o.cpu().numpy() for o in o_native]
+
+
+def test_split_bf16_adversarial_ranges():
+    """the bf16x3 split outside the O(1) operands every other test feeds it.  A piece of a split operand keeps
+    the operand's fp32 exponent range (bf16 has fp32's 8 exponent bits), so the arithmetic must not care where the exponents sit:
+      (a) exponents spread over 2^+-40 along the CONTRACTION (input feature k of x scaled by 2^e_k, column k of W1 by 2^-e_k) and
+          along the hidden features (row j of W1 / b1 by 2^f_j, column j of W2 by 2^-f_j; LeakyReLU is positively homogeneous, so the
+          exact result is that of the unscaled net): split and native kernels against fp64 at 1e-5;
+      (b) rows that mix 1e+30 and 1e-30 (the small terms must vanish against the large ones exactly as in fp32, nothing overflows);
+      (c) products down to 2^-90 (pieces far below 1, nothing flushed): still 1e-5 -- with the stated limit: a piece product below
+          the fp32 normal range (|a b| < 2^-110 or so) loses its low-order pieces to flushing, i.e. the emulation's result range
+          ends ~16 binades above fp32's own underflow; documented in DESIGN 4.1d;
+      (d) exact powers of two, small integers, +-0, slope 0.5: every partial sum is exact in fp32, so BOTH kernels must return the
+          fp64 result bit for bit (any dropped or duplicated piece product would show);
+      (e) inf / NaN: an element that is non-finite through the native kernel is non-finite through the split kernel and vice versa
+          (the VALUE may differ: the split of +inf has a NaN residual, so inf comes out as NaN), and the rows that
+          hold only finite data are untouched."""
+    rng = np.random.default_rng(2024)
+    K, H, N, M = 96, 200, 48, 144
+    W1 = (rng.uniform(-1, 1, size=(H, K)) / np.sqrt(K)).astype(np.float32)
+    W2 = (rng.uniform(-1, 1, size=(N, H)) / np.sqrt(H)).astype(np.float32)
+    b1 = rng.uniform(-0.5, 0.5, size=H).astype(np.float32); b2 = rng.uniform(-0.5, 0.5, size=N).astype(np.float32)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    base = _stack64(x, [W1, W2], [b1, b2], 0.01)
+
+    # (a) exponent spread (powers of two: the scaled operands are exact, the exact result is unchanged)
+    ek = rng.integers(-40, 41, size=K); fj = rng.integers(-40, 41, size=H)
+    xs = (x.astype(np.float64) * 2.0 ** ek).astype(np.float32)
+    W1s = (W1.astype(np.float64) * 2.0 ** (-ek)[None, :] * 2.0 ** fj[:, None]).astype(np.float32)
+    b1s = (b1.astype(np.float64) * 2.0 ** fj).astype(np.float32)
+    W2s = (W2.astype(np.float64) * 2.0 ** (-fj)[None, :]).astype(np.float32)
+    sp, nat = _run_both_stacks(xs, [W1s, W2s], [b1s, b2], 0.01)
+    PARITY.check("split_bf16_adversarial", "exponents 2^+-40", "y[split]", sp[1], base[1])
+    PARITY.check("split_bf16_adversarial", "exponents 2^+-40", "y[native]", nat[1], base[1])
+    PARITY.check("split_bf16_adversarial", "exponents 2^+-40", "hidden[split]", sp[0] * 2.0 ** (-fj)[None, :].astype(np.float64), base[0])
+
+    # (b) 1e+30 next to 1e-30 in every row
+    xb = x.copy(); xb[:, 0::2] *= np.float32(1e30); xb[:, 1::2] *= np.float32(1e-30)
+    W2b = (W2.astype(np.float64) * 1e-30).astype(np.float32)
+    refb = _stack64(xb, [W1, W2b], [b1, b2], 0.01)
+    sp, nat = _run_both_stacks(xb, [W1, W2b], [b1, b2], 0.01)
+    assert np.isfinite(sp[1]).all() and np.isfinite(nat[1]).all()
+    PARITY.check("split_bf16_adversarial", "1e30 with 1e-30", "y[split]", sp[1], refb[1])
+    PARITY.check("split_bf16_adversarial", "1e30 with 1e-30", "y[native]", nat[1], refb[1])
+    PARITY.check("split_bf16_adversarial", "1e30 with 1e-30", "hidden[split]", sp[0], refb[0])
+
+    # (c) tiny operands: products ~2^-90
+    xc = (x.astype(np.float64) * 2.0 ** -45).astype(np.float32)
+    W1c = (W1.astype(np.float64) * 2.0 ** -45).astype(np.float32)
+    b1c = (b1.astype(np.float64) * 2.0 ** -90).astype(np.float32)
+    W2c = (W2.astype(np.float64) * 2.0 ** 90).astype(np.float32)
+    sp, nat = _run_both_stacks(xc, [W1c, W2c], [b1c, b2], 0.01)
+    PARITY.check("split_bf16_adversarial", "products 2^-90", "y[split]", sp[1], base[1])
+    PARITY.check("split_bf16_adversarial", "products 2^-90", "y[native]", nat[1], base[1])
+
+    # (d) exactly representable everything: bit-for-bit the fp64 result through both kernels
+    xd = rng.choice(np.array([0.0, -0.0, 1.0, -1.0, 2.0, -0.5, 4.0, 0.25], np.float32), size=(M, K))
+    W1d = rng.choice(np.array([0.0, 0.125, -0.125, 0.5, -1.0, 2.0 ** -6], np.float32), size=(H, K))
+    W2d = rng.choice(np.array([0.0, 0.25, -0.25, 1.0, -2.0 ** -4], np.float32), size=(N, H))
+    b1d = rng.choice(np.array([0.0, 0.5, -1.0], np.float32), size=H); b2d = rng.choice(np.array([0.0, 2.0], np.float32), size=N)
+    refd = _stack64(xd, [W1d, W2d], [b1d, b2d], 0.5)
+    assert all(np.array_equal(r, r.astype(np.float32).astype(np.float64)) for r in refd)        # the fp64 result is an fp32 number
+    sp, nat = _run_both_stacks(xd, [W1d, W2d], [b1d, b2d], 0.5)
+    for l in range(2):
+        assert np.array_equal(sp[l].astype(np.float64), refd[l]), ("split", l, float(np.abs(sp[l] - refd[l]).max()))
+        assert np.array_equal(nat[l].astype(np.float64), refd[l]), ("native", l)
+
+    # (e) non-finite inputs poison the same elements in both kernels and nothing else
+    xe = x.copy(); xe[3, 5] = np.inf; xe[7, 2] = np.nan; xe[9, 0] = -np.inf; xe[11, 95] = np.inf
+    sp, nat = _run_both_stacks(xe, [W1, W2], [b1, b2], 0.01)
+    bad_rows = [3, 7, 9, 11]
+    good = np.setdiff1d(np.arange(M), bad_rows)
+    for l in range(2):
+        assert np.array_equal(np.isfinite(sp[l]), np.isfinite(nat[l])), ("non-finite sets differ", l)
+        assert not np.isfinite(sp[l][bad_rows]).any()
+        PARITY.check("split_bf16_adversarial", "non-finite rows", f"clean rows layer {l} [split]", sp[l][good], base[l][good])
+    # overflow INSIDE the product (finite operands): inf from both
+    xo = x.copy(); xo[5, :] = np.float32(3e38)
+    sp, nat = _run_both_stacks(xo, [(W1 * 8).astype(np.float32), W2], [b1, b2], 0.01)
+    assert np.array_equal(np.isfinite(sp[1]), np.isfinite(nat[1])) and not np.isfinite(sp[1][5]).all()
+
+
+def test_split_bf16_wgrad_adversarial_ranges():
+    """The same for the split-bf16 weight-gradient kernel (contraction over the batch rows): row m of X scaled by 2^e_m, row m of dZ by
+    2^-e_m with e_m in [-40, 40] -- dW = dZ^T X and db are unchanged in exact arithmetic -- and a 1e+30 / 1e-30 row mix."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(77)
+    M, N, K = 1000, 160, 130
+    x = rng.normal(size=(M, K)); dz = rng.normal(size=(M, N))
+    ref_w, ref_b = dz.T @ x, dz.sum(0)
+    em = rng.integers(-40, 41, size=M)
+    xs = (x * 2.0 ** em[:, None]).astype(np.float32); dzs = (dz * 2.0 ** (-em)[:, None]).astype(np.float32)
+    ref_w = dzs.astype(np.float64).T @ xs.astype(np.float64)
+    xp, dzp = ops.mlp_planes_from_f32(dev(xs), True), ops.mlp_planes_from_f32(dev(dzs), False)
+    dW, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+    ops.mlp_wgrad_split(M, [dzp], [xp], [None], [None], [dW], [db])
+    PARITY.check("split_bf16_adversarial", "wgrad rows 2^+-40", "dW", dW.cpu().numpy(), ref_w)
+    assert np.max(np.abs(dW.cpu().numpy() - ref_w) / (np.abs(dzs.astype(np.float64)).T @ np.abs(xs.astype(np.float64)))) < 1e-5
+    ref_b = dzs.astype(np.float64).sum(0)
+    PARITY.check("split_bf16_adversarial", "wgrad rows 2^+-40", "db", db.cpu().numpy(), ref_b, floor=float(np.abs(dzs.astype(np.float64)).sum(0).max()) * 0.05)
+    xm = x.astype(np.float32).copy(); xm[0::2] *= np.float32(1e30); xm[1::2] *= np.float32(1e-30)
+    dzm = (dz * 1e-30).astype(np.float32)
+    ref = dzm.astype(np.float64).T @ xm.astype(np.float64)
+    ops.mlp_wgrad_split(M, [ops.mlp_planes_from_f32(dev(dzm), False)], [ops.mlp_planes_from_f32(dev(xm), True)], [None], [None], [dW], [db])
+    PARITY.check("split_bf16_adversarial", "wgrad 1e30 with 1e-30", "dW", dW.cpu().numpy(), ref)
+
+
 @pytest.mark.parametrize("M,N,K", [(12288, 2000, 2000), (12288, 400, 40), (1000, 40, 400), (777, 129, 513), (16, 33, 17), (5000, 600, 120)])
 def test_planes_from_f32_feeds_split_wgrad(M, N, K):
     """clica_mlp_planes_from_f32 (fp32 -> bf16 planes, for operands of the per-layer kernels of wide encoders) + clica_mlp_wgrad_split
