@@ -482,8 +482,11 @@ def dropin_leg(args, device, steps=40, warmup=8):
                             "whole-encoder kernels (clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad)") if fused else
                            "per-layer GEMM kernels (clica_linear_*): a %d-row encoder call is %d workgroups of 48 rows, below the 128 the "
                            "whole-encoder kernels need to beat them" % (B, (B + 47) // 48))
-    res["what"] = ("reference train_step structure (main_mlp.py:258-285: two encoder calls of B rows, 3 host syncs per step, eager "
-                   "launches, torch autograd) on the drop-in modules")
+    from cl_ica_amd import lazy
+    res["what"] = ("reference train_step structure (main_mlp.py:258-285: two encoder calls of B rows, roll in the graph, 3 host syncs per "
+                   "step, eager launches, torch autograd) on the drop-in modules; deferred stacking of the two encoder calls "
+                   f"{'on' if lazy.enabled() else 'off'} (CLICA_DROPIN_LAZY), roll detection -> symmetric loss backward "
+                   f"{'on' if losses._sym_enabled() else 'off'} (CLICA_DROPIN_SYM)")
     return res
 
 

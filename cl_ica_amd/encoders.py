@@ -198,7 +198,7 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         kinds = [ops.mlp_wgrad_split_kind(w.shape[0], w.shape[1]) for w in ws]       # 0: matrix-core weight gradient from planes
         # layer l's output: as planes (with the ones column) if the NEXT layer's weight gradient reads planes, as fp32 if it reads
         # fp32 (tiny-dimension layer) or if it is the result
-        planes = [ops.mlp_planes_alloc(M, ws[l].shape[0], True, dev) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
+        planes = [ops.mlp_planes_alloc(M, ws[l].shape[0], True, dev, zero=False) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
         outs = [torch.empty((M, ws[l].shape[0]), dtype=torch.float32, device=dev) if (l == L - 1 or kinds[l + 1] == 1) else None
                 for l in range(L)]
         masks = ops.mlp_signmask_alloc(M, L - 1, dev, zero=False) + [None]
@@ -227,7 +227,7 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         # dZ of layer j = l - 1: planes for a matrix-core weight gradient, fp32 for a tiny-dimension one (and for d loss / d input)
         want_f32 = {j: (kinds[j] == 1 or (j == 0 and need[0])) for j in range(L - 1)}
         dz_f32 = {j: (torch.empty((M, ws[j].shape[0]), dtype=torch.float32, device=dev) if want_f32[j] else None) for j in range(L - 1)}
-        dz_pl = {j: (ops.mlp_planes_alloc(M, ws[j].shape[0], False, dev) if kinds[j] == 0 else None) for j in range(L - 1)}
+        dz_pl = {j: (ops.mlp_planes_alloc(M, ws[j].shape[0], False, dev, zero=False) if kinds[j] == 0 else None) for j in range(L - 1)}
         if L > 1:
             ops.mlp_dgrad_chain_split(gy, [ws[l] for l in chain], packed_t, [dz_f32[l - 1] for l in chain], slope,
                                       masks_chain=[masks[l - 1] for l in chain], planes=[dz_pl[l - 1] for l in chain])
@@ -339,7 +339,10 @@ class FusedMLP(nn.Sequential):
         # result, both batches run as one stacked launch per phase (cl_ica_amd/lazy.py); any other use computes it right away.
         if (lazy.enabled() and torch.is_grad_enabled() and x.is_cuda and (x.shape[0] + 47) // 48 < 256
                 and any(p.requires_grad for p in params if p is not None)):
-            every = [p for p in self.parameters()]
+            every = [p for p in params if p is not None]      # (not self.parameters(): a module-tree walk per call)
+            for m in mods:
+                if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
+                    every += [q for q in m._parameters.values() if q is not None]
             return lazy.defer(self, x, compute, (x.shape[0], linears[-1].out_features), every)
         return compute(x)
 

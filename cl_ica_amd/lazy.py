@@ -60,29 +60,35 @@ class _Pending:
         return x.shape[1:] == x0.shape[1:] and x.dtype == x0.dtype and x.device == x0.device
 
     def flush(self):
+        """Run the pending calls (one compute over the stacked inputs) and hand every LazyOut its rows.  Returns the list of results in
+        call order (None if the calls had gone stale)."""
         items, self.items = self.items, []
         _ALL_PENDING.discard(self)
         if getattr(self.owner, "_clica_pending", None) is self:
             self.owner._clica_pending = None
         if not items:
-            return
+            return None
         if self.stale():
             # a parameter was written in place (not by an optimizer: those flush first, see the step pre-hook below) while the call
             # was pending: its value for the OLD parameters can no longer be computed.  Nobody may have wanted it (a discarded
             # evaluation call); whoever does gets the error.
             for _, lz in items:
-                lz._stale = True
-            return
+                if lz is not None:
+                    lz._stale = True
+            return None
         with torch.enable_grad():      # the call was made with grad mode on; the first use may sit inside a no_grad block
             if len(items) == 1:
-                y = self.compute(items[0][0])
-                items[0][1]._value = y
-                return
-            ystack = self.compute(torch.cat([x for x, _ in items], 0))
-            off = 0
-            for x, lz in items:
-                lz._value = ystack[off:off + x.shape[0]]
-                off += x.shape[0]
+                vals = [self.compute(items[0][0])]
+            else:
+                ystack = self.compute(torch.cat([x for x, _ in items], 0))
+                vals, off = [], 0
+                for x, _ in items:
+                    vals.append(ystack[off:off + x.shape[0]])
+                    off += x.shape[0]
+        for (_, lz), v in zip(items, vals):
+            if lz is not None:
+                lz._value = v
+        return vals
 
 
 class LazyOut(torch.Tensor):
@@ -137,12 +143,10 @@ def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor
     run NOW (one launch); the result of this call is returned as a plain tensor.  Otherwise a LazyOut is returned."""
     pend: Optional[_Pending] = getattr(owner, "_clica_pending", None)
     if pend is not None and pend.compatible(x):
-        lz = LazyOut(pend, out_shape, x.dtype, x.device, True)
-        pend.items.append((x, lz))
-        pend.flush()
-        return lz.materialize()
+        pend.items.append((x, None))   # the call that completes the stack needs no placeholder: its rows are returned right away
+        return pend.flush()[-1]
     if pend is not None:
-        pend.flush()                   # an incompatible second call: the first one runs on its own
+        pend.flush()                   # an incompatible (or stale) first call: it runs (or is dropped) on its own
     pend = _Pending(owner, compute, params, max_items)
     owner._clica_pending = pend
     lz = LazyOut(pend, out_shape, x.dtype, x.device, True)

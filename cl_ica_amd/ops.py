@@ -173,11 +173,22 @@ def mlp_pack_split_both(weights, packed: Optional[torch.Tensor] = None, packed_t
     return packed, packed_t
 
 
-def mlp_planes_alloc(M: int, width: int, ones: bool, device) -> torch.Tensor:
-    """Opaque buffer for the bf16-plane copy of an [M, width] layer output (operand format of `mlp_wgrad_split`)."""
-    nb = C.c_size_t()
-    check(load().clica_mlp_planes_bytes(int(M), int(width), 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
-    return torch.zeros(nb.value, dtype=torch.uint8, device=device)
+_PLANES_BYTES = {}
+
+
+def mlp_planes_alloc(M: int, width: int, ones: bool, device, zero: bool = True) -> torch.Tensor:
+    """Opaque buffer for the bf16-plane copy of an [M, width] layer output (operand format of `mlp_wgrad_split`).
+    `zero=False`: uninitialised -- for buffers a producer kernel writes completely (the whole-stack kernels and
+    `mlp_planes_from_f32` write every piece of every 16-row group, padding and ones column included; pinned by the NaN-fill in
+    tests/test_gpu_mlp.py::test_split_bf16_wgrad_matches_fp64).  The drop-in path allocates per call: zeroing was two ~160 MB
+    memsets per training step."""
+    key = (int(M), int(width), bool(ones))
+    nbytes = _PLANES_BYTES.get(key)
+    if nbytes is None:
+        nb = C.c_size_t()
+        check(load().clica_mlp_planes_bytes(int(M), int(width), 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
+        nbytes = _PLANES_BYTES[key] = nb.value
+    return (torch.zeros if zero else torch.empty)(nbytes, dtype=torch.uint8, device=device)
 
 
 def mlp_planes_from_f32(x: torch.Tensor, ones: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -185,7 +196,7 @@ def mlp_planes_from_f32(x: torch.Tensor, ones: bool, out: Optional[torch.Tensor]
     (x, ldx) = _mat("x", x)
     M, width = x.shape
     if out is None:
-        out = mlp_planes_alloc(M, width, ones, x.device)
+        out = mlp_planes_alloc(M, width, ones, x.device, zero=False)
     check(load().clica_mlp_planes_from_f32(x.data_ptr(), ldx, M, width, 1 if ones else 0, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32")
     return out
 

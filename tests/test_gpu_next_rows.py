@@ -204,6 +204,119 @@ def test_dropin_fused_path_matches_per_layer_path(opt_kind, monkeypatch):
     assert res["1"][0][2][0] < res["1"][0][0][0]          # it trains: the packs followed the weights
 
 
+@pytest.mark.parametrize("B,p", [(6144, 2), (1000, 1), (333, 3)])
+def test_dropin_lazy_stacking_and_symmetric_loss_match_plain_path(B, p, monkeypatch):
+    """the reference's train_step structure (main_mlp.py:258-285: two encoder calls, roll, LpSimCLRLoss, backward)
+    on the drop-in modules.  Default path: the first f(.) is deferred, the second call stacks both batches into one launch per phase
+    (cl_ica_amd/lazy.py), and the loss recognises z3_rec = roll(z1_rec) in the autograd graph and takes the one-sweep symmetric backward.
+    Against the same step with both mechanisms off (CLICA_DROPIN_LAZY=0, CLICA_DROPIN_SYM=0: two half-size encoder passes, rolled copy,
+    generic two-sweep backward) and against the fp64 oracle: loss, per-item losses, embeddings, every parameter gradient."""
+    from cl_ica_amd import encoders, lazy, losses, optim
+    n = 10
+    res = {}
+    g = torch.Generator().manual_seed(B)
+    x1 = torch.rand(B, n, generator=g).cuda()
+    x2 = (x1 + 0.05 * torch.randn(B, n, generator=g).cuda()).clamp(0, 1)
+    for mode in ("fast", "plain"):
+        monkeypatch.setenv("CLICA_DROPIN_LAZY", "1" if mode == "fast" else "0")
+        monkeypatch.setenv("CLICA_DROPIN_SYM", "1" if mode == "fast" else "0")
+        f = build_mlp_n10().cuda()
+        opt = optim.Adam(f.parameters(), lr=1e-3)
+        L = losses.LpSimCLRLoss(p=p, tau=1.0, simclr_compatibility_mode=True)
+        opt.zero_grad()
+        a = f(x1)
+        assert isinstance(a, lazy.LazyOut) == (mode == "fast") and tuple(a.shape) == (B, n) and a.device.type == "cuda"
+        b = f(x2)
+        assert not isinstance(b, lazy.LazyOut)
+        z3 = torch.roll(a, 1, 0)
+        assert losses._rolled_rows_of(z3, lazy.plain(a))
+        tot, item, (pos, neg) = L(None, None, None, a, b, z3)
+        tot.backward()
+        res[mode] = dict(loss=tot.item(), item=item.detach().cpu().numpy(), pos=pos.item(), neg=neg.item(), a=lazy.plain(a).detach().cpu().numpy(),
+                         b=b.detach().cpu().numpy(), grads=[q.grad.detach().cpu().numpy().copy() for q in f.parameters()], f=f)
+    fam, case = "dropin_lazy_sym", f"B={B} p={p}"
+    lin = [m for m in res["fast"]["f"] if isinstance(m, torch.nn.Linear)]
+    P = O.MLPParams([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin], [m.bias.detach().cpu().numpy().astype(np.float64) for m in lin])
+    y, cache = O.mlp_forward(P, np.concatenate([x1.cpu().numpy(), x2.cpu().numpy()]))
+    ref = O.lp_simclr_loss(y[:B], y[B:], np.roll(y[:B], 1, 0), p=p, compat=True)
+    for mode in ("fast", "plain"):
+        r = res[mode]
+        PARITY.check(fam, case, f"embeddings z1 [{mode}]", r["a"], y[:B]); PARITY.check(fam, case, f"embeddings z2 [{mode}]", r["b"], y[B:])
+        PARITY.check(fam, case, f"loss [{mode}]", r["loss"], ref["loss_mean"])
+        PARITY.check(fam, case, f"loss_i [{mode}]", r["item"], ref["loss_i"])
+    # gradients: the two HIP paths against each other (p = 1 sign ties / LeakyReLU kinks make an end-to-end fp64 comparison a test of
+    # those, see test_c3_engine_full_size_vs_oracle); the last bias has an exactly-zero gradient
+    for k, (u, v) in enumerate(zip(res["fast"]["grads"][:-1], res["plain"]["grads"][:-1])):
+        PARITY.check(fam, case, f"grad{k} fast vs plain", u, v, tol=1e-5 if p != 1 else 5e-5, note=None if p != 1 else "p = 1 sign ties (see p1_tie_analysis)")
+    assert np.abs(res["fast"]["grads"][-1]).max() < 1e-6 * max(1.0, float(np.abs(res["fast"]["grads"][-2]).max()) * 1e3)
+
+
+def build_mlp_n10():
+    from test_gpu_configs import build_mlp
+    return build_mlp(10, [100, 500, 500, 100], None, gain=1.8)
+
+
+def test_dropin_lazy_output_single_use_and_per_item_upstream():
+    """A deferred output that is used before a second call runs on its own; a per-item upstream gradient takes the aliasing generic
+    backward inside the symmetric node (clica_lp_loss_bwd with z3 = z1, column part accumulated) -- against the plain path."""
+    from cl_ica_amd import encoders, lazy, losses
+    torch.manual_seed(3)
+    f = encoders.get_mlp(6, 6, [32, 64]).cuda()
+    x1, x2 = torch.rand(200, 6, device="cuda"), torch.rand(200, 6, device="cuda")
+    a = f(x1)
+    assert isinstance(a, lazy.LazyOut)
+    s = float(a.sum())                                    # any torch function materialises it
+    assert a._value is not None and abs(s - float(f(x1).sum())) < 1e-4 * abs(s)
+    L = losses.LpSimCLRLoss(p=2, tau=0.7, simclr_compatibility_mode=False)
+    w = torch.rand(200, device="cuda")
+    for q in f.parameters():
+        q.grad = None
+    a, b = f(x1), f(x2)
+    tot, item, _ = L(None, None, None, a, b, torch.roll(a, 1, 0))
+    (tot + (w * item).sum()).backward()
+    outs = [[q.grad.clone() for q in f.parameters()]]
+    # the same through the GENERIC node (autograd routes d loss / d z3 back through the roll)
+    import os
+    os.environ["CLICA_DROPIN_SYM"] = "0"
+    try:
+        for q in f.parameters():
+            q.grad = None
+        a, b = f(x1), f(x2)
+        tot, item, _ = L(None, None, None, a, b, torch.roll(a, 1, 0))
+        (tot + (w * item).sum()).backward()
+        ref = [q.grad.clone() for q in f.parameters()]
+    finally:
+        os.environ["CLICA_DROPIN_SYM"] = "1"
+    for k, (u, v) in enumerate(zip(outs[0][:-1], ref[:-1])):
+        PARITY.check("dropin_lazy_sym", "per-item upstream", f"grad{k}", u.cpu().numpy(), v.cpu().numpy())
+
+
+def test_dropin_autograd_grad_does_not_touch_the_arena():
+    """with the flat optimizer installed, torch.autograd.grad(y, x) / jacobian (reference losses.py:279) through the encoder
+    must not add dW / db into the parameters' .grad, and autograd.grad(loss, params) must return the gradients."""
+    from cl_ica_amd import encoders, optim
+    torch.manual_seed(0)
+    f = encoders.get_mlp(10, 10, [100, 500, 500, 100]).cuda()
+    opt = optim.Adam(f.parameters(), lr=1e-3)
+    opt.zero_grad()
+    x = torch.rand(6144, 10, device="cuda", requires_grad=True)
+    y = f(x)
+    (dx,) = torch.autograd.grad(y.sum(), x)
+    assert dx.shape == x.shape and float(dx.abs().max()) > 0
+    assert float(opt.grad_arena.abs().max()) == 0.0                  # nothing leaked into the arena
+    y = f(x)
+    gs = torch.autograd.grad((y ** 2).mean(), list(f.parameters()))
+    assert all(g is not None and torch.isfinite(g).all() for g in gs) and float(opt.grad_arena.abs().max()) == 0.0
+    y = f(x)
+    (y ** 2).mean().backward()                                         # the plain backward accumulates in place
+    for q, g in zip(f.parameters(), gs):
+        PARITY.check("dropin_inplace_grads", "autograd.grad vs backward", "param grad", q.grad.cpu().numpy(), g.cpu().numpy(), tol=2e-6, note="HIP vs HIP")
+    hits = []
+    h = next(f.parameters()).register_hook(lambda g: hits.append(1))   # a tensor hook must fire: in-place accumulation steps aside
+    opt.zero_grad(); y = f(x); (y ** 2).mean().backward(); h.remove()
+    assert hits and float(next(f.parameters()).grad.abs().max()) > 0
+
+
 def test_mixing_net_activations_goldens(golden):
     """Every hidden activation construct_invertible_mlp offers (--act-fct relu | leaky_relu | elu | smooth_leaky_relu | softplus,
     invertible_network_utils.py:51-66): the reference's weights loaded into MixingMLP, forward on the HIP kernel vs G17; the

@@ -250,3 +250,65 @@ def test_n3_our_checkpoints_load_into_the_reference():
         r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "ours.pth")], capture_output=True, text=True,
                            env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_lazy_stacking_mechanics_on_cpu():
+    """cl_ica_amd/lazy.py with a stand-in compute function (no device code involved): two calls of one owner become ONE compute over
+    the stacked batch with an ordinary autograd graph; a single call runs on first use; metadata needs no compute; optimizers flush
+    pending calls before they write the parameters; an in-place parameter write makes a pending output unusable (error on use only);
+    and the loss's roll detection reads torch.roll(z1, s, 0) off the graph."""
+    import torch
+    from cl_ica_amd import lazy, losses
+    net = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.LeakyReLU(), torch.nn.Linear(5, 2))
+    calls = []
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            def compute(xx):
+                calls.append(xx.shape[0])
+                return self.net(xx)
+            return lazy.defer(self, x, compute, (x.shape[0], 2), list(self.parameters()))
+    m = M()
+    x1, x2 = torch.randn(4, 3), torch.randn(4, 3)
+    a = m(x1)
+    assert isinstance(a, lazy.LazyOut) and a.shape == (4, 2) and a.dtype == torch.float32 and a.dim() == 2 and len(a) == 4 and calls == []
+    b = m(x2)
+    assert not isinstance(b, lazy.LazyOut) and calls == [8]                       # one compute over the stack
+    av = lazy.plain(a)
+    z3 = torch.roll(a, 1, 0)
+    assert type(z3) is torch.Tensor and losses._rolled_rows_of(z3, av) and not losses._rolled_rows_of(torch.roll(av, 1, 1), av)
+    assert not losses._rolled_rows_of(torch.roll(b, 1, 0), av)
+    ((a * b).sum() + z3.sum()).backward()
+    got = [p.grad.clone() for p in m.parameters()]
+    for p in m.parameters():
+        p.grad = None
+    ((net(x1) * net(x2)).sum() + torch.roll(net(x1), 1, 0).sum()).backward()
+    assert all(torch.allclose(u, p.grad, atol=1e-6) for u, p in zip(got, m.parameters())) and torch.allclose(av, net(x1))
+    calls.clear()
+    c = m(x1)
+    assert calls == [] and abs(float(c.detach().sum()) - float(net(x1).sum())) < 1e-6 and calls == [4]      # first use computes it alone
+    calls.clear()
+    d = m(x1)
+    ref = net(x1).detach().clone()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()                                                                      # global step pre-hook: flushed with the OLD parameters
+    assert calls == [4] and torch.allclose(d.detach(), ref) and not torch.allclose(net(x1), ref)
+    e = m(x1)
+    with torch.no_grad():
+        next(m.parameters()).add_(1.0)
+    f2 = m(x2)                                                                      # the stale call is dropped, not stacked
+    with pytest.raises(RuntimeError, match="modified in place"):
+        e.sum()
+    assert torch.allclose(lazy.plain(f2), net(x2))
+    g1 = m(x1)
+    with torch.no_grad():
+        _ = g1 * 1
+    assert lazy.plain(g1).grad_fn is not None                                       # first use inside no_grad keeps the graph
+    leaf = torch.randn(5, 2, requires_grad=True)
+    assert losses._rolled_rows_of(torch.roll(leaf, 2, 0), leaf) and not losses._rolled_rows_of(torch.roll(leaf * 1, 1, 0), leaf)

@@ -51,4 +51,4 @@ for _ in range(50):
     one()
 torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats(os.environ.get("SORT", "tottime")).print_stats(45); print(s.getvalue()[:9000])
