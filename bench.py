@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` leg (BASELINE config 3 on one rank: n = 40, sphere, p = 1, B = 6144, with the local pool and with "
                          "the emulated 49 152-row pool of the 8-GPU job; N = 1 only)")
+    ap.add_argument("--config", default=None, choices=("c4", "c5"),
+                    help="run ONLY the BASELINE configs[3] (c4: 3DIdent ResNet-18 train_step, batch 1024) or configs[4] (c5: KITTI-masks "
+                         "Solver iteration, batch 2048) leg and print its JSON line (used under rocprofv3: tools/profile_round.sh)")
+    ap.add_argument("--no-conv-configs", action="store_true", help="skip the c4 / c5 legs of `secondary`")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
@@ -613,6 +617,66 @@ def secondary_leg(args, device, steps=20, windows=3):
     return res
 
 
+def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
+    """BASELINE configs[3] / configs[4] on one GPU: the conv encoders run on PyTorch-ROCm / MIOpen as north_star
+    prescribes, head / loss / optimizer on the HIP library, the training step is the reference's own.
+      c4  main_3dident.py:467-503 train_step: ResNet-18 (cl_ica_amd/resnet.py, torchvision's layout) on (1024, 3, 64, 64) x 2 views,
+          channels-last, BatchNorm on batch statistics, LeakyReLU -> Linear(30 -> 3) -> position-only box head, LpSimCLRLoss(p = 2), flat Adam
+      c5  kitti_masks/solver.py:61-74: BetaVAE_H (five k = 4 convs + Linear(256 -> 5)) on (2048, 1, 64, 64) Bernoulli(0.1) masks = 1024
+          pairs, z_dim 5, p = 1, flat Adam; the whole global batch of the 4-rank job on ONE GPU (per rank it is 512 images / 256 pairs)
+    Synthetic inputs of the reference's shapes (no dataset in the image), no host sync inside the timed windows."""
+    import types
+    from cl_ica_amd.optim import Adam
+    torch.manual_seed(0)
+    if which == "c4":
+        from cl_ica_amd import threedident as T
+        a = types.SimpleNamespace(position_only=True, rotation_and_color_only=False, rotation_only=False, color_only=False,
+                                  non_periodic_rotation_and_color=False, box_constraint="fix", sphere_constraint=None,
+                                  unsupervised_loss="l2", identity_solution=False, encoder="rn18")
+        f = T.setup_f(a, 3, 0).to(device).to(memory_format=torch.channels_last)
+        f.train()
+        loss = T.make_unsupervised_loss(a, 3)
+        opt = Adam(f.parameters(), lr=1e-4)
+        x1 = torch.randn(1024, 3, 64, 64, device=device).contiguous(memory_format=torch.channels_last)
+        x2 = (x1 + 0.1 * torch.randn_like(x1)).contiguous(memory_format=torch.channels_last)
+
+        def step():
+            return T.train_step(((None, None), (x1, x2)), loss, opt, f, sync=False)[0]
+        n_params = sum(p.numel() for p in f.parameters())
+        work = ("main_3dident.py train_step (:467-503): ResNet-18 backbone (MIOpen, channels-last) on (1024, 3, 64, 64) x 2 views -> HIP "
+                "LeakyReLU / Linear(30, 3) / Softclip head -> HIP LpSimCLRLoss(p = 2) -> backward -> flat HIP Adam")
+    else:
+        from cl_ica_amd.kitti_masks.solver import Solver
+        a = types.SimpleNamespace(cuda=True, ckpt_dir="/tmp", output_dir="/tmp", dataset="kitti", max_iter=1, z_dim=5, num_channel=1,
+                                  lr=1e-4, beta1=0.9, beta2=0.999, ckpt_name="last", log_step=1000, save_step=10 ** 9, box_norm=True, p=1)
+        S = Solver(a, None)
+        S.net_mode(train=True)
+        x = (torch.rand(2048, 1, 64, 64, device=device) < 0.1).float()
+
+        def step():
+            return S.train_iteration(x)
+        n_params = sum(p.numel() for p in S.net.parameters())
+        work = ("kitti_masks Solver.train body (solver.py:61-74): BetaVAE_H conv encoder (MIOpen) on (2048, 1, 64, 64) binary masks = 1024 "
+                "pairs -> HIP Linear(256, 5) / Softclip -> strided views -> HIP LpSimCLRLoss(p = 1) -> backward -> flat HIP Adam")
+    for _ in range(warmup):
+        last = step()
+    torch.cuda.synchronize(device)
+    ws = []
+    for _ in range(windows):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            last = step()
+        e1.record()
+        torch.cuda.synchronize(device)
+        ws.append(e0.elapsed_time(e1) * 1e-3)
+    el = float(np.median(ws))
+    return {"workload": work, "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": windows,
+            "images_per_s": round((2048 if which == "c5" else 2048) * steps / el, 1), "parameters": int(n_params), "dtype": "f32",
+            "final_loss": float(last.item()), "launch": "eager (torch autograd drives MIOpen and the HIP library)",
+            "kernel_shares": "profiles/r4_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % (which, which)}
+
+
 def main():
     args = parse()
     from cl_ica_amd.distributed import init_from_env
@@ -621,6 +685,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.config is not None:        # one conv-config leg on its own (rank 0 of a one-rank run)
+        if world != 1:
+            raise SystemExit("--config c4|c5 is a one-GPU leg")
+        ent = conv_config_leg(args.config, device, steps=args.steps if args.steps != 300 else 20)
+        print(json.dumps({"metric": "training steps/sec (BASELINE configs[%d])" % (3 if args.config == "c4" else 4), "n_gpus": 1,
+                          "higher_is_better": True, "data": "synthetic", **ent}))
+        return
     tr = build_trainer(args, device, world)
     use_graph = capture_or_eager(tr, args, rank, world, device)
     # "median of 5 windows" -- a short driver run (--steps 20 = ~11 ms of GPU time per window) is then not at the
@@ -703,6 +774,10 @@ def main():
         out["native_fp32"] = leg
     if rank == 0 and world == 1 and not args.no_secondary and (args.n, args.space_type, args.p) == (10, "box", 2):
         out["secondary"] = secondary_leg(args, device)
+        if not args.no_conv_configs:
+            out["secondary"]["c4_3dident_resnet18"] = conv_config_leg("c4", device)
+            torch.cuda.empty_cache()
+            out["secondary"]["c5_kitti_masks"] = conv_config_leg("c5", device)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -67,10 +67,13 @@ def setup_f(args, n_non_angular_latents: int, n_angular_latents: int,
     if base_encoder is None:
         try:
             from torchvision import models       # not in this image; present in the reference's environment
+            base_encoder = {"rn18": models.resnet18, "rn50": models.resnet50, "rn101": models.resnet101,
+                            "rn152": models.resnet152}[args.encoder]
         except ImportError as e:
-            raise ImportError("torchvision is not installed: pass base_encoder=<callable building the backbone>") from e
-        base_encoder = {"rn18": models.resnet18, "rn50": models.resnet50, "rn101": models.resnet101,
-                        "rn152": models.resnet152}[args.encoder]
+            if getattr(args, "encoder", "rn18") != "rn18":
+                raise ImportError("torchvision is not installed: pass base_encoder=<callable building the backbone> "
+                                  "(only the default rn18 has a stand-in, cl_ica_amd/resnet.py)") from e
+            from .resnet import resnet18 as base_encoder      # same architecture and state-dict keys as torchvision's
     return nn.Sequential(base_encoder(False, num_classes=n_latents * 10), layers.LeakyReLU(),
                          HipLinear(n_latents * 10, n_latents), rescaling)
 

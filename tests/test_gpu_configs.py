@@ -525,39 +525,6 @@ def test_c4_3dident_head_and_loss_goldens(golden):
 
 
 # ================================================================================================== C4 with a real conv backbone
-class _BasicBlock(torch.nn.Module):
-    def __init__(self, cin, cout, stride):
-        super().__init__()
-        nn = torch.nn
-        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False); self.bn1 = nn.BatchNorm2d(cout)
-        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False); self.bn2 = nn.BatchNorm2d(cout)
-        self.down = None
-        if stride != 1 or cin != cout:
-            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
-
-    def forward(self, x):
-        y = torch.relu(self.bn1(self.conv1(x)))
-        y = self.bn2(self.conv2(y))
-        return torch.relu(y + (x if self.down is None else self.down(x)))
-
-
-class _ResNet18(torch.nn.Module):
-    """The ResNet-18 architecture (7x7 stem, max-pool, four stages of two basic blocks, global average pool, fc) in plain
-    torch.nn -- torchvision is not in the image.  Stands in for torchvision.models.resnet18(num_classes=...) of
-    main_3dident.py:287-292; runs on PyTorch-ROCm / MIOpen as BASELINE config 4 prescribes."""
-
-    def __init__(self, num_classes):
-        super().__init__()
-        nn = torch.nn
-        self.stem = nn.Sequential(nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
-        cfg = [(64, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 1), (128, 256, 2), (256, 256, 1), (256, 512, 2), (512, 512, 1)]
-        self.blocks = nn.Sequential(*[_BasicBlock(a, b, s) for a, b, s in cfg])
-        self.fc = nn.Linear(512, num_classes)
-
-    def forward(self, x):
-        return self.fc(torch.flatten(torch.nn.functional.adaptive_avg_pool2d(self.blocks(self.stem(x)), 1), 1))
-
-
 @pytest.mark.parametrize("mode", ["position_only_l2", "rotation_and_color_only_periodic"])
 def test_c4_resnet18_backbone_feeds_the_hip_head(mode):
     """BASELINE config 4 end to end at its real shape: (1024, 3, 64, 64) images x 2 views -> ResNet-18 (plain torch.nn, MIOpen;
@@ -581,7 +548,7 @@ def test_c4_resnet18_backbone_feeds_the_hip_head(mode):
                                   unsupervised_loss="l2", identity_solution=False, encoder="rn18")
         n_non, n_ang = 0, 7
     torch.manual_seed(0)
-    f = T.setup_f(a, n_non, n_ang, base_encoder=lambda pretrained, num_classes: _ResNet18(num_classes)).to("cuda")
+    f = T.setup_f(a, n_non, n_ang).to("cuda")              # torchvision absent: the stand-in of cl_ica_amd/resnet.py
     f = f.to(memory_format=torch.channels_last)
     f.train()                                   # BatchNorm on batch statistics, as during the reference's training
     loss = T.make_unsupervised_loss(a, n_non)
@@ -602,7 +569,7 @@ def test_c4_resnet18_backbone_feeds_the_hip_head(mode):
     la[0].backward()
     for name, prm in f[0].named_parameters():
         assert prm.grad is not None and bool(torch.isfinite(prm.grad).all()), name
-    assert float(f[0].stem[0].weight.grad.abs().max()) > 0 and float(f[0].fc.weight.grad.abs().max()) > 0
+    assert float(f[0].conv1.weight.grad.abs().max()) > 0 and float(f[0].fc.weight.grad.abs().max()) > 0
     ga = {k: prm.grad.clone() for k, prm in f.named_parameters() if k in head_names}
     dfa = [t.grad.clone() for t in feats]
     # (b) the same head and loss fed the DETACHED backbone features (what G15 pins against the reference)

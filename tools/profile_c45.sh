@@ -1,0 +1,14 @@
+#!/bin/bash
+# Kernel-trace stats of BASELINE configs[3] / [4] on one GPU:  bash tools/profile_c45.sh  (GPU box, via gpurun)
+# -> gpurun_out/profile_r4_c4|c5/{t_kernel_stats.csv, bench.json}; condensed into profiles/ by tools/conv_share_summary.py
+set -u
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd /tmp && export TMPDIR=/tmp
+for c in c4 c5; do
+  OUT=$ROOT/gpurun_out/profile_r4_$c
+  mkdir -p $OUT
+  rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- python $ROOT/bench.py --config $c --steps 10 > $OUT/bench.json 2> $OUT/trace.err
+  find $OUT/trace -name "t_kernel_stats.csv" -exec cp {} $OUT/t_kernel_stats.csv \;
+  rm -rf $OUT/trace
+  tail -1 $OUT/bench.json | cut -c1-300
+done
