@@ -72,12 +72,17 @@ def parse():
     ap.add_argument("--config", default=None, choices=("c4", "c5"),
                     help="run ONLY the BASELINE configs[3] (c4: 3DIdent ResNet-18 train_step, batch 1024) or configs[4] (c5: KITTI-masks "
                          "Solver iteration, batch 2048) leg and print its JSON line (used under rocprofv3: tools/profile_round.sh)")
+    ap.add_argument("--dry-ranks", type=int, default=0,
+                    help="one GPU, one process: plan, capture and run the step exactly as rank 0 of an R-rank data-parallel job would "
+                         "(pool of R x B rows, workspaces, weight-gradient halves, gradient buckets, every collective on a one-rank RCCL "
+                         "group inside the step graph; the other ranks' rows are copies).  Prints the plan and this rank's step time -- NOT "
+                         "a multi-GPU measurement")
     ap.add_argument("--no-conv-configs", action="store_true", help="skip the c4 / c5 legs of `secondary`")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
 
-def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1):
+def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1, dry_ranks=1):
     from cl_ica_amd import encoders, invertible_network_utils as inu
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
     import contextlib, io
@@ -90,10 +95,10 @@ def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1):
     f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 50, n * 50, n * 10])
     spec = SamplerSpec(space=args.space_type, n=n, box=(0.0, 1.0), marginal="uniform", conditional="normal", c_param=0.05, seed=0)
     return ContrastiveTrainer(f, g.weight_stack(), spec, batch_size=args.batch_size, p=args.p, tau=1.0, lr=1e-4,
-                              device=device, process_group=None if world == 1 else dist.group.WORLD,
+                              device=device, process_group=None if (world == 1 and dry_ranks == 1) else dist.group.WORLD,
                               overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward,
                               split_bf16=(not args.native_fp32) if split_bf16 is None else split_bf16,
-                              emulate_pool_ranks=emulate_pool_ranks)
+                              emulate_pool_ranks=emulate_pool_ranks, dry_ranks=dry_ranks, force_collectives=dry_ranks > 1)
 
 
 def _graph_time(fns, reps):
@@ -685,6 +690,23 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_ranks and args.dry_ranks > 1:
+        if world != 1:
+            raise SystemExit("--dry-ranks runs in ONE process on one GPU")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        trd = build_trainer(args, device, 1, dry_ranks=args.dry_ranks)
+        use_graph = capture_or_eager(trd, args, 0, 1, device)
+        w, _ = timed_windows(trd, args.steps if args.steps != 300 else 50, args.warmup, 3, 1, device)
+        el = float(np.median(w)); nst = args.steps if args.steps != 300 else 50
+        plan = trd.plan_summary()
+        print(json.dumps({"metric": f"DRY RUN: rank 0 of a {args.dry_ranks}-rank job on one GPU (B={args.batch_size}/rank, n={args.n}) -- not a multi-GPU measurement",
+                          "value": nst / el, "unit": "steps/s (this rank's compute + one-rank collectives)", "ms_per_step": 1e3 * el / nst,
+                          "n_gpus": 1, "launch": "hipGraph replay with the RCCL collectives captured" if use_graph else "eager",
+                          "final_loss": float(trd.loss_out[3 * trd.B].item()), "plan": plan}))
+        dist.destroy_process_group()
+        return
     if args.config is not None:        # one conv-config leg on its own (rank 0 of a one-rank run)
         if world != 1:
             raise SystemExit("--config c4|c5 is a one-GPU leg")

@@ -67,7 +67,7 @@ class ContrastiveTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
                  force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True,
-                 split_bf16: Optional[bool] = None, g_act_kind: int = 0, emulate_pool_ranks: int = 1):
+                 split_bf16: Optional[bool] = None, g_act_kind: int = 0, emulate_pool_ranks: int = 1, dry_ranks: int = 1):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -90,6 +90,15 @@ class ContrastiveTrainer:
         # pool holds R copies of the local embeddings (R x B rows, device-to-device copies stand in for the two all-gathers), so
         # the pair sweeps do the work they do on an R-GPU node.  Not a training mode: every negative counts R times.
         self.emulate_pool = int(emulate_pool_ranks) if (self.world == 1 and not self.dp) else 1
+        # DRY RUN of an R-rank job on one GPU (bench.py --dry-ranks R, tests/test_gpu_engine.py): this process plans and runs exactly
+        # what rank 0 of an R-rank data-parallel job would -- pool of R x B rows, loss workspaces and stream splits for that pool, the
+        # two-half weight-gradient launch, the gradient buckets, 1 / R gradient scale, every collective issued on the (world-1) RCCL
+        # group and captured into the step graph -- with the other ranks' contributions stood in for by copies of its own (all-gather
+        # results replicated, all-reduce over one rank).  Whatever an 8-GPU run can trip over on the host side (a workspace sized for
+        # the wrong plan, a capture RCCL refuses, a bucket boundary off by one) trips here; what it cannot show is the wire.
+        self.dry_ranks = int(dry_ranks) if (self.world == 1 and self.dp) else 1
+        if int(dry_ranks) > 1 and self.dry_ranks == 1:
+            raise ValueError("dry_ranks needs an initialised one-rank process group and force_collectives=True")
         if self.p == 0:
             raise NotImplementedError("p=0 (SimCLRLoss) runs through cl_ica_amd.losses.SimCLRLoss, not the fused engine")
 
@@ -207,7 +216,7 @@ class ContrastiveTrainer:
         self.side_stream = torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.overlap_backward) else None
         self.dy = torch.empty((R, n), **f32)
         self.loss_out = torch.empty(3 * B + 3, **f32)
-        Bg = B * self.world * self.emulate_pool
+        Bg = B * self.world * self.emulate_pool * self.dry_ranks
         pooled = self.dp or self.emulate_pool > 1
         self.z_all = torch.empty((Bg, n), **f32) if pooled else None
         self.lse_all = torch.empty((Bg,), **f32) if pooled else None
@@ -414,8 +423,11 @@ class ContrastiveTrainer:
         y1, y2 = self.y[:B], self.y[B:]
         lse = o[2 * B:3 * B]
         emu = self.emulate_pool > 1
+        dry = self.dry_ranks > 1
         if self.dp:
-            dist.all_gather_into_tensor(self.z_all, y1.contiguous(), group=self.pg)
+            dist.all_gather_into_tensor(self.z_all[:B * self.world] if dry else self.z_all, y1.contiguous(), group=self.pg)
+            if dry:      # the other ranks' rows: copies of this rank's
+                self.z_all.view(self.dry_ranks, B, n)[1:].copy_(self.z_all[:B].unsqueeze(0))
             pool = self.z_all
         elif emu:
             self.z_all.view(self.emulate_pool, B, n).copy_(y1.unsqueeze(0))
@@ -430,7 +442,9 @@ class ContrastiveTrainer:
                                                    self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n,
                                                    self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd_train")
             if self.dp:
-                dist.all_gather_into_tensor(self.lse_all, lse, group=self.pg)
+                dist.all_gather_into_tensor(self.lse_all[:B * self.world] if dry else self.lse_all, lse, group=self.pg)
+                if dry:
+                    self.lse_all.view(self.dry_ranks, B)[1:].copy_(self.lse_all[:B].unsqueeze(0))
             elif emu:
                 self.lse_all.view(self.emulate_pool, B).copy_(lse.unsqueeze(0))
             pool_lse = self.lse_all if (self.dp or emu) else lse
@@ -444,7 +458,9 @@ class ContrastiveTrainer:
                                          o[:B].data_ptr(), o[B:2 * B].data_ptr(), lse.data_ptr(), o[3 * B:].data_ptr(),
                                          None, 0, self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_fwd")
         if self.dp:
-            dist.all_gather_into_tensor(self.lse_all, lse, group=self.pg)
+            dist.all_gather_into_tensor(self.lse_all[:B * self.world] if dry else self.lse_all, lse, group=self.pg)
+            if dry:
+                self.lse_all.view(self.dry_ranks, B)[1:].copy_(self.lse_all[:B].unsqueeze(0))
             pool_lse = self.lse_all
         elif emu:
             self.lse_all.view(self.emulate_pool, B).copy_(lse.unsqueeze(0))
@@ -650,7 +666,7 @@ class ContrastiveTrainer:
         # the last Adam workgroup to finish also advances the device step / RNG counter (no separate tick launch)
         ticked, self._ticked = self._ticked, False
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / self.world,
+                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / (self.world * self.dry_ranks),
                       ticket=self.adam_ticket if (self.fuse_tick and not ticked) else None, t_offset=0 if ticked else 1)
         if not self.fuse_tick and not ticked:
             ops.tick(self.step_dev)
@@ -742,6 +758,25 @@ class ContrastiveTrainer:
             torch.cuda.current_stream(self.device).wait_stream(cap)
         self.graph = graph
         return graph
+
+    def plan_summary(self) -> dict:
+        """What this rank has planned for its data-parallel step: pool size, workspaces, weight-gradient halves, gradient buckets,
+        collectives per step.  bench.py prints it (`ranks` / `dry_ranks`), the dry-run tests assert it."""
+        B, n = self.B, self.n
+        ranks = self.world * self.dry_ranks
+        coll = []
+        if self.dp:
+            coll.append(dict(op="all_gather", what="embeddings z1_rec", bytes_per_rank=4 * B * n, gathered_bytes=4 * B * n * ranks))
+            coll.append(dict(op="all_gather", what="row log-sum-exp", bytes_per_rank=4 * B, gathered_bytes=4 * B * ranks))
+            for lo, hi in (self.buckets.buckets if self.buckets is not None else []):
+                coll.append(dict(op="all_reduce", what="gradient arena [%d, %d)" % (lo, hi), bytes=4 * (hi - lo)))
+        return dict(world=self.world, dry_ranks=self.dry_ranks, planned_ranks=ranks, batch_per_rank=B, pool_rows=int(self.desc.B3),
+                    loss_workspace_bytes=int(self.loss_ws.numel()), loss_entry_points="train pair" if self.loss_train else "generic",
+                    wgrad_halves=bool(self.wgrad_halves), wgrad_group_workspace_bytes=int(self.group_ws.numel()) if self.group_ws is not None else 0,
+                    gradient_buckets=[list(b) for b in (self.buckets.buckets if self.buckets is not None else [])],
+                    gradient_arena_elements=int(self.grad_arena.numel()), grad_scale=1.0 / ranks, collectives_per_step=coll,
+                    encoder_path="whole-stack" if self.fused_forward else "per-layer", split_bf16=bool(self.split_bf16),
+                    graph_captured=self.graph is not None)
 
     @property
     def steps_done(self) -> int:

@@ -221,6 +221,73 @@ def test_dp_code_path_single_rank():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("n,space,p", [(10, "box", 2), (40, "sphere", 1)])
+def test_dry_ranks_8_plan_capture_and_run(n, space, p):
+    """everything the HOST side of an 8-GPU run decides, on one GPU.  `dry_ranks=8` makes this process plan and run
+    what rank 0 of an 8-rank job does (engine.ContrastiveTrainer: pool of 49 152 rows, loss workspace and stream splits for that pool,
+    the two-half weight-gradient launch, gradient buckets, 1/8 gradient scale), with every collective issued on a one-rank RCCL group
+    and CAPTURED into the step graph; the other ranks' rows are copies of its own.  Asserts the plan (sizes derived independently
+    here), that capture + replays run, and that the dry run equals `emulate_pool_ranks=8` -- the same arithmetic without collectives --
+    bit for bit in its per-row losses (the step differs only in the 1/8 gradient scale).  Runs in a subprocess: it needs its own
+    process group.  Headline config (n = 10) and BASELINE configs[2] (n = 40)."""
+    import os
+    import subprocess
+    import sys
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    code = r"""
+import json, os, sys
+import torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from cl_ica_amd import encoders
+from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+n, space, p, B, R = %d, %r, %d, 6144, 8
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "%d"
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+def mk(**kw):
+    torch.manual_seed(0)
+    f = encoders.get_mlp(n, n, [10 * n, 50 * n, 50 * n, 50 * n, 50 * n, 10 * n])
+    return ContrastiveTrainer(f, torch.eye(n).repeat(3, 1, 1), SamplerSpec(space=space, n=n, seed=5), batch_size=B, p=p, lr=1e-4, device="cuda", **kw)
+tr = mk(process_group=dist.group.WORLD, force_collectives=True, dry_ranks=R)
+plan = tr.plan_summary()
+tr.capture(warmup=2)
+outs = [tr.step().clone() for _ in range(3)]
+torch.cuda.synchronize()
+li = tr.loss_out[:B].clone()
+te = mk(emulate_pool_ranks=R)
+for _ in range(1):
+    te.step()
+torch.cuda.synchronize()
+tr2 = mk(process_group=dist.group.WORLD, force_collectives=True, dry_ranks=R)
+tr2.step(); torch.cuda.synchronize()
+print("RESULT " + json.dumps(dict(plan=plan, captured=tr.graph is not None, finite=bool(torch.isfinite(torch.stack(outs)).all()),
+                                  loss=[float(o[0]) for o in outs], first_step_rows_equal_emulated=bool(torch.equal(tr2.loss_out[:B], te.loss_out[:B])),
+                                  params_finite=bool(torch.isfinite(tr.param_arena).all()))))
+dist.destroy_process_group()
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, space, p, port)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    import json
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    plan = res["plan"]
+    B, R = 6144, 8
+    assert plan["planned_ranks"] == R and plan["pool_rows"] == R * B == 49152 and plan["grad_scale"] == 1.0 / R
+    n_params = sum((a * b + 3) // 4 * 4 + (a + 3) // 4 * 4 for a, b in zip([10 * n, 50 * n, 50 * n, 50 * n, 50 * n, 10 * n, n], [n, 10 * n, 50 * n, 50 * n, 50 * n, 50 * n, 10 * n]))
+    assert plan["gradient_arena_elements"] == n_params
+    cov = sorted(plan["gradient_buckets"])
+    # the buckets tile the arena (up to the <= 3 padding elements behind the last parameter)
+    assert cov[0][0] == 0 and n_params - 3 <= cov[-1][1] <= n_params and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+    ag = [c for c in plan["collectives_per_step"] if c["op"] == "all_gather"]
+    assert [c["gathered_bytes"] for c in ag] == [4 * B * n * R, 4 * B * R]
+    if n == 10:
+        assert plan["wgrad_halves"] and len(plan["gradient_buckets"]) == 2 and plan["encoder_path"] == "whole-stack"
+    else:
+        assert plan["encoder_path"] == "per-layer" and len(plan["gradient_buckets"]) >= 3          # 54.6 MB of gradients in 8 MB buckets
+    assert res["captured"] and res["finite"] and res["params_finite"] and res["first_step_rows_equal_emulated"]
+    assert abs(res["loss"][0] - float(np.log(R * B + 1))) < 0.15 * np.log(R * B + 1)               # ~ln(49 153) at initialisation
+
+
 def test_failed_capture_leaves_the_engine_usable():
     """capture() of a step whose collectives cannot be captured (gloo on device tensors) must raise and leave the process able
     to run the same steps eagerly (bench.py / train_mlp fall back to eager launches when a RCCL build refuses capture).
