@@ -115,6 +115,9 @@ SIGNATURES: Dict[str, list] = {
     "clica_stamp": [C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_reload_env": [],
     "clica_abort_capture": [C.c_void_p],
+    "clica_kitti_gather_pairs": [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, c_f32p, c_f32p, c_i32, c_f32p, C.c_void_p],
+    "clica_moments_workspace_bytes": [c_i64, c_i32, C.POINTER(c_size)],
+    "clica_moments": [c_f32p, c_i64, c_i32, c_f32p, c_i64, c_i32, c_i64, C.c_void_p, C.c_void_p, c_size, C.c_void_p],
     "clica_nn_search_workspace_bytes": [c_i64, c_i64, c_i32, c_i32, C.POINTER(c_size)],
     "clica_nn_search": [c_f32p, c_i64, c_i64, c_f32p, c_i64, c_i64, c_i32, c_i32, C.c_void_p, c_f32p, C.c_void_p, c_size, C.c_void_p],
     "clica_sample": [C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p],

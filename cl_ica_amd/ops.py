@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import check, load, ptr, require_cuda, rowmajor, stream_ptr, workspace
+from ._lib import check, load, ptr, require_cuda, rowmajor, stream_ptr, workspace, ClicaError
 
 
 def _mat(name: str, t: torch.Tensor) -> Tuple[torch.Tensor, int]:
@@ -553,6 +553,55 @@ def nn_search(table: torch.Tensor, query: torch.Tensor, k: int = 1, want_dist: b
     check(load().clica_nn_search(tab.data_ptr(), ldt, N, qry.data_ptr(), ldq, Q, n, int(k), idx.data_ptr(), ptr(dist),
                                  ws.data_ptr(), ws.numel(), stream_ptr()), "clica_nn_search")
     return dist, idx
+
+
+def kitti_gather_pairs(frames: torch.Tensor, first: torch.Tensor, second: torch.Tensor, latents: Optional[torch.Tensor] = None,
+                       image_shape=None):
+    """Interleaved float32 image batch [2 B, 1, H, W] (and labels [2 B, n_lat]) of the frame pairs (first[i], second[i]) from a uint8 frame
+    table [F, H, W] in HBM (clica_kitti_gather_pairs: kitti_masks/dataset.py:90-142 on the device)."""
+    if not frames.is_cuda:
+        raise ClicaError(f"frames must live on the GPU (got device {frames.device}); cl_ica_amd runs only through its HIP kernels")
+    if frames.dtype != torch.uint8 or not frames.is_contiguous():
+        raise ValueError("frames must be a contiguous uint8 tensor [F, ...]")
+    F = frames.shape[0]
+    elems = frames[0].numel()
+    first = first.to(device=frames.device, dtype=torch.int64).contiguous()
+    second = second.to(device=frames.device, dtype=torch.int64).contiguous()
+    B = first.numel()
+    if second.numel() != B or B == 0:
+        raise ValueError("first / second must hold the same, non-zero number of frame indices")
+    shape = tuple(image_shape) if image_shape is not None else (1,) + tuple(frames.shape[1:])
+    images = torch.empty((2 * B,) + shape, dtype=torch.float32, device=frames.device)
+    labels = lat = None
+    n_lat = 0
+    if latents is not None:
+        require_cuda(latents, "latents")
+        lat = latents.detach().to(torch.float32).contiguous()
+        n_lat = lat.shape[1]
+        labels = torch.empty((2 * B, n_lat), dtype=torch.float32, device=frames.device)
+    check(load().clica_kitti_gather_pairs(frames.data_ptr(), elems, F, first.data_ptr(), second.data_ptr(), B, images.data_ptr(),
+                                          ptr(lat), n_lat, ptr(labels), stream_ptr()), "clica_kitti_gather_pairs")
+    return images, labels
+
+
+def moments(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """G = [a | b | 1]^T [a | b | 1] in fp64 (clica_moments): the (da + db + 1)^2 second-moment matrix every disentanglement score is a
+    function of (cl_ica_amd/disentanglement_utils.py).  a [M, da], b [M, db] fp32 on the device; returns a device fp64 tensor."""
+    (a, lda) = _mat("a", a)
+    M, da = a.shape
+    db, ldb, bp = 0, 0, None
+    if b is not None:
+        (b, ldb) = _mat("b", b)
+        if b.shape[0] != M:
+            raise ValueError(f"row counts differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        db, bp = b.shape[1], b.data_ptr()
+    d = da + db + 1
+    nbytes = C.c_size_t()
+    check(load().clica_moments_workspace_bytes(M, d, C.byref(nbytes)), "clica_moments_workspace_bytes")
+    ws = workspace("moments", nbytes.value, a.device)
+    out = torch.empty((d, d), dtype=torch.float64, device=a.device)
+    check(load().clica_moments(a.data_ptr(), lda, da, bp, ldb, db, M, out.data_ptr(), ws.data_ptr(), ws.numel(), stream_ptr()), "clica_moments")
+    return out
 
 
 SPACE = {"real": 0, "box": 1, "sphere": 2}

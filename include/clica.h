@@ -373,6 +373,28 @@ int clica_nn_search(const float* table, int64_t ldt, int64_t n_table, const floa
                     clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * KITTI-masks temporal pairs  --  the batch assembly of kitti_masks/dataset.py:90-131 (__getitem__: two frames of one pedestrian
+ * sequence, uint8 * 255 -> float32 / 255) and :134-142 (custom_collate: first / second interleaved) from a frame table in HBM:
+ *   images[2 i]     = float(frames[first_frame[i]]),  images[2 i + 1] = float(frames[second_frame[i]])     ([2 n_pairs][frame_elems])
+ *   labels[2 i + c] = latents[first / second frame]                                                          ([2 n_pairs][n_latents], optional)
+ * frames: uint8 [n_frames][frame_elems] (bool masks as 0 / 1), latents: float32 [n_frames][n_latents].
+ * ---------------------------------------------------------------------------------- */
+int clica_kitti_gather_pairs(const uint8_t* frames, int64_t frame_elems, int64_t n_frames, const int64_t* first_frame,
+                             const int64_t* second_frame, int64_t n_pairs, float* images, const float* latents, int32_t n_latents,
+                             float* labels, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Second moments for the disentanglement scores  --  replaces the host-side sklearn / numpy / scipy passes of
+ * disentanglement_utils.py:23 (r2_score), :40 (np.corrcoef), :38 (spearmanr, on ranks), :97-100 (LinearRegression.fit/predict):
+ *   out[d][d] (fp64, row-major) = [A | B | 1]^T [A | B | 1],  d = da + db + 1 <= 129,
+ * A [M, da], B [M, db] fp32 row-major with leading dimensions lda / ldb (B may be NULL with db = 0).  Every score of that
+ * file is a function of this matrix; only d x d doubles leave the device.  Deterministic (no atomics).
+ * ---------------------------------------------------------------------------------- */
+int clica_moments_workspace_bytes(int64_t M, int32_t d, size_t* bytes);
+int clica_moments(const float* A, int64_t lda, int32_t da, const float* B, int64_t ldb, int32_t db, int64_t M, double* out,
+                  void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Adam  --  torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8) as used at main_mlp.py:312,
  * over one flat parameter arena.  `step_dev` is a device int32 holding the number of
  * updates already applied; the call uses t = *step_dev + 1 for the bias corrections and

@@ -454,3 +454,29 @@ def threedident_snap(table, z, z_tilde):
     _, izt = flat_l2_search(table, z_tilde, 2)
     iz = iz[:, 0]
     return iz, np.where(izt[:, 0] != iz, izt[:, 0], izt[:, 1])
+
+
+# ------------------------------------------------------------------------------------------------ KITTI-masks pair assembly
+def kitti_getitem(data, latents, cumlens, index, t_steps_forward):
+    """Restatement of KittiMasks.__getitem__ (/root/reference/kitti_masks/dataset.py:90-131, transform=None) with the random time
+    step passed in (the reference draws ``np.random.randint(1, max_delta_t + 1)`` at :97).  data / latents: lists of per-sequence
+    arrays.  PARITY UNPINNED against the reference's own execution: its module imports torchvision / matplotlib, absent here."""
+    sequence_ind = int(np.searchsorted(cumlens, index, side="right"))                       # :91
+    start_ind = index if sequence_ind == 0 else index - cumlens[sequence_ind - 1]           # :92-95
+    seq_len = len(data[sequence_ind])                                                       # :96
+    end_ind = min(start_ind + t_steps_forward, seq_len - 1)                                 # :98
+    first = np.asarray(data[sequence_ind][start_ind]).astype(np.uint8) * 255                # :100
+    second = np.asarray(data[sequence_ind][end_ind]).astype(np.uint8) * 255                 # :101
+    l1, l2 = latents[sequence_ind][start_ind], latents[sequence_ind][end_ind]               # :103-108
+    first, second = first[None], second[None]                                               # :123-125 channel dim
+    first, second = first.astype(np.float32) / 255.0, second.astype(np.float32) / 255.0     # :127-131
+    return first, second, l1, l2
+
+
+def kitti_collate(sample):
+    """custom_collate (/root/reference/kitti_masks/dataset.py:134-142): first / second samples and labels interleaved."""
+    inputs, labels = [], []
+    for s in sample:
+        inputs += [s[0], s[1]]
+        labels += [s[2], s[3]]
+    return np.stack(inputs), np.stack(labels)

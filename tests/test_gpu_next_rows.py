@@ -106,6 +106,93 @@ def test_n2_metrics_on_device(golden):
         assert thz.shape == z.shape and thz.is_cuda
 
 
+def test_n2_all_modes_and_solvers_on_device(golden):
+    """Every mode (r2, adjusted_r2, pearson, spearman) x solver (munkres, naive) x rescaling / sign flips / train-test split of
+    disentanglement_utils.py:63-221 with device tensors through clica_moments (csrc/moments.hip), against the reference's sklearn /
+    scipy / Munkres values (G25, tests/golden/gen_goldens_r4.py)."""
+    from cl_ica_amd import disentanglement_utils as du
+    from test_host_logic import check_metric_modes
+
+    def check(what, a, b, tol):
+        PARITY.check("n2_metric_modes_g25", what.split("/")[0], what, a, b, tol=max(tol, 1e-5), floor=1.0,
+                     note=None if tol <= 1e-5 else "rank statistic of fp32-computed values (see test_host_logic.check_metric_modes)")
+    assert check_metric_modes(du, golden("g25_metrics_modes.npz").z, dev, check=check) >= 60
+
+
+@pytest.mark.parametrize("M,da,db", [(4096, 10, 10), (1000, 4, 0), (63, 1, 1), (65, 40, 40), (12288, 64, 64), (517, 3, 7)])
+def test_moments_kernel_vs_fp64(M, da, db):
+    """clica_moments: G = [A | B | 1]^T [A | B | 1] in fp64 against numpy fp64 on the same fp32 data (exact products, so only the
+    summation order differs: 1e-12), on strided views, with and without B, batches that are not whole 64-row chunks."""
+    from cl_ica_amd import ops
+    rng = np.random.default_rng(M + da)
+    a = dev(rng.normal(size=(M, da + 3)) * 3 + 1)[:, 1:1 + da]
+    b = dev(rng.uniform(size=(M, db + 2)))[:, :db] if db else None
+    G = ops.moments(a, b).cpu().numpy()
+    X = np.concatenate([a.cpu().numpy().astype(np.float64)] + ([b.cpu().numpy().astype(np.float64)] if db else []) + [np.ones((M, 1))], 1)
+    ref = X.T @ X
+    assert G.shape == ref.shape == (da + db + 1, da + db + 1)
+    assert np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max() and np.array_equal(G, G.T) and G[-1, -1] == M
+    with pytest.raises(Exception):
+        ops.moments(dev(np.zeros((8, 100))), dev(np.zeros((8, 100))))          # 201 columns > 129
+
+
+def _synthetic_kitti(rng, n_seq=17, hw=64):
+    lens = rng.integers(2, 40, size=n_seq)
+    data = [rng.random((int(T), hw, hw)) < 0.1 for T in lens]                       # bool masks like the pickle's
+    lat = [rng.normal(size=(int(T), 3)).astype(np.float32) for T in lens]
+    return {"pedestrians": data, "pedestrians_latents": lat}
+
+
+def test_kitti_pair_pipeline_matches_oracle():
+    """N4, second half: KittiMasks.__getitem__ + custom_collate + return_data (kitti_masks/dataset.py:90-175) on the
+    device -- batched index arithmetic + ONE gather launch -- against the oracle's restatement item by item: every start index of the
+    synthetic data set with every time step 1..5 (sequence ends clamp), bit-exact images and labels, interleaving; the loader's epoch
+    visits every index at most once, drops the ragged tail, draws time steps in 1..max_delta_t; the Solver trains from it."""
+    import types
+    from cl_ica_amd.kitti_masks import dataset as D
+    rng = np.random.default_rng(5)
+    raw = _synthetic_kitti(rng)
+    ds = D.KittiMasks(data=raw, max_delta_t=5)
+    cum = np.cumsum([len(s) - 1 for s in raw["pedestrians"]])
+    assert len(ds) == int(cum[-1]) and ds.frames.dtype == torch.uint8
+    idx = np.repeat(np.arange(len(ds)), 5); tt = np.tile(np.arange(1, 6), len(ds))
+    img, lab = ds.batch(torch.as_tensor(idx), torch.as_tensor(tt))
+    ref = O.kitti_collate([O.kitti_getitem(raw["pedestrians"], raw["pedestrians_latents"], cum, int(i), int(t)) for i, t in zip(idx, tt)])
+    assert img.shape == (2 * len(idx), 1, 64, 64) and lab.shape == (2 * len(idx), 3) and img.dtype == torch.float32
+    assert np.array_equal(img.cpu().numpy(), ref[0]) and np.array_equal(lab.cpu().numpy(), ref[1])       # bit-exact (byte data)
+    # the host-style accessors and the reference's collate give the same batch
+    np.random.seed(3)
+    items = [ds[i] for i in (0, 5, len(ds) - 1)]
+    ci, cl = D.custom_collate(items)
+    assert ci.shape == (6, 1, 64, 64) and torch.equal(ci[0], torch.tensor(items[0][0])) and torch.equal(ci[1], torch.tensor(items[0][1]))
+    assert set(np.unique(ci.numpy())) <= {0.0, 1.0}
+    # loader semantics of return_data (:145-175)
+    a = types.SimpleNamespace(dataset="KittiMasks", batch_size=64, num_workers=0, image_size=64, evaluate=False, kitti_max_delta_t=3, seed=11)
+    loader = D.return_data(a, data=raw)
+    assert loader.pairs == 32 and len(loader) == len(ds) // 32
+    seen = []
+    first_of_batch = None
+    for images, labels in loader:
+        assert images.shape == (64, 1, 64, 64) and labels.shape == (64, 3) and images.is_cuda
+        seen.append(labels[::2].cpu().numpy())
+        first_of_batch = images if first_of_batch is None else first_of_batch
+    seen = np.concatenate(seen)
+    all_first = np.concatenate([l[:-1] for l in raw["pedestrians_latents"]])
+    keys = {tuple(np.round(r, 6)) for r in all_first}
+    assert len({tuple(np.round(r, 6)) for r in seen}) == len(seen) == len(loader) * 32 and all(tuple(np.round(r, 6)) in keys for r in seen)
+    ts = loader.dataset.sample_time_steps(20000).cpu().numpy()
+    assert ts.min() == 1 and ts.max() == 3 and abs((ts == 2).mean() - 1 / 3) < 0.02
+    e1 = next(iter(loader))[1]; e2 = next(iter(loader))[1]
+    assert not torch.equal(e1, e2)                                                   # a fresh permutation every epoch
+    # and the Solver consumes the batches (one iteration from the device loader)
+    from cl_ica_amd.kitti_masks.solver import Solver
+    sa = types.SimpleNamespace(cuda=True, ckpt_dir="/tmp", output_dir="/tmp", dataset="kitti", max_iter=1, z_dim=5, num_channel=1, lr=1e-4,
+                               beta1=0.9, beta2=0.999, ckpt_name="last", log_step=10, save_step=10 ** 9, box_norm=True, p=1)
+    S = Solver(sa, loader)
+    S.net_mode(train=True)
+    assert bool(torch.isfinite(S.train_iteration(first_of_batch)))
+
+
 def test_autograd_loss_uses_forward_rowgrad_and_matches_row_pass():
     """Advisor finding: the flash-style row gradient of the forward sweep was never requested from losses.py.  Now it is
     whenever z1_rec needs a gradient; the result must equal the recomputing row pass of clica_lp_loss_bwd (rowgrad = NULL)."""

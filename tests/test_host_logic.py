@@ -179,9 +179,27 @@ def test_grad_bucket_partition():
     assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
 
 
-def test_metrics_goldens(golden):
-    """R^2 / MCC (torch + scipy assignment) vs the reference's sklearn + Munkres values (G11)."""
+def _host_moment_stand_ins(monkeypatch):
+    """The two device entry points disentanglement_utils calls, stood in for by host arithmetic so that ITS host logic (every score as a
+    function of the moment matrix) is tested without a GPU; the kernels themselves are tested with -m gpu."""
+    from cl_ica_amd import ops
+
+    def moments(a, b=None):
+        cols = [a.double()] + ([b.double()] if b is not None else []) + [torch.ones(a.shape[0], 1, dtype=torch.float64)]
+        X = torch.cat(cols, 1)
+        return X.T @ X
+
+    def linear_fwd(x, w, bias, leaky, slope=0.01, out=None):
+        y = x.double() @ w.double().T
+        return (y + bias.double() if bias is not None else y).float()
+    monkeypatch.setattr(ops, "moments", moments)
+    monkeypatch.setattr(ops, "linear_fwd", linear_fwd)
+
+
+def test_metrics_goldens(golden, monkeypatch):
+    """R^2 / MCC from the moment matrix vs the reference's sklearn + Munkres values (G11)."""
     from cl_ica_amd import disentanglement_utils as du
+    _host_moment_stand_ins(monkeypatch)
     z9 = golden("g11_metrics.npz").z
     for i in range(int(z9["n_cases"])):
         z, hz = torch.tensor(z9[f"c{i}/z"]), torch.tensor(z9[f"c{i}/hz"])
@@ -192,6 +210,68 @@ def test_metrics_goldens(golden):
         assert abs(mcc - float(z9[f"c{i}/mcc"])) < 1e-6
         assert np.abs(np.abs(np.diag(corr)) - np.abs(z9[f"c{i}/corr_diag"])).max() < 1e-6
         assert thz.shape == z.shape
+
+
+def check_metric_modes(du, z25, to_t, tol=2e-6, check=None):
+    """Every mode / solver of disentanglement_utils.py:63-221 against G25 (tests/golden/gen_goldens_r4.py); shared with the GPU test."""
+    def close(a, b, what):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        # rank statistics are discontinuous in the values ranked: where the ranked quantity is itself COMPUTED (the regression's
+        # prediction, in fp32 here and in the reference) two near-equal predictions may swap ranks
+        # (the reference's own value carries that noise: sklearn fits in fp32); a swap moves the coefficient by O(1 / N)
+        # rescaling=True ranks fp32-ROUNDED products hz * beta in the reference (numpy float32 matmul with the diagonal matrix): the
+        # same effect at a smaller scale
+        t = 0.1 / rows_eval[0] if ("spearman" in what and "/lin/" in what) else (0.02 / z.shape[0] if "spearman" in what else tol)
+        if check is not None:
+            check(what, a, b, t)
+        else:
+            assert a.shape == b.shape and np.abs(a - b).max() <= t * max(1.0, np.abs(b).max()), (what, float(np.abs(a - b).max()))
+    n_checked = 0
+    rows_eval = [1]
+    for i in range(int(z25["n_cases"])):
+        z, hz = to_t(z25[f"c{i}/z"]), to_t(z25[f"c{i}/hz"])
+        n = z.shape[1]
+        for mode in ("r2", "adjusted_r2", "pearson", "spearman"):
+            for split in (False, True):
+                rows_eval[0] = z.shape[0] - z.shape[0] // 2 if split else z.shape[0]
+                k = f"c{i}/lin/{mode}/{int(split)}"
+                (score, corr), (z2, pred) = du.linear_disentanglement(z, hz, mode=mode, train_test_split=split)
+                close(score, z25[k + "/score"], k + "/score")
+                assert (corr is None) == (k + "/corr" not in z25.files)
+                if corr is not None:
+                    close(corr, z25[k + "/corr"], k + "/corr")
+                close(pred[:16].cpu().numpy(), z25[k + "/pred_head"], k + "/pred_head")
+                assert z2.shape == pred.shape
+                n_checked += 1
+        for mode in ("pearson", "spearman"):
+            for resc in (True, False):
+                k = f"c{i}/munkres/{mode}/{int(resc)}"
+                (score, corr), thz = du.permutation_disentanglement(z, hz, mode=mode, solver="munkres", rescaling=resc)
+                close(score, z25[k + "/score"], k + "/score"); close(corr, z25[k + "/corr"], k + "/corr")
+                close(thz[:16].cpu().numpy(), z25[k + "/thz_head"], k + "/thz_head")
+                n_checked += 1
+        if n <= 4:
+            for mode in ("r2", "pearson", "spearman"):
+                for resc in (True, False):
+                    for flips in (True, False):
+                        k = f"c{i}/naive/{mode}/{int(resc)}/{int(flips)}"
+                        (score, corr), thz = du.permutation_disentanglement(z, hz, mode=mode, solver="naive", rescaling=resc, sign_flips=flips,
+                                                                            cache_permutations=(flips and resc))
+                        close(score, z25[k + "/score"], k + "/score")
+                        if corr is not None:
+                            close(corr, z25[k + "/corr"], k + "/corr")
+                        close(thz[:16].cpu().numpy(), z25[k + "/thz_head"], k + "/thz_head")
+                        n_checked += 1
+    return n_checked
+
+
+def test_metric_modes_goldens(golden, monkeypatch):
+    """All four modes x both solvers x rescaling / sign flips / train-test split (G25) through the host logic."""
+    from cl_ica_amd import disentanglement_utils as du
+    _host_moment_stand_ins(monkeypatch)
+    assert check_metric_modes(du, golden("g25_metrics_modes.npz").z, torch.tensor) >= 60
+    with pytest.raises(AssertionError):
+        du.permutation_disentanglement(torch.rand(8, 2), torch.rand(8, 2), mode="r2", solver="munkres")
 
 
 def test_train_mlp_cli_surface():
