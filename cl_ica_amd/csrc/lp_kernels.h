@@ -61,6 +61,12 @@ struct Params {
   float xs;       // logit = xs * neg * kscale : -1 for Lp distances, +1 for the dot-product kind
   int pow;        // 1: use sum |e|^p ; 0: its 1/p-th root
   int n;          // true embedding dim (<= NP)
+  // training entry points only (clica_lp_loss_fwd_train / bwd_sym_train: the pool CONTAINS the owner rows, integer p, pow):
+  //   bit 0: forward without the running maximum -- logits of an Lp distance are <= 0 and the owner's own pool row gives exactly 0, so
+  //          sum_j 2^x_ij >= 1 needs no rescaling (per pair: multiply, exp, add instead of max / subtract / exp / rescale)
+  //   bit 1: backward coefficient with ONE exponential, 2^x (u_i + u_j) with u = C 2^-L per row (L = log2 of a sum >= 1, so 2^-L is in
+  //          (0, 1]) instead of C_i 2^(x - L_i) + C_j 2^(x - L_j)
+  int train = 0;
   // dot kind, wide rows (n >= 64) only: <z1_i, z2_i> computed beforehand by a wave-per-row kernel (the finishing kernels run one
   // THREAD per row and would walk 512 strided coordinates each), and where the coefficient step leaves d loss / d pos_i for
   // an element-wise kernel instead of writing the two gradient rows itself
@@ -286,7 +292,7 @@ __device__ __forceinline__ void gaccum2_d(f32x2& g, float coef, f32x2 d) {
 constexpr int fwd_min_waves(int np, bool rowgrad) { return rowgrad ? (np <= 16 ? 3 : 2) : (np <= 16 ? 4 : (np <= 24 ? 3 : 2)); }
 constexpr int bwd_min_waves(int np) { return np <= 16 ? 3 : 2; }
 
-template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2>
+template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2, bool ZMAX = false>
 __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_partial_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
@@ -308,8 +314,9 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   for (int r = 0; r < (ROWGRAD ? R : 1); ++r)
 #pragma unroll
     for (int k2 = 0; k2 < NP / 2; ++k2) G[r][k2] = (f32x2){0.f, 0.f};
+  static_assert(!(ZMAX && ROWGRAD), "the fixed-maximum forward is the training sweep (no row gradient)");
 #pragma unroll
-  for (int r = 0; r < R; ++r) { m[r] = -INFINITY; s[r] = 0.f; }
+  for (int r = 0; r < R; ++r) { m[r] = ZMAX ? 0.f : -INFINITY; s[r] = 0.f; }
   const float xk = q.xs * q.kscale;
 
   const int64_t jb = (int64_t)blockIdx.y * chunk;
@@ -340,6 +347,13 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
         for (int c = 0; c < JBF; ++c) {
           x[c] = root_of<ROOT>(acc[c], q) * xk;
           if (RAGGED && jj + c >= cq) x[c] = -INFINITY;      // ragged tail of the stream
+        }
+        if constexpr (ZMAX) {      // training sweep: maximum known to be 0 (Params::train), s >= 1 from the owner's own pool row
+          float add = 0.f;
+#pragma unroll
+          for (int c = 0; c < JBF; ++c) add += fexp2(x[c]);
+          s[r] += add;
+          continue;
         }
         // clamp keeps (-inf) - (-inf) out of the exponent when nothing valid was seen yet
         float xm = x[0];
@@ -442,7 +456,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
 // column contributions to dz_i in one pass.  Same owner / partition layout as the forward; the eight partitions'
 // gradient partials are summed on chip (shuffle, then LDS in wave order) before one NP-float row per owner and
 // stream split goes to HBM.
-template <int NP, int PK, int R, int STATS, bool ROOT, int NQ = NP / 2>
+template <int NP, int PK, int R, int STATS, bool ROOT, int NQ = NP / 2, bool FOLD = false>
 __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
@@ -465,6 +479,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     const int64_t i = own0 + (int64_t)r * HALF + li;
     oL[r] = 0.f; oC[r] = 0.f;
     if (OWNER_STATS && i < n_own) { oL[r] = statL[i]; oC[r] = statC[i]; }
+    if (FOLD) oC[r] *= fexp2(-oL[r]);               // u_i = C_i 2^-L_i (Params::train bit 1: L_i >= 0)
 #pragma unroll
     for (int k2 = 0; k2 < NP / 2; ++k2) g[r][k2] = (f32x2){0.f, 0.f};
   }
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     }
   };
   auto store_stats = [&](int b) {
-    if (STREAM_STATS && (int)threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = rc; }
+    if (STREAM_STATS && (int)threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = FOLD ? rc * fexp2(-rl) : rc; }
   };
   if (jb < je) {
     const int c0 = (int)min((int64_t)TS, je - jb);
@@ -524,8 +539,13 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
         for (int c = 0; c < JW; ++c) {
           const float x = root_of<ROOT>(acc[c], q) * xk;
           float w = 0.f;
-          if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
-          if (STREAM_STATS) w = fmaf(tC[jj + c], fexp2(x - tL[jj + c]), w);   // tC = 0 masks the ragged tail
+          if constexpr (FOLD) {
+            static_assert(!FOLD || STATS == 3, "folded coefficient: symmetric training sweep only");
+            w = fexp2(x) * (oC[r] + tC[jj + c]);                              // one exponential per pair; tC = 0 in the ragged tail
+          } else {
+            if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
+            if (STREAM_STATS) w = fmaf(tC[jj + c], fexp2(x - tL[jj + c]), w);   // tC = 0 masks the ragged tail
+          }
           float cf = w * droot_of<ROOT>(acc[c], q) * csgn;
           if (OWNER_STATS && jj + c >= cq) cf = 0.f;
           coef[c] = cf;

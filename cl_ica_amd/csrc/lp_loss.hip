@@ -553,6 +553,8 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
 // ---- training-step pair of entry points: forward with the coefficient step folded into its finalize, symmetric backward
 // with the forward's means folded into its reduction (three launches fewer than fwd + bwd_sym) -------------------------
 struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes; };
+// CLICA_LP_TRAIN_FAST (bits, default 3): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (A/B switch; Params::train)
+static int train_flags() { static int v = [] { const char* e = getenv("CLICA_LP_TRAIN_FAST"); return e ? atoi(e) : 3; }(); return v; }
 static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols) {
   TrainWs w; char* p = (char*)ws; size_t off = 256;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
@@ -590,6 +592,7 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   TrainWs w = carve_train(workspace, PF, PR, rows, cols);
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd_train: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, false);
+  q.train = train_flags() & 1;       // the pool contains the owner rows: running maximum known (Params::train)
   hipStream_t st = as_stream(stream);
   float2* part = reinterpret_cast<float2*>(w.scratch);
   launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
@@ -623,6 +626,7 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
     strL = w.strL; strC = w.strC;
   }
   float* partR = reinterpret_cast<float*>(w.scratch);
+  q.train = train_flags() & 2;       // every row statistic is the log2 of a sum >= 1: folded coefficient (Params::train)
   launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
   const int blocks = (int)ceil_div(rows * PR.np, THREADS);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,

@@ -57,6 +57,9 @@ void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64
     else if (part_g)
       hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_bwd(NP), true, true, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
+    else if (q.pow && (q.train & 1) && PK >= 1 && PK <= 3)
+      hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false, false, NQ, (PK >= 1 && PK <= 3)>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                         n_str, q, part, part_g, P.chunk);
     else if (q.pow)
       hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), false, false, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
@@ -105,7 +108,10 @@ void CAT(launch_bwd_sym_pk, CLICA_PK)(const Plan& P, const float* own, int64_t l
   }
   dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
   LP_FOR_NP(P.np, {
-    if (q.pow)
+    if (q.pow && (q.train & 2) && PK >= 1 && PK <= 3)
+      hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, false, NQ, (PK >= 1 && PK <= 3)>), grid, block, 0, st, own, ldo, n_own, str,
+                         lds, n_str, q, ownL, ownC, strL, strC, part, P.chunk);
+    else if (q.pow)
       hipLaunchKernelGGL((bwd_pairs_k<NP, PK, owners_bwd(NP), 3, false, NQ>), grid, block, 0, st, own, ldo, n_own, str,
                          lds, n_str, q, ownL, ownC, strL, strC, part, P.chunk);
     else

@@ -129,7 +129,12 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * with the default upstream gradient d(mean loss) = 1, three launches fewer.  fwd_train also writes the positive-pair
  * part of dz1 / dz2 and keeps the row statistics in the workspace; bwd_sym_train ADDS the pair-sweep gradient to dz1
  * and delivers means[3] = (loss, pos, neg) of the forward.  Both calls share ONE workspace of
- * clica_lp_loss_train_workspace_bytes, untouched in between (only the all-gather of lse_i belongs there). */
+ * clica_lp_loss_train_workspace_bytes, untouched in between (only the all-gather of lse_i belongs there).
+ * REQUIREMENT (round 4): `pool` must CONTAIN the B rows of z1 bit for bit (it does in the training step: the pool is z1 itself or the
+ * all-gather of every rank's z1).  The sweeps use it: every logit is <= 0 and the row's own pool entry gives exactly 0, so the forward
+ * sums 2^x without a running maximum and the backward folds the row statistics into one factor per row (one exponential per pair).
+ * For negatives that do not include the anchors use clica_lp_loss_fwd / clica_lp_loss_bwd.  CLICA_LP_TRAIN_FAST=0 restores the
+ * general-purpose sweeps behind these entry points (A/B switch). */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);
 int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
                             const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
