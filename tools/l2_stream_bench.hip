@@ -42,6 +42,7 @@ struct Params {
   const u32x4* buf; int L; LayerD ly[MAXL];
   unsigned long long* stamps;     // per workgroup: {cycles, realtime ticks}
   u32x4* sink; long long private_entries;
+  int repeat;                      // the layer list is walked this many times (--repeat: sustained-load clock)
 };
 
 template <int ORDER, int MFMA, int DEPTH, int NC>
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(512) void stream_k(Params P) {
     for (int r = 0; r < 3; ++r) xf[p][r] = (u32x4){0x3F803F80u + lane, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u + r + p};
 
 #pragma unroll 1
-  for (int l = 0; l < P.L; ++l) {
+  for (int ll = 0; ll < P.L * P.repeat; ++ll) {
+    const int l = ll % P.L;
     const LayerD ly = P.ly[l];
     int nc = (ly.ncb - wave + WAVES - 1) / WAVES;
     nc = nc < 0 ? 0 : (nc > CBW ? CBW : nc);
@@ -239,12 +241,13 @@ static Result run(F launch, const Params& P, double bytes_per_wg, double mfma_cy
 }
 
 int main(int argc, char** argv) {
-  int reps = 20, wgs = 256;
-  bool narrow = false;
+  int reps = 20, wgs = 256, repeat = 1;
+  bool narrow = false, sustain_only = false;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
     if (!strcmp(argv[i], "--wgs") && i + 1 < argc) wgs = atoi(argv[++i]);
     if (!strcmp(argv[i], "--stack")) narrow = true;     // the whole n = 10 forward stack instead of 6 wide layers
+    if (!strcmp(argv[i], "--repeat") && i + 1 < argc) { repeat = atoi(argv[++i]); sustain_only = true; }   // long kernels: sustained clock
   }
   // layers as (N, K): fragment-order copy per piece = ceil(N/16) * ceil(K/32) KB
   std::vector<std::pair<int, int>> layers;
@@ -272,7 +275,8 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3F803F80u ^ (unsigned)((i * 2654435761u) & 0x007F007Fu);   // bf16 pairs near 1.0
     CHECK(hipMemcpy(buf, h.data(), h.size() * 4, hipMemcpyHostToDevice));
   }
-  P.buf = buf; P.private_entries = private_entries;
+  P.buf = buf; P.private_entries = private_entries; P.repeat = repeat;
+  bytes_per_wg *= repeat; mfma_cyc *= repeat;
   CHECK(hipMalloc(&P.stamps, 2 * wgs * 8));
   CHECK(hipMalloc(&P.sink, 512 * 16));
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
@@ -292,6 +296,11 @@ int main(int argc, char** argv) {
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_dma_k<ORDER, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm)); \
     auto f = [&]() { hipLaunchKernelGGL((stream_dma_k<ORDER, DEPTH>), dim3(wgs), dim3(512), shm, 0, P); }; \
     report(ORDER, 0, 1, DEPTH, run(f, P, bytes_per_wg, mfma_cyc, wgs, reps)); } while (0)
+  if (sustain_only) {      // the matrix work alone (weights from L1) and with the L2 stream, kernels of several milliseconds
+    printf("# --repeat %d: every kernel walks the layer list %d times (sustained load: does the shader clock hold?)\n", repeat, repeat);
+    RUN(7, 1, 1); RUN(0, 1, 1); RUN(7, 1, 1); RUN(0, 1, 1);
+    return 0;
+  }
   // loads only: what the memory system delivers to the pattern
   RUN(0, 0, 1); RUN(1, 0, 1); RUN(2, 0, 1); RUN(3, 0, 1); RUN(4, 0, 1); RUN(5, 0, 1); RUN(6, 0, 1); RUN(7, 0, 1);
   RUN(0, 0, 2); RUN(2, 0, 2); RUN(5, 0, 2); RUN(6, 0, 2); RUN(7, 0, 2);
