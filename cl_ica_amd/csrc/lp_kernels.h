@@ -67,6 +67,13 @@ struct Params {
   //   bit 1: backward coefficient with ONE exponential, 2^x (u_i + u_j) with u = C 2^-L per row (L = log2 of a sum >= 1, so 2^-L is in
   //          (0, 1]) instead of C_i 2^(x - L_i) + C_j 2^(x - L_j)
   int train = 0;
+  // coordinate scale applied to owner AND stream rows as they are loaded (the same fp32 multiply on both sides: identical rows stay
+  // identical, so exact-zero pairs stay exact).  1 outside the training sweeps; there pre = (log2(e) / tau)^(1/p), which makes the
+  // scaled distance sum the logit itself (x = -acc: no per-pair multiply), see fwd_partial_k<ZMAX> / bwd_pairs_k<FOLD>.  NOT for p = 1:
+  // its gradient is sign(o - s), and a scale that is not a power of two can round two coordinates a few ulps apart onto each other
+  // (measured: 1.8e-4 of the gradient scale in the n = 40 full-size test); p = 1 keeps unscaled rows and the multiply
+  float pre = 1.f;
+  float gfold = 1.f;   // FOLD sweeps: p / pre^(p-1), the factor between sum_j w_ij term'(d_scaled) and the gradient in unscaled coordinates
   // dot kind, wide rows (n >= 64) only: <z1_i, z2_i> computed beforehand by a wave-per-row kernel (the finishing kernels run one
   // THREAD per row and would walk 512 strided coordinates each), and where the coefficient step leaves d loss / d pos_i for
   // an element-wise kernel instead of writing the two gradient rows itself
@@ -179,14 +186,14 @@ struct Stager {
   static constexpr int ITERS = TS * NP / THREADS;
   static_assert((TS * NP) % THREADS == 0, "tile must divide over the workgroup");
   float v[ITERS];
-  __device__ __forceinline__ void load(const float* __restrict__ str, int64_t lds, int64_t j0, int cnt, int n) {
+  __device__ __forceinline__ void load(const float* __restrict__ str, int64_t lds, int64_t j0, int cnt, int n, float pre = 1.f) {
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
       const int idx = threadIdx.x + it * THREADS;
       const int row = idx / NP, k = idx - row * NP;
       const bool ok = row < cnt && k < n;
       const float x = str[ok ? (j0 + row) * lds + k : 0];
-      v[it] = ok ? x : 0.f;
+      v[it] = ok ? x * pre : 0.f;
     }
   }
   __device__ __forceinline__ void store(float* tile) const {
@@ -198,7 +205,7 @@ struct Stager {
 // owner r of this lane: row own0 + r * HALF + (lane & 31) -- both half-waves load the same rows
 template <int NP, int R>
 __device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* __restrict__ own, int64_t ldo,
-                                            int64_t own0, int64_t n_own, int n) {
+                                            int64_t own0, int64_t n_own, int n, float pre = 1.f) {
   const int li = threadIdx.x & (HALF - 1);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -208,7 +215,7 @@ __device__ __forceinline__ void load_owners(f32x2 (&o)[R][NP / 2], const float* 
     for (int k2 = 0; k2 < NP / 2; ++k2) {
       const bool a = ok && 2 * k2 < n, b = ok && 2 * k2 + 1 < n;
       const float x = own[a ? i * ldo + 2 * k2 : 0], y = own[b ? i * ldo + 2 * k2 + 1 : 0];
-      o[r][k2].x = a ? x : 0.f; o[r][k2].y = b ? y : 0.f;
+      o[r][k2].x = a ? x * pre : 0.f; o[r][k2].y = b ? y * pre : 0.f;
     }
   }
 }
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
   f32x2 o[R][NP / 2];
   f32x2 G[ROWGRAD ? R : 1][NP / 2];
-  load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
+  load_owners<NP, R>(o, own, ldo, own0, n_own, q.n, q.pre);
   float m[R], s[R];
   const float csgn = (PK == 0) ? q.sgn : 1.f;
 #pragma unroll
@@ -323,7 +330,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   const int64_t je = min(n_str, jb + (int64_t)chunk);
   Stager<NP> st;
   if (jb < je) {
-    st.load(str, lds, jb, (int)min((int64_t)TS, je - jb), q.n);
+    st.load(str, lds, jb, (int)min((int64_t)TS, je - jb), q.n, q.pre);
     st.store(tiles[0]);
   }
   __syncthreads();
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   for (int64_t j0 = jb; j0 < je; j0 += TS, cur ^= 1) {
     const int cnt = (int)min((int64_t)TS, je - j0);
     const bool more = j0 + TS < je;
-    if (more) st.load(str, lds, j0 + TS, (int)min((int64_t)TS, je - j0 - TS), q.n);   // in flight during the tile
+    if (more) st.load(str, lds, j0 + TS, (int)min((int64_t)TS, je - j0 - TS), q.n, q.pre);   // in flight during the tile
     const float* tile = tiles[cur] + pq * RPP * NP;
     const int cq = min(RPP, max(0, cnt - pq * RPP));    // valid rows of this partition (ragged last tile only)
     // full partitions (every tile but a ragged last one) skip the per-row tail mask: same values, two instructions fewer per pair
@@ -342,18 +349,18 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
       for (int r = 0; r < R; ++r) {
         float acc[JBF];
         dist_group<NP, PK, NQ, JBF>(o[r], tile, jj, q, acc);
+        if constexpr (ZMAX) {      // training sweep: maximum known to be 0 (Params::train), s >= 1 from the owner's own pool row; the
+          float add = 0.f;         // coordinates arrive scaled (Params::pre), so the distance sum IS the negated logit
+#pragma unroll
+          for (int c = 0; c < JBF; ++c) add += (RAGGED && jj + c >= cq) ? 0.f : fexp2(PK == 1 ? acc[c] * xk : -acc[c]);     // (p = 1: unscaled, see Params::pre)
+          s[r] += add;
+          continue;
+        }
         float x[JBF];
 #pragma unroll
         for (int c = 0; c < JBF; ++c) {
           x[c] = root_of<ROOT>(acc[c], q) * xk;
           if (RAGGED && jj + c >= cq) x[c] = -INFINITY;      // ragged tail of the stream
-        }
-        if constexpr (ZMAX) {      // training sweep: maximum known to be 0 (Params::train), s >= 1 from the owner's own pool row
-          float add = 0.f;
-#pragma unroll
-          for (int c = 0; c < JBF; ++c) add += fexp2(x[c]);
-          s[r] += add;
-          continue;
         }
         // clamp keeps (-inf) - (-inf) out of the exponent when nothing valid was seen yet
         float xm = x[0];
@@ -472,14 +479,14 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
   const int pq = wave * 2 + hf;
   const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
   f32x2 o[R][NP / 2], g[R][NP / 2];
-  load_owners<NP, R>(o, own, ldo, own0, n_own, q.n);
+  load_owners<NP, R>(o, own, ldo, own0, n_own, q.n, q.pre);
   float oL[R], oC[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int64_t i = own0 + (int64_t)r * HALF + li;
     oL[r] = 0.f; oC[r] = 0.f;
     if (OWNER_STATS && i < n_own) { oL[r] = statL[i]; oC[r] = statC[i]; }
-    if (FOLD) oC[r] *= fexp2(-oL[r]);               // u_i = C_i 2^-L_i (Params::train bit 1: L_i >= 0)
+    if (FOLD) oC[r] *= fexp2(-oL[r]) * q.gfold;     // u_i = C_i 2^-L_i x (p / pre^(p-1)) (Params::train bit 1: L_i >= 0; gfold see Params)
 #pragma unroll
     for (int k2 = 0; k2 < NP / 2; ++k2) g[r][k2] = (f32x2){0.f, 0.f};
   }
@@ -498,11 +505,11 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     }
   };
   auto store_stats = [&](int b) {
-    if (STREAM_STATS && (int)threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = FOLD ? rc * fexp2(-rl) : rc; }
+    if (STREAM_STATS && (int)threadIdx.x < TS) { tLs[b][threadIdx.x] = rl; tCs[b][threadIdx.x] = FOLD ? rc * fexp2(-rl) * q.gfold : rc; }
   };
   if (jb < je) {
     const int c0 = (int)min((int64_t)TS, je - jb);
-    st.load(str, lds, jb, c0, q.n); load_stats(jb, c0);
+    st.load(str, lds, jb, c0, q.n, q.pre); load_stats(jb, c0);
     st.store(tiles[0]); store_stats(0);
   }
   __syncthreads();
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     const bool more = j0 + TS < je;
     if (more) {
       const int c1 = (int)min((int64_t)TS, je - j0 - TS);
-      st.load(str, lds, j0 + TS, c1, q.n); load_stats(j0 + TS, c1);
+      st.load(str, lds, j0 + TS, c1, q.n, q.pre); load_stats(j0 + TS, c1);
     }
     const float* tile = tiles[cur] + pq * RPP * NP;
     const float* tL = tLs[cur] + pq * RPP;
@@ -537,11 +544,16 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
         float coef[JW];
 #pragma unroll
         for (int c = 0; c < JW; ++c) {
+          if constexpr (FOLD) {      // scaled coordinates: x = -acc; p, the sign and the gradient's 1 / pre^(p-1) live in the row factors
+            static_assert(!FOLD || (STATS == 3 && !ROOT), "folded coefficient: symmetric training sweep only");
+            float cf = fexp2(PK == 1 ? acc[c] * xk : -acc[c]) * (oC[r] + tC[jj + c]);   // one exponential, one add, one multiply per pair
+            if (jj + c >= cq) cf = 0.f;
+            coef[c] = cf;
+            continue;
+          }
           const float x = root_of<ROOT>(acc[c], q) * xk;
           float w = 0.f;
           if constexpr (FOLD) {
-            static_assert(!FOLD || STATS == 3, "folded coefficient: symmetric training sweep only");
-            w = fexp2(x) * (oC[r] + tC[jj + c]);                              // one exponential per pair; tC = 0 in the ragged tail
           } else {
             if (OWNER_STATS) w = oC[r] * fexp2(x - oL[r]);
             if (STREAM_STATS) w = fmaf(tC[jj + c], fexp2(x - tL[jj + c]), w);   // tC = 0 masks the ragged tail

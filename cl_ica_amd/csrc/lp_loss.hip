@@ -593,6 +593,7 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd_train: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, false);
   q.train = train_flags() & 1;       // the pool contains the owner rows: running maximum known (Params::train)
+  if (q.train && exponent_kind(d->p) >= 2 && d->pow) q.pre = powf(q.kscale, 1.f / d->p);     // scaled coordinates: the distance sum is -logit (p = 2, 3)
   hipStream_t st = as_stream(stream);
   float2* part = reinterpret_cast<float2*>(w.scratch);
   launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
@@ -627,6 +628,10 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   }
   float* partR = reinterpret_cast<float*>(w.scratch);
   q.train = train_flags() & 2;       // every row statistic is the log2 of a sum >= 1: folded coefficient (Params::train)
+  if (q.train && exponent_kind(d->p) != 0 && d->pow) {
+    if (exponent_kind(d->p) >= 2) q.pre = powf(q.kscale, 1.f / d->p);     // (p = 1 keeps unscaled coordinates: sign(d) must be exact)
+    q.gfold = d->p / powf(q.pre, d->p - 1.f);
+  }
   launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
   const int blocks = (int)ceil_div(rows * PR.np, THREADS);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,
