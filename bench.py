@@ -77,6 +77,9 @@ def parse():
                          "(pool of R x B rows, workspaces, weight-gradient halves, gradient buckets, every collective on a one-rank RCCL "
                          "group inside the step graph; the other ranks' rows are copies).  Prints the plan and this rank's step time -- NOT "
                          "a multi-GPU measurement")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not spawn the two short rocprofv3 --pmc passes that measure the dominant kernel's HBM-side bytes "
+                         "(roofline.traffic then falls back to the committed profile)")
     ap.add_argument("--no-conv-configs", action="store_true", help="skip the c4 / c5 legs of `secondary`")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
@@ -392,6 +395,52 @@ def roofline_leg(tr, reps=20):
     return roof, rows
 
 
+def measure_traffic(args, kernel_symbol, timeout_s=150):
+    """HBM-side bytes per launch of `kernel_symbol`, measured BY THIS RUN: two short child runs of this script
+    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no other trace domains, as
+    MI355X_MICROARCH.md prescribes), per-launch averages over the child's steps; FETCH_SIZE x 2 (the guide's gfx950 correction for wide
+    coalesced reads) + WRITE_SIZE, both reported in KB.  Returns (bytes, description) or (None, reason)."""
+    import csv, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    here = os.path.dirname(os.path.abspath(__file__))
+    child = [sys.executable, os.path.join(here, "bench.py"), "--steps", "6", "--warmup", "2", "--windows", "1", "--no-cpu-baseline", "--no-roofline",
+             "--no-native-leg", "--no-dropin", "--no-secondary", "--no-traffic", "--n", str(args.n), "--batch-size", str(args.batch_size),
+             "--p", str(args.p), "--space-type", args.space_type] + (["--native-fp32"] if args.native_fp32 else [])
+    want = kernel_symbol.split(" (+")[0].split(" [")[0]
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="clica_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "-d", out, "-o", "p", "--output-format", "csv", "--"] + child,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            path = None
+            for root, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(root, f)
+            if r.returncode != 0 or path is None:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {(r.stderr or '')[-200:]}"
+            acc = []
+            for row in csv.DictReader(open(path)):
+                if row.get("Counter_Name") == ctr and row["Kernel_Name"].split("(")[0].replace("void ", "") == want:
+                    acc.append(float(row["Counter_Value"]))
+            if not acc:
+                return None, f"no {ctr} rows for {want}"
+            vals[ctr] = (sum(acc) / len(acc), len(acc))
+    except Exception as e:      # noqa: BLE001  (a profiler hiccup must not cost the bench line)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    total = 2.0 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024
+    return round(total), (f"measured by this run: child runs of bench.py (6 steps) under rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE "
+                          f"(separate passes); per-launch averages over {vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} launches; 2 x FETCH_SIZE "
+                          f"({2 * vals['FETCH_SIZE'][0] / 1024:.1f} MB) + WRITE_SIZE ({vals['WRITE_SIZE'][0] / 1024:.1f} MB)")
+
+
 def loss_leg(tr, reps=20):
     """Event-time the tiled Lp-InfoNCE forward and backward (all their kernels) on the step's buffers."""
     import ctypes as C
@@ -399,11 +448,12 @@ def loss_leg(tr, reps=20):
     lib, st = _lib.load(), _lib.stream_ptr()
     B, n, o = tr.B, tr.n, tr.loss_out
     y1, y2 = tr.y[:B], tr.y[B:]
-    z3 = y1 if tr.world == 1 else tr.z_all
+    pooled = getattr(tr, "z_all", None) is not None          # data parallel, or the emulated / dry-run pool of an R-rank job
+    z3 = tr.z_all if pooled else y1
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf = tb = 0.0
     train = getattr(tr, "loss_train", False)
-    pool_lse = o[2 * B:3 * B] if tr.world == 1 else tr.lse_all
+    pool_lse = tr.lse_all if pooled else o[2 * B:3 * B]
     for _ in range(reps):
         ev[0].record()
         if train:      # the fused training pair of entry points the engine calls (coefficient step inside finalize, means inside the reduce)
@@ -432,6 +482,8 @@ def loss_leg(tr, reps=20):
     return {"fwd_us": 1e6 * tf / reps, "bwd_us": 1e6 * tb / reps, "pairs": pairs,
             "fwd_gpairs_per_s": pairs / (tf / reps) / 1e9, "fwd_tflops_valu": fl_f / (tf / reps) / 1e12,
             "bwd_tflops_valu": 3 * fl_f / (tb / reps) / 1e12, "valu_peak_tflops": PEAK_FP32_VALU_TFLOPS,
+            "fwd_valu_frac": fl_f / (tf / reps) / 1e12 / PEAK_FP32_VALU_TFLOPS, "bwd_valu_frac": 3 * fl_f / (tb / reps) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+            "negatives_pool": int(z3.shape[0]),
             "algorithmic_bytes_fwd": 4 * n * (2 * B + z3.shape[0]) + 12 * B}
 
 
@@ -762,10 +814,27 @@ def main():
             out["ranks"] = comm
     if rank == 0 and not args.no_roofline:
         roof, rows = roofline_leg(tr)
+        if world == 1 and not args.no_traffic:
+            tb_, src_ = measure_traffic(args, roof["kernel"])
+            if tb_ is not None:
+                roof["traffic_committed_profile"] = roof.get("traffic")
+                roof["traffic"], roof["traffic_source"] = tb_, src_
+            else:
+                roof["traffic_source"] = (roof.get("traffic_source") or "") + f" [in-run measurement unavailable: {src_}]"
         out["roofline"] = roof
         out["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
         ll = loss_leg(tr)
         out["loss_kernel"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ll.items()}
+        if world == 1 and (args.n, args.space_type, args.p) == (10, "box", 2):
+            # the same sweeps at the negatives pool of the 8-GPU job (49 152 rows: what bounds weak scaling)
+            tr8 = build_trainer(args, device, 1, emulate_pool_ranks=8)
+            for _ in range(3):
+                tr8.step()
+            torch.cuda.synchronize()
+            l8 = loss_leg(tr8, reps=10)
+            out["loss_kernel_pool_49152"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in l8.items()}
+            del tr8
+            torch.cuda.empty_cache()
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 src = f"gpurun_out/profile_{tag}"
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(f"{src}/trace/t_kernel_stats.csv", f"profiles/{tag}_kernel_stats.csv")
