@@ -678,7 +678,7 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
     """BASELINE configs[3] / configs[4] on one GPU: the conv encoders run on PyTorch-ROCm / MIOpen as north_star
     prescribes, head / loss / optimizer on the HIP library, the training step is the reference's own.
       c4  main_3dident.py:467-503 train_step: ResNet-18 (cl_ica_amd/resnet.py, torchvision's layout) on (1024, 3, 64, 64) x 2 views,
-          channels-last, BatchNorm on batch statistics, LeakyReLU -> Linear(30 -> 3) -> position-only box head, LpSimCLRLoss(p = 2), flat Adam
+          NCHW like the reference, BatchNorm on batch statistics, LeakyReLU -> Linear(30 -> 3) -> position-only box head, LpSimCLRLoss(p = 2), flat Adam
       c5  kitti_masks/solver.py:61-74: BetaVAE_H (five k = 4 convs + Linear(256 -> 5)) on (2048, 1, 64, 64) Bernoulli(0.1) masks = 1024
           pairs, z_dim 5, p = 1, flat Adam; the whole global batch of the 4-rank job on ONE GPU (per rank it is 512 images / 256 pairs)
     Synthetic inputs of the reference's shapes (no dataset in the image), no host sync inside the timed windows."""
@@ -690,17 +690,19 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
         a = types.SimpleNamespace(position_only=True, rotation_and_color_only=False, rotation_only=False, color_only=False,
                                   non_periodic_rotation_and_color=False, box_constraint="fix", sphere_constraint=None,
                                   unsupervised_loss="l2", identity_solution=False, encoder="rn18")
-        f = T.setup_f(a, 3, 0).to(device).to(memory_format=torch.channels_last)
+        # NCHW, the reference's layout (main_3dident.py never sets a memory format): measured 31.7 steps/s against 21.1 in channels_last,
+        # where MIOpen's NHWC BatchNorm kernels take 53 % of the step (tools/conv_layout_probe.py, profiles/r4_c4_*)
+        f = T.setup_f(a, 3, 0).to(device)
         f.train()
         loss = T.make_unsupervised_loss(a, 3)
         opt = Adam(f.parameters(), lr=1e-4)
-        x1 = torch.randn(1024, 3, 64, 64, device=device).contiguous(memory_format=torch.channels_last)
-        x2 = (x1 + 0.1 * torch.randn_like(x1)).contiguous(memory_format=torch.channels_last)
+        x1 = torch.randn(1024, 3, 64, 64, device=device)
+        x2 = x1 + 0.1 * torch.randn_like(x1)
 
         def step():
             return T.train_step(((None, None), (x1, x2)), loss, opt, f, sync=False)[0]
         n_params = sum(p.numel() for p in f.parameters())
-        work = ("main_3dident.py train_step (:467-503): ResNet-18 backbone (MIOpen, channels-last) on (1024, 3, 64, 64) x 2 views -> HIP "
+        work = ("main_3dident.py train_step (:467-503): ResNet-18 backbone (MIOpen, NCHW) on (1024, 3, 64, 64) x 2 views -> HIP "
                 "LeakyReLU / Linear(30, 3) / Softclip head -> HIP LpSimCLRLoss(p = 2) -> backward -> flat HIP Adam")
     else:
         from cl_ica_amd.kitti_masks.solver import Solver
