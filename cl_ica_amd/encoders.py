@@ -70,10 +70,11 @@ class _MLPFusedFn(torch.autograd.Function):
 
     @staticmethod
     def _wgrad_ws(dev, M, shapes):
-        key = (dev, M, tuple(shapes))
+        # keyed by the stream as well: the slabs are scratch of ONE backward at a time, and backwards on different streams may overlap
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, M, tuple(shapes))
         ws = _MLPFusedFn._ws_cache.get(key)
         if ws is None:
-            if len(_MLPFusedFn._ws_cache) > 8:
+            if len(_MLPFusedFn._ws_cache) >= 4:      # each entry is 30-60 MB: a few shapes (train / eval batch), not a leak
                 _MLPFusedFn._ws_cache.clear()
             ws = _MLPFusedFn._ws_cache[key] = ops.mlp_wgrad_workspace(M, shapes, dev)
         return ws
@@ -180,10 +181,10 @@ class _MLPFusedSplitFn(torch.autograd.Function):
 
     @staticmethod
     def _wgrad_ws(dev, M, shapes):
-        key = (dev, M, tuple(shapes))
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, M, tuple(shapes))
         ws = _MLPFusedSplitFn._ws_cache.get(key)
         if ws is None:
-            if len(_MLPFusedSplitFn._ws_cache) > 8:
+            if len(_MLPFusedSplitFn._ws_cache) >= 4:
                 _MLPFusedSplitFn._ws_cache.clear()
             ws = _MLPFusedSplitFn._ws_cache[key] = ops.mlp_wgrad_split_workspace(M, shapes, dev)
         return ws
