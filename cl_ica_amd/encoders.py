@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import weakref
+
 import torch
 from torch import nn
 
@@ -157,11 +159,77 @@ class _MLPFusedFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class _SplitPlan:
+    """What one (device, rows, layer shapes) call of the split whole-stack kernels needs and that does not change from step to step:
+    which layers take planes / fp32 (`clica_mlp_wgrad_split_kind`), the byte layout of ONE buffer for the forward's saved tensors
+    (planes, fp32 activations of tiny-dimension layers, sign bits) and of ONE for the backward's (dZ planes / fp32), and the constant
+    ctypes argument arrays.  Per call that leaves two allocations and a handful of pointer sums where the first version made ~25
+    tensors and ~40 list comprehensions over them (tools/dropin_hosttime.py: 104 -> ~35 us of host time in front of the forward launch,
+    in a step whose device waits for exactly that)."""
+
+    _cache = {}
+
+    @staticmethod
+    def get(dev, M, shapes):
+        key = (dev, M, shapes)
+        pl = _SplitPlan._cache.get(key)
+        if pl is None:
+            if len(_SplitPlan._cache) >= 16:
+                _SplitPlan._cache.clear()
+            pl = _SplitPlan._cache[key] = _SplitPlan(dev, M, shapes)
+        return pl
+
+    def __init__(self, dev, M, shapes):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        L = len(shapes)
+        self.dev, self.M, self.L, self.shapes = dev, M, L, shapes
+        self.kinds = kinds = [ops.mlp_wgrad_split_kind(N, K) for N, K in shapes]        # 0: matrix-core weight gradient from planes
+        nb = C.c_size_t()
+
+        def planes_bytes(width, ones):
+            _lib.check(lib.clica_mlp_planes_bytes(M, width, 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
+            return nb.value
+        _lib.check(lib.clica_mlp_signmask_bytes(M, C.byref(nb)), "clica_mlp_signmask_bytes")
+        mask_bytes = nb.value
+        off = [0]
+
+        def take(nbytes):
+            o = off[0]
+            off[0] = (o + nbytes + 255) & ~255
+            return o
+        # forward: layer l's output as planes (with the ones column) if the NEXT layer's weight gradient reads planes, as fp32 if it
+        # reads fp32 (tiny-dimension layer); the last layer's output is the result (its own tensor)
+        self.f_planes = [take(planes_bytes(shapes[l][0], True)) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
+        self.f_outs = [take(4 * M * shapes[l][0]) if (l + 1 < L and kinds[l + 1] == 1) else None for l in range(L)]
+        self.f_masks = [take(mask_bytes) if l + 1 < L else None for l in range(L)]
+        self.f_bytes = max(off[0], 256)
+        self.f_ldo = (C.c_int64 * L)(*[shapes[l][0] if (self.f_outs[l] is not None or l == L - 1) else 0 for l in range(L)])
+        self.N = (C.c_int32 * L)(*[s[0] for s in shapes])
+        self.K = (C.c_int32 * L)(*[s[1] for s in shapes])
+        # backward chain (layer L-1 first, down to layer 1): link i differentiates layer chain[i] and emits dZ of layer chain[i] - 1
+        self.chain = chain = list(range(L - 1, 0, -1))
+        off[0] = 0
+        self.b_planes = {j: (take(planes_bytes(shapes[j][0], False)) if kinds[j] == 0 else None) for j in range(L - 1)}
+        self.b_f32 = {j: (take(4 * M * shapes[j][0]) if kinds[j] == 1 else None) for j in range(L - 1)}
+        self.b_bytes = max(off[0], 256)
+        n = len(chain)
+        self.cN = (C.c_int32 * max(n, 1))(*[shapes[l][1] for l in chain])
+        self.cK = (C.c_int32 * max(n, 1))(*[shapes[l][0] for l in chain])
+        self.VP, self.VPc, self.I64, self.I64c = C.c_void_p * L, C.c_void_p * max(n, 1), C.c_int64 * L, C.c_int64 * max(n, 1)
+        self.lddw = (C.c_int64 * L)(*[s[1] for s in shapes])
+
+
 class _MLPFusedSplitFn(torch.autograd.Function):
     """``_MLPFusedFn`` in the split-bf16 arithmetic the training engine uses by default (fp32 results from six bf16 products of
     exact 3-way operand splits: csrc/fused_mlp.hip mlp_split_k, csrc/wgrad_split.hip): forward stack, backward data chain and the
     grouped weight gradients, with hidden activations / dZ handed from kernel to kernel as bf16 planes where a matrix-core weight
-    gradient is their only reader.  ``CLICA_SPLIT_BF16=0`` / ``CLICA_DROPIN_SPLIT=0`` keep the fp32-MFMA kernels."""
+    gradient is their only reader.  ``CLICA_SPLIT_BF16=0`` / ``CLICA_DROPIN_SPLIT=0`` keep the fp32-MFMA kernels.
+
+    ``apply(slope, n_in, x_0 .. x_{n_in-1}, W_0, b_0, ...)``: the `n_in` row batches run STACKED through one launch per phase and
+    come back as `n_in` outputs (row slices of one result) -- what `lazy.defer` does with the reference's two encoder calls per
+    step, without CatBackward / SliceBackward nodes around the function (their backward was five small launches)."""
 
     _pack_cache = {}
     _ws_cache = {}
@@ -176,8 +244,19 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         shapes = [tuple(w.shape) for w in params_w]
         reuse = c is not None and c["shapes"] == shapes
         packed, packed_t = ops.mlp_pack_split_both([w.detach() for w in params_w], c["packed"] if reuse else None, c["packed_t"] if reuse else None)
-        _MLPFusedSplitFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t)
+        _MLPFusedSplitFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t,
+                                                 params=[weakref.ref(w) for w in params_w])
         return packed, packed_t, key
+
+    @staticmethod
+    def repack_if_changed(*_a, **_k):
+        """Optimizer post-step hook: bring the fragment-order weight copies up to date NOW, at the end of the step, where the host is
+        about to wait for the device anyway -- not in front of the next step's first launch, where the device waits for the host."""
+        for dev, c in list(_MLPFusedSplitFn._pack_cache.items()):
+            ws = [r() for r in c.get("params", ())]
+            if ws and all(w is not None for w in ws) and _MLPFusedFn._weights_key(ws) != c["key"]:
+                with torch.cuda.device(dev):
+                    _MLPFusedSplitFn._packed(ws)
 
     @staticmethod
     def _wgrad_ws(dev, M, shapes):
@@ -190,71 +269,142 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         return ws
 
     @staticmethod
-    def forward(ctx, x, slope, *params):
+    def forward(ctx, slope, n_in, *args):
+        from . import _lib
+        xs, params = args[:n_in], args[n_in:]
         L = len(params) // 2
-        ws, bs = [p.detach() for p in params[0::2]], [p.detach() for p in params[1::2]]
-        x = x.detach()
+        x = xs[0].detach() if n_in == 1 else torch.cat([t.detach() for t in xs], 0)
+        (x, ldx) = ops._mat("x", x)
         M, dev = x.shape[0], x.device
-        packed, _, key = _MLPFusedSplitFn._packed(params[0::2])
-        kinds = [ops.mlp_wgrad_split_kind(w.shape[0], w.shape[1]) for w in ws]       # 0: matrix-core weight gradient from planes
-        # layer l's output: as planes (with the ones column) if the NEXT layer's weight gradient reads planes, as fp32 if it reads
-        # fp32 (tiny-dimension layer) or if it is the result
-        planes = [ops.mlp_planes_alloc(M, ws[l].shape[0], True, dev, zero=False) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
-        outs = [torch.empty((M, ws[l].shape[0]), dtype=torch.float32, device=dev) if (l == L - 1 or kinds[l + 1] == 1) else None
-                for l in range(L)]
-        masks = ops.mlp_signmask_alloc(M, L - 1, dev, zero=False) + [None]
-        ops.mlp_fwd_split(x, ws, bs, outs, packed, slope, signmasks=masks, planes=planes)
-        ctx.slope, ctx.L, ctx.kinds = slope, L, kinds
+        pw = params[0::2]
+        packed, _, key = _MLPFusedSplitFn._packed(pw)
+        pl = _SplitPlan.get(dev, M, tuple(tuple(w.shape) for w in pw))
+        arena = torch.empty(pl.f_bytes, dtype=torch.uint8, device=dev)
+        y = torch.empty((M, pl.shapes[-1][0]), dtype=torch.float32, device=dev)
+        base, VP = arena.data_ptr(), pl.VP
+        bias = VP(*[(b if b.is_contiguous() else b.contiguous()).data_ptr() for b in params[1::2]])
+        outs = VP(*[None if o is None else base + o for o in pl.f_outs[:-1]], y.data_ptr())
+        _lib.check(_lib.load().clica_mlp_fwd_split(x.data_ptr(), ldx, M, None, 0, 0.0, None, 0, L, bias, outs, pl.f_ldo, pl.N, pl.K,
+                                                   packed.data_ptr(), VP(*[None if o is None else base + o for o in pl.f_masks]),
+                                                   VP(*[None if o is None else base + o for o in pl.f_planes]),
+                                                   float(slope), _lib.stream_ptr()), "clica_mlp_fwd_split")
+        ctx.slope, ctx.L, ctx.plan, ctx.n_in = slope, L, pl, n_in
+        ctx.rows = [t.shape[0] for t in xs]
         ctx.pack_key = key
         ctx.params = params
-        ctx.save_for_backward(x, *outs[:-1], *planes[:-1], *masks[:-1], *ws)
-        return outs[-1]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, arena, *[w.detach() for w in pw])
+        if n_in == 1:
+            return y
+        # the row blocks as tensors of their own on y's storage (not autograd views of y: a view output of a multi-output function
+        # may not be modified in place, an ordinary output may)
+        res, off, N, st = [], 0, y.shape[1], y.untyped_storage()
+        for r in ctx.rows:
+            res.append(torch.empty(0, dtype=torch.float32, device=dev).set_(st, off * N, (r, N), (N, 1)))
+            off += r
+        return tuple(res)
 
     @staticmethod
-    def backward(ctx, gy):
-        L, slope, kinds = ctx.L, ctx.slope, ctx.kinds
+    def backward(ctx, *gys):
+        from . import _lib
+        import ctypes as C
+        L, slope, pl = ctx.L, ctx.slope, ctx.plan
+        kinds, shapes, M, dev = pl.kinds, pl.shapes, pl.M, pl.dev
         sv = ctx.saved_tensors
-        x = sv[0]
-        acts, planes, masks, ws = list(sv[1:L]), list(sv[L:2 * L - 1]), list(sv[2 * L - 1:3 * L - 2]), list(sv[3 * L - 2:])
-        gy = gy.contiguous()
-        M, dev = gy.shape[0], gy.device
+        x, arena, ws = sv[0], sv[1], list(sv[2:])
+        if ctx.n_in == 1:
+            gy = gys[0]
+            if gy is None:
+                return (None,) * (3 + 2 * L)
+            gy = gy.contiguous()
+        else:
+            if all(g is None for g in gys):
+                return (None,) * (2 + ctx.n_in + 2 * L)
+            gy = torch.cat([g if g is not None else x.new_zeros((r, shapes[-1][0])) for g, r in zip(gys, ctx.rows)], 0)
+        _lib.require_cuda(gy, "grad_output")
         need = ctx.needs_input_grad
+        need_x = any(need[2:2 + ctx.n_in])
         cur = _MLPFusedSplitFn._pack_cache.get(dev)
         if cur is not None and cur["key"] == ctx.pack_key:
             packed_t = cur["packed_t"]
         else:
             _, packed_t = ops.mlp_pack_split_both(ws)
-        chain = list(range(L - 1, 0, -1))
-        # dZ of layer j = l - 1: planes for a matrix-core weight gradient, fp32 for a tiny-dimension one (and for d loss / d input)
-        want_f32 = {j: (kinds[j] == 1 or (j == 0 and need[0])) for j in range(L - 1)}
-        dz_f32 = {j: (torch.empty((M, ws[j].shape[0]), dtype=torch.float32, device=dev) if want_f32[j] else None) for j in range(L - 1)}
-        dz_pl = {j: (ops.mlp_planes_alloc(M, ws[j].shape[0], False, dev, zero=False) if kinds[j] == 0 else None) for j in range(L - 1)}
+        lib, sp = _lib.load(), _lib.stream_ptr()
+        fb = arena.data_ptr()
+        barena = torch.empty(pl.b_bytes, dtype=torch.uint8, device=dev)
+        bb = barena.data_ptr()
+        # dZ of layer j: planes for a matrix-core weight gradient, fp32 for a tiny-dimension one (and for d loss / d input)
+        dz0 = None
+        f32_ptr = {j: (None if pl.b_f32[j] is None else bb + pl.b_f32[j]) for j in range(L - 1)}
+        if L > 1 and need_x and f32_ptr[0] is None:
+            dz0 = torch.empty((M, shapes[0][0]), dtype=torch.float32, device=dev)
+            f32_ptr[0] = dz0.data_ptr()
         if L > 1:
-            ops.mlp_dgrad_chain_split(gy, [ws[l] for l in chain], packed_t, [dz_f32[l - 1] for l in chain], slope,
-                                      masks_chain=[masks[l - 1] for l in chain], planes=[dz_pl[l - 1] for l in chain])
-        dz_f32[L - 1] = gy
-        dz_pl[L - 1] = ops.mlp_planes_from_f32(gy, False) if kinds[L - 1] == 0 else None
-        xin_f32 = [x] + acts                                   # fp32 input of layer l (None where only planes were written)
-        xin_pl = [ops.mlp_planes_from_f32(x, True) if kinds[0] == 0 else None] + planes
+            chain, VPc = pl.chain, pl.VPc
+            _lib.check(lib.clica_mlp_dgrad_split(gy.data_ptr(), gy.stride(0), M, L - 1, pl.cN, pl.cK, packed_t.data_ptr(),
+                                                 VPc(*[fb + pl.f_masks[l - 1] for l in chain]),
+                                                 VPc(*[f32_ptr[l - 1] for l in chain]),
+                                                 pl.I64c(*[0 if f32_ptr[l - 1] is None else shapes[l - 1][0] for l in chain]),
+                                                 VPc(*[None if pl.b_planes[l - 1] is None else bb + pl.b_planes[l - 1] for l in chain]),
+                                                 float(slope), sp), "clica_mlp_dgrad_split")
+        keep = [barena]
+        # operands of the weight gradients, per layer: planes (kind 0) or fp32 (kind 1)
+        dzp, xp, dzf, lddz, xf, ldxf = [None] * L, [None] * L, [None] * L, [0] * L, [None] * L, [0] * L
+        for l in range(L):
+            if kinds[l] == 0:
+                if l == L - 1:
+                    t = ops.mlp_planes_from_f32(gy, False); keep.append(t); dzp[l] = t.data_ptr()
+                else:
+                    dzp[l] = bb + pl.b_planes[l]
+                if l == 0:
+                    t = ops.mlp_planes_from_f32(x, True); keep.append(t); xp[l] = t.data_ptr()
+                else:
+                    xp[l] = fb + pl.f_planes[l - 1]
+            else:
+                dzf[l], lddz[l] = (gy.data_ptr(), gy.stride(0)) if l == L - 1 else (f32_ptr[l], shapes[l][0])
+                xf[l], ldxf[l] = (x.data_ptr(), x.stride(0)) if l == 0 else (fb + pl.f_outs[l - 1], shapes[l - 1][0])
         prm = ctx.params
-
-        in_place = _inplace_ok(prm, need)
+        in_place = _inplace_ok(prm, (True, True) + tuple(need[2 + ctx.n_in:]))
         if in_place:
-            dWs, dbs, acc = [prm[2 * l].grad for l in range(L)], [prm[2 * l + 1].grad for l in range(L)], True
+            dWs, dbs, acc = [prm[2 * l].grad for l in range(L)], [prm[2 * l + 1].grad for l in range(L)], 1
         else:
             dWs = [torch.empty_like(w) for w in ws]
             dbs = [torch.empty(w.shape[0], dtype=torch.float32, device=dev) for w in ws]
-            acc = False
-        ops.mlp_wgrad_split(M, [dz_pl[l] for l in range(L)], [xin_pl[l] if kinds[l] == 0 else None for l in range(L)],
-                            [dz_f32[l] if kinds[l] == 1 else None for l in range(L)], [xin_f32[l] if kinds[l] == 1 else None for l in range(L)],
-                            dWs, dbs, ws=_MLPFusedSplitFn._wgrad_ws(dev, M, [tuple(w.shape) for w in ws]), accumulate=acc)
+            acc = 0
+        wsb = _MLPFusedSplitFn._wgrad_ws(dev, M, shapes)
+        VP = pl.VP
+        _lib.check(lib.clica_mlp_wgrad_split(M, L, VP(*dzp), VP(*xp), VP(*dzf), pl.I64(*lddz), VP(*xf), pl.I64(*ldxf),
+                                             VP(*[w.data_ptr() for w in dWs]), pl.I64(*[w.stride(0) for w in dWs]),
+                                             VP(*[b.data_ptr() for b in dbs]), pl.N, pl.K, acc, wsb.data_ptr(), wsb.numel(), sp),
+                   "clica_mlp_wgrad_split")
         grads = [None] * (2 * L)
         if not in_place:
             for l in range(L):
-                grads[2 * l] = dWs[l] if need[2 + 2 * l] else None
-                grads[2 * l + 1] = dbs[l] if need[3 + 2 * l] else None
-        dx = ops.linear_dgrad(dz_f32[0], ws[0], None, slope) if need[0] else None
-        return (dx, None, *grads)
+                grads[2 * l] = dWs[l] if need[2 + ctx.n_in + 2 * l] else None
+                grads[2 * l + 1] = dbs[l] if need[3 + ctx.n_in + 2 * l] else None
+        dxs = [None] * ctx.n_in
+        if need_x:
+            d0 = gy if L == 1 else (dz0 if dz0 is not None else torch.as_strided(barena.view(torch.float32), (M, shapes[0][0]), (shapes[0][0], 1), pl.b_f32[0] // 4))
+            dx = ops.linear_dgrad(d0, ws[0], None, slope)
+            off = 0
+            for i, r in enumerate(ctx.rows):
+                dxs[i] = dx[off:off + r] if need[2 + i] else None
+                off += r
+        del keep
+        return (None, None, *dxs, *grads)
+
+
+def _early_repack() -> bool:
+    import os
+    return os.environ.get("CLICA_DROPIN_EARLY_PACK", "1") != "0"
+
+
+def _after_step():
+    if _early_repack():
+        _MLPFusedSplitFn.repack_if_changed()
+
+
+lazy.AFTER_STEP.append(_after_step)
 
 
 def _dropin_split(linears) -> bool:
@@ -328,13 +478,21 @@ class FusedMLP(nn.Sequential):
         for lin in linears:
             params += [lin.weight, lin.bias]
 
+        post = [m for m in mods if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer))]
+
         def compute(xx):
-            fn = (_MLPFusedSplitFn if _dropin_split(linears) else _MLPFusedFn) if _use_fused(linears, xx.shape[0]) else _MLPStackFn
-            y = fn.apply(xx, slope, *params)
-            for m in mods:
-                if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
-                    y = m(y)
+            if _use_fused(linears, xx.shape[0]):
+                y = _MLPFusedSplitFn.apply(slope, 1, xx, *params) if _dropin_split(linears) else _MLPFusedFn.apply(xx, slope, *params)
+            else:
+                y = _MLPStackFn.apply(xx, slope, *params)
+            for m in post:
+                y = m(y)
             return y
+
+        def compute_many(xlist):       # several pending calls as ONE function with several outputs (None: not on this path)
+            if post or not (_use_fused(linears, sum(t.shape[0] for t in xlist)) and _dropin_split(linears)):
+                return None
+            return list(_MLPFusedSplitFn.apply(slope, len(xlist), *xlist, *params))
         # The reference's train_step calls the encoder twice per step (main_mlp.py:270-271).  A training call that does not fill the
         # chip on its own (fewer than 256 panels of 48 rows) is DEFERRED: if the same module is called again before anything uses the
         # result, both batches run as one stacked launch per phase (cl_ica_amd/lazy.py); any other use computes it right away.
@@ -344,7 +502,7 @@ class FusedMLP(nn.Sequential):
             for m in mods:
                 if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
                     every += [q for q in m._parameters.values() if q is not None]
-            return lazy.defer(self, x, compute, (x.shape[0], linears[-1].out_features), every)
+            return lazy.defer(self, x, compute, (x.shape[0], linears[-1].out_features), every, compute_many=compute_many)
         return compute(x)
 
 

@@ -28,7 +28,7 @@ from typing import Callable, List, Optional
 import torch
 from torch.utils._pytree import tree_map
 
-__all__ = ["LazyOut", "defer", "plain", "enabled", "flush_all"]
+__all__ = ["LazyOut", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP"]
 
 _META_GETTERS = {"shape", "dtype", "device", "requires_grad", "ndim", "layout", "is_cuda", "is_leaf_placeholder"}
 _META_METHODS = {"dim", "size", "__len__", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "get_device",
@@ -43,8 +43,9 @@ def enabled() -> bool:
 class _Pending:
     """Calls of one owner (module) that have not run yet: at most `max_items` inputs of the same trailing shape."""
 
-    def __init__(self, owner, compute: Callable[[torch.Tensor], torch.Tensor], params, max_items: int = 2):
+    def __init__(self, owner, compute: Callable[[torch.Tensor], torch.Tensor], params, max_items: int = 2, compute_many=None):
         self.owner, self.compute, self.max_items = owner, compute, max_items
+        self.compute_many = compute_many       # optional: list of inputs -> list of outputs (or None) as one autograd node
         self.params = list(params)
         self.versions = [p._version for p in self.params]
         self.items: List = []          # (input tensor, LazyOut)
@@ -80,11 +81,13 @@ class _Pending:
             if len(items) == 1:
                 vals = [self.compute(items[0][0])]
             else:
-                ystack = self.compute(torch.cat([x for x, _ in items], 0))
-                vals, off = [], 0
-                for x, _ in items:
-                    vals.append(ystack[off:off + x.shape[0]])
-                    off += x.shape[0]
+                vals = self.compute_many([x for x, _ in items]) if self.compute_many is not None else None
+                if vals is None:
+                    ystack = self.compute(torch.cat([x for x, _ in items], 0))
+                    vals, off = [], 0
+                    for x, _ in items:
+                        vals.append(ystack[off:off + x.shape[0]])
+                        off += x.shape[0]
         for (_, lz), v in zip(items, vals):
             if lz is not None:
                 lz._value = v
@@ -138,7 +141,8 @@ def plain(t):
     return t.materialize() if isinstance(t, LazyOut) else t
 
 
-def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], out_shape, params, max_items: int = 2):
+def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], out_shape, params, max_items: int = 2,
+          compute_many=None):
     """Register the call `compute(x)` of `owner`.  If `owner` has a pending call with a compatible input the two are stacked and
     run NOW (one launch); the result of this call is returned as a plain tensor.  Otherwise a LazyOut is returned."""
     pend: Optional[_Pending] = getattr(owner, "_clica_pending", None)
@@ -147,7 +151,7 @@ def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor
         return pend.flush()[-1]
     if pend is not None:
         pend.flush()                   # an incompatible (or stale) first call: it runs (or is dropped) on its own
-    pend = _Pending(owner, compute, params, max_items)
+    pend = _Pending(owner, compute, params, max_items, compute_many)
     owner._clica_pending = pend
     lz = LazyOut(pend, out_shape, x.dtype, x.device, True)
     pend.items.append((x, lz))
@@ -161,8 +165,19 @@ def flush_all(*_args, **_kwargs):
         p.flush()
 
 
+AFTER_STEP: List[Callable] = []      # what modules of this package want done once the parameters have changed (weight re-packing)
+
+
+def after_step(*_args, **_kwargs):
+    """End of an optimizer step (global post-hook below; cl_ica_amd.optim.Adam calls it itself): work that depends only on the new
+    parameters runs here, where the host is about to wait for the device, instead of in front of the next step's first launch."""
+    for f in AFTER_STEP:
+        f()
+
+
 try:        # torch >= 2.0
-    from torch.optim.optimizer import register_optimizer_step_pre_hook as _reg
+    from torch.optim.optimizer import register_optimizer_step_pre_hook as _reg, register_optimizer_step_post_hook as _reg_post
     _reg(flush_all)
+    _reg_post(after_step)
 except Exception:      # pragma: no cover
     pass

@@ -10,7 +10,9 @@ all-pairs kernels with an online log-sum-exp (cl_ica_amd/csrc/lp_kernels.h).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import functools
 from abc import ABC, abstractmethod
 from typing import Optional
 
@@ -32,6 +34,61 @@ class CLLoss(ABC):
         return self.loss(z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec)
 
 
+PATHS = collections.Counter()     # which backward ran (tests assert the one-sweep path is the one the reference's train_step gets)
+
+
+class _SharedScalars:
+    """The scalars a loss call returns, fetched ONCE and without draining the stream.
+
+    The reference's train_step ends with ``total_loss_value.item()`` and ``[v.item() for v in losses_value]`` (main_mlp.py:283-285):
+    three blocking 4-byte copies, each a full synchronisation of the stream -- behind the backward pass and the optimizer step that
+    were queued in the meantime, with the device idle while the host then prepares the next step (tools/dropin_timeline.py: ~200 us
+    of a 0.9 ms step).  The three values are adjacent floats of ONE result buffer that nothing writes after the loss forward, so the
+    loss call itself queues one asynchronous copy of them into pinned host memory right behind the forward kernels and records an
+    event; ``.item()`` waits for THAT event and answers from the host copy.  The backward / optimizer kernels of this step keep running
+    while the host samples the next batch.  Installed as an INSTANCE attribute ``item`` of the returned tensors, which stay ordinary
+    tensors; a tensor written in place after the call falls back to ``Tensor.item``.  ``CLICA_DROPIN_ASYNC_ITEM=0``: fetch on first
+    use with an ordinary blocking copy (still one instead of three)."""
+
+    __slots__ = ("src", "vals", "host", "event")
+
+    def __init__(self, src):
+        self.src, self.vals, self.host, self.event = src, None, None, None
+        if src.is_cuda and _async_item():
+            self.host = torch.empty(src.numel(), dtype=src.dtype, pin_memory=True)
+            self.host.copy_(src, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+
+    def item(self, t, k, version):
+        if t._version != version:
+            return torch.Tensor.item(t)
+        if self.vals is None:
+            if self.event is not None:
+                self.event.synchronize()
+                self.vals = self.host.tolist()
+            else:
+                self.vals = self.src.tolist()
+        return self.vals[k]
+
+
+def _async_item() -> bool:
+    import os
+    return os.environ.get("CLICA_DROPIN_ASYNC_ITEM", "1") != "0"
+
+
+def _share_items(src, outs):
+    sh = _SharedScalars(src)
+    for k, t in enumerate(outs):
+        t.item = functools.partial(sh.item, t, k, t._version)
+        # (a reference cycle tensor -> partial -> tensor: collected by the cycle GC like any other; the tensors are 4-byte views)
+
+
+def _means_of(mean):
+    """The 3-float buffer (mean, pos_mean, neg_mean) the forward wrote, recovered from its first element (a 0-dim view at offset 3B)."""
+    return torch.as_strided(mean.detach(), (3,), (1,))
+
+
 def _prep(name, t):
     if t.dim() != 2:
         raise ValueError(f"{name} must be 2-D (batch, n), got shape {tuple(t.shape)}")
@@ -44,6 +101,7 @@ class _PairLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z1, z2, z3, kind, desc):
+        ctx.set_materialize_grads(False)      # an output nobody differentiates arrives as None in backward, not as a tensor of zeros
         lib = _lib.load()
         (a, lda), (b, ldb), (c, ldc) = _prep("z1_rec", z1), _prep("z2_con_z1_rec", z2), _prep("z3_rec", z3)
         B = a.shape[0]
@@ -96,6 +154,7 @@ class _PairLossFn(torch.autograd.Function):
         _lib.check(ws_query(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), f"clica_{kind}_loss_workspace_bytes")
         ws = _lib.workspace(f"{kind}_loss", max(fwd_b.value, bwd_b.value), dev)
         bwd = lib.clica_lp_loss_bwd if kind == "lp" else lib.clica_dot_loss_bwd
+        PATHS["generic"] += 1
         _lib.check(bwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, c.data_ptr(), ldc, lse_i.data_ptr(),
                        _lib.ptr(ctx.rowgrad), n, _lib.ptr(g_mean_t), _lib.ptr(g_item_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
                        _lib.ptr(dz1), n, _lib.ptr(dz2), n, _lib.ptr(dz3), n, 0,
@@ -128,6 +187,7 @@ class _PairLossSymFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, z1, z2, desc):
+        ctx.set_materialize_grads(False)      # (with materialised zeros for the unused per-item output the one-sweep backward was never taken)
         lib = _lib.load()
         (a, lda), (b, ldb) = _prep("z1_rec", z1), _prep("z2_con_z1_rec", z2)
         B = a.shape[0]
@@ -162,6 +222,7 @@ class _PairLossSymFn(torch.autograd.Function):
         fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
         _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), "clica_lp_loss_workspace_bytes")
         ws = _lib.workspace("lp_loss", max(fwd_b.value, bwd_b.value), dev)
+        PATHS["sym_one_sweep" if g_item is None and desc.p >= 1.0 else "sym_two_sweeps"] += 1
         if g_item is None and desc.p >= 1.0:
             _lib.check(lib.clica_lp_loss_bwd_sym(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, a.data_ptr(), lda,
                                                  lse_i.data_ptr(), lse_i.data_ptr(), _lib.ptr(g_mean_t), _lib.ptr(g_pos_t), _lib.ptr(g_neg_t),
@@ -212,6 +273,7 @@ class LpSimCLRLoss(CLLoss):
             mean, per_item, pos_mean, neg_mean = _PairLossSymFn.apply(z1_rec, z2_con_z1_rec, desc)
         else:
             mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "lp", desc)
+        _share_items(_means_of(mean), (mean, pos_mean, neg_mean))
         return mean, per_item, [pos_mean, neg_mean]
 
 
@@ -231,6 +293,7 @@ class SimCLRLoss(CLLoss):
         desc = _lib.DotLossDesc(B=z1_rec.shape[0], B3=z3_rec.shape[0], n=z1_rec.shape[1], tau=float(self.tau),
                                 alpha=float(self.alpha), normalize=int(bool(self.normalize)))
         mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "dot", desc)
+        _share_items(_means_of(mean), (mean, pos_mean, neg_mean))
         return mean, per_item, [pos_mean, neg_mean]
 
 

@@ -100,6 +100,7 @@ class Adam:
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
                       float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world)
         ops.tick(self.step_dev)
+        lazy.after_step()         # e.g. the encoder's fragment-order weight copies, re-packed now rather than in front of the next forward
         return loss
 
     # ------------------------------------------------------------------ checkpoints (torch.optim.Adam layout)

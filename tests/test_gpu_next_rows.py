@@ -318,7 +318,14 @@ def test_dropin_lazy_stacking_and_symmetric_loss_match_plain_path(B, p, monkeypa
         z3 = torch.roll(a, 1, 0)
         assert losses._rolled_rows_of(z3, lazy.plain(a))
         tot, item, (pos, neg) = L(None, None, None, a, b, z3)
+        before = dict(losses.PATHS)
         tot.backward()
+        ran = {k: v - before.get(k, 0) for k, v in losses.PATHS.items() if v != before.get(k, 0)}
+        # the backward the reference's train_step gets: ONE symmetric pair sweep (round 3 took the two-sweep fallback here without
+        # anybody noticing: autograd handed the unused per-item output a tensor of zeros, which read as "a per-item upstream gradient")
+        assert ran == ({"sym_one_sweep": 1} if mode == "fast" else {"generic": 1}), ran
+        # .item() of the three scalars: one device copy, the same numbers Tensor.item returns
+        assert (tot.item(), pos.item(), neg.item()) == (torch.Tensor.item(tot), torch.Tensor.item(pos), torch.Tensor.item(neg))
         res[mode] = dict(loss=tot.item(), item=item.detach().cpu().numpy(), pos=pos.item(), neg=neg.item(), a=lazy.plain(a).detach().cpu().numpy(),
                          b=b.detach().cpu().numpy(), grads=[q.grad.detach().cpu().numpy().copy() for q in f.parameters()], f=f)
     fam, case = "dropin_lazy_sym", f"B={B} p={p}"
@@ -376,6 +383,52 @@ def test_dropin_lazy_output_single_use_and_per_item_upstream():
         os.environ["CLICA_DROPIN_SYM"] = "1"
     for k, (u, v) in enumerate(zip(outs[0][:-1], ref[:-1])):
         PARITY.check("dropin_lazy_sym", "per-item upstream", f"grad{k}", u.cpu().numpy(), v.cpu().numpy())
+
+
+def test_dropin_stacked_outputs_are_ordinary_tensors():
+    """The two results of a stacked call are outputs of ONE autograd node on one buffer: using only one of them, modifying one in
+    place, and scalars whose tensor was written after the loss call must all behave like the plain path."""
+    from cl_ica_amd import encoders, lazy, losses
+    torch.manual_seed(5)
+    f = encoders.get_mlp(10, 10, [100, 500, 100]).cuda()
+    x1, x2 = torch.rand(6144, 10, device="cuda"), torch.rand(6144, 10, device="cuda")
+
+    def grads(fn):
+        for q in f.parameters():
+            q.grad = None
+        fn().backward()
+        return [q.grad.clone() for q in f.parameters()]
+
+    def only_second():
+        a, b = f(x1), f(x2)
+        assert isinstance(a, lazy.LazyOut)
+        return (b ** 2).mean()                        # a is never used: its gradient arrives as None
+
+    def plain_second():
+        return (f(torch.cat([x2, x2]))[:6144] ** 2).mean()      # (>= 256 panels: not deferred)
+
+    for k, (u, v) in enumerate(zip(grads(only_second), grads(plain_second))):
+        PARITY.check("dropin_lazy_sym", "one of two outputs used", f"grad{k}", u.cpu().numpy(), v.cpu().numpy(), tol=2e-6, note="HIP vs HIP")
+
+    def inplace_first():
+        a, b = f(x1), f(x2)
+        a = lazy.plain(a)
+        a *= 2.0                                      # in place on one of the two outputs
+        return (a * b).mean()
+
+    def functional_first():
+        y = f(torch.cat([x1, x2]))
+        return (2.0 * y[:6144] * y[6144:]).mean()
+
+    for k, (u, v) in enumerate(zip(grads(inplace_first), grads(functional_first))):
+        PARITY.check("dropin_lazy_sym", "in-place on a stacked output", f"grad{k}", u.cpu().numpy(), v.cpu().numpy(), tol=2e-6, note="HIP vs HIP")
+    L = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
+    a, b = f(x1), f(x2)
+    tot, _, (pos, neg) = L(None, None, None, a, b, torch.roll(a, 1, 0))
+    v = torch.Tensor.item(pos)
+    with torch.no_grad():
+        pos.mul_(3.0)                                 # written after the call: the shared copy must not answer for it
+    assert abs(pos.item() - 3.0 * v) <= 1e-6 * abs(v) and tot.item() == torch.Tensor.item(tot)
 
 
 def test_dropin_autograd_grad_does_not_touch_the_arena():

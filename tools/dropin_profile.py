@@ -4,6 +4,9 @@
 import cProfile, contextlib, io, os, pstats, sys, time, types
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.environ.get("CLICA_PKG_ROOT"):      # A/B against another copy of the Python package (same HIP library)
+    os.environ.setdefault("CLICA_LIB", os.path.join(ROOT, "cl_ica_amd", "lib", "libclica_hip.so"))
+    ROOT = os.path.abspath(os.environ["CLICA_PKG_ROOT"])
 sys.path.insert(0, ROOT)
 from cl_ica_amd import encoders, invertible_network_utils as inu, losses, optim, train_mlp
 
