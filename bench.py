@@ -494,7 +494,8 @@ def dropin_leg(args, device, steps=40, warmup=8):
     reference's modules; torch autograd drives the HIP kernels through the drop-in modules.  Reported next to the fused engine:
     `torch_adam` keeps the reference's `torch.optim.Adam` line, `flat_adam` swaps that one line for `cl_ica_amd.optim.Adam`."""
     import contextlib, io, types
-    from cl_ica_amd import encoders, invertible_network_utils as inu, losses, optim, train_mlp
+    from cl_ica_amd import encoders, invertible_network_utils as inu, lazy, losses, optim, train_mlp
+    lazy_on = lazy.enabled()
     n, B = args.n, args.batch_size
     a = types.SimpleNamespace(n=n, box_min=0.0, box_max=1.0, sphere_r=1.0, m_param=1.0, m_p=0, c_param=0.05, c_p=2,
                               space_type=args.space_type)
@@ -535,19 +536,20 @@ def dropin_leg(args, device, steps=40, warmup=8):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         res[name] = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "final_loss": lv}
-    fused = encoders._use_fused([m for m in f if isinstance(m, torch.nn.Linear)], B)
-    lin_ = [m for m in f if isinstance(m, torch.nn.Linear)]
+    st = f._structure() if hasattr(f, "_structure") else (None,) * 5 + (False, False)
+    fused = encoders._use_fused(st[5], 2 * B if lazy_on else B)
     res["encoder_path"] = (("whole-encoder kernels in the split-bf16 arithmetic (clica_mlp_fwd_split / clica_mlp_dgrad_split / "
                             "clica_mlp_wgrad_split; weight gradients added into the flat optimizer's gradient arena in place)"
-                            if encoders._dropin_split(lin_) else
+                            if encoders._dropin_split(st[6]) else
                             "whole-encoder kernels (clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad)") if fused else
                            "per-layer GEMM kernels (clica_linear_*): a %d-row encoder call is %d workgroups of 48 rows, below the 128 the "
                            "whole-encoder kernels need to beat them" % (B, (B + 47) // 48))
-    from cl_ica_amd import lazy
-    res["what"] = ("reference train_step structure (main_mlp.py:258-285: two encoder calls of B rows, roll in the graph, 3 host syncs per "
-                   "step, eager launches, torch autograd) on the drop-in modules; deferred stacking of the two encoder calls "
-                   f"{'on' if lazy.enabled() else 'off'} (CLICA_DROPIN_LAZY), roll detection -> symmetric loss backward "
-                   f"{'on' if losses._sym_enabled() else 'off'} (CLICA_DROPIN_SYM)")
+    res["what"] = ("reference train_step structure (main_mlp.py:258-285: two encoder calls of B rows, roll in the graph, three .item() "
+                   "calls per step, eager launches, torch autograd) on the drop-in modules; deferred stacking of the two encoder calls "
+                   f"{'on' if lazy_on else 'off'} (CLICA_DROPIN_LAZY), roll detection -> one-sweep symmetric loss backward "
+                   f"{'on' if losses._sym_enabled() else 'off'} (CLICA_DROPIN_SYM), loss scalars by one async copy behind the loss forward "
+                   f"{'on' if losses._async_item() else 'off'} (CLICA_DROPIN_ASYNC_ITEM), weights re-packed at step end "
+                   f"{'on' if encoders._early_repack() else 'off'} (CLICA_DROPIN_EARLY_PACK)")
     return res
 
 

@@ -159,6 +159,22 @@ class _MLPFusedFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+def _adjacent_rows(gs, rows, n):
+    """The tensors `gs` ([rows[i], n] each) as ONE [sum(rows), n] tensor if they already lie behind one another in one storage
+    (contiguous fp32 row blocks), else None."""
+    g0 = gs[0]
+    if g0 is None or g0.dtype != torch.float32 or not g0.is_contiguous():
+        return None
+    st, off = g0.untyped_storage(), g0.storage_offset()
+    ptr = st.data_ptr()
+    for g, r in zip(gs, rows):
+        if (g is None or g.dtype != torch.float32 or g.shape != (r, n) or not g.is_contiguous() or g.storage_offset() != off
+                or g.untyped_storage().data_ptr() != ptr):
+            return None
+        off += r * n
+    return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, g0.storage_offset(), (sum(rows), n), (n, 1))
+
+
 class _SplitPlan:
     """What one (device, rows, layer shapes) call of the split whole-stack kernels needs and that does not change from step to step:
     which layers take planes / fp32 (`clica_mlp_wgrad_split_kind`), the byte layout of ONE buffer for the forward's saved tensors
@@ -235,32 +251,52 @@ class _MLPFusedSplitFn(torch.autograd.Function):
     _ws_cache = {}
 
     @staticmethod
-    def _packed(params_w):
-        key = _MLPFusedFn._weights_key(params_w)
+    def _packed(params_w, key=None):
+        if key is None:
+            key = _MLPFusedFn._weights_key(params_w)
         dev = params_w[0].device
         c = _MLPFusedSplitFn._pack_cache.get(dev)
         if c is not None and c["key"] == key:
             return c["packed"], c["packed_t"], key
+        ptrs = tuple(k[0] for k in key[1:])
+        if c is not None and c.get("ptrs") == ptrs and c["strides"] == [w.stride() for w in params_w]:
+            # the same parameter tensors with new values (every training step): the argument arrays of the first call still hold
+            from . import _lib
+            _lib.check(_lib.load().clica_mlp_pack_split_both(*c["args"], c["packed"].data_ptr(), c["packed_t"].data_ptr(), _lib.stream_ptr()),
+                       "clica_mlp_pack_split_both")
+            c["key"] = key
+            return c["packed"], c["packed_t"], key
+        import ctypes as C
         shapes = [tuple(w.shape) for w in params_w]
         reuse = c is not None and c["shapes"] == shapes
-        packed, packed_t = ops.mlp_pack_split_both([w.detach() for w in params_w], c["packed"] if reuse else None, c["packed_t"] if reuse else None)
+        ws = [w.detach() for w in params_w]
+        packed, packed_t = ops.mlp_pack_split_both(ws, c["packed"] if reuse else None, c["packed_t"] if reuse else None)
+        L = len(ws)
+        args = None
+        if all(w.dim() == 2 and w.stride(1) == 1 and w.is_cuda and w.dtype == torch.float32 for w in ws):
+            args = (L, (C.c_void_p * L)(*[w.data_ptr() for w in ws]), (C.c_int64 * L)(*[w.stride(0) for w in ws]),
+                    (C.c_int32 * L)(*[s_[0] for s_ in shapes]), (C.c_int32 * L)(*[s_[1] for s_ in shapes]))
         _MLPFusedSplitFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t,
-                                                 params=[weakref.ref(w) for w in params_w])
+                                                 params=[weakref.ref(w) for w in params_w], args=args,
+                                                 ptrs=ptrs if args is not None else None, strides=[w.stride() for w in params_w])
         return packed, packed_t, key
 
     @staticmethod
     def repack_if_changed(*_a, **_k):
-        """Optimizer post-step hook: bring the fragment-order weight copies up to date NOW, at the end of the step, where the host is
-        about to wait for the device anyway -- not in front of the next step's first launch, where the device waits for the host."""
+        """Optimizer post-step hook: bring the fragment-order weight copies up to date NOW, at the end of the step -- work that only
+        depends on the new parameters, out of the way of the next step's first launch."""
         for dev, c in list(_MLPFusedSplitFn._pack_cache.items()):
             ws = [r() for r in c.get("params", ())]
-            if ws and all(w is not None for w in ws) and _MLPFusedFn._weights_key(ws) != c["key"]:
-                with torch.cuda.device(dev):
-                    _MLPFusedSplitFn._packed(ws)
+            if ws and all(w is not None for w in ws):
+                key = _MLPFusedFn._weights_key(ws)
+                if key != c["key"]:
+                    with torch.cuda.device(dev):
+                        _MLPFusedSplitFn._packed(ws, key)
 
     @staticmethod
     def _wgrad_ws(dev, M, shapes):
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream, M, tuple(shapes))
+        from . import _lib
+        key = (dev, _lib.stream_ptr(), M, tuple(shapes))
         ws = _MLPFusedSplitFn._ws_cache.get(key)
         if ws is None:
             if len(_MLPFusedSplitFn._ws_cache) >= 4:
@@ -320,7 +356,9 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         else:
             if all(g is None for g in gys):
                 return (None,) * (2 + ctx.n_in + 2 * L)
-            gy = torch.cat([g if g is not None else x.new_zeros((r, shapes[-1][0])) for g, r in zip(gys, ctx.rows)], 0)
+            gy = _adjacent_rows(gys, ctx.rows, shapes[-1][0])      # (the symmetric loss backward writes dz1 / dz2 into one buffer)
+            if gy is None:
+                gy = torch.cat([g if g is not None else x.new_zeros((r, shapes[-1][0])) for g, r in zip(gys, ctx.rows)], 0)
         _lib.require_cuda(gy, "grad_output")
         need = ctx.needs_input_grad
         need_x = any(need[2:2 + ctx.n_in])
@@ -407,9 +445,9 @@ def _after_step():
 lazy.AFTER_STEP.append(_after_step)
 
 
-def _dropin_split(linears) -> bool:
+def _dropin_split(fits: bool) -> bool:
+    """`fits`: the layers' padded widths fit the on-chip bias table of mlp_split_k (FusedMLP._structure)."""
     import os
-    fits = sum((lin.out_features + 31) // 32 * 32 for lin in linears) <= 3456        # on-chip bias table of mlp_split_k (fused_mlp.hip)
     return fits and os.environ.get("CLICA_SPLIT_BF16", "1") != "0" and os.environ.get("CLICA_DROPIN_SPLIT", "1") != "0"
 
 
@@ -432,33 +470,32 @@ def _inplace_ok(prm, need) -> bool:
     Otherwise the gradients are returned to autograd as ordinary tensors."""
     if not (_inplace_grads() and all(need[2:])):
         return False
-    for q in prm:
-        v = getattr(q, "_clica_grad_view", None)
-        if v is None or q.grad is None or q.grad.data_ptr() != v.data_ptr() or not q.grad.is_contiguous():
-            return False
-        if q._backward_hooks or getattr(q, "_post_accumulate_grad_hooks", None):
-            return False
+    will_run = torch._C._will_engine_execute_node
     try:
         for q in prm:
-            node = getattr(q, "_clica_acc_node", None)
+            v, g = q.__dict__.get("_clica_grad_view"), q.grad
+            if v is None or g is None or g.data_ptr() != v.data_ptr() or not g.is_contiguous():
+                return False
+            if q._backward_hooks or q.__dict__.get("_post_accumulate_grad_hooks"):
+                return False
+            node = q.__dict__.get("_clica_acc_node")
             if node is None:
                 node = q._clica_acc_node = torch.autograd.graph.get_gradient_edge(q).node     # the leaf's AccumulateGrad node
-            if not torch._C._will_engine_execute_node(node):
+            if not will_run(node):
                 return False
     except RuntimeError:          # autograd.grad(loss, params): the engine CAPTURES the leaf gradients -- they must be returned
         return False
     return True
 
 
-def _use_fused(linears, M: int) -> bool:
+def _use_fused(fusable: bool, M: int) -> bool:
     """Whole-encoder kernels for the autograd path?  They own 48 rows per workgroup for the whole stack, so they want
     half of the 256 CUs busy (measured at 128 workgroups = one B = 6144 encoder call of the reference's train_step: 645 against
     594 steps/s through the per-layer GEMMs); smaller batches (and wide encoders) take the per-layer GEMMs.
-    CLICA_DROPIN_FUSED=0/1 forces."""
+    CLICA_DROPIN_FUSED=0/1 forces.  `fusable`: > 1 layers, all with bias, every width <= 512 (FusedMLP._structure)."""
     import os
     e = os.environ.get("CLICA_DROPIN_FUSED", "auto")
-    ok = len(linears) > 1 and all(lin.bias is not None for lin in linears) and ops.mlp_fwd_fusable([lin.weight for lin in linears])
-    if not ok or e == "0":
+    if not fusable or e == "0":
         return False
     return True if e == "1" else (M + 47) // 48 >= 128
 
@@ -466,23 +503,41 @@ def _use_fused(linears, M: int) -> bool:
 class FusedMLP(nn.Sequential):
     """``nn.Sequential`` whose forward runs the fused HIP path (same modules, same state dict)."""
 
-    def forward(self, x):
-        x = lazy.plain(x)
+    def _structure(self):
+        """(linears, slope, params, post modules, all parameters, fusable, split) of the current module list -- cached, re-derived when a
+        child module or one of its parameters has been replaced (the walk over the children was 15 us per call, twice per step)."""
+        c = self.__dict__.get("_clica_structure")
+        if c is not None:
+            mods = self._modules
+            if len(mods) == c[7] and all(mods[k] is m for k, m in c[8]) and all(m._parameters[nm] is q for m, nm, q in c[9]):
+                return c
         mods = list(self)
         linears = [m for m in mods if isinstance(m, nn.Linear)]
         slopes = {m.negative_slope for m in mods if isinstance(m, nn.LeakyReLU)}
         slope = slopes.pop() if slopes else 0.01
-        if x.dim() != 2:
-            x = x.reshape(-1, x.shape[-1])
         params = []
         for lin in linears:
             params += [lin.weight, lin.bias]
-
         post = [m for m in mods if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer))]
+        every = [p for p in params if p is not None]      # (not self.parameters(): a module-tree walk per call)
+        for m in post:
+            every += [q for q in m._parameters.values() if q is not None]
+        fusable = len(linears) > 1 and all(lin.bias is not None for lin in linears) and ops.mlp_fwd_fusable([lin.weight for lin in linears])
+        split = sum((lin.out_features + 31) // 32 * 32 for lin in linears) <= 3456        # on-chip bias table of mlp_split_k (fused_mlp.hip)
+        guard = [(m, nm, q) for m in linears + post for nm, q in m._parameters.items()]
+        c = (linears, slope, params, post, every, fusable, split, len(self._modules), list(self._modules.items()), guard)
+        self.__dict__["_clica_structure"] = c
+        return c
+
+    def forward(self, x):
+        x = lazy.plain(x)
+        linears, slope, params, post, every, fusable, split = self._structure()[:7]
+        if x.dim() != 2:
+            x = x.reshape(-1, x.shape[-1])
 
         def compute(xx):
-            if _use_fused(linears, xx.shape[0]):
-                y = _MLPFusedSplitFn.apply(slope, 1, xx, *params) if _dropin_split(linears) else _MLPFusedFn.apply(xx, slope, *params)
+            if _use_fused(fusable, xx.shape[0]):
+                y = _MLPFusedSplitFn.apply(slope, 1, xx, *params) if _dropin_split(split) else _MLPFusedFn.apply(xx, slope, *params)
             else:
                 y = _MLPStackFn.apply(xx, slope, *params)
             for m in post:
@@ -490,18 +545,14 @@ class FusedMLP(nn.Sequential):
             return y
 
         def compute_many(xlist):       # several pending calls as ONE function with several outputs (None: not on this path)
-            if post or not (_use_fused(linears, sum(t.shape[0] for t in xlist)) and _dropin_split(linears)):
+            if post or not (_use_fused(fusable, sum(t.shape[0] for t in xlist)) and _dropin_split(split)):
                 return None
             return list(_MLPFusedSplitFn.apply(slope, len(xlist), *xlist, *params))
         # The reference's train_step calls the encoder twice per step (main_mlp.py:270-271).  A training call that does not fill the
         # chip on its own (fewer than 256 panels of 48 rows) is DEFERRED: if the same module is called again before anything uses the
         # result, both batches run as one stacked launch per phase (cl_ica_amd/lazy.py); any other use computes it right away.
         if (lazy.enabled() and torch.is_grad_enabled() and x.is_cuda and (x.shape[0] + 47) // 48 < 256
-                and any(p.requires_grad for p in params if p is not None)):
-            every = [p for p in params if p is not None]      # (not self.parameters(): a module-tree walk per call)
-            for m in mods:
-                if isinstance(m, (ls.RescaleLayer, ls.SoftclipLayer)):
-                    every += [q for q in m._parameters.values() if q is not None]
+                and any(p.requires_grad for p in every)):
             return lazy.defer(self, x, compute, (x.shape[0], linears[-1].out_features), every, compute_many=compute_many)
         return compute(x)
 

@@ -179,6 +179,28 @@ def _rolled_rows_of(z3, z1) -> bool:
         return False
 
 
+def _scal(g):
+    """0-dim upstream gradient -> fp32 device scalar the C ABI can read (None stays None)."""
+    if g is None:
+        return None
+    if g.dtype == torch.float32 and g.is_cuda:
+        return g.detach()                      # a 0-dim / 1-element tensor is its own contiguous buffer
+    return g.detach().to(torch.float32).reshape(1).contiguous()
+
+
+_WS_BYTES = {}       # (kind, B, B3, n, p, pow, compat/normalize) -> workspace bytes (a ctypes query per call otherwise)
+
+
+def _lp_ws(desc, dev):
+    key = (desc.B, desc.B3, desc.n, desc.p, desc.pow, desc.compat, desc.no_eps)
+    nb = _WS_BYTES.get(key)
+    if nb is None:
+        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
+        _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), "clica_lp_loss_workspace_bytes")
+        nb = _WS_BYTES[key] = max(fwd_b.value, bwd_b.value)
+    return _lib.workspace("lp_loss", nb, dev)
+
+
 class _PairLossSymFn(torch.autograd.Function):
     """LpSimCLRLoss when the negatives ARE the anchors in another order (``z3_rec = roll(z1_rec)``): the row-wise log-sum-exp does
     not depend on the order of the negatives, so the forward reads z1 as the pool (no rolled copy), and the backward is ONE pair sweep
@@ -192,12 +214,11 @@ class _PairLossSymFn(torch.autograd.Function):
         (a, lda), (b, ldb) = _prep("z1_rec", z1), _prep("z2_con_z1_rec", z2)
         B = a.shape[0]
         out = torch.empty(3 * B + 3, dtype=torch.float32, device=a.device)
-        loss_i, pos_i, lse_i, means = out[:B], out[B:2 * B], out[2 * B:3 * B], out[3 * B:]
-        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
-        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), "clica_lp_loss_workspace_bytes")
-        ws = _lib.workspace("lp_loss", max(fwd_b.value, bwd_b.value), a.device)
+        loss_i, lse_i, means = out[:B], out[2 * B:3 * B], out[3 * B:]
+        ws = _lp_ws(desc, a.device)
+        p0 = out.data_ptr()
         _lib.check(lib.clica_lp_loss_fwd(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, a.data_ptr(), lda,
-                                         loss_i.data_ptr(), pos_i.data_ptr(), lse_i.data_ptr(), means.data_ptr(),
+                                         p0, p0 + 4 * B, p0 + 8 * B, p0 + 12 * B,
                                          None, 0, ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "clica_lp_loss_fwd")
         ctx.save_for_backward(a, b, lse_i)
         ctx.lds, ctx.desc = (lda, ldb), desc
@@ -210,18 +231,17 @@ class _PairLossSymFn(torch.autograd.Function):
         a, b, lse_i = ctx.saved_tensors
         (lda, ldb), desc, dev, n = ctx.lds, ctx.desc, a.device, a.shape[1]
         need1, need2 = ctx.needs_input_grad[:2]
-
-        def scal(g):
-            return None if g is None else g.detach().to(torch.float32).reshape(1).contiguous()
-        g_mean_t = scal(g_mean)
+        g_mean_t = _scal(g_mean)
         if g_mean_t is None:
             g_mean_t = torch.zeros(1, dtype=torch.float32, device=dev)
-        g_pos_t, g_neg_t = scal(g_pos), scal(g_neg)
-        dz1 = torch.empty((a.shape[0], n), dtype=torch.float32, device=dev)
-        dz2 = torch.empty((b.shape[0], n), dtype=torch.float32, device=dev) if need2 else None
-        fwd_b, bwd_b = C.c_size_t(), C.c_size_t()
-        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(desc), C.byref(fwd_b), C.byref(bwd_b)), "clica_lp_loss_workspace_bytes")
-        ws = _lib.workspace("lp_loss", max(fwd_b.value, bwd_b.value), dev)
+        g_pos_t, g_neg_t = _scal(g_pos), _scal(g_neg)
+        # dz1 and dz2 as row blocks of ONE buffer: an encoder that produced z1 and z2 as one stacked call (cl_ica_amd/lazy.py) takes them
+        # back as its stacked output gradient without a copy
+        B1, B2 = a.shape[0], b.shape[0]
+        dz = torch.empty((B1 + (B2 if need2 else 0), n), dtype=torch.float32, device=dev)
+        dz1 = dz[:B1]
+        dz2 = dz[B1:] if need2 else None
+        ws = _lp_ws(desc, dev)
         PATHS["sym_one_sweep" if g_item is None and desc.p >= 1.0 else "sym_two_sweeps"] += 1
         if g_item is None and desc.p >= 1.0:
             _lib.check(lib.clica_lp_loss_bwd_sym(C.byref(desc), a.data_ptr(), lda, b.data_ptr(), ldb, a.data_ptr(), lda,
@@ -260,8 +280,12 @@ class LpSimCLRLoss(CLLoss):
         self.pow = pow
 
     def _desc(self, B, B3, n):
-        return _lib.LpLossDesc(B=B, B3=B3, n=n, p=float(self.p), tau=float(self.tau), alpha=float(self.alpha),
-                               compat=int(bool(self.simclr_compatibility_mode)), pow=int(bool(self.pow)))
+        key = (B, B3, n, self.p, self.tau, self.alpha, self.simclr_compatibility_mode, self.pow)
+        c = self.__dict__.get("_desc_cache")
+        if c is None or c[0] != key:       # (the descriptor is read-only on the C side: one per shape and setting, not one per call)
+            c = self._desc_cache = (key, _lib.LpLossDesc(B=B, B3=B3, n=n, p=float(self.p), tau=float(self.tau), alpha=float(self.alpha),
+                                                         compat=int(bool(self.simclr_compatibility_mode)), pow=int(bool(self.pow))))
+        return c[1]
 
     def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
         del z1, z2_con_z1, z3   # unused by the reference as well (losses.py:431)

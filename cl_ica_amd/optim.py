@@ -44,6 +44,7 @@ class Adam:
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ticket = torch.zeros(1, dtype=torch.int32, device=dev)       # clica_adam_step_tick: the update's last workgroup advances step_dev
         for p, off in zip(self.params, offs):
             view = self.param_arena[off:off + p.numel()].view(p.shape)
             view.copy_(p.data)
@@ -98,8 +99,7 @@ class Adam:
         self._adopt_foreign_grads()
         g = self.param_groups[0]
         ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
-                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world)
-        ops.tick(self.step_dev)
+                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world, ticket=self._ticket)
         lazy.after_step()         # e.g. the encoder's fragment-order weight copies, re-packed now rather than in front of the next forward
         return loss
 

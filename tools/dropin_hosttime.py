@@ -39,6 +39,12 @@ wrap(encoders._MLPFusedSplitFn, "_packed", "_MLPFusedSplitFn._packed")
 wrap(encoders, "_inplace_ok")
 wrap(lazy, "defer"); wrap(lazy._Pending, "flush", "_Pending.flush")
 wrap(torch, "roll"); wrap(torch, "cat")
+from cl_ica_amd import _lib
+_L = _lib.load()
+for nm in ("clica_mlp_fwd_split", "clica_mlp_dgrad_split", "clica_mlp_wgrad_split", "clica_mlp_pack_split_both", "clica_lp_loss_fwd",
+           "clica_lp_loss_bwd_sym", "clica_adam_step_tick", "clica_adam_step", "clica_sample", "clica_mixing_fwd", "clica_tick"):
+    if hasattr(_L, nm):
+        wrap(_L, nm, "C:" + nm)
 
 n, B, device = 10, 6144, "cuda"
 a = types.SimpleNamespace(n=n, box_min=0.0, box_max=1.0, sphere_r=1.0, m_param=1.0, m_p=0, c_param=0.05, c_p=2, space_type="box")
