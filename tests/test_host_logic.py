@@ -392,3 +392,67 @@ def test_lazy_stacking_mechanics_on_cpu():
     assert lazy.plain(g1).grad_fn is not None                                       # first use inside no_grad keeps the graph
     leaf = torch.randn(5, 2, requires_grad=True)
     assert losses._rolled_rows_of(torch.roll(leaf, 2, 0), leaf) and not losses._rolled_rows_of(torch.roll(leaf * 1, 1, 0), leaf)
+
+
+def test_lazy_compute_many_after_step_and_shared_items_on_cpu():
+    """Round-4 additions around the drop-in loop, device-free parts: `compute_many` (the stacked call as one multi-output node; None
+    falls back to cat + slices), the optimizer post-step hook list, the adjacency test that lets the encoder's backward take the loss
+    gradients without a copy, and the shared `.item()` of the loss scalars (blocking variant: no GPU here)."""
+    from cl_ica_amd import encoders, lazy, losses
+    w = torch.randn(3, 2, requires_grad=True)
+    seen = []
+
+    class Two(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w, *xs):
+            ctx.save_for_backward(w, *xs)
+            y = torch.cat(xs) @ w
+            st, n, off, out = y.untyped_storage(), y.shape[1], 0, []
+            for x in xs:
+                out.append(torch.empty(0).set_(st, off * n, (x.shape[0], n), (n, 1)))
+                off += x.shape[0]
+            return tuple(out)
+
+        @staticmethod
+        def backward(ctx, *gs):
+            w, *xs = ctx.saved_tensors
+            seen.append(encoders._adjacent_rows(gs, [x.shape[0] for x in xs], w.shape[1]) is not None)
+            return sum(x.t() @ g for x, g in zip(xs, gs)), *[None] * len(xs)
+
+    class Owner:
+        pass
+    o = Owner()
+    many = lambda xs: list(Two.apply(w, *xs))         # noqa: E731
+    x1, x2 = torch.randn(4, 3), torch.randn(5, 3)
+    a = lazy.defer(o, x1, lambda x: x @ w, (4, 2), [w], compute_many=many)
+    b = lazy.defer(o, x2, lambda x: x @ w, (5, 2), [w], compute_many=many)
+    pa = lazy.plain(a)
+    assert pa.grad_fn is b.grad_fn and (pa.output_nr, b.output_nr) == (0, 1)            # ONE node, two outputs
+    assert torch.allclose(pa, x1 @ w) and torch.allclose(b, x2 @ w)
+    g = torch.randn(9, 2)
+    torch.autograd.backward([pa, b], [g[:4], g[4:]])                                    # adjacent row blocks of one buffer ...
+    torch.testing.assert_close(w.grad, torch.cat([x1, x2]).t() @ g)
+    w.grad = None
+    a = lazy.defer(o, x1, lambda x: x @ w, (4, 2), [w], compute_many=many); b = lazy.defer(o, x2, lambda x: x @ w, (5, 2), [w], compute_many=many)
+    torch.autograd.backward([lazy.plain(a), b], [g[:4].clone(), g[4:].clone()])         # ... and separate ones
+    assert seen == [True, False]
+    # compute_many may decline
+    a = lazy.defer(o, x1, lambda x: x @ w, (4, 2), [w], compute_many=lambda xs: None); b = lazy.defer(o, x2, lambda x: x @ w, (5, 2), [w], compute_many=lambda xs: None)
+    assert torch.allclose(lazy.plain(a), x1 @ w) and b.grad_fn.name() == "SliceBackward0"
+    # post-step hooks: ours is registered, torch optimizers call it
+    hits = []
+    lazy.AFTER_STEP.append(lambda: hits.append(1))
+    try:
+        opt = torch.optim.SGD([w], lr=0.1)
+        w.grad = torch.zeros_like(w)
+        opt.step()
+    finally:
+        lazy.AFTER_STEP.pop()
+    assert hits == [1] and encoders._after_step in lazy.AFTER_STEP
+    # shared scalars
+    src = torch.tensor([1.5, 2.5, 3.5])
+    outs = src.unbind(0)
+    losses._share_items(src, outs)
+    assert [t.item() for t in outs] == [1.5, 2.5, 3.5]
+    src[1] = 7.0                                        # written after the call: Tensor.item answers
+    assert outs[1].item() == 7.0
