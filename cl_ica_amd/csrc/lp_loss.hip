@@ -1,6 +1,7 @@
 // C ABI of the Lp InfoNCE loss (include/clica.h) -- planning, workspace carve-up, launches.
 // Kernels: lp_kernels.h; per-exponent instantiations: lp_loss_pk.hip.
 #include "lp_kernels.h"
+#include "lp_mfma.h"
 
 namespace clica {
 namespace lp {
@@ -552,19 +553,30 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
 
 // ---- training-step pair of entry points: forward with the coefficient step folded into its finalize, symmetric backward
 // with the forward's means folded into its reduction (three launches fewer than fwd + bwd_sym) -------------------------
-struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes; };
-// CLICA_LP_TRAIN_FAST (bits, default 3): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (A/B switch; Params::train)
-static int train_flags() { static int v = [] { const char* e = getenv("CLICA_LP_TRAIN_FAST"); return e ? atoi(e) : 3; }(); return v; }
-static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols) {
+struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes;
+                 bool mfma; lp2::Plan P2; lp2::Ws w2; };
+// CLICA_LP_TRAIN_FAST (bits, default 7): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (A/B switches; Params::train),
+// 4 = p = 2 sweeps on the matrix cores (lp_mfma.hip; needs bits 1 and 2 semantics: pool contains the anchors)
+static int train_flags() { static int v = [] { const char* e = getenv("CLICA_LP_TRAIN_FAST"); return e ? atoi(e) : 7; }(); return v; }
+static bool train_mfma(const clica_lp_loss_desc* d) { return (train_flags() & 4) && lp2::applies(d->n, d->p, d->pow); }
+static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols, bool mfma) {
   TrainWs w; char* p = (char*)ws; size_t off = 256;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
   w.statL = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
   w.statC = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
   w.strL = (float*)(p + off); off += align_up((size_t)cols * sizeof(float), 256);
   w.strC = (float*)(p + off); off += align_up((size_t)cols * sizeof(float), 256);
+  w.mfma = mfma;
+  int nsf = PF.nsplit, nsr = PR.nsplit;
+  if (mfma) {       // operand planes of the matrix-core sweeps (written by the forward call, read by both)
+    w.P2 = lp2::make_plan(rows, cols);
+    w.w2 = lp2::carve(p + off, w.P2);
+    off += w.w2.bytes;
+    nsf = nsr = w.P2.nsplit;
+  }
   w.scratch = p + off;      // forward: per-split (max, sum) partials; backward: per-split gradient partials (the forward's are dead by then)
-  const size_t f = align_up((size_t)PF.nsplit * rows * sizeof(float2), 256);
-  const size_t b = align_up((size_t)PR.nsplit * rows * PR.np * sizeof(float), 256);
+  const size_t f = align_up((size_t)nsf * rows * sizeof(float2), 256);
+  const size_t b = align_up((size_t)nsr * rows * PR.np * sizeof(float), 256);
   w.scratch_bytes = f > b ? f : b;
   w.bytes = off + w.scratch_bytes; return w;
 }
@@ -573,7 +585,15 @@ extern "C" int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, 
   int rc = validate(d, "clica_lp_loss_train_workspace_bytes");
   if (rc) return rc;
   CLICA_CHECK_ARG(bytes != nullptr, "clica_lp_loss_train_workspace_bytes: bytes is NULL");
-  *bytes = carve_train(nullptr, make_plan(d->B, d->B3, d->n, false), make_plan(d->B, d->B3, d->n, true), d->B, d->B3).bytes;
+  *bytes = carve_train(nullptr, make_plan(d->B, d->B3, d->n, false), make_plan(d->B, d->B3, d->n, true), d->B, d->B3, train_mfma(d)).bytes;
+  return CLICA_OK;
+}
+
+extern "C" int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* path) {
+  int rc = validate(d, "clica_lp_loss_train_path");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(path != nullptr, "clica_lp_loss_train_path: path is NULL");
+  *path = train_mfma(d) ? 1 : 0;
   return CLICA_OK;
 }
 
@@ -589,18 +609,25 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   CLICA_CHECK_ARG(ld1 >= d->n && ld2 >= d->n && ldp >= d->n && ldd1 >= d->n && ldd2 >= d->n, "clica_lp_loss_fwd_train: leading dimension < n");
   const int64_t rows = d->B, cols = d->B3;
   Plan PF = make_plan(rows, cols, d->n, false), PR = make_plan(rows, cols, d->n, true);
-  TrainWs w = carve_train(workspace, PF, PR, rows, cols);
+  TrainWs w = carve_train(workspace, PF, PR, rows, cols, train_mfma(d));
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd_train: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, false);
   q.train = train_flags() & 1;       // the pool contains the owner rows: running maximum known (Params::train)
   if (q.train && exponent_kind(d->p) >= 2 && d->pow) q.pre = powf(q.kscale, 1.f / d->p);     // scaled coordinates: the distance sum is -logit (p = 2, 3)
   hipStream_t st = as_stream(stream);
   float2* part = reinterpret_cast<float2*>(w.scratch);
-  launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
+  int nsplit_f = PF.nsplit;
+  if (w.mfma) {      // p = 2: logits as one augmented inner product on the matrix cores (lp_mfma.hip); same partial format
+    lp2::launch_prep(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, q.kscale, st);
+    lp2::launch_fwd(w.P2, w.w2, rows, part, st);
+    nsplit_f = w.P2.nsplit;
+  } else {
+    launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
+  }
   Means M{w.blocksums};
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
-                     (const float2*)part, PF.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
+                     (const float2*)part, nsplit_f, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2});
   return launch_status("clica_lp_loss_fwd_train");
 }
@@ -616,7 +643,7 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   CLICA_CHECK_ARG(d->p >= 1.f && d->B3 >= d->B, "clica_lp_loss_bwd_sym_train: needs p >= 1 and a pool that contains the local rows");
   const int64_t rows = d->B, cols = d->B3;
   Plan PF = make_plan(rows, cols, d->n, false), PR = make_plan(rows, cols, d->n, true);
-  TrainWs w = carve_train(workspace, PF, PR, rows, cols);
+  TrainWs w = carve_train(workspace, PF, PR, rows, cols, train_mfma(d));
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_bwd_sym_train: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, false);
   hipStream_t st = as_stream(stream);
@@ -632,10 +659,16 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
     if (exponent_kind(d->p) >= 2) q.pre = powf(q.kscale, 1.f / d->p);     // (p = 1 keeps unscaled coordinates: sign(d) must be exact)
     q.gfold = d->p / powf(q.pre, d->p - 1.f);
   }
-  launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
+  int nsplit_r = PR.nsplit;
+  if (w.mfma) {      // the planes of the forward call are still in the workspace (same z1 / pool, as for the row statistics)
+    lp2::launch_bwd(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, PR.np, q.kscale, w.statL, w.statC, strL, strC, partR, st);
+    nsplit_r = w.P2.nsplit;
+  } else {
+    launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
+  }
   const int blocks = (int)ceil_div(rows * PR.np, THREADS);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,
-                     (const float*)partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1,
+                     (const float*)partR, nsplit_r, rows, PR.np, d->n, dz1, ldd1, 1,
                      MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks, tick_counter});
   return launch_status("clica_lp_loss_bwd_sym_train");
 }

@@ -1,0 +1,40 @@
+// Squared-Euclidean pair sweeps of LpSimCLRLoss (p = 2, pow) on the bf16 matrix cores -- interface of lp_mfma.hip.
+#pragma once
+#include "common.h"
+
+namespace clica {
+namespace lp2 {
+
+constexpr int ROWS = 32;             // rows per operand tile (one 32 x 32 x 16 MFMA block side)
+constexpr int KSLOTS = 16;           // feature slots of a row: n coordinates + 2 augmented columns, zero padded
+constexpr int MAX_N = KSLOTS - 2;
+constexpr int STAGE_TILES = 4;       // pool tiles per LDS stage
+constexpr int ROWVEC = 3 * 2 * ROWS; // 16-byte vectors of one tile's row planes   [piece][k half][row]      (3 KB)
+constexpr int FEATVEC = 3 * 2 * 2 * 32;   // ... of its feature planes              [piece][mfma][k half][feature slot < 32]   (6 KB)
+
+struct Plan {
+  int T;                  // anchor tiles per wave
+  int64_t groups;         // workgroups along the anchors (4 waves x T tiles x 32 rows each)
+  int64_t own_tiles;      // anchor tiles in the plane buffer (padded to whole workgroups)
+  int64_t pool_tiles;     // pool tiles in the plane buffers (padded to whole chunks)
+  int nsplit, chunk_tiles;
+};
+Plan make_plan(int64_t n_own, int64_t n_pool);
+bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0)
+
+struct Ws { void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };
+Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-provided workspace (256-byte aligned base)
+
+// x' = sqrt(2 log2(e) / tau) (x - origin): row planes of the anchors and of the pool (both sweeps read them)
+void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
+                 int n, float kscale, hipStream_t st);
+// part[split][row] = (0, sum_j 2^x_ij) -- the partial format of fwd_partial_k<ZMAX>
+void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st);
+// part[split][row][np] = gradient partials of the symmetric sweep (format of bwd_pairs_k<.., 3, .., FOLD>): 2 sum_j 2^x_ij (u_i + u_j) (a_i - p_j),
+// u = C 2^-L from (ownL, ownC) / (poolL, poolC)
+// (writes the pool's feature planes first: they carry the pool rows' u_j)
+void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
+                int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, hipStream_t st);
+
+}  // namespace lp2
+}  // namespace clica

@@ -1,0 +1,515 @@
+// LpSimCLRLoss with p = 2 (pow) on the bf16 matrix cores: the pair sweeps of the TRAINING entry points
+// (clica_lp_loss_fwd_train / clica_lp_loss_bwd_sym_train, /root/reference/losses.py:430-477 with main_mlp.py:272's z3 = roll(z1))
+// for n <= 14.
+//
+// Why this is matrix work.  With x' = sqrt(2 log2(e) / tau) (x - origin) the scaled logit of a pair is
+//     x_ij = -log2(e)/tau |a_i - p_j|^2 = a'_i . p'_j - |a'_i|^2 / 2 - |p'_j|^2 / 2,
+// i.e. ONE inner product of the augmented rows  (a', -|a'|^2/2, 1) . (p', 1, -|p'|^2/2)  -- n + 2 <= 16 feature slots, exactly the K of a
+// v_mfma_f32_32x32x16_bf16 -- and the symmetric backward is
+//     dz_i = 2 sum_j 2^x_ij (u_i + u_j) (a_i - p_j) = (2 / s) [ u_i (a'_i W1_i - T1_i) + (a'_i W2_i - T2_i) ],
+//     W1_i = sum_j e_ij,  T1_i = sum_j e_ij p'_j,  W2_i = sum_j e_ij u_j,  T2_i = sum_j e_ij u_j p'_j,   e_ij = 2^x_ij
+// which is a second product E [P', 1, u P', u] (n + 1 feature rows and their u_j-weighted copies: 2 (n + 1) <= 32 rows of ONE MFMA operand):
+// the structure of flash attention with K = V = the pool.  The VALU
+// sweeps (lp_kernels.h) spend ~22 (forward) / ~26 (backward) issue slots per pair at n = 10, 10 + 10 of them on the differences and
+// their squares / the gradient FMAs; here a pair costs its exponential (v_exp_f32, quarter rate), one add (forward) or the coefficient
+// and a two-piece bf16 split (backward), the rest runs on the matrix pipe next to it.
+//
+// Arithmetic.  Both operands of the logit product are EXACT three-piece bf16 splits (planes.h's scheme: 24 significand bits), six piece
+// products, fp32 accumulation: fp32-equivalent like the encoder GEMMs.  What the expansion costs is cancellation: the three
+// terms are of the size of |x'|^2 / 2 and their sum is the (possibly much smaller) negated scaled squared distance, so the logit carries
+// an ABSOLUTE error of a few 2^-24 max(|a'|^2, |p'|^2) -- which is why the rows are shifted by an origin inside the data (the pool's first
+// row; distances do not change): in a box / on a sphere with tau = 1 the terms are O(1) and the weights 2^x are good to ~1e-6.  The exact-zero
+// self pair (the anchor's own pool row) comes out as 2^(+-1e-7) instead of exactly 1.  The exponential e_ij enters the second product as
+// hi + mid bf16 pieces, both rounded to nearest (relative error <= 2^-18 per pair, unbiased), against three exact pieces of the pool
+// features (u_j p'_j rounded once to fp32, then split exactly): five products.  The W sums come out of the same product (ones / u columns),
+// so the e_ij that weigh a'_i and p'_j are the same numbers and the self pair cancels exactly.  Parity is measured, not assumed: tests/test_gpu_loss.py compares these sweeps with the VALU sweeps and the fp64
+// oracle at the bench sizes; CLICA_LP_MFMA=0 (or CLICA_LP_TRAIN_FAST without bit 2) keeps the VALU sweeps.
+//
+// Layout.  A prep launch writes the planes once per step, already in MFMA operand order, so staging is a linear copy and an operand is
+// one 16-byte LDS read:  row planes [tile of 32 rows][piece][k half][row] x 8 bf16 (operand of the logit product, for the anchors and
+// for the pool) and the pool's feature planes [tile][piece][mfma 0/1][k half][feature slot < 32] x 8 bf16 (slots 0..n: p', 1; slots
+// 16..16+n: the same times u_j -- written by the backward call, which knows u), element e = pool row
+// 16 t + 8 (e / 4) + 4 h + e % 4 of the tile -- the order in which a lane of the logit block holds its 16 results, so that the
+// coefficients go into the second product's B operand from the registers they were computed in (no LDS round trip, no shuffles).
+// A wave owns T x 32 anchors (lane l and l + 32: the same anchor, different pool rows), a workgroup four waves, the pool is cut into
+// HBM-level splits of whole stages; partial formats are those of fwd_partial_k<ZMAX> / bwd_pairs_k<FOLD>, finalize / reduce are shared.
+#include "lp_mfma.h"
+#include <math.h>
+#include <stdlib.h>
+
+namespace clica {
+namespace lp2 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int THREADS = 256, WAVES = 4;
+constexpr int STAGE_B = 2;            // pool tiles per LDS stage of the backward sweep (its stage also holds the feature planes)
+static_assert(STAGE_TILES % STAGE_B == 0, "chunks are whole stages of both sweeps");
+
+__device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// v = hi + mid + lo exactly (8 + 8 + 8 significand bits, truncation); returns the pieces' upper halves in the LOW 16 bits
+__device__ __forceinline__ void split3(float v, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const unsigned b = __float_as_uint(v);
+  const unsigned hb = b & 0xffff0000u;
+  const float r1 = v - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(mb);
+  hi = hb >> 16; mid = mb >> 16; lo = __float_as_uint(r2) >> 16;
+}
+__device__ __forceinline__ u32x4 pack8(const unsigned (&v)[8]) {
+  return (u32x4){v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
+}
+// two fp32 -> packed bf16, round to nearest even (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+#ifndef LP2_ABLATE
+#define LP2_ABLATE 0      // measurement builds only (make variant EXTRA=-DLP2_ABLATE=k): 1 = no MFMAs, 2 = no vector work in the backward block
+#endif
+__device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+#if LP2_ABLATE & 1
+  c[0] += __uint_as_float((a.x ^ b.x) & 1u);
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+// the six piece products of order <= 2, small ones first
+__device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (&b)[3]) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  acc = mfma(a[2], b[0], acc);
+  acc = mfma(a[0], b[2], acc);
+  acc = mfma(a[1], b[1], acc);
+  acc = mfma(a[1], b[0], acc);
+  acc = mfma(a[0], b[1], acc);
+  acc = mfma(a[0], b[0], acc);
+  return acc;
+}
+
+// ---- planes ---------------------------------------------------------------------------------------------------------------------
+// role 0 = pool rows (x', 1, -|x'|^2/2; rows >= `rows` masked with -1e30 in the last slot), role 1 = anchors (x', -|x'|^2/2, 1)
+__global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
+                                             const float* __restrict__ Xa, int64_t lda, int64_t rows_a, u32x4* __restrict__ RPa,
+                                             int n, const float* __restrict__ origin, float pre2) {
+  // one launch for both operands: blocks [0, pool_blocks) the pool (role 0), the rest the anchors (role 1); two tiles per block
+  const int role = (int)blockIdx.x >= pool_blocks ? 1 : 0;
+  const float* __restrict__ X = role ? Xa : Xp;
+  const int64_t ldx = role ? lda : ldp, rows = role ? rows_a : rows_p;
+  u32x4* __restrict__ RP = role ? RPa : RPp;
+  const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * 2 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+  {
+    const int64_t j = (int64_t)tile * ROWS + lane;
+    const bool live = j < rows;
+    float v[KSLOTS];
+    float nx = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_N; ++k) {
+      const bool ok = live && k < n;
+      const float x = pre2 * (X[ok ? j * ldx + k : 0] - origin[k < n ? k : 0]);
+      v[k] = ok ? x : 0.f;
+      nx = fmaf(v[k], v[k], nx);
+    }
+    v[MAX_N] = 0.f; v[MAX_N + 1] = 0.f;
+    nx *= 0.5f;
+    const float c0 = role == 0 ? 1.f : -nx, c1 = role == 0 ? (live ? -nx : -1e30f) : 1.f;
+#pragma unroll
+    for (int k = 0; k < KSLOTS; ++k) v[k] = k == n ? c0 : (k == n + 1 ? c1 : v[k]);
+    unsigned hb[KSLOTS], mb[KSLOTS], lb[KSLOTS];
+#pragma unroll
+    for (int k = 0; k < KSLOTS; ++k) split3(v[k], hb[k], mb[k], lb[k]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned t8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t8[e] = hb[8 * h + e];
+      RP[((int64_t)(tile * 3 + 0) * 2 + h) * ROWS + lane] = pack8(t8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t8[e] = mb[8 * h + e];
+      RP[((int64_t)(tile * 3 + 1) * 2 + h) * ROWS + lane] = pack8(t8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t8[e] = lb[8 * h + e];
+      RP[((int64_t)(tile * 3 + 2) * 2 + h) * ROWS + lane] = pack8(t8);
+    }
+  }
+}
+
+// the pool's feature planes (operand of the gradient product): slot f < 16: y_f = (p'_0 .. p'_{n-1}, 1, 0 ..), slot 16 + f: u_j y_f
+__global__ __launch_bounds__(128) void prep_feat_k(const float* __restrict__ X, int64_t ldx, int64_t rows, int n, const float* __restrict__ origin,
+                                                   float pre2, const float* __restrict__ poolL, const float* __restrict__ poolC,
+                                                   u32x4* __restrict__ FP) {
+  const int tile = blockIdx.x, id = threadIdx.x;
+  const int t = id >> 6, h = (id >> 5) & 1, slot = id & 31, f = slot & 15;
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int64_t j = (int64_t)tile * ROWS + 16 * t + 8 * (e >> 2) + 4 * h + (e & 3);
+    const bool live = j < rows, ok = live && f < n;
+    const float x = pre2 * (X[ok ? j * ldx + f : 0] - origin[f < n ? f : 0]);
+    float y = ok ? x : ((live && f == n) ? 1.f : 0.f);
+    if (slot >= 16) {
+      const float L = poolL[live ? j : 0], Cc = poolC[live ? j : 0];
+      y *= live ? Cc * fexp2(-L) : 0.f;
+    }
+    split3(y, hb[e], mb[e], lb[e]);
+  }
+  FP[(((int64_t)(tile * 3 + 0) * 2 + t) * 2 + h) * 32 + slot] = pack8(hb);
+  FP[(((int64_t)(tile * 3 + 1) * 2 + t) * 2 + h) * 32 + slot] = pack8(mb);
+  FP[(((int64_t)(tile * 3 + 2) * 2 + t) * 2 + h) * 32 + slot] = pack8(lb);
+}
+
+// Both sweeps are software pipelines over "blocks" (one pool tile x one anchor tile = 1024 pairs): the matrix pipe works on block q
+// (and, in the backward, on the gradient product of block q - 2) while the vector ALU turns block q - 1's logits into exponentials /
+// coefficient pieces.  Left to itself the compiler issues all MFMAs of a stage, then all exponentials (measured: 660 cycles per block
+// and SIMD where the exponentials alone need 290).  The state that crosses a block boundary lives in registers, so the skew also
+// crosses the stage barrier; before the first block it is "logits = -1e30, pieces = 0" (contributes exact zeros).
+#define LP2_SCHED_PAIR(nvalu) do { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x402, nvalu, 0); } while (0)
+
+// Workgroup -> (anchor group, pool split).  Consecutive workgroup ids go to consecutive XCDs (8 of them, each with its own 4 MB L2), and
+// the planes of a 49 152-row pool are 9.4 MB: with the natural mapping every XCD walks the WHOLE pool and every stage comes from the
+// Infinity Cache (~2 us; a workgroup keeps one stage in flight, so the sweep ran at 14 B/clk/CU of staging -- measured with the
+// arithmetic ablated: 65 of the backward's 150 us).  Remapped, XCD x owns the logical ids [x N / 8, (x + 1) N / 8): all anchor
+// groups of a FEW splits, whose chunks (432 KB each) stay in that XCD's L2 after the first workgroup touched them.
+__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
+  const unsigned gx = gridDim.x, n = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+  const unsigned m = n & ~7u;                   // ids beyond the last multiple of 8 keep their place
+  const unsigned logical = id < m ? (id & 7u) * (m >> 3) + (id >> 3) : id;
+  by = (int)(logical / gx); bx = (int)(logical - (unsigned)by * gx);
+}
+
+// ---- forward: sum_j 2^x_ij per anchor and split -------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RPa, const u32x4* __restrict__ RPp, int64_t n_own,
+                                                    float2* __restrict__ part, int chunk_tiles) {
+  constexpr int SV = STAGE_TILES * ROWVEC, PER = SV / THREADS;       // 768 vectors per stage, 3 per thread
+  static_assert(SV % THREADS == 0, "stage copy");
+  __shared__ u32x4 stage[2][SV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
+  u32x4 b[T][3];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[t][p] = RPa[(((atile0 + t) * 3 + p) * 2 + h) * ROWS + l31];
+  float s[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) s[t] = 0.f;
+  const u32x4* src = RPp + (int64_t)by * chunk_tiles * ROWVEC;
+  const int nst = chunk_tiles / STAGE_TILES;
+  u32x4 pre[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) pre[u] = src[threadIdx.x + u * THREADS];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) stage[0][threadIdx.x + u * THREADS] = pre[u];
+  __syncthreads();
+  f32x16 accP;                      // logits of the previous block, not yet exponentiated
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accP[r] = -1e30f;
+  auto finish = [&](int t) {        // block q - 1: sixteen exponentials into its anchor tile's sum
+    float add = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) add += fexp2(accP[r]);
+    s[t] += add;
+  };
+  int cur = 0;
+  for (int st = 0; st < nst; ++st, cur ^= 1) {
+    const bool more = st + 1 < nst;
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) pre[u] = src[(int64_t)(st + 1) * SV + threadIdx.x + u * THREADS];
+    }
+    u32x4 a[3];
+#pragma unroll
+    for (int q = 0; q < STAGE_TILES * T; ++q) {
+      const int tl = q / T, t = q % T;
+      if (t == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = stage[cur][((tl * 3 + p) * 2 + h) * ROWS + l31];
+      }
+      __builtin_amdgcn_sched_barrier(0);          // one scheduling region per block: the MFMAs of q with the exponentials of q - 1
+      f32x16 accN = logit_block(a, b[t]);
+      finish((q + T - 1) % T);
+      // (pure instructions carry no order towards the region fences: tie both results to this point of the program)
+      asm volatile("" : "+v"(accN), "+v"(s[(q + T - 1) % T]));
+      accP = accN;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) LP2_SCHED_PAIR(4);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) stage[cur ^ 1][threadIdx.x + u * THREADS] = pre[u];
+    }
+    __syncthreads();
+  }
+  finish(T - 1);
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const float so = __shfl_xor(s[t], 32, 64);
+    const float tot = h ? so + s[t] : s[t] + so;
+    const int64_t i = (atile0 + t) * ROWS + l31;
+    if (h == 0 && i < n_own) part[(int64_t)by * n_own + i] = make_float2(0.f, tot);
+  }
+}
+
+// ---- symmetric backward: (2 / s) (a'_i W_i - T_i) per anchor and split --------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RPa, const u32x4* __restrict__ RPp, const u32x4* __restrict__ FPp,
+                                                    const float* __restrict__ own, int64_t ldo, int64_t n_own,
+                                                    const float* __restrict__ origin, int64_t n_pool, int n, int np, float pre2,
+                                                    const float* __restrict__ ownL, const float* __restrict__ ownC,
+                                                    float* __restrict__ part, int chunk_tiles) {
+  constexpr int RV = STAGE_B * ROWVEC, FV = STAGE_B * FEATVEC, SV = RV + FV, PER = (SV + THREADS - 1) / THREADS;      // 384 + 768 vectors
+  constexpr int NB = STAGE_B * T;                                                                    // blocks per stage
+  static_assert(RV % 64 == 0 && SV % 64 == 0, "stage copy: whole waves on either side of the row / feature boundary");
+  constexpr int LV = SV;        // LDS image of a stage: [row planes of STAGE_B tiles][feature planes of STAGE_B tiles], a linear copy
+  __shared__ u32x4 stage[2][LV];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  int bx, by;
+  xcd_tile(bx, by);
+  const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
+  u32x4 b[T][3];
+  float ui[T];
+  f32x16 G[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[t][p] = RPa[(((atile0 + t) * 3 + p) * 2 + h) * ROWS + l31];
+    const int64_t i = (atile0 + t) * ROWS + l31;
+    const bool ok = i < n_own;
+    const float L = ownL[ok ? i : 0], Cc = ownC[ok ? i : 0];
+    ui[t] = ok ? Cc * fexp2(-L) : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
+  }
+  const int64_t tile_b = (int64_t)by * chunk_tiles;
+  const u32x4* srcR = RPp + tile_b * ROWVEC;
+  const u32x4* srcF = FPp + tile_b * FEATVEC;
+  const int nst = chunk_tiles / STAGE_B;
+  auto fetch = [&](int st, u32x4 (&pre)[PER]) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = threadIdx.x + u * THREADS;
+      if (idx < SV) pre[u] = idx < RV ? srcR[(int64_t)st * RV + idx] : srcF[(int64_t)st * FV + (idx - RV)];
+    }
+  };
+  auto put = [&](int bsel, const u32x4 (&pre)[PER]) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int idx = threadIdx.x + u * THREADS;
+      if (idx < SV) stage[bsel][idx] = pre[u];
+    }
+  };
+  u32x4 pre[PER];
+  {   // "the stage before the first", which the pipeline's first two gradient products read: zeros
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (int idx = threadIdx.x; idx < LV; idx += THREADS) stage[1][idx] = z;
+  }
+  fetch(0, pre);
+  put(0, pre);
+  __syncthreads();
+  // pipeline state: logits of block q - 1 (awaiting the vector work), coefficient pieces of block q - 2 (awaiting the gradient product)
+  f32x16 accP;
+  unsigned hpP[8], mpP[8];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accP[r] = -1e30f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { hpP[e] = 0u; mpP[e] = 0u; }
+  // One block of the pipeline, issued in a fixed interleave (the wave issues in order: an MFMA behind an MFMA waits for the matrix pipe,
+  // vector work behind it then waits too -- left to the scheduler the 16 MFMAs of a block go first and nothing overlaps, measured
+  // 1040 cycles per block for 512 + 512).  Eight steps; step e: one MFMA, the two exponentials of coefficient pair e, a second MFMA, the
+  // rest of pair e (coefficient, hi + mid bf16 pieces, both rounded to nearest, packed in B-operand order).  MFMA list: the six logit
+  // products of block q (S) and the ten gradient products of block q - 2 (G), two independent accumulation chains, alternating.
+  // `pin` ties a value to a point of the program (pure instructions carry no order towards the sched_barrier fences by themselves).
+#define LP2_PIN1(x) asm volatile("" : "+v"(x))
+#define LP2_FENCE() __builtin_amdgcn_sched_barrier(0)
+  auto block = [&](const u32x4 (&a)[3], const u32x4 (&bt)[3], bool do_s, f32x16& accN,       /* S: logits of block q */
+                   const f32x16& accV, unsigned (&hpN)[8], unsigned (&mpN)[8],                                /* V: block q - 1 */
+                   f32x16& Gt, int bufG, int tlG, const unsigned (&hpG)[8], const unsigned (&mpG)[8]) {          /* G: block q - 2 */
+    u32x4 fa[2][3];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fa[tt][p] = stage[bufG][RV + (((tlG * 3 + p) * 2 + tt) * 2 + h) * 32 + l31];
+    const u32x4 bh0 = {hpG[0], hpG[1], hpG[2], hpG[3]}, bm0 = {mpG[0], mpG[1], mpG[2], mpG[3]};
+    const u32x4 bh1 = {hpG[4], hpG[5], hpG[6], hpG[7]}, bm1 = {mpG[4], mpG[5], mpG[6], mpG[7]};
+    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};        // logit piece products, small ones first
+    constexpr int GA[5] = {1, 0, 2, 1, 0};                                       // gradient: (mid, mid), (hi, mid), (lo, hi), (mid, hi), (hi, hi)
+    auto gstep = [&](int i) {                                                     // i-th of the ten gradient products
+      const int tt = i / 5, k = i % 5;
+      const u32x4 bb = tt == 0 ? (k < 2 ? bm0 : bh0) : (k < 2 ? bm1 : bh1);
+      Gt = mfma(fa[tt][GA[k]], bb, Gt);
+      LP2_PIN1(Gt);
+    };
+    if (do_s) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accN[r] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // first MFMA of the step
+      if (e < 6) { if (do_s) { accN = mfma(a[SA[e]], bt[SB[e]], accN); LP2_PIN1(accN); } }
+      else gstep(6 + 2 * (e - 6));
+#if LP2_ABLATE & 2
+      float e0 = accV[2 * e], e1 = accV[2 * e + 1];
+#else
+      float e0 = fexp2(accV[2 * e]), e1 = fexp2(accV[2 * e + 1]);
+#endif
+      LP2_PIN1(e0); LP2_PIN1(e1);
+      LP2_FENCE();
+      // second MFMA
+      if (e < 6) gstep(e); else gstep(7 + 2 * (e - 6));
+#if LP2_ABLATE & 2
+      hpN[e] = __float_as_uint(e0);
+      mpN[e] = __float_as_uint(e1);
+#else
+      hpN[e] = cvt_pk_bf16(e0, e1);
+      const float r0 = e0 - __uint_as_float(hpN[e] << 16), r1 = e1 - __uint_as_float(hpN[e] & 0xffff0000u);
+      mpN[e] = cvt_pk_bf16(r0, r1);
+#endif
+      LP2_PIN1(hpN[e]); LP2_PIN1(mpN[e]);
+      LP2_FENCE();
+    }
+  };
+  int cur = 0;
+  for (int st = 0; st < nst; ++st, cur ^= 1) {
+    const bool more = st + 1 < nst;
+    if (more) fetch(st + 1, pre);
+    u32x4 a[3];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const int tl = q / T, t = q % T;
+      const int q2 = (q + NB - 2) % NB;          // block q - 2 (of the previous stage when q < 2)
+      const int buf2 = q >= 2 ? cur : cur ^ 1;
+      if (t == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = stage[cur][((tl * 3 + p) * 2 + h) * ROWS + l31];
+      }
+      LP2_FENCE();
+      f32x16 accN;
+      unsigned hpN[8], mpN[8];
+      block(a, b[t], true, accN, accP, hpN, mpN, G[q2 % T], buf2, q2 / T, hpP, mpP);
+      accP = accN;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { hpP[e] = hpN[e]; mpP[e] = mpN[e]; }
+    }
+    if (more) put(cur ^ 1, pre);
+    __syncthreads();
+  }
+  {   // drain (cur was flipped once more): block "NB" = vector work of the last block + gradient product of the last-but-one, then the
+      // last block's gradient product with idle vector slots (logits -1e30: coefficients exactly zero)
+    const int last = cur ^ 1;
+    u32x4 a0[3] = {b[0][0], b[0][1], b[0][2]};
+    f32x16 dummy;
+    unsigned hpN[8], mpN[8], hpX[8], mpX[8];
+    block(a0, b[0], false, dummy, accP, hpN, mpN, G[(NB - 2) % T], last, (NB - 2) / T, hpP, mpP);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[r] = -1e30f;
+    block(a0, b[0], false, dummy, accP, hpX, mpX, G[(NB - 1) % T], last, (NB - 1) / T, hpN, mpN);
+  }
+  // ---- epilogue: lane (anchor l31, half h) holds feature slots (r & 3) + 8 (r >> 2) + 4 h of G^T: r < 8 the plain sums (T1_k, W1 in slot n),
+  //      r >= 8 the u_j-weighted ones (T2_k in slot 16 + k, W2 in slot 16 + n) ----
+  const int hn = (n >> 2) & 1, rn = (n & 3) + 4 * (n >> 3);      // where slot n lives (slot 16 + n: the same lane, register rn + 8)
+  const float scale = 2.f / pre2;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    float w1 = 0.f, w2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { w1 = r == rn ? G[t][r] : w1; w2 = r == rn ? G[t][r + 8] : w2; }
+    const float W1 = __shfl(w1, l31 + 32 * hn, 64), W2 = __shfl(w2, l31 + 32 * hn, 64);
+    const int64_t i = (atile0 + t) * ROWS + l31;
+    if (i >= n_own) continue;
+    float* dst = part + ((int64_t)by * n_own + i) * np;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int k0 = 8 * g + 4 * h;
+      if (k0 >= np) continue;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + e;
+        const bool ok = k < n;
+        const float xa = pre2 * (own[ok ? i * ldo + k : i * ldo] - origin[ok ? k : 0]);
+        o[e] = ok ? scale * (ui[t] * (xa * W1 - G[t][4 * g + e]) + (xa * W2 - G[t][8 + 4 * g + e])) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dst + k0) = o;
+    }
+  }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------------------------------
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+bool applies(int n, float p, int pow) {
+  static const int on = env_int("CLICA_LP_MFMA", 1);
+  return on != 0 && p == 2.f && pow != 0 && n >= 1 && n <= MAX_N;
+}
+
+Plan make_plan(int64_t n_own, int64_t n_pool) {
+  static const int envT = env_int("CLICA_LP_MFMA_T", 1);      // measured: T = 1 / 3 workgroups per CU (pool 6 144: 29 + 36 us; pool 49 152: 71 + 146)
+  static const int wg_per_cu = env_int("CLICA_LP_MFMA_WG_PER_CU", 3);
+  Plan P;
+  P.T = envT == 2 ? 2 : 1;
+  const int64_t per_group = (int64_t)WAVES * P.T * ROWS;
+  P.groups = ceil_div(n_own > 0 ? n_own : 1, per_group);
+  P.own_tiles = P.groups * WAVES * P.T;
+  const int64_t tiles = ceil_div(n_pool > 0 ? n_pool : 1, (int64_t)ROWS);
+  int64_t ns = ceil_div((int64_t)kNumCU * wg_per_cu, P.groups);
+  const int64_t cap = ceil_div(tiles, (int64_t)STAGE_TILES);
+  if (ns > cap) ns = cap;
+  if (ns < 1) ns = 1;
+  const int64_t chunk = ceil_div(ceil_div(tiles, ns), (int64_t)STAGE_TILES) * STAGE_TILES;
+  P.chunk_tiles = (int)chunk;
+  P.nsplit = (int)ceil_div(tiles, chunk);
+  P.pool_tiles = (int64_t)P.nsplit * chunk;
+  return P;
+}
+
+Ws carve(void* base, const Plan& P) {
+  Ws w; char* p = (char*)base; size_t off = 0;
+  w.own_rows = p + off; off += align_up((size_t)P.own_tiles * ROWVEC * 16, 256);
+  w.pool_rows = p + off; off += align_up((size_t)P.pool_tiles * ROWVEC * 16, 256);
+  w.pool_feat = p + off; off += align_up((size_t)P.pool_tiles * FEATVEC * 16, 256);
+  w.bytes = off;
+  return w;
+}
+
+void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
+                 int n, float kscale, hipStream_t st) {
+  const float pre2 = sqrtf(2.f * kscale);
+  hipLaunchKernelGGL(prep_k, dim3((unsigned)((P.pool_tiles + P.own_tiles) / 2)), dim3(64), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows,
+                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pool, pre2);
+}
+
+void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st) {
+  dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
+  if (P.T == 1) hipLaunchKernelGGL(fwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles);
+  else hipLaunchKernelGGL(fwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles);
+}
+
+void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
+                int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, hipStream_t st) {
+  const float pre2 = sqrtf(2.f * kscale);
+  hipLaunchKernelGGL(prep_feat_k, dim3((unsigned)P.pool_tiles), dim3(128), 0, st, pool, ldp, n_pool, n, pool, pre2, poolL, poolC,
+                     (u32x4*)w.pool_feat);
+  dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
+  if (P.T == 1)
+    hipLaunchKernelGGL(bwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,
+                       n_own, pool, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles);
+  else
+    hipLaunchKernelGGL(bwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,
+                       n_own, pool, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles);
+}
+
+}  // namespace lp2
+}  // namespace clica

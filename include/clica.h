@@ -134,8 +134,16 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * all-gather of every rank's z1).  The sweeps use it: every logit is <= 0 and the row's own pool entry gives exactly 0, so the forward
  * sums 2^x without a running maximum and the backward folds the row statistics into one factor per row (one exponential per pair).
  * For negatives that do not include the anchors use clica_lp_loss_fwd / clica_lp_loss_bwd.  CLICA_LP_TRAIN_FAST=0 restores the
- * general-purpose sweeps behind these entry points (A/B switch). */
+ * general-purpose sweeps behind these entry points (A/B switch).
+ * p = 2, pow, n <= 14 (BASELINE config 2: main_mlp.py defaults): the two pair sweeps run on the bf16 matrix cores (csrc/lp_mfma.hip:
+ * logit = one augmented inner product of exact 3-piece bf16 splits, gradient = a second product against the pool) and z1 / pool
+ * must additionally be UNCHANGED between the two calls (fwd_train leaves their operand planes in the workspace).  The expansion
+ * |a|^2 + |b|^2 - 2ab behind it carries an absolute logit error of a few 2^-24 log2(e)/tau max_i |z_i - z_0|^2 (rows are shifted by
+ * the pool's first row): <= ~1e-6 for embeddings in the reference's box / sphere spaces at tau >= 0.1; data spread over many
+ * temperature-lengths should set CLICA_LP_MFMA=0 (VALU sweeps on coordinate differences).  clica_lp_loss_train_path reports the
+ * choice: *path = 1 matrix cores, 0 VALU sweeps. */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);
+int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* path);
 int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
                             const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
                             float* loss_i, float* pos_i, float* lse_i,

@@ -57,7 +57,10 @@ def test_engine_matches_autograd_path():
         f = encoders.get_mlp(n, n, [100, 500, 500, 100], output_normalization=head).to("cuda")
         gW = torch.randn(3, n, n, device="cuda") / n ** 0.5
         z1 = torch.rand(B, n, device="cuda"); z2 = (z1 + 0.05 * torch.randn_like(z1)).clamp(0, 1)
+        from cl_ica_amd import lazy
         a, b = f(ops.mixing_fwd(z1, gW)), f(ops.mixing_fwd(z2, gW))
+        a = lazy.plain(a)
+        a.retain_grad(); b.retain_grad()
         tot, _, _ = losses.LpSimCLRLoss(p=2, simclr_compatibility_mode=True)(None, None, None, a, b, torch.roll(a, 1, 0))
         tot.backward()
         ref_grads = {k: p.grad.clone() for k, p in f.named_parameters()}
@@ -72,7 +75,17 @@ def test_engine_matches_autograd_path():
                 # ~1e-7 residue of +-1e-4 summands.  Both paths hold summation-order noise there, nothing to compare.
                 assert g.abs().max().item() < (1e-8 if head is None else 1e-6)
                 continue
-            PARITY.check("engine_vs_autograd_dropin", f"head={head}", k, g.cpu().numpy(), ref_grads[k].cpu().numpy())
+            floor, note = 0.0, None
+            if k.endswith("max_abs_bound"):
+                # d loss / d bound_k = sum_i dy_ik sigmoid(x_ik).  The loss is translation invariant in y (sum_i dy_ik = 0), and this
+                # RANDOM-INIT encoder's sigmoid varies by 1e-3 around 0.5: the gradient is 1e-3 of its own summand mass
+                # sum_i |dy_ik| sigmoid_ik (measured: 1e-6 against 1e-3).  A cancelling sum is judged against that mass: the bound
+                # below is 1e-5 x 1e-2 x mass = 1e-7 of it (two fp32 ulps of the summands).  Measured: 1.3e-8 of the mass with the
+                # pair sweep on coordinate differences (whose terms cancel pairwise), 5e-8 with the p = 2 sweep on the matrix cores.
+                bound = p.detach()
+                mass = (a.grad.abs() * (a.detach() / bound).abs()).sum(0) + (b.grad.abs() * (b.detach() / bound).abs()).sum(0)
+                floor, note = 1e-2 * float(mass.max()), "cancelling sum: judged against 1e-2 of its summand mass"
+            PARITY.check("engine_vs_autograd_dropin", f"head={head}", k, g.cpu().numpy(), ref_grads[k].cpu().numpy(), floor=floor, note=note)
 
 
 def test_engine_seeded_sweep_vs_autograd_path():

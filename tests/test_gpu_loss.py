@@ -438,3 +438,94 @@ def test_simclr_mfma_matches_pair_sweep(normalize):
         PARITY.check("simclr_mfma_vs_sweep", f"norm={int(normalize)}", name, x, y)
     for path in ("1", "0"):
         PARITY.check("simclr_mfma_vs_sweep", f"norm={int(normalize)} path={path} vs fp64 oracle", "loss_i", res[path][1], orc["loss_i"])
+
+
+def _train_pair(z1, z2, pool, pool_lse, n, p, tau, alpha, compat=1):
+    """clica_lp_loss_fwd_train + clica_lp_loss_bwd_sym_train on device tensors; returns (out [3B+3], dz [2B, n], path)."""
+    import ctypes as C
+    from cl_ica_amd import _lib
+    lib = _lib.load()
+    B, B3 = z1.shape[0], pool.shape[0]
+    d = _lib.LpLossDesc(B=B, B3=B3, n=n, p=float(p), tau=tau, alpha=alpha, compat=compat, pow=1)
+    nb, path = C.c_size_t(), C.c_int32()
+    _lib.check(lib.clica_lp_loss_train_workspace_bytes(C.byref(d), C.byref(nb)), "ws")
+    _lib.check(lib.clica_lp_loss_train_path(C.byref(d), C.byref(path)), "path")
+    ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+    o = torch.empty(3 * B + 3, device="cuda"); dz = torch.full((2 * B, n), float("nan"), device="cuda")
+    st = _lib.stream_ptr()
+    _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), z1.data_ptr(), z1.stride(0), z2.data_ptr(), z2.stride(0), pool.data_ptr(), pool.stride(0),
+                                           o[:B].data_ptr(), o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(),
+                                           dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
+    lse = o[2 * B:3 * B] if pool_lse is None else pool_lse
+    if pool_lse is not None and pool_lse.numel() == 0:
+        return o, dz, path.value          # forward only
+    _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(d), z1.data_ptr(), z1.stride(0), pool.data_ptr(), pool.stride(0), o[2 * B:3 * B].data_ptr(),
+                                               lse.data_ptr(), dz[:B].data_ptr(), n, o[3 * B:].data_ptr(), None, ws.data_ptr(), ws.numel(), st),
+               "bwd_sym_train")
+    torch.cuda.synchronize()
+    return o, dz, path.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,n,tau,space", [(6144, 10, 1.0, "box"), (1000, 3, 0.3, "box"), (333, 14, 1.0, "sphere"), (97, 1, 0.5, "box"),
+                                           (2048, 10, 0.1, "box"), (4096, 7, 1.0, "far")])
+def test_p2_train_sweeps_on_matrix_cores_vs_oracle(B, n, tau, space):
+    """The p = 2 training sweeps on the bf16 matrix cores (csrc/lp_mfma.hip) against the fp64 oracle, single rank (pool = z1): loss
+    statistics and the complete gradient, at the bench size and at ragged sizes / other widths / temperatures.  'far': the cloud sits
+    1000 units from the coordinate origin (the kernel shifts rows by the pool's first row: the expansion must not see the offset)."""
+    rng = np.random.default_rng(B + n)
+    alpha = 0.5
+    if space == "sphere":
+        z = rng.normal(size=(B, n)); z /= np.linalg.norm(z, axis=1, keepdims=True)
+        zt = z + 0.05 * rng.normal(size=(B, n)); zt /= np.linalg.norm(zt, axis=1, keepdims=True)
+    else:
+        z = rng.random((B, n)); zt = np.clip(z + 0.05 * rng.normal(size=(B, n)), 0, 1)
+        if space == "far":
+            z += 1000.0; zt += 1000.0
+    z, zt = z.astype(np.float32), zt.astype(np.float32)
+    o, dz, path = _train_pair(dev(z), dev(zt), dev(z), None, n, 2, tau, alpha)
+    assert path == 1, "the p = 2 training sweeps must take the matrix-core path (CLICA_LP_MFMA / CLICA_LP_TRAIN_FAST unset)"
+    orc = O.lp_simclr_loss(z, zt, z, p=2, tau=tau, alpha=alpha, compat=True, grad=False)
+    fam, case = "p2_train_matrix_cores", f"B={B} n={n} tau={tau} {space}"
+    oc = o.cpu().numpy()
+    LN2 = np.log(2.0)
+    PARITY.check(fam, case, "loss_i", oc[:B], orc["loss_i"])
+    PARITY.check(fam, case, "lse_i", oc[2 * B:3 * B].astype(np.float64) * LN2, orc["lse"])
+    lse_nat = orc["lse"]
+    g1, g2 = O.lp_symmetric_row_grads(z, zt, z, lse_nat, lse_nat, 2, tau, alpha, local_rows=B)
+    PARITY.check(fam, case, "dz1", dz[:B].cpu().numpy(), g1)
+    PARITY.check(fam, case, "dz2", dz[B:].cpu().numpy(), g2)
+    assert abs(oc[3 * B] - oc[:B].astype(np.float64).mean()) < 2e-6 * abs(oc[3 * B])
+
+
+@pytest.mark.gpu
+def test_p2_train_sweeps_on_matrix_cores_pool_49152():
+    """The 8-rank shape of BASELINE config 2: B = 6144 local rows against the gathered pool of 49 152 rows, n = 10, p = 2; 96 sampled
+    rows exactly against the fp64 oracle (forward statistics of rows from every 'rank', gradients of local rows)."""
+    rng = np.random.default_rng(21)
+    B, R, n, tau, alpha = 6144, 8, 10, 1.0, 0.5
+    Bg = B * R
+    z_all = rng.random((Bg, n)).astype(np.float32)
+    zt_all = np.clip(z_all + 0.05 * rng.normal(size=(Bg, n)), 0, 1).astype(np.float32)
+    pool, pool2 = dev(z_all), dev(zt_all)
+    lse_all = torch.empty(Bg, device="cuda")
+    empty = torch.empty(0, device="cuda")
+    for r in range(R):
+        sl = slice(r * B, (r + 1) * B)
+        o_r, _, path = _train_pair(pool[sl], pool2[sl], pool, empty, n, 2, tau, alpha)
+        assert path == 1
+        lse_all[sl] = o_r[2 * B:3 * B]
+    o, dz, _ = _train_pair(pool[:B], pool2[:B], pool, lse_all, n, 2, tau, alpha)
+    S = np.sort(rng.choice(B, size=96, replace=False))
+    S2 = np.sort(rng.choice(Bg, size=64, replace=False))
+    fam, case = "p2_train_matrix_cores", f"B={B} B3={Bg} n={n} (sampled rows)"
+    LN2 = np.log(2.0)
+    orc = O.lp_simclr_loss(z_all[S], zt_all[S], z_all, p=2, tau=tau, alpha=alpha, compat=True, grad=False)
+    orc2 = O.lp_simclr_loss(z_all[S2], zt_all[S2], z_all, p=2, tau=tau, alpha=alpha, compat=True, grad=False)
+    oc = o.cpu().numpy()
+    lse_nat = lse_all.cpu().numpy().astype(np.float64) * LN2
+    PARITY.check(fam, case, "loss_i", oc[:B][S], orc["loss_i"])
+    PARITY.check(fam, case, "lse_pool", lse_nat[S2], orc2["lse"])
+    g1, g2 = O.lp_symmetric_row_grads(z_all[S], zt_all[S], z_all, lse_nat[S], lse_nat, 2, tau, alpha, local_rows=B)
+    PARITY.check(fam, case, "dz1", dz[:B].cpu().numpy()[S], g1)
+    PARITY.check(fam, case, "dz2", dz[B:].cpu().numpy()[S], g2)
