@@ -476,6 +476,9 @@ def loss_leg(tr, reps=20):
         torch.cuda.synchronize()
         tf += ev[0].elapsed_time(ev[1]) * 1e-3; tb += ev[1].elapsed_time(ev[2]) * 1e-3
     pairs = float(B) * z3.shape[0] + B
+    path = C.c_int32(0)
+    if train:
+        lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path))
     cp = {1: 2, 2: 2, 3: 4}.get(int(tr.p), 6)
     fl_f = pairs * (cp * n + 6)      # P (c_p n + 6); backward contract figure = 3x forward
     # (the symmetric backward does ONE pair sweep; the contract's 3x is kept as the algorithmic figure)
@@ -484,7 +487,10 @@ def loss_leg(tr, reps=20):
             "bwd_tflops_valu": 3 * fl_f / (tb / reps) / 1e12, "valu_peak_tflops": PEAK_FP32_VALU_TFLOPS,
             "fwd_valu_frac": fl_f / (tf / reps) / 1e12 / PEAK_FP32_VALU_TFLOPS, "bwd_valu_frac": 3 * fl_f / (tb / reps) / 1e12 / PEAK_FP32_VALU_TFLOPS,
             "negatives_pool": int(z3.shape[0]),
-            "algorithmic_bytes_fwd": 4 * n * (2 * B + z3.shape[0]) + 12 * B}
+            "algorithmic_bytes_fwd": 4 * n * (2 * B + z3.shape[0]) + 12 * B,
+            "sweeps": ("bf16 matrix cores (csrc/lp_mfma.hip: logit = augmented inner product of exact 3-piece splits, gradient = second product "
+                       "against the pool; the *_valu figures keep SURVEY 8(d)'s contract count as the algorithmic work)" if path.value == 1
+                       else "vector ALU on coordinate differences (csrc/lp_kernels.h)")}
 
 
 def dropin_leg(args, device, steps=40, warmup=8):
