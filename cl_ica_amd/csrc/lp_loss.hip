@@ -597,6 +597,22 @@ extern "C" int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* pa
   return CLICA_OK;
 }
 
+extern "C" int clica_lp_loss_train_spread(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* spread,
+                                          clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_train_spread");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(workspace && spread, "clica_lp_loss_train_spread: NULL pointer");
+  *spread = 0.f;
+  if (!train_mfma(d)) return CLICA_OK;
+  const int64_t rows = d->B, cols = d->B3;
+  TrainWs w = carve_train(const_cast<void*>(workspace), make_plan(rows, cols, d->n, false), make_plan(rows, cols, d->n, true), rows, cols, true);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_train_spread: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(spread, w.w2.spread, sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return launch_status("clica_lp_loss_train_spread");
+  return CLICA_OK;
+}
+
 extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
                                        const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
                                        float* loss_i, float* pos_i, float* lse_i,

@@ -22,10 +22,11 @@ struct Plan {
 Plan make_plan(int64_t n_own, int64_t n_pool);
 bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0)
 
-struct Ws { void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };
+struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };   // spread: running max of M (see launch_prep)
 Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-provided workspace (256-byte aligned base)
 
-// x' = sqrt(2 log2(e) / tau) (x - origin): row planes of the anchors and of the pool (both sweeps read them)
+// x' = sqrt(2 log2(e) / tau) (x - origin): row planes of the anchors and of the pool (both sweeps read them).  Also keeps the running maximum
+// of M = |x'|^2 / 2 = log2(e)/tau |x - origin|^2 over the pool rows in *w.spread (a float the caller zeroed with the workspace): what the logit's absolute error scales with
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st);
 // part[split][row] = (0, sum_j 2^x_ij) -- the partial format of fwd_partial_k<ZMAX>

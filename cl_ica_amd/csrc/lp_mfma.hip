@@ -99,7 +99,7 @@ __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (
 // role 0 = pool rows (x', 1, -|x'|^2/2; rows >= `rows` masked with -1e30 in the last slot), role 1 = anchors (x', -|x'|^2/2, 1)
 __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
                                              const float* __restrict__ Xa, int64_t lda, int64_t rows_a, u32x4* __restrict__ RPa,
-                                             int n, const float* __restrict__ origin, float pre2) {
+                                             int n, const float* __restrict__ origin, float pre2, float* __restrict__ spread) {
   // one launch for both operands: blocks [0, pool_blocks) the pool (role 0), the rest the anchors (role 1); two tiles per block
   const int role = (int)blockIdx.x >= pool_blocks ? 1 : 0;
   const float* __restrict__ X = role ? Xa : Xp;
@@ -120,6 +120,12 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
     }
     v[MAX_N] = 0.f; v[MAX_N + 1] = 0.f;
     nx *= 0.5f;
+    if (role == 0) {      // diagnostic: the largest M of the pool (non-negative floats order like their bit patterns)
+      float m = live ? nx : 0.f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+      if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(spread), __float_as_int(m));
+    }
     const float c0 = role == 0 ? 1.f : -nx, c1 = role == 0 ? (live ? -nx : -1e30f) : 1.f;
 #pragma unroll
     for (int k = 0; k < KSLOTS; ++k) v[k] = k == n ? c0 : (k == n + 1 ? c1 : v[k]);
@@ -477,6 +483,7 @@ Plan make_plan(int64_t n_own, int64_t n_pool) {
 
 Ws carve(void* base, const Plan& P) {
   Ws w; char* p = (char*)base; size_t off = 0;
+  w.spread = (float*)(p + off); off += 256;
   w.own_rows = p + off; off += align_up((size_t)P.own_tiles * ROWVEC * 16, 256);
   w.pool_rows = p + off; off += align_up((size_t)P.pool_tiles * ROWVEC * 16, 256);
   w.pool_feat = p + off; off += align_up((size_t)P.pool_tiles * FEATVEC * 16, 256);
@@ -488,7 +495,7 @@ void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int6
                  int n, float kscale, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
   hipLaunchKernelGGL(prep_k, dim3((unsigned)((P.pool_tiles + P.own_tiles) / 2)), dim3(64), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows,
-                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pool, pre2);
+                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pool, pre2, w.spread);
 }
 
 void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st) {

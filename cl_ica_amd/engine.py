@@ -759,6 +759,17 @@ class ContrastiveTrainer:
         self.graph = graph
         return graph
 
+    def loss_spread(self) -> float:
+        """M = log2(e)/tau max_i |y_i - y_0|^2 of the largest embedding cloud the p = 2 matrix-core loss sweeps have seen in this
+        trainer (0 on the VALU sweeps): their logit error scales with it (include/clica.h: 1e-5 from M ~ 200).  Host read + sync -- for
+        log points, not for the step."""
+        if not self.loss_train:
+            return 0.0
+        v = C.c_float(0.0)
+        _lib.check(_lib.load().clica_lp_loss_train_spread(C.byref(self.desc), self.loss_ws.data_ptr(), self.loss_ws.numel(), C.byref(v),
+                                                          _lib.stream_ptr()), "clica_lp_loss_train_spread")
+        return float(v.value)
+
     def plan_summary(self) -> dict:
         """What this rank has planned for its data-parallel step: pool size, workspaces, weight-gradient halves, gradient buckets,
         collectives per step.  bench.py prints it (`ranks` / `dry_ranks`), the dry-run tests assert it."""

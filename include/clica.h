@@ -138,14 +138,19 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * p = 2, pow, n <= 14 (BASELINE config 2: main_mlp.py defaults): the two pair sweeps run on the bf16 matrix cores (csrc/lp_mfma.hip:
  * logit = one augmented inner product of exact 3-piece bf16 splits, gradient = a second product against the pool) and z1 / pool
  * must additionally be UNCHANGED between the two calls (fwd_train leaves their operand planes in the workspace).  The expansion
- * |a|^2 + |b|^2 - 2ab behind it carries an absolute logit error of a few 2^-24 M, M = log2(e)/tau max_i |z_i - z_0|^2 / 2 (rows are
- * shifted by the pool's first row).  Measured against the fp64 oracle (tests/test_gpu_loss.py, ..._spread_limit): loss / gradient error
- * 2e-7 / 6e-7 at M = 7 (unit box, n = 10, tau = 1), 3e-6 at M = 30 (tau = 0.1), 1e-5 at M = 115, 6e-5 at M = 460.  The reference's
- * spaces (box [0, 1]^n, unit sphere; tau >= 0.1) stay below M = 40; data spread over more than ~10 temperature-lengths should set
- * CLICA_LP_MFMA=0 (VALU sweeps on coordinate differences, no such dependence).  clica_lp_loss_train_path reports the choice:
+ * |a|^2 + |b|^2 - 2ab behind it carries an absolute logit error of a few 2^-24 M, M = log2(e)/tau max_i |z_i - z_0|^2 (the size of the
+ * expansion's terms; rows are shifted by the pool's first row).  Measured against the fp64 oracle (tests/test_gpu_loss.py,
+ * ..._spread_limit): loss / gradient error 2e-7 / 6e-7 at M = 14 (unit box, n = 10, tau = 1), 3e-6 at M = 60 (tau = 0.1), 1e-5 at M = 230,
+ * 6e-5 at M = 920.  The reference's spaces (box [0, 1]^n, unit sphere; tau >= 0.1) stay below M = 80; data spread over more than ~10
+ * temperature-lengths should set CLICA_LP_MFMA=0 (VALU sweeps on coordinate differences, no such dependence).
+ * clica_lp_loss_train_path reports the choice:
  * *path = 1 matrix cores, 0 VALU sweeps. */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);
 int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* path);
+/* Diagnostic for the limit above: *spread (HOST float) = the largest M any clica_lp_loss_fwd_train call has seen in this workspace since it
+ * was zeroed (0 on the VALU path).  Synchronises `stream`; not for the training loop itself -- call it where the loop reads losses anyway. */
+int clica_lp_loss_train_spread(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* spread,
+                               clica_stream_t stream);
 int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
                             const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
                             float* loss_i, float* pos_i, float* lse_i,
