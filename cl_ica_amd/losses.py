@@ -54,7 +54,7 @@ class _SharedScalars:
 
     def __init__(self, src):
         self.src, self.vals, self.host, self.event = src, None, None, None
-        if src.is_cuda and _async_item():
+        if src.is_cuda and _async_item() and not torch.cuda.is_current_stream_capturing():      # (an event of a captured stream cannot be waited for)
             self.host = torch.empty(src.numel(), dtype=src.dtype, pin_memory=True)
             self.host.copy_(src, non_blocking=True)
             self.event = torch.cuda.Event()
