@@ -116,4 +116,14 @@ def test_kitti_solver_two_ranks(tmp_path, p, box):
         if name == "encoder.11.bias" and not box:
             assert np.abs(got).max() < 1e-5 * max(np.abs(g_ref).max(), 1e-30) + 1e-7       # translation invariance: exact gradient 0
             continue
-        PARITY.check(fam + "/grad", case, name, got, ref)
+        try:
+            PARITY.check(fam + "/grad", case, name, got, ref)
+        except AssertionError as e:      # seen once in ~10 full-suite runs (never in isolation): say WHICH side moved before failing
+            d2 = tmp_path / "single_again"; d2.mkdir(exist_ok=True)
+            S2 = Solver(solver_args(str(d2), p, box), data_loader=[(x, None)])
+            S2.net.load_state_dict(r0["init"])
+            S2.train()
+            ref2 = 2.0 * S2.optim.grad_arena.cpu().numpy()[sl]
+            den = max(float(np.abs(ref2).max()), 1e-30)
+            raise AssertionError(f"{e}; single-process reference recomputed: |ref - ref2| / max|ref2| = {np.abs(ref - ref2).max() / den:.3e}, "
+                                 f"|two-rank - ref2| / max|ref2| = {np.abs(got - ref2).max() / den:.3e}") from None
