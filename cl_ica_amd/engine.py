@@ -289,7 +289,8 @@ class ContrastiveTrainer:
         self.chain = set()
         if self.split_wgrad_wide and os.environ.get("CLICA_SPLIT_WIDE_CHAIN", "1") != "0":
             in_w = [lin.in_features for lin in self.linears]
-            self.chain = {l for l in range(1, L - 1) if self.wide_kinds[l] == 0 and in_w[l] >= 1024 and widths[l] >= 1024}
+            cmin = int(os.environ.get("CLICA_SPLIT_CHAIN_MIN", "1024"))
+            self.chain = {l for l in range(1, L - 1) if self.wide_kinds[l] == 0 and in_w[l] >= cmin and widths[l] >= cmin}
         if self.chain:
             in_w = [lin.in_features for lin in self.linears]
             self.wT = {l: ops.mlp_planes_alloc(in_w[l], widths[l], False, dev) for l in self.chain}      # planes of W^T
