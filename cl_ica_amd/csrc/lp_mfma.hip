@@ -462,10 +462,12 @@ bool applies(int n, float p, int pow) {
 }
 
 Plan make_plan(int64_t n_own, int64_t n_pool) {
-  static const int envT = env_int("CLICA_LP_MFMA_T", 1);      // measured: T = 1 / 3 workgroups per CU (pool 6 144: 29 + 36 us; pool 49 152: 71 + 146)
+  // anchor tiles per wave: measured (3 workgroups per CU) pool 6 144: T = 1 29 + 36 us, T = 2 31 + 43; pool 49 152: T = 1 71 + 146, T = 2 67 + 142
+  // -> two tiles (half the pool reads per pair) once the pool is several times the local rows; CLICA_LP_MFMA_T = 1 | 2 forces
+  static const int envT = env_int("CLICA_LP_MFMA_T", 0);
   static const int wg_per_cu = env_int("CLICA_LP_MFMA_WG_PER_CU", 3);
   Plan P;
-  P.T = envT == 2 ? 2 : 1;
+  P.T = envT == 2 ? 2 : (envT == 1 ? 1 : (n_pool >= 4 * n_own ? 2 : 1));
   const int64_t per_group = (int64_t)WAVES * P.T * ROWS;
   P.groups = ceil_div(n_own > 0 ? n_own : 1, per_group);
   P.own_tiles = P.groups * WAVES * P.T;
