@@ -350,11 +350,17 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
     const u32x4 bh0 = {hpG[0], hpG[1], hpG[2], hpG[3]}, bm0 = {mpG[0], mpG[1], mpG[2], mpG[3]};
     const u32x4 bh1 = {hpG[4], hpG[5], hpG[6], hpG[7]}, bm1 = {mpG[4], mpG[5], mpG[6], mpG[7]};
     constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};        // logit piece products, small ones first
-    constexpr int GA[5] = {1, 0, 2, 1, 0};                                       // gradient: (mid, mid), (hi, mid), (lo, hi), (mid, hi), (hi, hi)
-    auto gstep = [&](int i) {                                                     // i-th of the ten gradient products
-      const int tt = i / 5, k = i % 5;
-      const u32x4 bb = tt == 0 ? (k < 2 ? bm0 : bh0) : (k < 2 ? bm1 : bh1);
-      Gt = mfma(fa[tt][GA[k]], bb, Gt);
+#ifndef LP2_GPROD
+#define LP2_GPROD 5      // piece products of the gradient per K = 16 half: 5 = (mid, mid), (hi, mid), (lo, hi), (mid, hi), (hi, hi); 4 = without (mid, mid):
+                         // measured -6 % sweep time, but the gradient at tau = 0.1 goes from 3e-6 to 1.2e-5 against the oracle -- not taken
+#endif
+    constexpr int NGH = LP2_GPROD, NG = 2 * NGH, NM = NGH - 3;                   // NM products take the mid piece of e
+    constexpr int GA5[5] = {1, 0, 2, 1, 0}, GA4[4] = {0, 2, 1, 0};
+    auto gstep = [&](int i) {                                                     // i-th of the NG gradient products
+      if (i >= NG) return;
+      const int tt = i / NGH, k = i % NGH;
+      const u32x4 bb = tt == 0 ? (k < NM ? bm0 : bh0) : (k < NM ? bm1 : bh1);
+      Gt = mfma(fa[tt][NGH == 5 ? GA5[k] : GA4[k]], bb, Gt);
       LP2_PIN1(Gt);
     };
     if (do_s) {
