@@ -2,6 +2,7 @@
 // Kernels: lp_kernels.h; per-exponent instantiations: lp_loss_pk.hip.
 #include "lp_kernels.h"
 #include "lp_mfma.h"
+#include "lp_mfma_dev.h"
 
 namespace clica {
 namespace lp {
@@ -119,13 +120,17 @@ constexpr int FIN_ROWS = 64;   // rows per finalize block; the 4 waves split the
 // training forward: the finalize thread of a row also does that row's coefficient step (statistics for the pair
 // sweep + the positive-pair gradient, upstream gradient = d(mean loss) = 1), saving the bwd_coef_k launch
 struct TrainOut { float* statL; float* statC; float* dz1; int64_t ldd1; float* dz2; int64_t ldd2; };
+// one rank, p = 2 on the matrix cores (lp_mfma.hip): the finalize block of 64 rows = two pool tiles also writes their feature planes
+// (they carry u_j = C_j 2^-L_j, which this kernel has just computed) -- the separate plane launch of the backward call disappears
+struct FeatOut { lp2::u32x4_t* FP = nullptr; const float* origin = nullptr; float pre2 = 0.f; int64_t pool_tiles = 0; };
 
 __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float2* __restrict__ part, int nsplit, int64_t rows,
     const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
     Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
-    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T) {
+    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T, FeatOut F) {
   __shared__ float sm[THREADS / FIN_ROWS][FIN_ROWS], ss[THREADS / FIN_ROWS][FIN_ROWS];
+  __shared__ float ush[FIN_ROWS];
   // the block's z1 / z2 rows, staged by all 256 threads (coalesced) while the partials are in flight: the finishing
   // threads then read their row's coordinates from LDS instead of starting two more dependent global round trips
   constexpr int FIN_MAXN = 64;
@@ -202,6 +207,22 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
       coef_row(i, rows, ra, rb, q, tau, alpha, compat, frac, dot, L2, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
                T.dz1, T.ldd1, T.dz2, T.ldd2);
     v_loss = li; v_pos = lp; v_lse = lse;
+    if (F.FP) ush[lane_row] = T.statC[i] * fexp2(-L2);      // u_i (this thread's own store, read back)
+  } else if (F.FP && grp == 0) {
+    ush[lane_row] = 0.f;
+  }
+  if (F.FP) {      // (uniform over the launch; `staged` holds: n <= 14)
+    static_assert(THREADS == 2 * 128 && FIN_ROWS == 2 * lp2::ROWS, "a finalize block = two pool tiles of 128 feature vectors each");
+    __syncthreads();
+    const int id = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * FIN_ROWS;
+    lp2::feat_vectors((int64_t)blockIdx.x * 2 + (id >> 7), (id >> 6) & 1, (id >> 5) & 1, id & 31, rows, q.n, F.origin, F.pre2,
+                      [&](int64_t j, int f) { return zrows[0][(j - r0) * q.n + f]; },
+                      [&](int64_t j) { return ush[j - r0]; }, F.FP);
+    if (blockIdx.x == gridDim.x - 1) {      // padding tiles of the plan (masked rows: their e_ij are exact zeros, the planes must be finite)
+      const lp2::u32x4_t z4 = {0u, 0u, 0u, 0u};
+      for (int64_t v = (int64_t)gridDim.x * 2 * lp2::FEATVEC + id; v < F.pool_tiles * lp2::FEATVEC; v += THREADS) F.FP[v] = z4;
+    }
   }
   reduce_means(v_loss, v_pos, v_lse, M);
 }
@@ -457,7 +478,7 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{});
+                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{});
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)rows, means);
   if (rowgrad)
     hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(rows * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
@@ -642,9 +663,12 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   }
   Means M{w.blocksums};
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
+  FeatOut feat;
+  if (w.mfma && pool == z1 && cols == rows && ldp == ld1)      // one rank: see FeatOut; bwd_sym_train makes the same test
+    feat = FeatOut{(lp2::u32x4_t*)w.w2.pool_feat, pool, sqrtf(2.f * q.kscale), w.P2.pool_tiles};
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)part, nsplit_f, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2});
+                     d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, feat);
   return launch_status("clica_lp_loss_fwd_train");
 }
 
@@ -677,7 +701,8 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   }
   int nsplit_r = PR.nsplit;
   if (w.mfma) {      // the planes of the forward call are still in the workspace (same z1 / pool, as for the row statistics)
-    lp2::launch_bwd(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, PR.np, q.kscale, w.statL, w.statC, strL, strC, partR, st);
+    lp2::launch_bwd(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, PR.np, q.kscale, w.statL, w.statC, strL, strC, partR,
+                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1, st);
     nsplit_r = w.P2.nsplit;
   } else {
     launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
@@ -974,7 +999,7 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
                        (const float*)mw.S, mw.ldS, d->B, d->B3, q.kscale, mw.part);
     hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                        (const float2*)mw.part, mw.nchunk, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                       1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{});
+                       1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{});
     hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
     if (rowgrad) {          // softmax-weighted sum of the z3 rows: one more GEMM on the weights (coefficient 1)
       dot_weights(mw, d->B, d->B3, q.kscale, lse_i, nullptr, st);
@@ -986,7 +1011,7 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
   launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, w.part_g, st);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{});
+                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{});
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
   if (rowgrad)   // gradient w.r.t. the (normalised, if requested) rows
     hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(d->B * (P.np / 4), THREADS)), dim3(THREADS), 0, st,

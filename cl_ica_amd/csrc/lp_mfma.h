@@ -33,9 +33,11 @@ void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int6
 void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st);
 // part[split][row][np] = gradient partials of the symmetric sweep (format of bwd_pairs_k<.., 3, .., FOLD>): 2 sum_j 2^x_ij (u_i + u_j) (a_i - p_j),
 // u = C 2^-L from (ownL, ownC) / (poolL, poolC)
-// (writes the pool's feature planes first: they carry the pool rows' u_j)
+// (writes the pool's feature planes first -- they carry the pool rows' u_j -- unless `feat_ready`: on one rank the forward's finalize
+// has written them, lp_mfma_dev.h)
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
-                int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, hipStream_t st);
+                int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, bool feat_ready,
+                hipStream_t st);
 
 }  // namespace lp2
 }  // namespace clica

@@ -34,6 +34,7 @@
 // A wave owns T x 32 anchors (lane l and l + 32: the same anchor, different pool rows), a workgroup four waves, the pool is cut into
 // HBM-level splits of whole stages; partial formats are those of fwd_partial_k<ZMAX> / bwd_pairs_k<FOLD>, finalize / reduce are shared.
 #include "lp_mfma.h"
+#include "lp_mfma_dev.h"
 #include <math.h>
 #include <stdlib.h>
 
@@ -53,18 +54,6 @@ static_assert(STAGE_TILES % STAGE_B == 0, "chunks are whole stages of both sweep
 
 __device__ __forceinline__ float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// v = hi + mid + lo exactly (8 + 8 + 8 significand bits, truncation); returns the pieces' upper halves in the LOW 16 bits
-__device__ __forceinline__ void split3(float v, unsigned& hi, unsigned& mid, unsigned& lo) {
-  const unsigned b = __float_as_uint(v);
-  const unsigned hb = b & 0xffff0000u;
-  const float r1 = v - __uint_as_float(hb);
-  const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-  const float r2 = r1 - __uint_as_float(mb);
-  hi = hb >> 16; mid = mb >> 16; lo = __float_as_uint(r2) >> 16;
-}
-__device__ __forceinline__ u32x4 pack8(const unsigned (&v)[8]) {
-  return (u32x4){v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16)};
-}
 // two fp32 -> packed bf16, round to nearest even (v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   const f32x2 v = {a, b};
@@ -152,24 +141,10 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
 __global__ __launch_bounds__(128) void prep_feat_k(const float* __restrict__ X, int64_t ldx, int64_t rows, int n, const float* __restrict__ origin,
                                                    float pre2, const float* __restrict__ poolL, const float* __restrict__ poolC,
                                                    u32x4* __restrict__ FP) {
-  const int tile = blockIdx.x, id = threadIdx.x;
-  const int t = id >> 6, h = (id >> 5) & 1, slot = id & 31, f = slot & 15;
-  unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const int64_t j = (int64_t)tile * ROWS + 16 * t + 8 * (e >> 2) + 4 * h + (e & 3);
-    const bool live = j < rows, ok = live && f < n;
-    const float x = pre2 * (X[ok ? j * ldx + f : 0] - origin[f < n ? f : 0]);
-    float y = ok ? x : ((live && f == n) ? 1.f : 0.f);
-    if (slot >= 16) {
-      const float L = poolL[live ? j : 0], Cc = poolC[live ? j : 0];
-      y *= live ? Cc * fexp2(-L) : 0.f;
-    }
-    split3(y, hb[e], mb[e], lb[e]);
-  }
-  FP[(((int64_t)(tile * 3 + 0) * 2 + t) * 2 + h) * 32 + slot] = pack8(hb);
-  FP[(((int64_t)(tile * 3 + 1) * 2 + t) * 2 + h) * 32 + slot] = pack8(mb);
-  FP[(((int64_t)(tile * 3 + 2) * 2 + t) * 2 + h) * 32 + slot] = pack8(lb);
+  const int id = threadIdx.x;
+  feat_vectors((int64_t)blockIdx.x, id >> 6, (id >> 5) & 1, id & 31, rows, n, origin, pre2,
+               [&](int64_t j, int f) { return X[j * ldx + f]; },
+               [&](int64_t j) { return poolC[j] * fexp2(-poolL[j]); }, FP);
 }
 
 // Both sweeps are software pipelines over "blocks" (one pool tile x one anchor tile = 1024 pairs): the matrix pipe works on block q
@@ -513,10 +488,12 @@ void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStre
 }
 
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
-                int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, hipStream_t st) {
+                int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, bool feat_ready,
+                hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
-  hipLaunchKernelGGL(prep_feat_k, dim3((unsigned)P.pool_tiles), dim3(128), 0, st, pool, ldp, n_pool, n, pool, pre2, poolL, poolC,
-                     (u32x4*)w.pool_feat);
+  if (!feat_ready)
+    hipLaunchKernelGGL(prep_feat_k, dim3((unsigned)P.pool_tiles), dim3(128), 0, st, pool, ldp, n_pool, n, pool, pre2, poolL, poolC,
+                       (u32x4*)w.pool_feat);
   dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
   if (P.T == 1)
     hipLaunchKernelGGL(bwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,

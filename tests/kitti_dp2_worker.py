@@ -38,10 +38,17 @@ def main():
     S = Solver(solver_args(outdir, p, box), data_loader=[(mine, None)])
     assert S.world == 2
     init = {k: v.detach().cpu().clone() for k, v in S.net.state_dict().items()}
+    local = {}
+    reduce_grads = S.optim.all_reduce_grads
+
+    def recording_reduce():          # this rank's own gradient, as it stands when the exchange starts (diagnostics of the parent test)
+        local["before"] = S.optim.grad_arena.clone()
+        reduce_grads()
+    S.optim.all_reduce_grads = recording_reduce
     assert S.train() is False and S.global_iter == 1            # the real loop: one iteration, rank 0 writes log.csv + checkpoint
     torch.cuda.synchronize()
     torch.save(dict(init=init, final={k: v.detach().cpu() for k, v in S.net.state_dict().items()},
-                    grad=S.optim.grad_arena.cpu(), wrote_log=os.path.exists(os.path.join(outdir, "log.csv"))),
+                    grad=S.optim.grad_arena.cpu(), local_grad=local["before"].cpu(), wrote_log=os.path.exists(os.path.join(outdir, "log.csv"))),
                os.path.join(outdir, f"kitti_rank{rank}.pt"))
     dist.destroy_process_group()
 
