@@ -60,6 +60,18 @@ class _SharedScalars:
             self.event = torch.cuda.Event()
             self.event.record()
 
+    def __getstate__(self):      # copy.deepcopy / torch.save of a returned loss tensor carry this object along: keep only the numbers
+        if self.vals is None:
+            if self.event is not None:
+                self.event.synchronize()
+                self.vals = self.host.tolist()
+            else:
+                self.vals = self.src.tolist()
+        return {"vals": self.vals}
+
+    def __setstate__(self, state):
+        self.src, self.host, self.event, self.vals = None, None, None, state["vals"]
+
     def item(self, t, k, version):
         if t._version != version:
             return torch.Tensor.item(t)

@@ -456,3 +456,7 @@ def test_lazy_compute_many_after_step_and_shared_items_on_cpu():
     assert [t.item() for t in outs] == [1.5, 2.5, 3.5]
     src[1] = 7.0                                        # written after the call: Tensor.item answers
     assert outs[1].item() == 7.0
+    import copy, io
+    assert copy.deepcopy(outs[0]).item() == 1.5         # the attribute travels with copies / pickles of the tensor as plain numbers
+    buf = io.BytesIO(); torch.save(outs[2], buf); buf.seek(0)
+    assert torch.load(buf, weights_only=False).item() == 3.5
