@@ -702,7 +702,7 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   int nsplit_r = PR.nsplit;
   if (w.mfma) {      // the planes of the forward call are still in the workspace (same z1 / pool, as for the row statistics)
     lp2::launch_bwd(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, PR.np, q.kscale, w.statL, w.statC, strL, strC, partR,
-                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1, st);
+                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1 && pool_lse == lse_i, st);
     nsplit_r = w.P2.nsplit;
   } else {
     launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
