@@ -485,6 +485,11 @@ def test_p2_train_sweeps_on_matrix_cores_vs_oracle(B, n, tau, space):
     z, zt = z.astype(np.float32), zt.astype(np.float32)
     o, dz, path = _train_pair(dev(z), dev(zt), dev(z), None, n, 2, tau, alpha)
     assert path == 1, "the p = 2 training sweeps must take the matrix-core path (CLICA_LP_MFMA / CLICA_LP_TRAIN_FAST unset)"
+    # the engine's single-rank call passes ONE buffer as anchors and pool: then the forward's finalize writes the pool's feature planes
+    # itself (no plane launch in the backward call) -- same builder, so the same bits as the two-buffer call above
+    zd = dev(z)
+    o1, dz1b, _ = _train_pair(zd, dev(zt), zd, None, n, 2, tau, alpha)
+    assert torch.equal(o1, o) and torch.equal(dz1b, dz)
     orc = O.lp_simclr_loss(z, zt, z, p=2, tau=tau, alpha=alpha, compat=True, grad=False)
     fam, case = "p2_train_matrix_cores", f"B={B} n={n} tau={tau} {space}"
     oc = o.cpu().numpy()
