@@ -331,12 +331,17 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 #endif
     constexpr int NGH = LP2_GPROD, NG = 2 * NGH, NM = NGH - 3;                   // NM products take the mid piece of e
     constexpr int GA5[5] = {1, 0, 2, 1, 0}, GA4[4] = {0, 2, 1, 0};
+#ifndef LP2_PRIO
+#define LP2_PRIO 0       // measurement switch: 1 = s_setprio 1 around every MFMA issue (measured: 146 -> 168 us at the 49 152-row pool), 2 = around the vector work (150 -> 171 us): per-instruction priority flips cost more than the arbitration they buy
+#endif
     auto gstep = [&](int i) {                                                     // i-th of the NG gradient products
       if (i >= NG) return;
       const int tt = i / NGH, k = i % NGH;
       const u32x4 bb = tt == 0 ? (k < NM ? bm0 : bh0) : (k < NM ? bm1 : bh1);
+      if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 1 : 0);
       Gt = mfma(fa[tt][NGH == 5 ? GA5[k] : GA4[k]], bb, Gt);
       LP2_PIN1(Gt);
+      if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1);
     };
     if (do_s) {
 #pragma unroll
@@ -345,7 +350,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       // first MFMA of the step
-      if (e < 6) { if (do_s) { accN = mfma(a[SA[e]], bt[SB[e]], accN); LP2_PIN1(accN); } }
+      if (e < 6) { if (do_s) { if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 1 : 0); accN = mfma(a[SA[e]], bt[SB[e]], accN); LP2_PIN1(accN); if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1); } }
       else gstep(6 + 2 * (e - 6));
 #if LP2_ABLATE & 2
       float e0 = accV[2 * e], e1 = accV[2 * e + 1];
