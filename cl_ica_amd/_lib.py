@@ -50,6 +50,7 @@ SIGNATURES: Dict[str, list] = {
                               c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],
     "clica_lp_loss_train_workspace_bytes": [C.POINTER(LpLossDesc), C.POINTER(c_size)],
     "clica_lp_loss_train_path": [C.POINTER(LpLossDesc), C.POINTER(c_i32)],
+    "clica_lp_loss_set_matrix_cores": [c_i32],
     "clica_lp_loss_train_spread": [C.POINTER(LpLossDesc), C.c_void_p, c_size, C.POINTER(C.c_float), C.c_void_p],
     "clica_lp_loss_fwd_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p,
                                 c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],

@@ -618,6 +618,11 @@ extern "C" int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* pa
   return CLICA_OK;
 }
 
+extern "C" int clica_lp_loss_set_matrix_cores(int32_t on) {
+  lp2::set_enabled(on != 0);
+  return CLICA_OK;
+}
+
 extern "C" int clica_lp_loss_train_spread(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* spread,
                                           clica_stream_t stream) {
   int rc = validate(d, "clica_lp_loss_train_spread");

@@ -20,7 +20,8 @@ struct Plan {
   int nsplit, chunk_tiles;
 };
 Plan make_plan(int64_t n_own, int64_t n_pool);
-bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0)
+bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0, or set_enabled)
+void set_enabled(bool on);                  // process-wide override of CLICA_LP_MFMA (clica_lp_loss_set_matrix_cores)
 
 struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };   // spread: running max of M (see launch_prep)
 Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-provided workspace (256-byte aligned base)

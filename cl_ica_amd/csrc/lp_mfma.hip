@@ -442,8 +442,11 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 // ---- host ---------------------------------------------------------------------------------------------------------------------
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+static int g_enabled = -1;      // -1: take CLICA_LP_MFMA (default on); set_enabled overrides it for the process
+void set_enabled(bool on) { g_enabled = on ? 1 : 0; }
 bool applies(int n, float p, int pow) {
-  static const int on = env_int("CLICA_LP_MFMA", 1);
+  static const int env_on = env_int("CLICA_LP_MFMA", 1);
+  const int on = g_enabled >= 0 ? g_enabled : env_on;
   return on != 0 && p == 2.f && pow != 0 && n >= 1 && n <= MAX_N;
 }
 

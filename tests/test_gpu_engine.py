@@ -315,3 +315,34 @@ def test_failed_capture_leaves_the_engine_usable():
     r = subprocess.run([sys.executable, worker, str(port)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "FAILED_CAPTURE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     assert "capture failed as expected" in r.stdout
+
+
+def test_loss_matrix_core_switch_and_spread():
+    """The engine reports the spread the p = 2 matrix-core loss sweeps have seen and can be switched to the coordinate-difference sweeps
+    at run time (what cl_ica_amd.train_mlp does beyond M = 150): path query, results of both settings on a batch inside the stated range
+    agree at 1e-5, a captured graph is re-captured."""
+    import ctypes as C
+    from cl_ica_amd import _lib, encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(2)
+    n, B = 10, 1024
+    f = encoders.get_mlp(n, n, [100, 500, 100]).to("cuda")
+    gW = torch.eye(n, device="cuda").repeat(3, 1, 1).contiguous()
+    z1 = torch.rand(B, n, device="cuda"); z2 = (z1 + 0.05 * torch.randn_like(z1)).clamp(0, 1)
+    tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
+    lib, path = _lib.load(), C.c_int32()
+    try:
+        _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
+        out_m = tr.step_injected(z1, z2).clone(); g_m = tr.grad_arena.clone()
+        y = tr.y[:B]
+        want = 1.4426950408889634 * float(((y - y[0]) ** 2).sum(1).max())
+        assert abs(tr.loss_spread() - want) <= 1e-3 * want + 1e-6
+        tr.capture()
+        tr.set_loss_matrix_cores(False)
+        _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 0
+        assert tr.graph is not None                                   # captured again, with the other sweeps
+        out_v = tr.step_injected(z1, z2).clone(); g_v = tr.grad_arena.clone()
+        PARITY.check("loss_matrix_core_switch", f"n={n} B={B}", "means", out_m.cpu().numpy(), out_v.cpu().numpy())
+        PARITY.check("loss_matrix_core_switch", f"n={n} B={B}", "gradient arena", g_m.cpu().numpy(), g_v.cpu().numpy())
+    finally:
+        _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "restore")
