@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the split-bf16 mode issues six bf16 products per fp32 product)
+NOMINAL_GHZ = 2.4                 # MI355X peak engine clock (MI355X_MICROARCH.md): what the peak TFLOP/s figures are quoted at
 PEAK_FP32_VALU_TFLOPS = 157.3
 
 
@@ -246,6 +247,7 @@ def roofline_leg(tr, reps=20):
     # symbol back to back sees a different L2 / Infinity-Cache state (its own 108 MB output is still resident) and the
     # forward / backward-chain pair alone thrashes differently again (measured 208 / 201 / 215 us for the three variants).
     instep = {}
+    instep_ghz = {}
     instep_how = None
     if tr.fused_forward and tr.fused_backward and tr.grouped_wgrad and tr.head is None and not tr.dp and tr.graph is not None:
         # Preferred: the launches INSIDE the replayed step graph -- what the timed loop runs and what the rocprofv3 kernel trace
@@ -259,10 +261,20 @@ def roofline_leg(tr, reps=20):
             tr.stamps = {k: torch.zeros(1 + 2 * reps, dtype=torch.int64, device=tr.device) for k in names + ("null",)}
             tr.graph = None
             tr.capture()
+            # shader clock over the same replays: the one-wave probe on a side stream (clica_clock_probe), 10 us between samples
+            probe_stream = torch.cuda.Stream(device=tr.device)
+            probe = ops.clock_probe((WARM + reps) * 60 + 2000, 10.0, probe_stream)       # ~0.6 ms per step + slack
             for _ in range(WARM + reps):
                 tr.graph.replay()
             torch.cuda.synchronize()
             iv = {k: ops.stamp_intervals_us(tr.stamps[k]) for k in names + ("null",)}
+            smp = probe.cpu().numpy()
+            smp = smp[smp[:, 0] > 0]
+            for k in names:
+                g_ = [ops.clock_between(smp, b0, b1) for b0, b1 in ops.stamp_brackets(tr.stamps[k])]
+                g_ = [x for x in g_ if x is not None and 0.2 < x < 3.0]
+                if len(g_) >= max(3, reps // 4):
+                    instep_ghz[k] = float(np.median(g_))
             if all(len(v) == reps for v in iv.values()):
                 null_us = float(np.median(iv["null"]))       # begin stamp's run time + one launch boundary
                 instep = {k: float(np.median(iv[k])) - null_us for k in names}
@@ -315,6 +327,10 @@ def roofline_leg(tr, reps=20):
     for r in rows:
         if r["op"] in instep:
             r["in_step_us"] = instep[r["op"]]
+        if r["op"] in instep_ghz:
+            r["shader_clock_ghz"] = round(instep_ghz[r["op"]], 3)      # the probe wave's cycles / wall time inside the op's brackets (median)
+        elif r["op"] == fused_key[0] and "mlp_fwd" in instep_ghz and "mlp_dgrad" in instep_ghz:
+            r["shader_clock_ghz"] = round(0.5 * (instep_ghz["mlp_fwd"] + instep_ghz["mlp_dgrad"]), 3)
     if instep:       # the dominant symbol's entry: average of its two in-step launches (forward stack + backward chain)
         for r in rows:
             if r["op"] == fused_key[0]:
@@ -387,6 +403,13 @@ def roofline_leg(tr, reps=20):
             "peak": peak, "unit": "TFLOP/s", "frac": round(issued_factor * top["tflops"] / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top.get("alg_bytes"), "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
             "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": note}
+    if top.get("shader_clock_ghz"):
+        ghz = top["shader_clock_ghz"]
+        roof["shader_clock_ghz"] = ghz
+        roof["frac_at_measured_clock"] = round(issued_factor * top["tflops"] / (peak * ghz / NOMINAL_GHZ), 4)
+        roof["clock_note"] = ("shader clock over the kernel's in-step brackets (a one-wave probe on a side stream samples s_memtime / s_memrealtime every 10 us, clica_clock_probe); "
+                              "`peak` is the nominal %.1f GHz figure, `frac_at_measured_clock` prices the same launch against the matrix rate "
+                              "at the clock the chip actually held" % NOMINAL_GHZ)
     if issued_factor != 1.0:
         roof["flops_counted"] = "issued bf16 flops = 6 x algorithmic 2MNK (six piece products per fp32 product), against the dense bf16 MFMA peak"
         roof["fp32_equivalent"] = {"achieved": round(top["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

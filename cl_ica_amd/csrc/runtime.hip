@@ -29,7 +29,28 @@ __global__ void stamp_k(unsigned long long* slot, int which, int cap) {
   slot[1 + 2 * (c % (unsigned long long)cap) + which] = t;
   if (!which) slot[0] = c + 1;
 }
+// Shader-clock probe: ONE wave that samples (wall clock, core-clock counter) every `period` wall ticks, n times, and sleeps in between.
+// Launched on a side stream it shares a CU with whatever the main stream runs (16 registers, no LDS: it fits next to the 8-wave
+// workgroups of the encoder kernels), so the cycles it counts between two samples are that XCD's clock over that stretch of time.
+// (The core-clock counters are per CU and stop with it: stamps taken by different launches on different CUs cannot be subtracted --
+// tools/proto/xcc_probe.hip shows two workgroups of one launch on the same XCD 19 M cycles apart.)
+__global__ void clock_probe_k(unsigned long long* samples, int n, int period) {
+  unsigned long long next = wall_clock64();
+  for (int i = 0; i < n; ++i) {
+    unsigned long long t;
+    do { __builtin_amdgcn_s_sleep(8); t = wall_clock64(); } while (t < next);
+    samples[2 * i] = t;
+    samples[2 * i + 1] = __builtin_amdgcn_s_memtime();
+    next = t + (unsigned long long)period;
+  }
+}
 }  // namespace clica
+
+extern "C" int clica_clock_probe(unsigned long long* samples, int32_t n, int32_t period_ticks, clica_stream_t stream) {
+  CLICA_CHECK_ARG(samples != nullptr && n >= 1 && period_ticks >= 1, "clica_clock_probe: bad argument");
+  hipLaunchKernelGGL(clica::clock_probe_k, dim3(1), dim3(1), 0, clica::as_stream(stream), samples, (int)n, (int)period_ticks);
+  return clica::launch_status("clica_clock_probe");
+}
 
 extern "C" const char* clica_last_error(void) { return clica::g_err; }
 extern "C" int clica_version(void) { return 100; }

@@ -503,6 +503,32 @@ def stamp(slot: torch.Tensor, which: int):
     check(load().clica_stamp(slot.data_ptr(), int(which), (slot.numel() - 1) // 2, stream_ptr()), "clica_stamp")
 
 
+def clock_probe(n: int, period_us: float, stream: "torch.cuda.Stream") -> torch.Tensor:
+    """Start the one-wave shader-clock probe on `stream` (a SIDE stream): n samples, `period_us` apart; returns the device buffer
+    int64 [n, 2] = (wall clock in 100 MHz ticks, core-clock counter), complete once `stream` is (clica_clock_probe)."""
+    buf = torch.zeros((int(n), 2), dtype=torch.int64, device="cuda")
+    check(load().clica_clock_probe(buf.data_ptr(), int(n), max(1, int(round(period_us * 100))), stream.cuda_stream), "clica_clock_probe")
+    return buf
+
+
+def clock_between(samples_cpu, t0: int, t1: int) -> Optional[float]:
+    """Shader clock in GHz over the wall-clock window [t0, t1] (100 MHz ticks) from the probe's samples (numpy int64 [n, 2], sorted):
+    cycles between the first and the last sample inside the window / their distance in time; None with fewer than two samples."""
+    import numpy as np
+    w = samples_cpu[:, 0]
+    lo, hi = int(np.searchsorted(w, t0, "left")), int(np.searchsorted(w, t1, "right")) - 1
+    if hi - lo < 1 or w[lo] == 0:
+        return None
+    return float(samples_cpu[hi, 1] - samples_cpu[lo, 1]) / (float(w[hi] - w[lo]) * 10.0)       # cycles per 10 ns tick -> GHz
+
+
+def stamp_brackets(slot: torch.Tensor):
+    """Completed (begin, end) pairs of a stamp slot as absolute wall-clock ticks (100 MHz)."""
+    v = slot.cpu()
+    n = min(int(v[0]), (v.numel() - 1) // 2)
+    return [(int(v[1 + 2 * i]), int(v[2 + 2 * i])) for i in range(n)]
+
+
 def stamp_intervals_us(slot: torch.Tensor):
     """Completed (begin, end) pairs of a stamp slot as microseconds (100 MHz counter)."""
     v = slot.cpu()

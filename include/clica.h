@@ -444,6 +444,11 @@ int clica_tick(int32_t* counter, clica_stream_t stream);
  * begin (which = 0) / end (which = 1) entry (count % capacity) and the begin stamp advances the count in slot[0].  Launched on the
  * stream right before / after the kernel of interest, the pair brackets it exactly as the in-order stream executes it. */
 int clica_stamp(unsigned long long* slot, int32_t which, int32_t capacity, clica_stream_t stream);
+/* Shader-clock probe (bench.py): a one-wave kernel that writes n samples (wall clock in 100 MHz ticks, core-clock counter) `period_ticks`
+ * apart into samples[2 n] and sleeps in between.  Launched on a SIDE stream it shares a CU with the kernels of the main stream; cycles /
+ * wall time between two samples = the clock that XCD held over that stretch, which bench.py reports next to every in-step kernel time
+ * (the chip throttles under bf16 MFMA load: every roofline fraction against the nominal peak contains it). */
+int clica_clock_probe(unsigned long long* samples, int32_t n, int32_t period_ticks, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * On-device latent samplers (Philox4x32-10, counter = (element, draw, *step_dev, stream_id))

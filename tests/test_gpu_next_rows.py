@@ -585,6 +585,19 @@ def test_device_time_stamps_inside_a_graph():
     iv = ops.stamp_intervals_us(slot)
     assert int(slot[0].item()) == 6 and len(iv) == 4
     assert all(20.0 < v < 20000.0 for v in iv), iv
+    # the shader-clock probe (clica_clock_probe) on a side stream while the same graph replays: cycles / wall time inside a bracket is a
+    # clock between idle and the 2.4 GHz peak
+    side = torch.cuda.Stream()
+    probe = ops.clock_probe(3000, 10.0, side)
+    with torch.cuda.stream(s):
+        for _ in range(40):
+            g.replay()
+    torch.cuda.synchronize()
+    smp = probe.cpu().numpy()
+    assert (smp[:, 0] > 0).all() and (np.diff(smp[:, 0]) >= 1000).all()          # 3000 samples, >= 10 us apart
+    ghz = [ops.clock_between(smp, b0, b1) for b0, b1 in ops.stamp_brackets(slot)]
+    ghz = [x for x in ghz if x is not None]
+    assert len(ghz) >= 2 and all(0.3 < x < 2.6 for x in ghz), ghz
 
 
 def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
