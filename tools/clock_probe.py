@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
 """Effective shader clock while the training step (or one of its kernels) runs back to back: s_memtime delta / s_memrealtime delta.
+(Round 4: stamps taken by separate one-thread launches can land on different CUs, whose core-clock counters do not share an origin
+-- tools/proto/xcc_probe.hip; bench.py now uses a one-wave probe that stays on one CU, clica_clock_probe.  Kept for the rocm-smi
+readout and the back-to-back kernel loops; treat its GHz column as indicative.)
 usage: python tools/clock_probe.py   (builds tools/proto/clock_probe.hip with hipcc on the GPU box)"""
 import ctypes, os, subprocess, sys, time
 import torch
