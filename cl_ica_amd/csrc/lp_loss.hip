@@ -619,7 +619,7 @@ extern "C" int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* pa
 }
 
 extern "C" int clica_lp_loss_set_matrix_cores(int32_t on) {
-  lp2::set_enabled(on != 0);
+  lp2::set_enabled(on);
   return CLICA_OK;
 }
 

@@ -6,8 +6,8 @@ namespace clica {
 namespace lp2 {
 
 constexpr int ROWS = 32;             // rows per operand tile (one 32 x 32 x 16 MFMA block side)
-constexpr int KSLOTS = 16;           // feature slots of a row: n coordinates + 2 augmented columns, zero padded
-constexpr int MAX_N = KSLOTS - 2;
+constexpr int KSLOTS = 16;           // feature slots of a row: n coordinates + 3 ones + 3 norm pieces (lp_mfma.hip: planes)
+constexpr int MAX_N = KSLOTS - 6;
 constexpr int STAGE_TILES = 4;       // pool tiles per LDS stage
 constexpr int ROWVEC = 3 * 2 * ROWS; // 16-byte vectors of one tile's row planes   [piece][k half][row]      (3 KB)
 constexpr int FEATVEC = 3 * 2 * 2 * 32;   // ... of its feature planes              [piece][mfma][k half][feature slot < 32]   (6 KB)
@@ -21,7 +21,7 @@ struct Plan {
 };
 Plan make_plan(int64_t n_own, int64_t n_pool);
 bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0, or set_enabled)
-void set_enabled(bool on);                  // process-wide override of CLICA_LP_MFMA (clica_lp_loss_set_matrix_cores)
+void set_enabled(int on);                   // process-wide override of CLICA_LP_MFMA: 1 / 0, negative = back to the environment's setting
 
 struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };   // spread: running max of M (see launch_prep)
 Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-provided workspace (256-byte aligned base)

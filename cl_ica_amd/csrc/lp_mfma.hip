@@ -1,6 +1,6 @@
 // LpSimCLRLoss with p = 2 (pow) on the bf16 matrix cores: the pair sweeps of the TRAINING entry points
 // (clica_lp_loss_fwd_train / clica_lp_loss_bwd_sym_train, /root/reference/losses.py:430-477 with main_mlp.py:272's z3 = roll(z1))
-// for n <= 14.
+// for n <= 10.
 //
 // Why this is matrix work.  With x' = sqrt(2 log2(e) / tau) (x - origin) the scaled logit of a pair is
 //     x_ij = -log2(e)/tau |a_i - p_j|^2 = a'_i . p'_j - |a'_i|^2 / 2 - |p'_j|^2 / 2,
@@ -37,6 +37,7 @@
 #include "lp_mfma_dev.h"
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace clica {
 namespace lp2 {
@@ -70,70 +71,110 @@ __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 #endif
 }
-// the six piece products of order <= 2, small ones first
+// the six piece products of order <= 2: five in one accumulator (terms of size M / 128), hi x hi -- exact, see the planes -- in its own
 __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (&b)[3]) {
-  f32x16 acc;
+  f32x16 acc, acch;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acch[r] = 0.f; }
   acc = mfma(a[2], b[0], acc);
+  acch = mfma(a[0], b[0], acch);
   acc = mfma(a[0], b[2], acc);
   acc = mfma(a[1], b[1], acc);
   acc = mfma(a[1], b[0], acc);
   acc = mfma(a[0], b[1], acc);
-  acc = mfma(a[0], b[0], acc);
-  return acc;
+  return acc + acch;
 }
 
 // ---- planes ---------------------------------------------------------------------------------------------------------------------
-// role 0 = pool rows (x', 1, -|x'|^2/2; rows >= `rows` masked with -1e30 in the last slot), role 1 = anchors (x', -|x'|^2/2, 1)
+// The expansion's enemy is the size of its terms: a'.p' and the two half norms are ~M = log2(e)/tau |x - origin|^2 each, their sum is the
+// logit, and an fp32 accumulator that has held a number of size M carries 2^-24 M of rounding -- 6e-5 of relative error in the weights at
+// M = 1000, which is where the reference's own training lives (unnormalised encoder outputs grow to a standard deviation of ~10 within a
+// thousand steps of main_mlp.py's defaults).  So the LARGE part is made exact: the hi piece of every coordinate is a multiple of one grid
+// step D = 2^e for the whole launch (|x'| / D < 128 from the step's own max |x'|, maxabs_k), its half norm Nh = sum hi^2 / 2 goes into
+// three slots of the hi plane as an exact three-piece split, and the hi x hi product runs into an accumulator of its own: every partial
+// sum is an integer multiple of D^2 / 2 below 2^24 of them, i.e. exact, and the result -|hi_a - hi_p|^2 / 2 is small wherever the pair
+// matters.  The other five piece products carry terms of size M / 128 (remainders r = x' - hi, |r| <= D / 2, and the remainder norms
+// Nr = sum (hi r + r^2 / 2)) in a second accumulator; the two are added on the vector ALU.  Measured: section "spread" of the tests.
+// Slots (K = 16 = n + 6, n <= 10): coordinates 0..n-1; pool rows: ones at n..n+2, own norms at n+3..n+5; anchors the other way round;
+// own norm slots: hi plane = the three pieces of -Nh, mid plane = the three pieces of -Nr; rows >= `rows` of the pool: -Nr = -1e30.
+__global__ __launch_bounds__(256) void maxabs_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, const float* __restrict__ Xa, int64_t lda,
+                                                int64_t rows_a, int n, const float* __restrict__ origin, float pre2, float* __restrict__ words) {
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool pool = id < rows_p;
+  const int64_t j = pool ? id : id - rows_p;
+  float m = 0.f;
+  if (pool || j < rows_a) {
+    const float* row = pool ? Xp + j * ldp : Xa + j * lda;
+    for (int k = 0; k < n; ++k) m = fmaxf(m, fabsf(pre2 * (row[k] - origin[k])));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(words + 1), __float_as_int(m));     // (non-negative floats order like ints)
+}
+
 __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
                                              const float* __restrict__ Xa, int64_t lda, int64_t rows_a, u32x4* __restrict__ RPa,
-                                             int n, const float* __restrict__ origin, float pre2, float* __restrict__ spread) {
+                                             int n, const float* __restrict__ origin, float pre2, float* __restrict__ words) {
   // one launch for both operands: blocks [0, pool_blocks) the pool (role 0), the rest the anchors (role 1); two tiles per block
   const int role = (int)blockIdx.x >= pool_blocks ? 1 : 0;
   const float* __restrict__ X = role ? Xa : Xp;
   const int64_t ldx = role ? lda : ldp, rows = role ? rows_a : rows_p;
   u32x4* __restrict__ RP = role ? RPa : RPp;
   const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * 2 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
-  {
-    const int64_t j = (int64_t)tile * ROWS + lane;
-    const bool live = j < rows;
-    float v[KSLOTS];
-    float nx = 0.f;
+  // grid step: the power of two with max |x'| / D in [64, 128)
+  const unsigned xb = __float_as_uint(words[1]);
+  const int ex = (int)((xb >> 23) & 0xffu) - 6;
+  const float D = __uint_as_float((unsigned)(ex < 1 ? 1 : ex) << 23), invD = 1.f / D;
+  const int64_t j = (int64_t)tile * ROWS + lane;
+  const bool live = j < rows;
+  unsigned hb[KSLOTS], mb[KSLOTS], lb[KSLOTS];
+  float nh = 0.f, nr = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_N; ++k) {
-      const bool ok = live && k < n;
-      const float x = pre2 * (X[ok ? j * ldx + k : 0] - origin[k < n ? k : 0]);
-      v[k] = ok ? x : 0.f;
-      nx = fmaf(v[k], v[k], nx);
+  for (int k = 0; k < MAX_N; ++k) {
+    const bool ok = live && k < n;
+    const float xr = pre2 * (X[ok ? j * ldx + k : 0] - origin[k < n ? k : 0]);
+    const float x = ok ? xr : 0.f;
+    const float hi = __uint_as_float(__float_as_uint(rintf(x * invD) * D) & 0xffff0000u);      // a multiple of D with <= 8 significant bits
+    const float r = x - hi;
+    const unsigned mbits = __float_as_uint(r) & 0xffff0000u;
+    const float r2 = r - __uint_as_float(mbits);
+    hb[k] = __float_as_uint(hi) >> 16; mb[k] = mbits >> 16; lb[k] = __float_as_uint(r2) >> 16;
+    nh = fmaf(hi, hi, nh);
+    nr += fmaf(hi, r, 0.5f * r * r);
+  }
+  nh *= 0.5f;
+  if (role == 0) {      // diagnostic: the largest M of the pool so far
+    float m = live ? nh + nr : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(words), __float_as_int(fmaxf(m, 0.f)));
+  }
+  unsigned nhp[3], nrp[3];
+  split3(-nh, nhp[0], nhp[1], nhp[2]);
+  split3((role == 0 && !live) ? -1e30f : -nr, nrp[0], nrp[1], nrp[2]);
+  const int own0 = role == 0 ? n + 3 : n, one0 = role == 0 ? n : n + 3;
+#pragma unroll
+  for (int k = 0; k < KSLOTS; ++k) {
+    const int o = k - own0, u = k - one0;
+    if (k >= n) {
+      const bool isown = o >= 0 && o < 3, isone = u >= 0 && u < 3;
+      hb[k] = isown ? (o == 0 ? nhp[0] : (o == 1 ? nhp[1] : nhp[2])) : (isone ? 0x3f80u : 0u);
+      mb[k] = isown ? (o == 0 ? nrp[0] : (o == 1 ? nrp[1] : nrp[2])) : 0u;
+      lb[k] = 0u;
     }
-    v[MAX_N] = 0.f; v[MAX_N + 1] = 0.f;
-    nx *= 0.5f;
-    if (role == 0) {      // diagnostic: the largest M of the pool (non-negative floats order like their bit patterns)
-      float m = live ? nx : 0.f;
+  }
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-      if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(spread), __float_as_int(m));
-    }
-    const float c0 = role == 0 ? 1.f : -nx, c1 = role == 0 ? (live ? -nx : -1e30f) : 1.f;
+  for (int h = 0; h < 2; ++h) {
+    unsigned t8[8];
 #pragma unroll
-    for (int k = 0; k < KSLOTS; ++k) v[k] = k == n ? c0 : (k == n + 1 ? c1 : v[k]);
-    unsigned hb[KSLOTS], mb[KSLOTS], lb[KSLOTS];
+    for (int e = 0; e < 8; ++e) t8[e] = hb[8 * h + e];
+    RP[((int64_t)(tile * 3 + 0) * 2 + h) * ROWS + lane] = pack8(t8);
 #pragma unroll
-    for (int k = 0; k < KSLOTS; ++k) split3(v[k], hb[k], mb[k], lb[k]);
+    for (int e = 0; e < 8; ++e) t8[e] = mb[8 * h + e];
+    RP[((int64_t)(tile * 3 + 1) * 2 + h) * ROWS + lane] = pack8(t8);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      unsigned t8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t8[e] = hb[8 * h + e];
-      RP[((int64_t)(tile * 3 + 0) * 2 + h) * ROWS + lane] = pack8(t8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t8[e] = mb[8 * h + e];
-      RP[((int64_t)(tile * 3 + 1) * 2 + h) * ROWS + lane] = pack8(t8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) t8[e] = lb[8 * h + e];
-      RP[((int64_t)(tile * 3 + 2) * 2 + h) * ROWS + lane] = pack8(t8);
-    }
+    for (int e = 0; e < 8; ++e) t8[e] = lb[8 * h + e];
+    RP[((int64_t)(tile * 3 + 2) * 2 + h) * ROWS + lane] = pack8(t8);
   }
 }
 
@@ -169,13 +210,14 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by) {
 // ---- forward: sum_j 2^x_ij per anchor and split -------------------------------------------------------------------------------
 template <int T>
 __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RPa, const u32x4* __restrict__ RPp, int64_t n_own,
-                                                    float2* __restrict__ part, int chunk_tiles) {
+                                                    float2* __restrict__ part, int chunk_tiles, float* __restrict__ words) {
   constexpr int SV = STAGE_TILES * ROWVEC, PER = SV / THREADS;       // 768 vectors per stage, 3 per thread
   static_assert(SV % THREADS == 0, "stage copy");
   __shared__ u32x4 stage[2][SV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   int bx, by;
   xcd_tile(bx, by);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) words[1] = 0.f;      // the planes are written: next call's maxabs_k starts from 0
   const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
   u32x4 b[T][3];
 #pragma unroll
@@ -277,11 +319,24 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
   const u32x4* srcR = RPp + tile_b * ROWVEC;
   const u32x4* srcF = FPp + tile_b * FEATVEC;
   const int nst = chunk_tiles / STAGE_B;
+  // A stage's LDS image holds the row planes of ITS tiles and the feature planes of the tiles whose gradient product runs during it --
+  // the pipeline is two blocks behind, i.e. BACK tiles earlier -- so that every read of a stage goes to the buffer the barrier in front
+  // of it has completed.  (The first version read those feature planes from the previous stage's buffer, which a faster wave was already
+  // refilling: a race that showed as run-to-run differences of 1e-3 of the gradient scale once the waves drifted apart.)  Tile indices
+  // outside the chunk (the window of the first stage, the S-less last stage) are clamped: their coefficient pieces are exact zeros.
+  constexpr int BACK = T == 1 ? 2 : 1;
   auto fetch = [&](int st, u32x4 (&pre)[PER]) {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int idx = threadIdx.x + u * THREADS;
-      if (idx < SV) pre[u] = idx < RV ? srcR[(int64_t)st * RV + idx] : srcF[(int64_t)st * FV + (idx - RV)];
+      if (idx < RV) {
+        pre[u] = srcR[(int64_t)(st < nst ? st : nst - 1) * RV + idx];
+      } else if (idx < SV) {
+        const int fi = idx - RV, tl = fi / FEATVEC;
+        int tile = st * STAGE_B - BACK + tl;
+        tile = tile < 0 ? 0 : (tile > chunk_tiles - 1 ? chunk_tiles - 1 : tile);
+        pre[u] = srcF[(int64_t)tile * FEATVEC + (fi - tl * FEATVEC)];
+      }
     }
   };
   auto put = [&](int bsel, const u32x4 (&pre)[PER]) {
@@ -292,10 +347,6 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
     }
   };
   u32x4 pre[PER];
-  {   // "the stage before the first", which the pipeline's first two gradient products read: zeros
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    for (int idx = threadIdx.x; idx < LV; idx += THREADS) stage[1][idx] = z;
-  }
   fetch(0, pre);
   put(0, pre);
   __syncthreads();
@@ -343,14 +394,22 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
       LP2_PIN1(Gt);
       if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1);
     };
+    f32x16 accH;                 // the exact hi x hi product of block q (see the planes), added to the other five at the end
     if (do_s) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accN[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { accN[r] = 0.f; accH[r] = 0.f; }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       // first MFMA of the step
-      if (e < 6) { if (do_s) { if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 1 : 0); accN = mfma(a[SA[e]], bt[SB[e]], accN); LP2_PIN1(accN); if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1); } }
+      if (e < 6) {
+        if (do_s) {
+          if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 1 : 0);
+          if (SA[e] == 0 && SB[e] == 0) { accH = mfma(a[0], bt[0], accH); LP2_PIN1(accH); }
+          else { accN = mfma(a[SA[e]], bt[SB[e]], accN); LP2_PIN1(accN); }
+          if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1);
+        }
+      }
       else gstep(6 + 2 * (e - 6));
 #if LP2_ABLATE & 2
       float e0 = accV[2 * e], e1 = accV[2 * e + 1];
@@ -372,43 +431,41 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
       LP2_PIN1(hpN[e]); LP2_PIN1(mpN[e]);
       LP2_FENCE();
     }
+    if (do_s) accN = accN + accH;
   };
   int cur = 0;
-  for (int st = 0; st < nst; ++st, cur ^= 1) {
-    const bool more = st + 1 < nst;
-    if (more) fetch(st + 1, pre);
+  auto run_stage = [&](auto s_tag) {
+    constexpr bool DO_S = decltype(s_tag)::value;
     u32x4 a[3];
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
       const int tl = q / T, t = q % T;
-      const int q2 = (q + NB - 2) % NB;          // block q - 2 (of the previous stage when q < 2)
-      const int buf2 = q >= 2 ? cur : cur ^ 1;
-      if (t == 0) {
+      const int q2 = (q + NB - 2) % NB;          // block q - 2: its anchor tile is q2 % T, its feature planes sit at window index ...
+      const int tlG = (q - 2 + BACK * T) / T;
+      if (DO_S && t == 0) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) a[p] = stage[cur][((tl * 3 + p) * 2 + h) * ROWS + l31];
       }
       LP2_FENCE();
       f32x16 accN;
       unsigned hpN[8], mpN[8];
-      block(a, b[t], true, accN, accP, hpN, mpN, G[q2 % T], buf2, q2 / T, hpP, mpP);
+      block(DO_S ? a : b[t], b[t], DO_S, accN, accP, hpN, mpN, G[q2 % T], cur, tlG, hpP, mpP);
+      if (!DO_S) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accN[r] = -1e30f;
+      }
       accP = accN;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { hpP[e] = hpN[e]; mpP[e] = mpN[e]; }
     }
-    if (more) put(cur ^ 1, pre);
+  };
+  for (int st = 0; st < nst; ++st, cur ^= 1) {
+    fetch(st + 1, pre);                            // (st + 1 == nst: the feature window of the S-less last stage)
+    run_stage(std::true_type{});
+    put(cur ^ 1, pre);
     __syncthreads();
   }
-  {   // drain (cur was flipped once more): block "NB" = vector work of the last block + gradient product of the last-but-one, then the
-      // last block's gradient product with idle vector slots (logits -1e30: coefficients exactly zero)
-    const int last = cur ^ 1;
-    u32x4 a0[3] = {b[0][0], b[0][1], b[0][2]};
-    f32x16 dummy;
-    unsigned hpN[8], mpN[8], hpX[8], mpX[8];
-    block(a0, b[0], false, dummy, accP, hpN, mpN, G[(NB - 2) % T], last, (NB - 2) / T, hpP, mpP);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accP[r] = -1e30f;
-    block(a0, b[0], false, dummy, accP, hpX, mpX, G[(NB - 1) % T], last, (NB - 1) / T, hpN, mpN);
-  }
+  run_stage(std::false_type{});                    // no new logits: the pipeline's last two blocks drain
   // ---- epilogue: lane (anchor l31, half h) holds feature slots (r & 3) + 8 (r >> 2) + 4 h of G^T: r < 8 the plain sums (T1_k, W1 in slot n),
   //      r >= 8 the u_j-weighted ones (T2_k in slot 16 + k, W2 in slot 16 + n) ----
   const int hn = (n >> 2) & 1, rn = (n & 3) + 4 * (n >> 3);      // where slot n lives (slot 16 + n: the same lane, register rn + 8)
@@ -443,7 +500,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 static int g_enabled = -1;      // -1: take CLICA_LP_MFMA (default on); set_enabled overrides it for the process
-void set_enabled(bool on) { g_enabled = on ? 1 : 0; }
+void set_enabled(int on) { g_enabled = on < 0 ? -1 : (on ? 1 : 0); }
 bool applies(int n, float p, int pow) {
   static const int env_on = env_int("CLICA_LP_MFMA", 1);
   const int on = g_enabled >= 0 ? g_enabled : env_on;
@@ -485,14 +542,15 @@ Ws carve(void* base, const Plan& P) {
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
+  hipLaunchKernelGGL(maxabs_k, dim3((unsigned)ceil_div(n_pool + n_own, 256)), dim3(256), 0, st, pool, ldp, n_pool, own, ldo, n_own, n, pool, pre2, w.spread);
   hipLaunchKernelGGL(prep_k, dim3((unsigned)((P.pool_tiles + P.own_tiles) / 2)), dim3(64), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows,
                      (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pool, pre2, w.spread);
 }
 
 void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st) {
   dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
-  if (P.T == 1) hipLaunchKernelGGL(fwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles);
-  else hipLaunchKernelGGL(fwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles);
+  if (P.T == 1) hipLaunchKernelGGL(fwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread);
+  else hipLaunchKernelGGL(fwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread);
 }
 
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,

@@ -771,10 +771,10 @@ class ContrastiveTrainer:
                                                           _lib.stream_ptr()), "clica_lp_loss_train_spread")
         return float(v.value)
 
-    def set_loss_matrix_cores(self, on: bool):
-        """Switch the p = 2 loss sweeps between the matrix cores and the coordinate-difference sweeps (process-wide, see
-        clica_lp_loss_set_matrix_cores); a captured step graph is captured again with the new sweeps."""
-        _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(1 if on else 0), "clica_lp_loss_set_matrix_cores")
+    def set_loss_matrix_cores(self, on):
+        """Switch the p = 2 loss sweeps between the matrix cores (True) and the coordinate-difference sweeps (False); None = back to the
+        environment's setting.  Process-wide (clica_lp_loss_set_matrix_cores); a captured step graph is captured again."""
+        _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(-1 if on is None else (1 if on else 0)), "clica_lp_loss_set_matrix_cores")
         if self.graph is not None:
             self.graph = None
             self.capture()

@@ -132,6 +132,15 @@ def autograd_train_step(h, loss, optimizer, z1, z2, supervised: bool, world: int
 
 
 def main(argv=None):
+    try:
+        return _main(argv)
+    finally:      # the switch to the difference sweeps (below) is process-wide: a caller that runs main() in its own process gets its setting back
+        if torch.cuda.is_available():
+            from . import _lib
+            _lib.load().clica_lp_loss_set_matrix_cores(-1)
+
+
+def _main(argv=None):
     args = parse_args(argv)
     rank, world, device = init_from_env()
     if device.type != "cuda":

@@ -151,7 +151,8 @@ int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* path);
  * was zeroed (0 on the VALU path).  Synchronises `stream`; not for the training loop itself -- call it where the loop reads losses anyway. */
 int clica_lp_loss_train_spread(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* spread,
                                clica_stream_t stream);
-/* Process-wide switch between the matrix-core and the VALU sweeps behind the training pair (overrides CLICA_LP_MFMA).  Takes effect at
+/* Process-wide switch between the matrix-core (1) and the VALU (0) sweeps behind the training pair; negative: back to CLICA_LP_MFMA's
+ * setting.  Takes effect at
  * the next clica_lp_loss_fwd_train call; a workspace sized for the matrix-core path is large enough for the other one; a captured
  * graph keeps the sweeps it was captured with (re-capture).  cl_ica_amd.train_mlp calls it when the spread diagnostic passes 150. */
 int clica_lp_loss_set_matrix_cores(int32_t on);

@@ -331,6 +331,7 @@ def test_loss_matrix_core_switch_and_spread():
     z1 = torch.rand(B, n, device="cuda"); z2 = (z1 + 0.05 * torch.randn_like(z1)).clamp(0, 1)
     tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
     lib, path = _lib.load(), C.c_int32()
+    _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
     try:
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
         out_m = tr.step_injected(z1, z2).clone(); g_m = tr.grad_arena.clone()
@@ -345,4 +346,4 @@ def test_loss_matrix_core_switch_and_spread():
         PARITY.check("loss_matrix_core_switch", f"n={n} B={B}", "means", out_m.cpu().numpy(), out_v.cpu().numpy())
         PARITY.check("loss_matrix_core_switch", f"n={n} B={B}", "gradient arena", g_m.cpu().numpy(), g_v.cpu().numpy())
     finally:
-        _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "restore")
+        _lib.check(lib.clica_lp_loss_set_matrix_cores(-1), "restore")

@@ -467,7 +467,7 @@ def _train_pair(z1, z2, pool, pool_lse, n, p, tau, alpha, compat=1):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,n,tau,space", [(6144, 10, 1.0, "box"), (1000, 3, 0.3, "box"), (333, 14, 1.0, "sphere"), (97, 1, 0.5, "box"),
+@pytest.mark.parametrize("B,n,tau,space", [(6144, 10, 1.0, "box"), (1000, 3, 0.3, "box"), (333, 9, 1.0, "sphere"), (97, 1, 0.5, "box"),
                                            (2048, 10, 0.1, "box"), (4096, 7, 1.0, "far")])
 def test_p2_train_sweeps_on_matrix_cores_vs_oracle(B, n, tau, space):
     """The p = 2 training sweeps on the bf16 matrix cores (csrc/lp_mfma.hip) against the fp64 oracle, single rank (pool = z1): loss
