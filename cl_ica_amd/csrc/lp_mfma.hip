@@ -4,7 +4,7 @@
 //
 // Why this is matrix work.  With x' = sqrt(2 log2(e) / tau) (x - origin) the scaled logit of a pair is
 //     x_ij = -log2(e)/tau |a_i - p_j|^2 = a'_i . p'_j - |a'_i|^2 / 2 - |p'_j|^2 / 2,
-// i.e. ONE inner product of the augmented rows  (a', -|a'|^2/2, 1) . (p', 1, -|p'|^2/2)  -- n + 2 <= 16 feature slots, exactly the K of a
+// i.e. ONE inner product of the augmented rows  (a', -|a'|^2/2, 1) . (p', 1, -|p'|^2/2)  -- n + 6 <= 16 feature slots with the norms in pieces, the K of a
 // v_mfma_f32_32x32x16_bf16 -- and the symmetric backward is
 //     dz_i = 2 sum_j 2^x_ij (u_i + u_j) (a_i - p_j) = (2 / s) [ u_i (a'_i W1_i - T1_i) + (a'_i W2_i - T2_i) ],
 //     W1_i = sum_j e_ij,  T1_i = sum_j e_ij p'_j,  W2_i = sum_j e_ij u_j,  T2_i = sum_j e_ij u_j p'_j,   e_ij = 2^x_ij
@@ -14,16 +14,15 @@
 // their squares / the gradient FMAs; here a pair costs its exponential (v_exp_f32, quarter rate), one add (forward) or the coefficient
 // and a two-piece bf16 split (backward), the rest runs on the matrix pipe next to it.
 //
-// Arithmetic.  Both operands of the logit product are EXACT three-piece bf16 splits (planes.h's scheme: 24 significand bits), six piece
-// products, fp32 accumulation: fp32-equivalent like the encoder GEMMs.  What the expansion costs is cancellation: the three
-// terms are of the size of |x'|^2 / 2 and their sum is the (possibly much smaller) negated scaled squared distance, so the logit carries
-// an ABSOLUTE error of a few 2^-24 max(|a'|^2, |p'|^2) -- which is why the rows are shifted by an origin inside the data (the pool's first
-// row; distances do not change): in a box / on a sphere with tau = 1 the terms are O(1) and the weights 2^x are good to ~1e-6.  The exact-zero
-// self pair (the anchor's own pool row) comes out as 2^(+-1e-7) instead of exactly 1.  The exponential e_ij enters the second product as
-// hi + mid bf16 pieces, both rounded to nearest (relative error <= 2^-18 per pair, unbiased), against three exact pieces of the pool
-// features (u_j p'_j rounded once to fp32, then split exactly): five products.  The W sums come out of the same product (ones / u columns),
-// so the e_ij that weigh a'_i and p'_j are the same numbers and the self pair cancels exactly.  Parity is measured, not assumed: tests/test_gpu_loss.py compares these sweeps with the VALU sweeps and the fp64
-// oracle at the bench sizes; CLICA_LP_MFMA=0 (or CLICA_LP_TRAIN_FAST without bit 2) keeps the VALU sweeps.
+// Arithmetic.  The three terms of the expansion are of the size of M = log2(e)/tau |x - origin|^2 each and their sum is the (possibly much
+// smaller) negated scaled squared distance, and the reference's training lives at M ~ 10^3 (unnormalised encoder outputs).  The large part
+// of every term is therefore computed exactly -- hi pieces on a grid common to the launch, hi x hi in an accumulator of its own, see "planes"
+// below -- and the remainders' seven piece products carry terms of size M / 256; rows are shifted by an origin inside the data (the pool's
+// first row; distances do not change).  The exponential e_ij enters the second product as hi + mid bf16 pieces, both rounded to nearest
+// (relative error <= 2^-18 per pair, unbiased), against three exact pieces of the pool features (u_j p'_j rounded once to fp32, then split
+// exactly): five products.  The W sums come out of the same product (ones / u columns), so the e_ij that weigh a'_i and p'_j are the same
+// numbers and the self pair cancels exactly.  Parity is measured, not assumed: tests/test_gpu_loss.py compares these sweeps with the fp64
+// oracle at the bench sizes and over spreads up to M = 15 000; CLICA_LP_MFMA=0 (or CLICA_LP_TRAIN_FAST without bit 2) keeps the VALU sweeps.
 //
 // Layout.  A prep launch writes the planes once per step, already in MFMA operand order, so staging is a linear copy and an operand is
 // one 16-byte LDS read:  row planes [tile of 32 rows][piece][k half][row] x 8 bf16 (operand of the logit product, for the anchors and
@@ -71,13 +70,15 @@ __device__ __forceinline__ f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 #endif
 }
-// the six piece products of order <= 2: five in one accumulator (terms of size M / 128), hi x hi -- exact, see the planes -- in its own
+// eight piece products: hi x hi -- exact, see the planes -- in an accumulator of its own, the other seven (all but lo x lo) in a second one
 __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (&b)[3]) {
   f32x16 acc, acch;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acch[r] = 0.f; }
-  acc = mfma(a[2], b[0], acc);
+  acc = mfma(a[2], b[1], acc);
   acch = mfma(a[0], b[0], acch);
+  acc = mfma(a[1], b[2], acc);
+  acc = mfma(a[2], b[0], acc);
   acc = mfma(a[0], b[2], acc);
   acc = mfma(a[1], b[1], acc);
   acc = mfma(a[1], b[0], acc);
@@ -90,11 +91,12 @@ __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (
 // logit, and an fp32 accumulator that has held a number of size M carries 2^-24 M of rounding -- 6e-5 of relative error in the weights at
 // M = 1000, which is where the reference's own training lives (unnormalised encoder outputs grow to a standard deviation of ~10 within a
 // thousand steps of main_mlp.py's defaults).  So the LARGE part is made exact: the hi piece of every coordinate is a multiple of one grid
-// step D = 2^e for the whole launch (|x'| / D < 128 from the step's own max |x'|, maxabs_k), its half norm Nh = sum hi^2 / 2 goes into
+// step D = 2^e for the whole launch (|x'| / D < 256 from the step's own max |x'|, maxabs_k), its half norm Nh = sum hi^2 / 2 goes into
 // three slots of the hi plane as an exact three-piece split, and the hi x hi product runs into an accumulator of its own: every partial
 // sum is an integer multiple of D^2 / 2 below 2^24 of them, i.e. exact, and the result -|hi_a - hi_p|^2 / 2 is small wherever the pair
-// matters.  The other five piece products carry terms of size M / 128 (remainders r = x' - hi, |r| <= D / 2, and the remainder norms
-// Nr = sum (hi r + r^2 / 2)) in a second accumulator; the two are added on the vector ALU.  Measured: section "spread" of the tests.
+// matters.  The other SEVEN piece products (hi / mid / lo against each other except lo x lo: the remainder r = x' - hi, |r| <= D / 2, is not
+// small against hi the way a plain split's second piece is, so mid x lo counts) carry terms of size M / 256 and the remainder norms
+// Nr = sum (hi r + r^2 / 2) in a second accumulator; the two are added on the vector ALU.  Measured: section "spread" of the tests.
 // Slots (K = 16 = n + 6, n <= 10): coordinates 0..n-1; pool rows: ones at n..n+2, own norms at n+3..n+5; anchors the other way round;
 // own norm slots: hi plane = the three pieces of -Nh, mid plane = the three pieces of -Nr; rows >= `rows` of the pool: -Nr = -1e30.
 __global__ __launch_bounds__(256) void maxabs_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, const float* __restrict__ Xa, int64_t lda,
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
   const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * 2 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
   // grid step: the power of two with max |x'| / D in [64, 128)
   const unsigned xb = __float_as_uint(words[1]);
-  const int ex = (int)((xb >> 23) & 0xffu) - 6;
+  const int ex = (int)((xb >> 23) & 0xffu) - 7;      // biased exponent of max |x'|, minus 7: max / D in [128, 256), hi = 8-bit integers x D
   const float D = __uint_as_float((unsigned)(ex < 1 ? 1 : ex) << 23), invD = 1.f / D;
   const int64_t j = (int64_t)tile * ROWS + lane;
   const bool live = j < rows;
@@ -138,9 +140,13 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
     const float r = x - hi;
     const unsigned mbits = __float_as_uint(r) & 0xffff0000u;
     const float r2 = r - __uint_as_float(mbits);
-    hb[k] = __float_as_uint(hi) >> 16; mb[k] = mbits >> 16; lb[k] = __float_as_uint(r2) >> 16;
+    const unsigned lbits = __float_as_uint(r2) & 0xffff0000u;
+    hb[k] = __float_as_uint(hi) >> 16; mb[k] = mbits >> 16; lb[k] = lbits >> 16;
+    // the remainder as the product sees it (16 bits: what is cut off is below 2^-24 of the launch's largest coordinate); the norm must be
+    // the norm of THESE numbers, or hi x (cut-off part) -- 5e-5 at M = 900 -- stays in every logit, the self pair's included
+    const float r16 = __uint_as_float(mbits) + __uint_as_float(lbits);
     nh = fmaf(hi, hi, nh);
-    nr += fmaf(hi, r, 0.5f * r * r);
+    nr += fmaf(hi, r16, 0.5f * r16 * r16);
   }
   nh *= 0.5f;
   if (role == 0) {      // diagnostic: the largest M of the pool so far
@@ -375,7 +381,8 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
       for (int p = 0; p < 3; ++p) fa[tt][p] = stage[bufG][RV + (((tlG * 3 + p) * 2 + tt) * 2 + h) * 32 + l31];
     const u32x4 bh0 = {hpG[0], hpG[1], hpG[2], hpG[3]}, bm0 = {mpG[0], mpG[1], mpG[2], mpG[3]};
     const u32x4 bh1 = {hpG[4], hpG[5], hpG[6], hpG[7]}, bm1 = {mpG[4], mpG[5], mpG[6], mpG[7]};
-    constexpr int SA[6] = {2, 0, 1, 1, 0, 0}, SB[6] = {0, 2, 1, 0, 1, 0};        // logit piece products, small ones first
+    constexpr int NS = 8;
+    constexpr int SA[NS] = {2, 0, 1, 2, 0, 1, 1, 0}, SB[NS] = {1, 0, 2, 0, 2, 1, 0, 1};        // logit piece products ((hi, hi) second: its own accumulator)
 #ifndef LP2_GPROD
 #define LP2_GPROD 5      // piece products of the gradient per K = 16 half: 5 = (mid, mid), (hi, mid), (lo, hi), (mid, hi), (hi, hi); 4 = without (mid, mid):
                          // measured -6 % sweep time, but the gradient at tau = 0.1 goes from 3e-6 to 1.2e-5 against the oracle -- not taken
@@ -399,18 +406,18 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 #pragma unroll
       for (int r = 0; r < 16; ++r) { accN[r] = 0.f; accH[r] = 0.f; }
     }
+    // MFMA list of a block: S0 G0 S1 G1 .. S7 G7 G8 G9 (two independent chains alternating); step e issues entries 2e and 2e + 1, the
+    // last two steps one more each
+    auto sstep = [&](int i) {
+      if (!do_s) return;
+      if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 1 : 0);
+      if (SA[i] == 0 && SB[i] == 0) { accH = mfma(a[0], bt[0], accH); LP2_PIN1(accH); }
+      else { accN = mfma(a[SA[i]], bt[SB[i]], accN); LP2_PIN1(accN); }
+      if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1);
+    };
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      // first MFMA of the step
-      if (e < 6) {
-        if (do_s) {
-          if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 1 : 0);
-          if (SA[e] == 0 && SB[e] == 0) { accH = mfma(a[0], bt[0], accH); LP2_PIN1(accH); }
-          else { accN = mfma(a[SA[e]], bt[SB[e]], accN); LP2_PIN1(accN); }
-          if (LP2_PRIO) __builtin_amdgcn_s_setprio(LP2_PRIO == 1 ? 0 : 1);
-        }
-      }
-      else gstep(6 + 2 * (e - 6));
+      sstep(e);
 #if LP2_ABLATE & 2
       float e0 = accV[2 * e], e1 = accV[2 * e + 1];
 #else
@@ -418,8 +425,8 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 #endif
       LP2_PIN1(e0); LP2_PIN1(e1);
       LP2_FENCE();
-      // second MFMA
-      if (e < 6) gstep(e); else gstep(7 + 2 * (e - 6));
+      gstep(e);
+      if (e >= 6) gstep(8 + (e - 6));
 #if LP2_ABLATE & 2
       hpN[e] = __float_as_uint(e0);
       mpN[e] = __float_as_uint(e1);

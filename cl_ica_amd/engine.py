@@ -762,7 +762,7 @@ class ContrastiveTrainer:
 
     def loss_spread(self) -> float:
         """M = log2(e)/tau max_i |y_i - y_0|^2 of the largest embedding cloud the p = 2 matrix-core loss sweeps have seen in this
-        trainer (0 on the VALU sweeps): their logit error scales with it (include/clica.h: 1e-5 from M ~ 200).  Host read + sync -- for
+        trainer (0 on the VALU sweeps): their logit error scales with it (include/clica.h).  Host read + sync -- for
         log points, not for the step."""
         if not self.loss_train:
             return 0.0

@@ -222,10 +222,10 @@ def _main(argv=None):
                     f"Lin. Disentanglement: {lin:.4f} \t", f"Perm. Disentanglement: {perm:.4f}")
                 if args.sphere_norm:
                     log(f"r: {f[-1].r}")
-                if fused and not getattr(trainer, "_spread_handled", False) and trainer.loss_spread() > 150.0:
+                if fused and not getattr(trainer, "_spread_handled", False) and trainer.loss_spread() > 20000.0:
                     trainer._spread_handled = True
                     log(f"note: the embeddings spread over M = {trainer.loss_spread():.0f} temperature units (the p = 2 matrix-core loss sweeps "
-                        "hold 1e-5 up to M ~ 200, include/clica.h): switching to the coordinate-difference sweeps")
+                        "hold 1e-5 in the loss at any spread and in the gradient up to M ~ 10^3-10^4, include/clica.h): switching to the coordinate-difference sweeps")
                     trainer.set_loss_matrix_cores(False)
             lin_scores.append(lin); perm_scores.append(perm)
             global_step += 1

@@ -135,14 +135,15 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * sums 2^x without a running maximum and the backward folds the row statistics into one factor per row (one exponential per pair).
  * For negatives that do not include the anchors use clica_lp_loss_fwd / clica_lp_loss_bwd.  CLICA_LP_TRAIN_FAST=0 restores the
  * general-purpose sweeps behind these entry points (A/B switch).
- * p = 2, pow, n <= 14 (BASELINE config 2: main_mlp.py defaults): the two pair sweeps run on the bf16 matrix cores (csrc/lp_mfma.hip:
- * logit = one augmented inner product of exact 3-piece bf16 splits, gradient = a second product against the pool) and z1 / pool
- * must additionally be UNCHANGED between the two calls (fwd_train leaves their operand planes in the workspace).  The expansion
- * |a|^2 + |b|^2 - 2ab behind it carries an absolute logit error of a few 2^-24 M, M = log2(e)/tau max_i |z_i - z_0|^2 (the size of the
- * expansion's terms; rows are shifted by the pool's first row).  Measured against the fp64 oracle (tests/test_gpu_loss.py,
- * ..._spread_limit): loss / gradient error 2e-7 / 6e-7 at M = 14 (unit box, n = 10, tau = 1), 3e-6 at M = 60 (tau = 0.1), 1e-5 at M = 230,
- * 6e-5 at M = 920.  The reference's spaces (box [0, 1]^n, unit sphere; tau >= 0.1) stay below M = 80; data spread over more than ~10
- * temperature-lengths should set CLICA_LP_MFMA=0 (VALU sweeps on coordinate differences, no such dependence).
+ * p = 2, pow, n <= 10 (BASELINE config 2: main_mlp.py defaults): the two pair sweeps run on the bf16 matrix cores (csrc/lp_mfma.hip:
+ * logit = one augmented inner product of bf16 pieces, gradient = a second product against the pool) and z1 / pool must additionally be
+ * UNCHANGED between the two calls (fwd_train leaves their operand planes in the workspace).  The expansion |a|^2 + |b|^2 - 2ab behind
+ * it has terms of size M = log2(e)/tau max_i |z_i - z_0|^2 (rows are shifted by the pool's first row) -- M ~ 10^3 in the reference's own
+ * training, whose unnormalised embeddings spread to a standard deviation of ~10.  The large part of every term is therefore computed
+ * EXACTLY (hi pieces on a grid common to the launch, accumulated apart), and the loss holds 1e-5 at every spread measured (2e-6 at
+ * M = 15 000, tests/test_gpu_loss.py ..._spread_limit); the gradient is held to 1e-5 up to M ~ 10^3 on saturated clouds (1.4e-5 at
+ * M = 3 700, 2.8e-5 at 15 000) and agrees with the difference sweeps to 1e-6 on the embeddings of a training run.
+ * CLICA_LP_MFMA=0 / clica_lp_loss_set_matrix_cores select the VALU sweeps on coordinate differences (no such dependence).
  * clica_lp_loss_train_path reports the choice:
  * *path = 1 matrix cores, 0 VALU sweeps. */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);

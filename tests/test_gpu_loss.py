@@ -505,15 +505,17 @@ def test_p2_train_sweeps_on_matrix_cores_vs_oracle(B, n, tau, space):
 
 @pytest.mark.gpu
 def test_p2_train_sweeps_on_matrix_cores_spread_limit():
-    """The stated limit of the matrix-core sweeps (include/clica.h): the expansion's absolute logit error grows with
-    M = log2(e)/tau max_i |z_i - z_0|^2.  Box clouds of growing edge length at tau = 1, against the fp64 oracle: the error must stay
-    under 1e-5 through the reference's regimes (edge <= 2: M <= 60) and is LOGGED beyond (edge 4, 8: M up to 1000), where
-    CLICA_LP_MFMA=0 is the documented setting -- the log is what keeps the header's statement honest."""
+    """What the expansion behind the matrix-core sweeps costs as the embeddings spread out, M = log2(e)/tau max_i |z_i - z_0|^2 (the size of
+    its terms).  Box clouds of growing edge length at tau = 1 (M = 14 ... 15 000; the reference's own training sits at M ~ 10^3: unnormalised
+    encoder outputs), against the fp64 oracle.  The logits are exact in their large part (hi pieces on a common grid, own accumulator), so
+    the LOSS holds 1e-5 at every size; the gradient's second product accumulates terms of size |x'| and is held to 1e-5 up to
+    M ~ 10^3 and LOGGED beyond (1.4e-5 at M = 3 700, 2.8e-5 at M = 15 000 on these saturated clouds; 1e-6 against the difference sweeps on
+    embeddings of a training run at M ~ 3 500)."""
     B, n, tau, alpha = 2048, 10, 1.0, 0.5
     rng = np.random.default_rng(5)
     base = rng.random((B, n)); noise = 0.05 * rng.normal(size=(B, n))
     worst = {}
-    for edge in (1.0, 2.0, 4.0, 8.0):
+    for edge in (1.0, 2.0, 4.0, 8.0, 16.0, 32.0):
         z = (edge * base).astype(np.float32); zt = (edge * base + noise).astype(np.float32)
         o, dz, path = _train_pair(dev(z), dev(zt), dev(z), None, n, 2, tau, alpha)
         assert path == 1
@@ -522,11 +524,11 @@ def test_p2_train_sweeps_on_matrix_cores_spread_limit():
         e_l = rel_err(o.cpu().numpy()[:B], orc["loss_i"]); e_g = rel_err(dz[:B].cpu().numpy(), g1)
         worst[edge] = (e_l, e_g)
         M = 1.4427 / tau * float(((z - z[0]) ** 2).sum(1).max())
-        fam = "p2_train_matrix_cores" if edge <= 2.0 else "p2_train_matrix_cores_beyond_stated_range"
-        PARITY.check(fam, f"box edge {edge} (M = {M:.0f})", "loss_i", o.cpu().numpy()[:B], orc["loss_i"], tol=1e-5 if edge <= 2.0 else 1e-3,
-                     note=None if edge <= 2.0 else "beyond the stated range of the matrix-core sweeps (logged, CLICA_LP_MFMA=0 there)")
-        PARITY.check(fam, f"box edge {edge} (M = {M:.0f})", "dz1", dz[:B].cpu().numpy(), g1, tol=1e-5 if edge <= 2.0 else 1e-3,
-                     note=None if edge <= 2.0 else "beyond the stated range of the matrix-core sweeps (logged, CLICA_LP_MFMA=0 there)")
+        PARITY.check("p2_train_matrix_cores", f"box edge {edge} (M = {M:.0f})", "loss_i", o.cpu().numpy()[:B], orc["loss_i"])
+        wide = edge > 8.0
+        PARITY.check("p2_train_matrix_cores_gradient_beyond_M_1000" if wide else "p2_train_matrix_cores", f"box edge {edge} (M = {M:.0f})", "dz1",
+                     dz[:B].cpu().numpy(), g1, tol=1e-4 if wide else 1e-5,
+                     note="gradient of saturated clouds beyond M ~ 10^3 (logged; the second product's accumulation of terms of size |x'|)" if wide else None)
     print("matrix-core sweep error by box edge (loss_i, dz1):", worst)
     # the diagnostic the training loop prints from: the largest M a workspace has seen
     import ctypes as C
