@@ -1,5 +1,7 @@
 """Fused train step (engine) against the reference's injected-step trajectory (G7), the autograd
 drop-in path, and HIP-graph replay."""
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -345,5 +347,45 @@ def test_loss_matrix_core_switch_and_spread():
         out_v = tr.step_injected(z1, z2).clone(); g_v = tr.grad_arena.clone()
         PARITY.check("loss_matrix_core_switch", f"n={n} B={B}", "means", out_m.cpu().numpy(), out_v.cpu().numpy())
         PARITY.check("loss_matrix_core_switch", f"n={n} B={B}", "gradient arena", g_m.cpu().numpy(), g_v.cpu().numpy())
+    finally:
+        _lib.check(lib.clica_lp_loss_set_matrix_cores(-1), "restore")
+
+
+def test_matrix_core_loss_on_training_embeddings():
+    """Parity of the p = 2 matrix-core loss sweeps WHERE THE BENCH RUNS: main_mlp.py's unnormalised encoder spreads its outputs to a
+    standard deviation of ~10 within a few hundred steps (M = log2(e)/tau max |y - y_0|^2 in the thousands, where a plain
+    |a|^2 + |b|^2 - 2ab expansion in fp32 is off by 1e-4).  The headline trainer after 60 / 300 / 1000 of its own steps: loss, row statistics
+    and d loss / d y of the matrix-core sweeps against the coordinate-difference sweeps on the same embeddings, 1e-5."""
+    import ctypes as C
+    import bench
+    from cl_ica_amd import _lib
+    argv, sys.argv = sys.argv, [sys.argv[0]]
+    try:
+        args = bench.parse()
+    finally:
+        sys.argv = argv
+    tr = bench.build_trainer(args, torch.device("cuda"), 1)
+    lib, path = _lib.load(), C.c_int32()
+    _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
+    try:
+        _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
+        B = tr.B
+        for k in (60, 300, 1000):
+            while tr.steps_done < k:
+                tr.step()
+            tr.sample(); tr.forward()
+            res = {}
+            for mode in (1, 0):
+                _lib.check(lib.clica_lp_loss_set_matrix_cores(mode), "switch")
+                tr.loss_forward_backward()
+                torch.cuda.synchronize()
+                res[mode] = (tr.dy.clone(), tr.loss_out.clone())
+                if mode == 1:
+                    spread = tr.loss_spread()
+            _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
+            case = f"after {k} steps (y std {float(tr.y.std()):.2f}, M = {spread:.0f})"
+            PARITY.check("matrix_core_loss_training_regime", case, "loss_i", res[1][1][:B].cpu().numpy(), res[0][1][:B].cpu().numpy(), note="HIP vs HIP")
+            PARITY.check("matrix_core_loss_training_regime", case, "lse_i", res[1][1][2 * B:3 * B].cpu().numpy(), res[0][1][2 * B:3 * B].cpu().numpy())
+            PARITY.check("matrix_core_loss_training_regime", case, "d loss / d y", res[1][0].cpu().numpy(), res[0][0].cpu().numpy())
     finally:
         _lib.check(lib.clica_lp_loss_set_matrix_cores(-1), "restore")
