@@ -746,8 +746,10 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
         def step():
             return S.train_iteration(x)
         n_params = sum(p.numel() for p in S.net.parameters())
-        work = ("kitti_masks Solver.train body (solver.py:61-74): BetaVAE_H conv encoder (MIOpen) on (2048, 1, 64, 64) binary masks = 1024 "
-                "pairs -> HIP Linear(256, 5) / Softclip -> strided views -> HIP LpSimCLRLoss(p = 1) -> backward -> flat HIP Adam")
+        conv_path = ("MIOpen via nn.Conv2d (CLICA_CONV=miopen)" if os.environ.get("CLICA_CONV", "hip") == "miopen"
+                     else "HIP implicit-GEMM stages, clica_conv_* (CLICA_CONV=miopen selects nn.Conv2d)")
+        work = ("kitti_masks Solver.train body (solver.py:61-74): BetaVAE_H conv encoder (%s) on (2048, 1, 64, 64) binary masks = 1024 "
+                "pairs -> HIP Linear(256, 5) / Softclip -> strided views -> HIP LpSimCLRLoss(p = 1) -> backward -> flat HIP Adam" % conv_path)
     for _ in range(warmup):
         last = step()
     torch.cuda.synchronize(device)
@@ -763,7 +765,7 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
     el = float(np.median(ws))
     return {"workload": work, "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": windows,
             "images_per_s": round((2048 if which == "c5" else 2048) * steps / el, 1), "parameters": int(n_params), "dtype": "f32",
-            "final_loss": float(last.item()), "launch": "eager (torch autograd drives MIOpen and the HIP library)",
+            "final_loss": float(last.item()), "launch": "eager (torch autograd drives the HIP library%s)" % (" and MIOpen" if which == "c4" or os.environ.get("CLICA_CONV", "hip") == "miopen" else ""),
             "kernel_shares": "profiles/r4_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % (which, which)}
 
 

@@ -1,0 +1,190 @@
+"""Conv stack of the KITTI-masks encoder on the HIP library (``clica_conv_*``, csrc/linear.hip, conv section).
+
+Replaces the five ``nn.Conv2d(k = 4) + ReLU`` stages of ``BetaVAE_H`` (/root/reference/kitti_masks/model.py:41-56) -- forward,
+data gradients, weight and bias gradients -- for (images, nc, 64, 64) inputs: four implicit-GEMM stride-2 stages that hand
+their output to the next stage as its padded space-to-depth tensor (channels-last, no NCHW <-> NHWC copies, bias + ReLU in the
+GEMM epilogue, ReLU gate in the data-gradient epilogue) and the k = 4 stage on the 4 x 4 map as ``clica_linear_*`` over the
+flattened map.  The ``nn.Conv2d`` modules stay the owners of the parameters (state dict = the reference's); per call the
+weights are re-ordered into the GEMM layouts (a few tiny copies) and the gradients come back in ``Conv2d.weight`` layout.
+
+``conv_stack(x, w1, b1, ..., w5, b5) -> (images, 256)`` is one autograd node.  The activations it saves live in a per-shape
+buffer set that is zeroed once (borders / non-output rows are never written) and handed back by the backward pass.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import ops
+from ._lib import check, load, ptr, stream_ptr, workspace
+
+__all__ = ["conv_stack", "STAGES"]
+
+# (out_channels, spatial size of the output) of the four stride-2 stages for a 64 x 64 input; the fifth stage maps the
+# 4 x 4 x 64 map to 256 features
+STAGES = ((32, 32), (32, 16), (64, 8), (64, 4))
+_FEATURES = 256
+_IMAGE = 64
+
+
+class _Buffers:
+    """Activations / gradients of one in-flight forward-backward pair for a given (images, nc, device)."""
+
+    def __init__(self, images: int, nc: int, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.images, self.nc = images, nc
+        self.patches = torch.empty((images * 32 * 32, 16 * nc), **f32)
+        self.S: Dict[int, torch.Tensor] = {}        # stage index (1..3) -> its space-to-depth INPUT, flat, zero tail
+        self.dO: Dict[int, torch.Tensor] = {}       # stage index (0..3) -> gradient of its pre-activation output on its row grid
+        self._dO_store: Dict[int, torch.Tensor] = {}
+        cin = nc
+        for l, (cout, ho) in enumerate(STAGES):
+            if l >= 1:
+                hs = STAGES[l - 1][1] // 2 + 1
+                self.S[l] = torch.zeros(images * hs * hs * 4 * cin + (hs + 2) * 4 * cin, **f32)
+                front = (hs + 1) * cout
+                store = torch.zeros(front + images * hs * hs * cout, **f32)
+                self._dO_store[l] = store
+                self.dO[l] = store[front:]
+            else:
+                self.dO[0] = torch.empty(images * ho * ho * cout, **f32)
+            cin = cout
+        self.O4 = torch.empty((images, 5 * 5 * 64), **f32)     # last stride-2 stage's output on its 5 x 5 row grid
+        # first stage's weight gradient: the small-matrix streaming kernel where its shape fits (nc = 1), the grouped GEMM path otherwise
+        self.ws1 = self.ws1p = None
+        if 256 % ((STAGES[0][0] // 4) * (16 * nc // 4)) == 0:
+            nbytes = C.c_size_t()
+            check(load().clica_conv_k4s2_wgrad_patches_workspace_bytes(images * 32 * 32, STAGES[0][0], 16 * nc, C.byref(nbytes)),
+                  "clica_conv_k4s2_wgrad_patches_workspace_bytes")
+            self.ws1p = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
+        else:
+            self.ws1 = ops.mlp_wgrad_workspace(images * 32 * 32, [(STAGES[0][0], 16 * nc)], device)
+
+
+_POOL: Dict[Tuple, List[_Buffers]] = {}
+
+
+def _take(images: int, nc: int, device) -> _Buffers:
+    free = _POOL.setdefault((images, nc, device.index), [])
+    return free.pop() if free else _Buffers(images, nc, device)
+
+
+def _give(buf: _Buffers, device) -> None:
+    free = _POOL.setdefault((buf.images, buf.nc, device.index), [])
+    if len(free) < 2:
+        free.append(buf)
+
+
+def _wg(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d weight [co][c][ky][kx] -> GEMM rows [co][(dy, dx, py, px, c)], ky = 2 dy + py, kx = 2 dx + px."""
+    co, c = w.shape[:2]
+    return w.detach().view(co, c, 2, 2, 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(co, 16 * c)
+
+
+def _wd(w: torch.Tensor) -> torch.Tensor:
+    """Conv2d weight -> data-gradient operand [(1 - dy, 1 - dx, co)][(py, px, c)]."""
+    co, c = w.shape[:2]
+    return w.detach().view(co, c, 2, 2, 2, 2).flip(2, 4).permute(2, 4, 0, 3, 5, 1).reshape(4 * co, 4 * c)
+
+
+def _wg_to_conv(dwg: torch.Tensor, co: int, c: int) -> torch.Tensor:
+    return dwg.view(co, 2, 2, 2, 2, c).permute(0, 5, 1, 3, 2, 4).reshape(co, c, 4, 4)
+
+
+def _w5(w: torch.Tensor) -> torch.Tensor:
+    """[256][64][4][4] -> [256][(y, x, c) over the 5 x 5 row grid of the stage in front], zero columns for the non-output rows."""
+    g = w.detach().permute(0, 2, 3, 1)
+    return torch.nn.functional.pad(g, (0, 0, 0, 1, 0, 1)).reshape(w.shape[0], 5 * 5 * w.shape[1])
+
+
+class _ConvStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, keep, *params):
+        lib, st = load(), stream_ptr()
+        ws_, bs_ = params[0::2], params[1::2]
+        images, nc = x.shape[0], x.shape[1]
+        dev = x.device
+        buf = _take(images, nc, dev)
+        x = x.detach().contiguous()
+        check(lib.clica_conv_im2col_k4s2(x.data_ptr(), images, nc, _IMAGE, _IMAGE, buf.patches.data_ptr(), st), "clica_conv_im2col_k4s2")
+        w1g = ws_[0].detach().permute(0, 2, 3, 1).reshape(STAGES[0][0], 16 * nc)
+        check(lib.clica_conv_k4s2_fwd_patches(buf.patches.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
+                                              32, 32, 1, 1, buf.S[1].data_ptr(), st), "clica_conv_k4s2_fwd_patches")
+        cin = STAGES[0][0]
+        for l in (1, 2, 3):
+            cout, ho = STAGES[l]
+            hs = ho + 1
+            out = buf.S[l + 1] if l < 3 else buf.O4
+            check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), _wg(ws_[l]).data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
+                                          1, 1 if l < 3 else 0, out.data_ptr(), st), "clica_conv_k4s2_fwd")
+            cin = cout
+        w5g = _w5(ws_[4])
+        feats = torch.empty((images, _FEATURES), dtype=torch.float32, device=dev)
+        check(lib.clica_conv_k4s2_fwd_patches(buf.O4.data_ptr(), w5g.data_ptr(), ptr(bs_[4].detach()), images, 5 * 5 * 64, _FEATURES, 1, 1, 1, 0,
+                                              feats.data_ptr(), st), "clica_conv_k4s2_fwd_patches")
+        if keep:
+            ctx.buf, ctx.w5g, ctx.nc = buf, w5g, nc
+            ctx.save_for_backward(feats, *ws_)
+        else:
+            _give(buf, dev)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        lib, st = load(), stream_ptr()
+        feats, *ws_ = ctx.saved_tensors
+        buf, nc = ctx.buf, ctx.nc
+        if buf is None:
+            raise RuntimeError("conv_stack: backward called twice (the saved activations were handed back to the pool)")
+        ctx.buf = None
+        images, dev = buf.images, feats.device
+        grads: List = [None] * 10
+        dpre = ops.leaky_relu_bwd(feats, dfeats.contiguous(), slope=0.0)
+        dw5g, db5 = ops.linear_wgrad(dpre, buf.O4)
+        grads[8] = dw5g.view(_FEATURES, 5, 5, 64)[:, :4, :4, :].permute(0, 3, 1, 2).contiguous()
+        grads[9] = db5
+        ops.linear_dgrad(dpre, ctx.w5g, buf.O4, slope=0.0, out=buf.dO[3].view(images, 5 * 5 * 64))
+        for l in (3, 2, 1):
+            cout, ho = STAGES[l]
+            cin, hs = STAGES[l - 1][0], ho + 1
+            nbytes = C.c_size_t()
+            check(lib.clica_conv_k4s2_wgrad_workspace_bytes(images * hs * hs, cout, 16 * cin, C.byref(nbytes)), "clica_conv_k4s2_wgrad_workspace_bytes")
+            wsp = workspace("conv_wgrad", nbytes.value, dev)
+            dwg = torch.empty((cout, 16 * cin), dtype=torch.float32, device=dev)
+            db = torch.empty((cout,), dtype=torch.float32, device=dev)
+            check(lib.clica_conv_k4s2_wgrad(buf.dO[l].data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs, dwg.data_ptr(), db.data_ptr(),
+                                            0, wsp.data_ptr(), wsp.numel(), st), "clica_conv_k4s2_wgrad")
+            grads[2 * l], grads[2 * l + 1] = _wg_to_conv(dwg, cout, cin), db
+            dgrid = STAGES[l - 1][1] + (1 if l > 1 else 0)          # previous stage's row grid (the first stage's is its 32 x 32 output)
+            check(lib.clica_conv_k4s2_dgrad(buf.dO[l].data_ptr(), _wd(ws_[l]).data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs,
+                                            buf.dO[l - 1].data_ptr(), dgrid, dgrid, st), "clica_conv_k4s2_dgrad")
+        cout = STAGES[0][0]
+        dw1g = torch.empty((cout, 16 * nc), dtype=torch.float32, device=dev)
+        db1 = torch.empty((cout,), dtype=torch.float32, device=dev)
+        if buf.ws1p is not None:
+            check(lib.clica_conv_k4s2_wgrad_patches(buf.dO[0].data_ptr(), buf.patches.data_ptr(), images * 32 * 32, cout, 16 * nc, dw1g.data_ptr(),
+                                                    db1.data_ptr(), 0, buf.ws1p.data_ptr(), buf.ws1p.numel(), st), "clica_conv_k4s2_wgrad_patches")
+        else:
+            ops.mlp_wgrad([buf.dO[0].view(-1, cout)], [buf.patches], [dw1g], [db1], ws=buf.ws1)
+        grads[0], grads[1] = dw1g.view(cout, 4, 4, nc).permute(0, 3, 1, 2).contiguous(), db1
+        _give(buf, dev)
+        return (None, None, *grads)
+
+
+def conv_stack(x: torch.Tensor, convs) -> torch.Tensor:
+    """``convs`` = the five ``nn.Conv2d`` modules of ``BetaVAE_H.encoder``; ``x`` = (images, nc, 64, 64) float32 on the GPU."""
+    if x.dim() != 4 or x.shape[2] != _IMAGE or x.shape[3] != _IMAGE:
+        raise ValueError(f"conv_stack: input must be (images, nc, {_IMAGE}, {_IMAGE}), got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise TypeError(f"conv_stack: float32 input expected, got {x.dtype}")
+    params = []
+    for m in convs:
+        if m.bias is None:
+            raise ValueError("conv_stack: Conv2d stages without bias are not supported")
+        params += [m.weight, m.bias]
+    # `keep`: a backward pass may follow (forward() itself always runs with grad mode off, so it cannot tell); without one the
+    # buffer set goes straight back to the pool
+    keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    return _ConvStackFn.apply(x, keep, *params)

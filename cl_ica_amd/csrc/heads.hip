@@ -147,7 +147,8 @@ extern "C" int clica_leaky_relu_fwd(const float* X, int64_t ldx, float* Y, int64
 extern "C" int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_t lddy, float* dX, int64_t lddx,
                                     int64_t M, int32_t n, float slope, clica_stream_t stream) {
   CLICA_CHECK_ARG(Yact && dY && dX && M > 0 && n > 0 && ldy >= n && lddy >= n && lddx >= n, "clica_leaky_relu_bwd: bad argument");
-  CLICA_CHECK_ARG(slope > 0.f, "clica_leaky_relu_bwd: slope=%g must be > 0 (the backward recovers the sign from the output)", slope);
+  // slope = 0 is ReLU: its output is > 0 exactly where its derivative is 1, so the saved output still carries the gate
+  CLICA_CHECK_ARG(slope >= 0.f, "clica_leaky_relu_bwd: slope=%g must be >= 0 (the backward recovers the gate from the output)", slope);
   hipLaunchKernelGGL(leaky_bwd_k, dim3((unsigned)ceil_div(M * n, THREADS)), dim3(THREADS), 0, as_stream(stream), Yact, ldy, dY, lddy, dX, lddx, M, n, slope);
   return launch_status("clica_leaky_relu_bwd");
 }

@@ -43,6 +43,19 @@ __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0
 // {1, 0, 0, 0}: the first padding column of the wgrad B operand reads this, so the MFMAs produce db = dZ^T 1 there
 __device__ __attribute__((aligned(16))) float g_one_page[4] = {1.f, 0.f, 0.f, 0.f};
 
+// Implicit-GEMM view of the k = 4, stride-2, pad-1 convolutions of BetaVAE_H (conv section at the end of this file): operand
+// segments for the loaders and the row <-> pixel geometry the two scattering epilogues need.
+struct ConvX {
+  int64_t a_seg, a_jump;     // A operand (see Tile::load)
+  int64_t b_seg, b_jump;     // B operand
+  int mode;                  // 0: rows are stored as they are; 1: forward scatter into the next layer's space-to-depth
+                             // tensor; 2: data-gradient scatter back into the previous layer's output-gradient pixels
+  int hs, ws, ho, wo;        // GEMM row r = (image * hs + y) * ws + x; mode 1 stores rows with y < ho and x < wo only
+  int dhs, dws, dho, dwo;    // destination pixel grid (rows of dhs x dws per image, valid dho x dwo)
+  int c;                     // channels per pixel of the scattered tensor: mode 1 = N, mode 2 = N / 4
+  float inv_pix, inv_ws;     // 1 / (hs * ws), 1 / ws for the epilogues' row -> pixel arithmetic (rows < 2^24)
+};
+
 // ---- tile loaders: global -> registers ------------------------------------------------------
 // CONTIG: operand stored [rows][Kc]; tile = ROWS x BK, float4 along k.
 // !CONTIG: operand stored [Kc][rows]; tile = BK x ROWS, float4 along rows.
@@ -59,7 +72,11 @@ struct Tile {
   // contraction/row extent that is a multiple of 4 (every float4 is then fully in or fully out).
   template <bool VEC>
   static __device__ __forceinline__ void load(float4 (&r)[PER_THREAD], const float* __restrict__ src, int64_t ld,
-                                              int64_t row0, int64_t nrows, int64_t k0, int64_t kend) {
+                                              int64_t row0, int64_t nrows, int64_t k0, int64_t kend,
+                                              const int64_t seg = 0, const int64_t jump = 0) {
+    // (seg, jump): two-segment operand of the implicit-GEMM convolutions (conv section below) -- the index along the float4
+    // direction (k when CONTIG, the row index otherwise) continues `jump` elements further on once it reaches `seg`
+    // (a multiple of 4); jump = 0 is the plain operand and folds away.
 #pragma unroll
     for (int i = 0; i < PER_THREAD; ++i) {
       const int u = threadIdx.x + i * THREADS;
@@ -68,11 +85,11 @@ struct Tile {
       if (CONTIG) {
         const int row = u / (BK / 4), kq = u % (BK / 4);
         const int64_t gr = row0 + row, gk = k0 + 4 * kq;
-        ok = gr < nrows; off = gr * ld + gk; lim_a = kend - gk;
+        ok = gr < nrows; off = gr * ld + gk + (gk >= seg ? jump : 0); lim_a = kend - gk;
       } else {
         const int k = u / (ROWS / 4), rq = u % (ROWS / 4);
         const int64_t gk = k0 + k, gr = row0 + 4 * rq;
-        ok = gk < kend; off = gk * ld + gr; lim_a = nrows - gr;
+        ok = gk < kend; off = gk * ld + gr + (gr >= seg ? jump : 0); lim_a = nrows - gr;
       }
       (void)lim_b;
       float4 v;
@@ -115,8 +132,9 @@ struct Tile {
 };
 
 // The workgroup's whole job for output tile (bx, by) and contraction split bz of problem g.
-template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC>
-__device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int by, const int bz) {
+template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC, bool CONV = false>
+__device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int by, const int bz, const ConvX cx = ConvX{}) {
+  const int64_t aseg = CONV ? cx.a_seg : 0, ajump = CONV ? cx.a_jump : 0, bseg = CONV ? cx.b_seg : 0, bjump = CONV ? cx.b_jump : 0;
   constexpr int THREADS = 64 * WM * WN;
   using TA = Tile<BM, A_CONTIG, THREADS>;
   using TB = Tile<BN, B_CONTIG, THREADS>;
@@ -162,13 +180,13 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
   float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
   if (ntiles > 0) {
-    TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg, kend);
-    TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend);
+    TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, aseg, ajump);
+    TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, bseg, bjump);
     TA::store(ra, smem);
     TB::store(rb, smem + TA::LDS_FLOATS);
     if (ntiles > 1) {
-      TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg + BK, kend);
-      TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg + BK, kend);
+      TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg + BK, kend, aseg, ajump);
+      TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg + BK, kend, bseg, bjump);
     }
   }
   __syncthreads();
@@ -208,8 +226,8 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
         }
         if (t + 2 < ntiles) {
           const int64_t k0 = kbeg + (int64_t)(t + 2) * BK;
-          TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend);
-          TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend);
+          TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend, aseg, ajump);
+          TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend, bseg, bjump);
         }
         if (STAGES == 3) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -237,6 +255,56 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
       if (col >= g.N) continue;
       float bv = 0.f;
       if (EPI == EPI_BIAS_ACT && g.bias) bv = g.bias[col];
+      if (CONV && cx.mode != 0) {
+        // scattering epilogues of the convolutions: the GEMM row is a pixel of a (hs x ws) grid per image.  Two passes: destination
+        // offsets and (mode 2) the gate values of all 16 rows first -- the gate loads are then in flight together instead of one
+        // round trip in front of every store -- then the stores.
+        const int q = (int)col / cx.c, ch = (int)col - q * cx.c;       // mode 2: column = (py, px, channel)
+        const float* __restrict__ gate_src = g.xact;
+        float* __restrict__ dst = g.C;
+        int64_t off[16];
+        float gate[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          off[r] = -1; gate[r] = 1.f;
+          if (row >= g.M) continue;
+          // row -> (image, y, x) without integer division: rows < 2^24 are exact in fp32, the rounded reciprocal can miss the
+          // quotient by one either way, one correction step each
+          const int pix = cx.hs * cx.ws;
+          int img = (int)((float)(int)row * cx.inv_pix), rem = (int)row - img * pix;
+          if (rem < 0) { --img; rem += pix; } else if (rem >= pix) { ++img; rem -= pix; }
+          int y = (int)((float)rem * cx.inv_ws), x = rem - y * cx.ws;
+          if (x < 0) { --y; x += cx.ws; } else if (x >= cx.ws) { ++y; x -= cx.ws; }
+          if (cx.mode == 1) {
+            // y, x = output pixel; it is element ((y+1)&1, (x+1)&1, col) of pixel ((y+1)/2, (x+1)/2) of the next layer's
+            // padded space-to-depth input (4 * c channels)
+            if (y >= cx.ho || x >= cx.wo) continue;
+            const int Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
+            off[r] = (((int64_t)img * cx.dhs + Y) * cx.dws + X) * (4 * cx.c) + qq * cx.c + col;
+          } else {
+            // y, x = pixel of this layer's space-to-depth input, column q = (py, px): the gradient of the previous layer's
+            // output pixel (2y + py - 1, 2x + px - 1), gated by that output's ReLU (xact = the space-to-depth tensor itself)
+            const int yy = 2 * y + (q >> 1) - 1, xx = 2 * x + (q & 1) - 1;
+            if (yy < 0 || xx < 0 || yy >= cx.dho || xx >= cx.dwo) continue;
+            off[r] = (((int64_t)img * cx.dhs + yy) * cx.dws + xx) * cx.c + ch;
+            if (gate_src) gate[r] = gate_src[row * g.ldxa + col];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (off[r] < 0) continue;
+          float v = acc[i][j][r];
+          if (cx.mode == 1) {
+            v += bv;
+            if (g.leaky) v = v > 0.f ? v : v * g.slope;
+          } else if (gate_src) {
+            v *= (gate[r] > 0.f ? 1.f : g.slope);
+          }
+          dst[off[r]] = v;
+        }
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1403,4 +1471,265 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   if (rc) return rc;
   launch_slab_reduce(slab, dbslab, p.splits, N, K, dW, lddw, db, accumulate ? 1 : 0, st);
   return launch_status("clica_linear_wgrad(reduce)");
+}
+
+// =====================================================================================================================
+// Convolutions of the KITTI-masks encoder (BetaVAE_H, /root/reference/kitti_masks/model.py:41-56): four Conv2d(k = 4,
+// stride 2, pad 1) + ReLU stages (the fifth, k = 4 on a 4 x 4 map, is a plain Linear over the flattened map) as
+// IMPLICIT GEMMs on the fp32-MFMA template above.  Layout: channels-last.  The input of a stage is kept as the padded
+// "space-to-depth" tensor  S[image][sy][sx][(py, px, c)] = in[image][2 sy + py - 1][2 sx + px - 1][c]  (hs = H/2 + 1 by
+// ws = W/2 + 1 pixels of 4C channels, zero border), in which the 4 x 4 stride-2 window of output pixel (oy, ox) is the 2 x 2
+// stride-1 window (oy + dy, ox + dx): two runs of 8C contiguous floats, the second one ws * 4C floats behind the first.
+// So with GEMM rows numbered over the WHOLE hs x ws grid (r = (image * hs + y) * ws + x; rows with y = hs - 1 or
+// x = ws - 1 are not outputs and are computed for nothing: (ws/(ws-1))^2 of the useful work),
+//   forward   out[r][co] = sum_k A[r][k] Wg[co][k],      A[r][k] = S_flat[r * 4C + k + (k >= 8C ? (ws - 2) * 4C : 0)]
+//   wgrad     dWg[co][k] = sum_r dO[r][co] A[r][k]       (dO = 0 on the non-output rows), db = column sums of dO
+//   dgrad     dS[r][j]   = sum_{dy,dx,co} dO[r - dy ws - dx][co] Wg[co][(dy, dx, j)]   -- the same two-run operand on dO
+// and nothing is ever materialised: the loaders jump between the runs (Tile::load's seg / jump), the forward epilogue adds
+// bias + ReLU and scatters a row straight into the NEXT stage's space-to-depth tensor, the dgrad epilogue applies the ReLU
+// gate (S itself is the saved activation) and scatters into the previous stage's dO grid.  Borders and non-output rows are
+// never written, so buffers zeroed once stay valid (the host keeps them: cl_ica_amd/conv.py).
+// The first stage (C = 1 or 3 input channels, K = 16C) runs on an explicit patch matrix (clica_conv_im2col_k4s2, 64 B per
+// output pixel for the masks) -- its A operand has no run long enough to tile.
+namespace clica {
+namespace gemm {
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_k(Args g, ConvX cx) {
+  const int gx = gridDim.x;
+  const int id = xcd_contiguous(blockIdx.y * gx + blockIdx.x, gx * gridDim.y);   // N fastest
+  const int by = id / gx;
+  gemm_body<BM, BN, WM, WN, STAGES, A_CONTIG, B_CONTIG, EPI, true, true>(g, id - by * gx, by, blockIdx.z, cx);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI>
+static int launch_conv(const Args& g, const ConvX& cx, int splits, hipStream_t st, const char* who) {
+  constexpr int THREADS = 64 * WM * WN;
+  dim3 grid((unsigned)ceil_div(g.N, BN), (unsigned)ceil_div(g.M, BM), (unsigned)splits), block(THREADS);
+  constexpr size_t lds = STAGES * (Tile<BM, A_CONTIG, THREADS>::LDS_FLOATS + Tile<BN, B_CONTIG, THREADS>::LDS_FLOATS) * sizeof(float);
+  auto k = conv_gemm_k<BM, BN, WM, WN, STAGES, A_CONTIG, B_CONTIG, EPI>;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  hipLaunchKernelGGL(k, grid, block, lds, st, g, cx);
+  return launch_status(who);
+}
+
+// forward of one stage from either operand form
+static int conv_fwd_launch(const float* A, int64_t lda, int64_t seg, int64_t jump, const float* Wg, const float* bias, int64_t rows,
+                           int32_t K, int32_t Cout, int32_t hs, int32_t ws, int32_t ho, int32_t wo, int32_t relu, int32_t scatter,
+                           float* out, hipStream_t st, const char* who) {
+  Args g{}; g.A = A; g.lda = lda; g.B = Wg; g.ldb = K; g.C = out; g.ldc = Cout; g.M = rows; g.N = Cout; g.Kc = K;
+  g.bias = bias; g.leaky = relu ? 1 : 0; g.slope = 0.f;
+  ConvX cx{}; cx.a_seg = seg; cx.a_jump = jump; cx.mode = scatter ? 1 : 0;
+  cx.hs = hs; cx.ws = ws; cx.ho = ho; cx.wo = wo; cx.dhs = ho / 2 + 1; cx.dws = wo / 2 + 1; cx.c = Cout;
+  cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
+  if (scatter && rows >= (1 << 24)) { set_error("%s: %lld rows (the scattering epilogue handles < 2^24)", who, (long long)rows); return CLICA_E_INVALID; }
+  // few rows (the k = 4 stage on the 4 x 4 map: images x 1600 -> 256): small tiles so that the launch still covers the chip
+  if (Cout > 64 && rows <= 8192) return launch_conv<64, 64, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
+  if (Cout <= 32) return launch_conv<128, 32, 4, 1, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);   // 3 workgroups x 4 waves per CU (LDS-limited)
+  if (Cout <= 64) return launch_conv<128, 64, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
+  return launch_conv<64, 128, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
+}
+
+struct ConvWgradPlan { int bm, splits; int64_t k_per_split; };
+static ConvWgradPlan plan_conv_wgrad(int64_t rows, int32_t Cout, int32_t K) {
+  ConvWgradPlan p;
+  p.bm = Cout <= 32 ? 32 : 64;
+  const int64_t tiles = ceil_div(Cout, p.bm) * ceil_div(K, 128);
+  // ~three small workgroups per CU, and contraction chains of at most ~1024 rows: an accumulator adds its rows one after the other, and
+  // over the 592 k rows of the widest stage 3 000-row chains measured 1.2e-5 of max|dW| against fp64 (1 000-row chains: see tests)
+  int64_t want = std::max<int64_t>(std::max<int64_t>(1, 3 * kNumCU / tiles), ceil_div(rows, 1024));
+  want = std::min<int64_t>(want, std::max<int64_t>(1, rows / (8 * BK)));
+  p.k_per_split = ceil_div(ceil_div(rows, want), (int64_t)BK) * BK;
+  p.splits = (int)ceil_div(rows, p.k_per_split);
+  return p;
+}
+
+// x [images][C][H][W] (NCHW, as the data loader hands it over) -> patches [images * H/2 * W/2][16 C], column (ky * 4 + kx) * C + c.
+// One thread per (output pixel, tap): consecutive lanes write consecutive floats (C = 1) and read consecutive input columns.
+__global__ __launch_bounds__(256) void conv_im2col_k4s2_k(const float* __restrict__ x, unsigned pixels, int C, int H, int W,
+                                                           float* __restrict__ patches) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned pixel = t >> 4, tap = t & 15u;
+  if (pixel >= pixels) return;
+  const unsigned Wo = W / 2, Ho = H / 2;
+  const unsigned prow = pixel / Wo, ox = pixel - prow * Wo, img = prow / Ho, oy = prow - img * Ho;
+  const int y = 2 * (int)oy + (int)(tap >> 2) - 1, xx = 2 * (int)ox + (int)(tap & 3u) - 1;
+  const bool in = y >= 0 && y < H && xx >= 0 && xx < W;
+  const float* src = x + ((int64_t)img * C * H + y) * W + xx;
+  float* dst = patches + ((int64_t)pixel * 16 + tap) * C;
+  for (int c = 0; c < C; ++c) dst[c] = in ? src[(int64_t)c * H * W] : 0.f;
+}
+
+// First stage's weight / bias gradient from the patch matrix: dWg[Cout][K] = dO[rows][Cout]^T P[rows][K] with Cout x K small (32 x 16 for the
+// masks) and rows in the millions -- HBM-bound (dO 128 B + P 64 B per row).  A thread owns a 4 x 4 block of dWg; the (Cout/4)(K/4)
+// threads of a group read one row's dO and P as float4s (the same 128 / 64 bytes for the whole group: one cache line each), the
+// G = 256 / group size groups of a workgroup take rows r = g (mod G) of the workgroup's row range, are summed through LDS, and every
+// workgroup writes ONE slab for the shared deterministic slab reduction.
+__global__ __launch_bounds__(256) void conv_wgrad_patches_k(const float* __restrict__ dO, const float* __restrict__ P, int64_t rows,
+                                                             int Cout, int K, int64_t rows_per_block, float* __restrict__ slab,
+                                                             float* __restrict__ dbslab) {
+  extern __shared__ float red[];                       // [G][Cout * K + Cout]
+  const int ncg = Cout / 4, gsz = ncg * (K / 4), G = 256 / gsz;
+  const int g = threadIdx.x / gsz, u = threadIdx.x - g * gsz, cg = u % ncg, kg = u / ncg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[4][4] = {};
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (g < G) {
+#pragma unroll 4
+    for (int64_t r = r0 + g; r < r1; r += G) {
+      const float4 d = *reinterpret_cast<const float4*>(dO + r * Cout + 4 * cg);
+      const float4 p = *reinterpret_cast<const float4*>(P + r * K + 4 * kg);
+      const float dv[4] = {d.x, d.y, d.z, d.w}, pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], pv[j], acc[i][j]);
+      bsum.x += d.x; bsum.y += d.y; bsum.z += d.z; bsum.w += d.w;
+    }
+    float* mine = red + (size_t)g * (Cout * K + Cout);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[(4 * cg + i) * K + 4 * kg + j] = acc[i][j];
+    if (kg == 0) { mine[Cout * K + 4 * cg] = bsum.x; mine[Cout * K + 4 * cg + 1] = bsum.y; mine[Cout * K + 4 * cg + 2] = bsum.z; mine[Cout * K + 4 * cg + 3] = bsum.w; }
+  }
+  __syncthreads();
+  const int per = Cout * K + Cout;
+  for (int e = threadIdx.x; e < per; e += 256) {
+    float v = 0.f;
+    for (int gg = 0; gg < G; ++gg) v += red[(size_t)gg * per + e];
+    if (e < Cout * K) slab[(int64_t)blockIdx.x * Cout * K + e] = v;
+    else if (dbslab) dbslab[(int64_t)blockIdx.x * Cout + (e - Cout * K)] = v;
+  }
+}
+
+struct PatchWgradPlan { int blocks; int64_t rows_per_block; };
+static bool patch_wgrad_ok(int32_t Cout, int32_t K) {
+  if (Cout % 4 || K % 4) return false;
+  const int gsz = (Cout / 4) * (K / 4);
+  return gsz <= 256 && 256 % gsz == 0 && (size_t)(256 / gsz) * (Cout * K + Cout) * sizeof(float) <= 64 * 1024;
+}
+static PatchWgradPlan plan_patch_wgrad(int64_t rows) {
+  PatchWgradPlan p;
+  p.rows_per_block = std::max<int64_t>(256, ceil_div(rows, (int64_t)kNumCU * 8));
+  p.blocks = (int)ceil_div(rows, p.rows_per_block);
+  return p;
+}
+
+}  // namespace gemm
+}  // namespace clica
+
+extern "C" int clica_conv_im2col_k4s2(const float* x, int64_t images, int32_t C, int32_t H, int32_t W, float* patches,
+                                      clica_stream_t stream) {
+  CLICA_CHECK_ARG(x && patches && images > 0 && C >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0,
+                  "clica_conv_im2col_k4s2: bad argument (even H, W required)");
+  const int64_t pixels = images * (H / 2) * (W / 2);
+  CLICA_CHECK_ARG(pixels * 16 < ((int64_t)1 << 32), "clica_conv_im2col_k4s2: %lld output pixels (< 2^28 supported)", (long long)pixels);
+  hipLaunchKernelGGL(conv_im2col_k4s2_k, dim3((unsigned)ceil_div(pixels * 16, 256)), dim3(256), 0, as_stream(stream), x, (unsigned)pixels,
+                     (int)C, (int)H, (int)W, patches);
+  return launch_status("clica_conv_im2col_k4s2");
+}
+
+extern "C" int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
+                                           int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
+                                           clica_stream_t stream) {
+  CLICA_CHECK_ARG(patches && Wg && out && images > 0 && K >= 4 && K % 4 == 0 && Cout >= 1 && ho >= 1 && wo >= 1,
+                  "clica_conv_k4s2_fwd_patches: bad argument");
+  CLICA_CHECK_ARG(!scatter || (ho % 2 == 0 && wo % 2 == 0), "clica_conv_k4s2_fwd_patches: scatter needs an even output grid");
+  CLICA_CHECK_ARG(aligned16(patches) && aligned16(Wg), "clica_conv_k4s2_fwd_patches: operands must be 16-byte aligned");
+  return conv_fwd_launch(patches, K, 0, 0, Wg, bias, images * ho * wo, K, Cout, ho, wo, ho, wo, relu, scatter, out, as_stream(stream),
+                         "clica_conv_k4s2_fwd_patches");
+}
+
+extern "C" int clica_conv_k4s2_fwd(const float* S, const float* Wg, const float* bias, int64_t images, int32_t C, int32_t Cout,
+                                   int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, clica_stream_t stream) {
+  CLICA_CHECK_ARG(S && Wg && out && images > 0 && C >= 1 && C % 4 == 0 && Cout >= 1 && hs >= 2 && ws >= 2,
+                  "clica_conv_k4s2_fwd: bad argument (C must be a multiple of 4)");
+  CLICA_CHECK_ARG(!scatter || ((hs - 1) % 2 == 0 && (ws - 1) % 2 == 0), "clica_conv_k4s2_fwd: scatter needs an even output grid");
+  CLICA_CHECK_ARG(aligned16(S) && aligned16(Wg), "clica_conv_k4s2_fwd: operands must be 16-byte aligned");
+  return conv_fwd_launch(S, 4 * (int64_t)C, 8 * (int64_t)C, (int64_t)(ws - 2) * 4 * C, Wg, bias, images * hs * ws, 16 * C, Cout,
+                         hs, ws, hs - 1, ws - 1, relu, scatter, out, as_stream(stream), "clica_conv_k4s2_fwd");
+}
+
+extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const float* S, int64_t images, int32_t C, int32_t Cout,
+                                     int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dO && Wd && dPrev && images > 0 && C >= 1 && C % 4 == 0 && Cout >= 1 && Cout % 4 == 0 && hs >= 2 && ws >= 2,
+                  "clica_conv_k4s2_dgrad: bad argument (C, Cout must be multiples of 4)");
+  CLICA_CHECK_ARG(dhs >= 2 * (hs - 1) && dws >= 2 * (ws - 1), "clica_conv_k4s2_dgrad: destination grid smaller than 2 (hs - 1) x 2 (ws - 1)");
+  CLICA_CHECK_ARG(aligned16(dO) && aligned16(Wd), "clica_conv_k4s2_dgrad: operands must be 16-byte aligned");
+  // dS[r][j] = sum_k A[r][k] Wd[k][j],  k = (1 - dy, 1 - dx, co):  A[r][k] = dO_flat[(r - ws - 1) Cout + k + (k >= 2 Cout ? (ws - 2) Cout : 0)]
+  Args g{}; g.A = dO - (int64_t)(ws + 1) * Cout; g.lda = Cout; g.B = Wd; g.ldb = 4 * (int64_t)C; g.C = dPrev; g.ldc = C;
+  g.M = images * hs * ws; g.N = 4 * (int64_t)C; g.Kc = 4 * (int64_t)Cout;
+  g.xact = S; g.ldxa = 4 * (int64_t)C; g.slope = 0.f;
+  ConvX cx{}; cx.a_seg = 2 * (int64_t)Cout; cx.a_jump = (int64_t)(ws - 2) * Cout; cx.mode = 2;
+  cx.hs = hs; cx.ws = ws; cx.ho = hs; cx.wo = ws; cx.dhs = dhs; cx.dws = dws; cx.dho = 2 * (hs - 1); cx.dwo = 2 * (ws - 1); cx.c = C;
+  cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
+  CLICA_CHECK_ARG(g.M < (1 << 24), "clica_conv_k4s2_dgrad: %lld rows (the scattering epilogue handles < 2^24)", (long long)g.M);
+  return launch_conv<64, 128, 2, 2, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
+}
+
+extern "C" int clica_conv_k4s2_wgrad_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && rows > 0 && Cout >= 1 && K >= 1, "clica_conv_k4s2_wgrad_workspace_bytes: bad argument");
+  const ConvWgradPlan p = plan_conv_wgrad(rows, Cout, K);
+  *bytes = align_up((size_t)p.splits * Cout * K * sizeof(float), 256) + align_up((size_t)p.splits * Cout * sizeof(float), 256);
+  return CLICA_OK;
+}
+
+extern "C" int clica_conv_k4s2_wgrad(const float* dO, const float* S, int64_t images, int32_t C, int32_t Cout, int32_t hs, int32_t ws,
+                                     float* dWg, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                                     clica_stream_t stream) {
+  CLICA_CHECK_ARG(dO && S && dWg && workspace && images > 0 && C >= 1 && C % 4 == 0 && Cout >= 1 && Cout % 4 == 0 && hs >= 2 && ws >= 2,
+                  "clica_conv_k4s2_wgrad: bad argument (C, Cout must be multiples of 4)");
+  CLICA_CHECK_ARG(aligned16(dO) && aligned16(S), "clica_conv_k4s2_wgrad: operands must be 16-byte aligned");
+  const int64_t rows = images * hs * ws;
+  const int32_t K = 16 * C;
+  const ConvWgradPlan p = plan_conv_wgrad(rows, Cout, K);
+  const size_t slab_bytes = align_up((size_t)p.splits * Cout * K * sizeof(float), 256);
+  const size_t need = slab_bytes + align_up((size_t)p.splits * Cout * sizeof(float), 256);
+  if (need > workspace_bytes) { set_error("clica_conv_k4s2_wgrad: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  float* slab = (float*)workspace;
+  float* dbslab = (float*)((char*)workspace + slab_bytes);
+  hipStream_t st = as_stream(stream);
+  // dWg[Cout][16C] = dO[rows][Cout]^T A[rows][16C]: "M" = Cout, "N" = 16C, contraction over the rows; B is the two-run operand
+  Args g{}; g.A = dO; g.lda = Cout; g.B = S; g.ldb = 4 * (int64_t)C; g.C = slab; g.ldc = K; g.M = Cout; g.N = K; g.Kc = rows;
+  g.k_per_split = p.k_per_split; g.dbias_slab = db ? dbslab : nullptr;
+  ConvX cx{}; cx.b_seg = 8 * (int64_t)C; cx.b_jump = (int64_t)(ws - 2) * 4 * C;
+  int rc = p.bm == 32 ? launch_conv<32, 128, 1, 4, 2, false, false, EPI_SLAB>(g, cx, p.splits, st, "clica_conv_k4s2_wgrad")
+                      : launch_conv<64, 128, 2, 2, 2, false, false, EPI_SLAB>(g, cx, p.splits, st, "clica_conv_k4s2_wgrad");
+  if (rc) return rc;
+  launch_slab_reduce(slab, dbslab, p.splits, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
+  return launch_status("clica_conv_k4s2_wgrad(reduce)");
+}
+
+extern "C" int clica_conv_k4s2_wgrad_patches_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && rows > 0 && Cout >= 1 && K >= 1, "clica_conv_k4s2_wgrad_patches_workspace_bytes: bad argument");
+  CLICA_CHECK_ARG(patch_wgrad_ok(Cout, K), "clica_conv_k4s2_wgrad_patches: Cout = %d, K = %d not supported (multiples of 4 with (Cout/4)(K/4) "
+                  "dividing 256); use clica_mlp_wgrad on the patch matrix", Cout, K);
+  const PatchWgradPlan p = plan_patch_wgrad(rows);
+  *bytes = align_up((size_t)p.blocks * Cout * K * sizeof(float), 256) + align_up((size_t)p.blocks * Cout * sizeof(float), 256);
+  return CLICA_OK;
+}
+
+extern "C" int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patches, int64_t rows, int32_t Cout, int32_t K, float* dWg,
+                                             float* db, int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dO && patches && dWg && workspace && rows > 0, "clica_conv_k4s2_wgrad_patches: NULL pointer / no rows");
+  CLICA_CHECK_ARG(patch_wgrad_ok(Cout, K), "clica_conv_k4s2_wgrad_patches: Cout = %d, K = %d not supported (multiples of 4 with (Cout/4)(K/4) "
+                  "dividing 256); use clica_mlp_wgrad on the patch matrix", Cout, K);
+  CLICA_CHECK_ARG(aligned16(dO) && aligned16(patches), "clica_conv_k4s2_wgrad_patches: operands must be 16-byte aligned");
+  const PatchWgradPlan p = plan_patch_wgrad(rows);
+  const size_t slab_bytes = align_up((size_t)p.blocks * Cout * K * sizeof(float), 256);
+  const size_t need = slab_bytes + align_up((size_t)p.blocks * Cout * sizeof(float), 256);
+  if (need > workspace_bytes) { set_error("clica_conv_k4s2_wgrad_patches: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  float* slab = (float*)workspace;
+  float* dbslab = (float*)((char*)workspace + slab_bytes);
+  hipStream_t st = as_stream(stream);
+  const int G = 256 / ((Cout / 4) * (K / 4));
+  const size_t lds = (size_t)G * (Cout * K + Cout) * sizeof(float);
+  hipLaunchKernelGGL(conv_wgrad_patches_k, dim3((unsigned)p.blocks), dim3(256), lds, st, dO, patches, rows, (int)Cout, (int)K, p.rows_per_block,
+                     slab, db ? dbslab : (float*)nullptr);
+  int rc = launch_status("clica_conv_k4s2_wgrad_patches");
+  if (rc) return rc;
+  launch_slab_reduce(slab, dbslab, p.blocks, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
+  return launch_status("clica_conv_k4s2_wgrad_patches(reduce)");
 }

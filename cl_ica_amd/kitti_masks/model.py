@@ -4,8 +4,9 @@ Same constructor (``z_dim, nc, box_norm``), same ``self.encoder`` ``nn.Sequentia
 (``encoder.{0,2,4,6,8}.{weight,bias}``, ``encoder.11.{weight,bias}``, ``encoder.12.max_abs_bound`` with ``box_norm``), the
 same Kaiming-normal initialisation with zero biases (:76-79, :102-110) and the same ``forward(x) -> (B, z_dim)``.
 
-Execution: the five ``Conv2d(k=4) + ReLU`` stages run on PyTorch-ROCm / MIOpen (north_star keeps the conv path there,
-BASELINE.json configs[4]); everything behind the ``View`` -- ``Linear(256 -> z_dim)`` forward / dgrad / wgrad
+Execution: on the GPU the five ``Conv2d(k=4) + ReLU`` stages run on the HIP library since round 4 (implicit-GEMM stages,
+``cl_ica_amd/conv.py`` / ``clica_conv_*``; ``CLICA_CONV=miopen`` selects PyTorch-ROCm / MIOpen, which north_star allows for the
+conv path, BASELINE.json configs[4]); everything behind the ``View`` -- ``Linear(256 -> z_dim)`` forward / dgrad / wgrad
 (``clica_linear_*``), the learnable Softclip head (``clica_softclip_*``) -- runs on the HIP kernels, and the result feeds
 ``cl_ica_amd.losses.LpSimCLRLoss`` through strided ``mu[::2]`` / ``mu[1::2]`` views without a copy.
 """
@@ -14,7 +15,10 @@ from __future__ import annotations
 import torch
 from torch import nn
 
+import os
+
 from .. import layers
+from ..conv import conv_stack
 from ..encoders import _MLPStackFn
 
 __all__ = ["BetaVAE_H", "View", "kaiming_init"]
@@ -63,6 +67,13 @@ class BetaVAE_H(nn.Module):
             kaiming_init(m)
 
     def _encode(self, x):
+        if x.is_cuda and _hip_convs():
+            # the five Conv2d + ReLU stages as ONE autograd node on the HIP library (cl_ica_amd/conv.py); the Conv2d modules keep
+            # the parameters.  CLICA_CONV=miopen runs them through nn.Conv2d instead (the layout the reference executes, for A/B).
+            feats = conv_stack(x.float(), [self.encoder[i] for i in (0, 2, 4, 6, 8)])
+            for stage in self.encoder[10:]:
+                feats = stage(feats)
+            return feats
         return self.encoder(x)
 
     def forward(self, x, return_z=False):
@@ -71,6 +82,10 @@ class BetaVAE_H(nn.Module):
 
 def _identity(x):
     return x
+
+
+def _hip_convs() -> bool:
+    return os.environ.get("CLICA_CONV", "hip") != "miopen"
 
 
 def kaiming_init(m):

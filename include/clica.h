@@ -366,11 +366,54 @@ int clica_softclip_bwd(const float* X, int64_t ldx, const float* bound, const fl
 
 /* Stand-alone LeakyReLU between a backbone's output and the encoder head's Linear
  * (/root/reference/main_3dident.py:365-370: Sequential(backbone, nn.LeakyReLU(), nn.Linear(10 n_lat, n_lat), rescaling)).
- * The backward takes the saved OUTPUT Yact (slope > 0). */
+ * The backward takes the saved OUTPUT Yact (slope >= 0; slope = 0 is ReLU, whose output is positive exactly where its derivative is 1). */
 int clica_leaky_relu_fwd(const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t M, int32_t n, float slope,
                          clica_stream_t stream);
 int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_t lddy, float* dX, int64_t lddx,
                          int64_t M, int32_t n, float slope, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution stack of the KITTI-masks encoder  --  BetaVAE_H, /root/reference/kitti_masks/model.py:41-56:
+ * Conv2d(k = 4, stride 2, pad 1) + ReLU stages as implicit GEMMs (fp32 MFMA, csrc/linear.hip, conv section), channels-last.
+ * (The reference runs them through nn.Conv2d = MIOpen; these entry points replace the forward, the data gradient and the
+ * weight / bias gradients of kitti_masks/model.py:42-49; the k = 4 stage on the 4 x 4 map (:50) is clica_linear_* over the flattened map.)
+ *
+ *   S    padded space-to-depth input of a stage: [images][hs][ws][4 C], hs = H/2 + 1, ws = W/2 + 1,
+ *        S[i][sy][sx][(py * 2 + px) * C + c] = in[i][2 sy + py - 1][2 sx + px - 1][c], zero where that pixel is outside the
+ *        H x W map; the buffer must be readable (zeros) for (ws + 2) * 4 C floats behind its end.
+ *   Wg   GEMM weights [Cout][16 C]: Wg[co][((dy * 2 + dx) * 4 + py * 2 + px) * C + c] = weight[co][c][2 dy + py][2 dx + px]
+ *   rows GEMM rows cover the whole hs x ws grid, r = (i * hs + y) * ws + x; outputs are the rows with y < hs - 1, x < ws - 1.
+ *
+ *   fwd:   scatter = 1: out = the NEXT stage's S tensor ([images][(hs-1)/2 + 1][(ws-1)/2 + 1][4 Cout], border pre-zeroed by
+ *          the caller and never written);  scatter = 0: out[r][Cout] for every row r (non-output rows hold finite garbage).
+ *          relu != 0 applies ReLU after the bias.
+ *   fwd_patches: the same from an explicit patch matrix [images * ho * wo][K] (first stage; clica_conv_im2col_k4s2 builds it
+ *          from the NCHW input with K = 16 C, column (ky * 4 + kx) * C + c), rows = output pixels of an ho x wo grid.
+ *   dgrad: dO [rows][Cout] = gradient of the stage's pre-activation output on the hs x ws row grid, ZERO on non-output rows, with
+ *          (ws + 1) * Cout readable zeros IN FRONT of it;  Wd [4 Cout][4 C]: Wd[((1-dy) * 2 + (1-dx)) * Cout + co][j] = Wg[co][(dy * 2 + dx) * 4 C + j];
+ *          the result, gated by ReLU' of the previous stage (S > 0), is scattered to dPrev[images][dhs][dws][C] = the previous
+ *          stage's dO grid (its valid 2(hs-1) x 2(ws-1) pixels are all written, the others never).
+ *   wgrad: dWg[Cout][16 C] (+)= sum_r dO[r]^T A[r],  db[Cout] (+)= sum_r dO[r]   (A = the stage's implicit patch rows of S)
+ * ---------------------------------------------------------------------------------- */
+int clica_conv_im2col_k4s2(const float* x /*[images][C][H][W]*/, int64_t images, int32_t C, int32_t H, int32_t W,
+                           float* patches /*[images * H/2 * W/2][16 C]*/, clica_stream_t stream);
+int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg /*[Cout][K]*/, const float* bias, int64_t images, int32_t K,
+                                int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
+                                clica_stream_t stream);
+int clica_conv_k4s2_fwd(const float* S, const float* Wg, const float* bias, int64_t images, int32_t C, int32_t Cout,
+                        int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, clica_stream_t stream);
+int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const float* S, int64_t images, int32_t C, int32_t Cout,
+                          int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, clica_stream_t stream);
+int clica_conv_k4s2_wgrad_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes);
+int clica_conv_k4s2_wgrad(const float* dO, const float* S, int64_t images, int32_t C, int32_t Cout, int32_t hs, int32_t ws,
+                          float* dWg, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                          clica_stream_t stream);
+
+/* First stage: dWg[Cout][K] (+)= dO^T patches, db (+)= column sums of dO, from the explicit patch matrix (HBM-bound VALU kernel for a
+ * small Cout x K, e.g. 32 x 16; Cout, K multiples of 4 with (Cout/4)(K/4) dividing 256 -- otherwise CLICA_E_INVALID: use clica_mlp_wgrad). */
+int clica_conv_k4s2_wgrad_patches_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes);
+int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patches, int64_t rows, int32_t Cout, int32_t K, float* dWg, float* db,
+                                  int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Mixing network g  --  construct_invertible_mlp's nn.Sequential forward,
