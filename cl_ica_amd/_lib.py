@@ -108,9 +108,9 @@ SIGNATURES: Dict[str, list] = {
     "clica_leaky_relu_fwd": [c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i32, C.c_float, C.c_void_p],
     "clica_leaky_relu_bwd": [c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, c_i32, C.c_float, C.c_void_p],
     "clica_conv_im2col_k4s2": [c_f32p, c_i64, c_i32, c_i32, c_i32, c_f32p, C.c_void_p],
-    "clica_conv_k4s2_fwd_patches": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p],
-    "clica_conv_k4s2_fwd": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p],
-    "clica_conv_k4s2_dgrad": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, c_i32, c_i32, C.c_void_p],
+    "clica_conv_k4s2_fwd_patches": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p, C.c_void_p],
+    "clica_conv_k4s2_fwd": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p, C.c_void_p],
+    "clica_conv_k4s2_dgrad": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, c_i32, c_i32, C.c_void_p, C.c_void_p],
     "clica_conv_k4s2_wgrad_workspace_bytes": [c_i64, c_i32, c_i32, C.POINTER(c_size)],
     "clica_conv_k4s2_wgrad": [c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, c_f32p, c_i32, C.c_void_p, c_size, C.c_void_p],
     "clica_conv_k4s2_wgrad_patches_workspace_bytes": [c_i64, c_i32, c_i32, C.POINTER(c_size)],

@@ -39,8 +39,12 @@ class _Buffers:
         self.S: Dict[int, torch.Tensor] = {}        # stage index (1..3) -> its space-to-depth INPUT, flat, zero tail
         self.dO: Dict[int, torch.Tensor] = {}       # stage index (0..3) -> gradient of its pre-activation output on its row grid
         self._dO_store: Dict[int, torch.Tensor] = {}
+        self.gate: Dict[int, torch.Tensor] = {}     # stage index (0..2) -> (output > 0) bits on the stage's row grid, [row][cout / 32] words
         cin = nc
         for l, (cout, ho) in enumerate(STAGES):
+            if l < 3:
+                grid = ho if l == 0 else ho + 1
+                self.gate[l] = torch.empty(images * grid * grid * (cout // 32), dtype=torch.int32, device=device)
             if l >= 1:
                 hs = STAGES[l - 1][1] // 2 + 1
                 self.S[l] = torch.zeros(images * hs * hs * 4 * cin + (hs + 2) * 4 * cin, **f32)
@@ -111,19 +115,19 @@ class _ConvStackFn(torch.autograd.Function):
         check(lib.clica_conv_im2col_k4s2(x.data_ptr(), images, nc, _IMAGE, _IMAGE, buf.patches.data_ptr(), st), "clica_conv_im2col_k4s2")
         w1g = ws_[0].detach().permute(0, 2, 3, 1).reshape(STAGES[0][0], 16 * nc)
         check(lib.clica_conv_k4s2_fwd_patches(buf.patches.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
-                                              32, 32, 1, 1, buf.S[1].data_ptr(), st), "clica_conv_k4s2_fwd_patches")
+                                              32, 32, 1, 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), st), "clica_conv_k4s2_fwd_patches")
         cin = STAGES[0][0]
         for l in (1, 2, 3):
             cout, ho = STAGES[l]
             hs = ho + 1
             out = buf.S[l + 1] if l < 3 else buf.O4
             check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), _wg(ws_[l]).data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
-                                          1, 1 if l < 3 else 0, out.data_ptr(), st), "clica_conv_k4s2_fwd")
+                                          1, 1 if l < 3 else 0, out.data_ptr(), buf.gate[l].data_ptr() if l < 3 else None, st), "clica_conv_k4s2_fwd")
             cin = cout
         w5g = _w5(ws_[4])
         feats = torch.empty((images, _FEATURES), dtype=torch.float32, device=dev)
         check(lib.clica_conv_k4s2_fwd_patches(buf.O4.data_ptr(), w5g.data_ptr(), ptr(bs_[4].detach()), images, 5 * 5 * 64, _FEATURES, 1, 1, 1, 0,
-                                              feats.data_ptr(), st), "clica_conv_k4s2_fwd_patches")
+                                              feats.data_ptr(), None, st), "clica_conv_k4s2_fwd_patches")
         if keep:
             ctx.buf, ctx.w5g, ctx.nc = buf, w5g, nc
             ctx.save_for_backward(feats, *ws_)
@@ -159,7 +163,7 @@ class _ConvStackFn(torch.autograd.Function):
             grads[2 * l], grads[2 * l + 1] = _wg_to_conv(dwg, cout, cin), db
             dgrid = STAGES[l - 1][1] + (1 if l > 1 else 0)          # previous stage's row grid (the first stage's is its 32 x 32 output)
             check(lib.clica_conv_k4s2_dgrad(buf.dO[l].data_ptr(), _wd(ws_[l]).data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs,
-                                            buf.dO[l - 1].data_ptr(), dgrid, dgrid, st), "clica_conv_k4s2_dgrad")
+                                            buf.dO[l - 1].data_ptr(), dgrid, dgrid, buf.gate[l - 1].data_ptr(), st), "clica_conv_k4s2_dgrad")
         cout = STAGES[0][0]
         dw1g = torch.empty((cout, 16 * nc), dtype=torch.float32, device=dev)
         db1 = torch.empty((cout,), dtype=torch.float32, device=dev)

@@ -54,6 +54,8 @@ struct ConvX {
   int dhs, dws, dho, dwo;    // destination pixel grid (rows of dhs x dws per image, valid dho x dwo)
   int c;                     // channels per pixel of the scattered tensor: mode 1 = N, mode 2 = N / 4
   float inv_pix, inv_ws;     // 1 / (hs * ws), 1 / ws for the epilogues' row -> pixel arithmetic (rows < 2^24)
+  unsigned* gate_out;        // mode 1: one bit per output element, (y > 0), word [row][col / 32] of this stage's row grid (or nullptr)
+  const unsigned* gate_in;   // mode 2: the previous stage's gate bits on the destination grid (replaces the 4-byte gate read of xact)
 };
 
 // ---- tile loaders: global -> registers ------------------------------------------------------
@@ -288,7 +290,12 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
             const int yy = 2 * y + (q >> 1) - 1, xx = 2 * x + (q & 1) - 1;
             if (yy < 0 || xx < 0 || yy >= cx.dho || xx >= cx.dwo) continue;
             off[r] = (((int64_t)img * cx.dhs + yy) * cx.dws + xx) * cx.c + ch;
-            if (gate_src) gate[r] = gate_src[row * g.ldxa + col];
+            if (cx.gate_in) {
+              const unsigned word = cx.gate_in[(((int64_t)img * cx.dhs + yy) * cx.dws + xx) * (cx.c >> 5) + (ch >> 5)];
+              gate[r] = (word >> (ch & 31)) & 1u ? 1.f : 0.f;
+            } else if (gate_src) {
+              gate[r] = gate_src[row * g.ldxa + col];
+            }
           }
         }
 #pragma unroll
@@ -298,10 +305,16 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
           if (cx.mode == 1) {
             v += bv;
             if (g.leaky) v = v > 0.f ? v : v * g.slope;
-          } else if (gate_src) {
+          } else if (gate_src || cx.gate_in) {
             v *= (gate[r] > 0.f ? 1.f : g.slope);
           }
           dst[off[r]] = v;
+          if (cx.mode == 1 && cx.gate_out) {
+            // the 32 lanes of a half-wave hold 32 consecutive channels of one row: their (v > 0) bits are one word of the gate tensor
+            const unsigned long long bits = __ballot(v > 0.f);
+            const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (l31 == 0) cx.gate_out[row * (g.N >> 5) + (col >> 5)] = (unsigned)(bits >> (32 * h));
+          }
         }
         continue;
       }
@@ -1517,12 +1530,14 @@ static int launch_conv(const Args& g, const ConvX& cx, int splits, hipStream_t s
 // forward of one stage from either operand form
 static int conv_fwd_launch(const float* A, int64_t lda, int64_t seg, int64_t jump, const float* Wg, const float* bias, int64_t rows,
                            int32_t K, int32_t Cout, int32_t hs, int32_t ws, int32_t ho, int32_t wo, int32_t relu, int32_t scatter,
-                           float* out, hipStream_t st, const char* who) {
+                           float* out, uint32_t* gate_bits, hipStream_t st, const char* who) {
   Args g{}; g.A = A; g.lda = lda; g.B = Wg; g.ldb = K; g.C = out; g.ldc = Cout; g.M = rows; g.N = Cout; g.Kc = K;
   g.bias = bias; g.leaky = relu ? 1 : 0; g.slope = 0.f;
   ConvX cx{}; cx.a_seg = seg; cx.a_jump = jump; cx.mode = scatter ? 1 : 0;
   cx.hs = hs; cx.ws = ws; cx.ho = ho; cx.wo = wo; cx.dhs = ho / 2 + 1; cx.dws = wo / 2 + 1; cx.c = Cout;
   cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
+  cx.gate_out = gate_bits;
+  if (gate_bits && !(scatter && Cout % 32 == 0)) { set_error("%s: gate bits need the scattering epilogue and Cout %% 32 == 0", who); return CLICA_E_INVALID; }
   if (scatter && rows >= (1 << 24)) { set_error("%s: %lld rows (the scattering epilogue handles < 2^24)", who, (long long)rows); return CLICA_E_INVALID; }
   // few rows (the k = 4 stage on the 4 x 4 map: images x 1600 -> 256): small tiles so that the launch still covers the chip
   if (Cout > 64 && rows <= 8192) return launch_conv<64, 64, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
@@ -1604,6 +1619,57 @@ __global__ __launch_bounds__(256) void conv_wgrad_patches_k(const float* __restr
   }
 }
 
+// First stage's forward from the patch matrix on the vector ALUs: K = 16 C is far too short a contraction for a 32-deep MFMA k-tile
+// (the GEMM path spent 220 us per 2 M pixels on tile prologues and epilogues), and the stage is HBM-bound anyway: 64 B of patch in,
+// 128 B of activation out per pixel.  A thread owns 8 output channels (its K x 8 weights live in registers) and walks over pixels;
+// the four threads of a pixel write its 32 channels as one 128-byte piece of the next stage's space-to-depth tensor.
+template <int K>
+__global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __restrict__ P, const float* __restrict__ Wg,
+                                                                const float* __restrict__ bias, unsigned pixels, int Cout, int ho, int wo,
+                                                                int relu, float* __restrict__ out, unsigned* __restrict__ gate_out) {
+  const int groups = Cout / 8;                          // threads per pixel
+  const int cg = threadIdx.x % groups;
+  float w[8][K], b[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    b[c] = bias ? bias[8 * cg + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[c][k] = Wg[(8 * cg + c) * K + k];
+  }
+  const unsigned per_block = 256 / groups, stride = gridDim.x * per_block;
+  const int dhs = ho / 2 + 1, dws = wo / 2 + 1;
+  for (unsigned pixel = blockIdx.x * per_block + threadIdx.x / groups; pixel < pixels; pixel += stride) {
+    float a[K];
+#pragma unroll
+    for (int k = 0; k < K; k += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(P + (int64_t)pixel * K + k);
+      a[k] = v.x; a[k + 1] = v.y; a[k + 2] = v.z; a[k + 3] = v.w;
+    }
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc = fmaf(a[k], w[c][k], acc);       // k ascending, like the MFMA chain of the GEMM path
+      acc += b[c];
+      o[c] = (relu && !(acc > 0.f)) ? 0.f : acc;
+    }
+    const unsigned prow = pixel / (unsigned)wo, x = pixel - prow * (unsigned)wo, img = prow / (unsigned)ho, y = prow - img * (unsigned)ho;
+    const unsigned Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
+    float* dst = out + (((int64_t)img * dhs + Y) * dws + X) * (4 * Cout) + qq * Cout + 8 * cg;
+    *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    if (gate_out) {               // Cout == 32: the four threads of a pixel combine their 8 bits into the pixel's gate word
+      unsigned bits = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bits |= (o[c] > 0.f ? 1u : 0u) << (8 * cg + c);
+      bits |= __shfl_xor(bits, 1);
+      bits |= __shfl_xor(bits, 2);
+      if (cg == 0) gate_out[pixel] = bits;
+    }
+  }
+}
+
 struct PatchWgradPlan { int blocks; int64_t rows_per_block; };
 static bool patch_wgrad_ok(int32_t Cout, int32_t K) {
   if (Cout % 4 || K % 4) return false;
@@ -1633,27 +1699,36 @@ extern "C" int clica_conv_im2col_k4s2(const float* x, int64_t images, int32_t C,
 
 extern "C" int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
                                            int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
-                                           clica_stream_t stream) {
+                                           uint32_t* gate_bits, clica_stream_t stream) {
   CLICA_CHECK_ARG(patches && Wg && out && images > 0 && K >= 4 && K % 4 == 0 && Cout >= 1 && ho >= 1 && wo >= 1,
                   "clica_conv_k4s2_fwd_patches: bad argument");
   CLICA_CHECK_ARG(!scatter || (ho % 2 == 0 && wo % 2 == 0), "clica_conv_k4s2_fwd_patches: scatter needs an even output grid");
   CLICA_CHECK_ARG(aligned16(patches) && aligned16(Wg), "clica_conv_k4s2_fwd_patches: operands must be 16-byte aligned");
-  return conv_fwd_launch(patches, K, 0, 0, Wg, bias, images * ho * wo, K, Cout, ho, wo, ho, wo, relu, scatter, out, as_stream(stream),
+  static const bool valu_on = [] { const char* e = getenv("CLICA_CONV_VALU_STAGE1"); return !(e && atoi(e) == 0); }();
+  if (valu_on && scatter && K == 16 && Cout == 32 && aligned16(out) && images * ho * wo < ((int64_t)1 << 32)) {
+    // short contraction (one input channel): vector-ALU kernel, bound by the 128 B per pixel it writes
+    hipLaunchKernelGGL(conv_fwd_patches_valu_k<16>, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), patches, Wg, bias,
+                       (unsigned)(images * ho * wo), (int)Cout, (int)ho, (int)wo, (int)relu, out, gate_bits);
+    return launch_status("clica_conv_k4s2_fwd_patches(valu)");
+  }
+  return conv_fwd_launch(patches, K, 0, 0, Wg, bias, images * ho * wo, K, Cout, ho, wo, ho, wo, relu, scatter, out, gate_bits, as_stream(stream),
                          "clica_conv_k4s2_fwd_patches");
 }
 
 extern "C" int clica_conv_k4s2_fwd(const float* S, const float* Wg, const float* bias, int64_t images, int32_t C, int32_t Cout,
-                                   int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, clica_stream_t stream) {
+                                   int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, uint32_t* gate_bits,
+                                   clica_stream_t stream) {
   CLICA_CHECK_ARG(S && Wg && out && images > 0 && C >= 1 && C % 4 == 0 && Cout >= 1 && hs >= 2 && ws >= 2,
                   "clica_conv_k4s2_fwd: bad argument (C must be a multiple of 4)");
   CLICA_CHECK_ARG(!scatter || ((hs - 1) % 2 == 0 && (ws - 1) % 2 == 0), "clica_conv_k4s2_fwd: scatter needs an even output grid");
   CLICA_CHECK_ARG(aligned16(S) && aligned16(Wg), "clica_conv_k4s2_fwd: operands must be 16-byte aligned");
   return conv_fwd_launch(S, 4 * (int64_t)C, 8 * (int64_t)C, (int64_t)(ws - 2) * 4 * C, Wg, bias, images * hs * ws, 16 * C, Cout,
-                         hs, ws, hs - 1, ws - 1, relu, scatter, out, as_stream(stream), "clica_conv_k4s2_fwd");
+                         hs, ws, hs - 1, ws - 1, relu, scatter, out, gate_bits, as_stream(stream), "clica_conv_k4s2_fwd");
 }
 
 extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const float* S, int64_t images, int32_t C, int32_t Cout,
-                                     int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, clica_stream_t stream) {
+                                     int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, const uint32_t* gate_bits,
+                                     clica_stream_t stream) {
   CLICA_CHECK_ARG(dO && Wd && dPrev && images > 0 && C >= 1 && C % 4 == 0 && Cout >= 1 && Cout % 4 == 0 && hs >= 2 && ws >= 2,
                   "clica_conv_k4s2_dgrad: bad argument (C, Cout must be multiples of 4)");
   CLICA_CHECK_ARG(dhs >= 2 * (hs - 1) && dws >= 2 * (ws - 1), "clica_conv_k4s2_dgrad: destination grid smaller than 2 (hs - 1) x 2 (ws - 1)");
@@ -1665,7 +1740,13 @@ extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const flo
   ConvX cx{}; cx.a_seg = 2 * (int64_t)Cout; cx.a_jump = (int64_t)(ws - 2) * Cout; cx.mode = 2;
   cx.hs = hs; cx.ws = ws; cx.ho = hs; cx.wo = ws; cx.dhs = dhs; cx.dws = dws; cx.dho = 2 * (hs - 1); cx.dwo = 2 * (ws - 1); cx.c = C;
   cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
+  cx.gate_in = gate_bits;
+  CLICA_CHECK_ARG(!gate_bits || C % 32 == 0, "clica_conv_k4s2_dgrad: gate bits need C %% 32 == 0");
   CLICA_CHECK_ARG(g.M < (1 << 24), "clica_conv_k4s2_dgrad: %lld rows (the scattering epilogue handles < 2^24)", (long long)g.M);
+  static const int variant = [] { const char* e = getenv("CLICA_CONV_DGRAD_CFG"); return e ? atoi(e) : 0; }();
+  if (variant == 1) return launch_conv<128, 128, 2, 4, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
+  if (variant == 2) return launch_conv<64, 128, 2, 2, 3, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
+  if (variant == 3) return launch_conv<128, 128, 4, 2, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
   return launch_conv<64, 128, 2, 2, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
 }
 

@@ -393,17 +393,22 @@ int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_
  *          (ws + 1) * Cout readable zeros IN FRONT of it;  Wd [4 Cout][4 C]: Wd[((1-dy) * 2 + (1-dx)) * Cout + co][j] = Wg[co][(dy * 2 + dx) * 4 C + j];
  *          the result, gated by ReLU' of the previous stage (S > 0), is scattered to dPrev[images][dhs][dws][C] = the previous
  *          stage's dO grid (its valid 2(hs-1) x 2(ws-1) pixels are all written, the others never).
+ *   gate_bits (optional, Cout resp. C a multiple of 32): the forward also writes one bit per output element, (out > 0), as words
+ *          [row][Cout / 32] on ITS row grid (scatter = 1 only); the NEXT stage's dgrad, whose destination grid that is, reads the bit
+ *          instead of the 4-byte element of S (the gate then costs 1/32 of the traffic: 485 -> 320 us on the widest stage).  NULL:
+ *          no bits are written / the gate is read from S.
  *   wgrad: dWg[Cout][16 C] (+)= sum_r dO[r]^T A[r],  db[Cout] (+)= sum_r dO[r]   (A = the stage's implicit patch rows of S)
  * ---------------------------------------------------------------------------------- */
 int clica_conv_im2col_k4s2(const float* x /*[images][C][H][W]*/, int64_t images, int32_t C, int32_t H, int32_t W,
                            float* patches /*[images * H/2 * W/2][16 C]*/, clica_stream_t stream);
 int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg /*[Cout][K]*/, const float* bias, int64_t images, int32_t K,
                                 int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
-                                clica_stream_t stream);
+                                uint32_t* gate_bits, clica_stream_t stream);
 int clica_conv_k4s2_fwd(const float* S, const float* Wg, const float* bias, int64_t images, int32_t C, int32_t Cout,
-                        int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, clica_stream_t stream);
+                        int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, uint32_t* gate_bits, clica_stream_t stream);
 int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const float* S, int64_t images, int32_t C, int32_t Cout,
-                          int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, clica_stream_t stream);
+                          int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, const uint32_t* gate_bits,
+                          clica_stream_t stream);
 int clica_conv_k4s2_wgrad_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes);
 int clica_conv_k4s2_wgrad(const float* dO, const float* S, int64_t images, int32_t C, int32_t Cout, int32_t hs, int32_t ws,
                           float* dWg, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
