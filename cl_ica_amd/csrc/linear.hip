@@ -133,6 +133,17 @@ struct Tile {
   }
 };
 
+// GEMM row -> (image, y, x) on the conv's hs x ws row grid without integer division: rows < 2^24 are exact in fp32, the rounded
+// reciprocal can miss the quotient by one either way, one correction step each.
+__device__ __forceinline__ void conv_row_to_pixel(const ConvX& cx, int64_t row, int& img, int& y, int& x) {
+  const int pix = cx.hs * cx.ws;
+  img = (int)((float)(int)row * cx.inv_pix);
+  int rem = (int)row - img * pix;
+  if (rem < 0) { --img; rem += pix; } else if (rem >= pix) { ++img; rem -= pix; }
+  y = (int)((float)rem * cx.inv_ws); x = rem - y * cx.ws;
+  if (x < 0) { --y; x += cx.ws; } else if (x >= cx.ws) { ++y; x -= cx.ws; }
+}
+
 // The workgroup's whole job for output tile (bx, by) and contraction split bz of problem g.
 template <int BM, int BN, int WM, int WN, int STAGES, bool A_CONTIG, bool B_CONTIG, int EPI, bool VEC, bool CONV = false>
 __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int by, const int bz, const ConvX cx = ConvX{}) {
@@ -166,6 +177,28 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float colsum = 0.f;  // wgrad: db partial for A_op row (threadIdx.x < BM), only blockIdx.x == 0
+
+  // conv data gradient: the gate words of this lane's output elements are requested HERE, a whole k-loop ahead of the epilogue that
+  // consumes them (fetched in the epilogue they were a dependent round trip in front of its stores: 80 us of the widest stage's 427)
+  unsigned gate_w[CONV ? NBM : 1][CONV ? NBN : 1][16];
+  if (CONV && cx.mode == 2 && cx.gate_in) {
+#pragma unroll
+    for (int i = 0; i < NBM; ++i)
+#pragma unroll
+      for (int j = 0; j < NBN; ++j) {
+        const int col = (int)n0 + wn * TN + j * 32 + l31;
+        const int q = col / cx.c, ch = col - q * cx.c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          int img, y, x;
+          conv_row_to_pixel(cx, row, img, y, x);
+          const int yy = 2 * y + (q >> 1) - 1, xx = 2 * x + (q & 1) - 1;
+          const bool ok = row < g.M && col < g.N && yy >= 0 && xx >= 0 && yy < cx.dho && xx < cx.dwo;
+          gate_w[i][j][r] = ok ? cx.gate_in[(((int64_t)img * cx.dhs + yy) * cx.dws + xx) * (cx.c >> 5) + (ch >> 5)] : 0u;
+        }
+      }
+  }
 
   // Pipeline: STAGES LDS stages + one register stage for the global loads + double-buffered MFMA
   // fragments.
@@ -271,13 +304,8 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
           const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           off[r] = -1; gate[r] = 1.f;
           if (row >= g.M) continue;
-          // row -> (image, y, x) without integer division: rows < 2^24 are exact in fp32, the rounded reciprocal can miss the
-          // quotient by one either way, one correction step each
-          const int pix = cx.hs * cx.ws;
-          int img = (int)((float)(int)row * cx.inv_pix), rem = (int)row - img * pix;
-          if (rem < 0) { --img; rem += pix; } else if (rem >= pix) { ++img; rem -= pix; }
-          int y = (int)((float)rem * cx.inv_ws), x = rem - y * cx.ws;
-          if (x < 0) { --y; x += cx.ws; } else if (x >= cx.ws) { ++y; x -= cx.ws; }
+          int img, y, x;
+          conv_row_to_pixel(cx, row, img, y, x);
           if (cx.mode == 1) {
             // y, x = output pixel; it is element ((y+1)&1, (x+1)&1, col) of pixel ((y+1)/2, (x+1)/2) of the next layer's
             // padded space-to-depth input (4 * c channels)
@@ -291,8 +319,7 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
             if (yy < 0 || xx < 0 || yy >= cx.dho || xx >= cx.dwo) continue;
             off[r] = (((int64_t)img * cx.dhs + yy) * cx.dws + xx) * cx.c + ch;
             if (cx.gate_in) {
-              const unsigned word = cx.gate_in[(((int64_t)img * cx.dhs + yy) * cx.dws + xx) * (cx.c >> 5) + (ch >> 5)];
-              gate[r] = (word >> (ch & 31)) & 1u ? 1.f : 0.f;
+              gate[r] = (gate_w[i][j][r] >> (ch & 31)) & 1u ? 1.f : 0.f;
             } else if (gate_src) {
               gate[r] = gate_src[row * g.ldxa + col];
             }
@@ -1670,6 +1697,21 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
   }
 }
 
+// Weight re-ordering between nn.Conv2d's [co][c][ky][kx] and the GEMM layouts (forward rows, data-gradient rows, the zero-padded rows of
+// the 4 x 4 stage) and back for the gradients: up to MAXG index-mapped copies in ONE launch, dst[e] = map[e] >= 0 ? src[map[e]] : 0.
+// The maps are permutations the host builds once per shape (cl_ica_amd/conv.py applies its layout functions to an index tensor).
+struct GatherArgs { int n; const float* src[MAXG]; const int* map[MAXG]; float* dst[MAXG]; int count[MAXG]; };
+__global__ __launch_bounds__(256) void conv_gather_k(GatherArgs G) {
+  const int s = blockIdx.y;
+  const float* __restrict__ src = G.src[s];
+  const int* __restrict__ map = G.map[s];
+  float* __restrict__ dst = G.dst[s];
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < G.count[s]; e += gridDim.x * 256) {
+    const int m = map[e];
+    dst[e] = m >= 0 ? src[m] : 0.f;
+  }
+}
+
 struct PatchWgradPlan { int blocks; int64_t rows_per_block; };
 static bool patch_wgrad_ok(int32_t Cout, int32_t K) {
   if (Cout % 4 || K % 4) return false;
@@ -1813,4 +1855,19 @@ extern "C" int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patch
   if (rc) return rc;
   launch_slab_reduce(slab, dbslab, p.blocks, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
   return launch_status("clica_conv_k4s2_wgrad_patches(reduce)");
+}
+
+extern "C" int clica_conv_gather(int32_t n, const float* const* src, const int32_t* const* map, float* const* dst, const int32_t* count,
+                                 clica_stream_t stream) {
+  CLICA_CHECK_ARG(n >= 1 && n <= MAXG && src && map && dst && count, "clica_conv_gather: 1..%d segments", MAXG);
+  GatherArgs G{}; G.n = n;
+  int most = 0;
+  for (int i = 0; i < n; ++i) {
+    CLICA_CHECK_ARG(src[i] && map[i] && dst[i] && count[i] >= 0, "clica_conv_gather: segment %d: bad argument", i);
+    G.src[i] = src[i]; G.map[i] = map[i]; G.dst[i] = dst[i]; G.count[i] = count[i];
+    most = std::max(most, (int)count[i]);
+  }
+  if (most == 0) return CLICA_OK;
+  hipLaunchKernelGGL(conv_gather_k, dim3((unsigned)std::min<int64_t>(ceil_div(most, 256), 256), (unsigned)n), dim3(256), 0, as_stream(stream), G);
+  return launch_status("clica_conv_gather");
 }

@@ -5,7 +5,7 @@ profiles/r4_<c>_kernel_stats.csv (verbatim copy) + profiles/r4_<c>_summary.md.""
 import csv, json, os, shutil, sys
 
 BUCKETS = [
-    ("HIP library (cl_ica_amd: head Linear / Softclip / LeakyReLU, Lp loss sweeps, flat Adam)", lambda n: "clica::" in n),
+    ("HIP library (cl_ica_amd: conv stack of config 5 since the clica_conv_* kernels, head Linear / Softclip / LeakyReLU, Lp loss sweeps, flat Adam)", lambda n: "clica::" in n),
     ("MIOpen / rocBLAS convolution kernels (forward, data and weight gradients)",
      lambda n: any(t in n.lower() for t in ("conv", "igemm", "sp3", "cijk_", "gemm", "winograd", "im2col", "col2im", "miopen", "xdlops", "implicit"))
      and "batchnorm" not in n.lower() and "batch_norm" not in n.lower()),
