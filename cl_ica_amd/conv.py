@@ -55,6 +55,7 @@ class _Buffers:
             else:
                 self.dO[0] = torch.empty(images * ho * ho * cout, **f32)
             cin = cout
+        self.wpack = None                               # GEMM-layout weights of the step in flight (conv._maps order)
         self.O4 = torch.empty((images, 5 * 5 * 64), **f32)     # last stride-2 stage's output on its 5 x 5 row grid
         # first stage's weight gradient: the small-matrix streaming kernel where its shape fits (nc = 1), the grouped GEMM path otherwise
         self.ws1 = self.ws1p = None
@@ -103,6 +104,51 @@ def _w5(w: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(g, (0, 0, 0, 1, 0, 1)).reshape(w.shape[0], 5 * 5 * w.shape[1])
 
 
+def _w5_back(dw5g: torch.Tensor) -> torch.Tensor:
+    return dw5g.view(dw5g.shape[0], 5, 5, -1)[:, :4, :4, :].permute(0, 3, 1, 2)
+
+
+_MAPS: Dict[Tuple, dict] = {}
+
+
+def _maps(nc: int, device) -> dict:
+    """Index maps of every weight re-ordering of a step, built once by running the layout functions above on index tensors:
+    ``pack`` -- Conv2d.weight -> (W1g, W2g, W3g, W4g, W2d, W3d, W4d, W5g), ``unpack`` -- (dW1g .. dW5g) -> Conv2d.weight layout."""
+    key = (nc, device.index)
+    m = _MAPS.get(key)
+    if m is not None:
+        return m
+    shapes = [(STAGES[0][0], nc, 4, 4), (32, 32, 4, 4), (64, 32, 4, 4), (64, 64, 4, 4), (_FEATURES, 64, 4, 4)]
+
+    def idx(shape):
+        n = 1
+        for d in shape:
+            n *= d
+        return torch.arange(n, dtype=torch.int64).view(shape)
+
+    def i32(t):
+        return t.reshape(-1).to(torch.int32).to(device)
+
+    w = [idx(sh) for sh in shapes]
+    pack = [w[0].permute(0, 2, 3, 1).reshape(shapes[0][0], 16 * nc)] + [_wg(w[l]) for l in (1, 2, 3)] + [_wd(w[l]) for l in (1, 2, 3)]
+    pack.append(torch.nn.functional.pad(w[4].permute(0, 2, 3, 1), (0, 0, 0, 1, 0, 1), value=-1).reshape(_FEATURES, 5 * 5 * 64))
+    pack_src = [0, 1, 2, 3, 1, 2, 3, 4]
+    gshapes = [(shapes[0][0], 16 * nc), (32, 512), (64, 512), (64, 1024), (_FEATURES, 5 * 5 * 64)]
+    g = [idx(sh) for sh in gshapes]
+    unpack = [g[0].view(shapes[0][0], 4, 4, nc).permute(0, 3, 1, 2)] + [_wg_to_conv(g[l], shapes[l][0], shapes[l][1]) for l in (1, 2, 3)] + [_w5_back(g[4])]
+    m = {"pack": [i32(t) for t in pack], "pack_shapes": [tuple(t.shape) for t in pack], "pack_src": pack_src,
+         "unpack": [i32(t) for t in unpack], "shapes": shapes}
+    _MAPS[key] = m
+    return m
+
+
+def _gather(srcs, maps, dsts):
+    n = len(srcs)
+    VP, I32 = C.c_void_p * n, C.c_int32 * n
+    check(load().clica_conv_gather(n, VP(*[t.data_ptr() for t in srcs]), VP(*[t.data_ptr() for t in maps]), VP(*[t.data_ptr() for t in dsts]),
+                                   I32(*[t.numel() for t in dsts]), stream_ptr()), "clica_conv_gather")
+
+
 class _ConvStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, keep, *params):
@@ -113,7 +159,14 @@ class _ConvStackFn(torch.autograd.Function):
         buf = _take(images, nc, dev)
         x = x.detach().contiguous()
         check(lib.clica_conv_im2col_k4s2(x.data_ptr(), images, nc, _IMAGE, _IMAGE, buf.patches.data_ptr(), st), "clica_conv_im2col_k4s2")
-        w1g = ws_[0].detach().permute(0, 2, 3, 1).reshape(STAGES[0][0], 16 * nc)
+        m = _maps(nc, dev)
+        if buf.wpack is None:
+            buf.wpack = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in m["pack_shapes"]]
+        srcs = [ws_[i].detach() for i in m["pack_src"]]
+        if not all(t.is_contiguous() for t in srcs):
+            srcs = [t.contiguous() for t in srcs]
+        _gather(srcs, m["pack"], buf.wpack)          # W1g, W2g, W3g, W4g, W2d, W3d, W4d, W5g in one launch
+        w1g = buf.wpack[0]
         check(lib.clica_conv_k4s2_fwd_patches(buf.patches.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
                                               32, 32, 1, 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), st), "clica_conv_k4s2_fwd_patches")
         cin = STAGES[0][0]
@@ -121,10 +174,10 @@ class _ConvStackFn(torch.autograd.Function):
             cout, ho = STAGES[l]
             hs = ho + 1
             out = buf.S[l + 1] if l < 3 else buf.O4
-            check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), _wg(ws_[l]).data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
+            check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), buf.wpack[l].data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
                                           1, 1 if l < 3 else 0, out.data_ptr(), buf.gate[l].data_ptr() if l < 3 else None, st), "clica_conv_k4s2_fwd")
             cin = cout
-        w5g = _w5(ws_[4])
+        w5g = buf.wpack[7]
         feats = torch.empty((images, _FEATURES), dtype=torch.float32, device=dev)
         check(lib.clica_conv_k4s2_fwd_patches(buf.O4.data_ptr(), w5g.data_ptr(), ptr(bs_[4].detach()), images, 5 * 5 * 64, _FEATURES, 1, 1, 1, 0,
                                               feats.data_ptr(), None, st), "clica_conv_k4s2_fwd_patches")
@@ -147,8 +200,8 @@ class _ConvStackFn(torch.autograd.Function):
         grads: List = [None] * 10
         dpre = ops.leaky_relu_bwd(feats, dfeats.contiguous(), slope=0.0)
         dw5g, db5 = ops.linear_wgrad(dpre, buf.O4)
-        grads[8] = dw5g.view(_FEATURES, 5, 5, 64)[:, :4, :4, :].permute(0, 3, 1, 2).contiguous()
         grads[9] = db5
+        dwg_all = [None, None, None, None, dw5g]
         ops.linear_dgrad(dpre, ctx.w5g, buf.O4, slope=0.0, out=buf.dO[3].view(images, 5 * 5 * 64))
         for l in (3, 2, 1):
             cout, ho = STAGES[l]
@@ -160,9 +213,9 @@ class _ConvStackFn(torch.autograd.Function):
             db = torch.empty((cout,), dtype=torch.float32, device=dev)
             check(lib.clica_conv_k4s2_wgrad(buf.dO[l].data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs, dwg.data_ptr(), db.data_ptr(),
                                             0, wsp.data_ptr(), wsp.numel(), st), "clica_conv_k4s2_wgrad")
-            grads[2 * l], grads[2 * l + 1] = _wg_to_conv(dwg, cout, cin), db
+            dwg_all[l], grads[2 * l + 1] = dwg, db
             dgrid = STAGES[l - 1][1] + (1 if l > 1 else 0)          # previous stage's row grid (the first stage's is its 32 x 32 output)
-            check(lib.clica_conv_k4s2_dgrad(buf.dO[l].data_ptr(), _wd(ws_[l]).data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs,
+            check(lib.clica_conv_k4s2_dgrad(buf.dO[l].data_ptr(), buf.wpack[3 + l].data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs,
                                             buf.dO[l - 1].data_ptr(), dgrid, dgrid, buf.gate[l - 1].data_ptr(), st), "clica_conv_k4s2_dgrad")
         cout = STAGES[0][0]
         dw1g = torch.empty((cout, 16 * nc), dtype=torch.float32, device=dev)
@@ -172,7 +225,12 @@ class _ConvStackFn(torch.autograd.Function):
                                                     db1.data_ptr(), 0, buf.ws1p.data_ptr(), buf.ws1p.numel(), st), "clica_conv_k4s2_wgrad_patches")
         else:
             ops.mlp_wgrad([buf.dO[0].view(-1, cout)], [buf.patches], [dw1g], [db1], ws=buf.ws1)
-        grads[0], grads[1] = dw1g.view(cout, 4, 4, nc).permute(0, 3, 1, 2).contiguous(), db1
+        dwg_all[0], grads[1] = dw1g, db1
+        m = _maps(nc, dev)
+        out = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in m["shapes"]]
+        _gather(dwg_all, m["unpack"], out)           # the five weight gradients back in Conv2d.weight layout, one launch
+        for l in range(5):
+            grads[2 * l] = out[l]
         _give(buf, dev)
         return (None, None, *grads)
 

@@ -178,28 +178,6 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
 
   float colsum = 0.f;  // wgrad: db partial for A_op row (threadIdx.x < BM), only blockIdx.x == 0
 
-  // conv data gradient: the gate words of this lane's output elements are requested HERE, a whole k-loop ahead of the epilogue that
-  // consumes them (fetched in the epilogue they were a dependent round trip in front of its stores: 80 us of the widest stage's 427)
-  unsigned gate_w[CONV ? NBM : 1][CONV ? NBN : 1][16];
-  if (CONV && cx.mode == 2 && cx.gate_in) {
-#pragma unroll
-    for (int i = 0; i < NBM; ++i)
-#pragma unroll
-      for (int j = 0; j < NBN; ++j) {
-        const int col = (int)n0 + wn * TN + j * 32 + l31;
-        const int q = col / cx.c, ch = col - q * cx.c;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          int img, y, x;
-          conv_row_to_pixel(cx, row, img, y, x);
-          const int yy = 2 * y + (q >> 1) - 1, xx = 2 * x + (q & 1) - 1;
-          const bool ok = row < g.M && col < g.N && yy >= 0 && xx >= 0 && yy < cx.dho && xx < cx.dwo;
-          gate_w[i][j][r] = ok ? cx.gate_in[(((int64_t)img * cx.dhs + yy) * cx.dws + xx) * (cx.c >> 5) + (ch >> 5)] : 0u;
-        }
-      }
-  }
-
   // Pipeline: STAGES LDS stages + one register stage for the global loads + double-buffered MFMA
   // fragments.
   //   * registers hold tile t+1 at the top of iteration t; they are stored to LDS stage (t+1)%STAGES
@@ -319,7 +297,10 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
             if (yy < 0 || xx < 0 || yy >= cx.dho || xx >= cx.dwo) continue;
             off[r] = (((int64_t)img * cx.dhs + yy) * cx.dws + xx) * cx.c + ch;
             if (cx.gate_in) {
-              gate[r] = (gate_w[i][j][r] >> (ch & 31)) & 1u ? 1.f : 0.f;
+              // (requesting these words ahead of the k-loop instead was measured: 32 more live registers cost every data-gradient launch
+              //  20-40 % -- 427 -> 596 us on the widest stage -- far more than the dependent round trip here)
+              const unsigned word = cx.gate_in[(((int64_t)img * cx.dhs + yy) * cx.dws + xx) * (cx.c >> 5) + (ch >> 5)];
+              gate[r] = (word >> (ch & 31)) & 1u ? 1.f : 0.f;
             } else if (gate_src) {
               gate[r] = gate_src[row * g.ldxa + col];
             }
@@ -1568,6 +1549,7 @@ static int conv_fwd_launch(const float* A, int64_t lda, int64_t seg, int64_t jum
   if (scatter && rows >= (1 << 24)) { set_error("%s: %lld rows (the scattering epilogue handles < 2^24)", who, (long long)rows); return CLICA_E_INVALID; }
   // few rows (the k = 4 stage on the 4 x 4 map: images x 1600 -> 256): small tiles so that the launch still covers the chip
   if (Cout > 64 && rows <= 8192) return launch_conv<64, 64, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
+  // Cout = 32 measured on the 17 x 17 stage: 128 x 32 / 4 waves 286 us; 64 x 32 / 2 waves 312; 256 x 32 / 4 waves 392; 64 x 32 with 3 stages 392
   if (Cout <= 32) return launch_conv<128, 32, 4, 1, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);   // 3 workgroups x 4 waves per CU (LDS-limited)
   if (Cout <= 64) return launch_conv<128, 64, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
   return launch_conv<64, 128, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
@@ -1785,10 +1767,8 @@ extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const flo
   cx.gate_in = gate_bits;
   CLICA_CHECK_ARG(!gate_bits || C % 32 == 0, "clica_conv_k4s2_dgrad: gate bits need C %% 32 == 0");
   CLICA_CHECK_ARG(g.M < (1 << 24), "clica_conv_k4s2_dgrad: %lld rows (the scattering epilogue handles < 2^24)", (long long)g.M);
-  static const int variant = [] { const char* e = getenv("CLICA_CONV_DGRAD_CFG"); return e ? atoi(e) : 0; }();
-  if (variant == 1) return launch_conv<128, 128, 2, 4, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
-  if (variant == 2) return launch_conv<64, 128, 2, 2, 3, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
-  if (variant == 3) return launch_conv<128, 128, 4, 2, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
+  // tile shape measured on config 5 (steps/s): 64 x 128 / 4 waves 391; 128 x 128 / 8 waves 402 and 393 (2 x 4, 4 x 2 waves); three LDS stages 352
+  // -- within one box's spread except the last; the smallest LDS footprint is kept
   return launch_conv<64, 128, 2, 2, 2, true, false, EPI_DACT>(g, cx, 1, as_stream(stream), "clica_conv_k4s2_dgrad");
 }
 
