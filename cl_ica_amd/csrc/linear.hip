@@ -54,6 +54,7 @@ struct ConvX {
   int dhs, dws, dho, dwo;    // destination pixel grid (rows of dhs x dws per image, valid dho x dwo)
   int c;                     // channels per pixel of the scattered tensor: mode 1 = N, mode 2 = N / 4
   float inv_pix, inv_ws;     // 1 / (hs * ws), 1 / ws for the epilogues' row -> pixel arithmetic (rows < 2^24)
+  int fast;                  // contraction is a whole number of k-tiles and unsplit: CONTIG operands take Tile::load_fast
   unsigned* gate_out;        // mode 1: one bit per output element, (y > 0), word [row][col / 32] of this stage's row grid (or nullptr)
   const unsigned* gate_in;   // mode 2: the previous stage's gate bits on the destination grid (replaces the 4-byte gate read of xact)
 };
@@ -105,6 +106,27 @@ struct Tile {
       }
       r[i] = v;
     }
+  }
+
+  // Conv fast path (CONTIG operands, contraction a multiple of BK, no splits): per-thread row pointers are set up ONCE, a tile load is
+  // then one compare / select / add per thread and one 16-byte load per unit.  (The generic loader recomputes 64-bit row offsets, bounds and
+  // zero-page selects per unit and tile: PMC counted 9 vector instructions per MFMA on the 32-wide conv stage, 145 per 16-MFMA k-tile.)
+  // Rows past the end are clamped to the last row instead of zero-filled: their results are never stored.
+  struct Fast { const float* p[PER_THREAD]; int thr; };
+  static __device__ __forceinline__ void prep(Fast& f, const float* src, int64_t ld, int64_t row0, int64_t nrows, int64_t seg) {
+    const int kq = threadIdx.x % (BK / 4);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) {
+      const int row = (threadIdx.x + i * THREADS) / (BK / 4);
+      const int64_t gr = min(row0 + row, nrows - 1);
+      f.p[i] = src + gr * ld + 4 * kq;
+    }
+    f.thr = (int)min(seg, (int64_t)1 << 30) - 4 * kq;        // tile start k0 >= thr: this thread's float4 lies in the second run
+  }
+  static __device__ __forceinline__ void load_fast(float4 (&r)[PER_THREAD], const Fast& f, int k0, int jump) {
+    const int o = k0 + (k0 >= f.thr ? jump : 0);
+#pragma unroll
+    for (int i = 0; i < PER_THREAD; ++i) r[i] = *reinterpret_cast<const float4*>(f.p[i] + o);
   }
 
   static __device__ __forceinline__ void store(const float4 (&r)[PER_THREAD], float* lds) {
@@ -191,15 +213,27 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
   static_assert(STAGES == 2 || STAGES == 3, "2 or 3 LDS stages");
   constexpr int KSTEPS = BK / 8;
   float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
+  typename TA::Fast fa; typename TB::Fast fb;
+  const bool fast = CONV && cx.fast;                        // uniform: conv launch whose contraction is whole k-tiles, no splits
+  if (CONV && A_CONTIG && fast) TA::prep(fa, g.A, g.lda, m0, g.M, cx.a_jump ? cx.a_seg : (int64_t)1 << 30);
+  if (CONV && B_CONTIG && fast) TB::prep(fb, g.B, g.ldb, n0, g.N, (int64_t)1 << 30);
+  auto load_a = [&](int64_t k0) {
+    if (CONV && A_CONTIG && fast) TA::load_fast(ra, fa, (int)k0, (int)cx.a_jump);
+    else TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend, aseg, ajump);
+  };
+  auto load_b = [&](int64_t k0) {
+    if (CONV && B_CONTIG && fast) TB::load_fast(rb, fb, (int)k0, 0);
+    else TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend, bseg, bjump);
+  };
   const int ntiles = (int)((kend - kbeg + BK - 1) / BK);
   if (ntiles > 0) {
-    TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg, kend, aseg, ajump);
-    TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg, kend, bseg, bjump);
+    load_a(kbeg);
+    load_b(kbeg);
     TA::store(ra, smem);
     TB::store(rb, smem + TA::LDS_FLOATS);
     if (ntiles > 1) {
-      TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, kbeg + BK, kend, aseg, ajump);
-      TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, kbeg + BK, kend, bseg, bjump);
+      load_a(kbeg + BK);
+      load_b(kbeg + BK);
     }
   }
   __syncthreads();
@@ -239,8 +273,8 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
         }
         if (t + 2 < ntiles) {
           const int64_t k0 = kbeg + (int64_t)(t + 2) * BK;
-          TA::template load<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend, aseg, ajump);
-          TB::template load<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend, bseg, bjump);
+          load_a(k0);
+          load_b(k0);
         }
         if (STAGES == 3) __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -1545,6 +1579,7 @@ static int conv_fwd_launch(const float* A, int64_t lda, int64_t seg, int64_t jum
   cx.hs = hs; cx.ws = ws; cx.ho = ho; cx.wo = wo; cx.dhs = ho / 2 + 1; cx.dws = wo / 2 + 1; cx.c = Cout;
   cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
   cx.gate_out = gate_bits;
+  cx.fast = (K % BK == 0 && lda % 4 == 0 && jump % 4 == 0 && seg % 4 == 0 && jump < (1 << 30)) ? 1 : 0;
   if (gate_bits && !(scatter && Cout % 32 == 0)) { set_error("%s: gate bits need the scattering epilogue and Cout %% 32 == 0", who); return CLICA_E_INVALID; }
   if (scatter && rows >= (1 << 24)) { set_error("%s: %lld rows (the scattering epilogue handles < 2^24)", who, (long long)rows); return CLICA_E_INVALID; }
   // few rows (the k = 4 stage on the 4 x 4 map: images x 1600 -> 256): small tiles so that the launch still covers the chip
@@ -1765,6 +1800,7 @@ extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const flo
   cx.hs = hs; cx.ws = ws; cx.ho = hs; cx.wo = ws; cx.dhs = dhs; cx.dws = dws; cx.dho = 2 * (hs - 1); cx.dwo = 2 * (ws - 1); cx.c = C;
   cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
   cx.gate_in = gate_bits;
+  cx.fast = ((4 * Cout) % BK == 0 && cx.a_jump < (1 << 30)) ? 1 : 0;
   CLICA_CHECK_ARG(!gate_bits || C % 32 == 0, "clica_conv_k4s2_dgrad: gate bits need C %% 32 == 0");
   CLICA_CHECK_ARG(g.M < (1 << 24), "clica_conv_k4s2_dgrad: %lld rows (the scattering epilogue handles < 2^24)", (long long)g.M);
   // tile shape measured on config 5 (steps/s): 64 x 128 / 4 waves 391; 128 x 128 / 8 waves 402 and 393 (2 x 4, 4 x 2 waves); three LDS stages 352
