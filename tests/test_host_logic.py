@@ -460,3 +460,62 @@ def test_lazy_compute_many_after_step_and_shared_items_on_cpu():
     assert copy.deepcopy(outs[0]).item() == 1.5         # the attribute travels with copies / pickles of the tensor as plain numbers
     buf = io.BytesIO(); torch.save(outs[2], buf); buf.seek(0)
     assert torch.load(buf, weights_only=False).item() == 3.5
+
+
+def test_conv_stack_formulation_and_layouts_on_cpu():
+    """What the conv kernels compute (csrc/linear.hip, conv section), restated with torch ops in fp64 on the CPU and pinned against
+    nn.Conv2d's own arithmetic (/root/reference/kitti_masks/model.py:42-49: Conv2d(k = 4, stride 2, pad 1)): the padded space-to-depth
+    tensor, the two-run row operand on the whole hs x ws grid, the data-gradient operand on the zero-padded dO grid, the weight-gradient
+    contraction -- through the layout functions the GPU path uses (cl_ica_amd/conv.py: _wg, _wd, _wg_to_conv, _w5, _w5_back, and the
+    index maps clica_conv_gather is driven with)."""
+    from cl_ica_amd import conv
+    g = torch.Generator().manual_seed(5)
+    N, C_, Co, H = 3, 8, 12, 8
+    x = torch.randn(N, C_, H, H, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, C_, 4, 4, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(Co, generator=g, dtype=torch.float64, requires_grad=True)
+    ref = torch.nn.functional.conv2d(x, w, b, stride=2, padding=1)
+    dref = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dref)
+    ho, hs = H // 2, H // 2 + 1
+    # S[n][sy][sx][(py, px, c)] = x[n][c][2 sy + py - 1][2 sx + px - 1]
+    xp = torch.nn.functional.pad(x.detach().permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))            # NHWC, one zero pixel all round
+    S = xp.view(N, hs, 2, hs, 2, C_).permute(0, 1, 3, 2, 4, 5).reshape(N * hs * hs, 4 * C_)
+    rows = N * hs * hs
+    flat = torch.cat([S.reshape(-1), torch.zeros((hs + 2) * 4 * C_, dtype=torch.float64)])
+    A = torch.stack([torch.cat([flat[r * 4 * C_: r * 4 * C_ + 8 * C_], flat[(r + hs) * 4 * C_: (r + hs) * 4 * C_ + 8 * C_]]) for r in range(rows)])
+    out = (A @ conv._wg(w).t() + b.detach()).view(N, hs, hs, Co)[:, :ho, :ho, :]
+    assert rel_err(out.permute(0, 3, 1, 2).numpy(), ref.detach().numpy()) < 1e-13
+    # weight / bias gradient: dO on the whole grid, zero on the non-output rows
+    dO = torch.zeros(N, hs, hs, Co, dtype=torch.float64)
+    dO[:, :ho, :ho, :] = dref.permute(0, 2, 3, 1)
+    dO = dO.view(rows, Co)
+    assert rel_err(conv._wg_to_conv(dO.t() @ A, Co, C_).numpy(), w.grad.numpy()) < 1e-13
+    assert rel_err(dO.sum(0).numpy(), b.grad.numpy()) < 1e-13
+    # data gradient: two runs of dO, (hs + 1) rows of zeros in front; result row r = gradient of S pixel r
+    dflat = torch.cat([torch.zeros((hs + 1) * Co, dtype=torch.float64), dO.reshape(-1)])
+    Ad = torch.stack([torch.cat([dflat[r * Co: r * Co + 2 * Co], dflat[(r + hs) * Co: (r + hs) * Co + 2 * Co]]) for r in range(rows)])
+    dS = (Ad @ conv._wd(w)).view(N, hs, hs, 2, 2, C_)                                             # [n][sy][sx][py][px][c]
+    dxp = dS.permute(0, 1, 3, 2, 4, 5).reshape(N, 2 * hs, 2 * hs, C_)[:, 1:H + 1, 1:H + 1, :]     # pixel (2 sy + py - 1, 2 sx + px - 1)
+    assert rel_err(dxp.permute(0, 3, 1, 2).numpy(), x.grad.numpy()) < 1e-13
+    # the 4 x 4 stage as a Linear over the 5 x 5 row grid of the stage in front (zero columns for its non-output rows)
+    w5 = torch.randn(7, 6, 4, 4, generator=g, dtype=torch.float64)
+    a4 = torch.randn(2, 5, 5, 6, generator=g, dtype=torch.float64)                               # grid rows incl. garbage at y = 4 / x = 4
+    got = a4.reshape(2, -1) @ conv._w5(w5).t()
+    want = torch.nn.functional.conv2d(a4[:, :4, :4, :].permute(0, 3, 1, 2), w5).flatten(1)
+    assert rel_err(got.numpy(), want.numpy()) < 1e-13
+    d5 = torch.randn(7, 5 * 5 * 6, generator=g, dtype=torch.float64)
+    assert torch.equal(conv._w5_back(d5), d5.view(7, 5, 5, 6)[:, :4, :4, :].permute(0, 3, 1, 2))
+    # index maps = the layout functions (what clica_conv_gather executes on the device)
+    m = conv._maps(1, torch.device("cpu"))
+    ws = [torch.randn(sh, generator=g) for sh in m["shapes"]]
+    exp = [ws[0].permute(0, 2, 3, 1).reshape(32, 16)] + [conv._wg(ws[l]) for l in (1, 2, 3)] + [conv._wd(ws[l]) for l in (1, 2, 3)] + [conv._w5(ws[4])]
+    for i, (mp, src) in enumerate(zip(m["pack"], m["pack_src"])):
+        flat_w = ws[src].reshape(-1)
+        got = torch.where(mp >= 0, flat_w[mp.clamp(min=0).long()], torch.zeros(()))
+        assert torch.equal(got.view(exp[i].shape), exp[i]), i
+    gs = [torch.randn(32, 16, generator=g), torch.randn(32, 512, generator=g), torch.randn(64, 512, generator=g), torch.randn(64, 1024, generator=g),
+          torch.randn(256, 1600, generator=g)]
+    back = [gs[0].view(32, 4, 4, 1).permute(0, 3, 1, 2)] + [conv._wg_to_conv(gs[l], *m["shapes"][l][:2]) for l in (1, 2, 3)] + [conv._w5_back(gs[4])]
+    for i, mp in enumerate(m["unpack"]):
+        assert torch.equal(gs[i].reshape(-1)[mp.long()].view(m["shapes"][i]), back[i].contiguous()), i
