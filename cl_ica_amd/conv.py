@@ -241,6 +241,10 @@ def conv_stack(x: torch.Tensor, convs) -> torch.Tensor:
         raise ValueError(f"conv_stack: input must be (images, nc, {_IMAGE}, {_IMAGE}), got {tuple(x.shape)}")
     if x.dtype != torch.float32:
         raise TypeError(f"conv_stack: float32 input expected, got {x.dtype}")
+    if x.requires_grad and torch.is_grad_enabled():
+        # the first stage has no data-gradient kernel (the encoder's input is data); returning None for it silently would be wrong
+        raise NotImplementedError("conv_stack: gradients with respect to the input images are not provided (BetaVAE_H falls back to nn.Conv2d "
+                                  "for such inputs)")
     params = []
     for m in convs:
         if m.bias is None:

@@ -125,3 +125,15 @@ def test_conv_stack_buffers_are_reusable_and_switchable(monkeypatch):
     mu_lib = net(xa)
     PARITY.check("c5_conv_stack", "BetaVAE_H hip vs nn.Conv2d", "mu", mu_hip.detach().cpu().numpy(), mu_lib.detach().cpu().numpy(), tol=1e-4,
                  note="fp32 MIOpen on the other side, not an fp64 reference")
+
+
+def test_conv_stack_input_gradients_are_not_silently_dropped():
+    """conv_stack has no d/d(images): asking for it raises, and BetaVAE_H serves such inputs through nn.Conv2d (gradient present)."""
+    from cl_ica_amd import conv
+    from cl_ica_amd.kitti_masks.model import BetaVAE_H
+    x = torch.rand(4, 1, 64, 64, device="cuda", requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        conv.conv_stack(x, _convs(1))
+    net = BetaVAE_H(z_dim=5, nc=1, box_norm=False).to("cuda")
+    net(x).sum().backward()
+    assert x.grad is not None and float(x.grad.abs().max()) > 0
