@@ -18,6 +18,7 @@ from typing import Dict, List, Tuple
 import torch
 
 from . import ops
+from .encoders import _inplace_ok
 from ._lib import check, load, ptr, stream_ptr, workspace
 
 __all__ = ["conv_stack", "STAGES"]
@@ -142,11 +143,12 @@ def _maps(nc: int, device) -> dict:
     return m
 
 
-def _gather(srcs, maps, dsts):
+def _gather(srcs, maps, dsts, accumulate=False):
     n = len(srcs)
     VP, I32 = C.c_void_p * n, C.c_int32 * n
-    check(load().clica_conv_gather(n, VP(*[t.data_ptr() for t in srcs]), VP(*[t.data_ptr() for t in maps]), VP(*[t.data_ptr() for t in dsts]),
-                                   I32(*[t.numel() for t in dsts]), stream_ptr()), "clica_conv_gather")
+    check(load().clica_conv_gather(n, VP(*[t.data_ptr() for t in srcs]), VP(*[None if t is None else t.data_ptr() for t in maps]),
+                                   VP(*[t.data_ptr() for t in dsts]), I32(*[t.numel() for t in dsts]), int(accumulate), stream_ptr()),
+          "clica_conv_gather")
 
 
 class _ConvStackFn(torch.autograd.Function):
@@ -183,6 +185,7 @@ class _ConvStackFn(torch.autograd.Function):
                                               feats.data_ptr(), None, st), "clica_conv_k4s2_fwd_patches")
         if keep:
             ctx.buf, ctx.w5g, ctx.nc = buf, w5g, nc
+            ctx.params = params
             ctx.save_for_backward(feats, *ws_)
         else:
             _give(buf, dev)
@@ -227,10 +230,18 @@ class _ConvStackFn(torch.autograd.Function):
             ops.mlp_wgrad([buf.dO[0].view(-1, cout)], [buf.patches], [dw1g], [db1], ws=buf.ws1)
         dwg_all[0], grads[1] = dw1g, db1
         m = _maps(nc, dev)
-        out = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in m["shapes"]]
-        _gather(dwg_all, m["unpack"], out)           # the five weight gradients back in Conv2d.weight layout, one launch
-        for l in range(5):
-            grads[2 * l] = out[l]
+        prm = ctx.params
+        if _inplace_ok(prm, (True, True) + tuple(ctx.needs_input_grad[2:])):
+            # flat optimizer + a plain loss.backward(): the ten gradients are ADDED into its .grad views by one launch (what autograd's
+            # AccumulateGrad nodes would do with ten adds) and autograd is handed None -- same rule as the MLP encoders (encoders._inplace_ok)
+            _gather(dwg_all + [grads[2 * l + 1] for l in range(5)], m["unpack"] + [None] * 5,
+                    [prm[2 * l].grad for l in range(5)] + [prm[2 * l + 1].grad for l in range(5)], accumulate=True)
+            grads = [None] * 10
+        else:
+            out = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in m["shapes"]]
+            _gather(dwg_all, m["unpack"], out)           # the five weight gradients back in Conv2d.weight layout, one launch
+            for l in range(5):
+                grads[2 * l] = out[l]
         _give(buf, dev)
         return (None, None, *grads)
 

@@ -1720,15 +1720,17 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
 // Weight re-ordering between nn.Conv2d's [co][c][ky][kx] and the GEMM layouts (forward rows, data-gradient rows, the zero-padded rows of
 // the 4 x 4 stage) and back for the gradients: up to MAXG index-mapped copies in ONE launch, dst[e] = map[e] >= 0 ? src[map[e]] : 0.
 // The maps are permutations the host builds once per shape (cl_ica_amd/conv.py applies its layout functions to an index tensor).
-struct GatherArgs { int n; const float* src[MAXG]; const int* map[MAXG]; float* dst[MAXG]; int count[MAXG]; };
+constexpr int MAXGATHER = 16;
+struct GatherArgs { int n, accumulate; const float* src[MAXGATHER]; const int* map[MAXGATHER]; float* dst[MAXGATHER]; int count[MAXGATHER]; };
 __global__ __launch_bounds__(256) void conv_gather_k(GatherArgs G) {
   const int s = blockIdx.y;
   const float* __restrict__ src = G.src[s];
-  const int* __restrict__ map = G.map[s];
+  const int* __restrict__ map = G.map[s];            // nullptr: identity
   float* __restrict__ dst = G.dst[s];
   for (int e = blockIdx.x * 256 + threadIdx.x; e < G.count[s]; e += gridDim.x * 256) {
-    const int m = map[e];
-    dst[e] = m >= 0 ? src[m] : 0.f;
+    const int m = map ? map[e] : e;
+    const float v = m >= 0 ? src[m] : 0.f;
+    dst[e] = G.accumulate ? dst[e] + v : v;
   }
 }
 
@@ -1877,12 +1879,12 @@ extern "C" int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patch
 }
 
 extern "C" int clica_conv_gather(int32_t n, const float* const* src, const int32_t* const* map, float* const* dst, const int32_t* count,
-                                 clica_stream_t stream) {
-  CLICA_CHECK_ARG(n >= 1 && n <= MAXG && src && map && dst && count, "clica_conv_gather: 1..%d segments", MAXG);
-  GatherArgs G{}; G.n = n;
+                                 int32_t accumulate, clica_stream_t stream) {
+  CLICA_CHECK_ARG(n >= 1 && n <= MAXGATHER && src && map && dst && count, "clica_conv_gather: 1..%d segments", MAXGATHER);
+  GatherArgs G{}; G.n = n; G.accumulate = accumulate ? 1 : 0;
   int most = 0;
   for (int i = 0; i < n; ++i) {
-    CLICA_CHECK_ARG(src[i] && map[i] && dst[i] && count[i] >= 0, "clica_conv_gather: segment %d: bad argument", i);
+    CLICA_CHECK_ARG(src[i] && dst[i] && count[i] >= 0, "clica_conv_gather: segment %d: bad argument", i);
     G.src[i] = src[i]; G.map[i] = map[i]; G.dst[i] = dst[i]; G.count[i] = count[i];
     most = std::max(most, (int)count[i]);
   }

@@ -420,11 +420,12 @@ int clica_conv_k4s2_wgrad_patches_workspace_bytes(int64_t rows, int32_t Cout, in
 int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patches, int64_t rows, int32_t Cout, int32_t K, float* dWg, float* db,
                                   int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
-/* Weight re-ordering for the conv stack: n <= 8 index-mapped copies in one launch, dst[i][e] = map[i][e] >= 0 ? src[i][map[i][e]] : 0 for
+/* Weight re-ordering for the conv stack: n <= 16 index-mapped copies in one launch, dst[i][e] (+)= map[i][e] >= 0 ? src[i][map[i][e]] : 0 for
  * e < count[i] (nn.Conv2d.weight [co][c][ky][kx] -> Wg / Wd / the zero-padded rows of the 4 x 4 stage before a step, GEMM-layout gradients
- * -> Conv2d.weight layout after it; the maps are permutations built once per shape by the caller). */
+ * -> Conv2d.weight layout after it; the maps are permutations built once per shape by the caller; map[i] = NULL is the identity, e.g. a
+ * bias gradient).  accumulate != 0 adds into dst: the step's gradients go straight into the optimizer's .grad views. */
 int clica_conv_gather(int32_t n, const float* const* src, const int32_t* const* map, float* const* dst, const int32_t* count,
-                      clica_stream_t stream);
+                      int32_t accumulate, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Mixing network g  --  construct_invertible_mlp's nn.Sequential forward,
