@@ -1623,6 +1623,22 @@ __global__ __launch_bounds__(256) void conv_im2col_k4s2_k(const float* __restric
   for (int c = 0; c < C; ++c) dst[c] = in ? src[(int64_t)c * H * W] : 0.f;
 }
 
+// One input channel (the masks): a thread owns one window ROW of one output pixel -- four taps, one 16-byte store (the generic kernel's
+// 4-byte stores were instruction-bound: 69 us for 167 MB).
+__global__ __launch_bounds__(256) void conv_im2col_k4s2_c1_k(const float* __restrict__ x, unsigned pixels, int H, int W, float* __restrict__ patches) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  const unsigned pixel = t >> 2, ky = t & 3u;
+  if (pixel >= pixels) return;
+  const unsigned Wo = W / 2, Ho = H / 2;
+  const unsigned prow = pixel / Wo, ox = pixel - prow * Wo, img = prow / Ho, oy = prow - img * Ho;
+  const int y = 2 * (int)oy + (int)ky - 1, x0 = 2 * (int)ox - 1;
+  const bool rin = y >= 0 && y < H;
+  const float* rowp = x + ((int64_t)img * H + (rin ? y : 0)) * W;
+  const bool i0 = rin && x0 >= 0, i3 = rin && x0 + 3 < W;
+  const float v0 = rowp[i0 ? x0 : 0], v1 = rowp[x0 + 1], v2 = rowp[x0 + 2], v3 = rowp[i3 ? x0 + 3 : 0];
+  *reinterpret_cast<float4*>(patches + (int64_t)pixel * 16 + 4 * ky) = make_float4(i0 ? v0 : 0.f, rin ? v1 : 0.f, rin ? v2 : 0.f, i3 ? v3 : 0.f);
+}
+
 // First stage's weight / bias gradient from the patch matrix: dWg[Cout][K] = dO[rows][Cout]^T P[rows][K] with Cout x K small (32 x 16 for the
 // masks) and rows in the millions -- HBM-bound (dO 128 B + P 64 B per row).  A thread owns a 4 x 4 block of dWg; the (Cout/4)(K/4)
 // threads of a group read one row's dO and P as float4s (the same 128 / 64 bytes for the whole group: one cache line each), the
@@ -1676,21 +1692,34 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
                                                                 int relu, float* __restrict__ out, unsigned* __restrict__ gate_out) {
   const int groups = Cout / 8;                          // threads per pixel
   const int cg = threadIdx.x % groups;
+  // channel of this thread's c-th output: two runs of four, [4 cg, 4 cg + 4) and [Cout/2 + 4 cg, ...), so that each of the thread's two
+  // 16-byte stores is contiguous with its neighbours' (a pixel's group writes 64 contiguous bytes per store instruction, not 16 of every 32)
+  const int half = Cout / 2;
+  auto chan = [&](int c) { return c < 4 ? 4 * cg + c : half + 4 * cg + (c - 4); };
   float w[8][K], b[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    b[c] = bias ? bias[8 * cg + c] : 0.f;
+    b[c] = bias ? bias[chan(c)] : 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) w[c][k] = Wg[(8 * cg + c) * K + k];
+    for (int k = 0; k < K; ++k) w[c][k] = Wg[chan(c) * K + k];
   }
   const unsigned per_block = 256 / groups, stride = gridDim.x * per_block;
   const int dhs = ho / 2 + 1, dws = wo / 2 + 1;
-  for (unsigned pixel = blockIdx.x * per_block + threadIdx.x / groups; pixel < pixels; pixel += stride) {
+  // the next pixel's patch is requested before this pixel's arithmetic (load -> use was an exposed round trip per pixel: PMC had the waves
+  // waiting 61 % of their cycles at three waves per SIMD)
+  float4 nxt[K / 4];
+  const unsigned first = blockIdx.x * per_block + threadIdx.x / groups;
+  if (first < pixels) {
+#pragma unroll
+    for (int k = 0; k < K; k += 4) nxt[k / 4] = *reinterpret_cast<const float4*>(P + (int64_t)first * K + k);
+  }
+  for (unsigned pixel = first; pixel < pixels; pixel += stride) {
     float a[K];
 #pragma unroll
-    for (int k = 0; k < K; k += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(P + (int64_t)pixel * K + k);
-      a[k] = v.x; a[k + 1] = v.y; a[k + 2] = v.z; a[k + 3] = v.w;
+    for (int k = 0; k < K; k += 4) { a[k] = nxt[k / 4].x; a[k + 1] = nxt[k / 4].y; a[k + 2] = nxt[k / 4].z; a[k + 3] = nxt[k / 4].w; }
+    if (pixel + stride < pixels) {
+#pragma unroll
+      for (int k = 0; k < K; k += 4) nxt[k / 4] = *reinterpret_cast<const float4*>(P + (int64_t)(pixel + stride) * K + k);
     }
     float o[8];
 #pragma unroll
@@ -1703,13 +1732,13 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
     }
     const unsigned prow = pixel / (unsigned)wo, x = pixel - prow * (unsigned)wo, img = prow / (unsigned)ho, y = prow - img * (unsigned)ho;
     const unsigned Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
-    float* dst = out + (((int64_t)img * dhs + Y) * dws + X) * (4 * Cout) + qq * Cout + 8 * cg;
+    float* dst = out + (((int64_t)img * dhs + Y) * dws + X) * (4 * Cout) + qq * Cout + 4 * cg;
     *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<float4*>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    *reinterpret_cast<float4*>(dst + half) = make_float4(o[4], o[5], o[6], o[7]);
     if (gate_out) {               // Cout == 32: the four threads of a pixel combine their 8 bits into the pixel's gate word
       unsigned bits = 0;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) bits |= (o[c] > 0.f ? 1u : 0u) << (8 * cg + c);
+      for (int c = 0; c < 8; ++c) bits |= (o[c] > 0.f ? 1u : 0u) << chan(c);
       bits |= __shfl_xor(bits, 1);
       bits |= __shfl_xor(bits, 2);
       if (cg == 0) gate_out[pixel] = bits;
@@ -1756,8 +1785,12 @@ extern "C" int clica_conv_im2col_k4s2(const float* x, int64_t images, int32_t C,
                   "clica_conv_im2col_k4s2: bad argument (even H, W required)");
   const int64_t pixels = images * (H / 2) * (W / 2);
   CLICA_CHECK_ARG(pixels * 16 < ((int64_t)1 << 32), "clica_conv_im2col_k4s2: %lld output pixels (< 2^28 supported)", (long long)pixels);
-  hipLaunchKernelGGL(conv_im2col_k4s2_k, dim3((unsigned)ceil_div(pixels * 16, 256)), dim3(256), 0, as_stream(stream), x, (unsigned)pixels,
-                     (int)C, (int)H, (int)W, patches);
+  if (C == 1 && aligned16(patches))
+    hipLaunchKernelGGL(conv_im2col_k4s2_c1_k, dim3((unsigned)ceil_div(pixels * 4, 256)), dim3(256), 0, as_stream(stream), x, (unsigned)pixels,
+                       (int)H, (int)W, patches);
+  else
+    hipLaunchKernelGGL(conv_im2col_k4s2_k, dim3((unsigned)ceil_div(pixels * 16, 256)), dim3(256), 0, as_stream(stream), x, (unsigned)pixels,
+                       (int)C, (int)H, (int)W, patches);
   return launch_status("clica_conv_im2col_k4s2");
 }
 
