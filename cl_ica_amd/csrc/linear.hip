@@ -1598,9 +1598,10 @@ static ConvWgradPlan plan_conv_wgrad(int64_t rows, int32_t Cout, int32_t K) {
   ConvWgradPlan p;
   p.bm = Cout <= 32 ? 32 : 64;
   const int64_t tiles = ceil_div(Cout, p.bm) * ceil_div(K, 128);
-  // ~three small workgroups per CU, and contraction chains of at most ~1024 rows: an accumulator adds its rows one after the other, and
-  // over the 592 k rows of the widest stage 3 000-row chains measured 1.2e-5 of max|dW| against fp64 (1 000-row chains: see tests)
-  int64_t want = std::max<int64_t>(std::max<int64_t>(1, 3 * kNumCU / tiles), ceil_div(rows, 1024));
+  // ~three small workgroups per CU.  (Capping the contraction chains at ~1024 rows -- 578 splits on the widest stage -- was tried when that
+  // stage's dW read 1.2e-5 against fp64: the figure did not move, it was a ReLU gate tie, see tests/test_gpu_conv.py; the extra slabs only
+  // cost the reduction 25 us.)
+  int64_t want = std::max<int64_t>(1, 3 * kNumCU / tiles);
   want = std::min<int64_t>(want, std::max<int64_t>(1, rows / (8 * BK)));
   p.k_per_split = ceil_div(ceil_div(rows, want), (int64_t)BK) * BK;
   p.splits = (int)ceil_div(rows, p.k_per_split);
