@@ -57,7 +57,7 @@ class _Buffers:
                 self.dO[0] = torch.empty(images * ho * ho * cout, **f32)
             cin = cout
         self.wpack = None                               # GEMM-layout weights of the step in flight (conv._maps order)
-        self.O4 = torch.empty((images, 5 * 5 * 64), **f32)     # last stride-2 stage's output on its 5 x 5 row grid
+        self.O4 = torch.zeros((images, 5 * 5 * 64), **f32)     # last stride-2 stage's output on its 5 x 5 row grid (non-output rows stay 0)
         # first stage's weight gradient: the small-matrix streaming kernel where its shape fits (nc = 1), the grouped GEMM path otherwise
         self.ws1 = self.ws1p = None
         if 256 % ((STAGES[0][0] // 4) * (16 * nc // 4)) == 0:
@@ -177,7 +177,7 @@ class _ConvStackFn(torch.autograd.Function):
             hs = ho + 1
             out = buf.S[l + 1] if l < 3 else buf.O4
             check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), buf.wpack[l].data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
-                                          1, 1 if l < 3 else 0, out.data_ptr(), buf.gate[l].data_ptr() if l < 3 else None, st), "clica_conv_k4s2_fwd")
+                                          1, 1 if l < 3 else 2, out.data_ptr(), buf.gate[l].data_ptr() if l < 3 else None, st), "clica_conv_k4s2_fwd")
             cin = cout
         w5g = buf.wpack[7]
         feats = torch.empty((images, _FEATURES), dtype=torch.float32, device=dev)

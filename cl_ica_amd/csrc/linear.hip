@@ -55,6 +55,8 @@ struct ConvX {
   int c;                     // channels per pixel of the scattered tensor: mode 1 = N, mode 2 = N / 4
   float inv_pix, inv_ws;     // 1 / (hs * ws), 1 / ws for the epilogues' row -> pixel arithmetic (rows < 2^24)
   int fast;                  // contraction is a whole number of k-tiles and unsplit: CONTIG operands take Tile::load_fast
+  int compact;               // forward only (needs fast): GEMM rows run over the OUTPUT pixels alone (hs = ho, ws = wo above) and a row's
+  int ghs, gws;              // A pointer is taken at pixel (y, x) of the ghs x gws grid S is stored on -- no work on non-output rows
   unsigned* gate_out;        // mode 1: one bit per output element, (y > 0), word [row][col / 32] of this stage's row grid (or nullptr)
   const unsigned* gate_in;   // mode 2: the previous stage's gate bits on the destination grid (replaces the 4-byte gate read of xact)
 };
@@ -215,7 +217,18 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
   float4 ra[TA::PER_THREAD], rb[TB::PER_THREAD];
   typename TA::Fast fa; typename TB::Fast fb;
   const bool fast = CONV && cx.fast;                        // uniform: conv launch whose contraction is whole k-tiles, no splits
-  if (CONV && A_CONTIG && fast) TA::prep(fa, g.A, g.lda, m0, g.M, cx.a_jump ? cx.a_seg : (int64_t)1 << 30);
+  if (CONV && A_CONTIG && fast) {
+    TA::prep(fa, g.A, g.lda, m0, g.M, cx.a_jump ? cx.a_seg : (int64_t)1 << 30);
+    if (cx.compact) {          // row -> output pixel -> its place on the storage grid
+#pragma unroll
+      for (int i = 0; i < TA::PER_THREAD; ++i) {
+        const int row = (threadIdx.x + i * THREADS) / (BK / 4);
+        int img, y, x;
+        conv_row_to_pixel(cx, min(m0 + row, g.M - 1), img, y, x);
+        fa.p[i] = g.A + (((int64_t)img * cx.ghs + y) * cx.gws + x) * g.lda + 4 * (threadIdx.x % (BK / 4));
+      }
+    }
+  }
   if (CONV && B_CONTIG && fast) TB::prep(fb, g.B, g.ldb, n0, g.N, (int64_t)1 << 30);
   auto load_a = [&](int64_t k0) {
     if (CONV && A_CONTIG && fast) TA::load_fast(ra, fa, (int)k0, (int)cx.a_jump);
@@ -311,6 +324,7 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
         float* __restrict__ dst = g.C;
         int64_t off[16];
         float gate[16];
+        int grid_row[16];                                                 // mode 1: the row's index on the stage's storage grid (gate words)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -318,12 +332,18 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
           if (row >= g.M) continue;
           int img, y, x;
           conv_row_to_pixel(cx, row, img, y, x);
-          if (cx.mode == 1) {
+          if (cx.mode == 3) {
+            // plain rows, but at the row's place on the storage grid: only output rows are computed and written (the others stay what
+            // the caller put there once: zeros)
+            if (y >= cx.ho || x >= cx.wo) continue;
+            off[r] = (int64_t)((img * cx.ghs + y) * cx.gws + x) * g.ldc + col;
+          } else if (cx.mode == 1) {
             // y, x = output pixel; it is element ((y+1)&1, (x+1)&1, col) of pixel ((y+1)/2, (x+1)/2) of the next layer's
             // padded space-to-depth input (4 * c channels)
             if (y >= cx.ho || x >= cx.wo) continue;
             const int Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
             off[r] = (((int64_t)img * cx.dhs + Y) * cx.dws + X) * (4 * cx.c) + qq * cx.c + col;
+            grid_row[r] = (img * cx.ghs + y) * cx.gws + x;
           } else {
             // y, x = pixel of this layer's space-to-depth input, column q = (py, px): the gradient of the previous layer's
             // output pixel (2y + py - 1, 2x + px - 1), gated by that output's ReLU (xact = the space-to-depth tensor itself)
@@ -344,7 +364,7 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
         for (int r = 0; r < 16; ++r) {
           if (off[r] < 0) continue;
           float v = acc[i][j][r];
-          if (cx.mode == 1) {
+          if (cx.mode == 1 || cx.mode == 3) {
             v += bv;
             if (g.leaky) v = v > 0.f ? v : v * g.slope;
           } else if (gate_src || cx.gate_in) {
@@ -354,8 +374,7 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
           if (cx.mode == 1 && cx.gate_out) {
             // the 32 lanes of a half-wave hold 32 consecutive channels of one row: their (v > 0) bits are one word of the gate tensor
             const unsigned long long bits = __ballot(v > 0.f);
-            const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (l31 == 0) cx.gate_out[row * (g.N >> 5) + (col >> 5)] = (unsigned)(bits >> (32 * h));
+            if (l31 == 0) cx.gate_out[(int64_t)grid_row[r] * (g.N >> 5) + (col >> 5)] = (unsigned)(bits >> (32 * h));
           }
         }
         continue;
@@ -1575,15 +1594,20 @@ static int launch_conv(const Args& g, const ConvX& cx, int splits, hipStream_t s
 // forward of one stage from either operand form
 static int conv_fwd_launch(const float* A, int64_t lda, int64_t seg, int64_t jump, const float* Wg, const float* bias, int64_t rows,
                            int32_t K, int32_t Cout, int32_t hs, int32_t ws, int32_t ho, int32_t wo, int32_t relu, int32_t scatter,
-                           float* out, uint32_t* gate_bits, hipStream_t st, const char* who) {
+                           float* out, uint32_t* gate_bits, hipStream_t st, const char* who, int compact = 0) {
+  const int ghs = hs, gws = ws;
+  const bool fast_ok = K % BK == 0 && lda % 4 == 0 && jump % 4 == 0 && seg % 4 == 0 && jump < (1 << 30);
+  if (compact && fast_ok && scatter) { rows = rows / ((int64_t)hs * ws) * ((int64_t)ho * wo); hs = ho; ws = wo; } else { compact = 0; }
+  if (scatter == 2 && !compact) { set_error("%s: scatter = 2 needs a contraction of whole k-tiles", who); return CLICA_E_INVALID; }
   Args g{}; g.A = A; g.lda = lda; g.B = Wg; g.ldb = K; g.C = out; g.ldc = Cout; g.M = rows; g.N = Cout; g.Kc = K;
   g.bias = bias; g.leaky = relu ? 1 : 0; g.slope = 0.f;
-  ConvX cx{}; cx.a_seg = seg; cx.a_jump = jump; cx.mode = scatter ? 1 : 0;
+  ConvX cx{}; cx.a_seg = seg; cx.a_jump = jump; cx.mode = scatter == 2 ? 3 : (scatter ? 1 : 0);
   cx.hs = hs; cx.ws = ws; cx.ho = ho; cx.wo = wo; cx.dhs = ho / 2 + 1; cx.dws = wo / 2 + 1; cx.c = Cout;
   cx.inv_pix = 1.f / (float)(hs * ws); cx.inv_ws = 1.f / (float)ws;
   cx.gate_out = gate_bits;
-  cx.fast = (K % BK == 0 && lda % 4 == 0 && jump % 4 == 0 && seg % 4 == 0 && jump < (1 << 30)) ? 1 : 0;
-  if (gate_bits && !(scatter && Cout % 32 == 0)) { set_error("%s: gate bits need the scattering epilogue and Cout %% 32 == 0", who); return CLICA_E_INVALID; }
+  cx.fast = fast_ok ? 1 : 0;
+  cx.compact = compact; cx.ghs = ghs; cx.gws = gws;
+  if (gate_bits && !(scatter == 1 && Cout % 32 == 0)) { set_error("%s: gate bits need the scattering epilogue and Cout %% 32 == 0", who); return CLICA_E_INVALID; }
   if (scatter && rows >= (1 << 24)) { set_error("%s: %lld rows (the scattering epilogue handles < 2^24)", who, (long long)rows); return CLICA_E_INVALID; }
   // few rows (the k = 4 stage on the 4 x 4 map: images x 1600 -> 256): small tiles so that the launch still covers the chip
   if (Cout > 64 && rows <= 8192) return launch_conv<64, 64, 2, 2, 2, true, true, EPI_BIAS_ACT>(g, cx, 1, st, who);
@@ -1907,7 +1931,7 @@ extern "C" int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg
   CLICA_CHECK_ARG(!scatter || (ho % 2 == 0 && wo % 2 == 0), "clica_conv_k4s2_fwd_patches: scatter needs an even output grid");
   CLICA_CHECK_ARG(aligned16(patches) && aligned16(Wg), "clica_conv_k4s2_fwd_patches: operands must be 16-byte aligned");
   static const bool valu_on = [] { const char* e = getenv("CLICA_CONV_VALU_STAGE1"); return !(e && atoi(e) == 0); }();
-  if (valu_on && scatter && K == 16 && Cout == 32 && aligned16(out) && images * ho * wo < ((int64_t)1 << 32)) {
+  if (valu_on && scatter == 1 && K == 16 && Cout == 32 && aligned16(out) && images * ho * wo < ((int64_t)1 << 32)) {
     // short contraction (one input channel): vector-ALU kernel, bound by the 128 B per pixel it writes
     hipLaunchKernelGGL(conv_fwd_patches_valu_k<16>, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), patches, Wg, bias,
                        (unsigned)(images * ho * wo), (int)Cout, (int)ho, (int)wo, (int)relu, out, gate_bits);
@@ -1922,10 +1946,12 @@ extern "C" int clica_conv_k4s2_fwd(const float* S, const float* Wg, const float*
                                    clica_stream_t stream) {
   CLICA_CHECK_ARG(S && Wg && out && images > 0 && C >= 1 && C % 4 == 0 && Cout >= 1 && hs >= 2 && ws >= 2,
                   "clica_conv_k4s2_fwd: bad argument (C must be a multiple of 4)");
-  CLICA_CHECK_ARG(!scatter || ((hs - 1) % 2 == 0 && (ws - 1) % 2 == 0), "clica_conv_k4s2_fwd: scatter needs an even output grid");
+  CLICA_CHECK_ARG(scatter != 1 || ((hs - 1) % 2 == 0 && (ws - 1) % 2 == 0), "clica_conv_k4s2_fwd: scatter = 1 needs an even output grid");
   CLICA_CHECK_ARG(aligned16(S) && aligned16(Wg), "clica_conv_k4s2_fwd: operands must be 16-byte aligned");
+  // scattering stages run their GEMM over the output pixels only (no work on the grid's non-output rows: 13 / 27 % of the 17 x 17 / 9 x 9 stages)
+  static const bool compact_on = [] { const char* e = getenv("CLICA_CONV_COMPACT"); return !(e && atoi(e) == 0); }();
   return conv_fwd_launch(S, 4 * (int64_t)C, 8 * (int64_t)C, (int64_t)(ws - 2) * 4 * C, Wg, bias, images * hs * ws, 16 * C, Cout,
-                         hs, ws, hs - 1, ws - 1, relu, scatter, out, gate_bits, as_stream(stream), "clica_conv_k4s2_fwd");
+                         hs, ws, hs - 1, ws - 1, relu, scatter, out, gate_bits, as_stream(stream), "clica_conv_k4s2_fwd", compact_on ? 1 : 0);
 }
 
 extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const float* S, int64_t images, int32_t C, int32_t Cout,

@@ -386,6 +386,8 @@ int clica_leaky_relu_bwd(const float* Yact, int64_t ldy, const float* dY, int64_
  *
  *   fwd:   scatter = 1: out = the NEXT stage's S tensor ([images][(hs-1)/2 + 1][(ws-1)/2 + 1][4 Cout], border pre-zeroed by
  *          the caller and never written);  scatter = 0: out[r][Cout] for every row r (non-output rows hold finite garbage).
+ *          scatter = 2: out[r][Cout] on the row grid like scatter = 0, but only the OUTPUT rows are computed and written (the caller
+ *          zeroes the buffer once; the GEMM then runs over images * (hs-1) * (ws-1) rows -- scatter = 1 does the same).
  *          relu != 0 applies ReLU after the bias.
  *   fwd_patches: the same from an explicit patch matrix [images * ho * wo][K] (first stage; clica_conv_im2col_k4s2 builds it
  *          from the NCHW input with K = 16 C, column (ky * 4 + kx) * C + c), rows = output pixels of an ho x wo grid.
