@@ -1619,105 +1619,72 @@ static int conv_fwd_launch(const float* A, int64_t lda, int64_t seg, int64_t jum
 
 // Data gradient of the widest stage (C = Cout = 32: a [rows x 128] x [128 x 128] product, 43 % of the stack's data-gradient work) as a
 // PERSISTENT kernel.  With a 128-deep contraction the tiled GEMM above is all prologue and epilogue (PMC: matrix pipes busy 0.34): every
-// 64-row workgroup re-reads the whole 64 KB operand matrix Wd and pays its load / barrier / scatter latencies for 4 k-tiles of work.  Here one
-// workgroup per CU (8 waves) keeps Wd in LDS for its whole life and walks over 256-row tiles; a tile's A operand is the block of dO rows
-// [r0 - ws - 1, r0 + 256) x 32 channels (39 KB, double-buffered: the next block is in flight while this one is multiplied), from which the
-// fragment of row r, contraction index (1 - dy, 1 - dx, co) is LDS row r + (1 - dy) ws + (1 - dx) -- no global A traffic and no barrier inside a
-// tile, and the scattering epilogue of one wave runs under the other waves' matrix work.
-constexpr int DG_ROWS = 256, DG_ALD = 36;
-__global__ __launch_bounds__(512) void conv_dgrad32_persist_k(const float* __restrict__ A0 /* dO - (ws + 1) * 32 */, const float* __restrict__ Wd,
-                                                              int64_t rows, float* __restrict__ dst, ConvX cx) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
+// 64-row workgroup re-reads the whole 64 KB operand matrix Wd and pays its load / barrier / scatter latencies for 4 k-tiles of work.  Here a
+// workgroup (8 waves, two per CU) keeps Wd in LDS for its whole life and walks over 256-row tiles.  A wave reads its A fragments -- row r,
+// contraction index (1 - dy, 1 - dx, co) = dO row r - ws - 1 + (1 - dy) ws + (1 - dx) -- straight from global memory two k-steps ahead (16
+// bytes per lane and step out of the same 19 KB of dO per 256 rows: L1 / L2 hits); there is no barrier after the first one, so waves drift
+// apart and one wave's scattering epilogue runs under the others' matrix work.  (A version that also staged the dO block in LDS, double-
+// buffered with one barrier per tile, measured 358-370 us against this one's 347; the tiled GEMM 427.)
+constexpr int DG_ROWS = 256;
+__global__ __launch_bounds__(512) void conv_dgrad32_stream_k(const float* __restrict__ A0 /* dO - (ws + 1) * 32 */, const float* __restrict__ Wd,
+                                                             int64_t rows, float* __restrict__ dst, ConvX cx) {
+  extern __shared__ __attribute__((aligned(16))) float sB[];   // [128][128]
   const int ws = cx.ws;
-  const int nblk = DG_ROWS + ws + 2;                       // dO rows per tile block
-  float* const sB = sm;                                      // [128][128]
-  float* const sA = sm + 128 * 128;                          // two buffers of nblk x DG_ALD
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
   for (int u = threadIdx.x; u < 128 * 32; u += 512) reinterpret_cast<float4*>(sB)[u] = reinterpret_cast<const float4*>(Wd)[u];
+  __syncthreads();
   const int64_t ntiles = (rows + DG_ROWS - 1) / DG_ROWS;
   const int64_t last = rows + ws;                            // last readable row of A0
-  constexpr int PER = 5;                                     // float4 units per thread of a block: (256 + 19 + 2) * 8 / 512 <= 5 for ws <= 33
-  float4 stage[PER];
-  auto fetch = [&](int64_t tile) {
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t r0 = tile * DG_ROWS;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int u = threadIdx.x + i * 512;
-      const int row = u >> 3, c4 = u & 7;
-      const int64_t gr = min(r0 + min(row, nblk - 1), last);
-      stage[i] = *reinterpret_cast<const float4*>(A0 + gr * 32 + 4 * c4);
-    }
-  };
-  auto stash = [&](float* buf) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int u = threadIdx.x + i * 512;
-      const int row = u >> 3, c4 = u & 7;
-      if (row < nblk) *reinterpret_cast<float4*>(&buf[row * DG_ALD + 4 * c4]) = stage[i];
-    }
-  };
-  int64_t tile = blockIdx.x;
-  if (tile < ntiles) { fetch(tile); stash(sA); }
-  __syncthreads();
-  int cur = 0;
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int64_t nxt = tile + gridDim.x;
-    if (nxt < ntiles) fetch(nxt);
-    const float* a_s = sA + cur * nblk * DG_ALD;
-    const int rl = wave * 32 + l31;
+    const int64_t rbase = r0 + wave * 32 + l31;
+    auto lda = [&](int st) {
+      const int64_t gr = min(rbase + (st >> 3) * ws + ((st & 7) >> 2), last);
+      return *reinterpret_cast<const float4*>(A0 + gr * 32 + 8 * (st & 3) + 4 * h);
+    };
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    // fragments of k-step st + 1 are read from LDS while the MFMAs of k-step st run (explicit double buffer, as in gemm_body)
-    float a4[2][4], b4[2][4][4];
-    auto frags = [&](int buf, int st) {
-      // k = 8 st + 4 h + t: run (st >> 3) = 1 - dy, piece ((st & 7) >> 2) = 1 - dx, channel 8 (st & 3) + 4 h + t
-      const float4 av = *reinterpret_cast<const float4*>(&a_s[(rl + (st >> 3) * ws + ((st & 7) >> 2)) * DG_ALD + 8 * (st & 3) + 4 * h]);
-      a4[buf][0] = av.x; a4[buf][1] = av.y; a4[buf][2] = av.z; a4[buf][3] = av.w;
+    float4 aq[3];
+    aq[0] = lda(0); aq[1] = lda(1);
+    float b4[2][4][4];
+    auto bfr = [&](int buf, int st) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) b4[buf][j][t] = sB[(8 * st + 4 * h + t) * 128 + j * 32 + l31];
     };
-    frags(0, 0);
+    bfr(0, 0);
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
-      if (st + 1 < 16) frags((st + 1) & 1, st + 1);
+      if (st + 2 < 16) aq[(st + 2) % 3] = lda(st + 2);
+      if (st + 1 < 16) bfr((st + 1) & 1, st + 1);
       __builtin_amdgcn_sched_barrier(0);
+      const float4 av = aq[st % 3];
+      const float a4[4] = {av.x, av.y, av.z, av.w};
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[st & 1][t], b4[st & 1][j][t], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[t], b4[st & 1][j][t], acc[j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // epilogue: column block j = (py, px) = (j >> 1, j & 1), channel l31; gated scatter to the previous stage's dO grid
-    const int64_t r0 = tile * DG_ROWS;
-    // two passes: all 64 gate words of the lane are requested first (one round trip, not 64), then the stores
-    int pixi[16][4];
-    unsigned gw[16][4];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int64_t row = r0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row >= rows) continue;
       int img, y, x;
       conv_row_to_pixel(cx, row, img, y, x);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int yy = 2 * y + (j >> 1) - 1, xx = 2 * x + (j & 1) - 1;
-        const bool ok = row < rows && yy >= 0 && xx >= 0 && yy < cx.dho && xx < cx.dwo;
-        pixi[r][j] = ok ? (img * cx.dhs + yy) * cx.dws + xx : -1;
-        gw[r][j] = ok ? cx.gate_in[pixi[r][j]] : 0u;
+        if (yy < 0 || xx < 0 || yy >= cx.dho || xx >= cx.dwo) continue;
+        const int64_t pix = ((int64_t)img * cx.dhs + yy) * cx.dws + xx;
+        const unsigned word = cx.gate_in[pix];
+        dst[pix * 32 + l31] = ((word >> l31) & 1u) ? acc[j][r] : 0.f;
       }
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (pixi[r][j] >= 0) dst[(int64_t)pixi[r][j] * 32 + l31] = ((gw[r][j] >> l31) & 1u) ? acc[j][r] : 0.f;
-    if (nxt < ntiles) stash(sA + (cur ^ 1) * nblk * DG_ALD);
-    __syncthreads();
-    cur ^= 1;
   }
 }
 
@@ -1973,13 +1940,12 @@ extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const flo
   CLICA_CHECK_ARG(!gate_bits || C % 32 == 0, "clica_conv_k4s2_dgrad: gate bits need C %% 32 == 0");
   CLICA_CHECK_ARG(g.M < (1 << 24), "clica_conv_k4s2_dgrad: %lld rows (the scattering epilogue handles < 2^24)", (long long)g.M);
   static const bool persist_on = [] { const char* e = getenv("CLICA_CONV_DGRAD_PERSIST"); return !(e && atoi(e) == 0); }();
-  if (persist_on && C == 32 && Cout == 32 && gate_bits && ws <= 33 && g.M >= 8 * DG_ROWS) {
-    const size_t lds = (size_t)(128 * 128 + 2 * (DG_ROWS + ws + 2) * DG_ALD) * sizeof(float);
-    auto k = conv_dgrad32_persist_k;
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+  if (persist_on && C == 32 && Cout == 32 && gate_bits && g.M >= 8 * DG_ROWS) {
+    auto k = conv_dgrad32_stream_k;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024), true);
     (void)once;
     const int64_t ntiles = ceil_div(g.M, DG_ROWS);
-    hipLaunchKernelGGL(k, dim3((unsigned)std::min<int64_t>(ntiles, kNumCU)), dim3(512), lds, as_stream(stream), g.A, Wd, g.M, dPrev, cx);
+    hipLaunchKernelGGL(k, dim3((unsigned)std::min<int64_t>(ntiles, 2 * kNumCU)), dim3(512), 64 * 1024, as_stream(stream), g.A, Wd, g.M, dPrev, cx);
     return launch_status("clica_conv_k4s2_dgrad(persistent)");
   }
   // tile shape measured on config 5 (steps/s): 64 x 128 / 4 waves 391; 128 x 128 / 8 waves 402 and 393 (2 x 4, 4 x 2 waves); three LDS stages 352
