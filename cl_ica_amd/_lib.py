@@ -52,6 +52,8 @@ SIGNATURES: Dict[str, list] = {
     "clica_lp_loss_train_path": [C.POINTER(LpLossDesc), C.POINTER(c_i32)],
     "clica_lp_loss_set_matrix_cores": [c_i32],
     "clica_lp_loss_train_spread": [C.POINTER(LpLossDesc), C.c_void_p, c_size, C.POINTER(C.c_float), C.c_void_p],
+    "clica_lp_loss_train_guard": [C.POINTER(LpLossDesc), C.c_void_p, c_size, C.POINTER(C.c_float), C.c_void_p],
+    "clica_lp_loss_set_spread_limit": [C.c_float],
     "clica_lp_loss_fwd_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p,
                                 c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],
     "clica_lp_loss_bwd_sym_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, C.c_void_p,

@@ -79,6 +79,10 @@ struct Params {
   // an element-wise kernel instead of writing the two gradient rows itself
   const float* posdot = nullptr;
   float* dpos = nullptr;
+  // training entry points with the p = 2 matrix-core sweeps in front (lp_mfma.h, "the guard"): this sweep runs only when the call's
+  // spread *gate exceeds gate_limit -- otherwise the matrix-core sweep has done the work and every workgroup returns at once
+  const float* gate = nullptr;
+  float gate_limit = 0.f;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -304,6 +308,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
     Params q, float2* __restrict__ part, float* __restrict__ part_g, int chunk) {
+  if (q.gate && *q.gate <= q.gate_limit) return;
   constexpr int TS = tile_rows(NP), RPP = TS / PARTS, JBF = jb_fwd(NP);
   static_assert(RPP % JBF == 0, "partition rows must be whole JB groups");
   static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");
@@ -470,6 +475,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
     Params q, const float* __restrict__ statL, const float* __restrict__ statC,
     const float* __restrict__ strL, const float* __restrict__ strC,
     float* __restrict__ part, int chunk) {
+  if (q.gate && *q.gate <= q.gate_limit) return;
   constexpr bool OWNER_STATS = (STATS & 1) != 0, STREAM_STATS = (STATS & 2) != 0;
   constexpr int TS = tile_rows(NP), RPP = TS / PARTS;
   static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");

@@ -123,12 +123,19 @@ struct TrainOut { float* statL; float* statC; float* dz1; int64_t ldd1; float* d
 // one rank, p = 2 on the matrix cores (lp_mfma.hip): the finalize block of 64 rows = two pool tiles also writes their feature planes
 // (they carry u_j = C_j 2^-L_j, which this kernel has just computed) -- the separate plane launch of the backward call disappears
 struct FeatOut { lp2::u32x4_t* FP = nullptr; const float* origin = nullptr; float pre2 = 0.f; int64_t pool_tiles = 0; };
+// the matrix-core guard (lp_mfma.h): which of the two sweeps wrote the partials is decided on the device per call -- the finishing
+// kernels read the same word and take the split count of the sweep that ran; the forward's also counts the fallbacks
+struct Gate { float* words = nullptr; float limit = 0.f; int nsplit_alt = 0; };
 
 __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float2* __restrict__ part, int nsplit, int64_t rows,
     const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
     Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
-    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T, FeatOut F) {
+    float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T, FeatOut F, Gate G) {
+  if (G.words && G.words[lp2::W_STEP_M] > G.limit) {
+    nsplit = G.nsplit_alt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) G.words[lp2::W_FALLBACKS] += 1.f;
+  }
   __shared__ float sm[THREADS / FIN_ROWS][FIN_ROWS], ss[THREADS / FIN_ROWS][FIN_ROWS];
   __shared__ float ush[FIN_ROWS];
   // the block's z1 / z2 rows, staged by all 256 threads (coalesced) while the partials are in flight: the finishing
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(THREADS) void bwd_coef_k(
 struct MeansJob { const float* blocksums; int nblocks; float inv_count; float* means; int block; int32_t* tick; };   // block < 0: none
 __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
                                                        int np, int n, float* __restrict__ out, int64_t ldo,
-                                                       int accumulate, MeansJob mj) {
+                                                       int accumulate, MeansJob mj, Gate G) {
+  if (G.words && G.words[lp2::W_STEP_M] > G.limit) nsplit = G.nsplit_alt;
   if ((int)blockIdx.x == mj.block) {        // training step: the forward's three means, off its critical path (see means_k)
     if (threadIdx.x < 64) {
       float v[3] = {0.f, 0.f, 0.f};
@@ -478,7 +486,7 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{});
+                     d->compat ? 1 : 0, frac ? 1 : 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{}, Gate{});
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)rows, means);
   if (rowgrad)
     hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(rows * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
@@ -525,14 +533,14 @@ extern "C" int clica_lp_loss_bwd(const clica_lp_loss_desc* d,
     launch_bwd_pairs(true, PR, pk, rows_p, ldr, rows, cols_p, ldc, cols, q, w.statL, w.statC, w.partR, st);
     const int acc = frac ? (accumulate_dz3 ? 1 : 0) : 1;
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
+                       (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, d_rows, ld_dr, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr}, Gate{});
   }
   if (d_cols) {
     Params qc = q; qc.sgn = -q.sgn;   // e = -(owner - stream) + eps seen from the column side
     launch_bwd_pairs(false, PC, pk, cols_p, ldc, cols, rows_p, ldr, rows, qc, w.statL, w.statC, w.partC, st);
     const int acc = frac ? 1 : (accumulate_dz3 ? 1 : 0);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(cols * PC.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
+                       (const float*)w.partC, PC.nsplit, cols, PC.np, d->n, d_cols, ld_dc, acc, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr}, Gate{});
   }
   return launch_status("clica_lp_loss_bwd");
 }
@@ -568,7 +576,7 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
   }
   launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, w.partR, st);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
-                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
+                     (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr}, Gate{});
   return launch_status("clica_lp_loss_bwd_sym");
 }
 
@@ -593,7 +601,8 @@ static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t row
     w.P2 = lp2::make_plan(rows, cols);
     w.w2 = lp2::carve(p + off, w.P2);
     off += w.w2.bytes;
-    nsf = nsr = w.P2.nsplit;
+    nsf = w.P2.nsplit > nsf ? w.P2.nsplit : nsf;       // either sweep may write the partials (the guard decides per call on the device)
+    nsr = w.P2.nsplit > nsr ? w.P2.nsplit : nsr;
   }
   w.scratch = p + off;      // forward: per-split (max, sum) partials; backward: per-split gradient partials (the forward's are dead by then)
   const size_t f = align_up((size_t)nsf * rows * sizeof(float2), 256);
@@ -639,6 +648,29 @@ extern "C" int clica_lp_loss_train_spread(const clica_lp_loss_desc* d, const voi
   return CLICA_OK;
 }
 
+extern "C" int clica_lp_loss_set_spread_limit(float limit) {
+  lp2::set_spread_limit(limit);
+  return CLICA_OK;
+}
+
+extern "C" int clica_lp_loss_train_guard(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* out4,
+                                         clica_stream_t stream) {
+  int rc = validate(d, "clica_lp_loss_train_guard");
+  if (rc) return rc;
+  CLICA_CHECK_ARG(workspace && out4, "clica_lp_loss_train_guard: NULL pointer");
+  out4[0] = out4[1] = out4[3] = 0.f; out4[2] = lp2::spread_limit();
+  if (!train_mfma(d)) return CLICA_OK;
+  const int64_t rows = d->B, cols = d->B3;
+  TrainWs w = carve_train(const_cast<void*>(workspace), make_plan(rows, cols, d->n, false), make_plan(rows, cols, d->n, true), rows, cols, true);
+  if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_train_guard: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
+  hipStream_t st = as_stream(stream);
+  float words[4];
+  if (hipMemcpyAsync(words, w.w2.spread, sizeof(words), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return launch_status("clica_lp_loss_train_guard");
+  out4[0] = words[lp2::W_RUN_M]; out4[1] = words[lp2::W_STEP_M]; out4[3] = words[lp2::W_FALLBACKS];
+  return CLICA_OK;
+}
+
 extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
                                        const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,
                                        float* loss_i, float* pos_i, float* lse_i,
@@ -659,10 +691,16 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   hipStream_t st = as_stream(stream);
   float2* part = reinterpret_cast<float2*>(w.scratch);
   int nsplit_f = PF.nsplit;
+  Gate gate;
   if (w.mfma) {      // p = 2: logits as one augmented inner product on the matrix cores (lp_mfma.hip); same partial format
-    lp2::launch_prep(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, q.kscale, st);
-    lp2::launch_fwd(w.P2, w.w2, rows, part, st);
+    const float limit = lp2::spread_limit();
+    lp2::launch_prep(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, q.kscale, st);       // also measures this call's spread M
+    lp2::launch_fwd(w.P2, w.w2, rows, part, limit, st);                                      // returns at once when M > limit ...
+    Params qv = q;
+    qv.gate = w.w2.spread + lp2::W_STEP_M; qv.gate_limit = limit;                           // ... and this one when M <= limit
+    launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, qv, part, nullptr, st);
     nsplit_f = w.P2.nsplit;
+    gate = Gate{w.w2.spread, limit, PF.nsplit};
   } else {
     launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
   }
@@ -670,10 +708,10 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   FeatOut feat;
   if (w.mfma && pool == z1 && cols == rows && ldp == ld1)      // one rank: see FeatOut; bwd_sym_train makes the same test
-    feat = FeatOut{(lp2::u32x4_t*)w.w2.pool_feat, pool, sqrtf(2.f * q.kscale), w.P2.pool_tiles};
+    feat = FeatOut{(lp2::u32x4_t*)w.w2.pool_feat, w.w2.spread + lp2::W_ORIGIN, sqrtf(2.f * q.kscale), w.P2.pool_tiles};
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)part, nsplit_f, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, feat);
+                     d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, feat, gate);
   return launch_status("clica_lp_loss_fwd_train");
 }
 
@@ -705,17 +743,23 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
     q.gfold = d->p / powf(q.pre, d->p - 1.f);
   }
   int nsplit_r = PR.nsplit;
-  if (w.mfma) {      // the planes of the forward call are still in the workspace (same z1 / pool, as for the row statistics)
+  Gate gate;
+  if (w.mfma) {      // the planes of the forward call are still in the workspace (same z1 / pool, as for the row statistics), and so is its spread
+    const float limit = lp2::spread_limit();
     lp2::launch_bwd(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, PR.np, q.kscale, w.statL, w.statC, strL, strC, partR,
-                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1 && pool_lse == lse_i, st);
+                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1 && pool_lse == lse_i, limit, st);
+    Params qv = q;
+    qv.gate = w.w2.spread + lp2::W_STEP_M; qv.gate_limit = limit;
+    launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, qv, w.statL, w.statC, strL, strC, partR, st);
     nsplit_r = w.P2.nsplit;
+    gate = Gate{w.w2.spread, limit, PR.nsplit};
   } else {
     launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
   }
   const int blocks = (int)ceil_div(rows * PR.np, THREADS);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,
                      (const float*)partR, nsplit_r, rows, PR.np, d->n, dz1, ldd1, 1,
-                     MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks, tick_counter});
+                     MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks, tick_counter}, gate);
   return launch_status("clica_lp_loss_bwd_sym_train");
 }
 
@@ -1004,7 +1048,7 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
                        (const float*)mw.S, mw.ldS, d->B, d->B3, q.kscale, mw.part);
     hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                        (const float2*)mw.part, mw.nchunk, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                       1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{});
+                       1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{}, Gate{});
     hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
     if (rowgrad) {          // softmax-weighted sum of the z3 rows: one more GEMM on the weights (coefficient 1)
       dot_weights(mw, d->B, d->B3, q.kscale, lse_i, nullptr, st);
@@ -1016,7 +1060,7 @@ extern "C" int clica_dot_loss_fwd(const clica_dot_loss_desc* d,
   launch_fwd_partial(P, PK_DOT, z1, ld1, d->B, z3, ld3, d->B3, q, w.part, w.part_g, st);
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)w.part, P.nsplit, d->B, z1, ld1, z2, ld2, q, d->tau, d->alpha,
-                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{});
+                     1, 0, 1, 0.f, loss_i, pos_i, lse_i, M, TrainOut{}, FeatOut{}, Gate{});
   hipLaunchKernelGGL(means_k, dim3(1), dim3(64), 0, st, (const float*)w.blocksums, nfin, 1.f / (float)d->B, means);
   if (rowgrad)   // gradient w.r.t. the (normalised, if requested) rows
     hipLaunchKernelGGL(rowgrad_combine_k, dim3((unsigned)ceil_div(d->B * (P.np / 4), THREADS)), dim3(THREADS), 0, st,
@@ -1077,7 +1121,7 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
   } else if (o1) {
     launch_bwd_pairs(true, PR, PK_DOT, z1, ld1, B, z3, ld3, B3, q, w.statL, w.statC, w.partR, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B * PR.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
+                       (const float*)w.partR, PR.nsplit, B, PR.np, n, o1, lo1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr}, Gate{});
   }
   if (o3 && mfma) {
     rc = clica_linear_wgrad(mw.S, mw.ldS, z1, ld1, o3, lo3, nullptr, B, B3, n, acc3, mw.wg, mw.wg_bytes, stream);
@@ -1085,7 +1129,7 @@ extern "C" int clica_dot_loss_bwd(const clica_dot_loss_desc* d,
   } else if (o3) {
     launch_bwd_pairs(false, PC, PK_DOT, z3, ld3, B3, z1, ld1, B, q, w.statL, w.statC, w.partC, st);
     hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(B3 * PC.np, THREADS)), dim3(THREADS), 0, st,
-                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr});
+                       (const float*)w.partC, PC.nsplit, B3, PC.np, n, o3, lo3, acc3, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr}, Gate{});
   }
   if (d->normalize) {
     if (dz1) normalize_rows_bwd(dw.u1, dw.du1, dw.i1, B, n, dz1, ldd1, 0, st);

@@ -23,7 +23,22 @@ Plan make_plan(int64_t n_own, int64_t n_pool);
 bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0, or set_enabled)
 void set_enabled(int on);                   // process-wide override of CLICA_LP_MFMA: 1 / 0, negative = back to the environment's setting
 
-struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };   // spread: running max of M (see launch_prep)
+// `spread` = 64 device floats in front of the planes (zeroed with the workspace):
+//   [W_RUN_M] largest M any forward call has seen (diagnostic)          [W_MAXABS] this call's max |x'| (grid step of the hi pieces)
+//   [W_STEP_M] THIS call's M -- the device-side guard reads it          [W_FALLBACKS] number of forward calls that fell back (as a float)
+//   [W_ORIGIN .. +16) the origin rows are shifted by: the mean of the pool's first <= 64 rows (any point inside the data is valid;
+//   the centre keeps M = log2(e)/tau max |x - origin|^2 at about a quarter of what an arbitrary data row gives)
+constexpr int W_RUN_M = 0, W_MAXABS = 1, W_STEP_M = 2, W_FALLBACKS = 3, W_ORIGIN = 4;
+struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };
+
+// The guard.  The expansion's gradient product accumulates terms of size sqrt(M) in fp32, so its error grows ~ sqrt(M) (measured against
+// the fp64 oracle: tests/test_gpu_loss.py ..._spread_limit).  Every forward call measures its own M on the device (prep_k); when it exceeds
+// spread_limit() the matrix-core sweeps of THIS call return at once and the coordinate-difference sweeps (lp_kernels.h), which are launched
+// behind them with the opposite condition, do the work -- same partial formats, same finalize / reduce.  Both sets of launches are always
+// in the stream (and in a captured graph), the choice is made per call by the kernels themselves: no host round trip, valid under replay.
+float spread_limit();                       // CLICA_LP_MFMA_LIMIT (default kDefaultSpreadLimit) or set_spread_limit
+void set_spread_limit(float m);             // <= 0: back to the environment's / default value
+constexpr float kDefaultSpreadLimit = 512.f;
 Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-provided workspace (256-byte aligned base)
 
 // x' = sqrt(2 log2(e) / tau) (x - origin): row planes of the anchors and of the pool (both sweeps read them).  Also keeps the running maximum
@@ -31,14 +46,14 @@ Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-prov
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st);
 // part[split][row] = (0, sum_j 2^x_ij) -- the partial format of fwd_partial_k<ZMAX>
-void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st);
+void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, hipStream_t st);
 // part[split][row][np] = gradient partials of the symmetric sweep (format of bwd_pairs_k<.., 3, .., FOLD>): 2 sum_j 2^x_ij (u_i + u_j) (a_i - p_j),
 // u = C 2^-L from (ownL, ownC) / (poolL, poolC)
 // (writes the pool's feature planes first -- they carry the pool rows' u_j -- unless `feat_ready`: on one rank the forward's finalize
 // has written them, lp_mfma_dev.h)
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
                 int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, bool feat_ready,
-                hipStream_t st);
+                float limit, hipStream_t st);
 
 }  // namespace lp2
 }  // namespace clica

@@ -100,18 +100,36 @@ __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (
 // Slots (K = 16 = n + 6, n <= 10): coordinates 0..n-1; pool rows: ones at n..n+2, own norms at n+3..n+5; anchors the other way round;
 // own norm slots: hi plane = the three pieces of -Nh, mid plane = the three pieces of -Nr; rows >= `rows` of the pool: -Nr = -1e30.
 __global__ __launch_bounds__(256) void maxabs_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, const float* __restrict__ Xa, int64_t lda,
-                                                int64_t rows_a, int n, const float* __restrict__ origin, float pre2, float* __restrict__ words) {
+                                                int64_t rows_a, int n, float pre2, float* __restrict__ words) {
+  // origin = mean of the pool's first <= 64 rows, computed by every block the same way (fixed shuffle tree: deterministic and identical
+  // in all blocks); block 0 publishes it for the launches behind this one and opens the step's guard word
+  __shared__ float org[KSLOTS];
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt = rows_p < 64 ? (int)rows_p : 64;
+    for (int k = wave; k < n; k += 4) {
+      float v = lane < cnt ? Xp[(int64_t)lane * ldp + k] : 0.f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) org[k] = v / (float)cnt;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if ((int)threadIdx.x < n) words[W_ORIGIN + threadIdx.x] = org[threadIdx.x];
+    if (threadIdx.x == 0) words[W_STEP_M] = 0.f;
+  }
   const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool pool = id < rows_p;
   const int64_t j = pool ? id : id - rows_p;
   float m = 0.f;
   if (pool || j < rows_a) {
     const float* row = pool ? Xp + j * ldp : Xa + j * lda;
-    for (int k = 0; k < n; ++k) m = fmaxf(m, fabsf(pre2 * (row[k] - origin[k])));
+    for (int k = 0; k < n; ++k) m = fmaxf(m, fabsf(pre2 * (row[k] - org[k])));
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(words + 1), __float_as_int(m));     // (non-negative floats order like ints)
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(words + W_MAXABS), __float_as_int(m));     // (non-negative floats order like ints)
 }
 
 __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
@@ -124,7 +142,7 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
   u32x4* __restrict__ RP = role ? RPa : RPp;
   const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * 2 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
   // grid step: the power of two with max |x'| / D in [64, 128)
-  const unsigned xb = __float_as_uint(words[1]);
+  const unsigned xb = __float_as_uint(words[W_MAXABS]);
   const int ex = (int)((xb >> 23) & 0xffu) - 7;      // biased exponent of max |x'|, minus 7: max / D in [128, 256), hi = 8-bit integers x D
   const float D = __uint_as_float((unsigned)(ex < 1 ? 1 : ex) << 23), invD = 1.f / D;
   const int64_t j = (int64_t)tile * ROWS + lane;
@@ -149,11 +167,14 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
     nr += fmaf(hi, r16, 0.5f * r16 * r16);
   }
   nh *= 0.5f;
-  if (role == 0) {      // diagnostic: the largest M of the pool so far
+  {      // M of this call (the guard: anchors and pool rows both enter the expansion) and the largest M so far (diagnostic)
     float m = live ? nh + nr : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(words), __float_as_int(fmaxf(m, 0.f)));
+    if (threadIdx.x == 0) {
+      atomicMax(reinterpret_cast<int*>(words + W_STEP_M), __float_as_int(fmaxf(m, 0.f)));
+      atomicMax(reinterpret_cast<int*>(words + W_RUN_M), __float_as_int(fmaxf(m, 0.f)));
+    }
   }
   unsigned nhp[3], nrp[3];
   split3(-nh, nhp[0], nhp[1], nhp[2]);
@@ -216,14 +237,15 @@ __device__ __forceinline__ void xcd_tile(int& bx, int& by) {
 // ---- forward: sum_j 2^x_ij per anchor and split -------------------------------------------------------------------------------
 template <int T>
 __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RPa, const u32x4* __restrict__ RPp, int64_t n_own,
-                                                    float2* __restrict__ part, int chunk_tiles, float* __restrict__ words) {
+                                                    float2* __restrict__ part, int chunk_tiles, float* __restrict__ words, float limit) {
   constexpr int SV = STAGE_TILES * ROWVEC, PER = SV / THREADS;       // 768 vectors per stage, 3 per thread
   static_assert(SV % THREADS == 0, "stage copy");
   __shared__ u32x4 stage[2][SV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   int bx, by;
   xcd_tile(bx, by);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) words[1] = 0.f;      // the planes are written: next call's maxabs_k starts from 0
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) words[W_MAXABS] = 0.f;      // the planes are written: next call's maxabs_k starts from 0
+  if (words[W_STEP_M] > limit) return;      // the guard (lp_mfma.h): this call's spread is beyond what the expansion holds 1e-5 at -- the difference sweep behind this launch runs instead
   const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
   u32x4 b[T][3];
 #pragma unroll
@@ -297,7 +319,8 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
                                                     const float* __restrict__ own, int64_t ldo, int64_t n_own,
                                                     const float* __restrict__ origin, int64_t n_pool, int n, int np, float pre2,
                                                     const float* __restrict__ ownL, const float* __restrict__ ownC,
-                                                    float* __restrict__ part, int chunk_tiles) {
+                                                    float* __restrict__ part, int chunk_tiles, const float* __restrict__ words, float limit) {
+  if (words[W_STEP_M] > limit) return;      // the guard, as in fwd_k
   constexpr int RV = STAGE_B * ROWVEC, FV = STAGE_B * FEATVEC, SV = RV + FV, PER = (SV + THREADS - 1) / THREADS;      // 384 + 768 vectors
   constexpr int NB = STAGE_B * T;                                                                    // blocks per stage
   static_assert(RV % 64 == 0 && SV % 64 == 0, "stage copy: whole waves on either side of the row / feature boundary");
@@ -506,6 +529,13 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
 // ---- host ---------------------------------------------------------------------------------------------------------------------
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
+static float g_limit = 0.f;     // <= 0: CLICA_LP_MFMA_LIMIT / the default
+void set_spread_limit(float m) { g_limit = m > 0.f ? m : 0.f; }
+float spread_limit() {
+  static const float env_limit = [] { const char* e = getenv("CLICA_LP_MFMA_LIMIT"); const float v = e ? (float)atof(e) : 0.f; return v > 0.f ? v : kDefaultSpreadLimit; }();
+  return g_limit > 0.f ? g_limit : env_limit;
+}
+
 static int g_enabled = -1;      // -1: take CLICA_LP_MFMA (default on); set_enabled overrides it for the process
 void set_enabled(int on) { g_enabled = on < 0 ? -1 : (on ? 1 : 0); }
 bool applies(int n, float p, int pow) {
@@ -549,31 +579,32 @@ Ws carve(void* base, const Plan& P) {
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
-  hipLaunchKernelGGL(maxabs_k, dim3((unsigned)ceil_div(n_pool + n_own, 256)), dim3(256), 0, st, pool, ldp, n_pool, own, ldo, n_own, n, pool, pre2, w.spread);
+  hipLaunchKernelGGL(maxabs_k, dim3((unsigned)ceil_div(n_pool + n_own, 256)), dim3(256), 0, st, pool, ldp, n_pool, own, ldo, n_own, n, pre2, w.spread);
   hipLaunchKernelGGL(prep_k, dim3((unsigned)((P.pool_tiles + P.own_tiles) / 2)), dim3(64), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows,
-                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pool, pre2, w.spread);
+                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, (const float*)(w.spread + W_ORIGIN), pre2, w.spread);
 }
 
-void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, hipStream_t st) {
+void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, hipStream_t st) {
   dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
-  if (P.T == 1) hipLaunchKernelGGL(fwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread);
-  else hipLaunchKernelGGL(fwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread);
+  if (P.T == 1) hipLaunchKernelGGL(fwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread, limit);
+  else hipLaunchKernelGGL(fwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread, limit);
 }
 
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
                 int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, bool feat_ready,
-                hipStream_t st) {
+                float limit, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
+  const float* origin = w.spread + W_ORIGIN;
   if (!feat_ready)
-    hipLaunchKernelGGL(prep_feat_k, dim3((unsigned)P.pool_tiles), dim3(128), 0, st, pool, ldp, n_pool, n, pool, pre2, poolL, poolC,
+    hipLaunchKernelGGL(prep_feat_k, dim3((unsigned)P.pool_tiles), dim3(128), 0, st, pool, ldp, n_pool, n, origin, pre2, poolL, poolC,
                        (u32x4*)w.pool_feat);
   dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
   if (P.T == 1)
     hipLaunchKernelGGL(bwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,
-                       n_own, pool, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles);
+                       n_own, origin, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles, (const float*)w.spread, limit);
   else
     hipLaunchKernelGGL(bwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,
-                       n_own, pool, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles);
+                       n_own, origin, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles, (const float*)w.spread, limit);
 }
 
 }  // namespace lp2

@@ -771,6 +771,17 @@ class ContrastiveTrainer:
                                                           _lib.stream_ptr()), "clica_lp_loss_train_spread")
         return float(v.value)
 
+    def loss_guard(self) -> dict:
+        """State of the device-side guard of the p = 2 matrix-core loss sweeps (include/clica.h, "THE GUARD"): the largest spread M seen, the
+        last step's M, the limit in force and how many steps fell back to the coordinate-difference sweeps.  The decision itself is made
+        per step by the kernels (also inside graph replays); this is a host read + sync for log points."""
+        if not self.loss_train:
+            return dict(max_spread=0.0, last_spread=0.0, limit=0.0, fallback_steps=0)
+        v = (C.c_float * 4)()
+        _lib.check(_lib.load().clica_lp_loss_train_guard(C.byref(self.desc), self.loss_ws.data_ptr(), self.loss_ws.numel(), v,
+                                                         _lib.stream_ptr()), "clica_lp_loss_train_guard")
+        return dict(max_spread=float(v[0]), last_spread=float(v[1]), limit=float(v[2]), fallback_steps=int(v[3]))
+
     def set_loss_matrix_cores(self, on):
         """Switch the p = 2 loss sweeps between the matrix cores (True) and the coordinate-difference sweeps (False); None = back to the
         environment's setting.  Process-wide (clica_lp_loss_set_matrix_cores); a captured step graph is captured again."""

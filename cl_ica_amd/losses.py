@@ -305,7 +305,9 @@ class LpSimCLRLoss(CLLoss):
         if z1_rec.shape != z2_con_z1_rec.shape or z1_rec.shape[1] != z3_rec.shape[1]:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_con_z1_rec.shape)}, {tuple(z3_rec.shape)}")
         desc = self._desc(z1_rec.shape[0], z3_rec.shape[0], z1_rec.shape[1])
-        if _sym_enabled() and z1_rec.dim() == 2 and _rolled_rows_of(z3_rec, z1_rec):
+        # the roll shortcut only for p >= 1: the p < 1 branch of the reference (losses.py:433-442) transposes the pair matrix, so row k
+        # belongs to z3[k] = z1[k-1] and is combined with pos[k] -- reading z1 itself as the pool would pair pos[k] with the wrong row
+        if _sym_enabled() and float(self.p) >= 1.0 and z1_rec.dim() == 2 and _rolled_rows_of(z3_rec, z1_rec):
             mean, per_item, pos_mean, neg_mean = _PairLossSymFn.apply(z1_rec, z2_con_z1_rec, desc)
         else:
             mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "lp", desc)

@@ -132,12 +132,7 @@ def autograd_train_step(h, loss, optimizer, z1, z2, supervised: bool, world: int
 
 
 def main(argv=None):
-    try:
-        return _main(argv)
-    finally:      # the switch to the difference sweeps (below) is process-wide: a caller that runs main() in its own process gets its setting back
-        if torch.cuda.is_available():
-            from . import _lib
-            _lib.load().clica_lp_loss_set_matrix_cores(-1)
+    return _main(argv)
 
 
 def _main(argv=None):
@@ -222,11 +217,11 @@ def _main(argv=None):
                     f"Lin. Disentanglement: {lin:.4f} \t", f"Perm. Disentanglement: {perm:.4f}")
                 if args.sphere_norm:
                     log(f"r: {f[-1].r}")
-                if fused and not getattr(trainer, "_spread_handled", False) and trainer.loss_spread() > 20000.0:
-                    trainer._spread_handled = True
-                    log(f"note: the embeddings spread over M = {trainer.loss_spread():.0f} temperature units (the p = 2 matrix-core loss sweeps "
-                        "hold 1e-5 in the loss at any spread and in the gradient up to M ~ 10^3-10^4, include/clica.h): switching to the coordinate-difference sweeps")
-                    trainer.set_loss_matrix_cores(False)
+                if fused and not getattr(trainer, "_guard_noted", False) and trainer.loss_guard()["fallback_steps"] > 0:
+                    trainer._guard_noted = True      # (nothing to do: the library's device-side guard switches per step, include/clica.h)
+                    g = trainer.loss_guard()
+                    log(f"note: the embeddings spread over M = {g['last_spread']:.0f} temperature units (> {g['limit']:.0f}): the p = 2 loss "
+                        "runs on the coordinate-difference sweeps for such steps")
             lin_scores.append(lin); perm_scores.append(perm)
             global_step += 1
         if pending:

@@ -138,24 +138,32 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * p = 2, pow, n <= 10 (BASELINE config 2: main_mlp.py defaults): the two pair sweeps run on the bf16 matrix cores (csrc/lp_mfma.hip:
  * logit = one augmented inner product of bf16 pieces, gradient = a second product against the pool) and z1 / pool must additionally be
  * UNCHANGED between the two calls (fwd_train leaves their operand planes in the workspace).  The expansion |a|^2 + |b|^2 - 2ab behind
- * it has terms of size M = log2(e)/tau max_i |z_i - z_0|^2 (rows are shifted by the pool's first row) -- M ~ 10^3 in the reference's own
- * training, whose unnormalised embeddings spread to a standard deviation of ~10.  The large part of every term is therefore computed
- * EXACTLY (hi pieces on a grid common to the launch, accumulated apart), and the loss holds 1e-5 at every spread measured (2e-6 at
- * M = 15 000, tests/test_gpu_loss.py ..._spread_limit); the gradient is held to 1e-5 up to M ~ 10^3 on saturated clouds (1.4e-5 at
- * M = 3 700, 2.8e-5 at 15 000) and agrees with the difference sweeps to 1e-6 on the embeddings of a training run.
- * CLICA_LP_MFMA=0 / clica_lp_loss_set_matrix_cores select the VALU sweeps on coordinate differences (no such dependence).
- * clica_lp_loss_train_path reports the choice:
- * *path = 1 matrix cores, 0 VALU sweeps. */
+ * it has terms of size M = log2(e)/tau max_i |z_i - origin|^2 (origin = the mean of the pool's first 64 rows).  The large part of every
+ * term of the logit is computed EXACTLY (hi pieces on a grid common to the launch, accumulated apart) and the loss holds 1e-5 at every
+ * spread measured (2e-6 at M = 15 000); the gradient's second product accumulates terms of size sqrt(M) in fp32 and its error grows
+ * ~ sqrt(M).  THE GUARD (round 5): every fwd_train call measures its own M on the device; when it exceeds the spread limit (default 512:
+ * gradient error < 1e-5 against the fp64 oracle with margin, tests/test_gpu_loss.py ..._spread_limit) the matrix-core sweeps of THAT call
+ * return at once and the coordinate-difference sweeps (no such dependence), launched behind them with the opposite condition, do the
+ * work.  The decision is made by the kernels per call -- no host round trip, valid inside a replayed graph.
+ * CLICA_LP_MFMA=0 / clica_lp_loss_set_matrix_cores(0) remove the matrix-core sweeps altogether.
+ * clica_lp_loss_train_path reports which launches a call makes:
+ * *path = 1 matrix cores with the guarded fallback behind them, 0 VALU sweeps only. */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);
 int clica_lp_loss_train_path(const clica_lp_loss_desc* d, int32_t* path);
-/* Diagnostic for the limit above: *spread (HOST float) = the largest M any clica_lp_loss_fwd_train call has seen in this workspace since it
- * was zeroed (0 on the VALU path).  Synchronises `stream`; not for the training loop itself -- call it where the loop reads losses anyway. */
+/* Diagnostic: *spread (HOST float) = the largest M any clica_lp_loss_fwd_train call has seen in this workspace since it was zeroed
+ * (0 on the VALU path).  Synchronises `stream`; not for the training loop itself -- call it where the loop reads losses anyway. */
 int clica_lp_loss_train_spread(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* spread,
                                clica_stream_t stream);
-/* Process-wide switch between the matrix-core (1) and the VALU (0) sweeps behind the training pair; negative: back to CLICA_LP_MFMA's
- * setting.  Takes effect at
- * the next clica_lp_loss_fwd_train call; a workspace sized for the matrix-core path is large enough for the other one; a captured
- * graph keeps the sweeps it was captured with (re-capture).  cl_ica_amd.train_mlp calls it when the spread diagnostic passes 150. */
+/* The guard's state, HOST floats out4[4] = { largest M so far, M of the last forward call, the limit in force, number of forward calls
+ * that fell back to the difference sweeps since the workspace was zeroed }.  Synchronises `stream`. */
+int clica_lp_loss_train_guard(const clica_lp_loss_desc* d, const void* workspace, size_t workspace_bytes, float* out4,
+                              clica_stream_t stream);
+/* Process-wide spread limit of the guard (M above which a call falls back); <= 0: back to CLICA_LP_MFMA_LIMIT / the default.  The limit is
+ * a kernel ARGUMENT: a captured graph keeps the one it was captured with. */
+int clica_lp_loss_set_spread_limit(float limit);
+/* Process-wide switch between the matrix-core (1) and the VALU-only (0) launches behind the training pair; negative: back to
+ * CLICA_LP_MFMA's setting.  Takes effect at the next clica_lp_loss_fwd_train call; a workspace sized for the matrix-core path is large
+ * enough for the other one; a captured graph keeps the launches it was captured with (re-capture). */
 int clica_lp_loss_set_matrix_cores(int32_t on);
 int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
                             const float* z1, int64_t ld1, const float* z2, int64_t ld2, const float* pool, int64_t ldp,

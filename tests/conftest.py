@@ -18,7 +18,7 @@ def pytest_configure(config):
 # Every GPU parity comparison goes through PARITY.check(): it computes the NORM-WISE relative error
 #     err = max|got - ref| / max(max|ref|, floor)
 # asserts err < tol (north_star: 1e-5 relative fp32) and records the measured value per test family.  At session end
-# the table is written to gpurun_out/r4_parity_errors.json (copied to profiles/ after a GPU run).
+# the table is written to gpurun_out/r5_parity_errors.json (copied to profiles/ after a GPU run).
 # Next to the max-norm figure every family carries an ELEMENT-WISE statistic: the 99.9th percentile of
 # |got - ref| / |ref| over the elements with |ref| > 1e-3 max(max|ref|, floor) (elements the max-norm cannot hide behind a large neighbour),
 # worst case per family (`p999_elem_rel_err`).  It is logged, not asserted: cancellation (loss_i = 2(a pos + (1-a) lse), embedding
@@ -75,7 +75,7 @@ class ParityLog:
     def dump(self):
         if not self.fam:
             return
-        out = os.environ.get("CLICA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r4_parity_errors.json"))
+        out = os.environ.get("CLICA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r5_parity_errors.json"))
         os.makedirs(os.path.dirname(out), exist_ok=True)
         import json
         prev = {}

@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from conftest import PARITY, mlp_formula_params
+from oracle import np_oracle as O
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("encoder_arith")]   # every test in both encoder arithmetics
 
@@ -321,8 +322,8 @@ def test_failed_capture_leaves_the_engine_usable():
 
 def test_loss_matrix_core_switch_and_spread():
     """The engine reports the spread the p = 2 matrix-core loss sweeps have seen and can be switched to the coordinate-difference sweeps
-    at run time (what cl_ica_amd.train_mlp does beyond M = 150): path query, results of both settings on a batch inside the stated range
-    agree at 1e-5, a captured graph is re-captured."""
+    at run time (process-wide switch; the per-step guard is tested below): path query, results of both settings on a batch inside the
+    guard's limit agree at 1e-5, a captured graph is re-captured."""
     import ctypes as C
     from cl_ica_amd import _lib, encoders
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
@@ -338,8 +339,9 @@ def test_loss_matrix_core_switch_and_spread():
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
         out_m = tr.step_injected(z1, z2).clone(); g_m = tr.grad_arena.clone()
         y = tr.y[:B]
-        want = 1.4426950408889634 * float(((y - y[0]) ** 2).sum(1).max())
-        assert abs(tr.loss_spread() - want) <= 1e-3 * want + 1e-6
+        want = 1.4426950408889634 * float(((y - y[:64].mean(0)) ** 2).sum(1).max())       # origin = mean of the pool's first 64 rows
+        assert abs(tr.loss_spread() - want) <= 2e-3 * want + 1e-6
+        assert tr.loss_guard()["fallback_steps"] == 0 and tr.loss_guard()["last_spread"] < tr.loss_guard()["limit"]
         tr.capture()
         tr.set_loss_matrix_cores(False)
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 0
@@ -351,11 +353,63 @@ def test_loss_matrix_core_switch_and_spread():
         _lib.check(lib.clica_lp_loss_set_matrix_cores(-1), "restore")
 
 
+def _oracle_check_of_loss_state(tr, fam, case):
+    """loss_i, row statistics and d loss / d y of the engine's current loss buffers against the fp64 oracle on its current embeddings."""
+    B = tr.B
+    y = tr.y.detach().cpu().numpy().astype(np.float64)
+    orc = O.lp_simclr_loss(y[:B], y[B:], y[:B], p=2, tau=tr.desc.tau, alpha=tr.desc.alpha, compat=True, grad=False)
+    g1, g2 = O.lp_symmetric_row_grads(y[:B], y[B:], y[:B], orc["lse"], orc["lse"], 2, tr.desc.tau, tr.desc.alpha, local_rows=B)
+    o = tr.loss_out.cpu().numpy()
+    PARITY.check(fam, case, "loss_i", o[:B], orc["loss_i"])
+    PARITY.check(fam, case, "lse_i", o[2 * B:3 * B].astype(np.float64) * np.log(2.0), orc["lse"])
+    PARITY.check(fam, case, "d loss / d y1", tr.dy[:B].cpu().numpy(), g1)
+    PARITY.check(fam, case, "d loss / d y2", tr.dy[B:].cpu().numpy(), g2)
+
+
+def test_matrix_core_guard_falls_back_inside_graph_replay():
+    """The guard is a device-side decision: a CAPTURED step graph whose embeddings spread beyond the limit between two replays (the last
+    layer is scaled under the graph) runs that replay on the coordinate-difference sweeps -- no re-capture, no host round trip -- and comes
+    back to the matrix cores when the spread does.  Every state is checked against the fp64 oracle."""
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(4)
+    n, B = 10, 1024
+    f = encoders.get_mlp(n, n, [100, 500, 100]).to("cuda")
+    gW = torch.eye(n, device="cuda").repeat(3, 1, 1).contiguous()
+    tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
+    if tr.loss_guard()["limit"] == 0.0:
+        pytest.skip("matrix-core sweeps disabled in this environment")
+    last = [m for m in f if isinstance(m, torch.nn.Linear)][-1]
+    tr.capture()
+    graph = tr.graph
+    tr.step(); torch.cuda.synchronize()
+    g0 = tr.loss_guard()
+    assert g0["fallback_steps"] == 0 and 0 < g0["last_spread"] <= g0["limit"], g0
+    _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay inside the limit (M = {g0['last_spread']:.0f})")
+    scale = (4.0 * g0["limit"] / g0["last_spread"]) ** 0.5         # M grows with the square of the embedding scale: 4 x the limit (not so far that rows saturate)
+    with torch.no_grad():
+        last.weight.mul_(scale); last.bias.mul_(scale)
+    tr.step(); torch.cuda.synchronize()
+    g1 = tr.loss_guard()
+    assert tr.graph is graph, "no re-capture"
+    assert g1["fallback_steps"] == 1 and g1["last_spread"] > 2 * g1["limit"], g1
+    _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay beyond the limit (M = {g1['last_spread']:.0f}, difference sweeps)")
+    tr.step(); torch.cuda.synchronize()
+    assert tr.loss_guard()["fallback_steps"] == 2
+    with torch.no_grad():
+        last.weight.div_(scale); last.bias.div_(scale)
+    tr.step(); torch.cuda.synchronize()
+    g2 = tr.loss_guard()
+    assert g2["fallback_steps"] == 2 and g2["last_spread"] <= g2["limit"], g2
+    _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay back inside the limit (M = {g2['last_spread']:.0f})")
+
+
 def test_matrix_core_loss_on_training_embeddings():
     """Parity of the p = 2 matrix-core loss sweeps WHERE THE BENCH RUNS: main_mlp.py's unnormalised encoder spreads its outputs to a
     standard deviation of ~10 within a few hundred steps (M = log2(e)/tau max |y - y_0|^2 in the thousands, where a plain
     |a|^2 + |b|^2 - 2ab expansion in fp32 is off by 1e-4).  The headline trainer after 60 / 300 / 1000 of its own steps: loss, row statistics
-    and d loss / d y of the matrix-core sweeps against the coordinate-difference sweeps on the same embeddings, 1e-5."""
+    and d loss / d y of the DEFAULT path (matrix cores behind the device-side guard) against the coordinate-difference sweeps on the same
+    embeddings AND against the fp64 oracle, 1e-5, out to 3 000 steps; the guard's state is logged with every case."""
     import ctypes as C
     import bench
     from cl_ica_amd import _lib
@@ -370,7 +424,7 @@ def test_matrix_core_loss_on_training_embeddings():
     try:
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
         B = tr.B
-        for k in (60, 300, 1000):
+        for k in (60, 300, 1000, 3000):
             while tr.steps_done < k:
                 tr.step()
             tr.sample(); tr.forward()
@@ -381,9 +435,12 @@ def test_matrix_core_loss_on_training_embeddings():
                 torch.cuda.synchronize()
                 res[mode] = (tr.dy.clone(), tr.loss_out.clone())
                 if mode == 1:
-                    spread = tr.loss_spread()
+                    gs = tr.loss_guard()
+                    spread = gs["last_spread"]
+                    case = (f"after {k} steps (y std {float(tr.y.std()):.2f}, M = {spread:.0f}, "
+                            f"{'difference sweeps (guard)' if spread > gs['limit'] else 'matrix cores'}, {gs['fallback_steps']} fallback steps so far)")
+                    _oracle_check_of_loss_state(tr, "matrix_core_loss_training_regime_vs_oracle", case)
             _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
-            case = f"after {k} steps (y std {float(tr.y.std()):.2f}, M = {spread:.0f})"
             PARITY.check("matrix_core_loss_training_regime", case, "loss_i", res[1][1][:B].cpu().numpy(), res[0][1][:B].cpu().numpy(), note="HIP vs HIP")
             PARITY.check("matrix_core_loss_training_regime", case, "lse_i", res[1][1][2 * B:3 * B].cpu().numpy(), res[0][1][2 * B:3 * B].cpu().numpy())
             PARITY.check("matrix_core_loss_training_regime", case, "d loss / d y", res[1][0].cpu().numpy(), res[0][0].cpu().numpy())

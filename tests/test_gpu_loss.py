@@ -135,6 +135,35 @@ def test_lp_roll_goldens(golden):
         compare("lp_roll_goldens", f"{key} p={int(m['p'])} shape={z1.shape}", out, c["out"], ("dz1", "dz2"), sat_tol, note, lf, gf, mf)
 
 
+def test_lp_roll_fractional_p_vs_oracle():
+    """p < 1 with z3 = roll(z1) in the graph: the reference's p < 1 branch transposes the pair matrix (losses.py:433-442), so
+    row k of the negatives belongs to z3[k] = z1[k-1] while pos[k] is z1[k] vs z2[k] -- the roll shortcut (pool := z1) is NOT valid there
+    and must not be taken.  Checked against the fp64 oracle fed the really rolled z3, compat on and off."""
+    from cl_ica_amd import losses
+    from cl_ica_amd.losses import LpSimCLRLoss
+    rng = np.random.default_rng(5)
+    z1 = rng.normal(size=(48, 6)).astype(np.float32)
+    z2 = (z1 + 0.1 * rng.normal(size=z1.shape)).astype(np.float32)
+    for compat in (True, False):
+        losses.PATHS.clear()
+        out = run_hip(LpSimCLRLoss(p=0.5, tau=0.7, simclr_compatibility_mode=compat), z1, z2, None, roll=True)
+        assert not any(k.startswith("sym") for k in losses.PATHS), dict(losses.PATHS)
+        orc = O.lp_simclr_loss(z1, z2, np.roll(z1, 1, 0), p=0.5, tau=0.7, compat=compat)
+        ref = dict(loss_mean=orc["loss_mean"], loss_i=orc["loss_i"], dz1=orc["dz1"] + np.roll(orc["dz3"], -1, 0), dz2=orc["dz2"])
+        fam, case = "lp_roll_fractional_p", f"p=0.5 compat={int(compat)}"
+        PARITY.check(fam, case, "loss_mean", out["loss_mean"], float(ref["loss_mean"]))
+        PARITY.check(fam, case, "loss_i", out["loss_i"], ref["loss_i"])
+        PARITY.check(fam, case, "dz2", out["dz2"], ref["dz2"])
+        # d |d + 1e-12|^0.5 / dd is 5e5 at the exact-zero pairs the roll guarantees; those terms enter dz1 through z1 and (rolled back)
+        # through z3 with opposite signs, so dz1 is a cancelled sum of 1e4-sized summands (the fp32 reference itself sits 6e-3 of max|dz1|
+        # from the fp64 oracle on this case): accurate relative to the summands -- the floor, as everywhere (summand_floors)
+        PARITY.check(fam, case, "dz1", out["dz1"], ref["dz1"], floor=float(np.abs(orc["dz1"]).max()))
+        # and NOT the value the shortcut would give (pool := z1 pairs pos[k] with the wrong row): the two differ by 5e-5 of the loss
+        wrong = O.lp_simclr_loss(z1, z2, z1, p=0.5, tau=0.7, compat=compat, grad=False)
+        if compat:
+            assert abs(out["loss_mean"] - orc["loss_mean"]) < 0.1 * abs(wrong["loss_mean"] - orc["loss_mean"])
+
+
 @pytest.fixture
 def dot_path(request):
     """SimCLRLoss contraction path: "mfma" (default from n = 96: fp32 MFMA GEMMs over a materialised logit matrix) or "valu" (pair sweep)."""
@@ -472,7 +501,7 @@ def _train_pair(z1, z2, pool, pool_lse, n, p, tau, alpha, compat=1):
 def test_p2_train_sweeps_on_matrix_cores_vs_oracle(B, n, tau, space):
     """The p = 2 training sweeps on the bf16 matrix cores (csrc/lp_mfma.hip) against the fp64 oracle, single rank (pool = z1): loss
     statistics and the complete gradient, at the bench size and at ragged sizes / other widths / temperatures.  'far': the cloud sits
-    1000 units from the coordinate origin (the kernel shifts rows by the pool's first row: the expansion must not see the offset)."""
+    1000 units from the coordinate origin (the kernel shifts rows by an origin inside the data: the expansion must not see the offset)."""
     rng = np.random.default_rng(B + n)
     alpha = 0.5
     if space == "sphere":
@@ -504,48 +533,101 @@ def test_p2_train_sweeps_on_matrix_cores_vs_oracle(B, n, tau, space):
 
 
 @pytest.mark.gpu
+def _spread_of(z, tau):
+    """M as the library measures it: log2(e)/tau max_i |z_i - origin|^2, origin = mean of the pool's first 64 rows."""
+    z = np.asarray(z, np.float64)
+    return 1.4426950408889634 / tau * float(((z - z[:64].mean(0)) ** 2).sum(1).max())
+
+
+def _guard_state(d, ws):
+    import ctypes as C
+    from cl_ica_amd import _lib
+    v = (C.c_float * 4)()
+    _lib.check(_lib.load().clica_lp_loss_train_guard(C.byref(d), ws.data_ptr(), ws.numel(), v, _lib.stream_ptr()), "guard")
+    return dict(max_spread=float(v[0]), last_spread=float(v[1]), limit=float(v[2]), fallback_steps=int(v[3]))
+
+
+@pytest.mark.gpu
 def test_p2_train_sweeps_on_matrix_cores_spread_limit():
-    """What the expansion behind the matrix-core sweeps costs as the embeddings spread out, M = log2(e)/tau max_i |z_i - z_0|^2 (the size of
-    its terms).  Box clouds of growing edge length at tau = 1 (M = 14 ... 15 000; the reference's own training sits at M ~ 10^3: unnormalised
-    encoder outputs), against the fp64 oracle.  The logits are exact in their large part (hi pieces on a common grid, own accumulator), so
-    the LOSS holds 1e-5 at every size; the gradient's second product accumulates terms of size |x'| and is held to 1e-5 up to
-    M ~ 10^3 and LOGGED beyond (1.4e-5 at M = 3 700, 2.8e-5 at M = 15 000 on these saturated clouds; 1e-6 against the difference sweeps on
-    embeddings of a training run at M ~ 3 500)."""
-    B, n, tau, alpha = 2048, 10, 1.0, 0.5
-    rng = np.random.default_rng(5)
-    base = rng.random((B, n)); noise = 0.05 * rng.normal(size=(B, n))
-    worst = {}
-    for edge in (1.0, 2.0, 4.0, 8.0, 16.0, 32.0):
-        z = (edge * base).astype(np.float32); zt = (edge * base + noise).astype(np.float32)
-        o, dz, path = _train_pair(dev(z), dev(zt), dev(z), None, n, 2, tau, alpha)
-        assert path == 1
-        orc = O.lp_simclr_loss(z, zt, z, p=2, tau=tau, alpha=alpha, compat=True, grad=False)
-        g1, _ = O.lp_symmetric_row_grads(z, zt, z, orc["lse"], orc["lse"], 2, tau, alpha, local_rows=B)
-        e_l = rel_err(o.cpu().numpy()[:B], orc["loss_i"]); e_g = rel_err(dz[:B].cpu().numpy(), g1)
-        worst[edge] = (e_l, e_g)
-        M = 1.4427 / tau * float(((z - z[0]) ** 2).sum(1).max())
-        PARITY.check("p2_train_matrix_cores", f"box edge {edge} (M = {M:.0f})", "loss_i", o.cpu().numpy()[:B], orc["loss_i"])
-        wide = edge > 8.0
-        PARITY.check("p2_train_matrix_cores_gradient_beyond_M_1000" if wide else "p2_train_matrix_cores", f"box edge {edge} (M = {M:.0f})", "dz1",
-                     dz[:B].cpu().numpy(), g1, tol=1e-4 if wide else 1e-5,
-                     note="gradient of saturated clouds beyond M ~ 10^3 (logged; the second product's accumulation of terms of size |x'|)" if wide else None)
-    print("matrix-core sweep error by box edge (loss_i, dz1):", worst)
-    # the diagnostic the training loop prints from: the largest M a workspace has seen
+    """The guard of the matrix-core sweeps (include/clica.h).  The expansion's terms are of size M = log2(e)/tau max_i |z_i - origin|^2; the
+    logit's large part is exact, so the LOSS holds 1e-5 at every spread, but the gradient's second product accumulates terms of size
+    sqrt(M) in fp32 and its error grows ~ sqrt(M).  Box clouds of growing edge at tau = 1 against the fp64 oracle:
+    (A) with the DEFAULT limit every spread -- far beyond what the reference's training reaches -- holds 1e-5 in loss and gradient, because
+        calls beyond the limit fall back to the coordinate-difference sweeps on the device (counted by the guard);
+    (B) with the guard LIFTED (limit = 1e30) the raw error of the matrix-core sweeps is logged per spread: the curve the default limit was
+        chosen from (asserted at 1e-5 up to the limit, logged at 1e-4 beyond it -- a path the default never takes)."""
     import ctypes as C
     from cl_ica_amd import _lib
     lib = _lib.load()
-    z = (4.0 * base).astype(np.float32)
+    B, n, tau, alpha = 2048, 10, 1.0, 0.5
+    rng = np.random.default_rng(5)
+    base = rng.random((B, n)); noise = 0.05 * rng.normal(size=(B, n))
+    edges = (1.0, 2.0, 4.0, 6.0, 8.0, 11.0, 13.0, 16.0, 23.0, 32.0, 64.0)
+    refs = {}
+    for edge in edges:
+        z = (edge * base).astype(np.float32); zt = (edge * base + noise).astype(np.float32)
+        orc = O.lp_simclr_loss(z, zt, z, p=2, tau=tau, alpha=alpha, compat=True, grad=False)
+        g1, _ = O.lp_symmetric_row_grads(z, zt, z, orc["lse"], orc["lse"], 2, tau, alpha, local_rows=B)
+        refs[edge] = (z, zt, orc["loss_i"], g1, _spread_of(z, tau))
     d = _lib.LpLossDesc(B=B, B3=B, n=n, p=2.0, tau=tau, alpha=alpha, compat=1, pow=1)
     nb = C.c_size_t(); _lib.check(lib.clica_lp_loss_train_workspace_bytes(C.byref(d), C.byref(nb)), "ws")
+
+    def run(z, zt, ws):
+        zd, ztd = dev(z), dev(zt)
+        o = torch.empty(3 * B + 3, device="cuda"); dz = torch.empty(2 * B, n, device="cuda")
+        st = _lib.stream_ptr()
+        _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), zd.data_ptr(), n, ztd.data_ptr(), n, zd.data_ptr(), n, o[:B].data_ptr(), o[B:2 * B].data_ptr(),
+                                               o[2 * B:3 * B].data_ptr(), dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
+        _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(d), zd.data_ptr(), n, zd.data_ptr(), n, o[2 * B:3 * B].data_ptr(), o[2 * B:3 * B].data_ptr(),
+                                                   dz[:B].data_ptr(), n, o[3 * B:].data_ptr(), None, ws.data_ptr(), ws.numel(), st), "bwd_sym_train")
+        torch.cuda.synchronize()
+        return o.cpu().numpy(), dz.cpu().numpy()
+
+    # (A) the default guard
+    _lib.check(lib.clica_lp_loss_set_spread_limit(0.0), "default limit")
     ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
-    zd = dev(z); o = torch.empty(3 * B + 3, device="cuda"); dzz = torch.empty(2 * B, n, device="cuda")
-    _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), zd.data_ptr(), n, zd.data_ptr(), n, zd.data_ptr(), n, o[:B].data_ptr(), o[B:2 * B].data_ptr(),
-                                           o[2 * B:3 * B].data_ptr(), dzz[:B].data_ptr(), n, dzz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(),
-                                           _lib.stream_ptr()), "fwd_train")
+    limit = _guard_state(d, ws)["limit"]
+    expected_fallbacks = 0
+    for edge in edges:
+        z, zt, li, g1, M = refs[edge]
+        o, dz = run(z, zt, ws)
+        st = _guard_state(d, ws)
+        assert abs(st["last_spread"] - M) < 2e-3 * M, (st, M)
+        expected_fallbacks += int(st["last_spread"] > limit)
+        assert st["fallback_steps"] == expected_fallbacks, (edge, st, expected_fallbacks)
+        path = "difference sweeps (guard)" if st["last_spread"] > limit else "matrix cores"
+        PARITY.check("p2_train_guarded", f"box edge {edge} (M = {M:.0f}, {path})", "loss_i", o[:B], li)
+        PARITY.check("p2_train_guarded", f"box edge {edge} (M = {M:.0f}, {path})", "dz1", dz[:B], g1)
+    assert 0 < expected_fallbacks < len(edges), "the sweep of edges must cross the limit"
+    assert abs(_guard_state(d, ws)["max_spread"] - max(r[4] for r in refs.values())) < 2e-3 * max(r[4] for r in refs.values())
+    # (B) the guard lifted: the raw error curve of the matrix-core sweeps
+    _lib.check(lib.clica_lp_loss_set_spread_limit(1e30), "lift")
+    try:
+        ws2 = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+        curve = {}
+        for edge in edges:
+            z, zt, li, g1, M = refs[edge]
+            o, dz = run(z, zt, ws2)
+            curve[round(M)] = (rel_err(o[:B], li), rel_err(dz[:B], g1))
+            inside = M <= limit
+            fam = "p2_train_matrix_cores" if inside else "p2_train_matrix_cores_guard_lifted_characterisation"
+            note = None if inside else "guard lifted (limit 1e30): a spread the default path hands to the difference sweeps; logged to document the limit"
+            PARITY.check(fam, f"box edge {edge} (M = {M:.0f})", "loss_i", o[:B], li)
+            PARITY.check(fam, f"box edge {edge} (M = {M:.0f})", "dz1", dz[:B], g1, tol=1e-5 if inside else 1e-4, note=note)
+        assert _guard_state(d, ws2)["fallback_steps"] == 0
+        print("matrix-core sweep error by spread M (loss_i, dz1), guard lifted:", curve, "limit", limit)
+        import json, os
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        json.dump({"what": "raw error of the p = 2 matrix-core loss sweeps against the fp64 oracle by spread M (guard lifted), box clouds, B = 2048, n = 10, tau = 1",
+                   "limit_in_force": limit, "M": list(curve), "loss_i_rel_err": [v[0] for v in curve.values()],
+                   "dz1_rel_err": [v[1] for v in curve.values()]}, open(os.path.join(out, "r5_loss_spread_curve.json"), "w"), indent=1)
+    finally:
+        _lib.check(lib.clica_lp_loss_set_spread_limit(0.0), "restore")
+    # the older diagnostic entry point still answers (largest M a workspace has seen)
     got = C.c_float()
     _lib.check(lib.clica_lp_loss_train_spread(C.byref(d), ws.data_ptr(), ws.numel(), C.byref(got), _lib.stream_ptr()), "spread")
-    want = 1.4426950408889634 / tau * float(((z.astype(np.float64) - z[0]) ** 2).sum(1).max())
-    assert abs(got.value - want) < 1e-4 * want, (got.value, want)
+    assert abs(got.value - _guard_state(d, ws)["max_spread"]) < 1e-6 * got.value
 
 
 @pytest.mark.gpu
