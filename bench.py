@@ -351,15 +351,19 @@ def roofline_leg(tr, reps=20):
         # fp32 product is SIX bf16 MFMA products: `achieved` counts the bf16 flops the kernel ISSUES (6 x algorithmic) against the
         # dense bf16 peak; `fp32_equivalent` is the algorithmic 2MNK against the fp32 matrix peak the native kernel is bound by.
         top = [r for r in rows if r["op"] == fused_key[0]][0]
-        peak, issued_factor = PEAK_BF16_MFMA_TFLOPS, 6.0
+        f16 = bool(getattr(tr, "split_f16", False))
+        pb = 4 if f16 else 6                       # bytes per element of a plane copy / of the piece weights
+        peak, issued_factor = PEAK_BF16_MFMA_TFLOPS, (3.0 if f16 else 6.0)      # (the dense fp16 MFMA peak equals the bf16 one)
         pl = getattr(tr, "split_wgrad", False)
-        per = lambda l, planes: (6 if (pl and planes[l] is not None) else 0) + (4 if (not pl or tr.acts_out[l] is not None) else 0)   # noqa: E731
-        fwd_b = 4 * R * tr.linears[0].in_features * 2 + R * sum(widths[l] * per(l, tr.act_planes) for l in range(L)) + 6 * nparam + mask_b
-        perz = lambda l: (6 if (pl and tr.dz_planes[l] is not None) else 0) + (4 if (not pl or tr.dz_out[l] is not None) else 0)         # noqa: E731
-        bwd_b = 4 * R * widths[-1] + R * sum(widths[l] * perz(l) for l in range(L - 1)) + 6 * (nparam - widths[0] * tr.linears[0].in_features) + mask_b
+        per = lambda l, planes: (pb if (pl and planes[l] is not None) else 0) + (4 if (not pl or tr.acts_out[l] is not None) else 0)   # noqa: E731
+        fwd_b = 4 * R * tr.linears[0].in_features * 2 + R * sum(widths[l] * per(l, tr.act_planes) for l in range(L)) + pb * nparam + mask_b
+        perz = lambda l: (pb if (pl and tr.dz_planes[l] is not None) else 0) + (4 if (not pl or tr.dz_out[l] is not None) else 0)         # noqa: E731
+        bwd_b = 4 * R * widths[-1] + R * sum(widths[l] * perz(l) for l in range(L - 1)) + pb * (nparam - widths[0] * tr.linears[0].in_features) + mask_b
         top["alg_bytes"] = (fwd_b + bwd_b) // 2
-        note = ("f32 results from six bf16 products of exact 3-way bf16 operand splits (v_mfma_f32_16x16x32_bf16, fp32 accumulate); "
-                "activation planes resident in LDS")
+        note = (("f32 results from three fp16 products (hi.hi, hi.lo, lo.hi) of two-piece fp16 operand splits with per-tensor power-of-two "
+                 "scales (v_mfma_f32_16x16x32_f16, fp32 accumulate); activation planes resident in LDS") if f16 else
+                ("f32 results from six bf16 products of exact 3-way bf16 operand splits (v_mfma_f32_16x16x32_bf16, fp32 accumulate); "
+                 "activation planes resident in LDS"))
     elif fused_key in groups:
         top = [r for r in rows if r["op"] == fused_key[0]][0]
         # minimum HBM bytes per launch (average of the two launches): every layer output written once (saved
@@ -411,7 +415,9 @@ def roofline_leg(tr, reps=20):
                               "`peak` is the nominal %.1f GHz figure, `frac_at_measured_clock` prices the same launch against the matrix rate "
                               "at the clock the chip actually held" % NOMINAL_GHZ)
     if issued_factor != 1.0:
-        roof["flops_counted"] = "issued bf16 flops = 6 x algorithmic 2MNK (six piece products per fp32 product), against the dense bf16 MFMA peak"
+        roof["flops_counted"] = ("issued fp16 flops = 3 x algorithmic 2MNK (three piece products per fp32 product), against the dense fp16 / bf16 MFMA peak"
+                                 if issued_factor == 3.0 else
+                                 "issued bf16 flops = 6 x algorithmic 2MNK (six piece products per fp32 product), against the dense bf16 MFMA peak")
         roof["fp32_equivalent"] = {"achieved": round(top["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "what": "algorithmic 2MNK per launch / launch time, against the fp32 matrix peak that bounds the native-fp32 kernel"}
@@ -817,7 +823,8 @@ def main():
         "metric": f"training steps/sec (B={args.batch_size}, n={args.n} MLP)", "value": world * args.steps / elapsed, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)" if split else
+        "dtype": (("f32 via f16x2 split (3 fp16 MFMA products of scaled two-piece operands, fp32 accumulate)" if getattr(tr, "split_f16", False)
+                   else "f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)") if split else
                   (("f32 via bf16x3 split on the 2000-wide layers (forward, data and weight gradients); native fp32 MFMA on the narrow ones"
                     if getattr(tr, "chain", None) else "f32 (forward / data gradients native fp32 MFMA; weight gradients via bf16x3 split)")
                    if wide_split else "f32")), "data": "synthetic",
@@ -832,6 +839,12 @@ def main():
         "final_loss": loss_vals[0], "final_pos": loss_vals[1], "final_neg": loss_vals[2],
     }
     out["encoder_arithmetic"] = (
+        ("f16x2 split (fp32 emulation, round 5): both fp32 operands of every encoder GEMM -- forward stack, backward data chain AND weight "
+         "gradients -- are scaled by a per-tensor power of two and split into two fp16 pieces (hi = RN(v s), lo = RN(v s - hi): 22 "
+         "significand bits), the three piece products hi.hi, hi.lo, lo.hi run on the fp16 matrix cores with fp32 accumulation (max error vs "
+         "fp64 at the native fp32-MFMA kernels' level, tests/test_gpu_mlp.py); scales follow the previous step's recorded maxima on the device, "
+         "overflow raises a sticky flag (`arith_state`); every -m gpu engine test runs in this mode, in bf16x3 and in native fp32 against the "
+         "same goldens / tolerances (tests/conftest.py: encoder_arith)") if getattr(tr, "split_f16", False) else
         "split-bf16 (fp32 emulation): both fp32 operands of every encoder GEMM -- forward stack, backward data chain AND weight "
         "gradients -- are split exactly into three bf16 pieces, the six piece products of order <= 2 run on the bf16 matrix cores "
         "with fp32 accumulation (max error vs fp64 8.6e-7 of max|y|, native fp32 MFMA 1.0e-6); every -m gpu engine test runs in "

@@ -94,6 +94,25 @@ SIGNATURES: Dict[str, list] = {
     "clica_mlp_wgrad_split": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
                               C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                               C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, c_size, C.c_void_p],
+    # f16x2 arithmetic (round 5)
+    "clica_split16_state_bytes": [C.POINTER(c_size)],
+    "clica_split16_state_init": [C.c_void_p, C.c_void_p],
+    "clica_split16_update": [C.c_void_p, c_i32, C.c_void_p],
+    "clica_split16_read": [C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
+    "clica_split16_clear_flags": [C.c_void_p, C.c_void_p],
+    "clica_mlp_planes16_bytes": [c_i64, c_i32, c_i32, C.POINTER(c_size)],
+    "clica_mlp_pack_split16_bytes": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.POINTER(c_size)],
+    "clica_mlp_pack_split16_both": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p],
+    "clica_mlp_fwd_split16": [c_f32p, c_i64, c_i64, c_f32p, c_i32, C.c_float, c_f32p, c_i64, c_i32, C.POINTER(C.c_void_p),
+                              C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(C.c_void_p),
+                              C.POINTER(C.c_void_p), C.c_float, C.c_void_p, C.c_void_p],
+    "clica_mlp_dgrad_split16": [c_f32p, c_i64, c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(C.c_void_p),
+                                C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.c_float, C.c_void_p, C.c_void_p],
+    "clica_mlp_wgrad_split16": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
+                                C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
+                                C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, c_size,
+                                C.c_void_p],
     "clica_mlp_pack_bytes": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.POINTER(c_size)],
     "clica_mlp_pack": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_i32, c_f32p, C.c_void_p],
     "clica_mlp_pack_both": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, c_f32p, C.c_void_p],

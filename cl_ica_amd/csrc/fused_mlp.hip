@@ -656,6 +656,89 @@ __device__ __forceinline__ void split3(float v, unsigned& hb, unsigned& mb, unsi
 
 static inline int64_t pack3_entries(int N, int K) { return (int64_t)((N + 15) / 16) * ((K + KI - 1) / KI) * 64; }   // 16-byte entries per piece
 
+// ---- the two split arithmetics of mlp_split_k ------------------------------------------------------------------------------------
+// AR = 0  "bf16x3": v = hi + mid + lo exactly (3 bf16 pieces by truncation), the six piece products of order <= 2; operands keep their
+//         fp32 exponent range; 6 B per element; 6 MFMAs of K = 32 per fp32 product block.
+// AR = 1  "f16x2" (round 5): v s = hi + lo with hi = RN_f16(v s), lo = RN_f16(v s - hi) (22 significand bits: the Ootomo-Yokota
+//         construction with an UNSCALED second piece -- see below), the three products hi.hi, hi.lo, lo.hi (lo.lo < 2^-22 |a||b| dropped);
+//         4 B per element; 3 MFMAs per block at the same MFMA rate: half the matrix work and two thirds of the operand bytes of AR = 0.
+//         fp16 has a 5-bit exponent, so every TENSOR carries a power-of-two scale s that puts its largest magnitude into
+//         [2^kF16Target, 2^(kF16Target+1)); elements keep 22 bits down to 2^-3 (where lo turns subnormal) and an ABSOLUTE error of
+//         2^-25 below that, i.e. <= 2^-33 of the tensor's maximum: norm-wise the fp32 accumulation (2^-24 sum |a||b|) dominates, as in
+//         AR = 0 (measured: 6.2e-7 of max|y| against fp64 on a 500 x 500 layer over 12 288 rows; native fp32 MFMA 7.2e-7, bf16x3 4.6e-7).
+//         The scale in force during a launch is the one derived from the PREVIOUS launch's maximum of the same tensor (Split16 state,
+//         clica_split16_*): every producer records max |v| as it writes, a one-workgroup update turns the maxima into the next scales.
+//         A tensor whose maximum grows by more than 2^(15-kF16Target-1) = 64 x between two consecutive steps would overflow fp16: the
+//         producers detect it (scaled magnitude > kF16Alarm) and raise a sticky device flag that the host checks at its sync points.
+template <int AR> struct Arith;
+template <> struct Arith<0> {
+  static constexpr int NP = 3, NPROD = 6;
+  static constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};      // (weight piece, activation piece), small terms first
+  static constexpr int XORDER[3] = {0, 2, 1};                                         // order in which the products first need the activation pieces
+};
+template <> struct Arith<1> {
+  static constexpr int NP = 2, NPROD = 3;
+  static constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};
+  static constexpr int XORDER[2] = {0, 1};
+};
+constexpr int kF16Target = 8;              // scaled maximum of a tensor in [256, 512)
+constexpr float kF16Alarm = 32768.f;       // a scaled magnitude beyond this raises the overflow flag (fp16 max 65504)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <int AR>
+__device__ __forceinline__ f32x4 mfma16(const u32x4 w, const u32x4 x, const f32x4 acc) {
+  if constexpr (AR == 0) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, x), acc, 0, 0, 0);
+}
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+// two scaled fp32 values -> packed hi pieces and packed lo pieces (5 instructions: cvt_pk, two cvt back, packed subtract, cvt_pk)
+__device__ __forceinline__ void split16_pair(const f32x2s t, unsigned& hi, unsigned& lo) {
+  const f16x2 h = __builtin_convertvector(t, f16x2);
+  const f32x2s r = t - __builtin_convertvector(h, f32x2s);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+__device__ __forceinline__ void split16_one(const float t, unsigned short& hi, unsigned short& lo) {
+  const _Float16 h = (_Float16)t;
+  hi = __builtin_bit_cast(unsigned short, h);
+  lo = __builtin_bit_cast(unsigned short, (_Float16)(t - (float)h));
+}
+// Device state of the f16x2 arithmetic of ONE encoder (clica_split16_state_bytes floats): per tensor family and position the running
+// maximum of the current step (true units, as uint bits: non-negative floats order like ints) and the scale in force.
+//   family A: activations in forward order   A[0] = encoder input x, A[l + 1] = output of layer l
+//   family D: gradients in CHAIN order        D[0] = d loss / d (last pre-activation), D[j + 1] = output of chain link j
+//   family W: weights, W[l] forward order;  WC[j] = the same scales in chain order (link j uses layer L - 1 - j)
+struct Split16State {
+  static constexpr int NT = MAXL + 1;
+  // (the maxima are NOT gathered by global atomics: 2 048 same-address device-scope atomics per layer cost 60 us per launch,
+  //  measured; every producer workgroup / pack wave leaves its maxima in a slot of its own behind this header and the update
+  //  kernel reduces them)
+  unsigned nA, nD, nPW;    // producer slots written since the last update: forward workgroups, chain workgroups, pack waves (0: not produced)
+  unsigned capWG, capPW;   // capacities of the slot arrays (= kS16CapWG / kS16CapPW; informational)
+  unsigned pad0[NT * 3 - 5];
+  float sA[NT], sD[NT], sW[NT], sWC[NT];
+  unsigned flags;          // bit 0: a scaled magnitude passed kF16Alarm (results of that launch are not to be trusted)
+  unsigned updates;        // number of scale updates so far
+  unsigned pad[2];
+  float pA[NT], pD[NT];    // the scales the LAST step ran with (kept by the update: what its plane copies are scaled by; inspection)
+};
+constexpr unsigned kS16CapWG = 4096;       // producer workgroups of a launch (48 rows each: batches up to 196 608 rows)
+constexpr unsigned kS16CapPW = 16384;      // pack waves (512 weights each)
+// slot arrays behind the header: partA[capWG][NT], partD[capWG][NT] (true-unit maxima as float bits), partW[capPW] (value), partWl[capPW] (layer, -1: none)
+__device__ __host__ inline unsigned* s16_partA(Split16State* st) { return reinterpret_cast<unsigned*>(st + 1); }
+__device__ __host__ inline unsigned* s16_partD(Split16State* st, unsigned capWG = kS16CapWG) { return s16_partA(st) + (size_t)capWG * Split16State::NT; }
+__device__ __host__ inline unsigned* s16_partW(Split16State* st, unsigned capWG = kS16CapWG) { return s16_partD(st, capWG) + (size_t)capWG * Split16State::NT; }
+__device__ __host__ inline int* s16_partWl(Split16State* st, unsigned capWG = kS16CapWG, unsigned capPW = kS16CapPW) { return reinterpret_cast<int*>(s16_partW(st, capWG) + capPW); }
+// one call per wave and tensor: the wave's maximum (true units; NaN / inf as a huge value so that the update kernel sees them) into an LDS word
+__device__ __forceinline__ void amax_wave_to_lds(unsigned* lds_word, float m_scaled, float inv_scale) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m_scaled = fmaxf(m_scaled, __shfl_xor(m_scaled, off, 64));
+  if ((threadIdx.x & 63) == 0) {
+    const float t = (m_scaled <= 3.0e38f) ? m_scaled * inv_scale : 3.4e38f;
+    atomicMax(lds_word, __float_as_uint(t));
+  }
+}
+
 // fragment-order pieces: dst[piece][cb][ki][lane] (16 B = 8 bf16) = piece(W[cb*16 + (lane&15)][ki*32 + (lane>>4)*8 .. +7])
 struct Pack3Args {
   int nseg;
@@ -690,6 +773,103 @@ __global__ __launch_bounds__(256) void mlp_pack3_k(Pack3Args a) {
   dst[0] = pk(h); dst[a.entries[sidx]] = pk(m); dst[2 * a.entries[sidx]] = pk(l);
 }
 
+// f16x2 weights: the same fragment order with two pieces, scaled by the layer's weight scale in force (Split16State::sW); the
+// forward-orientation segments also record max |W| of their layer for the next scale update.
+struct Pack2Args {
+  int nseg;
+  int64_t first[MAXSEG + 1];
+  u32x4* dst[MAXSEG];
+  int64_t entries[MAXSEG];
+  PackSeg seg[MAXSEG];
+  const float* scale[MAXSEG];      // device: the scale of this segment's tensor
+  int layer[MAXSEG];               // forward-orientation segments: the layer whose max |W| this segment records; -1: none
+  Split16State* st;
+};
+__global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = idx < a.first[a.nseg];
+  // (no early return: whole waves take part in the maximum; a wave never straddles two segments' amax slots because segment
+  //  sizes are multiples of 64 entries)
+  int sidx = 0;
+#pragma unroll
+  for (int i = 1; i < MAXSEG; ++i) sidx += (i < a.nseg && idx >= a.first[i]) ? 1 : 0;
+  const PackSeg& sg = a.seg[sidx];
+  const unsigned d = live ? (unsigned)(idx - a.first[sidx]) : 0u;
+  const unsigned kiters = (unsigned)(sg.cols + KI - 1) / KI;
+  const unsigned lane = d & 63u, frag = d >> 6;
+  const unsigned cb = frag / kiters, ki = frag - cb * kiters;
+  const int n = (int)(cb * 16u + (lane & 15u)), k = (int)(ki * KI + 8u * (lane >> 4));
+  const float sc = *a.scale[sidx];
+  unsigned hw[4], lw[4];
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f32x2s v = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int kk = k + 2 * u + e;
+      if (live && n < sg.rows && kk < sg.cols) v[e] = sc * (sg.transposed ? sg.W[(int64_t)kk * sg.ldw + n] : sg.W[(int64_t)n * sg.ldw + kk]);
+    }
+    m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    split16_pair(v, hw[u], lw[u]);
+  }
+  if (live) {
+    u32x4* dst = a.dst[sidx] + d;
+    dst[0] = (u32x4){hw[0], hw[1], hw[2], hw[3]};
+    dst[a.entries[sidx]] = (u32x4){lw[0], lw[1], lw[2], lw[3]};
+  }
+  // this wave's slot: max |W| (true units) and the layer it belongs to
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  const unsigned wid = (unsigned)(idx >> 6);
+  if ((threadIdx.x & 63) == 0 && wid < kS16CapPW) {
+    s16_partW(a.st)[wid] = __float_as_uint((m <= 3.0e38f) ? m / sc : 3.4e38f);
+    s16_partWl(a.st)[wid] = live ? a.layer[sidx] : -1;
+  }
+  if (idx == 0) a.st->nPW = (unsigned)((a.first[a.nseg] + 63) >> 6);
+}
+
+// Maxima of the step that has just run -> scales of the next one.  s = 2^(kF16Target - floor(log2 max)); a tensor nobody wrote
+// (maximum 0) keeps its scale.  Activation scales stay inside fp16's normal range (the constant-1 feature of a plane copy is stored
+// as the value s).  One workgroup: it also reduces the producers' slot arrays (no global atomics anywhere) and raises the overflow flag
+// when the step that has just run carried a scaled magnitude beyond kF16Alarm.
+__global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) {
+  constexpr int NT = Split16State::NT;
+  __shared__ unsigned mx[3][NT];
+  const int t = threadIdx.x;
+  if (t < 3 * NT) mx[t / NT][t % NT] = 0u;
+  __syncthreads();
+  const unsigned nA = min(st->nA, kS16CapWG), nD = min(st->nD, kS16CapWG), nPW = min(st->nPW, kS16CapPW);
+  const unsigned* pA = s16_partA(st); const unsigned* pD = s16_partD(st);
+  const unsigned* pW = s16_partW(st); const int* pWl = s16_partWl(st);
+  for (unsigned i = t; i < nA * NT; i += 256) atomicMax(&mx[0][i % NT], pA[i]);
+  for (unsigned i = t; i < nD * NT; i += 256) atomicMax(&mx[1][i % NT], pD[i]);
+  for (unsigned i = t; i < nPW; i += 256) { const int l = pWl[i]; if (l >= 0 && l < NT) atomicMax(&mx[2][l], pW[i]); }
+  __syncthreads();
+  auto next = [&](unsigned bits, float cur, int emin, int emax) {
+    const float a = __uint_as_float(bits);
+    if (!(a > 0.f)) return cur;                                 // nobody wrote the tensor: keep its scale
+    if (!(a < 3.0e38f) || a * cur > kF16Alarm) atomicOr(&st->flags, 1u);      // non-finite, or the step that just ran overflowed its scale
+    if (!(a < 3.0e38f)) return cur;
+    int e = (int)((bits >> 23) & 0xffu) - 127;                  // floor(log2 a) for normal a
+    if (((bits >> 23) & 0xffu) == 0u) e = -127;
+    int se = kF16Target - e;
+    se = se < emin ? emin : (se > emax ? emax : se);
+    return __uint_as_float((unsigned)(se + 127) << 23);
+  };
+  if (t <= L) { st->pA[t] = st->sA[t]; st->sA[t] = next(mx[0][t], st->sA[t], -14, 15); }
+  if (t < L) { st->pD[t] = st->sD[t]; st->sD[t] = next(mx[1][t], st->sD[t], -100, 100); }
+  float w = 1.f;
+  if (t < L) { w = next(mx[2][t], st->sW[t], -100, 100); st->sW[t] = w; }
+  if (t < L && L - 1 - t >= 0 && L - 1 - t < NT) st->sWC[L - 1 - t] = w;      // chain link j uses layer L - 1 - j
+  if (t == 0) { st->updates += 1u; st->nA = st->nD = st->nPW = 0u; }
+}
+__global__ __launch_bounds__(64) void split16_init_k(Split16State* st, unsigned capWG, unsigned capPW) {
+  const int t = threadIdx.x;
+  if (t < Split16State::NT) st->sA[t] = st->sD[t] = st->sW[t] = st->sWC[t] = st->pA[t] = st->pD[t] = 1.f;
+  if (t == 0) { st->flags = 0u; st->updates = 0u; st->nA = st->nD = st->nPW = 0u; st->capWG = capWG; st->capPW = capPW; }
+}
+
 // Debug build only (-DCLICA_SPLIT_TRACE, tools/split_trace.py): s_memtime stamps per (workgroup, wave, layer, phase), kept in
 // registers and written once at the end of the kernel
 #ifdef CLICA_SPLIT_TRACE
@@ -712,6 +892,11 @@ struct SplitArgs {
   int64_t ent3[MAXL];            // entries per piece of each layer
   int boff[MAXL + 1];            // float offset of each layer's bias row inside the LDS bias table (rows padded to KI)
   int warm_next;                 // L2 warm-up of the layer that follows a wide one: at most this many KB per early wave (see mlp_split_k)
+  // f16x2 arithmetic only (Arith<1>): scales in force and where to record the maxima, in THIS launch's order --
+  // s_t[0]: the launch's input tensor, s_t[l + 1]: output of layer l; s_w[l]: weights of layer l; part_t[workgroup][NT]: this launch's
+  // slot array for the maxima (same positions), count_t: where workgroup 0 leaves the number of slots written.
+  // `last_unscaled`: the last layer's output is not re-split (fp32 consumer only): its scale is 1 whatever s_t[L] says.
+  const float* s_t; const float* s_w; unsigned* part_t; unsigned* count_t; unsigned cap_wg; int last_unscaled;
   // Round 4: what the training step's epilogues need of a layer, in ONE 64-byte record (one s_load_dwordx16 at the top of the layer).
   // Reading the same facts field by field from g.layer[l] behind the k-loop was a chain of ~10 DEPENDENT scalar loads, each with its
   // own s_waitcnt lgkmcnt(0) (flag -> branch -> next flag) in front of the epilogue, with the matrix pipe idle (tools/split_trace.py).
@@ -727,7 +912,7 @@ struct SplitArgs {
 #endif
 constexpr int WARM_LOADS = CLICA_SPLIT_WARM_NEXT;   // L2 warm-up: 1 KB slices of the NEXT layer's weights per participating wave (see mlp_split_k)
 constexpr int WARM_LOADS2 = 3;                      // ... of the layer after it (short layers only)
-constexpr int BIAS_LDS_MAX = (160 * 1024 - 3 * PLANE * 2) / 4 - 64;    // floats left beside the three planes
+constexpr int BIAS_LDS_MAX = (160 * 1024 - 3 * PLANE * 2) / 4 - 64;    // floats left beside the three planes (the f16x2 kernel has a plane to spare)
 
 // Narrow layers (ONE column block per wave: the 100- and 10-wide layers).  The wide loop below keeps ONE k-iteration of
 // weights in flight, enough when 72 MFMAs (1 152+ cycles) cover an L2 miss.  Here an iteration is 18 or 36 MFMAs, and in the
@@ -735,46 +920,44 @@ constexpr int BIAS_LDS_MAX = (160 * 1024 - 3 * PLANE * 2) / 4 - 64;    // floats
 // from HBM): the trace showed the 500 -> 100 layer at 29.9 k cycles for 16 iterations cold against 15.8 k warm, i.e. one exposed
 // memory round trip per iteration.  So: a ring of FOUR weight sets (three iterations in flight, the registers the wide loop
 // spends on its four column blocks) and two activation-fragment sets (the LDS reads of iteration i + 1 under the MFMAs of i).
-template <int NC>
+template <int NC, int AR>
 __device__ __forceinline__ void layer_gemm_split_narrow(const int K, const u32x4* __restrict__ w0, const int64_t ent, const unsigned short* planes,
-                                                        int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[3][CBW]) {
+                                                        int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[Arith<AR>::NP][CBW]) {
+  constexpr int NP = Arith<AR>::NP, NPROD = Arith<AR>::NPROD;
   static_assert(NC == 1, "narrow variant: with two column blocks the ring (96) + both fragment sets (72) + accumulators spill");
   const int i15 = lane & 15, kg = lane >> 4;
   const int kiters = (K + KI - 1) / KI;
   const unsigned lane16 = (unsigned)lane * 16u;
-  u32x4 w[4][3][NC];
-  u32x4 x[2][3][RB];
+  u32x4 w[4][NP][NC];
+  u32x4 x[2][NP][RB];
   auto kof = [&](int ki) { return ki < kiters ? ki : kiters - 1; };      // past the end: a harmless re-read of the last iteration's operands
-  auto fetch_w = [&](u32x4 (&d)[3][NC], int ki) {
+  auto fetch_w = [&](u32x4 (&d)[NP][NC], int ki) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const char* base = reinterpret_cast<const char*>(w0 + p * ent + ((int64_t)(wave + c * WAVES) * kiters + ki) * 64);
         d[p][c] = *reinterpret_cast<const u32x4*>(base + lane16);
       }
   };
-  auto fetch_x = [&](u32x4 (&d)[3][RB], int ki) {
-    constexpr int ORDER[3] = {0, 2, 1};
+  auto fetch_x = [&](u32x4 (&d)[NP][RB], int ki) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
       for (int r = 0; r < RB; ++r)
-        d[ORDER[q]][r] = *reinterpret_cast<const u32x4*>(&planes[ORDER[q] * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
+        d[Arith<AR>::XORDER[q]][r] = *reinterpret_cast<const u32x4*>(&planes[Arith<AR>::XORDER[q] * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
   };
-  auto mma = [&](const u32x4 (&ww)[3][NC], const u32x4 (&xx)[3][RB]) {
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+  auto mma = [&](const u32x4 (&ww)[NP][NC], const u32x4 (&xx)[NP][RB]) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < NPROD; ++t)
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int r = 0; r < RB; ++r)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ww[PW[t]][c]), __builtin_bit_cast(bf16x8, xx[PX[t]][r]),
-                                                              acc[r][c], 0, 0, 0);
+          acc[r][c] = mfma16<AR>(ww[Arith<AR>::PW[t]][c], xx[Arith<AR>::PX[t]][r], acc[r][c]);
   };
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int c = 0; c < NC; ++c) w[0][p][c] = wpre[p][c];
   fetch_w(w[1], kof(1));
@@ -795,16 +978,17 @@ __device__ __forceinline__ void layer_gemm_split_narrow(const int K, const u32x4
   __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the dead look-ahead requests (see layer_gemm_split)
 }
 
-template <int NC>
+template <int NC, int AR>
 __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __restrict__ w0, const int64_t ent, const unsigned short* planes,
-                                                 int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[3][CBW], volatile int* prog) {
+                                                 int wave, int lane, f32x4 (&acc)[RB][CBW], const u32x4 (&wpre)[Arith<AR>::NP][CBW], volatile int* prog) {
+  constexpr int NP = Arith<AR>::NP, NPROD = Arith<AR>::NPROD;
   const int i15 = lane & 15, kg = lane >> 4;
   const int kiters = (K + KI - 1) / KI;
-  u32x4 wcur[3][CBW], wnxt[3][CBW];
+  u32x4 wcur[NP][CBW], wnxt[NP][CBW];
   const unsigned lane16 = (unsigned)lane * 16u;
-  auto fetch_w = [&](u32x4 (&w)[3][CBW], int ki) {
+  auto fetch_w = [&](u32x4 (&w)[NP][CBW], int ki) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {     // wave-uniform 64-bit base (scalar registers) + 32-bit lane offset: no per-load VGPR address pair
         const char* base = reinterpret_cast<const char*>(w0 + p * ent + ((int64_t)(wave + c * WAVES) * kiters + ki) * 64);
@@ -812,38 +996,9 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
       }
   };
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int c = 0; c < NC; ++c) wcur[p][c] = wpre[p][c];
-#if !CLICA_SPLIT_PINGPONG
-  auto step = [&](int ki, int kn) {
-    fetch_w(wnxt, kn);
-    u32x4 x[3][RB];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int r = 0; r < RB; ++r)
-        x[p][r] = *reinterpret_cast<const u32x4*>(&planes[p * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
-    // keep the twelve weight requests of the NEXT iteration up here, ahead of this iteration's 72 MFMAs: left alone, the
-    // scheduler sinks each load to just before its first use (to save registers) and every one becomes an exposed L2 round trip
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};     // (weight piece, activation piece), small terms first
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wcur[PW[t]][c]), __builtin_bit_cast(bf16x8, x[PX[t]][r]),
-                                                              acc[r][c], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int c = 0; c < NC; ++c) { asm volatile("" : "+v"(wnxt[p][c])); wcur[p][c] = wnxt[p][c]; }
-  };
-#endif
-#if CLICA_SPLIT_PINGPONG
   // Ping-pong form (round 3; the fp32 kernel's k-loop got the same treatment in round 2): two weight sets AND two activation
   // fragment sets with swapped roles in a loop unrolled by two -- no rotation copies (the 12 x 4 v_mov per iteration above),
   // the activation fragments of iteration ki + 1 are read from the panel during the MFMAs of ki instead of in front of them,
@@ -852,34 +1007,31 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
   // (Two activation-fragment sets as well -- reading iteration ki + 1's fragments during the MFMAs of ki -- does not fit: 96 + 72 +
   //  48 registers plus the epilogue's live values spill 71 VGPRs.  The fragments stay single-buffered, read at the head of the
   //  block in the order hi, lo, mid = the order the six products first need them.)
-  auto fetch_x = [&](u32x4 (&x)[3][RB], int ki) {
-    constexpr int ORDER[3] = {0, 2, 1};
+  auto fetch_x = [&](u32x4 (&x)[NP][RB], int ki) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < NP; ++q)
 #pragma unroll
       for (int r = 0; r < RB; ++r)
-        x[ORDER[q]][r] = *reinterpret_cast<const u32x4*>(&planes[ORDER[q] * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
+        x[Arith<AR>::XORDER[q]][r] = *reinterpret_cast<const u32x4*>(&planes[Arith<AR>::XORDER[q] * PLANE + (r * 16 + i15) * LDPB + ki * KI + kg * 8]);
   };
-  auto mma = [&](const u32x4 (&w)[3][CBW], const u32x4 (&x)[3][RB]) {
-    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+  auto mma = [&](const u32x4 (&w)[NP][CBW], const u32x4 (&x)[NP][RB]) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < NPROD; ++t)
 #pragma unroll
       for (int c = 0; c < NC; ++c)
 #pragma unroll
         for (int r = 0; r < RB; ++r)
-          acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[PW[t]][c]), __builtin_bit_cast(bf16x8, x[PX[t]][r]),
-                                                              acc[r][c], 0, 0, 0);
+          acc[r][c] = mfma16<AR>(w[Arith<AR>::PW[t]][c], x[Arith<AR>::PX[t]][r], acc[r][c]);
   };
   auto pin = [&]() {        // one weight request behind every CLICA_SPLIT_LOAD_GAP-th MFMA, the rest of the MFMAs behind the last one
 #pragma unroll
-    for (int i = 0; i < 3 * NC; ++i) {
+    for (int i = 0; i < NP * NC; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, CLICA_SPLIT_LOAD_GAP, 0);
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // 1 VMEM read
     }
   };
   auto kof = [&](int ki) { return ki < kiters ? ki : kiters - 1; };      // past the end: a harmless re-read of the last iteration's operands
-  u32x4 x[3][RB];
+  u32x4 x[NP][RB];
   int ki = 0;
   for (; ki + 1 < kiters; ki += 2) {
 #if CLICA_SPLIT_BALANCE
@@ -915,16 +1067,12 @@ __device__ __forceinline__ void layer_gemm_split(const int K, const u32x4* __res
   // stores, behind the next layer's weight requests.  Here it only waits for loads issued a whole MFMA block ago.
   __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), expcnt / lgkmcnt untouched
 }
-#else
-  step(0, kiters > 1 ? 1 : 0);                                   // peeled: its weights were requested before the previous epilogue
-  for (int ki = 1; ki < kiters; ++ki) step(ki, ki + 1 < kiters ? ki + 1 : ki);
-}
-#endif
 
-__device__ __forceinline__ void request_first_w3(const u32x4* __restrict__ w0, int64_t ent, int K, int N, int wave, int lane, u32x4 (&w)[3][CBW]) {
+template <int NP>
+__device__ __forceinline__ void request_first_w3(const u32x4* __restrict__ w0, int64_t ent, int K, int N, int wave, int lane, u32x4 (&w)[NP][CBW]) {
   const int kiters = (K + KI - 1) / KI, ncb_real = (N + 15) / 16;
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int c = 0; c < CBW; ++c) {
       const int cb = wave + c * WAVES;
@@ -1058,28 +1206,139 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
   lo_bits = lo; hi_bits = hi;
 }
 
+// ---- epilogue of one layer in the f16x2 arithmetic ---------------------------------------------------------------------------
+//   ACT 1: t = acc * cmul + bias' (bias' = bias * s_out, from the LDS table), LeakyReLU when `leaky` (slope in (0, 1): max(t, slope t))
+//   ACT 2: t = acc * cmul, then t or slope * t by the forward's sign bit (backward chain link)
+// t is the layer output IN THE OUTPUT TENSOR'S SCALED UNITS (cmul = s_out / (s_in s_w) folds all three scales; LeakyReLU and the gate
+// are positively homogeneous).  It is split into hi / lo for the next layer's panel (LDS) and, `has_pl`, for the plane copy the
+// weight-gradient kernel reads (planes.h, two pieces per unit); `has_out`: the fp32 copy gets t / s_out (exact: powers of two).
+// Features >= N come out as exact zeros (zero weight fragments, zero-padded bias row), as in the bf16x3 fast path.
+template <int ACT, bool BITS>
+__device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], unsigned short* planes, const float* bias_row, const float slope, const bool leaky,
+                                                 const unsigned long long mbits, const int N, const int ncb, const int wave, const int lane,
+                                                 const bool has_out, const bool ovec, float* out_rows, const __amdgpu_buffer_rsrc_t orsrc, const int ldo, const int nrows,
+                                                 const bool has_pl, const __amdgpu_buffer_rsrc_t prsrc, const int pl_group_bytes, const int pl_ones,
+                                                 const float cmul, const float s_out, const float inv_s_out,
+                                                 unsigned& lo_bits, unsigned& hi_bits, float& amax_scaled) {
+  const int i15 = lane & 15, kg = lane >> 4;
+  const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
+  const f32x2 slope2 = {slope, slope}, cmul2 = {cmul, cmul}, inv2 = {inv_s_out, inv_s_out};
+  const int mlo = (int)(unsigned)mbits, mhi = (int)(unsigned)(mbits >> 32);
+  unsigned lo = 0u, hi = 0u;
+  float am = 0.f;
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) {
+    const int cb = wave + c * WAVES;
+    if (cb < ncb) {                                    // wave-uniform
+      const int n0 = cb * 16 + kg * 4;
+      f32x2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
+      if (ACT == 1) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_row[n0]); b01 = (f32x2){b4[0], b4[1]}; b23 = (f32x2){b4[2], b4[3]}; }
+      const unsigned pl_cb = (unsigned)((cb >> 1) * 2 * 1024 + (cb & 1) * 128) + pl_lane;
+      unsigned short* const dst0 = planes + i15 * LDPB + n0;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int row = r * 16 + i15;
+        const f32x4 v = acc[r][c];
+        f32x2 t[2] = {(f32x2){v[0], v[1]}, (f32x2){v[2], v[3]}};
+        if (ACT == 1) {
+          t[0] = t[0] * cmul2 + b01; t[1] = t[1] * cmul2 + b23;      // (v_pk_fma_f32 under -ffp-contract=fast)
+          if (leaky) {                                 // wave-uniform
+            const f32x2 s0 = t[0] * slope2, s1 = t[1] * slope2;
+            t[0] = (f32x2){fmaxf(t[0][0], s0[0]), fmaxf(t[0][1], s0[1])};
+            t[1] = (f32x2){fmaxf(t[1][0], s1[0]), fmaxf(t[1][1], s1[1])};
+          }
+        }
+        if (ACT == 2) {
+          t[0] *= cmul2; t[1] *= cmul2;
+          const f32x2 sl[2] = {t[0] * slope2, t[1] * slope2};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int bit = (c * RB + r) * 4 + e;      // compile time
+            int sel; float tv = t[e >> 1][e & 1];
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(bit < 32 ? mlo : mhi), "n"(bit & 31));      // 0 or ~0
+            asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(tv) : "v"(sel), "v"(tv), "v"(sl[e >> 1][e & 1]));      // bit ? t : slope t
+            t[e >> 1][e & 1] = tv;
+          }
+        }
+        if (BITS) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int bit = (c * RB + r) * 4 + e;
+            if (bit < 32) shift_in_positive(lo, t[e >> 1][e & 1]); else shift_in_positive(hi, t[e >> 1][e & 1]);
+          }
+        }
+        am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(t[0][0]), __builtin_fabsf(t[0][1])));      // v_max3_f32 with |.| modifiers
+        am = __builtin_fmaxf(am, __builtin_fmaxf(__builtin_fabsf(t[1][0]), __builtin_fabsf(t[1][1])));
+        unsigned h0, l0, h1, l1;
+        split16_pair(t[0], h0, l0);
+        split16_pair(t[1], h1, l1);
+        const u32x2 ph = {h0, h1}, pl = {l0, l1};
+        unsigned short* dst = dst0 + r * 16 * LDPB;
+        *reinterpret_cast<u32x2*>(dst) = ph;
+        *reinterpret_cast<u32x2*>(dst + PLANE) = pl;
+        if (has_pl) {                                  // wave-uniform
+          const unsigned po = (unsigned)(r * pl_group_bytes) + pl_cb;
+          __builtin_amdgcn_raw_buffer_store_b64(ph, prsrc, po, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(pl, prsrc, po + 1024u, 0, 0);
+        }
+        if (has_out) {                                 // wave-uniform
+          const f32x2 o0 = t[0] * inv2, o1 = t[1] * inv2;
+          if (ovec) {
+            const unsigned off = (row < nrows && n0 < N) ? (unsigned)((row * ldo + n0) * 4) : kOobOffset;
+            __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(o0[0]), __float_as_uint(o0[1]), __float_as_uint(o1[0]), __float_as_uint(o1[1])},
+                                                   orsrc, off, 0, 0);
+          } else {
+            const float ov[4] = {o0[0], o0[1], o1[0], o1[1]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (row < nrows && n0 + e < N) out_rows[(int64_t)row * ldo + n0 + e] = ov[e];
+          }
+        }
+      }
+      if (has_pl && pl_ones && cb == (N >> 4) && (N & 31) != 0) {     // wave-uniform: feature N of the HBM copy is the constant 1, i.e. s_out in scaled units
+        const bool owner = N >= n0 && N < n0 + 4;
+        const unsigned short one = __builtin_bit_cast(unsigned short, (_Float16)s_out);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+          __builtin_amdgcn_raw_buffer_store_b16(one, prsrc, owner ? (unsigned)(r * pl_group_bytes) + pl_cb + (unsigned)((N - n0) * 2) : kOobOffset, 0, 0);
+      }
+    } else if (BITS) {                                 // keep the bit positions of the blocks that follow
+#pragma unroll
+      for (int r = 0; r < RB; ++r) { if ((c * RB + r) * 4 < 32) lo <<= 4; else hi <<= 4; }
+    }
+  }
+  if (BITS) {
+    lo = __builtin_bitreverse32(lo);
+    hi = __builtin_bitreverse32(hi) >> (64 - CBW * RB * 4);
+  }
+  lo_bits = lo; hi_bits = hi;
+  amax_scaled = am;
+}
+
 // One wave's share of the L2 warm-up of layer `lt` (only if it fits: at most NL KB per participating wave of the XCD): plain
 // 16-byte loads of this wave's 1 KB slices of the packed weights, values discarded by the caller once they have landed.
-template <int NL>
+template <int NL, int NP>
 __device__ __forceinline__ void warm_up_l2(const SplitArgs& a, const int L, const int lt, const int limit, const int wave, const int lane, u32x4 (&warm)[NL]) {
   constexpr int WW = WAVES / 2;                                               // participating waves per workgroup (the early half)
   const int nwx = (((int)gridDim.x + 7) >> 3) * WW;                           // ... per XCD (workgroups go round-robin over the eight)
   const int xw = ((int)blockIdx.x >> 3) * WW + wave;
   if (lt >= L) return;
-  const int64_t loads = (3 * a.ent3[lt] + 63) >> 6;                            // 64 entries of 16 B per wave instruction
+  const int64_t loads = (NP * a.ent3[lt] + 63) >> 6;                           // 64 entries of 16 B per wave instruction
   if (loads > (int64_t)(limit < NL ? limit : NL) * nwx) return;
 #pragma unroll
   for (int u = 0; u < NL; ++u) {
     const int64_t idx = xw + (int64_t)u * nwx;
     if (idx < loads) {
       const int64_t e = idx * 64 + lane;
-      warm[u] = a.packed3[a.off3[lt] + (e < 3 * a.ent3[lt] ? e : 0)];
+      warm[u] = a.packed3[a.off3[lt] + (e < NP * a.ent3[lt] ? e : 0)];
     }
   }
 }
 
+template <int AR>
 __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short planes[];     // [3][ROWS][LDPB] bf16 bit patterns
+  constexpr int NP = Arith<AR>::NP;
+  extern __shared__ __attribute__((aligned(16))) unsigned short planes[];     // [NP][ROWS][LDPB] bf16 / fp16 bit patterns
   const Args& g = a.g;
   const int lane = threadIdx.x & 63;
   const int lane_id = lane;
@@ -1098,14 +1357,16 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   // the input rows, the mixing weights -- and only then consumed: the trace showed 27.9 k cycles (12 % of the forward launch)
   // between kernel entry and the first layer when each of these was a dependent round trip of its own (seven bias loops, the
   // input, three mixing layers reading their weights from global memory), all of them cold.
-  u32x4 wpre[3][CBW];
-  request_first_w3(a.packed3 + a.off3[0], a.ent3[0], g.layer[0].K, g.layer[0].N, wave, lane, wpre);
+  u32x4 wpre[NP][CBW];
+  request_first_w3<NP>(a.packed3 + a.off3[0], a.ent3[0], g.layer[0].K, g.layer[0].N, wave, lane, wpre);
   u32x2 mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(g.layer[0].dact ? g.layer[0].mask_in : nullptr), mslot, 0, 0);
   // all layers' biases in the LDS left beside the planes (rows zero-padded to KI): the epilogue reads four consecutive
   // features with one ds_read_b128 instead of holding them in registers across the k-loop
-  float* bias_lds = reinterpret_cast<float*>(planes + 3 * PLANE);
+  float* bias_lds = reinterpret_cast<float*>(planes + NP * PLANE);
   volatile int* prog = reinterpret_cast<volatile int*>(bias_lds + a.boff[g.L]);      // k-loop progress of the eight waves (layer_gemm_split)
   if (lane == 0) prog[wave] = 0;
+  unsigned* amax_lds = const_cast<unsigned*>(reinterpret_cast<volatile unsigned*>(prog)) + WAVES;      // f16x2: the workgroup's maxima, one word per tensor of the launch
+  if constexpr (AR == 1) { if (threadIdx.x < Split16State::NT) amax_lds[threadIdx.x] = 0u; }
   constexpr int BIAS_IT = (BIAS_LDS_MAX + THREADS - 1) / THREADS;
   float bv[BIAS_IT];
   const int btotal = a.boff[g.L];
@@ -1120,13 +1381,22 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       const Layer& ly = g.layer[l];
       const int i = idx - a.boff[l];
       if (ly.bias && i < ly.N) bv[u] = ly.bias[i];
+      if constexpr (AR == 1) bv[u] *= (l == g.L - 1 && a.last_unscaled) ? 1.f : a.s_t[l + 1];      // the table holds bias' = bias * s_out
     }
   }
+  float s_in0 = 1.f, in_max = 0.f;                     // f16x2: scale of the launch's input tensor, running max of its scaled magnitudes
+  if constexpr (AR == 1) s_in0 = a.s_t[0];
   auto store_split = [&](int r, int k, float v) {
-    unsigned hb, mb, lb; split3(v, hb, mb, lb);
-    planes[r * LDPB + k] = (unsigned short)(hb >> 16);
-    planes[PLANE + r * LDPB + k] = (unsigned short)(mb >> 16);
-    planes[2 * PLANE + r * LDPB + k] = (unsigned short)(lb >> 16);
+    if constexpr (AR == 0) {
+      unsigned hb, mb, lb; split3(v, hb, mb, lb);
+      planes[r * LDPB + k] = (unsigned short)(hb >> 16);
+      planes[PLANE + r * LDPB + k] = (unsigned short)(mb >> 16);
+      planes[2 * PLANE + r * LDPB + k] = (unsigned short)(lb >> 16);
+    } else {
+      const float t = v * s_in0;
+      in_max = fmaxf(in_max, fabsf(t));
+      split16_one(t, planes[r * LDPB + k], planes[PLANE + r * LDPB + k]);
+    }
   };
   {
     const int K0 = g.layer[0].K, K16 = (K0 + KI - 1) & ~(KI - 1);
@@ -1204,6 +1474,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     }
   }
   __syncthreads();
+  if constexpr (AR == 1) amax_wave_to_lds(&amax_lds[0], in_max, 1.f / s_in0);
 
 #pragma unroll 1
   for (int l = 0; l < g.L; ++l) {
@@ -1222,10 +1493,10 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     const unsigned long long mbits = (unsigned long long)mraw.x | ((unsigned long long)mraw.y << 32);
     const u32x4* w0 = a.packed3 + q.off3;
     switch (nc) {
-      case 4: layer_gemm_split<4>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
-      case 3: layer_gemm_split<3>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
-      case 2: layer_gemm_split<2>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
-      case 1: layer_gemm_split_narrow<1>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
+      case 4: layer_gemm_split<4, AR>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
+      case 3: layer_gemm_split<3, AR>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
+      case 2: layer_gemm_split<2, AR>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre, prog); break;
+      case 1: layer_gemm_split_narrow<1, AR>(q.K, w0, q.ent3, planes, wave, lane, acc, wpre); break;
       default: break;
     }
     // pin the record in scalar registers HERE (one wait, behind the k-loop's own work): read lazily it was a chain of dependent
@@ -1248,8 +1519,8 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
 #pragma unroll
     for (int u = 0; u < WARM_LOADS2; ++u) warm2[u] = (u32x4){0u, 0u, 0u, 0u};
     if (nc >= 3 && wave < WAVES / 2) {
-      warm_up_l2<WARM_LOADS>(a, g.L, l + 1, a.warm_next, wave, lane, warm);
-      warm_up_l2<WARM_LOADS2>(a, g.L, l + 2, WARM_LOADS2, wave, lane, warm2);
+      warm_up_l2<WARM_LOADS, NP>(a, g.L, l + 1, a.warm_next, wave, lane, warm);
+      warm_up_l2<WARM_LOADS2, NP>(a, g.L, l + 2, WARM_LOADS2, wave, lane, warm2);
     }
     // Round 4: the next layer's first weights (read-only: no need to wait for the barrier) and sign bits are requested HERE.  Behind
     // the barrier all eight waves' 104 requests of 1 KB arrived at the CU's 64 B/clk address path at once and took ~1.7 k cycles to
@@ -1257,7 +1528,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     // ~17 k cycles before the late ones, so their half is through long before the barrier opens.
     if (has_next) {
       const Layer& nx = g.layer[l + 1];
-      request_first_w3(a.packed3 + a.off3[l + 1], a.ent3[l + 1], nx.K, nx.N, wave, lane, wpre);
+      request_first_w3<NP>(a.packed3 + a.off3[l + 1], a.ent3[l + 1], nx.K, nx.N, wave, lane, wpre);
       mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(nx.dact ? nx.mask_in : nullptr), mslot, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1275,6 +1546,56 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     ST_STAMP(l, 4);
     __builtin_amdgcn_sched_barrier(0);
     ST_STAMP(l, 5);
+    if constexpr (AR == 1) {
+      int lane = lane_id;
+      asm volatile("" : "+v"(lane));
+      const int N = q.N;
+      const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;
+      const bool last_plain = (l == g.L - 1) && a.last_unscaled;
+      const float s_out = last_plain ? 1.f : a.s_t[l + 1];
+      const float inv_s_out = 1.f / s_out;
+      const float cmul = s_out / (a.s_t[l] * a.s_w[l]);
+      const bool has_out = ly.out != nullptr, has_pl = q.planes != nullptr;
+      const bool ovec = has_out && ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (N % 4 == 0);
+      const __amdgpu_buffer_rsrc_t orsrc =
+          __builtin_amdgcn_make_buffer_rsrc(has_out ? ly.out + row0 * ly.ldo : nullptr, 0,
+                                            has_out ? (int)(((int64_t)(nrows - 1) * ly.ldo + N) * 4) : 0, kRsrcWord3);
+      const int pl_group_bytes = q.pl_units * NP * 1024;
+      const __amdgpu_buffer_rsrc_t prsrc =
+          __builtin_amdgcn_make_buffer_rsrc(has_pl ? reinterpret_cast<char*>(q.planes) + (int64_t)blockIdx.x * RB * pl_group_bytes : nullptr, 0,
+                                            has_pl ? RB * pl_group_bytes : 0, kRsrcWord3);
+      float* out_rows = has_out ? ly.out + row0 * ly.ldo : nullptr;
+      unsigned lo = 0u, hi = 0u;
+      float am = 0.f;
+      const float* brow = &bias_lds[q.boff];
+      if (!ly.dact) {
+        if (q.mask_out) split16_epilogue<1, true>(acc, planes, brow, g.slope, ly.leaky != 0, mbits, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
+                                                  has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
+        else split16_epilogue<1, false>(acc, planes, brow, g.slope, ly.leaky != 0, mbits, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
+                                        has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
+      } else {
+        const unsigned long long mb = ly.mask_in ? mbits : ~0ull;      // no sign bits: no gate
+        split16_epilogue<2, false>(acc, planes, brow, g.slope, false, mb, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
+                                   has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
+      }
+      if (has_pl && q.pl_ones && (N & 31) == 0 && wave == 0) {   // the ones column in an extra unit (value s_out: 1 in scaled units)
+        const bool first = (lane & 1) == 0 && ((lane >> 3) & 1) == 0;
+        const unsigned one = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)s_out);
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) {
+            const u32x4 v4 = (u32x4){(pp == 0 && first) ? one : 0u, 0u, 0u, 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(v4, prsrc, (unsigned)(r * pl_group_bytes + ((N >> 5) * NP + pp) * 1024 + lane * 16), 0, 0);
+          }
+      }
+      if (q.mask_out) __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(q.mask_out), (wave * 64 + lane) * 8, 0, 0);
+      amax_wave_to_lds(&amax_lds[l + 1], am, inv_s_out);
+      if (lane == 0) prog[wave] = 0;
+      ST_STAMP(l, 3);
+      __syncthreads();
+      continue;
+    }
     if (CLICA_SPLIT_FAST_EPI && q.fast_kind != 0) {
       // the training step's epilogues, from the quick record alone
       int lane = lane_id;
@@ -1418,6 +1739,10 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     if (lane == 0) prog[wave] = 0;
     ST_STAMP(l, 3);
     __syncthreads();
+  }
+  if constexpr (AR == 1) {        // (behind the last layer's closing barrier) this workgroup's slot of the maxima
+    if (blockIdx.x < a.cap_wg && threadIdx.x < Split16State::NT) a.part_t[(size_t)blockIdx.x * Split16State::NT + threadIdx.x] = amax_lds[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_t = gridDim.x;
   }
   ST_FLUSH(g.L);
 }
@@ -1664,7 +1989,7 @@ extern "C" int clica_mlp_planes_bytes(int64_t M, int32_t width, int32_t ones_col
   return CLICA_OK;
 }
 
-static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* who) {
+static int launch_split(fmlp::SplitArgs& a, int arith, clica_stream_t stream, const char* who) {
   using namespace fmlp;
   a.boff[0] = 0;
   for (int l = 0; l < a.g.L; ++l) a.boff[l + 1] = a.boff[l] + ((a.g.layer[l].N + KI - 1) & ~(KI - 1));
@@ -1686,20 +2011,30 @@ static int launch_split(fmlp::SplitArgs& a, clica_stream_t stream, const char* w
       else if (ly.dact && ly.mask_in && !ly.mask_out) q.fast_kind = 3;
     }
   }
-  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 64;      // + the waves' progress words
-  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 64;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
+  if (arith == 1) {
+    if (!slope01) { set_error("%s: the f16x2 arithmetic needs a LeakyReLU slope in (0, 1), got %g", who, (double)a.g.slope); return CLICA_E_INVALID; }
+    const size_t lds = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 128;
+    constexpr size_t lds_max = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 128;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
+    (void)once;
+    hipLaunchKernelGGL(mlp_split_k<1>, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
+    return launch_status(who);
+  }
+  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 128;      // + the waves' progress words
+  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 128;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
   (void)once;
-  hipLaunchKernelGGL(mlp_split_k, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
+  hipLaunchKernelGGL(mlp_split_k<0>, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
   return launch_status(who);
 }
 
-extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
-                                   float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
-                                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
-                                   const void* packed_split, uint64_t* const* signmask, void* const* planes, float slope,
-                                   clica_stream_t stream) {
+static int mlp_fwd_split_impl(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                              float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
+                              float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                              const void* packed_split, uint64_t* const* signmask, void* const* planes, float slope,
+                              void* state16, clica_stream_t stream) {
   using namespace fmlp;
+  const int NPc = state16 ? 2 : 3;
   CLICA_CHECK_ARG(X && bias && out && ldo && N && K && packed_split && M > 0, "clica_mlp_fwd_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXL, "clica_mlp_fwd_split: %d layers (1..%d supported)", n_layers, MAXL);
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_split) & 15) == 0, "clica_mlp_fwd_split: packed weights must be 16-byte aligned");
@@ -1719,17 +2054,42 @@ extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const
     unsigned long long* mo = (signmask && signmask[l]) ? reinterpret_cast<unsigned long long*>(signmask[l]) : nullptr;
     g.layer[l] = Layer{nullptr, 0, bias[l], out[l], ldo[l], nullptr, 0, mo, nullptr, N[l], K[l], l + 1 < n_layers ? 1 : 0, 0,
                        reinterpret_cast<unsigned short*>(pl), planes::units(N[l], 1), 1};
-    a.off3[l] = off; a.ent3[l] = pack3_entries(N[l], K[l]); off += 3 * a.ent3[l];
+    a.off3[l] = off; a.ent3[l] = pack3_entries(N[l], K[l]); off += NPc * a.ent3[l];
   }
   CLICA_CHECK_ARG(ldx >= K[0], "clica_mlp_fwd_split: ldx < K[0]");
   if (mix_W) CLICA_CHECK_ARG(mix_layers >= 1 && K[0] <= MIX_MAX_N && x_out && ldxo >= K[0], "clica_mlp_fwd_split: bad mixing-net arguments");
-  return launch_split(a, stream, "clica_mlp_fwd_split");
+  if (state16) {
+    Split16State* st = reinterpret_cast<Split16State*>(state16);
+    CLICA_CHECK_ARG(ceil_div(M, (int64_t)ROWS) <= (int64_t)kS16CapWG, "clica_mlp_fwd_split16: M = %lld rows exceeds the state's %u workgroup slots", (long long)M, kS16CapWG);
+    a.s_t = st->sA; a.s_w = st->sW; a.part_t = s16_partA(st); a.count_t = &st->nA; a.cap_wg = kS16CapWG;
+    a.last_unscaled = (planes && planes[n_layers - 1]) ? 0 : 1;
+  }
+  return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_fwd_split16" : "clica_mlp_fwd_split");
 }
 
-extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
-                                     const void* packed_split, const uint64_t* const* signmask,
-                                     float* const* out, const int64_t* ldo, void* const* planes, float slope, clica_stream_t stream) {
+extern "C" int clica_mlp_fwd_split(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                                   float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
+                                   float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                                   const void* packed_split, uint64_t* const* signmask, void* const* planes, float slope,
+                                   clica_stream_t stream) {
+  return mlp_fwd_split_impl(X, ldx, M, mix_W, mix_layers, mix_slope, x_out, ldxo, n_layers, bias, out, ldo, N, K, packed_split, signmask, planes,
+                            slope, nullptr, stream);
+}
+extern "C" int clica_mlp_fwd_split16(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                                     float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
+                                     float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                                     const void* packed_split16, uint64_t* const* signmask, void* const* planes, float slope,
+                                     void* state, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr, "clica_mlp_fwd_split16: state is NULL");
+  return mlp_fwd_split_impl(X, ldx, M, mix_W, mix_layers, mix_slope, x_out, ldxo, n_layers, bias, out, ldo, N, K, packed_split16, signmask, planes,
+                            slope, state, stream);
+}
+
+static int mlp_dgrad_split_impl(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                                const void* packed_split, const uint64_t* const* signmask,
+                                float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state16, clica_stream_t stream) {
   using namespace fmlp;
+  const int NPc = state16 ? 2 : 3;
   CLICA_CHECK_ARG(dY && N && K && packed_split && out && ldo && M > 0, "clica_mlp_dgrad_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_links >= 1 && n_links <= MAXL, "clica_mlp_dgrad_split: %d links (1..%d supported)", n_links, MAXL);
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_split) & 15) == 0, "clica_mlp_dgrad_split: packed weights must be 16-byte aligned");
@@ -1748,9 +2108,108 @@ extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, i
     const unsigned long long* mi = (signmask && signmask[j]) ? reinterpret_cast<const unsigned long long*>(signmask[j]) : nullptr;
     g.layer[j] = Layer{nullptr, 0, nullptr, out[j], ldo[j], nullptr, 0, nullptr, mi, N[j], K[j], 0, 1,
                        reinterpret_cast<unsigned short*>(pl), planes::units(N[j], 0), 0};
-    a.off3[j] = off; a.ent3[j] = pack3_entries(N[j], K[j]); off += 3 * a.ent3[j];
+    a.off3[j] = off; a.ent3[j] = pack3_entries(N[j], K[j]); off += NPc * a.ent3[j];
   }
   CLICA_CHECK_ARG(lddy >= K[0], "clica_mlp_dgrad_split: lddy < K[0]");
-  return launch_split(a, stream, "clica_mlp_dgrad_split");
+  if (state16) {
+    Split16State* st = reinterpret_cast<Split16State*>(state16);
+    CLICA_CHECK_ARG(ceil_div(M, (int64_t)ROWS) <= (int64_t)kS16CapWG, "clica_mlp_dgrad_split16: M = %lld rows exceeds the state's %u workgroup slots", (long long)M, kS16CapWG);
+    a.s_t = st->sD; a.s_w = st->sWC; a.cap_wg = kS16CapWG; a.part_t = s16_partD(st); a.count_t = &st->nD;
+    a.last_unscaled = (planes && planes[n_links - 1]) ? 0 : 1;
+  }
+  return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_dgrad_split16" : "clica_mlp_dgrad_split");
+}
+
+extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                                     const void* packed_split, const uint64_t* const* signmask,
+                                     float* const* out, const int64_t* ldo, void* const* planes, float slope, clica_stream_t stream) {
+  return mlp_dgrad_split_impl(dY, lddy, M, n_links, N, K, packed_split, signmask, out, ldo, planes, slope, nullptr, stream);
+}
+extern "C" int clica_mlp_dgrad_split16(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                                       const void* packed_split16, const uint64_t* const* signmask,
+                                       float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr, "clica_mlp_dgrad_split16: state is NULL");
+  return mlp_dgrad_split_impl(dY, lddy, M, n_links, N, K, packed_split16, signmask, out, ldo, planes, slope, state, stream);
+}
+
+// ---- f16x2 arithmetic: state, weights ---------------------------------------------------------------------------------------------
+extern "C" int clica_split16_state_bytes(size_t* bytes) {
+  CLICA_CHECK_ARG(bytes != nullptr, "clica_split16_state_bytes: bytes is NULL");
+  *bytes = sizeof(fmlp::Split16State) + (size_t)fmlp::kS16CapWG * fmlp::Split16State::NT * 4 * 2 + (size_t)fmlp::kS16CapPW * 8;
+  return CLICA_OK;
+}
+extern "C" int clica_split16_state_init(void* state, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state && (reinterpret_cast<uintptr_t>(state) & 15) == 0, "clica_split16_state_init: state must be a 16-byte aligned device buffer");
+  hipLaunchKernelGGL(fmlp::split16_init_k, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<fmlp::Split16State*>(state), fmlp::kS16CapWG, fmlp::kS16CapPW);
+  return launch_status("clica_split16_state_init");
+}
+extern "C" int clica_split16_update(void* state, int32_t n_layers, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state && n_layers >= 1 && n_layers <= fmlp::MAXL, "clica_split16_update: bad argument");
+  hipLaunchKernelGGL(fmlp::split16_update_k, dim3(1), dim3(256), 0, as_stream(stream), reinterpret_cast<fmlp::Split16State*>(state), (int)n_layers);
+  return launch_status("clica_split16_update");
+}
+extern "C" int clica_split16_read(const void* state, int32_t* flags, int32_t* updates, float* scales_a, float* scales_d, float* scales_w,
+                                  float* last_scales_a, float* last_scales_d, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr, "clica_split16_read: state is NULL");
+  fmlp::Split16State h;
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return launch_status("clica_split16_read");
+  if (flags) *flags = (int32_t)h.flags;
+  if (updates) *updates = (int32_t)h.updates;
+  for (int i = 0; i < fmlp::Split16State::NT; ++i) {
+    if (scales_a) scales_a[i] = h.sA[i];
+    if (scales_d) scales_d[i] = h.sD[i];
+    if (scales_w) scales_w[i] = h.sW[i];
+    if (last_scales_a) last_scales_a[i] = h.pA[i];
+    if (last_scales_d) last_scales_d[i] = h.pD[i];
+  }
+  return CLICA_OK;
+}
+extern "C" int clica_split16_clear_flags(void* state, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr, "clica_split16_clear_flags: state is NULL");
+  if (hipMemsetAsync(&reinterpret_cast<fmlp::Split16State*>(state)->flags, 0, sizeof(unsigned), as_stream(stream)) != hipSuccess)
+    return launch_status("clica_split16_clear_flags");
+  return CLICA_OK;
+}
+extern "C" int clica_mlp_pack_split16_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(N && K && bytes && n_layers >= 1 && n_layers <= MAXL, "clica_mlp_pack_split16_bytes: bad argument");
+  int64_t e = 0;
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW, "clica_mlp_pack_split16_bytes: layer %d is %d x %d (max %d)", l, N[l], K[l], MAXW);
+    e += 2 * (transpose ? pack3_entries(K[l], N[l]) : pack3_entries(N[l], K[l]));
+  }
+  *bytes = (size_t)e * 16;
+  return CLICA_OK;
+}
+extern "C" int clica_mlp_pack_split16_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                           void* packed_fwd, void* packed_bwd, void* state, clica_stream_t stream) {
+  using namespace fmlp;
+  CLICA_CHECK_ARG(W && ldw && N && K && packed_fwd && packed_bwd && state && n_layers >= 2 && n_layers <= MAXL, "clica_mlp_pack_split16_both: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_bwd) & 15) == 0,
+                  "clica_mlp_pack_split16_both: packed buffers must be 16-byte aligned");
+  Split16State* st = reinterpret_cast<Split16State*>(state);
+  Pack2Args a{};
+  a.st = st;
+  int sgi = 0; int64_t off = 0;
+  auto fill = [&](const float* Wl, int64_t ld, int rows, int cols, int transposed, void* base, const float* sc, int layer) {
+    a.seg[sgi] = PackSeg{Wl, ld, rows, cols, transposed};
+    const int64_t ent = pack3_entries(rows, cols);
+    a.dst[sgi] = reinterpret_cast<u32x4*>(base) + off;
+    a.entries[sgi] = ent; a.first[sgi + 1] = a.first[sgi] + ent;
+    a.scale[sgi] = sc; a.layer[sgi] = layer;
+    off += 2 * ent; ++sgi;
+  };
+  for (int l = 0; l < n_layers; ++l) {
+    CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack_split16_both: layer %d: bad argument", l);
+    fill(W[l], ldw[l], N[l], K[l], 0, packed_fwd, &st->sW[l], l);
+  }
+  off = 0;
+  for (int l = n_layers - 1; l >= 1; --l) fill(W[l], ldw[l], K[l], N[l], 1, packed_bwd, &st->sW[l], -1);
+  a.nseg = sgi;
+  CLICA_CHECK_ARG(((a.first[a.nseg] + 63) >> 6) <= (int64_t)kS16CapPW, "clica_mlp_pack_split16_both: the weights exceed the state's %u pack-wave slots", kS16CapPW);
+  hipLaunchKernelGGL(mlp_pack2_k, dim3((unsigned)ceil_div(a.first[a.nseg], 256)), dim3(256), 0, as_stream(stream), a);
+  return launch_status("clica_mlp_pack_split16_both");
 }
 

@@ -41,10 +41,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #endif
 constexpr int STG = 4;                      // LDS stages of one 16-row step each
 constexpr int UW = 8, UN = 4;               // 32-feature units of the wide / narrow side of a tile (256 / 128 features)
-constexpr int PIECES = 3 * (UW + UN);       // one-KB pieces per step (36 KB)
-constexpr int STAGE_BYTES = PIECES * 1024;
 constexpr int THREADS = 512;
-constexpr size_t kLdsBytes = (size_t)STG * STAGE_BYTES;      // 144 KB
+// The two split arithmetics (fused_mlp.hip: Arith): AR = 0 bf16x3 -- three pieces per unit, six piece products; AR = 1 f16x2 -- two
+// pieces per unit (planes.h with 2 KB units), three products (hi.hi, hi.lo, lo.hi), operands scaled per tensor (the scales in force
+// arrive as device pointers in Prob and are divided out of the slab).
+template <int AR> struct WArith;
+template <> struct WArith<0> { static constexpr int NP = 3, NPROD = 6; static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct WArith<1> { static constexpr int NP = 2, NPROD = 3; static constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0}; };
+template <int AR> constexpr int pieces_of() { return WArith<AR>::NP * (UW + UN); }        // one-KB pieces per step (36 / 24 KB)
+template <int AR> constexpr int stage_bytes_of() { return pieces_of<AR>() * 1024; }
+constexpr size_t kLdsBytes = (size_t)STG * stage_bytes_of<0>();      // 144 KB (the f16x2 launches use 96 KB)
+template <int AR> constexpr size_t lds_bytes_of() { return (size_t)STG * stage_bytes_of<AR>(); }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 struct Prob {
   const char* A; const char* B;   // plane buffers of dZ_l (rows of dW) and X_l (columns of dW)
@@ -63,6 +71,7 @@ struct Prob {
   char* outT; int fuT;            // output as planes of C^T (rows = C column, features = C row) or nullptr
   char* outN; int fuN;            // output as planes of C   (rows = C row, features = C column) or nullptr
   float* outF; int64_t ldf;       // output as fp32 C[row][column] or nullptr
+  const float* scaleA; const float* scaleB;   // f16x2 only: device pointers to the scales of the A and B tensors (the slab gets acc / (sA sB))
 };
 struct GroupArgs { int n, total; int first[MAXG + 1]; Prob p[MAXG]; };
 
@@ -90,6 +99,12 @@ __device__ __forceinline__ frag_t read_frag(const char* p) {   // keys 8h .. 8h+
   const u32x2 a = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds_ptr)p));
   const u32x2 b = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(lds_ptr)(p + 256)));
   return (frag_t){a.x, a.y, b.x, b.y};
+}
+
+template <int AR>
+__device__ __forceinline__ f32x16 mfma32(const frag_t a, const frag_t b, const f32x16 c) {
+  if constexpr (AR == 0) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
 // Debug build only (-DCLICA_WSPLIT_TRACE, tools/wsplit_trace.py): s_memtime stamps per (workgroup, wave, phase), kept in
@@ -230,8 +245,12 @@ __device__ __forceinline__ void fused_epilogue(const Prob& g, const f32x16 (&acc
 // 2 + 2 unit fragments x 3 planes (24 transposing reads of 512 B) and issues 24 MFMAs (768 matrix cycles).
 // Pipeline: four 36 KB stages; the pieces of step t + 3 are requested during the first half of step t, the fragments of
 // step t + 1 are read during its second half (two register sets, ping-pong), one barrier per step (in the middle).
-template <bool A_WIDE, bool FUSED>
+template <bool A_WIDE, bool FUSED, int AR>
 __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, const int bz) {
+  constexpr int NP = WArith<AR>::NP, NPROD = WArith<AR>::NPROD, PIECES = pieces_of<AR>(), STAGE_BYTES = stage_bytes_of<AR>();
+  constexpr int NJ = (PIECES + 7) / 8;                       // DMA pieces per wave and step (the last one only for the first PIECES - 8 (NJ - 1) waves)
+  constexpr int NM = NPROD * 4;                              // MFMAs per wave and step
+  static_assert(!FUSED || AR == 0, "the fused forward / data-gradient epilogues exist in the bf16x3 arithmetic only");
   constexpr int UA = A_WIDE ? UW : UN, UB = A_WIDE ? UN : UW;
   constexpr int BM = UA * 32, BN = UB * 32;
   constexpr int WN = BN / 64;
@@ -252,53 +271,52 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // this wave's DMA pieces: piece pi = wave + 8 j of the stage image [A: UA units x 3 planes][B: UB units x 3 planes];
+  // this wave's DMA pieces: piece pi = wave + 8 j of the stage image [A: UA units x NP planes][B: UB units x NP planes];
   // units beyond the tensor (a tile that sticks out) are read from a 16-byte page of zeros with stride 0
-  const bool five = wave < PIECES - 32;                      // waves 0..3 move five pieces per step, waves 4..7 four
-  const char* src[5]; int stride[5];
+  const bool five = wave < PIECES - 8 * (NJ - 1);            // bf16x3: waves 0..3 move five pieces per step, waves 4..7 four; f16x2: three each
+  const char* src[NJ]; int stride[NJ];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int pi = wave + 8 * j;
-    const bool is_a = pi < 3 * UA;
-    const int q = is_a ? pi : pi - 3 * UA;
-    const int unit = q / 3, plane = q - 3 * unit;
+    const bool is_a = pi < NP * UA;
+    const int q = is_a ? pi : pi - NP * UA;
+    const int unit = q / NP, plane = q - NP * unit;
     const int u = (is_a ? by * UA : bx * UB) + unit, fu = is_a ? g.fuA : g.fuB;
     const bool ok = pi < PIECES && u < fu;
     const char* base = is_a ? g.A : g.B;
-    src[j] = ok ? base + (((int64_t)g0 * fu + u) * 3 + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
-    stride[j] = (ok && !(CLICA_WSPLIT_ABLATE & 2)) ? fu * planes::kUnitBytes : 0;
+    src[j] = ok ? base + (((int64_t)g0 * fu + u) * NP + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
+    stride[j] = (ok && !(CLICA_WSPLIT_ABLATE & 2)) ? fu * NP * planes::kPieceBytes : 0;
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   auto issue = [&](int t) {
     const unsigned st = lds0 + (unsigned)((t % STG) * STAGE_BYTES + wave * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { dma_1k(src[j], st + 8192u * j); src[j] += stride[j]; }
-    if (five) { dma_1k(src[4], st + 8192u * 4); src[4] += stride[4]; }
+    for (int j = 0; j < NJ - 1; ++j) { dma_1k(src[j], st + 8192u * j); src[j] += stride[j]; }
+    if (five) { dma_1k(src[NJ - 1], st + 8192u * (NJ - 1)); src[NJ - 1] += stride[NJ - 1]; }
   };
   // at most `k` of the most recently requested steps may still be in flight
   auto wait_steps = [&](int k) {
     if (k <= 0) wait_vm<0>();
-    else if (five) { if (k == 1) wait_vm<5>(); else wait_vm<10>(); }
-    else { if (k == 1) wait_vm<4>(); else wait_vm<8>(); }
+    else if (five) { if (k == 1) wait_vm<NJ>(); else wait_vm<2 * NJ>(); }
+    else { if (k == 1) wait_vm<NJ - 1>(); else wait_vm<2 * (NJ - 1)>(); }
   };
 
   const int lane_off = h * 512 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
-  const char* fa_base = smem + lane_off + (wm * 2) * 3 * 1024;
-  const char* fb_base = smem + lane_off + (UA + wn * 2) * 3 * 1024;
-  frag_t fa0[3][2], fb0[3][2], fa1[3][2], fb1[3][2];
-  auto load_frags_of = [&](frag_t (&f)[3][2], const char* base, int t) {
+  const char* fa_base = smem + lane_off + (wm * 2) * NP * 1024;
+  const char* fb_base = smem + lane_off + (UA + wn * 2) * NP * 1024;
+  frag_t fa0[NP][2], fb0[NP][2], fa1[NP][2], fb1[NP][2];
+  auto load_frags_of = [&](frag_t (&f)[NP][2], const char* base, int t) {
     const int so = (t % STG) * STAGE_BYTES;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) f[p][i] = read_frag(base + so + (3 * i + p) * 1024);
+      for (int i = 0; i < 2; ++i) f[p][i] = read_frag(base + so + (NP * i + p) * 1024);
   };
-  auto load_frags = [&](frag_t (&fa)[3][2], frag_t (&fb)[3][2], int t) { load_frags_of(fa, fa_base, t); load_frags_of(fb, fb_base, t); };
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // (dZ piece, X piece) of the six products, small terms first
-  auto mfma1 = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], int m) {      // MFMA m = 0..23 of a step: product m / 4, block ((m % 4) / 2, m % 2)
+  auto load_frags = [&](frag_t (&fa)[NP][2], frag_t (&fb)[NP][2], int t) { load_frags_of(fa, fa_base, t); load_frags_of(fb, fb_base, t); };
+  // (dZ piece, X piece) of the products, small terms first: WArith<AR>::PA / PB
+  auto mfma1 = [&](const frag_t (&fa)[NP][2], const frag_t (&fb)[NP][2], int m) {      // MFMA m = 0..NM-1 of a step: product m / 4, block ((m % 4) / 2, m % 2)
     const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]),
-                                                        acc[i][j], 0, 0, 0);
+    acc[i][j] = mfma32<AR>(fa[WArith<AR>::PA[t]][i], fb[WArith<AR>::PB[t]][j], acc[i][j]);
   };
   auto issue_one = [&](int t, int j) { dma_1k(src[j], lds0 + (unsigned)((t % STG) * STAGE_BYTES + (wave + 8 * j) * 1024)); src[j] += stride[j]; };
   // Step t (all eight waves run the same schedule; a wave issues in order):
@@ -309,15 +327,16 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   //   phase 2: MFMAs 12..23 of step t with the 24 transposing reads of step t + 1's fragments pinned two behind each MFMA (one
   //            burst of 24 fills the LDS queue of all eight waves at once and stalls every wave's MFMA issue behind its own reads).
   // Stage (t + 3) % STG was last read in phase 2 of step t - 2, which every wave has left before anyone passes the barrier of t - 1.
-  auto step = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], frag_t (&na)[3][2], frag_t (&nb)[3][2], int t) {
+  auto step = [&](const frag_t (&fa)[NP][2], const frag_t (&fb)[NP][2], frag_t (&na)[NP][2], frag_t (&nb)[NP][2], int t) {
     const bool more = t + 3 < nt && !(CLICA_WSPLIT_ABLATE & 1);
     WS_STEP_STAMP(t, 4); WS_STEP_STAMP(t - 1, 10);
+    static_assert(NM / 4 >= NJ, "one DMA request behind every second MFMA of the first half");
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < NM / 4; ++q) {
       mfma1(fa, fb, 2 * q); mfma1(fa, fb, 2 * q + 1);
       __builtin_amdgcn_sched_barrier(0);
-      if (q < 4) { if (more) issue_one(t + 3, q); }
-      else if (q == 4) { if (more && five) issue_one(t + 3, 4); }
+      if (q < NJ - 1) { if (more) issue_one(t + 3, q); }
+      else if (q == NJ - 1) { if (more && five) issue_one(t + 3, NJ - 1); }
       __builtin_amdgcn_sched_barrier(0);
     }
     WS_STEP_STAMP(t, 5);
@@ -330,16 +349,17 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
       load_frags(na, nb, t + 1);
 #endif
 #pragma unroll
-      for (int m = 12; m < 24; ++m) mfma1(fa, fb, m);
+      for (int m = NM / 2; m < NM; ++m) mfma1(fa, fb, m);
+      constexpr int RPM = (8 * NP + NM / 2 - 1) / (NM / 2);      // transposing reads per MFMA: 8 NP reads over the second half's NM / 2 MFMAs (2 / 3)
 #pragma unroll
-      for (int i = 0; i < 12; ++i) {
+      for (int i = 0; i < NM / 2; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+        __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);    // RPM DS reads
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
 #pragma unroll
-      for (int m = 12; m < 24; ++m) mfma1(fa, fb, m);
+      for (int m = NM / 2; m < NM; ++m) mfma1(fa, fb, m);
     }
     WS_STEP_STAMP(t, 8);
   };
@@ -363,6 +383,8 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   const int m0 = by * BM, n0 = bx * BN;
   if constexpr (FUSED) { fused_epilogue<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane); return; }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+  float unscale = 1.f;
+  if constexpr (AR == 1) unscale = 1.f / (*g.scaleA * *g.scaleB);      // powers of two: exact
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -376,7 +398,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= g.M) continue;
-        dst[row * ld] = acc[i][j][r];
+        dst[row * ld] = AR == 1 ? acc[i][j][r] * unscale : acc[i][j][r];
       }
     }
   }
@@ -394,10 +416,14 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
 //   H1(t): 24 MFMAs on A-half 1 / B(t), requesting tile t + 3 (6 pieces per wave) and reading A-half 0 and B of tile t + 1.
 // Registers: 128 accumulators + 2 x 24 (A halves) + 2 x 24 (B, ping-pong across steps).  Three 48 KB stages: stage t % 3 is last
 // read in H0(t), free behind barrier(t), refilled by the requests of H1(t) with tile t + 3, first needed at barrier(t + 2).
-constexpr int STG2 = 3, PIECES2 = 3 * (UW + UW), STAGE2_BYTES = PIECES2 * 1024;
-static_assert((size_t)STG2 * STAGE2_BYTES <= kLdsBytes, "the big-tile stages must fit the launch's LDS");
-template <bool FUSED>
+constexpr int STG2 = 3;
+static_assert((size_t)STG2 * 3 * (UW + UW) * 1024 <= kLdsBytes && (size_t)STG2 * 2 * (UW + UW) * 1024 <= lds_bytes_of<1>(), "the big-tile stages must fit the launch's LDS");
+template <bool FUSED, int AR>
 __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int by, const int bz) {
+  constexpr int NP = WArith<AR>::NP, NPROD = WArith<AR>::NPROD, PIECES2 = NP * (UW + UW), STAGE2_BYTES = PIECES2 * 1024;
+  constexpr int NJ2 = PIECES2 / 8;                            // DMA pieces per wave and step (6 / 4)
+  constexpr int NMH = NPROD * 4;                              // MFMAs per half step
+  static_assert(!FUSED || AR == 0, "the fused forward / data-gradient epilogues exist in the bf16x3 arithmetic only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -412,56 +438,54 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // six DMA pieces per wave and step: piece pi = wave + 8 j of the stage image [A: 8 units x 3 planes][B: 8 units x 3 planes]
-  const char* src[6]; int stride[6];
+  const char* src[NJ2]; int stride[NJ2];
 #pragma unroll
-  for (int j = 0; j < 6; ++j) {
+  for (int j = 0; j < NJ2; ++j) {
     const int pi = wave + 8 * j;
-    const bool is_a = pi < 3 * UW;
-    const int q = is_a ? pi : pi - 3 * UW;
-    const int unit = q / 3, plane = q - 3 * unit;
+    const bool is_a = pi < NP * UW;
+    const int q = is_a ? pi : pi - NP * UW;
+    const int unit = q / NP, plane = q - NP * unit;
     const int u = (is_a ? by : bx) * UW + unit, fu = is_a ? g.fuA : g.fuB;
     const bool ok = u < fu;
     const char* base = is_a ? g.A : g.B;
-    src[j] = ok ? base + (((int64_t)g0 * fu + u) * 3 + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
-    stride[j] = ok ? fu * planes::kUnitBytes : 0;
+    src[j] = ok ? base + (((int64_t)g0 * fu + u) * NP + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
+    stride[j] = ok ? fu * NP * planes::kPieceBytes : 0;
   }
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   auto issue_one = [&](int t, int j) { dma_1k(src[j], lds0 + (unsigned)((t % STG2) * STAGE2_BYTES + (wave + 8 * j) * 1024)); src[j] += stride[j]; };
   const int lane_off = h * 512 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
-  const char* fa_base = smem + lane_off + (wm * 4) * 3 * 1024;
-  const char* fb_base = smem + lane_off + (UW + wn * 2) * 3 * 1024;
-  frag_t a0[3][2], a1[3][2], b0[3][2], b1[3][2];            // [plane][unit of the half / of the wave's two B units]
-  auto load_a = [&](frag_t (&f)[3][2], int t, int half) {
+  const char* fa_base = smem + lane_off + (wm * 4) * NP * 1024;
+  const char* fb_base = smem + lane_off + (UW + wn * 2) * NP * 1024;
+  frag_t a0[NP][2], a1[NP][2], b0[NP][2], b1[NP][2];        // [plane][unit of the half / of the wave's two B units]
+  auto load_a = [&](frag_t (&f)[NP][2], int t, int half) {
     const int so = (t % STG2) * STAGE2_BYTES;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) f[p][i] = read_frag(fa_base + so + (3 * (2 * half + i) + p) * 1024);
+      for (int i = 0; i < 2; ++i) f[p][i] = read_frag(fa_base + so + (NP * (2 * half + i) + p) * 1024);
   };
-  auto load_b = [&](frag_t (&f)[3][2], int t) {
+  auto load_b = [&](frag_t (&f)[NP][2], int t) {
     const int so = (t % STG2) * STAGE2_BYTES;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
+    for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) f[p][j] = read_frag(fb_base + so + (3 * j + p) * 1024);
+      for (int j = 0; j < 2; ++j) f[p][j] = read_frag(fb_base + so + (NP * j + p) * 1024);
   };
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-  auto mfma1 = [&](const frag_t (&fa)[3][2], const frag_t (&fb)[3][2], int half, int m) {     // m = 0..23 of a half
+  auto mfma1 = [&](const frag_t (&fa)[NP][2], const frag_t (&fb)[NP][2], int half, int m) {     // m = 0..NMH-1 of a half
     const int t = m >> 2, i = (m >> 1) & 1, j = m & 1;
-    acc[2 * half + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]),
-                                                                   acc[2 * half + i][j], 0, 0, 0);
+    acc[2 * half + i][j] = mfma32<AR>(fa[WArith<AR>::PA[t]][i], fb[WArith<AR>::PB[t]][j], acc[2 * half + i][j]);
   };
-  auto wait_tiles = [&](int k) {            // at most k of the most recently requested tiles (6 pieces each) may be in flight
-    if (k <= 0) wait_vm<0>(); else if (k == 1) wait_vm<6>(); else wait_vm<12>();
+  auto wait_tiles = [&](int k) {            // at most k of the most recently requested tiles (NJ2 pieces each) may be in flight
+    if (k <= 0) wait_vm<0>(); else if (k == 1) wait_vm<NJ2>(); else wait_vm<2 * NJ2>();
   };
-  auto step = [&](const frag_t (&fb)[3][2], frag_t (&nb)[3][2], int t) {
+  auto step = [&](const frag_t (&fb)[NP][2], frag_t (&nb)[NP][2], int t) {
     load_a(a1, t, 1);
 #pragma unroll
-    for (int m = 0; m < 24; ++m) mfma1(a0, fb, 0, m);
+    for (int m = 0; m < NMH; ++m) mfma1(a0, fb, 0, m);
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < NMH / 2; ++i) {                        // the half's 4 NP transposing reads spread over its MFMAs
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // 1 DS read
+      __builtin_amdgcn_sched_group_barrier(0x100, AR == 0 ? 1 : 2, 0);      // DS reads
     }
     __builtin_amdgcn_sched_barrier(0);
     const bool next = t + 1 < nt;
@@ -470,29 +494,28 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
       __syncthreads();
     }
     const bool more = t + 3 < nt;
+    constexpr int NG = 2 * NP, MPG = NMH / NG;                 // groups of the half: one piece's two fragments (four reads) and MPG MFMAs each (4 / 3)
+    static_assert(NG >= NJ2 && NMH % NG == 0, "one DMA request per group");
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
+    for (int q = 0; q < NG; ++q) {
       if (next) {
-        if (q < 3) {                                        // A-half 0 of tile t + 1: two fragments (four reads) per group
+        if (q < NP) {                                       // A-half 0 of tile t + 1: two fragments (four reads) per group
 #pragma unroll
-          for (int i = 0; i < 2; ++i) a0[q][i] = read_frag(fa_base + ((t + 1) % STG2) * STAGE2_BYTES + (3 * i + q) * 1024);
+          for (int i = 0; i < 2; ++i) a0[q][i] = read_frag(fa_base + ((t + 1) % STG2) * STAGE2_BYTES + (NP * i + q) * 1024);
         } else {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) nb[q - 3][j] = read_frag(fb_base + ((t + 1) % STG2) * STAGE2_BYTES + (3 * j + (q - 3)) * 1024);
+          for (int j = 0; j < 2; ++j) nb[q - NP][j] = read_frag(fb_base + ((t + 1) % STG2) * STAGE2_BYTES + (NP * j + (q - NP)) * 1024);
         }
       }
 #pragma unroll
-      for (int m = 4 * q; m < 4 * q + 4; ++m) mfma1(a1, fb, 1, m);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      for (int m = MPG * q; m < MPG * q + MPG; ++m) mfma1(a1, fb, 1, m);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
-      if (more) issue_one(t + 3, q);
+      if (more && q < NJ2) issue_one(t + 3, q);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -501,7 +524,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
   for (int tt = 0; tt < 3; ++tt)
     if (tt < nt) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) issue_one(tt, j);
+      for (int j = 0; j < NJ2; ++j) issue_one(tt, j);
     }
   wait_tiles(nt > 2 ? 2 : nt - 1);
   __syncthreads();
@@ -513,6 +536,8 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
   const int m0 = by * 256, n0 = bx * 256;
   if constexpr (FUSED) { fused_epilogue<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane); return; }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
+  float unscale = 1.f;
+  if constexpr (AR == 1) unscale = 1.f / (*g.scaleA * *g.scaleB);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -526,7 +551,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= g.M) continue;
-        dst[row * ld] = acc[i][j][r];
+        dst[row * ld] = AR == 1 ? acc[i][j][r] * unscale : acc[i][j][r];
       }
     }
   }
@@ -537,6 +562,7 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {     // each XCD 
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+template <int AR>
 __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
   const int id = xcd_contiguous(blockIdx.x, G.total);
   int q = 0;
@@ -547,7 +573,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
   const int tiles = g.gx * g.gy;
   const int bz = local / tiles, t = local - bz * tiles;
   const int by = t / g.gx, bx = t - by * g.gx;
-  if (g.a_wide == 2) body_big<false>(g, bx, by, bz); else if (g.a_wide) body<true, false>(g, bx, by, bz); else body<false, false>(g, bx, by, bz);
+  if (g.a_wide == 2) body_big<false, AR>(g, bx, by, bz); else if (g.a_wide) body<true, false, AR>(g, bx, by, bz); else body<false, false, AR>(g, bx, by, bz);
 }
 
 // ---- forward / data gradient of ONE wide layer on the same bodies -------------------------------------------------------------------
@@ -568,17 +594,17 @@ __global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
     if (b < g.n_big) {
       const int id = xcd_contiguous(b, g.n_big);
       const int by = id / g.gx, bx = id - by * g.gx;
-      body_big<true>(g, bx, by, 0);
+      body_big<true, 0>(g, bx, by, 0);
     } else {
       const int id = xcd_contiguous(b - g.n_big, G.total - g.n_big);
       const int by = id / g.gx, bx = id - by * g.gx;
-      body<false, true>(g, bx, g.rows_big / 128 + by, 0);
+      body<false, true, 0>(g, bx, g.rows_big / 128 + by, 0);
     }
     return;
   }
   const int id = xcd_contiguous(blockIdx.x, G.total);
   const int by = id / g.gx, bx = id - by * g.gx;
-  if (g.a_wide == 2) body_big<true>(g, bx, by, 0); else if (g.a_wide) body<true, true>(g, bx, by, 0); else body<false, true>(g, bx, by, 0);
+  if (g.a_wide == 2) body_big<true, 0>(g, bx, by, 0); else if (g.a_wide) body<true, true, 0>(g, bx, by, 0); else body<false, true, 0>(g, bx, by, 0);
 }
 
 #ifdef CLICA_WSPLIT_TRACE
@@ -769,10 +795,14 @@ extern "C" int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers
   return CLICA_OK;
 }
 
-extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
-                                     const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
-                                     float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
-                                     int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+// the layout of the f16x2 state's scale arrays (fused_mlp.hip: Split16State) as far as this file needs it
+struct Split16Scales { unsigned counts[27]; float sA[9], sD[9], sW[9], sWC[9]; unsigned flags, updates, pad[2]; };
+
+static int mlp_wgrad_split_impl(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                int32_t accumulate, const void* state16, const int32_t* a_index, const int32_t* d_index,
+                                void* workspace, size_t workspace_bytes, clica_stream_t stream) {
   CLICA_CHECK_ARG(dZ_planes && X_planes && dZ && lddz && X && ldx && dW && lddw && db && N && K && workspace && M > 0,
                   "clica_mlp_wgrad_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_split: %d layers (1..%d supported)", n_layers, MAXG);
@@ -812,6 +842,12 @@ extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* co
       // column tile may simply have nothing to store
       tile_shape(N[l], K[l], &g.a_wide, &g.gx, &g.gy, true);
       g.groups = p.groups; g.gps = problem_gps(p, g.a_wide);
+      if (state16) {
+        const Split16Scales* st16 = reinterpret_cast<const Split16Scales*>(state16);
+        CLICA_CHECK_ARG(a_index && d_index && a_index[l] >= 0 && a_index[l] < 9 && d_index[l] >= 0 && d_index[l] < 9,
+                        "clica_mlp_wgrad_split16: layer %d: scale index out of range", l);
+        g.scaleA = &st16->sD[d_index[l]]; g.scaleB = &st16->sA[a_index[l]];
+      }
       G.first[ng] = item; item += g.gx * g.gy * sp;
       ++ng;
     }
@@ -823,13 +859,44 @@ extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* co
     if (rct) return rct;
   }
   if (ng > 0) {
-    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
-    (void)once;
-    hipLaunchKernelGGL(wgrad_split_k, dim3((unsigned)item), dim3(THREADS), kLdsBytes, st, G);
+    if (state16) {
+      static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_of<1>()), true);
+      (void)once;
+      hipLaunchKernelGGL(wgrad_split_k<1>, dim3((unsigned)item), dim3(THREADS), lds_bytes_of<1>(), st, G);
+    } else {
+      static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
+      (void)once;
+      hipLaunchKernelGGL(wgrad_split_k<0>, dim3((unsigned)item), dim3(THREADS), kLdsBytes, st, G);
+    }
     int rc = launch_status("clica_mlp_wgrad_split");
     if (rc) return rc;
   }
   return gemm::launch_slab_reduce_group(R, rblock, st);
+}
+
+extern "C" int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                     const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                     float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                     int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, accumulate, nullptr, nullptr, nullptr,
+                              workspace, workspace_bytes, stream);
+}
+// f16x2 plane copies (two pieces per unit, written by clica_mlp_fwd_split16 / clica_mlp_dgrad_split16 of the same `state`):
+// a_index[l] / d_index[l] = positions of layer l's input activation / of dZ_l in the state's activation / chain-gradient scale arrays
+// (forward order: a_index = l; chain order: d_index = L - 1 - l for an L-layer encoder)
+extern "C" int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                       const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                       float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                       int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
+                                       void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state && a_index && d_index, "clica_mlp_wgrad_split16: NULL state / index arrays");
+  return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, accumulate, state, a_index, d_index,
+                              workspace, workspace_bytes, stream);
+}
+extern "C" int clica_mlp_planes16_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes) {
+  CLICA_CHECK_ARG(bytes && M > 0 && width >= 1, "clica_mlp_planes16_bytes: bad argument");
+  *bytes = (size_t)planes::groups_alloc(M) * planes::units(width, ones_column) * 2 * planes::kPieceBytes;
+  return CLICA_OK;
 }
 
 

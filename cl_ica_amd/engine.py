@@ -67,7 +67,8 @@ class ContrastiveTrainer:
                  betas=(0.9, 0.999), eps: float = 1e-8, device=None,
                  process_group: Optional[dist.ProcessGroup] = None, bucket_bytes: int = 8 << 20,
                  force_collectives: bool = False, overlap_backward: bool = True, fused_forward: bool = True,
-                 split_bf16: Optional[bool] = None, g_act_kind: int = 0, emulate_pool_ranks: int = 1, dry_ranks: int = 1):
+                 split_bf16: Optional[bool] = None, g_act_kind: int = 0, emulate_pool_ranks: int = 1, dry_ranks: int = 1,
+                 split_arith: Optional[str] = None):
         self.device = torch.device(device if device is not None else "cuda")
         self.f = f.to(self.device)
         self.B = int(batch_size)
@@ -125,6 +126,15 @@ class ContrastiveTrainer:
         self._want_split = want_split
         self.split_bf16 = self.fused_backward and want_split and all(lin.bias is not None for lin in self.linears) and \
             sum((lin.out_features + 31) // 32 * 32 for lin in self.linears) <= 3456      # on-chip bias table (fused_mlp.hip)
+        # which split arithmetic (round 5): "f16" = two fp16 pieces per operand with per-tensor power-of-two scales, three MFMA products
+        # (half the matrix work, 4 B/element; include/clica.h "f16x2 arithmetic") -- the default; "bf16" = the round-3 bf16x3 scheme
+        # (six products, 6 B/element, full fp32 exponent range).  CLICA_SPLIT_ARITH / split_arith select; a slope outside (0, 1) keeps bf16.
+        arith = (split_arith or os.environ.get("CLICA_SPLIT_ARITH", "f16")).lower()
+        if arith not in ("f16", "bf16"):
+            raise ValueError(f"split_arith must be 'f16' or 'bf16', got {arith!r}")
+        self.split_f16 = bool(self.split_bf16 and arith == "f16" and 0.0 < self.slope < 1.0 and self.device.type == "cuda")
+        self.s16 = ops.Split16(len(self.linears), self.device) if self.split_f16 else None
+        self._s16_calibrated = False
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         if self.world > 1:
             # identical replicas by construction: rank 0's parameters and mixing weights win (callers that seed every rank
@@ -258,9 +268,9 @@ class ContrastiveTrainer:
         if self.split_wgrad:
             keep = os.environ.get("CLICA_SPLIT_KEEP_FP32", "0") == "1"      # debug: also write every fp32 copy
             for l in range(L):
-                if kinds[l] == 0:                            # dW_l = dZ_l^T acts_{l-1} on the bf16 matrix cores
-                    self.act_planes[l - 1] = ops.mlp_planes_alloc(R, widths[l - 1], True, dev)
-                    self.dz_planes[l] = ops.mlp_planes_alloc(R, widths[l], False, dev)
+                if kinds[l] == 0:                            # dW_l = dZ_l^T acts_{l-1} on the bf16 / fp16 matrix cores
+                    self.act_planes[l - 1] = ops.mlp_planes_alloc(R, widths[l - 1], True, dev, f16=self.split_f16)
+                    self.dz_planes[l] = ops.mlp_planes_alloc(R, widths[l], False, dev, f16=self.split_f16)
             for l in range(L - 1):
                 if not keep and kinds[l + 1] == 0:           # acts[l] feeds only an MFMA-sized weight gradient
                     self.acts_out[l] = None
@@ -350,7 +360,7 @@ class ContrastiveTrainer:
         for both layouts when both are used).  Valid until the next optimizer step."""
         ws = [lin.weight for lin in self.linears]
         if self.split_bf16:
-            self.packed, self.packed_t = ops.mlp_pack_split_both(ws, self.packed, self.packed_t)
+            self.packed, self.packed_t = ops.mlp_pack_split_both(ws, self.packed, self.packed_t, state=self.s16)
         elif self.fused_backward and self.pack_weights:
             self.packed, self.packed_t = ops.mlp_pack_both(ws, self.packed, self.packed_t)
         elif self.fused_forward and self.pack_weights:
@@ -373,7 +383,7 @@ class ContrastiveTrainer:
                 cur, mix, self._x_pending = self.z, (self.gW, self.g_slope, self.x), False
             if self.split_bf16:
                 ops.mlp_fwd_split(cur, ws, [lin.bias for lin in self.linears], self.acts_out, self.packed, self.slope,
-                                  signmasks=self.signmasks, mix=mix, planes=self.act_planes if self.split_wgrad else None)
+                                  signmasks=self.signmasks, mix=mix, planes=self.act_planes if self.split_wgrad else None, state=self.s16)
             else:
                 ops.mlp_fwd(cur, ws, [lin.bias for lin in self.linears], self.acts, self.slope, packed=self.packed,
                             signmasks=self.signmasks, mix=mix)
@@ -504,7 +514,7 @@ class ContrastiveTrainer:
         if self.split_bf16:
             ops.mlp_dgrad_chain_split(g, ws, self.packed_t, [self.dz_out[l - 1] for l in chain], self.slope,
                                       masks_chain=[self.signmasks[l - 1] for l in chain],
-                                      planes=[self.dz_planes[l - 1] for l in chain] if self.split_wgrad else None)
+                                      planes=[self.dz_planes[l - 1] for l in chain] if self.split_wgrad else None, state=self.s16)
         else:
             ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
                                 masks_chain=[self.signmasks[l - 1] for l in chain])
@@ -520,7 +530,8 @@ class ContrastiveTrainer:
         if self.split_wgrad:
             ops.mlp_wgrad_split(R, [self.dz_planes[l] for l in order], [self.act_planes[l - 1] if l > 0 else None for l in order],
                                 [g if l == L - 1 else self.dz_out[l] for l in order],
-                                [self.acts_out[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
+                                [self.acts_out[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws,
+                                state=self.s16, a_index=order, d_index=[L - 1 - l for l in order])
         else:
             ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
                           [self.acts[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
@@ -533,6 +544,8 @@ class ContrastiveTrainer:
         if l in getattr(self, "chain", set()) and (l + 1) in self.chain:
             return ops.mlp_planes_to_f32(self.xin_planes[l + 1], R, w, True)
         if self.acts_out[l] is None:
+            if self.split_f16:       # the planes of the last step are scaled by the activation scale that step ran with
+                return ops.mlp_planes16_to_f32(self.act_planes[l], R, w, True, self.s16.read()["last_scales_a"][l + 1])
             return ops.mlp_planes_to_f32(self.act_planes[l], R, w, True)
         return self.acts[l]
 
@@ -676,6 +689,8 @@ class ContrastiveTrainer:
     def _step_body(self, sample: bool):
         # the fragment-order weight copies only depend on the parameters: pack them on the side stream while the
         # main stream samples the batch and runs the mixing net
+        if self.split_f16 and not self._s16_calibrated:
+            self.calibrate_scales(sample)
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         side = self.side_stream
         self._packed_current = False          # a step always re-packs (parameters may have been set from outside)
@@ -697,6 +712,45 @@ class ContrastiveTrainer:
         self.loss_forward_backward()
         self.backward()
         self.optimizer_step()
+        if self.split_f16:
+            self.s16.update()                  # this step's recorded maxima -> the next step's scales (one one-wave launch)
+
+    def calibrate_scales(self, sample: bool = True, passes: Optional[int] = None):
+        """f16x2 arithmetic: a launch runs on the scales derived from the PREVIOUS step's maxima, so before the first step (and after
+        parameters were replaced from outside) the scales are brought up to the data by un-applied passes: pack, forward, loss and
+        backward on the current batch (sampled when `sample`), scale update, no optimizer step; the device step / RNG counter is put
+        back, so the first real step draws the very batch it would have drawn.  L + 1 passes: a producer measures its output in fp32
+        BEFORE it is cut to fp16, so a pass on scales of 1 gets every activation right, but a gradient of 1e-8 is flushed on its way into
+        the next chain link and that link then measures nothing -- each pass settles (at least) one more link of the chain."""
+        if not self.split_f16:
+            return
+        passes = len(self.linears) + 1 if passes is None else int(passes)
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("calibrate_scales() inside a graph capture: call capture(), which calibrates first")
+        self._s16_calibrated = True
+        tick = self.step_dev.clone()
+        for _ in range(passes):
+            self._packed_current = False
+            if sample:
+                self.sample()
+            elif self.mix_in_forward:
+                self._x_pending = True           # the injected latents go through the mixing prologue again
+            self.forward()
+            self.loss_forward_backward()
+            self.backward()
+            self.s16.update()
+            self.step_dev.copy_(tick)
+            self._ticked = False
+        self.s16.clear_flags()                   # the first pass ran on scales of 1: whatever it flagged is not a finding
+
+    def arith_state(self) -> dict:
+        """Which encoder arithmetic runs and, for f16x2, the state of its scales (host read + sync: log points, tests).  A non-zero
+        `flags` means a tensor outgrew its scale by more than 64 x within one step: the step that raised it is not to be trusted."""
+        if not self.split_bf16:
+            return dict(arith="native_fp32")
+        if not self.split_f16:
+            return dict(arith="bf16x3")
+        return dict(arith="f16x2", **self.s16.read())
 
     def step(self):
         """One unsupervised step with on-device sampling.  Returns the device tensor
@@ -723,7 +777,10 @@ class ContrastiveTrainer:
         and then replay in lock-step."""
         # warm-up launches (lazy kernel-attribute setup, allocator) must not count as training: snapshot
         # and restore parameters, optimizer state and the device step / RNG counter around them
-        snap = [t.clone() for t in (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev)]
+        if self.split_f16 and not self._s16_calibrated:
+            self.calibrate_scales(True)
+        state = (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev) + ((self.s16.buf,) if self.split_f16 else ())
+        snap = [t.clone() for t in state]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -731,7 +788,7 @@ class ContrastiveTrainer:
                 self._step_body(True)
         torch.cuda.current_stream(self.device).wait_stream(s)
         torch.cuda.synchronize(self.device)
-        for dst, src in zip((self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev), snap):
+        for dst, src in zip(state, snap):
             dst.copy_(src)
         graph = torch.cuda.CUDAGraph()
         # with collectives in the step, other threads (the process group's watchdog) may legitimately touch the HIP runtime

@@ -150,43 +150,76 @@ def mlp_pack_both(weights, packed: Optional[torch.Tensor] = None, packed_t: Opti
 
 
 # ---- opt-in split-bf16 arithmetic (clica_mlp_*_split): fp32-grade results on the bf16 matrix cores -------------------
-def mlp_pack_split_both(weights, packed: Optional[torch.Tensor] = None, packed_t: Optional[torch.Tensor] = None):
-    """bf16x3 fragment-order copies for `mlp_fwd_split` (layers 0..L-1) and `mlp_dgrad_chain_split` (layers L-1..1,
-    transposed) in one launch."""
+def mlp_pack_split_both(weights, packed: Optional[torch.Tensor] = None, packed_t: Optional[torch.Tensor] = None, state=None):
+    """Fragment-order piece copies for `mlp_fwd_split` (layers 0..L-1) and `mlp_dgrad_chain_split` (layers L-1..1, transposed) in one
+    launch: bf16x3, or -- with a `Split16` state -- f16x2 scaled by the state's weight scales (clica_mlp_pack_split16_both)."""
     L = len(weights)
     ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
     I32 = C.c_int32 * L
     Ns, Ks = I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws])
     dev = ws[0][0].device
     nb = C.c_size_t()
+    nbytes = load().clica_mlp_pack_split_bytes if state is None else load().clica_mlp_pack_split16_bytes
     if packed is None:
-        check(load().clica_mlp_pack_split_bytes(L, Ns, Ks, 0, C.byref(nb)), "clica_mlp_pack_split_bytes")
+        check(nbytes(L, Ns, Ks, 0, C.byref(nb)), "clica_mlp_pack_split_bytes")
         packed = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
     if packed_t is None:
         chain = list(range(L - 1, 0, -1))
         I32c = C.c_int32 * (L - 1)
-        check(load().clica_mlp_pack_split_bytes(L - 1, I32c(*[ws[l][0].shape[0] for l in chain]), I32c(*[ws[l][0].shape[1] for l in chain]), 1,
-                                                C.byref(nb)), "clica_mlp_pack_split_bytes")
+        check(nbytes(L - 1, I32c(*[ws[l][0].shape[0] for l in chain]), I32c(*[ws[l][0].shape[1] for l in chain]), 1, C.byref(nb)),
+              "clica_mlp_pack_split_bytes")
         packed_t = torch.zeros(nb.value, dtype=torch.uint8, device=dev)
-    check(load().clica_mlp_pack_split_both(L, (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws]),
-                                           Ns, Ks, packed.data_ptr(), packed_t.data_ptr(), stream_ptr()), "clica_mlp_pack_split_both")
+    Wp, ldp = (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws])
+    if state is None:
+        check(load().clica_mlp_pack_split_both(L, Wp, ldp, Ns, Ks, packed.data_ptr(), packed_t.data_ptr(), stream_ptr()), "clica_mlp_pack_split_both")
+    else:
+        check(load().clica_mlp_pack_split16_both(L, Wp, ldp, Ns, Ks, packed.data_ptr(), packed_t.data_ptr(), state.buf.data_ptr(), stream_ptr()),
+              "clica_mlp_pack_split16_both")
     return packed, packed_t
+
+
+class Split16:
+    """Device state of the f16x2 encoder arithmetic of ONE encoder (include/clica.h, "f16x2 arithmetic"): per-tensor scales in force and
+    the running maxima the producer kernels record.  `update()` (one tiny launch, once per training step after its last producer) turns
+    the maxima into the next step's scales; `read()` synchronises and reports flags / scales (log points, tests)."""
+
+    def __init__(self, n_layers: int, device):
+        nb = C.c_size_t()
+        check(load().clica_split16_state_bytes(C.byref(nb)), "clica_split16_state_bytes")
+        self.n_layers = int(n_layers)
+        self.buf = torch.zeros(nb.value, dtype=torch.uint8, device=device)
+        check(load().clica_split16_state_init(self.buf.data_ptr(), stream_ptr()), "clica_split16_state_init")
+
+    def update(self):
+        check(load().clica_split16_update(self.buf.data_ptr(), self.n_layers, stream_ptr()), "clica_split16_update")
+
+    def clear_flags(self):
+        check(load().clica_split16_clear_flags(self.buf.data_ptr(), stream_ptr()), "clica_split16_clear_flags")
+
+    def read(self) -> dict:
+        fl, up = C.c_int32(), C.c_int32()
+        a, d, w, pa, pd = (C.c_float * 9)(), (C.c_float * 9)(), (C.c_float * 9)(), (C.c_float * 9)(), (C.c_float * 9)()
+        check(load().clica_split16_read(self.buf.data_ptr(), C.byref(fl), C.byref(up), a, d, w, pa, pd, stream_ptr()), "clica_split16_read")
+        L = self.n_layers
+        return dict(flags=int(fl.value), updates=int(up.value), scales_a=list(a)[:L + 1], scales_d=list(d)[:L], scales_w=list(w)[:L],
+                    last_scales_a=list(pa)[:L + 1], last_scales_d=list(pd)[:L])
 
 
 _PLANES_BYTES = {}
 
 
-def mlp_planes_alloc(M: int, width: int, ones: bool, device, zero: bool = True) -> torch.Tensor:
+def mlp_planes_alloc(M: int, width: int, ones: bool, device, zero: bool = True, f16: bool = False) -> torch.Tensor:
     """Opaque buffer for the bf16-plane copy of an [M, width] layer output (operand format of `mlp_wgrad_split`).
     `zero=False`: uninitialised -- for buffers a producer kernel writes completely (the whole-stack kernels and
     `mlp_planes_from_f32` write every piece of every 16-row group, padding and ones column included; pinned by the NaN-fill in
     tests/test_gpu_mlp.py::test_split_bf16_wgrad_matches_fp64).  The drop-in path allocates per call: zeroing was two ~160 MB
     memsets per training step."""
-    key = (int(M), int(width), bool(ones))
+    key = (int(M), int(width), bool(ones), bool(f16))
     nbytes = _PLANES_BYTES.get(key)
     if nbytes is None:
         nb = C.c_size_t()
-        check(load().clica_mlp_planes_bytes(int(M), int(width), 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
+        fn = load().clica_mlp_planes16_bytes if f16 else load().clica_mlp_planes_bytes      # f16x2: two pieces per unit
+        check(fn(int(M), int(width), 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
         nbytes = _PLANES_BYTES[key] = nb.value
     return (torch.zeros if zero else torch.empty)(nbytes, dtype=torch.uint8, device=device)
 
@@ -209,6 +242,17 @@ def mlp_planes_to_f32(buf: torch.Tensor, rows: int, feats: int, ones: bool) -> t
     groups = raw.numel() // (units * 3 * 512)
     a = (raw.view(groups, units, 3, 4, 2, 4, 16).to(torch.int32) << 16).view(torch.float32)      # [g][u][plane][k/4][f/16][k%4][f%16]
     v = (a[:, :, 0] + a[:, :, 1]) + a[:, :, 2]
+    return v.permute(0, 2, 4, 1, 3, 5).reshape(groups * 16, units * 32)[:rows, :feats].contiguous()
+
+
+def mlp_planes16_to_f32(buf: torch.Tensor, rows: int, feats: int, ones: bool, scale: float) -> torch.Tensor:
+    """Decode an f16x2 plane buffer (two fp16 pieces per unit, scaled by `scale`) into the fp32 [rows, feats] matrix it represents:
+    (hi + lo) / scale.  Inspection / tests only."""
+    units = (feats + (1 if ones else 0) + 31) // 32
+    raw = buf.view(torch.float16)
+    groups = raw.numel() // (units * 2 * 512)
+    a = raw.view(groups, units, 2, 4, 2, 4, 16).to(torch.float32)       # [g][u][piece][k/4][f/16][k%4][f%16]
+    v = (a[:, :, 0] + a[:, :, 1]) / float(scale)
     return v.permute(0, 2, 4, 1, 3, 5).reshape(groups * 16, units * 32)[:rows, :feats].contiguous()
 
 
@@ -259,7 +303,7 @@ def mlp_wgrad_split_kind(N: int, K: int) -> int:
 
 
 def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Tensor, slope: float = 0.01, signmasks=None, mix=None,
-                  planes=None):
+                  planes=None, state=None):
     """`mlp_fwd` on the bf16 matrix cores with exact 3-way bf16 splits (clica_mlp_fwd_split); `weights` only give the shapes.
     `planes[l]` (from mlp_planes_alloc(M, width_l, True), or None) receives layer l's output as bf16 planes for
     `mlp_wgrad_split`; `outs[l]` may then be None (no fp32 copy of that hidden activation)."""
@@ -270,30 +314,36 @@ def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Te
     gW, gslope, xout = mix if mix is not None else (None, 0.0, None)
     if gW is not None:
         gW = gW.detach().contiguous()
-    check(load().clica_mlp_fwd_split(x.data_ptr(), ldx, x.shape[0], ptr(gW), 0 if gW is None else gW.shape[0], float(gslope),
-                                     ptr(xout), 0 if xout is None else xout.stride(0), L,
-                                     VP(*[None if b is None else b.data_ptr() for b in bs]),
-                                     VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
-                                     I32(*[w.shape[0] for w in weights]), I32(*[w.shape[1] for w in weights]),
-                                     packed_split.data_ptr(), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
-                                     None if planes is None else VP(*[ptr(q) for q in planes]),
-                                     float(slope), stream_ptr()), "clica_mlp_fwd_split")
+    args = (x.data_ptr(), ldx, x.shape[0], ptr(gW), 0 if gW is None else gW.shape[0], float(gslope),
+            ptr(xout), 0 if xout is None else xout.stride(0), L,
+            VP(*[None if b is None else b.data_ptr() for b in bs]),
+            VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
+            I32(*[w.shape[0] for w in weights]), I32(*[w.shape[1] for w in weights]),
+            packed_split.data_ptr(), None if signmasks is None else VP(*[ptr(m) for m in signmasks]),
+            None if planes is None else VP(*[ptr(q) for q in planes]), float(slope))
+    if state is None:
+        check(load().clica_mlp_fwd_split(*args, stream_ptr()), "clica_mlp_fwd_split")
+    else:      # f16x2 arithmetic on `state`'s scales (ops.Split16)
+        check(load().clica_mlp_fwd_split16(*args, state.buf.data_ptr(), stream_ptr()), "clica_mlp_fwd_split16")
     return outs[-1]
 
 
 def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch.Tensor, outs, slope: float = 0.01, masks_chain=None,
-                          planes=None):
+                          planes=None, state=None):
     """`mlp_dgrad_chain` on the bf16 matrix cores (clica_mlp_dgrad_split); sign bits from `mlp_fwd_split`.  `planes[j]`
     (mlp_planes_alloc(M, width, False) or None) receives link j's dZ as bf16 planes; `outs[j]` may then be None."""
     (dy, lddy) = _mat("dy", dy)
     n = len(weights_chain)
     I32, I64, VP = C.c_int32 * n, C.c_int64 * n, C.c_void_p * n
-    check(load().clica_mlp_dgrad_split(dy.data_ptr(), lddy, dy.shape[0], n,
-                                       I32(*[w.shape[1] for w in weights_chain]), I32(*[w.shape[0] for w in weights_chain]),
-                                       packed_split_t.data_ptr(), None if masks_chain is None else VP(*[ptr(m) for m in masks_chain]),
-                                       VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
-                                       None if planes is None else VP(*[ptr(q) for q in planes]),
-                                       float(slope), stream_ptr()), "clica_mlp_dgrad_split")
+    args = (dy.data_ptr(), lddy, dy.shape[0], n,
+            I32(*[w.shape[1] for w in weights_chain]), I32(*[w.shape[0] for w in weights_chain]),
+            packed_split_t.data_ptr(), None if masks_chain is None else VP(*[ptr(m) for m in masks_chain]),
+            VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
+            None if planes is None else VP(*[ptr(q) for q in planes]), float(slope))
+    if state is None:
+        check(load().clica_mlp_dgrad_split(*args, stream_ptr()), "clica_mlp_dgrad_split")
+    else:
+        check(load().clica_mlp_dgrad_split16(*args, state.buf.data_ptr(), stream_ptr()), "clica_mlp_dgrad_split16")
     return outs
 
 
@@ -306,7 +356,8 @@ def mlp_wgrad_split_workspace(M: int, shapes, device) -> torch.Tensor:
     return torch.zeros(nb.value, dtype=torch.uint8, device=device)
 
 
-def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional[torch.Tensor] = None, accumulate: bool = False):
+def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional[torch.Tensor] = None, accumulate: bool = False,
+                    state=None, a_index=None, d_index=None):
     """Every layer's dW / db in the split-bf16 arithmetic (clica_mlp_wgrad_split).  Per layer EITHER the two plane buffers
     (`dz_planes[l]`, `x_planes[l]`: layers with `mlp_wgrad_split_kind` 0) OR the fp32 operands (`dzs[l]`, `xs[l]`: kind 1)."""
     L = len(dWs)
@@ -316,12 +367,16 @@ def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional
     shapes = [tuple(w.shape) for w in dWs]
     if ws is None:
         ws = mlp_wgrad_split_workspace(M, shapes, dWs[0].device)
-    check(load().clica_mlp_wgrad_split(int(M), L, VP(*[ptr(q) for q in dz_planes]), VP(*[ptr(q) for q in x_planes]),
-                                       VP(*[None if m is None else m[0].data_ptr() for m in dzm]), I64(*[0 if m is None else m[1] for m in dzm]),
-                                       VP(*[None if m is None else m[0].data_ptr() for m in xm]), I64(*[0 if m is None else m[1] for m in xm]),
-                                       VP(*[w.data_ptr() for w in dWs]), I64(*[w.stride(0) for w in dWs]),
-                                       VP(*[ptr(b) for b in dbs]), I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]),
-                                       1 if accumulate else 0, ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split")
+    args = (int(M), L, VP(*[ptr(q) for q in dz_planes]), VP(*[ptr(q) for q in x_planes]),
+            VP(*[None if m is None else m[0].data_ptr() for m in dzm]), I64(*[0 if m is None else m[1] for m in dzm]),
+            VP(*[None if m is None else m[0].data_ptr() for m in xm]), I64(*[0 if m is None else m[1] for m in xm]),
+            VP(*[w.data_ptr() for w in dWs]), I64(*[w.stride(0) for w in dWs]),
+            VP(*[ptr(b) for b in dbs]), I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]), 1 if accumulate else 0)
+    if state is None:
+        check(load().clica_mlp_wgrad_split(*args, ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split")
+    else:      # f16x2 plane copies: per layer the positions of its operands' scales in the state (include/clica.h)
+        check(load().clica_mlp_wgrad_split16(*args, state.buf.data_ptr(), I32(*[int(i) for i in a_index]), I32(*[int(i) for i in d_index]),
+                                             ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split16")
     return ws
 
 

@@ -348,6 +348,51 @@ int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_pla
                           float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
                           int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
+/* ---- f16x2 arithmetic (round 5): the same whole-encoder kernels with TWO fp16 pieces per operand --------------------------------
+ * Replaces nothing in the reference: it is a second fp32 EMULATION next to the bf16x3 one above, for encoders.py:36-48's Linear
+ * stack.  v s = hi + lo with hi = RN_f16(v s), lo = RN_f16(v s - hi) (22 significand bits) and the three products hi.hi, hi.lo,
+ * lo.hi accumulated in fp32 (v_mfma_f32_*_f16): half the matrix work and 4 instead of 6 bytes per operand element.  fp16's 5-bit
+ * exponent needs a power-of-two scale s PER TENSOR: a caller-owned device `state` (clica_split16_state_bytes bytes, 16-byte aligned,
+ * initialised once by clica_split16_state_init) holds, per tensor of one encoder, the scale in force and the running maximum the
+ * producers record; clica_split16_update (one tiny launch per training step, after the step's last producer) turns the maxima into
+ * the next step's scales (largest scaled magnitude in [256, 512)).  So a launch uses the scales of the PREVIOUS step: run two
+ * un-applied passes after initialisation / after parameters were set from outside so that the scales match the data (the engine
+ * does).  A scaled magnitude beyond 32768 (a tensor grew > 64 x between consecutive steps) raises bit 0 of the state's sticky
+ * flags -- results of that launch are not to be trusted; clica_split16_read (synchronises) reports it.  Measured error: at the
+ * native fp32-MFMA kernels' level (tests: every engine family in this arithmetic at 1e-5).
+ * Order of one training step on a state: clica_mlp_pack_split16_both -> clica_mlp_fwd_split16 -> clica_mlp_dgrad_split16 ->
+ * clica_mlp_wgrad_split16 -> clica_split16_update.  Plane buffers hold 2 KB per unit (clica_mlp_planes16_bytes); everything else
+ * (fragment order, sign bits, the constant-1 feature -- stored as the activation's scale --, argument meaning) is as for the
+ * bf16x3 entry points of the same name without "16".  Needs a LeakyReLU slope in (0, 1). */
+int clica_split16_state_bytes(size_t* bytes);
+int clica_split16_state_init(void* state, clica_stream_t stream);
+int clica_split16_update(void* state, int32_t n_layers, clica_stream_t stream);
+/* HOST outputs (each may be NULL): sticky flags, number of updates, the scales in force for the activations (forward order, [0] =
+ * encoder input), for the chain gradients (chain order, [0] = d loss / d last pre-activation) and for the weights, and the activation /
+ * gradient scales the LAST step ran with (what its plane copies are scaled by); 9 floats each.  Synchronises `stream`. */
+int clica_split16_read(const void* state, int32_t* flags, int32_t* updates, float* scales_a, float* scales_d, float* scales_w,
+                       float* last_scales_a, float* last_scales_d, clica_stream_t stream);
+int clica_split16_clear_flags(void* state, clica_stream_t stream);
+int clica_mlp_planes16_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes);
+int clica_mlp_pack_split16_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
+int clica_mlp_pack_split16_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                void* packed_fwd, void* packed_bwd, void* state, clica_stream_t stream);
+int clica_mlp_fwd_split16(const float* X, int64_t ldx, int64_t M, const float* mix_W, int32_t mix_layers, float mix_slope,
+                          float* x_out, int64_t ldxo, int32_t n_layers, const float* const* bias,
+                          float* const* out, const int64_t* ldo, const int32_t* N, const int32_t* K,
+                          const void* packed_split16, uint64_t* const* signmask, void* const* planes, float slope,
+                          void* state, clica_stream_t stream);
+int clica_mlp_dgrad_split16(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                            const void* packed_split16, const uint64_t* const* signmask,
+                            float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state, clica_stream_t stream);
+/* a_index[l] / d_index[l]: positions of layer l's input activation / of dZ_l in the state's activation / chain-gradient scale
+ * arrays (an L-layer encoder passed whole: a_index[l] = l, d_index[l] = L - 1 - l). */
+int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                            const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                            float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                            int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
+                            void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
 /* Weight/bias gradients of ALL layers in two launches (one grouped split-K GEMM over equal-length work items
  * + one grouped deterministic slab reduction):  dW[l] = dZ[l]^T X[l]  ([N_l, K_l]),  db[l] = column sums of dZ[l]
  * (db[l] may be NULL).  dZ[l] = [M, N_l] gradient at layer l's pre-activation, X[l] = [M, K_l] its input. */

@@ -38,8 +38,8 @@ class ParityLog:
 
     def check(self, family, case, what, got, ref, tol=TOL, floor=0.0, note=None):
         got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
-        if self.mode == "split_bf16":
-            family = family + "[split_bf16]"
+        if self.mode in ("split_bf16", "split_f16"):
+            family = family + f"[{self.mode}]"
         assert got.shape == ref.shape, (family, case, what, got.shape, ref.shape)
         den = max(float(np.max(np.abs(ref))) if ref.size else 0.0, float(floor), 1e-30)
         err = (float(np.max(np.abs(got - ref))) if ref.size else 0.0) / den
@@ -101,7 +101,7 @@ def recorded_r3_error(family):
     """max_rel_err the round-3 GPU run recorded for `family` (profiles/r3_parity_errors.json; the [split_bf16] suffix is added here as
     in ParityLog.check), or None.  Used to cap allowances at 10 x what was measured."""
     import json
-    if PARITY.mode == "split_bf16":
+    if PARITY.mode in ("split_bf16", "split_f16"):      # (the f16x2 arithmetic did not exist in round 3: bounded by the bf16x3 record)
         family = family + "[split_bf16]"
     try:
         fam = json.load(open(os.path.join(ROOT, "profiles", "r3_parity_errors.json")))["families"]
@@ -141,14 +141,16 @@ class Golden:
             yield f"c{i:03d}", self.case(f"c{i:03d}")
 
 
-@pytest.fixture(params=["native_fp32", "split_bf16"])
+@pytest.fixture(params=["native_fp32", "split_bf16", "split_f16"])
 def encoder_arith(request, monkeypatch):
     """Run a test once per encoder arithmetic of the fused training engine: native fp32 MFMA, and the split-bf16 mode
     (exact 3-way bf16 operand splits, six bf16-MFMA products, fp32 accumulate -- forward stack, backward chain and weight
     gradients; the mode bench.py's headline runs in).  The engine reads CLICA_SPLIT_BF16 at construction (worker processes
     inherit it); encoders the whole-stack kernels cannot take (a width beyond 512) run the fp32 per-layer kernels in
     both.  Same goldens, same tolerances."""
-    monkeypatch.setenv("CLICA_SPLIT_BF16", "1" if request.param == "split_bf16" else "0")
+    # (round 5) "split_f16": two fp16 pieces per operand with per-tensor scales, three products -- the engine's default since round 5
+    monkeypatch.setenv("CLICA_SPLIT_BF16", "0" if request.param == "native_fp32" else "1")
+    monkeypatch.setenv("CLICA_SPLIT_ARITH", "f16" if request.param == "split_f16" else "bf16")
     PARITY.mode = request.param
     yield request.param
     PARITY.mode = None

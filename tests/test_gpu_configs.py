@@ -53,7 +53,7 @@ def test_c2_engine_full_size_vs_oracle(encoder_arith):
     z1 = z1.astype(np.float32); z2 = z2.astype(np.float32)
     tr = ContrastiveTrainer(f, dev(gW), SamplerSpec(space="box", n=n), batch_size=B, p=2, lr=0.0, device="cuda")
     assert tr.fused_forward and tr.fused_backward           # the whole-stack kernels, not the per-layer GEMMs
-    assert bool(tr.split_bf16) == (encoder_arith == "split_bf16")
+    assert bool(tr.split_bf16) == (encoder_arith != "native_fp32") and bool(tr.split_f16) == (encoder_arith == "split_f16")
     out = tr.step_injected(dev(z1), dev(z2)).cpu().numpy()
     lin = [m for m in f if isinstance(m, torch.nn.Linear)]
     P = O.MLPParams([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin],

