@@ -82,11 +82,12 @@ def parse():
                     help="do not spawn the two short rocprofv3 --pmc passes that measure the dominant kernel's HBM-side bytes "
                          "(roofline.traffic then falls back to the committed profile)")
     ap.add_argument("--no-conv-configs", action="store_true", help="skip the c4 / c5 legs of `secondary`")
+    ap.add_argument("--no-dry-leg", action="store_true", help="skip the `dry_ranks_8` leg (rank 0 of an 8-rank job planned, captured and run on this GPU; N = 1 only)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
 
-def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1, dry_ranks=1):
+def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1, dry_ranks=1, split_arith=None):
     from cl_ica_amd import encoders, invertible_network_utils as inu
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
     import contextlib, io
@@ -102,7 +103,8 @@ def build_trainer(args, device, world, split_bf16=None, emulate_pool_ranks=1, dr
                               device=device, process_group=None if (world == 1 and dry_ranks == 1) else dist.group.WORLD,
                               overlap_backward=not args.no_overlap, fused_forward=not args.no_fused_forward,
                               split_bf16=(not args.native_fp32) if split_bf16 is None else split_bf16,
-                              emulate_pool_ranks=emulate_pool_ranks, dry_ranks=dry_ranks, force_collectives=dry_ranks > 1)
+                              emulate_pool_ranks=emulate_pool_ranks, dry_ranks=dry_ranks, force_collectives=dry_ranks > 1,
+                              split_arith=split_arith)
 
 
 def _graph_time(fns, reps):
@@ -775,6 +777,42 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
             "kernel_shares": "profiles/r4_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % (which, which)}
 
 
+def dry_ranks_leg(args, device, R=8, steps=50, windows=3):
+    """Rank 0 of an R-rank data-parallel job, planned, captured (with its RCCL collectives, on a one-rank group) and run on THIS GPU:
+    pool of R x B rows, loss workspaces / stream splits for that pool, two-half weight-gradient launch, gradient buckets, 1 / R
+    gradient scale (ContrastiveTrainer(dry_ranks=R)).  What it shows: this rank's compute at R GPUs, i.e. the
+    ceiling of per-rank speed before any wire time.  What it cannot show: the wire.  NOT a multi-GPU measurement."""
+    made_group = False
+    try:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            made_group = True
+        trd = build_trainer(args, device, 1, dry_ranks=R)
+        use_graph = capture_or_eager(trd, args, 0, 1, device)
+        w, _ = timed_windows(trd, steps, args.warmup, windows, 1, device)
+        el = float(np.median(w))
+        loss = loss_leg(trd, reps=20)
+        plan = trd.plan_summary()
+        coll = plan.get("collectives_per_step", [])
+        return {"what": f"DRY RUN: rank 0 of a {R}-rank job on one GPU (B={args.batch_size}/rank, n={args.n}; the other ranks' rows are copies) -- this "
+                        "rank's compute with the R-rank negatives pool and every collective issued on a one-rank RCCL group inside the step graph; "
+                        "not a multi-GPU measurement",
+                "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": windows,
+                "launch": "hipGraph replay with the RCCL collectives captured" if use_graph else "eager",
+                "loss_fwd_us": round(loss["fwd_us"], 1), "loss_bwd_us": round(loss["bwd_us"], 1), "loss_sweeps": loss.get("sweeps"),
+                "negatives_pool": plan.get("pool_rows"), "collective_bytes_per_step": sum(int(c.get("bytes_per_rank", c.get("bytes", 0))) for c in coll),
+                "plan": plan, "final_loss": float(trd.loss_out[3 * trd.B].item())}
+    except Exception as e:      # (a RCCL build that refuses a one-rank group / capture must not take the headline line down)
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        if made_group:
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+
+
 def main():
     args = parse()
     from cl_ica_amd.distributed import init_from_env
@@ -808,6 +846,7 @@ def main():
                           "higher_is_better": True, "data": "synthetic", **ent}))
         return
     tr = build_trainer(args, device, world)
+    args._f16_headline = bool(getattr(tr, "split_f16", False))
     use_graph = capture_or_eager(tr, args, rank, world, device)
     # "median of 5 windows" -- a short driver run (--steps 20 = ~11 ms of GPU time per window) is then not at the
     # mercy of one scheduling hiccup
@@ -911,6 +950,20 @@ def main():
             leg["roofline"] = {k: roof2[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
                                                      "algorithmic_gflop_per_launch", "dtype")}
         out["native_fp32"] = leg
+    if rank == 0 and world == 1 and not args.no_native_leg and getattr(args, "_f16_headline", False):
+        # the round-3 / round-4 arithmetic (bf16x3: six bf16 products, 6 B/element planes) next to the f16x2 headline, same box, same call
+        tr3 = build_trainer(args, device, world, split_arith="bf16")
+        capture_or_eager(tr3, args, rank, world, device)
+        w3, _ = timed_windows(tr3, min(args.steps, 200), args.warmup, 3, world, device)
+        el = float(np.median(w3)); nst = min(args.steps, 200)
+        out["split_bf16x3"] = {"value": nst / el, "unit": "steps/s", "ms_per_step": 1e3 * el / nst, "steps": nst, "windows": len(w3),
+                               "final_loss": float(tr3.loss_out[3 * tr3.B].item()),
+                               "what": "identical step in the bf16x3 split arithmetic (CLICA_SPLIT_ARITH=bf16: the headline arithmetic of rounds 3-4)"}
+        del tr3
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_dry_leg and (args.n, args.space_type, args.p) == (10, "box", 2):
+        out["dry_ranks_8"] = dry_ranks_leg(args, device, R=8)
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_secondary and (args.n, args.space_type, args.p) == (10, "box", 2):
         out["secondary"] = secondary_leg(args, device)
         if not args.no_conv_configs:

@@ -142,6 +142,8 @@ SIGNATURES: Dict[str, list] = {
     "clica_adam_step": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
     "clica_adam_step_at": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_i32,
                            C.c_void_p],
+    "clica_adam_step_s16": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_i32,
+                            C.c_void_p, c_i32, C.c_void_p],
     "clica_adam_step_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                              C.c_void_p, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],

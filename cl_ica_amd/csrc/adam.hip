@@ -4,6 +4,7 @@
 //   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 // HBM-bound: 16 B read + 12 B written per parameter, one launch for all layers.
 #include "common.h"
+#include "split16.h"
 
 namespace clica {
 namespace adam {
@@ -11,7 +12,12 @@ constexpr int THREADS = 256;
 
 __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                  float* __restrict__ v, int64_t count, float lr, float b1, float b2, float eps,
-                                                 float gscale, int32_t* __restrict__ step_dev, int32_t* __restrict__ ticket, int t_offset) {
+                                                 float gscale, int32_t* __restrict__ step_dev, int32_t* __restrict__ ticket, int t_offset,
+                                                 s16::Split16State* s16_state, int s16_layers) {
+  // f16x2 encoder arithmetic: the scale update of the step (split16.h) rides in this launch as ONE extra workgroup -- every producer
+  // of the step has finished by stream order, and the next step's pack launch (the first reader of the new scales) comes behind it
+  const unsigned nwork = gridDim.x - (s16_state ? 1u : 0u);
+  if (s16_state && blockIdx.x == nwork) { s16::split16_update_body(s16_state, s16_layers); return; }
   __shared__ float s_step_size, s_inv_bc2_sqrt;
   if (threadIdx.x == 0) {
     const double t = (double)(step_dev[0] + t_offset);
@@ -24,7 +30,7 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
   const float step_size = s_step_size, inv_bc2_sqrt = s_inv_bc2_sqrt;
   const float omb1 = 1.f - b1, omb2 = 1.f - b2;
   const int64_t n4 = count / 4;
-  const int64_t stride = (int64_t)gridDim.x * THREADS;
+  const int64_t stride = (int64_t)nwork * THREADS;
   float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
   for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += stride) {
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
   if (ticket) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      if (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)nwork - 1) {
         step_dev[0] += 1;
         __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -67,15 +73,16 @@ using namespace clica;
 
 static int adam_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                        float lr, float beta1, float beta2, float eps, float grad_scale,
-                       int32_t* step_dev, int32_t* ticket, int t_offset, clica_stream_t stream) {
+                       int32_t* step_dev, int32_t* ticket, int t_offset, clica_stream_t stream, void* s16_state = nullptr, int s16_layers = 0) {
   CLICA_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step_dev && count > 0, "clica_adam_step: bad argument");
   CLICA_CHECK_ARG(((uintptr_t)param % 16 == 0) && ((uintptr_t)grad % 16 == 0) && ((uintptr_t)exp_avg % 16 == 0) && ((uintptr_t)exp_avg_sq % 16 == 0),
                   "clica_adam_step: arenas must be 16-byte aligned");
   int64_t blocks = ceil_div(ceil_div(count, 4), adam::THREADS);
   if (blocks > kNumCU * 8) blocks = kNumCU * 8;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks), dim3(adam::THREADS), 0, as_stream(stream),
-                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, t_offset);
+  hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks + (s16_state ? 1u : 0u)), dim3(adam::THREADS), 0, as_stream(stream),
+                     param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, t_offset,
+                     reinterpret_cast<s16::Split16State*>(s16_state), s16_layers);
   return launch_status("clica_adam_step");
 }
 
@@ -97,4 +104,14 @@ extern "C" int clica_adam_step_at(float* param, const float* grad, float* exp_av
                                   const int32_t* step_dev, int32_t t_offset, clica_stream_t stream) {
   CLICA_CHECK_ARG(t_offset == 0 || t_offset == 1, "clica_adam_step_at: t_offset must be 0 or 1");
   return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, t_offset, stream);
+}
+
+// clica_adam_step_at + the f16x2 encoder arithmetic's scale update (clica_split16_update) in the same launch
+extern "C" int clica_adam_step_s16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                                   float lr, float beta1, float beta2, float eps, float grad_scale,
+                                   const int32_t* step_dev, int32_t t_offset, void* split16_state, int32_t n_layers, clica_stream_t stream) {
+  CLICA_CHECK_ARG(t_offset == 0 || t_offset == 1, "clica_adam_step_s16: t_offset must be 0 or 1");
+  CLICA_CHECK_ARG(split16_state && n_layers >= 1 && n_layers <= 8, "clica_adam_step_s16: bad state / layer count");
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, t_offset, stream,
+                     split16_state, n_layers);
 }

@@ -17,6 +17,7 @@
 // One launch replaces seven; the panel never round-trips through HBM between layers.
 #include "common.h"
 #include "planes.h"
+#include "split16.h"
 #include <stdlib.h>
 
 namespace clica {
@@ -681,8 +682,8 @@ template <> struct Arith<1> {
   static constexpr int PW[3] = {1, 0, 0}, PX[3] = {0, 1, 0};
   static constexpr int XORDER[2] = {0, 1};
 };
-constexpr int kF16Target = 8;              // scaled maximum of a tensor in [256, 512)
-constexpr float kF16Alarm = 32768.f;       // a scaled magnitude beyond this raises the overflow flag (fp16 max 65504)
+using s16::kF16Target; using s16::kF16Alarm; using s16::Split16State; using s16::kS16CapWG; using s16::kS16CapPW;
+using s16::s16_partA; using s16::s16_partD; using s16::s16_partW; using s16::s16_partWl; using s16::split16_update_body;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int AR>
@@ -703,32 +704,6 @@ __device__ __forceinline__ void split16_one(const float t, unsigned short& hi, u
   hi = __builtin_bit_cast(unsigned short, h);
   lo = __builtin_bit_cast(unsigned short, (_Float16)(t - (float)h));
 }
-// Device state of the f16x2 arithmetic of ONE encoder (clica_split16_state_bytes floats): per tensor family and position the running
-// maximum of the current step (true units, as uint bits: non-negative floats order like ints) and the scale in force.
-//   family A: activations in forward order   A[0] = encoder input x, A[l + 1] = output of layer l
-//   family D: gradients in CHAIN order        D[0] = d loss / d (last pre-activation), D[j + 1] = output of chain link j
-//   family W: weights, W[l] forward order;  WC[j] = the same scales in chain order (link j uses layer L - 1 - j)
-struct Split16State {
-  static constexpr int NT = MAXL + 1;
-  // (the maxima are NOT gathered by global atomics: 2 048 same-address device-scope atomics per layer cost 60 us per launch,
-  //  measured; every producer workgroup / pack wave leaves its maxima in a slot of its own behind this header and the update
-  //  kernel reduces them)
-  unsigned nA, nD, nPW;    // producer slots written since the last update: forward workgroups, chain workgroups, pack waves (0: not produced)
-  unsigned capWG, capPW;   // capacities of the slot arrays (= kS16CapWG / kS16CapPW; informational)
-  unsigned pad0[NT * 3 - 5];
-  float sA[NT], sD[NT], sW[NT], sWC[NT];
-  unsigned flags;          // bit 0: a scaled magnitude passed kF16Alarm (results of that launch are not to be trusted)
-  unsigned updates;        // number of scale updates so far
-  unsigned pad[2];
-  float pA[NT], pD[NT];    // the scales the LAST step ran with (kept by the update: what its plane copies are scaled by; inspection)
-};
-constexpr unsigned kS16CapWG = 4096;       // producer workgroups of a launch (48 rows each: batches up to 196 608 rows)
-constexpr unsigned kS16CapPW = 16384;      // pack waves (512 weights each)
-// slot arrays behind the header: partA[capWG][NT], partD[capWG][NT] (true-unit maxima as float bits), partW[capPW] (value), partWl[capPW] (layer, -1: none)
-__device__ __host__ inline unsigned* s16_partA(Split16State* st) { return reinterpret_cast<unsigned*>(st + 1); }
-__device__ __host__ inline unsigned* s16_partD(Split16State* st, unsigned capWG = kS16CapWG) { return s16_partA(st) + (size_t)capWG * Split16State::NT; }
-__device__ __host__ inline unsigned* s16_partW(Split16State* st, unsigned capWG = kS16CapWG) { return s16_partD(st, capWG) + (size_t)capWG * Split16State::NT; }
-__device__ __host__ inline int* s16_partWl(Split16State* st, unsigned capWG = kS16CapWG, unsigned capPW = kS16CapPW) { return reinterpret_cast<int*>(s16_partW(st, capWG) + capPW); }
 // one call per wave and tensor: the wave's maximum (true units; NaN / inf as a huge value so that the update kernel sees them) into an LDS word
 __device__ __forceinline__ void amax_wave_to_lds(unsigned* lds_word, float m_scaled, float inv_scale) {
 #pragma unroll
@@ -829,41 +804,7 @@ __global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
   if (idx == 0) a.st->nPW = (unsigned)((a.first[a.nseg] + 63) >> 6);
 }
 
-// Maxima of the step that has just run -> scales of the next one.  s = 2^(kF16Target - floor(log2 max)); a tensor nobody wrote
-// (maximum 0) keeps its scale.  Activation scales stay inside fp16's normal range (the constant-1 feature of a plane copy is stored
-// as the value s).  One workgroup: it also reduces the producers' slot arrays (no global atomics anywhere) and raises the overflow flag
-// when the step that has just run carried a scaled magnitude beyond kF16Alarm.
-__global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) {
-  constexpr int NT = Split16State::NT;
-  __shared__ unsigned mx[3][NT];
-  const int t = threadIdx.x;
-  if (t < 3 * NT) mx[t / NT][t % NT] = 0u;
-  __syncthreads();
-  const unsigned nA = min(st->nA, kS16CapWG), nD = min(st->nD, kS16CapWG), nPW = min(st->nPW, kS16CapPW);
-  const unsigned* pA = s16_partA(st); const unsigned* pD = s16_partD(st);
-  const unsigned* pW = s16_partW(st); const int* pWl = s16_partWl(st);
-  for (unsigned i = t; i < nA * NT; i += 256) atomicMax(&mx[0][i % NT], pA[i]);
-  for (unsigned i = t; i < nD * NT; i += 256) atomicMax(&mx[1][i % NT], pD[i]);
-  for (unsigned i = t; i < nPW; i += 256) { const int l = pWl[i]; if (l >= 0 && l < NT) atomicMax(&mx[2][l], pW[i]); }
-  __syncthreads();
-  auto next = [&](unsigned bits, float cur, int emin, int emax) {
-    const float a = __uint_as_float(bits);
-    if (!(a > 0.f)) return cur;                                 // nobody wrote the tensor: keep its scale
-    if (!(a < 3.0e38f) || a * cur > kF16Alarm) atomicOr(&st->flags, 1u);      // non-finite, or the step that just ran overflowed its scale
-    if (!(a < 3.0e38f)) return cur;
-    int e = (int)((bits >> 23) & 0xffu) - 127;                  // floor(log2 a) for normal a
-    if (((bits >> 23) & 0xffu) == 0u) e = -127;
-    int se = kF16Target - e;
-    se = se < emin ? emin : (se > emax ? emax : se);
-    return __uint_as_float((unsigned)(se + 127) << 23);
-  };
-  if (t <= L) { st->pA[t] = st->sA[t]; st->sA[t] = next(mx[0][t], st->sA[t], -14, 15); }
-  if (t < L) { st->pD[t] = st->sD[t]; st->sD[t] = next(mx[1][t], st->sD[t], -100, 100); }
-  float w = 1.f;
-  if (t < L) { w = next(mx[2][t], st->sW[t], -100, 100); st->sW[t] = w; }
-  if (t < L && L - 1 - t >= 0 && L - 1 - t < NT) st->sWC[L - 1 - t] = w;      // chain link j uses layer L - 1 - j
-  if (t == 0) { st->updates += 1u; st->nA = st->nD = st->nPW = 0u; }
-}
+__global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) { split16_update_body(st, L); }
 __global__ __launch_bounds__(64) void split16_init_k(Split16State* st, unsigned capWG, unsigned capPW) {
   const int t = threadIdx.x;
   if (t < Split16State::NT) st->sA[t] = st->sD[t] = st->sW[t] = st->sWC[t] = st->pA[t] = st->pD[t] = 1.f;

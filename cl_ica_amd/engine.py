@@ -679,9 +679,11 @@ class ContrastiveTrainer:
         self._packed_current = False
         # the last Adam workgroup to finish also advances the device step / RNG counter (no separate tick launch)
         ticked, self._ticked = self._ticked, False
-        ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
-                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / (self.world * self.dry_ranks),
-                      ticket=self.adam_ticket if (self.fuse_tick and not ticked) else None, t_offset=0 if ticked else 1)
+        fused_update = ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
+                                     self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / (self.world * self.dry_ranks),
+                                     ticket=self.adam_ticket if (self.fuse_tick and not ticked) else None, t_offset=0 if ticked else 1,
+                                     s16=self.s16 if self.split_f16 else None)
+        self._s16_updated = bool(fused_update)
         if not self.fuse_tick and not ticked:
             ops.tick(self.step_dev)
 
@@ -712,8 +714,8 @@ class ContrastiveTrainer:
         self.loss_forward_backward()
         self.backward()
         self.optimizer_step()
-        if self.split_f16:
-            self.s16.update()                  # this step's recorded maxima -> the next step's scales (one one-wave launch)
+        if self.split_f16 and not getattr(self, "_s16_updated", False):
+            self.s16.update()                  # this step's recorded maxima -> the next step's scales (normally inside the Adam launch)
 
     def calibrate_scales(self, sample: bool = True, passes: Optional[int] = None):
         """f16x2 arithmetic: a launch runs on the scales derived from the PREVIOUS step's maxima, so before the first step (and after

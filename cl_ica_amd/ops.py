@@ -530,7 +530,7 @@ PARAM_EPOCH = 0     # bumped by every raw-pointer parameter update (adam_step): 
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
-              ticket: Optional[torch.Tensor] = None, t_offset: int = 1):
+              ticket: Optional[torch.Tensor] = None, t_offset: int = 1, s16=None):
     """In-place Adam on flat fp32 arenas; `step_dev` int32[1] = updates already applied.  With `ticket` (device
     int32[1], zero) the same launch also advances `step_dev` by one (clica_adam_step_tick)."""
     global PARAM_EPOCH
@@ -539,6 +539,11 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
         require_cuda(t, nm)
         if not t.is_contiguous():
             raise ValueError(f"{nm} must be contiguous")
+    if s16 is not None and ticket is None:     # the f16x2 arithmetic's scale update rides in the optimizer launch (clica_adam_step_s16)
+        check(load().clica_adam_step_s16(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                         param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                         step_dev.data_ptr(), int(t_offset), s16.buf.data_ptr(), s16.n_layers, stream_ptr()), "clica_adam_step_s16")
+        return True
     if ticket is None and t_offset != 1:       # the counter was already advanced earlier in the step
         check(load().clica_adam_step_at(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                         param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),

@@ -544,6 +544,11 @@ int clica_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int clica_adam_step_at(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                        float lr, float beta1, float beta2, float eps, float grad_scale,
                        const int32_t* step_dev, int32_t t_offset, clica_stream_t stream);
+/* clica_adam_step_at with the f16x2 encoder arithmetic's scale update (clica_split16_update(state, n_layers)) riding in the same launch
+ * as one extra workgroup: the training step's last launch then also prepares the next step's scales. */
+int clica_adam_step_s16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                        float lr, float beta1, float beta2, float eps, float grad_scale,
+                        const int32_t* step_dev, int32_t t_offset, void* split16_state, int32_t n_layers, clica_stream_t stream);
 /* Same update, and the LAST workgroup to finish advances *step_dev by one (replaces the separate clica_tick launch).
  * `ticket` is a device int32 owned by the caller, zero before the first call; the kernel leaves it at zero. */
 int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,

@@ -389,18 +389,21 @@ def test_matrix_core_guard_falls_back_inside_graph_replay():
     scale = (4.0 * g0["limit"] / g0["last_spread"]) ** 0.5         # M grows with the square of the embedding scale: 4 x the limit (not so far that rows saturate)
     with torch.no_grad():
         last.weight.mul_(scale); last.bias.mul_(scale)
+    tr.calibrate_scales()       # (f16x2 arithmetic: parameters replaced from outside by a factor of hundreds -- its scales follow; eager passes, the graph stays)
     tr.step(); torch.cuda.synchronize()
     g1 = tr.loss_guard()
     assert tr.graph is graph, "no re-capture"
-    assert g1["fallback_steps"] == 1 and g1["last_spread"] > 2 * g1["limit"], g1
+    assert g1["fallback_steps"] >= 1 and g1["last_spread"] > 2 * g1["limit"], g1      # (the calibration passes of the f16x2 arithmetic are loss calls too)
     _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay beyond the limit (M = {g1['last_spread']:.0f}, difference sweeps)")
     tr.step(); torch.cuda.synchronize()
-    assert tr.loss_guard()["fallback_steps"] == 2
+    fb = tr.loss_guard()["fallback_steps"]
+    assert fb == g1["fallback_steps"] + 1
     with torch.no_grad():
         last.weight.div_(scale); last.bias.div_(scale)
+    tr.calibrate_scales()
     tr.step(); torch.cuda.synchronize()
     g2 = tr.loss_guard()
-    assert g2["fallback_steps"] == 2 and g2["last_spread"] <= g2["limit"], g2
+    assert g2["fallback_steps"] == fb and g2["last_spread"] <= g2["limit"], g2
     _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay back inside the limit (M = {g2['last_spread']:.0f})")
 
 
