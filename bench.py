@@ -970,10 +970,19 @@ def main():
             out["secondary"]["c4_3dident_resnet18"] = conv_config_leg("c4", device)
             torch.cuda.empty_cache()
             out["secondary"]["c5_kitti_masks"] = conv_config_leg("c5", device)
-    if rank == 0:
-        print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    # RCCL prints a version banner through C stdio, which is fully buffered on a pipe and would come out at process exit -- BEHIND the
+    # contract line.  Flush the C streams first so that the JSON line is the last line of stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -683,7 +683,7 @@ template <> struct Arith<1> {
   static constexpr int XORDER[2] = {0, 1};
 };
 using s16::kF16Target; using s16::kF16Alarm; using s16::Split16State; using s16::kS16CapWG; using s16::kS16CapPW;
-using s16::s16_partA; using s16::s16_partD; using s16::s16_partW; using s16::s16_partWl; using s16::split16_update_body;
+using s16::s16_partA; using s16::s16_partD; using s16::s16_partW; using s16::split16_update_body;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int AR>
@@ -758,6 +758,7 @@ struct Pack2Args {
   PackSeg seg[MAXSEG];
   const float* scale[MAXSEG];      // device: the scale of this segment's tensor
   int layer[MAXSEG];               // forward-orientation segments: the layer whose max |W| this segment records; -1: none
+  int nfwd;                        // number of forward-orientation segments = layers (they come first)
   Split16State* st;
 };
 __global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
@@ -797,11 +798,12 @@ __global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   const unsigned wid = (unsigned)(idx >> 6);
-  if ((threadIdx.x & 63) == 0 && wid < kS16CapPW) {
-    s16_partW(a.st)[wid] = __float_as_uint((m <= 3.0e38f) ? m / sc : 3.4e38f);
-    s16_partWl(a.st)[wid] = live ? a.layer[sidx] : -1;
+  if ((threadIdx.x & 63) == 0 && wid < kS16CapPW && a.layer[sidx] >= 0) s16_partW(a.st)[wid] = __float_as_uint((m <= 3.0e38f) ? m / sc : 3.4e38f);
+  if (blockIdx.x == 0 && threadIdx.x <= Split16State::NT) {      // wave ranges of the layers (forward-orientation segments come first, one per layer)
+    const int l = threadIdx.x;
+    a.st->wfirst[l] = (unsigned)(a.first[l < a.nfwd ? l : a.nfwd] >> 6);
+    if (l == 0) a.st->nPW = (unsigned)(a.first[a.nfwd] >> 6);
   }
-  if (idx == 0) a.st->nPW = (unsigned)((a.first[a.nseg] + 63) >> 6);
 }
 
 __global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) { split16_update_body(st, L); }
@@ -1148,7 +1150,7 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
 }
 
 // ---- epilogue of one layer in the f16x2 arithmetic ---------------------------------------------------------------------------
-//   ACT 1: t = acc * cmul + bias' (bias' = bias * s_out, from the LDS table), LeakyReLU when `leaky` (slope in (0, 1): max(t, slope t))
+//   ACT 1: t = acc * cmul + bias * s_out, LeakyReLU when `leaky` (slope in (0, 1): max(t, slope t))
 //   ACT 2: t = acc * cmul, then t or slope * t by the forward's sign bit (backward chain link)
 // t is the layer output IN THE OUTPUT TENSOR'S SCALED UNITS (cmul = s_out / (s_in s_w) folds all three scales; LeakyReLU and the gate
 // are positively homogeneous).  It is split into hi / lo for the next layer's panel (LDS) and, `has_pl`, for the plane copy the
@@ -1163,7 +1165,7 @@ __device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], un
                                                  unsigned& lo_bits, unsigned& hi_bits, float& amax_scaled) {
   const int i15 = lane & 15, kg = lane >> 4;
   const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
-  const f32x2 slope2 = {slope, slope}, cmul2 = {cmul, cmul}, inv2 = {inv_s_out, inv_s_out};
+  const f32x2 slope2 = {slope, slope}, cmul2 = {cmul, cmul}, inv2 = {inv_s_out, inv_s_out}, sout2 = {s_out, s_out};
   const int mlo = (int)(unsigned)mbits, mhi = (int)(unsigned)(mbits >> 32);
   unsigned lo = 0u, hi = 0u;
   float am = 0.f;
@@ -1173,7 +1175,10 @@ __device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], un
     if (cb < ncb) {                                    // wave-uniform
       const int n0 = cb * 16 + kg * 4;
       f32x2 b01 = {0.f, 0.f}, b23 = {0.f, 0.f};
-      if (ACT == 1) { const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_row[n0]); b01 = (f32x2){b4[0], b4[1]}; b23 = (f32x2){b4[2], b4[3]}; }
+      if (ACT == 1) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&bias_row[n0]);
+        b01 = (f32x2){b4[0], b4[1]} * sout2; b23 = (f32x2){b4[2], b4[3]} * sout2;      // bias in the output's scaled units (once per column block)
+      }
       const unsigned pl_cb = (unsigned)((cb >> 1) * 2 * 1024 + (cb & 1) * 128) + pl_lane;
       unsigned short* const dst0 = planes + i15 * LDPB + n0;
 #pragma unroll
@@ -1307,7 +1312,17 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   volatile int* prog = reinterpret_cast<volatile int*>(bias_lds + a.boff[g.L]);      // k-loop progress of the eight waves (layer_gemm_split)
   if (lane == 0) prog[wave] = 0;
   unsigned* amax_lds = const_cast<unsigned*>(reinterpret_cast<volatile unsigned*>(prog)) + WAVES;      // f16x2: the workgroup's maxima, one word per tensor of the launch
-  if constexpr (AR == 1) { if (threadIdx.x < Split16State::NT) amax_lds[threadIdx.x] = 0u; }
+  // ... and the layers' scale factors, derived ONCE here by one thread per layer (read through the scalar cache in every epilogue they
+  // were two cold misses in front of the first layers' epilogues: 8.5 k cycles for a 100-wide layer against 3.3 k for the same layer later)
+  float* lscale = reinterpret_cast<float*>(amax_lds + 16);          // [cmul | s_out | 1 / s_out][MAXL]
+  if constexpr (AR == 1) {
+    if (threadIdx.x < Split16State::NT) amax_lds[threadIdx.x] = 0u;
+    if ((int)threadIdx.x < g.L) {
+      const int l = threadIdx.x;
+      const float so = (l == g.L - 1 && a.last_unscaled) ? 1.f : a.s_t[l + 1];
+      lscale[l] = so / (a.s_t[l] * a.s_w[l]); lscale[MAXL + l] = so; lscale[2 * MAXL + l] = 1.f / so;
+    }
+  }
   constexpr int BIAS_IT = (BIAS_LDS_MAX + THREADS - 1) / THREADS;
   float bv[BIAS_IT];
   const int btotal = a.boff[g.L];
@@ -1322,7 +1337,6 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       const Layer& ly = g.layer[l];
       const int i = idx - a.boff[l];
       if (ly.bias && i < ly.N) bv[u] = ly.bias[i];
-      if constexpr (AR == 1) bv[u] *= (l == g.L - 1 && a.last_unscaled) ? 1.f : a.s_t[l + 1];      // the table holds bias' = bias * s_out
     }
   }
   float s_in0 = 1.f, in_max = 0.f;                     // f16x2: scale of the launch's input tensor, running max of its scaled magnitudes
@@ -1492,10 +1506,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       asm volatile("" : "+v"(lane));
       const int N = q.N;
       const int ncb = ((N + KI - 1) & ~(KI - 1)) / 16;
-      const bool last_plain = (l == g.L - 1) && a.last_unscaled;
-      const float s_out = last_plain ? 1.f : a.s_t[l + 1];
-      const float inv_s_out = 1.f / s_out;
-      const float cmul = s_out / (a.s_t[l] * a.s_w[l]);
+      const float cmul = lscale[l], s_out = lscale[MAXL + l], inv_s_out = lscale[2 * MAXL + l];
       const bool has_out = ly.out != nullptr, has_pl = q.planes != nullptr;
       const bool ovec = has_out && ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (N % 4 == 0);
       const __amdgpu_buffer_rsrc_t orsrc =
@@ -1519,6 +1530,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
         split16_epilogue<2, false>(acc, planes, brow, g.slope, false, mb, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
                                    has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
       }
+      ST_STAMP(l, 6);
       if (has_pl && q.pl_ones && (N & 31) == 0 && wave == 0) {   // the ones column in an extra unit (value s_out: 1 in scaled units)
         const bool first = (lane & 1) == 0 && ((lane >> 3) & 1) == 0;
         const unsigned one = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)s_out);
@@ -1682,7 +1694,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     __syncthreads();
   }
   if constexpr (AR == 1) {        // (behind the last layer's closing barrier) this workgroup's slot of the maxima
-    if (blockIdx.x < a.cap_wg && threadIdx.x < Split16State::NT) a.part_t[(size_t)blockIdx.x * Split16State::NT + threadIdx.x] = amax_lds[threadIdx.x];
+    if (blockIdx.x < a.cap_wg && threadIdx.x < Split16State::NT) a.part_t[(size_t)threadIdx.x * kS16CapWG + blockIdx.x] = amax_lds[threadIdx.x];
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_t = gridDim.x;
   }
   ST_FLUSH(g.L);
@@ -1954,15 +1966,15 @@ static int launch_split(fmlp::SplitArgs& a, int arith, clica_stream_t stream, co
   }
   if (arith == 1) {
     if (!slope01) { set_error("%s: the f16x2 arithmetic needs a LeakyReLU slope in (0, 1), got %g", who, (double)a.g.slope); return CLICA_E_INVALID; }
-    const size_t lds = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 128;
-    constexpr size_t lds_max = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 128;
+    const size_t lds = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256;
+    constexpr size_t lds_max = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
     (void)once;
     hipLaunchKernelGGL(mlp_split_k<1>, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
     return launch_status(who);
   }
-  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 128;      // + the waves' progress words
-  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 128;
+  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256;      // + the waves' progress words
+  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
   (void)once;
   hipLaunchKernelGGL(mlp_split_k<0>, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
@@ -2076,7 +2088,7 @@ extern "C" int clica_mlp_dgrad_split16(const float* dY, int64_t lddy, int64_t M,
 // ---- f16x2 arithmetic: state, weights ---------------------------------------------------------------------------------------------
 extern "C" int clica_split16_state_bytes(size_t* bytes) {
   CLICA_CHECK_ARG(bytes != nullptr, "clica_split16_state_bytes: bytes is NULL");
-  *bytes = sizeof(fmlp::Split16State) + (size_t)fmlp::kS16CapWG * fmlp::Split16State::NT * 4 * 2 + (size_t)fmlp::kS16CapPW * 8;
+  *bytes = s16::kS16StateBytes;
   return CLICA_OK;
 }
 extern "C" int clica_split16_state_init(void* state, clica_stream_t stream) {
@@ -2146,6 +2158,7 @@ extern "C" int clica_mlp_pack_split16_both(int32_t n_layers, const float* const*
     CLICA_CHECK_ARG(W[l] && N[l] >= 1 && K[l] >= 1 && N[l] <= MAXW && K[l] <= MAXW && ldw[l] >= K[l], "clica_mlp_pack_split16_both: layer %d: bad argument", l);
     fill(W[l], ldw[l], N[l], K[l], 0, packed_fwd, &st->sW[l], l);
   }
+  a.nfwd = sgi;
   off = 0;
   for (int l = n_layers - 1; l >= 1; --l) fill(W[l], ldw[l], K[l], N[l], 1, packed_bwd, &st->sW[l], -1);
   a.nseg = sgi;

@@ -79,10 +79,6 @@ struct Params {
   // an element-wise kernel instead of writing the two gradient rows itself
   const float* posdot = nullptr;
   float* dpos = nullptr;
-  // training entry points with the p = 2 matrix-core sweeps in front (lp_mfma.h, "the guard"): this sweep runs only when the call's
-  // spread *gate exceeds gate_limit -- otherwise the matrix-core sweep has done the work and every workgroup returns at once
-  const float* gate = nullptr;
-  float gate_limit = 0.f;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -303,12 +299,13 @@ __device__ __forceinline__ void gaccum2_d(f32x2& g, float coef, f32x2 d) {
 constexpr int fwd_min_waves(int np, bool rowgrad) { return rowgrad ? (np <= 16 ? 3 : 2) : (np <= 16 ? 4 : (np <= 24 ? 3 : 2)); }
 constexpr int bwd_min_waves(int np) { return np <= 16 ? 3 : 2; }
 
+// (the sweep as a device function of the workgroup's (owner tile, stream split) = (bx, by): fwd_partial_k below is its kernel; lp_mfma.hip
+//  instantiates it a second time INSIDE its matrix-core forward kernel as the guard's fallback -- one launch, no empty gated launch)
 template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2, bool ZMAX = false>
-__global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_partial_k(
+__device__ __forceinline__ void fwd_partial_body(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
-    Params q, float2* __restrict__ part, float* __restrict__ part_g, int chunk) {
-  if (q.gate && *q.gate <= q.gate_limit) return;
+    const Params& q, float2* __restrict__ part, float* __restrict__ part_g, int chunk, const int bx, const int by) {
   constexpr int TS = tile_rows(NP), RPP = TS / PARTS, JBF = jb_fwd(NP);
   static_assert(RPP % JBF == 0, "partition rows must be whole JB groups");
   static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");
@@ -316,7 +313,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   __shared__ float2 wred[WAVES][HALF * R];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (HALF - 1), hf = lane >> 5;
   const int pq = wave * 2 + hf;                       // this half-wave's partition of every tile
-  const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
+  const int64_t own0 = (int64_t)bx * (HALF * R);
   f32x2 o[R][NP / 2];
   f32x2 G[ROWGRAD ? R : 1][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n, q.pre);
@@ -331,7 +328,7 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   for (int r = 0; r < R; ++r) { m[r] = ZMAX ? 0.f : -INFINITY; s[r] = 0.f; }
   const float xk = q.xs * q.kscale;
 
-  const int64_t jb = (int64_t)blockIdx.y * chunk;
+  const int64_t jb = (int64_t)by * chunk;
   const int64_t je = min(n_str, jb + (int64_t)chunk);
   Stager<NP> st;
   if (jb < je) {
@@ -442,9 +439,9 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) { f[w] = fexp2(wred[w][t].x - mm); ss = fmaf(wred[w][t].y, f[w], ss); }
     if (i < n_own) {
-      part[(int64_t)blockIdx.y * n_own + i] = make_float2(mm, ss);
+      part[(int64_t)by * n_own + i] = make_float2(mm, ss);
       if (ROWGRAD) {
-        float4* dst = reinterpret_cast<float4*>(part_g + ((int64_t)blockIdx.y * n_own + i) * NP);
+        float4* dst = reinterpret_cast<float4*>(part_g + ((int64_t)by * n_own + i) * NP);
 #pragma unroll
         for (int k4 = 0; k4 < NP / 4; ++k4) {
           float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -460,6 +457,14 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
   }
 }
 
+template <int NP, int PK, int R, bool ROOT, bool ROWGRAD, int NQ = NP / 2, bool ZMAX = false>
+__global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_partial_k(
+    const float* __restrict__ own, int64_t ldo, int64_t n_own,
+    const float* __restrict__ str, int64_t lds, int64_t n_str,
+    Params q, float2* __restrict__ part, float* __restrict__ part_g, int chunk) {
+  fwd_partial_body<NP, PK, R, ROOT, ROWGRAD, NQ, ZMAX>(own, ldo, n_own, str, lds, n_str, q, part, part_g, chunk, blockIdx.x, blockIdx.y);
+}
+
 // ---- backward ------------------------------------------------------------------------------
 // Owner-gradient partials.  STATS bit 0: softmax statistics of the OWNER rows weigh the pair (d/dz1: row
 // reduction); bit 1: statistics of the STREAM rows do (d/dz3: column reduction over row-normalised
@@ -469,13 +474,12 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, ROWGRAD)) void fwd_parti
 // gradient partials are summed on chip (shuffle, then LDS in wave order) before one NP-float row per owner and
 // stream split goes to HBM.
 template <int NP, int PK, int R, int STATS, bool ROOT, int NQ = NP / 2, bool FOLD = false>
-__global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
+__device__ __forceinline__ void bwd_pairs_body(
     const float* __restrict__ own, int64_t ldo, int64_t n_own,
     const float* __restrict__ str, int64_t lds, int64_t n_str,
-    Params q, const float* __restrict__ statL, const float* __restrict__ statC,
+    const Params& q, const float* __restrict__ statL, const float* __restrict__ statC,
     const float* __restrict__ strL, const float* __restrict__ strC,
-    float* __restrict__ part, int chunk) {
-  if (q.gate && *q.gate <= q.gate_limit) return;
+    float* __restrict__ part, int chunk, const int bx, const int by) {
   constexpr bool OWNER_STATS = (STATS & 1) != 0, STREAM_STATS = (STATS & 2) != 0;
   constexpr int TS = tile_rows(NP), RPP = TS / PARTS;
   static_assert(WAVES * HALF * R * NP <= 2 * TS * NP, "the cross-wave merge reuses the tile buffers");
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
   __shared__ float tLs[2][TS], tCs[2][TS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (HALF - 1), hf = lane >> 5;
   const int pq = wave * 2 + hf;
-  const int64_t own0 = (int64_t)blockIdx.x * (HALF * R);
+  const int64_t own0 = (int64_t)bx * (HALF * R);
   f32x2 o[R][NP / 2], g[R][NP / 2];
   load_owners<NP, R>(o, own, ldo, own0, n_own, q.n, q.pre);
   float oL[R], oC[R];
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
   }
   const float xk = q.xs * q.kscale;
   const float csgn = (PK == 0) ? q.sgn : 1.f;
-  const int64_t jb = (int64_t)blockIdx.y * chunk;
+  const int64_t jb = (int64_t)by * chunk;
   const int64_t je = min(n_str, jb + (int64_t)chunk);
   Stager<NP> st;
   float rl = 0.f, rc = 0.f;     // staged stream statistics (threads < TS)
@@ -619,8 +623,18 @@ __global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
       const float4 g4 = *reinterpret_cast<const float4*>(gred + ((size_t)w * (HALF * R) + t) * NP + 4 * k4);
       a4.x += g4.x; a4.y += g4.y; a4.z += g4.z; a4.w += g4.w;
     }
-    *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * n_own + i) * NP + 4 * k4) = a4;
+    *reinterpret_cast<float4*>(part + ((int64_t)by * n_own + i) * NP + 4 * k4) = a4;
   }
+}
+
+template <int NP, int PK, int R, int STATS, bool ROOT, int NQ = NP / 2, bool FOLD = false>
+__global__ __launch_bounds__(THREADS, bwd_min_waves(NP)) void bwd_pairs_k(
+    const float* __restrict__ own, int64_t ldo, int64_t n_own,
+    const float* __restrict__ str, int64_t lds, int64_t n_str,
+    Params q, const float* __restrict__ statL, const float* __restrict__ statC,
+    const float* __restrict__ strL, const float* __restrict__ strC,
+    float* __restrict__ part, int chunk) {
+  bwd_pairs_body<NP, PK, R, STATS, ROOT, NQ, FOLD>(own, ldo, n_own, str, lds, n_str, q, statL, statC, strL, strC, part, chunk, blockIdx.x, blockIdx.y);
 }
 
 // ---- wide rows: 64 < n <= 512 ------------------------------------------------------------------

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float* __restrict__ z1, int64_t ld1, const float* __restrict__ z2, int64_t ld2,
     Params q, float tau, float alpha, int compat, int frac, int dot, float log_b3,
     float* __restrict__ loss_i, float* __restrict__ pos_i, float* __restrict__ lse_i, Means M, TrainOut T, FeatOut F, Gate G) {
-  if (G.words && G.words[lp2::W_STEP_M] > G.limit) {
+  if (G.words && lp2::guard_falls_back(G.words, G.limit)) {
     nsplit = G.nsplit_alt;
     if (blockIdx.x == 0 && threadIdx.x == 0) G.words[lp2::W_FALLBACKS] += 1.f;
   }
@@ -257,7 +257,7 @@ struct MeansJob { const float* blocksums; int nblocks; float inv_count; float* m
 __global__ __launch_bounds__(THREADS) void bwd_reduce_k(const float* __restrict__ part, int nsplit, int64_t rows,
                                                        int np, int n, float* __restrict__ out, int64_t ldo,
                                                        int accumulate, MeansJob mj, Gate G) {
-  if (G.words && G.words[lp2::W_STEP_M] > G.limit) nsplit = G.nsplit_alt;
+  if (G.words && lp2::guard_falls_back(G.words, G.limit)) nsplit = G.nsplit_alt;
   if ((int)blockIdx.x == mj.block) {        // training step: the forward's three means, off its critical path (see means_k)
     if (threadIdx.x < 64) {
       float v[3] = {0.f, 0.f, 0.f};
@@ -587,7 +587,7 @@ struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; floa
 // CLICA_LP_TRAIN_FAST (bits, default 7): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (A/B switches; Params::train),
 // 4 = p = 2 sweeps on the matrix cores (lp_mfma.hip; needs bits 1 and 2 semantics: pool contains the anchors)
 static int train_flags() { static int v = [] { const char* e = getenv("CLICA_LP_TRAIN_FAST"); return e ? atoi(e) : 7; }(); return v; }
-static bool train_mfma(const clica_lp_loss_desc* d) { return (train_flags() & 4) && lp2::applies(d->n, d->p, d->pow); }
+static bool train_mfma(const clica_lp_loss_desc* d) { return (train_flags() & 7) == 7 && lp2::applies(d->n, d->p, d->pow); }      // (its fallback is the fixed-maximum / folded-coefficient difference sweep)
 static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols, bool mfma) {
   TrainWs w; char* p = (char*)ws; size_t off = 256;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
@@ -664,10 +664,10 @@ extern "C" int clica_lp_loss_train_guard(const clica_lp_loss_desc* d, const void
   TrainWs w = carve_train(const_cast<void*>(workspace), make_plan(rows, cols, d->n, false), make_plan(rows, cols, d->n, true), rows, cols, true);
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_train_guard: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   hipStream_t st = as_stream(stream);
-  float words[4];
+  float words[16];
   if (hipMemcpyAsync(words, w.w2.spread, sizeof(words), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return launch_status("clica_lp_loss_train_guard");
-  out4[0] = words[lp2::W_RUN_M]; out4[1] = words[lp2::W_STEP_M]; out4[3] = words[lp2::W_FALLBACKS];
+  out4[0] = words[lp2::W_RUN_M]; out4[1] = words[lp2::W_M64]; out4[3] = words[lp2::W_FALLBACKS];      // (the low word of the tagged M holds the float)
   return CLICA_OK;
 }
 
@@ -695,10 +695,8 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   if (w.mfma) {      // p = 2: logits as one augmented inner product on the matrix cores (lp_mfma.hip); same partial format
     const float limit = lp2::spread_limit();
     lp2::launch_prep(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, q.kscale, st);       // also measures this call's spread M
-    lp2::launch_fwd(w.P2, w.w2, rows, part, limit, st);                                      // returns at once when M > limit ...
-    Params qv = q;
-    qv.gate = w.w2.spread + lp2::W_STEP_M; qv.gate_limit = limit;                           // ... and this one when M <= limit
-    launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, qv, part, nullptr, st);
+    // one launch: the matrix-core sweep, or -- decided by its workgroups from the guard words -- the difference sweep of plan PF
+    lp2::launch_fwd(w.P2, w.w2, rows, part, limit, PF, z1, ld1, pool, ldp, cols, q, st);
     nsplit_f = w.P2.nsplit;
     gate = Gate{w.w2.spread, limit, PF.nsplit};
   } else {
@@ -708,7 +706,7 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
   FeatOut feat;
   if (w.mfma && pool == z1 && cols == rows && ldp == ld1)      // one rank: see FeatOut; bwd_sym_train makes the same test
-    feat = FeatOut{(lp2::u32x4_t*)w.w2.pool_feat, w.w2.spread + lp2::W_ORIGIN, sqrtf(2.f * q.kscale), w.P2.pool_tiles};
+    feat = FeatOut{(lp2::u32x4_t*)w.w2.pool_feat, w.w2.spread + lp2::W_ORIGIN_USED, sqrtf(2.f * q.kscale), w.P2.pool_tiles};
   hipLaunchKernelGGL(fwd_finalize_k, dim3((unsigned)nfin), dim3(THREADS), 0, st,
                      (const float2*)part, nsplit_f, rows, z1, ld1, z2, ld2, q, d->tau, d->alpha,
                      d->compat ? 1 : 0, 0, 0, logf((float)cols), loss_i, pos_i, lse_i, M, TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, feat, gate);
@@ -747,10 +745,7 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   if (w.mfma) {      // the planes of the forward call are still in the workspace (same z1 / pool, as for the row statistics), and so is its spread
     const float limit = lp2::spread_limit();
     lp2::launch_bwd(w.P2, w.w2, z1, ld1, rows, pool, ldp, cols, d->n, PR.np, q.kscale, w.statL, w.statC, strL, strC, partR,
-                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1 && pool_lse == lse_i, limit, st);
-    Params qv = q;
-    qv.gate = w.w2.spread + lp2::W_STEP_M; qv.gate_limit = limit;
-    launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, qv, w.statL, w.statC, strL, strC, partR, st);
+                    /*feat_ready=*/pool == z1 && cols == rows && ldp == ld1 && pool_lse == lse_i, limit, PR, q, st);
     nsplit_r = w.P2.nsplit;
     gate = Gate{w.w2.spread, limit, PR.nsplit};
   } else {

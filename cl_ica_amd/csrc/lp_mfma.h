@@ -1,6 +1,7 @@
 // Squared-Euclidean pair sweeps of LpSimCLRLoss (p = 2, pow) on the bf16 matrix cores -- interface of lp_mfma.hip.
 #pragma once
 #include "common.h"
+#include "lp_kernels.h"
 
 namespace clica {
 namespace lp2 {
@@ -23,12 +24,28 @@ Plan make_plan(int64_t n_own, int64_t n_pool);
 bool applies(int n, float p, int pow);      // the shapes / settings this path covers (and CLICA_LP_MFMA != 0, or set_enabled)
 void set_enabled(int on);                   // process-wide override of CLICA_LP_MFMA: 1 / 0, negative = back to the environment's setting
 
-// `spread` = 64 device floats in front of the planes (zeroed with the workspace):
-//   [W_RUN_M] largest M any forward call has seen (diagnostic)          [W_MAXABS] this call's max |x'| (grid step of the hi pieces)
-//   [W_STEP_M] THIS call's M -- the device-side guard reads it          [W_FALLBACKS] number of forward calls that fell back (as a float)
-//   [W_ORIGIN .. +16) the origin rows are shifted by: the mean of the pool's first <= 64 rows (any point inside the data is valid;
-//   the centre keeps M = log2(e)/tau max |x - origin|^2 at about a quarter of what an arbitrary data row gives)
-constexpr int W_RUN_M = 0, W_MAXABS = 1, W_STEP_M = 2, W_FALLBACKS = 3, W_ORIGIN = 4;
+// `spread` = 64 device words (256 B, zeroed with the workspace) in front of the planes.  The planes of a call are built on a grid step
+// D and an origin that were MEASURED BY THE PREVIOUS CALL (round 5: the separate launch that measured them first -- 7 us, latency-bound --
+// is gone).  Any origin inside the data is valid and any D with max |x'| / D < 256 keeps the hi x hi product exact; every prep workgroup
+// checks the latter for its rows and a violation (the cloud grew across a power of two since the last call; the very first call) sends
+// THIS call to the difference sweeps through the guard below.  No locks, no resets between kernels of one call:
+//   [W_RUN_M]      float   largest M any call has seen (diagnostic; atomicMax on the bits)
+//   [W_M64, +1]    u64     (call id << 32) | bits of this call's M          -- tagged atomicMax: an older call's value can never win
+//   [W_V64, +1]    u64     (call id << 32) | 1 if a row violated the grid    -- written by EVERY prep workgroup (0 or 1), so the latest tag is this call's
+//   [W_CALL]       u32     call id, advanced by workgroup (0, 0) of the forward sweep (prep has finished; nobody else reads it afterwards)
+//   [W_FALLBACKS]  float   number of calls that fell back
+//   [W_MAXABS_CUR] float   max |x'| the current grid step derives from;  [W_MAXABS_NEXT]: accumulated by this call's prep for the next one
+//   [W_ORIGIN_CUR .. +16)  origin of this call's planes;  [W_ORIGIN_NEXT .. +16): mean of this call's first <= 64 pool rows;
+//   [W_ORIGIN_USED .. +16) copy of the origin this call's planes were built on: what the kernels BEHIND the forward sweep read (finalize's
+//                          feature planes, the backward sweep) -- the forward sweep's workgroup (0, 0) moves NEXT -> CUR meanwhile
+constexpr int W_RUN_M = 0, W_M64 = 2, W_V64 = 4, W_CALL = 6, W_FALLBACKS = 7, W_MAXABS_CUR = 8, W_MAXABS_NEXT = 9,
+              W_ORIGIN_CUR = 16, W_ORIGIN_NEXT = 32, W_ORIGIN_USED = 48;
+// what a gated kernel reads: {M64, V64} -> fall back when this call's M exceeds the limit or a row violated the grid
+__device__ __forceinline__ bool guard_falls_back(const float* words, float limit) {
+  const unsigned long long* w64 = reinterpret_cast<const unsigned long long*>(words);
+  const float m = __uint_as_float((unsigned)w64[W_M64 / 2]);
+  return m > limit || (unsigned)w64[W_V64 / 2] != 0u;
+}
 struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };
 
 // The guard.  The expansion's gradient product accumulates terms of size sqrt(M) in fp32, so its error grows ~ sqrt(M) (measured against
@@ -38,7 +55,7 @@ struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; siz
 // in the stream (and in a captured graph), the choice is made per call by the kernels themselves: no host round trip, valid under replay.
 float spread_limit();                       // CLICA_LP_MFMA_LIMIT (default kDefaultSpreadLimit) or set_spread_limit
 void set_spread_limit(float m);             // <= 0: back to the environment's / default value
-constexpr float kDefaultSpreadLimit = 512.f;
+constexpr float kDefaultSpreadLimit = 768.f;
 Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-provided workspace (256-byte aligned base)
 
 // x' = sqrt(2 log2(e) / tau) (x - origin): row planes of the anchors and of the pool (both sweeps read them).  Also keeps the running maximum
@@ -46,14 +63,16 @@ Ws carve(void* base, const Plan& P);       // plane buffers inside a caller-prov
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st);
 // part[split][row] = (0, sum_j 2^x_ij) -- the partial format of fwd_partial_k<ZMAX>
-void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, hipStream_t st);
+// (PV, own .. q: the difference sweep of the same call -- lp_kernels.h's plan and parameters -- which the launch runs instead when the guard says so)
+void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, const lp::Plan& PV, const float* own, int64_t ldo,
+                const float* pool, int64_t ldp, int64_t n_pool, const lp::Params& q, hipStream_t st);
 // part[split][row][np] = gradient partials of the symmetric sweep (format of bwd_pairs_k<.., 3, .., FOLD>): 2 sum_j 2^x_ij (u_i + u_j) (a_i - p_j),
 // u = C 2^-L from (ownL, ownC) / (poolL, poolC)
 // (writes the pool's feature planes first -- they carry the pool rows' u_j -- unless `feat_ready`: on one rank the forward's finalize
 // has written them, lp_mfma_dev.h)
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
                 int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, bool feat_ready,
-                float limit, hipStream_t st);
+                float limit, const lp::Plan& PV, const lp::Params& q, hipStream_t st);
 
 }  // namespace lp2
 }  // namespace clica

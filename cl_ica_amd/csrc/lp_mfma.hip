@@ -34,6 +34,7 @@
 // HBM-level splits of whole stages; partial formats are those of fwd_partial_k<ZMAX> / bwd_pairs_k<FOLD>, finalize / reduce are shared.
 #include "lp_mfma.h"
 #include "lp_mfma_dev.h"
+#include "lp_kernels.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -99,61 +100,51 @@ __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (
 // Nr = sum (hi r + r^2 / 2) in a second accumulator; the two are added on the vector ALU.  Measured: section "spread" of the tests.
 // Slots (K = 16 = n + 6, n <= 10): coordinates 0..n-1; pool rows: ones at n..n+2, own norms at n+3..n+5; anchors the other way round;
 // own norm slots: hi plane = the three pieces of -Nh, mid plane = the three pieces of -Nr; rows >= `rows` of the pool: -Nr = -1e30.
-__global__ __launch_bounds__(256) void maxabs_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, const float* __restrict__ Xa, int64_t lda,
-                                                int64_t rows_a, int n, float pre2, float* __restrict__ words) {
-  // origin = mean of the pool's first <= 64 rows, computed by every block the same way (fixed shuffle tree: deterministic and identical
-  // in all blocks); block 0 publishes it for the launches behind this one and opens the step's guard word
-  __shared__ float org[KSLOTS];
-  {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt = rows_p < 64 ? (int)rows_p : 64;
-    for (int k = wave; k < n; k += 4) {
-      float v = lane < cnt ? Xp[(int64_t)lane * ldp + k] : 0.f;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) org[k] = v / (float)cnt;
-    }
-  }
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if ((int)threadIdx.x < n) words[W_ORIGIN + threadIdx.x] = org[threadIdx.x];
-    if (threadIdx.x == 0) words[W_STEP_M] = 0.f;
-  }
-  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool pool = id < rows_p;
-  const int64_t j = pool ? id : id - rows_p;
-  float m = 0.f;
-  if (pool || j < rows_a) {
-    const float* row = pool ? Xp + j * ldp : Xa + j * lda;
-    for (int k = 0; k < n; ++k) m = fmaxf(m, fabsf(pre2 * (row[k] - org[k])));
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(words + W_MAXABS), __float_as_int(m));     // (non-negative floats order like ints)
-}
-
 __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
                                              const float* __restrict__ Xa, int64_t lda, int64_t rows_a, u32x4* __restrict__ RPa,
-                                             int n, const float* __restrict__ origin, float pre2, float* __restrict__ words) {
+                                             int n, float pre2, float* __restrict__ words) {
   // one launch for both operands: blocks [0, pool_blocks) the pool (role 0), the rest the anchors (role 1); two tiles per block
   const int role = (int)blockIdx.x >= pool_blocks ? 1 : 0;
+  // the grid of THIS call (measured by the previous one, lp_mfma.h) and, for the next call, the mean of the pool's first <= 64 rows --
+  // computed by every workgroup the same way (one wave, fixed shuffle tree: identical everywhere), so that each can measure ITS rows
+  // against the next origin
+  const unsigned call = reinterpret_cast<const unsigned*>(words)[W_CALL];
+  const float* __restrict__ origin = words + W_ORIGIN_CUR;
+  float onext = 0.f;                                   // lane k < n: coordinate k of the next origin
+  {
+    const int lane64 = threadIdx.x;
+    const int cnt = rows_p < 64 ? (int)rows_p : 64;
+    for (int k = 0; k < n; ++k) {
+      float v = lane64 < cnt ? Xp[(int64_t)lane64 * ldp + k] : 0.f;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane64 == k) onext = v / (float)cnt;
+    }
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < KSLOTS) {
+    words[W_ORIGIN_USED + threadIdx.x] = (int)threadIdx.x < n ? origin[threadIdx.x] : 0.f;      // (nobody reads USED before the next kernel)
+    words[W_ORIGIN_NEXT + threadIdx.x] = (int)threadIdx.x < n ? onext : 0.f;
+  }
   const float* __restrict__ X = role ? Xa : Xp;
   const int64_t ldx = role ? lda : ldp, rows = role ? rows_a : rows_p;
   u32x4* __restrict__ RP = role ? RPa : RPp;
   const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * 2 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
   // grid step: the power of two with max |x'| / D in [64, 128)
-  const unsigned xb = __float_as_uint(words[W_MAXABS]);
+  const unsigned xb = __float_as_uint(words[W_MAXABS_CUR] * 1.03125f);      // (a 3 % margin: a cloud that merely breathes does not cross the power of two)
   const int ex = (int)((xb >> 23) & 0xffu) - 7;      // biased exponent of max |x'|, minus 7: max / D in [128, 256), hi = 8-bit integers x D
   const float D = __uint_as_float((unsigned)(ex < 1 ? 1 : ex) << 23), invD = 1.f / D;
   const int64_t j = (int64_t)tile * ROWS + lane;
   const bool live = j < rows;
   unsigned hb[KSLOTS], mb[KSLOTS], lb[KSLOTS];
-  float nh = 0.f, nr = 0.f;
+  float nh = 0.f, nr = 0.f, amax = 0.f, amax_next = 0.f;
 #pragma unroll
   for (int k = 0; k < MAX_N; ++k) {
     const bool ok = live && k < n;
-    const float xr = pre2 * (X[ok ? j * ldx + k : 0] - origin[k < n ? k : 0]);
+    const float xv = X[ok ? j * ldx + k : 0];
+    const float xr = pre2 * (xv - origin[k < n ? k : 0]);
     const float x = ok ? xr : 0.f;
+    amax = fmaxf(amax, fabsf(x));
+    amax_next = fmaxf(amax_next, ok ? fabsf(pre2 * (xv - __shfl(onext, k, 64))) : 0.f);
     const float hi = __uint_as_float(__float_as_uint(rintf(x * invD) * D) & 0xffff0000u);      // a multiple of D with <= 8 significant bits
     const float r = x - hi;
     const unsigned mbits = __float_as_uint(r) & 0xffff0000u;
@@ -167,13 +158,20 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
     nr += fmaf(hi, r16, 0.5f * r16 * r16);
   }
   nh *= 0.5f;
-  {      // M of this call (the guard: anchors and pool rows both enter the expansion) and the largest M so far (diagnostic)
+  {      // M of this call (the guard: anchors and pool rows both enter the expansion), the grid check, the next call's max |x'|
     float m = live ? nh + nr : 0.f;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    for (int off = 32; off > 0; off >>= 1) {
+      m = fmaxf(m, __shfl_xor(m, off, 64)); amax = fmaxf(amax, __shfl_xor(amax, off, 64)); amax_next = fmaxf(amax_next, __shfl_xor(amax_next, off, 64));
+    }
     if (threadIdx.x == 0) {
-      atomicMax(reinterpret_cast<int*>(words + W_STEP_M), __float_as_int(fmaxf(m, 0.f)));
-      atomicMax(reinterpret_cast<int*>(words + W_RUN_M), __float_as_int(fmaxf(m, 0.f)));
+      const unsigned long long tag = (unsigned long long)call << 32;
+      unsigned long long* w64 = reinterpret_cast<unsigned long long*>(words);
+      const bool viol = !(amax * invD < 256.f) || !(m <= 3.0e38f);        // hi pieces beyond 8 bits (or non-finite rows): the expansion is not exact here
+      atomicMax(w64 + W_M64 / 2, tag | (unsigned long long)__float_as_uint(fminf(fmaxf(m, 0.f), 3.0e38f)));
+      atomicMax(w64 + W_V64 / 2, tag | (viol ? 1ull : 0ull));
+      if (!viol) atomicMax(reinterpret_cast<int*>(words + W_RUN_M), __float_as_int(fminf(fmaxf(m, 0.f), 3.0e38f)));      // (a call without a grid measures M against a stale origin)
+      atomicMax(reinterpret_cast<int*>(words + W_MAXABS_NEXT), __float_as_int(fminf(amax_next, 3.0e38f)));
     }
   }
   unsigned nhp[3], nrp[3];
@@ -227,25 +225,46 @@ __global__ __launch_bounds__(128) void prep_feat_k(const float* __restrict__ X, 
 // Infinity Cache (~2 us; a workgroup keeps one stage in flight, so the sweep ran at 14 B/clk/CU of staging -- measured with the
 // arithmetic ablated: 65 of the backward's 150 us).  Remapped, XCD x owns the logical ids [x N / 8, (x + 1) N / 8): all anchor
 // groups of a FEW splits, whose chunks (432 KB each) stay in that XCD's L2 after the first workgroup touched them.
-__device__ __forceinline__ void xcd_tile(int& bx, int& by) {
-  const unsigned gx = gridDim.x, n = gx * gridDim.y, id = blockIdx.y * gx + blockIdx.x;
+__device__ __forceinline__ void xcd_tile(const unsigned id, const unsigned gx, const unsigned gy, int& bx, int& by) {
+  const unsigned n = gx * gy;
   const unsigned m = n & ~7u;                   // ids beyond the last multiple of 8 keep their place
   const unsigned logical = id < m ? (id & 7u) * (m >> 3) + (id >> 3) : id;
   by = (int)(logical / gx); bx = (int)(logical - (unsigned)by * gx);
 }
 
 // ---- forward: sum_j 2^x_ij per anchor and split -------------------------------------------------------------------------------
-template <int T>
+// The guard's fallback rides in the SAME launch (round 5; as a launch of its own behind this one it cost ~5 us per sweep even when
+// it had nothing to do): a 1-D grid of max(matrix-core workgroups, difference-sweep workgroups); every workgroup reads the guard
+// words and runs one sweep or the other.  The difference sweep is lp_kernels.h's fwd_partial_k / bwd_pairs_k body, instantiated
+// here for the p = 2 training variants (fixed maximum / folded coefficient) of the three padded widths n <= 10 takes.
+struct ValuSweep {
+  const float* own; int64_t ldo, n_own; const float* str; int64_t lds, n_str; lp::Params q; int chunk, gx, gy;
+  const float* ownL; const float* ownC; const float* strL; const float* strC;      // backward only
+};
+template <int T, int NP, int NQ>
 __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RPa, const u32x4* __restrict__ RPp, int64_t n_own,
-                                                    float2* __restrict__ part, int chunk_tiles, float* __restrict__ words, float limit) {
+                                                    float2* __restrict__ part, int chunk_tiles, float* __restrict__ words, float limit,
+                                                    const unsigned mgx, const unsigned mgy, const ValuSweep v) {
   constexpr int SV = STAGE_TILES * ROWVEC, PER = SV / THREADS;       // 768 vectors per stage, 3 per thread
   static_assert(SV % THREADS == 0, "stage copy");
   __shared__ u32x4 stage[2][SV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {      // the planes are written: hand the next call its grid (lp_mfma.h)
+    if (threadIdx.x < KSLOTS) words[W_ORIGIN_CUR + threadIdx.x] = words[W_ORIGIN_NEXT + threadIdx.x];
+    if (threadIdx.x == 0) {
+      words[W_MAXABS_CUR] = words[W_MAXABS_NEXT]; words[W_MAXABS_NEXT] = 0.f;
+      reinterpret_cast<unsigned*>(words)[W_CALL] += 1u;
+    }
+  }
+  if (guard_falls_back(words, limit)) {            // the guard (lp_mfma.h): this call runs on the coordinate differences
+    if (blockIdx.x < (unsigned)(v.gx * v.gy))
+      lp::fwd_partial_body<NP, 2, lp::owners_fwd(NP), false, false, NQ, true>(v.own, v.ldo, v.n_own, v.str, v.lds, v.n_str, v.q, part, nullptr, v.chunk,
+                                                                             (int)(blockIdx.x % (unsigned)v.gx), (int)(blockIdx.x / (unsigned)v.gx));
+    return;
+  }
+  if (blockIdx.x >= mgx * mgy) return;
   int bx, by;
-  xcd_tile(bx, by);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) words[W_MAXABS] = 0.f;      // the planes are written: next call's maxabs_k starts from 0
-  if (words[W_STEP_M] > limit) return;      // the guard (lp_mfma.h): this call's spread is beyond what the expansion holds 1e-5 at -- the difference sweep behind this launch runs instead
+  xcd_tile(blockIdx.x, mgx, mgy, bx, by);
   const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
   u32x4 b[T][3];
 #pragma unroll
@@ -314,13 +333,20 @@ __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RP
 }
 
 // ---- symmetric backward: (2 / s) (a'_i W_i - T_i) per anchor and split --------------------------------------------------------
-template <int T>
+template <int T, int NP, int NQ>
 __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RPa, const u32x4* __restrict__ RPp, const u32x4* __restrict__ FPp,
                                                     const float* __restrict__ own, int64_t ldo, int64_t n_own,
                                                     const float* __restrict__ origin, int64_t n_pool, int n, int np, float pre2,
                                                     const float* __restrict__ ownL, const float* __restrict__ ownC,
-                                                    float* __restrict__ part, int chunk_tiles, const float* __restrict__ words, float limit) {
-  if (words[W_STEP_M] > limit) return;      // the guard, as in fwd_k
+                                                    float* __restrict__ part, int chunk_tiles, const float* __restrict__ words, float limit,
+                                                    const unsigned mgx, const unsigned mgy, const ValuSweep v) {
+  if (guard_falls_back(words, limit)) {            // the guard, as in fwd_k
+    if (blockIdx.x < (unsigned)(v.gx * v.gy))
+      lp::bwd_pairs_body<NP, 2, lp::owners_bwd(NP), 3, false, NQ, true>(v.own, v.ldo, v.n_own, v.str, v.lds, v.n_str, v.q, v.ownL, v.ownC, v.strL, v.strC,
+                                                                       part, v.chunk, (int)(blockIdx.x % (unsigned)v.gx), (int)(blockIdx.x / (unsigned)v.gx));
+    return;
+  }
+  if (blockIdx.x >= mgx * mgy) return;
   constexpr int RV = STAGE_B * ROWVEC, FV = STAGE_B * FEATVEC, SV = RV + FV, PER = (SV + THREADS - 1) / THREADS;      // 384 + 768 vectors
   constexpr int NB = STAGE_B * T;                                                                    // blocks per stage
   static_assert(RV % 64 == 0 && SV % 64 == 0, "stage copy: whole waves on either side of the row / feature boundary");
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
   __shared__ u32x4 stage[2][LV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   int bx, by;
-  xcd_tile(bx, by);
+  xcd_tile(blockIdx.x, mgx, mgy, bx, by);
   const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
   u32x4 b[T][3];
   float ui[T];
@@ -579,32 +605,48 @@ Ws carve(void* base, const Plan& P) {
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
-  hipLaunchKernelGGL(maxabs_k, dim3((unsigned)ceil_div(n_pool + n_own, 256)), dim3(256), 0, st, pool, ldp, n_pool, own, ldo, n_own, n, pre2, w.spread);
   hipLaunchKernelGGL(prep_k, dim3((unsigned)((P.pool_tiles + P.own_tiles) / 2)), dim3(64), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows,
-                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, (const float*)(w.spread + W_ORIGIN), pre2, w.spread);
+                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pre2, w.spread);
 }
 
-void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, hipStream_t st) {
-  dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
-  if (P.T == 1) hipLaunchKernelGGL(fwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread, limit);
-  else hipLaunchKernelGGL(fwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, P.chunk_tiles, w.spread, limit);
+template <int T>
+static void launch_fwd_T(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, const ValuSweep& v, hipStream_t st) {
+  const unsigned mg = (unsigned)(P.groups * P.nsplit), vg = (unsigned)(v.gx * v.gy);
+  dim3 grid(mg > vg ? mg : vg), block(THREADS);
+#define LP2_FWD(NPV, NQV) hipLaunchKernelGGL((fwd_k<T, NPV, NQV>), grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, n_own, part, \
+                                             P.chunk_tiles, w.spread, limit, (unsigned)P.groups, (unsigned)P.nsplit, v)
+  if (v.q.n <= 4) LP2_FWD(4, 2); else if (v.q.n <= 8) LP2_FWD(8, 4); else LP2_FWD(12, 5);
+#undef LP2_FWD
+}
+void launch_fwd(const Plan& P, const Ws& w, int64_t n_own, float2* part, float limit, const lp::Plan& PV, const float* own, int64_t ldo,
+                const float* pool, int64_t ldp, int64_t n_pool, const lp::Params& q, hipStream_t st) {
+  ValuSweep v{own, ldo, n_own, pool, ldp, n_pool, q, PV.chunk, (int)PV.tiles, PV.nsplit, nullptr, nullptr, nullptr, nullptr};
+  if (P.T == 1) launch_fwd_T<1>(P, w, n_own, part, limit, v, st); else launch_fwd_T<2>(P, w, n_own, part, limit, v, st);
 }
 
+template <int T>
+static void launch_bwd_T(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, int64_t n_pool, int n, int np, float pre2,
+                         const float* ownL, const float* ownC, float* part, float limit, const ValuSweep& v, hipStream_t st) {
+  const unsigned mg = (unsigned)(P.groups * P.nsplit), vg = (unsigned)(v.gx * v.gy);
+  dim3 grid(mg > vg ? mg : vg), block(THREADS);
+  const float* origin = w.spread + W_ORIGIN_USED;
+#define LP2_BWD(NPV, NQV) hipLaunchKernelGGL((bwd_k<T, NPV, NQV>), grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, \
+                                             (const u32x4*)w.pool_feat, own, ldo, n_own, origin, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles, \
+                                             (const float*)w.spread, limit, (unsigned)P.groups, (unsigned)P.nsplit, v)
+  if (n <= 4) LP2_BWD(4, 2); else if (n <= 8) LP2_BWD(8, 4); else LP2_BWD(12, 5);
+#undef LP2_BWD
+}
 void launch_bwd(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool, int n,
                 int np, float kscale, const float* ownL, const float* ownC, const float* poolL, const float* poolC, float* part, bool feat_ready,
-                float limit, hipStream_t st) {
+                float limit, const lp::Plan& PV, const lp::Params& q, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
-  const float* origin = w.spread + W_ORIGIN;
+  const float* origin = w.spread + W_ORIGIN_USED;
   if (!feat_ready)
     hipLaunchKernelGGL(prep_feat_k, dim3((unsigned)P.pool_tiles), dim3(128), 0, st, pool, ldp, n_pool, n, origin, pre2, poolL, poolC,
                        (u32x4*)w.pool_feat);
-  dim3 grid((unsigned)P.groups, (unsigned)P.nsplit), block(THREADS);
-  if (P.T == 1)
-    hipLaunchKernelGGL(bwd_k<1>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,
-                       n_own, origin, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles, (const float*)w.spread, limit);
-  else
-    hipLaunchKernelGGL(bwd_k<2>, grid, block, 0, st, (const u32x4*)w.own_rows, (const u32x4*)w.pool_rows, (const u32x4*)w.pool_feat, own, ldo,
-                       n_own, origin, n_pool, n, np, pre2, ownL, ownC, part, P.chunk_tiles, (const float*)w.spread, limit);
+  ValuSweep v{own, ldo, n_own, pool, ldp, n_pool, q, PV.chunk, (int)PV.tiles, PV.nsplit, ownL, ownC, poolL, poolC};
+  if (P.T == 1) launch_bwd_T<1>(P, w, own, ldo, n_own, n_pool, n, np, pre2, ownL, ownC, part, limit, v, st);
+  else launch_bwd_T<2>(P, w, own, ldo, n_own, n_pool, n, np, pre2, ownL, ownC, part, limit, v, st);
 }
 
 }  // namespace lp2

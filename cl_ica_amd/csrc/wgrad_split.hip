@@ -23,6 +23,7 @@
 // tiny dimension (the n-wide first / last layer) keep the fp32 VALU kernel (wgrad_tiny_k) on fp32 operands.
 #include "common.h"
 #include "planes.h"
+#include "split16.h"
 #include "wgrad_shared.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -796,7 +797,7 @@ extern "C" int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers
 }
 
 // the layout of the f16x2 state's scale arrays (fused_mlp.hip: Split16State) as far as this file needs it
-struct Split16Scales { unsigned counts[27]; float sA[9], sD[9], sW[9], sWC[9]; unsigned flags, updates, pad[2]; };
+typedef s16::Split16State Split16Scales;
 
 static int mlp_wgrad_split_impl(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
                                 const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,

@@ -781,7 +781,9 @@ class ContrastiveTrainer:
         # and restore parameters, optimizer state and the device step / RNG counter around them
         if self.split_f16 and not self._s16_calibrated:
             self.calibrate_scales(True)
-        state = (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev) + ((self.s16.buf,) if self.split_f16 else ())
+        # (also what makes a step depend on its predecessors besides the parameters: the f16x2 scales, and the loss workspace -- the
+        #  matrix-core sweeps build their planes on the grid the previous call measured, csrc/lp_mfma.h)
+        state = (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.loss_ws) + ((self.s16.buf,) if self.split_f16 else ())
         snap = [t.clone() for t in state]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))

@@ -217,11 +217,12 @@ def _main(argv=None):
                     f"Lin. Disentanglement: {lin:.4f} \t", f"Perm. Disentanglement: {perm:.4f}")
                 if args.sphere_norm:
                     log(f"r: {f[-1].r}")
-                if fused and not getattr(trainer, "_guard_noted", False) and trainer.loss_guard()["fallback_steps"] > 0:
-                    trainer._guard_noted = True      # (nothing to do: the library's device-side guard switches per step, include/clica.h)
-                    g = trainer.loss_guard()
-                    log(f"note: the embeddings spread over M = {g['last_spread']:.0f} temperature units (> {g['limit']:.0f}): the p = 2 loss "
-                        "runs on the coordinate-difference sweeps for such steps")
+                if fused and not getattr(trainer, "_guard_noted", False):
+                    gs = trainer.loss_guard()          # (nothing to do: the library's device-side guard switches per step, include/clica.h)
+                    if gs["limit"] > 0 and gs["last_spread"] > gs["limit"]:
+                        trainer._guard_noted = True
+                        log(f"note: the embeddings spread over M = {gs['last_spread']:.0f} temperature units (> {gs['limit']:.0f}): the p = 2 "
+                            "loss runs on the coordinate-difference sweeps for such steps")
             lin_scores.append(lin); perm_scores.append(perm)
             global_step += 1
         if pending:

@@ -141,7 +141,7 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * it has terms of size M = log2(e)/tau max_i |z_i - origin|^2 (origin = the mean of the pool's first 64 rows).  The large part of every
  * term of the logit is computed EXACTLY (hi pieces on a grid common to the launch, accumulated apart) and the loss holds 1e-5 at every
  * spread measured (2e-6 at M = 15 000); the gradient's second product accumulates terms of size sqrt(M) in fp32 and its error grows
- * ~ sqrt(M).  THE GUARD (round 5): every fwd_train call measures its own M on the device; when it exceeds the spread limit (default 512:
+ * ~ sqrt(M).  THE GUARD (round 5): every fwd_train call measures its own M on the device; when it exceeds the spread limit (default 768:
  * gradient error < 1e-5 against the fp64 oracle with margin, tests/test_gpu_loss.py ..._spread_limit) the matrix-core sweeps of THAT call
  * return at once and the coordinate-difference sweeps (no such dependence), launched behind them with the opposite condition, do the
  * work.  The decision is made by the kernels per call -- no host round trip, valid inside a replayed graph.

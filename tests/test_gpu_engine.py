@@ -341,7 +341,11 @@ def test_loss_matrix_core_switch_and_spread():
         y = tr.y[:B]
         want = 1.4426950408889634 * float(((y - y[:64].mean(0)) ** 2).sum(1).max())       # origin = mean of the pool's first 64 rows
         assert abs(tr.loss_spread() - want) <= 2e-3 * want + 1e-6
-        assert tr.loss_guard()["fallback_steps"] == 0 and tr.loss_guard()["last_spread"] < tr.loss_guard()["limit"]
+        # (the first loss call of a workspace measures the grid of the planes and falls back itself, csrc/lp_mfma.h; a repeated step must not)
+        fb = tr.loss_guard()["fallback_steps"]
+        tr.step_injected(z1, z2)
+        assert tr.loss_guard()["fallback_steps"] == fb and tr.loss_guard()["last_spread"] < tr.loss_guard()["limit"]
+        out_m = tr.loss_out[3 * B:].clone(); g_m = tr.grad_arena.clone()
         tr.capture()
         tr.set_loss_matrix_cores(False)
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 0
@@ -383,8 +387,10 @@ def test_matrix_core_guard_falls_back_inside_graph_replay():
     tr.capture()
     graph = tr.graph
     tr.step(); torch.cuda.synchronize()
+    fb0 = tr.loss_guard()["fallback_steps"]
+    tr.step(); torch.cuda.synchronize()
     g0 = tr.loss_guard()
-    assert g0["fallback_steps"] == 0 and 0 < g0["last_spread"] <= g0["limit"], g0
+    assert g0["fallback_steps"] == fb0 and 0 < g0["last_spread"] <= g0["limit"], g0      # a settled replay runs on the matrix cores
     _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay inside the limit (M = {g0['last_spread']:.0f})")
     scale = (4.0 * g0["limit"] / g0["last_spread"]) ** 0.5         # M grows with the square of the embedding scale: 4 x the limit (not so far that rows saturate)
     with torch.no_grad():
@@ -393,7 +399,7 @@ def test_matrix_core_guard_falls_back_inside_graph_replay():
     tr.step(); torch.cuda.synchronize()
     g1 = tr.loss_guard()
     assert tr.graph is graph, "no re-capture"
-    assert g1["fallback_steps"] >= 1 and g1["last_spread"] > 2 * g1["limit"], g1      # (the calibration passes of the f16x2 arithmetic are loss calls too)
+    assert g1["fallback_steps"] > g0["fallback_steps"] and g1["last_spread"] > 2 * g1["limit"], g1      # (the calibration passes of the f16x2 arithmetic are loss calls too)
     _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay beyond the limit (M = {g1['last_spread']:.0f}, difference sweeps)")
     tr.step(); torch.cuda.synchronize()
     fb = tr.loss_guard()["fallback_steps"]
@@ -401,7 +407,9 @@ def test_matrix_core_guard_falls_back_inside_graph_replay():
     with torch.no_grad():
         last.weight.div_(scale); last.bias.div_(scale)
     tr.calibrate_scales()
-    tr.step(); torch.cuda.synchronize()
+    tr.step(); torch.cuda.synchronize()      # (the cloud shrank 60 x: this replay re-measures the grid ...)
+    fb = tr.loss_guard()["fallback_steps"]
+    tr.step(); torch.cuda.synchronize()      # (... and this one is back on the matrix cores)
     g2 = tr.loss_guard()
     assert g2["fallback_steps"] == fb and g2["last_spread"] <= g2["limit"], g2
     _oracle_check_of_loss_state(tr, "matrix_core_guard_in_graph_replay", f"replay back inside the limit (M = {g2['last_spread']:.0f})")

@@ -470,7 +470,9 @@ def test_simclr_mfma_matches_pair_sweep(normalize):
 
 
 def _train_pair(z1, z2, pool, pool_lse, n, p, tau, alpha, compat=1):
-    """clica_lp_loss_fwd_train + clica_lp_loss_bwd_sym_train on device tensors; returns (out [3B+3], dz [2B, n], path)."""
+    """clica_lp_loss_fwd_train + clica_lp_loss_bwd_sym_train on device tensors; returns (out [3B+3], dz [2B, n], path).
+    The matrix-core sweeps build their planes on the grid the PREVIOUS call measured (csrc/lp_mfma.h), so a fresh workspace gets one
+    un-checked forward call first; `path` is 1 only if the checked forward then really ran on the matrix cores (no fallback counted)."""
     import ctypes as C
     from cl_ica_amd import _lib
     lib = _lib.load()
@@ -482,9 +484,26 @@ def _train_pair(z1, z2, pool, pool_lse, n, p, tau, alpha, compat=1):
     ws = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
     o = torch.empty(3 * B + 3, device="cuda"); dz = torch.full((2 * B, n), float("nan"), device="cuda")
     st = _lib.stream_ptr()
-    _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), z1.data_ptr(), z1.stride(0), z2.data_ptr(), z2.stride(0), pool.data_ptr(), pool.stride(0),
-                                           o[:B].data_ptr(), o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(),
-                                           dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
+
+    def fwd():
+        _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), z1.data_ptr(), z1.stride(0), z2.data_ptr(), z2.stride(0), pool.data_ptr(), pool.stride(0),
+                                               o[:B].data_ptr(), o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(),
+                                               dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
+
+    def fallbacks():
+        v = (C.c_float * 4)()
+        _lib.check(lib.clica_lp_loss_train_guard(C.byref(d), ws.data_ptr(), ws.numel(), v, st), "guard")
+        return int(v[3]), float(v[1]), float(v[2])
+
+    fwd()                                  # measures the grid (and falls back itself: there was none)
+    before = fallbacks()[0]
+    dz.fill_(float("nan"))
+    fwd()
+    after, m_step, limit = fallbacks()
+    if path.value == 1 and m_step <= limit and after != before:
+        path.value = -1                    # should have run on the matrix cores and did not
+    elif path.value == 1 and m_step > limit:
+        path.value = 2                     # beyond the guard's limit: the difference sweeps, by design
     lse = o[2 * B:3 * B] if pool_lse is None else pool_lse
     if pool_lse is not None and pool_lse.numel() == 0:
         return o, dz, path.value          # forward only
@@ -576,6 +595,10 @@ def test_p2_train_sweeps_on_matrix_cores_spread_limit():
         zd, ztd = dev(z), dev(zt)
         o = torch.empty(3 * B + 3, device="cuda"); dz = torch.empty(2 * B, n, device="cuda")
         st = _lib.stream_ptr()
+        # (the planes are built on the grid the previous call measured: one un-checked forward on THIS cloud first)
+        _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), zd.data_ptr(), n, ztd.data_ptr(), n, zd.data_ptr(), n, o[:B].data_ptr(), o[B:2 * B].data_ptr(),
+                                               o[2 * B:3 * B].data_ptr(), dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train (grid)")
+        run.before = _guard_state(d, ws)["fallback_steps"]
         _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), zd.data_ptr(), n, ztd.data_ptr(), n, zd.data_ptr(), n, o[:B].data_ptr(), o[B:2 * B].data_ptr(),
                                                o[2 * B:3 * B].data_ptr(), dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
         _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(d), zd.data_ptr(), n, zd.data_ptr(), n, o[2 * B:3 * B].data_ptr(), o[2 * B:3 * B].data_ptr(),
@@ -594,7 +617,7 @@ def test_p2_train_sweeps_on_matrix_cores_spread_limit():
         st = _guard_state(d, ws)
         assert abs(st["last_spread"] - M) < 2e-3 * M, (st, M)
         expected_fallbacks += int(st["last_spread"] > limit)
-        assert st["fallback_steps"] == expected_fallbacks, (edge, st, expected_fallbacks)
+        assert st["fallback_steps"] - run.before == int(st["last_spread"] > limit), (edge, st, run.before)      # the checked call fell back iff M > limit
         path = "difference sweeps (guard)" if st["last_spread"] > limit else "matrix cores"
         PARITY.check("p2_train_guarded", f"box edge {edge} (M = {M:.0f}, {path})", "loss_i", o[:B], li)
         PARITY.check("p2_train_guarded", f"box edge {edge} (M = {M:.0f}, {path})", "dz1", dz[:B], g1)
@@ -608,13 +631,13 @@ def test_p2_train_sweeps_on_matrix_cores_spread_limit():
         for edge in edges:
             z, zt, li, g1, M = refs[edge]
             o, dz = run(z, zt, ws2)
+            assert _guard_state(d, ws2)["fallback_steps"] == run.before, "guard lifted: the checked call must run on the matrix cores"
             curve[round(M)] = (rel_err(o[:B], li), rel_err(dz[:B], g1))
             inside = M <= limit
             fam = "p2_train_matrix_cores" if inside else "p2_train_matrix_cores_guard_lifted_characterisation"
             note = None if inside else "guard lifted (limit 1e30): a spread the default path hands to the difference sweeps; logged to document the limit"
             PARITY.check(fam, f"box edge {edge} (M = {M:.0f})", "loss_i", o[:B], li)
             PARITY.check(fam, f"box edge {edge} (M = {M:.0f})", "dz1", dz[:B], g1, tol=1e-5 if inside else 1e-4, note=note)
-        assert _guard_state(d, ws2)["fallback_steps"] == 0
         print("matrix-core sweep error by spread M (loss_i, dz1), guard lifted:", curve, "limit", limit)
         import json, os
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")

@@ -9,9 +9,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PARTS=${PARTS:-"head c3"}
 if [[ "$PARTS" == *head* ]]; then
-CMD="python $ROOT/bench.py --steps 100 --warmup 10 --windows 1 --no-cpu-baseline --no-native-leg --no-dropin --no-secondary --no-traffic"
+CMD="python $ROOT/bench.py --steps 100 --warmup 10 --windows 1 --no-cpu-baseline --no-native-leg --no-dropin --no-secondary --no-traffic --no-dry-leg"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
-CMD2="python $ROOT/bench.py --steps 10 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-native-leg --no-dropin --no-secondary --no-traffic"
+CMD2="python $ROOT/bench.py --steps 10 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-native-leg --no-dropin --no-secondary --no-traffic --no-dry-leg"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 -d $OUT/pmc_sq -o p --output-format csv -- $CMD2 > /dev/null 2> $OUT/pmc_sq.err
@@ -26,9 +26,9 @@ rm -f $OUT/trace_native/*agent_info.csv $OUT/trace_native/*kernel_trace.csv
 fi
 if [[ "$PARTS" == *c3* ]]; then
 # BASELINE config 3 on one rank (n = 40, sphere, p = 1: the per-layer fp32-MFMA kernels): kernel trace + HBM-side traffic
-C3="python $ROOT/bench.py --n 40 --space-type sphere --p 1 --steps 20 --warmup 5 --windows 1 --no-cpu-baseline --no-native-leg --no-dropin --no-secondary --no-traffic"
+C3="python $ROOT/bench.py --n 40 --space-type sphere --p 1 --steps 20 --warmup 5 --windows 1 --no-cpu-baseline --no-native-leg --no-dropin --no-secondary --no-traffic --no-dry-leg"
 rocprofv3 --kernel-trace --stats -d $OUT/trace_c3 -o t --output-format csv -- $C3 > $OUT/bench_c3_under_rocprof.json 2> $OUT/trace_c3.err
-C3B="python $ROOT/bench.py --n 40 --space-type sphere --p 1 --steps 4 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-native-leg --no-dropin --no-secondary --no-traffic"
+C3B="python $ROOT/bench.py --n 40 --space-type sphere --p 1 --steps 4 --warmup 2 --windows 1 --no-cpu-baseline --no-roofline --no-native-leg --no-dropin --no-secondary --no-traffic --no-dry-leg"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_c3_fetch -o p --output-format csv -- $C3B > /dev/null 2> $OUT/pmc_c3_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_c3_write -o p --output-format csv -- $C3B > /dev/null 2> $OUT/pmc_c3_write.err
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_c3_sq -o p --output-format csv -- $C3B > /dev/null 2> $OUT/pmc_c3_sq.err
