@@ -242,8 +242,14 @@ class _ConvStackFn(torch.autograd.Function):
             _gather(dwg_all, m["unpack"], out)           # the five weight gradients back in Conv2d.weight layout, one launch
             for l in range(5):
                 grads[2 * l] = out[l]
+        dx = None
+        if ctx.needs_input_grad[0]:      # d loss / d image (never in a training step: the encoder's input is data)
+            dx = torch.empty((images, nc, _IMAGE, _IMAGE), dtype=torch.float32, device=dev)
+            w1 = ws_[0].detach().contiguous()
+            check(lib.clica_conv_k4s2_dgrad_input(buf.dO[0].data_ptr(), w1.data_ptr(), images, nc, STAGES[0][0], _IMAGE, _IMAGE, dx.data_ptr(), st),
+                  "clica_conv_k4s2_dgrad_input")
         _give(buf, dev)
-        return (None, None, *grads)
+        return (dx, None, *grads)
 
 
 def conv_stack(x: torch.Tensor, convs) -> torch.Tensor:
@@ -252,10 +258,8 @@ def conv_stack(x: torch.Tensor, convs) -> torch.Tensor:
         raise ValueError(f"conv_stack: input must be (images, nc, {_IMAGE}, {_IMAGE}), got {tuple(x.shape)}")
     if x.dtype != torch.float32:
         raise TypeError(f"conv_stack: float32 input expected, got {x.dtype}")
-    if x.requires_grad and torch.is_grad_enabled():
-        # the first stage has no data-gradient kernel (the encoder's input is data); returning None for it silently would be wrong
-        raise NotImplementedError("conv_stack: gradients with respect to the input images are not provided (BetaVAE_H falls back to nn.Conv2d "
-                                  "for such inputs)")
+    if x.requires_grad and torch.is_grad_enabled() and x.shape[1] > 4:
+        raise NotImplementedError("conv_stack: the input-image gradient kernel covers nc <= 4 channels")
     params = []
     for m in convs:
         if m.bias is None:
@@ -263,5 +267,5 @@ def conv_stack(x: torch.Tensor, convs) -> torch.Tensor:
         params += [m.weight, m.bias]
     # `keep`: a backward pass may follow (forward() itself always runs with grad mode off, so it cannot tell); without one the
     # buffer set goes straight back to the pool
-    keep = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    keep = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
     return _ConvStackFn.apply(x, keep, *params)

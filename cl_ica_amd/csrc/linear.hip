@@ -2018,6 +2018,63 @@ extern "C" int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patch
   return launch_status("clica_conv_k4s2_wgrad_patches(reduce)");
 }
 
+// ---- data gradient of the FIRST stage: d loss / d image (kitti_masks/model.py:41-56 is plain nn.Conv2d, differentiable w.r.t. its input) ----
+// The training step never needs it (the encoder's input is data); a caller that does differentiate through the images (saliency, an
+// adversarial probe) got nn.Conv2d / MIOpen until round 5.  dX[img][c][y][x] = sum over the <= 2 x 2 output pixels whose 4 x 4 / stride-2 /
+// pad-1 window covers (y, x) of dO[pixel][co] W[co][c][ky][kx]: one thread per input pixel, the (Cout x C x 16) weights in LDS, the four
+// dO rows it needs (Cout floats each) read as float4s -- neighbouring threads share them through L1 / L2.  HBM-bound: dO read once
+// (images x ho x wo x Cout x 4 B), dX written once.
+namespace clica {
+namespace convin {
+constexpr int MAXW = 32 * 4 * 16;      // Cout x C x 16 floats of weights in LDS (Cout = 32, C <= 4)
+__global__ __launch_bounds__(256) void dgrad_input_k(const float* __restrict__ dO, const float* __restrict__ Wc, int64_t images, int C, int Cout,
+                                                    int H, int Wd, float* __restrict__ dX) {
+  __shared__ float w[MAXW];
+  for (int i = threadIdx.x; i < Cout * C * 16; i += 256) w[i] = Wc[i];
+  __syncthreads();
+  const int ho = H / 2, wo = Wd / 2;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= images * H * Wd) return;
+  const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H);
+  const int64_t img = pix / ((int64_t)Wd * H);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int oy = ((y + 1) >> 1) - a, ky = ((y + 1) & 1) + 2 * a;      // 2 oy + ky - 1 = y
+    if (oy < 0 || oy >= ho) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ox = ((x + 1) >> 1) - b, kx = ((x + 1) & 1) + 2 * b;
+      if (ox < 0 || ox >= wo) continue;
+      const float4* row = reinterpret_cast<const float4*>(dO + ((img * ho + oy) * wo + ox) * Cout);
+      for (int c4 = 0; c4 < Cout / 4; ++c4) {
+        const float4 g = row[c4];
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float* wr = w + ((c4 * 4 + e) * C) * 16 + ky * 4 + kx;
+          for (int c = 0; c < C; ++c) acc[c] = fmaf(gv[e], wr[c * 16], acc[c]);
+        }
+      }
+    }
+  }
+  for (int c = 0; c < C; ++c) dX[((img * C + c) * H + y) * Wd + x] = acc[c];
+}
+}  // namespace convin
+}  // namespace clica
+
+extern "C" int clica_conv_k4s2_dgrad_input(const float* dO, const float* W, int64_t images, int32_t C, int32_t Cout, int32_t H, int32_t Wd,
+                                           float* dX, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dO && W && dX && images > 0, "clica_conv_k4s2_dgrad_input: NULL pointer / empty batch");
+  CLICA_CHECK_ARG(C >= 1 && C <= 4 && Cout >= 4 && Cout % 4 == 0 && Cout * C * 16 <= convin::MAXW && H >= 2 && Wd >= 2 && H % 2 == 0 && Wd % 2 == 0,
+                  "clica_conv_k4s2_dgrad_input: unsupported shape (C = %d <= 4, Cout = %d with Cout * C <= 128, even H x W = %d x %d)", C, Cout, H, Wd);
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(dO) & 15) == 0, "clica_conv_k4s2_dgrad_input: dO must be 16-byte aligned");
+  const int64_t n = images * H * Wd;
+  hipLaunchKernelGGL(convin::dgrad_input_k, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, as_stream(stream), dO, W, images, (int)C, (int)Cout,
+                     (int)H, (int)Wd, dX);
+  return launch_status("clica_conv_k4s2_dgrad_input");
+}
+
 extern "C" int clica_conv_gather(int32_t n, const float* const* src, const int32_t* const* map, float* const* dst, const int32_t* count,
                                  int32_t accumulate, clica_stream_t stream) {
   CLICA_CHECK_ARG(n >= 1 && n <= MAXGATHER && src && map && dst && count, "clica_conv_gather: 1..%d segments", MAXGATHER);

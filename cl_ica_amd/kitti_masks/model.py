@@ -67,10 +67,9 @@ class BetaVAE_H(nn.Module):
             kaiming_init(m)
 
     def _encode(self, x):
-        if x.is_cuda and _hip_convs() and not (x.requires_grad and torch.is_grad_enabled()):
-            # the five Conv2d + ReLU stages as ONE autograd node on the HIP library (cl_ica_amd/conv.py); the Conv2d modules keep
-            # the parameters.  CLICA_CONV=miopen runs them through nn.Conv2d instead (the layout the reference executes, for A/B), and so does
-            # an input that itself requires a gradient (the HIP stack has no data gradient for its first stage).
+        if x.is_cuda and _hip_convs():
+            # the five Conv2d + ReLU stages as ONE autograd node on the HIP library (cl_ica_amd/conv.py), input-image gradient included;
+            # the Conv2d modules keep the parameters.  CLICA_CONV=miopen runs them through nn.Conv2d instead (A/B switch only).
             feats = conv_stack(x.float(), [self.encoder[i] for i in (0, 2, 4, 6, 8)])
             for stage in self.encoder[10:]:
                 feats = stage(feats)

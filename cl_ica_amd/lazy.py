@@ -28,7 +28,7 @@ from typing import Callable, List, Optional
 import torch
 from torch.utils._pytree import tree_map
 
-__all__ = ["LazyOut", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP"]
+__all__ = ["LazyOut", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP", "attach", "find_optimizers"]
 
 _META_GETTERS = {"shape", "dtype", "device", "requires_grad", "ndim", "layout", "is_cuda", "is_leaf_placeholder"}
 _META_METHODS = {"dim", "size", "__len__", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "get_device",
@@ -145,6 +145,7 @@ def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor
           compute_many=None):
     """Register the call `compute(x)` of `owner`.  If `owner` has a pending call with a compatible input the two are stacked and
     run NOW (one launch); the result of this call is returned as a plain tensor.  Otherwise a LazyOut is returned."""
+    _attach_owners(owner, params)
     pend: Optional[_Pending] = getattr(owner, "_clica_pending", None)
     if pend is not None and pend.compatible(x):
         pend.items.append((x, None))   # the call that completes the stack needs no placeholder: its rows are returned right away
@@ -175,9 +176,66 @@ def after_step(*_args, **_kwargs):
         f()
 
 
-try:        # torch >= 2.0
-    from torch.optim.optimizer import register_optimizer_step_pre_hook as _reg, register_optimizer_step_post_hook as _reg_post
-    _reg(flush_all)
-    _reg_post(after_step)
-except Exception:      # pragma: no cover
-    pass
+# ---- optimizer hooks, per INSTANCE (round 5) --------------------------------------------------------------------------------------
+# Rounds 3-4 registered flush_all / after_step as GLOBAL optimizer step hooks at import: every optimizer of the process ran them.  Now
+# only the optimizers that actually hold parameters of a deferring module get them, as instance-level hooks
+# (Optimizer.register_step_pre_hook / register_step_post_hook).  The module does not see the optimizer being built
+# (`torch.optim.Adam(f.parameters(), lr)`, main_mlp.py:312, consumes a generator), so the owners are looked up once, from the module's
+# first deferred calls, through the garbage collector's referrer graph: parameter <- param_group["params"] list <- param group dict <-
+# optimizer.param_groups list <- optimizer.  cl_ica_amd.optim.Adam needs none of this (its step() calls both functions itself).
+# Without an attached optimizer nothing breaks: a deferred output still pending when the parameters change raises on use (the staleness
+# check above) instead of having been flushed, and the weight copies are re-packed in front of the next forward instead of at step end.
+_ATTACHED = weakref.WeakSet()
+
+
+def attach(optimizer) -> bool:
+    """Give `optimizer` the two step hooks of this module (idempotent).  Returns True if it was newly attached."""
+    if optimizer in _ATTACHED or not hasattr(optimizer, "register_step_pre_hook"):
+        return False
+    optimizer.register_step_pre_hook(flush_all)
+    optimizer.register_step_post_hook(after_step)
+    _ATTACHED.add(optimizer)
+    return True
+
+
+def find_optimizers(params) -> list:
+    """The torch.optim.Optimizer instances whose param_groups hold `params[0]` (see above); a few gc.get_referrers walks."""
+    import gc
+    if not params:
+        return []
+    p0, found = params[0], []
+    for lst in gc.get_referrers(p0):
+        if not isinstance(lst, list) or not any(q is p0 for q in lst):
+            continue
+        for grp in gc.get_referrers(lst):
+            if not (isinstance(grp, dict) and grp.get("params") is lst):
+                continue
+            for groups in gc.get_referrers(grp):
+                if not (isinstance(groups, list) and any(g is grp for g in groups)):
+                    continue
+                for od in gc.get_referrers(groups):
+                    if not (isinstance(od, dict) and od.get("param_groups") is groups):
+                        continue
+                    for o in gc.get_referrers(od):
+                        if isinstance(o, torch.optim.Optimizer) and getattr(o, "__dict__", None) is od and not any(o is f for f in found):
+                            found.append(o)
+    return found
+
+
+_SEARCH_TRIES = 3
+
+
+def _attach_owners(owner, params):
+    st = getattr(owner, "_clica_opt_search", None)
+    if st is None:
+        st = [0, False]
+        try:
+            object.__setattr__(owner, "_clica_opt_search", st)
+        except Exception:
+            return
+    if st[1] or st[0] >= _SEARCH_TRIES:
+        return
+    st[0] += 1
+    for o in find_optimizers(list(params)):
+        attach(o)
+        st[1] = True

@@ -479,6 +479,11 @@ int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patches, int64_t
  * e < count[i] (nn.Conv2d.weight [co][c][ky][kx] -> Wg / Wd / the zero-padded rows of the 4 x 4 stage before a step, GEMM-layout gradients
  * -> Conv2d.weight layout after it; the maps are permutations built once per shape by the caller; map[i] = NULL is the identity, e.g. a
  * bias gradient).  accumulate != 0 adds into dst: the step's gradients go straight into the optimizer's .grad views. */
+/* d loss / d image of the first stage (the reference's nn.Conv2d is differentiable w.r.t. its input, kitti_masks/model.py:41-56):
+ * dO = gradient at the first stage's pre-activation on its (H/2) x (W/2) output grid [images][ho][wo][Cout], W = Conv2d.weight
+ * [Cout][C][4][4] as the module stores it, dX = [images][C][H][W].  C <= 4, Cout * C <= 128. */
+int clica_conv_k4s2_dgrad_input(const float* dO, const float* W, int64_t images, int32_t C, int32_t Cout, int32_t H, int32_t Wd,
+                                float* dX, clica_stream_t stream);
 int clica_conv_gather(int32_t n, const float* const* src, const int32_t* const* map, float* const* dst, const int32_t* count,
                       int32_t accumulate, clica_stream_t stream);
 

@@ -127,13 +127,72 @@ def test_conv_stack_buffers_are_reusable_and_switchable(monkeypatch):
                  note="fp32 MIOpen on the other side, not an fp64 reference")
 
 
-def test_conv_stack_input_gradients_are_not_silently_dropped():
-    """conv_stack has no d/d(images): asking for it raises, and BetaVAE_H serves such inputs through nn.Conv2d (gradient present)."""
+@pytest.mark.parametrize("nc,images", [(1, 6), (3, 3)])
+def test_conv_stack_input_gradient_vs_fp64(nc, images):
+    """d loss / d image through the HIP stack (round 5: clica_conv_k4s2_dgrad_input; until then BetaVAE_H switched to nn.Conv2d / MIOpen for
+    inputs that require a gradient): against the fp64 evaluation of the same nn.Sequential, together with the parameter gradients of the
+    same backward pass; and BetaVAE_H has no second backend left behind a runtime condition."""
     from cl_ica_amd import conv
     from cl_ica_amd.kitti_masks.model import BetaVAE_H
-    x = torch.rand(4, 1, 64, 64, device="cuda", requires_grad=True)
-    with pytest.raises(NotImplementedError):
-        conv.conv_stack(x, _convs(1))
-    net = BetaVAE_H(z_dim=5, nc=1, box_norm=False).to("cuda")
-    net(x).sum().backward()
-    assert x.grad is not None and float(x.grad.abs().max()) > 0
+    g = torch.Generator().manual_seed(40 + nc)
+    convs = _convs(nc)
+    x0 = torch.rand(images, nc, 64, 64, generator=g).to("cuda")
+    dfeats = torch.randn(images, 256, generator=g).to("cuda")
+    x = x0.clone().requires_grad_(True)
+    for m in convs:
+        m.weight.grad = None; m.bias.grad = None
+    conv.conv_stack(x, convs).backward(dfeats)
+    got_dx, got_w1 = x.grad.clone(), convs[0].weight.grad.clone()
+    x64 = x0.double().requires_grad_(True)
+    h = x64
+    c64 = []
+    for m in convs:
+        d = torch.nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding).to("cuda", torch.float64)
+        d.weight.data = m.weight.data.double(); d.bias.data = m.bias.data.double()
+        c64.append(d)
+        h = torch.relu(d(h))
+    (h.flatten(1) * dfeats.double()).sum().backward()
+    PARITY.check("c5_conv_stack/grad", f"nc={nc} images={images}", "d loss / d image", got_dx.cpu().numpy(), x64.grad.cpu().numpy())
+    PARITY.check("c5_conv_stack/grad", f"nc={nc} images={images}", "stage1.weight (same pass)", got_w1.cpu().numpy(), c64[0].weight.grad.cpu().numpy())
+    assert float(x64.grad.abs().max()) > 0
+    if nc == 1:
+        import inspect
+        assert "requires_grad" not in inspect.getsource(BetaVAE_H._encode), "BetaVAE_H must not pick its conv backend by the input's requires_grad"
+        net = BetaVAE_H(z_dim=5, nc=1, box_norm=False).to("cuda")
+        xi = x0.clone().requires_grad_(True)
+        net(xi).sum().backward()
+        assert xi.grad is not None and float(xi.grad.abs().max()) > 0
+
+
+def test_conv_stack_full_batch_zero_mean_upstream_vs_fp64():
+    """The full 2048-mask batch with a ZERO-MEAN upstream gradient (the all-positive dfeats of the test above cannot show
+    cancellation).  Every weight gradient is then a random-walk sum over up to 592 k pixels, |sum| ~ sqrt(n) |term|, and ONE ReLU gate that
+    the fp32 and the fp64 forward decide differently (a pre-activation within fp32 rounding of zero) moves it by ~1 / sqrt(n): that is the
+    conditioning of the comparison, not of the kernels -- so the bound is stated against what fp32 nn.Conv2d / MIOpen shows ON THE SAME DATA
+    against the same fp64 reference: per gradient, the HIP stack may be at most 1.5 x as far from fp64 as nn.Conv2d is, and never beyond
+    3e-3 (measured round 5: see profiles/r5_parity_errors.json, family c5_conv_stack/zero_mean)."""
+    g = torch.Generator().manual_seed(7)
+    field = torch.nn.functional.avg_pool2d(torch.randn(2048, 1, 64, 64, generator=g), 9, 1, 4)
+    x = (field > 0.05).float().to("cuda")
+    dfeats = (torch.randn(2048, 256, generator=g) / 2048).to("cuda")
+    convs = _convs(1)
+    got_f, got_g = _run_hip(x, convs, dfeats)
+    ref_f, ref_g = _reference_fp64(x, convs, dfeats)
+    for m in convs:
+        m.weight.grad = None; m.bias.grad = None
+    h = x
+    for m in convs:
+        h = torch.relu(m(h))
+    h.flatten(1).backward(dfeats)
+    lib_g = []
+    for m in convs:
+        lib_g += [m.weight.grad, m.bias.grad]
+    torch.cuda.synchronize()
+    PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048", "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
+    from conftest import rel_err
+    for i, (gh, gl, r) in enumerate(zip(got_g, lib_g, ref_g)):
+        name = f"stage{i // 2 + 1}." + ("weight" if i % 2 == 0 else "bias")
+        e_lib = rel_err(gl.cpu().numpy(), r.cpu().numpy())
+        tol = min(3e-3, max(1e-5, 1.5 * e_lib))
+        PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048", name, gh.cpu().numpy(), r.cpu().numpy(), tol=tol,
+                     note=f"zero-mean upstream gradient: bound = min(3e-3, 1.5 x fp32 nn.Conv2d's own distance from fp64 on the same data)")

@@ -337,15 +337,15 @@ def test_loss_matrix_core_switch_and_spread():
     _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
     try:
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
-        out_m = tr.step_injected(z1, z2).clone(); g_m = tr.grad_arena.clone()
-        y = tr.y[:B]
-        want = 1.4426950408889634 * float(((y - y[:64].mean(0)) ** 2).sum(1).max())       # origin = mean of the pool's first 64 rows
-        assert abs(tr.loss_spread() - want) <= 2e-3 * want + 1e-6
+        tr.step_injected(z1, z2)
         # (the first loss call of a workspace measures the grid of the planes and falls back itself, csrc/lp_mfma.h; a repeated step must not)
         fb = tr.loss_guard()["fallback_steps"]
         tr.step_injected(z1, z2)
         assert tr.loss_guard()["fallback_steps"] == fb and tr.loss_guard()["last_spread"] < tr.loss_guard()["limit"]
         out_m = tr.loss_out[3 * B:].clone(); g_m = tr.grad_arena.clone()
+        y = tr.y[:B]
+        want = 1.4426950408889634 * float(((y - y[:64].mean(0)) ** 2).sum(1).max())       # origin = mean of the pool's first 64 rows
+        assert abs(tr.loss_spread() - want) <= 2e-3 * want + 1e-6
         tr.capture()
         tr.set_loss_matrix_cores(False)
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 0

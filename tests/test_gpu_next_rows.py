@@ -587,16 +587,22 @@ def test_device_time_stamps_inside_a_graph():
     assert all(20.0 < v < 20000.0 for v in iv), iv
     # the shader-clock probe (clica_clock_probe) on a side stream while the same graph replays: cycles / wall time inside a bracket is a
     # clock between idle and the 2.4 GHz peak
-    side = torch.cuda.Stream()
-    probe = ops.clock_probe(3000, 10.0, side)
-    with torch.cuda.stream(s):
-        for _ in range(40):
-            g.replay()
-    torch.cuda.synchronize()
-    smp = probe.cpu().numpy()
-    assert (smp[:, 0] > 0).all() and (np.diff(smp[:, 0]) >= 1000).all()          # 3000 samples, >= 10 us apart
-    ghz = [ops.clock_between(smp, b0, b1) for b0, b1 in ops.stamp_brackets(slot)]
-    ghz = [x for x in ghz if x is not None]
+    # (HIP multiplexes streams onto a few hardware queues in creation order: in a long test session the probe's stream can land on the SAME
+    #  queue as the replaying stream, the two then run one after the other and no sample falls into a bracket -- try a few fresh streams)
+    ghz = []
+    for _attempt in range(6):
+        side = torch.cuda.Stream()
+        probe = ops.clock_probe(3000, 10.0, side)
+        with torch.cuda.stream(s):
+            for _ in range(40):
+                g.replay()
+        torch.cuda.synchronize()
+        smp = probe.cpu().numpy()
+        assert (smp[:, 0] > 0).all() and (np.diff(smp[:, 0]) >= 1000).all()          # 3000 samples, >= 10 us apart
+        ghz = [ops.clock_between(smp, b0, b1) for b0, b1 in ops.stamp_brackets(slot)]
+        ghz = [x for x in ghz if x is not None]
+        if len(ghz) >= 2:
+            break
     assert len(ghz) >= 2 and all(0.3 < x < 2.6 for x in ghz), ghz
 
 

@@ -353,8 +353,16 @@ def test_lazy_stacking_mechanics_on_cpu():
                 return self.net(xx)
             return lazy.defer(self, x, compute, (x.shape[0], 2), list(self.parameters()))
     m = M()
+    # (round 5) no GLOBAL optimizer hooks any more: the optimizer that holds the module's parameters is found from the module's first
+    # deferred call and gets instance-level hooks; an unrelated optimizer is left alone
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)                                   # created before the loop, as main_mlp.py:312 does
+    other = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1)
     x1, x2 = torch.randn(4, 3), torch.randn(4, 3)
     a = m(x1)
+    assert opt in lazy._ATTACHED and other not in lazy._ATTACHED and lazy.find_optimizers(list(m.parameters())) == [opt]
+    from torch.optim import optimizer as _topt
+    assert lazy.flush_all not in getattr(_topt, "_global_optimizer_pre_hooks", {}).values()
+    assert lazy.after_step not in getattr(_topt, "_global_optimizer_post_hooks", {}).values()
     assert isinstance(a, lazy.LazyOut) and a.shape == (4, 2) and a.dtype == torch.float32 and a.dim() == 2 and len(a) == 4 and calls == []
     b = m(x2)
     assert not isinstance(b, lazy.LazyOut) and calls == [8]                       # one compute over the stack
@@ -374,10 +382,9 @@ def test_lazy_stacking_mechanics_on_cpu():
     calls.clear()
     d = m(x1)
     ref = net(x1).detach().clone()
-    opt = torch.optim.SGD(m.parameters(), lr=0.1)
     for p in m.parameters():
         p.grad = torch.ones_like(p)
-    opt.step()                                                                      # global step pre-hook: flushed with the OLD parameters
+    opt.step()                                                                      # its step pre-hook: flushed with the OLD parameters
     assert calls == [4] and torch.allclose(d.detach(), ref) and not torch.allclose(net(x1), ref)
     e = m(x1)
     with torch.no_grad():
@@ -439,12 +446,15 @@ def test_lazy_compute_many_after_step_and_shared_items_on_cpu():
     # compute_many may decline
     a = lazy.defer(o, x1, lambda x: x @ w, (4, 2), [w], compute_many=lambda xs: None); b = lazy.defer(o, x2, lambda x: x @ w, (5, 2), [w], compute_many=lambda xs: None)
     assert torch.allclose(lazy.plain(a), x1 @ w) and b.grad_fn.name() == "SliceBackward0"
-    # post-step hooks: ours is registered, torch optimizers call it
+    # post-step hooks: an attached optimizer calls ours, an optimizer nobody attached does not (no global hook)
     hits = []
     lazy.AFTER_STEP.append(lambda: hits.append(1))
     try:
         opt = torch.optim.SGD([w], lr=0.1)
         w.grad = torch.zeros_like(w)
+        opt.step()
+        assert hits == []
+        assert lazy.attach(opt) and not lazy.attach(opt)
         opt.step()
     finally:
         lazy.AFTER_STEP.pop()
