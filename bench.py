@@ -426,7 +426,7 @@ def roofline_leg(tr, reps=20):
     return roof, rows
 
 
-def measure_traffic(args, kernel_symbol, timeout_s=150):
+def measure_traffic(args, kernel_symbol, timeout_s=150, child_args=None):
     """HBM-side bytes per launch of `kernel_symbol`, measured BY THIS RUN: two short child runs of this script
     under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no other trace domains, as
     MI355X_MICROARCH.md prescribes), per-launch averages over the child's steps; FETCH_SIZE x 2 (the guide's gfx950 correction for wide
@@ -437,8 +437,10 @@ def measure_traffic(args, kernel_symbol, timeout_s=150):
         return None, "rocprofv3 not on PATH"
     here = os.path.dirname(os.path.abspath(__file__))
     child = [sys.executable, os.path.join(here, "bench.py"), "--steps", "6", "--warmup", "2", "--windows", "1", "--no-cpu-baseline", "--no-roofline",
-             "--no-native-leg", "--no-dropin", "--no-secondary", "--no-traffic", "--n", str(args.n), "--batch-size", str(args.batch_size),
+             "--no-native-leg", "--no-dropin", "--no-secondary", "--no-traffic", "--no-dry-leg", "--n", str(args.n), "--batch-size", str(args.batch_size),
              "--p", str(args.p), "--space-type", args.space_type] + (["--native-fp32"] if args.native_fp32 else [])
+    if child_args is not None:      # another leg's command (bench.py --config c5 ...)
+        child = [sys.executable, os.path.join(here, "bench.py")] + list(child_args)
     want = kernel_symbol.split(" (+")[0].split(" [")[0]
     vals = {}
     tmp = tempfile.mkdtemp(prefix="clica_pmc_", dir="/tmp")
@@ -777,6 +779,60 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
             "kernel_shares": "profiles/r4_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % (which, which)}
 
 
+def c5_conv_roofline(device, reps=20, traffic=True):
+    """`roofline` object of BASELINE configs[4]'s dominant kernel: the persistent data-gradient kernel of the
+    widest conv stage (32 -> 32 channels on the 17 x 17 grid, `conv_dgrad32_stream_k`: 43 % of the stack's flops).  Timed by HIP events
+    around isolated launches on the buffers one real forward / backward of the 2048-mask batch has left behind (the step itself is eager
+    torch autograd, its launches cannot be bracketed from here); algorithmic flops = 2 x images x (16 x 16 output pixels) x (4 x 4 x 32
+    taps) x 32 channels (SURVEY 8(d)-style: the useful MACs, not the row grid's); peak = the fp32 matrix pipe the kernel runs on;
+    `traffic` from child runs of `bench.py --config c5` under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)."""
+    import ctypes as C
+    from cl_ica_amd import conv, _lib
+    from cl_ica_amd.kitti_masks.model import BetaVAE_H
+    lib = _lib.load()
+    torch.manual_seed(0)
+    net = BetaVAE_H(z_dim=5, nc=1, box_norm=True).to(device)
+    x = (torch.rand(2048, 1, 64, 64, device=device) < 0.1).float()
+    conv._POOL.clear()
+    net(x).sum().backward()
+    torch.cuda.synchronize(device)
+    buf = conv._POOL[(2048, 1, device.index if device.index is not None else torch.cuda.current_device())][0]
+    images, l = 2048, 1
+    cout, ho = conv.STAGES[l]; cin, hs = conv.STAGES[l - 1][0], ho + 1
+    dgrid = conv.STAGES[l - 1][1]
+    st = _lib.stream_ptr()
+
+    def launch():
+        _lib.check(lib.clica_conv_k4s2_dgrad(buf.dO[l].data_ptr(), buf.wpack[3 + l].data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs,
+                                             buf.dO[l - 1].data_ptr(), dgrid, dgrid, buf.gate[l - 1].data_ptr(), st), "clica_conv_k4s2_dgrad")
+    for _ in range(5):
+        launch()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(reps):
+        launch()
+    ev[1].record()
+    torch.cuda.synchronize(device)
+    us = ev[0].elapsed_time(ev[1]) * 1e3 / reps
+    gflop = 2.0 * images * ho * ho * 16 * cin * cout / 1e9
+    grid_gflop = 2.0 * images * hs * hs * (4 * cout) * (4 * cin) / 1e9
+    roof = {"kernel": "clica::gemm::conv_dgrad32_stream_k", "op": "data gradient of the 32 -> 32 stage (kitti_masks/model.py:41-56, second Conv2d)", "bound": "mfma",
+            "achieved": round(gflop / us * 1e-3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(gflop / us * 1e-3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "avg_launch_us": round(us, 2), "timing": f"HIP events around {reps} isolated launches on the 2048-mask batch's buffers",
+            "algorithmic_gflop_per_launch": round(gflop, 3), "issued_gflop_per_launch_on_the_row_grid": round(grid_gflop, 3),
+            "algorithmic_bytes_per_launch": int(4 * images * (hs * hs * cout + dgrid * dgrid * cin) + images * dgrid * dgrid * cin // 8),
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)", "traffic": None, "traffic_source": None}
+    if traffic:
+        class _A:      # what measure_traffic reads of the headline's arguments (unused by the c5 child command)
+            n, batch_size, p, space_type, native_fp32 = 10, 6144, 2, "box", False
+        tb, src = measure_traffic(_A, roof["kernel"], child_args=["--config", "c5", "--steps", "3"])
+        roof["traffic"], roof["traffic_source"] = tb, src
+    del net
+    conv._POOL.clear()
+    torch.cuda.empty_cache()
+    return roof
+
+
 def dry_ranks_leg(args, device, R=8, steps=50, windows=3):
     """Rank 0 of an R-rank data-parallel job, planned, captured (with its RCCL collectives, on a one-rank group) and run on THIS GPU:
     pool of R x B rows, loss workspaces / stream splits for that pool, two-half weight-gradient launch, gradient buckets, 1 / R
@@ -970,6 +1026,10 @@ def main():
             out["secondary"]["c4_3dident_resnet18"] = conv_config_leg("c4", device)
             torch.cuda.empty_cache()
             out["secondary"]["c5_kitti_masks"] = conv_config_leg("c5", device)
+            try:
+                out["secondary"]["c5_kitti_masks"]["roofline"] = c5_conv_roofline(device, traffic=not args.no_traffic)
+            except Exception as e:      # noqa: BLE001
+                out["secondary"]["c5_kitti_masks"]["roofline"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -112,13 +112,18 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
   const float* __restrict__ origin = words + W_ORIGIN_CUR;
   float onext = 0.f;                                   // lane k < n: coordinate k of the next origin
   {
+    // (all MAX_N loads in flight before the first shuffle: as a loop over n with a load + six shuffles per turn this was ten
+    //  dependent memory round trips in front of every workgroup's real work -- 17 us for the launch, profiles/r5_summary.md)
     const int lane64 = threadIdx.x;
     const int cnt = rows_p < 64 ? (int)rows_p : 64;
-    for (int k = 0; k < n; ++k) {
-      float v = lane64 < cnt ? Xp[(int64_t)lane64 * ldp + k] : 0.f;
+    float v[MAX_N];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane64 == k) onext = v / (float)cnt;
+    for (int k = 0; k < MAX_N; ++k) v[k] = (lane64 < cnt && k < n) ? Xp[(int64_t)lane64 * ldp + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_N; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+      if (lane64 == k) onext = v[k] / (float)cnt;
     }
   }
   if (blockIdx.x == 0 && (int)threadIdx.x < KSLOTS) {
@@ -249,6 +254,21 @@ __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RP
   static_assert(SV % THREADS == 0, "stage copy");
   __shared__ u32x4 stage[2][SV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  // The guard words come from memory another XCD wrote a moment ago (~2 us): they are requested FIRST, the matrix-core path's own first
+  // loads (anchor fragments, first pool stage) go out behind them, and only then does the workgroup branch on the answer.
+  const bool fall_back = guard_falls_back(words, limit);
+  int bx, by;
+  xcd_tile(blockIdx.x < mgx * mgy ? blockIdx.x : 0u, mgx, mgy, bx, by);
+  const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
+  u32x4 b[T][3];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[t][p] = RPa[(((atile0 + t) * 3 + p) * 2 + h) * ROWS + l31];
+  const u32x4* src = RPp + (int64_t)by * chunk_tiles * ROWVEC;
+  u32x4 pre[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) pre[u] = src[threadIdx.x + u * THREADS];
   if (blockIdx.x == 0 && threadIdx.x < 64) {      // the planes are written: hand the next call its grid (lp_mfma.h)
     if (threadIdx.x < KSLOTS) words[W_ORIGIN_CUR + threadIdx.x] = words[W_ORIGIN_NEXT + threadIdx.x];
     if (threadIdx.x == 0) {
@@ -256,29 +276,17 @@ __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RP
       reinterpret_cast<unsigned*>(words)[W_CALL] += 1u;
     }
   }
-  if (guard_falls_back(words, limit)) {            // the guard (lp_mfma.h): this call runs on the coordinate differences
+  if (fall_back) {                                  // the guard (lp_mfma.h): this call runs on the coordinate differences
     if (blockIdx.x < (unsigned)(v.gx * v.gy))
       lp::fwd_partial_body<NP, 2, lp::owners_fwd(NP), false, false, NQ, true>(v.own, v.ldo, v.n_own, v.str, v.lds, v.n_str, v.q, part, nullptr, v.chunk,
                                                                              (int)(blockIdx.x % (unsigned)v.gx), (int)(blockIdx.x / (unsigned)v.gx));
     return;
   }
   if (blockIdx.x >= mgx * mgy) return;
-  int bx, by;
-  xcd_tile(blockIdx.x, mgx, mgy, bx, by);
-  const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
-  u32x4 b[T][3];
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int p = 0; p < 3; ++p) b[t][p] = RPa[(((atile0 + t) * 3 + p) * 2 + h) * ROWS + l31];
   float s[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) s[t] = 0.f;
-  const u32x4* src = RPp + (int64_t)by * chunk_tiles * ROWVEC;
   const int nst = chunk_tiles / STAGE_TILES;
-  u32x4 pre[PER];
-#pragma unroll
-  for (int u = 0; u < PER; ++u) pre[u] = src[threadIdx.x + u * THREADS];
 #pragma unroll
   for (int u = 0; u < PER; ++u) stage[0][threadIdx.x + u * THREADS] = pre[u];
   __syncthreads();
@@ -340,13 +348,7 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
                                                     const float* __restrict__ ownL, const float* __restrict__ ownC,
                                                     float* __restrict__ part, int chunk_tiles, const float* __restrict__ words, float limit,
                                                     const unsigned mgx, const unsigned mgy, const ValuSweep v) {
-  if (guard_falls_back(words, limit)) {            // the guard, as in fwd_k
-    if (blockIdx.x < (unsigned)(v.gx * v.gy))
-      lp::bwd_pairs_body<NP, 2, lp::owners_bwd(NP), 3, false, NQ, true>(v.own, v.ldo, v.n_own, v.str, v.lds, v.n_str, v.q, v.ownL, v.ownC, v.strL, v.strC,
-                                                                       part, v.chunk, (int)(blockIdx.x % (unsigned)v.gx), (int)(blockIdx.x / (unsigned)v.gx));
-    return;
-  }
-  if (blockIdx.x >= mgx * mgy) return;
+  const bool fall_back = guard_falls_back(words, limit);      // requested first, consumed behind the path's own first loads (see fwd_k)
   constexpr int RV = STAGE_B * ROWVEC, FV = STAGE_B * FEATVEC, SV = RV + FV, PER = (SV + THREADS - 1) / THREADS;      // 384 + 768 vectors
   constexpr int NB = STAGE_B * T;                                                                    // blocks per stage
   static_assert(RV % 64 == 0 && SV % 64 == 0, "stage copy: whole waves on either side of the row / feature boundary");
@@ -354,10 +356,10 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
   __shared__ u32x4 stage[2][LV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   int bx, by;
-  xcd_tile(blockIdx.x, mgx, mgy, bx, by);
+  xcd_tile(blockIdx.x < mgx * mgy ? blockIdx.x : 0u, mgx, mgy, bx, by);
   const int64_t atile0 = ((int64_t)bx * WAVES + wave) * T;
   u32x4 b[T][3];
-  float ui[T];
+  float ui[T], Lrow[T], Crow[T];
   f32x16 G[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) {
@@ -365,8 +367,18 @@ __global__ __launch_bounds__(THREADS, 2) void bwd_k(const u32x4* __restrict__ RP
     for (int p = 0; p < 3; ++p) b[t][p] = RPa[(((atile0 + t) * 3 + p) * 2 + h) * ROWS + l31];
     const int64_t i = (atile0 + t) * ROWS + l31;
     const bool ok = i < n_own;
-    const float L = ownL[ok ? i : 0], Cc = ownC[ok ? i : 0];
-    ui[t] = ok ? Cc * fexp2(-L) : 0.f;
+    Lrow[t] = ownL[ok ? i : 0]; Crow[t] = ok ? ownC[i] : 0.f;
+  }
+  if (fall_back) {                                  // the guard (lp_mfma.h): this call runs on the coordinate differences
+    if (blockIdx.x < (unsigned)(v.gx * v.gy))
+      lp::bwd_pairs_body<NP, 2, lp::owners_bwd(NP), 3, false, NQ, true>(v.own, v.ldo, v.n_own, v.str, v.lds, v.n_str, v.q, v.ownL, v.ownC, v.strL, v.strC,
+                                                                       part, v.chunk, (int)(blockIdx.x % (unsigned)v.gx), (int)(blockIdx.x / (unsigned)v.gx));
+    return;
+  }
+  if (blockIdx.x >= mgx * mgy) return;
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    ui[t] = Crow[t] * fexp2(-Lrow[t]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) G[t][r] = 0.f;
   }

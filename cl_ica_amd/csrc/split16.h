@@ -48,6 +48,10 @@ __device__ __forceinline__ void split16_update_body(Split16State* st, int L) {
   __shared__ unsigned mx[3][NT];
   const int t = threadIdx.x, lane = t & 63;
   if (t < 3 * NT) mx[t / NT][t % NT] = 0u;
+  // everything the header holds is requested FIRST (counts, wave ranges, this thread's scales): the state sits in memory another XCD
+  // wrote, every dependent read is a ~2 us round trip, and this body rides in a 7 us launch
+  const int tc = t < NT ? t : 0;
+  const float curA = st->sA[tc], curD = st->sD[tc], curW = st->sW[tc];
   const unsigned nA = min(st->nA, kS16CapWG), nD = min(st->nD, kS16CapWG), nPW = min(st->nPW, kS16CapPW);
   unsigned wf[NT + 1];
 #pragma unroll
@@ -97,10 +101,10 @@ __device__ __forceinline__ void split16_update_body(Split16State* st, int L) {
     se = se < emin ? emin : (se > emax ? emax : se);
     return __uint_as_float((unsigned)(se + 127) << 23);
   };
-  if (t <= L) { st->pA[t] = st->sA[t]; st->sA[t] = next(mx[0][t], st->sA[t], -14, 15); }
-  if (t < L) { st->pD[t] = st->sD[t]; st->sD[t] = next(mx[1][t], st->sD[t], -100, 100); }
+  if (t <= L) { st->pA[t] = curA; st->sA[t] = next(mx[0][t], curA, -14, 15); }
+  if (t < L) { st->pD[t] = curD; st->sD[t] = next(mx[1][t], curD, -100, 100); }
   float w = 1.f;
-  if (t < L) { w = next(mx[2][t], st->sW[t], -100, 100); st->sW[t] = w; }
+  if (t < L) { w = next(mx[2][t], curW, -100, 100); st->sW[t] = w; }
   if (t < L && L - 1 - t >= 0 && L - 1 - t < NT) st->sWC[L - 1 - t] = w;      // chain link j uses layer L - 1 - j
   if (t == 0) { st->updates += 1u; st->nA = st->nD = st->nPW = 0u; }
 }

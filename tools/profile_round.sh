@@ -2,7 +2,7 @@
 # Round profile on the GPU box: kernel-trace stats of the bench command + separate PMC passes.
 # usage (via gpurun): bash tools/profile_round.sh r1
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/profile_$TAG
 mkdir -p $OUT
