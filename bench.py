@@ -168,7 +168,8 @@ def roofline_leg(tr, reps=20):
     chain_key = ("linear_fwd+linear_dgrad (wide layers)", "clica::wsplit::gemm_split_k")
     wide_w = bool(getattr(tr, "split_wgrad_wide", False))
     split = bool(getattr(tr, "split_bf16", False))
-    fused_sym = "clica::fmlp::mlp_split_k" if split else "clica::fmlp::mlp_fwd_k<true, false>"
+    fused_sym = (("clica::fmlp::mlp_split_k<1>" if getattr(tr, "split_f16", False) else "clica::fmlp::mlp_split_k<0>") if split
+                 else "clica::fmlp::mlp_fwd_k<true, false>")
     fused_key = ("mlp_fwd+mlp_dgrad", fused_sym)
     if tr.fused_forward:
         fl = sum(2.0 * R * lin.out_features * lin.in_features for lin in tr.linears)
@@ -817,7 +818,7 @@ def c5_conv_roofline(device, reps=20, traffic=True):
     gflop = 2.0 * images * ho * ho * 16 * cin * cout / 1e9
     grid_gflop = 2.0 * images * hs * hs * (4 * cout) * (4 * cin) / 1e9
     roof = {"kernel": "clica::gemm::conv_dgrad32_stream_k", "op": "data gradient of the 32 -> 32 stage (kitti_masks/model.py:41-56, second Conv2d)", "bound": "mfma",
-            "achieved": round(gflop / us * 1e-3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(gflop / us * 1e-3 / PEAK_FP32_MFMA_TFLOPS, 4),
+            "achieved": round(gflop / us * 1e3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(gflop / us * 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
             "avg_launch_us": round(us, 2), "timing": f"HIP events around {reps} isolated launches on the 2048-mask batch's buffers",
             "algorithmic_gflop_per_launch": round(gflop, 3), "issued_gflop_per_launch_on_the_row_grid": round(grid_gflop, 3),
             "algorithmic_bytes_per_launch": int(4 * images * (hs * hs * cout + dgrid * dgrid * cin) + images * dgrid * dgrid * cin // 8),
