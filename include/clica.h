@@ -144,7 +144,11 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * ~ sqrt(M).  THE GUARD (round 5): every fwd_train call measures its own M on the device; when it exceeds the spread limit (default 768:
  * gradient error < 1e-5 against the fp64 oracle with margin, tests/test_gpu_loss.py ..._spread_limit) the matrix-core sweeps of THAT call
  * return at once and the coordinate-difference sweeps (no such dependence), launched behind them with the opposite condition, do the
- * work.  The decision is made by the kernels per call -- no host round trip, valid inside a replayed graph.
+ * work.  The decision is made by the kernels per call -- no host round trip, valid inside a replayed graph; the fallback is not a launch
+ * of its own: the forward / backward launch carries both sweeps and its workgroups branch on the guard words.  The planes of a call are
+ * built on the grid (step D, origin) the PREVIOUS call's prep launch measured; a call whose rows do not fit that grid (the first call on
+ * a zeroed workspace, a cloud that grew across a power of two) is sent to the difference sweep by the same guard -- so keep ONE
+ * workspace per training loop and do not zero it between steps.
  * CLICA_LP_MFMA=0 / clica_lp_loss_set_matrix_cores(0) remove the matrix-core sweeps altogether.
  * clica_lp_loss_train_path reports which launches a call makes:
  * *path = 1 matrix cores with the guarded fallback behind them, 0 VALU sweeps only. */
@@ -355,9 +359,9 @@ int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_pla
  * exponent needs a power-of-two scale s PER TENSOR: a caller-owned device `state` (clica_split16_state_bytes bytes, 16-byte aligned,
  * initialised once by clica_split16_state_init) holds, per tensor of one encoder, the scale in force and the running maximum the
  * producers record; clica_split16_update (one tiny launch per training step, after the step's last producer) turns the maxima into
- * the next step's scales (largest scaled magnitude in [256, 512)).  So a launch uses the scales of the PREVIOUS step: run two
- * un-applied passes after initialisation / after parameters were set from outside so that the scales match the data (the engine
- * does).  A scaled magnitude beyond 32768 (a tensor grew > 64 x between consecutive steps) raises bit 0 of the state's sticky
+ * the next step's scales (largest scaled magnitude in [256, 512)).  So a launch uses the scales of the PREVIOUS step: run L + 1
+ * un-applied passes (L = number of layers: each pass settles at least one more link of the gradient chain) after initialisation /
+ * after parameters were set from outside so that the scales match the data (the engine does: ContrastiveTrainer.calibrate_scales).  A scaled magnitude beyond 32768 (a tensor grew > 64 x between consecutive steps) raises bit 0 of the state's sticky
  * flags -- results of that launch are not to be trusted; clica_split16_read (synchronises) reports it.  Measured error: at the
  * native fp32-MFMA kernels' level (tests: every engine family in this arithmetic at 1e-5).
  * Order of one training step on a state: clica_mlp_pack_split16_both -> clica_mlp_fwd_split16 -> clica_mlp_dgrad_split16 ->
