@@ -113,6 +113,12 @@ SIGNATURES: Dict[str, list] = {
                                 C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                                 C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, c_size,
                                 C.c_void_p],
+    "clica_mlp_planes16_from_f32": [c_f32p, c_i64, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p, c_i32, c_i32, C.c_void_p],
+    "clica_mlp_planes16_from_f32_t": [c_f32p, c_i64, c_i64, c_i32, C.c_void_p, C.c_void_p, c_i32, c_i32, C.c_void_p],
+    "clica_linear_split_fwd16": [C.c_void_p, C.c_void_p, c_f32p, c_i64, c_i32, c_i32, c_i32, C.c_float, C.c_void_p, C.c_void_p, c_i32,
+                                 c_f32p, c_i64, C.c_void_p, c_i32, C.c_void_p],
+    "clica_linear_split_dgrad16": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p,
+                                   c_f32p, c_i64, C.c_void_p, c_i32, C.c_void_p],
     "clica_mlp_pack_bytes": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.POINTER(c_size)],
     "clica_mlp_pack": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_i32, c_f32p, C.c_void_p],
     "clica_mlp_pack_both": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, c_f32p, C.c_void_p],

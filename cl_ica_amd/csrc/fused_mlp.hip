@@ -810,7 +810,8 @@ __global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L)
 __global__ __launch_bounds__(64) void split16_init_k(Split16State* st, unsigned capWG, unsigned capPW) {
   const int t = threadIdx.x;
   if (t < Split16State::NT) st->sA[t] = st->sD[t] = st->sW[t] = st->sWC[t] = st->pA[t] = st->pD[t] = 1.f;
-  if (t == 0) { st->flags = 0u; st->updates = 0u; st->nA = st->nD = st->nPW = 0u; st->capWG = capWG; st->capPW = capPW; }
+  if (t < Split16State::NT) st->cntA[t] = st->cntD[t] = st->cntW[t] = 0u;
+  if (t == 0) { st->flags = 0u; st->updates = 0u; st->nPW = 0u; st->capWG = capWG; st->capPW = capPW; }
 }
 
 // Debug build only (-DCLICA_SPLIT_TRACE, tools/split_trace.py): s_memtime stamps per (workgroup, wave, layer, phase), kept in
@@ -1241,9 +1242,9 @@ __device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], un
           }
         }
       }
-      if (has_pl && pl_ones && cb == (N >> 4) && (N & 31) != 0) {     // wave-uniform: feature N of the HBM copy is the constant 1, i.e. s_out in scaled units
+      if (has_pl && pl_ones && cb == (N >> 4) && (N & 31) != 0) {     // wave-uniform: feature N of the HBM copy is the constant 1
         const bool owner = N >= n0 && N < n0 + 4;
-        const unsigned short one = __builtin_bit_cast(unsigned short, (_Float16)s_out);
+        const unsigned short one = 0x3C00u;      // fp16 1.0 -- NOT the activation's scale: the weight-gradient kernel takes the scale of X out of dW only
 #pragma unroll
         for (int r = 0; r < RB; ++r)
           __builtin_amdgcn_raw_buffer_store_b16(one, prsrc, owner ? (unsigned)(r * pl_group_bytes) + pl_cb + (unsigned)((N - n0) * 2) : kOobOffset, 0, 0);
@@ -1531,9 +1532,9 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
                                    has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
       }
       ST_STAMP(l, 6);
-      if (has_pl && q.pl_ones && (N & 31) == 0 && wave == 0) {   // the ones column in an extra unit (value s_out: 1 in scaled units)
+      if (has_pl && q.pl_ones && (N & 31) == 0 && wave == 0) {   // the ones column in an extra unit
         const bool first = (lane & 1) == 0 && ((lane >> 3) & 1) == 0;
-        const unsigned one = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)s_out);
+        const unsigned one = 0x3C00u;
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
@@ -1695,7 +1696,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   }
   if constexpr (AR == 1) {        // (behind the last layer's closing barrier) this workgroup's slot of the maxima
     if (blockIdx.x < a.cap_wg && threadIdx.x < Split16State::NT) a.part_t[(size_t)threadIdx.x * kS16CapWG + blockIdx.x] = amax_lds[threadIdx.x];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *a.count_t = gridDim.x;
+    if (blockIdx.x == 0 && (int)threadIdx.x <= g.L) a.count_t[threadIdx.x] = gridDim.x < a.cap_wg ? gridDim.x : a.cap_wg;
   }
   ST_FLUSH(g.L);
 }
@@ -2014,7 +2015,7 @@ static int mlp_fwd_split_impl(const float* X, int64_t ldx, int64_t M, const floa
   if (state16) {
     Split16State* st = reinterpret_cast<Split16State*>(state16);
     CLICA_CHECK_ARG(ceil_div(M, (int64_t)ROWS) <= (int64_t)kS16CapWG, "clica_mlp_fwd_split16: M = %lld rows exceeds the state's %u workgroup slots", (long long)M, kS16CapWG);
-    a.s_t = st->sA; a.s_w = st->sW; a.part_t = s16_partA(st); a.count_t = &st->nA; a.cap_wg = kS16CapWG;
+    a.s_t = st->sA; a.s_w = st->sW; a.part_t = s16_partA(st); a.count_t = st->cntA; a.cap_wg = kS16CapWG;
     a.last_unscaled = (planes && planes[n_layers - 1]) ? 0 : 1;
   }
   return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_fwd_split16" : "clica_mlp_fwd_split");
@@ -2067,7 +2068,7 @@ static int mlp_dgrad_split_impl(const float* dY, int64_t lddy, int64_t M, int32_
   if (state16) {
     Split16State* st = reinterpret_cast<Split16State*>(state16);
     CLICA_CHECK_ARG(ceil_div(M, (int64_t)ROWS) <= (int64_t)kS16CapWG, "clica_mlp_dgrad_split16: M = %lld rows exceeds the state's %u workgroup slots", (long long)M, kS16CapWG);
-    a.s_t = st->sD; a.s_w = st->sWC; a.cap_wg = kS16CapWG; a.part_t = s16_partD(st); a.count_t = &st->nD;
+    a.s_t = st->sD; a.s_w = st->sWC; a.cap_wg = kS16CapWG; a.part_t = s16_partD(st); a.count_t = st->cntD;
     a.last_unscaled = (planes && planes[n_links - 1]) ? 0 : 1;
   }
   return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_dgrad_split16" : "clica_mlp_dgrad_split");

@@ -73,6 +73,7 @@ struct Prob {
   char* outN; int fuN;            // output as planes of C   (rows = C row, features = C column) or nullptr
   float* outF; int64_t ldf;       // output as fp32 C[row][column] or nullptr
   const float* scaleA; const float* scaleB;   // f16x2 only: device pointers to the scales of the A and B tensors (the slab gets acc / (sA sB))
+  s16::S16Tensor outS;                        // f16x2 fused epilogues: scale in force for the OUTPUT tensor's planes, and where to record its maximum
 };
 struct GroupArgs { int n, total; int first[MAXG + 1]; Prob p[MAXG]; };
 
@@ -241,6 +242,109 @@ __device__ __forceinline__ void fused_epilogue(const Prob& g, const f32x16 (&acc
   }
 }
 
+// The same epilogue in the f16x2 arithmetic: the accumulator holds (sA sB) x the true product; t = acc / (sA sB) (+ bias, LeakyReLU, or
+// the sign gate -- read from the hi piece of the gate tensor's T-planes: an fp16's sign bit and "non-zero" test are the bf16 ones), the
+// workgroup's max |t| goes to the output tensor's slot (split16.h), the planes get the two fp16 pieces of t x s_out (units of 2 KB: two
+// pieces), the fp32 copy gets t.  The constant-1 column of an N-plane buffer is 1.0 whatever the scale (written once by the conversion
+// kernel that prepared the buffer) and is left alone here as in the bf16x3 epilogue.
+__device__ __forceinline__ void split16_hi_lo(float t, unsigned& hb, unsigned& lb) {     // piece bits in the LOW half
+  const _Float16 h = (_Float16)t;
+  hb = (unsigned)__builtin_bit_cast(unsigned short, h);
+  lb = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)(t - (float)h));
+}
+template <int NI>
+__device__ __forceinline__ void fused_epilogue16(const Prob& g, const f32x16 (&acc)[NI][2], const int row0, const int col0, int lane) {
+  asm volatile("" : "+v"(lane));
+  __shared__ float red[8];
+  const int h = lane >> 5, l31 = lane & 31;
+  const bool fwd = g.epi == 1;
+  const bool slope01 = g.slope > 0.f && g.slope < 1.f;
+  const int j4 = lane & 3;
+  const unsigned sel = (j4 & 1) ? 0x03020706u : 0x05040100u;
+  const bool upper = (j4 & 2) != 0;
+  const float unscale = 1.f / (*g.scaleA * *g.scaleB);
+  const float s_out = g.outS.scale ? *g.outS.scale : 1.f;
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + j * 32 + l31;
+    const bool col_ok = col < g.N;
+    const int colc = col_ok ? col : 0;
+    const float b = (fwd && g.bias && col_ok) ? g.bias[colc] : 0.f;
+    const size_t t_grp = (size_t)(colc >> 4) * 2048, t_in = (size_t)(((colc & 15) >> 2) * 256 + (colc & 3) * 32);
+    const size_t n_col = (size_t)(colc >> 5) * 2048 + (size_t)(((colc >> 4) & 1) * 128 + (colc & 15) * 2);
+    const int c0 = col & ~3;
+    const bool quad_full = c0 + 3 < g.N;
+    const size_t n_c0 = (size_t)(c0 >> 5) * 2048 + (size_t)(((c0 >> 4) & 1) * 128 + (c0 & 15) * 2);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = row0 + i * 32 + 8 * q + 4 * h;
+        const bool m_ok = m < g.M;
+        const int mc = m_ok ? m : 0;
+        const size_t t_feat = (size_t)(mc >> 5) * 2048 + (size_t)(((mc >> 4) & 1) * 128 + (mc & 15) * 2);
+        unsigned sgn[2] = {0x3C003C00u, 0x3C003C00u};           // "positive" when there is no gate
+        if (!fwd && g.signT && col_ok && m_ok) {
+          const u32x2 sv = *reinterpret_cast<const u32x2*>(g.signT + t_grp * g.fuS + t_in + t_feat);
+          sgn[0] = sv.x; sgn[1] = sv.y;
+        }
+        unsigned hb[4], lb[4];
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][4 * q + e] * unscale;
+          if (fwd) {
+            t += b;
+            if (g.leaky) t = slope01 ? fmaxf(t, t * g.slope) : (t > 0.f ? t : t * g.slope);
+          } else {
+            const unsigned hbits = (e & 1) ? (sgn[e >> 1] >> 16) : (sgn[e >> 1] & 0xFFFFu);
+            const bool pos = (hbits & 0x8000u) == 0u && (hbits & 0x7FFFu) != 0u;
+            t = pos ? t : t * g.slope;
+          }
+          if (m + e >= g.M || !col_ok) t = 0.f;
+          v[e] = t;
+          amax = fmaxf(amax, fabsf(t));
+          split16_hi_lo(t * s_out, hb[e], lb[e]);
+        }
+        const u32x2 ph = (u32x2){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+        const u32x2 pl = (u32x2){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+        if (g.outT && col_ok && m_ok) {
+          char* dst = g.outT + t_grp * g.fuT + t_in + t_feat;
+          *reinterpret_cast<u32x2*>(dst) = ph;
+          *reinterpret_cast<u32x2*>(dst + 1024) = pl;
+        }
+        if (g.outN) {
+          const u32x2 th = quad_transpose16(ph.x, ph.y, sel, upper);
+          const u32x2 tl = quad_transpose16(pl.x, pl.y, sel, upper);
+          const int row = m + j4;
+          if (quad_full) {
+            if (row < g.M) {
+              char* dst = g.outN + (size_t)(row >> 4) * 2048 * g.fuN + (size_t)(((row & 15) >> 2) * 256 + (row & 3) * 32) + n_c0;
+              *reinterpret_cast<u32x2*>(dst) = th;
+              *reinterpret_cast<u32x2*>(dst + 1024) = tl;
+            }
+          } else if (col_ok && m_ok) {
+            char* dst = g.outN + (size_t)(m >> 4) * 2048 * g.fuN + (size_t)(((m & 15) >> 2) * 256) + n_col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (m + e >= g.M) continue;
+              unsigned short* d2 = reinterpret_cast<unsigned short*>(dst + e * 32);
+              d2[0] = (unsigned short)hb[e]; d2[512] = (unsigned short)lb[e];
+            }
+          }
+        }
+        if (g.outF && col_ok) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (m + e < g.M) g.outF[(int64_t)(m + e) * g.ldf + col] = v[e];
+        }
+      }
+    }
+  }
+  if (g.outS.slots) s16::s16_commit_block_max(g.outS, amax, red, blockIdx.x, gridDim.x);
+}
+
 // One work item: output tile (bx, by) of problem g over the row groups of contraction split bz.
 // Eight waves, wave tile 64 x 64 = 2 x 2 accumulator blocks of 32 x 32 (64 registers); per 16-row step a wave reads
 // 2 + 2 unit fragments x 3 planes (24 transposing reads of 512 B) and issues 24 MFMAs (768 matrix cycles).
@@ -251,7 +355,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   constexpr int NP = WArith<AR>::NP, NPROD = WArith<AR>::NPROD, PIECES = pieces_of<AR>(), STAGE_BYTES = stage_bytes_of<AR>();
   constexpr int NJ = (PIECES + 7) / 8;                       // DMA pieces per wave and step (the last one only for the first PIECES - 8 (NJ - 1) waves)
   constexpr int NM = NPROD * 4;                              // MFMAs per wave and step
-  static_assert(!FUSED || AR == 0, "the fused forward / data-gradient epilogues exist in the bf16x3 arithmetic only");
+
   constexpr int UA = A_WIDE ? UW : UN, UB = A_WIDE ? UN : UW;
   constexpr int BM = UA * 32, BN = UB * 32;
   constexpr int WN = BN / 64;
@@ -382,10 +486,13 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
 
   // slab epilogue (same layout as the fp32 kernel: accumulator row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31)
   const int m0 = by * BM, n0 = bx * BN;
-  if constexpr (FUSED) { fused_epilogue<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane); return; }
+  if constexpr (FUSED) {
+    if constexpr (AR == 0) fused_epilogue<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane); else fused_epilogue16<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    return;
+  }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
-  float unscale = 1.f;
-  if constexpr (AR == 1) unscale = 1.f / (*g.scaleA * *g.scaleB);      // powers of two: exact
+  float unscale = 1.f, unscale_db = 1.f;
+  if constexpr (AR == 1) { unscale = 1.f / (*g.scaleA * *g.scaleB); unscale_db = 1.f / *g.scaleA; }      // powers of two: exact; the constant-1 feature of X is stored as 1.0, not as X's scale
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -399,7 +506,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= g.M) continue;
-        dst[row * ld] = AR == 1 ? acc[i][j][r] * unscale : acc[i][j][r];
+        dst[row * ld] = AR == 1 ? acc[i][j][r] * (is_db ? unscale_db : unscale) : acc[i][j][r];
       }
     }
   }
@@ -424,7 +531,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
   constexpr int NP = WArith<AR>::NP, NPROD = WArith<AR>::NPROD, PIECES2 = NP * (UW + UW), STAGE2_BYTES = PIECES2 * 1024;
   constexpr int NJ2 = PIECES2 / 8;                            // DMA pieces per wave and step (6 / 4)
   constexpr int NMH = NPROD * 4;                              // MFMAs per half step
-  static_assert(!FUSED || AR == 0, "the fused forward / data-gradient epilogues exist in the bf16x3 arithmetic only");
+
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -535,10 +642,13 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
   if (t < nt) step(b0, b1, t);
 
   const int m0 = by * 256, n0 = bx * 256;
-  if constexpr (FUSED) { fused_epilogue<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane); return; }
+  if constexpr (FUSED) {
+    if constexpr (AR == 0) fused_epilogue<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane); else fused_epilogue16<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    return;
+  }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
-  float unscale = 1.f;
-  if constexpr (AR == 1) unscale = 1.f / (*g.scaleA * *g.scaleB);
+  float unscale = 1.f, unscale_db = 1.f;
+  if constexpr (AR == 1) { unscale = 1.f / (*g.scaleA * *g.scaleB); unscale_db = 1.f / *g.scaleA; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -552,7 +662,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (row >= g.M) continue;
-        dst[row * ld] = AR == 1 ? acc[i][j][r] * unscale : acc[i][j][r];
+        dst[row * ld] = AR == 1 ? acc[i][j][r] * (is_db ? unscale_db : unscale) : acc[i][j][r];
       }
     }
   }
@@ -588,6 +698,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
 // costs more than the big tile's 2/3 bytes per flop save (572 us against 511 us for 768 tiles of 128 x 256).  So ONE full round of big
 // tiles over the first rows_big rows (the first 256 workgroups, one per CU) and the remaining rows as 128 x 256 tiles, picked up as
 // the CUs come free: 286 + 170 us of work per CU instead of 3 x 170.
+template <int AR>
 __global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
   const Prob& g = G.p[0];
   if (g.a_wide == 3) {
@@ -595,17 +706,17 @@ __global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
     if (b < g.n_big) {
       const int id = xcd_contiguous(b, g.n_big);
       const int by = id / g.gx, bx = id - by * g.gx;
-      body_big<true, 0>(g, bx, by, 0);
+      body_big<true, AR>(g, bx, by, 0);
     } else {
       const int id = xcd_contiguous(b - g.n_big, G.total - g.n_big);
       const int by = id / g.gx, bx = id - by * g.gx;
-      body<false, true, 0>(g, bx, g.rows_big / 128 + by, 0);
+      body<false, true, AR>(g, bx, g.rows_big / 128 + by, 0);
     }
     return;
   }
   const int id = xcd_contiguous(blockIdx.x, G.total);
   const int by = id / g.gx, bx = id - by * g.gx;
-  if (g.a_wide == 2) body_big<true, 0>(g, bx, by, 0); else if (g.a_wide) body<true, true, 0>(g, bx, by, 0); else body<false, true, 0>(g, bx, by, 0);
+  if (g.a_wide == 2) body_big<true, AR>(g, bx, by, 0); else if (g.a_wide) body<true, true, AR>(g, bx, by, 0); else body<false, true, AR>(g, bx, by, 0);
 }
 
 #ifdef CLICA_WSPLIT_TRACE
@@ -698,6 +809,86 @@ __global__ __launch_bounds__(256) void planes_from_f32_t_k(const float* __restri
   *reinterpret_cast<u32x2*>(dst) = (u32x2){(hb[0] >> 16) | hb[1], (hb[2] >> 16) | hb[3]};
   *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){(mb[0] >> 16) | mb[1], (mb[2] >> 16) | mb[3]};
   *reinterpret_cast<u32x2*>(dst + 2048) = (u32x2){(lb[0] >> 16) | lb[1], (lb[2] >> 16) | lb[3]};
+}
+
+// ---- the same two conversions in the f16x2 arithmetic: v x scale -> hi / lo fp16 pieces (2 KB units), the constant-1 feature as 1.0;
+//      the workgroup's max |v| goes to the tensor's slots (split16.h) for the next step's scale ----
+__global__ __launch_bounds__(256) void planes16_from_f32_k(const float* __restrict__ X, int64_t ldx, int64_t M, int F, int ones, int units,
+                                                           char* __restrict__ out, int64_t groups, const s16::S16Tensor T) {
+  __shared__ float red[8];
+  const int64_t wu = (int64_t)blockIdx.x * 2 + (threadIdx.x >> 7);
+  const bool live = wu < groups * units;
+  const int64_t g = live ? wu / units : 0; const int u = live ? (int)(wu - g * units) : 0;
+  const int t = threadIdx.x & 127, k = t >> 3, q = t & 7;
+  const int64_t row = g * 16 + k;
+  const int f0 = u * 32 + q * 4;
+  const float sc = *T.scale;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (live && row < M) {
+    const float* src = X + row * ldx + f0;
+    if (f0 + 3 < F && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+      const float4 x4 = *reinterpret_cast<const float4*>(src);
+      v[0] = x4.x; v[1] = x4.y; v[2] = x4.z; v[3] = x4.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (f0 + e < F) v[e] = src[e];
+    }
+  }
+  float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  unsigned hb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    split16_hi_lo(v[e] * sc, hb[e], lb[e]);
+    if (ones && f0 + e == F) { hb[e] = 0x3C00u; lb[e] = 0u; }       // every row of the group, padded rows included (they meet zero rows)
+  }
+  if (live) {
+    const int s2 = q >> 2, c = (q & 3) * 4;
+    char* dst = out + ((g * units + u) * 2) * 1024 + (k >> 2) * 256 + s2 * 128 + (k & 3) * 32 + c * 2;
+    *reinterpret_cast<u32x2*>(dst) = (u32x2){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+    *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+  }
+  s16::s16_commit_block_max(T, amax, red, blockIdx.x, gridDim.x);
+}
+__global__ __launch_bounds__(256) void planes16_from_f32_t_k(const float* __restrict__ X, int64_t ldx, int64_t M, int F, int units,
+                                                             char* __restrict__ out, int64_t groups, const s16::S16Tensor T) {
+  __shared__ float tile[2][16][33];
+  __shared__ float red[8];
+  const int half = threadIdx.x >> 7, t = threadIdx.x & 127;
+  const int64_t wu = (int64_t)blockIdx.x * 2 + half;
+  const bool live = wu < groups * units;
+  const int64_t g = live ? wu / units : 0; const int u = live ? (int)(wu - g * units) : 0;
+  const float sc = *T.scale;
+  float amax = 0.f;
+  {
+    const int phi = t >> 2, c = (t & 3) * 4;
+    const int64_t row = (int64_t)u * 32 + phi; const int64_t f0 = g * 16 + c;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live && row < M) {
+      const float* src = X + row * ldx + f0;
+      if (f0 + 3 < F && ((reinterpret_cast<uintptr_t>(src) & 15) == 0)) {
+        const float4 x4 = *reinterpret_cast<const float4*>(src);
+        v[0] = x4.x; v[1] = x4.y; v[2] = x4.z; v[3] = x4.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (f0 + e < F) v[e] = src[e];
+      }
+    }
+    amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[half][c + e][phi] = v[e];
+  }
+  __syncthreads();
+  if (live) {
+    const int k = t >> 3, q = t & 7;
+    unsigned hb[4], lb[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split16_hi_lo(tile[half][k][q * 4 + e] * sc, hb[e], lb[e]);
+    const int sidx = q >> 2, c = (q & 3) * 4;
+    char* dst = out + ((g * units + u) * 2) * 1024 + (k >> 2) * 256 + sidx * 128 + (k & 3) * 32 + c * 2;
+    *reinterpret_cast<u32x2*>(dst) = (u32x2){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+    *reinterpret_cast<u32x2*>(dst + 1024) = (u32x2){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+  }
+  s16::s16_commit_block_max(T, amax, red, blockIdx.x, gridDim.x);
 }
 
 // ---- plan: which body per layer, how many contraction splits -----------------------------------------------------------------
@@ -913,7 +1104,7 @@ extern "C" int clica_mlp_planes_from_f32_t(const float* X, int64_t ldx, int64_t 
   return launch_status("clica_mlp_planes_from_f32_t");
 }
 
-static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, const char* who) {
+static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, const char* who, bool f16 = false) {
   static const int forced = [] { const char* e = getenv("CLICA_SPLIT_GEMM_TILE"); return e ? atoi(e) : -1; }();     // 0 / 1 / 2 (tuning)
   // 128 x 256 tiles when the output is wide enough, else 256 x 128; with whole rounds of 256 x 256 tiles in front where they fit
   // (mixed tiling, see gemm_split_k).  CLICA_SPLIT_GEMM_TILE = 0 / 1 / 2 forces one shape, 3 / unset = this rule.
@@ -939,9 +1130,15 @@ static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, c
   g.gps = g.groups;
   GroupArgs G{};
   G.n = 1; G.p[0] = g; G.first[0] = 0; G.first[1] = G.total = total;
-  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
+  if (f16) {
+    static bool once16 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_of<1>()), true);
+    (void)once16;
+    hipLaunchKernelGGL(gemm_split_k<1>, dim3((unsigned)G.total), dim3(THREADS), lds_bytes_of<1>(), st, G);
+    return launch_status(who);
+  }
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBytes), true);
   (void)once;
-  hipLaunchKernelGGL(gemm_split_k, dim3((unsigned)G.total), dim3(THREADS), kLdsBytes, st, G);
+  hipLaunchKernelGGL(gemm_split_k<0>, dim3((unsigned)G.total), dim3(THREADS), kLdsBytes, st, G);
   return launch_status(who);
 }
 static bool aligned16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -985,4 +1182,85 @@ extern "C" int clica_linear_split_dgrad(const void* dzT_planes, const void* wN_p
   g.outN = reinterpret_cast<char*>(dxN_planes); g.fuN = planes::units(K, 0);
   g.outF = dX; g.ldf = lddx;
   return launch_gemm_split(g, M, K, as_stream(stream), "clica_linear_split_dgrad");
+}
+
+// ---- f16x2 variants of the per-layer entry points (config 3's wide chain; include/clica.h "f16x2 arithmetic") -------------------------
+// Tensors are named by (family, index) in the caller's Split16 state: family 0 = activations (index l = INPUT of layer l), 1 = gradients
+// (index l = dZ_l), 2 = weights (index l).  Producers run on the scale in force and record their maximum for the next update.
+static int s16_ok(const void* state, int family, int index, const char* who) {
+  CLICA_CHECK_ARG(state && family >= 0 && family <= 2 && index >= 0 && index < s16::Split16State::NT, "%s: bad state / tensor (%d, %d)", who, family, index);
+  return CLICA_OK;
+}
+extern "C" int clica_mlp_planes16_from_f32(const float* X, int64_t ldx, int64_t M, int32_t width, int32_t ones_column, void* planes_out,
+                                           void* state, int32_t family, int32_t index, clica_stream_t stream) {
+  CLICA_CHECK_ARG(X && planes_out && M > 0 && width >= 1 && ldx >= width, "clica_mlp_planes16_from_f32: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(planes_out) & 15) == 0, "clica_mlp_planes16_from_f32: plane buffer must be 16-byte aligned");
+  int rc = s16_ok(state, family, index, "clica_mlp_planes16_from_f32"); if (rc) return rc;
+  const int units = planes::units(width, ones_column);
+  const int64_t groups = planes::groups_alloc(M);
+  hipLaunchKernelGGL(planes16_from_f32_k, dim3((unsigned)ceil_div(groups * units, 2)), dim3(256), 0, as_stream(stream),
+                     X, ldx, M, (int)width, ones_column ? 1 : 0, units, reinterpret_cast<char*>(planes_out), groups,
+                     s16::s16_tensor(reinterpret_cast<s16::Split16State*>(state), family, index));
+  return launch_status("clica_mlp_planes16_from_f32");
+}
+extern "C" int clica_mlp_planes16_from_f32_t(const float* X, int64_t ldx, int64_t M, int32_t width, void* planes_out,
+                                             void* state, int32_t family, int32_t index, clica_stream_t stream) {
+  CLICA_CHECK_ARG(X && planes_out && M > 0 && width >= 1 && ldx >= width, "clica_mlp_planes16_from_f32_t: bad argument");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(planes_out) & 15) == 0, "clica_mlp_planes16_from_f32_t: plane buffer must be 16-byte aligned");
+  CLICA_CHECK_ARG(M < ((int64_t)1 << 31) - 64, "clica_mlp_planes16_from_f32_t: M too large");
+  int rc = s16_ok(state, family, index, "clica_mlp_planes16_from_f32_t"); if (rc) return rc;
+  const int units = planes::units((int)M, 0);
+  const int64_t groups = planes::groups_alloc(width);
+  hipLaunchKernelGGL(planes16_from_f32_t_k, dim3((unsigned)ceil_div(groups * units, 2)), dim3(256), 0, as_stream(stream),
+                     X, ldx, M, (int)width, units, reinterpret_cast<char*>(planes_out), groups,
+                     s16::s16_tensor(reinterpret_cast<s16::Split16State*>(state), family, index));
+  return launch_status("clica_mlp_planes16_from_f32_t");
+}
+extern "C" int clica_linear_split_fwd16(const void* xT_planes, const void* wT_planes, const float* bias, int64_t M, int32_t N, int32_t K,
+                                        int32_t leaky, float slope, void* yT_planes, void* yN_planes, int32_t yN_ones,
+                                        float* Y, int64_t ldy, void* state, int32_t layer, clica_stream_t stream) {
+  CLICA_CHECK_ARG(xT_planes && wT_planes && M > 0 && N >= 1 && K >= 1, "clica_linear_split_fwd16: bad argument");
+  CLICA_CHECK_ARG(M < ((int64_t)1 << 31) - 512, "clica_linear_split_fwd16: M too large");
+  CLICA_CHECK_ARG(yT_planes || yN_planes || Y, "clica_linear_split_fwd16: no output");
+  CLICA_CHECK_ARG(!Y || ldy >= N, "clica_linear_split_fwd16: leading dimension too small");
+  CLICA_CHECK_ARG(aligned16p(xT_planes) && aligned16p(wT_planes) && aligned16p(yT_planes) && aligned16p(yN_planes),
+                  "clica_linear_split_fwd16: plane buffers must be 16-byte aligned");
+  int rc = s16_ok(state, 0, layer + 1, "clica_linear_split_fwd16"); if (rc) return rc;
+  s16::Split16State* st16 = reinterpret_cast<s16::Split16State*>(state);
+  Prob g{};
+  g.A = reinterpret_cast<const char*>(xT_planes); g.fuA = planes::units((int)M, 0);
+  g.B = reinterpret_cast<const char*>(wT_planes); g.fuB = planes::units(N, 0);
+  g.M = (int)M; g.N = N; g.groups = (int)planes::groups_used(K);
+  g.epi = 1; g.leaky = leaky ? 1 : 0; g.slope = slope; g.bias = bias;
+  g.outT = reinterpret_cast<char*>(yT_planes); g.fuT = planes::units((int)M, 0);
+  g.outN = reinterpret_cast<char*>(yN_planes); g.fuN = planes::units(N, yN_ones ? 1 : 0);
+  g.outF = Y; g.ldf = ldy;
+  g.scaleA = &st16->sA[layer]; g.scaleB = &st16->sW[layer];            // X = input of `layer`, W = its weights
+  g.outS = s16::s16_tensor(st16, 0, layer + 1);                         // Y = input of layer + 1
+  return launch_gemm_split(g, M, N, as_stream(stream), "clica_linear_split_fwd16", true);
+}
+extern "C" int clica_linear_split_dgrad16(const void* dzT_planes, const void* wN_planes, const void* actT_planes, float slope,
+                                          int64_t M, int32_t N, int32_t K, void* dxT_planes, void* dxN_planes,
+                                          float* dX, int64_t lddx, void* state, int32_t layer, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dzT_planes && wN_planes && M > 0 && N >= 1 && K >= 1, "clica_linear_split_dgrad16: bad argument");
+  CLICA_CHECK_ARG(M < ((int64_t)1 << 31) - 512, "clica_linear_split_dgrad16: M too large");
+  CLICA_CHECK_ARG(dxT_planes || dxN_planes || dX, "clica_linear_split_dgrad16: no output");
+  CLICA_CHECK_ARG(!dX || lddx >= K, "clica_linear_split_dgrad16: leading dimension too small");
+  CLICA_CHECK_ARG(aligned16p(dzT_planes) && aligned16p(wN_planes) && aligned16p(actT_planes) && aligned16p(dxT_planes) && aligned16p(dxN_planes),
+                  "clica_linear_split_dgrad16: plane buffers must be 16-byte aligned");
+  CLICA_CHECK_ARG(layer >= 1, "clica_linear_split_dgrad16: layer must be >= 1 (its output is dZ of layer - 1)");
+  int rc = s16_ok(state, 1, layer, "clica_linear_split_dgrad16"); if (rc) return rc;
+  s16::Split16State* st16 = reinterpret_cast<s16::Split16State*>(state);
+  Prob g{};
+  g.A = reinterpret_cast<const char*>(dzT_planes); g.fuA = planes::units((int)M, 0);
+  g.B = reinterpret_cast<const char*>(wN_planes); g.fuB = planes::units(K, 0);
+  g.M = (int)M; g.N = K; g.groups = (int)planes::groups_used(N);
+  g.epi = 2; g.slope = slope;
+  g.signT = reinterpret_cast<const char*>(actT_planes); g.fuS = planes::units((int)M, 0);
+  g.outT = reinterpret_cast<char*>(dxT_planes); g.fuT = planes::units((int)M, 0);
+  g.outN = reinterpret_cast<char*>(dxN_planes); g.fuN = planes::units(K, 0);
+  g.outF = dX; g.ldf = lddx;
+  g.scaleA = &st16->sD[layer]; g.scaleB = &st16->sW[layer];            // dZ_layer, W_layer
+  g.outS = s16::s16_tensor(st16, 1, layer - 1);                         // dZ_{layer - 1}
+  return launch_gemm_split(g, M, K, as_stream(stream), "clica_linear_split_dgrad16", true);
 }

@@ -132,8 +132,10 @@ class ContrastiveTrainer:
         arith = (split_arith or os.environ.get("CLICA_SPLIT_ARITH", "f16")).lower()
         if arith not in ("f16", "bf16"):
             raise ValueError(f"split_arith must be 'f16' or 'bf16', got {arith!r}")
-        self.split_f16 = bool(self.split_bf16 and arith == "f16" and 0.0 < self.slope < 1.0 and self.device.type == "cuda")
-        self.s16 = ops.Split16(len(self.linears), self.device) if self.split_f16 else None
+        self._arith_f16 = bool(arith == "f16" and 0.0 < self.slope < 1.0 and self.device.type == "cuda")
+        self.split_f16 = bool(self.split_bf16 and self._arith_f16)          # whole-stack kernels in f16x2
+        self.split_f16_wide = False                                          # per-layer wide path in f16x2 (decided in _allocate)
+        self.s16 = None
         self._s16_calibrated = False
         self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         if self.world > 1:
@@ -144,6 +146,9 @@ class ContrastiveTrainer:
             dist.broadcast(self.gW, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0,
                            group=process_group)
         self._allocate()
+        if self.split_f16 or self.split_f16_wide:
+            self.s16 = ops.Split16(len(self.linears), self.device)
+            self._init_wide_ones()
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         # data parallel + grouped weight gradients: the grouped launch is issued in TWO halves (layers L-1 .. h, then h-1 .. 0) and
         # the first half's slice of the gradient arena is all-reduced on the communication stream while the second half's GEMMs run
@@ -284,10 +289,13 @@ class ContrastiveTrainer:
                                      and all(lin.bias is not None for lin in self.linears)
                                      and os.environ.get("CLICA_SPLIT_WGRAD_WIDE", "1") != "0")
         if self.split_wgrad_wide:
+            # (round 5) the per-layer split kernels in the f16x2 arithmetic too: plane copies of 4 B/element, three products, per-tensor scales
+            # in the same Split16 state (tensor = (family, layer): activations by the layer they feed, gradients and weights by their layer)
+            self.split_f16_wide = f16w = bool(self._arith_f16 and L <= 8)
             self.wide_kinds = [ops.mlp_wgrad_split_kind(lin.out_features, lin.in_features) for lin in self.linears]
             in_w = [lin.in_features for lin in self.linears]
-            self.xin_planes = [ops.mlp_planes_alloc(R, in_w[l], True, dev) if self.wide_kinds[l] == 0 else None for l in range(L)]
-            self.dzw_planes = [ops.mlp_planes_alloc(R, widths[l], False, dev) if self.wide_kinds[l] == 0 else None for l in range(L)]
+            self.xin_planes = [ops.mlp_planes_alloc(R, in_w[l], True, dev, f16=f16w) if self.wide_kinds[l] == 0 else None for l in range(L)]
+            self.dzw_planes = [ops.mlp_planes_alloc(R, widths[l], False, dev, f16=f16w) if self.wide_kinds[l] == 0 else None for l in range(L)]
             shapes = [tuple(lin.weight.shape) for lin in self.linears]
             self.wide_ws = max((ops.mlp_wgrad_split_workspace(R, [shapes[l]], dev) for l in range(L) if self.wide_kinds[l] == 0),
                                key=lambda t: t.numel(), default=None)
@@ -303,13 +311,13 @@ class ContrastiveTrainer:
             self.chain = {l for l in range(1, L - 1) if self.wide_kinds[l] == 0 and in_w[l] >= cmin and widths[l] >= cmin}
         if self.chain:
             in_w = [lin.in_features for lin in self.linears]
-            self.wT = {l: ops.mlp_planes_alloc(in_w[l], widths[l], False, dev) for l in self.chain}      # planes of W^T
-            self.wN = {l: ops.mlp_planes_alloc(widths[l], in_w[l], False, dev) for l in self.chain}      # planes of W
-            self.xT = {l: ops.mlp_planes_alloc(in_w[l], R, False, dev) for l in self.chain}              # T-planes of the layer input
-            self.dzT = {l: ops.mlp_planes_alloc(widths[l], R, False, dev) for l in self.chain}           # T-planes of dZ_l
-            for l in self.chain:                              # the epilogues never touch the ones column of the N-planes they fill
-                if l + 1 < L and self.wide_kinds[l + 1] == 0:
-                    ops.mlp_planes_from_f32(torch.zeros((R, widths[l]), **f32), True, out=self.xin_planes[l + 1])
+            f16w = self.split_f16_wide
+            self.wT = {l: ops.mlp_planes_alloc(in_w[l], widths[l], False, dev, f16=f16w) for l in self.chain}      # planes of W^T
+            self.wN = {l: ops.mlp_planes_alloc(widths[l], in_w[l], False, dev, f16=f16w) for l in self.chain}      # planes of W
+            self.xT = {l: ops.mlp_planes_alloc(in_w[l], R, False, dev, f16=f16w) for l in self.chain}              # T-planes of the layer input
+            self.dzT = {l: ops.mlp_planes_alloc(widths[l], R, False, dev, f16=f16w) for l in self.chain}           # T-planes of dZ_l
+            if not f16w:
+                self._init_wide_ones()
             self._wide_packed = False
         if self.head is not None:
             self.head_part = torch.empty(((R + 255) // 256, n if isinstance(self.head, ls.SoftclipLayer) else 1), **f32)
@@ -317,6 +325,21 @@ class ContrastiveTrainer:
             self.head_param = hp.data if isinstance(hp, nn.Parameter) else hp.to(dev).contiguous()
             self.head_learnable = isinstance(hp, nn.Parameter)
             self.dpre = torch.empty((R, n), **f32)
+
+    def _init_wide_ones(self):
+        """The fused epilogues of the wide chain never touch the constant-1 column of the N-planes they fill: written once here."""
+        if not getattr(self, "chain", None):
+            return
+        L, R = len(self.linears), 2 * self.B
+        widths = [lin.out_features for lin in self.linears]
+        for l in self.chain:
+            if l + 1 < L and self.wide_kinds[l + 1] == 0:
+                ops.mlp_planes_from_f32(torch.zeros((R, widths[l]), dtype=torch.float32, device=self.device), True, out=self.xin_planes[l + 1],
+                                        **self._s16w(0, l + 1))
+
+    def _s16w(self, family: int, index: int) -> dict:
+        """Keyword arguments that name a tensor of the f16x2 state for the per-layer producers (empty in the bf16x3 arithmetic)."""
+        return dict(state=self.s16, tensor=(family, index)) if self.split_f16_wide else {}
 
     # -------------------------------------------------------------------------------- data
     def sample(self):
@@ -393,22 +416,23 @@ class ContrastiveTrainer:
             chain = getattr(self, "chain", set())
             if chain and not (self._wide_packed and self._packed_current):
                 for l in chain:                             # plane copies of the CURRENT weights, both orientations
-                    ops.mlp_planes_from_f32_t(self.linears[l].weight, out=self.wT[l])
-                    ops.mlp_planes_from_f32(self.linears[l].weight, False, out=self.wN[l])
+                    ops.mlp_planes_from_f32_t(self.linears[l].weight, out=self.wT[l], **self._s16w(2, l))
+                    ops.mlp_planes_from_f32(self.linears[l].weight, False, out=self.wN[l], **self._s16w(2, l))
                 self._wide_packed = self._packed_current = True
             R = self.x.shape[0]
             for l, lin in enumerate(self.linears):
                 fed = (l - 1) in chain                      # the previous layer's epilogue already wrote this layer's plane operands
                 if wide and self.wide_kinds[l] == 0 and not fed:        # this layer's input as bf16 planes for its weight gradient
-                    ops.mlp_planes_from_f32(cur, True, out=self.xin_planes[l])
+                    ops.mlp_planes_from_f32(cur, True, out=self.xin_planes[l], **self._s16w(0, l))
                 if l in chain:
                     if not fed:
-                        ops.mlp_planes_from_f32_t(cur, out=self.xT[l])
+                        ops.mlp_planes_from_f32_t(cur, out=self.xT[l], **self._s16w(0, l))
                     nxt = (l + 1) in chain
                     out = None if nxt else self.acts[l]
                     ops.linear_split_fwd(self.xT[l], self.wT[l], lin.bias, R, lin.out_features, lin.in_features, l < L - 1, self.slope,
                                          yT=self.xT[l + 1] if nxt else None,
-                                         yN=self.xin_planes[l + 1] if (l + 1 < L and self.wide_kinds[l + 1] == 0) else None, yN_ones=True, y=out)
+                                         yN=self.xin_planes[l + 1] if (l + 1 < L and self.wide_kinds[l + 1] == 0) else None, yN_ones=True, y=out,
+                                         **(dict(state=self.s16, layer=l) if self.split_f16_wide else {}))
                     cur = out
                     continue
                 ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=self.slope, out=self.acts[l])
@@ -542,6 +566,8 @@ class ContrastiveTrainer:
         fp32 value.  Inspection / tests."""
         R, w = self.x.shape[0], self.linears[l].out_features
         if l in getattr(self, "chain", set()) and (l + 1) in self.chain:
+            if self.split_f16_wide:
+                return ops.mlp_planes16_to_f32(self.xin_planes[l + 1], R, w, True, self.s16.read()["last_scales_a"][l + 1])
             return ops.mlp_planes_to_f32(self.xin_planes[l + 1], R, w, True)
         if self.acts_out[l] is None:
             if self.split_f16:       # the planes of the last step are scaled by the activation scale that step ran with
@@ -556,8 +582,9 @@ class ContrastiveTrainer:
         dW, db = self._gviews[id(lin.weight)], self._gviews[id(lin.bias)]
         if getattr(self, "split_wgrad_wide", False) and self.wide_kinds[l] == 0:
             if not planes_ready:                            # (a split data-gradient epilogue has written dZ_l's planes already)
-                ops.mlp_planes_from_f32(g, False, out=self.dzw_planes[l])
-            ops.mlp_wgrad_split(self.x.shape[0], [self.dzw_planes[l]], [self.xin_planes[l]], [None], [None], [dW], [db], ws=self.wide_ws)
+                ops.mlp_planes_from_f32(g, False, out=self.dzw_planes[l], **self._s16w(1, l))
+            ops.mlp_wgrad_split(self.x.shape[0], [self.dzw_planes[l]], [self.xin_planes[l]], [None], [None], [dW], [db], ws=self.wide_ws,
+                                **(dict(state=self.s16, a_index=[l], d_index=[l]) if self.split_f16_wide else {}))
         else:
             ops.linear_wgrad(g, inp, dW=dW, db=db, accumulate=False, ws=ws)
 
@@ -645,7 +672,7 @@ class ContrastiveTrainer:
                 # dZ_{l-1} = (dZ_l W_l) * LeakyReLU'(acts_{l-1}) on the split bodies: T-planes in, gate from the T-planes of the
                 # layer input, T-planes out for the next chain layer, N-planes out for the weight gradient of layer l - 1
                 if not dzT_ready:
-                    ops.mlp_planes_from_f32_t(g, out=self.dzT[l])
+                    ops.mlp_planes_from_f32_t(g, out=self.dzT[l], **self._s16w(1, l))
                 prev = (l - 1) in chain
                 out = None
                 if not prev:
@@ -654,7 +681,8 @@ class ContrastiveTrainer:
                     out = self.dbuf[nxt][:, :lin.in_features]
                 dxN = self.dzw_planes[l - 1] if self.wide_kinds[l - 1] == 0 else None
                 ops.linear_split_dgrad(self.dzT[l], self.wN[l], self.xT[l], self.slope, R, lin.out_features, lin.in_features,
-                                       dxT=self.dzT[l - 1] if prev else None, dxN=dxN, dx=out)
+                                       dxT=self.dzT[l - 1] if prev else None, dxN=dxN, dx=out,
+                                       **(dict(state=self.s16, layer=l) if self.split_f16_wide else {}))
                 dzT_ready, dzN_ready = prev, dxN is not None
                 g = out
                 if out is not None:
@@ -682,7 +710,7 @@ class ContrastiveTrainer:
         fused_update = ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / (self.world * self.dry_ranks),
                                      ticket=self.adam_ticket if (self.fuse_tick and not ticked) else None, t_offset=0 if ticked else 1,
-                                     s16=self.s16 if self.split_f16 else None)
+                                     s16=self.s16)
         self._s16_updated = bool(fused_update)
         if not self.fuse_tick and not ticked:
             ops.tick(self.step_dev)
@@ -691,7 +719,7 @@ class ContrastiveTrainer:
     def _step_body(self, sample: bool):
         # the fragment-order weight copies only depend on the parameters: pack them on the side stream while the
         # main stream samples the batch and runs the mixing net
-        if self.split_f16 and not self._s16_calibrated:
+        if self.s16 is not None and not self._s16_calibrated:
             self.calibrate_scales(sample)
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         side = self.side_stream
@@ -714,7 +742,7 @@ class ContrastiveTrainer:
         self.loss_forward_backward()
         self.backward()
         self.optimizer_step()
-        if self.split_f16 and not getattr(self, "_s16_updated", False):
+        if self.s16 is not None and not getattr(self, "_s16_updated", False):
             self.s16.update()                  # this step's recorded maxima -> the next step's scales (normally inside the Adam launch)
 
     def calibrate_scales(self, sample: bool = True, passes: Optional[int] = None):
@@ -724,7 +752,7 @@ class ContrastiveTrainer:
         back, so the first real step draws the very batch it would have drawn.  L + 1 passes: a producer measures its output in fp32
         BEFORE it is cut to fp16, so a pass on scales of 1 gets every activation right, but a gradient of 1e-8 is flushed on its way into
         the next chain link and that link then measures nothing -- each pass settles (at least) one more link of the chain."""
-        if not self.split_f16:
+        if self.s16 is None:
             return
         passes = len(self.linears) + 1 if passes is None else int(passes)
         if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
@@ -748,11 +776,11 @@ class ContrastiveTrainer:
     def arith_state(self) -> dict:
         """Which encoder arithmetic runs and, for f16x2, the state of its scales (host read + sync: log points, tests).  A non-zero
         `flags` means a tensor outgrew its scale by more than 64 x within one step: the step that raised it is not to be trusted."""
-        if not self.split_bf16:
+        if self.s16 is not None:
+            return dict(arith="f16x2" if self.split_f16 else "f16x2 (per-layer wide path; narrow layers native fp32 MFMA)", **self.s16.read())
+        if not (self.split_bf16 or getattr(self, "split_wgrad_wide", False)):
             return dict(arith="native_fp32")
-        if not self.split_f16:
-            return dict(arith="bf16x3")
-        return dict(arith="f16x2", **self.s16.read())
+        return dict(arith="bf16x3")
 
     def step(self):
         """One unsupervised step with on-device sampling.  Returns the device tensor
@@ -779,11 +807,11 @@ class ContrastiveTrainer:
         and then replay in lock-step."""
         # warm-up launches (lazy kernel-attribute setup, allocator) must not count as training: snapshot
         # and restore parameters, optimizer state and the device step / RNG counter around them
-        if self.split_f16 and not self._s16_calibrated:
+        if self.s16 is not None and not self._s16_calibrated:
             self.calibrate_scales(True)
         # (also what makes a step depend on its predecessors besides the parameters: the f16x2 scales, and the loss workspace -- the
         #  matrix-core sweeps build their planes on the grid the previous call measured, csrc/lp_mfma.h)
-        state = (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.loss_ws) + ((self.s16.buf,) if self.split_f16 else ())
+        state = (self.param_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.loss_ws) + ((self.s16.buf,) if self.s16 is not None else ())
         snap = [t.clone() for t in state]
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))

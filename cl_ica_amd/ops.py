@@ -224,13 +224,18 @@ def mlp_planes_alloc(M: int, width: int, ones: bool, device, zero: bool = True, 
     return (torch.zeros if zero else torch.empty)(nbytes, dtype=torch.uint8, device=device)
 
 
-def mlp_planes_from_f32(x: torch.Tensor, ones: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16 plane copy (operand format of `mlp_wgrad_split`) of a fp32 [M, width] tensor (clica_mlp_planes_from_f32)."""
+def mlp_planes_from_f32(x: torch.Tensor, ones: bool, out: Optional[torch.Tensor] = None, state=None, tensor=None) -> torch.Tensor:
+    """Plane copy (operand format of `mlp_wgrad_split`) of a fp32 [M, width] tensor: bf16x3 (clica_mlp_planes_from_f32), or -- with a
+    `Split16` state and `tensor` = (family, index) in it -- f16x2 on that tensor's scale (clica_mlp_planes16_from_f32)."""
     (x, ldx) = _mat("x", x)
     M, width = x.shape
     if out is None:
-        out = mlp_planes_alloc(M, width, ones, x.device, zero=False)
-    check(load().clica_mlp_planes_from_f32(x.data_ptr(), ldx, M, width, 1 if ones else 0, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32")
+        out = mlp_planes_alloc(M, width, ones, x.device, zero=False, f16=state is not None)
+    if state is None:
+        check(load().clica_mlp_planes_from_f32(x.data_ptr(), ldx, M, width, 1 if ones else 0, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32")
+    else:
+        check(load().clica_mlp_planes16_from_f32(x.data_ptr(), ldx, M, width, 1 if ones else 0, out.data_ptr(), state.buf.data_ptr(),
+                                                 int(tensor[0]), int(tensor[1]), stream_ptr()), "clica_mlp_planes16_from_f32")
     return out
 
 
@@ -256,14 +261,18 @@ def mlp_planes16_to_f32(buf: torch.Tensor, rows: int, feats: int, ones: bool, sc
     return v.permute(0, 2, 4, 1, 3, 5).reshape(groups * 16, units * 32)[:rows, :feats].contiguous()
 
 
-def mlp_planes_from_f32_t(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """T-planes of a fp32 [M, width] tensor = bf16 planes of its transpose (rows = feature, features = batch row): the A operand of
-    `linear_split_fwd` / `linear_split_dgrad` (clica_mlp_planes_from_f32_t)."""
+def mlp_planes_from_f32_t(x: torch.Tensor, out: Optional[torch.Tensor] = None, state=None, tensor=None) -> torch.Tensor:
+    """T-planes of a fp32 [M, width] tensor = planes of its transpose (rows = feature, features = batch row): the A operand of
+    `linear_split_fwd` / `linear_split_dgrad` (clica_mlp_planes_from_f32_t; f16x2 with `state` / `tensor` as in mlp_planes_from_f32)."""
     (x, ldx) = _mat("x", x)
     M, width = x.shape
     if out is None:
-        out = mlp_planes_alloc(width, M, False, x.device)
-    check(load().clica_mlp_planes_from_f32_t(x.data_ptr(), ldx, M, width, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32_t")
+        out = mlp_planes_alloc(width, M, False, x.device, f16=state is not None)
+    if state is None:
+        check(load().clica_mlp_planes_from_f32_t(x.data_ptr(), ldx, M, width, out.data_ptr(), stream_ptr()), "clica_mlp_planes_from_f32_t")
+    else:
+        check(load().clica_mlp_planes16_from_f32_t(x.data_ptr(), ldx, M, width, out.data_ptr(), state.buf.data_ptr(), int(tensor[0]), int(tensor[1]),
+                                                   stream_ptr()), "clica_mlp_planes16_from_f32_t")
     return out
 
 
@@ -271,7 +280,8 @@ def _pp(t):
     return t.data_ptr() if t is not None else None
 
 
-def linear_split_fwd(xT, wT, bias, M: int, N: int, K: int, leaky: bool, slope: float, yT=None, yN=None, yN_ones: bool = True, y=None):
+def linear_split_fwd(xT, wT, bias, M: int, N: int, K: int, leaky: bool, slope: float, yT=None, yN=None, yN_ones: bool = True, y=None,
+                     state=None, layer=None):
     """One wide nn.Linear (+ LeakyReLU) forward in split-bf16 arithmetic from T-plane operands (clica_linear_split_fwd)."""
     ldy = 0
     if y is not None:
@@ -279,11 +289,15 @@ def linear_split_fwd(xT, wT, bias, M: int, N: int, K: int, leaky: bool, slope: f
         if y.dim() != 2 or y.stride(1) != 1:
             raise ValueError("y must be a 2-D tensor with contiguous rows")
         ldy = y.stride(0)
-    check(load().clica_linear_split_fwd(xT.data_ptr(), wT.data_ptr(), _pp(bias), int(M), int(N), int(K), 1 if leaky else 0, float(slope),
-                                        _pp(yT), _pp(yN), 1 if yN_ones else 0, _pp(y), ldy, stream_ptr()), "clica_linear_split_fwd")
+    args = (xT.data_ptr(), wT.data_ptr(), _pp(bias), int(M), int(N), int(K), 1 if leaky else 0, float(slope), _pp(yT), _pp(yN),
+            1 if yN_ones else 0, _pp(y), ldy)
+    if state is None:
+        check(load().clica_linear_split_fwd(*args, stream_ptr()), "clica_linear_split_fwd")
+    else:      # f16x2: operands are the state's tensors A[layer] / W[layer], the output is A[layer + 1]
+        check(load().clica_linear_split_fwd16(*args, state.buf.data_ptr(), int(layer), stream_ptr()), "clica_linear_split_fwd16")
 
 
-def linear_split_dgrad(dzT, wN, actT, slope: float, M: int, N: int, K: int, dxT=None, dxN=None, dx=None):
+def linear_split_dgrad(dzT, wN, actT, slope: float, M: int, N: int, K: int, dxT=None, dxN=None, dx=None, state=None, layer=None):
     """dX = (dZ W) * LeakyReLU'(layer input) of one wide layer in split-bf16 arithmetic (clica_linear_split_dgrad)."""
     ldd = 0
     if dx is not None:
@@ -291,8 +305,11 @@ def linear_split_dgrad(dzT, wN, actT, slope: float, M: int, N: int, K: int, dxT=
         if dx.dim() != 2 or dx.stride(1) != 1:
             raise ValueError("dx must be a 2-D tensor with contiguous rows")
         ldd = dx.stride(0)
-    check(load().clica_linear_split_dgrad(dzT.data_ptr(), wN.data_ptr(), _pp(actT), float(slope), int(M), int(N), int(K),
-                                          _pp(dxT), _pp(dxN), _pp(dx), ldd, stream_ptr()), "clica_linear_split_dgrad")
+    args = (dzT.data_ptr(), wN.data_ptr(), _pp(actT), float(slope), int(M), int(N), int(K), _pp(dxT), _pp(dxN), _pp(dx), ldd)
+    if state is None:
+        check(load().clica_linear_split_dgrad(*args, stream_ptr()), "clica_linear_split_dgrad")
+    else:      # f16x2: operands D[layer] / W[layer], the output is D[layer - 1]
+        check(load().clica_linear_split_dgrad16(*args, state.buf.data_ptr(), int(layer), stream_ptr()), "clica_linear_split_dgrad16")
 
 
 def mlp_wgrad_split_kind(N: int, K: int) -> int:

@@ -366,7 +366,7 @@ int clica_mlp_wgrad_split(int64_t M, int32_t n_layers, const void* const* dZ_pla
  * native fp32-MFMA kernels' level (tests: every engine family in this arithmetic at 1e-5).
  * Order of one training step on a state: clica_mlp_pack_split16_both -> clica_mlp_fwd_split16 -> clica_mlp_dgrad_split16 ->
  * clica_mlp_wgrad_split16 -> clica_split16_update.  Plane buffers hold 2 KB per unit (clica_mlp_planes16_bytes); everything else
- * (fragment order, sign bits, the constant-1 feature -- stored as the activation's scale --, argument meaning) is as for the
+ * (fragment order, sign bits, the constant-1 feature -- stored as 1.0; the weight-gradient kernel takes X's scale out of dW only --, argument meaning) is as for the
  * bf16x3 entry points of the same name without "16".  Needs a LeakyReLU slope in (0, 1). */
 int clica_split16_state_bytes(size_t* bytes);
 int clica_split16_state_init(void* state, clica_stream_t stream);
@@ -396,6 +396,20 @@ int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* const* dZ_p
                             float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
                             int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
                             void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
+/* f16x2 variants of the per-layer entry points (BASELINE config 3's wide chain).  A tensor is named by (family, index) in the state:
+ * family 0 = activations (index l = the INPUT of layer l), 1 = gradients (index l = dZ_l), 2 = weights (index l); here the caller passes
+ * a_index[l] = l and d_index[l] = l to clica_mlp_wgrad_split16.  The constant-1 feature of an N-plane buffer is 1.0 (not the scale). */
+int clica_mlp_planes16_from_f32(const float* X, int64_t ldx, int64_t M, int32_t width, int32_t ones_column, void* planes_out,
+                                void* state, int32_t family, int32_t index, clica_stream_t stream);
+int clica_mlp_planes16_from_f32_t(const float* X, int64_t ldx, int64_t M, int32_t width, void* planes_out,
+                                  void* state, int32_t family, int32_t index, clica_stream_t stream);
+int clica_linear_split_fwd16(const void* xT_planes, const void* wT_planes, const float* bias, int64_t M, int32_t N, int32_t K,
+                             int32_t leaky, float slope, void* yT_planes, void* yN_planes, int32_t yN_ones,
+                             float* Y, int64_t ldy, void* state, int32_t layer, clica_stream_t stream);
+int clica_linear_split_dgrad16(const void* dzT_planes, const void* wN_planes, const void* actT_planes, float slope,
+                               int64_t M, int32_t N, int32_t K, void* dxT_planes, void* dxN_planes,
+                               float* dX, int64_t lddx, void* state, int32_t layer, clica_stream_t stream);
 
 /* Weight/bias gradients of ALL layers in two launches (one grouped split-K GEMM over equal-length work items
  * + one grouped deterministic slab reduction):  dW[l] = dZ[l]^T X[l]  ([N_l, K_l]),  db[l] = column sums of dZ[l]
