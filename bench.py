@@ -165,7 +165,7 @@ def roofline_leg(tr, reps=20):
                 + (" (+ slab_reduce_k)" if op == "wgrad" else ""))
 
     chain = getattr(tr, "chain", set())
-    chain_key = ("linear_fwd+linear_dgrad (wide layers)", "clica::wsplit::gemm_split_k")
+    chain_key = ("linear_fwd+linear_dgrad (wide layers)", "clica::wsplit::gemm_split_k<%d>" % (1 if getattr(tr, "split_f16_wide", False) else 0))
     wide_w = bool(getattr(tr, "split_wgrad_wide", False))
     split = bool(getattr(tr, "split_bf16", False))
     fused_sym = (("clica::fmlp::mlp_split_k<1>" if getattr(tr, "split_f16", False) else "clica::fmlp::mlp_split_k<0>") if split
@@ -378,9 +378,12 @@ def roofline_leg(tr, reps=20):
     elif chain_key in groups:
         # wide encoder with the split chain: the symbol with the largest share is the split GEMM of the 2000 x 2000 layers
         top = [r for r in rows if r["op"] == chain_key[0]][0]
-        peak, issued_factor = PEAK_BF16_MFMA_TFLOPS, 6.0
-        note = ("f32 results from six bf16 products of exact 3-way bf16 operand splits (v_mfma_f32_32x32x16_bf16, fp32 accumulate); "
-                "operands as bf16 planes of the transposed tensors, fused bias / LeakyReLU / gate / re-split epilogue")
+        f16w = bool(getattr(tr, "split_f16_wide", False))
+        peak, issued_factor = PEAK_BF16_MFMA_TFLOPS, (3.0 if f16w else 6.0)
+        note = (("f32 results from three fp16 products of two-piece fp16 operand splits with per-tensor scales (v_mfma_f32_32x32x16_f16, fp32 accumulate); "
+                 "operands as fp16 planes of the transposed tensors, fused bias / LeakyReLU / gate / re-split epilogue") if f16w else
+                ("f32 results from six bf16 products of exact 3-way bf16 operand splits (v_mfma_f32_32x32x16_bf16, fp32 accumulate); "
+                 "operands as bf16 planes of the transposed tensors, fused bias / LeakyReLU / gate / re-split epilogue"))
     else:
         top = [r for r in rows if r["op"] == "linear_fwd"][0]
         note = "f32 (v_mfma_f32_32x32x2_f32)"
@@ -693,10 +696,12 @@ def secondary_leg(args, device, steps=20, windows=3):
     a.n, a.space_type, a.p = 40, "sphere", 1
     res = {"workload": "main_mlp.py --n 40 --space-type sphere --p 1 --batch-size 6144 (BASELINE configs[2], one rank's work)",
            "encoder_gflop_per_step": round(3 * 2 * 13632000 * 2 * a.batch_size / 1e9, 1),
-           "dtype": ("f32: the 2000 x 2000 layers via bf16x3 split (forward, data and weight gradients: gemm_split_k / wgrad_split_k); narrow "
-                     "layers native fp32 MFMA forward / data gradient, bf16x3 split weight gradients")}
+           "dtype": None}
     for name, ranks in (("pool_6144", 1), ("pool_49152_emulated_8_ranks", 8)):
         tr = build_trainer(a, device, 1, emulate_pool_ranks=ranks)
+        sp = "f16x2 split (3 fp16 MFMA products, per-tensor scales)" if getattr(tr, "split_f16_wide", False) else "bf16x3 split"
+        res["dtype"] = (f"f32: the 2000 x 2000 layers via {sp} (forward, data and weight gradients: gemm_split_k / wgrad_split_k); narrow "
+                        f"layers native fp32 MFMA forward / data gradient, {sp} weight gradients")
         capture_or_eager(tr, a, 0, 1, device)
         w, _ = timed_windows(tr, steps, 5, windows, 1, device)
         el = float(np.median(w))
@@ -921,8 +926,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": (("f32 via f16x2 split (3 fp16 MFMA products of scaled two-piece operands, fp32 accumulate)" if getattr(tr, "split_f16", False)
                    else "f32 via bf16x3 split (6 bf16 MFMA products, fp32 accumulate)") if split else
-                  (("f32 via bf16x3 split on the 2000-wide layers (forward, data and weight gradients); native fp32 MFMA on the narrow ones"
-                    if getattr(tr, "chain", None) else "f32 (forward / data gradients native fp32 MFMA; weight gradients via bf16x3 split)")
+                  ((("f32 via %s split on the 2000-wide layers (forward, data and weight gradients); native fp32 MFMA on the narrow ones"
+                     if getattr(tr, "chain", None) else "f32 (forward / data gradients native fp32 MFMA; weight gradients via %s split)")
+                    % ("f16x2" if getattr(tr, "split_f16_wide", False) else "bf16x3"))
                    if wide_split else "f32")), "data": "synthetic",
         "global_steps_per_s": args.steps / elapsed,
         "warmup_extra_steps": extra_warm, "windows": len(window_s), "timed_steps_total": args.steps * len(window_s), "timing": "median window of `windows` x `steps` steps",
