@@ -307,7 +307,9 @@ class ContrastiveTrainer:
         self.chain = set()
         if self.split_wgrad_wide and os.environ.get("CLICA_SPLIT_WIDE_CHAIN", "1") != "0":
             in_w = [lin.in_features for lin in self.linears]
-            cmin = int(os.environ.get("CLICA_SPLIT_CHAIN_MIN", "1024"))
+            # (bf16x3: 1024 -- with the 400-wide layers in the chain one p = 1 gradient check of G13 measures 1.1e-5; f16x2: 384 -- all of
+            #  config 3's checks hold 1e-5 and the step gains 13 %: 198 -> 225 steps/s)
+            cmin = int(os.environ.get("CLICA_SPLIT_CHAIN_MIN", "384" if self.split_f16_wide else "1024"))
             self.chain = {l for l in range(1, L - 1) if self.wide_kinds[l] == 0 and in_w[l] >= cmin and widths[l] >= cmin}
         if self.chain:
             in_w = [lin.in_features for lin in self.linears]
