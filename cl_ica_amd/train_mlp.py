@@ -239,11 +239,21 @@ def _main(argv=None):
             (l, _), _ = du.linear_disentanglement(z1, z1_rec, mode="r2")
             (pm, _), _ = du.permutation_disentanglement(z1, z1_rec, mode="pearson", solver="munkres", rescaling=True)
             final_lin.append(l); final_perm.append(pm)
+    engine_state = None
+    if fused:      # what the engine ran on (f16x2 scales / overflow flag, the loss guard's counters): part of the run's record
+        st, gs = trainer.arith_state(), trainer.loss_guard()
+        engine_state = dict(arith=st.get("arith"), f16_flags=st.get("flags"), loss_max_spread=gs["max_spread"], loss_spread_limit=gs["limit"],
+                            loss_fallback_steps=gs["fallback_steps"])
+        log(f"engine: encoder arithmetic {st.get('arith')}" + (f", scale flags {st.get('flags')}" if "flags" in st else "") +
+            f"; p = 2 loss guard: largest spread M = {gs['max_spread']:.0f} (limit {gs['limit']:.0f}), {gs['fallback_steps']} calls on the difference sweeps")
+        if st.get("flags"):
+            raise RuntimeError("the f16x2 encoder arithmetic flagged an overflow (a tensor outgrew its scale by > 64 x within one step): "
+                               "results of this run are not to be trusted; rerun with CLICA_SPLIT_ARITH=bf16")
     log("linear mean: {} std: {}".format(np.mean(final_lin), np.std(final_lin)))
     log("perm mean: {} std: {}".format(np.mean(final_perm), np.std(final_perm)))
     if world > 1:
         torch.distributed.destroy_process_group()
-    return dict(linear=float(np.mean(final_lin)), perm=float(np.mean(final_perm)), losses=total_loss_values)
+    return dict(linear=float(np.mean(final_lin)), perm=float(np.mean(final_perm)), losses=total_loss_values, engine=engine_state)
 
 
 if __name__ == "__main__":
