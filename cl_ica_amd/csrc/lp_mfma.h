@@ -26,8 +26,9 @@ void set_enabled(int on);                   // process-wide override of CLICA_LP
 
 // `spread` = 64 device words (256 B, zeroed with the workspace) in front of the planes.  The planes of a call are built on a grid step
 // D and an origin that were MEASURED BY THE PREVIOUS CALL (round 5: the separate launch that measured them first -- 7 us, latency-bound --
-// is gone).  Any origin inside the data is valid and any D with max |x'| / D < 256 keeps the hi x hi product exact; every prep workgroup
-// checks the latter for its rows and a violation (the cloud grew across a power of two since the last call; the very first call) sends
+// is gone).  Any origin inside the data is valid and any D with max |x'| / D < 512 keeps the hi x hi product exact (D aims at
+// [128, 256); a row in [256, 512) lands on the 2 D grid and only carries a larger remainder); every prep workgroup
+// checks the latter for its rows and a violation (the cloud more than doubled since the last call; the very first call) sends
 // THIS call to the difference sweeps through the guard below.  No locks, no resets between kernels of one call:
 //   [W_RUN_M]      float   largest M any call has seen (diagnostic; atomicMax on the bits)
 //   [W_M64, +1]    u64     (call id << 32) | bits of this call's M          -- tagged atomicMax: an older call's value can never win

@@ -172,7 +172,11 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
     if (threadIdx.x == 0) {
       const unsigned long long tag = (unsigned long long)call << 32;
       unsigned long long* w64 = reinterpret_cast<unsigned long long*>(words);
-      const bool viol = !(amax * invD < 256.f) || !(m <= 3.0e38f);        // hi pieces beyond 8 bits (or non-finite rows): the expansion is not exact here
+      // A row up to 2 x beyond the grid is still exact: its hi piece is cut to 8 significant bits, i.e. lands on the 2 D grid (sums of
+      // products of integers < 512 stay below 2^24 multiples of D^2 / 2), only its remainder is up to D instead of D / 2.  Violation =
+      // beyond that (the cloud more than doubled since the last call; the very first call), or non-finite rows.  (With the check at 256 a
+      // 300 000-step run fell back on 8 % of its calls -- the cloud's max |x'| breathing across a power of two -- profiles/r5_long_run_*.)
+      const bool viol = !(amax * invD < 512.f) || !(m <= 3.0e38f);
       atomicMax(w64 + W_M64 / 2, tag | (unsigned long long)__float_as_uint(fminf(fmaxf(m, 0.f), 3.0e38f)));
       atomicMax(w64 + W_V64 / 2, tag | (viol ? 1ull : 0ull));
       if (!viol) atomicMax(reinterpret_cast<int*>(words + W_RUN_M), __float_as_int(fminf(fmaxf(m, 0.f), 3.0e38f)));      // (a call without a grid measures M against a stale origin)
