@@ -623,6 +623,36 @@ def test_p2_train_sweeps_on_matrix_cores_spread_limit():
         PARITY.check("p2_train_guarded", f"box edge {edge} (M = {M:.0f}, {path})", "dz1", dz[:B], g1)
     assert 0 < expected_fallbacks < len(edges), "the sweep of edges must cross the limit"
     assert abs(_guard_state(d, ws)["max_spread"] - max(r[4] for r in refs.values())) < 2e-3 * max(r[4] for r in refs.values())
+    # (A2) a cloud that GROWS between two calls: the planes of the second call sit on the grid the smaller cloud left behind.  Up to 2 x
+    #      beyond that grid the expansion stays exact (rows on the doubled grid step), so the call stays on the matrix cores and holds
+    #      1e-5; beyond 2 x it falls back.  (The reference's training moves the cloud's extent by per cents per step.)
+    ws3 = torch.zeros(nb.value, dtype=torch.uint8, device="cuda")
+    z6, zt6, li6, g6, M6 = refs[6.0]
+
+    def one_call(z, zt, ws, bwd):
+        zd, ztd = dev(z), dev(zt)
+        o = torch.empty(3 * B + 3, device="cuda"); dz = torch.empty(2 * B, n, device="cuda")
+        st = _lib.stream_ptr()
+        _lib.check(lib.clica_lp_loss_fwd_train(C.byref(d), zd.data_ptr(), n, ztd.data_ptr(), n, zd.data_ptr(), n, o[:B].data_ptr(), o[B:2 * B].data_ptr(),
+                                               o[2 * B:3 * B].data_ptr(), dz[:B].data_ptr(), n, dz[B:].data_ptr(), n, ws.data_ptr(), ws.numel(), st), "fwd_train")
+        if bwd:
+            _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(d), zd.data_ptr(), n, zd.data_ptr(), n, o[2 * B:3 * B].data_ptr(), o[2 * B:3 * B].data_ptr(),
+                                                       dz[:B].data_ptr(), n, o[3 * B:].data_ptr(), None, ws.data_ptr(), ws.numel(), st), "bwd_sym_train")
+        torch.cuda.synchronize()
+        return o.cpu().numpy(), dz.cpu().numpy()
+
+    centre = z6.mean(axis=0, keepdims=True)
+    # (the grid step leaves max |x'| / D in [124, 248): growth <= 2 x always stays below 512, growth > 4.2 x never does)
+    for shrink, stays in ((1.0 / 1.7, True), (1.0 / 4.5, False)):
+        zs = (centre + shrink * (z6 - centre)).astype(np.float32); zts = (centre + shrink * (zt6 - centre)).astype(np.float32)
+        one_call(zs, zts, ws3, False); one_call(zs, zts, ws3, False)              # the grid of the SMALL cloud is in force and measured
+        before = _guard_state(d, ws3)["fallback_steps"]
+        o, dz = one_call(z6, zt6, ws3, True)                                      # the cloud grew by 1 / shrink since the last call
+        fell = _guard_state(d, ws3)["fallback_steps"] - before
+        assert fell == (0 if stays else 1), (shrink, fell)
+        case = f"box edge 6 right after the same cloud at edge {6 * shrink:.2f} ({'matrix cores, rows beyond the grid' if stays else 'difference sweeps'})"
+        PARITY.check("p2_train_guarded", case, "loss_i", o[:B], li6)
+        PARITY.check("p2_train_guarded", case, "dz1", dz[:B], g6)
     # (B) the guard lifted: the raw error curve of the matrix-core sweeps
     _lib.check(lib.clica_lp_loss_set_spread_limit(1e30), "lift")
     try:
