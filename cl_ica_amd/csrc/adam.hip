@@ -14,10 +14,12 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
                                                  float* __restrict__ v, int64_t count, float lr, float b1, float b2, float eps,
                                                  float gscale, int32_t* __restrict__ step_dev, int32_t* __restrict__ ticket, int t_offset,
                                                  s16::Split16State* s16_state, int s16_layers) {
-  // f16x2 encoder arithmetic: the scale update of the step (split16.h) rides in this launch as ONE extra workgroup -- every producer
-  // of the step has finished by stream order, and the next step's pack launch (the first reader of the new scales) comes behind it
-  const unsigned nwork = gridDim.x - (s16_state ? 1u : 0u);
-  if (s16_state && blockIdx.x == nwork) { s16::split16_update_body(s16_state, s16_layers); return; }
+  // f16x2 encoder arithmetic: the scale update of the step (split16.h) rides in this launch as its FIRST kS16UpdateBlocks workgroups,
+  // one tensor each -- every producer of the step has finished by stream order, and the next step's pack launch (the first reader of
+  // the new scales) comes behind it
+  const unsigned nupd = s16_state ? (unsigned)s16::kS16UpdateBlocks : 0u;
+  if (blockIdx.x < nupd) { s16::split16_update_tensor(s16_state, s16_layers, (int)blockIdx.x); return; }
+  const unsigned nwork = gridDim.x - nupd, block = blockIdx.x - nupd;
   __shared__ float s_step_size, s_inv_bc2_sqrt;
   if (threadIdx.x == 0) {
     const double t = (double)(step_dev[0] + t_offset);
@@ -33,7 +35,7 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
   const int64_t stride = (int64_t)nwork * THREADS;
   float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
   float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
-  for (int64_t i = (int64_t)blockIdx.x * THREADS + threadIdx.x; i < n4; i += stride) {
+  for (int64_t i = (int64_t)block * THREADS + threadIdx.x; i < n4; i += stride) {
     float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
     float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
@@ -45,7 +47,7 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
     }
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
   }
-  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * THREADS + threadIdx.x; i < count; i += stride) {
+  for (int64_t i = n4 * 4 + (int64_t)block * THREADS + threadIdx.x; i < count; i += stride) {
     const float gr = g[i] * gscale;
     const float mn = b1 * m[i] + omb1 * gr;
     const float vn = b2 * v[i] + omb2 * gr * gr;
@@ -80,7 +82,7 @@ static int adam_launch(float* param, const float* grad, float* exp_avg, float* e
   int64_t blocks = ceil_div(ceil_div(count, 4), adam::THREADS);
   if (blocks > kNumCU * 8) blocks = kNumCU * 8;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks + (s16_state ? 1u : 0u)), dim3(adam::THREADS), 0, as_stream(stream),
+  hipLaunchKernelGGL(adam::adam_k, dim3((unsigned)blocks + (s16_state ? (unsigned)s16::kS16UpdateBlocks : 0u)), dim3(adam::THREADS), 0, as_stream(stream),
                      param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, t_offset,
                      reinterpret_cast<s16::Split16State*>(s16_state), s16_layers);
   return launch_status("clica_adam_step");

@@ -683,7 +683,7 @@ template <> struct Arith<1> {
   static constexpr int XORDER[2] = {0, 1};
 };
 using s16::kF16Target; using s16::kF16Alarm; using s16::Split16State; using s16::kS16CapWG; using s16::kS16CapPW;
-using s16::s16_partA; using s16::s16_partD; using s16::s16_partW; using s16::split16_update_body;
+using s16::s16_partA; using s16::s16_partD; using s16::s16_partW; using s16::split16_update_tensor;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 template <int AR>
@@ -806,7 +806,7 @@ __global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
   }
 }
 
-__global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) { split16_update_body(st, L); }
+__global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) { split16_update_tensor(st, L, (int)blockIdx.x); }
 __global__ __launch_bounds__(64) void split16_init_k(Split16State* st, unsigned capWG, unsigned capPW) {
   const int t = threadIdx.x;
   if (t < Split16State::NT) st->sA[t] = st->sD[t] = st->sW[t] = st->sWC[t] = st->pA[t] = st->pD[t] = 1.f;
@@ -2099,7 +2099,7 @@ extern "C" int clica_split16_state_init(void* state, clica_stream_t stream) {
 }
 extern "C" int clica_split16_update(void* state, int32_t n_layers, clica_stream_t stream) {
   CLICA_CHECK_ARG(state && n_layers >= 1 && n_layers <= fmlp::MAXL, "clica_split16_update: bad argument");
-  hipLaunchKernelGGL(fmlp::split16_update_k, dim3(1), dim3(256), 0, as_stream(stream), reinterpret_cast<fmlp::Split16State*>(state), (int)n_layers);
+  hipLaunchKernelGGL(fmlp::split16_update_k, dim3(s16::kS16UpdateBlocks), dim3(256), 0, as_stream(stream), reinterpret_cast<fmlp::Split16State*>(state), (int)n_layers);
   return launch_status("clica_split16_update");
 }
 extern "C" int clica_split16_read(const void* state, int32_t* flags, int32_t* updates, float* scales_a, float* scales_d, float* scales_w,

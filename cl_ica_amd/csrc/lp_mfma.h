@@ -30,9 +30,9 @@ void set_enabled(int on);                   // process-wide override of CLICA_LP
 // [128, 256); a row in [256, 512) lands on the 2 D grid and only carries a larger remainder); every prep workgroup
 // checks the latter for its rows and a violation (the cloud more than doubled since the last call; the very first call) sends
 // THIS call to the difference sweeps through the guard below.  No locks, no resets between kernels of one call:
-//   [W_RUN_M]      float   largest M any call has seen (diagnostic; atomicMax on the bits)
+//   [W_RUN_M]      float   largest M any call with a valid grid has seen (diagnostic; kept by the forward sweep's workgroup 0)
 //   [W_M64, +1]    u64     (call id << 32) | bits of this call's M          -- tagged atomicMax: an older call's value can never win
-//   [W_V64, +1]    u64     (call id << 32) | 1 if a row violated the grid    -- written by EVERY prep workgroup (0 or 1), so the latest tag is this call's
+//   [W_V64, +1]    u64     (call id << 32) | 1 -- written only by a prep workgroup whose rows violated the grid; valid when its tag equals W_M64's
 //   [W_CALL]       u32     call id, advanced by workgroup (0, 0) of the forward sweep (prep has finished; nobody else reads it afterwards)
 //   [W_FALLBACKS]  float   number of calls that fell back
 //   [W_MAXABS_CUR] float   max |x'| the current grid step derives from;  [W_MAXABS_NEXT]: accumulated by this call's prep for the next one
@@ -41,11 +41,19 @@ void set_enabled(int on);                   // process-wide override of CLICA_LP
 //                          feature planes, the backward sweep) -- the forward sweep's workgroup (0, 0) moves NEXT -> CUR meanwhile
 constexpr int W_RUN_M = 0, W_M64 = 2, W_V64 = 4, W_CALL = 6, W_FALLBACKS = 7, W_MAXABS_CUR = 8, W_MAXABS_NEXT = 9,
               W_ORIGIN_CUR = 16, W_ORIGIN_NEXT = 32, W_ORIGIN_USED = 48;
-// what a gated kernel reads: {M64, V64} -> fall back when this call's M exceeds the limit or a row violated the grid
+// what a gated kernel reads: {M64, V64} -> fall back when this call's M exceeds the limit or a row violated the grid.  Every prep
+// workgroup sends its M with the call's tag, so after prep the tag of W_M64 is this call's id; W_V64 is only written on a violation
+// and counts when it carries the same tag.  (The id is 32 bits: a workspace is good for 4.29e9 calls.)
+__device__ __forceinline__ bool guard_violated(const float* words) {
+  const unsigned long long* w64 = reinterpret_cast<const unsigned long long*>(words);
+  const unsigned long long m64 = w64[W_M64 / 2], v64 = w64[W_V64 / 2];
+  return (v64 >> 32) == (m64 >> 32) && (v64 & 1ull) != 0ull;
+}
 __device__ __forceinline__ bool guard_falls_back(const float* words, float limit) {
   const unsigned long long* w64 = reinterpret_cast<const unsigned long long*>(words);
-  const float m = __uint_as_float((unsigned)w64[W_M64 / 2]);
-  return m > limit || (unsigned)w64[W_V64 / 2] != 0u;
+  const unsigned long long m64 = w64[W_M64 / 2], v64 = w64[W_V64 / 2];
+  const float m = __uint_as_float((unsigned)m64);
+  return m > limit || ((v64 >> 32) == (m64 >> 32) && (v64 & 1ull) != 0ull);
 }
 struct Ws { float* spread; void* own_rows; void* pool_rows; void* pool_feat; size_t bytes; };
 

@@ -100,10 +100,13 @@ __device__ __forceinline__ f32x16 logit_block(const u32x4 (&a)[3], const u32x4 (
 // Nr = sum (hi r + r^2 / 2) in a second accumulator; the two are added on the vector ALU.  Measured: section "spread" of the tests.
 // Slots (K = 16 = n + 6, n <= 10): coordinates 0..n-1; pool rows: ones at n..n+2, own norms at n+3..n+5; anchors the other way round;
 // own norm slots: hi plane = the three pieces of -Nh, mid plane = the three pieces of -Nr; rows >= `rows` of the pool: -Nr = -1e30.
-__global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
-                                             const float* __restrict__ Xa, int64_t lda, int64_t rows_a, u32x4* __restrict__ RPa,
-                                             int n, float pre2, float* __restrict__ words) {
-  // one launch for both operands: blocks [0, pool_blocks) the pool (role 0), the rest the anchors (role 1); two tiles per block
+constexpr int PREP_TILES = 8;                         // tiles (32 rows each) per prep workgroup: 4 waves x 2
+__global__ __launch_bounds__(256) void prep_k(const float* __restrict__ Xp, int64_t ldp, int64_t rows_p, u32x4* __restrict__ RPp, int pool_blocks,
+                                              int pool_tiles, const float* __restrict__ Xa, int64_t lda, int64_t rows_a, u32x4* __restrict__ RPa,
+                                              int own_tiles, int n, float pre2, float* __restrict__ words) {
+  // one launch for both operands: blocks [0, pool_blocks) the pool (role 0), the rest the anchors (role 1); PREP_TILES tiles per block.
+  // (Round 5: 256 rows and TWO atomics per workgroup.  With one wave per workgroup and four same-line atomics each -- 768 of them at
+  //  B = 6144, serialised in one L2 channel -- the launch took 17 us; the arithmetic is a few hundred instructions per row.)
   const int role = (int)blockIdx.x >= pool_blocks ? 1 : 0;
   // the grid of THIS call (measured by the previous one, lp_mfma.h) and, for the next call, the mean of the pool's first <= 64 rows --
   // computed by every workgroup the same way (one wave, fixed shuffle tree: identical everywhere), so that each can measure ITS rows
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
   {
     // (all MAX_N loads in flight before the first shuffle: as a loop over n with a load + six shuffles per turn this was ten
     //  dependent memory round trips in front of every workgroup's real work -- 17 us for the launch, profiles/r5_summary.md)
-    const int lane64 = threadIdx.x;
+    const int lane64 = threadIdx.x & 63;           // (every wave for itself: no barrier in front of the real work)
     const int cnt = rows_p < 64 ? (int)rows_p : 64;
     float v[MAX_N];
 #pragma unroll
@@ -133,13 +136,14 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
   const float* __restrict__ X = role ? Xa : Xp;
   const int64_t ldx = role ? lda : ldp, rows = role ? rows_a : rows_p;
   u32x4* __restrict__ RP = role ? RPa : RPp;
-  const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * 2 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+  const int tile = ((int)blockIdx.x - (role ? pool_blocks : 0)) * PREP_TILES + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+  const bool tile_ok = tile < (role ? own_tiles : pool_tiles);
   // grid step: the power of two with max |x'| / D in [64, 128)
   const unsigned xb = __float_as_uint(words[W_MAXABS_CUR] * 1.03125f);      // (a 3 % margin: a cloud that merely breathes does not cross the power of two)
   const int ex = (int)((xb >> 23) & 0xffu) - 7;      // biased exponent of max |x'|, minus 7: max / D in [128, 256), hi = 8-bit integers x D
   const float D = __uint_as_float((unsigned)(ex < 1 ? 1 : ex) << 23), invD = 1.f / D;
   const int64_t j = (int64_t)tile * ROWS + lane;
-  const bool live = j < rows;
+  const bool live = tile_ok && j < rows;
   unsigned hb[KSLOTS], mb[KSLOTS], lb[KSLOTS];
   float nh = 0.f, nr = 0.f, amax = 0.f, amax_next = 0.f;
 #pragma unroll
@@ -164,12 +168,18 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
   }
   nh *= 0.5f;
   {      // M of this call (the guard: anchors and pool rows both enter the expansion), the grid check, the next call's max |x'|
+    __shared__ float red[3][4];
     float m = live ? nh + nr : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       m = fmaxf(m, __shfl_xor(m, off, 64)); amax = fmaxf(amax, __shfl_xor(amax, off, 64)); amax_next = fmaxf(amax_next, __shfl_xor(amax_next, off, 64));
     }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = amax; red[2][threadIdx.x >> 6] = amax_next; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+      m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+      amax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+      amax_next = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
       const unsigned long long tag = (unsigned long long)call << 32;
       unsigned long long* w64 = reinterpret_cast<unsigned long long*>(words);
       // A row up to 2 x beyond the grid is still exact: its hi piece is cut to 8 significant bits, i.e. lands on the 2 D grid (sums of
@@ -177,9 +187,8 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
       // beyond that (the cloud more than doubled since the last call; the very first call), or non-finite rows.  (With the check at 256 a
       // 300 000-step run fell back on 8 % of its calls -- the cloud's max |x'| breathing across a power of two -- profiles/r5_long_run_*.)
       const bool viol = !(amax * invD < 512.f) || !(m <= 3.0e38f);
-      atomicMax(w64 + W_M64 / 2, tag | (unsigned long long)__float_as_uint(fminf(fmaxf(m, 0.f), 3.0e38f)));
-      atomicMax(w64 + W_V64 / 2, tag | (viol ? 1ull : 0ull));
-      if (!viol) atomicMax(reinterpret_cast<int*>(words + W_RUN_M), __float_as_int(fminf(fmaxf(m, 0.f), 3.0e38f)));      // (a call without a grid measures M against a stale origin)
+      atomicMax(w64 + W_M64 / 2, tag | (unsigned long long)__float_as_uint(fminf(fmaxf(m, 0.f), 3.0e38f)));      // every workgroup: the tag of W_M64 IS this call's id
+      if (viol) atomicMax(w64 + W_V64 / 2, tag | 1ull);                                                            // (read against that tag: guard_falls_back)
       atomicMax(reinterpret_cast<int*>(words + W_MAXABS_NEXT), __float_as_int(fminf(amax_next, 3.0e38f)));
     }
   }
@@ -197,6 +206,7 @@ __global__ __launch_bounds__(64) void prep_k(const float* __restrict__ Xp, int64
       lb[k] = 0u;
     }
   }
+  if (!tile_ok) return;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     unsigned t8[8];
@@ -278,6 +288,7 @@ __global__ __launch_bounds__(THREADS, 2) void fwd_k(const u32x4* __restrict__ RP
     if (threadIdx.x == 0) {
       words[W_MAXABS_CUR] = words[W_MAXABS_NEXT]; words[W_MAXABS_NEXT] = 0.f;
       reinterpret_cast<unsigned*>(words)[W_CALL] += 1u;
+      if (!guard_violated(words)) words[W_RUN_M] = fmaxf(words[W_RUN_M], words[W_M64]);      // (a call without a grid measures M against a stale origin)
     }
   }
   if (fall_back) {                                  // the guard (lp_mfma.h): this call runs on the coordinate differences
@@ -621,8 +632,9 @@ Ws carve(void* base, const Plan& P) {
 void launch_prep(const Plan& P, const Ws& w, const float* own, int64_t ldo, int64_t n_own, const float* pool, int64_t ldp, int64_t n_pool,
                  int n, float kscale, hipStream_t st) {
   const float pre2 = sqrtf(2.f * kscale);
-  hipLaunchKernelGGL(prep_k, dim3((unsigned)((P.pool_tiles + P.own_tiles) / 2)), dim3(64), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows,
-                     (int)(P.pool_tiles / 2), own, ldo, n_own, (u32x4*)w.own_rows, n, pre2, w.spread);
+  const int pb = (int)ceil_div(P.pool_tiles, (int64_t)PREP_TILES), ob = (int)ceil_div(P.own_tiles, (int64_t)PREP_TILES);
+  hipLaunchKernelGGL(prep_k, dim3((unsigned)(pb + ob)), dim3(256), 0, st, pool, ldp, n_pool, (u32x4*)w.pool_rows, pb, (int)P.pool_tiles,
+                     own, ldo, n_own, (u32x4*)w.own_rows, (int)P.own_tiles, n, pre2, w.spread);
 }
 
 template <int T>

@@ -19,7 +19,7 @@ struct Split16State {
   // (the maxima are NOT gathered by same-address global atomics: 2 048 of them per layer cost 60 us per launch, measured; every
   //  producer leaves its maxima in slots behind this header and the update reduces them)
   unsigned cntA[NT], cntD[NT], cntW[NT];   // live slots per tensor in the tensor-major slot arrays (0: not produced since the last update)
-  unsigned nPW, capWG, capPW, pad1;        // pack waves written by the whole-stack weight pack; capacities (informational)
+  unsigned nPW, capWG, capPW, pad1;        // pack waves written by the LAST whole-stack weight pack (their maxima stay valid until the next pack); capacities (informational)
   unsigned wfirst[NT + 1];                 // pack waves [wfirst[l], wfirst[l + 1]) hold the maxima of layer l's weights
   unsigned pad0[3];
   float sA[NT], sD[NT], sW[NT], sWC[NT];
@@ -66,88 +66,64 @@ __device__ __forceinline__ void s16_commit_block_max(const S16Tensor& T, float m
 }
 
 // Maxima of the step that has just run -> scales of the next one.  s = 2^(kF16Target - floor(log2 max)); a tensor nobody wrote
-// (maximum 0) keeps its scale.  One workgroup of 256 threads: it reduces the producers' slot arrays (every thread has all its loads in
-// flight before the first use -- as a chain of dependent loads + LDS atomics this body took 17 us, longer than the optimizer launch it
-// rides in), zeroes the slots it read and raises the overflow flag when the step carried a scaled magnitude beyond kF16Alarm.
-__device__ __forceinline__ void split16_update_body(Split16State* st, int L) {
+// (maximum 0) keeps its scale.  kS16UpdateBlocks workgroups of 256 threads, ONE TENSOR EACH (family = idx / NT, position = idx % NT):
+// a workgroup reads its tensor's count and scale, then all of its slots at once, zeroes the slots it read, and raises the overflow flag
+// when the step carried a scaled magnitude beyond kF16Alarm.  (As ONE workgroup walking all 27 tensors this body took 16 us -- every
+// step a chain of dependent round trips to memory another XCD wrote -- and the 7 us optimizer launch it rides in took 18.)
+constexpr int kS16UpdateBlocks = 3 * Split16State::NT;
+__device__ __forceinline__ void split16_update_tensor(Split16State* st, int L, int idx) {
   constexpr int NT = Split16State::NT;
-  __shared__ unsigned mx[3][NT];
-  const int t = threadIdx.x, lane = t & 63;
-  if (t < 3 * NT) mx[t / NT][t % NT] = 0u;
-  // everything the header holds is requested FIRST (counts, wave ranges, this thread's scales): the state sits in memory another XCD
-  // wrote, every dependent read is a ~2 us round trip, and this body rides in a 7 us launch
-  const int tc = t < NT ? t : 0;
-  const float curA = st->sA[tc], curD = st->sD[tc], curW = st->sW[tc];
-  unsigned cA[NT], cD[NT], cW[NT], wf[NT + 1];
+  __shared__ unsigned red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fam = idx / NT, k = idx - fam * NT;
+  unsigned* cntp = fam == 0 ? &st->cntA[k] : (fam == 1 ? &st->cntD[k] : &st->cntW[k]);
+  float* sp = fam == 0 ? &st->sA[k] : (fam == 1 ? &st->sD[k] : &st->sW[k]);
+  unsigned* slots = (fam == 0 ? s16_partA(st) : (fam == 1 ? s16_partD(st) : s16_partW2(st))) + (size_t)k * kS16CapWG;
+  // header fields first, all requested together
+  const unsigned cnt = min(*cntp, kS16CapWG);
+  const float cur = *sp;
+  unsigned w0 = 0u, w1 = 0u;
+  if (fam == 2) { const unsigned nPW = min(st->nPW, kS16CapPW); w0 = min(st->wfirst[k], nPW); w1 = min(st->wfirst[k + 1], nPW); }
+  unsigned m = 0u;
+  constexpr int U = kS16CapWG / 256;                   // every slot of the tensor in flight at once
+  unsigned v[U];
 #pragma unroll
-  for (int k = 0; k < NT; ++k) { cA[k] = min(st->cntA[k], kS16CapWG); cD[k] = min(st->cntD[k], kS16CapWG); cW[k] = min(st->cntW[k], kS16CapWG); }
-  const unsigned nPW = min(st->nPW, kS16CapPW);
+  for (int u = 0; u < U; ++u) { const unsigned w = (unsigned)t + 256u * u; v[u] = w < cnt ? slots[w] : 0u; }
 #pragma unroll
-  for (int l = 0; l <= NT; ++l) wf[l] = st->wfirst[l];
-  unsigned* pA = s16_partA(st); unsigned* pD = s16_partD(st); unsigned* pW2 = s16_partW2(st); const unsigned* pW = s16_partW(st);
-  unsigned ma[NT], md[NT], mw[NT];
-  unsigned nmax = 0u, nmaxw = 0u;
+  for (int u = 0; u < U; ++u) { const unsigned w = (unsigned)t + 256u * u; m = max(m, v[u]); if (w < cnt) slots[w] = 0u; }
+  if (fam == 2) {                                      // weights packed by the whole-stack path: one maximum per pack wave, layer k's range
+    const unsigned* pW = s16_partW(st);
+    for (unsigned i0 = w0; i0 < w1; i0 += 256 * 8) {
+      unsigned q[8];
 #pragma unroll
-  for (int k = 0; k < NT; ++k) { ma[k] = 0u; md[k] = 0u; mw[k] = 0u; nmax = max(nmax, max(cA[k], cD[k])); nmaxw = max(nmaxw, cW[k]); }
-  for (unsigned w0 = 0; w0 < nmax; w0 += 256) {                  // one pass for the whole-stack kernels up to 12 288 rows
-    const unsigned w = w0 + t;
-    unsigned va[NT], vd[NT];
+      for (int u = 0; u < 8; ++u) { const unsigned i = i0 + t + 256u * u; q[u] = i < w1 ? pW[i] : 0u; }
 #pragma unroll
-    for (int k = 0; k < NT; ++k) { va[k] = w < cA[k] ? pA[(size_t)k * kS16CapWG + w] : 0u; vd[k] = w < cD[k] ? pD[(size_t)k * kS16CapWG + w] : 0u; }
-#pragma unroll
-    for (int k = 0; k < NT; ++k) {
-      ma[k] = max(ma[k], va[k]); md[k] = max(md[k], vd[k]);
-      if (w < cA[k]) pA[(size_t)k * kS16CapWG + w] = 0u;
-      if (w < cD[k]) pD[(size_t)k * kS16CapWG + w] = 0u;
+      for (int u = 0; u < 8; ++u) m = max(m, q[u]);
     }
   }
-  for (unsigned w0 = 0; w0 < nmaxw; w0 += 256) {                 // weights converted by the per-layer path
-    const unsigned w = w0 + t;
-    unsigned vw[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) vw[k] = w < cW[k] ? pW2[(size_t)k * kS16CapWG + w] : 0u;
-#pragma unroll
-    for (int k = 0; k < NT; ++k) { mw[k] = max(mw[k], vw[k]); if (w < cW[k]) pW2[(size_t)k * kS16CapWG + w] = 0u; }
-  }
-  for (unsigned i0 = 0; i0 < nPW; i0 += 256 * 8) {               // weights packed by the whole-stack path
-    unsigned v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { const unsigned i = i0 + t + 256u * u; v[u] = i < nPW ? pW[i] : 0u; }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const unsigned i = i0 + t + 256u * u;
-#pragma unroll
-      for (int l = 0; l < NT; ++l) mw[l] = (i >= wf[l] && i < wf[l + 1]) ? max(mw[l], v[u]) : mw[l];
-    }
-  }
-  __syncthreads();                                                 // mx zeroed
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    unsigned a = ma[k], d = md[k], w = mw[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a = max(a, (unsigned)__shfl_xor((int)a, off, 64)); d = max(d, (unsigned)__shfl_xor((int)d, off, 64)); w = max(w, (unsigned)__shfl_xor((int)w, off, 64));
-    }
-    if (lane == 0) { atomicMax(&mx[0][k], a); atomicMax(&mx[1][k], d); atomicMax(&mx[2][k], w); }
-  }
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+  if (lane == 0) red[wave] = m;
   __syncthreads();
-  auto next = [&](unsigned bits, float cur, int emin, int emax) {
-    const float a = __uint_as_float(bits);
-    if (!(a > 0.f)) return cur;                                 // nobody wrote the tensor: keep its scale
+  if (t != 0) return;
+  const unsigned bits = max(max(red[0], red[1]), max(red[2], red[3]));
+  const float a = __uint_as_float(bits);
+  float nxt = cur;
+  if (a > 0.f) {                                       // (nobody wrote the tensor: keep its scale)
     if (!(a < 3.0e38f) || a * cur > kF16Alarm) atomicOr(&st->flags, 1u);      // non-finite, or the step that just ran overflowed its scale
-    if (!(a < 3.0e38f)) return cur;
-    int e = (int)((bits >> 23) & 0xffu) - 127;                  // floor(log2 a) for normal a
-    if (((bits >> 23) & 0xffu) == 0u) e = -127;
-    int se = kF16Target - e;
-    se = se < emin ? emin : (se > emax ? emax : se);
-    return __uint_as_float((unsigned)(se + 127) << 23);
-  };
-  if (t < NT) { st->pA[t] = curA; st->sA[t] = next(mx[0][t], curA, -100, 100); st->cntA[t] = 0u; }
-  if (t < NT) { st->pD[t] = curD; st->sD[t] = next(mx[1][t], curD, -100, 100); st->cntD[t] = 0u; }
-  float w = 1.f;
-  if (t < NT) { w = next(mx[2][t], curW, -100, 100); st->sW[t] = w; st->cntW[t] = 0u; }
-  if (t < L && L - 1 - t >= 0 && L - 1 - t < NT) st->sWC[L - 1 - t] = w;      // chain link j uses layer L - 1 - j
-  if (t == 0) { st->updates += 1u; st->nPW = 0u; }
+    if (a < 3.0e38f) {
+      int e = (int)((bits >> 23) & 0xffu) - 127;      // floor(log2 a) for normal a
+      if (((bits >> 23) & 0xffu) == 0u) e = -127;
+      int se = kF16Target - e;
+      se = se < -100 ? -100 : (se > 100 ? 100 : se);
+      nxt = __uint_as_float((unsigned)(se + 127) << 23);
+    }
+  }
+  if (fam == 0) st->pA[k] = cur;
+  if (fam == 1) st->pD[k] = cur;
+  *sp = nxt; *cntp = 0u;
+  if (fam == 2 && k < L) st->sWC[L - 1 - k] = nxt;     // chain link j uses layer L - 1 - j
+  if (idx == 0) st->updates += 1u;
 }
 }  // namespace s16
 }  // namespace clica
