@@ -25,6 +25,13 @@ class LpLossDesc(C.Structure):
                 ("alpha", C.c_float), ("compat", c_i32), ("pow", c_i32), ("no_eps", c_i32)]
 
 
+class AdamDesc(C.Structure):
+    """clica_adam_desc (include/clica.h): the optimizer applied by clica_mlp_wgrad_split_adam's reduction launch."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("count", c_i64),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("grad_scale", C.c_float),
+                ("step_dev", C.c_void_p), ("t_offset", c_i32), ("split16_state", C.c_void_p), ("n_layers", c_i32)]
+
+
 class DotLossDesc(C.Structure):
     _fields_ = [("B", c_i64), ("B3", c_i64), ("n", c_i32), ("tau", C.c_float), ("alpha", C.c_float),
                 ("normalize", c_i32)]
@@ -113,6 +120,10 @@ SIGNATURES: Dict[str, list] = {
                                 C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                                 C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, c_size,
                                 C.c_void_p],
+    "clica_mlp_wgrad_split_adam": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
+                                   C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
+                                   C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(AdamDesc),
+                                   C.c_void_p, c_size, C.c_void_p],
     "clica_mlp_planes16_from_f32": [c_f32p, c_i64, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_mlp_planes16_from_f32_t": [c_f32p, c_i64, c_i64, c_i32, C.c_void_p, C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_linear_split_fwd16": [C.c_void_p, C.c_void_p, c_f32p, c_i64, c_i32, c_i32, c_i32, C.c_float, C.c_void_p, C.c_void_p, c_i32,

@@ -5,6 +5,7 @@
 // HBM-bound: 16 B read + 12 B written per parameter, one launch for all layers.
 #include "common.h"
 #include "split16.h"
+#include "adam_math.h"
 
 namespace clica {
 namespace adam {
@@ -20,17 +21,10 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
   const unsigned nupd = s16_state ? (unsigned)s16::kS16UpdateBlocks : 0u;
   if (blockIdx.x < nupd) { s16::split16_update_tensor(s16_state, s16_layers, (int)blockIdx.x); return; }
   const unsigned nwork = gridDim.x - nupd, block = blockIdx.x - nupd;
-  __shared__ float s_step_size, s_inv_bc2_sqrt;
-  if (threadIdx.x == 0) {
-    const double t = (double)(step_dev[0] + t_offset);
-    const double bc1 = 1.0 - pow((double)b1, t);
-    const double bc2 = 1.0 - pow((double)b2, t);
-    s_step_size = (float)((double)lr / bc1);
-    s_inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-  }
+  __shared__ Consts s_c;
+  if (threadIdx.x == 0) s_c = consts_of(step_dev[0] + t_offset, lr, b1, b2);
   __syncthreads();
-  const float step_size = s_step_size, inv_bc2_sqrt = s_inv_bc2_sqrt;
-  const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+  const Consts c = s_c;
   const int64_t n4 = count / 4;
   const int64_t stride = (int64_t)nwork * THREADS;
   float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -39,20 +33,13 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
     float4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
     float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float gr = ga[u] * gscale;
-      ma[u] = b1 * ma[u] + omb1 * gr;
-      va[u] = b2 * va[u] + omb2 * gr * gr;
-      pa[u] -= step_size * ma[u] / (sqrtf(va[u]) * inv_bc2_sqrt + eps);
-    }
+    for (int u = 0; u < 4; ++u) update(pa[u], ga[u], ma[u], va[u], c, b1, b2, eps, gscale);
     p4[i] = pp; m4[i] = mm; v4[i] = vv;
   }
   for (int64_t i = n4 * 4 + (int64_t)block * THREADS + threadIdx.x; i < count; i += stride) {
-    const float gr = g[i] * gscale;
-    const float mn = b1 * m[i] + omb1 * gr;
-    const float vn = b2 * v[i] + omb2 * gr * gr;
-    m[i] = mn; v[i] = vn;
-    p[i] -= step_size * mn / (sqrtf(vn) * inv_bc2_sqrt + eps);
+    float pn = p[i], mn = m[i], vn = v[i];
+    update(pn, g[i], mn, vn, c, b1, b2, eps, gscale);
+    m[i] = mn; v[i] = vn; p[i] = pn;
   }
   // optional fused tick: every workgroup read *step_dev on entry (same thread, earlier in program order than its
   // arrival below), so the LAST one to arrive may advance it.  Relaxed arrival counter, NO fence: nothing but that

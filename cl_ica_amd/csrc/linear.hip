@@ -18,6 +18,8 @@
 // batch) over blockIdx.z into fp32 slabs that a second tiny kernel sums deterministically.
 #include "common.h"
 #include "wgrad_shared.h"
+#include "split16.h"
+#include "adam_math.h"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -1111,34 +1113,67 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_k(const float* __rest
 // result, all its <= 8 slab loads in flight at once, summed in split order (deterministic).  The 64-units-per-block scheme above
 // is built for many short slabs and spends a whole workgroup (and an LDS pass) on 64 float4s: 138 us for a 2000 x 2000 layer with
 // four splits (80 MB, 0.6 TB/s) against ~30 us here.
-constexpr int FLAT_MAX_SPLITS = 8;
+constexpr int FLAT_MAX_SPLITS = 24;      // (round 5: 8 -> 24.  The whole-stack plan cuts its 500 x 500 problems into 18 splits; on the
+                                         //  64-units-per-block scheme they made this launch 15 us for 31 MB)
 static inline bool reduce_flat(int splits, bool v4) { return v4 && splits <= FLAT_MAX_SPLITS; }
+__device__ __forceinline__ void adam_apply4(const ReduceAdam& A, const adam::Consts& c, const float* dst, const float4& g, float4 pp, float4 mm, float4 vv) {
+  const int64_t off = dst - A.gbase;
+  adam::update(pp.x, g.x, mm.x, vv.x, c, A.b1, A.b2, A.eps, A.gscale); adam::update(pp.y, g.y, mm.y, vv.y, c, A.b1, A.b2, A.eps, A.gscale);
+  adam::update(pp.z, g.z, mm.z, vv.z, c, A.b1, A.b2, A.eps, A.gscale); adam::update(pp.w, g.w, mm.w, vv.w, c, A.b1, A.b2, A.eps, A.gscale);
+  *reinterpret_cast<float4*>(A.p + off) = pp; *reinterpret_cast<float4*>(A.m + off) = mm; *reinterpret_cast<float4*>(A.v + off) = vv;
+}
+__device__ __forceinline__ void adam_apply1(const ReduceAdam& A, const adam::Consts& c, const float* dst, float g) {
+  const int64_t off = dst - A.gbase;
+  float pp = A.p[off], mm = A.m[off], vv = A.v[off];
+  adam::update(pp, g, mm, vv, c, A.b1, A.b2, A.eps, A.gscale);
+  A.p[off] = pp; A.m[off] = mm; A.v[off] = vv;
+}
 __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupArgs G) {
   __shared__ float4 red[RED_THREADS / 64][64];
+  __shared__ adam::Consts s_c;
+  const ReduceAdam& A = G.adam;
+  const bool with_adam = A.p != nullptr;
+  const int nfront = (with_adam && A.s16_state) ? s16::kS16UpdateBlocks : 0;
+  if ((int)blockIdx.x < nfront) { s16::split16_update_tensor(reinterpret_cast<s16::Split16State*>(A.s16_state), A.s16_layers, (int)blockIdx.x); return; }
+  const int blk = (int)blockIdx.x - nfront;
+  if (with_adam && threadIdx.x == RED_THREADS - 1) s_c = adam::consts_of(A.step_dev[0] + A.t_offset, A.lr, A.b1, A.b2);
   const int w = threadIdx.x >> 6;
   int q = 0;
 #pragma unroll
-  for (int i = 1; i < MAXG; ++i) q += (i < G.n && (int)blockIdx.x >= G.first[i]) ? 1 : 0;
-  const int b = (int)blockIdx.x - G.first[q];
+  for (int i = 1; i < MAXG; ++i) q += (i < G.n && blk >= G.first[i]) ? 1 : 0;
+  const int b = blk - G.first[q];
   const int64_t M = G.M[q], N = G.N[q];
   float4 t; int64_t e;
   if (b < G.dw_blocks[q]) {
     const int64_t total = M * N;
     if (G.vec4[q] && G.splits[q] <= FLAT_MAX_SPLITS) {       // flat: RED_THREADS float4 units per block (see slab_reduce_entry)
       e = ((int64_t)b * RED_THREADS + threadIdx.x) * 4;
-      if (e >= total) return;
-      const float* src = G.slab[q] + e;
+      const bool live = e < total;
+      if (!live && !with_adam) return;
+      const int splits = live ? G.splits[q] : 0;
+      const float* src = G.slab[q] + (live ? e : 0);
+      const int64_t i = e / N, j = e - i * N;
+      float4* dst = reinterpret_cast<float4*>(G.dW[q] + (live ? i * G.lddw[q] + j : 0));
       float4 v[FLAT_MAX_SPLITS];
 #pragma unroll
       for (int sIdx = 0; sIdx < FLAT_MAX_SPLITS; ++sIdx)
-        v[sIdx] = sIdx < G.splits[q] ? *reinterpret_cast<const float4*>(src + (int64_t)sIdx * total) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[sIdx] = sIdx < splits ? *reinterpret_cast<const float4*>(src + (int64_t)sIdx * total) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 pp, mm, vv;                                     // the optimizer's operands travel with the slabs
+      if (with_adam && live) {
+        const int64_t off = reinterpret_cast<const float*>(dst) - A.gbase;
+        pp = *reinterpret_cast<const float4*>(A.p + off); mm = *reinterpret_cast<const float4*>(A.m + off); vv = *reinterpret_cast<const float4*>(A.v + off);
+      }
       t = v[0];
 #pragma unroll
       for (int sIdx = 1; sIdx < FLAT_MAX_SPLITS; ++sIdx) { t.x += v[sIdx].x; t.y += v[sIdx].y; t.z += v[sIdx].z; t.w += v[sIdx].w; }
-      const int64_t i = e / N, j = e - i * N;
-      float4* dst = reinterpret_cast<float4*>(G.dW[q] + i * G.lddw[q] + j);
-      if (G.accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
-      *dst = t;
+      if (live) {
+        if (G.accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+        *dst = t;
+      }
+      if (with_adam) {
+        __syncthreads();                                     // s_c
+        if (live) adam_apply4(A, s_c, reinterpret_cast<const float*>(dst), t, pp, mm, vv);
+      }
       return;
     }
     if (G.vec4[q]) {
@@ -1148,19 +1183,30 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupAr
         float4* dst = reinterpret_cast<float4*>(G.dW[q] + i * G.lddw[q] + j);
         if (G.accumulate) { const float4 o = *dst; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
         *dst = t;
+        if (with_adam) {
+          const int64_t off = reinterpret_cast<const float*>(dst) - A.gbase;
+          adam_apply4(A, s_c, reinterpret_cast<const float*>(dst), t, *reinterpret_cast<const float4*>(A.p + off),
+                      *reinterpret_cast<const float4*>(A.m + off), *reinterpret_cast<const float4*>(A.v + off));
+        }
       }
     } else {
       reduce_units<false>(G.slab[q], G.splits[q], total, (int64_t)b * 64, red, t, e);
       if (w == 0 && e < total) {
         const int64_t i = e / N, j = e - i * N;
         float* dst = G.dW[q] + i * G.lddw[q] + j;
-        *dst = G.accumulate ? (*dst + t.x) : t.x;
+        t.x = G.accumulate ? (*dst + t.x) : t.x;
+        *dst = t.x;
+        if (with_adam) adam_apply1(A, s_c, dst, t.x);
       }
     }
   } else {
     reduce_units<false>(G.dbslab[q], G.splits[q], M, (int64_t)(b - G.dw_blocks[q]) * 64, red, t, e);
     float* db = G.db[q];
-    if (w == 0 && e < M) db[e] = G.accumulate ? (db[e] + t.x) : t.x;
+    if (w == 0 && e < M) {
+      t.x = G.accumulate ? (db[e] + t.x) : t.x;
+      db[e] = t.x;
+      if (with_adam) adam_apply1(A, s_c, db + e, t.x);
+    }
   }
 }
 
@@ -1351,7 +1397,8 @@ int launch_wgrad_tiny(const TinyArgs& T, int splits, hipStream_t st) {
   return launch_status("clica_mlp_wgrad(tiny)");
 }
 int launch_slab_reduce_group(const ReduceGroupArgs& R, int blocks, hipStream_t st) {
-  hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)blocks), dim3(RED_THREADS), 0, st, R);
+  const int front = (R.adam.p && R.adam.s16_state) ? s16::kS16UpdateBlocks : 0;      // the f16x2 scale update in front (ReduceAdam)
+  hipLaunchKernelGGL(slab_reduce_group_k, dim3((unsigned)(blocks + front)), dim3(RED_THREADS), 0, st, R);
   return launch_status("clica_mlp_wgrad(reduce)");
 }
 int slab_reduce_entry(ReduceGroupArgs& R, int l, int first_block, int sp, const float* slab, const float* dbslab,

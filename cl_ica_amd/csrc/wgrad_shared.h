@@ -27,8 +27,19 @@ constexpr int TINY_MAX_LG = 128;    // widest large dimension: LDS tile [TINY_RO
 constexpr int TINY_THREADS = 256;
 struct TinyArgs { int n; Args p[MAXG]; };
 
+// Optional epilogue of the grouped slab reduction: the Adam update of the elements it has just reduced (adam_math.h), so that the
+// training step needs no optimizer launch of its own.  dW / db of every problem must then be views of ONE gradient arena starting at
+// `gbase`; p / m / v are the parameter / exp_avg / exp_avg_sq arenas of the same layout (element offset = address - gbase).
+// s16_state != nullptr: the f16x2 arithmetic's scale update (split16.h) rides in front of the launch, as it does in adam_k.
+struct ReduceAdam {
+  float* p; float* m; float* v; const float* gbase;      // p == nullptr: plain reduction
+  float lr, b1, b2, eps, gscale;
+  const int* step_dev; int t_offset;
+  void* s16_state; int s16_layers;
+};
 // grouped slab reduction: dW[i][j] (+)= sum_s slab[s][i][j];  db[i] (+)= sum_s dbslab[s][i]  for up to MAXG problems
 struct ReduceGroupArgs {
+  ReduceAdam adam;
   int n, accumulate;
   int splits[MAXG];
   int first[MAXG + 1];      // first block of each problem

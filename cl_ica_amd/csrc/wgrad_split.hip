@@ -994,7 +994,7 @@ static int mlp_wgrad_split_impl(int64_t M, int32_t n_layers, const void* const* 
                                 const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
                                 float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
                                 int32_t accumulate, const void* state16, const int32_t* a_index, const int32_t* d_index,
-                                void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+                                void* workspace, size_t workspace_bytes, clica_stream_t stream, const clica_adam_desc* adam = nullptr) {
   CLICA_CHECK_ARG(dZ_planes && X_planes && dZ && lddz && X && ldx && dW && lddw && db && N && K && workspace && M > 0,
                   "clica_mlp_wgrad_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_split: %d layers (1..%d supported)", n_layers, MAXG);
@@ -1007,6 +1007,28 @@ static int mlp_wgrad_split_impl(int64_t M, int32_t n_layers, const void* const* 
   gemm::ReduceGroupArgs R{};
   gemm::TinyArgs T{};
   R.n = n_layers; R.accumulate = accumulate ? 1 : 0;
+  if (adam) {      // the optimizer in the reduction's epilogue (clica_mlp_wgrad_split_adam)
+    CLICA_CHECK_ARG(adam->param && adam->grad && adam->exp_avg && adam->exp_avg_sq && adam->step_dev && adam->count > 0 && !accumulate,
+                    "clica_mlp_wgrad_split_adam: NULL arena / accumulate set");
+    CLICA_CHECK_ARG((((uintptr_t)adam->param | (uintptr_t)adam->grad | (uintptr_t)adam->exp_avg | (uintptr_t)adam->exp_avg_sq) & 15) == 0,
+                    "clica_mlp_wgrad_split_adam: arenas must be 16-byte aligned");
+    CLICA_CHECK_ARG(adam->t_offset == 0 || adam->t_offset == 1, "clica_mlp_wgrad_split_adam: t_offset must be 0 or 1");
+    CLICA_CHECK_ARG(!adam->split16_state || (adam->n_layers >= 1 && adam->n_layers <= 8), "clica_mlp_wgrad_split_adam: bad layer count");
+    int64_t covered = 0;
+    for (int l = 0; l < n_layers; ++l) {
+      CLICA_CHECK_ARG(dW[l] && db[l] && lddw[l] == K[l], "clica_mlp_wgrad_split_adam: layer %d: dW must be contiguous, db present", l);
+      CLICA_CHECK_ARG(dW[l] >= adam->grad && dW[l] + (int64_t)N[l] * K[l] <= adam->grad + adam->count && db[l] >= adam->grad &&
+                      db[l] + N[l] <= adam->grad + adam->count, "clica_mlp_wgrad_split_adam: layer %d: dW / db outside the gradient arena", l);
+      covered += (int64_t)N[l] * K[l] + N[l];
+    }
+    // every parameter of the arena must be one this call produces the gradient of (alignment padding aside: <= 3 floats per tensor)
+    CLICA_CHECK_ARG(adam->count - covered >= 0 && adam->count - covered <= 8 * (int64_t)n_layers,
+                    "clica_mlp_wgrad_split_adam: the arena holds %lld elements, the layers cover %lld", (long long)adam->count, (long long)covered);
+    R.adam.p = adam->param; R.adam.m = adam->exp_avg; R.adam.v = adam->exp_avg_sq; R.adam.gbase = adam->grad;
+    R.adam.lr = adam->lr; R.adam.b1 = adam->beta1; R.adam.b2 = adam->beta2; R.adam.eps = adam->eps; R.adam.gscale = adam->grad_scale;
+    R.adam.step_dev = adam->step_dev; R.adam.t_offset = adam->t_offset;
+    R.adam.s16_state = adam->split16_state; R.adam.s16_layers = adam->n_layers;
+  }
   int item = 0, rblock = 0, ng = 0;
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(dW[l] && N[l] >= 1 && K[l] >= 1 && lddw[l] >= K[l], "clica_mlp_wgrad_split: layer %d: bad argument", l);
@@ -1084,6 +1106,19 @@ extern "C" int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* 
   CLICA_CHECK_ARG(state && a_index && d_index, "clica_mlp_wgrad_split16: NULL state / index arrays");
   return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, accumulate, state, a_index, d_index,
                               workspace, workspace_bytes, stream);
+}
+// Weight gradients AND the optimizer: the trailing reduction launch applies Adam to every element it has just reduced (and carries the
+// f16x2 scale update in front when adam->split16_state is set), so a training step needs no optimizer launch.  state == NULL: bf16x3
+// plane copies (clica_mlp_wgrad_split), else f16x2 (clica_mlp_wgrad_split16).
+extern "C" int clica_mlp_wgrad_split_adam(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                          const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                          float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                          const void* state, const int32_t* a_index, const int32_t* d_index, const clica_adam_desc* adam,
+                                          void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(adam, "clica_mlp_wgrad_split_adam: NULL optimizer descriptor");
+  CLICA_CHECK_ARG(!state || (a_index && d_index), "clica_mlp_wgrad_split_adam: NULL index arrays");
+  return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, 0, state, a_index, d_index,
+                              workspace, workspace_bytes, stream, adam);
 }
 extern "C" int clica_mlp_planes16_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && M > 0 && width >= 1, "clica_mlp_planes16_bytes: bad argument");

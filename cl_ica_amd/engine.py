@@ -554,10 +554,19 @@ class ContrastiveTrainer:
         dWs = [self._gviews[id(self.linears[l].weight)] for l in order]
         dbs = [self._gviews[id(self.linears[l].bias)] for l in order]
         if self.split_wgrad:
+            adam = None
+            if getattr(self, "_fold_adam", False) and layers is None and not (self.fuse_tick and not self._ticked):
+                # inside a training step (N = 1): the reduction launch that ends the weight gradients applies the optimizer as well
+                # (clica_mlp_wgrad_split_adam) -- optimizer_step() then has nothing left to launch
+                adam = dict(param=self.param_arena, grad=self.grad_arena, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
+                            step_dev=self.step_dev, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], eps=self.eps,
+                            grad_scale=1.0, t_offset=0 if self._ticked else 1, s16=self.s16)
             ops.mlp_wgrad_split(R, [self.dz_planes[l] for l in order], [self.act_planes[l - 1] if l > 0 else None for l in order],
                                 [g if l == L - 1 else self.dz_out[l] for l in order],
                                 [self.acts_out[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws,
-                                state=self.s16, a_index=order, d_index=[L - 1 - l for l in order])
+                                state=self.s16, a_index=order, d_index=[L - 1 - l for l in order], adam=adam)
+            if adam is not None:
+                self._adam_done = True
         else:
             ops.mlp_wgrad([g if l == L - 1 else self.dz[l] for l in order],
                           [self.acts[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws)
@@ -705,8 +714,27 @@ class ContrastiveTrainer:
         if self.buckets is not None:
             self.buckets.wait()
 
+    def _adam_folds_into_wgrad(self) -> bool:
+        """The optimizer can ride in the weight-gradient reduction when ONE whole-stack split launch produces every gradient of the
+        arena and nothing has to happen between gradient and update (no data-parallel all-reduce, no gradient scaling)."""
+        if os.environ.get("CLICA_ADAM_IN_WGRAD", "1") == "0":
+            return False
+        if not (self.split_wgrad and self.fused_backward and self.grouped_wgrad) or self.buckets is not None:
+            return False
+        if self.world * self.dry_ranks != 1:
+            return False
+        lin_ids = {id(q) for lin in self.linears for q in (lin.weight, lin.bias)}
+        return all(lin.bias is not None for lin in self.linears) and all(id(q) in lin_ids for q in self.f.parameters())
+
     def optimizer_step(self):
         self._packed_current = False
+        if getattr(self, "_adam_done", False):       # applied by the weight-gradient reduction of this step (weight_grads)
+            self._adam_done = False
+            ticked, self._ticked = self._ticked, False
+            self._s16_updated = self.s16 is not None
+            if not ticked:
+                ops.tick(self.step_dev)
+            return
         # the last Adam workgroup to finish also advances the device step / RNG counter (no separate tick launch)
         ticked, self._ticked = self._ticked, False
         fused_update = ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
@@ -742,7 +770,11 @@ class ContrastiveTrainer:
         if st:
             ops.stamp(st["mlp_fwd"], 1)
         self.loss_forward_backward()
-        self.backward()
+        self._fold_adam = self._adam_folds_into_wgrad()
+        try:
+            self.backward()
+        finally:
+            self._fold_adam = False
         self.optimizer_step()
         if self.s16 is not None and not getattr(self, "_s16_updated", False):
             self.s16.update()                  # this step's recorded maxima -> the next step's scales (normally inside the Adam launch)

@@ -374,9 +374,11 @@ def mlp_wgrad_split_workspace(M: int, shapes, device) -> torch.Tensor:
 
 
 def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional[torch.Tensor] = None, accumulate: bool = False,
-                    state=None, a_index=None, d_index=None):
+                    state=None, a_index=None, d_index=None, adam: Optional[dict] = None):
     """Every layer's dW / db in the split-bf16 arithmetic (clica_mlp_wgrad_split).  Per layer EITHER the two plane buffers
-    (`dz_planes[l]`, `x_planes[l]`: layers with `mlp_wgrad_split_kind` 0) OR the fp32 operands (`dzs[l]`, `xs[l]`: kind 1)."""
+    (`dz_planes[l]`, `x_planes[l]`: layers with `mlp_wgrad_split_kind` 0) OR the fp32 operands (`dzs[l]`, `xs[l]`: kind 1).
+    `adam` = dict(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, grad_scale, t_offset, s16): the trailing
+    reduction launch also applies the optimizer to the arenas the dW / db views live in (clica_mlp_wgrad_split_adam)."""
     L = len(dWs)
     VP, I64, I32 = C.c_void_p * L, C.c_int64 * L, C.c_int32 * L
     dzm = [None if t is None else _mat("dz", t) for t in dzs]
@@ -389,7 +391,23 @@ def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional
             VP(*[None if m is None else m[0].data_ptr() for m in xm]), I64(*[0 if m is None else m[1] for m in xm]),
             VP(*[w.data_ptr() for w in dWs]), I64(*[w.stride(0) for w in dWs]),
             VP(*[ptr(b) for b in dbs]), I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]), 1 if accumulate else 0)
-    if state is None:
+    if adam is not None:
+        global PARAM_EPOCH
+        PARAM_EPOCH += 1
+        if accumulate:
+            raise ValueError("mlp_wgrad_split(adam=...): accumulate is not supported")
+        s16 = adam.get("s16")
+        desc = _lib.AdamDesc(param=adam["param"].data_ptr(), grad=adam["grad"].data_ptr(), exp_avg=adam["exp_avg"].data_ptr(),
+                             exp_avg_sq=adam["exp_avg_sq"].data_ptr(), count=adam["param"].numel(), lr=float(adam["lr"]),
+                             beta1=float(adam["beta1"]), beta2=float(adam["beta2"]), eps=float(adam["eps"]),
+                             grad_scale=float(adam.get("grad_scale", 1.0)), step_dev=adam["step_dev"].data_ptr(),
+                             t_offset=int(adam.get("t_offset", 1)), split16_state=None if s16 is None else s16.buf.data_ptr(),
+                             n_layers=0 if s16 is None else s16.n_layers)
+        check(load().clica_mlp_wgrad_split_adam(*args[:-1], None if state is None else state.buf.data_ptr(),
+                                                None if state is None else I32(*[int(i) for i in a_index]),
+                                                None if state is None else I32(*[int(i) for i in d_index]), C.byref(desc),
+                                                ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split_adam")
+    elif state is None:
         check(load().clica_mlp_wgrad_split(*args, ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split")
     else:      # f16x2 plane copies: per layer the positions of its operands' scales in the state (include/clica.h)
         check(load().clica_mlp_wgrad_split16(*args, state.buf.data_ptr(), I32(*[int(i) for i in a_index]), I32(*[int(i) for i in d_index]),

@@ -397,6 +397,24 @@ int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* const* dZ_p
                             int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
                             void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
+/* Weight gradients + optimizer in one call (round 5: the N = 1 training step has no optimizer launch of its own).  The reduction that
+ * ends clica_mlp_wgrad_split / _split16 applies torch.optim.Adam's update (main_mlp.py:312, as clica_adam_step_at) to every element
+ * it has just reduced; dW[l] (contiguous: lddw[l] = K[l]) and db[l] must be views of ONE gradient arena `grad` that this call covers
+ * completely (alignment padding aside), param / exp_avg / exp_avg_sq are arenas of the same layout.  The gradients are still written.
+ * split16_state != NULL: the f16x2 scale update (clica_split16_update(state, n_layers)) rides in front of the same launch.
+ * `state` (NULL: bf16x3 plane copies, else f16x2), a_index, d_index as for clica_mlp_wgrad_split16. */
+typedef struct clica_adam_desc {
+  float* param; float* grad; float* exp_avg; float* exp_avg_sq; int64_t count;
+  float lr, beta1, beta2, eps, grad_scale;
+  const int32_t* step_dev; int32_t t_offset;      /* update number = *step_dev + t_offset (0 or 1), as clica_adam_step_at */
+  void* split16_state; int32_t n_layers;
+} clica_adam_desc;
+int clica_mlp_wgrad_split_adam(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                               const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                               float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                               const void* state, const int32_t* a_index, const int32_t* d_index, const clica_adam_desc* adam,
+                               void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
 /* f16x2 variants of the per-layer entry points (BASELINE config 3's wide chain).  A tensor is named by (family, index) in the state:
  * family 0 = activations (index l = the INPUT of layer l), 1 = gradients (index l = dZ_l), 2 = weights (index l); here the caller passes
  * a_index[l] = l and d_index[l] = l to clica_mlp_wgrad_split16.  The constant-1 feature of an N-plane buffer is 1.0 (not the scale). */
@@ -568,7 +586,7 @@ int clica_adam_step_at(float* param, const float* grad, float* exp_avg, float* e
                        float lr, float beta1, float beta2, float eps, float grad_scale,
                        const int32_t* step_dev, int32_t t_offset, clica_stream_t stream);
 /* clica_adam_step_at with the f16x2 encoder arithmetic's scale update (clica_split16_update(state, n_layers)) riding in the same launch
- * as one extra workgroup: the training step's last launch then also prepares the next step's scales. */
+ * (its first 27 workgroups, one tensor each): the training step's last launch then also prepares the next step's scales. */
 int clica_adam_step_s16(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                         float lr, float beta1, float beta2, float eps, float grad_scale,
                         const int32_t* step_dev, int32_t t_offset, void* split16_state, int32_t n_layers, clica_stream_t stream);

@@ -463,6 +463,95 @@ def test_split_bf16_wgrad_matches_fp64(dims, M, arith):
         assert rel_err(dWs[l].cpu().numpy(), 2 * before[l].cpu().numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("dims,M", [([10, 100, 500, 500, 500, 500, 100, 10], 12288), ([7, 33, 512, 129, 64, 5], 1000), ([5, 100, 320, 100, 5], 16)])
+@pytest.mark.parametrize("arith", ["bf16x3", "f16x2"])
+def test_wgrad_split_adam_equals_wgrad_then_adam(dims, M, arith):
+    """clica_mlp_wgrad_split_adam (the optimizer in the epilogue of the weight gradients' reduction launch) against the two separate
+    calls on copies of the same arenas: gradients, parameters and both moment arenas bit for bit, over three updates (the bias
+    corrections move); f16x2: the scale update that rides in front of the launch leaves the same scales as clica_adam_step_s16's.
+    A dW view outside the gradient arena is refused."""
+    from cl_ica_amd import ops, _lib
+    rng = np.random.default_rng(len(dims) * 23 + M)
+    L = len(dims) - 1
+    sizes = []
+    for l in range(L):
+        sizes += [dims[l + 1] * dims[l], dims[l + 1]]
+    offs, total = [], 0
+    for k in sizes:
+        offs.append(total); total += (k + 3) // 4 * 4
+    f16 = arith == "f16x2"
+
+    def arenas():
+        a = {k: torch.zeros(total, device="cuda") for k in ("param", "grad", "exp_avg", "exp_avg_sq")}
+        r2 = np.random.default_rng(3)
+        for l in range(L):
+            w = (r2.uniform(-1, 1, size=(dims[l + 1], dims[l])) / np.sqrt(dims[l])).astype(np.float32)
+            a["param"][offs[2 * l]:offs[2 * l] + w.size] = dev(w).flatten()
+            a["param"][offs[2 * l + 1]:offs[2 * l + 1] + dims[l + 1]] = dev(r2.uniform(-0.5, 0.5, size=dims[l + 1]).astype(np.float32))
+        views = lambda t: ([t[offs[2 * l]:offs[2 * l] + sizes[2 * l]].view(dims[l + 1], dims[l]) for l in range(L)],
+                           [t[offs[2 * l + 1]:offs[2 * l + 1] + sizes[2 * l + 1]] for l in range(L)])
+        return a, views
+
+    x = dev(rng.normal(size=(M, dims[0])).astype(np.float32))
+    dy = dev((1e-4 if f16 else 1.0) * rng.normal(size=(M, dims[-1])).astype(np.float32))
+    kinds = [ops.mlp_wgrad_split_kind(dims[l + 1], dims[l]) for l in range(L)]
+    chain = list(range(L - 1, 0, -1))
+    results = []
+    for fold in (False, True):
+        a, views = arenas()
+        Ws, bs = views(a["param"]); dWs, dbs = views(a["grad"])
+        step_dev = torch.zeros(1, dtype=torch.int32, device="cuda")
+        state = ops.Split16(L, "cuda") if f16 else None
+        sk = dict(state=state, a_index=list(range(L)), d_index=[L - 1 - l for l in range(L)]) if f16 else {}
+        outs = [torch.empty(M, d, device="cuda") for d in dims[1:]]
+        masks = ops.mlp_signmask_alloc(M, L - 1, "cuda") + [None]
+        act_pl = [ops.mlp_planes_alloc(M, dims[l + 1], True, "cuda", f16=f16) if (l + 1 < L and kinds[l + 1] == 0) else None for l in range(L)]
+        dz_pl = [ops.mlp_planes_alloc(M, dims[l + 1], False, "cuda", f16=f16) if kinds[l] == 0 else None for l in range(L)]
+        dz = [torch.empty(M, dims[l], device="cuda") for l in chain]
+        packed = packed_t = None
+        for it in range(3 + (L + 1 if f16 else 0)):
+            apply = it >= (L + 1 if f16 else 0)          # f16x2: L + 1 un-applied passes settle the scales first
+            packed, packed_t = ops.mlp_pack_split_both(Ws, packed, packed_t, state=state)
+            ops.mlp_fwd_split(x, Ws, bs, outs, packed, 0.01, signmasks=masks, planes=act_pl, state=state)
+            ops.mlp_dgrad_chain_split(dy, [Ws[l] for l in chain], packed_t, dz, 0.01, masks_chain=[masks[l - 1] for l in chain],
+                                      planes=[dz_pl[l - 1] for l in chain], state=state)
+            dz_of = {l - 1: dz[j] for j, l in enumerate(chain)}; dz_of[L - 1] = dy
+            xs = [x] + outs[:-1]
+            wargs = (M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)], [dz_of[l] if kinds[l] == 1 else None for l in range(L)],
+                     [xs[l] if kinds[l] == 1 else None for l in range(L)], dWs, dbs)
+            adam = dict(param=a["param"], grad=a["grad"], exp_avg=a["exp_avg"], exp_avg_sq=a["exp_avg_sq"], step_dev=step_dev, lr=1e-3,
+                        beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, t_offset=1, s16=state)
+            if not apply:
+                ops.mlp_wgrad_split(*wargs, **sk)
+                state.update()
+                state.clear_flags()                      # (the first passes run on scales of 1: what they flag is not a finding)
+            elif fold:
+                ops.mlp_wgrad_split(*wargs, adam=adam, **sk)
+            else:
+                ops.mlp_wgrad_split(*wargs, **sk)
+                ops.adam_step(a["param"], a["grad"], a["exp_avg"], a["exp_avg_sq"], step_dev, 1e-3, s16=state)
+            if apply:
+                ops.tick(step_dev)
+        results.append(({k: v.clone() for k, v in a.items()}, None if state is None else state.read()))
+    (sep, st_sep), (fol, st_fol) = results
+    assert float(sep["param"].abs().max()) > 0 and float(sep["exp_avg_sq"].max()) > 0
+    for k in sep:
+        assert torch.equal(sep[k], fol[k]), (k, float((sep[k] - fol[k]).abs().max()))
+    if f16:
+        assert st_sep["updates"] == st_fol["updates"] and st_sep["flags"] == st_fol["flags"] == 0
+        for k in ("scales_a", "scales_d", "scales_w"):
+            assert list(st_sep[k]) == list(st_fol[k]), k
+    # a gradient view that is not part of the arena
+    a, views = arenas()
+    Ws, bs = views(a["param"]); dWs, dbs = views(a["grad"])
+    dWs[1] = torch.empty_like(dWs[1])
+    with pytest.raises(_lib.ClicaError):
+        ops.mlp_wgrad_split(M, dz_pl, [act_pl[l - 1] if l > 0 else None for l in range(L)], [dz_of[l] if kinds[l] == 1 else None for l in range(L)],
+                            [xs[l] if kinds[l] == 1 else None for l in range(L)], dWs, dbs,
+                            adam=dict(param=a["param"], grad=a["grad"], exp_avg=a["exp_avg"], exp_avg_sq=a["exp_avg_sq"], step_dev=step_dev,
+                                      lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, s16=state), **sk)
+
+
 def _stack64(x, Ws, bs, slope):
     a = np.asarray(x, np.float64)
     outs = []
