@@ -189,7 +189,8 @@ def roofline_leg(tr, reps=20):
                     lambda lin=lin, l=l, nxt=nxt: ops.linear_split_fwd(
                         tr.xT[l], tr.wT[l], lin.bias, R, lin.out_features, lin.in_features, l < L - 1, tr.slope,
                         yT=tr.xT[l + 1] if nxt else None, yN=tr.xin_planes[l + 1] if (l + 1 < L and tr.wide_kinds[l + 1] == 0) else None,
-                        yN_ones=True, y=None if nxt else tr.acts[l]))
+                        yN_ones=True, y=None if nxt else tr.acts[l],
+                        **(dict(state=tr.s16, layer=l) if getattr(tr, "split_f16_wide", False) else {})))
             else:
                 add(gemm_key("fwd", N, K), 2.0 * R * N * K,
                     lambda cur=cur, lin=lin, l=l: ops.linear_fwd(cur, lin.weight, lin.bias, leaky=(l < L - 1), slope=tr.slope, out=tr.acts[l]))
@@ -237,7 +238,8 @@ def roofline_leg(tr, reps=20):
                 add(chain_key, 2.0 * R * N * K,
                     lambda lin=lin, l=l, prev=prev, out=out: ops.linear_split_dgrad(
                         tr.dzT[l], tr.wN[l], tr.xT[l], tr.slope, R, lin.out_features, lin.in_features,
-                        dxT=tr.dzT[l - 1] if prev else None, dxN=tr.dzw_planes[l - 1] if tr.wide_kinds[l - 1] == 0 else None, dx=out))
+                        dxT=tr.dzT[l - 1] if prev else None, dxN=tr.dzw_planes[l - 1] if tr.wide_kinds[l - 1] == 0 else None, dx=out,
+                        **(dict(state=tr.s16, layer=l) if getattr(tr, "split_f16_wide", False) else {})))
                 g_ = out if out is not None else g_
             elif l > 0:
                 out = tr.dbuf[l & 1][:, :K]

@@ -32,6 +32,12 @@ class AdamDesc(C.Structure):
                 ("step_dev", C.c_void_p), ("t_offset", c_i32), ("split16_state", C.c_void_p), ("n_layers", c_i32)]
 
 
+class ChainTail(C.Structure):
+    """clica_chain_tail (include/clica.h): what the backward chain needs to leave the n-wide layers' weight-gradient slabs."""
+    _fields_ = [("a_last", C.c_void_p), ("lda", c_i64), ("x", C.c_void_p), ("ldx", c_i64), ("n_layers", c_i32),
+                ("N", C.POINTER(c_i32)), ("K", C.POINTER(c_i32)), ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", c_size)]
+
+
 class DotLossDesc(C.Structure):
     _fields_ = [("B", c_i64), ("B3", c_i64), ("n", c_i32), ("tau", C.c_float), ("alpha", C.c_float),
                 ("normalize", c_i32)]
@@ -123,7 +129,11 @@ SIGNATURES: Dict[str, list] = {
     "clica_mlp_wgrad_split_adam": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
                                    C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                                    C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(AdamDesc),
-                                   C.c_void_p, c_size, C.c_void_p],
+                                   c_i32, C.c_void_p, c_size, C.c_void_p],
+    "clica_mlp_chain_tail_supported": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32)],
+    "clica_mlp_dgrad_split_tail": [c_f32p, c_i64, c_i64, c_i32, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.c_float, C.c_void_p,
+                                   C.POINTER(ChainTail), C.c_void_p],
     "clica_mlp_planes16_from_f32": [c_f32p, c_i64, c_i64, c_i32, c_i32, C.c_void_p, C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_mlp_planes16_from_f32_t": [c_f32p, c_i64, c_i64, c_i32, C.c_void_p, C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_linear_split_fwd16": [C.c_void_p, C.c_void_p, c_f32p, c_i64, c_i32, c_i32, c_i32, C.c_float, C.c_void_p, C.c_void_p, c_i32,
@@ -214,10 +224,17 @@ def load() -> C.CDLL:
     return lib
 
 
+_DEBUG_SYNC = os.environ.get("CLICA_DEBUG_SYNC", "0") != "0"      # name every library call on stderr and drain the device behind it
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = load().clica_last_error().decode("utf-8", "replace")
         raise ClicaError(f"{what} failed (rc={rc}): {msg}")
+    if _DEBUG_SYNC and not torch.cuda.is_current_stream_capturing():
+        import sys
+        sys.stderr.write(f"[clica] {what}\n"); sys.stderr.flush()
+        torch.cuda.synchronize()
 
 
 def require_cuda(t: torch.Tensor, name: str) -> None:

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "planes.h"
 #include "split16.h"
+#include "wgrad_shared.h"
 #include <stdlib.h>
 
 namespace clica {
@@ -841,6 +842,15 @@ struct SplitArgs {
   // slot array for the maxima (same positions), count_t: where workgroup 0 leaves the number of slots written.
   // `last_unscaled`: the last layer's output is not re-split (fp32 consumer only): its scale is 1 whatever s_t[L] says.
   const float* s_t; const float* s_w; unsigned* part_t; unsigned* count_t; unsigned cap_wg; int last_unscaled;
+  // Backward chain of a training step (clica_mlp_dgrad_split_tail): behind its last link every workgroup also leaves the partial weight
+  // gradients of the encoder's n-wide FIRST and LAST layer over its 48 rows (fp32 vector ALU, as wgrad_tiny_k computes them), one slab
+  // per workgroup in the weight-gradient workspace -- the separate wgrad_tiny_k launch (12.8 us, latency-bound) is gone from the step.
+  //   last layer:  dW = dzl^T al  [n_l][w_l], db = column sums of dzl;   first layer: dW = dz0^T x  [w_0][n_0], db = column sums of dz0
+  struct Tail {
+    const float* dzl; int64_t ld_dzl; const float* al; int64_t ld_al; const float* dz0; int64_t ld_dz0; const float* x; int64_t ld_x;
+    int n_l, w_l, w_0, n_0;                  // n_l <= 16, n_0 <= 15, w_l <= 127, w_0 <= 128 (clica_mlp_chain_tail_supported)
+    float* slab_l; float* dbslab_l; float* slab_0; float* dbslab_0;      // [workgroups][...]; slab_l == nullptr: no tail
+  } tail;
   // Round 4: what the training step's epilogues need of a layer, in ONE 64-byte record (one s_load_dwordx16 at the top of the layer).
   // Reading the same facts field by field from g.layer[l] behind the k-loop was a chain of ~10 DEPENDENT scalar loads, each with its
   // own s_waitcnt lgkmcnt(0) (flag -> branch -> next flag) in front of the epilogue, with the matrix pipe idle (tools/split_trace.py).
@@ -1282,6 +1292,69 @@ __device__ __forceinline__ void warm_up_l2(const SplitArgs& a, const int L, cons
   }
 }
 
+// The tail of a training step's backward chain (SplitArgs::Tail): two small fp32 products over the workgroup's 48 rows on
+// v_mfma_f32_16x16x4_f32 (exact fp32 products, the arithmetic of the native GEMMs) --
+//   last layer   slab[i][j] = sum_r dzl[r][i] al[r][j]      A = dzl^T (n_l <= 16 rows of the product), B = al  (w_l columns)
+//   first layer  slab[j][k] = sum_r dz0[r][j] x[r][k]       A = x^T   (n_0 <= 15),                     B = dz0 (w_0 columns), stored transposed
+// Waves 0..3 take the last layer, 4..7 the first; a wave owns two 16-column blocks of the wide operand and walks the 48 rows in twelve
+// k-steps of four: 24 MFMAs, 36 loads, all in flight.  Bias gradients ride as one more column / row: B column w_l = 1 (column sums of
+// dzl), A row n_0 = 1 (column sums of dz0).  Operands come straight from global memory in the MFMA's own lane order -- no LDS.
+// (First version: vector-ALU products with the narrow operand handed out by v_readlane -- 768 dependent readlane + FMA pairs per wave
+//  on two waves per job: +20 us on the chain launch, more than the 12.8 us launch it replaced.)
+__device__ __forceinline__ void tail_wgrad(const SplitArgs::Tail& T, int64_t row0, int nrows, int wave, int lane) {
+  static_assert(WAVES == 8 && ROWS == 48, "tail_wgrad: eight waves, twelve k-steps");
+  const bool first = wave >= 4;
+  const int q = wave & 3, l15 = lane & 15, kr = lane >> 4;
+  const int n = first ? T.n_0 : T.n_l, width = first ? T.w_0 : T.w_l;
+  const float* __restrict__ narrow = first ? T.x : T.dzl;
+  const float* __restrict__ wide = first ? T.dz0 : T.al;
+  const int64_t ldn = first ? T.ld_x : T.ld_dzl, ldw = first ? T.ld_dz0 : T.ld_al;
+  float av[ROWS / 4], bv[2][ROWS / 4];
+  auto load_wide = [&]() {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int col = (2 * q + c) * 16 + l15;
+#pragma unroll
+      for (int v = 0; v < ROWS / 4; ++v) {
+        const int r = 4 * v + kr;
+        bv[c][v] = (r < nrows && col < width) ? wide[(row0 + r) * ldw + col] : ((!first && r < nrows && col == width) ? 1.f : 0.f);
+      }
+    }
+  };
+  // dz0 was written by THIS workgroup's last epilogue: its stores are complete (workgroup-scope release) before anybody reads them back.
+  // (The last layer's operands do not depend on this launch, but requested in front of the fence they would hold it up for an HBM
+  //  round trip; the kernel's prologue has touched them into L2 instead.)
+  __threadfence_block();
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < ROWS / 4; ++v) {
+    const int r = 4 * v + kr;
+    av[v] = (r < nrows && l15 < n) ? narrow[(row0 + r) * ldn + l15] : ((first && r < nrows && l15 == n) ? 1.f : 0.f);
+  }
+  load_wide();
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int v = 0; v < ROWS / 4; ++v)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v], bv[c][v], acc[c], 0, 0, 0);
+  // D[i = 4 (lane / 16) + e][j = column]
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int col = (2 * q + c) * 16 + l15;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * kr + e;
+      if (!first) {
+        if (i < n && col < width) T.slab_l[((size_t)blockIdx.x * n + i) * width + col] = acc[c][e];
+        if (i < n && col == width) T.dbslab_l[(size_t)blockIdx.x * n + i] = acc[c][e];
+      } else {
+        if (i < n && col < width) T.slab_0[((size_t)blockIdx.x * width + col) * n + i] = acc[c][e];
+        if (i == n && col < width) T.dbslab_0[(size_t)blockIdx.x * width + col] = acc[c][e];
+      }
+    }
+  }
+}
+
 template <int AR>
 __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   constexpr int NP = Arith<AR>::NP;
@@ -1306,6 +1379,14 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   // input, three mixing layers reading their weights from global memory), all of them cold.
   u32x4 wpre[NP][CBW];
   request_first_w3<NP>(a.packed3 + a.off3[0], a.ent3[0], g.layer[0].K, g.layer[0].N, wave, lane, wpre);
+  // the tail's wide operand of the last layer (tail_wgrad) comes from HBM, cold: its 48 rows are touched HERE (one load per 128 bytes,
+  // value discarded), where every wave waits for memory anyway, so that the tail finds them in this XCD's L2
+  float tail_touch = 0.f;
+  if (a.tail.slab_l && wave < 3) {
+    const int idx = wave * 64 + lane, r = idx >> 2, c = (idx & 3) * 32;
+    if (r < nrows && c < a.tail.w_l) tail_touch = a.tail.al[(row0 + r) * a.tail.ld_al + c];
+  }
+  if (a.tail.slab_l && wave == 3 && lane < nrows) tail_touch = a.tail.x[(row0 + lane) * a.tail.ld_x];      // ... and the first layer's narrow one
   u32x2 mraw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc(g.layer[0].dact ? g.layer[0].mask_in : nullptr), mslot, 0, 0);
   // all layers' biases in the LDS left beside the planes (rows zero-padded to KI): the epilogue reads four consecutive
   // features with one ds_read_b128 instead of holding them in registers across the k-loop
@@ -1430,6 +1511,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     }
   }
   __syncthreads();
+  asm volatile("" ::"v"(tail_touch));
   if constexpr (AR == 1) amax_wave_to_lds(&amax_lds[0], in_max, 1.f / s_in0);
 
 #pragma unroll 1
@@ -1698,6 +1780,7 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     if (blockIdx.x < a.cap_wg && threadIdx.x < Split16State::NT) a.part_t[(size_t)threadIdx.x * kS16CapWG + blockIdx.x] = amax_lds[threadIdx.x];
     if (blockIdx.x == 0 && (int)threadIdx.x <= g.L) a.count_t[threadIdx.x] = gridDim.x < a.cap_wg ? gridDim.x : a.cap_wg;
   }
+  if (a.tail.slab_l) tail_wgrad(a.tail, row0, nrows, wave, lane_id);
   ST_FLUSH(g.L);
 }
 #ifdef CLICA_SPLIT_TRACE
@@ -2041,7 +2124,8 @@ extern "C" int clica_mlp_fwd_split16(const float* X, int64_t ldx, int64_t M, con
 
 static int mlp_dgrad_split_impl(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
                                 const void* packed_split, const uint64_t* const* signmask,
-                                float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state16, clica_stream_t stream) {
+                                float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state16, clica_stream_t stream,
+                                const clica_chain_tail* tail = nullptr) {
   using namespace fmlp;
   const int NPc = state16 ? 2 : 3;
   CLICA_CHECK_ARG(dY && N && K && packed_split && out && ldo && M > 0, "clica_mlp_dgrad_split: NULL pointer / empty batch");
@@ -2071,7 +2155,33 @@ static int mlp_dgrad_split_impl(const float* dY, int64_t lddy, int64_t M, int32_
     a.s_t = st->sD; a.s_w = st->sWC; a.cap_wg = kS16CapWG; a.part_t = s16_partD(st); a.count_t = st->cntD;
     a.last_unscaled = (planes && planes[n_links - 1]) ? 0 : 1;
   }
+  if (tail) {      // the n-wide first / last layer's weight-gradient slabs behind the last link (SplitArgs::Tail)
+    const int Le = tail->n_layers;
+    CLICA_CHECK_ARG(tail->a_last && tail->x && tail->N && tail->K && tail->wgrad_workspace, "clica_mlp_dgrad_split_tail: NULL pointer in the tail descriptor");
+    CLICA_CHECK_ARG(Le == n_links + 1, "clica_mlp_dgrad_split_tail: the chain has %d links, the encoder %d layers (links + 1 expected)", n_links, Le);
+    CLICA_CHECK_ARG(wsplit::chain_tail_supported(Le, tail->N, tail->K), "clica_mlp_dgrad_split_tail: layer shapes not covered (clica_mlp_chain_tail_supported)");
+    // chain link 0 contracts over the last layer's outputs, the last link produces dZ_0 (width of the first layer's output)
+    CLICA_CHECK_ARG(K[0] == tail->N[Le - 1] && N[0] == tail->K[Le - 1] && N[n_links - 1] == tail->N[0],
+                    "clica_mlp_dgrad_split_tail: the chain's widths do not match the encoder's first / last layer");
+    CLICA_CHECK_ARG(out[n_links - 1] && tail->lda >= tail->K[Le - 1] && tail->ldx >= tail->K[0],
+                    "clica_mlp_dgrad_split_tail: the last link needs its fp32 output (dZ_0); leading dimensions too small");
+    SplitArgs::Tail& T = a.tail;
+    int rc = wsplit::chain_tail_slabs(M, Le, tail->N, tail->K, tail->wgrad_workspace, tail->wgrad_workspace_bytes,
+                                      &T.slab_0, &T.dbslab_0, &T.slab_l, &T.dbslab_l);
+    if (rc) return rc;
+    T.dzl = dY; T.ld_dzl = lddy; T.al = tail->a_last; T.ld_al = tail->lda; T.dz0 = out[n_links - 1]; T.ld_dz0 = ldo[n_links - 1];
+    T.x = tail->x; T.ld_x = tail->ldx; T.n_l = tail->N[Le - 1]; T.w_l = tail->K[Le - 1]; T.w_0 = tail->N[0]; T.n_0 = tail->K[0];
+  }
   return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_dgrad_split16" : "clica_mlp_dgrad_split");
+}
+// The backward chain of a training step: clica_mlp_dgrad_split (state == NULL) / clica_mlp_dgrad_split16 plus, behind the last link,
+// the weight-gradient slabs of the encoder's n-wide first and last layer (clica_chain_tail, include/clica.h).
+extern "C" int clica_mlp_dgrad_split_tail(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                                          const void* packed_split, const uint64_t* const* signmask,
+                                          float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state,
+                                          const clica_chain_tail* tail, clica_stream_t stream) {
+  CLICA_CHECK_ARG(tail != nullptr, "clica_mlp_dgrad_split_tail: tail is NULL");
+  return mlp_dgrad_split_impl(dY, lddy, M, n_links, N, K, packed_split, signmask, out, ldo, planes, slope, state, stream, tail);
 }
 
 extern "C" int clica_mlp_dgrad_split(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,

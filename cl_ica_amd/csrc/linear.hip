@@ -1034,22 +1034,24 @@ __device__ __forceinline__ void reduce_units(const float* __restrict__ src, int 
 #pragma unroll
   for (int u = 0; u < 4; ++u) p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < total && splits > 32) {
-    // many short slabs (the tiny-dimension layers: ~100 row chunks): eight loads in flight per wave and pass; the partial sums
-    // keep a fixed association ((u, u + 4) pairs into p[u]) so the result does not depend on timing
-    for (int s0 = w; s0 < splits; s0 += 8 * W) {
-      float4 q8[8];
+    // many short slabs (the tiny-dimension layers: ~100 row chunks from wgrad_tiny_k, 256 workgroup partials from the backward
+    // chain's tail): sixteen loads in flight per wave and pass; the partial sums keep a fixed association (u, u + 4, u + 8, u + 12
+    // into p[u]) so the result does not depend on timing
+    for (int s0 = w; s0 < splits; s0 += 16 * W) {
+      float4 q16[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 16; ++u) {
         const int s = s0 + u * W;
-        q8[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        q16[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (s < splits) {
-          if (VEC4) q8[u] = *reinterpret_cast<const float4*>(src + (int64_t)s * total + e);
-          else q8[u].x = src[(int64_t)s * total + e];
+          if (VEC4) q16[u] = *reinterpret_cast<const float4*>(src + (int64_t)s * total + e);
+          else q16[u].x = src[(int64_t)s * total + e];
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        p[u].x += q8[u].x + q8[u + 4].x; p[u].y += q8[u].y + q8[u + 4].y; p[u].z += q8[u].z + q8[u + 4].z; p[u].w += q8[u].w + q8[u + 4].w;
+        p[u].x += (q16[u].x + q16[u + 4].x) + (q16[u + 8].x + q16[u + 12].x); p[u].y += (q16[u].y + q16[u + 4].y) + (q16[u + 8].y + q16[u + 12].y);
+        p[u].z += (q16[u].z + q16[u + 4].z) + (q16[u + 8].z + q16[u + 12].z); p[u].w += (q16[u].w + q16[u + 4].w) + (q16[u + 8].w + q16[u + 12].w);
       }
     }
   } else if (e < total) {

@@ -59,4 +59,14 @@ int slab_reduce_entry(ReduceGroupArgs& R, int l, int first_block, int sp, const 
                       float* dW, int64_t lddw, float* db, int32_t N, int32_t K);
 
 }  // namespace gemm
+
+namespace wsplit {
+// The backward chain of a training step can leave the weight-gradient slabs of the encoder's n-wide first and last layer itself
+// (fused_mlp.hip: SplitArgs::Tail; one slab per chain workgroup of kChainRows rows).  Defined in wgrad_split.hip, which owns the
+// workspace layout: the encoder's shapes in forward order, as clica_mlp_wgrad_split* gets them.
+constexpr int kChainRows = 48;
+bool chain_tail_supported(int n_layers, const int32_t* N, const int32_t* K);
+int chain_tail_slabs(int64_t M, int n_layers, const int32_t* N, const int32_t* K, void* workspace, size_t workspace_bytes,
+                     float** slab_first, float** db_first, float** slab_last, float** db_last);
+}  // namespace wsplit
 }  // namespace clica

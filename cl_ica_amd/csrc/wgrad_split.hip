@@ -945,16 +945,40 @@ static int layer_splits(const Plan& p, int32_t N, int32_t K) {
   int kind, gx, gy; tile_shape(N, K, &kind, &gx, &gy, true);
   return problem_splits(p, kind);
 }
-static size_t ws_layout(const Plan& p, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
+bool chain_tail_supported(int n_layers, const int32_t* N, const int32_t* K) {
+  if (n_layers < 2) return false;
+  const int l = n_layers - 1;
+  return gemm::wgrad_tiny_shape(N[0], K[0]) && gemm::wgrad_tiny_shape(N[l], K[l]) && K[0] <= 15 && N[0] <= 128 && N[l] <= 16 && K[l] <= 127;
+}
+static int tail_splits(int64_t Mrows) { return (int)ceil_div(Mrows, (int64_t)kChainRows); }
+// slabs a layer's region of the workspace holds: the plan's own splits, or -- first / last layer of an encoder whose chain can leave
+// their slabs (one per chain workgroup) -- whichever of the two is larger, so that the layout does not depend on who fills it
+static size_t slabs_alloc(const Plan& p, int64_t Mrows, int n, const int32_t* N, const int32_t* K, int l) {
+  size_t sp = (size_t)layer_splits(p, N[l], K[l]);
+  if ((l == 0 || l == n - 1) && chain_tail_supported(n, N, K)) sp = std::max(sp, (size_t)tail_splits(Mrows));
+  return sp;
+}
+static size_t ws_layout(const Plan& p, int64_t Mrows, int n, const int32_t* N, const int32_t* K, size_t* slab_off, size_t* db_off) {
   size_t off = 0;
   for (int l = 0; l < n; ++l) {
-    const size_t sp = (size_t)layer_splits(p, N[l], K[l]);
+    const size_t sp = slabs_alloc(p, Mrows, n, N, K, l);
     if (slab_off) slab_off[l] = off;
     off += align_up(sp * N[l] * K[l] * sizeof(float), 256);
     if (db_off) db_off[l] = off;
     off += align_up(sp * N[l] * sizeof(float), 256);
   }
   return off;
+}
+int chain_tail_slabs(int64_t M, int n_layers, const int32_t* N, const int32_t* K, void* workspace, size_t workspace_bytes,
+                     float** slab_first, float** db_first, float** slab_last, float** db_last) {
+  if (!chain_tail_supported(n_layers, N, K) || n_layers > MAXG) { set_error("chain tail: these layer shapes are not supported"); return CLICA_E_INVALID; }
+  size_t slab_off[MAXG], db_off[MAXG];
+  const size_t need = ws_layout(make_plan(M, n_layers, N, K), M, n_layers, N, K, slab_off, db_off);
+  if (!workspace || need > workspace_bytes) { set_error("chain tail: weight-gradient workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  char* w = reinterpret_cast<char*>(workspace);
+  *slab_first = reinterpret_cast<float*>(w + slab_off[0]); *db_first = reinterpret_cast<float*>(w + db_off[0]);
+  *slab_last = reinterpret_cast<float*>(w + slab_off[n_layers - 1]); *db_last = reinterpret_cast<float*>(w + db_off[n_layers - 1]);
+  return CLICA_OK;
 }
 
 }  // namespace wsplit
@@ -983,7 +1007,7 @@ extern "C" int clica_mlp_wgrad_split_kind(int32_t N, int32_t K, int32_t* kind) {
 extern "C" int clica_mlp_wgrad_split_workspace_bytes(int64_t M, int32_t n_layers, const int32_t* N, const int32_t* K, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && N && K && M > 0 && n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_split_workspace_bytes: bad argument");
   for (int l = 0; l < n_layers; ++l) CLICA_CHECK_ARG(N[l] >= 1 && K[l] >= 1, "clica_mlp_wgrad_split_workspace_bytes: layer %d: bad size", l);
-  *bytes = ws_layout(make_plan(M, n_layers, N, K), n_layers, N, K, nullptr, nullptr);
+  *bytes = ws_layout(make_plan(M, n_layers, N, K), M, n_layers, N, K, nullptr, nullptr);
   return CLICA_OK;
 }
 
@@ -994,13 +1018,15 @@ static int mlp_wgrad_split_impl(int64_t M, int32_t n_layers, const void* const* 
                                 const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
                                 float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
                                 int32_t accumulate, const void* state16, const int32_t* a_index, const int32_t* d_index,
-                                void* workspace, size_t workspace_bytes, clica_stream_t stream, const clica_adam_desc* adam = nullptr) {
+                                void* workspace, size_t workspace_bytes, clica_stream_t stream, const clica_adam_desc* adam = nullptr,
+                                int tail_slabs = 0) {
   CLICA_CHECK_ARG(dZ_planes && X_planes && dZ && lddz && X && ldx && dW && lddw && db && N && K && workspace && M > 0,
                   "clica_mlp_wgrad_split: NULL pointer / empty batch");
   CLICA_CHECK_ARG(n_layers >= 1 && n_layers <= MAXG, "clica_mlp_wgrad_split: %d layers (1..%d supported)", n_layers, MAXG);
+  CLICA_CHECK_ARG(!tail_slabs || chain_tail_supported(n_layers, N, K), "clica_mlp_wgrad_split_adam: tail_slabs set for shapes the chain's tail does not cover");
   const Plan p = make_plan(M, n_layers, N, K);
   size_t slab_off[MAXG], db_off[MAXG];
-  const size_t need = ws_layout(p, n_layers, N, K, slab_off, db_off);
+  const size_t need = ws_layout(p, M, n_layers, N, K, slab_off, db_off);
   if (need > workspace_bytes) { set_error("clica_mlp_wgrad_split: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
   hipStream_t st = as_stream(stream);
   GroupArgs G{};
@@ -1033,10 +1059,13 @@ static int mlp_wgrad_split_impl(int64_t M, int32_t n_layers, const void* const* 
   for (int l = 0; l < n_layers; ++l) {
     CLICA_CHECK_ARG(dW[l] && N[l] >= 1 && K[l] >= 1 && lddw[l] >= K[l], "clica_mlp_wgrad_split: layer %d: bad argument", l);
     const bool tiny = gemm::wgrad_tiny_shape(N[l], K[l]);
-    const int sp = layer_splits(p, N[l], K[l]);
+    const bool from_chain = tail_slabs && (l == 0 || l == n_layers - 1);      // the chain's tail has left this layer's slabs (one per workgroup)
+    const int sp = from_chain ? tail_splits(M) : layer_splits(p, N[l], K[l]);
     float* slab = (float*)((char*)workspace + slab_off[l]);
     float* dbslab = (float*)((char*)workspace + db_off[l]);
-    if (tiny) {
+    if (from_chain) {
+      CLICA_CHECK_ARG(db[l], "clica_mlp_wgrad_split_adam: layer %d: tail slabs need a bias gradient", l);
+    } else if (tiny) {
       CLICA_CHECK_ARG(dZ[l] && X[l] && lddz[l] >= N[l] && ldx[l] >= K[l],
                       "clica_mlp_wgrad_split: layer %d (%d x %d) takes the fp32 tiny-dimension kernel: fp32 operands required", l, N[l], K[l]);
       gemm::Args g{};
@@ -1114,11 +1143,16 @@ extern "C" int clica_mlp_wgrad_split_adam(int64_t M, int32_t n_layers, const voi
                                           const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
                                           float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
                                           const void* state, const int32_t* a_index, const int32_t* d_index, const clica_adam_desc* adam,
-                                          void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+                                          int32_t tail_slabs, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
   CLICA_CHECK_ARG(adam, "clica_mlp_wgrad_split_adam: NULL optimizer descriptor");
   CLICA_CHECK_ARG(!state || (a_index && d_index), "clica_mlp_wgrad_split_adam: NULL index arrays");
   return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, 0, state, a_index, d_index,
-                              workspace, workspace_bytes, stream, adam);
+                              workspace, workspace_bytes, stream, adam, tail_slabs ? 1 : 0);
+}
+extern "C" int clica_mlp_chain_tail_supported(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t* supported) {
+  CLICA_CHECK_ARG(supported && N && K && n_layers >= 1 && n_layers <= MAXG, "clica_mlp_chain_tail_supported: bad argument");
+  *supported = chain_tail_supported(n_layers, N, K) ? 1 : 0;
+  return CLICA_OK;
 }
 extern "C" int clica_mlp_planes16_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes) {
   CLICA_CHECK_ARG(bytes && M > 0 && width >= 1, "clica_mlp_planes16_bytes: bad argument");

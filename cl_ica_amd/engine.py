@@ -538,9 +538,20 @@ class ContrastiveTrainer:
         if not self._packed_current:
             self.pack()
         if self.split_bf16:
+            tail = None
+            self._tail_ready = False
+            if getattr(self, "_fold_adam", False) and self.split_wgrad and not (self.fuse_tick and not self._ticked):
+                # inside a training step (N = 1): the chain's workgroups also leave the n-wide first / last layer's weight-gradient
+                # slabs (clica_mlp_dgrad_split_tail) -- weight_grads() then needs no tiny-dimension launch
+                if not hasattr(self, "_tail_ok"):
+                    self._tail_ok = (os.environ.get("CLICA_CHAIN_TAIL", "1") != "0" and self.dz_out[0] is not None and
+                                     ops.mlp_chain_tail_supported([tuple(lin.weight.shape) for lin in self.linears]))
+                if self._tail_ok:
+                    tail = dict(a_last=self.acts_out[L - 2], x=self.x, shapes=[tuple(lin.weight.shape) for lin in self.linears], ws=self.group_ws)
+                    self._tail_ready = True
             ops.mlp_dgrad_chain_split(g, ws, self.packed_t, [self.dz_out[l - 1] for l in chain], self.slope,
                                       masks_chain=[self.signmasks[l - 1] for l in chain],
-                                      planes=[self.dz_planes[l - 1] for l in chain] if self.split_wgrad else None, state=self.s16)
+                                      planes=[self.dz_planes[l - 1] for l in chain] if self.split_wgrad else None, state=self.s16, tail=tail)
         else:
             ops.mlp_dgrad_chain(g, ws, self.packed_t, [self.acts[l - 1] for l in chain], [self.dz[l - 1] for l in chain], self.slope,
                                 masks_chain=[self.signmasks[l - 1] for l in chain])
@@ -564,7 +575,9 @@ class ContrastiveTrainer:
             ops.mlp_wgrad_split(R, [self.dz_planes[l] for l in order], [self.act_planes[l - 1] if l > 0 else None for l in order],
                                 [g if l == L - 1 else self.dz_out[l] for l in order],
                                 [self.acts_out[l - 1] if l > 0 else self.x for l in order], dWs, dbs, ws=self.group_ws,
-                                state=self.s16, a_index=order, d_index=[L - 1 - l for l in order], adam=adam)
+                                state=self.s16, a_index=order, d_index=[L - 1 - l for l in order], adam=adam,
+                                tail_slabs=adam is not None and getattr(self, "_tail_ready", False))
+            self._tail_ready = False
             if adam is not None:
                 self._adam_done = True
         else:

@@ -345,10 +345,24 @@ def mlp_fwd_split(x: torch.Tensor, weights, biases, outs, packed_split: torch.Te
     return outs[-1]
 
 
+def mlp_chain_tail_supported(shapes) -> bool:
+    """Can the backward chain leave the weight-gradient slabs of the first / last layer of an encoder with these (out, in) shapes
+    (forward order) itself?  (clica_mlp_chain_tail_supported)"""
+    L = len(shapes)
+    I32 = C.c_int32 * L
+    ok = C.c_int32()
+    check(load().clica_mlp_chain_tail_supported(L, I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]), C.byref(ok)),
+          "clica_mlp_chain_tail_supported")
+    return bool(ok.value)
+
+
 def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch.Tensor, outs, slope: float = 0.01, masks_chain=None,
-                          planes=None, state=None):
+                          planes=None, state=None, tail: Optional[dict] = None):
     """`mlp_dgrad_chain` on the bf16 matrix cores (clica_mlp_dgrad_split); sign bits from `mlp_fwd_split`.  `planes[j]`
-    (mlp_planes_alloc(M, width, False) or None) receives link j's dZ as bf16 planes; `outs[j]` may then be None."""
+    (mlp_planes_alloc(M, width, False) or None) receives link j's dZ as bf16 planes; `outs[j]` may then be None.
+    `tail` = dict(a_last, x, shapes, ws): the launch also leaves the weight-gradient slabs of the encoder's n-wide first and last
+    layer in `ws`, the workspace of the `mlp_wgrad_split(..., adam=..., tail_slabs=True)` call that follows
+    (clica_mlp_dgrad_split_tail)."""
     (dy, lddy) = _mat("dy", dy)
     n = len(weights_chain)
     I32, I64, VP = C.c_int32 * n, C.c_int64 * n, C.c_void_p * n
@@ -357,7 +371,16 @@ def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch
             packed_split_t.data_ptr(), None if masks_chain is None else VP(*[ptr(m) for m in masks_chain]),
             VP(*[ptr(o) for o in outs]), I64(*[0 if o is None else o.stride(0) for o in outs]),
             None if planes is None else VP(*[ptr(q) for q in planes]), float(slope))
-    if state is None:
+    if tail is not None:
+        (al, lda), (xx, ldx) = _mat("a_last", tail["a_last"]), _mat("x", tail["x"])
+        shapes = [tuple(sh) for sh in tail["shapes"]]
+        Le = len(shapes)
+        N32, K32 = (C.c_int32 * Le)(*[sh[0] for sh in shapes]), (C.c_int32 * Le)(*[sh[1] for sh in shapes])
+        desc = _lib.ChainTail(a_last=al.data_ptr(), lda=lda, x=xx.data_ptr(), ldx=ldx, n_layers=Le, N=N32, K=K32,
+                              wgrad_workspace=tail["ws"].data_ptr(), wgrad_workspace_bytes=tail["ws"].numel())
+        check(load().clica_mlp_dgrad_split_tail(*args, None if state is None else state.buf.data_ptr(), C.byref(desc), stream_ptr()),
+              "clica_mlp_dgrad_split_tail")
+    elif state is None:
         check(load().clica_mlp_dgrad_split(*args, stream_ptr()), "clica_mlp_dgrad_split")
     else:
         check(load().clica_mlp_dgrad_split16(*args, state.buf.data_ptr(), stream_ptr()), "clica_mlp_dgrad_split16")
@@ -374,7 +397,7 @@ def mlp_wgrad_split_workspace(M: int, shapes, device) -> torch.Tensor:
 
 
 def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional[torch.Tensor] = None, accumulate: bool = False,
-                    state=None, a_index=None, d_index=None, adam: Optional[dict] = None):
+                    state=None, a_index=None, d_index=None, adam: Optional[dict] = None, tail_slabs: bool = False):
     """Every layer's dW / db in the split-bf16 arithmetic (clica_mlp_wgrad_split).  Per layer EITHER the two plane buffers
     (`dz_planes[l]`, `x_planes[l]`: layers with `mlp_wgrad_split_kind` 0) OR the fp32 operands (`dzs[l]`, `xs[l]`: kind 1).
     `adam` = dict(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps, grad_scale, t_offset, s16): the trailing
@@ -391,6 +414,8 @@ def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional
             VP(*[None if m is None else m[0].data_ptr() for m in xm]), I64(*[0 if m is None else m[1] for m in xm]),
             VP(*[w.data_ptr() for w in dWs]), I64(*[w.stride(0) for w in dWs]),
             VP(*[ptr(b) for b in dbs]), I32(*[s[0] for s in shapes]), I32(*[s[1] for s in shapes]), 1 if accumulate else 0)
+    if tail_slabs and adam is None:
+        raise ValueError("mlp_wgrad_split(tail_slabs=True) needs adam=...: the slabs the chain left are consumed by clica_mlp_wgrad_split_adam")
     if adam is not None:
         global PARAM_EPOCH
         PARAM_EPOCH += 1
@@ -406,7 +431,7 @@ def mlp_wgrad_split(M: int, dz_planes, x_planes, dzs, xs, dWs, dbs, ws: Optional
         check(load().clica_mlp_wgrad_split_adam(*args[:-1], None if state is None else state.buf.data_ptr(),
                                                 None if state is None else I32(*[int(i) for i in a_index]),
                                                 None if state is None else I32(*[int(i) for i in d_index]), C.byref(desc),
-                                                ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split_adam")
+                                                1 if tail_slabs else 0, ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split_adam")
     elif state is None:
         check(load().clica_mlp_wgrad_split(*args, ws.data_ptr(), ws.numel(), stream_ptr()), "clica_mlp_wgrad_split")
     else:      # f16x2 plane copies: per layer the positions of its operands' scales in the state (include/clica.h)

@@ -397,12 +397,34 @@ int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* const* dZ_p
                             int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
                             void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
+/* Round 5, the training step's small launches: the backward chain can leave the weight-gradient slabs of the encoder's n-wide FIRST
+ * and LAST layer itself (every chain workgroup adds the products of its 48 rows behind the last link, fp32 on the vector ALU -- the
+ * arithmetic of the tiny-dimension kernel that clica_mlp_wgrad_split* would otherwise launch).  `tail` names what that needs beyond
+ * the chain's own arguments: the fp32 input activation of the last layer, the encoder input, the encoder's shapes in forward order
+ * (n_layers = n_links + 1) and the workspace the FOLLOWING clica_mlp_wgrad_split_adam(..., tail_slabs = 1, ...) call is given (the
+ * slabs go where that call's plan expects them).  The last link must write its fp32 output.  clica_mlp_chain_tail_supported: first
+ * and last layer of the tiny-dimension kind with K[0] <= 15, N[0] <= 128, N[L-1] <= 16, K[L-1] <= 127 (get_mlp's n -> 10 n ... 10 n -> n
+ * up to n = 12; encoders.py:36-48). */
+typedef struct clica_chain_tail {
+  const float* a_last; int64_t lda;      /* [M][K[L-1]] input of the last layer */
+  const float* x; int64_t ldx;           /* [M][K[0]]   encoder input */
+  int32_t n_layers; const int32_t* N; const int32_t* K;
+  void* wgrad_workspace; size_t wgrad_workspace_bytes;
+} clica_chain_tail;
+int clica_mlp_chain_tail_supported(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t* supported);
+/* state == NULL: bf16x3 (clica_mlp_dgrad_split), else f16x2 (clica_mlp_dgrad_split16) */
+int clica_mlp_dgrad_split_tail(const float* dY, int64_t lddy, int64_t M, int32_t n_links, const int32_t* N, const int32_t* K,
+                               const void* packed_split, const uint64_t* const* signmask,
+                               float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state,
+                               const clica_chain_tail* tail, clica_stream_t stream);
+
 /* Weight gradients + optimizer in one call (round 5: the N = 1 training step has no optimizer launch of its own).  The reduction that
  * ends clica_mlp_wgrad_split / _split16 applies torch.optim.Adam's update (main_mlp.py:312, as clica_adam_step_at) to every element
  * it has just reduced; dW[l] (contiguous: lddw[l] = K[l]) and db[l] must be views of ONE gradient arena `grad` that this call covers
  * completely (alignment padding aside), param / exp_avg / exp_avg_sq are arenas of the same layout.  The gradients are still written.
  * split16_state != NULL: the f16x2 scale update (clica_split16_update(state, n_layers)) rides in front of the same launch.
- * `state` (NULL: bf16x3 plane copies, else f16x2), a_index, d_index as for clica_mlp_wgrad_split16. */
+ * `state` (NULL: bf16x3 plane copies, else f16x2), a_index, d_index as for clica_mlp_wgrad_split16.  tail_slabs != 0: the slabs of the
+ * first and last layer are already in the workspace (clica_mlp_dgrad_split_tail of the same step): no tiny-dimension launch. */
 typedef struct clica_adam_desc {
   float* param; float* grad; float* exp_avg; float* exp_avg_sq; int64_t count;
   float lr, beta1, beta2, eps, grad_scale;
@@ -413,7 +435,7 @@ int clica_mlp_wgrad_split_adam(int64_t M, int32_t n_layers, const void* const* d
                                const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
                                float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
                                const void* state, const int32_t* a_index, const int32_t* d_index, const clica_adam_desc* adam,
-                               void* workspace, size_t workspace_bytes, clica_stream_t stream);
+                               int32_t tail_slabs, void* workspace, size_t workspace_bytes, clica_stream_t stream);
 
 /* f16x2 variants of the per-layer entry points (BASELINE config 3's wide chain).  A tensor is named by (family, index) in the state:
  * family 0 = activations (index l = the INPUT of layer l), 1 = gradients (index l = dZ_l), 2 = weights (index l); here the caller passes
