@@ -7,12 +7,18 @@ GEMM epilogue, ReLU gate in the data-gradient epilogue) and the k = 4 stage on t
 flattened map.  The ``nn.Conv2d`` modules stay the owners of the parameters (state dict = the reference's); per call the
 weights are re-ordered into the GEMM layouts (a few tiny copies) and the gradients come back in ``Conv2d.weight`` layout.
 
+Arithmetic of the three 16C-deep stages (forward, data and weight gradients): ``f16x2`` (default; csrc/conv16.hip -- three fp16 matrix
+products of two-piece operands per fp32 product, per-tensor power-of-two scales measured in the same step, fp32 accumulation) or
+``f32`` (``CLICA_CONV_ARITH=f32`` / ``set_arith("f32")``: the fp32-MFMA kernels of csrc/linear.hip).  The first stage (K = 16) and the
+4 x 4 stage stay fp32 kernels in both.
+
 ``conv_stack(x, w1, b1, ..., w5, b5) -> (images, 256)`` is one autograd node.  The activations it saves live in a per-shape
 buffer set that is zeroed once (borders / non-output rows are never written) and handed back by the backward pass.
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -21,7 +27,25 @@ from . import ops
 from .encoders import _inplace_ok
 from ._lib import check, load, ptr, stream_ptr, workspace
 
-__all__ = ["conv_stack", "STAGES"]
+__all__ = ["conv_stack", "STAGES", "set_arith", "get_arith"]
+
+_ARITH = os.environ.get("CLICA_CONV_ARITH", "f16x2")
+if _ARITH not in ("f16x2", "f32"):
+    raise ValueError(f"CLICA_CONV_ARITH={_ARITH!r}: 'f16x2' or 'f32'")
+_SLOTS = 256          # csrc/conv16.hip: kSlots
+
+
+def set_arith(name: str) -> str:
+    """Select the arithmetic of the 16C-deep stages ('f16x2' or 'f32'); returns the previous one."""
+    global _ARITH
+    if name not in ("f16x2", "f32"):
+        raise ValueError(f"conv arithmetic {name!r}: 'f16x2' or 'f32'")
+    prev, _ARITH = _ARITH, name
+    return prev
+
+
+def get_arith() -> str:
+    return _ARITH
 
 # (out_channels, spatial size of the output) of the four stride-2 stages for a 64 x 64 input; the fifth stage maps the
 # 4 x 4 x 64 map to 256 features
@@ -57,6 +81,10 @@ class _Buffers:
                 self.dO[0] = torch.empty(images * ho * ho * cout, **f32)
             cin = cout
         self.wpack = None                               # GEMM-layout weights of the step in flight (conv._maps order)
+        # f16x2 arithmetic: maxima slots of S1, S2, S3, dO3, dO2, dO1 (float bits), packed weight pieces + scales of W2g, W3g, W4g, W2dT, W3dT, W4dT
+        self.amax = torch.zeros(6 * _SLOTS, dtype=torch.int32, device=device)
+        self.w16 = None
+        self.wscale = torch.ones(6, **f32)
         self.O4 = torch.zeros((images, 5 * 5 * 64), **f32)     # last stride-2 stage's output on its 5 x 5 row grid (non-output rows stay 0)
         # first stage's weight gradient: the small-matrix streaming kernel where its shape fits (nc = 1), the grouped GEMM path otherwise
         self.ws1 = self.ws1p = None
@@ -137,8 +165,10 @@ def _maps(nc: int, device) -> dict:
     gshapes = [(shapes[0][0], 16 * nc), (32, 512), (64, 512), (64, 1024), (_FEATURES, 5 * 5 * 64)]
     g = [idx(sh) for sh in gshapes]
     unpack = [g[0].view(shapes[0][0], 4, 4, nc).permute(0, 3, 1, 2)] + [_wg_to_conv(g[l], shapes[l][0], shapes[l][1]) for l in (1, 2, 3)] + [_w5_back(g[4])]
+    pack16 = [pack[l] for l in (1, 2, 3)] + [pack[l].t().contiguous() for l in (4, 5, 6)]     # Wg as they are, Wd TRANSPOSED ([4 C][4 Cout])
     m = {"pack": [i32(t) for t in pack], "pack_shapes": [tuple(t.shape) for t in pack], "pack_src": pack_src,
-         "unpack": [i32(t) for t in unpack], "shapes": shapes}
+         "unpack": [i32(t) for t in unpack], "shapes": shapes,
+         "pack16": [i32(t) for t in pack16], "pack16_shapes": [tuple(t.shape) for t in pack16], "pack16_src": [1, 2, 3, 1, 2, 3]}
     _MAPS[key] = m
     return m
 
@@ -149,6 +179,24 @@ def _gather(srcs, maps, dsts, accumulate=False):
     check(load().clica_conv_gather(n, VP(*[t.data_ptr() for t in srcs]), VP(*[None if t is None else t.data_ptr() for t in maps]),
                                    VP(*[t.data_ptr() for t in dsts]), I32(*[t.numel() for t in dsts]), int(accumulate), stream_ptr()),
           "clica_conv_gather")
+
+
+def _pack16(buf: "_Buffers", ws_, m: dict) -> None:
+    """Conv2d weights -> packed f16 hi / lo planes of the six GEMM operands + their scales (one launch)."""
+    dev = buf.amax.device
+    if buf.w16 is None:
+        buf.w16 = [torch.empty(2 * sh[0] * sh[1], dtype=torch.int16, device=dev) for sh in m["pack16_shapes"]]
+    n = 6
+    srcs = [ws_[i].detach() for i in m["pack16_src"]]
+    srcs = [t if t.is_contiguous() else t.contiguous() for t in srcs]
+    VP, I32 = C.c_void_p * n, C.c_int32 * n
+    check(load().clica_conv16_pack(n, VP(*[t.data_ptr() for t in srcs]), I32(*[t.numel() for t in srcs]), VP(*[t.data_ptr() for t in m["pack16"]]),
+                                   VP(*[t.data_ptr() for t in buf.w16]), I32(*[t.numel() for t in m["pack16"]]), buf.wscale.data_ptr(), stream_ptr()),
+          "clica_conv16_pack")
+
+
+def _slots(buf: "_Buffers", i: int) -> int:
+    return buf.amax.data_ptr() + 4 * _SLOTS * i
 
 
 class _ConvStackFn(torch.autograd.Function):
@@ -167,24 +215,40 @@ class _ConvStackFn(torch.autograd.Function):
         srcs = [ws_[i].detach() for i in m["pack_src"]]
         if not all(t.is_contiguous() for t in srcs):
             srcs = [t.contiguous() for t in srcs]
-        _gather(srcs, m["pack"], buf.wpack)          # W1g, W2g, W3g, W4g, W2d, W3d, W4d, W5g in one launch
+        f16 = _ARITH == "f16x2"
+        if f16:
+            _gather([srcs[0], srcs[7]], [m["pack"][0], m["pack"][7]], [buf.wpack[0], buf.wpack[7]])     # the two fp32 stages' weights
+            check(lib.clica_conv16_zero_slots(buf.amax.data_ptr(), 6, st), "clica_conv16_zero_slots")
+            _pack16(buf, ws_, m)
+        else:
+            _gather(srcs, m["pack"], buf.wpack)          # W1g, W2g, W3g, W4g, W2d, W3d, W4d, W5g in one launch
         w1g = buf.wpack[0]
-        check(lib.clica_conv_k4s2_fwd_patches(buf.patches.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
-                                              32, 32, 1, 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), st), "clica_conv_k4s2_fwd_patches")
+        in_kernel = f16 and nc == 1        # the K = 16 masks kernel records its output's maximum itself; other first stages get a pass of their own
+        check(lib.clica_conv_k4s2_fwd_patches_amax(buf.patches.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
+                                                   32, 32, 1, 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), _slots(buf, 0) if in_kernel else None, st),
+              "clica_conv_k4s2_fwd_patches")
+        if f16 and not in_kernel:
+            check(lib.clica_conv16_amax(buf.S[1].data_ptr(), buf.S[1].numel(), _slots(buf, 0), st), "clica_conv16_amax")
         cin = STAGES[0][0]
         for l in (1, 2, 3):
             cout, ho = STAGES[l]
             hs = ho + 1
             out = buf.S[l + 1] if l < 3 else buf.O4
-            check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), buf.wpack[l].data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
-                                          1, 1 if l < 3 else 2, out.data_ptr(), buf.gate[l].data_ptr() if l < 3 else None, st), "clica_conv_k4s2_fwd")
+            if f16:
+                check(lib.clica_conv16_k4s2_fwd(buf.S[l].data_ptr(), buf.w16[l - 1].data_ptr(), buf.wscale.data_ptr() + 4 * (l - 1), ptr(bs_[l].detach()),
+                                                images, cin, cout, hs, hs, 1, 1 if l < 3 else 2, out.data_ptr(),
+                                                buf.gate[l].data_ptr() if l < 3 else None, _slots(buf, l - 1), _slots(buf, l) if l < 3 else None, st),
+                      "clica_conv16_k4s2_fwd")
+            else:
+                check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), buf.wpack[l].data_ptr(), ptr(bs_[l].detach()), images, cin, cout, hs, hs,
+                                              1, 1 if l < 3 else 2, out.data_ptr(), buf.gate[l].data_ptr() if l < 3 else None, st), "clica_conv_k4s2_fwd")
             cin = cout
         w5g = buf.wpack[7]
         feats = torch.empty((images, _FEATURES), dtype=torch.float32, device=dev)
         check(lib.clica_conv_k4s2_fwd_patches(buf.O4.data_ptr(), w5g.data_ptr(), ptr(bs_[4].detach()), images, 5 * 5 * 64, _FEATURES, 1, 1, 1, 0,
                                               feats.data_ptr(), None, st), "clica_conv_k4s2_fwd_patches")
         if keep:
-            ctx.buf, ctx.w5g, ctx.nc = buf, w5g, nc
+            ctx.buf, ctx.w5g, ctx.nc, ctx.f16 = buf, w5g, nc, f16
             ctx.params = params
             ctx.save_for_backward(feats, *ws_)
         else:
@@ -206,10 +270,27 @@ class _ConvStackFn(torch.autograd.Function):
         grads[9] = db5
         dwg_all = [None, None, None, None, dw5g]
         ops.linear_dgrad(dpre, ctx.w5g, buf.O4, slope=0.0, out=buf.dO[3].view(images, 5 * 5 * 64))
+        f16 = ctx.f16
+        if f16:
+            check(lib.clica_conv16_amax(buf.dO[3].data_ptr(), images * 5 * 5 * 64, _slots(buf, 3), st), "clica_conv16_amax")
         for l in (3, 2, 1):
             cout, ho = STAGES[l]
             cin, hs = STAGES[l - 1][0], ho + 1
             nbytes = C.c_size_t()
+            if f16:
+                check(lib.clica_conv16_k4s2_wgrad_workspace_bytes(images * hs * hs, cout, 16 * cin, C.byref(nbytes)), "clica_conv16_k4s2_wgrad_workspace_bytes")
+                wsp = workspace("conv16_wgrad", nbytes.value, dev)
+                dwg = torch.empty((cout, 16 * cin), dtype=torch.float32, device=dev)
+                db = torch.empty((cout,), dtype=torch.float32, device=dev)
+                sd = 3 + (3 - l)                                 # slots of dO[l]
+                check(lib.clica_conv16_k4s2_wgrad(buf.dO[l].data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs, dwg.data_ptr(), db.data_ptr(),
+                                                  0, _slots(buf, sd), _slots(buf, l - 1), wsp.data_ptr(), wsp.numel(), st), "clica_conv16_k4s2_wgrad")
+                dwg_all[l], grads[2 * l + 1] = dwg, db
+                dgrid = STAGES[l - 1][1] + (1 if l > 1 else 0)
+                check(lib.clica_conv16_k4s2_dgrad(buf.dO[l].data_ptr(), buf.w16[3 + l - 1].data_ptr(), buf.wscale.data_ptr() + 4 * (3 + l - 1), images, cin, cout,
+                                                  hs, hs, buf.dO[l - 1].data_ptr(), dgrid, dgrid, buf.gate[l - 1].data_ptr(),
+                                                  _slots(buf, sd), _slots(buf, sd + 1) if l > 1 else None, st), "clica_conv16_k4s2_dgrad")
+                continue
             check(lib.clica_conv_k4s2_wgrad_workspace_bytes(images * hs * hs, cout, 16 * cin, C.byref(nbytes)), "clica_conv_k4s2_wgrad_workspace_bytes")
             wsp = workspace("conv_wgrad", nbytes.value, dev)
             dwg = torch.empty((cout, 16 * cin), dtype=torch.float32, device=dev)

@@ -1834,8 +1834,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_patches_k(const float* __restr
 template <int K>
 __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __restrict__ P, const float* __restrict__ Wg,
                                                                 const float* __restrict__ bias, unsigned pixels, int Cout, int ho, int wo,
-                                                                int relu, float* __restrict__ out, unsigned* __restrict__ gate_out) {
+                                                                int relu, float* __restrict__ out, unsigned* __restrict__ gate_out,
+                                                                unsigned* __restrict__ amax_slots) {
   const int groups = Cout / 8;                          // threads per pixel
+  float amax = 0.f;                                     // conv16.hip: the maximum of what this thread stored (its consumer's f16 scale)
   const int cg = threadIdx.x % groups;
   // channel of this thread's c-th output: two runs of four, [4 cg, 4 cg + 4) and [Cout/2 + 4 cg, ...), so that each of the thread's two
   // 16-byte stores is contiguous with its neighbours' (a pixel's group writes 64 contiguous bytes per store instruction, not 16 of every 32)
@@ -1874,6 +1876,7 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
       for (int k = 0; k < K; ++k) acc = fmaf(a[k], w[c][k], acc);       // k ascending, like the MFMA chain of the GEMM path
       acc += b[c];
       o[c] = (relu && !(acc > 0.f)) ? 0.f : acc;
+      amax = fmaxf(amax, fabsf(o[c]));
     }
     const unsigned prow = pixel / (unsigned)wo, x = pixel - prow * (unsigned)wo, img = prow / (unsigned)ho, y = prow - img * (unsigned)ho;
     const unsigned Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
@@ -1887,6 +1890,14 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
       bits |= __shfl_xor(bits, 1);
       bits |= __shfl_xor(bits, 2);
       if (cg == 0) gate_out[pixel] = bits;
+    }
+  }
+  if (amax_slots) {                                     // one atomic per wave, 256 slots (conv16.hip: commit_amax)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+      amax = (amax <= 3.0e38f) ? amax : 3.4e38f;
+      if (amax > 0.f) atomicMax(amax_slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), __float_as_uint(amax));
     }
   }
 }
@@ -1939,9 +1950,17 @@ extern "C" int clica_conv_im2col_k4s2(const float* x, int64_t images, int32_t C,
   return launch_status("clica_conv_im2col_k4s2");
 }
 
+extern "C" int clica_conv_k4s2_fwd_patches_amax(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
+                                                int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
+                                                uint32_t* gate_bits, uint32_t* amax_slots, clica_stream_t stream);
 extern "C" int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
                                            int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
                                            uint32_t* gate_bits, clica_stream_t stream) {
+  return clica_conv_k4s2_fwd_patches_amax(patches, Wg, bias, images, K, Cout, ho, wo, relu, scatter, out, gate_bits, nullptr, stream);
+}
+extern "C" int clica_conv_k4s2_fwd_patches_amax(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
+                                                int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
+                                                uint32_t* gate_bits, uint32_t* amax_slots, clica_stream_t stream) {
   CLICA_CHECK_ARG(patches && Wg && out && images > 0 && K >= 4 && K % 4 == 0 && Cout >= 1 && ho >= 1 && wo >= 1,
                   "clica_conv_k4s2_fwd_patches: bad argument");
   CLICA_CHECK_ARG(!scatter || (ho % 2 == 0 && wo % 2 == 0), "clica_conv_k4s2_fwd_patches: scatter needs an even output grid");
@@ -1950,9 +1969,10 @@ extern "C" int clica_conv_k4s2_fwd_patches(const float* patches, const float* Wg
   if (valu_on && scatter == 1 && K == 16 && Cout == 32 && aligned16(out) && images * ho * wo < ((int64_t)1 << 32)) {
     // short contraction (one input channel): vector-ALU kernel, bound by the 128 B per pixel it writes
     hipLaunchKernelGGL(conv_fwd_patches_valu_k<16>, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), patches, Wg, bias,
-                       (unsigned)(images * ho * wo), (int)Cout, (int)ho, (int)wo, (int)relu, out, gate_bits);
+                       (unsigned)(images * ho * wo), (int)Cout, (int)ho, (int)wo, (int)relu, out, gate_bits, amax_slots);
     return launch_status("clica_conv_k4s2_fwd_patches(valu)");
   }
+  CLICA_CHECK_ARG(!amax_slots, "clica_conv_k4s2_fwd_patches_amax: the maximum is recorded by the K = 16, Cout = 32 first-stage kernel only");
   return conv_fwd_launch(patches, K, 0, 0, Wg, bias, images * ho * wo, K, Cout, ho, wo, ho, wo, relu, scatter, out, gate_bits, as_stream(stream),
                          "clica_conv_k4s2_fwd_patches");
 }

@@ -546,6 +546,39 @@ int clica_conv_gather(int32_t n, const float* const* src, const int32_t* const* 
                       int32_t accumulate, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * The same convolution stages in the f16x2 split arithmetic (csrc/conv16.hip)  --  kitti_masks/model.py:42-49.
+ * Every product runs as three fp16 matrix instructions on two-piece operands (hi = RN_f16(v s), lo = RN_f16(v s - hi), s a power
+ * of two per tensor; fp32 accumulation; the encoder's arithmetic, clica_mlp_*_split16).  Tensors stay fp32 in HBM with the layouts
+ * documented above and are split by the consuming kernel; the scale of a tensor comes from its MAXIMUM SLOTS, 256 uint32 (float
+ * bits of max |value|) that the producing kernel fills in the same step (amax_out) and the consumer reduces (amax_in; NULL = scale 1).
+ * Slots are zeroed by the caller before the producer runs (clica_conv16_zero_slots: `tensors` consecutive slot arrays).
+ *   pack:   n <= 8 weight matrices, dst[i] = [hi plane][lo plane] of count[i] f16 each, element e = piece(src[i][map[i][e]] * scale_i)
+ *           (map[i] = NULL: identity; a negative index gives 0), scale_i from the maximum over src[i][0 .. src_count[i]), written to scales[i].
+ *   fwd:    Wg16 = packed [Cout][16 C] (clica_conv_k4s2_fwd's Wg); scatter 1 or 2 as there; only output rows are computed.
+ *   dgrad:  WdT16 = packed TRANSPOSE of clica_conv_k4s2_dgrad's Wd, i.e. [4 C][4 Cout]; gate bits required.
+ *   wgrad:  as clica_conv_k4s2_wgrad (C a multiple of 32, Cout 32 or 64).
+ *   clica_conv_k4s2_fwd_patches_amax: the fp32 first-stage kernel, also recording its output's maximum (K = 16, Cout = 32 only).
+ *   clica_conv16_amax: max |x| of a tensor some other kernel produced, into its slots.
+ * ---------------------------------------------------------------------------------- */
+int clica_conv16_pack(int32_t n, const float* const* src, const int32_t* src_count, const int32_t* const* map, uint16_t* const* dst,
+                      const int32_t* count, float* scales, clica_stream_t stream);
+int clica_conv16_amax(const float* x, int64_t n, uint32_t* slots, clica_stream_t stream);
+int clica_conv16_zero_slots(uint32_t* slots, int32_t tensors, clica_stream_t stream);
+int clica_conv_k4s2_fwd_patches_amax(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
+                                     int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
+                                     uint32_t* gate_bits, uint32_t* amax_slots, clica_stream_t stream);
+int clica_conv16_k4s2_fwd(const float* S, const uint16_t* Wg16, const float* wscale, const float* bias, int64_t images, int32_t C,
+                          int32_t Cout, int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, uint32_t* gate_bits,
+                          const uint32_t* amax_in, uint32_t* amax_out, clica_stream_t stream);
+int clica_conv16_k4s2_dgrad(const float* dO, const uint16_t* WdT16, const float* wscale, int64_t images, int32_t C, int32_t Cout,
+                            int32_t hs, int32_t ws, float* dPrev, int32_t dhs, int32_t dws, const uint32_t* gate_bits,
+                            const uint32_t* amax_in, uint32_t* amax_out, clica_stream_t stream);
+int clica_conv16_k4s2_wgrad_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes);
+int clica_conv16_k4s2_wgrad(const float* dO, const float* S, int64_t images, int32_t C, int32_t Cout, int32_t hs, int32_t ws,
+                            float* dWg, float* db, int32_t accumulate, const uint32_t* amax_dO, const uint32_t* amax_S,
+                            void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Mixing network g  --  construct_invertible_mlp's nn.Sequential forward,
  * /root/reference/invertible_network_utils.py:87-115: bias-free n x n Linear layers with
  * LeakyReLU(slope) between them; frozen (no backward).

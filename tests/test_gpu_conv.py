@@ -10,6 +10,23 @@ from conftest import PARITY, conv_formula
 
 pytestmark = pytest.mark.gpu
 
+_TAG = ""
+
+
+@pytest.fixture(params=["f16x2", "f32"], autouse=True)
+def conv_arith(request):
+    """Every test of this file runs in both arithmetics of the 16C-deep stages (cl_ica_amd/conv.py: f16x2 = csrc/conv16.hip, the default;
+    f32 = the fp32-MFMA kernels of csrc/linear.hip) against the same references at the same tolerances; f32 cases carry a `[conv_f32]` tag."""
+    global _TAG
+    from cl_ica_amd import conv
+    prev = conv.set_arith(request.param)
+    _TAG = "" if request.param == "f16x2" else " [conv_f32]"
+    conv._POOL.clear()
+    yield request.param
+    conv.set_arith(prev)
+    conv._POOL.clear()
+    _TAG = ""
+
 _STAGES = ((32, 4, 2, 1), (32, 4, 2, 1), (64, 4, 2, 1), (64, 4, 2, 1), (256, 4, 1, 0))
 
 
@@ -59,6 +76,7 @@ def _run_hip(x, convs, dfeats):
 
 
 def _compare(family, case, x, convs, dfeats, gate_ties=False):
+    case = case + _TAG
     got_f, got_g = _run_hip(x, convs, dfeats)
     ref_f, ref_g = _reference_fp64(x, convs, dfeats)
     torch.cuda.synchronize()
@@ -123,7 +141,7 @@ def test_conv_stack_buffers_are_reusable_and_switchable(monkeypatch):
     mu_hip = net(xa)
     monkeypatch.setenv("CLICA_CONV", "miopen")
     mu_lib = net(xa)
-    PARITY.check("c5_conv_stack", "BetaVAE_H hip vs nn.Conv2d", "mu", mu_hip.detach().cpu().numpy(), mu_lib.detach().cpu().numpy(), tol=1e-4,
+    PARITY.check("c5_conv_stack", "BetaVAE_H hip vs nn.Conv2d" + _TAG, "mu", mu_hip.detach().cpu().numpy(), mu_lib.detach().cpu().numpy(), tol=1e-4,
                  note="fp32 MIOpen on the other side, not an fp64 reference")
 
 
@@ -152,8 +170,8 @@ def test_conv_stack_input_gradient_vs_fp64(nc, images):
         c64.append(d)
         h = torch.relu(d(h))
     (h.flatten(1) * dfeats.double()).sum().backward()
-    PARITY.check("c5_conv_stack/grad", f"nc={nc} images={images}", "d loss / d image", got_dx.cpu().numpy(), x64.grad.cpu().numpy())
-    PARITY.check("c5_conv_stack/grad", f"nc={nc} images={images}", "stage1.weight (same pass)", got_w1.cpu().numpy(), c64[0].weight.grad.cpu().numpy())
+    PARITY.check("c5_conv_stack/grad", f"nc={nc} images={images}" + _TAG, "d loss / d image", got_dx.cpu().numpy(), x64.grad.cpu().numpy())
+    PARITY.check("c5_conv_stack/grad", f"nc={nc} images={images}" + _TAG, "stage1.weight (same pass)", got_w1.cpu().numpy(), c64[0].weight.grad.cpu().numpy())
     assert float(x64.grad.abs().max()) > 0
     if nc == 1:
         import inspect
@@ -188,7 +206,7 @@ def test_conv_stack_full_batch_zero_mean_upstream_vs_fp64():
     for m in convs:
         lib_g += [m.weight.grad, m.bias.grad]
     torch.cuda.synchronize()
-    PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048", "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
+    PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048" + _TAG, "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
     from conftest import rel_err
     # (per gradient the two fp32 evaluations land on different sides of the ties: compared one to one the bound flickers -- stage1.weight
     #  measured 3.4e-4 against 1.2e-4 for nn.Conv2d in one run, 1.0e-4 against 2.6e-4 in another; so the yardstick is nn.Conv2d's WORST
@@ -197,5 +215,5 @@ def test_conv_stack_full_batch_zero_mean_upstream_vs_fp64():
     tol = min(3e-3, max(1e-5, 3.0 * e_lib))
     for i, (gh, r) in enumerate(zip(got_g, ref_g)):
         name = f"stage{i // 2 + 1}." + ("weight" if i % 2 == 0 else "bias")
-        PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048", name, gh.cpu().numpy(), r.cpu().numpy(), tol=tol,
+        PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048" + _TAG, name, gh.cpu().numpy(), r.cpu().numpy(), tol=tol,
                      note="zero-mean upstream gradient: bound = min(3e-3, 3 x the worst distance of fp32 nn.Conv2d's ten gradients from fp64 on the same data)")

@@ -631,6 +631,12 @@ def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
             opt.step()
         outs[kind] = [p.detach().clone() for p in f.parameters()] + [tot.detach().clone()]
     # (two Adam implementations, three steps at lr = 1e-3: rounding-level gradient differences move an element by << lr)
-    for a, b in zip(outs["flat"][:-1], outs["torch"][:-1]):
-        assert float((a - b).abs().max()) <= 1e-4, float((a - b).abs().max())      # 10 % of lr: an element whose gradient is at rounding level
+    params = list(zip(outs["flat"][:-1], outs["torch"][:-1]))
+    for i, (a, b) in enumerate(params):
+        # 10 % of lr: an element whose gradient is at rounding level.  The LAST bias is all such elements: the loss sees only differences
+        # of embeddings, so d loss / d b_last = sum_i d loss / d z_i is exactly zero and what reaches Adam is summation noise, which Adam
+        # normalises to steps of order lr in whatever direction the noise points (measured 1e-5 ... 1.4e-4 between the two runs): bounded by
+        # the three steps' total travel instead
+        tol = 3e-3 if i == len(params) - 1 else 1e-4
+        assert float((a - b).abs().max()) <= tol, (i, float((a - b).abs().max()))
     assert abs(float(outs["flat"][-1]) - float(outs["torch"][-1])) <= 1e-5 * abs(float(outs["torch"][-1]))
