@@ -399,7 +399,7 @@ static int launch_gemm16_auto(const GArgs& a, hipStream_t st, const char* who) {
 // under the other waves' matrix work.  Wider outputs (N = 256, or K = 1024 x N = 64) are split along N over `nsplit` workgroups.
 constexpr int ST_THREADS = 512;
 template <int NBN>
-__global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit) {
+__global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit, int kperm) {
   extern __shared__ __attribute__((aligned(16))) half_t sB[];      // [2 planes][NBN * 32][K + 8]
   __shared__ unsigned s_word;
   constexpr int NC = NBN * 32, WAVES = ST_THREADS / 64;
@@ -409,45 +409,61 @@ __global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit) {
   const int n_off = part * NC;
   const Geo g = a.g;
   const float sA = tensor_scale(a.amax_in, &s_word);
-  {   // this workgroup's columns of both planes -> LDS
+  {   // this workgroup's columns of both planes -> LDS, eight 16-byte loads in flight per thread (one at a time this prologue was a chain
+      // of 8-16 memory round trips)
     const int per_row = a.K / 8;                         // 16-byte units per row
     const int total = 2 * NC * per_row;
-    for (int v = threadIdx.x; v < total; v += ST_THREADS) {
-      const int plane = v / (NC * per_row), rem = v - plane * (NC * per_row), n = rem / per_row, k8 = rem - n * per_row;
-      const u32x4 w = *reinterpret_cast<const u32x4*>(a.B + (int64_t)plane * a.N * a.K + (int64_t)(n_off + n) * a.K + 8 * k8);
-      *reinterpret_cast<u32x4*>(sB + (plane * NC + n) * LDB + 8 * k8) = w;
+    for (int v0 = threadIdx.x; v0 < total; v0 += 8 * ST_THREADS) {
+      u32x4 w[8];
+      int dst[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int v = v0 + i * ST_THREADS;
+        const int vv = min(v, total - 1);
+        const int plane = vv / (NC * per_row), rem = vv - plane * (NC * per_row), n = rem / per_row, k8 = rem - n * per_row;
+        w[i] = *reinterpret_cast<const u32x4*>(a.B + (int64_t)plane * a.N * a.K + (int64_t)(n_off + n) * a.K + 8 * k8);
+        dst[i] = v < total ? (plane * NC + n) * LDB + 8 * k8 : -1;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (dst[i] >= 0) *reinterpret_cast<u32x4*>(sB + dst[i]) = w[i];
     }
   }
   __syncthreads();
   const float cs = 1.f / (sA * *a.bscale);
   const int ntiles = (int)((a.M + 31) / 32);
   const int KS = a.K / 16;                               // a multiple of 4
+  const int kq = a.K >> 2;
   const half_t* bbase = sB + l31 * LDB + 8 * h;
   const int planeB = NC * LDB;
   float amax = 0.f;
-  for (int tile = wg * WAVES + wave; tile < ntiles; tile += nwg * WAVES) {
+  // contraction index of step s.  kperm: the K axis is four pixel positions (the 2 x 2 window of the space-to-depth grid) of K / 4
+  // channels each; visiting the four positions of one 16-channel block back to back puts the loads of neighbouring rows -- whose windows
+  // overlap in two of the four pixels -- a few instructions apart instead of K / 64 steps, where the L1 can still serve them.
+  auto k_of = [&](int s) { return kperm ? (s & 3) * kq + 16 * (s >> 2) : 16 * s; };
+  auto row_ptr = [&](int tile) -> const float* {
     const int row = min(tile * 32 + l31, (int)a.M - 1);
-    const float* pa;
-    if (g.mode == 2) {
-      pa = a.A + (int64_t)row * a.lda + 8 * h;
-    } else {
-      int img, y, x;
-      row_to_pixel(g, row, img, y, x);
-      pa = a.A + (((int64_t)img * g.ghs + y) * g.gws + x) * a.lda + 8 * h;
-    }
+    if (g.mode == 2) return a.A + (int64_t)row * a.lda + 8 * h;
+    int img, y, x;
+    row_to_pixel(g, row, img, y, x);
+    return a.A + (((int64_t)img * g.ghs + y) * g.gws + x) * a.lda + 8 * h;
+  };
+  float4 q[4][2];
+  const float* pa = nullptr;
+  auto lda = [&](int s, int slot) {
+    const int k = k_of(s);
+    const float* p = pa + k + (k >= a.seg ? a.jump : 0);
+    q[slot][0] = *reinterpret_cast<const float4*>(p);
+    q[slot][1] = *reinterpret_cast<const float4*>(p + 4);
+  };
+  int tile = wg * WAVES + wave;
+  if (tile < ntiles) { pa = row_ptr(tile); lda(0, 0); lda(1, 1); lda(2, 2); }
+  for (; tile < ntiles; tile += nwg * WAVES) {
     f32x16 acc[NBN];
 #pragma unroll
     for (int j = 0; j < NBN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    float4 q[4][2];
-    auto lda = [&](int s, int slot) {
-      const int k = 16 * s;
-      const float* p = pa + k + (k >= a.seg ? a.jump : 0);
-      q[slot][0] = *reinterpret_cast<const float4*>(p);
-      q[slot][1] = *reinterpret_cast<const float4*>(p + 4);
-    };
-    lda(0, 0); lda(1, 1); lda(2, 2);
     for (int s0 = 0; s0 < KS; s0 += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -457,9 +473,10 @@ __global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit) {
         split4(q[u][0], sA, h0, l0);
         split4(q[u][1], sA, h1, l1);
         const u32x4 ahi = {h0.x, h0.y, h1.x, h1.y}, alo = {l0.x, l0.y, l1.x, l1.y};
+        const int kb = k_of(s);
 #pragma unroll
         for (int j = 0; j < NBN; ++j) {
-          const half_t* pb = bbase + j * 32 * LDB + 16 * s;
+          const half_t* pb = bbase + j * 32 * LDB + kb;
           const u32x4 bhi = *reinterpret_cast<const u32x4*>(pb);
           const u32x4 blo = *reinterpret_cast<const u32x4*>(pb + planeB);
           acc[j] = mfma(alo, bhi, acc[j]);
@@ -468,63 +485,81 @@ __global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit) {
         }
       }
     }
-    // epilogue of the wave's 32 x NC block (see gemm16_k), four accumulator rows at a time (the index arithmetic of all sixteen at once
-    // cost 100 registers)
+    // the next tile's first loads go out before this tile's epilogue (their latency hides under the stores)
+    const int next = tile + nwg * WAVES;
+    if (next < ntiles) { pa = row_ptr(next); lda(0, 0); lda(1, 1); lda(2, 2); }
+
+    // ---- epilogue of the wave's 32 x NC block.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The index
+    // arithmetic (row -> pixel -> destination, and the data gradient's gate words) is done ONCE per (row, column block) pair by one lane
+    // of the half-wave that owns the row and handed round by shuffles: every gate word of the tile is requested before the first store,
+    // one memory round trip per tile.  (Per lane and row, with a gate load in front of each group of stores: a chain of sixteen round
+    // trips per tile -- 112 us per data-gradient launch.)
+    if (g.mode == 2) {
+      constexpr int PP = (16 * NBN + 31) / 32;
+      int mypix[PP]; unsigned myword[PP];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-      int64_t off[4];
-      int grow[4], py[4], px[4], pimg[4];
+      for (int pi = 0; pi < PP; ++pi) {
+        const int p = l31 + 32 * pi, r = p & 15, j = p >> 4;
+        const int orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int col0 = n_off + 32 * j, qd = col0 / g.c, cw = (col0 - qd * g.c) >> 5;
+        mypix[pi] = -1; myword[pi] = 0u;
+        if (p < 16 * NBN && orow < a.M) {
+          int img, y, x;
+          row_to_pixel(g, orow, img, y, x);
+          const int yy = 2 * y + (qd >> 1) - 1, xx = 2 * x + (qd & 1) - 1;
+          if (yy >= 0 && xx >= 0 && yy < g.dho && xx < g.dwo) {
+            mypix[pi] = (img * g.dhs + yy) * g.dws + xx;
+            myword[pi] = a.gate_in[(int64_t)mypix[pi] * (g.c >> 5) + cw];
+          }
+        }
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int orow = tile * 32 + i + 8 * rb + 4 * h;
-        off[i] = -1; grow[i] = 0; py[i] = px[i] = pimg[i] = 0;
-        if (orow >= a.M) continue;
-        int img, y, x;
-        row_to_pixel(g, orow, img, y, x);
-        pimg[i] = img; py[i] = y; px[i] = x;
-        if (g.mode == 3) {
-          off[i] = (int64_t)((img * g.ghs + y) * g.gws + x) * a.N;
-        } else if (g.mode == 1) {
-          const int Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
-          off[i] = (((int64_t)img * g.dhs + Y) * g.dws + X) * (4 * g.c) + qq * g.c;
-          grow[i] = (img * g.ghs + y) * g.gws + x;
-        } else {
-          off[i] = 0;
+      for (int j = 0; j < NBN; ++j) {
+        const int col0 = n_off + 32 * j, ch = col0 % g.c + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = 16 * j + r, src = (p & 31) + 32 * h;
+          const int pix = __shfl(mypix[p >> 5], src, 64);
+          const unsigned word = (unsigned)__shfl((int)myword[p >> 5], src, 64);
+          if (pix < 0) continue;
+          const float v = ((word >> l31) & 1u) ? acc[j][r] * cs : 0.f;
+          a.C[(int64_t)pix * g.c + ch] = v;
+          amax = fmaxf(amax, fabsf(v));
+        }
+      }
+    } else {
+      int myoff = -1, mygrow = 0;                          // lanes 0..15 of each half: row r = lane & 15 of the half's sixteen
+      {
+        const int r = l31 & 15;
+        const int orow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (orow < a.M) {
+          int img, y, x;
+          row_to_pixel(g, orow, img, y, x);
+          if (g.mode == 3) {
+            myoff = ((img * g.ghs + y) * g.gws + x) * a.N;
+          } else {
+            const int Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
+            myoff = ((img * g.dhs + Y) * g.dws + X) * (4 * g.c) + qq * g.c;
+            mygrow = (img * g.ghs + y) * g.gws + x;
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < NBN; ++j) {
         const int col = n_off + j * 32 + l31;
-        if (g.mode == 2) {
-          const int qd = col / g.c, ch = col - qd * g.c;
-          int64_t pix[4];
-          unsigned gw[4];
+        const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int yy = 2 * py[i] + (qd >> 1) - 1, xx = 2 * px[i] + (qd & 1) - 1;
-            pix[i] = (off[i] < 0 || yy < 0 || xx < 0 || yy >= g.dho || xx >= g.dwo) ? -1 : ((int64_t)pimg[i] * g.dhs + yy) * g.dws + xx;
-            gw[i] = pix[i] >= 0 ? a.gate_in[pix[i] * (g.c >> 5) + (ch >> 5)] : 0u;
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (pix[i] < 0) continue;
-            const float v = ((gw[i] >> (ch & 31)) & 1u) ? acc[j][4 * rb + i] * cs : 0.f;
-            a.C[pix[i] * g.c + ch] = v;
-            amax = fmaxf(amax, fabsf(v));
-          }
-        } else {
-          const float bv = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (off[i] < 0) continue;
-            float v = acc[j][4 * rb + i] * cs + bv;
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            a.C[off[i] + col] = v;
-            amax = fmaxf(amax, fabsf(v));
-            if (g.mode == 1 && a.gate_out) {
-              const unsigned long long bits = __ballot(v > 0.f);
-              if (l31 == 0) a.gate_out[(int64_t)grow[i] * (a.N >> 5) + (col >> 5)] = (unsigned)(bits >> (32 * h));
-            }
+        for (int r = 0; r < 16; ++r) {
+          const int off = __shfl(myoff, r + 32 * h, 64);
+          if (off < 0) continue;
+          float v = acc[j][r] * cs + bv;
+          if (a.relu) v = v > 0.f ? v : 0.f;
+          a.C[(int64_t)off + col] = v;
+          amax = fmaxf(amax, fabsf(v));
+          if (g.mode == 1 && a.gate_out) {
+            const int grow = __shfl(mygrow, r + 32 * h, 64);
+            const unsigned long long bits = __ballot(v > 0.f);
+            if (l31 == 0) a.gate_out[(int64_t)grow * (a.N >> 5) + (col >> 5)] = (unsigned)(bits >> (32 * h));
           }
         }
       }
@@ -543,7 +578,8 @@ static int launch_stream16_n(const GArgs& a, int nsplit, hipStream_t st, const c
   const int64_t tiles = ceil_div(a.M, 32);
   int64_t wgs = std::min<int64_t>((int64_t)per_cu * kNumCU / nsplit, ceil_div(tiles, ST_THREADS / 64));
   wgs = std::max<int64_t>(wgs, 1);
-  hipLaunchKernelGGL(k, dim3((unsigned)(wgs * nsplit)), dim3(ST_THREADS), lds, st, a, nsplit);
+  static const int kperm = [] { const char* e = getenv("CLICA_CONV16_KPERM"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  hipLaunchKernelGGL(k, dim3((unsigned)(wgs * nsplit)), dim3(ST_THREADS), lds, st, a, nsplit, (a.K % 64 == 0 && (a.K / 4) % 16 == 0) ? kperm : 0);
   return launch_status(who);
 }
 // false: the shape does not fit the streaming kernel (the caller takes the tiled one)
@@ -770,6 +806,12 @@ __global__ __launch_bounds__(256) void slab_sum_k(const float* __restrict__ slab
   }
 }
 
+// (also used by linear.hip's first-stage weight gradient)
+void launch_slab_sum(const float* slab1, int n1, float* out1, const float* slab2, int n2, float* out2, int splits, int accumulate, hipStream_t st) {
+  const int blocks1 = (int)ceil_div(n1 / 4, 16), blocks2 = out2 ? (int)ceil_div(n2 / 4, 16) : 0;
+  hipLaunchKernelGGL(slab_sum_k, dim3((unsigned)(blocks1 + blocks2)), dim3(256), 0, st, slab1, n1, out1, slab2, n2, out2, splits, accumulate, blocks1);
+}
+
 struct WPlan { int splits; int64_t rows_per_split; };
 static WPlan plan_wgrad(int64_t rows, int K) {
   const int ktiles = K / WG_COLS;
@@ -888,8 +930,6 @@ extern "C" int clica_conv16_k4s2_wgrad(const float* dO, const float* S, int64_t 
   else hipLaunchKernelGGL(wgrad16_k<2>, dim3(nwg), dim3(WG_THREADS), 0, st, a);
   int rc = launch_status("clica_conv16_k4s2_wgrad");
   if (rc) return rc;
-  const int blocks1 = (int)ceil_div((int64_t)Cout * K / 4, 16), blocks2 = db ? (int)ceil_div(Cout / 4, 16) : 0;
-  hipLaunchKernelGGL(slab_sum_k, dim3((unsigned)(blocks1 + blocks2)), dim3(256), 0, st, a.slab, Cout * K, dWg, a.dbslab, (int)Cout, db, p.splits,
-                     accumulate ? 1 : 0, blocks1);
+  launch_slab_sum(a.slab, Cout * K, dWg, a.dbslab, (int)Cout, db, p.splits, accumulate ? 1 : 0, st);
   return launch_status("clica_conv16_k4s2_wgrad(reduce)");
 }

@@ -30,6 +30,9 @@ bool skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, const 
 bool skinny_dgrad(const float* dY, int64_t lddy, const float* W, int64_t ldw, const float* Xact, int64_t ldxa, float slope,
                   float* dX, int64_t lddx, int64_t M, int64_t N, int64_t K, hipStream_t st);
 
+namespace conv16 {   // conv16.hip
+void launch_slab_sum(const float* slab1, int n1, float* out1, const float* slab2, int n2, float* out2, int splits, int accumulate, hipStream_t st);
+}
 namespace gemm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -2083,7 +2086,11 @@ extern "C" int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patch
                      slab, db ? dbslab : (float*)nullptr);
   int rc = launch_status("clica_conv_k4s2_wgrad_patches");
   if (rc) return rc;
-  launch_slab_reduce(slab, dbslab, p.blocks, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
+  // thousands of small slabs: the 16-way split reduction of conv16.hip (the shared slab_reduce_k walks them as four chains: 31 us here)
+  if ((Cout * K) % 4 == 0 && Cout % 4 == 0 && aligned16(dWg) && (!db || aligned16(db)))
+    conv16::launch_slab_sum(slab, Cout * K, dWg, db ? dbslab : nullptr, Cout, db, p.blocks, accumulate ? 1 : 0, st);
+  else
+    launch_slab_reduce(slab, dbslab, p.blocks, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
   return launch_status("clica_conv_k4s2_wgrad_patches(reduce)");
 }
 

@@ -42,25 +42,88 @@ def _convs(nc, dtype=torch.float32):
     return mods
 
 
-def _reference_fp64(x, convs32, dfeats, chunk=256):
-    """Features and parameter gradients of the Conv2d + ReLU stack in fp64 (ATen's fp64 convolution on the GPU), in chunks of images."""
+def _reference_fp64(x, convs32, dfeats, chunk=256, hip_gate=None):
+    """Features and parameter gradients of the Conv2d + ReLU stack in fp64 (ATen's fp64 convolution on the GPU), in chunks of images.
+    `hip_gate` (from _hip_gates): the first three stages are gated by the bits the HIP forward wrote instead of by the sign of the fp64
+    pre-activation; returns also, per stage, (number of elements gated differently, largest |fp64 pre-activation| among them / max)."""
     convs = []
     for m in convs32:
         d = torch.nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding).to("cuda", torch.float64)
         d.weight.data = m.weight.data.double(); d.bias.data = m.bias.data.double()
         convs.append(d)
     feats = []
+    mism = [[0, 0.0, 0.0] for _ in range(3)]
     for i0 in range(0, x.shape[0], chunk):
         h = x[i0:i0 + chunk].double()
-        for m in convs:
-            h = torch.relu(m(h))
+        for l, m in enumerate(convs):
+            z = m(h)
+            if hip_gate is not None and l < 3:
+                hg = hip_gate[l][i0:i0 + chunk]
+                diff = (z > 0) != hg
+                za = z.detach().abs()
+                mism[l][0] += int(diff.sum()); mism[l][2] = max(mism[l][2], float(za.max()))
+                if diff.any():
+                    mism[l][1] = max(mism[l][1], float(za[diff].max()))
+                h = z * hg.double()
+            else:
+                h = torch.relu(z)
         h = h.flatten(1)
         (h * dfeats[i0:i0 + chunk].double()).sum().backward()
         feats.append(h.detach())
     grads = []
     for m in convs:
         grads += [m.weight.grad, m.bias.grad]
+    if hip_gate is not None:
+        return torch.cat(feats), grads, [(n, (zm / allm if allm > 0 else 0.0)) for n, zm, allm in mism]
     return torch.cat(feats), grads
+
+
+def _hip_gates(images, device):
+    """The (output > 0) bits the last HIP forward of `images` one-channel images left in its pooled buffers, per stage as [img][ch][y][x]."""
+    from cl_ica_amd import conv
+    buf = conv._POOL[(images, 1, device.index)][0]
+    gates = []
+    for l in range(3):
+        cout, ho = conv.STAGES[l]
+        grid = ho if l == 0 else ho + 1
+        w = buf.gate[l].view(images, grid, grid, cout // 32)[:, :ho, :ho, :].to(torch.int64) & 0xFFFFFFFF
+        bits = ((w.unsqueeze(-1) >> torch.arange(32, device=w.device)) & 1).reshape(images, ho, ho, cout)
+        gates.append(bits.permute(0, 3, 1, 2).bool())
+    return gates
+
+
+_TIE_NOTE = ("informational: plain fp64 reference.  A pre-activation within rounding of zero is gated differently by the HIP forward and the "
+             "fp64 forward, and ONE such element moves a weight gradient of the stages below it by 1e-5 ... 1e-3 (tools/conv_tie_probe.py, "
+             "profiles/r5_conv_gate_ties.json: one stage-3 element at 2e-8 of max|z| accounts for 3.0e-5 on stage3.weight); the asserted "
+             "statement is the comparison with the HIP gates forced into the fp64 reference")
+
+
+def _compare_full_batch(family, case, x, convs, dfeats, tol_forced, note_forced=""):
+    """The 2048-image batch: (a) gates the HIP forward decided differently from the fp64 forward are ties (|z| <= 1e-6 max|z|) and few;
+    (b) against the fp64 reference evaluated WITH the HIP gates every gradient holds `tol_forced`; (c) the plain comparison is logged."""
+    from cl_ica_amd import conv
+    case = case + _TAG
+    conv._POOL.clear()
+    got_f, got_g = _run_hip(x, convs, dfeats)
+    torch.cuda.synchronize()
+    gates = _hip_gates(x.shape[0], x.device)
+    ref_f, ref_g = _reference_fp64(x, convs, dfeats)
+    ref_g = [t.clone() for t in ref_g]
+    frc_f, frc_g, mism = _reference_fp64(x, convs, dfeats, hip_gate=gates)
+    torch.cuda.synchronize()
+    PARITY.check(family, case, "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
+    assert float(ref_f.abs().max()) > 1e-2 and float((ref_f > 0).float().mean()) > 0.05
+    for l, (n, zrel) in enumerate(mism):
+        assert n <= 64 and zrel <= 1e-6, f"stage {l + 1}: {n} gates differ from the fp64 forward, largest |z| / max|z| = {zrel:.2e} (ties only expected)"
+    for i, (gh, r, rf) in enumerate(zip(got_g, ref_g, frc_g)):
+        name = f"stage{i // 2 + 1}." + ("weight" if i % 2 == 0 else "bias")
+        assert gh.shape == r.shape
+        if tol_forced == 1e-5:
+            PARITY.check(family + "/grad", case, name + " (fp64 with the HIP gates)", gh.cpu().numpy(), rf.cpu().numpy())
+        else:
+            PARITY.check(family + "/grad", case, name + " (fp64 with the HIP gates)", gh.cpu().numpy(), rf.cpu().numpy(), tol=tol_forced, note=note_forced)
+        PARITY.check(family + "/plain_reference", case, name, gh.cpu().numpy(), r.cpu().numpy(), tol=2e-2, note=_TIE_NOTE)
+    return mism
 
 
 def _run_hip(x, convs, dfeats):
@@ -105,17 +168,15 @@ def test_conv_stack_small_vs_fp64(nc, images):
 
 
 def test_conv_stack_full_batch_vs_fp64():
-    """BASELINE configs[4]'s batch: 2048 binary 64 x 64 masks."""
+    """BASELINE configs[4]'s batch: 2048 binary 64 x 64 masks.  Every gradient within 1e-5 of the fp64 reference evaluated with the gates
+    the HIP forward decided (measured 1.3e-7 ... 2.6e-7 in f16x2); the gates that differ from the fp64 forward's are ties."""
     g = torch.Generator().manual_seed(7)
     # blobs rather than white noise: threshold a smoothed field so that masks have the data set's large connected regions
     field = torch.nn.functional.avg_pool2d(torch.randn(2048, 1, 64, 64, generator=g), 9, 1, 4)
     x = (field > 0.05).float().to("cuda")
-    # Upstream gradient of one sign pattern per feature, not white noise: with a zero-mean dfeats every weight gradient is a random-walk sum
-    # over up to 592 k pixels, |sum| ~ sqrt(n) |term|, and ONE ReLU gate that the fp32 and the fp64 forward decide differently (a
-    # pre-activation within rounding of zero) moves it by 1/sqrt(n) ~ 1e-3 -- measured: 3e-4 ... 1e-3 here and 2e-3 ... 5e-3 for
-    # nn.Conv2d in fp32 on the same data (tools/conv_err_probe.py); that is the conditioning of the test, not of the kernels
+    # upstream gradient of one sign pattern per feature (the zero-mean case is the test at the end of this file)
     dfeats = ((torch.randn(2048, 256, generator=g).abs() + 0.1) / 2048).to("cuda")
-    _compare("c5_conv_stack", "nc=1 images=2048", x, _convs(1), dfeats, gate_ties=True)
+    _compare_full_batch("c5_conv_stack", "nc=1 images=2048", x, _convs(1), dfeats, 1e-5)
 
 
 def test_conv_stack_buffers_are_reusable_and_switchable(monkeypatch):
@@ -184,36 +245,14 @@ def test_conv_stack_input_gradient_vs_fp64(nc, images):
 
 def test_conv_stack_full_batch_zero_mean_upstream_vs_fp64():
     """The full 2048-mask batch with a ZERO-MEAN upstream gradient (the all-positive dfeats of the test above cannot show
-    cancellation).  Every weight gradient is then a random-walk sum over up to 592 k pixels, |sum| ~ sqrt(n) |term|, and ONE ReLU gate that
-    the fp32 and the fp64 forward decide differently (a pre-activation within fp32 rounding of zero) moves it by ~1 / sqrt(n): that is the
-    conditioning of the comparison, not of the kernels -- so the bound is stated against what fp32 nn.Conv2d / MIOpen shows ON THE SAME DATA
-    against the same fp64 reference: every gradient of the HIP stack within 3 x the WORST of nn.Conv2d's ten gradients, and never beyond 3e-3
-    (measured round 5: 1.3e-3 worst, nn.Conv2d 1.1e-3 worst; profiles/r5_parity_errors.json, family c5_conv_stack/zero_mean)."""
+    cancellation).  Every weight gradient is then a random-walk sum over up to 592 k pixels, |sum| ~ sqrt(n) |term|: rounding errors of the
+    terms weigh ~sqrt(n) more against max|dW| than in the test above (measured with the HIP gates forced: 1.4e-6 ... 2.3e-5 in f16x2), and
+    ONE ReLU gate that the fp32 and the fp64 forward decide differently moves a gradient by ~1 / sqrt(n) ~ 1e-3 -- which is why the asserted
+    comparison forces the HIP gates into the fp64 reference (bound 1e-4) and the plain comparison is logged only.  fp32 nn.Conv2d on the
+    same data, for scale, sits 1e-3 ... 5e-3 from the plain fp64 reference (round 4/5 records)."""
     g = torch.Generator().manual_seed(7)
     field = torch.nn.functional.avg_pool2d(torch.randn(2048, 1, 64, 64, generator=g), 9, 1, 4)
     x = (field > 0.05).float().to("cuda")
     dfeats = (torch.randn(2048, 256, generator=g) / 2048).to("cuda")
-    convs = _convs(1)
-    got_f, got_g = _run_hip(x, convs, dfeats)
-    ref_f, ref_g = _reference_fp64(x, convs, dfeats)
-    for m in convs:
-        m.weight.grad = None; m.bias.grad = None
-    h = x
-    for m in convs:
-        h = torch.relu(m(h))
-    h.flatten(1).backward(dfeats)
-    lib_g = []
-    for m in convs:
-        lib_g += [m.weight.grad, m.bias.grad]
-    torch.cuda.synchronize()
-    PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048" + _TAG, "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
-    from conftest import rel_err
-    # (per gradient the two fp32 evaluations land on different sides of the ties: compared one to one the bound flickers -- stage1.weight
-    #  measured 3.4e-4 against 1.2e-4 for nn.Conv2d in one run, 1.0e-4 against 2.6e-4 in another; so the yardstick is nn.Conv2d's WORST
-    #  gradient on this data)
-    e_lib = max(rel_err(gl.cpu().numpy(), r.cpu().numpy()) for gl, r in zip(lib_g, ref_g))
-    tol = min(3e-3, max(1e-5, 3.0 * e_lib))
-    for i, (gh, r) in enumerate(zip(got_g, ref_g)):
-        name = f"stage{i // 2 + 1}." + ("weight" if i % 2 == 0 else "bias")
-        PARITY.check("c5_conv_stack/zero_mean", "nc=1 images=2048" + _TAG, name, gh.cpu().numpy(), r.cpu().numpy(), tol=tol,
-                     note="zero-mean upstream gradient: bound = min(3e-3, 3 x the worst distance of fp32 nn.Conv2d's ten gradients from fp64 on the same data)")
+    _compare_full_batch("c5_conv_stack/zero_mean", "nc=1 images=2048", x, _convs(1), dfeats, 1e-4,
+                        "zero-mean upstream gradient: the gradients are cancelling sums (max|dW| ~ sqrt(n) |term|), bound 1e-4 against fp64 with the HIP gates")
