@@ -165,6 +165,8 @@ SIGNATURES: Dict[str, list] = {
     "clica_conv_k4s2_wgrad_patches": [c_f32p, c_f32p, c_i64, c_i32, c_i32, c_f32p, c_f32p, c_i32, C.c_void_p, c_size, C.c_void_p],
     "clica_conv_k4s2_dgrad_input": [c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p],
     "clica_conv_gather": [c_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_i32, C.c_void_p],
+    "clica_conv_k4s2_fwd_image": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "clica_conv_k4s2_wgrad_image": [c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_f32p, c_f32p, c_i32, C.c_void_p, c_size, C.c_void_p],
     "clica_conv16_pack": [c_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_f32p, C.c_void_p],
     "clica_conv16_amax": [c_f32p, c_i64, C.c_void_p, C.c_void_p],
     "clica_conv16_zero_slots": [C.c_void_p, c_i32, C.c_void_p],

@@ -33,6 +33,7 @@ _ARITH = os.environ.get("CLICA_CONV_ARITH", "f16x2")
 if _ARITH not in ("f16x2", "f32"):
     raise ValueError(f"CLICA_CONV_ARITH={_ARITH!r}: 'f16x2' or 'f32'")
 _SLOTS = 256          # csrc/conv16.hip: kSlots
+_FIRST_FROM_IMAGE = os.environ.get("CLICA_CONV_FIRST", "image") != "patches"      # A/B switch for the one-channel first stage
 
 
 def set_arith(name: str) -> str:
@@ -60,7 +61,7 @@ class _Buffers:
     def __init__(self, images: int, nc: int, device):
         f32 = dict(dtype=torch.float32, device=device)
         self.images, self.nc = images, nc
-        self.patches = torch.empty((images * 32 * 32, 16 * nc), **f32)
+        self._patches = None                            # patch matrix of the first stage, allocated on first use (nc = 1 reads the images instead)
         self.S: Dict[int, torch.Tensor] = {}        # stage index (1..3) -> its space-to-depth INPUT, flat, zero tail
         self.dO: Dict[int, torch.Tensor] = {}       # stage index (0..3) -> gradient of its pre-activation output on its row grid
         self._dO_store: Dict[int, torch.Tensor] = {}
@@ -95,6 +96,12 @@ class _Buffers:
             self.ws1p = torch.empty(nbytes.value, dtype=torch.uint8, device=device)
         else:
             self.ws1 = ops.mlp_wgrad_workspace(images * 32 * 32, [(STAGES[0][0], 16 * nc)], device)
+
+
+    def patches_(self) -> torch.Tensor:
+        if self._patches is None:
+            self._patches = torch.empty((self.images * 32 * 32, 16 * self.nc), dtype=torch.float32, device=self.amax.device)
+        return self._patches
 
 
 _POOL: Dict[Tuple, List[_Buffers]] = {}
@@ -208,7 +215,9 @@ class _ConvStackFn(torch.autograd.Function):
         dev = x.device
         buf = _take(images, nc, dev)
         x = x.detach().contiguous()
-        check(lib.clica_conv_im2col_k4s2(x.data_ptr(), images, nc, _IMAGE, _IMAGE, buf.patches.data_ptr(), st), "clica_conv_im2col_k4s2")
+        from_image = nc == 1 and _FIRST_FROM_IMAGE      # one input channel: the first stage reads the images themselves, no patch matrix
+        if not from_image:
+            check(lib.clica_conv_im2col_k4s2(x.data_ptr(), images, nc, _IMAGE, _IMAGE, buf.patches_().data_ptr(), st), "clica_conv_im2col_k4s2")
         m = _maps(nc, dev)
         if buf.wpack is None:
             buf.wpack = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in m["pack_shapes"]]
@@ -224,9 +233,14 @@ class _ConvStackFn(torch.autograd.Function):
             _gather(srcs, m["pack"], buf.wpack)          # W1g, W2g, W3g, W4g, W2d, W3d, W4d, W5g in one launch
         w1g = buf.wpack[0]
         in_kernel = f16 and nc == 1        # the K = 16 masks kernel records its output's maximum itself; other first stages get a pass of their own
-        check(lib.clica_conv_k4s2_fwd_patches_amax(buf.patches.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
-                                                   32, 32, 1, 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), _slots(buf, 0) if in_kernel else None, st),
-              "clica_conv_k4s2_fwd_patches")
+        if from_image:
+            check(lib.clica_conv_k4s2_fwd_image(x.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, _IMAGE, _IMAGE, STAGES[0][0], 1,
+                                                buf.S[1].data_ptr(), buf.gate[0].data_ptr(), _slots(buf, 0) if in_kernel else None, st),
+                  "clica_conv_k4s2_fwd_image")
+        else:
+            check(lib.clica_conv_k4s2_fwd_patches_amax(buf.patches_().data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, 16 * nc, STAGES[0][0],
+                                                       32, 32, 1, 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), _slots(buf, 0) if in_kernel else None, st),
+                  "clica_conv_k4s2_fwd_patches")
         if f16 and not in_kernel:
             check(lib.clica_conv16_amax(buf.S[1].data_ptr(), buf.S[1].numel(), _slots(buf, 0), st), "clica_conv16_amax")
         cin = STAGES[0][0]
@@ -249,6 +263,7 @@ class _ConvStackFn(torch.autograd.Function):
                                               feats.data_ptr(), None, st), "clica_conv_k4s2_fwd_patches")
         if keep:
             ctx.buf, ctx.w5g, ctx.nc, ctx.f16 = buf, w5g, nc, f16
+            ctx.x_image = x if from_image else None
             ctx.params = params
             ctx.save_for_backward(feats, *ws_)
         else:
@@ -304,11 +319,14 @@ class _ConvStackFn(torch.autograd.Function):
         cout = STAGES[0][0]
         dw1g = torch.empty((cout, 16 * nc), dtype=torch.float32, device=dev)
         db1 = torch.empty((cout,), dtype=torch.float32, device=dev)
-        if buf.ws1p is not None:
-            check(lib.clica_conv_k4s2_wgrad_patches(buf.dO[0].data_ptr(), buf.patches.data_ptr(), images * 32 * 32, cout, 16 * nc, dw1g.data_ptr(),
+        if ctx.x_image is not None:
+            check(lib.clica_conv_k4s2_wgrad_image(buf.dO[0].data_ptr(), ctx.x_image.data_ptr(), images, _IMAGE, _IMAGE, cout, dw1g.data_ptr(),
+                                                  db1.data_ptr(), 0, buf.ws1p.data_ptr(), buf.ws1p.numel(), st), "clica_conv_k4s2_wgrad_image")
+        elif buf.ws1p is not None:
+            check(lib.clica_conv_k4s2_wgrad_patches(buf.dO[0].data_ptr(), buf.patches_().data_ptr(), images * 32 * 32, cout, 16 * nc, dw1g.data_ptr(),
                                                     db1.data_ptr(), 0, buf.ws1p.data_ptr(), buf.ws1p.numel(), st), "clica_conv_k4s2_wgrad_patches")
         else:
-            ops.mlp_wgrad([buf.dO[0].view(-1, cout)], [buf.patches], [dw1g], [db1], ws=buf.ws1)
+            ops.mlp_wgrad([buf.dO[0].view(-1, cout)], [buf.patches_()], [dw1g], [db1], ws=buf.ws1)
         dwg_all[0], grads[1] = dw1g, db1
         m = _maps(nc, dev)
         prm = ctx.params

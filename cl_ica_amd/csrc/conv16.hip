@@ -399,7 +399,7 @@ static int launch_gemm16_auto(const GArgs& a, hipStream_t st, const char* who) {
 // under the other waves' matrix work.  Wider outputs (N = 256, or K = 1024 x N = 64) are split along N over `nsplit` workgroups.
 constexpr int ST_THREADS = 512;
 template <int NBN>
-__global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit, int kperm) {
+__global__ __launch_bounds__(ST_THREADS, NBN == 1 ? 4 : 2) void stream16_k(GArgs a, int nsplit, int kperm) {
   extern __shared__ __attribute__((aligned(16))) half_t sB[];      // [2 planes][NBN * 32][K + 8]
   __shared__ unsigned s_word;
   constexpr int NC = NBN * 32, WAVES = ST_THREADS / 64;
@@ -432,29 +432,33 @@ __global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit, in
   __syncthreads();
   const float cs = 1.f / (sA * *a.bscale);
   const int ntiles = (int)((a.M + 31) / 32);
-  const int KS = a.K / 16;                               // a multiple of 4
+  const int NB = a.K / 32;                               // 32-deep contraction blocks, a multiple of 4
   const int kq = a.K >> 2;
-  const half_t* bbase = sB + l31 * LDB + 8 * h;
+  const half_t* bbase = sB + l31 * LDB + 16 * h;
   const int planeB = NC * LDB;
   float amax = 0.f;
-  // contraction index of step s.  kperm: the K axis is four pixel positions (the 2 x 2 window of the space-to-depth grid) of K / 4
-  // channels each; visiting the four positions of one 16-channel block back to back puts the loads of neighbouring rows -- whose windows
-  // overlap in two of the four pixels -- a few instructions apart instead of K / 64 steps, where the L1 can still serve them.
-  auto k_of = [&](int s) { return kperm ? (s & 3) * kq + 16 * (s >> 2) : 16 * s; };
+  // A lane fetches 64 contiguous bytes per block -- floats [16 h, 16 h + 16) of the row's 32 -- so the two lanes of a row take one whole
+  // 128-byte line with four back-to-back loads, and the block's two 16-deep matrix steps pair A floats 16 h + 8 u + j with the B
+  // elements at the same offsets (the contraction order is free).  (Eight floats per lane and step touched every line twice, four
+  // steps apart: with half-lines as the unit the L1 missed 16.8 M times per launch and the kernel waited 68 % of its cycles.)
+  // kperm: the K axis is four pixel positions (the 2 x 2 window of the space-to-depth grid) of K / 4 channels each; visiting the four
+  // positions of one 32-channel block back to back puts the loads of neighbouring rows -- whose windows overlap in two of the four
+  // pixels -- a few instructions apart instead of K / 128 blocks.
+  auto k_of = [&](int blk) { return kperm ? (blk & 3) * kq + 32 * (blk >> 2) : 32 * blk; };
   auto row_ptr = [&](int tile) -> const float* {
     const int row = min(tile * 32 + l31, (int)a.M - 1);
-    if (g.mode == 2) return a.A + (int64_t)row * a.lda + 8 * h;
+    if (g.mode == 2) return a.A + (int64_t)row * a.lda + 16 * h;
     int img, y, x;
     row_to_pixel(g, row, img, y, x);
-    return a.A + (((int64_t)img * g.ghs + y) * g.gws + x) * a.lda + 8 * h;
+    return a.A + (((int64_t)img * g.ghs + y) * g.gws + x) * a.lda + 16 * h;
   };
-  float4 q[4][2];
+  float4 q[4][4];
   const float* pa = nullptr;
-  auto lda = [&](int s, int slot) {
-    const int k = k_of(s);
+  auto lda = [&](int blk, int slot) {
+    const int k = k_of(blk);
     const float* p = pa + k + (k >= a.seg ? a.jump : 0);
-    q[slot][0] = *reinterpret_cast<const float4*>(p);
-    q[slot][1] = *reinterpret_cast<const float4*>(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[slot][i] = *reinterpret_cast<const float4*>(p + 4 * i);
   };
   int tile = wg * WAVES + wave;
   if (tile < ntiles) { pa = row_ptr(tile); lda(0, 0); lda(1, 1); lda(2, 2); }
@@ -464,24 +468,27 @@ __global__ __launch_bounds__(ST_THREADS) void stream16_k(GArgs a, int nsplit, in
     for (int j = 0; j < NBN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int s0 = 0; s0 < KS; s0 += 4) {
+    for (int b0 = 0; b0 < NB; b0 += 4) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int s = s0 + u;
-        if (s + 3 < KS) lda(s + 3, (u + 3) & 3);
-        u32x2 h0, l0, h1, l1;
-        split4(q[u][0], sA, h0, l0);
-        split4(q[u][1], sA, h1, l1);
-        const u32x4 ahi = {h0.x, h0.y, h1.x, h1.y}, alo = {l0.x, l0.y, l1.x, l1.y};
-        const int kb = k_of(s);
+        const int blk = b0 + u;
+        if (blk + 3 < NB) lda(blk + 3, (u + 3) & 3);
+        const int kb = k_of(blk);
 #pragma unroll
-        for (int j = 0; j < NBN; ++j) {
-          const half_t* pb = bbase + j * 32 * LDB + kb;
-          const u32x4 bhi = *reinterpret_cast<const u32x4*>(pb);
-          const u32x4 blo = *reinterpret_cast<const u32x4*>(pb + planeB);
-          acc[j] = mfma(alo, bhi, acc[j]);
-          acc[j] = mfma(ahi, blo, acc[j]);
-          acc[j] = mfma(ahi, bhi, acc[j]);
+        for (int sub = 0; sub < 2; ++sub) {
+          u32x2 h0, l0, h1, l1;
+          split4(q[u][2 * sub], sA, h0, l0);
+          split4(q[u][2 * sub + 1], sA, h1, l1);
+          const u32x4 ahi = {h0.x, h0.y, h1.x, h1.y}, alo = {l0.x, l0.y, l1.x, l1.y};
+#pragma unroll
+          for (int j = 0; j < NBN; ++j) {
+            const half_t* pb = bbase + j * 32 * LDB + kb + 8 * sub;
+            const u32x4 bhi = *reinterpret_cast<const u32x4*>(pb);
+            const u32x4 blo = *reinterpret_cast<const u32x4*>(pb + planeB);
+            acc[j] = mfma(alo, bhi, acc[j]);
+            acc[j] = mfma(ahi, blo, acc[j]);
+            acc[j] = mfma(ahi, bhi, acc[j]);
+          }
         }
       }
     }
@@ -579,13 +586,13 @@ static int launch_stream16_n(const GArgs& a, int nsplit, hipStream_t st, const c
   int64_t wgs = std::min<int64_t>((int64_t)per_cu * kNumCU / nsplit, ceil_div(tiles, ST_THREADS / 64));
   wgs = std::max<int64_t>(wgs, 1);
   static const int kperm = [] { const char* e = getenv("CLICA_CONV16_KPERM"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  hipLaunchKernelGGL(k, dim3((unsigned)(wgs * nsplit)), dim3(ST_THREADS), lds, st, a, nsplit, (a.K % 64 == 0 && (a.K / 4) % 16 == 0) ? kperm : 0);
+  hipLaunchKernelGGL(k, dim3((unsigned)(wgs * nsplit)), dim3(ST_THREADS), lds, st, a, nsplit, (a.K / 4) % 32 == 0 ? kperm : 0);
   return launch_status(who);
 }
 // false: the shape does not fit the streaming kernel (the caller takes the tiled one)
 static bool stream16_fits(const GArgs& a, int& nbn, int& nsplit) {
   static const bool on = [] { const char* e = getenv("CLICA_CONV16_STREAM"); return !(e && atoi(e) == 0); }();
-  if (!on || a.N % 32 || a.K % 64 || a.seg % 16) return false;
+  if (!on || a.N % 32 || a.K % 128 || a.seg % 32) return false;
   for (nbn = std::min(4, a.N / 32); nbn >= 1; nbn >>= 1) {
     if ((a.N / 32) % nbn) continue;
     if ((size_t)2 * nbn * 32 * (a.K + 8) * sizeof(half_t) <= 150 * 1024) { nsplit = a.N / (32 * nbn); return nbn != 3; }
@@ -603,23 +610,29 @@ static int launch_conv16(const GArgs& a, hipStream_t st, const char* who) {
 }
 
 // ---- weight gradient: dWg[Cout][K] = sum_r dO[r][Cout] A[r][K], contraction over the rows of the stage's grid --------------------
+// The implicit operand is the same S pixel seen through four shifts: A[r][(dy, dx, j)] = S[r + dy ws + dx][j] (j < 4C), so with p = the
+// S row,   dWg[co][(dy, dx), j] = sum_p dO[p - dy ws - dx][co] S[p][j]:   one pass over S serves all four (dy, dx) blocks of dWg, each
+// against dO shifted by 0 / 1 / ws / ws + 1 rows.  (Taking the four blocks as four column tiles of one GEMM, as the fp32 path does, reads
+// S four times -- 1.2 GB through L2 on the widest stage, 156 us.)  A workgroup (eight waves) owns all Cout rows x 128 columns j of the
+// four blocks for one contraction split: per step of 32 S rows it fetches the 32 x 128 S tile once and the four shifted 32 x Cout windows
+// of dO (overlapping, L1 / L2 hits), splits them to f16 pieces on the way into LDS, and wave (pair q, column block cb) accumulates
+// shifts 2q, 2q + 1 against S columns 32 cb .. + 31.
 // Both operands have the contraction along their ROWS, so an MFMA operand (eight consecutive contraction indices per lane) is a
-// transposed read: the tiles go into LDS as f16 pieces of 16 rows x 32 features in the order planes.h describes
+// transposed read: the tiles sit in LDS as f16 pieces of 16 rows x 32 features in the order planes.h describes
 //     byte = (k / 4) * 256 + (f / 16) * 128 + (k % 4) * 32 + (f % 16) * 2            (k = row % 16, f = feature % 32)
-// and a fragment is two ds_read_b64_tr_b16.  A workgroup (four waves) owns all Cout rows x 128 columns of dWg (one whole
-// 128-float run of the two-run operand: 128 divides 8 C) for one contraction split; a step is 32 rows: S 16 KB + dO 4-8 KB of fp32
-// from global memory into registers one step ahead, split, two LDS stages, one barrier per step.  db = column sums of dO, kept in
-// registers by the column tile 0 workgroups.
+// and a fragment is two ds_read_b64_tr_b16.  Registers hold the next step's fp32 values, two LDS stages, one barrier per step.
+// db = column sums of the unshifted dO window, kept in registers by the column tile 0 workgroups.
 constexpr int WG_ROWS = 32;                     // contraction rows per step
-constexpr int WG_COLS = 128;                    // dWg columns per workgroup
-constexpr int WG_THREADS = 256;
+constexpr int WG_COLS = 128;                    // S columns per workgroup
+constexpr int WG_THREADS = 512;
 constexpr int PIECE = 1024;                     // bytes of a 16 x 32 f16 piece
 struct WArgs {
   const float* dO; const float* S;
   int Cout, C4;                                 // C4 = 4 C = floats per S row
-  int seg, jump;                                // column k of the implicit A operand lives at S[r * C4 + k + (k >= seg ? jump : 0)]
-  int64_t rows; int64_t rows_per_split;         // rows_per_split a multiple of WG_ROWS
-  int K;
+  int ws;                                       // shifts 0, 1, ws, ws + 1
+  int64_t rows;                                 // rows of the stage's grid (dO rows); the contraction runs over rows + ws + 1 S rows
+  int64_t prows, rows_per_split;                // prows = rows + ws + 1; rows_per_split a multiple of WG_ROWS
+  int K;                                        // 4 * C4
   const unsigned* amax_dO; const unsigned* amax_S;
   float* slab; float* dbslab;                   // [splits][Cout][K], [splits][Cout]
 };
@@ -630,52 +643,53 @@ __device__ __forceinline__ u32x4 read_frag_tr(const char* p) {   // keys 8h .. 8
 }
 
 template <int NBM>      // Cout = 32 NBM
-__global__ __launch_bounds__(WG_THREADS) void wgrad16_k(WArgs a) {
+__global__ __launch_bounds__(WG_THREADS, NBM == 1 ? 4 : 2) void wgrad16_k(WArgs a) {
   constexpr int COUT = 32 * NBM;
-  constexpr int B_UNITS = WG_ROWS * WG_COLS / 4 / WG_THREADS;         // 4 float4 of S per thread and step
-  constexpr int A_UNITS = WG_ROWS * COUT / 4 / WG_THREADS;            // 1 or 2 float4 of dO
-  // LDS stage: [row group 0..1][unit: NBM of dO then 4 of S][hi / lo][1 KB]; unit stride padded by 64 B (the four units of a row
+  constexpr int B_UNITS = WG_ROWS * WG_COLS / 4 / WG_THREADS;         // 2 float4 of S per thread and step
+  constexpr int A_UNITS = 4 * WG_ROWS * COUT / 4 / WG_THREADS;        // 2 or 4 float4 of the four dO windows
+  constexpr int UPW = WG_ROWS * COUT / 4;                             // float4 units per dO window
+  // LDS stage: [row group 0..1][unit: 4 shifts x NBM of dO, then 4 of S][hi / lo][1 KB]; unit stride padded by 64 B (the units of a row
   // would otherwise land on the same banks when the split values are stored)
   constexpr int UNIT = 2 * PIECE + 64;
-  constexpr int GROUP = (NBM + 4) * UNIT;
+  constexpr int GROUP = (4 * NBM + 4) * UNIT;
   constexpr int STAGE = 2 * GROUP;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) char wsmem[];        // 2 * STAGE
+  char* const smem = wsmem;
   __shared__ unsigned s_word;
   __shared__ float s_db[WG_THREADS * 4];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
-  const int ktiles = a.K / WG_COLS;
+  const int q = wave >> 2, cb = wave & 3;
+  const int ctiles = a.C4 / WG_COLS;
   const int id = xcd_contiguous(blockIdx.x, gridDim.x);
-  const int split = id / ktiles, kt = id - split * ktiles;
-  const int kcol0 = kt * WG_COLS;
-  const int64_t r_beg = (int64_t)split * a.rows_per_split, r_end = min(a.rows, r_beg + a.rows_per_split);
-  const int nsteps = (int)((r_end - r_beg + WG_ROWS - 1) / WG_ROWS);
+  const int split = id / ctiles, ct = id - split * ctiles;
+  const int64_t p_beg = (int64_t)split * a.rows_per_split, p_end = min(a.prows, p_beg + a.rows_per_split);
+  const int nsteps = (int)((p_end - p_beg + WG_ROWS - 1) / WG_ROWS);
 
   const float sD = tensor_scale(a.amax_dO, &s_word);
   const float sS = tensor_scale(a.amax_S, &s_word);
 
-  // S tile: thread -> (row = u / 32, float4 q = u % 32) of the step's 32 x 128 floats
-  const float* __restrict__ Sbase = a.S + kcol0 + (kcol0 >= a.seg ? a.jump : 0);
+  const float* __restrict__ Sbase = a.S + ct * WG_COLS;
   float4 rs[B_UNITS], rd[A_UNITS];
   auto load = [&](int step) {
-    const int64_t r0 = r_beg + (int64_t)step * WG_ROWS;
+    const int64_t p0 = p_beg + (int64_t)step * WG_ROWS;
 #pragma unroll
     for (int i = 0; i < B_UNITS; ++i) {
       const int u = threadIdx.x + i * WG_THREADS;
-      const int64_t r = r0 + u / 32;
-      // rows past the end of the split contribute zero through dO (zeroed below); S is readable behind its end (the caller's zero tail)
-      rs[i] = *reinterpret_cast<const float4*>(Sbase + min(r, a.rows - 1) * a.C4 + 4 * (u % 32));
+      const int64_t pr = p0 + u / 32;
+      // (rows past the end of the split meet zero dO windows; S is readable up to row prows by the caller's zero tail)
+      rs[i] = *reinterpret_cast<const float4*>(Sbase + min(pr, a.prows) * a.C4 + 4 * (u % 32));
     }
 #pragma unroll
     for (int i = 0; i < A_UNITS; ++i) {
       const int u = threadIdx.x + i * WG_THREADS;
-      const int64_t r = r0 + u / (COUT / 4);
-      rd[i] = r < r_end ? *reinterpret_cast<const float4*>(a.dO + r * COUT + 4 * (u % (COUT / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int w = u / UPW, rem = u - w * UPW;
+      const int shift = (w >> 1) * a.ws + (w & 1);
+      const int64_t pr = p0 + rem / (COUT / 4), r = pr - shift;          // r >= -(ws + 1): the caller's zero rows in front of dO
+      rd[i] = (pr < p_end && r < a.rows) ? *reinterpret_cast<const float4*>(a.dO + r * COUT + 4 * (rem % (COUT / 4))) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  float4 dbsum[A_UNITS];
-#pragma unroll
-  for (int i = 0; i < A_UNITS; ++i) dbsum[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dbsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto piece_off = [](int k, int f) { return (k >> 2) * 256 + ((f >> 4) & 1) * 128 + (k & 3) * 32 + (f & 15) * 2; };
   auto store = [&](char* st) {
 #pragma unroll
@@ -684,28 +698,31 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_k(WArgs a) {
       const int row = u / 32, f = 4 * (u % 32);
       u32x2 hi, lo;
       split4(rs[i], sS, hi, lo);
-      char* p = st + (row >> 4) * GROUP + (NBM + (f >> 5)) * UNIT + piece_off(row & 15, f & 31);
+      char* p = st + (row >> 4) * GROUP + (4 * NBM + (f >> 5)) * UNIT + piece_off(row & 15, f & 31);
       *reinterpret_cast<u32x2*>(p) = hi;
       *reinterpret_cast<u32x2*>(p + PIECE) = lo;
     }
 #pragma unroll
     for (int i = 0; i < A_UNITS; ++i) {
       const int u = threadIdx.x + i * WG_THREADS;
-      const int row = u / (COUT / 4), f = 4 * (u % (COUT / 4));
+      const int w = u / UPW, rem = u - w * UPW;
+      const int row = rem / (COUT / 4), f = 4 * (rem % (COUT / 4));
       u32x2 hi, lo;
       split4(rd[i], sD, hi, lo);
-      char* p = st + (row >> 4) * GROUP + (f >> 5) * UNIT + piece_off(row & 15, f & 31);
+      char* p = st + (row >> 4) * GROUP + (w * NBM + (f >> 5)) * UNIT + piece_off(row & 15, f & 31);
       *reinterpret_cast<u32x2*>(p) = hi;
       *reinterpret_cast<u32x2*>(p + PIECE) = lo;
-      dbsum[i].x += rd[i].x; dbsum[i].y += rd[i].y; dbsum[i].z += rd[i].z; dbsum[i].w += rd[i].w;
+      if (w == 0) { dbsum.x += rd[i].x; dbsum.y += rd[i].y; dbsum.z += rd[i].z; dbsum.w += rd[i].w; }
     }
   };
 
-  f32x16 acc[NBM];
+  f32x16 acc[2][NBM];
 #pragma unroll
-  for (int i = 0; i < NBM; ++i)
+  for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    for (int i = 0; i < NBM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[sh][i][r] = 0.f;
 
   const int lane_off = h * 512 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
   if (nsteps > 0) {
@@ -717,51 +734,54 @@ __global__ __launch_bounds__(WG_THREADS) void wgrad16_k(WArgs a) {
   int cur = 0;
   for (int t = 0; t < nsteps; ++t) {
     const char* st = smem + cur * STAGE;
-    u32x4 fa[2][NBM][2], fb[2][2];
 #pragma unroll
-    for (int gq = 0; gq < 2; ++gq) {
+    for (int gq = 0; gq < 2; ++gq) {                  // the step's two 16-row groups
+      u32x4 fa[2][NBM][2], fb[2];                     // [shift of the pair][block][hi / lo], [hi / lo]
 #pragma unroll
-      for (int i = 0; i < NBM; ++i) {
-        fa[gq][i][0] = read_frag_tr(st + gq * GROUP + i * UNIT + lane_off);
-        fa[gq][i][1] = read_frag_tr(st + gq * GROUP + i * UNIT + PIECE + lane_off);
+      for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+        for (int i = 0; i < NBM; ++i) {
+          const char* pu = st + gq * GROUP + ((2 * q + sh) * NBM + i) * UNIT + lane_off;
+          fa[sh][i][0] = read_frag_tr(pu);
+          fa[sh][i][1] = read_frag_tr(pu + PIECE);
+        }
+      const char* pb = st + gq * GROUP + (4 * NBM + cb) * UNIT + lane_off;
+      fb[0] = read_frag_tr(pb);
+      fb[1] = read_frag_tr(pb + PIECE);
+      if (gq == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nsteps) store(smem + (cur ^ 1) * STAGE);
+        if (t + 2 < nsteps) load(t + 2);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      fb[gq][0] = read_frag_tr(st + gq * GROUP + (NBM + wave) * UNIT + lane_off);
-      fb[gq][1] = read_frag_tr(st + gq * GROUP + (NBM + wave) * UNIT + PIECE + lane_off);
+#pragma unroll
+      for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+        for (int i = 0; i < NBM; ++i) {
+          acc[sh][i] = mfma(fa[sh][i][1], fb[0], acc[sh][i]);
+          acc[sh][i] = mfma(fa[sh][i][0], fb[1], acc[sh][i]);
+          acc[sh][i] = mfma(fa[sh][i][0], fb[0], acc[sh][i]);
+        }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nsteps) store(smem + (cur ^ 1) * STAGE);
-    if (t + 2 < nsteps) load(t + 2);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int gq = 0; gq < 2; ++gq)
-#pragma unroll
-      for (int i = 0; i < NBM; ++i) {
-        acc[i] = mfma(fa[gq][i][1], fb[gq][0], acc[i]);
-        acc[i] = mfma(fa[gq][i][0], fb[gq][1], acc[i]);
-        acc[i] = mfma(fa[gq][i][0], fb[gq][0], acc[i]);
-      }
     __syncthreads();
     cur ^= 1;
   }
 
-  // slab: rows = output channel (A operand's feature), columns = this wave's 32 columns of the k-tile
+  // slab: rows = output channel, columns = block (dy, dx) = shift index 2q + sh, then this wave's 32 of the tile's 128 S columns
   const float cs = 1.f / (sD * sS);
   float* __restrict__ slab = a.slab + (int64_t)split * COUT * a.K;
 #pragma unroll
-  for (int i = 0; i < NBM; ++i)
+  for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      slab[(int64_t)co * a.K + kcol0 + wave * 32 + l31] = acc[i][r] * cs;
-    }
-  if (a.dbslab && kt == 0) {
-    // the threads that hold channel group q = u % (COUT / 4): sum over them in a fixed order
+    for (int i = 0; i < NBM; ++i)
 #pragma unroll
-    for (int i = 0; i < A_UNITS; ++i) {
-      if (i > 0) { dbsum[0].x += dbsum[i].x; dbsum[0].y += dbsum[i].y; dbsum[0].z += dbsum[i].z; dbsum[0].w += dbsum[i].w; }
-    }
-    // (units u and u + WG_THREADS share the channel group because WG_THREADS % (COUT / 4) == 0)
-    reinterpret_cast<float4*>(s_db)[threadIdx.x] = dbsum[0];
+      for (int r = 0; r < 16; ++r) {
+        const int co = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        slab[(int64_t)co * a.K + (2 * q + sh) * a.C4 + ct * WG_COLS + cb * 32 + l31] = acc[sh][i][r] * cs;
+      }
+  if (a.dbslab && ct == 0) {
+    // threads whose units lie in the unshifted window hold the column sums of their channel group (the others hold zero)
+    reinterpret_cast<float4*>(s_db)[threadIdx.x] = dbsum;
     __syncthreads();
     if (threadIdx.x < COUT) {
       const int qg = threadIdx.x >> 2, e = threadIdx.x & 3;
@@ -813,13 +833,13 @@ void launch_slab_sum(const float* slab1, int n1, float* out1, const float* slab2
 }
 
 struct WPlan { int splits; int64_t rows_per_split; };
-static WPlan plan_wgrad(int64_t rows, int K) {
-  const int ktiles = K / WG_COLS;
-  int64_t want = std::max<int64_t>(1, 4 * (int64_t)kNumCU / ktiles);
-  want = std::min<int64_t>(want, std::max<int64_t>(1, rows / (8 * WG_ROWS)));
+static WPlan plan_wgrad(int64_t prows, int C4) {
+  const int ctiles = C4 / WG_COLS;
+  int64_t want = std::max<int64_t>(1, 2 * (int64_t)kNumCU / ctiles);       // ~two eight-wave workgroups per CU
+  want = std::min<int64_t>(want, std::max<int64_t>(1, prows / (4 * WG_ROWS)));
   WPlan p;
-  p.rows_per_split = ceil_div(ceil_div(rows, want), (int64_t)WG_ROWS) * WG_ROWS;
-  p.splits = (int)ceil_div(rows, p.rows_per_split);
+  p.rows_per_split = ceil_div(ceil_div(prows, want), (int64_t)WG_ROWS) * WG_ROWS;
+  p.splits = (int)ceil_div(prows, p.rows_per_split);
   return p;
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -901,33 +921,45 @@ extern "C" int clica_conv16_k4s2_dgrad(const float* dO, const uint16_t* WdT16, c
 }
 
 extern "C" int clica_conv16_k4s2_wgrad_workspace_bytes(int64_t rows, int32_t Cout, int32_t K, size_t* bytes) {
-  CLICA_CHECK_ARG(bytes && rows > 0 && Cout >= 1 && K >= WG_COLS && K % WG_COLS == 0, "clica_conv16_k4s2_wgrad_workspace_bytes: bad argument");
-  const WPlan p = plan_wgrad(rows, K);
-  *bytes = align_up((size_t)p.splits * Cout * K * sizeof(float), 256) + align_up((size_t)p.splits * Cout * sizeof(float), 256);
+  CLICA_CHECK_ARG(bytes && rows > 0 && Cout >= 1 && K >= 4 * WG_COLS && K % (4 * WG_COLS) == 0, "clica_conv16_k4s2_wgrad_workspace_bytes: bad argument");
+  const WPlan p = plan_wgrad(rows + 4 * 1024, K / 4);      // an upper bound over the grid widths (prows = rows + ws + 1)
+  *bytes = align_up((size_t)(p.splits + 2) * Cout * K * sizeof(float), 256) + align_up((size_t)(p.splits + 2) * Cout * sizeof(float), 256);
   return CLICA_OK;
 }
 
 extern "C" int clica_conv16_k4s2_wgrad(const float* dO, const float* S, int64_t images, int32_t C, int32_t Cout, int32_t hs, int32_t ws,
                                        float* dWg, float* db, int32_t accumulate, const uint32_t* amax_dO, const uint32_t* amax_S,
                                        void* workspace, size_t workspace_bytes, clica_stream_t stream) {
-  CLICA_CHECK_ARG(dO && S && dWg && workspace && images > 0 && C >= 32 && C % 32 == 0 && (Cout == 32 || Cout == 64) && hs >= 2 && ws >= 2,
+  CLICA_CHECK_ARG(dO && S && dWg && workspace && images > 0 && C >= 32 && C % 32 == 0 && (Cout == 32 || Cout == 64) && hs >= 2 && ws >= 2 && ws < 4096,
                   "clica_conv16_k4s2_wgrad: bad argument (C a multiple of 32, Cout 32 or 64)");
-  CLICA_CHECK_ARG(aligned16(dO) && aligned16(S) && aligned16(dWg), "clica_conv16_k4s2_wgrad: operands must be 16-byte aligned");
+  CLICA_CHECK_ARG(aligned16(dO) && aligned16(S) && aligned16(dWg) && (!db || aligned16(db)), "clica_conv16_k4s2_wgrad: operands must be 16-byte aligned");
   const int64_t rows = images * hs * ws;
   const int32_t K = 16 * C;
-  const WPlan p = plan_wgrad(rows, K);
+  const int64_t prows = rows + ws + 1;
+  const WPlan p = plan_wgrad(prows, 4 * C);
   const size_t slab_bytes = align_up((size_t)p.splits * Cout * K * sizeof(float), 256);
   const size_t need = slab_bytes + align_up((size_t)p.splits * Cout * sizeof(float), 256);
   if (need > workspace_bytes) { set_error("clica_conv16_k4s2_wgrad: workspace %zu < %zu", workspace_bytes, need); return CLICA_E_WORKSPACE; }
   WArgs a{};
-  a.dO = dO; a.S = S; a.Cout = Cout; a.C4 = 4 * C; a.seg = 8 * C; a.jump = (ws - 2) * 4 * C;
-  a.rows = rows; a.rows_per_split = p.rows_per_split; a.K = K;
+  a.dO = dO; a.S = S; a.Cout = Cout; a.C4 = 4 * C; a.ws = ws;
+  a.rows = rows; a.prows = prows; a.rows_per_split = p.rows_per_split; a.K = K;
   a.amax_dO = amax_dO; a.amax_S = amax_S;
   a.slab = (float*)workspace; a.dbslab = db ? (float*)((char*)workspace + slab_bytes) : nullptr;
   hipStream_t st = as_stream(stream);
-  const unsigned nwg = (unsigned)(p.splits * (K / WG_COLS));
-  if (Cout == 32) hipLaunchKernelGGL(wgrad16_k<1>, dim3(nwg), dim3(WG_THREADS), 0, st, a);
-  else hipLaunchKernelGGL(wgrad16_k<2>, dim3(nwg), dim3(WG_THREADS), 0, st, a);
+  const unsigned nwg = (unsigned)(p.splits * (4 * C / WG_COLS));
+  const int nbm = Cout / 32;
+  const size_t lds = (size_t)2 * 2 * (4 * nbm + 4) * (2 * PIECE + 64);
+  if (Cout == 32) {
+    auto k = wgrad16_k<1>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(WG_THREADS), lds, st, a);
+  } else {
+    auto k = wgrad16_k<2>;
+    static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+    (void)once;
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(WG_THREADS), lds, st, a);
+  }
   int rc = launch_status("clica_conv16_k4s2_wgrad");
   if (rc) return rc;
   launch_slab_sum(a.slab, Cout * K, dWg, a.dbslab, (int)Cout, db, p.splits, accumulate ? 1 : 0, st);

@@ -1905,6 +1905,190 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
   }
 }
 
+// The same two first-stage kernels for ONE input channel reading the IMAGE instead of a patch matrix (round 5): the 4 x 4 window of an
+// output pixel is twelve aligned 8-byte loads out of 33 MB of masks that live in L1 / L2, where the patch matrix cost 134 MB written by
+// the im2col launch and 134 MB read by each of the two kernels (42 + ~45 + ~40 us of a 1.7 ms step).  Window value (ky, kx) of output
+// pixel (oy, ox) = x[img][2 oy - 1 + ky][2 ox - 1 + kx], zero outside the H x W image: columns 2 ox - 2 .. 2 ox + 3 as three float2.
+// branch-free: out-of-image taps are read from a clamped address and zeroed by a select (as conditional loads the window cost twelve
+// exec-mask branches per pixel: the kernel was instruction-bound at ~800 instructions per pixel and thread)
+__device__ __forceinline__ float4 win_row(const float* __restrict__ ximg, int yy, int ox, int H, int W) {
+  const int yc = min(max(yy, 0), H - 1);
+  const bool rin = yy == yc, lin = ox > 0, rgt = 2 * ox + 2 < W;
+  const float* rowp = ximg + (int64_t)yc * W + 2 * ox;
+  const float l = rowp[lin ? -1 : 0];
+  const float2 m = *reinterpret_cast<const float2*>(rowp);
+  const float r = rowp[rgt ? 2 : 0];
+  return make_float4((rin && lin) ? l : 0.f, rin ? m.x : 0.f, rin ? m.y : 0.f, (rin && rgt) ? r : 0.f);
+}
+__device__ __forceinline__ void pixel_decode(unsigned pixel, int ho, int wo, int ho_shift, int wo_shift, unsigned& img, unsigned& oy, unsigned& ox) {
+  if (wo_shift >= 0 && ho_shift >= 0) {
+    ox = pixel & (unsigned)(wo - 1); const unsigned prow = pixel >> wo_shift; oy = prow & (unsigned)(ho - 1); img = prow >> ho_shift;
+  } else {
+    const unsigned prow = pixel / (unsigned)wo; ox = pixel - prow * (unsigned)wo; img = prow / (unsigned)ho; oy = prow - img * (unsigned)ho;
+  }
+}
+__global__ __launch_bounds__(256) void conv_fwd_image_valu_k(const float* __restrict__ X, const float* __restrict__ Wg, const float* __restrict__ bias,
+                                                              unsigned pixels, int Cout, int H, int W, int ho_shift, int wo_shift, int relu,
+                                                              float* __restrict__ out, unsigned* __restrict__ gate_out, unsigned* __restrict__ amax_slots) {
+  constexpr int K = 16;
+  const int ho = H / 2, wo = W / 2;
+  const int groups = Cout / 8;                          // threads per pixel
+  const int cg = threadIdx.x % groups;
+  const int half = Cout / 2;
+  auto chan = [&](int c) { return c < 4 ? 4 * cg + c : half + 4 * cg + (c - 4); };      // as in conv_fwd_patches_valu_k
+  float amax = 0.f;
+  float w[8][K], b[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    b[c] = bias ? bias[chan(c)] : 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[c][k] = Wg[chan(c) * K + k];
+  }
+  const unsigned per_block = 256 / groups, stride = gridDim.x * per_block;
+  const int dhs = ho / 2 + 1, dws = wo / 2 + 1;
+  // The four threads of a pixel (a lane quad: cg = lane & 3) fetch ONE window row each and hand the values round with quad-permute
+  // moves: a thread pays a quarter of the address / clamp / select work (each thread fetching the whole window: ~400 vector
+  // instructions per pixel for 64 packed FMAs).  Two pixels in flight per thread.
+  struct Pre { float4 v; unsigned img, y, x; };
+  Pre P0, P1;
+  __shared__ __attribute__((aligned(16))) float stage[64 * 36];      // [wave][pixel of the wave][32 channels + 4 pad]
+  const int lane = threadIdx.x & 63, pl = lane >> 2;
+  // every condition of the loop is uniform over the wave (a wave's 16 pixels start at `base`): the stores below cross lanes
+  const unsigned base0 = blockIdx.x * per_block + (threadIdx.x >> 6) * 16;
+  auto fetch = [&](Pre& P, unsigned base) {
+    const unsigned pixel = min(base + (unsigned)pl, pixels - 1u);
+    pixel_decode(pixel, ho, wo, ho_shift, wo_shift, P.img, P.y, P.x);
+    P.v = win_row(X + (int64_t)P.img * H * W, 2 * (int)P.y - 1 + cg, (int)P.x, H, W);
+  };
+  auto quad = [](float v, int src) -> float {       // value of lane (lane & ~3) + src
+    const int i = __builtin_bit_cast(int, v);
+    int r;
+    switch (src) {
+      case 0: r = __builtin_amdgcn_update_dpp(i, i, 0x00, 0xf, 0xf, false); break;
+      case 1: r = __builtin_amdgcn_update_dpp(i, i, 0x55, 0xf, 0xf, false); break;
+      case 2: r = __builtin_amdgcn_update_dpp(i, i, 0xaa, 0xf, 0xf, false); break;
+      default: r = __builtin_amdgcn_update_dpp(i, i, 0xff, 0xf, 0xf, false); break;
+    }
+    return __builtin_bit_cast(float, r);
+  };
+  auto process = [&](Pre& P, unsigned base) {
+    const unsigned pixel = base + (unsigned)pl;
+    const bool valid = pixel < pixels;
+    float a[K];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) { a[4 * ky] = quad(P.v.x, ky); a[4 * ky + 1] = quad(P.v.y, ky); a[4 * ky + 2] = quad(P.v.z, ky); a[4 * ky + 3] = quad(P.v.w, ky); }
+    const unsigned img = P.img, y = P.y, x = P.x;
+    if (base + 2 * stride < pixels) fetch(P, base + 2 * stride);
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc = fmaf(a[k], w[c][k], acc);
+      acc += b[c];
+      o[c] = (relu && !(acc > 0.f)) ? 0.f : acc;
+      amax = fmaxf(amax, fabsf(o[c]));
+    }
+    const unsigned Y = (y + 1) >> 1, Xs = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
+    // The wave's 16 pixels x 128 B go through LDS so that a store instruction writes WHOLE 128-byte lines (eight lanes per pixel):
+    // with each thread storing its two 16-byte runs directly, an instruction wrote half of every line it touched and the kernel sat at
+    // 2.1 TB/s whatever its arithmetic looked like (three versions of the loads: 121 ... 128 us).
+    const int myoff = valid ? (int)((((int64_t)img * dhs + Y) * dws + Xs) * (4 * Cout) + qq * Cout) : -1;
+    float* mine = stage + (threadIdx.x >> 2) * 36;
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<float4*>(mine + 4 * cg) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(mine + half + 4 * cg) = make_float4(o[4], o[5], o[6], o[7]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int p2 = hh * 8 + (lane >> 3);
+      const float4 v = *reinterpret_cast<const float4*>(stage + ((threadIdx.x >> 6) * 16 + p2) * 36 + 4 * (lane & 7));
+      const int off = __shfl(myoff, 4 * p2, 64);
+      if (off >= 0) *reinterpret_cast<float4*>(out + off + 4 * (lane & 7)) = v;
+    }
+    if (gate_out && valid) {
+      unsigned bits = 0;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) bits |= (o[c] > 0.f ? 1u : 0u) << chan(c);
+      bits |= __shfl_xor(bits, 1);
+      bits |= __shfl_xor(bits, 2);
+      if (cg == 0) gate_out[pixel] = bits;
+    }
+  };
+  if (base0 < pixels) fetch(P0, base0);
+  if (base0 + stride < pixels) fetch(P1, base0 + stride);
+  for (unsigned base = base0; base < pixels; base += 2 * stride) {
+    process(P0, base);
+    if (base + stride < pixels) process(P1, base + stride);
+  }
+  if (amax_slots) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if ((threadIdx.x & 63) == 0) {
+      amax = (amax <= 3.0e38f) ? amax : 3.4e38f;
+      if (amax > 0.f) atomicMax(amax_slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255), __float_as_uint(amax));
+    }
+  }
+}
+
+// dWg[Cout][16] = dO[rows][Cout]^T window(rows), db = column sums of dO: conv_wgrad_patches_k with the window row read from the image and
+// an 8 x 4 block of dWg per thread (eight channels x one window row: 32 FMAs per row for one row decode, one window row and two
+// 16-byte dO loads; 4 x 4 blocks measured 117 us, 16 x 4 blocks -- fewer waves per SIMD -- 129, this shape 105).
+// The (Cout/8) x 4 threads of a group share a row; the groups of a workgroup take rows r = g (mod G); a wave's groups are summed with
+// lane shuffles, the four waves through LDS, every workgroup writes one slab.
+__global__ __launch_bounds__(256) void conv_wgrad_image_k(const float* __restrict__ dO, const float* __restrict__ X, int64_t rows, int Cout, int H, int W,
+                                                           int ho_shift, int wo_shift, int64_t rows_per_block, float* __restrict__ slab,
+                                                           float* __restrict__ dbslab) {
+  extern __shared__ float red[];                       // [4 waves][Cout * 16 + Cout]
+  constexpr int K = 16;
+  const int ho = H / 2, wo = W / 2;
+  const int ncg = Cout / 8, gsz = ncg * 4, G = 256 / gsz;           // gsz = 16 for Cout = 32 (a power of two <= 64 is required)
+  const int g = threadIdx.x / gsz, u = threadIdx.x - g * gsz, cg = u % ncg, kg = u / ncg;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  float acc[8][4] = {};
+  float bsum[8] = {};
+#pragma unroll 4
+  for (int64_t r = r0 + g; r < r1; r += G) {
+    const float4 d0 = *reinterpret_cast<const float4*>(dO + r * Cout + 8 * cg);
+    const float4 d1 = *reinterpret_cast<const float4*>(dO + r * Cout + 8 * cg + 4);
+    unsigned img, oy, ox;
+    pixel_decode((unsigned)r, ho, wo, ho_shift, wo_shift, img, oy, ox);
+    const float4 wv = win_row(X + (int64_t)img * H * W, 2 * (int)oy - 1 + kg, (int)ox, H, W);
+    const float dv[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w}, pv[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(dv[i], pv[j], acc[i][j]);
+      bsum[i] += dv[i];
+    }
+  }
+  // groups of one wave: lanes l, l + gsz, l + 2 gsz ... hold the same (cg, kg)
+  for (int off = gsz; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] += __shfl_xor(acc[i][j], off, 64);
+      bsum[i] += __shfl_xor(bsum[i], off, 64);
+    }
+  }
+  const int per = Cout * K + Cout;
+  if ((threadIdx.x & 63) < gsz) {
+    float* mine = red + (size_t)(threadIdx.x >> 6) * per;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[(8 * cg + i) * K + 4 * kg + j] = acc[i][j];
+      if (kg == 0) mine[Cout * K + 8 * cg + i] = bsum[i];
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < per; e += 256) {
+    const float v = (red[e] + red[per + e]) + (red[2 * per + e] + red[3 * per + e]);
+    if (e < Cout * K) slab[(int64_t)blockIdx.x * Cout * K + e] = v;
+    else if (dbslab) dbslab[(int64_t)blockIdx.x * Cout + (e - Cout * K)] = v;
+  }
+}
+
 // Weight re-ordering between nn.Conv2d's [co][c][ky][kx] and the GEMM layouts (forward rows, data-gradient rows, the zero-padded rows of
 // the 4 x 4 stage) and back for the gradients: up to MAXG index-mapped copies in ONE launch, dst[e] = map[e] >= 0 ? src[map[e]] : 0.
 // The maps are permutations the host builds once per shape (cl_ica_amd/conv.py applies its layout functions to an index tensor).
@@ -2092,6 +2276,48 @@ extern "C" int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patch
   else
     launch_slab_reduce(slab, dbslab, p.blocks, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
   return launch_status("clica_conv_k4s2_wgrad_patches(reduce)");
+}
+
+static int shift_of(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
+
+extern "C" int clica_conv_k4s2_fwd_image(const float* x, const float* Wg, const float* bias, int64_t images, int32_t H, int32_t W, int32_t Cout,
+                                         int32_t relu, float* out, uint32_t* gate_bits, uint32_t* amax_slots, clica_stream_t stream) {
+  CLICA_CHECK_ARG(x && Wg && out && images > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && Cout == 32,
+                  "clica_conv_k4s2_fwd_image: bad argument (one input channel, Cout = 32, H and W multiples of 4)");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7) == 0 && aligned16(out), "clica_conv_k4s2_fwd_image: x must be 8-byte, out 16-byte aligned");
+  const int64_t pixels = images * (H / 2) * (W / 2);
+  CLICA_CHECK_ARG(pixels < ((int64_t)1 << 31), "clica_conv_k4s2_fwd_image: %lld output pixels (< 2^31 supported)", (long long)pixels);
+  hipLaunchKernelGGL(conv_fwd_image_valu_k, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), x, Wg, bias, (unsigned)pixels, (int)Cout,
+                     (int)H, (int)W, shift_of(H / 2), shift_of(W / 2), (int)relu, out, gate_bits, amax_slots);
+  return launch_status("clica_conv_k4s2_fwd_image");
+}
+
+extern "C" int clica_conv_k4s2_wgrad_image(const float* dO, const float* x, int64_t images, int32_t H, int32_t W, int32_t Cout, float* dWg, float* db,
+                                           int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(dO && x && dWg && workspace && images > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0,
+                  "clica_conv_k4s2_wgrad_image: NULL pointer / bad shape (H and W multiples of 4)");
+  const int32_t K = 16;
+  CLICA_CHECK_ARG(Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64 || Cout == 128, "clica_conv_k4s2_wgrad_image: Cout = %d not supported (8 ... 128, a power of two)", Cout);
+  CLICA_CHECK_ARG(aligned16(dO) && (reinterpret_cast<uintptr_t>(x) & 7) == 0, "clica_conv_k4s2_wgrad_image: dO must be 16-byte, x 8-byte aligned");
+  const int64_t rows = images * (H / 2) * (W / 2);
+  CLICA_CHECK_ARG(rows < ((int64_t)1 << 32), "clica_conv_k4s2_wgrad_image: %lld rows (< 2^32 supported)", (long long)rows);
+  const PatchWgradPlan p = plan_patch_wgrad(rows);
+  const size_t slab_bytes = align_up((size_t)p.blocks * Cout * K * sizeof(float), 256);
+  const size_t need = slab_bytes + align_up((size_t)p.blocks * Cout * sizeof(float), 256);
+  if (need > workspace_bytes) { set_error("clica_conv_k4s2_wgrad_image: workspace %zu < %zu (clica_conv_k4s2_wgrad_patches_workspace_bytes)", workspace_bytes, need); return CLICA_E_WORKSPACE; }
+  float* slab = (float*)workspace;
+  float* dbslab = (float*)((char*)workspace + slab_bytes);
+  hipStream_t st = as_stream(stream);
+  const size_t lds = (size_t)4 * (Cout * K + Cout) * sizeof(float);
+  hipLaunchKernelGGL(conv_wgrad_image_k, dim3((unsigned)p.blocks), dim3(256), lds, st, dO, x, rows, (int)Cout, (int)H, (int)W, shift_of(H / 2), shift_of(W / 2),
+                     p.rows_per_block, slab, db ? dbslab : (float*)nullptr);
+  int rc = launch_status("clica_conv_k4s2_wgrad_image");
+  if (rc) return rc;
+  if ((Cout * K) % 4 == 0 && Cout % 4 == 0 && aligned16(dWg) && (!db || aligned16(db)))
+    conv16::launch_slab_sum(slab, Cout * K, dWg, db ? dbslab : nullptr, Cout, db, p.blocks, accumulate ? 1 : 0, st);
+  else
+    launch_slab_reduce(slab, dbslab, p.blocks, Cout, K, dWg, K, db, accumulate ? 1 : 0, st);
+  return launch_status("clica_conv_k4s2_wgrad_image(reduce)");
 }
 
 // ---- data gradient of the FIRST stage: d loss / d image (kitti_masks/model.py:41-56 is plain nn.Conv2d, differentiable w.r.t. its input) ----

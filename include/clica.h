@@ -537,6 +537,14 @@ int clica_conv_k4s2_wgrad_patches(const float* dO, const float* patches, int64_t
  * e < count[i] (nn.Conv2d.weight [co][c][ky][kx] -> Wg / Wd / the zero-padded rows of the 4 x 4 stage before a step, GEMM-layout gradients
  * -> Conv2d.weight layout after it; the maps are permutations built once per shape by the caller; map[i] = NULL is the identity, e.g. a
  * bias gradient).  accumulate != 0 adds into dst: the step's gradients go straight into the optimizer's .grad views. */
+/* First stage for ONE input channel straight from the images x [images][1][H][W] (no patch matrix): forward = clica_conv_k4s2_fwd_patches_amax
+ * with K = 16, Cout = 32, scatter = 1 (out = the next stage's S, gate bits / maximum slots optional); weight gradient =
+ * clica_conv_k4s2_wgrad_patches (same workspace size: clica_conv_k4s2_wgrad_patches_workspace_bytes(rows, Cout, 16)).  Wg / dWg in the
+ * patch-matrix order [Cout][ky * 4 + kx].  H, W multiples of 4. */
+int clica_conv_k4s2_fwd_image(const float* x, const float* Wg, const float* bias, int64_t images, int32_t H, int32_t W, int32_t Cout,
+                              int32_t relu, float* out, uint32_t* gate_bits, uint32_t* amax_slots, clica_stream_t stream);
+int clica_conv_k4s2_wgrad_image(const float* dO, const float* x, int64_t images, int32_t H, int32_t W, int32_t Cout, float* dWg, float* db,
+                                int32_t accumulate, void* workspace, size_t workspace_bytes, clica_stream_t stream);
 /* d loss / d image of the first stage (the reference's nn.Conv2d is differentiable w.r.t. its input, kitti_masks/model.py:41-56):
  * dO = gradient at the first stage's pre-activation on its (H/2) x (W/2) output grid [images][ho][wo][Cout], W = Conv2d.weight
  * [Cout][C][4][4] as the module stores it, dX = [images][C][H][W].  C <= 4, Cout * C <= 128. */

@@ -44,7 +44,7 @@ def _convs(nc, dtype=torch.float32):
 
 def _reference_fp64(x, convs32, dfeats, chunk=256, hip_gate=None):
     """Features and parameter gradients of the Conv2d + ReLU stack in fp64 (ATen's fp64 convolution on the GPU), in chunks of images.
-    `hip_gate` (from _hip_gates): the first three stages are gated by the bits the HIP forward wrote instead of by the sign of the fp64
+    `hip_gate` (from _hip_gates): every stage is gated by what the HIP forward decided instead of by the sign of the fp64
     pre-activation; returns also, per stage, (number of elements gated differently, largest |fp64 pre-activation| among them / max)."""
     convs = []
     for m in convs32:
@@ -52,12 +52,12 @@ def _reference_fp64(x, convs32, dfeats, chunk=256, hip_gate=None):
         d.weight.data = m.weight.data.double(); d.bias.data = m.bias.data.double()
         convs.append(d)
     feats = []
-    mism = [[0, 0.0, 0.0] for _ in range(3)]
+    mism = [[0, 0.0, 0.0] for _ in range(5)]
     for i0 in range(0, x.shape[0], chunk):
         h = x[i0:i0 + chunk].double()
         for l, m in enumerate(convs):
             z = m(h)
-            if hip_gate is not None and l < 3:
+            if hip_gate is not None:
                 hg = hip_gate[l][i0:i0 + chunk]
                 diff = (z > 0) != hg
                 za = z.detach().abs()
@@ -78,8 +78,9 @@ def _reference_fp64(x, convs32, dfeats, chunk=256, hip_gate=None):
     return torch.cat(feats), grads
 
 
-def _hip_gates(images, device):
-    """The (output > 0) bits the last HIP forward of `images` one-channel images left in its pooled buffers, per stage as [img][ch][y][x]."""
+def _hip_gates(images, device, feats):
+    """What the last HIP forward of `images` one-channel images decided at its five ReLUs, per stage as [img][ch][y][x]: the (output > 0)
+    bits of the first three stages from the pooled buffers, the fourth stage's output on its 5 x 5 row grid, the returned features."""
     from cl_ica_amd import conv
     buf = conv._POOL[(images, 1, device.index)][0]
     gates = []
@@ -89,6 +90,8 @@ def _hip_gates(images, device):
         w = buf.gate[l].view(images, grid, grid, cout // 32)[:, :ho, :ho, :].to(torch.int64) & 0xFFFFFFFF
         bits = ((w.unsqueeze(-1) >> torch.arange(32, device=w.device)) & 1).reshape(images, ho, ho, cout)
         gates.append(bits.permute(0, 3, 1, 2).bool())
+    gates.append((buf.O4.view(images, 5, 5, 64)[:, :4, :4, :] > 0).permute(0, 3, 1, 2))
+    gates.append((feats > 0).view(images, -1, 1, 1))
     return gates
 
 
@@ -106,7 +109,7 @@ def _compare_full_batch(family, case, x, convs, dfeats, tol_forced, note_forced=
     conv._POOL.clear()
     got_f, got_g = _run_hip(x, convs, dfeats)
     torch.cuda.synchronize()
-    gates = _hip_gates(x.shape[0], x.device)
+    gates = _hip_gates(x.shape[0], x.device, got_f)
     ref_f, ref_g = _reference_fp64(x, convs, dfeats)
     ref_g = [t.clone() for t in ref_g]
     frc_f, frc_g, mism = _reference_fp64(x, convs, dfeats, hip_gate=gates)
@@ -198,6 +201,16 @@ def test_conv_stack_buffers_are_reusable_and_switchable(monkeypatch):
     with torch.no_grad():
         conv.conv_stack(xa, convs)
     assert len(conv._POOL[(16, 1, xa.device.index)]) == 1
+    # (d) the one-channel first stage from the patch matrix (clica_conv_im2col_k4s2 + *_patches kernels; CLICA_CONV_FIRST=patches) gives
+    # what the image-reading kernels give: same products in the same order
+    monkeypatch.setattr(conv, "_FIRST_FROM_IMAGE", False)
+    conv._POOL.clear()
+    fb2, gb2 = _run_hip(xb, convs, d)
+    assert torch.equal(fb0, fb2)
+    for a, b in zip(gb0, gb2):
+        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+    monkeypatch.setattr(conv, "_FIRST_FROM_IMAGE", True)
+    conv._POOL.clear()
     net = BetaVAE_H(z_dim=5, nc=1, box_norm=True).to("cuda")
     mu_hip = net(xa)
     monkeypatch.setenv("CLICA_CONV", "miopen")

@@ -34,6 +34,8 @@ for l in range(3):
     w = buf.gate[l].view(2048, grid, grid, cout // 32)[:, :ho, :ho, :].to(torch.int64) & 0xFFFFFFFF
     bits = ((w.unsqueeze(-1) >> torch.arange(32, device=w.device)) & 1).reshape(2048, ho, ho, cout)      # [img][y][x][ch]
     hip_gate.append(bits.permute(0, 3, 1, 2).bool())
+hip_gate.append((buf.O4.view(2048, 5, 5, 64)[:, :4, :4, :] > 0).permute(0, 3, 1, 2))
+hip_gate.append((got_f > 0).view(2048, -1, 1, 1))
 c64 = []
 for m in convs:
     d = torch.nn.Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding).to("cuda", torch.float64)
@@ -48,15 +50,13 @@ def run64(force):
         h = x[i0:i0 + 256].double()
         for l, d in enumerate(c64):
             z = d(h)
-            if l < 3:
+            if True:
                 hg = hip_gate[l][i0:i0 + 256]
                 mism = (z > 0) != hg
                 if i0 == 0 or True:
                     zm = z.detach().abs()
                     stats.append((l, int(mism.sum()), float(zm[mism].max()) if mism.any() else 0.0, float(zm.max())))
                 h = z * hg.double() if force else torch.relu(z)
-            else:
-                h = torch.relu(z)
         (h.flatten(1) * dfeats[i0:i0 + 256].double()).sum().backward()
     grads = []
     for d in c64:
@@ -65,7 +65,7 @@ def run64(force):
 
 plain, stats = run64(False)
 forced, _ = run64(True)
-for l in range(3):
+for l in range(5):
     n = sum(s[1] for s in stats if s[0] == l); zmax = max(s[2] for s in stats if s[0] == l); allmax = max(s[3] for s in stats if s[0] == l)
     out[f"stage{l + 1}_gate_mismatches"] = n
     out[f"stage{l + 1}_largest_mismatched_preactivation_over_max"] = zmax / allmax
