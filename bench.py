@@ -41,6 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+PEAK_F16_MFMA_TFLOPS = 2500.0   # same guide: dense fp16 MFMA (= the bf16 figure)
+PEAK_HBM_GBS = 8000.0           # same guide: HBM3E peak (about 6.3 TB/s achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA (the split-bf16 mode issues six bf16 products per fp32 product)
 NOMINAL_GHZ = 2.4                 # MI355X peak engine clock (MI355X_MICROARCH.md): what the peak TFLOP/s figures are quoted at
 PEAK_FP32_VALU_TFLOPS = 157.3
@@ -432,7 +434,7 @@ def roofline_leg(tr, reps=20):
     return roof, rows
 
 
-def measure_traffic(args, kernel_symbol, timeout_s=150, child_args=None):
+def measure_traffic(args, kernel_symbol, timeout_s=150, child_args=None, grid_size=None):
     """HBM-side bytes per launch of `kernel_symbol`, measured BY THIS RUN: two short child runs of this script
     under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, no other trace domains, as
     MI355X_MICROARCH.md prescribes), per-launch averages over the child's steps; FETCH_SIZE x 2 (the guide's gfx950 correction for wide
@@ -466,6 +468,8 @@ def measure_traffic(args, kernel_symbol, timeout_s=150, child_args=None):
             acc = []
             for row in csv.DictReader(open(path)):
                 if row.get("Counter_Name") == ctr and row["Kernel_Name"].split("(")[0].replace("void ", "") == want:
+                    if grid_size is not None and str(row.get("Grid_Size", grid_size)) != str(grid_size):
+                        continue      # (another launch shape of the same kernel)
                     acc.append(float(row["Counter_Value"]))
             if not acc:
                 return None, f"no {ctr} rows for {want}"
@@ -765,7 +769,8 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
             return S.train_iteration(x)
         n_params = sum(p.numel() for p in S.net.parameters())
         conv_path = ("MIOpen via nn.Conv2d (CLICA_CONV=miopen)" if os.environ.get("CLICA_CONV", "hip") == "miopen"
-                     else "HIP implicit-GEMM stages, clica_conv_* (CLICA_CONV=miopen selects nn.Conv2d)")
+                     else "HIP implicit-GEMM stages, clica_conv16_* in the f16x2 split arithmetic (CLICA_CONV_ARITH=f32: the fp32-MFMA kernels; CLICA_CONV=miopen: nn.Conv2d)"
+                     if os.environ.get("CLICA_CONV_ARITH", "f16x2") == "f16x2" else "HIP implicit-GEMM stages, clica_conv_* on fp32 MFMA (CLICA_CONV_ARITH=f32)")
         work = ("kitti_masks Solver.train body (solver.py:61-74): BetaVAE_H conv encoder (%s) on (2048, 1, 64, 64) binary masks = 1024 "
                 "pairs -> HIP Linear(256, 5) / Softclip -> strided views -> HIP LpSimCLRLoss(p = 1) -> backward -> flat HIP Adam" % conv_path)
     for _ in range(warmup):
@@ -782,18 +787,22 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
         ws.append(e0.elapsed_time(e1) * 1e-3)
     el = float(np.median(ws))
     return {"workload": work, "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": windows,
-            "images_per_s": round((2048 if which == "c5" else 2048) * steps / el, 1), "parameters": int(n_params), "dtype": "f32",
+            "images_per_s": round((2048 if which == "c5" else 2048) * steps / el, 1), "parameters": int(n_params),
+            "dtype": ("f32 via f16x2 split in the 16C-deep conv stages (3 fp16 MFMA products of two-piece operands, fp32 accumulate), f32 elsewhere"
+                      if which == "c5" and os.environ.get("CLICA_CONV", "hip") != "miopen" and os.environ.get("CLICA_CONV_ARITH", "f16x2") == "f16x2" else "f32"),
             "final_loss": float(last.item()), "launch": "eager (torch autograd drives the HIP library%s)" % (" and MIOpen" if which == "c4" or os.environ.get("CLICA_CONV", "hip") == "miopen" else ""),
-            "kernel_shares": "profiles/r4_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % (which, which)}
+            "kernel_shares": "profiles/%s_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % ("r5" if which == "c5" else "r4", which, which)}
 
 
 def c5_conv_roofline(device, reps=20, traffic=True):
-    """`roofline` object of BASELINE configs[4]'s dominant kernel: the persistent data-gradient kernel of the
-    widest conv stage (32 -> 32 channels on the 17 x 17 grid, `conv_dgrad32_stream_k`: 43 % of the stack's flops).  Timed by HIP events
-    around isolated launches on the buffers one real forward / backward of the 2048-mask batch has left behind (the step itself is eager
-    torch autograd, its launches cannot be bracketed from here); algorithmic flops = 2 x images x (16 x 16 output pixels) x (4 x 4 x 32
-    taps) x 32 channels (SURVEY 8(d)-style: the useful MACs, not the row grid's); peak = the fp32 matrix pipe the kernel runs on;
-    `traffic` from child runs of `bench.py --config c5` under rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes)."""
+    """`roofline` object of BASELINE configs[4]'s dominant kernel.  Round 5: the stack runs in the f16x2 split
+    arithmetic (csrc/conv16.hip) and the longest launch is the FORWARD of the widest stage (32 -> 32 channels, 2048 x 16 x 16 output pixels,
+    K = 512: `conv16::stream16_k<1>`).  Timed by HIP events around isolated launches on the buffers one real forward / backward of the
+    2048-mask batch has left behind (the step itself is eager torch autograd, its launches cannot be bracketed from here).  By the roofline
+    model the kernel is HBM-bound: 17.2 GFLOP over 370 MB (S1 read once + S2 written) = 46 flop/B against a balance of 104 flop/B for three
+    fp16 products per fp32 product -- so `achieved` / `peak` are algorithmic bytes per second against 8 TB/s; the matrix-side figures
+    (issued fp16 flops against the 2.5 PFLOP/s pipe the kernel runs on, fp32-equivalent flops against the fp32 matrix peak that bounded
+    the round-4 kernel) ride along.  `traffic` from child runs of `bench.py --config c5` under rocprofv3 --pmc (separate passes)."""
     import ctypes as C
     from cl_ica_amd import conv, _lib
     from cl_ica_amd.kitti_masks.model import BetaVAE_H
@@ -807,12 +816,18 @@ def c5_conv_roofline(device, reps=20, traffic=True):
     buf = conv._POOL[(2048, 1, device.index if device.index is not None else torch.cuda.current_device())][0]
     images, l = 2048, 1
     cout, ho = conv.STAGES[l]; cin, hs = conv.STAGES[l - 1][0], ho + 1
-    dgrid = conv.STAGES[l - 1][1]
     st = _lib.stream_ptr()
+    f16 = conv.get_arith() == "f16x2"
+    bias = net.encoder[2].bias.detach()
 
     def launch():
-        _lib.check(lib.clica_conv_k4s2_dgrad(buf.dO[l].data_ptr(), buf.wpack[3 + l].data_ptr(), buf.S[l].data_ptr(), images, cin, cout, hs, hs,
-                                             buf.dO[l - 1].data_ptr(), dgrid, dgrid, buf.gate[l - 1].data_ptr(), st), "clica_conv_k4s2_dgrad")
+        if f16:
+            _lib.check(lib.clica_conv16_k4s2_fwd(buf.S[l].data_ptr(), buf.w16[l - 1].data_ptr(), buf.wscale.data_ptr() + 4 * (l - 1), bias.data_ptr(),
+                                                 images, cin, cout, hs, hs, 1, 1, buf.S[l + 1].data_ptr(), buf.gate[l].data_ptr(),
+                                                 conv._slots(buf, l - 1), conv._slots(buf, l), st), "clica_conv16_k4s2_fwd")
+        else:
+            _lib.check(lib.clica_conv_k4s2_fwd(buf.S[l].data_ptr(), buf.wpack[l].data_ptr(), bias.data_ptr(), images, cin, cout, hs, hs,
+                                               1, 1, buf.S[l + 1].data_ptr(), buf.gate[l].data_ptr(), st), "clica_conv_k4s2_fwd")
     for _ in range(5):
         launch()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -823,17 +838,27 @@ def c5_conv_roofline(device, reps=20, traffic=True):
     torch.cuda.synchronize(device)
     us = ev[0].elapsed_time(ev[1]) * 1e3 / reps
     gflop = 2.0 * images * ho * ho * 16 * cin * cout / 1e9
-    grid_gflop = 2.0 * images * hs * hs * (4 * cout) * (4 * cin) / 1e9
-    roof = {"kernel": "clica::gemm::conv_dgrad32_stream_k", "op": "data gradient of the 32 -> 32 stage (kitti_masks/model.py:41-56, second Conv2d)", "bound": "mfma",
-            "achieved": round(gflop / us * 1e3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(gflop / us * 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+    alg_bytes = int(4 * images * (hs * hs * 4 * cin + (ho // 2 + 1) ** 2 * 4 * cout) + images * ho * ho * cout // 8)
+    tbs = alg_bytes / us / 1e6
+    roof = {"kernel": "clica::conv16::stream16_k<1>" if f16 else "clica::gemm::conv_gemm_k<128, 32, 4, 1, 2, true, true, 0>",
+            "op": "forward of the 32 -> 32 stage (kitti_masks/model.py:41-56, second Conv2d + ReLU): implicit GEMM 524 288 x 32 x 512, bias + ReLU + "
+                  "scatter into the next stage's input + gate bits + maximum in the epilogue",
+            "bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(tbs * 1e3 / PEAK_HBM_GBS, 4),
             "avg_launch_us": round(us, 2), "timing": f"HIP events around {reps} isolated launches on the 2048-mask batch's buffers",
-            "algorithmic_gflop_per_launch": round(gflop, 3), "issued_gflop_per_launch_on_the_row_grid": round(grid_gflop, 3),
-            "algorithmic_bytes_per_launch": int(4 * images * (hs * hs * cout + dgrid * dgrid * cin) + images * dgrid * dgrid * cin // 8),
-            "dtype": "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)", "traffic": None, "traffic_source": None}
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_gflop_per_launch": round(gflop, 3),
+            "matrix_side": {"issued_tflops": round((3.0 if f16 else 1.0) * gflop / us * 1e3, 1), "pipe_peak_tflops": PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS,
+                            "frac_of_the_pipe_it_runs_on": round((3.0 if f16 else 1.0) * gflop / us * 1e3 / (PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS), 4),
+                            "fp32_equivalent_tflops": round(gflop / us * 1e3, 1), "frac_of_fp32_matrix_peak": round(gflop / us * 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
+            "dtype": ("f32 results from three fp16 products of two-piece operand splits, per-tensor power-of-two scales measured in the same step "
+                      "(v_mfma_f32_32x32x16_f16, fp32 accumulate)") if f16 else "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)",
+            "what_bounds_it": "each input pixel is used by four output pixels; the kernel requests 1.07 GB through the L1 for 303 MB of unique input (the HBM side sees "
+                              "~350 MB): the waves wait on the vector-memory path (PMC: waits 0.68 of wave cycles, matrix pipes busy 0.12)",
+            "traffic": None, "traffic_source": None}
     if traffic:
         class _A:      # what measure_traffic reads of the headline's arguments (unused by the c5 child command)
             n, batch_size, p, space_type, native_fp32 = 10, 6144, 2, "box", False
-        tb, src = measure_traffic(_A, roof["kernel"], child_args=["--config", "c5", "--steps", "3"])
+        # (the last stride-2 stage's forward is the same kernel on a smaller grid: select this stage's launch shape, 2 x 256 workgroups of 512)
+        tb, src = measure_traffic(_A, roof["kernel"], child_args=["--config", "c5", "--steps", "3"], grid_size=(2 * 256 * 512 if f16 else None))
         roof["traffic"], roof["traffic_source"] = tb, src
     del net
     conv._POOL.clear()

@@ -12,10 +12,11 @@ BUCKETS = [
     ("BatchNorm (MIOpen / ATen)", lambda n: "batchnorm" in n.lower() or "batch_norm" in n.lower() or "bn_" in n.lower()),
     ("ATen element-wise / reductions / pooling / copies (ReLU, residual adds, max-pool, avg-pool, layout, zero_)", lambda n: True),
 ]
+TAG = os.environ.get("PTAG", "r4")
 for c in sys.argv[1:] or ["c4", "c5"]:
-    src = f"gpurun_out/profile_r4_{c}"
+    src = f"gpurun_out/profile_{TAG}_{c}"
     rows = list(csv.DictReader(open(f"{src}/t_kernel_stats.csv")))
-    shutil.copy(f"{src}/t_kernel_stats.csv", f"profiles/r4_{c}_kernel_stats.csv")
+    shutil.copy(f"{src}/t_kernel_stats.csv", f"profiles/{TAG}_{c}_kernel_stats.csv")
     bench = json.loads(open(f"{src}/bench.json").read().strip().splitlines()[-1])
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     shares = [[name, 0.0, 0, []] for name, _ in BUCKETS]
@@ -34,5 +35,5 @@ for c in sys.argv[1:] or ["c4", "c5"]:
     lines += ["", "Top kernels:", "", "| kernel | calls | avg us | % time |", "|---|---|---|---|"]
     for r in rows[:14]:
         lines.append(f"| `{r['Name'].split('(')[0][:110]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
-    open(f"profiles/r4_{c}_summary.md", "w").write("\n".join(lines) + "\n")
+    open(f"profiles/{TAG}_{c}_summary.md", "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:12]))

@@ -5,7 +5,7 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 for c in ${@:-c4 c5}; do
-  OUT=$ROOT/gpurun_out/profile_r4_$c
+  OUT=$ROOT/gpurun_out/profile_${PTAG:-r4}_$c
   mkdir -p $OUT
   # un-profiled first run: MIOpen benchmarks its candidate kernels the first time it sees a convolution on a box (hundreds of thousands
   # of launches that would drown the trace); its user find-db remembers the choice for the profiled run
