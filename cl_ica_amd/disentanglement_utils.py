@@ -8,7 +8,9 @@ Same two entry points, arguments and return structure as the reference:
 with every ``mode`` ("r2", "adjusted_r2", "pearson", "spearman") and both solvers ("naive", "munkres").  The reference copies the
 4096 x n embeddings to the host and runs sklearn / numpy / scipy over them every ``n_log_steps``; here ONE pass of the HIP library
 (``clica_moments``: G = [z | hz | 1]^T [z | hz | 1] in fp64, csrc/moments.hip) is the only thing that touches the data, and every score is
-evaluated from that (2n + 1)^2 matrix in fp64 on the host:
+evaluated from that (2n + 1)^2 matrix in fp64 on the host (one launch covers 2n + 1 <= 129, i.e. n <= 64; wider inputs go through the
+same kernel over 64-column blocks, ``ops.moments``.  Inputs are taken in fp32, the reference's embedding dtype; fp64 host arrays are
+rounded to fp32 first -- the sums themselves are fp64):
 
   * LinearRegression (:97-100): normal equations on G's hz / 1 block; r2_score of the prediction (:23) from the quadratic form
     z^T z - 2 c^T X^T z + c^T X^T X c -- no second pass over the data; Pearson of (z, prediction) likewise (a linear map of G);

@@ -21,6 +21,7 @@ This file has no device code; the mechanics are covered on CPU (tests/test_host_
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import weakref
 from typing import Callable, List, Optional
@@ -49,10 +50,20 @@ class _Pending:
         self.params = list(params)
         self.versions = [p._version for p in self.params]
         self.items: List = []          # (input tensor, LazyOut)
+        self.in_versions: List[int] = []      # _version of every input at the moment of its call (an input mutated in place
+                                              # between the call and the first use would silently give the output for the NEW values)
+        self.grad_mode = torch.is_grad_enabled()
+        self.stream = torch.cuda.current_stream() if torch.cuda.is_available() else None      # the deferred launches belong to this stream
         _ALL_PENDING.add(self)
 
+    def add(self, x: torch.Tensor, lz) -> None:
+        self.items.append((x, lz))
+        self.in_versions.append(x._version)
+
     def stale(self) -> bool:
-        return any(p._version != v for p, v in zip(self.params, self.versions))
+        if any(p._version != v for p, v in zip(self.params, self.versions)):
+            return True
+        return any(x._version != v for (x, _), v in zip(self.items, self.in_versions))
 
     def compatible(self, x: torch.Tensor) -> bool:
         if not self.items or len(self.items) >= self.max_items or self.stale():
@@ -63,13 +74,15 @@ class _Pending:
     def flush(self):
         """Run the pending calls (one compute over the stacked inputs) and hand every LazyOut its rows.  Returns the list of results in
         call order (None if the calls had gone stale)."""
+        was_stale = self.stale()
         items, self.items = self.items, []
+        self.in_versions = []
         _ALL_PENDING.discard(self)
         if getattr(self.owner, "_clica_pending", None) is self:
             self.owner._clica_pending = None
         if not items:
             return None
-        if self.stale():
+        if was_stale:
             # a parameter was written in place (not by an optimizer: those flush first, see the step pre-hook below) while the call
             # was pending: its value for the OLD parameters can no longer be computed.  Nobody may have wanted it (a discarded
             # evaluation call); whoever does gets the error.
@@ -77,7 +90,12 @@ class _Pending:
                 if lz is not None:
                     lz._stale = True
             return None
-        with torch.enable_grad():      # the call was made with grad mode on; the first use may sit inside a no_grad block
+        # the call's own grad mode and stream, not those of the first use (which may sit inside a no_grad block or on another stream)
+        cur = torch.cuda.current_stream() if self.stream is not None else None
+        other = self.stream is not None and cur != self.stream
+        if other:
+            self.stream.wait_stream(cur)       # inputs the current stream produced since
+        with torch.set_grad_enabled(self.grad_mode), (torch.cuda.stream(self.stream) if other else contextlib.nullcontext()):
             if len(items) == 1:
                 vals = [self.compute(items[0][0])]
             else:
@@ -88,6 +106,8 @@ class _Pending:
                     for x, _ in items:
                         vals.append(ystack[off:off + x.shape[0]])
                         off += x.shape[0]
+        if other:
+            cur.wait_stream(self.stream)
         for (_, lz), v in zip(items, vals):
             if lz is not None:
                 lz._value = v
@@ -109,8 +129,8 @@ class LazyOut(torch.Tensor):
         if self._value is None and not self._stale:
             self._pending.flush()
         if self._stale:
-            raise RuntimeError("cl_ica_amd: a parameter of the encoder was modified in place between the call and the first use of its "
-                               "(deferred) output; use the output first, or set CLICA_DROPIN_LAZY=0")
+            raise RuntimeError("cl_ica_amd: a parameter of the encoder or the input of the call was modified in place between the call and the "
+                               "first use of its (deferred) output; use the output first, or set CLICA_DROPIN_LAZY=0")
         return self._value
 
     @classmethod
@@ -148,14 +168,14 @@ def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor
     _attach_owners(owner, params)
     pend: Optional[_Pending] = getattr(owner, "_clica_pending", None)
     if pend is not None and pend.compatible(x):
-        pend.items.append((x, None))   # the call that completes the stack needs no placeholder: its rows are returned right away
+        pend.add(x, None)              # the call that completes the stack needs no placeholder: its rows are returned right away
         return pend.flush()[-1]
     if pend is not None:
         pend.flush()                   # an incompatible (or stale) first call: it runs (or is dropped) on its own
     pend = _Pending(owner, compute, params, max_items, compute_many)
     owner._clica_pending = pend
     lz = LazyOut(pend, out_shape, x.dtype, x.device, True)
-    pend.items.append((x, lz))
+    pend.add(x, lz)
     return lz
 
 

@@ -742,6 +742,27 @@ def moments(a: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
             raise ValueError(f"row counts differ: {tuple(a.shape)} vs {tuple(b.shape)}")
         db, bp = b.shape[1], b.data_ptr()
     d = da + db + 1
+    if d > 129:
+        # wider than one launch of the kernel covers (2 n + 1 <= 129, i.e. n <= 64): the same kernel over 64-column blocks of
+        # X = [a | b], G[I, J] = X_I^T X_J from the cross block of the launch on (X_I, X_J), sums from its last column
+        X = [(a, c0, min(c0 + 64, da)) for c0 in range(0, da, 64)] + ([(b, c0, min(c0 + 64, db)) for c0 in range(0, db, 64)] if b is not None else [])
+        offs, o = [], 0
+        for (_, c0, c1) in X:
+            offs.append(o); o += c1 - c0
+        G = torch.empty((d, d), dtype=torch.float64, device=a.device)
+        G[-1, -1] = float(M)
+        for i, (ti, i0, i1) in enumerate(X):
+            for j in range(i, len(X)):
+                tj, j0, j1 = X[j]
+                blk = moments(ti[:, i0:i1], tj[:, j0:j1])
+                ni, nj = i1 - i0, j1 - j0
+                G[offs[i]:offs[i] + ni, offs[j]:offs[j] + nj] = blk[:ni, ni:ni + nj]
+                G[offs[j]:offs[j] + nj, offs[i]:offs[i] + ni] = blk[:ni, ni:ni + nj].t()
+                if j == i:
+                    G[offs[i]:offs[i] + ni, offs[i]:offs[i] + ni] = blk[:ni, :ni]
+                    G[offs[i]:offs[i] + ni, -1] = blk[:ni, -1]
+                    G[-1, offs[i]:offs[i] + ni] = blk[-1, :ni]
+        return G
     nbytes = C.c_size_t()
     check(load().clica_moments_workspace_bytes(M, d, C.byref(nbytes)), "clica_moments_workspace_bytes")
     ws = workspace("moments", nbytes.value, a.device)

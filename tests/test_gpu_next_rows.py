@@ -119,10 +119,10 @@ def test_n2_all_modes_and_solvers_on_device(golden):
     assert check_metric_modes(du, golden("g25_metrics_modes.npz").z, dev, check=check) >= 60
 
 
-@pytest.mark.parametrize("M,da,db", [(4096, 10, 10), (1000, 4, 0), (63, 1, 1), (65, 40, 40), (12288, 64, 64), (517, 3, 7)])
+@pytest.mark.parametrize("M,da,db", [(4096, 10, 10), (1000, 4, 0), (63, 1, 1), (65, 40, 40), (12288, 64, 64), (517, 3, 7), (300, 100, 100), (257, 150, 0), (513, 70, 130)])
 def test_moments_kernel_vs_fp64(M, da, db):
     """clica_moments: G = [A | B | 1]^T [A | B | 1] in fp64 against numpy fp64 on the same fp32 data (exact products, so only the
-    summation order differs: 1e-12), on strided views, with and without B, batches that are not whole 64-row chunks."""
+    summation order differs: 1e-12), on strided views, with and without B, batches that are not whole 64-row chunks, widths beyond one launch."""
     from cl_ica_amd import ops
     rng = np.random.default_rng(M + da)
     a = dev(rng.normal(size=(M, da + 3)) * 3 + 1)[:, 1:1 + da]
@@ -132,8 +132,7 @@ def test_moments_kernel_vs_fp64(M, da, db):
     ref = X.T @ X
     assert G.shape == ref.shape == (da + db + 1, da + db + 1)
     assert np.abs(G - ref).max() <= 1e-12 * np.abs(ref).max() and np.array_equal(G, G.T) and G[-1, -1] == M
-    with pytest.raises(Exception):
-        ops.moments(dev(np.zeros((8, 100))), dev(np.zeros((8, 100))))          # 201 columns > 129
+    # (more than 129 columns -- n > 64 -- go through the same kernel over 64-column blocks: the last three cases)
 
 
 def _synthetic_kitti(rng, n_seq=17, hw=64):
@@ -348,6 +347,32 @@ def test_dropin_lazy_stacking_and_symmetric_loss_match_plain_path(B, p, monkeypa
 def build_mlp_n10():
     from test_gpu_configs import build_mlp
     return build_mlp(10, [100, 500, 500, 100], None, gain=1.8)
+
+
+def test_dropin_lazy_input_mutation_is_loud_and_first_use_on_another_stream():
+    """(a) an input written in place between the call and the first use of its deferred output raises (the output for the OLD
+    values can no longer be computed) instead of silently giving the output for the new ones; (b) a first use on another stream runs
+    the deferred launches on the CALL's stream and makes the using stream wait: same numbers as an eager call."""
+    from cl_ica_amd import encoders, lazy
+    torch.manual_seed(5)
+    f = encoders.get_mlp(6, 6, [32, 64]).cuda()
+    x = torch.rand(128, 6, device="cuda")
+    a = f(x)
+    assert isinstance(a, lazy.LazyOut)
+    x.mul_(2.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        a.sum()
+    x = torch.rand(128, 6, device="cuda")
+    want = lazy.plain(f(x)).detach().clone()
+    torch.cuda.synchronize()
+    b = f(x)
+    assert isinstance(b, lazy.LazyOut)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side), torch.no_grad():
+        got = (b * 1.0)
+    torch.cuda.synchronize()
+    assert got.requires_grad is False and lazy.plain(b).requires_grad        # the call was made with grad mode on
+    assert torch.equal(got, want)
 
 
 def test_dropin_lazy_output_single_use_and_per_item_upstream():
