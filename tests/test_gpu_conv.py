@@ -101,7 +101,7 @@ _TIE_NOTE = ("informational: plain fp64 reference.  A pre-activation within roun
              "statement is the comparison with the HIP gates forced into the fp64 reference")
 
 
-def _compare_full_batch(family, case, x, convs, dfeats, tol_forced, note_forced=""):
+def _compare_full_batch(family, case, x, convs, dfeats, tol_forced, note_forced="", feat_floor=1e-2):
     """The 2048-image batch: (a) gates the HIP forward decided differently from the fp64 forward are ties (|z| <= 1e-6 max|z|) and few;
     (b) against the fp64 reference evaluated WITH the HIP gates every gradient holds `tol_forced`; (c) the plain comparison is logged."""
     from cl_ica_amd import conv
@@ -115,7 +115,7 @@ def _compare_full_batch(family, case, x, convs, dfeats, tol_forced, note_forced=
     frc_f, frc_g, mism = _reference_fp64(x, convs, dfeats, hip_gate=gates)
     torch.cuda.synchronize()
     PARITY.check(family, case, "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
-    assert float(ref_f.abs().max()) > 1e-2 and float((ref_f > 0).float().mean()) > 0.05
+    assert float(ref_f.abs().max()) > feat_floor and float((ref_f > 0).float().mean()) > 0.05
     for l, (n, zrel) in enumerate(mism):
         assert n <= 64 and zrel <= 1e-6, f"stage {l + 1}: {n} gates differ from the fp64 forward, largest |z| / max|z| = {zrel:.2e} (ties only expected)"
     for i, (gh, r, rf) in enumerate(zip(got_g, ref_g, frc_g)):
@@ -141,13 +141,13 @@ def _run_hip(x, convs, dfeats):
     return feats.detach(), grads
 
 
-def _compare(family, case, x, convs, dfeats, gate_ties=False):
+def _compare(family, case, x, convs, dfeats, gate_ties=False, feat_floor=1e-2):
     case = case + _TAG
     got_f, got_g = _run_hip(x, convs, dfeats)
     ref_f, ref_g = _reference_fp64(x, convs, dfeats)
     torch.cuda.synchronize()
     PARITY.check(family, case, "features", got_f.cpu().numpy(), ref_f.cpu().numpy())
-    assert float(ref_f.abs().max()) > 1e-2 and float((ref_f > 0).float().mean()) > 0.05       # not a collapsed stack
+    assert float(ref_f.abs().max()) > feat_floor and float((ref_f > 0).float().mean()) > 0.05       # not a collapsed stack
     for i, (g, r) in enumerate(zip(got_g, ref_g)):
         name = f"stage{i // 2 + 1}." + ("weight" if i % 2 == 0 else "bias")
         assert g.shape == r.shape
@@ -168,6 +168,24 @@ def test_conv_stack_small_vs_fp64(nc, images):
         x = (x > 0.6).float()          # binary masks, as the data set's
     dfeats = torch.randn(images, 256, generator=g).to("cuda")
     _compare("c5_conv_stack", f"nc={nc} images={images}", x, _convs(nc), dfeats)
+
+
+@pytest.mark.parametrize("gscale,xscale", [(1e-18, 1.0), (1e12, 1.0), (1.0, 1e-6), (1e-10, 3e4)])
+def test_conv_stack_scale_extremes(gscale, xscale):
+    """The f16x2 stages carry fp16's five exponent bits; what makes them fp32-equivalent is the per-tensor power-of-two scale every
+    consumer derives from the maximum its producer recorded IN THE SAME STEP (csrc/conv16.hip).  Upstream gradients of 1e-18 / 1e12
+    and inputs of 1e-6 / 3e4 (fp16 would flush the first to zero and overflow on the last): same 1e-5 against fp64 as at scale 1.
+    (A workgroup that read a neighbour's half-written scale word -- a race this test exists for -- was invisible at scale ~1.)"""
+    g = torch.Generator().manual_seed(11)
+    images = 24
+    x = (torch.rand(images, 1, 64, 64, generator=g) > 0.6).float().to("cuda") * xscale
+    dfeats = (torch.randn(images, 256, generator=g) * gscale).to("cuda")
+    convs = _convs(1)
+    if xscale != 1.0:      # keep the biases in proportion so that the ReLUs see the same pattern as at scale 1
+        for m in convs:
+            m.bias.data *= xscale
+        # (weights unchanged: every stage's pre-activation is then xscale times the scale-1 one)
+    _compare_full_batch("c5_conv_stack/scales", f"gscale={gscale:g} xscale={xscale:g}", x, convs, dfeats, 1e-5, feat_floor=1e-2 * xscale)
 
 
 def test_conv_stack_full_batch_vs_fp64():
