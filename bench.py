@@ -797,7 +797,7 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
 def c5_conv_roofline(device, reps=20, traffic=True):
     """`roofline` object of BASELINE configs[4]'s dominant kernel.  Round 5: the stack runs in the f16x2 split
     arithmetic (csrc/conv16.hip) and the longest launch is the FORWARD of the widest stage (32 -> 32 channels, 2048 x 16 x 16 output pixels,
-    K = 512: `conv16::stream16_k<1>`).  Timed by HIP events around isolated launches on the buffers one real forward / backward of the
+    K = 512: `conv16::fwd_tile16_k`).  Timed by HIP events around isolated launches on the buffers one real forward / backward of the
     2048-mask batch has left behind (the step itself is eager torch autograd, its launches cannot be bracketed from here).  By the roofline
     model the kernel is HBM-bound: 17.2 GFLOP over 370 MB (S1 read once + S2 written) = 46 flop/B against a balance of 104 flop/B for three
     fp16 products per fp32 product -- so `achieved` / `peak` are algorithmic bytes per second against 8 TB/s; the matrix-side figures
@@ -840,7 +840,7 @@ def c5_conv_roofline(device, reps=20, traffic=True):
     gflop = 2.0 * images * ho * ho * 16 * cin * cout / 1e9
     alg_bytes = int(4 * images * (hs * hs * 4 * cin + (ho // 2 + 1) ** 2 * 4 * cout) + images * ho * ho * cout // 8)
     tbs = alg_bytes / us / 1e6
-    roof = {"kernel": "clica::conv16::stream16_k<1>" if f16 else "clica::gemm::conv_gemm_k<128, 32, 4, 1, 2, true, true, 0>",
+    roof = {"kernel": "clica::conv16::fwd_tile16_k" if f16 else "clica::gemm::conv_gemm_k<128, 32, 4, 1, 2, true, true, 0>",
             "op": "forward of the 32 -> 32 stage (kitti_masks/model.py:41-56, second Conv2d + ReLU): implicit GEMM 524 288 x 32 x 512, bias + ReLU + "
                   "scatter into the next stage's input + gate bits + maximum in the epilogue",
             "bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(tbs * 1e3 / PEAK_HBM_GBS, 4),
@@ -851,14 +851,14 @@ def c5_conv_roofline(device, reps=20, traffic=True):
                             "fp32_equivalent_tflops": round(gflop / us * 1e3, 1), "frac_of_fp32_matrix_peak": round(gflop / us * 1e3 / PEAK_FP32_MFMA_TFLOPS, 4)},
             "dtype": ("f32 results from three fp16 products of two-piece operand splits, per-tensor power-of-two scales measured in the same step "
                       "(v_mfma_f32_32x32x16_f16, fp32 accumulate)") if f16 else "f32 (v_mfma_f32_32x32x2_f32, exact fp32 products)",
-            "what_bounds_it": "each input pixel is used by four output pixels; the kernel requests 1.07 GB through the L1 for 303 MB of unique input (the HBM side sees "
-                              "~350 MB): the waves wait on the vector-memory path (PMC: waits 0.68 of wave cycles, matrix pipes busy 0.12)",
+            "what_bounds_it": ("HBM: a workgroup fetches the 9 x 17 input pixels of its 8 x 16 output pixels once (one contiguous 78 KB block, split to f16 pieces "
+                               "on the way into LDS, weights in registers), so the launch moves its algorithmic bytes ~once; the streaming version of round 5 "
+                               "(every output pixel fetching its own 2 x 2 window: 1.07 GB through the L1) took 148 us") if f16 else "fp32 matrix rate at N = 32",
             "traffic": None, "traffic_source": None}
     if traffic:
         class _A:      # what measure_traffic reads of the headline's arguments (unused by the c5 child command)
             n, batch_size, p, space_type, native_fp32 = 10, 6144, 2, "box", False
-        # (the last stride-2 stage's forward is the same kernel on a smaller grid: select this stage's launch shape, 2 x 256 workgroups of 512)
-        tb, src = measure_traffic(_A, roof["kernel"], child_args=["--config", "c5", "--steps", "3"], grid_size=(2 * 256 * 512 if f16 else None))
+        tb, src = measure_traffic(_A, roof["kernel"], child_args=["--config", "c5", "--steps", "3"])
         roof["traffic"], roof["traffic_source"] = tb, src
     del net
     conv._POOL.clear()

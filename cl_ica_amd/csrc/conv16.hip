@@ -599,7 +599,150 @@ static bool stream16_fits(const GArgs& a, int& nbn, int& nsplit) {
   }
   return false;
 }
+// ---- forward of a 16-pixel-wide stage with 32 -> 32 channels from IMAGE TILES in LDS ---------------------------------------------
+// In the streaming kernel every output pixel fetches its own 2 x 2 window of S pixels: 1.07 GB requested through the L1 for the 303 MB
+// of the widest stage's input, the waves wait 0.68 of their cycles on the vector-memory path (148 us).  Here a workgroup takes 8 output
+// rows x 16 of one image: their 9 x 17 S pixels are ONE contiguous 78 KB block of the space-to-depth tensor, fetched once (registers,
+// one tile ahead) and split to f16 pieces on the way into LDS ([plane][pixel][128 channels + 8]).  Wave (pg, kh) computes output rows
+// 2 pg, 2 pg + 1 over the window row dy = kh (half of the contraction) with v_mfma_f32_16x16x32_f16: its A fragments -- lane (x, k
+// group) = 8 channels of S pixel (row + kh, x + dx) -- come from LDS, its B fragments (the packed weights of its contraction half, 32
+// columns x 256) stay in 128 REGISTERS for the whole kernel; the two halves meet through LDS.  (With the weights read from LDS by
+// every wave the kernel moved 768 KB through LDS per tile, 6 k of its 12 k cycles: 95 us; this version 288 KB.)
+constexpr int TL_TY = 8, TL_PIX = (TL_TY + 1) * 17, TL_LDA = 128 + 8, TL_THREADS = 512;
+constexpr int TL_F4 = TL_PIX * 32;                                   // float4 units of a tile (4896)
+constexpr int TL_UNITS = (TL_F4 + TL_THREADS - 1) / TL_THREADS;      // 10 per thread
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16(const u32x4 a, const u32x4 b, const f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+__global__ __launch_bounds__(TL_THREADS) void fwd_tile16_k(GArgs a, int ntiles, int tiles_per_image) {
+  extern __shared__ __attribute__((aligned(16))) half_t tsm[];       // A: [2][TL_PIX][TL_LDA]; behind it: partial sums [4 pg][16][64] floats
+  __shared__ unsigned s_word;
+  half_t* const sA = tsm;
+  float* const red = reinterpret_cast<float*>(tsm + 2 * TL_PIX * TL_LDA);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = lane & 15, kg = lane >> 4;
+  const int pg = wave >> 1, kh = wave & 1;
+  const Geo g = a.g;
+  const float sA_scale = tensor_scale(a.amax_in, &s_word);
+  // this wave's half of the packed weights: [step 0..7][column block 0..1][hi / lo], lane (column x, k group kg)
+  u32x4 bw[8][2][2];
+#pragma unroll
+  for (int st = 0; st < 8; ++st)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl)
+        bw[st][blk][pl] = *reinterpret_cast<const u32x4*>(a.B + (int64_t)pl * 32 * 512 + (16 * blk + x) * 512 + kh * 256 + 32 * st + 8 * kg);
+  const float cs = 1.f / (sA_scale * *a.bscale);
+  const float bv0 = a.bias ? a.bias[x] : 0.f, bv1 = a.bias ? a.bias[16 + x] : 0.f;
+  float4 rq[TL_UNITS];
+  auto load = [&](int tile) {
+    const int img = tile / tiles_per_image, ty = tile - img * tiles_per_image;
+    const float* src = a.A + (((int64_t)img * g.ghs + ty * TL_TY) * g.gws) * 128;
+#pragma unroll
+    for (int i = 0; i < TL_UNITS; ++i) {
+      const int f = threadIdx.x + i * TL_THREADS;
+      rq[i] = *reinterpret_cast<const float4*>(src + 4 * min(f, TL_F4 - 1));
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int i = 0; i < TL_UNITS; ++i) {
+      const int f = threadIdx.x + i * TL_THREADS;
+      if (f >= TL_F4) continue;
+      const int pix = f >> 5, ch = (f & 31) * 4;
+      u32x2 hi, lo;
+      split4(rq[i], sA_scale, hi, lo);
+      *reinterpret_cast<u32x2*>(sA + pix * TL_LDA + ch) = hi;
+      *reinterpret_cast<u32x2*>(sA + TL_PIX * TL_LDA + pix * TL_LDA + ch) = lo;
+    }
+  };
+  float amax = 0.f;
+  int tile = blockIdx.x;
+  if (tile < ntiles) load(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                     // the previous tile's fragments and partial sums have been read
+    store();
+    if (tile + (int)gridDim.x < ntiles) load(tile + gridDim.x);
+    __syncthreads();
+    f32x4v acc[2][2];                                    // [output row of the pair][column block]
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) acc[rr][blk] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    const half_t* arow = sA + ((2 * pg + kh) * 17 + x) * TL_LDA + 8 * kg;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const int dx = st >> 2, cb = st & 3;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const half_t* pa = arow + (rr * 17 + dx) * TL_LDA + 32 * cb;
+        const u32x4 ahi = *reinterpret_cast<const u32x4*>(pa), alo = *reinterpret_cast<const u32x4*>(pa + TL_PIX * TL_LDA);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          acc[rr][blk] = mfma16(alo, bw[st][blk][0], acc[rr][blk]);
+          acc[rr][blk] = mfma16(ahi, bw[st][blk][1], acc[rr][blk]);
+          acc[rr][blk] = mfma16(ahi, bw[st][blk][0], acc[rr][blk]);
+        }
+      }
+    }
+    // the two contraction halves meet: kh = 1 leaves its sums in LDS, kh = 0 adds them and runs the epilogue
+    if (kh == 1) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(pg * 16 + (rr * 2 + blk) * 4 + r) * 64 + lane] = acc[rr][blk][r];
+    }
+    __syncthreads();
+    if (kh == 0) {
+      // C/D layout of a 16 x 16 block: column (channel) = lane & 15, row (output x) = 4 (lane >> 4) + r
+      const int img = tile / tiles_per_image, ty = tile - img * tiles_per_image;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int y = ty * TL_TY + 2 * pg + rr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ox = 4 * kg + r;
+          const int Y = (y + 1) >> 1, X = (ox + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((ox + 1) & 1);
+          float* dst = a.C + (((int64_t)img * g.dhs + Y) * g.dws + X) * (4 * 32) + qq * 32;
+          float v0 = (acc[rr][0][r] + red[(pg * 16 + (rr * 2 + 0) * 4 + r) * 64 + lane]) * cs + bv0;
+          float v1 = (acc[rr][1][r] + red[(pg * 16 + (rr * 2 + 1) * 4 + r) * 64 + lane]) * cs + bv1;
+          if (a.relu) { v0 = v0 > 0.f ? v0 : 0.f; v1 = v1 > 0.f ? v1 : 0.f; }
+          dst[x] = v0;
+          dst[16 + x] = v1;
+          amax = fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1)));
+          if (a.gate_out) {
+            const unsigned long long b0 = __ballot(v0 > 0.f), b1 = __ballot(v1 > 0.f);
+            const unsigned word = (unsigned)((b0 >> (16 * kg)) & 0xffffull) | ((unsigned)((b1 >> (16 * kg)) & 0xffffull) << 16);
+            if (x == 0) a.gate_out[((int64_t)img * g.ghs + y) * g.gws + ox] = word;
+          }
+        }
+      }
+    }
+  }
+  commit_amax(a.amax_out, amax, blockIdx.x * (TL_THREADS / 64) + wave);
+}
+static bool tile16_fits(const GArgs& a) {
+  static const bool on = [] { const char* e = getenv("CLICA_CONV16_TILE"); return !(e && atoi(e) == 0); }();
+  const Geo& g = a.g;
+  return on && g.mode == 1 && a.N == 32 && a.K == 512 && a.lda == 128 && g.ws == 16 && g.gws == 17 && g.hs % TL_TY == 0 && g.ghs == g.hs + 1 && g.c == 32;
+}
+static int launch_tile16(const GArgs& a, hipStream_t st, const char* who) {
+  constexpr size_t lds = (size_t)(2 * TL_PIX * TL_LDA) * sizeof(half_t) + 4 * 16 * 64 * sizeof(float);
+  auto k = fwd_tile16_k;
+  static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), true);
+  (void)once;
+  const int tiles_per_image = a.g.hs / TL_TY;
+  const int ntiles = (int)(a.M / (a.g.hs * a.g.ws)) * tiles_per_image;
+  hipLaunchKernelGGL(k, dim3((unsigned)std::min(ntiles, kNumCU)), dim3(TL_THREADS), lds, st, a, ntiles, tiles_per_image);
+  return launch_status(who);
+}
+
 static int launch_conv16(const GArgs& a, hipStream_t st, const char* who) {
+  if (tile16_fits(a)) return launch_tile16(a, st, who);
   int nbn = 0, nsplit = 0;
   if (stream16_fits(a, nbn, nsplit)) {
     if (nbn == 1) return launch_stream16_n<1>(a, nsplit, st, who);
