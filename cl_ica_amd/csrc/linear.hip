@@ -1911,6 +1911,20 @@ __global__ __launch_bounds__(256) void conv_fwd_patches_valu_k(const float* __re
 // pixel (oy, ox) = x[img][2 oy - 1 + ky][2 ox - 1 + kx], zero outside the H x W image: columns 2 ox - 2 .. 2 ox + 3 as three float2.
 // branch-free: out-of-image taps are read from a clamped address and zeroed by a select (as conditional loads the window cost twelve
 // exec-mask branches per pixel: the kernel was instruction-bound at ~800 instructions per pixel and thread)
+// the raw loads only (clamped addresses); win_mask() applies the zeroing when the values are USED -- a select on a value that has just
+// been requested makes the compiler wait for it on the spot, which is what a prefetch must not do
+__device__ __forceinline__ float4 win_row_raw(const float* __restrict__ ximg, int yy, int ox, int H, int W) {
+  const int yc = min(max(yy, 0), H - 1);
+  const float* rowp = ximg + (int64_t)yc * W + 2 * ox;
+  const float l = rowp[ox > 0 ? -1 : 0];
+  const float2 m = *reinterpret_cast<const float2*>(rowp);
+  const float r = rowp[2 * ox + 2 < W ? 2 : 0];
+  return make_float4(l, m.x, m.y, r);
+}
+__device__ __forceinline__ float4 win_mask(const float4 v, int yy, int ox, int H, int W) {
+  const bool rin = yy >= 0 && yy < H, lin = ox > 0, rgt = 2 * ox + 2 < W;
+  return make_float4((rin && lin) ? v.x : 0.f, rin ? v.y : 0.f, rin ? v.z : 0.f, (rin && rgt) ? v.w : 0.f);
+}
 __device__ __forceinline__ float4 win_row(const float* __restrict__ ximg, int yy, int ox, int H, int W) {
   const int yc = min(max(yy, 0), H - 1);
   const bool rin = yy == yc, lin = ox > 0, rgt = 2 * ox + 2 < W;
@@ -1958,7 +1972,7 @@ __global__ __launch_bounds__(256) void conv_fwd_image_valu_k(const float* __rest
   auto fetch = [&](Pre& P, unsigned base) {
     const unsigned pixel = min(base + (unsigned)pl, pixels - 1u);
     pixel_decode(pixel, ho, wo, ho_shift, wo_shift, P.img, P.y, P.x);
-    P.v = win_row(X + (int64_t)P.img * H * W, 2 * (int)P.y - 1 + cg, (int)P.x, H, W);
+    P.v = win_row_raw(X + (int64_t)P.img * H * W, 2 * (int)P.y - 1 + cg, (int)P.x, H, W);
   };
   auto quad = [](float v, int src) -> float {       // value of lane (lane & ~3) + src
     const int i = __builtin_bit_cast(int, v);
@@ -1975,10 +1989,11 @@ __global__ __launch_bounds__(256) void conv_fwd_image_valu_k(const float* __rest
     const unsigned pixel = base + (unsigned)pl;
     const bool valid = pixel < pixels;
     float a[K];
+    const float4 pv = win_mask(P.v, 2 * (int)P.y - 1 + cg, (int)P.x, H, W);
 #pragma unroll
-    for (int ky = 0; ky < 4; ++ky) { a[4 * ky] = quad(P.v.x, ky); a[4 * ky + 1] = quad(P.v.y, ky); a[4 * ky + 2] = quad(P.v.z, ky); a[4 * ky + 3] = quad(P.v.w, ky); }
+    for (int ky = 0; ky < 4; ++ky) { a[4 * ky] = quad(pv.x, ky); a[4 * ky + 1] = quad(pv.y, ky); a[4 * ky + 2] = quad(pv.z, ky); a[4 * ky + 3] = quad(pv.w, ky); }
     const unsigned img = P.img, y = P.y, x = P.x;
-    if (base + 2 * stride < pixels) fetch(P, base + 2 * stride);
+    if (base + 4 * stride < pixels) fetch(P, base + 4 * stride);
     float o[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -2015,11 +2030,27 @@ __global__ __launch_bounds__(256) void conv_fwd_image_valu_k(const float* __rest
       if (cg == 0) gate_out[pixel] = bits;
     }
   };
+  // The 128 weights must have ARRIVED before the loop: left pending, their waits end up inside the loop body as s_waitcnt vmcnt(0) -- and
+  // on this ISA a wait for loads with stores in flight is a wait for EVERYTHING anyway (loads and stores share one counter and complete
+  // out of order with respect to each other, so the compiler emits vmcnt(0)): every pixel paid a full round trip for its stores to be
+  // acknowledged, the kernel wrote its 268 MB at 2.1 TB/s whatever its loads looked like (five versions: 121 ... 157 us).  Hence:
+  // weights pinned here, and FOUR pixels in flight per thread, refilled together -- one drain per four pixels.
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) asm volatile("" ::"v"(w[c][k]));
+    asm volatile("" ::"v"(b[c]));
+  }
+  Pre P2, P3;
   if (base0 < pixels) fetch(P0, base0);
   if (base0 + stride < pixels) fetch(P1, base0 + stride);
-  for (unsigned base = base0; base < pixels; base += 2 * stride) {
+  if (base0 + 2 * stride < pixels) fetch(P2, base0 + 2 * stride);
+  if (base0 + 3 * stride < pixels) fetch(P3, base0 + 3 * stride);
+  for (unsigned base = base0; base < pixels; base += 4 * stride) {
     process(P0, base);
     if (base + stride < pixels) process(P1, base + stride);
+    if (base + 2 * stride < pixels) process(P2, base + 2 * stride);
+    if (base + 3 * stride < pixels) process(P3, base + 3 * stride);
   }
   if (amax_slots) {
 #pragma unroll
@@ -2114,7 +2145,7 @@ static bool patch_wgrad_ok(int32_t Cout, int32_t K) {
 }
 static PatchWgradPlan plan_patch_wgrad(int64_t rows) {
   PatchWgradPlan p;
-  p.rows_per_block = std::max<int64_t>(256, ceil_div(rows, (int64_t)kNumCU * 8));
+  p.rows_per_block = std::max<int64_t>(256, ceil_div(rows, (int64_t)kNumCU * 4));      // (x 8: twice the slabs for the reduction to walk, the kernel no faster)
   p.blocks = (int)ceil_div(rows, p.rows_per_block);
   return p;
 }
