@@ -765,8 +765,20 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
         S.net_mode(train=True)
         x = (torch.rand(2048, 1, 64, 64, device=device) < 0.1).float()
 
-        def step():
-            return S.train_iteration(x)
+        launch_mode = "eager (torch autograd drives the HIP library)"
+        step_eager = lambda: S.train_iteration(x)      # noqa: E731
+        step = step_eager
+        if os.environ.get("CLICA_C5_GRAPH", "1") != "0" and os.environ.get("CLICA_CONV", "hip") != "miopen":
+            try:      # the whole iteration as one HIP graph (Solver.capture); any failure falls back to the eager loop and is reported
+                replay, loss_t = S.capture(x)
+
+                def step():
+                    replay()
+                    return loss_t
+                launch_mode = "HIP graph replay of the whole iteration (Solver.capture: forward, loss, backward, flat Adam)"
+            except Exception as e:      # noqa: BLE001
+                step = step_eager
+                launch_mode = f"eager (graph capture failed: {type(e).__name__}: {str(e)[:160]})"
         n_params = sum(p.numel() for p in S.net.parameters())
         conv_path = ("MIOpen via nn.Conv2d (CLICA_CONV=miopen)" if os.environ.get("CLICA_CONV", "hip") == "miopen"
                      else "HIP implicit-GEMM stages, clica_conv16_* in the f16x2 split arithmetic (CLICA_CONV_ARITH=f32: the fp32-MFMA kernels; CLICA_CONV=miopen: nn.Conv2d)"
@@ -790,7 +802,7 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
             "images_per_s": round((2048 if which == "c5" else 2048) * steps / el, 1), "parameters": int(n_params),
             "dtype": ("f32 via f16x2 split in the 16C-deep conv stages (3 fp16 MFMA products of two-piece operands, fp32 accumulate), f32 elsewhere"
                       if which == "c5" and os.environ.get("CLICA_CONV", "hip") != "miopen" and os.environ.get("CLICA_CONV_ARITH", "f16x2") == "f16x2" else "f32"),
-            "final_loss": float(last.item()), "launch": "eager (torch autograd drives the HIP library%s)" % (" and MIOpen" if which == "c4" or os.environ.get("CLICA_CONV", "hip") == "miopen" else ""),
+            "final_loss": float(last.item()), "launch": (launch_mode if which == "c5" else "eager (torch autograd drives the HIP library and MIOpen)"),
             "kernel_shares": "profiles/%s_%s_summary.md (rocprofv3 --kernel-trace --stats of `bench.py --config %s`)" % ("r5" if which == "c5" else "r4", which, which)}
 
 

@@ -86,6 +86,29 @@ class Solver(object):
         self.optim.step()
         return total
 
+    def capture(self, x, warmup: int = 3):
+        """The whole iteration on a static batch `x` as ONE HIP graph: returns ``(replay, loss)`` -- ``replay()`` runs
+        forward, loss, backward and the optimizer step again on whatever ``x`` holds by then (copy the next batch into it) and refreshes
+        the 0-dim tensor ``loss``.  Everything the step launches is capture-safe by construction (no host sync, device-side step counter
+        in the flat Adam, the conv stack's buffers pooled); the warm-up iterations run on the capture stream first, so that the
+        per-stream workspaces and the pooled buffers exist before the capture begins.  The parameters advance during the warm-up
+        (`warmup` optimizer steps on `x`, exactly as if ``train_iteration`` had been called); the capture itself executes nothing, ``loss``
+        holds a value after the first ``replay()``."""
+        if self.world > 1:
+            raise RuntimeError("Solver.capture: the data-parallel step (gloo / RCCL collectives issued from Python) is not captured")
+        x = x.to(self.device)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.train_iteration(x)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            loss = self.train_iteration(x)
+        return graph.replay, loss
+
     # ------------------------------------------------------------------ the loop
     def _batches(self):
         """Endless stream of image batches: the loader is re-iterated epoch after epoch, labels dropped."""

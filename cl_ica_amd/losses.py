@@ -90,6 +90,8 @@ def _async_item() -> bool:
 
 
 def _share_items(src, outs):
+    if src.is_cuda and torch.cuda.is_current_stream_capturing():
+        return      # tensors of a captured graph are rewritten by every replay: they keep the plain Tensor.item (a cached value would go stale)
     sh = _SharedScalars(src)
     for k, t in enumerate(outs):
         t.item = functools.partial(sh.item, t, k, t._version)

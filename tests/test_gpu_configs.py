@@ -413,6 +413,34 @@ def test_c5_kitti_solver_goldens(golden, tmp_path):
         assert set(ck["optim_states"]["optim"]["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
 
 
+def test_c5_solver_graph_replay_equals_eager():
+    """Solver.capture (round 5): the whole iteration of kitti_masks/solver.py:61-74 as one HIP graph.  Two solvers from the same
+    weights: one runs five eager iterations (three on the first batch, then two new batches), the other captures after three warm-up
+    iterations on the first batch (the capture itself executes nothing) and replays twice, with the new batch copied into the static input
+    before each replay -- same losses and same parameters, bit for bit."""
+    from cl_ica_amd.kitti_masks.solver import Solver
+    import tempfile
+    d = tempfile.mkdtemp()
+    args = types.SimpleNamespace(ckpt_dir=d, output_dir=d, dataset="kittimasks", cuda=True, max_iter=1, z_dim=5, num_channel=1,
+                                 lr=1e-3, beta1=0.9, beta2=0.999, box_norm=True, ckpt_name="last", log_step=10, save_step=10, p=1)
+    g = torch.Generator().manual_seed(5)
+    xs = [(torch.rand(64, 1, 64, 64, generator=g) < 0.15).float().cuda() for _ in range(3)]
+    A, B = Solver(args, data_loader=None), Solver(args, data_loader=None)
+    fill_formula(A.net, conv_formula); fill_formula(B.net, conv_formula)
+    eager = [A.train_iteration(xs[0]).item() for _ in range(3)] + [A.train_iteration(xs[1]).item(), A.train_iteration(xs[2]).item()]
+    x = xs[0].clone()
+    replay, loss = B.capture(x, warmup=3)
+    got = []
+    for nxt in xs[1:]:
+        x.copy_(nxt)
+        replay()
+        torch.cuda.synchronize()
+        got.append(loss.item())
+    assert got == eager[3:], (got, eager)
+    for pa, pb in zip(A.net.parameters(), B.net.parameters()):
+        assert torch.equal(pa, pb)
+
+
 def test_c5_kitti_full_batch_properties():
     """Config 5's full shape (2048 x 1 x 64 x 64 images = 1024 pairs, z_dim 5, p 1): no fp64 reference fits the test
     budget, so size-independent properties: (i) the per-item losses of a batch do not depend on the order of the pairs
