@@ -171,6 +171,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_conv16_amax": [c_f32p, c_i64, C.c_void_p, C.c_void_p],
     "clica_conv16_zero_slots": [C.c_void_p, c_i32, C.c_void_p],
     "clica_conv_k4s2_fwd_patches_amax": [c_f32p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "clica_conv16_first_fwd": [c_f32p, C.c_void_p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "clica_conv16_k4s2_fwd": [c_f32p, C.c_void_p, c_f32p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "clica_conv16_k4s2_dgrad": [c_f32p, C.c_void_p, c_f32p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32p, c_i32, c_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "clica_conv16_k4s2_wgrad_workspace_bytes": [c_i64, c_i32, c_i32, C.POINTER(c_size)],

@@ -34,6 +34,7 @@ if _ARITH not in ("f16x2", "f32"):
     raise ValueError(f"CLICA_CONV_ARITH={_ARITH!r}: 'f16x2' or 'f32'")
 _SLOTS = 256          # csrc/conv16.hip: kSlots
 _FIRST_FROM_IMAGE = os.environ.get("CLICA_CONV_FIRST", "image") != "patches"      # A/B switch for the one-channel first stage
+_FIRST_MFMA = os.environ.get("CLICA_CONV_FIRST_MFMA", "1") != "0"                  # f16x2: its forward on the matrix cores too (0: the fp32 vector-ALU kernel)
 
 
 def set_arith(name: str) -> str:
@@ -83,9 +84,9 @@ class _Buffers:
             cin = cout
         self.wpack = None                               # GEMM-layout weights of the step in flight (conv._maps order)
         # f16x2 arithmetic: maxima slots of S1, S2, S3, dO3, dO2, dO1 (float bits), packed weight pieces + scales of W2g, W3g, W4g, W2dT, W3dT, W4dT
-        self.amax = torch.zeros(6 * _SLOTS, dtype=torch.int32, device=device)
+        self.amax = torch.zeros(7 * _SLOTS, dtype=torch.int32, device=device)     # (slot array 6: the input images, first stage on the matrix cores)
         self.w16 = None
-        self.wscale = torch.ones(6, **f32)
+        self.wscale = torch.ones(7, **f32)
         self.O4 = torch.zeros((images, 5 * 5 * 64), **f32)     # last stride-2 stage's output on its 5 x 5 row grid (non-output rows stay 0)
         # first stage's weight gradient: the small-matrix streaming kernel where its shape fits (nc = 1), the grouped GEMM path otherwise
         self.ws1 = self.ws1p = None
@@ -172,10 +173,10 @@ def _maps(nc: int, device) -> dict:
     gshapes = [(shapes[0][0], 16 * nc), (32, 512), (64, 512), (64, 1024), (_FEATURES, 5 * 5 * 64)]
     g = [idx(sh) for sh in gshapes]
     unpack = [g[0].view(shapes[0][0], 4, 4, nc).permute(0, 3, 1, 2)] + [_wg_to_conv(g[l], shapes[l][0], shapes[l][1]) for l in (1, 2, 3)] + [_w5_back(g[4])]
-    pack16 = [pack[l] for l in (1, 2, 3)] + [pack[l].t().contiguous() for l in (4, 5, 6)]     # Wg as they are, Wd TRANSPOSED ([4 C][4 Cout])
+    pack16 = [pack[l] for l in (1, 2, 3)] + [pack[l].t().contiguous() for l in (4, 5, 6)] + [pack[0]]     # Wg as they are, Wd TRANSPOSED ([4 C][4 Cout]), W1g
     m = {"pack": [i32(t) for t in pack], "pack_shapes": [tuple(t.shape) for t in pack], "pack_src": pack_src,
          "unpack": [i32(t) for t in unpack], "shapes": shapes,
-         "pack16": [i32(t) for t in pack16], "pack16_shapes": [tuple(t.shape) for t in pack16], "pack16_src": [1, 2, 3, 1, 2, 3]}
+         "pack16": [i32(t) for t in pack16], "pack16_shapes": [tuple(t.shape) for t in pack16], "pack16_src": [1, 2, 3, 1, 2, 3, 0]}
     _MAPS[key] = m
     return m
 
@@ -193,7 +194,7 @@ def _pack16(buf: "_Buffers", ws_, m: dict) -> None:
     dev = buf.amax.device
     if buf.w16 is None:
         buf.w16 = [torch.empty(2 * sh[0] * sh[1], dtype=torch.int16, device=dev) for sh in m["pack16_shapes"]]
-    n = 6
+    n = len(m["pack16_src"])
     srcs = [ws_[i].detach() for i in m["pack16_src"]]
     srcs = [t if t.is_contiguous() else t.contiguous() for t in srcs]
     VP, I32 = C.c_void_p * n, C.c_int32 * n
@@ -227,13 +228,21 @@ class _ConvStackFn(torch.autograd.Function):
         f16 = _ARITH == "f16x2"
         if f16:
             _gather([srcs[0], srcs[7]], [m["pack"][0], m["pack"][7]], [buf.wpack[0], buf.wpack[7]])     # the two fp32 stages' weights
-            check(lib.clica_conv16_zero_slots(buf.amax.data_ptr(), 6, st), "clica_conv16_zero_slots")
+            check(lib.clica_conv16_zero_slots(buf.amax.data_ptr(), 7, st), "clica_conv16_zero_slots")
             _pack16(buf, ws_, m)
         else:
             _gather(srcs, m["pack"], buf.wpack)          # W1g, W2g, W3g, W4g, W2d, W3d, W4d, W5g in one launch
         w1g = buf.wpack[0]
         in_kernel = f16 and nc == 1        # the K = 16 masks kernel records its output's maximum itself; other first stages get a pass of their own
-        if from_image:
+        if from_image and f16 and _FIRST_MFMA:
+            # the first stage too as three fp16 matrix products (csrc/conv16.hip: fwd_first16_k); the images' own maximum gives their scale
+            if x.data_ptr() % 16:
+                x = x.clone()
+            check(lib.clica_conv16_amax(x.data_ptr(), x.numel(), _slots(buf, 6), st), "clica_conv16_amax")
+            check(lib.clica_conv16_first_fwd(x.data_ptr(), buf.w16[6].data_ptr(), buf.wscale.data_ptr() + 4 * 6, ptr(bs_[0].detach()), images, _IMAGE, _IMAGE,
+                                             STAGES[0][0], 1, buf.S[1].data_ptr(), buf.gate[0].data_ptr(), _slots(buf, 6), _slots(buf, 0), st),
+                  "clica_conv16_first_fwd")
+        elif from_image:
             check(lib.clica_conv_k4s2_fwd_image(x.data_ptr(), w1g.data_ptr(), ptr(bs_[0].detach()), images, _IMAGE, _IMAGE, STAGES[0][0], 1,
                                                 buf.S[1].data_ptr(), buf.gate[0].data_ptr(), _slots(buf, 0) if in_kernel else None, st),
                   "clica_conv_k4s2_fwd_image")

@@ -599,6 +599,96 @@ static bool stream16_fits(const GArgs& a, int& nbn, int& nsplit) {
   }
   return false;
 }
+// ---- first stage (one input channel, K = 16) on the matrix cores ---------------------------------------------------------------
+// 1 -> 32 channels, k = 4, stride 2: a [pixels x 16] x [16 x 32] product, one 16-deep matrix step.  On the vector ALUs (linear.hip:
+// conv_fwd_image_valu_k) the stage is instruction-bound -- 230 vector instructions per 16 pixels, 64 of them FMAs; 90 us with its stores
+// switched off, 126 with them -- so it runs here as the same three fp16 products as the other stages: a wave takes 32 consecutive output
+// pixels, lane (pixel, h) fetches window rows 2h, 2h + 1 of its pixel straight from the image (the A fragment: k = 8h .. 8h + 7 =
+// (ky, kx)), splits them in registers; the packed weights are 8 registers for the whole kernel; the epilogue is the other stages'
+// (bias + ReLU + scatter into the next stage's input + gate word + maximum).  ~6 vector instructions per pixel instead of 14.
+__global__ __launch_bounds__(256) void fwd_first16_k(const float* __restrict__ X, const half_t* __restrict__ W16, const float* __restrict__ wscale,
+                                                      const float* __restrict__ bias, int64_t pixels, int H, int Wd, int relu, float* __restrict__ out,
+                                                      unsigned* __restrict__ gate_out, const unsigned* __restrict__ amax_in, unsigned* __restrict__ amax_out) {
+  __shared__ unsigned s_word;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+  const int ho = H / 2, wo = Wd / 2, dhs = ho / 2 + 1, dws = wo / 2 + 1;
+  const float sX = tensor_scale(amax_in, &s_word);
+  const float cs = 1.f / (sX * *wscale);
+  const u32x4 bhi = *reinterpret_cast<const u32x4*>(W16 + l31 * 16 + 8 * h);
+  const u32x4 blo = *reinterpret_cast<const u32x4*>(W16 + 32 * 16 + l31 * 16 + 8 * h);
+  const float bv = bias ? bias[l31] : 0.f;
+  const float inv_pix = 1.f / (float)(ho * wo), inv_wo = 1.f / (float)wo;
+  const int64_t ntiles = (pixels + 31) / 32;
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  float4 q0, q1;
+  int py = 0, px = 0, myoff = -1, mypix = 0;
+  auto fetch = [&](int64_t tile) {
+    const int64_t p = tile * 32 + l31;
+    const int pc = (int)min(p, pixels - 1);
+    int img = (int)((float)pc * inv_pix);
+    int rem = pc - img * (ho * wo);
+    if (rem < 0) { --img; rem += ho * wo; } else if (rem >= ho * wo) { ++img; rem -= ho * wo; }
+    int y = (int)((float)rem * inv_wo), x = rem - y * wo;
+    if (x < 0) { --y; x += wo; } else if (x >= wo) { ++y; x -= wo; }
+    py = y; px = x; mypix = pc;
+    const int Y = (y + 1) >> 1, Xs = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
+    myoff = p < pixels ? ((img * dhs + Y) * dws + Xs) * 128 + qq * 32 : -1;
+    const float* ximg = X + (int64_t)img * H * Wd;
+    const int wy = 2 * y - 1 + 2 * h;
+    // raw loads only (clamped addresses): masked at use
+    {
+      const int yc = min(max(wy, 0), H - 1);
+      const float* rowp = ximg + (int64_t)yc * Wd + 2 * x;
+      const float l = rowp[x > 0 ? -1 : 0];
+      const float2 m = *reinterpret_cast<const float2*>(rowp);
+      const float r = rowp[2 * x + 2 < Wd ? 2 : 0];
+      q0 = make_float4(l, m.x, m.y, r);
+    }
+    {
+      const int yc = min(max(wy + 1, 0), H - 1);
+      const float* rowp = ximg + (int64_t)yc * Wd + 2 * x;
+      const float l = rowp[x > 0 ? -1 : 0];
+      const float2 m = *reinterpret_cast<const float2*>(rowp);
+      const float r = rowp[2 * x + 2 < Wd ? 2 : 0];
+      q1 = make_float4(l, m.x, m.y, r);
+    }
+  };
+  float amax = 0.f;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tstride) {
+    const int wy = 2 * py - 1 + 2 * h;
+    const bool lin = px > 0, rgt = 2 * px + 2 < Wd, r0 = wy >= 0 && wy < H, r1 = wy + 1 >= 0 && wy + 1 < H;
+    const float4 a0 = make_float4((r0 && lin) ? q0.x : 0.f, r0 ? q0.y : 0.f, r0 ? q0.z : 0.f, (r0 && rgt) ? q0.w : 0.f);
+    const float4 a1 = make_float4((r1 && lin) ? q1.x : 0.f, r1 ? q1.y : 0.f, r1 ? q1.z : 0.f, (r1 && rgt) ? q1.w : 0.f);
+    u32x2 h0, l0, h1, l1;
+    split4(a0, sX, h0, l0);
+    split4(a1, sX, h1, l1);
+    const u32x4 ahi = {h0.x, h0.y, h1.x, h1.y}, alo = {l0.x, l0.y, l1.x, l1.y};
+    const int off_mine = myoff, pix_mine = mypix;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = mfma(alo, bhi, acc);
+    acc = mfma(ahi, blo, acc);
+    acc = mfma(ahi, bhi, acc);
+    if (tile + tstride < ntiles) fetch(tile + tstride);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;          // row of the block = pixel i of the tile; its lane (i, any h) holds the offsets
+      const int off = __shfl(off_mine, i, 64), pixg = __shfl(pix_mine, i, 64);
+      float v = acc[r] * cs + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      const unsigned long long bits = __ballot(v > 0.f);
+      if (off < 0) continue;
+      out[off + l31] = v;
+      amax = fmaxf(amax, fabsf(v));
+      if (gate_out && l31 == 0) gate_out[pixg] = (unsigned)(bits >> (32 * h));
+    }
+  }
+  commit_amax(amax_out, amax, blockIdx.x * 4 + wave);
+}
+
 // ---- forward of a 16-pixel-wide stage with 32 -> 32 channels from IMAGE TILES in LDS ---------------------------------------------
 // In the streaming kernel every output pixel fetches its own 2 x 2 window of S pixels: 1.07 GB requested through the L1 for the 303 MB
 // of the widest stage's input, the waves wait 0.68 of their cycles on the vector-memory path (148 us).  Here a workgroup takes 8 output
@@ -1107,4 +1197,18 @@ extern "C" int clica_conv16_k4s2_wgrad(const float* dO, const float* S, int64_t 
   if (rc) return rc;
   launch_slab_sum(a.slab, Cout * K, dWg, a.dbslab, (int)Cout, db, p.splits, accumulate ? 1 : 0, st);
   return launch_status("clica_conv16_k4s2_wgrad(reduce)");
+}
+
+extern "C" int clica_conv16_first_fwd(const float* x, const uint16_t* W16, const float* wscale, const float* bias, int64_t images, int32_t H, int32_t W,
+                                      int32_t Cout, int32_t relu, float* out, uint32_t* gate_bits, const uint32_t* amax_in, uint32_t* amax_out,
+                                      clica_stream_t stream) {
+  CLICA_CHECK_ARG(x && W16 && wscale && out && images > 0 && H >= 4 && W >= 4 && H % 4 == 0 && W % 4 == 0 && Cout == 32,
+                  "clica_conv16_first_fwd: bad argument (one input channel, Cout = 32, H and W multiples of 4)");
+  CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7) == 0 && aligned16(W16), "clica_conv16_first_fwd: x must be 8-byte, the packed weights 16-byte aligned");
+  const int64_t pixels = images * (H / 2) * (W / 2);
+  CLICA_CHECK_ARG(pixels < (1 << 24), "clica_conv16_first_fwd: %lld output pixels (< 2^24 supported)", (long long)pixels);
+  const int64_t tiles = ceil_div(pixels, 32);
+  hipLaunchKernelGGL(fwd_first16_k, dim3((unsigned)std::min<int64_t>(ceil_div(tiles, 4), 8 * kNumCU)), dim3(256), 0, as_stream(stream), x, W16, wscale, bias,
+                     pixels, (int)H, (int)W, (int)relu, out, gate_bits, amax_in, amax_out);
+  return launch_status("clica_conv16_first_fwd");
 }

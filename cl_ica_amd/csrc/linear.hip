@@ -1943,7 +1943,8 @@ __device__ __forceinline__ void pixel_decode(unsigned pixel, int ho, int wo, int
 }
 __global__ __launch_bounds__(256) void conv_fwd_image_valu_k(const float* __restrict__ X, const float* __restrict__ Wg, const float* __restrict__ bias,
                                                               unsigned pixels, int Cout, int H, int W, int ho_shift, int wo_shift, int relu,
-                                                              float* __restrict__ out, unsigned* __restrict__ gate_out, unsigned* __restrict__ amax_slots) {
+                                                              float* __restrict__ out, unsigned* __restrict__ gate_out, unsigned* __restrict__ amax_slots,
+                                                              int ablate) {
   constexpr int K = 16;
   const int ho = H / 2, wo = W / 2;
   const int groups = Cout / 8;                          // threads per pixel
@@ -2019,9 +2020,9 @@ __global__ __launch_bounds__(256) void conv_fwd_image_valu_k(const float* __rest
       const int p2 = hh * 8 + (lane >> 3);
       const float4 v = *reinterpret_cast<const float4*>(stage + ((threadIdx.x >> 6) * 16 + p2) * 36 + 4 * (lane & 7));
       const int off = __shfl(myoff, 4 * p2, 64);
-      if (off >= 0) *reinterpret_cast<float4*>(out + off + 4 * (lane & 7)) = v;
+      if (off >= 0 && !(ablate & 1)) *reinterpret_cast<float4*>(out + off + 4 * (lane & 7)) = v;
     }
-    if (gate_out && valid) {
+    if (gate_out && valid && !(ablate & 2)) {
       unsigned bits = 0;
 #pragma unroll
       for (int c = 0; c < 8; ++c) bits |= (o[c] > 0.f ? 1u : 0u) << chan(c);
@@ -2318,8 +2319,9 @@ extern "C" int clica_conv_k4s2_fwd_image(const float* x, const float* Wg, const 
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7) == 0 && aligned16(out), "clica_conv_k4s2_fwd_image: x must be 8-byte, out 16-byte aligned");
   const int64_t pixels = images * (H / 2) * (W / 2);
   CLICA_CHECK_ARG(pixels < ((int64_t)1 << 31), "clica_conv_k4s2_fwd_image: %lld output pixels (< 2^31 supported)", (long long)pixels);
+  static const int ablate = [] { const char* e = getenv("CLICA_FWD_IMAGE_ABLATE"); return e ? atoi(e) : 0; }();      // timing ablations (WRONG results): 1 no output stores, 2 no gate words
   hipLaunchKernelGGL(conv_fwd_image_valu_k, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), x, Wg, bias, (unsigned)pixels, (int)Cout,
-                     (int)H, (int)W, shift_of(H / 2), shift_of(W / 2), (int)relu, out, gate_bits, amax_slots);
+                     (int)H, (int)W, shift_of(H / 2), shift_of(W / 2), (int)relu, out, gate_bits, amax_slots, ablate);
   return launch_status("clica_conv_k4s2_fwd_image");
 }
 

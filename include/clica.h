@@ -575,6 +575,11 @@ int clica_conv16_zero_slots(uint32_t* slots, int32_t tensors, clica_stream_t str
 int clica_conv_k4s2_fwd_patches_amax(const float* patches, const float* Wg, const float* bias, int64_t images, int32_t K,
                                      int32_t Cout, int32_t ho, int32_t wo, int32_t relu, int32_t scatter, float* out,
                                      uint32_t* gate_bits, uint32_t* amax_slots, clica_stream_t stream);
+/* First stage for ONE input channel in the same arithmetic: x [images][1][H][W] -> the next stage's S (scatter = 1), W16 = packed
+ * [Cout = 32][16] in the patch-matrix order (ky * 4 + kx), amax_in = maximum slots of x (clica_conv16_amax), amax_out = those of S. */
+int clica_conv16_first_fwd(const float* x, const uint16_t* W16, const float* wscale, const float* bias, int64_t images, int32_t H, int32_t W,
+                           int32_t Cout, int32_t relu, float* out, uint32_t* gate_bits, const uint32_t* amax_in, uint32_t* amax_out,
+                           clica_stream_t stream);
 int clica_conv16_k4s2_fwd(const float* S, const uint16_t* Wg16, const float* wscale, const float* bias, int64_t images, int32_t C,
                           int32_t Cout, int32_t hs, int32_t ws, int32_t relu, int32_t scatter, float* out, uint32_t* gate_bits,
                           const uint32_t* amax_in, uint32_t* amax_out, clica_stream_t stream);

@@ -224,9 +224,10 @@ def test_conv_stack_buffers_are_reusable_and_switchable(monkeypatch):
     monkeypatch.setattr(conv, "_FIRST_FROM_IMAGE", False)
     conv._POOL.clear()
     fb2, gb2 = _run_hip(xb, convs, d)
-    assert torch.equal(fb0, fb2)
+    # (f32 arithmetic: same products in the same order, identical features; f16x2: the image-fed first stage runs on the matrix cores)
+    assert torch.equal(fb0, fb2) if conv.get_arith() == "f32" else float((fb0 - fb2).abs().max()) <= 2e-6 * float(fb0.abs().max())
     for a, b in zip(gb0, gb2):
-        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())
+        assert float((a - b).abs().max()) <= (1e-6 if conv.get_arith() == "f32" else 1e-5) * float(a.abs().max())
     monkeypatch.setattr(conv, "_FIRST_FROM_IMAGE", True)
     conv._POOL.clear()
     net = BetaVAE_H(z_dim=5, nc=1, box_norm=True).to("cuda")
