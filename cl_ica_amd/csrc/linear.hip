@@ -2121,6 +2121,90 @@ __global__ __launch_bounds__(256) void conv_wgrad_image_k(const float* __restric
   }
 }
 
+// The same weight gradient for Cout = 32 on the fp32 matrix cores (round 5, last session).  The vector-ALU kernel above is
+// instruction-bound like the forward was (16 threads x ~65 instructions per output pixel: ~63 us of issue for the 2048-mask batch, 102 us
+// measured against ~60 us for its 268 MB of dO at the rate the other streaming kernels reach).  dWg[co][k] = sum_pixel dO[pixel][co] x
+// window(pixel)[k] is a [32 x pixels] x [pixels x 16] product: v_mfma_f32_16x16x4_f32 contracts FOUR pixels per instruction -- exact fp32
+// products, fp32 accumulation: no split, no scales -- and both operands are one register per lane straight from memory:
+//   A[i][kq]: lane (i = l & 15, kq = l >> 4) loads the float2 dO[pixel + kq][2 i, 2 i + 1] (the 16 lanes of a pixel cover its whole 128-byte
+//             row); the .x values are the A operand of the even channels' instruction, the .y values of the odd channels'
+//   B[kq][j]: lane (j = l & 15 = (ky, kx), kq) loads window value (ky, kx) of pixel + kq from the image (L1 / L2 resident), zero outside
+// i.e. ~25 vector instructions per FOUR pixels and wave instead of ~1 000 lane-instructions per pixel.  A wave walks over runs of 32 pixels
+// (eight steps, the next run's loads in flight under this run's instructions), the four waves of a workgroup meet through LDS; slab
+// format and reduction are the vector-ALU kernel's.  db: the lanes add what they load, the four kq lanes of a channel pair meet by shuffles.
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv_wgrad_image_mfma_k(const float* __restrict__ dO, const float* __restrict__ X, int64_t rows, int H, int W,
+                                                                int ho_shift, int wo_shift, int64_t rows_per_block, float* __restrict__ slab,
+                                                                float* __restrict__ dbslab) {
+  constexpr int Cout = 32, K = 16, U = 8, PER = Cout * K + Cout;
+  __shared__ float red[4][PER];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4, ky = i >> 2, kx = i & 3;
+  const int ho = H / 2, wo = W / 2;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  struct Run { float2 a[U]; float b[U]; unsigned mask; };      // mask: bit u = pixel inside the block's rows, bit 8 + u = window tap inside the image
+  auto fetch = [&](Run& R, int64_t base) {
+    R.mask = 0u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t pixel = base + 4 * u + kq;
+      const bool ok = pixel < r1;
+      const int64_t pc = ok ? pixel : r1 - 1;
+      R.a[u] = *reinterpret_cast<const float2*>(dO + pc * Cout + 2 * i);
+      unsigned img, oy, ox;
+      pixel_decode((unsigned)pc, ho, wo, ho_shift, wo_shift, img, oy, ox);
+      const int yy = 2 * (int)oy - 1 + ky, xx = 2 * (int)ox - 1 + kx;
+      const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+      R.b[u] = X[(int64_t)img * H * W + yc * W + xc];
+      R.mask |= (ok ? 1u : 0u) << u;
+      R.mask |= ((yy == yc && xx == xc) ? 1u : 0u) << (8 + u);
+    }
+  };
+  f32x4w acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float bs0 = 0.f, bs1 = 0.f;
+  auto consume = [&](const Run& R) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool oka = (R.mask >> u) & 1u, okb = (R.mask >> (8 + u)) & 1u;
+      const float ax = oka ? R.a[u].x : 0.f, ay = oka ? R.a[u].y : 0.f, bv = okb ? R.b[u] : 0.f;
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, bv, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ay, bv, acc1, 0, 0, 0);
+      bs0 += ax; bs1 += ay;
+    }
+  };
+  constexpr int RUN = 4 * U;                           // pixels per run
+  Run Ra, Rb;
+  int64_t base = r0 + (int64_t)wave * RUN;
+  if (base < r1) fetch(Ra, base);
+  for (; base < r1; base += 8 * RUN) {                 // (four waves x two runs per turn)
+    const int64_t nb = base + 4 * RUN, nn = base + 8 * RUN;
+    if (nb < r1) fetch(Rb, nb);
+    consume(Ra);
+    if (nb < r1) {
+      if (nn < r1) fetch(Ra, nn);
+      consume(Rb);
+    }
+  }
+  // the four kq lanes of a channel pair
+  bs0 += __shfl_xor(bs0, 16, 64); bs1 += __shfl_xor(bs1, 16, 64);
+  bs0 += __shfl_xor(bs0, 32, 64); bs1 += __shfl_xor(bs1, 32, 64);
+  // D[row = 4 kq + r][col = i]: row = channel pair, col = window index
+  float* mine = red[wave];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cp = 4 * kq + r;
+    mine[(2 * cp) * K + i] = acc0[r];
+    mine[(2 * cp + 1) * K + i] = acc1[r];
+  }
+  if (kq == 0) { mine[Cout * K + 2 * i] = bs0; mine[Cout * K + 2 * i + 1] = bs1; }
+  __syncthreads();
+  for (int e = threadIdx.x; e < PER; e += 256) {
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    if (e < Cout * K) slab[(int64_t)blockIdx.x * Cout * K + e] = v;
+    else if (dbslab) dbslab[(int64_t)blockIdx.x * Cout + (e - Cout * K)] = v;
+  }
+}
+
 // Weight re-ordering between nn.Conv2d's [co][c][ky][kx] and the GEMM layouts (forward rows, data-gradient rows, the zero-padded rows of
 // the 4 x 4 stage) and back for the gradients: up to MAXG index-mapped copies in ONE launch, dst[e] = map[e] >= 0 ? src[map[e]] : 0.
 // The maps are permutations the host builds once per shape (cl_ica_amd/conv.py applies its layout functions to an index tensor).
@@ -2342,8 +2426,13 @@ extern "C" int clica_conv_k4s2_wgrad_image(const float* dO, const float* x, int6
   float* dbslab = (float*)((char*)workspace + slab_bytes);
   hipStream_t st = as_stream(stream);
   const size_t lds = (size_t)4 * (Cout * K + Cout) * sizeof(float);
-  hipLaunchKernelGGL(conv_wgrad_image_k, dim3((unsigned)p.blocks), dim3(256), lds, st, dO, x, rows, (int)Cout, (int)H, (int)W, shift_of(H / 2), shift_of(W / 2),
-                     p.rows_per_block, slab, db ? dbslab : (float*)nullptr);
+  static const int valu = [] { const char* e = getenv("CLICA_WGRAD_IMAGE"); return (e && e[0] == 'v') ? 1 : 0; }();      // A/B switch: CLICA_WGRAD_IMAGE=valu keeps the vector-ALU kernel
+  if (Cout == 32 && !valu)
+    hipLaunchKernelGGL(conv_wgrad_image_mfma_k, dim3((unsigned)p.blocks), dim3(256), 0, st, dO, x, rows, (int)H, (int)W, shift_of(H / 2), shift_of(W / 2),
+                       p.rows_per_block, slab, db ? dbslab : (float*)nullptr);
+  else
+    hipLaunchKernelGGL(conv_wgrad_image_k, dim3((unsigned)p.blocks), dim3(256), lds, st, dO, x, rows, (int)Cout, (int)H, (int)W, shift_of(H / 2), shift_of(W / 2),
+                       p.rows_per_block, slab, db ? dbslab : (float*)nullptr);
   int rc = launch_status("clica_conv_k4s2_wgrad_image");
   if (rc) return rc;
   if ((Cout * K) % 4 == 0 && Cout % 4 == 0 && aligned16(dWg) && (!db || aligned16(db)))
