@@ -174,6 +174,9 @@ struct GArgs {
   unsigned* gate_out; const unsigned* gate_in;
   Geo g;
 };
+#ifndef STREAM16_ABLATE
+#define STREAM16_ABLATE 0      // measurement builds only (make EXTRA=-DSTREAM16_ABLATE=k, WRONG results): 1 = no stores, 2 = no matrix products in the data gradient
+#endif                         // (round 5, 2048-mask batch: 155 us as built, 127 without stores, 144 without products, 108 without both)
 
 __device__ __forceinline__ void row_to_pixel(const Geo& g, int row, int& img, int& y, int& x) {      // rows < 2^24: exact in fp32
   const int pix = g.hs * g.ws;
@@ -462,48 +465,16 @@ __global__ __launch_bounds__(ST_THREADS, NBN == 1 ? 4 : 2) void stream16_k(GArgs
   };
   int tile = wg * WAVES + wave;
   if (tile < ntiles) { pa = row_ptr(tile); lda(0, 0); lda(1, 1); lda(2, 2); }
+  constexpr int PP = (16 * NBN + 31) / 32;
   for (; tile < ntiles; tile += nwg * WAVES) {
     f32x16 acc[NBN];
 #pragma unroll
     for (int j = 0; j < NBN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-    for (int b0 = 0; b0 < NB; b0 += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int blk = b0 + u;
-        if (blk + 3 < NB) lda(blk + 3, (u + 3) & 3);
-        const int kb = k_of(blk);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-          u32x2 h0, l0, h1, l1;
-          split4(q[u][2 * sub], sA, h0, l0);
-          split4(q[u][2 * sub + 1], sA, h1, l1);
-          const u32x4 ahi = {h0.x, h0.y, h1.x, h1.y}, alo = {l0.x, l0.y, l1.x, l1.y};
-#pragma unroll
-          for (int j = 0; j < NBN; ++j) {
-            const half_t* pb = bbase + j * 32 * LDB + kb + 8 * sub;
-            const u32x4 bhi = *reinterpret_cast<const u32x4*>(pb);
-            const u32x4 blo = *reinterpret_cast<const u32x4*>(pb + planeB);
-            acc[j] = mfma(alo, bhi, acc[j]);
-            acc[j] = mfma(ahi, blo, acc[j]);
-            acc[j] = mfma(ahi, bhi, acc[j]);
-          }
-        }
-      }
-    }
-    // the next tile's first loads go out before this tile's epilogue (their latency hides under the stores)
     const int next = tile + nwg * WAVES;
-    if (next < ntiles) { pa = row_ptr(next); lda(0, 0); lda(1, 1); lda(2, 2); }
-
-    // ---- epilogue of the wave's 32 x NC block.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The index
-    // arithmetic (row -> pixel -> destination, and the data gradient's gate words) is done ONCE per (row, column block) pair by one lane
-    // of the half-wave that owns the row and handed round by shuffles: every gate word of the tile is requested before the first store,
-    // one memory round trip per tile.  (Per lane and row, with a gate load in front of each group of stores: a chain of sixteen round
-    // trips per tile -- 112 us per data-gradient launch.)
-    if (g.mode == 2) {
-      constexpr int PP = (16 * NBN + 31) / 32;
-      int mypix[PP]; unsigned myword[PP];
+    int mypix[PP]; unsigned myword[PP];                    // data gradient: destination offsets and gate words of this tile's rows
+    auto gate_request = [&]() {
 #pragma unroll
       for (int pi = 0; pi < PP; ++pi) {
         const int p = l31 + 32 * pi, r = p & 15, j = p >> 4;
@@ -515,23 +486,81 @@ __global__ __launch_bounds__(ST_THREADS, NBN == 1 ? 4 : 2) void stream16_k(GArgs
           row_to_pixel(g, orow, img, y, x);
           const int yy = 2 * y + (qd >> 1) - 1, xx = 2 * x + (qd & 1) - 1;
           if (yy >= 0 && xx >= 0 && yy < g.dho && xx < g.dwo) {
-            mypix[pi] = (img * g.dhs + yy) * g.dws + xx;
-            myword[pi] = a.gate_in[(int64_t)mypix[pi] * (g.c >> 5) + cw];
+            const int pix = (img * g.dhs + yy) * g.dws + xx;
+            myword[pi] = a.gate_in[(int64_t)pix * (g.c >> 5) + cw];
+            mypix[pi] = pix * g.c;                          // element offset of the pixel's channel row (< 2^31: checked at launch)
           }
         }
       }
+    };
+    for (int b0 = 0; b0 < NB; b0 += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int blk = b0 + u;
+        if (blk + 3 < NB) lda(blk + 3, (u + 3) & 3);
+        const int kb = k_of(blk);
+        auto products = [&](int sub, const u32x4 ahi, const u32x4 alo) {
+#if STREAM16_ABLATE & 2
+          if (g.mode == 2) { acc[0][0] += __uint_as_float((ahi.x ^ alo.y) & 1u); return; }
+#endif
+#pragma unroll
+          for (int j = 0; j < NBN; ++j) {
+            const half_t* pb = bbase + j * 32 * LDB + kb + 8 * sub;
+            const u32x4 bhi = *reinterpret_cast<const u32x4*>(pb);
+            const u32x4 blo = *reinterpret_cast<const u32x4*>(pb + planeB);
+            acc[j] = mfma(alo, bhi, acc[j]);
+            acc[j] = mfma(ahi, blo, acc[j]);
+            acc[j] = mfma(ahi, bhi, acc[j]);
+          }
+        };
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+          u32x2 h0, l0, h1, l1;
+          split4(q[u][2 * sub], sA, h0, l0);
+          split4(q[u][2 * sub + 1], sA, h1, l1);
+          products(sub, (u32x4){h0.x, h0.y, h1.x, h1.y}, (u32x4){l0.x, l0.y, l1.x, l1.y});
+        }
+      }
+    }
+    // the next tile's first loads go out before this tile's epilogue (their latency hides under the stores)
+    if (next < ntiles) { pa = row_ptr(next); lda(0, 0); lda(1, 1); lda(2, 2); }
+
+    // ---- epilogue of the wave's 32 x NC block.  C/D layout: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5).  The index
+    // arithmetic (row -> pixel -> destination, and the data gradient's gate words) is done ONCE per (row, column block) pair by one lane
+    // of the half-wave that owns the row and handed round by shuffles: every gate word of the tile is requested before the first store,
+    // one memory round trip per tile.  (Per lane and row, with a gate load in front of each group of stores: a chain of sixteen round
+    // trips per tile -- 112 us per data-gradient launch.)
+    if (g.mode == 2) {
+      gate_request();
+#pragma unroll
+      for (int pi = 0; pi < PP; ++pi) asm volatile("" ::"v"(myword[pi]));      // (one wait, outside the row loop's divergent control flow)
+      // The offsets / gate words of a column block's sixteen rows are fetched from their owner lanes EIGHT AT A TIME before the first of
+      // their stores (one shuffle pair and its LDS round trip in front of each store before), offsets are 32-bit element indices (one add
+      // per row instead of a 64-bit multiply-add).  Measured: the data-gradient launches do not move (131 / 63 / 44 us: with stores AND
+      // matrix products compiled out -- STREAM16_ABLATE=3 -- the widest one still takes 0.7 of its time: it waits on its operand loads
+      // with two waves per SIMD), the forward launches 60.8 -> 55 us with the bias fix below.
 #pragma unroll
       for (int j = 0; j < NBN; ++j) {
         const int col0 = n_off + 32 * j, ch = col0 % g.c + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int p = 16 * j + r, src = (p & 31) + 32 * h;
-          const int pix = __shfl(mypix[p >> 5], src, 64);
-          const unsigned word = (unsigned)__shfl((int)myword[p >> 5], src, 64);
-          if (pix < 0) continue;
-          const float v = ((word >> l31) & 1u) ? acc[j][r] * cs : 0.f;
-          a.C[(int64_t)pix * g.c + ch] = v;
-          amax = fmaxf(amax, fabsf(v));
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+          int po[8]; unsigned wd[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int p = 16 * j + r0 + i, src = (p & 31) + 32 * h;
+            po[i] = __shfl(mypix[p >> 5], src, 64);
+            wd[i] = (unsigned)__shfl((int)myword[p >> 5], src, 64);
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (po[i] < 0) continue;
+            const float v = ((wd[i] >> l31) & 1u) ? acc[j][r0 + i] * cs : 0.f;
+#if STREAM16_ABLATE & 1
+            if (v != 12345.678f) continue;
+#endif
+            a.C[(unsigned)(po[i] + ch)] = v;
+            amax = fmaxf(amax, fabsf(v));
+          }
         }
       }
     } else {
@@ -547,26 +576,38 @@ __global__ __launch_bounds__(ST_THREADS, NBN == 1 ? 4 : 2) void stream16_k(GArgs
           } else {
             const int Y = (y + 1) >> 1, X = (x + 1) >> 1, qq = ((y + 1) & 1) * 2 + ((x + 1) & 1);
             myoff = ((img * g.dhs + Y) * g.dws + X) * (4 * g.c) + qq * g.c;
-            mygrow = (img * g.ghs + y) * g.gws + x;
+            mygrow = ((img * g.ghs + y) * g.gws + x) * (a.N >> 5);
           }
         }
       }
+      const bool gates = g.mode == 1 && a.gate_out;
 #pragma unroll
       for (int j = 0; j < NBN; ++j) {
         const int col = n_off + j * 32 + l31;
         const float bv = a.bias ? a.bias[col] : 0.f;
+        // consumed HERE, in uniform control flow: first used inside the row loop's `off < 0` branches, the compiler repeated the wait for
+        // this load in front of every row -- a vmcnt(0) that also waited for the previous row's STORES: 16 serialised store round trips
+        // per column block and tile
+        asm volatile("" ::"v"(bv));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int off = __shfl(myoff, r + 32 * h, 64);
-          if (off < 0) continue;
-          float v = acc[j][r] * cs + bv;
-          if (a.relu) v = v > 0.f ? v : 0.f;
-          a.C[(int64_t)off + col] = v;
-          amax = fmaxf(amax, fabsf(v));
-          if (g.mode == 1 && a.gate_out) {
-            const int grow = __shfl(mygrow, r + 32 * h, 64);
-            const unsigned long long bits = __ballot(v > 0.f);
-            if (l31 == 0) a.gate_out[(int64_t)grow * (a.N >> 5) + (col >> 5)] = (unsigned)(bits >> (32 * h));
+        for (int r0 = 0; r0 < 16; r0 += 8) {
+          int po[8], gr[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            po[i] = __shfl(myoff, r0 + i + 32 * h, 64);
+            gr[i] = gates ? __shfl(mygrow, r0 + i + 32 * h, 64) : 0;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (po[i] < 0) continue;
+            float v = acc[j][r0 + i] * cs + bv;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            a.C[(unsigned)(po[i] + col)] = v;
+            amax = fmaxf(amax, fabsf(v));
+            if (gates) {
+              const unsigned long long bits = __ballot(v > 0.f);
+              if (l31 == 0) a.gate_out[(unsigned)(gr[i] + (col >> 5))] = (unsigned)(bits >> (32 * h));
+            }
           }
         }
       }
@@ -1126,6 +1167,8 @@ extern "C" int clica_conv16_k4s2_fwd(const float* S, const uint16_t* Wg16, const
   a.M = images * ho * wo; a.N = Cout; a.K = 16 * C;
   a.gate_out = gate_bits;
   CLICA_CHECK_ARG(a.M < (1 << 24), "clica_conv16_k4s2_fwd: %lld rows (< 2^24 supported)", (long long)a.M);
+  CLICA_CHECK_ARG(a.M * Cout < ((int64_t)1 << 30), "clica_conv16_k4s2_fwd: %lld output elements (< 2^30 supported: 32-bit offsets into the padded destination)",
+                  (long long)(a.M * Cout));
   Geo& g = a.g;
   g.mode = scatter == 1 ? 1 : 3;
   g.hs = ho; g.ws = wo; g.ghs = hs; g.gws = ws; g.dhs = ho / 2 + 1; g.dws = wo / 2 + 1; g.dho = g.dwo = 0; g.c = Cout;
@@ -1147,6 +1190,8 @@ extern "C" int clica_conv16_k4s2_dgrad(const float* dO, const uint16_t* WdT16, c
   a.M = images * hs * ws; a.N = 4 * C; a.K = 4 * Cout;
   a.gate_in = gate_bits;
   CLICA_CHECK_ARG(a.M < (1 << 24), "clica_conv16_k4s2_dgrad: %lld rows (< 2^24 supported)", (long long)a.M);
+  CLICA_CHECK_ARG(images * dhs * dws * C < ((int64_t)1 << 31), "clica_conv16_k4s2_dgrad: %lld destination elements (< 2^31 supported: 32-bit offsets)",
+                  (long long)(images * dhs * dws * C));
   Geo& g = a.g;
   g.mode = 2; g.hs = hs; g.ws = ws; g.ghs = hs; g.gws = ws; g.dhs = dhs; g.dws = dws; g.dho = 2 * (hs - 1); g.dwo = 2 * (ws - 1); g.c = C;
   g.inv_pix = 1.f / (float)(hs * ws); g.inv_ws = 1.f / (float)ws;
