@@ -320,6 +320,10 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
       if (col >= g.N) continue;
       float bv = 0.f;
       if (EPI == EPI_BIAS_ACT && g.bias) bv = g.bias[col];
+      // consumed HERE, in uniform control flow: first used inside the row loops' bounds branches, the compiler repeated the wait for this
+      // load -- a vmcnt(0), which also waits for every store issued so far -- in front of EVERY row's store (found in the disassembly of
+      // conv16's streaming kernel, round 5: all 64 stores of this epilogue were preceded by one)
+      asm volatile("" ::"v"(bv));
       if (CONV && cx.mode != 0) {
         // scattering epilogues of the convolutions: the GEMM row is a pixel of a (hs x ws) grid per image.  Two passes: destination
         // offsets and (mode 2) the gate values of all 16 rows first -- the gate loads are then in flight together instead of one
@@ -384,6 +388,18 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
         }
         continue;
       }
+      // EPI_DACT: the sixteen activations of the block are requested together and consumed once (one load and its round trip -- plus the
+      // drain of the previous row's store -- in front of every store before)
+      float xa[16];
+      if (EPI == EPI_DACT) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          xa[r] = g.xact ? g.xact[min(row, g.M - 1) * g.ldxa + col] : 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(xa[r]));
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -393,7 +409,7 @@ __device__ __forceinline__ void gemm_body(const Args& g, const int bx, const int
           v += bv;
           if (g.leaky) v = v > 0.f ? v : v * g.slope;
         } else if (EPI == EPI_DACT) {
-          if (g.xact) v *= (g.xact[row * g.ldxa + col] > 0.f ? 1.f : g.slope);
+          v *= (xa[r] > 0.f ? 1.f : g.slope);
         }
         Cbase[row * g.ldc + col] = v;
       }
