@@ -1392,17 +1392,23 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   // features with one ds_read_b128 instead of holding them in registers across the k-loop
   float* bias_lds = reinterpret_cast<float*>(planes + NP * PLANE);
   volatile int* prog = reinterpret_cast<volatile int*>(bias_lds + a.boff[g.L]);      // k-loop progress of the eight waves (layer_gemm_split)
+#if CLICA_SPLIT_BALANCE
   if (lane == 0) prog[wave] = 0;
+#endif
+  // (prog is VOLATILE and reaches the stores as a generic pointer: every `prog[wave] = 0` was a flat_store followed by s_waitcnt vmcnt(0)
+  //  -- in the prologue a wait for every weight / bias / input request issued above it, behind each layer's epilogue a drain of the
+  //  wave's plane stores in front of the barrier.  The balance experiment is off; so are its stores.)
   unsigned* amax_lds = const_cast<unsigned*>(reinterpret_cast<volatile unsigned*>(prog)) + WAVES;      // f16x2: the workgroup's maxima, one word per tensor of the launch
   // ... and the layers' scale factors, derived ONCE here by one thread per layer (read through the scalar cache in every epilogue they
   // were two cold misses in front of the first layers' epilogues: 8.5 k cycles for a 100-wide layer against 3.3 k for the same layer later)
   float* lscale = reinterpret_cast<float*>(amax_lds + 16);          // [cmul | s_out | 1 / s_out][MAXL]
+  float sc_out = 1.f, sc_in = 1.f, sc_w = 1.f;        // requested here, turned into the layer's factors below, behind every other request
   if constexpr (AR == 1) {
     if (threadIdx.x < Split16State::NT) amax_lds[threadIdx.x] = 0u;
     if ((int)threadIdx.x < g.L) {
       const int l = threadIdx.x;
-      const float so = (l == g.L - 1 && a.last_unscaled) ? 1.f : a.s_t[l + 1];
-      lscale[l] = so / (a.s_t[l] * a.s_w[l]); lscale[MAXL + l] = so; lscale[2 * MAXL + l] = 1.f / so;
+      sc_out = (l == g.L - 1 && a.last_unscaled) ? 1.f : a.s_t[l + 1];
+      sc_in = a.s_t[l]; sc_w = a.s_w[l];
     }
   }
   constexpr int BIAS_IT = (BIAS_LDS_MAX + THREADS - 1) / THREADS;
@@ -1508,6 +1514,12 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < BIAS_IT; ++u) { const int idx = threadIdx.x + u * THREADS; if (idx < btotal) bias_lds[idx] = bv[u]; }
+    }
+  }
+  if constexpr (AR == 1) {
+    if ((int)threadIdx.x < g.L) {
+      const int l = threadIdx.x;
+      lscale[l] = sc_out / (sc_in * sc_w); lscale[MAXL + l] = sc_out; lscale[2 * MAXL + l] = 1.f / sc_out;
     }
   }
   __syncthreads();
@@ -1627,7 +1639,9 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       }
       if (q.mask_out) __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(q.mask_out), (wave * 64 + lane) * 8, 0, 0);
       amax_wave_to_lds(&amax_lds[l + 1], am, inv_s_out);
+#if CLICA_SPLIT_BALANCE
       if (lane == 0) prog[wave] = 0;
+#endif
       ST_STAMP(l, 3);
       __syncthreads();
       continue;
@@ -1657,7 +1671,9 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
           }
       }
       __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(q.mask_out), (wave * 64 + lane) * 8, 0, 0);
+#if CLICA_SPLIT_BALANCE
       if (lane == 0) prog[wave] = 0;
+#endif
       ST_STAMP(l, 3);
       __syncthreads();
       continue;
@@ -1772,7 +1788,9 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
         }
     }
     __builtin_amdgcn_raw_buffer_store_b64((u32x2){lo, hi}, mask_rsrc(ly.mask_out), mslot, 0, 0);
+#if CLICA_SPLIT_BALANCE
     if (lane == 0) prog[wave] = 0;
+#endif
     ST_STAMP(l, 3);
     __syncthreads();
   }
