@@ -6,7 +6,8 @@ fields and public attributes, ``train()`` (returns ``False``, writes ``log.csv``
 checkpoints in the ``{iter, model_states, optim_states}`` layout), ``save_checkpoint`` / ``load_checkpoint`` / ``net_mode``.
 The per-batch arithmetic (:61-74) lives in ``train_iteration``: ``mu = net(x)``, the strided views ``mu[::2]`` /
 ``mu[1::2]`` go to ``LpSimCLRLoss(p, tau=1, compat)`` without copies, negatives are the rolled first views, then
-``zero_grad / backward / step`` on the flat-arena Adam (one launch).  The convolutions are PyTorch-ROCm / MIOpen.
+``zero_grad / backward / step`` on the flat-arena Adam (one launch).  The encoder's convolutions are the hand-written stack of
+``cl_ica_amd/conv.py`` (``BetaVAE_H``); ``capture`` turns the whole iteration into one HIP graph.
 
 Data parallel (BASELINE.json configs[4]: "DDP over 4 x MI355X"; the reference itself has none): with an initialised
 ``torch.distributed`` group of world > 1 every rank encodes its own batch, the negatives pool is the autograd-aware
@@ -30,6 +31,25 @@ from .model import BetaVAE_H
 __all__ = ["Solver"]
 
 _MILESTONE = 50000          # iterations between numbered checkpoints (solver.py:86-87)
+
+
+class _SplitPairs(torch.autograd.Function):
+    """``mu -> (mu[::2], mu[1::2])`` (solver.py:64-65) as the same strided views; the backward interleaves the two gradients with ONE
+    launch.  Autograd's own slice backward costs two zero fills, two strided copies and an add per step (five launches of ~5 us in a
+    1.05 ms iteration, `tools/c5_step_sequence.sh`)."""
+
+    @staticmethod
+    def forward(ctx, mu):
+        ctx.rows = mu.shape[0]
+        return mu[::2], mu[1::2]
+
+    @staticmethod
+    def backward(ctx, g_first, g_second):
+        if g_first is None or g_second is None:
+            ref = g_first if g_first is not None else g_second
+            g_first = torch.zeros_like(ref) if g_first is None else g_first
+            g_second = torch.zeros_like(ref) if g_second is None else g_second
+        return torch.stack((g_first, g_second), dim=1).flatten(0, 1)
 
 
 class _WindowMean:
@@ -76,7 +96,7 @@ class Solver(object):
     def train_iteration(self, x):
         """One batch of image pairs (rows 2i, 2i+1): returns the 0-dim loss tensor, no host sync (solver.py:61-74)."""
         mu = self.net(x.to(self.device))
-        first, second = mu[::2], mu[1::2]                       # strided views, consumed as such by the loss kernels
+        first, second = _SplitPairs.apply(mu)                   # mu[::2], mu[1::2]: strided views, consumed as such by the loss kernels
         # negatives: the other first views.  One rank: the reference's roll; several: every rank's (order is invisible to the LSE)
         negatives = gather_negatives(first.contiguous()) if self.world > 1 else torch.roll(first, 1, 0)
         total, _, _ = self.loss(None, None, None, first, second, negatives)
