@@ -98,7 +98,7 @@ class Solver(object):
         mu = self.net(x.to(self.device))
         first, second = _SplitPairs.apply(mu)                   # mu[::2], mu[1::2]: strided views, consumed as such by the loss kernels
         # negatives: the other first views.  One rank: the reference's roll; several: every rank's (order is invisible to the LSE)
-        negatives = gather_negatives(first.contiguous()) if self.world > 1 else torch.roll(first, 1, 0)
+        negatives = gather_negatives(first.contiguous()) if self.world > 1 else losses.RolledRows(first, 1)      # torch.roll(first, 1, 0), not materialised
         total, _, _ = self.loss(None, None, None, first, second, negatives)
         self.optim.zero_grad()
         total.backward()

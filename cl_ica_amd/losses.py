@@ -176,6 +176,23 @@ class _PairLossFn(torch.autograd.Function):
         return (dz1 if need1 else None), dz2, dz3, None, None
 
 
+class RolledRows:
+    """``torch.roll(source, shift, 0)`` that has not been computed: what a caller inside this package (the KITTI-masks solver) passes as
+    ``z3_rec`` when the negatives are its own first views in another order.  ``LpSimCLRLoss`` with p >= 1 never reads the rolled copy
+    (the row-wise log-sum-exp does not depend on the order of the negatives: `_PairLossSymFn`), so the contiguous copy and the roll
+    launch of ``torch.roll`` on a strided view are not spent; every other consumer gets the real tensor from ``materialize()``."""
+
+    def __init__(self, source, shift: int = 1):
+        self.source, self.shift = source, int(shift)
+
+    @property
+    def shape(self):
+        return self.source.shape
+
+    def materialize(self):
+        return torch.roll(self.source, self.shift, 0)
+
+
 def _rolled_rows_of(z3, z1) -> bool:
     """Is `z3` the autograd result of ``torch.roll(z1, s, 0)`` (the reference's ``z3_rec = torch.roll(z1_rec, 1, 0)``,
     main_mlp.py:272)?  Read off the graph: z3's node is RollBackward0 along dim 0 and its input edge is z1's own gradient edge."""
@@ -303,13 +320,17 @@ class LpSimCLRLoss(CLLoss):
 
     def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
         del z1, z2_con_z1, z3   # unused by the reference as well (losses.py:431)
-        z1_rec, z2_con_z1_rec, z3_rec = lazy.plain(z1_rec), lazy.plain(z2_con_z1_rec), lazy.plain(z3_rec)
+        rolled = isinstance(z3_rec, RolledRows) and z3_rec.source is z1_rec
+        if isinstance(z3_rec, RolledRows) and not (rolled and _sym_enabled() and float(self.p) >= 1.0 and z1_rec.dim() == 2):
+            z3_rec, rolled = z3_rec.materialize(), False
+        z1_rec, z2_con_z1_rec = lazy.plain(z1_rec), lazy.plain(z2_con_z1_rec)
+        z3_rec = z1_rec if rolled else lazy.plain(z3_rec)
         if z1_rec.shape != z2_con_z1_rec.shape or z1_rec.shape[1] != z3_rec.shape[1]:
             raise ValueError(f"shape mismatch: {tuple(z1_rec.shape)}, {tuple(z2_con_z1_rec.shape)}, {tuple(z3_rec.shape)}")
         desc = self._desc(z1_rec.shape[0], z3_rec.shape[0], z1_rec.shape[1])
         # the roll shortcut only for p >= 1: the p < 1 branch of the reference (losses.py:433-442) transposes the pair matrix, so row k
         # belongs to z3[k] = z1[k-1] and is combined with pos[k] -- reading z1 itself as the pool would pair pos[k] with the wrong row
-        if _sym_enabled() and float(self.p) >= 1.0 and z1_rec.dim() == 2 and _rolled_rows_of(z3_rec, z1_rec):
+        if rolled or (_sym_enabled() and float(self.p) >= 1.0 and z1_rec.dim() == 2 and _rolled_rows_of(z3_rec, z1_rec)):
             mean, per_item, pos_mean, neg_mean = _PairLossSymFn.apply(z1_rec, z2_con_z1_rec, desc)
         else:
             mean, per_item, pos_mean, neg_mean = _PairLossFn.apply(z1_rec, z2_con_z1_rec, z3_rec, "lp", desc)

@@ -164,6 +164,30 @@ def test_lp_roll_fractional_p_vs_oracle():
             assert abs(out["loss_mean"] - orc["loss_mean"]) < 0.1 * abs(wrong["loss_mean"] - orc["loss_mean"])
 
 
+def test_rolled_rows_placeholder_equals_torch_roll():
+    """`losses.RolledRows(z1, 1)` (the KITTI-masks solver's negatives, never materialised) gives bit for bit what ``torch.roll(z1, 1, 0)``
+    gives through the same module: p = 1 / 2 on the one-sweep path, p = 0.5 by materialising the roll (the shortcut is invalid there)."""
+    import torch
+    from cl_ica_amd import losses
+    from cl_ica_amd.losses import LpSimCLRLoss
+    rng = np.random.default_rng(11)
+    base = torch.tensor(rng.normal(size=(64, 5)).astype(np.float32), device="cuda")
+    for p_, compat in ((1, True), (2, False), (0.5, True)):
+        res = []
+        for mode in ("placeholder", "roll"):
+            mu = base.clone().requires_grad_(True)
+            first, second = mu[::2], mu[1::2]
+            losses.PATHS.clear()
+            neg = losses.RolledRows(first, 1) if mode == "placeholder" else torch.roll(first, 1, 0)
+            total, per_item, _ = LpSimCLRLoss(p=p_, tau=1.0, simclr_compatibility_mode=compat)(None, None, None, first, second, neg)
+            total.backward()
+            took_sym = any(k.startswith("sym") for k in losses.PATHS)
+            assert took_sym == (p_ >= 1), (p_, mode, dict(losses.PATHS))
+            res.append((float(total), per_item.detach().cpu().numpy(), mu.grad.detach().cpu().numpy()))
+        assert res[0][0] == res[1][0], (p_, res[0][0], res[1][0])
+        assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2]), p_
+
+
 @pytest.fixture
 def dot_path(request):
     """SimCLRLoss contraction path: "mfma" (default from n = 96: fp32 MFMA GEMMs over a materialised logit matrix) or "valu" (pair sweep)."""
