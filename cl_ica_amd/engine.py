@@ -34,6 +34,9 @@ from .distributed import GradBuckets
 __all__ = ["SamplerSpec", "ContrastiveTrainer"]
 
 
+_PACK_FORK = os.environ.get("CLICA_PACK_FORK", "0") == "1"      # see ContrastiveTrainer._step_body
+
+
 @dataclass
 class SamplerSpec:
     """Ground-truth latent distribution (main_mlp.py:136-200)."""
@@ -760,12 +763,14 @@ class ContrastiveTrainer:
 
     # -------------------------------------------------------------------------------- whole step
     def _step_body(self, sample: bool):
-        # the fragment-order weight copies only depend on the parameters: pack them on the side stream while the
-        # main stream samples the batch and runs the mixing net
+        # The fragment-order weight copies only depend on the parameters.  Rounds 2-5 packed them on the side stream beside the samplers
+        # (two parallel branches at the root of the step graph); measured at the end of round 5: the fork / join of a HIP graph costs more
+        # than the 9 us of sampling it hides -- 2 622 / 2 609 steps/s forked against 2 649 / 2 638 with the pack in line on one box
+        # (tools/headline_ab.sh; the same fork in front of the KITTI-masks conv stack cost 107 us per step).  CLICA_PACK_FORK=1 keeps the fork.
         if self.s16 is not None and not self._s16_calibrated:
             self.calibrate_scales(sample)
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        side = self.side_stream
+        side = self.side_stream if _PACK_FORK else None
         self._packed_current = False          # a step always re-packs (parameters may have been set from outside)
         if (self.fused_forward or self.fused_backward) and main is not None and side is not None and sample:
             side.wait_stream(main)
@@ -773,8 +778,11 @@ class ContrastiveTrainer:
                 self.pack()
             self.sample()
             main.wait_stream(side)
-        elif sample:
-            self.sample()
+        else:
+            if sample:
+                self.sample()
+            if (self.fused_forward or self.fused_backward) and main is not None:
+                self.pack()                    # (here, not inside forward(): bench.py's stamps bracket the encoder launch alone)
         st = getattr(self, "stamps", None)         # bench.py: device time stamps around the encoder launches, valid inside the graph
         if st:
             ops.stamp(st["null"], 0); ops.stamp(st["null"], 1)      # empty bracket: the stamp pair's own cost, subtracted by the reader
