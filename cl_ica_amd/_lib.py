@@ -199,6 +199,9 @@ SIGNATURES: Dict[str, list] = {
     "clica_sample_scaled": [C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, C.c_void_p, C.c_void_p],
     "clica_sample_pair": [C.POINTER(SamplerDesc), C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64,
                           C.c_void_p, C.c_void_p],
+    "clica_mlp_pack_split16_both_sample": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.POINTER(SamplerDesc), C.POINTER(SamplerDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_i64,
+                                           c_i64, C.c_void_p, C.c_void_p],
 }
 
 _lib: Optional[C.CDLL] = None

@@ -19,6 +19,7 @@
 #include "planes.h"
 #include "split16.h"
 #include "wgrad_shared.h"
+#include "sampler_dev.h"
 #include <stdlib.h>
 
 namespace clica {
@@ -762,8 +763,8 @@ struct Pack2Args {
   int nfwd;                        // number of forward-orientation segments = layers (they come first)
   Split16State* st;
 };
-__global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack2_block(const Pack2Args& a, const unsigned block) {
+  const int64_t idx = (int64_t)block * 256 + threadIdx.x;
   const bool live = idx < a.first[a.nseg];
   // (no early return: whole waves take part in the maximum; a wave never straddles two segments' amax slots because segment
   //  sizes are multiples of 64 entries)
@@ -800,11 +801,24 @@ __global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) {
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   const unsigned wid = (unsigned)(idx >> 6);
   if ((threadIdx.x & 63) == 0 && wid < kS16CapPW && a.layer[sidx] >= 0) s16_partW(a.st)[wid] = __float_as_uint((m <= 3.0e38f) ? m / sc : 3.4e38f);
-  if (blockIdx.x == 0 && threadIdx.x <= Split16State::NT) {      // wave ranges of the layers (forward-orientation segments come first, one per layer)
+  if (block == 0 && threadIdx.x <= Split16State::NT) {      // wave ranges of the layers (forward-orientation segments come first, one per layer)
     const int l = threadIdx.x;
     a.st->wfirst[l] = (unsigned)(a.first[l < a.nfwd ? l : a.nfwd] >> 6);
     if (l == 0) a.st->nPW = (unsigned)(a.first[a.nfwd] >> 6);
   }
+}
+__global__ __launch_bounds__(256) void mlp_pack2_k(Pack2Args a) { pack2_block(a, blockIdx.x); }
+// The training step's two independent front launches in one -- the weight pack (blocks [0, pack_blocks))
+// and the latent pair draw z, z~ (the blocks behind them; rng::sample_pair_elem, the body of sampler.hip's sample_pair_elem_k: same Philox
+// counters, same numbers).  As two launches in line they cost 12 + 9 us in front of the forward; forked onto two streams the HIP graph's
+// fork / join cost more than it hid (engine.py: _step_body).
+static_assert(rng::THREADS == 256, "the merged launch uses one block size for both bodies");
+__global__ __launch_bounds__(256) void mlp_pack2_sample_k(Pack2Args a, rng::PairArgs s, unsigned pack_blocks) {
+  if (blockIdx.x >= pack_blocks) {
+    rng::sample_pair_elem(s, (int64_t)(blockIdx.x - pack_blocks) * 256 + threadIdx.x);
+    return;
+  }
+  pack2_block(a, blockIdx.x);
 }
 
 __global__ __launch_bounds__(256) void split16_update_k(Split16State* st, int L) { split16_update_tensor(st, L, (int)blockIdx.x); }
@@ -2265,14 +2279,14 @@ extern "C" int clica_mlp_pack_split16_bytes(int32_t n_layers, const int32_t* N, 
   *bytes = (size_t)e * 16;
   return CLICA_OK;
 }
-extern "C" int clica_mlp_pack_split16_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
-                                           void* packed_fwd, void* packed_bwd, void* state, clica_stream_t stream) {
+static int pack2_fill(fmlp::Pack2Args& a, int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                      void* packed_fwd, void* packed_bwd, void* state) {
   using namespace fmlp;
   CLICA_CHECK_ARG(W && ldw && N && K && packed_fwd && packed_bwd && state && n_layers >= 2 && n_layers <= MAXL, "clica_mlp_pack_split16_both: bad argument");
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(packed_fwd) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_bwd) & 15) == 0,
                   "clica_mlp_pack_split16_both: packed buffers must be 16-byte aligned");
   Split16State* st = reinterpret_cast<Split16State*>(state);
-  Pack2Args a{};
+  a = Pack2Args{};
   a.st = st;
   int sgi = 0; int64_t off = 0;
   auto fill = [&](const float* Wl, int64_t ld, int rows, int cols, int transposed, void* base, const float* sc, int layer) {
@@ -2292,7 +2306,37 @@ extern "C" int clica_mlp_pack_split16_both(int32_t n_layers, const float* const*
   for (int l = n_layers - 1; l >= 1; --l) fill(W[l], ldw[l], K[l], N[l], 1, packed_bwd, &st->sW[l], -1);
   a.nseg = sgi;
   CLICA_CHECK_ARG(((a.first[a.nseg] + 63) >> 6) <= (int64_t)kS16CapPW, "clica_mlp_pack_split16_both: the weights exceed the state's %u pack-wave slots", kS16CapPW);
-  hipLaunchKernelGGL(mlp_pack2_k, dim3((unsigned)ceil_div(a.first[a.nseg], 256)), dim3(256), 0, as_stream(stream), a);
+  return CLICA_OK;
+}
+extern "C" int clica_mlp_pack_split16_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                           void* packed_fwd, void* packed_bwd, void* state, clica_stream_t stream) {
+  fmlp::Pack2Args a;
+  int rc = pack2_fill(a, n_layers, W, ldw, N, K, packed_fwd, packed_bwd, state);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fmlp::mlp_pack2_k, dim3((unsigned)ceil_div(a.first[a.nseg], 256)), dim3(256), 0, as_stream(stream), a);
   return launch_status("clica_mlp_pack_split16_both");
+}
+extern "C" int clica_mlp_pack_split16_both_sample(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                                  void* packed_fwd, void* packed_bwd, void* state,
+                                                  const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
+                                                  const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
+                                                  int64_t M, const int32_t* step_dev, clica_stream_t stream) {
+  fmlp::Pack2Args a;
+  int rc = pack2_fill(a, n_layers, W, ldw, N, K, packed_fwd, packed_bwd, state);
+  if (rc) return rc;
+  clica::rng::PairArgs pa;
+  int one = 0;
+  rc = clica_sample_pair_args(marginal, conditional, marginal_mean, ldmm, z, ldz, zt, ldzt, M, step_dev, &pa, &one);
+  if (rc) return rc;
+  const unsigned pack_blocks = (unsigned)ceil_div(a.first[a.nseg], 256);
+  if (!one) {      // row-wise sampler kinds (sphere, vMF): the two calls one after the other
+    hipLaunchKernelGGL(fmlp::mlp_pack2_k, dim3(pack_blocks), dim3(256), 0, as_stream(stream), a);
+    rc = launch_status("clica_mlp_pack_split16_both_sample");
+    if (rc) return rc;
+    return clica_sample_pair(marginal, conditional, marginal_mean, ldmm, z, ldz, zt, ldzt, M, step_dev, stream);
+  }
+  const unsigned sample_blocks = (unsigned)ceil_div(M * marginal->n, 256);
+  hipLaunchKernelGGL(fmlp::mlp_pack2_sample_k, dim3(pack_blocks + sample_blocks), dim3(256), 0, as_stream(stream), a, pa, pack_blocks);
+  return launch_status("clica_mlp_pack_split16_both_sample");
 }
 

@@ -8,93 +8,10 @@
 // (with a host sync per round); that is per-element rejection sampling, done here in a register loop.
 // RNG streams cannot match torch/NumPy bit-for-bit: parity is distributional (tests/test_gpu_samplers).
 #include "common.h"
+#include "sampler_dev.h"
 
 namespace clica {
 namespace rng {
-constexpr int THREADS = 256;
-
-struct Philox {
-  uint32_t key0, key1;
-  uint32_t c0, c1, c2, c3;   // c0 = element index, c1 = draw block, c2 = step, c3 = stream id
-  uint32_t o0, o1, o2, o3;   // named registers: a runtime-indexed array would live in scratch memory
-  int have;
-  __device__ Philox(uint64_t seed, uint32_t idx, uint32_t step, uint32_t stream)
-      : key0((uint32_t)seed), key1((uint32_t)(seed >> 32)), c0(idx), c1(0), c2(step), c3(stream), have(0) {}
-  __device__ void refill() {
-    uint32_t a0 = c0, a1 = c1, a2 = c2, a3 = c3, k0 = key0, k1 = key1;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      const uint64_t p0 = (uint64_t)0xD2511F53u * a0;
-      const uint64_t p1 = (uint64_t)0xCD9E8D57u * a2;
-      const uint32_t n0 = (uint32_t)(p1 >> 32) ^ a1 ^ k0;
-      const uint32_t n1 = (uint32_t)p1;
-      const uint32_t n2 = (uint32_t)(p0 >> 32) ^ a3 ^ k1;
-      const uint32_t n3 = (uint32_t)p0;
-      a0 = n0; a1 = n1; a2 = n2; a3 = n3;
-      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    o0 = a0; o1 = a1; o2 = a2; o3 = a3;
-    ++c1; have = 4;
-  }
-  __device__ uint32_t next() {
-    if (have == 0) refill();
-    const uint32_t r = o0;
-    o0 = o1; o1 = o2; o2 = o3; --have;
-    return r;
-  }
-  __device__ float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }          // [0,1)
-  __device__ float uniform_open() { return ((float)(next() >> 8) + 1.0f) * (1.0f / 16777216.0f); }  // (0,1]
-  __device__ float normal() {  // Box-Muller, one value per call (the twin is discarded: draws are cheap)
-    const float u1 = uniform_open(), u2 = uniform();
-    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
-  }
-  __device__ float laplace() {  // unit-scale Laplace by inverse CDF, as torch.distributions.Laplace.rsample
-    const float u = 2.0f * uniform() - 1.0f;   // [-1,1)
-    const float a = fabsf(u);
-    const float m = -log1pf(-fminf(a, 0.99999994f));
-    return u < 0.f ? -m : m;
-  }
-  __device__ float gamma(float a) {  // Marsaglia-Tsang; shape < 1 via the U^(1/a) boost
-    float boost = 1.f;
-    if (a < 1.f) { boost = powf(uniform_open(), 1.f / a); a += 1.f; }
-    const float d = a - 1.f / 3.f, c = 1.f / sqrtf(9.f * d);
-    for (int it = 0; it < 64; ++it) {
-      const float x = normal();
-      float v = 1.f + c * x;
-      if (v <= 0.f) continue;
-      v = v * v * v;
-      const float u = uniform_open();
-      if (logf(u) < 0.5f * x * x + d - d * v + d * logf(v)) return d * v * boost;
-    }
-    return d * boost;
-  }
-  __device__ float gennorm(float p) {  // +-Gamma(1/p,1)^(1/p)  (spaces_utils.py:95-102)
-    const float gmm = gamma(1.f / p);
-    const float mag = powf(gmm, 1.f / p);
-    return (next() & 1u) ? mag : -mag;
-  }
-};
-
-struct Desc {
-  int space, dist, n;
-  float box_min, box_max, scale, shape_p;
-  uint64_t seed; uint32_t stream_id;
-  const float* svec; int64_t lds;     // optional per-coordinate scale (spaces.py:60-72: `std` may be a tensor), row stride 0 = one row
-};
-
-// scale of coordinate k of row i: the descriptor's scalar, times the per-coordinate tensor when there is one
-__device__ __forceinline__ float scale_of(const Desc& d, int64_t i, int k) {
-  return d.svec ? d.scale * d.svec[i * d.lds + k] : d.scale;
-}
-__device__ __forceinline__ float noise(Philox& g, const Desc& d, float sc) {
-  switch (d.dist) {
-    case CLICA_DIST_NORMAL: return sc * g.normal();
-    case CLICA_DIST_LAPLACE: return sc * g.laplace();
-    case CLICA_DIST_GENNORM: return sc * g.gennorm(d.shape_p);
-    default: return 0.f;
-  }
-}
-
 // one thread per ELEMENT for the coordinate-wise kinds (box, R^n): B*n threads instead of B
 __global__ __launch_bounds__(THREADS) void sample_elem_k(Desc d, const float* __restrict__ mean, int64_t ldm,
                                                         float* __restrict__ out, int64_t ldo, int64_t M,
@@ -119,35 +36,8 @@ __global__ __launch_bounds__(THREADS) void sample_elem_k(Desc d, const float* __
 
 // marginal draw z and conditional draw z~ | z of the same element in one launch (both coordinate-wise kinds):
 // the same Philox counters as two sample_elem_k launches, hence the same numbers
-__global__ __launch_bounds__(THREADS) void sample_pair_elem_k(Desc dm, Desc dc, const float* __restrict__ mmean, int64_t ldmm,
-                                                             float* __restrict__ z, int64_t ldz, float* __restrict__ zt, int64_t ldzt,
-                                                             int64_t M, const int32_t* __restrict__ step_dev) {
-  const int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-  if (idx >= M * dm.n) return;
-  const int64_t i = idx / dm.n;
-  const int k = (int)(idx - i * dm.n);
-  const uint32_t step = step_dev ? (uint32_t)step_dev[0] : 0u;
-  float v;
-  {
-    Philox g(dm.seed, (uint32_t)idx, step, dm.stream_id);
-    if (dm.dist == CLICA_DIST_UNIFORM) {
-      v = g.uniform() * (dm.box_max - dm.box_min) + dm.box_min;
-    } else {
-      const float m = mmean[i * ldmm + k];
-      v = m + noise(g, dm, dm.scale);
-      if (dm.space == CLICA_SPACE_BOX)
-        for (int it = 0; it < 4096 && !(v >= dm.box_min && v <= dm.box_max); ++it) v = m + noise(g, dm, dm.scale);
-    }
-    z[i * ldz + k] = v;
-  }
-  {
-    Philox g(dc.seed, (uint32_t)idx, step, dc.stream_id);
-    const float m = v;
-    float w = m + noise(g, dc, dc.scale);
-    if (dc.space == CLICA_SPACE_BOX)
-      for (int it = 0; it < 4096 && !(w >= dc.box_min && w <= dc.box_max); ++it) w = m + noise(g, dc, dc.scale);
-    zt[i * ldzt + k] = w;
-  }
+__global__ __launch_bounds__(THREADS) void sample_pair_elem_k(PairArgs a) {
+  sample_pair_elem(a, (int64_t)blockIdx.x * THREADS + threadIdx.x);
 }
 
 // one thread per sample row
@@ -222,17 +112,14 @@ using namespace clica;
 
 static bool rowwise_kind(const clica_sampler_desc* d) { return d->space == CLICA_SPACE_SPHERE || d->dist == CLICA_DIST_VMF; }
 
-extern "C" int clica_sample_pair(const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
-                                 const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
-                                 int64_t M, const int32_t* step_dev, clica_stream_t stream) {
-  CLICA_CHECK_ARG(marginal && conditional && z && zt && M > 0, "clica_sample_pair: bad argument");
+int clica_sample_pair_args(const clica_sampler_desc* marginal, const clica_sampler_desc* conditional, const float* marginal_mean, int64_t ldmm,
+                           float* z, int64_t ldz, float* zt, int64_t ldzt, int64_t M, const int32_t* step_dev,
+                           clica::rng::PairArgs* out, int* mergeable) {
+  CLICA_CHECK_ARG(marginal && conditional && z && zt && M > 0 && out && mergeable, "clica_sample_pair: bad argument");
   CLICA_CHECK_ARG(marginal->n == conditional->n, "clica_sample_pair: the two descriptors disagree on n");
   CLICA_CHECK_ARG(conditional->dist != CLICA_DIST_UNIFORM, "clica_sample_pair: the second draw must be a conditional kind");
-  if (rowwise_kind(marginal) || rowwise_kind(conditional) || (marginal->dist != CLICA_DIST_UNIFORM && ldmm == 0)) {
-    int rc = clica_sample(marginal, marginal_mean, ldmm, z, ldz, M, step_dev, stream);     // row-wise kinds: two launches
-    if (rc) return rc;
-    return clica_sample(conditional, z, ldz, zt, ldzt, M, step_dev, stream);
-  }
+  *mergeable = 0;
+  if (rowwise_kind(marginal) || rowwise_kind(conditional) || (marginal->dist != CLICA_DIST_UNIFORM && ldmm == 0)) return CLICA_OK;     // row-wise kinds: two launches
   // validate through the single-draw entry's rules without launching twice
   const clica_sampler_desc* both[2] = {marginal, conditional};
   for (const clica_sampler_desc* d : both) {
@@ -244,12 +131,29 @@ extern "C" int clica_sample_pair(const clica_sampler_desc* marginal, const clica
     if (d->space == CLICA_SPACE_BOX) CLICA_CHECK_ARG(d->box_max > d->box_min, "clica_sample_pair: empty box");
   }
   if (marginal->dist != CLICA_DIST_UNIFORM) CLICA_CHECK_ARG(marginal_mean != nullptr && ldmm >= marginal->n, "clica_sample_pair: marginal mean missing");
-  rng::Desc qm{marginal->space, marginal->dist, marginal->n, marginal->box_min, marginal->box_max, marginal->scale, marginal->shape_p,
-               marginal->seed, marginal->stream_id, nullptr, 0};
-  rng::Desc qc{conditional->space, conditional->dist, conditional->n, conditional->box_min, conditional->box_max, conditional->scale,
-               conditional->shape_p, conditional->seed, conditional->stream_id, nullptr, 0};
+  out->dm = rng::Desc{marginal->space, marginal->dist, marginal->n, marginal->box_min, marginal->box_max, marginal->scale, marginal->shape_p,
+                      marginal->seed, marginal->stream_id, nullptr, 0};
+  out->dc = rng::Desc{conditional->space, conditional->dist, conditional->n, conditional->box_min, conditional->box_max, conditional->scale,
+                      conditional->shape_p, conditional->seed, conditional->stream_id, nullptr, 0};
+  out->mmean = marginal_mean; out->ldmm = ldmm; out->z = z; out->ldz = ldz; out->zt = zt; out->ldzt = ldzt; out->M = M; out->step_dev = step_dev;
+  *mergeable = 1;
+  return CLICA_OK;
+}
+
+extern "C" int clica_sample_pair(const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
+                                 const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
+                                 int64_t M, const int32_t* step_dev, clica_stream_t stream) {
+  rng::PairArgs pa;
+  int one = 0;
+  int rc = clica_sample_pair_args(marginal, conditional, marginal_mean, ldmm, z, ldz, zt, ldzt, M, step_dev, &pa, &one);
+  if (rc) return rc;
+  if (!one) {
+    rc = clica_sample(marginal, marginal_mean, ldmm, z, ldz, M, step_dev, stream);     // row-wise kinds: two launches
+    if (rc) return rc;
+    return clica_sample(conditional, z, ldz, zt, ldzt, M, step_dev, stream);
+  }
   hipLaunchKernelGGL(rng::sample_pair_elem_k, dim3((unsigned)ceil_div(M * marginal->n, rng::THREADS)), dim3(rng::THREADS), 0,
-                     as_stream(stream), qm, qc, marginal_mean, ldmm, z, ldz, zt, ldzt, M, step_dev);
+                     as_stream(stream), pa);
   return launch_status("clica_sample_pair");
 }
 

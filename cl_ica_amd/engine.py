@@ -383,6 +383,27 @@ class ContrastiveTrainer:
             ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x, act_kind=self.g_act_kind)
 
     # -------------------------------------------------------------------------------- step pieces
+    def _pack_sample_merged(self) -> bool:
+        """The step's two independent front launches -- weight pack and latent pair draw -- in ONE (clica_mlp_pack_split16_both_sample):
+        f16x2 arithmetic, packed buffers already allocated, the one-launch sampler path.  False: the caller runs them separately."""
+        if (self.s16 is None or not self.split_bf16 or self.packed is None or self.packed_t is None or not self.fuse_small
+                or os.environ.get("CLICA_PACK_SAMPLE_MERGE", "1") == "0"):
+            return False
+        s, B, n = self.sampler, self.B, self.n
+        mean = None
+        if s.marginal != "uniform":
+            if not hasattr(self, "_eta"):
+                self._eta = torch.zeros(1, n, device=self.device)
+                if s.space == "sphere":
+                    self._eta[0, 0] = 1.0                      # main_mlp.py:148-150
+            mean = self._eta
+        ops.mlp_pack_split16_sample([lin.weight for lin in self.linears], self.packed, self.packed_t, self.s16, s.space, s.marginal,
+                                    s.conditional, n, B, self.z[:B], self.z[B:], marginal_mean=mean, m_scale=s.m_param, m_p=s.m_p,
+                                    c_scale=s.c_param, c_p=s.c_p, box=s.box, seed=s.seed, stream_id=2 * self.rank, step_dev=self.step_dev)
+        self._packed_current = True
+        self._mix()
+        return True
+
     def pack(self):
         """Fragment-order copies of the CURRENT weights for the fused forward / backward-chain kernels (one launch
         for both layouts when both are used).  Valid until the next optimizer step."""
@@ -779,10 +800,12 @@ class ContrastiveTrainer:
             self.sample()
             main.wait_stream(side)
         else:
-            if sample:
-                self.sample()
-            if (self.fused_forward or self.fused_backward) and main is not None:
-                self.pack()                    # (here, not inside forward(): bench.py's stamps bracket the encoder launch alone)
+            fused = (self.fused_forward or self.fused_backward) and main is not None
+            if not (sample and fused and self._pack_sample_merged()):
+                if sample:
+                    self.sample()
+                if fused:
+                    self.pack()                # (here, not inside forward(): bench.py's stamps bracket the encoder launch alone)
         st = getattr(self, "stamps", None)         # bench.py: device time stamps around the encoder launches, valid inside the graph
         if st:
             ops.stamp(st["null"], 0); ops.stamp(st["null"], 1)      # empty bracket: the stamp pair's own cost, subtracted by the reader

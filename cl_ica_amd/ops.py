@@ -660,12 +660,7 @@ def tick(counter: torch.Tensor):
     check(load().clica_tick(counter.data_ptr(), stream_ptr()), "clica_tick")
 
 
-def sample_pair(space: str, marginal: str, conditional: str, n: int, size: int, z: torch.Tensor, zt: torch.Tensor,
-                marginal_mean: Optional[torch.Tensor] = None, m_scale: float = 1.0, m_p: float = 2.0,
-                c_scale: float = 1.0, c_p: float = 2.0, box=(0.0, 1.0), seed: int = 0, stream_id: int = 0,
-                step_dev: Optional[torch.Tensor] = None):
-    """z ~ marginal, zt ~ conditional(. | z) with Philox stream ids `stream_id` and `stream_id + 1` (clica_sample_pair:
-    one launch for the coordinate-wise kinds; same numbers as two `sample` calls)."""
+def _pair_descs(space, marginal, conditional, n, marginal_mean, m_scale, m_p, c_scale, c_p, box, seed, stream_id):
     mk = lambda dist, scale, p, sid: _lib.SamplerDesc(space=SPACE[space], dist=DIST[dist], n=n, box_min=float(box[0]), box_max=float(box[1]),
                                                       scale=float(scale), shape_p=float(p), seed=int(seed) & (2**64 - 1),
                                                       stream_id=int(sid) & 0xFFFFFFFF)
@@ -677,9 +672,37 @@ def sample_pair(space: str, marginal: str, conditional: str, n: int, size: int, 
         marginal_mean, ldmm = rowmajor(marginal_mean.detach())
         if marginal_mean.shape[0] == 1:
             ldmm = 0
+    return dm, dc, marginal_mean, ldmm
+
+
+def sample_pair(space: str, marginal: str, conditional: str, n: int, size: int, z: torch.Tensor, zt: torch.Tensor,
+                marginal_mean: Optional[torch.Tensor] = None, m_scale: float = 1.0, m_p: float = 2.0,
+                c_scale: float = 1.0, c_p: float = 2.0, box=(0.0, 1.0), seed: int = 0, stream_id: int = 0,
+                step_dev: Optional[torch.Tensor] = None):
+    """z ~ marginal, zt ~ conditional(. | z) with Philox stream ids `stream_id` and `stream_id + 1` (clica_sample_pair:
+    one launch for the coordinate-wise kinds; same numbers as two `sample` calls)."""
+    dm, dc, marginal_mean, ldmm = _pair_descs(space, marginal, conditional, n, marginal_mean, m_scale, m_p, c_scale, c_p, box, seed, stream_id)
     check(load().clica_sample_pair(C.byref(dm), C.byref(dc), ptr(marginal_mean), ldmm, z.data_ptr(), z.stride(0), zt.data_ptr(),
                                    zt.stride(0), size, ptr(step_dev), stream_ptr()), "clica_sample_pair")
     return z, zt
+
+
+def mlp_pack_split16_sample(weights, packed: torch.Tensor, packed_t: torch.Tensor, state, space: str, marginal: str, conditional: str, n: int,
+                            size: int, z: torch.Tensor, zt: torch.Tensor, marginal_mean: Optional[torch.Tensor] = None, m_scale: float = 1.0,
+                            m_p: float = 2.0, c_scale: float = 1.0, c_p: float = 2.0, box=(0.0, 1.0), seed: int = 0, stream_id: int = 0,
+                            step_dev: Optional[torch.Tensor] = None):
+    """`mlp_pack_split_both(weights, packed, packed_t, state)` and `sample_pair(...)` in ONE launch (clica_mlp_pack_split16_both_sample):
+    the training step's two independent front launches; same results bit for bit.  `packed` / `packed_t` must exist."""
+    L = len(weights)
+    ws = [_mat(f"weight[{l}]", w) for l, w in enumerate(weights)]
+    I32 = C.c_int32 * L
+    Ns, Ks = I32(*[w.shape[0] for w, _ in ws]), I32(*[w.shape[1] for w, _ in ws])
+    Wp, ldp = (C.c_void_p * L)(*[w.data_ptr() for w, _ in ws]), (C.c_int64 * L)(*[ld for _, ld in ws])
+    dm, dc, marginal_mean, ldmm = _pair_descs(space, marginal, conditional, n, marginal_mean, m_scale, m_p, c_scale, c_p, box, seed, stream_id)
+    check(load().clica_mlp_pack_split16_both_sample(L, Wp, ldp, Ns, Ks, packed.data_ptr(), packed_t.data_ptr(), state.buf.data_ptr(),
+                                                    C.byref(dm), C.byref(dc), ptr(marginal_mean), ldmm, z.data_ptr(), z.stride(0), zt.data_ptr(),
+                                                    zt.stride(0), size, ptr(step_dev), stream_ptr()), "clica_mlp_pack_split16_both_sample")
+    return packed, packed_t
 
 
 # ------------------------------------------------------------------------------- nearest neighbours

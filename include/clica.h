@@ -720,6 +720,16 @@ int clica_sample_scaled(const clica_sampler_desc* d, const float* mean, int64_t 
 int clica_sample_pair(const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
                       const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
                       int64_t M, const int32_t* step_dev, clica_stream_t stream);
+/* The two independent front launches of a training step in ONE: clica_mlp_pack_split16_both (the f16x2 weight pieces of the
+ * parameters Adam has just written; reference: the nn.Linear weights of encoders.py:36-48 as the kernels' operand) and clica_sample_pair
+ * (z, z~ of main_mlp.py:196-200) -- same arguments, same results bit for bit (the pair draw keeps its Philox counters).  As two launches
+ * in line they cost 12 + 9 us in front of the encoder; as two branches of a HIP graph the fork / join cost more than it hid.  Row-wise
+ * sampler kinds (sphere, vMF) run the two calls one after the other. */
+int clica_mlp_pack_split16_both_sample(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,
+                                       void* packed_fwd, void* packed_bwd, void* state,
+                                       const clica_sampler_desc* marginal, const clica_sampler_desc* conditional,
+                                       const float* marginal_mean, int64_t ldmm, float* z, int64_t ldz, float* zt, int64_t ldzt,
+                                       int64_t M, const int32_t* step_dev, clica_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -196,3 +196,36 @@ def test_product_latent_space_on_device(golden):
     zt0 = prod.sample_conditional(z0, size=1000, device="cuda")
     assert zt0.shape == (1000, 20) and float((zt0[:, :10] - z0[:10]).abs().max()) < 0.5
     assert float((zt0[:, 10:].norm(dim=-1) - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_pack_and_pair_draw_in_one_launch_equal_the_two_launches():
+    """clica_mlp_pack_split16_both_sample (the training step's merged front launch) == clica_mlp_pack_split16_both followed by
+    clica_sample_pair, bit for bit: packed f16x2 pieces in both orientations, the state's recorded weight maxima, z and z~ -- for the
+    headline's box / uniform / normal kinds and for a row-wise kind (sphere: the merged entry runs the two calls one after the other)."""
+    import torch
+    from cl_ica_amd import ops
+    dev = torch.device("cuda")
+    torch.manual_seed(3)
+    widths = [(100, 10), (500, 100), (500, 500), (100, 500), (10, 100)]
+    ws = [torch.randn(n, k, device=dev) * 0.1 for n, k in widths]
+    B, n = 1024, 10
+    step = torch.tensor([7], dtype=torch.int32, device=dev)
+    for space, marginal, conditional in (("box", "uniform", "normal"), ("box", "uniform", "laplace"), ("sphere", "uniform", "normal")):
+        out = []
+        for merged in (False, True):
+            st = ops.Split16(len(ws), dev)
+            packed, packed_t = ops.mlp_pack_split_both(ws, None, None, state=st)       # allocates; contents overwritten below
+            packed.zero_(); packed_t.zero_()
+            z, zt = torch.zeros(B, n, device=dev), torch.zeros(B, n, device=dev)
+            kw = dict(m_scale=1.0, c_scale=0.05, box=(0.0, 1.0), seed=1234, stream_id=4, step_dev=step)
+            if merged:
+                ops.mlp_pack_split16_sample(ws, packed, packed_t, st, space, marginal, conditional, n, B, z, zt, **kw)
+            else:
+                ops.mlp_pack_split_both(ws, packed, packed_t, state=st)
+                ops.sample_pair(space, marginal, conditional, n, B, z, zt, **kw)
+            torch.cuda.synchronize()
+            out.append((packed.clone(), packed_t.clone(), st.buf.clone(), z.clone(), zt.clone()))
+        for a, b in zip(*out):
+            assert torch.equal(a, b), (space, marginal, conditional)
+        assert float(out[0][3].abs().sum()) > 0 and float((out[0][4] - out[0][3]).abs().sum()) > 0
