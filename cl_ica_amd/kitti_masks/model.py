@@ -4,9 +4,9 @@ Same constructor (``z_dim, nc, box_norm``), same ``self.encoder`` ``nn.Sequentia
 (``encoder.{0,2,4,6,8}.{weight,bias}``, ``encoder.11.{weight,bias}``, ``encoder.12.max_abs_bound`` with ``box_norm``), the
 same Kaiming-normal initialisation with zero biases (:76-79, :102-110) and the same ``forward(x) -> (B, z_dim)``.
 
-Execution: on the GPU the five ``Conv2d(k=4) + ReLU`` stages run on the HIP library since round 4 (implicit-GEMM stages,
-``cl_ica_amd/conv.py`` / ``clica_conv_*``; ``CLICA_CONV=miopen`` selects PyTorch-ROCm / MIOpen, which north_star allows for the
-conv path, BASELINE.json configs[4]); everything behind the ``View`` -- ``Linear(256 -> z_dim)`` forward / dgrad / wgrad
+Execution: on the GPU the five ``Conv2d(k=4) + ReLU`` stages run on the HIP library (implicit-GEMM stages in the f16x2 split
+arithmetic since round 5, ``cl_ica_amd/conv.py`` / ``clica_conv16_*`` / ``clica_conv_*``; ``CLICA_CONV=miopen`` selects PyTorch-ROCm / MIOpen
+as an explicit A/B switch only); everything behind the ``View`` -- ``Linear(256 -> z_dim)`` forward / dgrad / wgrad
 (``clica_linear_*``), the learnable Softclip head (``clica_softclip_*``) -- runs on the HIP kernels, and the result feeds
 ``cl_ica_amd.losses.LpSimCLRLoss`` through strided ``mu[::2]`` / ``mu[1::2]`` views without a copy.
 """
@@ -53,7 +53,7 @@ class BetaVAE_H(nn.Module):
         super().__init__()
         self.z_dim, self.nc = z_dim, nc
         stages, width = [], nc
-        for out_ch, kernel, stride, pad in _CONV_STAGES:          # indices 0..9: Conv2d, ReLU alternating (MIOpen)
+        for out_ch, kernel, stride, pad in _CONV_STAGES:          # indices 0..9: Conv2d, ReLU alternating (parameter holders: the stages run on cl_ica_amd/conv.py)
             stages += [nn.Conv2d(width, out_ch, kernel, stride, pad), nn.ReLU(True)]
             width = out_ch
         head = layers.SoftclipLayer(n=z_dim, init_abs_bound=1.0, fixed_abs_bound=False) if box_norm else layers.Lambda(_identity)
