@@ -32,10 +32,18 @@ class AdamDesc(C.Structure):
                 ("step_dev", C.c_void_p), ("t_offset", c_i32), ("split16_state", C.c_void_p), ("n_layers", c_i32)]
 
 
+class DyParts(C.Structure):
+    """clica_lp_dy_parts (include/clica.h): the pair sweep's partials + what the loss's reduction launch would have done with them."""
+    _fields_ = [("part", C.c_void_p), ("nsplit", c_i32), ("nsplit_alt", c_i32), ("np", c_i32), ("n", c_i32), ("rows", c_i64),
+                ("guard_words", C.c_void_p), ("guard_limit", C.c_float), ("blocksums", C.c_void_p), ("nblocks", c_i32),
+                ("inv_count", C.c_float), ("means", C.c_void_p), ("tick", C.c_void_p)]
+
+
 class ChainTail(C.Structure):
     """clica_chain_tail (include/clica.h): what the backward chain needs to leave the n-wide layers' weight-gradient slabs."""
     _fields_ = [("a_last", C.c_void_p), ("lda", c_i64), ("x", C.c_void_p), ("ldx", c_i64), ("n_layers", c_i32),
-                ("N", C.POINTER(c_i32)), ("K", C.POINTER(c_i32)), ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", c_size)]
+                ("N", C.POINTER(c_i32)), ("K", C.POINTER(c_i32)), ("wgrad_workspace", C.c_void_p), ("wgrad_workspace_bytes", c_size),
+                ("dy_parts", C.POINTER(DyParts))]
 
 
 class DotLossDesc(C.Structure):
@@ -71,6 +79,8 @@ SIGNATURES: Dict[str, list] = {
                                 c_f32p, c_i64, c_f32p, c_i64, C.c_void_p, c_size, C.c_void_p],
     "clica_lp_loss_bwd_sym_train": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, C.c_void_p,
                                     C.c_void_p, c_size, C.c_void_p],
+    "clica_lp_loss_bwd_sym_train_parts": [C.POINTER(LpLossDesc), c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, C.c_void_p,
+                                          C.c_void_p, c_size, C.POINTER(DyParts), C.c_void_p],
     "clica_dot_loss_workspace_bytes": [C.POINTER(DotLossDesc), C.POINTER(c_size), C.POINTER(c_size)],
     "clica_dot_loss_fwd": [C.POINTER(DotLossDesc)] + _LOSS_FWD,
     "clica_dot_loss_bwd": [C.POINTER(DotLossDesc)] + _LOSS_BWD,

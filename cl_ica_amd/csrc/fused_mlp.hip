@@ -20,6 +20,7 @@
 #include "split16.h"
 #include "wgrad_shared.h"
 #include "sampler_dev.h"
+#include "lp_guard.h"
 #include <stdlib.h>
 
 namespace clica {
@@ -865,6 +866,13 @@ struct SplitArgs {
     int n_l, w_l, w_0, n_0;                  // n_l <= 16, n_0 <= 15, w_l <= 127, w_0 <= 128 (clica_mlp_chain_tail_supported)
     float* slab_l; float* dbslab_l; float* slab_0; float* dbslab_0;      // [workgroups][...]; slab_l == nullptr: no tail
   } tail;
+  // The launch's input still lacks the loss's pair-sweep partials (clica_lp_dy_parts, include/clica.h): the prologue adds them -- the
+  // sums bwd_reduce_k (lp_loss.hip) would have formed, in its order -- writes the finished rows back for the tail, and workgroup 0 leaves
+  // the forward's means and ticks the step counter.  part == nullptr: plain input.
+  struct DyParts {
+    const float* part; int nsplit, nsplit_alt, np, n; long long rows; const float* words; float limit;
+    const float* blocksums; int nblocks; float inv_count; float* means; int* tick; float* dy; long long ldy;
+  } parts;
   // Round 4: what the training step's epilogues need of a layer, in ONE 64-byte record (one s_load_dwordx16 at the top of the layer).
   // Reading the same facts field by field from g.layer[l] behind the k-loop was a chain of ~10 DEPENDENT scalar loads, each with its
   // own s_waitcnt lgkmcnt(0) (flag -> branch -> next flag) in front of the epilogue, with the matrix pipe idle (tools/split_trace.py).
@@ -1512,13 +1520,49 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
     } else {
       // the input rows: requested for up to four values per thread before the first is used
       constexpr int XIT = 4;
+      const SplitArgs::DyParts& P = a.parts;
+      int nsp = 0;
+      if (P.part) {
+        nsp = P.nsplit;
+        if (P.words && lp2::guard_falls_back(P.words, P.limit)) nsp = P.nsplit_alt;      // the sweep that wrote the partials (as bwd_reduce_k reads it)
+        if (blockIdx.x == 0 && threadIdx.x < 64) {      // the forward's three means + the counter tick: bwd_reduce_k's extra block, verbatim
+          float v[3] = {0.f, 0.f, 0.f};
+          for (int b = threadIdx.x; b < P.nblocks; b += 64) {
+            v[0] += P.blocksums[b * 3 + 0]; v[1] += P.blocksums[b * 3 + 1]; v[2] += P.blocksums[b * 3 + 2];
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_down(v[c], off, 64);
+          if (threadIdx.x == 0) {
+            P.means[0] = v[0] * P.inv_count; P.means[1] = v[1] * P.inv_count; P.means[2] = v[2] * P.inv_count;
+            if (P.tick) P.tick[0] += 1;
+          }
+        }
+      }
       for (int idx0 = threadIdx.x; idx0 < ROWS * K16; idx0 += XIT * THREADS) {
         float xv[XIT];
 #pragma unroll
         for (int u = 0; u < XIT; ++u) {
           const int idx = idx0 + u * THREADS;
           const int r = idx / K16, k = idx - r * K16;
-          xv[u] = (idx < ROWS * K16 && r < nrows && k < K0) ? g.X[(row0 + r) * g.ldx + k] : 0.f;
+          const bool ok = idx < ROWS * K16 && r < nrows && k < K0;
+          xv[u] = ok ? g.X[(row0 + r) * g.ldx + k] : 0.f;
+          if (P.part && ok) {
+            if (row0 + r < P.rows) {
+              // bwd_reduce_k's order: four interleaved partial sums over the splits, then (t0 + t1) + (t2 + t3), then + what is there
+              float t4[4] = {0.f, 0.f, 0.f, 0.f};
+              const float* src = P.part + (row0 + r) * P.np + k;
+              const long long stride = P.rows * (long long)P.np;
+              for (int sp = 0; sp < nsp; sp += 4) {
+#pragma unroll
+                for (int sub = 0; sub < 4; ++sub)
+                  if (sp + sub < nsp) t4[sub] += src[(long long)(sp + sub) * stride];
+              }
+              xv[u] = xv[u] + ((t4[0] + t4[1]) + (t4[2] + t4[3]));
+            }
+            P.dy[(row0 + r) * P.ldy + k] = xv[u];
+          }
         }
 #pragma unroll
         for (int u = 0; u < XIT; ++u) {
@@ -2203,6 +2247,14 @@ static int mlp_dgrad_split_impl(const float* dY, int64_t lddy, int64_t M, int32_
     if (rc) return rc;
     T.dzl = dY; T.ld_dzl = lddy; T.al = tail->a_last; T.ld_al = tail->lda; T.dz0 = out[n_links - 1]; T.ld_dz0 = ldo[n_links - 1];
     T.x = tail->x; T.ld_x = tail->ldx; T.n_l = tail->N[Le - 1]; T.w_l = tail->K[Le - 1]; T.w_0 = tail->N[0]; T.n_0 = tail->K[0];
+    if (tail->dy_parts) {
+      const clica_lp_dy_parts& dp = *tail->dy_parts;
+      CLICA_CHECK_ARG(dp.part && dp.means && dp.blocksums && dp.rows >= 1 && dp.rows <= M && dp.n == K[0] && dp.np >= dp.n && dp.nsplit >= 1,
+                      "clica_mlp_dgrad_split_tail: dy_parts does not match the chain's input (%lld rows of %d, chain input %lld x %d)",
+                      (long long)dp.rows, dp.n, (long long)M, K[0]);
+      a.parts = SplitArgs::DyParts{dp.part, dp.nsplit, dp.nsplit_alt > 0 ? dp.nsplit_alt : dp.nsplit, dp.np, dp.n, dp.rows, dp.guard_words, dp.guard_limit,
+                                   dp.blocksums, dp.nblocks, dp.inv_count, dp.means, dp.tick, const_cast<float*>(dY), lddy};
+    }
   }
   return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_dgrad_split16" : "clica_mlp_dgrad_split");
 }

@@ -713,14 +713,14 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
   return launch_status("clica_lp_loss_fwd_train");
 }
 
-extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
-                                           const float* z1, int64_t ld1, const float* pool, int64_t ldp,
-                                           const float* lse_i, const float* pool_lse,
-                                           float* dz1, int64_t ldd1, float* means, int32_t* tick_counter,
-                                           void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+static int bwd_sym_train_impl(const clica_lp_loss_desc* d,
+                              const float* z1, int64_t ld1, const float* pool, int64_t ldp,
+                              const float* lse_i, const float* pool_lse,
+                              float* dz1, int64_t ldd1, float* means, int32_t* tick_counter,
+                              void* workspace, size_t workspace_bytes, clica_lp_dy_parts* parts, clica_stream_t stream) {
   int rc = validate(d, "clica_lp_loss_bwd_sym_train");
   if (rc) return rc;
-  CLICA_CHECK_ARG(z1 && pool && lse_i && pool_lse && dz1 && means && workspace, "clica_lp_loss_bwd_sym_train: NULL pointer");
+  CLICA_CHECK_ARG(z1 && pool && lse_i && pool_lse && (dz1 || parts) && means && workspace, "clica_lp_loss_bwd_sym_train: NULL pointer");
   CLICA_CHECK_ARG(d->p >= 1.f && d->B3 >= d->B, "clica_lp_loss_bwd_sym_train: needs p >= 1 and a pool that contains the local rows");
   const int64_t rows = d->B, cols = d->B3;
   Plan PF = make_plan(rows, cols, d->n, false), PR = make_plan(rows, cols, d->n, true);
@@ -751,11 +751,30 @@ extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
   } else {
     launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, partR, st);
   }
+  if (parts) {      // the consumer (clica_mlp_dgrad_split_tail) does the reduction, the means and the tick itself
+    *parts = clica_lp_dy_parts{partR, nsplit_r, gate.nsplit_alt, PR.np, d->n, rows, gate.words, gate.limit,
+                               w.blocksums, (int32_t)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, tick_counter};
+    return launch_status("clica_lp_loss_bwd_sym_train_parts");
+  }
   const int blocks = (int)ceil_div(rows * PR.np, THREADS);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)(blocks + 1)), dim3(THREADS), 0, st,
                      (const float*)partR, nsplit_r, rows, PR.np, d->n, dz1, ldd1, 1,
                      MeansJob{w.blocksums, (int)ceil_div(rows, FIN_ROWS), 1.f / (float)rows, means, blocks, tick_counter}, gate);
   return launch_status("clica_lp_loss_bwd_sym_train");
+}
+extern "C" int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
+                                           const float* z1, int64_t ld1, const float* pool, int64_t ldp,
+                                           const float* lse_i, const float* pool_lse,
+                                           float* dz1, int64_t ldd1, float* means, int32_t* tick_counter,
+                                           void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  return bwd_sym_train_impl(d, z1, ld1, pool, ldp, lse_i, pool_lse, dz1, ldd1, means, tick_counter, workspace, workspace_bytes, nullptr, stream);
+}
+extern "C" int clica_lp_loss_bwd_sym_train_parts(const clica_lp_loss_desc* d,
+                                                 const float* z1, int64_t ld1, const float* pool, int64_t ldp,
+                                                 const float* lse_i, const float* pool_lse, float* means, int32_t* tick_counter,
+                                                 void* workspace, size_t workspace_bytes, clica_lp_dy_parts* parts, clica_stream_t stream) {
+  CLICA_CHECK_ARG(parts != nullptr, "clica_lp_loss_bwd_sym_train_parts: parts is NULL");
+  return bwd_sym_train_impl(d, z1, ld1, pool, ldp, lse_i, pool_lse, nullptr, 0, means, tick_counter, workspace, workspace_bytes, parts, stream);
 }
 
 // =====================================================================================

@@ -509,6 +509,19 @@ class ContrastiveTrainer:
             elif emu:
                 self.lse_all.view(self.emulate_pool, B).copy_(lse.unsqueeze(0))
             pool_lse = self.lse_all if (self.dp or emu) else lse
+            self._dy_parts = None
+            if self._chain_takes_partials(emu):
+                # N = 1 training step: no reduction launch -- the backward chain's prologue sums the pair sweep's partials into dy, leaves
+                # the forward's means and ticks the counter (clica_lp_dy_parts; same sums in the same order)
+                self._dy_parts = _lib.DyParts()
+                self._dy_parts_taken = getattr(self, "_dy_parts_taken", 0) + 1      # (tests: which path a trainer took)
+                _lib.check(lib.clica_lp_loss_bwd_sym_train_parts(C.byref(self.desc), y1.data_ptr(), n, pool.data_ptr(), n,
+                                                                 lse.data_ptr(), pool_lse.data_ptr(), o[3 * B:].data_ptr(),
+                                                                 self.step_dev.data_ptr() if self.early_tick else None,
+                                                                 self.loss_ws.data_ptr(), self.loss_ws.numel(), C.byref(self._dy_parts), st),
+                           "clica_lp_loss_bwd_sym_train_parts")
+                self._ticked = self.early_tick
+                return
             _lib.check(lib.clica_lp_loss_bwd_sym_train(C.byref(self.desc), y1.data_ptr(), n, pool.data_ptr(), n,
                                                        lse.data_ptr(), pool_lse.data_ptr(), self.dy[:B].data_ptr(), n, o[3 * B:].data_ptr(),
                                                        self.step_dev.data_ptr() if self.early_tick else None,
@@ -532,6 +545,22 @@ class ContrastiveTrainer:
                                              lse.data_ptr(), pool_lse.data_ptr(), None, None, None,
                                              self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n,
                                              self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd_sym")
+
+    def _chain_tail_ok(self) -> bool:
+        if not hasattr(self, "_tail_ok"):
+            self._tail_ok = (os.environ.get("CLICA_CHAIN_TAIL", "1") != "0" and self.dz_out[0] is not None and
+                             ops.mlp_chain_tail_supported([tuple(lin.weight.shape) for lin in self.linears]))
+        return self._tail_ok
+
+    def _chain_takes_partials(self, emu: bool) -> bool:
+        """Will THIS step's backward chain run with its tail (clica_mlp_dgrad_split_tail) directly on dy?  Then it can finish dy itself."""
+        if os.environ.get("CLICA_FOLD_DY_REDUCE", "1") == "0" or not getattr(self, "_in_step", False):
+            return False
+        if self.dp or emu or self.head is not None or not (self.split_bf16 and self.split_wgrad and self.fused_backward):
+            return False
+        if self.fuse_tick and not self.early_tick:
+            return False
+        return self._adam_folds_into_wgrad() and self._chain_tail_ok()
 
     def _head_backward(self):
         """d loss / d (pre-head output): the head's backward (and its parameter gradient), or dy itself."""
@@ -567,12 +596,13 @@ class ContrastiveTrainer:
             if getattr(self, "_fold_adam", False) and self.split_wgrad and not (self.fuse_tick and not self._ticked):
                 # inside a training step (N = 1): the chain's workgroups also leave the n-wide first / last layer's weight-gradient
                 # slabs (clica_mlp_dgrad_split_tail) -- weight_grads() then needs no tiny-dimension launch
-                if not hasattr(self, "_tail_ok"):
-                    self._tail_ok = (os.environ.get("CLICA_CHAIN_TAIL", "1") != "0" and self.dz_out[0] is not None and
-                                     ops.mlp_chain_tail_supported([tuple(lin.weight.shape) for lin in self.linears]))
-                if self._tail_ok:
-                    tail = dict(a_last=self.acts_out[L - 2], x=self.x, shapes=[tuple(lin.weight.shape) for lin in self.linears], ws=self.group_ws)
+                if self._chain_tail_ok():
+                    tail = dict(a_last=self.acts_out[L - 2], x=self.x, shapes=[tuple(lin.weight.shape) for lin in self.linears], ws=self.group_ws,
+                                dy_parts=getattr(self, "_dy_parts", None))
                     self._tail_ready = True
+            if getattr(self, "_dy_parts", None) is not None and (tail is None or g is not self.dy):
+                raise _lib.ClicaError("engine: the loss left its partials for the backward chain, but the chain does not run with its tail on dy")
+            self._dy_parts = None
             ops.mlp_dgrad_chain_split(g, ws, self.packed_t, [self.dz_out[l - 1] for l in chain], self.slope,
                                       masks_chain=[self.signmasks[l - 1] for l in chain],
                                       planes=[self.dz_planes[l - 1] for l in chain] if self.split_wgrad else None, state=self.s16, tail=tail)
@@ -813,12 +843,13 @@ class ContrastiveTrainer:
         self.forward()
         if st:
             ops.stamp(st["mlp_fwd"], 1)
-        self.loss_forward_backward()
-        self._fold_adam = self._adam_folds_into_wgrad()
+        self._in_step = True                   # (loss_forward_backward may leave dy to be finished by this step's backward chain)
         try:
+            self.loss_forward_backward()
+            self._fold_adam = self._adam_folds_into_wgrad()
             self.backward()
         finally:
-            self._fold_adam = False
+            self._fold_adam = self._in_step = False
         self.optimizer_step()
         if self.s16 is not None and not getattr(self, "_s16_updated", False):
             self.s16.update()                  # this step's recorded maxima -> the next step's scales (normally inside the Adam launch)

@@ -376,8 +376,10 @@ def mlp_dgrad_chain_split(dy: torch.Tensor, weights_chain, packed_split_t: torch
         shapes = [tuple(sh) for sh in tail["shapes"]]
         Le = len(shapes)
         N32, K32 = (C.c_int32 * Le)(*[sh[0] for sh in shapes]), (C.c_int32 * Le)(*[sh[1] for sh in shapes])
+        parts = tail.get("dy_parts")          # _lib.DyParts filled by clica_lp_loss_bwd_sym_train_parts: the chain's prologue finishes dy
         desc = _lib.ChainTail(a_last=al.data_ptr(), lda=lda, x=xx.data_ptr(), ldx=ldx, n_layers=Le, N=N32, K=K32,
-                              wgrad_workspace=tail["ws"].data_ptr(), wgrad_workspace_bytes=tail["ws"].numel())
+                              wgrad_workspace=tail["ws"].data_ptr(), wgrad_workspace_bytes=tail["ws"].numel(),
+                              dy_parts=C.pointer(parts) if parts is not None else None)
         check(load().clica_mlp_dgrad_split_tail(*args, None if state is None else state.buf.data_ptr(), C.byref(desc), stream_ptr()),
               "clica_mlp_dgrad_split_tail")
     elif state is None:

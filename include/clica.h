@@ -179,6 +179,26 @@ int clica_lp_loss_bwd_sym_train(const clica_lp_loss_desc* d,
                                 const float* lse_i, const float* pool_lse,
                                 float* dz1, int64_t ldd1, float* means, int32_t* tick_counter /* NULL, or a device counter to advance by 1 */,
                                 void* workspace, size_t workspace_bytes, clica_stream_t stream);
+/* The same call WITHOUT its closing reduction launch: the symmetric sweep's per-split partials stay in the workspace and `parts` (host
+ * struct, filled here) tells the consumer what that launch would have done -- dz1[i][k] += sum over the splits of part[split][i][k], the
+ * forward's three means from the row blocks' sums, the counter tick.  clica_mlp_dgrad_split_tail takes it and does all three in its
+ * prologue (the training step then has no launch between the pair sweep and the backward chain; same sums in the same order, bit for
+ * bit).  Which sweep wrote the partials -- matrix cores or, beyond the guard's limit, coordinate differences -- is read from the guard
+ * words on the device, as the reduction launch does.  Reference: the backward of losses.py:430-477 through main_mlp.py:274-285. */
+typedef struct clica_lp_dy_parts {
+  const float* part;                 /* [nsplit][rows][np] */
+  int32_t nsplit, nsplit_alt;        /* splits of the sweep that ran by default / of the other one (guard) */
+  int32_t np, n;                     /* padded / real row width */
+  int64_t rows;
+  const float* guard_words;          /* NULL: no guard, nsplit is final */
+  float guard_limit;
+  const float* blocksums; int32_t nblocks; float inv_count; float* means;      /* the forward's loss / pos / neg means */
+  int32_t* tick;                     /* device counter to advance by 1, or NULL */
+} clica_lp_dy_parts;
+int clica_lp_loss_bwd_sym_train_parts(const clica_lp_loss_desc* d,
+                                      const float* z1, int64_t ld1, const float* pool, int64_t ldp,
+                                      const float* lse_i, const float* pool_lse, float* means, int32_t* tick_counter,
+                                      void* workspace, size_t workspace_bytes, clica_lp_dy_parts* parts, clica_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Dot-product InfoNCE  --  SimCLRLoss.loss, /root/reference/losses.py:177-202
@@ -410,6 +430,7 @@ typedef struct clica_chain_tail {
   const float* x; int64_t ldx;           /* [M][K[0]]   encoder input */
   int32_t n_layers; const int32_t* N; const int32_t* K;
   void* wgrad_workspace; size_t wgrad_workspace_bytes;
+  const clica_lp_dy_parts* dy_parts;     /* NULL, or: dY (which must be writable) still lacks the pair sweep's partials -- see clica_lp_dy_parts */
 } clica_chain_tail;
 int clica_mlp_chain_tail_supported(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t* supported);
 /* state == NULL: bf16x3 (clica_mlp_dgrad_split), else f16x2 (clica_mlp_dgrad_split16) */

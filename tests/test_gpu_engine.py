@@ -461,3 +461,41 @@ def test_matrix_core_loss_on_training_embeddings():
             PARITY.check("matrix_core_loss_training_regime", case, "d loss / d y", res[1][0].cpu().numpy(), res[0][0].cpu().numpy())
     finally:
         _lib.check(lib.clica_lp_loss_set_matrix_cores(-1), "restore")
+
+
+def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypatch):
+    """N = 1 training step without the loss's closing reduction launch (clica_lp_loss_bwd_sym_train_parts -> clica_mlp_dgrad_split_tail with
+    dy_parts: the backward chain's prologue sums the pair sweep's partials, leaves the forward's means and ticks the counter) == the step
+    with that launch, bit for bit: reported means, dy, every parameter and the step counter after several steps, eager and in graph
+    replay, inside the guard's limit and -- the last layer scaled up -- on the difference sweeps (the other split count)."""
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+
+    def run(fold: bool, scale_last: float, graph: bool):
+        monkeypatch.setenv("CLICA_FOLD_DY_REDUCE", "1" if fold else "0")
+        torch.manual_seed(7)
+        n, B = 10, 1536
+        f = encoders.get_mlp(n, n, [100, 500, 500, 100]).to("cuda")
+        if scale_last != 1.0:
+            last = [m for m in f if isinstance(m, torch.nn.Linear)][-1]
+            with torch.no_grad():
+                last.weight.mul_(scale_last); last.bias.mul_(scale_last)
+        gW = (torch.randn(3, n, n) / n ** 0.5).to("cuda")
+        tr = ContrastiveTrainer(f, gW, SamplerSpec(space="box", n=n, seed=5), batch_size=B, p=2, lr=1e-3, device="cuda")
+        if graph:
+            tr.capture(warmup=2)
+        outs = [tr.step().clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        took = getattr(tr, "_dy_parts_taken", None)
+        return (torch.stack(outs), tr.dy.clone(), tr.param_arena.clone(), int(tr.steps_done), tr.loss_guard(), took, bool(tr.split_bf16))
+
+    for scale_last, graph in ((1.0, False), (1.0, True), (300.0, False)):
+        a = run(True, scale_last, graph)
+        b = run(False, scale_last, graph)
+        assert a[3] == b[3] == 4, (a[3], b[3])
+        if a[6]:      # (split arithmetics: the whole-stack chain with its tail; the native-fp32 engine keeps the reduction launch)
+            assert (a[5] or 0) > 0 and not b[5], (a[5], b[5])          # the first trainer took the folded path, the second did not
+        for x, y, what in zip(a[:3], b[:3], ("means", "dy", "parameters")):
+            assert torch.equal(x, y), (what, scale_last, graph, float((x - y).abs().max()))
+        if scale_last > 1.0 and a[4]["limit"] > 0.0:
+            assert a[4]["fallback_steps"] > 0, a[4]          # this case did run on the difference sweeps
