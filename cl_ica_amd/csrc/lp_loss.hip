@@ -70,14 +70,16 @@ __device__ __forceinline__ void coef_row(
     const float* __restrict__ g_mean, const float* __restrict__ g_item,
     const float* __restrict__ g_pos, const float* __restrict__ g_neg,
     float* __restrict__ statL, float* __restrict__ statC,
-    float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2) {
+    float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2, float* statC_value = nullptr) {
   const float inv_rows = 1.f / (float)rows;
   const float gi = (g_mean ? g_mean[0] : 1.f) * inv_rows + (g_item ? g_item[i] : 0.f);
   const float A = 2.f * alpha * gi + (g_pos ? g_pos[0] * inv_rows : 0.f);
   const float C = 2.f * (1.f - alpha) * gi + (g_neg ? g_neg[0] * inv_rows : 0.f);
   statL[i] = L2;      // row statistic stays in the log2 domain end to end: no ln <-> log2 round trip of a number that is
                       // ~10^3 in saturated rows (each rounding of it is a 1e-4 relative error on every weight of the row)
-  statC[i] = q.xs * C / tau;
+  const float sc = q.xs * C / tau;
+  statC[i] = sc;
+  if (statC_value) *statC_value = sc;       // (the caller's copy: reading statC[i] back is a load behind this thread's own stores -- a vmcnt(0))
   if (!dz1 && !dz2) return;
   if (dot) {
     float pos = 0.f;
@@ -210,11 +212,12 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
     const float lp = pos / tau;
     const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
     loss_i[i] = li; pos_i[i] = lp; lse_i[i] = L2;
+    float sc_i = 0.f;
     if (T.statL)
       coef_row(i, rows, ra, rb, q, tau, alpha, compat, frac, dot, L2, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
-               T.dz1, T.ldd1, T.dz2, T.ldd2);
+               T.dz1, T.ldd1, T.dz2, T.ldd2, &sc_i);
     v_loss = li; v_pos = lp; v_lse = lse;
-    if (F.FP) ush[lane_row] = T.statC[i] * fexp2(-L2);      // u_i (this thread's own store, read back)
+    if (F.FP) ush[lane_row] = sc_i * fexp2(-L2);            // u_i = C_i 2^-L_i (the value coef_row has just stored in statC[i])
   } else if (F.FP && grp == 0) {
     ush[lane_row] = 0.f;
   }
