@@ -85,6 +85,9 @@ def parse():
                          "(roofline.traffic then falls back to the committed profile)")
     ap.add_argument("--no-conv-configs", action="store_true", help="skip the c4 / c5 legs of `secondary`")
     ap.add_argument("--no-dry-leg", action="store_true", help="skip the `dry_ranks_8` leg (rank 0 of an 8-rank job planned, captured and run on this GPU; N = 1 only)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only the multi-rank control flow (rendezvous, barrier-bracketed windows, max over ranks, one JSON line from rank 0) around a "
+                         "stub step; works on CPU ranks over gloo.  Nothing is measured")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in leg (the reference's train_step on the swapped-in modules, N = 1 only)")
     return ap.parse_args()
 
@@ -413,21 +416,26 @@ def roofline_leg(tr, reps=20):
                 break
     except Exception:
         pass
-    roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(issued_factor * top["tflops"], 2),
-            "peak": peak, "unit": "TFLOP/s", "frac": round(issued_factor * top["tflops"] / peak, 4),
+    # `achieved` / `frac`: ALGORITHMIC flops (2MNK per Linear application) / launch time against the peak of the matrix
+    # pipe the kernel runs on; the flops the emulation ISSUES (3 or 6 piece products per fp32 product) are pipe
+    # utilisation and sit beside it as `achieved_issued` / `frac_issued`
+    roof = {"kernel": top["kernel"], "op": top["op"], "bound": "mfma", "achieved": round(top["tflops"], 2),
+            "peak": peak, "unit": "TFLOP/s", "frac": round(top["tflops"] / peak, 4),
+            "achieved_issued": round(issued_factor * top["tflops"], 2), "frac_issued": round(issued_factor * top["tflops"] / peak, 4),
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": top.get("alg_bytes"), "avg_launch_us": round(top["avg_us"], 2), "launches_per_step": top["launches_per_step"],
             "algorithmic_gflop_per_launch": round(top["gflop_per_launch"], 4), "dtype": note}
     if top.get("shader_clock_ghz"):
         ghz = top["shader_clock_ghz"]
         roof["shader_clock_ghz"] = ghz
-        roof["frac_at_measured_clock"] = round(issued_factor * top["tflops"] / (peak * ghz / NOMINAL_GHZ), 4)
+        roof["frac_at_measured_clock"] = round(top["tflops"] / (peak * ghz / NOMINAL_GHZ), 4)
+        roof["frac_issued_at_measured_clock"] = round(issued_factor * top["tflops"] / (peak * ghz / NOMINAL_GHZ), 4)
         roof["clock_note"] = ("shader clock over the kernel's in-step brackets (a one-wave probe on a side stream samples s_memtime / s_memrealtime every 10 us, clica_clock_probe); "
                               "`peak` is the nominal %.1f GHz figure, `frac_at_measured_clock` prices the same launch against the matrix rate "
                               "at the clock the chip actually held" % NOMINAL_GHZ)
     if issued_factor != 1.0:
-        roof["flops_counted"] = ("issued fp16 flops = 3 x algorithmic 2MNK (three piece products per fp32 product), against the dense fp16 / bf16 MFMA peak"
-                                 if issued_factor == 3.0 else
-                                 "issued bf16 flops = 6 x algorithmic 2MNK (six piece products per fp32 product), against the dense bf16 MFMA peak")
+        roof["flops_counted"] = ("`achieved` / `frac`: algorithmic 2MNK against the dense fp16 / bf16 MFMA peak; `*_issued`: x %d (the piece products one fp32 "
+                                 "product costs in this arithmetic) = matrix-pipe utilisation; the emulation's own ceiling is peak / %d fp32-equivalent"
+                                 % (int(issued_factor), int(issued_factor)))
         roof["fp32_equivalent"] = {"achieved": round(top["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(top["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
                                    "what": "algorithmic 2MNK per launch / launch time, against the fp32 matrix peak that bounds the native-fp32 kernel"}
@@ -607,6 +615,9 @@ def capture_or_eager(tr, args, rank, world, device):
     use_graph = not args.no_graph
     if use_graph:
         try:
+            inj = os.environ.get("CLICA_BENCH_INJECT_CAPTURE_FAILURE")      # test hook: "all" or a rank number (tests/test_gpu_bench.py)
+            if inj is not None and world > 1 and inj in ("all", str(rank)):
+                raise RuntimeError("injected capture failure (CLICA_BENCH_INJECT_CAPTURE_FAILURE)")
             tr.capture()
         except Exception as e:   # e.g. a RCCL build that cannot capture collectives: run eagerly, say so
             if world == 1:
@@ -627,9 +638,10 @@ def timed_windows(tr, steps, warmup, windows, world, device):
     """`warmup` untimed steps (+ >= 60 ms of continuous work: the chip settles at its sustained clock only after tens of
     milliseconds, see _graph_time), then `windows` windows of EXACTLY `steps` steps, every window bracketed by barrier +
     synchronize on both sides and reduced with MAX over the ranks.  Returns (window seconds, extra warm-up steps)."""
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)   # (--launch-check runs on CPU ranks too)
     for _ in range(warmup):
         tr.step()
-    torch.cuda.synchronize()
+    sync()
     extra_warm = 0
     if world == 1:
         t_w = time.perf_counter()
@@ -637,7 +649,7 @@ def timed_windows(tr, steps, warmup, windows, world, device):
             for _ in range(10):
                 tr.step()
             extra_warm += 10
-            torch.cuda.synchronize()
+            sync()
     else:               # a FIXED count under data parallelism: every rank must run the same number of collective-bearing steps
         extra_warm = max(0, 80 - warmup)
         for _ in range(extra_warm):
@@ -646,11 +658,11 @@ def timed_windows(tr, steps, warmup, windows, world, device):
     for _ in range(max(1, windows)):
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             tr.step()
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -914,14 +926,66 @@ def dry_ranks_leg(args, device, R=8, steps=50, windows=3):
                 pass
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks ourselves (one process per GPU,
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1 and a free port) with the same arguments, pass
+    their stdout / stderr through (rank 0's JSON line stays the last line of stdout) and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # `--` ends torchrun's own options: bench.py's `--n` would otherwise be claimed as an abbreviation of torchrun's `--nnodes`
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "--", os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks on 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, rank, world, device):
+    """`--launch-check`: the multi-rank control flow of this file WITHOUT the engine -- rendezvous, `timed_windows` (barrier +
+    synchronize on both sides of every window, MAX over the ranks) around a step that is one small all-reduce, process group torn
+    down and C stdio flushed before rank 0 prints the contract-shaped line.  Runs on CPU ranks over gloo as well (tests/
+    test_host_logic.py::test_bench_self_launch_two_ranks); `value` is null: nothing is measured."""
+    class _Stub:
+        def __init__(self):
+            self.t = torch.ones(8, device=device)
+
+        def step(self):
+            if world > 1:
+                dist.all_reduce(self.t)
+                self.t /= world
+    stub = _Stub()
+    window_s, extra_warm = timed_windows(stub, args.steps, args.warmup, args.windows, world, device)
+    seen = torch.tensor([1.0], device=device)
+    if world > 1:
+        dist.all_reduce(seen)
+        dist.barrier()
+        dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no engine, nothing measured)", "value": None, "unit": "steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "launch check", "parallelism": f"dp{world}"},
+                          "launch_check": {"ranks_seen": int(seen.item()), "windows": len(window_s), "device": device.type,
+                                           "value_all_reduced": float(stub.t[0].item())}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     from cl_ica_amd.distributed import init_from_env
     rank, world, device = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or unset WORLD_SIZE: bench.py then starts the ranks itself)")
+    if args.launch_check:
+        return launch_check(args, rank, world, device)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if args.dry_ranks and args.dry_ranks > 1:
         if world != 1:
             raise SystemExit("--dry-ranks runs in ONE process on one GPU")

@@ -20,11 +20,14 @@ def test_bench_emits_contract_line():
         assert k in line, k
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["value"] > 100
     assert line["metric"] == "training steps/sec (B=6144, n=10 MLP)" and "f16x2 split" in line["dtype"]
-    rf = line["roofline"]      # headline mode: issued fp16 flops (3 x algorithmic) against the dense fp16 / bf16 peak, fp32-equivalent figure next to it
+    rf = line["roofline"]      # headline mode: ALGORITHMIC flops against the dense fp16 / bf16 peak; the issued piece products (x 3) beside it
     assert rf["bound"] == "mfma" and 0 < rf["frac"] < 1 and rf["peak"] == 2500.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert abs(rf["frac_issued"] - 3 * rf["frac"]) < 2e-3 and abs(rf["achieved_issued"] - 3 * rf["achieved"]) < 0.05
+    # `achieved` must follow from the line's own numbers: algorithmic GFLOP per launch / the launch's measured duration
+    assert abs(rf["achieved"] - rf["algorithmic_gflop_per_launch"] / rf["avg_launch_us"] * 1e-3 * 1e3) < 0.02 * rf["achieved"]
     fe = rf["fp32_equivalent"]
     # (the fp32-EQUIVALENT rate may exceed the fp32 matrix peak: the three fp16 products of one fp32 product cost 0.19 of its matrix time)
-    assert fe["peak"] == 157.3 and 0 < fe["frac"] < 5.0 and abs(3 * fe["achieved"] - rf["achieved"]) < 0.05 * rf["achieved"]
+    assert fe["peak"] == 157.3 and 0 < fe["frac"] < 5.0 and abs(fe["achieved"] - rf["achieved"]) < 0.05 * rf["achieved"]
     b3 = line["split_bf16x3"]      # the rounds 3-4 arithmetic on the same box in the same call
     assert b3["value"] > 100 and abs(b3["final_loss"]) < 20
     dr = line["dry_ranks_8"]       # rank 0 of an 8-rank job planned, captured with its RCCL collectives and run on this GPU
@@ -33,3 +36,24 @@ def test_bench_emits_contract_line():
     nat = line["native_fp32"]
     assert nat["value"] > 100 and nat["dtype"] == "f32" and nat["roofline"]["peak"] == 157.3 and 0 < nat["roofline"]["frac"] < 1
     assert abs(line["final_loss"]) < 20 and abs(nat["final_loss"]) < 20
+
+
+def test_bench_gpus_2_starts_its_own_ranks_and_falls_back_to_eager():
+    """`python bench.py --gpus 2 ...` exactly as the driver types it for N = 1 (no torchrun, no WORLD_SIZE): bench.py starts the two
+    ranks itself.  On this one-GPU box both ranks share cuda:0 and the collectives run over gloo (RCCL refuses two ranks on one
+    device), and the capture is made to fail on every rank, so the run also covers `capture_or_eager`'s agreement on eager launches
+    (VERDICT r5 item 3).  The product collectives, the barrier-bracketed windows, the max over ranks, the `ranks` object and the
+    single JSON line from rank 0 are the real ones; the numbers mean nothing."""
+    env = dict(os.environ, CLICA_SHARE_DEVICE="1", CLICA_DIST_BACKEND="gloo", CLICA_BENCH_INJECT_CAPTURE_FAILURE="all", PYTHONFAULTHANDLER="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--windows", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "eager launches" in r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["launch"] == "eager" and line["config"]["negatives_pool"] == 2 * 6144 and line["config"]["parallelism"] == "dp2"
+    assert [e["rank"] for e in line["ranks"]] == [0, 1] and all(e["world_size_seen"] == 2 for e in line["ranks"])
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith("{")) == 1        # only rank 0 prints
+    assert abs(line["final_loss"]) < 20

@@ -529,3 +529,26 @@ def test_conv_stack_formulation_and_layouts_on_cpu():
     back = [gs[0].view(32, 4, 4, 1).permute(0, 3, 1, 2)] + [conv._wg_to_conv(gs[l], *m["shapes"][l][:2]) for l in (1, 2, 3)] + [conv._w5_back(gs[4])]
     for i, mp in enumerate(m["unpack"]):
         assert torch.equal(gs[i].reshape(-1)[mp.long()].view(m["shapes"][i]), back[i].contiguous()), i
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` without a torchrun environment starts its own two ranks (the driver's command
+    shape for N > 1 must not need a launcher).  `--launch-check` swaps the engine for a stub so the control flow -- rendezvous on
+    127.0.0.1, barrier-bracketed windows, max over ranks, teardown, ONE JSON line from rank 0 -- runs on CPU ranks over gloo."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--windows", "2",
+                        "--n", "10", "--launch-check"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["launch_check"]["ranks_seen"] == 2 and line["launch_check"]["windows"] == 2
+    # a mismatch between --gpus and an inherited WORLD_SIZE is still refused loudly
+    r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
