@@ -728,8 +728,8 @@ def secondary_leg(args, device, steps=20, windows=3):
                "whole_step_encoder_tflops": round(3 * 2 * 13632000 * 2 * a.batch_size / (el / steps) / 1e12, 1)}
         if ranks == 1 and not args.no_roofline:
             roof, rows = roofline_leg(tr, reps=5)
-            ent["roofline"] = {k: roof[k] for k in ("kernel", "op", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
-                                                    "algorithmic_gflop_per_launch", "dtype")}
+            ent["roofline"] = {k: roof[k] for k in ("kernel", "op", "achieved", "peak", "unit", "frac", "achieved_issued", "frac_issued", "avg_launch_us",
+                                                    "launches_per_step", "algorithmic_gflop_per_launch", "dtype")}
             ent["kernels"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
             ll = loss_leg(tr, reps=5)
             ent["loss_kernel"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in ll.items()}
