@@ -123,6 +123,9 @@ SIGNATURES: Dict[str, list] = {
     "clica_split16_update": [C.c_void_p, c_i32, C.c_void_p],
     "clica_split16_read": [C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p],
     "clica_split16_clear_flags": [C.c_void_p, C.c_void_p],
+    "clica_split16_guard": [C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p],
+    "clica_split16_set_dp_poison": [C.c_void_p, C.c_void_p, C.c_void_p],
+    "clica_split16_poison_export": [C.c_void_p, C.c_void_p, C.c_void_p],
     "clica_mlp_planes16_bytes": [c_i64, c_i32, c_i32, C.POINTER(c_size)],
     "clica_mlp_pack_split16_bytes": [c_i32, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.POINTER(c_size)],
     "clica_mlp_pack_split16_both": [c_i32, C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.c_void_p,

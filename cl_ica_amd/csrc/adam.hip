@@ -19,8 +19,11 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
   // one tensor each -- every producer of the step has finished by stream order, and the next step's pack launch (the first reader of
   // the new scales) comes behind it
   const unsigned nupd = s16_state ? (unsigned)s16::kS16UpdateBlocks : 0u;
-  if (blockIdx.x < nupd) { s16::split16_update_tensor(s16_state, s16_layers, (int)blockIdx.x); return; }
+  if (blockIdx.x < nupd) { s16::split16_update_tensor(s16_state, s16_layers, (int)blockIdx.x, step_dev); return; }
   const unsigned nwork = gridDim.x - nupd, block = blockIdx.x - nupd;
+  // the guard (split16.h): a producer of this step cut a tensor that had outgrown its scale -- parameters and moments stay as they are,
+  // the update above takes the step counter back and the next replay redoes the step on the scales this one measured
+  if (s16_state && s16::s16_step_poisoned(s16_state)) return;
   __shared__ Consts s_c;
   if (threadIdx.x == 0) s_c = consts_of(step_dev[0] + t_offset, lr, b1, b2);
   __syncthreads();

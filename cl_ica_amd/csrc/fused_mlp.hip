@@ -802,6 +802,8 @@ __device__ __forceinline__ void pack2_block(const Pack2Args& a, const unsigned b
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
   const unsigned wid = (unsigned)(idx >> 6);
   if ((threadIdx.x & 63) == 0 && wid < kS16CapPW && a.layer[sidx] >= 0) s16_partW(a.st)[wid] = __float_as_uint((m <= 3.0e38f) ? m / sc : 3.4e38f);
+  if ((threadIdx.x & 63) == 0 && !(m <= kF16Alarm)) s16::s16_raise_poison(a.st);      // the guard: a weight that does not fit its layer's scale (parameters set from outside)
+  if (block == 0 && threadIdx.x == 0) s16::s16_refresh_gen(a.st);
   if (block == 0 && threadIdx.x <= Split16State::NT) {      // wave ranges of the layers (forward-orientation segments come first, one per layer)
     const int l = threadIdx.x;
     a.st->wfirst[l] = (unsigned)(a.first[l < a.nfwd ? l : a.nfwd] >> 6);
@@ -827,19 +829,27 @@ __global__ __launch_bounds__(64) void split16_init_k(Split16State* st, unsigned 
   const int t = threadIdx.x;
   if (t < Split16State::NT) st->sA[t] = st->sD[t] = st->sW[t] = st->sWC[t] = st->pA[t] = st->pD[t] = 1.f;
   if (t < Split16State::NT) st->cntA[t] = st->cntD[t] = st->cntW[t] = 0u;
-  if (t == 0) { st->flags = 0u; st->updates = 0u; st->nPW = 0u; st->capWG = capWG; st->capPW = capPW; }
+  if (t == 0) {
+    st->flags = 0u; st->updates = 0u; st->nPW = 0u; st->capWG = capWG; st->capPW = capPW;
+    st->gen_copy = 0xFFFFFFFEu; st->poison = 0xFFFFFFFFu; st->skipped = 0u; st->dp_poison = nullptr;      // the guard (split16.h): no step poisoned
+  }
 }
 
 // Debug build only (-DCLICA_SPLIT_TRACE, tools/split_trace.py): s_memtime stamps per (workgroup, wave, layer, phase), kept in
 // registers and written once at the end of the kernel
 #ifdef CLICA_SPLIT_TRACE
+// (round 6: the stamps live in LDS behind the kernel's own words -- as a dynamically indexed private array they put the trace build on
+//  scratch memory, 528 B per lane, which the product kernel does not use)
 __device__ unsigned long long* g_strace = nullptr;
 #define ST_NS 8
-#define ST_DECL unsigned long long st_ts[MAXL][ST_NS] = {}
-#define ST_STAMP(l, ph) do { st_ts[l][ph] = __builtin_readcyclecounter(); } while (0)
-#define ST_FLUSH(L) do { if (g_strace && lane == 0) { for (int l_ = 0; l_ < MAXL; ++l_) for (int q_ = 0; q_ < ST_NS; ++q_) \
-      g_strace[(((size_t)blockIdx.x * WAVES + wave) * MAXL + l_) * ST_NS + q_] = st_ts[l_][q_]; } } while (0)
+#define ST_LDS_BYTES (WAVES * MAXL * ST_NS * 8)
+#define ST_DECL unsigned long long* st_lds = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(planes) + (size_t)Arith<AR>::NP * PLANE * 2 + (size_t)a.boff[a.g.L] * 4 + 256); \
+  for (int i_ = lane; i_ < MAXL * ST_NS; i_ += 64) st_lds[wave * MAXL * ST_NS + i_] = 0ull
+#define ST_STAMP(l, ph) do { if (lane_id == 0) st_lds[(wave * MAXL + (l)) * ST_NS + (ph)] = __builtin_readcyclecounter(); } while (0)
+#define ST_FLUSH(L) do { if (g_strace) { for (int i_ = lane_id; i_ < MAXL * ST_NS; i_ += 64) \
+      g_strace[((size_t)blockIdx.x * WAVES + wave) * MAXL * ST_NS + i_] = st_lds[wave * MAXL * ST_NS + i_]; } } while (0)
 #else
+#define ST_LDS_BYTES 0
 #define ST_DECL do { } while (0)
 #define ST_STAMP(l, ph) do { } while (0)
 #define ST_FLUSH(L) do { } while (0)
@@ -857,6 +867,7 @@ struct SplitArgs {
   // slot array for the maxima (same positions), count_t: where workgroup 0 leaves the number of slots written.
   // `last_unscaled`: the last layer's output is not re-split (fp32 consumer only): its scale is 1 whatever s_t[L] says.
   const float* s_t; const float* s_w; unsigned* part_t; unsigned* count_t; unsigned cap_wg; int last_unscaled;
+  Split16State* st16;            // the guard (split16.h): where a workgroup announces a tensor that outgrew its scale
   // Backward chain of a training step (clica_mlp_dgrad_split_tail): behind its last link every workgroup also leaves the partial weight
   // gradients of the encoder's n-wide FIRST and LAST layer over its 48 rows (fp32 vector ALU, as wgrad_tiny_k computes them), one slab
   // per workgroup in the weight-gradient workspace -- the separate wgrad_tiny_k launch (12.8 us, latency-bound) is gone from the step.
@@ -1855,6 +1866,13 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
   if constexpr (AR == 1) {        // (behind the last layer's closing barrier) this workgroup's slot of the maxima
     if (blockIdx.x < a.cap_wg && threadIdx.x < Split16State::NT) a.part_t[(size_t)threadIdx.x * kS16CapWG + blockIdx.x] = amax_lds[threadIdx.x];
     if (blockIdx.x == 0 && (int)threadIdx.x <= g.L) a.count_t[threadIdx.x] = gridDim.x < a.cap_wg ? gridDim.x : a.cap_wg;
+    // the guard: tensor t of this launch (0: its input, l + 1: output of layer l) was cut to fp16 on scale s_t[t]; a maximum beyond the
+    // alarm (or a non-finite one) in this workgroup's rows poisons the step (the last layer's output stays fp32 when nobody re-splits it)
+    if ((int)threadIdx.x <= g.L && !((int)threadIdx.x == g.L && a.last_unscaled)) {
+      const float m = __uint_as_float(amax_lds[threadIdx.x]);
+      if (!(m * a.s_t[threadIdx.x] <= kF16Alarm)) s16::s16_raise_poison(a.st16);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) s16::s16_refresh_gen(a.st16);
   }
   if (a.tail.slab_l) tail_wgrad(a.tail, row0, nrows, wave, lane_id);
   ST_FLUSH(g.L);
@@ -2126,15 +2144,15 @@ static int launch_split(fmlp::SplitArgs& a, int arith, clica_stream_t stream, co
   }
   if (arith == 1) {
     if (!slope01) { set_error("%s: the f16x2 arithmetic needs a LeakyReLU slope in (0, 1), got %g", who, (double)a.g.slope); return CLICA_E_INVALID; }
-    const size_t lds = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256;
-    constexpr size_t lds_max = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256;
+    const size_t lds = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256 + ST_LDS_BYTES;
+    constexpr size_t lds_max = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256 + ST_LDS_BYTES;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
     (void)once;
     hipLaunchKernelGGL(mlp_split_k<1>, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
     return launch_status(who);
   }
-  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256;      // + the waves' progress words
-  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256;
+  const size_t lds = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256 + ST_LDS_BYTES;      // + the waves' progress words
+  constexpr size_t lds_max = 3 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256 + ST_LDS_BYTES;
   static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
   (void)once;
   hipLaunchKernelGGL(mlp_split_k<0>, dim3((unsigned)ceil_div(a.g.M, ROWS)), dim3(THREADS), lds, as_stream(stream), a);
@@ -2174,7 +2192,7 @@ static int mlp_fwd_split_impl(const float* X, int64_t ldx, int64_t M, const floa
   if (state16) {
     Split16State* st = reinterpret_cast<Split16State*>(state16);
     CLICA_CHECK_ARG(ceil_div(M, (int64_t)ROWS) <= (int64_t)kS16CapWG, "clica_mlp_fwd_split16: M = %lld rows exceeds the state's %u workgroup slots", (long long)M, kS16CapWG);
-    a.s_t = st->sA; a.s_w = st->sW; a.part_t = s16_partA(st); a.count_t = st->cntA; a.cap_wg = kS16CapWG;
+    a.s_t = st->sA; a.s_w = st->sW; a.part_t = s16_partA(st); a.count_t = st->cntA; a.cap_wg = kS16CapWG; a.st16 = st;
     a.last_unscaled = (planes && planes[n_layers - 1]) ? 0 : 1;
   }
   return launch_split(a, state16 ? 1 : 0, stream, state16 ? "clica_mlp_fwd_split16" : "clica_mlp_fwd_split");
@@ -2228,7 +2246,7 @@ static int mlp_dgrad_split_impl(const float* dY, int64_t lddy, int64_t M, int32_
   if (state16) {
     Split16State* st = reinterpret_cast<Split16State*>(state16);
     CLICA_CHECK_ARG(ceil_div(M, (int64_t)ROWS) <= (int64_t)kS16CapWG, "clica_mlp_dgrad_split16: M = %lld rows exceeds the state's %u workgroup slots", (long long)M, kS16CapWG);
-    a.s_t = st->sD; a.s_w = st->sWC; a.cap_wg = kS16CapWG; a.part_t = s16_partD(st); a.count_t = st->cntD;
+    a.s_t = st->sD; a.s_w = st->sWC; a.cap_wg = kS16CapWG; a.part_t = s16_partD(st); a.count_t = st->cntD; a.st16 = st;
     a.last_unscaled = (planes && planes[n_links - 1]) ? 0 : 1;
   }
   if (tail) {      // the n-wide first / last layer's weight-gradient slabs behind the last link (SplitArgs::Tail)
@@ -2313,6 +2331,32 @@ extern "C" int clica_split16_read(const void* state, int32_t* flags, int32_t* up
     if (last_scales_d) last_scales_d[i] = h.pD[i];
   }
   return CLICA_OK;
+}
+extern "C" int clica_split16_guard(const void* state, int32_t* flags, int32_t* skipped, int32_t* updates, int32_t* poisoned, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr, "clica_split16_guard: state is NULL");
+  fmlp::Split16State h;
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(&h, state, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return launch_status("clica_split16_guard");
+  if (flags) *flags = (int32_t)h.flags;
+  if (skipped) *skipped = (int32_t)h.skipped;
+  if (updates) *updates = (int32_t)h.updates;
+  if (poisoned) *poisoned = (h.poison == h.gen_copy) ? 1 : 0;      // the step whose producers ran last (data parallel: this rank's own verdict)
+  return CLICA_OK;
+}
+namespace clica { namespace fmlp {
+__global__ void split16_poison_export_k(const Split16State* st, float* slot) { slot[0] = (st->poison == st->gen_copy) ? 1.f : 0.f; }
+__global__ void split16_set_dp_k(Split16State* st, const float* slot) { st->dp_poison = slot; }
+} }
+extern "C" int clica_split16_set_dp_poison(void* state, const float* slot, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr, "clica_split16_set_dp_poison: state is NULL");
+  hipLaunchKernelGGL(fmlp::split16_set_dp_k, dim3(1), dim3(1), 0, as_stream(stream), reinterpret_cast<fmlp::Split16State*>(state), slot);
+  return launch_status("clica_split16_set_dp_poison");
+}
+extern "C" int clica_split16_poison_export(const void* state, float* slot, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state != nullptr && slot != nullptr, "clica_split16_poison_export: NULL argument");
+  hipLaunchKernelGGL(fmlp::split16_poison_export_k, dim3(1), dim3(1), 0, as_stream(stream), reinterpret_cast<const fmlp::Split16State*>(state), slot);
+  return launch_status("clica_split16_poison_export");
 }
 extern "C" int clica_split16_clear_flags(void* state, clica_stream_t stream) {
   CLICA_CHECK_ARG(state != nullptr, "clica_split16_clear_flags: state is NULL");

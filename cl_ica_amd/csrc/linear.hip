@@ -1153,10 +1153,15 @@ __global__ __launch_bounds__(RED_THREADS) void slab_reduce_group_k(ReduceGroupAr
   __shared__ float4 red[RED_THREADS / 64][64];
   __shared__ adam::Consts s_c;
   const ReduceAdam& A = G.adam;
-  const bool with_adam = A.p != nullptr;
-  const int nfront = (with_adam && A.s16_state) ? s16::kS16UpdateBlocks : 0;
-  if ((int)blockIdx.x < nfront) { s16::split16_update_tensor(reinterpret_cast<s16::Split16State*>(A.s16_state), A.s16_layers, (int)blockIdx.x); return; }
+  const bool with_adam_ = A.p != nullptr;
+  const int nfront = (with_adam_ && A.s16_state) ? s16::kS16UpdateBlocks : 0;
+  if ((int)blockIdx.x < nfront) {
+    s16::split16_update_tensor(reinterpret_cast<s16::Split16State*>(A.s16_state), A.s16_layers, (int)blockIdx.x, const_cast<int*>(A.step_dev));
+    return;
+  }
   const int blk = (int)blockIdx.x - nfront;
+  // the guard (split16.h): the step is poisoned -> the gradients are still reduced (inspection), the optimizer is not applied
+  const bool with_adam = with_adam_ && !(A.s16_state && s16::s16_step_poisoned(reinterpret_cast<const s16::Split16State*>(A.s16_state)));
   if (with_adam && threadIdx.x == RED_THREADS - 1) s_c = adam::consts_of(A.step_dev[0] + A.t_offset, A.lr, A.b1, A.b2);
   const int w = threadIdx.x >> 6;
   int q = 0;

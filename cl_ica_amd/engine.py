@@ -152,6 +152,11 @@ class ContrastiveTrainer:
         if self.split_f16 or self.split_f16_wide:
             self.s16 = ops.Split16(len(self.linears), self.device)
             self._init_wide_ones()
+            if self.dp:      # all ranks must take the guard's decision together: the verdict is all-reduced with the gradients
+                self.s16.set_dp_poison(self._guard_slot)
+        self._watch_versions = True            # step(): parameters written from outside (load_state_dict, copy_) -> recalibrate the f16x2 scales
+        self._versions_seen = self._param_versions()
+        self._guard_skipped_seen = 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         # data parallel + grouped weight gradients: the grouped launch is issued in TWO halves (layers L-1 .. h, then h-1 .. 0) and
         # the first half's slice of the gradient arena is all-reduced on the communication stream while the second half's GEMMs run
@@ -168,8 +173,19 @@ class ContrastiveTrainer:
                 w = mk(2 * self.B, part, self.device)
                 if w.numel() > self.group_ws.numel():
                     self.group_ws = w
-        self.buckets = GradBuckets(self.grad_arena, self._layer_slices, self.world, process_group, bucket_bytes, force=self.dp,
-                                   boundaries=(L - 1 - self._half,) if self.wgrad_halves else ()) if self.dp else None
+        slices = list(self._layer_slices)
+        self._guard_rides = bool(self.dp and self.s16 is not None and self.fused_backward and slices)
+        if self._guard_rides:
+            # whole-stack path: every producer of the step has run when the first bucket (the last layer's slice: the arena's tail) goes
+            # out, so the verdict slot behind the arena rides in that bucket; the per-layer path reduces the slot on its own at the end
+            total = self.grad_arena.numel()
+            k = max(range(len(slices)), key=lambda i: slices[i][1])
+            if k == 0 and slices[k][1] >= total - 3:
+                slices[k] = (slices[k][0], total + 4)
+            else:
+                self._guard_rides = False
+        self.buckets = GradBuckets(self._grad_buf if self._guard_rides else self.grad_arena, slices, self.world, process_group, bucket_bytes,
+                                   force=self.dp, boundaries=(L - 1 - self._half,) if self.wgrad_halves else ()) if self.dp else None
 
     # -------------------------------------------------------------------------------- arenas
     def _flatten_parameters(self):
@@ -182,7 +198,11 @@ class ContrastiveTrainer:
             total += (prm.numel() + 3) // 4 * 4
         dev = self.device
         self.param_arena = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.grad_arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        # (+ 4 floats behind the gradients: the f16x2 guard's verdict slot, which rides through the data-parallel all-reduce of the
+        #  last layer's bucket -- include/clica.h, "THE GUARD of the f16x2 arithmetic")
+        self._grad_buf = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+        self.grad_arena = self._grad_buf[:total]
+        self._guard_slot = self._grad_buf[total:total + 1]
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         self._views, self._gviews = {}, {}
@@ -678,6 +698,8 @@ class ContrastiveTrainer:
             if st:
                 ops.stamp(st["mlp_dgrad"], 0)
             self.backward_chain(g)
+            if self._guard_rides:                      # this rank's verdict into the slot the first gradient bucket carries
+                self.s16.poison_export(self._guard_slot)
             if st:
                 ops.stamp(st["mlp_dgrad"], 1)
                 if self.grouped_wgrad and self.buckets is None:
@@ -780,6 +802,10 @@ class ContrastiveTrainer:
             main.wait_stream(side)
         if self.buckets is not None:
             self.buckets.wait()
+        if self.dp and self.s16 is not None and not self._guard_rides:
+            # per-layer path: producers run until the last layer's gradient, so the verdict is reduced on its own (4 bytes) behind them
+            self.s16.poison_export(self._guard_slot)
+            dist.all_reduce(self._guard_slot, op=dist.ReduceOp.SUM, group=self.pg)
 
     def _adam_folds_into_wgrad(self) -> bool:
         """The optimizer can ride in the weight-gradient reduction when ONE whole-stack split launch produces every gradient of the
@@ -881,6 +907,41 @@ class ContrastiveTrainer:
             self.step_dev.copy_(tick)
             self._ticked = False
         self.s16.clear_flags()                   # the first pass ran on scales of 1: whatever it flagged is not a finding
+        self._versions_seen = self._param_versions()
+        self._guard_skipped_seen = self.s16.guard()["skipped"]      # (calibration passes the guard withheld are not training steps)
+
+    def _param_versions(self) -> int:
+        """Changes when somebody writes the parameters through torch (load_state_dict, copy_, an optimizer of their own): the kernels write
+        the arena through raw pointers and leave the version counters alone."""
+        return int(self.param_arena._version) + sum(int(q._version) for q in self.f.parameters())
+
+    def _check_external_writes(self):
+        """f16x2: parameters replaced from outside since the last look -> the scales are re-measured before the next step.
+        Without this the device-side guard would still keep a step on stale scales away from the parameters; this saves its redo steps."""
+        if self.s16 is None or not self._watch_versions:
+            return
+        v = self._param_versions()
+        if v != self._versions_seen:
+            self._versions_seen = v
+            self._s16_calibrated = False
+            if self.graph is not None and not torch.cuda.is_current_stream_capturing():
+                self.calibrate_scales(True)
+
+    def check_arith(self, raise_on_bug: bool = True) -> dict:
+        """LOG-POINT check of the f16x2 arithmetic (host read + sync; a no-op dict for the other arithmetics): the guard's flags, how many
+        steps it has withheld so far (`skipped`; `new_skipped` since the last call) and whether the last step is poisoned.  A withheld step
+        left parameters, moments and the step / RNG counter untouched and the next step redid its batch on fresh scales, so training has
+        lost replays, not correctness; callers that count steps compare with `steps_done`.  Flag bit 2 -- an overflow the update saw but no
+        producer announced -- would be a hole in the guard and raises."""
+        if self.s16 is None:
+            return dict(flags=0, skipped=0, new_skipped=0, poisoned=False, updates=0)
+        g = self.s16.guard()
+        g["new_skipped"] = g["skipped"] - self._guard_skipped_seen
+        self._guard_skipped_seen = g["skipped"]
+        if raise_on_bug and (g["flags"] & 4):
+            raise _lib.ClicaError("f16x2 arithmetic: the scale update saw an overflow that no producer had announced (flags bit 2): a "
+                                  "producer kernel without the guard -- results since the last check are not to be trusted")
+        return g
 
     def arith_state(self) -> dict:
         """Which encoder arithmetic runs and, for f16x2, the state of its scales (host read + sync: log points, tests).  A non-zero
@@ -894,6 +955,7 @@ class ContrastiveTrainer:
     def step(self):
         """One unsupervised step with on-device sampling.  Returns the device tensor
         ``[loss_mean, pos_mean, neg_mean]`` of this rank's rows (no host sync)."""
+        self._check_external_writes()
         if self.graph is not None:
             self.graph.replay()
             # a replay updates the parameter arena without passing through ops.adam_step: caches derived from the weights
@@ -904,6 +966,7 @@ class ContrastiveTrainer:
         return self.loss_out[3 * self.B:]
 
     def step_injected(self, z1, z2):
+        self._check_external_writes()
         self.inject(z1, z2)
         self._step_body(False)
         ops.PARAM_EPOCH += 1
@@ -931,6 +994,7 @@ class ContrastiveTrainer:
         torch.cuda.synchronize(self.device)
         for dst, src in zip(state, snap):
             dst.copy_(src)
+        self._versions_seen = self._param_versions()      # (the restore wrote the arena through torch: not an external write)
         graph = torch.cuda.CUDAGraph()
         # with collectives in the step, other threads (the process group's watchdog) may legitimately touch the HIP runtime
         # during capture: "thread_local" keeps their calls from invalidating it

@@ -196,6 +196,21 @@ class Split16:
     def clear_flags(self):
         check(load().clica_split16_clear_flags(self.buf.data_ptr(), stream_ptr()), "clica_split16_clear_flags")
 
+    def guard(self) -> dict:
+        """State of the device-side guard (include/clica.h, "THE GUARD of the f16x2 arithmetic"): sticky flags, steps withheld so far, scale
+        updates so far, and whether the step whose producers ran last is poisoned.  Host read + sync: log points, tests."""
+        fl, sk, up, po = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(load().clica_split16_guard(self.buf.data_ptr(), C.byref(fl), C.byref(sk), C.byref(up), C.byref(po), stream_ptr()), "clica_split16_guard")
+        return dict(flags=int(fl.value), skipped=int(sk.value), updates=int(up.value), poisoned=bool(po.value))
+
+    def set_dp_poison(self, slot: Optional[torch.Tensor]):
+        """Data parallel: the optimizer launches take the step's verdict from the device float `slot` (all-reduced by the caller)."""
+        check(load().clica_split16_set_dp_poison(self.buf.data_ptr(), ptr(slot), stream_ptr()), "clica_split16_set_dp_poison")
+        self._dp_slot = slot
+
+    def poison_export(self, slot: torch.Tensor):
+        check(load().clica_split16_poison_export(self.buf.data_ptr(), slot.data_ptr(), stream_ptr()), "clica_split16_poison_export")
+
     def read(self) -> dict:
         fl, up = C.c_int32(), C.c_int32()
         a, d, w, pa, pd = (C.c_float * 9)(), (C.c_float * 9)(), (C.c_float * 9)(), (C.c_float * 9)(), (C.c_float * 9)()

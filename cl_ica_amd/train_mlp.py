@@ -206,6 +206,7 @@ def _main(argv=None):
         last_step = args.n_steps if supervised else args.n_steps * args.more_unsupervised
         global_step = len(total_loss_values) + 1
         pending = []     # device scalars, fetched only at log time: no host sync per step
+        applied0, first_step = (trainer.steps_done if fused else 0), global_step
         while global_step <= last_step:
             pending.append(trainer.step()[0].clone() if fused else autograd_step().detach())
             if global_step % args.n_log_steps == 1 or global_step == args.n_steps:
@@ -217,6 +218,13 @@ def _main(argv=None):
                     f"Lin. Disentanglement: {lin:.4f} \t", f"Perm. Disentanglement: {perm:.4f}")
                 if args.sphere_norm:
                     log(f"r: {f[-1].r}")
+                if fused:
+                    # f16x2 arithmetic: the device-side guard withholds a step whose tensors outgrew their scales and the next step redoes
+                    # its batch (include/clica.h); here -- a log point, the host is synchronised anyway -- it is reported and checked
+                    ga = trainer.check_arith()
+                    if ga["new_skipped"]:
+                        log(f"note: the f16x2 guard withheld {ga['new_skipped']} step(s) since the last log point (redone on fresh scales; "
+                            f"{ga['skipped']} in total)")
                 if fused and not getattr(trainer, "_guard_noted", False):
                     gs = trainer.loss_guard()          # (nothing to do: the library's device-side guard switches per step, include/clica.h)
                     if gs["limit"] > 0 and gs["last_spread"] > gs["limit"]:
@@ -225,6 +233,13 @@ def _main(argv=None):
                             "loss runs on the coordinate-difference sweeps for such steps")
             lin_scores.append(lin); perm_scores.append(perm)
             global_step += 1
+        if fused:
+            # steps the guard withheld did not advance the device step counter: top the phase up to the number of APPLIED steps asked for
+            want = last_step - first_step + 1
+            for _ in range(64):
+                if trainer.steps_done - applied0 >= want:
+                    break
+                pending.append(trainer.step()[0].clone())
         if pending:
             total_loss_values += [float(v) for v in torch.stack(pending).cpu()]
         if args.save_dir and rank == 0:
@@ -241,14 +256,11 @@ def _main(argv=None):
             final_lin.append(l); final_perm.append(pm)
     engine_state = None
     if fused:      # what the engine ran on (f16x2 scales / overflow flag, the loss guard's counters): part of the run's record
-        st, gs = trainer.arith_state(), trainer.loss_guard()
-        engine_state = dict(arith=st.get("arith"), f16_flags=st.get("flags"), loss_max_spread=gs["max_spread"], loss_spread_limit=gs["limit"],
-                            loss_fallback_steps=gs["fallback_steps"])
-        log(f"engine: encoder arithmetic {st.get('arith')}" + (f", scale flags {st.get('flags')}" if "flags" in st else "") +
+        st, gs, ga = trainer.arith_state(), trainer.loss_guard(), trainer.check_arith()
+        engine_state = dict(arith=st.get("arith"), f16_flags=st.get("flags"), f16_steps_withheld=ga["skipped"], loss_max_spread=gs["max_spread"],
+                            loss_spread_limit=gs["limit"], loss_fallback_steps=gs["fallback_steps"])
+        log(f"engine: encoder arithmetic {st.get('arith')}" + (f", scale flags {st.get('flags')}, steps withheld by the guard {ga['skipped']}" if "flags" in st else "") +
             f"; p = 2 loss guard: largest spread M = {gs['max_spread']:.0f} (limit {gs['limit']:.0f}), {gs['fallback_steps']} calls on the difference sweeps")
-        if st.get("flags"):
-            raise RuntimeError("the f16x2 encoder arithmetic flagged an overflow (a tensor outgrew its scale by > 64 x within one step): "
-                               "results of this run are not to be trusted; rerun with CLICA_SPLIT_ARITH=bf16")
     log("linear mean: {} std: {}".format(np.mean(final_lin), np.std(final_lin)))
     log("perm mean: {} std: {}".format(np.mean(final_perm), np.std(final_perm)))
     if world > 1:

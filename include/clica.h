@@ -397,6 +397,22 @@ int clica_split16_update(void* state, int32_t n_layers, clica_stream_t stream);
 int clica_split16_read(const void* state, int32_t* flags, int32_t* updates, float* scales_a, float* scales_d, float* scales_w,
                        float* last_scales_a, float* last_scales_d, clica_stream_t stream);
 int clica_split16_clear_flags(void* state, clica_stream_t stream);
+/* THE GUARD of the f16x2 arithmetic (round 6; the reference's fp32 encoder, encoders.py:36-48, has no input it silently mis-computes, so
+ * neither may this one).  Every producer checks the fp32 magnitudes it cuts to fp16 against the scale in force; a scaled magnitude beyond
+ * 2^15 (or a non-finite value) POISONS the step on the device.  The launch that applies the optimizer for that step -- clica_adam_step_s16,
+ * clica_mlp_wgrad_split_adam -- then leaves parameters and moments untouched; the scale update riding in it counts the step as skipped,
+ * raises flag bit 1 and takes the step / RNG counter back by one, so a replayed step graph redoes the SAME batch on the scales the
+ * withheld step measured (one more link of the chain settles per redo at worst).  No host round trip: valid inside graph replay.
+ * flags: bit 0 an overflow was seen (sticky), bit 1 a step was withheld (sticky), bit 2 the update saw an overflow no producer announced.
+ * clica_split16_guard: HOST outputs (each may be NULL) flags, number of withheld steps, number of updates, and whether the step whose
+ * producers ran last is poisoned; synchronises `stream`.
+ * Data parallel: all ranks must take the same decision.  clica_split16_set_dp_poison(state, slot) makes the optimizer launches read the
+ * verdict from the device float `slot` (> 0: poisoned) instead of the rank's own words; clica_split16_poison_export(state, slot) writes
+ * this rank's verdict (0 / 1) there -- the caller puts `slot` behind its gradient arena and lets it ride through the gradient
+ * all-reduce (sum).  slot == NULL restores the single-rank behaviour. */
+int clica_split16_guard(const void* state, int32_t* flags, int32_t* skipped, int32_t* updates, int32_t* poisoned, clica_stream_t stream);
+int clica_split16_set_dp_poison(void* state, const float* slot, clica_stream_t stream);
+int clica_split16_poison_export(const void* state, float* slot, clica_stream_t stream);
 int clica_mlp_planes16_bytes(int64_t M, int32_t width, int32_t ones_column, size_t* bytes);
 int clica_mlp_pack_split16_bytes(int32_t n_layers, const int32_t* N, const int32_t* K, int32_t transpose, size_t* bytes);
 int clica_mlp_pack_split16_both(int32_t n_layers, const float* const* W, const int64_t* ldw, const int32_t* N, const int32_t* K,

@@ -254,6 +254,24 @@ def p1_tie_analysis(z1, z2, tau=1.0, alpha=0.5, thr=None):
     return rows, q
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def with_free_port(run, attempts=4):
+    """`run(port)` -> (returncode, text).  A rendezvous port chosen by bind-then-close can be taken by somebody else before the worker
+    binds it (seen once on a GPU box: EADDRINUSE in a test that had nothing else wrong): such a start is repeated on a fresh port."""
+    last = None
+    for _ in range(attempts):
+        last = run(free_port())
+        if last[0] == 0 or not ("EADDRINUSE" in last[1] or "address already in use" in last[1].lower()):
+            break
+    return last
+
+
 def rel_err(a, b):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     den = max(float(np.max(np.abs(b))), 1e-30)

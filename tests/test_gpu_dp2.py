@@ -140,3 +140,32 @@ def test_kitti_solver_two_ranks(tmp_path, p, box):
                                  f"|two-rank - ref2| / max|ref2| = {np.abs(got - ref2).max() / den:.3e}, "
                                  f"|rank0 local + rank1 local - ref2| / max|ref2| = {np.abs(loc - ref2).max() / den:.3e}; "
                                  f"got {got[:6]}, local sum {loc[:6]}, ref {ref2[:6]}") from None
+
+
+def test_f16x2_guard_two_ranks_take_the_same_decision(tmp_path):
+    """Data parallel: the f16x2 guard's decision must be the SAME on every rank (a rank that applies an update its peers withhold ends the
+    replicas' identity).  Two ranks on one GPU over gloo; only rank 1's batch outgrows its scales (x 300): both ranks withhold that step --
+    parameters, moments, counter untouched, rank 0 although its own producers saw nothing wrong -- both redo it the same number of times,
+    and the replicas are bit-identical afterwards."""
+    import json
+    from conftest import with_free_port
+    box = {}
+
+    def run(port):
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "guard_dp2_worker.py"), str(r), str(port), str(tmp_path)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [q.communicate(timeout=600)[0].decode() for q in procs]
+        box["procs"], box["outs"] = procs, outs
+        return max(q.returncode for q in procs), "\n".join(outs)
+    with_free_port(run)
+    for q, o in zip(box["procs"], box["outs"]):
+        assert q.returncode == 0, o[-3000:]
+    r0, r1 = (json.load(open(tmp_path / f"guard{r}.json")) for r in range(2))
+    if r0["skip"]:
+        pytest.skip("the f16x2 guard belongs to the f16x2 arithmetic")
+    for r in (r0, r1):
+        assert r["flags0"] == 0 and r["skipped1"] == 1 and (r["flags1"] & 2) and r["untouched"], r
+        assert r["steps_done"] == r["steps0"] + 1 and r["finite"] and r["changed"] and not (r["flags2"] & 4), r
+    assert r1["own_poisoned"] and not r0["own_poisoned"]                     # the verdict travelled: rank 0 withheld on rank 1's word
+    assert r0["replays"] == r1["replays"] and r0["skipped2"] == r1["skipped2"]
+    assert np.array_equal(np.load(tmp_path / "params0.npy"), np.load(tmp_path / "params1.npy"))

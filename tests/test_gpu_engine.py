@@ -253,9 +253,7 @@ def test_dry_ranks_8_plan_capture_and_run(n, space, p):
     import os
     import subprocess
     import sys
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    from conftest import with_free_port
     code = r"""
 import json, os, sys
 import torch, torch.distributed as dist
@@ -285,8 +283,15 @@ print("RESULT " + json.dumps(dict(plan=plan, captured=tr.graph is not None, fini
                                   loss=[float(o[0]) for o in outs], first_step_rows_equal_emulated=bool(torch.equal(tr2.loss_out[:B], te.loss_out[:B])),
                                   params_finite=bool(torch.isfinite(tr.param_arena).all()))))
 dist.destroy_process_group()
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, space, p, port)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+"""
+    box = {}
+
+    def run(port):
+        box["r"] = r = subprocess.run([sys.executable, "-c", code % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n, space, p, port)],
+                                      capture_output=True, text=True, timeout=900)
+        return r.returncode, r.stderr
+    with_free_port(run)
+    r = box["r"]
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     import json
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
@@ -296,8 +301,8 @@ dist.destroy_process_group()
     n_params = sum((a * b + 3) // 4 * 4 + (a + 3) // 4 * 4 for a, b in zip([10 * n, 50 * n, 50 * n, 50 * n, 50 * n, 10 * n, n], [n, 10 * n, 50 * n, 50 * n, 50 * n, 50 * n, 10 * n]))
     assert plan["gradient_arena_elements"] == n_params
     cov = sorted(plan["gradient_buckets"])
-    # the buckets tile the arena (up to the <= 3 padding elements behind the last parameter)
-    assert cov[0][0] == 0 and n_params - 3 <= cov[-1][1] <= n_params and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+    # the buckets tile the arena (up to the <= 3 padding elements behind the last parameter; in the f16x2 arithmetic + the guard's verdict slot, 4 floats)
+    assert cov[0][0] == 0 and n_params - 3 <= cov[-1][1] <= n_params + 4 and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
     ag = [c for c in plan["collectives_per_step"] if c["op"] == "all_gather"]
     assert [c["gathered_bytes"] for c in ag] == [4 * B * n * R, 4 * B * R]
     if n == 10:
@@ -313,13 +318,17 @@ def test_failed_capture_leaves_the_engine_usable():
     to run the same steps eagerly (bench.py / train_mlp fall back to eager launches when a RCCL build refuses capture).
     Runs in a subprocess: a failed capture must not leak into this session either way."""
     import os
-    import socket
     import subprocess
     import sys
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    from conftest import with_free_port
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "failed_capture_worker.py")
-    r = subprocess.run([sys.executable, worker, str(port)], capture_output=True, text=True, timeout=600)
+    box = {}
+
+    def run(port):
+        box["r"] = r = subprocess.run([sys.executable, worker, str(port)], capture_output=True, text=True, timeout=600)
+        return r.returncode, r.stderr + r.stdout
+    with_free_port(run)
+    r = box["r"]
     assert r.returncode == 0 and "FAILED_CAPTURE_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     assert "capture failed as expected" in r.stdout
 
@@ -499,3 +508,135 @@ def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypat
             assert torch.equal(x, y), (what, scale_last, graph, float((x - y).abs().max()))
         if scale_last > 1.0 and a[4]["limit"] > 0.0:
             assert a[4]["fallback_steps"] > 0, a[4]          # this case did run on the difference sweeps
+
+
+def _guard_trainer(seed=7, n=10, B=1024, hidden=(100, 500, 500, 100), lr=1e-3):
+    from cl_ica_amd import encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    torch.manual_seed(seed)
+    f = encoders.get_mlp(n, n, list(hidden)).to("cuda")
+    gW = (torch.randn(3, n, n, device="cuda") / n ** 0.5).contiguous()
+    tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n, seed=3), batch_size=B, p=2, lr=lr, device="cuda")
+    return f, tr
+
+
+def _oracle_check_of_applied_step(tr, f, snap, steps0, fam, case):
+    """The step the engine has just APPLIED, against the fp64 oracle and against its own optimizer kernel: loss and every parameter gradient
+    of the batch in tr.z at the parameters of `snap` within 1e-5, and parameters / moments == clica_adam_step(snap, that gradient, t = steps0 + 1)
+    bit for bit (the update was applied exactly once, with the step count of an APPLIED step)."""
+    from cl_ica_amd import ops
+    B = tr.B
+    lin = tr.linears
+    offs, o = [], 0
+    for q in f.parameters():
+        offs.append(o); o += (q.numel() + 3) // 4 * 4
+    pa = snap[0].cpu().numpy().astype(np.float64)
+    views = [pa[o:o + q.numel()].reshape(tuple(q.shape)) for o, q in zip(offs, f.parameters())]
+    P = O.MLPParams([views[2 * l] for l in range(len(lin))], [views[2 * l + 1] for l in range(len(lin))])
+    Ws = [w.cpu().numpy().astype(np.float64) for w in tr.gW]
+    z = tr.z.cpu().numpy().astype(np.float64)
+    x = np.concatenate([O.mixing_forward(Ws, z[:B], tr.g_slope), O.mixing_forward(Ws, z[B:], tr.g_slope)])
+    y, cache = O.mlp_forward(P, x)
+    ref = O.lp_simclr_loss(y[:B], y[B:], np.roll(y[:B], 1, 0), p=2, compat=True)
+    out = tr.loss_out[3 * B:].cpu().numpy()
+    PARITY.check(fam, case, "loss", out[0], ref["loss_mean"])
+    gy = np.concatenate([ref["dz1"] + np.roll(ref["dz3"], -1, 0), ref["dz2"]])
+    gr = O.mlp_backward(P, cache, gy)
+    gmax = max(float(np.abs(g).max()) for g in gr["dW"])
+    for l, m in enumerate(lin):
+        PARITY.check(fam, case, f"dW{l}", tr._gviews[id(m.weight)].cpu().numpy(), gr["dW"][l], floor=1e-3 * gmax)
+        if l < len(lin) - 1:      # (the last bias: an exactly-zero gradient, translation invariance)
+            PARITY.check(fam, case, f"db{l}", tr._gviews[id(m.bias)].cpu().numpy(), gr["db"][l], floor=1e-3 * gmax)
+    p2, m2, v2 = (t.clone() for t in snap[:3])
+    cnt = torch.tensor([steps0], dtype=torch.int32, device="cuda")
+    ops.adam_step(p2, tr.grad_arena, m2, v2, cnt, tr.lr, tr.betas[0], tr.betas[1], tr.eps)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, tr.param_arena) and torch.equal(m2, tr.exp_avg) and torch.equal(v2, tr.exp_avg_sq), "the applied update is not Adam(snapshot, gradient, t)"
+
+
+def test_f16x2_guard_withholds_the_step_and_redoes_it_inside_graph_replay():
+    """VERDICT r5 item 2 / ADVICE r5 (medium).  The f16x2 arithmetic runs a step on the scales of the step before; when a tensor outgrows
+    them by more than 64 x between two REPLAYS of the captured step graph -- here the batch: the mixing network's last layer is scaled by
+    1 000 under the graph, a `step_injected` with data of another magnitude does the same -- the replay must not reach the parameters: they,
+    the moments and the step / RNG counter come out bit-identical, the guard's flag and counter say so, and the following replays redo the
+    SAME batch on the fresh scales until it is applied.  The applied step is then checked against the fp64 oracle (1e-5) and against the
+    optimizer kernel (bit for bit).  The host does nothing in between but read."""
+    f, tr = _guard_trainer()
+    if tr.s16 is None or not tr.split_f16:
+        pytest.skip("the f16x2 guard belongs to the f16x2 arithmetic")
+    tr._watch_versions = False                  # (nothing is written through torch here; the device-side guard alone is under test)
+    tr.capture()
+    graph = tr.graph
+    for _ in range(6):
+        tr.step()
+    torch.cuda.synchronize()
+    g0 = tr.check_arith()
+    steps0 = tr.steps_done
+    assert g0["flags"] == 0 and g0["skipped"] == 0 and steps0 == 6, g0
+    snap = [t.clone() for t in (tr.param_arena, tr.exp_avg, tr.exp_avg_sq)]
+    tr.gW[-1].mul_(1000.0)                      # x = g(z) grows 1 000 x: beyond the 64 x headroom of last step's scale
+    tr.step(); torch.cuda.synchronize()
+    g1 = tr.check_arith()
+    assert g1["skipped"] == 1 and g1["new_skipped"] == 1 and (g1["flags"] & 2) and not (g1["flags"] & 4), g1
+    assert tr.steps_done == steps0, "a withheld step must not advance the step / RNG counter"
+    for a, b in zip(snap, (tr.param_arena, tr.exp_avg, tr.exp_avg_sq)):
+        assert torch.equal(a, b), "a withheld step must leave parameters and moments untouched"
+    z_withheld = tr.z.clone()
+    L = len(tr.linears)
+    replays = 0
+    while tr.steps_done == steps0 and replays < 2 * L + 6:
+        tr.step(); torch.cuda.synchronize(); replays += 1
+    g2 = tr.check_arith()
+    assert tr.steps_done == steps0 + 1, (replays, g2)
+    assert tr.graph is graph and not (g2["flags"] & 4) and g2["skipped"] == replays, (replays, g2)
+    assert torch.equal(z_withheld, tr.z), "the redo must draw the batch of the withheld step"
+    assert not torch.equal(snap[0], tr.param_arena)
+    _oracle_check_of_applied_step(tr, f, snap, steps0, "f16x2_guard_in_graph_replay", f"batch x 1000 between replays (applied after {replays} redo replays)")
+    for _ in range(3):                           # and training goes on
+        tr.step()
+    torch.cuda.synchronize()
+    g3 = tr.check_arith()
+    assert tr.steps_done == steps0 + 4 and g3["new_skipped"] == 0 and not g3["poisoned"], g3
+
+
+def test_f16x2_guard_catches_parameters_replaced_without_calibration():
+    """The other way in: parameters replaced from outside (a loaded checkpoint) WITHOUT calibrate_scales -- the first layer 200 x larger.
+    With the engine's own watch on the parameter versions switched off, the device-side guard alone keeps the stale-scale steps away from
+    the parameters inside graph replay and lets the first healthy one through (oracle / optimizer-kernel check as above); with the watch
+    on (the default), step() re-measures the scales itself and nothing is withheld."""
+    f, tr = _guard_trainer(seed=8)
+    if tr.s16 is None or not tr.split_f16:
+        pytest.skip("the f16x2 guard belongs to the f16x2 arithmetic")
+    tr.capture()
+    for _ in range(4):
+        tr.step()
+    torch.cuda.synchronize()
+    lin0 = tr.linears[0]
+    # (a) the default: the version watch recalibrates
+    with torch.no_grad():
+        lin0.weight.mul_(200.0); lin0.bias.mul_(200.0)
+    steps0 = tr.steps_done
+    tr.step(); torch.cuda.synchronize()
+    ga = tr.check_arith()
+    assert tr.steps_done == steps0 + 1 and ga["new_skipped"] == 0, ga
+    # (b) the guard alone
+    tr._watch_versions = False
+    with torch.no_grad():
+        lin0.weight.div_(200.0); lin0.bias.div_(200.0)      # shrinking is harmless for fp16 range: one step on coarse scales, no overflow
+    tr.step(); torch.cuda.synchronize()
+    with torch.no_grad():
+        lin0.weight.mul_(200.0); lin0.bias.mul_(200.0)
+    torch.cuda.synchronize()
+    tr.check_arith()
+    steps0 = tr.steps_done
+    snap = [t.clone() for t in (tr.param_arena, tr.exp_avg, tr.exp_avg_sq)]
+    L = len(tr.linears)
+    replays = 0
+    while tr.steps_done == steps0 and replays < 2 * L + 6:
+        tr.step(); torch.cuda.synchronize(); replays += 1
+        if tr.steps_done == steps0:
+            for a, b in zip(snap, (tr.param_arena, tr.exp_avg, tr.exp_avg_sq)):
+                assert torch.equal(a, b), "a withheld step must leave parameters and moments untouched"
+    gb = tr.check_arith()
+    assert tr.steps_done == steps0 + 1 and replays >= 2 and gb["new_skipped"] == replays - 1 and not (gb["flags"] & 4), (replays, gb)
+    _oracle_check_of_applied_step(tr, f, snap, steps0, "f16x2_guard_in_graph_replay", f"first layer x 200 without calibration (applied after {replays - 1} redo replays)")
