@@ -1200,13 +1200,20 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
 // are positively homogeneous).  It is split into hi / lo for the next layer's panel (LDS) and, `has_pl`, for the plane copy the
 // weight-gradient kernel reads (planes.h, two pieces per unit); `has_out`: the fp32 copy gets t / s_out (exact: powers of two).
 // Features >= N come out as exact zeros (zero weight fragments, zero-padded bias row), as in the bf16x3 fast path.
-template <int ACT, bool BITS>
-__device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], unsigned short* planes, const float* bias_row, const float slope, const bool leaky,
+// MODE (round 6): 0 = which copies to write is decided at run time (wave-uniform flags: any combination);  1 = the plane copy only;
+// 2 = the fp32 copy only, 16-byte stores -- the four combinations a training step runs (hidden layer -> planes, the 100-wide layer in
+// front of an n-wide one -> fp32, both directions), compiled without the other paths: in the generic form every accumulator block
+// carries the branches and the exec-mask code of the copies it does not write (phase trace: epilogue body 8.3 k cycles per 500-wide
+// layer against 3.0 k for the same arithmetic in isolation, tools/proto/epi_probe.hip).  ACT 1 in MODE 1 / 2 is a LeakyReLU layer.
+template <int ACT, bool BITS, int MODE>
+__device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], unsigned short* planes, const float* bias_row, const float slope, const bool leaky_,
                                                  const unsigned long long mbits, const int N, const int ncb, const int wave, const int lane,
-                                                 const bool has_out, const bool ovec, float* out_rows, const __amdgpu_buffer_rsrc_t orsrc, const int ldo, const int nrows,
-                                                 const bool has_pl, const __amdgpu_buffer_rsrc_t prsrc, const int pl_group_bytes, const int pl_ones,
+                                                 const bool has_out_, const bool ovec_, float* out_rows, const __amdgpu_buffer_rsrc_t orsrc, const int ldo, const int nrows,
+                                                 const bool has_pl_, const __amdgpu_buffer_rsrc_t prsrc, const int pl_group_bytes, const int pl_ones,
                                                  const float cmul, const float s_out, const float inv_s_out,
                                                  unsigned& lo_bits, unsigned& hi_bits, float& amax_scaled) {
+  const bool leaky = MODE == 0 ? leaky_ : true, has_pl = MODE == 0 ? has_pl_ : (MODE == 1), has_out = MODE == 0 ? has_out_ : (MODE == 2),
+             ovec = MODE == 0 ? ovec_ : true;
   const int i15 = lane & 15, kg = lane >> 4;
   const unsigned pl_lane = (unsigned)((i15 >> 2) * 256 + (i15 & 3) * 32 + kg * 8);
   const f32x2 slope2 = {slope, slope}, cmul2 = {cmul, cmul}, inv2 = {inv_s_out, inv_s_out}, sout2 = {s_out, s_out};
@@ -1684,16 +1691,23 @@ __global__ __launch_bounds__(THREADS) void mlp_split_k(SplitArgs a) {
       unsigned lo = 0u, hi = 0u;
       float am = 0.f;
       const float* brow = &bias_lds[q.boff];
-      if (!ly.dact) {
-        if (q.mask_out) split16_epilogue<1, true>(acc, planes, brow, g.slope, ly.leaky != 0, mbits, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
-                                                  has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
-        else split16_epilogue<1, false>(acc, planes, brow, g.slope, ly.leaky != 0, mbits, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
-                                        has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
-      } else {
-        const unsigned long long mb = ly.mask_in ? mbits : ~0ull;      // no sign bits: no gate
-        split16_epilogue<2, false>(acc, planes, brow, g.slope, false, mb, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows,
-                                   has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am);
+#define CLICA_EPI16_ARGS(MB) acc, planes, brow, g.slope, ly.leaky != 0, MB, N, ncb, wave, lane, has_out, ovec, out_rows, orsrc, (int)ly.ldo, nrows, \
+                             has_pl, prsrc, pl_group_bytes, q.pl_ones, cmul, s_out, inv_s_out, lo, hi, am
+      const unsigned long long mb = ly.mask_in ? mbits : ~0ull;      // backward link without sign bits: no gate
+      switch (q.fast_kind) {             // (launch_split: the training step's combinations; 0 = anything else)
+        case 11: split16_epilogue<1, true, 1>(CLICA_EPI16_ARGS(mbits)); break;
+        case 12: split16_epilogue<1, true, 2>(CLICA_EPI16_ARGS(mbits)); break;
+        case 21: split16_epilogue<2, false, 1>(CLICA_EPI16_ARGS(mb)); break;
+        case 22: split16_epilogue<2, false, 2>(CLICA_EPI16_ARGS(mb)); break;
+        default:
+          if (!ly.dact) {
+            if (q.mask_out) split16_epilogue<1, true, 0>(CLICA_EPI16_ARGS(mbits));
+            else split16_epilogue<1, false, 0>(CLICA_EPI16_ARGS(mbits));
+          } else {
+            split16_epilogue<2, false, 0>(CLICA_EPI16_ARGS(mb));
+          }
       }
+#undef CLICA_EPI16_ARGS
       ST_STAMP(l, 6);
       if (has_pl && q.pl_ones && (N & 31) == 0 && wave == 0) {   // the ones column in an extra unit
         const bool first = (lane & 1) == 0 && ((lane >> 3) & 1) == 0;
@@ -2144,6 +2158,15 @@ static int launch_split(fmlp::SplitArgs& a, int arith, clica_stream_t stream, co
   }
   if (arith == 1) {
     if (!slope01) { set_error("%s: the f16x2 arithmetic needs a LeakyReLU slope in (0, 1), got %g", who, (double)a.g.slope); return CLICA_E_INVALID; }
+    for (int l = 0; l < a.g.L; ++l) {      // the specialised f16x2 epilogues (split16_epilogue, MODE 1 / 2)
+      const Layer& ly = a.g.layer[l];
+      const bool pl_only = ly.planes && !ly.out;
+      const bool out_vec = ly.out && !ly.planes && ((reinterpret_cast<uintptr_t>(ly.out) & 15) == 0) && (ly.ldo % 4 == 0) && (ly.N % 4 == 0);
+      int k = 0;
+      if (!ly.dact && ly.leaky && ly.mask_out) k = pl_only ? 11 : (out_vec ? 12 : 0);
+      else if (ly.dact && !ly.mask_out) k = pl_only ? 21 : (out_vec ? 22 : 0);
+      a.q[l].fast_kind = k;
+    }
     const size_t lds = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)a.boff[a.g.L] * sizeof(float) + 256 + ST_LDS_BYTES;
     constexpr size_t lds_max = 2 * (size_t)PLANE * sizeof(unsigned short) + (size_t)BIAS_LDS_MAX * sizeof(float) + 256 + ST_LDS_BYTES;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max), true);
