@@ -603,10 +603,8 @@ def dropin_leg(args, device, steps=40, warmup=8):
                            "whole-encoder kernels need to beat them" % (B, (B + 47) // 48))
     res["what"] = ("reference train_step structure (main_mlp.py:258-285: two encoder calls of B rows, roll in the graph, three .item() "
                    "calls per step, eager launches, torch autograd) on the drop-in modules; deferred stacking of the two encoder calls "
-                   f"{'on' if lazy_on else 'off'} (CLICA_DROPIN_LAZY), roll detection -> one-sweep symmetric loss backward "
-                   f"{'on' if losses._sym_enabled() else 'off'} (CLICA_DROPIN_SYM), loss scalars by one async copy behind the loss forward "
-                   f"{'on' if losses._async_item() else 'off'} (CLICA_DROPIN_ASYNC_ITEM), weights re-packed at step end "
-                   f"{'on' if encoders._early_repack() else 'off'} (CLICA_DROPIN_EARLY_PACK)")
+                   f"{'on' if lazy_on else 'off'} (CLICA_DROPIN_LAZY), roll detection -> one-sweep symmetric loss backward, loss scalars by one "
+                   "async copy behind the loss forward, weights re-packed at step end")
     return res
 
 

@@ -201,7 +201,7 @@ SIGNATURES: Dict[str, list] = {
     "clica_tick": [C.c_void_p, C.c_void_p],
     "clica_stamp": [C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_clock_probe": [C.c_void_p, c_i32, c_i32, C.c_void_p],
-    "clica_reload_env": [],
+    "clica_set_tuning": [C.c_char_p, c_i32],
     "clica_abort_capture": [C.c_void_p],
     "clica_kitti_gather_pairs": [C.c_void_p, c_i64, c_i64, C.c_void_p, C.c_void_p, c_i64, c_f32p, c_f32p, c_i32, c_f32p, C.c_void_p],
     "clica_moments_workspace_bytes": [c_i64, c_i32, C.POINTER(c_size)],

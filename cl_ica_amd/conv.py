@@ -33,8 +33,8 @@ _ARITH = os.environ.get("CLICA_CONV_ARITH", "f16x2")
 if _ARITH not in ("f16x2", "f32"):
     raise ValueError(f"CLICA_CONV_ARITH={_ARITH!r}: 'f16x2' or 'f32'")
 _SLOTS = 256          # csrc/conv16.hip: kSlots
-_FIRST_FROM_IMAGE = os.environ.get("CLICA_CONV_FIRST", "image") != "patches"      # A/B switch for the one-channel first stage
-_FIRST_MFMA = os.environ.get("CLICA_CONV_FIRST_MFMA", "1") != "0"                  # f16x2: its forward on the matrix cores too (0: the fp32 vector-ALU kernel)
+_FIRST_FROM_IMAGE = True     # the one-channel first stage reads the images themselves (test hook: False = from the patch matrix, tests/test_gpu_conv.py)
+_FIRST_MFMA = True           # f16x2: its forward on the matrix cores too
 
 
 def set_arith(name: str) -> str:

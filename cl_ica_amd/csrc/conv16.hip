@@ -626,14 +626,12 @@ static int launch_stream16_n(const GArgs& a, int nsplit, hipStream_t st, const c
   const int64_t tiles = ceil_div(a.M, 32);
   int64_t wgs = std::min<int64_t>((int64_t)per_cu * kNumCU / nsplit, ceil_div(tiles, ST_THREADS / 64));
   wgs = std::max<int64_t>(wgs, 1);
-  static const int kperm = [] { const char* e = getenv("CLICA_CONV16_KPERM"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  hipLaunchKernelGGL(k, dim3((unsigned)(wgs * nsplit)), dim3(ST_THREADS), lds, st, a, nsplit, (a.K / 4) % 32 == 0 ? kperm : 0);
+  hipLaunchKernelGGL(k, dim3((unsigned)(wgs * nsplit)), dim3(ST_THREADS), lds, st, a, nsplit, (a.K / 4) % 32 == 0 ? 1 : 0);
   return launch_status(who);
 }
 // false: the shape does not fit the streaming kernel (the caller takes the tiled one)
 static bool stream16_fits(const GArgs& a, int& nbn, int& nsplit) {
-  static const bool on = [] { const char* e = getenv("CLICA_CONV16_STREAM"); return !(e && atoi(e) == 0); }();
-  if (!on || a.N % 32 || a.K % 128 || a.seg % 32) return false;
+  if (a.N % 32 || a.K % 128 || a.seg % 32) return false;
   for (nbn = std::min(4, a.N / 32); nbn >= 1; nbn >>= 1) {
     if ((a.N / 32) % nbn) continue;
     if ((size_t)2 * nbn * 32 * (a.K + 8) * sizeof(half_t) <= 150 * 1024) { nsplit = a.N / (32 * nbn); return nbn != 3; }
@@ -857,9 +855,8 @@ __global__ __launch_bounds__(TL_THREADS) void fwd_tile16_k(GArgs a, int ntiles, 
   commit_amax(a.amax_out, amax, blockIdx.x * (TL_THREADS / 64) + wave);
 }
 static bool tile16_fits(const GArgs& a) {
-  static const bool on = [] { const char* e = getenv("CLICA_CONV16_TILE"); return !(e && atoi(e) == 0); }();
   const Geo& g = a.g;
-  return on && g.mode == 1 && a.N == 32 && a.K == 512 && a.lda == 128 && g.ws == 16 && g.gws == 17 && g.hs % TL_TY == 0 && g.ghs == g.hs + 1 && g.c == 32;
+  return g.mode == 1 && a.N == 32 && a.K == 512 && a.lda == 128 && g.ws == 16 && g.gws == 17 && g.hs % TL_TY == 0 && g.ghs == g.hs + 1 && g.c == 32;
 }
 static int launch_tile16(const GArgs& a, hipStream_t st, const char* who) {
   constexpr size_t lds = (size_t)(2 * TL_PIX * TL_LDA) * sizeof(half_t) + 4 * 16 * 64 * sizeof(float);

@@ -17,6 +17,7 @@
 // LDS double buffer; one barrier per K tile.  wgrad splits the long contraction (Kc = rows of the
 // batch) over blockIdx.z into fp32 slabs that a second tiny kernel sums deterministically.
 #include "common.h"
+#include <string.h>
 #include "wgrad_shared.h"
 #include "split16.h"
 #include "adam_math.h"
@@ -1301,16 +1302,12 @@ static int launch(int cfg, const Args& g, int splits, hipStream_t st, const char
   }
 }
 
-// Tuning switches from the environment, read ONCE (first launch) and again only on clica_reload_env(): the launch path
-// of the per-layer entry points is called from autograd nodes in eager mode, where a getenv per call is measurable.
-//   CLICA_GEMM_CFG_{FWD,DGRAD,WGRAD}=id  tile configuration override;  CLICA_SKINNY=0 forces every shape through the MFMA template
+// Test / tuning hook (clica_set_tuning, include/clica.h): the per-layer entry points choose their body by SHAPE; a test that wants the other
+// product path on a given shape (every shape through the MFMA template, another tile configuration) sets it here.  No environment reads:
+// the launch path is called from autograd nodes in eager mode.
+//   gemm_cfg_{fwd,dgrad,wgrad} = tile configuration id (-1: by shape);  skinny = 0 forces every shape through the MFMA template
 struct Tuning { int cfg_fwd, cfg_dgrad, cfg_wgrad; bool skinny; };
-static Tuning read_tuning() {
-  auto num = [](const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; };
-  const char* sk = getenv("CLICA_SKINNY");
-  return Tuning{num("CLICA_GEMM_CFG_FWD"), num("CLICA_GEMM_CFG_DGRAD"), num("CLICA_GEMM_CFG_WGRAD"), !(sk && atoi(sk) == 0)};
-}
-static Tuning& tuning() { static Tuning t = read_tuning(); return t; }
+static Tuning& tuning() { static Tuning t{-1, -1, -1, true}; return t; }
 static bool use_skinny() { return tuning().skinny; }
 
 // measured on MI355X (tools/gemm_bench.py): wide outputs -> 96x128 tiles, two 4-wave workgroups per
@@ -1351,11 +1348,9 @@ constexpr int GBM = 128, GBN = 128;
 // 3 / 4 = 256 x 128 / 128 x 256 DMA tiles (a dimension beyond 128), 1 = 128 x 128 DMA tiles, 0 = register-staged (odd widths).
 // Every MFMA item of a launch should cover the same work; mixed 128 x 128 and big-tile problems are legal, just not balanced.
 static int group_kind(int32_t N, int32_t K) {
-  static const bool tiny_on = [] { const char* e = getenv("CLICA_WGRAD_TINY"); return !(e && atoi(e) == 0); }();
-  static const bool big_on = [] { const char* e = getenv("CLICA_WGRAD_BIG"); return !(e && atoi(e) == 0); }();
-  if (tiny_on && tiny_eligible(N, K, TINY_THREADS)) return 2;
+  if (tiny_eligible(N, K, TINY_THREADS)) return 2;
   if (N % 4 != 0 || K % 4 != 0) return 0;
-  if (big_on && (N > 128 || K > 128)) return N >= K ? 3 : 4;
+  if (N > 128 || K > 128) return N >= K ? 3 : 4;
   return 1;
 }
 static void group_tile(int kind, int* bm, int* bn) {
@@ -1380,11 +1375,6 @@ static GroupPlan plan_wgrad_group(int64_t Mrows, int n, const int32_t* N, const 
     // (weights fitted on MI355X, tools/wgrad_probe.py)
     const double cost = (double)rounds * (kps + 32.0) + 8.0 * sp;
     if (cost < best) { best = cost; p.splits = (int)sp; p.k_per_split = kps; }
-  }
-  static const int forced = [] { const char* e = getenv("CLICA_WGRAD_GROUP_SPLITS"); return e ? atoi(e) : 0; }();
-  if (forced > 0) {
-    const int64_t kps = ceil_div(ceil_div(Mrows, (int64_t)forced), (int64_t)BK) * BK;
-    p.k_per_split = kps; p.splits = (int)ceil_div(Mrows, kps);
   }
   if (p.n_tiny > 0) wgrad_tiny_plan(Mrows, p.n_tiny, &p.tiny_splits, &p.tiny_kps);
   return p;
@@ -1559,10 +1549,17 @@ extern "C" int clica_linear_plan(int32_t op, int64_t M, int64_t N, int64_t K, in
   return CLICA_OK;
 }
 
-namespace clica { namespace lp { void reload_dot_env(); } }      // lp_loss.hip: CLICA_DOT_MFMA
-extern "C" int clica_reload_env(void) {
-  gemm::tuning() = gemm::read_tuning();
-  clica::lp::reload_dot_env();
+namespace clica { namespace lp { void set_dot_mfma(int on); } }      // lp_loss.hip: SimCLRLoss contraction path
+extern "C" int clica_set_tuning(const char* key, int32_t value) {
+  CLICA_CHECK_ARG(key != nullptr, "clica_set_tuning: key is NULL");
+  gemm::Tuning& t = gemm::tuning();
+  if (!strcmp(key, "skinny")) t.skinny = value != 0;
+  else if (!strcmp(key, "gemm_cfg_fwd")) t.cfg_fwd = value;
+  else if (!strcmp(key, "gemm_cfg_dgrad")) t.cfg_dgrad = value;
+  else if (!strcmp(key, "gemm_cfg_wgrad")) t.cfg_wgrad = value;
+  else if (!strcmp(key, "dot_mfma")) clica::lp::set_dot_mfma(value);
+  else if (!strcmp(key, "reset")) { t = gemm::Tuning{-1, -1, -1, true}; clica::lp::set_dot_mfma(1); }
+  else { set_error("clica_set_tuning: unknown key '%s'", key); return CLICA_E_INVALID; }
   return CLICA_OK;
 }
 
@@ -1596,9 +1593,8 @@ extern "C" int clica_linear_wgrad(const float* dY, int64_t lddy, const float* X,
   g.k_per_split = p.k_per_split;
   g.dbias_slab = db ? dbslab : nullptr;
   int rc;
-  static const bool dma_ok = [] { const char* e = getenv("CLICA_WGRAD_DMA"); return !(e && atoi(e) == 0); }();
   const bool vec = aligned16(g.A) && aligned16(g.B) && g.lda % 4 == 0 && g.ldb % 4 == 0 && N % 4 == 0 && K % 4 == 0;
-  if (dma_ok && vec && p.cfg == 1) {
+  if (vec && p.cfg == 1) {
     // 128x128 8-wave tiles: the direct global -> LDS body of the grouped kernel, as a one-problem group
     GroupArgs G{};
     G.n = 1; G.p[0] = g; G.vec[0] = 1;
@@ -2289,8 +2285,7 @@ extern "C" int clica_conv_k4s2_fwd_patches_amax(const float* patches, const floa
                   "clica_conv_k4s2_fwd_patches: bad argument");
   CLICA_CHECK_ARG(!scatter || (ho % 2 == 0 && wo % 2 == 0), "clica_conv_k4s2_fwd_patches: scatter needs an even output grid");
   CLICA_CHECK_ARG(aligned16(patches) && aligned16(Wg), "clica_conv_k4s2_fwd_patches: operands must be 16-byte aligned");
-  static const bool valu_on = [] { const char* e = getenv("CLICA_CONV_VALU_STAGE1"); return !(e && atoi(e) == 0); }();
-  if (valu_on && scatter == 1 && K == 16 && Cout == 32 && aligned16(out) && images * ho * wo < ((int64_t)1 << 32)) {
+  if (scatter == 1 && K == 16 && Cout == 32 && aligned16(out) && images * ho * wo < ((int64_t)1 << 32)) {
     // short contraction (one input channel): vector-ALU kernel, bound by the 128 B per pixel it writes
     hipLaunchKernelGGL(conv_fwd_patches_valu_k<16>, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), patches, Wg, bias,
                        (unsigned)(images * ho * wo), (int)Cout, (int)ho, (int)wo, (int)relu, out, gate_bits, amax_slots);
@@ -2309,9 +2304,8 @@ extern "C" int clica_conv_k4s2_fwd(const float* S, const float* Wg, const float*
   CLICA_CHECK_ARG(scatter != 1 || ((hs - 1) % 2 == 0 && (ws - 1) % 2 == 0), "clica_conv_k4s2_fwd: scatter = 1 needs an even output grid");
   CLICA_CHECK_ARG(aligned16(S) && aligned16(Wg), "clica_conv_k4s2_fwd: operands must be 16-byte aligned");
   // scattering stages run their GEMM over the output pixels only (no work on the grid's non-output rows: 13 / 27 % of the 17 x 17 / 9 x 9 stages)
-  static const bool compact_on = [] { const char* e = getenv("CLICA_CONV_COMPACT"); return !(e && atoi(e) == 0); }();
   return conv_fwd_launch(S, 4 * (int64_t)C, 8 * (int64_t)C, (int64_t)(ws - 2) * 4 * C, Wg, bias, images * hs * ws, 16 * C, Cout,
-                         hs, ws, hs - 1, ws - 1, relu, scatter, out, gate_bits, as_stream(stream), "clica_conv_k4s2_fwd", compact_on ? 1 : 0);
+                         hs, ws, hs - 1, ws - 1, relu, scatter, out, gate_bits, as_stream(stream), "clica_conv_k4s2_fwd", 1);
 }
 
 extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const float* S, int64_t images, int32_t C, int32_t Cout,
@@ -2332,8 +2326,7 @@ extern "C" int clica_conv_k4s2_dgrad(const float* dO, const float* Wd, const flo
   cx.fast = ((4 * Cout) % BK == 0 && cx.a_jump < (1 << 30)) ? 1 : 0;
   CLICA_CHECK_ARG(!gate_bits || C % 32 == 0, "clica_conv_k4s2_dgrad: gate bits need C %% 32 == 0");
   CLICA_CHECK_ARG(g.M < (1 << 24), "clica_conv_k4s2_dgrad: %lld rows (the scattering epilogue handles < 2^24)", (long long)g.M);
-  static const bool persist_on = [] { const char* e = getenv("CLICA_CONV_DGRAD_PERSIST"); return !(e && atoi(e) == 0); }();
-  if (persist_on && C == 32 && Cout == 32 && gate_bits && g.M >= 8 * DG_ROWS) {
+  if (C == 32 && Cout == 32 && gate_bits && g.M >= 8 * DG_ROWS) {
     auto k = conv_dgrad32_stream_k;
     static bool once = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024), true);
     (void)once;
@@ -2424,7 +2417,7 @@ extern "C" int clica_conv_k4s2_fwd_image(const float* x, const float* Wg, const 
   CLICA_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 7) == 0 && aligned16(out), "clica_conv_k4s2_fwd_image: x must be 8-byte, out 16-byte aligned");
   const int64_t pixels = images * (H / 2) * (W / 2);
   CLICA_CHECK_ARG(pixels < ((int64_t)1 << 31), "clica_conv_k4s2_fwd_image: %lld output pixels (< 2^31 supported)", (long long)pixels);
-  static const int ablate = [] { const char* e = getenv("CLICA_FWD_IMAGE_ABLATE"); return e ? atoi(e) : 0; }();      // timing ablations (WRONG results): 1 no output stores, 2 no gate words
+  constexpr int ablate = 0;
   hipLaunchKernelGGL(conv_fwd_image_valu_k, dim3((unsigned)kNumCU * 8), dim3(256), 0, as_stream(stream), x, Wg, bias, (unsigned)pixels, (int)Cout,
                      (int)H, (int)W, shift_of(H / 2), shift_of(W / 2), (int)relu, out, gate_bits, amax_slots, ablate);
   return launch_status("clica_conv_k4s2_fwd_image");
@@ -2447,8 +2440,7 @@ extern "C" int clica_conv_k4s2_wgrad_image(const float* dO, const float* x, int6
   float* dbslab = (float*)((char*)workspace + slab_bytes);
   hipStream_t st = as_stream(stream);
   const size_t lds = (size_t)4 * (Cout * K + Cout) * sizeof(float);
-  static const int valu = [] { const char* e = getenv("CLICA_WGRAD_IMAGE"); return (e && e[0] == 'v') ? 1 : 0; }();      // A/B switch: CLICA_WGRAD_IMAGE=valu keeps the vector-ALU kernel
-  if (Cout == 32 && !valu)
+  if (Cout == 32)
     hipLaunchKernelGGL(conv_wgrad_image_mfma_k, dim3((unsigned)p.blocks), dim3(256), 0, st, dO, x, rows, (int)H, (int)W, shift_of(H / 2), shift_of(W / 2),
                        p.rows_per_block, slab, db ? dbslab : (float*)nullptr);
   else

@@ -807,10 +807,6 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd, int residen
   // HBM-level stream splits.  A workgroup already cuts its chunk eight ways on chip, so HBM-level splits only exist to fill
   // the chip (cost model below).  Splits are whole LDS tiles.  E.g. B = B3 = 6144, n = 10: 96 tiles x 8 splits of 768 rows
   // = exactly 3 workgroups per CU; the 8-rank pool (B3 = 49 152): 96 x 24 splits of 2048 rows = three rounds of that.
-  // CLICA_LP_WG_PER_CU[_FWD] = <k> forces "about k per CU" instead (tuning; read once).
-  static const int env_b = [] { const char* e = getenv("CLICA_LP_WG_PER_CU"); return e ? atoi(e) : 0; }();
-  static const int env_f = [] { const char* e = getenv("CLICA_LP_WG_PER_CU_FWD"); return e ? atoi(e) : 0; }();
-  const int env = bwd ? env_b : env_f;
   const int64_t max_split = ceil_div(n_str, TS);
   auto finish = [&](int64_t ns) {
     if (ns < 1) ns = 1;
@@ -820,7 +816,6 @@ inline Plan make_plan(int64_t n_own, int64_t n_str, int n, bool bwd, int residen
     P.chunk = (int)chunk;
     P.nsplit = (int)(n_str > 0 ? ceil_div(n_str, chunk) : 1);
   };
-  if (env > 0) { finish(ceil_div((int64_t)kNumCU * env, P.tiles)); return P; }
   // Cost model (fitted to tools/loss_train_probe.py sweeps, B = 6144, pools of 6144 and 49 152 rows, n = 10 and n = 40):
   // a CU holds RES workgroups at a time (register-limited: 3 waves per SIMD up to the 16-wide layout, 2 above), which share
   // it, so a "round" of RES workgroups per CU lasts RES x (rows per split + a fixed prologue / merge cost of ~192 rows'

@@ -587,10 +587,12 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
 // with the forward's means folded into its reduction (three launches fewer than fwd + bwd_sym) -------------------------
 struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes;
                  bool mfma; lp2::Plan P2; lp2::Ws w2; };
-// CLICA_LP_TRAIN_FAST (bits, default 7): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (A/B switches; Params::train),
-// 4 = p = 2 sweeps on the matrix cores (lp_mfma.hip; needs bits 1 and 2 semantics: pool contains the anchors)
-static int train_flags() { static int v = [] { const char* e = getenv("CLICA_LP_TRAIN_FAST"); return e ? atoi(e) : 7; }(); return v; }
-static bool train_mfma(const clica_lp_loss_desc* d) { return (train_flags() & 7) == 7 && lp2::applies(d->n, d->p, d->pow); }      // (its fallback is the fixed-maximum / folded-coefficient difference sweep)
+// training-pair forms (bits; all on): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (Params::train),
+// 4 = p = 2 sweeps on the matrix cores where lp_mfma.hip's policy admits them (needs the semantics of bits 1 and 2: the pool contains the anchors)
+static constexpr int train_flags() { return 7; }
+static bool train_mfma_shape(const clica_lp_loss_desc* d) { return (train_flags() & 7) == 7 && lp2::applies(d->n, d->p, d->pow); }
+// (its fallback is the fixed-maximum / folded-coefficient difference sweep)
+static bool train_mfma(const clica_lp_loss_desc* d) { return train_mfma_shape(d) && lp2::applies_to_pool(d->B, d->B3); }
 static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols, bool mfma) {
   TrainWs w; char* p = (char*)ws; size_t off = 256;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
@@ -618,7 +620,9 @@ extern "C" int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, 
   int rc = validate(d, "clica_lp_loss_train_workspace_bytes");
   if (rc) return rc;
   CLICA_CHECK_ARG(bytes != nullptr, "clica_lp_loss_train_workspace_bytes: bytes is NULL");
-  *bytes = carve_train(nullptr, make_plan(d->B, d->B3, d->n, false), make_plan(d->B, d->B3, d->n, true), d->B, d->B3, train_mfma(d)).bytes;
+  // (sized for the matrix-core sweeps wherever the shape admits them, whatever the pool policy in force: clica_lp_loss_set_matrix_cores
+  //  may switch them on for this workspace later)
+  *bytes = carve_train(nullptr, make_plan(d->B, d->B3, d->n, false), make_plan(d->B, d->B3, d->n, true), d->B, d->B3, train_mfma_shape(d)).bytes;
   return CLICA_OK;
 }
 
@@ -927,12 +931,11 @@ static void row_dots(const float* a, int64_t lda, const float* b, int64_t ldb, i
 //   backward  S again, then in place  W_ij = statC_i 2^(S_ij log2(e)/tau - statL_i)   (bwd_coef_k's row statistics)
 //             dU1 += W U3                  clica_linear_dgrad (M = B,  N = B3, K = n)
 //             dU3 (+)= W^T U1              clica_linear_wgrad (M = B,  N = B3, K = n)
-// CLICA_DOT_MFMA=0 keeps the pair sweep at every width.
+// clica_set_tuning("dot_mfma", 0) keeps the pair sweep at every width (test hook: both paths are product paths, chosen by width).
 constexpr int kDotMfmaMinN = 96;      // measured crossover (tools/simclr_bench.py, B = 4096): n = 64 472 vs 512 us, n = 128 925 vs 554 us
 constexpr int DOT_CHUNK = 2048;            // columns per (max, sum) partial: 32 values per lane
-static int read_dot_env() { const char* e = getenv("CLICA_DOT_MFMA"); return !(e && atoi(e) == 0); }
-static int& dot_mfma_switch() { static int on = read_dot_env(); return on; }
-void reload_dot_env() { dot_mfma_switch() = read_dot_env(); }       // clica_reload_env (linear.hip)
+static int& dot_mfma_switch() { static int on = 1; return on; }
+void set_dot_mfma(int on) { dot_mfma_switch() = on ? 1 : 0; }       // clica_set_tuning (linear.hip)
 static bool dot_mfma(const clica_dot_loss_desc* d) { return dot_mfma_switch() && d->n >= kDotMfmaMinN; }
 struct DotMfmaWs { float* S; int64_t ldS; float2* part; int nchunk; float* T; void* wg; size_t wg_bytes; size_t bytes; };
 static DotMfmaWs carve_dot_mfma(void* ws, size_t off, int64_t B, int64_t B3, int n, bool bwd) {

@@ -589,21 +589,26 @@ float spread_limit() {
   return g_limit > 0.f ? g_limit : env_limit;
 }
 
-static int g_enabled = -1;      // -1: take CLICA_LP_MFMA (default on); set_enabled overrides it for the process
-void set_enabled(int on) { g_enabled = on < 0 ? -1 : (on ? 1 : 0); }
-bool applies(int n, float p, int pow) {
+// 0: never; 1 (the default): only where the negatives pool is at least four times the local rows (the gathered pool of a data-parallel
+// job); 2: whatever the pool.  Round 6: at the reference's own spread (M ~ 511) the gradient of the matrix-core sweeps
+// measures 6.4e-6 of its 1e-5 budget where the coordinate-difference sweeps hold 2.1e-6, and at a local pool (B3 = B) the trade buys 13 us
+// of a 350 us step -- so a single-rank step runs the difference sweeps (which is also what north_star describes: MFMA for the GEMMs, not
+// for the Lp distance); at the 49 152-row pool of the 8-rank job the sweeps are ~40 % of the step and the matrix cores stay.
+static int g_enabled = -1;      // -1: take CLICA_LP_MFMA (default 1); set_enabled overrides it for the process
+void set_enabled(int on) { g_enabled = on < 0 ? -1 : (on > 2 ? 2 : on); }
+static int mode() {
   static const int env_on = env_int("CLICA_LP_MFMA", 1);
-  const int on = g_enabled >= 0 ? g_enabled : env_on;
-  return on != 0 && p == 2.f && pow != 0 && n >= 1 && n <= MAX_N;
+  return g_enabled >= 0 ? g_enabled : env_on;
 }
+bool applies(int n, float p, int pow) { return mode() != 0 && p == 2.f && pow != 0 && n >= 1 && n <= MAX_N; }
+bool applies_to_pool(int64_t n_own, int64_t n_pool) { return mode() >= 2 || (mode() == 1 && n_pool >= 4 * n_own); }
 
 Plan make_plan(int64_t n_own, int64_t n_pool) {
   // anchor tiles per wave: measured (3 workgroups per CU) pool 6 144: T = 1 29 + 36 us, T = 2 31 + 43; pool 49 152: T = 1 71 + 146, T = 2 67 + 142
-  // -> two tiles (half the pool reads per pair) once the pool is several times the local rows; CLICA_LP_MFMA_T = 1 | 2 forces
-  static const int envT = env_int("CLICA_LP_MFMA_T", 0);
-  static const int wg_per_cu = env_int("CLICA_LP_MFMA_WG_PER_CU", 3);
+  // -> two tiles (half the pool reads per pair) once the pool is several times the local rows
+  constexpr int wg_per_cu = 3;
   Plan P;
-  P.T = envT == 2 ? 2 : (envT == 1 ? 1 : (n_pool >= 4 * n_own ? 2 : 1));
+  P.T = n_pool >= 4 * n_own ? 2 : 1;
   const int64_t per_group = (int64_t)WAVES * P.T * ROWS;
   P.groups = ceil_div(n_own > 0 ? n_own : 1, per_group);
   P.own_tiles = P.groups * WAVES * P.T;

@@ -141,7 +141,10 @@ __device__ __forceinline__ void split16_update_tensor(Split16State* st, int L, i
       int e = (int)((bits >> 23) & 0xffu) - 127;      // floor(log2 a) for normal a
       if (((bits >> 23) & 0xffu) == 0u) e = -127;
       int se = kF16Target - e;
-      se = se < -100 ? -100 : (se > 100 ? 100 : se);
+      // (+-60: the weight-gradient kernel divides its slab by the PRODUCT of two scales, which must stay a finite, non-zero fp32 number
+      //  -- 2^+-120 -- for tensors of any size; a tensor whose maximum lies beyond 2^68 then overflows its scale and is caught
+      //  by the guard, one below 2^-52 keeps fewer than 22 bits)
+      se = se < -60 ? -60 : (se > 60 ? 60 : se);
       nxt = __uint_as_float((unsigned)(se + 127) << 23);
     }
   }

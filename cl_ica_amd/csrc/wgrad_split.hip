@@ -893,12 +893,11 @@ __global__ __launch_bounds__(256) void planes16_from_f32_t_k(const float* __rest
 
 // ---- plan: which body per layer, how many contraction splits -----------------------------------------------------------------
 struct Plan { int splits, gps, groups, tiles, n_tiny, tiny_splits; int64_t tiny_kps; int big_tiles; };
-static bool big_on() { static const bool on = [] { const char* e = getenv("CLICA_WSPLIT_BIG"); return !(e && atoi(e) == 0); }(); return on; }
 // tile shape of a problem: 2 = 256 x 256 when both dimensions need more than one 128-wide tile, else 256 x 128 / 128 x 256 along
 // the longer side
 static void tile_shape(int32_t N, int32_t K, int* kind, int* gx, int* gy, bool with_db) {
   const int cols = K + (with_db ? 1 : 0);
-  if (big_on() && N > 128 && cols > 128) { *kind = 2; *gy = (int)ceil_div(N, 256); *gx = (int)ceil_div(cols, 256); return; }
+  if (N > 128 && cols > 128) { *kind = 2; *gy = (int)ceil_div(N, 256); *gx = (int)ceil_div(cols, 256); return; }
   *kind = N >= K ? 1 : 0;
   const int bm = *kind ? 256 : 128, bn = *kind ? 128 : 256;
   *gy = (int)ceil_div(N, bm);
@@ -930,12 +929,6 @@ static Plan make_plan(int64_t Mrows, int n, const int32_t* N, const int32_t* K) 
     const int64_t rounds = ceil_div(items, kNumCU);
     const double cost = (double)rounds * (16.0 * gps + 48.0) + 8.0 * sp + (p.big_tiles ? 4.0 * sp_big : 0.0);
     if (cost < best) { best = cost; p.splits = sp; p.gps = gps; }
-  }
-  static const int forced = [] { const char* e = getenv("CLICA_WSPLIT_SPLITS"); return e ? atoi(e) : 0; }();
-  if (forced > 0) {
-    p.gps = (int)ceil_div(p.groups, forced);
-    if (p.big_tiles) p.gps = std::max(2, (p.gps + 1) & ~1);
-    p.splits = (int)ceil_div(p.groups, p.gps);
   }
   if (p.n_tiny > 0) gemm::wgrad_tiny_plan(Mrows, p.n_tiny, &p.tiny_splits, &p.tiny_kps);
   return p;
@@ -1174,16 +1167,15 @@ extern "C" int clica_mlp_planes_from_f32_t(const float* X, int64_t ldx, int64_t 
 }
 
 static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, const char* who, bool f16 = false) {
-  static const int forced = [] { const char* e = getenv("CLICA_SPLIT_GEMM_TILE"); return e ? atoi(e) : -1; }();     // 0 / 1 / 2 (tuning)
   // 128 x 256 tiles when the output is wide enough, else 256 x 128; with whole rounds of 256 x 256 tiles in front where they fit
-  // (mixed tiling, see gemm_split_k).  CLICA_SPLIT_GEMM_TILE = 0 / 1 / 2 forces one shape, 3 / unset = this rule.
-  g.a_wide = forced >= 0 && forced <= 3 ? forced : (cols >= 256 ? 0 : 1);
+  // (mixed tiling, see gemm_split_k)
+  g.a_wide = cols >= 256 ? 0 : 1;
   int total;
   const int gx256 = (int)ceil_div((int64_t)cols, (int64_t)256);
   // mixed: whole rounds of 256 x 256 tiles (kNumCU / gx row tiles each) while a full round fits, 128 x 256 tiles for the rest
   const int64_t rows_per_big_round = (int64_t)(kNumCU / gx256) * 256;
-  const int64_t big_rounds = (gx256 <= kNumCU && forced != 0 && forced != 1 && forced != 2 && cols >= 256) ? M / rows_per_big_round : 0;
-  if ((forced == 3 || forced < 0) && big_rounds >= 1 && M - big_rounds * rows_per_big_round > 0) {
+  const int64_t big_rounds = (gx256 <= kNumCU && cols >= 256) ? M / rows_per_big_round : 0;
+  if (big_rounds >= 1 && M - big_rounds * rows_per_big_round > 0) {
     g.a_wide = 3;
     g.gx = gx256;
     g.rows_big = (int)(big_rounds * rows_per_big_round);
@@ -1191,7 +1183,6 @@ static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, c
     total = g.n_big + (int)ceil_div(M - g.rows_big, (int64_t)128) * g.gx;
     g.gy = 0;
   } else {
-    if (g.a_wide == 3) g.a_wide = cols >= 256 ? 0 : 1;
     const int bm = g.a_wide == 0 ? 128 : 256, bn = g.a_wide == 1 ? 128 : 256;
     g.gy = (int)ceil_div(M, (int64_t)bm); g.gx = (int)ceil_div((int64_t)cols, (int64_t)bn);
     total = g.gx * g.gy;

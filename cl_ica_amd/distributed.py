@@ -95,11 +95,11 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # test hooks (tools/dp_bench_smoke.sh: the multi-rank control flow of bench.py on a ONE-GPU box): every rank on cuda:0,
-    # collectives over gloo
-    if os.environ.get("CLICA_SHARE_DEVICE") == "1":
-        local = 0
+    # test hook (tools/dp_bench_smoke.sh, tests/test_gpu_bench.py: the multi-rank control flow of bench.py on a ONE-GPU box):
+    # CLICA_DIST_BACKEND=gloo runs the collectives over gloo, and ranks beyond the box's GPUs share cuda:0 (RCCL refuses two ranks on one device)
     backend = backend or os.environ.get("CLICA_DIST_BACKEND") or None
+    if backend == "gloo" and torch.cuda.is_available() and local >= torch.cuda.device_count():
+        local = 0
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)

@@ -432,14 +432,8 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         return (None, None, *dxs, *grads)
 
 
-def _early_repack() -> bool:
-    import os
-    return os.environ.get("CLICA_DROPIN_EARLY_PACK", "1") != "0"
-
-
 def _after_step():
-    if _early_repack():
-        _MLPFusedSplitFn.repack_if_changed()
+    _MLPFusedSplitFn.repack_if_changed()          # weights re-packed at step end (the next forward finds them ready)
 
 
 lazy.AFTER_STEP.append(_after_step)
@@ -448,13 +442,12 @@ lazy.AFTER_STEP.append(_after_step)
 def _dropin_split(fits: bool) -> bool:
     """`fits`: the layers' padded widths fit the on-chip bias table of mlp_split_k (FusedMLP._structure)."""
     import os
-    return fits and os.environ.get("CLICA_SPLIT_BF16", "1") != "0" and os.environ.get("CLICA_DROPIN_SPLIT", "1") != "0"
+    return fits and os.environ.get("CLICA_SPLIT_BF16", "1") != "0"
 
 
 def _inplace_grads() -> bool:
-    """Master switch of the in-place weight-gradient accumulation (`_inplace_ok`); CLICA_DROPIN_INPLACE_GRAD=0 turns it off."""
-    import os
-    return os.environ.get("CLICA_DROPIN_INPLACE_GRAD", "1") != "0"
+    """In-place weight-gradient accumulation (`_inplace_ok`) is always on."""
+    return True
 
 
 def _inplace_ok(prm, need) -> bool:
@@ -492,12 +485,15 @@ def _use_fused(fusable: bool, M: int) -> bool:
     """Whole-encoder kernels for the autograd path?  They own 48 rows per workgroup for the whole stack, so they want
     half of the 256 CUs busy (measured at 128 workgroups = one B = 6144 encoder call of the reference's train_step: 645 against
     594 steps/s through the per-layer GEMMs); smaller batches (and wide encoders) take the per-layer GEMMs.
-    CLICA_DROPIN_FUSED=0/1 forces.  `fusable`: > 1 layers, all with bias, every width <= 512 (FusedMLP._structure)."""
-    import os
-    e = os.environ.get("CLICA_DROPIN_FUSED", "auto")
+    `FUSED_MODE` ("auto" / "0" / "1"; tests force either product path on one shape).  `fusable`: > 1 layers, all with bias, every width
+    <= 512 (FusedMLP._structure)."""
+    e = FUSED_MODE
     if not fusable or e == "0":
         return False
     return True if e == "1" else (M + 47) // 48 >= 128
+
+
+FUSED_MODE = "auto"          # test hook (tests/test_gpu_mlp.py, test_gpu_next_rows.py): monkeypatch.setattr(encoders, "FUSED_MODE", "0" | "1")
 
 
 class FusedMLP(nn.Sequential):

@@ -34,9 +34,6 @@ from .distributed import GradBuckets
 __all__ = ["SamplerSpec", "ContrastiveTrainer"]
 
 
-_PACK_FORK = os.environ.get("CLICA_PACK_FORK", "0") == "1"      # see ContrastiveTrainer._step_body
-
-
 @dataclass
 class SamplerSpec:
     """Ground-truth latent distribution (main_mlp.py:136-200)."""
@@ -114,14 +111,13 @@ class ContrastiveTrainer:
         self.head = heads[0] if heads else None
         self._flatten_parameters()
         self.fused_forward = bool(fused_forward) and ops.mlp_fwd_fusable([lin.weight for lin in self.linears])
-        # CLICA_FUSE_SMALL bit 4: mixing net g inside the fused forward's prologue (needs the one-launch forward, n <= 16)
-        self.mix_in_forward = bool(getattr(self, "_fuse_flags", int(os.environ.get("CLICA_FUSE_SMALL", "13"))) & 4) \
-            and self.fused_forward and self.n <= 16 and self.g_act_kind == 0
+        # mixing net g inside the fused forward's prologue (needs the one-launch forward, n <= 16)
+        self.mix_in_forward = self.fused_forward and self.n <= 16 and self.g_act_kind == 0
         self._x_pending = False
         self.packed = None
         self.packed_t = None
         self._packed_current = False
-        self.fused_backward = self.fused_forward and os.environ.get("CLICA_FUSED_BWD", "1") != "0" and len(self.linears) > 1
+        self.fused_backward = self.fused_forward and len(self.linears) > 1
         # encoder arithmetic: the whole-stack kernels and the weight gradients on the bf16 matrix cores with exact 3-way bf16
         # operand splits (fp32 emulation: six bf16 products per fp32 product, fp32 accumulate, fp32-grade error) --
         # the default where the encoder fits the whole-stack kernels; split_bf16=False / CLICA_SPLIT_BF16=0 = native fp32 MFMA
@@ -140,7 +136,6 @@ class ContrastiveTrainer:
         self.split_f16_wide = False                                          # per-layer wide path in f16x2 (decided in _allocate)
         self.s16 = None
         self._s16_calibrated = False
-        self.pack_weights = os.environ.get("CLICA_MLP_PACK", "1") != "0"     # A/B switch
         if self.world > 1:
             # identical replicas by construction: rank 0's parameters and mixing weights win (callers that seed every rank
             # identically are unaffected; callers that do not would otherwise train `world` different models silently)
@@ -161,8 +156,7 @@ class ContrastiveTrainer:
         # data parallel + grouped weight gradients: the grouped launch is issued in TWO halves (layers L-1 .. h, then h-1 .. 0) and
         # the first half's slice of the gradient arena is all-reduced on the communication stream while the second half's GEMMs run
         L = len(self.linears)
-        self.wgrad_halves = bool(self.dp and self.fused_backward and self.grouped_wgrad and L >= 4
-                                 and os.environ.get("CLICA_WGRAD_HALVES", "1") != "0")
+        self.wgrad_halves = bool(self.dp and self.fused_backward and self.grouped_wgrad and L >= 4)
         self._half = L // 2
         if self.wgrad_halves and self.group_ws is not None:
             # each half's launch plans its own contraction splits (fewer tiles -> more splits per layer -> larger slabs than in the
@@ -231,13 +225,6 @@ class ContrastiveTrainer:
                 lo, hi = self._layer_slices[0]
                 self._layer_slices[0] = (min(lo, o), max(hi, o + (k + 3) // 4 * 4))
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # clica_adam_step_tick's arrival counter
-        # A/B switch (bits): 1 = pair sampler launch (+0.7 %), 2 = tick inside Adam (-0.5 %: 834 same-address atomics cost more
-        # than the 4.6 us single-thread tick launch they replace; off), 4 = mixing net in the fused forward's prologue,
-        # 8 = step counter advanced by the loss backward's reduction launch (+0.4 %)
-        fs = int(os.environ.get("CLICA_FUSE_SMALL", "13"))
-        self.fuse_small, self.fuse_tick = bool(fs & 1), bool(fs & 2)
-        self._fuse_flags = fs
 
     def _allocate(self):
         dev, B, n = self.device, self.B, self.n
@@ -262,13 +249,13 @@ class ContrastiveTrainer:
         fb, bb = C.c_size_t(), C.c_size_t()
         _lib.check(_lib.load().clica_lp_loss_workspace_bytes(C.byref(self.desc), C.byref(fb), C.byref(bb)), "workspace")
         tb = C.c_size_t()
-        self.loss_train = self.p >= 1 and os.environ.get("CLICA_LOSS_TRAIN", "1") != "0"     # fused training pair of loss entry points
+        self.loss_train = self.p >= 1                  # fused training pair of loss entry points
         if self.loss_train:
             _lib.check(_lib.load().clica_lp_loss_train_workspace_bytes(C.byref(self.desc), C.byref(tb)), "train workspace")
         self.loss_ws = torch.zeros(max(fb.value, bb.value, tb.value), dtype=torch.uint8, device=dev)
         # the step / RNG counter is advanced by the loss backward's reduction launch (all samplers of the step have run by then)
         # instead of a separate one-thread launch at the end; Adam then takes t = counter
-        self.early_tick = self.loss_train and not self.fuse_tick and bool(self._fuse_flags & 8)
+        self.early_tick = self.loss_train
         self._ticked = False
         nb = C.c_size_t(); need = 0
         for lin in self.linears:
@@ -277,8 +264,7 @@ class ContrastiveTrainer:
         self.wgrad_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         self.wgrad_ws2 = torch.zeros(need, dtype=torch.uint8, device=dev)    # second stream's slabs
         self.dz = [torch.empty((R, w), **f32) for w in widths[:-1]] if self.fused_backward else None   # dZ_l for the wgrads
-        self.grouped_wgrad = self.fused_backward and os.environ.get("CLICA_GROUPED_WGRAD", "1") != "0" and all(
-            lin.bias is not None for lin in self.linears)
+        self.grouped_wgrad = self.fused_backward and all(lin.bias is not None for lin in self.linears)
         self.group_ws = ops.mlp_wgrad_workspace(R, [tuple(lin.weight.shape) for lin in self.linears], dev) if self.grouped_wgrad else None
         # sign bits of every hidden activation, written by the fused forward, read by the fused backward chain
         self.signmasks = (ops.mlp_signmask_alloc(R, len(self.linears) - 1, dev) + [None]) if self.fused_backward else None
@@ -287,14 +273,13 @@ class ContrastiveTrainer:
         # dZ); the tiny first / last layer keeps the fp32 VALU kernel, so the tensors next to them stay fp32 as well.
         L = len(self.linears)
         kinds = [ops.mlp_wgrad_split_kind(lin.out_features, lin.in_features) for lin in self.linears] if self.split_bf16 else []
-        self.split_wgrad = bool(self.split_bf16 and self.grouped_wgrad and L >= 3 and kinds[0] == 1 and kinds[-1] == 1
-                                and os.environ.get("CLICA_SPLIT_WGRAD", "1") != "0")
+        self.split_wgrad = bool(self.split_bf16 and self.grouped_wgrad and L >= 3 and kinds[0] == 1 and kinds[-1] == 1)
         self.act_planes = [None] * L
         self.dz_planes = [None] * L
         self.acts_out = list(self.acts)                      # what the forward writes as fp32 (None: planes only)
         self.dz_out = list(self.dz) if self.dz is not None else None
         if self.split_wgrad:
-            keep = os.environ.get("CLICA_SPLIT_KEEP_FP32", "0") == "1"      # debug: also write every fp32 copy
+            keep = bool(getattr(self, "keep_fp32_copies", False))          # (inspection: also write every fp32 copy)
             for l in range(L):
                 if kinds[l] == 0:                            # dW_l = dZ_l^T acts_{l-1} on the bf16 / fp16 matrix cores
                     self.act_planes[l - 1] = ops.mlp_planes_alloc(R, widths[l - 1], True, dev, f16=self.split_f16)
@@ -309,8 +294,7 @@ class ContrastiveTrainer:
         # the fp32-MFMA kernels, the WEIGHT gradients of the MFMA-sized layers run in the split-bf16 arithmetic on plane copies
         # that an HBM-bound conversion kernel makes of the fp32 activations / gradients (clica_mlp_planes_from_f32)
         self.split_wgrad_wide = bool(self._want_split and not self.fused_forward and not self.fused_backward
-                                     and all(lin.bias is not None for lin in self.linears)
-                                     and os.environ.get("CLICA_SPLIT_WGRAD_WIDE", "1") != "0")
+                                     and all(lin.bias is not None for lin in self.linears))
         if self.split_wgrad_wide:
             # (round 5) the per-layer split kernels in the f16x2 arithmetic too: plane copies of 4 B/element, three products, per-tensor scales
             # in the same Split16 state (tensor = (family, layer): activations by the layer they feed, gradients and weights by their layer)
@@ -328,11 +312,11 @@ class ContrastiveTrainer:
         # activation), written by the previous chain layer's epilogue or converted from fp32 at the chain's head, and writes
         # T-planes for the next chain layer, N-planes for the next layer's weight gradient, fp32 only where an fp32 kernel follows.
         self.chain = set()
-        if self.split_wgrad_wide and os.environ.get("CLICA_SPLIT_WIDE_CHAIN", "1") != "0":
+        if self.split_wgrad_wide:
             in_w = [lin.in_features for lin in self.linears]
             # (bf16x3: 1024 -- with the 400-wide layers in the chain one p = 1 gradient check of G13 measures 1.1e-5; f16x2: 384 -- all of
             #  config 3's checks hold 1e-5 and the step gains 13 %: 198 -> 225 steps/s)
-            cmin = int(os.environ.get("CLICA_SPLIT_CHAIN_MIN", "384" if self.split_f16_wide else "1024"))
+            cmin = 384 if self.split_f16_wide else 1024
             self.chain = {l for l in range(1, L - 1) if self.wide_kinds[l] == 0 and in_w[l] >= cmin and widths[l] >= cmin}
         if self.chain:
             in_w = [lin.in_features for lin in self.linears]
@@ -380,13 +364,6 @@ class ContrastiveTrainer:
                     self._eta[0, 0] = 1.0                      # main_mlp.py:148-150
             mean = self._eta
         # both draws in one launch for the coordinate-wise kinds (box, R^n); two for the sphere / vMF
-        if not self.fuse_small:
-            ops.sample(s.space, s.marginal, n, B, self.device, mean=mean, scale=s.m_param, shape_p=s.m_p, box=s.box,
-                       seed=s.seed, stream_id=sid, step_dev=self.step_dev, out=z)
-            ops.sample(s.space, s.conditional, n, B, self.device, mean=z, scale=s.c_param, shape_p=s.c_p, box=s.box,
-                       seed=s.seed, stream_id=sid + 1, step_dev=self.step_dev, out=zt)
-            ops.mixing_fwd(self.z, self.gW, self.g_slope, out=self.x, act_kind=self.g_act_kind)
-            return
         ops.sample_pair(s.space, s.marginal, s.conditional, n, B, z, zt, marginal_mean=mean, m_scale=s.m_param, m_p=s.m_p,
                         c_scale=s.c_param, c_p=s.c_p, box=s.box, seed=s.seed, stream_id=sid, step_dev=self.step_dev)
         self._mix()
@@ -406,8 +383,7 @@ class ContrastiveTrainer:
     def _pack_sample_merged(self) -> bool:
         """The step's two independent front launches -- weight pack and latent pair draw -- in ONE (clica_mlp_pack_split16_both_sample):
         f16x2 arithmetic, packed buffers already allocated, the one-launch sampler path.  False: the caller runs them separately."""
-        if (self.s16 is None or not self.split_bf16 or self.packed is None or self.packed_t is None or not self.fuse_small
-                or os.environ.get("CLICA_PACK_SAMPLE_MERGE", "1") == "0"):
+        if self.s16 is None or not self.split_bf16 or self.packed is None or self.packed_t is None:
             return False
         s, B, n = self.sampler, self.B, self.n
         mean = None
@@ -430,13 +406,10 @@ class ContrastiveTrainer:
         ws = [lin.weight for lin in self.linears]
         if self.split_bf16:
             self.packed, self.packed_t = ops.mlp_pack_split_both(ws, self.packed, self.packed_t, state=self.s16)
-        elif self.fused_backward and self.pack_weights:
-            self.packed, self.packed_t = ops.mlp_pack_both(ws, self.packed, self.packed_t)
-        elif self.fused_forward and self.pack_weights:
-            self.packed = ops.mlp_pack_weights(ws, self.packed)
         elif self.fused_backward:
-            chain = [self.linears[l].weight for l in range(len(self.linears) - 1, 0, -1)]
-            self.packed_t = ops.mlp_pack_weights(chain, self.packed_t, transpose=True)
+            self.packed, self.packed_t = ops.mlp_pack_both(ws, self.packed, self.packed_t)
+        elif self.fused_forward:
+            self.packed = ops.mlp_pack_weights(ws, self.packed)
         self._packed_current = True
 
     def forward(self):
@@ -566,19 +539,22 @@ class ContrastiveTrainer:
                                              self.dy[:B].data_ptr(), n, self.dy[B:].data_ptr(), n,
                                              self.loss_ws.data_ptr(), self.loss_ws.numel(), st), "clica_lp_loss_bwd_sym")
 
+    # Test hooks (class attributes, tests/test_gpu_engine.py): both the folded and the unfolded launch structures are product paths -- the
+    # unfolded ones run under data parallelism and behind a head -- and the equivalence tests compare them on ONE trainer configuration.
+    chain_tail = True            # the backward chain's tail writes the n-wide layers' weight-gradient slabs (clica_mlp_dgrad_split_tail)
+    fold_dy_reduce = True        # ... and its prologue finishes dy from the loss sweep's partials (no reduction launch)
+
     def _chain_tail_ok(self) -> bool:
         if not hasattr(self, "_tail_ok"):
-            self._tail_ok = (os.environ.get("CLICA_CHAIN_TAIL", "1") != "0" and self.dz_out[0] is not None and
+            self._tail_ok = (self.chain_tail and self.dz_out[0] is not None and
                              ops.mlp_chain_tail_supported([tuple(lin.weight.shape) for lin in self.linears]))
         return self._tail_ok
 
     def _chain_takes_partials(self, emu: bool) -> bool:
         """Will THIS step's backward chain run with its tail (clica_mlp_dgrad_split_tail) directly on dy?  Then it can finish dy itself."""
-        if os.environ.get("CLICA_FOLD_DY_REDUCE", "1") == "0" or not getattr(self, "_in_step", False):
+        if not self.fold_dy_reduce or not getattr(self, "_in_step", False):
             return False
         if self.dp or emu or self.head is not None or not (self.split_bf16 and self.split_wgrad and self.fused_backward):
-            return False
-        if self.fuse_tick and not self.early_tick:
             return False
         return self._adam_folds_into_wgrad() and self._chain_tail_ok()
 
@@ -613,7 +589,7 @@ class ContrastiveTrainer:
         if self.split_bf16:
             tail = None
             self._tail_ready = False
-            if getattr(self, "_fold_adam", False) and self.split_wgrad and not (self.fuse_tick and not self._ticked):
+            if getattr(self, "_fold_adam", False) and self.split_wgrad:
                 # inside a training step (N = 1): the chain's workgroups also leave the n-wide first / last layer's weight-gradient
                 # slabs (clica_mlp_dgrad_split_tail) -- weight_grads() then needs no tiny-dimension launch
                 if self._chain_tail_ok():
@@ -640,7 +616,7 @@ class ContrastiveTrainer:
         dbs = [self._gviews[id(self.linears[l].bias)] for l in order]
         if self.split_wgrad:
             adam = None
-            if getattr(self, "_fold_adam", False) and layers is None and not (self.fuse_tick and not self._ticked):
+            if getattr(self, "_fold_adam", False) and layers is None:
                 # inside a training step (N = 1): the reduction launch that ends the weight gradients applies the optimizer as well
                 # (clica_mlp_wgrad_split_adam) -- optimizer_step() then has nothing left to launch
                 adam = dict(param=self.param_arena, grad=self.grad_arena, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq,
@@ -810,8 +786,6 @@ class ContrastiveTrainer:
     def _adam_folds_into_wgrad(self) -> bool:
         """The optimizer can ride in the weight-gradient reduction when ONE whole-stack split launch produces every gradient of the
         arena and nothing has to happen between gradient and update (no data-parallel all-reduce, no gradient scaling)."""
-        if os.environ.get("CLICA_ADAM_IN_WGRAD", "1") == "0":
-            return False
         if not (self.split_wgrad and self.fused_backward and self.grouped_wgrad) or self.buckets is not None:
             return False
         if self.world * self.dry_ranks != 1:
@@ -828,40 +802,28 @@ class ContrastiveTrainer:
             if not ticked:
                 ops.tick(self.step_dev)
             return
-        # the last Adam workgroup to finish also advances the device step / RNG counter (no separate tick launch)
         ticked, self._ticked = self._ticked, False
         fused_update = ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                                      self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / (self.world * self.dry_ranks),
-                                     ticket=self.adam_ticket if (self.fuse_tick and not ticked) else None, t_offset=0 if ticked else 1,
-                                     s16=self.s16)
+                                     t_offset=0 if ticked else 1, s16=self.s16)
         self._s16_updated = bool(fused_update)
-        if not self.fuse_tick and not ticked:
+        if not ticked:
             ops.tick(self.step_dev)
 
     # -------------------------------------------------------------------------------- whole step
     def _step_body(self, sample: bool):
-        # The fragment-order weight copies only depend on the parameters.  Rounds 2-5 packed them on the side stream beside the samplers
-        # (two parallel branches at the root of the step graph); measured at the end of round 5: the fork / join of a HIP graph costs more
-        # than the 9 us of sampling it hides -- 2 622 / 2 609 steps/s forked against 2 649 / 2 638 with the pack in line on one box
-        # (tools/headline_ab.sh; the same fork in front of the KITTI-masks conv stack cost 107 us per step).  CLICA_PACK_FORK=1 keeps the fork.
+        # The fragment-order weight copies only depend on the parameters; they are packed IN LINE in front of the forward -- merged with the
+        # latent pair draw into one launch where that exists.  (Rounds 2-5 packed on a side stream beside the samplers: the fork / join of
+        # a HIP graph costs more than the 9 us of sampling it hid, profiles/r4_DESIGN_history.md.)
         if self.s16 is not None and not self._s16_calibrated:
             self.calibrate_scales(sample)
-        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        side = self.side_stream if _PACK_FORK else None
         self._packed_current = False          # a step always re-packs (parameters may have been set from outside)
-        if (self.fused_forward or self.fused_backward) and main is not None and side is not None and sample:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self.pack()
-            self.sample()
-            main.wait_stream(side)
-        else:
-            fused = (self.fused_forward or self.fused_backward) and main is not None
-            if not (sample and fused and self._pack_sample_merged()):
-                if sample:
-                    self.sample()
-                if fused:
-                    self.pack()                # (here, not inside forward(): bench.py's stamps bracket the encoder launch alone)
+        fused = (self.fused_forward or self.fused_backward) and self.device.type == "cuda"
+        if not (sample and fused and self._pack_sample_merged()):
+            if sample:
+                self.sample()
+            if fused:
+                self.pack()                    # (here, not inside forward(): bench.py's stamps bracket the encoder launch alone)
         st = getattr(self, "stamps", None)         # bench.py: device time stamps around the encoder launches, valid inside the graph
         if st:
             ops.stamp(st["null"], 0); ops.stamp(st["null"], 1)      # empty bracket: the stamp pair's own cost, subtracted by the reader
@@ -1045,9 +1007,9 @@ class ContrastiveTrainer:
         return dict(max_spread=float(v[0]), last_spread=float(v[1]), limit=float(v[2]), fallback_steps=int(v[3]))
 
     def set_loss_matrix_cores(self, on):
-        """Switch the p = 2 loss sweeps between the matrix cores (True) and the coordinate-difference sweeps (False); None = back to the
-        environment's setting.  Process-wide (clica_lp_loss_set_matrix_cores); a captured step graph is captured again."""
-        _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(-1 if on is None else (1 if on else 0)), "clica_lp_loss_set_matrix_cores")
+        """Switch the p = 2 loss sweeps between the matrix cores for every pool (True) and the coordinate-difference sweeps (False); None = back
+        to the default policy (matrix cores only against a pool of >= 4 x the local rows: include/clica.h).  Process-wide (clica_lp_loss_set_matrix_cores); a captured step graph is captured again."""
+        _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(-1 if on is None else (2 if on else 0)), "clica_lp_loss_set_matrix_cores")
         if self.graph is not None:
             self.graph = None
             self.capture()

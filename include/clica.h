@@ -37,9 +37,12 @@ extern "C" {
 typedef void* clica_stream_t;    /* hipStream_t */
 
 const char* clica_last_error(void);
-/* The library reads its tuning switches (CLICA_GEMM_CFG_*, CLICA_SKINNY, CLICA_DOT_MFMA) from the environment once, at the first launch;
- * call this after changing them inside a running process (tests, tuning sweeps). */
-int clica_reload_env(void);
+/* Test / tuning hook, process-wide (not part of the stable surface): the per-layer Linear entry points and SimCLRLoss choose their body
+ * by SHAPE; a test that wants the other product path on a given shape sets it here.  Keys: "skinny" (0: every Linear shape through the MFMA
+ * template instead of the vector-ALU kernels for tiny K / N), "gemm_cfg_fwd" / "gemm_cfg_dgrad" / "gemm_cfg_wgrad" (tile configuration id,
+ * -1: by shape), "dot_mfma" (0: SimCLRLoss pair sweep at every width), "reset" (all defaults).  Unknown key: CLICA_E_INVALID.  The library
+ * reads NO tuning switch from the environment (the environment variables it does read are listed in INTEGRATION.md). */
+int clica_set_tuning(const char* key, int32_t value);
 /* After a FAILED stream capture on `stream` (e.g. a collective that cannot be captured): end the capture if the stream is
  * still capturing, wait for the device and clear the runtime's pending error, so that later launches report their own
  * status.  Harmless when nothing failed. */
@@ -141,7 +144,7 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * it has terms of size M = log2(e)/tau max_i |z_i - origin|^2 (origin = the mean of the pool's first 64 rows).  The large part of every
  * term of the logit is computed EXACTLY (hi pieces on a grid common to the launch, accumulated apart) and the loss holds 1e-5 at every
  * spread measured (2e-6 at M = 15 000); the gradient's second product accumulates terms of size sqrt(M) in fp32 and its error grows
- * ~ sqrt(M).  THE GUARD (round 5): every fwd_train call measures its own M on the device; when it exceeds the spread limit (default 768:
+ * ~ sqrt(M).  THE GUARD (round 5): every fwd_train call measures its own M on the device; when it exceeds the spread limit (default 700:
  * gradient error < 1e-5 against the fp64 oracle with margin, tests/test_gpu_loss.py ..._spread_limit) the matrix-core sweeps of THAT call
  * return at once and the coordinate-difference sweeps (no such dependence), launched behind them with the opposite condition, do the
  * work.  The decision is made by the kernels per call -- no host round trip, valid inside a replayed graph; the fallback is not a launch
@@ -149,7 +152,11 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * built on the grid (step D, origin) the PREVIOUS call's prep launch measured; a call whose rows do not fit that grid (the first call on
  * a zeroed workspace, a cloud that grew across a power of two) is sent to the difference sweep by the same guard -- so keep ONE
  * workspace per training loop and do not zero it between steps.
- * CLICA_LP_MFMA=0 / clica_lp_loss_set_matrix_cores(0) remove the matrix-core sweeps altogether.
+ * WHERE THEY RUN (round 6): by default only against a pool of at least four times the local rows (B3 >= 4 B: the gathered negatives of a
+ * data-parallel job, where the pair sweeps are ~40 % of the step).  A single-rank step (B3 = B) runs the coordinate-difference sweeps: at
+ * the spread the reference's own training reaches (M ~ 511) the matrix-core gradient measures 6.4e-6 of the 1e-5 budget where the
+ * difference sweeps hold 2.1e-6, and the trade buys 13 us of a 350 us step.  CLICA_LP_MFMA / clica_lp_loss_set_matrix_cores: 0 never,
+ * 1 the default policy, 2 every pool.
  * clica_lp_loss_train_path reports which launches a call makes:
  * *path = 1 matrix cores with the guarded fallback behind them, 0 VALU sweeps only. */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);
@@ -165,8 +172,8 @@ int clica_lp_loss_train_guard(const clica_lp_loss_desc* d, const void* workspace
 /* Process-wide spread limit of the guard (M above which a call falls back); <= 0: back to CLICA_LP_MFMA_LIMIT / the default.  The limit is
  * a kernel ARGUMENT: a captured graph keeps the one it was captured with. */
 int clica_lp_loss_set_spread_limit(float limit);
-/* Process-wide switch between the matrix-core (1) and the VALU-only (0) launches behind the training pair; negative: back to
- * CLICA_LP_MFMA's setting.  Takes effect at the next clica_lp_loss_fwd_train call; a workspace sized for the matrix-core path is large
+/* Process-wide policy of the matrix-core sweeps behind the training pair: 0 never (VALU sweeps only), 1 pools of >= 4 x the local rows
+ * (the default), 2 every pool; negative: back to CLICA_LP_MFMA's setting.  Takes effect at the next clica_lp_loss_fwd_train call; a workspace sized for the matrix-core path is large
  * enough for the other one; a captured graph keeps the launches it was captured with (re-capture). */
 int clica_lp_loss_set_matrix_cores(int32_t on);
 int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,

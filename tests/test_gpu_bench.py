@@ -44,7 +44,7 @@ def test_bench_gpus_2_starts_its_own_ranks_and_falls_back_to_eager():
     device), and the capture is made to fail on every rank, so the run also covers `capture_or_eager`'s agreement on eager launches
     (VERDICT r5 item 3).  The product collectives, the barrier-bracketed windows, the max over ranks, the `ranks` object and the
     single JSON line from rank 0 are the real ones; the numbers mean nothing."""
-    env = dict(os.environ, CLICA_SHARE_DEVICE="1", CLICA_DIST_BACKEND="gloo", CLICA_BENCH_INJECT_CAPTURE_FAILURE="all", PYTHONFAULTHANDLER="1")
+    env = dict(os.environ, CLICA_DIST_BACKEND="gloo", CLICA_BENCH_INJECT_CAPTURE_FAILURE="all", PYTHONFAULTHANDLER="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--windows", "2"],

@@ -184,10 +184,10 @@ def test_dp_code_path_single_rank(monkeypatch):
     data-parallel path launches; for the bit-for-bit comparison it runs with that fold off.  With it on: within 1e-5 of the largest
     gradient, test_gpu_mlp.py::test_wgrad_split_adam_equals_wgrad_then_adam.)"""
     import os
-    monkeypatch.setenv("CLICA_CHAIN_TAIL", "0")
     import torch.distributed as dist
     from cl_ica_amd import encoders
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    monkeypatch.setattr(ContrastiveTrainer, "chain_tail", False)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29517")
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -347,7 +347,7 @@ def test_loss_matrix_core_switch_and_spread():
     z1 = torch.rand(B, n, device="cuda"); z2 = (z1 + 0.05 * torch.randn_like(z1)).clamp(0, 1)
     tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
     lib, path = _lib.load(), C.c_int32()
-    _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
+    _lib.check(lib.clica_lp_loss_set_matrix_cores(2), "on for every pool (the default policy keeps a local pool on the difference sweeps)")
     try:
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
         tr.step_injected(z1, z2)
@@ -383,16 +383,19 @@ def _oracle_check_of_loss_state(tr, fam, case):
     PARITY.check(fam, case, "d loss / d y2", tr.dy[B:].cpu().numpy(), g2)
 
 
-def test_matrix_core_guard_falls_back_inside_graph_replay():
+def test_matrix_core_guard_falls_back_inside_graph_replay(request):
     """The guard is a device-side decision: a CAPTURED step graph whose embeddings spread beyond the limit between two replays (the last
     layer is scaled under the graph) runs that replay on the coordinate-difference sweeps -- no re-capture, no host round trip -- and comes
     back to the matrix cores when the spread does.  Every state is checked against the fp64 oracle."""
     from cl_ica_amd import encoders
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    from cl_ica_amd import _lib
     torch.manual_seed(4)
     n, B = 10, 1024
     f = encoders.get_mlp(n, n, [100, 500, 100]).to("cuda")
     gW = torch.eye(n, device="cuda").repeat(3, 1, 1).contiguous()
+    _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(2), "on for every pool (this test is about their guard; the default policy keeps a local pool off them)")
+    request.addfinalizer(lambda: _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(-1), "default policy"))
     tr = ContrastiveTrainer(f, gW, SamplerSpec(n=n), batch_size=B, p=2, lr=0.0, device="cuda")
     if tr.loss_guard()["limit"] == 0.0:
         pytest.skip("matrix-core sweeps disabled in this environment")
@@ -444,7 +447,7 @@ def test_matrix_core_loss_on_training_embeddings():
         sys.argv = argv
     tr = bench.build_trainer(args, torch.device("cuda"), 1)
     lib, path = _lib.load(), C.c_int32()
-    _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
+    _lib.check(lib.clica_lp_loss_set_matrix_cores(2), "on for every pool")
     try:
         _lib.check(lib.clica_lp_loss_train_path(C.byref(tr.desc), C.byref(path)), "path"); assert path.value == 1
         B = tr.B
@@ -453,35 +456,38 @@ def test_matrix_core_loss_on_training_embeddings():
                 tr.step()
             tr.sample(); tr.forward()
             res = {}
-            for mode in (1, 0):
+            for mode in (2, 0):
                 _lib.check(lib.clica_lp_loss_set_matrix_cores(mode), "switch")
                 tr.loss_forward_backward()
                 torch.cuda.synchronize()
                 res[mode] = (tr.dy.clone(), tr.loss_out.clone())
-                if mode == 1:
+                if mode == 2:
                     gs = tr.loss_guard()
                     spread = gs["last_spread"]
                     case = (f"after {k} steps (y std {float(tr.y.std()):.2f}, M = {spread:.0f}, "
                             f"{'difference sweeps (guard)' if spread > gs['limit'] else 'matrix cores'}, {gs['fallback_steps']} fallback steps so far)")
                     _oracle_check_of_loss_state(tr, "matrix_core_loss_training_regime_vs_oracle", case)
-            _lib.check(lib.clica_lp_loss_set_matrix_cores(1), "on")
-            PARITY.check("matrix_core_loss_training_regime", case, "loss_i", res[1][1][:B].cpu().numpy(), res[0][1][:B].cpu().numpy(), note="HIP vs HIP")
-            PARITY.check("matrix_core_loss_training_regime", case, "lse_i", res[1][1][2 * B:3 * B].cpu().numpy(), res[0][1][2 * B:3 * B].cpu().numpy())
-            PARITY.check("matrix_core_loss_training_regime", case, "d loss / d y", res[1][0].cpu().numpy(), res[0][0].cpu().numpy())
+            _lib.check(lib.clica_lp_loss_set_matrix_cores(2), "on")
+            PARITY.check("matrix_core_loss_training_regime", case, "loss_i", res[2][1][:B].cpu().numpy(), res[0][1][:B].cpu().numpy(), note="HIP vs HIP")
+            PARITY.check("matrix_core_loss_training_regime", case, "lse_i", res[2][1][2 * B:3 * B].cpu().numpy(), res[0][1][2 * B:3 * B].cpu().numpy())
+            PARITY.check("matrix_core_loss_training_regime", case, "d loss / d y", res[2][0].cpu().numpy(), res[0][0].cpu().numpy())
     finally:
         _lib.check(lib.clica_lp_loss_set_matrix_cores(-1), "restore")
 
 
-def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypatch):
+def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypatch, request):
     """N = 1 training step without the loss's closing reduction launch (clica_lp_loss_bwd_sym_train_parts -> clica_mlp_dgrad_split_tail with
     dy_parts: the backward chain's prologue sums the pair sweep's partials, leaves the forward's means and ticks the counter) == the step
     with that launch, bit for bit: reported means, dy, every parameter and the step counter after several steps, eager and in graph
-    replay, inside the guard's limit and -- the last layer scaled up -- on the difference sweeps (the other split count)."""
-    from cl_ica_amd import encoders
+    replay, inside the guard's limit and -- the last layer scaled up -- on the difference sweeps (the other split count).  Runs with the
+    matrix-core sweeps switched on for the local pool (the default policy would keep every case on the difference sweeps: one split count)
+    AND with the default policy."""
+    from cl_ica_amd import _lib, encoders
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    request.addfinalizer(lambda: _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(-1), "default policy"))
 
     def run(fold: bool, scale_last: float, graph: bool):
-        monkeypatch.setenv("CLICA_FOLD_DY_REDUCE", "1" if fold else "0")
+        monkeypatch.setattr(ContrastiveTrainer, "fold_dy_reduce", bool(fold))
         torch.manual_seed(7)
         n, B = 10, 1536
         f = encoders.get_mlp(n, n, [100, 500, 500, 100]).to("cuda")
@@ -498,7 +504,8 @@ def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypat
         took = getattr(tr, "_dy_parts_taken", None)
         return (torch.stack(outs), tr.dy.clone(), tr.param_arena.clone(), int(tr.steps_done), tr.loss_guard(), took, bool(tr.split_bf16))
 
-    for scale_last, graph in ((1.0, False), (1.0, True), (300.0, False)):
+    for scale_last, graph, mfma in ((1.0, False, 2), (1.0, True, 2), (300.0, False, 2), (1.0, True, -1)):
+        _lib.check(_lib.load().clica_lp_loss_set_matrix_cores(mfma), "matrix-core policy")
         a = run(True, scale_last, graph)
         b = run(False, scale_last, graph)
         assert a[3] == b[3] == 4, (a[3], b[3])
@@ -506,7 +513,7 @@ def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypat
             assert (a[5] or 0) > 0 and not b[5], (a[5], b[5])          # the first trainer took the folded path, the second did not
         for x, y, what in zip(a[:3], b[:3], ("means", "dy", "parameters")):
             assert torch.equal(x, y), (what, scale_last, graph, float((x - y).abs().max()))
-        if scale_last > 1.0 and a[4]["limit"] > 0.0:
+        if scale_last > 1.0 and mfma == 2 and a[4]["limit"] > 0.0:
             assert a[4]["fallback_steps"] > 0, a[4]          # this case did run on the difference sweeps
 
 

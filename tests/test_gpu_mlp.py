@@ -15,15 +15,13 @@ def dev(a):
 
 @pytest.fixture
 def tuning_env(monkeypatch):
-    """Set a library tuning switch for one test: the library caches them, so re-read after setting AND after restoring."""
+    """Set a library tuning hook (clica_set_tuning, include/clica.h) for one test; everything back to the defaults afterwards."""
     from cl_ica_amd import _lib
 
-    def set_(name, value):
-        monkeypatch.setenv(name, value)
-        assert _lib.load().clica_reload_env() == 0
+    def set_(key, value):
+        assert _lib.load().clica_set_tuning(key.encode(), int(value)) == 0
     yield set_
-    monkeypatch.undo()
-    assert _lib.load().clica_reload_env() == 0
+    assert _lib.load().clica_set_tuning(b"reset", 0) == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(48, 40, 4), (300, 100, 10), (1000, 500, 100), (12288, 500, 500), (257, 10, 100),
@@ -34,7 +32,7 @@ def test_linear_kernels_vs_fp64(M, N, K, skinny, tuning_env):
     """skinny=1: tiny-K / tiny-N layers take the VALU kernels (csrc/skinny.hip); skinny=0 forces every
     shape through the MFMA template.  Both must match fp64."""
     from cl_ica_amd import ops
-    tuning_env("CLICA_SKINNY", skinny)
+    tuning_env("skinny", skinny)
     rng = np.random.default_rng(M * 7 + N)
     x = rng.normal(size=(M, K)).astype(np.float32)
     w = (rng.uniform(-1, 1, size=(N, K)) / np.sqrt(K)).astype(np.float32)
@@ -100,6 +98,26 @@ def test_mlp_goldens(golden):
                 PARITY.check("mlp_goldens_g6/grad", case, name, got, c["out"][f"grad/{name}"])
             else:
                 PARITY.check("mlp_goldens_g6/grad", case, name, np.ascontiguousarray(got.reshape(-1)[::97]), c["out"][f"gradsub/{name}"])
+        # element-wise: against the fp64 oracle, output / input gradient / every parameter gradient may be at most 4 x
+        # as far off as the reference's own fp32 golden, element by element (p99.9)
+        from oracle import np_oracle as O
+        P64 = O.MLPParams(Ws, bs, head=head, head_param=hp)
+        y64, cache = O.mlp_forward(P64, c["in"]["x"])
+        g64 = O.mlp_backward(P64, cache, c["in"]["gy"])
+        PARITY.check_elementwise("mlp_goldens_g6", case, "y", y.detach().cpu().numpy(), c["out"]["y"], y64)
+        PARITY.check_elementwise("mlp_goldens_g6", case, "dx", x.grad.cpu().numpy(), c["out"]["dx"], g64["dx"])
+        lin_names = [nm for nm, _ in f.named_parameters()]
+        for name, prm in f.named_parameters():
+            if not (name.endswith(".weight") or name.endswith(".bias")) or int(name.split(".")[0]) % 2:
+                continue
+            l = int(name.split(".")[0]) // 2
+            t64 = g64["dW"][l] if name.endswith(".weight") else g64["db"][l]
+            got = prm.grad.cpu().numpy()
+            if f"grad/{name}" in c["out"]:
+                PARITY.check_elementwise("mlp_goldens_g6/grad", case, name, got, c["out"][f"grad/{name}"], t64)
+            else:
+                PARITY.check_elementwise("mlp_goldens_g6/grad", case, name, np.ascontiguousarray(got.reshape(-1)[::97]), c["out"][f"gradsub/{name}"],
+                                         np.ascontiguousarray(np.asarray(t64).reshape(-1)[::97]))
 
 
 @pytest.mark.parametrize("mode", ["bn", "gn"])
@@ -729,7 +747,7 @@ def test_get_mlp_autograd_seeded_sweep_vs_fp64(fused, monkeypatch):
     module under torch autograd -- whole-encoder kernels (fused=1) and per-layer kernels (fused=0) -- against the same
     network in fp64 torch ops: output, input gradient and every parameter gradient at 1e-5."""
     from cl_ica_amd import encoders
-    monkeypatch.setenv("CLICA_DROPIN_FUSED", fused)
+    monkeypatch.setattr("cl_ica_amd.encoders.FUSED_MODE", fused)
     rng = np.random.default_rng(77)
     widths = [1, 2, 3, 10, 16, 17, 48, 100, 130, 256, 500, 512]
     for case in range(12):

@@ -263,7 +263,7 @@ def test_dropin_fused_path_matches_per_layer_path(opt_kind, monkeypatch):
     from cl_ica_amd import encoders, losses, optim
     res = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("CLICA_DROPIN_FUSED", fused)
+        monkeypatch.setattr("cl_ica_amd.encoders.FUSED_MODE", fused)
         torch.manual_seed(0)
         f = encoders.get_mlp(10, 10, [100, 500, 500, 100]).cuda()
         opt = torch.optim.Adam(f.parameters(), lr=1e-3) if opt_kind == "torch" else optim.Adam(f.parameters(), lr=1e-3)
@@ -295,7 +295,7 @@ def test_dropin_lazy_stacking_and_symmetric_loss_match_plain_path(B, p, monkeypa
     """the reference's train_step structure (main_mlp.py:258-285: two encoder calls, roll, LpSimCLRLoss, backward)
     on the drop-in modules.  Default path: the first f(.) is deferred, the second call stacks both batches into one launch per phase
     (cl_ica_amd/lazy.py), and the loss recognises z3_rec = roll(z1_rec) in the autograd graph and takes the one-sweep symmetric backward.
-    Against the same step with both mechanisms off (CLICA_DROPIN_LAZY=0, CLICA_DROPIN_SYM=0: two half-size encoder passes, rolled copy,
+    Against the same step with both mechanisms off (CLICA_DROPIN_LAZY=0, losses.SYM_ENABLED = False: two half-size encoder passes, rolled copy,
     generic two-sweep backward) and against the fp64 oracle: loss, per-item losses, embeddings, every parameter gradient."""
     from cl_ica_amd import encoders, lazy, losses, optim
     n = 10
@@ -305,7 +305,7 @@ def test_dropin_lazy_stacking_and_symmetric_loss_match_plain_path(B, p, monkeypa
     x2 = (x1 + 0.05 * torch.randn(B, n, generator=g).cuda()).clamp(0, 1)
     for mode in ("fast", "plain"):
         monkeypatch.setenv("CLICA_DROPIN_LAZY", "1" if mode == "fast" else "0")
-        monkeypatch.setenv("CLICA_DROPIN_SYM", "1" if mode == "fast" else "0")
+        monkeypatch.setattr(losses, "SYM_ENABLED", mode == "fast")
         f = build_mlp_n10().cuda()
         opt = optim.Adam(f.parameters(), lr=1e-3)
         L = losses.LpSimCLRLoss(p=p, tau=1.0, simclr_compatibility_mode=True)
@@ -395,8 +395,7 @@ def test_dropin_lazy_output_single_use_and_per_item_upstream():
     (tot + (w * item).sum()).backward()
     outs = [[q.grad.clone() for q in f.parameters()]]
     # the same through the GENERIC node (autograd routes d loss / d z3 back through the roll)
-    import os
-    os.environ["CLICA_DROPIN_SYM"] = "0"
+    losses.SYM_ENABLED = False
     try:
         for q in f.parameters():
             q.grad = None
@@ -405,7 +404,7 @@ def test_dropin_lazy_output_single_use_and_per_item_upstream():
         (tot + (w * item).sum()).backward()
         ref = [q.grad.clone() for q in f.parameters()]
     finally:
-        os.environ["CLICA_DROPIN_SYM"] = "1"
+        losses.SYM_ENABLED = True
     for k, (u, v) in enumerate(zip(outs[0][:-1], ref[:-1])):
         PARITY.check("dropin_lazy_sym", "per-item upstream", f"grad{k}", u.cpu().numpy(), v.cpu().numpy())
 
@@ -636,7 +635,7 @@ def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
     cl_ica_amd.optim.Adam: the fused encoder backward adds dW / db straight into the optimizer's gradient arena (autograd gets
     None).  Three steps against the same loop with torch.optim.Adam (ordinary autograd accumulation): parameters agree."""
     from cl_ica_amd import encoders, losses, optim
-    monkeypatch.setenv("CLICA_DROPIN_FUSED", "1")
+    monkeypatch.setattr("cl_ica_amd.encoders.FUSED_MODE", "1")
     n, B = 10, 1536
     loss = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
     outs = {}

@@ -7,6 +7,6 @@
 # Config 3 the same way: tools/dp_bench_smoke.sh --latent-dim 40 --space-type sphere --p 1   (torchrun claims a bare `--n`)
 set -e
 cd "$(dirname "$0")/.."
-export PYTHONFAULTHANDLER=1 CLICA_SHARE_DEVICE=1 CLICA_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
+export PYTHONFAULTHANDLER=1 CLICA_DIST_BACKEND=gloo HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 2 --steps 10 --warmup 3 --no-graph "$@"

@@ -37,12 +37,8 @@ def main():
         fl = 2.0 * M * N * K
         print(f"--- M={M} N={N} K={K} ({fl/1e9:.2f} GFLOP)")
         for cfg in ("auto", 0, 1, 2, 3, 4, 5):
-            for var in ("CLICA_GEMM_CFG_FWD", "CLICA_GEMM_CFG_DGRAD", "CLICA_GEMM_CFG_WGRAD"):
-                if cfg == "auto":
-                    os.environ.pop(var, None)
-                else:
-                    os.environ[var] = str(cfg)
-            _lib.load().clica_reload_env()          # the library caches its tuning switches
+            for key in (b"gemm_cfg_fwd", b"gemm_cfg_dgrad", b"gemm_cfg_wgrad"):
+                _lib.load().clica_set_tuning(key, -1 if cfg == "auto" else int(cfg))
             y = ops.linear_fwd(x, w, b, True); dx = ops.linear_dgrad(dy, w, xa); dw, db = ops.linear_wgrad(dy, x)
             errs = [float((y - ref_y).abs().max() / ref_y.abs().max()), float((dx - ref_dx).abs().max() / ref_dx.abs().max()),
                     float((dw - ref_dw).abs().max() / ref_dw.abs().max())]

@@ -18,8 +18,7 @@ for n in (32, 64, 128, 256, 512):
     z = [torch.randn(B, n, device="cuda").requires_grad_(True) for _ in range(3)]
     row = [f"n = {n:4d}"]
     for path in ("0", "1"):
-        os.environ["CLICA_DOT_MFMA"] = path
-        lib.clica_reload_env()
+        lib.clica_set_tuning(b"dot_mfma", int(path))
         ts = []
         for it in range(25):
             for t in z:
