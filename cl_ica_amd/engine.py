@@ -415,6 +415,7 @@ class ContrastiveTrainer:
     def forward(self):
         cur = self.x
         L = len(self.linears)
+        self._planes_on_current_scales = True      # (saved_activation: the plane copies this pass writes are scaled by the scales in force NOW)
         if self.fused_forward:
             # one launch for the whole stack, activation panel resident in LDS (csrc/fused_mlp.hip)
             ws = [lin.weight for lin in self.linears]
@@ -639,13 +640,16 @@ class ContrastiveTrainer:
         bf16 planes (no fp32 copy: nobody but the matrix cores reads it) the planes are decoded -- exactly, hi + mid + lo is the
         fp32 value.  Inspection / tests."""
         R, w = self.x.shape[0], self.linears[l].out_features
+        # f16x2: the planes are scaled by the activation scale the pass that WROTE them ran with -- the scales in force if no update has run
+        # since (a bare forward(), a calibration pass), the previous ones (kept by the update) after a full step (ADVICE r5)
+        which = "scales_a" if getattr(self, "_planes_on_current_scales", False) else "last_scales_a"
         if l in getattr(self, "chain", set()) and (l + 1) in self.chain:
             if self.split_f16_wide:
-                return ops.mlp_planes16_to_f32(self.xin_planes[l + 1], R, w, True, self.s16.read()["last_scales_a"][l + 1])
+                return ops.mlp_planes16_to_f32(self.xin_planes[l + 1], R, w, True, self.s16.read()[which][l + 1])
             return ops.mlp_planes_to_f32(self.xin_planes[l + 1], R, w, True)
         if self.acts_out[l] is None:
-            if self.split_f16:       # the planes of the last step are scaled by the activation scale that step ran with
-                return ops.mlp_planes16_to_f32(self.act_planes[l], R, w, True, self.s16.read()["last_scales_a"][l + 1])
+            if self.split_f16:
+                return ops.mlp_planes16_to_f32(self.act_planes[l], R, w, True, self.s16.read()[which][l + 1])
             return ops.mlp_planes_to_f32(self.act_planes[l], R, w, True)
         return self.acts[l]
 
@@ -841,6 +845,7 @@ class ContrastiveTrainer:
         self.optimizer_step()
         if self.s16 is not None and not getattr(self, "_s16_updated", False):
             self.s16.update()                  # this step's recorded maxima -> the next step's scales (normally inside the Adam launch)
+        self._planes_on_current_scales = False     # (an update has run behind the forward that wrote the planes)
 
     def calibrate_scales(self, sample: bool = True, passes: Optional[int] = None):
         """f16x2 arithmetic: a launch runs on the scales derived from the PREVIOUS step's maxima, so before the first step (and after
@@ -866,6 +871,7 @@ class ContrastiveTrainer:
             self.loss_forward_backward()
             self.backward()
             self.s16.update()
+            self._planes_on_current_scales = False
             self.step_dev.copy_(tick)
             self._ticked = False
         self.s16.clear_flags()                   # the first pass ran on scales of 1: whatever it flagged is not a finding
@@ -920,6 +926,7 @@ class ContrastiveTrainer:
         self._check_external_writes()
         if self.graph is not None:
             self.graph.replay()
+            self._planes_on_current_scales = False
             # a replay updates the parameter arena without passing through ops.adam_step: caches derived from the weights
             # (the drop-in encoder's fragment-order packs, encoders._MLPFusedFn) key on this epoch and must see the change
             ops.PARAM_EPOCH += 1

@@ -89,6 +89,7 @@ class _Pending:
             for _, lz in items:
                 if lz is not None:
                     lz._stale = True
+            _rearm_search(self.owner)      # (an optimizer this module has not found yet may have written them: look again at the next call)
             return None
         # the call's own grad mode and stream, not those of the first use (which may sit inside a no_grad block or on another stream)
         cur = torch.cuda.current_stream() if self.stream is not None else None
@@ -179,9 +180,14 @@ def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor
     return lz
 
 
+HOOK_EPOCH = 0      # number of optimizer steps that went through this module's pre-hook (see _attach_owners)
+
+
 def flush_all(*_args, **_kwargs):
-    """Run every pending call.  Registered as a global optimizer-step pre-hook below (and called by cl_ica_amd.optim.Adam): a deferred
-    output is always computed with the parameters of the moment the call was made."""
+    """Run every pending call.  Registered as an optimizer-step pre-hook on the attached optimizers (and called by cl_ica_amd.optim.Adam):
+    a deferred output is always computed with the parameters of the moment the call was made."""
+    global HOOK_EPOCH
+    HOOK_EPOCH += 1
     for p in list(_ALL_PENDING):
         p.flush()
 
@@ -219,11 +225,18 @@ def attach(optimizer) -> bool:
 
 
 def find_optimizers(params) -> list:
-    """The torch.optim.Optimizer instances whose param_groups hold `params[0]` (see above); a few gc.get_referrers walks."""
+    """The torch.optim.Optimizer instances whose param_groups hold one of `params` (see above); a few gc.get_referrers walks, started from
+    the parameter's direct referrers only (lists that contain it: an optimizer's param_group["params"] is one)."""
     import gc
     if not params:
         return []
-    p0, found = params[0], []
+    found = []
+    for p0 in params[:1] + params[-1:]:          # first and last parameter: an optimizer over a sub-set of the module is found too
+        _find_from(p0, found, gc)
+    return found
+
+
+def _find_from(p0, found, gc) -> None:
     for lst in gc.get_referrers(p0):
         if not isinstance(lst, list) or not any(q is p0 for q in lst):
             continue
@@ -239,23 +252,42 @@ def find_optimizers(params) -> list:
                     for o in gc.get_referrers(od):
                         if isinstance(o, torch.optim.Optimizer) and getattr(o, "__dict__", None) is od and not any(o is f for f in found):
                             found.append(o)
-    return found
 
 
 _SEARCH_TRIES = 3
 
 
-def _attach_owners(owner, params):
+def _rearm_search(owner) -> None:
     st = getattr(owner, "_clica_opt_search", None)
+    if st is not None:
+        st[0], st[1] = 0, False
+
+
+def _attach_owners(owner, params):
+    """Look the owners of `params` up (at most _SEARCH_TRIES deferred calls in a row) and attach the step hooks.  The search is RE-ARMED
+     whenever the evidence says an optimizer without the hooks is at work: a pending output went stale (flush), or the
+    parameters' versions moved since this module's last deferred call although no hooked optimizer step happened in between, or every
+    optimizer found so far has been garbage-collected -- an optimizer built later (re-created after a learning-rate change, built after a
+    few evaluation calls) is then found at the next call."""
+    st = getattr(owner, "_clica_opt_search", None)
+    params = list(params)
     if st is None:
-        st = [0, False]
+        # tries, found, parameter versions at the last call, HOOK_EPOCH at the last call, the optimizers found for this owner (weak)
+        st = [0, False, None, HOOK_EPOCH, weakref.WeakSet()]
         try:
             object.__setattr__(owner, "_clica_opt_search", st)
         except Exception:
             return
+    vers = sum(int(q._version) for q in params)
+    if st[2] is not None and vers != st[2] and HOOK_EPOCH == st[3]:
+        st[0], st[1] = 0, False                       # somebody stepped without our hooks
+    if st[1] and len(st[4]) == 0:
+        st[0], st[1] = 0, False                       # every optimizer found for this module is gone (re-created: look for its successor)
+    st[2], st[3] = vers, HOOK_EPOCH
     if st[1] or st[0] >= _SEARCH_TRIES:
         return
     st[0] += 1
-    for o in find_optimizers(list(params)):
+    for o in find_optimizers(params):
         attach(o)
+        st[4].add(o)
         st[1] = True

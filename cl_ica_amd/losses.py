@@ -20,7 +20,8 @@ import torch
 
 from . import _lib, lazy
 
-__all__ = ["CLLoss", "ConditionalPairCLLoss", "MarginalPairCLLoss", "LpSimCLRLoss", "SimCLRLoss", "UniformityLoss", "AlignmentLoss"]
+__all__ = ["CLLoss", "ConditionalPairCLLoss", "MarginalPairCLLoss", "LpSimCLRLoss", "SimCLRLoss", "UniformityLoss", "AlignmentLoss",
+           "AlignmentUniformityLoss"]
 
 
 class CLLoss(ABC):
@@ -421,3 +422,24 @@ class AlignmentLoss(ConditionalPairCLLoss):
         mean2, item2, _, _ = _PairLossFn.apply(z1_rec, z2_rec, z1_rec[:1].detach(), "lp", desc)
         loss = 0.5 * mean2
         return loss, 0.5 * item2, [loss]
+
+
+class AlignmentUniformityLoss(CLLoss):
+    """Convex combination of AlignmentLoss and UniformityLoss: ``(1 - alpha) * alignment(z1_rec, z2_con_z1_rec) + alpha *
+    uniformity(z1_rec, z3_rec)`` (reference losses.py:242-250: same constructor, same weights ``[1 - alpha, alpha]``).  The reference
+    builds it on CombinedCLLoss / SplitCombinedCLLoss, whose ``loss`` cannot be called with the pair losses' two-argument signature and
+    raises (losses.py:118-151) -- this one is the working combination the docstring there describes, behind the 6-argument CLLoss call.
+    Returns ``(mean, per_item, [alignment mean, uniformity mean])``; ``per_item`` is the same combination row by row when the two
+    batches have the same number of rows (alignment is anchored at the rows of z1_rec, uniformity at those of z3_rec), else None."""
+
+    def __init__(self, alpha=0.5, p=2.0):
+        assert 0 <= alpha <= 1
+        self.alpha, self.p = float(alpha), p
+        self._align, self._unif = AlignmentLoss(p=p), UniformityLoss(p=p)
+
+    def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
+        del z1, z2_con_z1, z3
+        a, a_i, _ = self._align.loss(z1_rec, z2_con_z1_rec)
+        u, u_i, _ = self._unif.loss(z1_rec, z3_rec)
+        per_item = (1.0 - self.alpha) * a_i + self.alpha * u_i if a_i.shape == u_i.shape else None
+        return (1.0 - self.alpha) * a + self.alpha * u, per_item, [a, u]

@@ -79,13 +79,24 @@ class ParityLog:
         over the same elements.  The 2-ulp term: the CPU reference accumulates torch.norm and its matrix products in fp64 internally
         (at::acc_type<float, false> = double) and often returns the correctly ROUNDED result, half an ulp from the truth -- no evaluation that
         really computes in fp32 can be held to a multiple of that; an element within 8 ulp (factor 4 x 2 ulp) of the fp64 truth always
-        passes (measured on the first run: 2.2 ulp on a 72-term sum whose golden sits at 0.5 ulp).  Logged per family (`elementwise`)."""
+        passes (measured on the first run: 2.2 ulp on a 72-term sum whose golden sits at 0.5 ulp).
+        WHICH elements: those with |truth| >= 1e-3 max|truth| (the set the logged p99.9 figure has always used) -- an element a thousand times
+        below its tensor's scale is a cancelling sum of terms at that scale (a saturated row's gradient: alpha g - (1 - alpha) w g with w = 1
+        cancels EXACTLY in the reference's formulation and to rounding level, 3e-6 of the scale, in another), only its norm-wise accuracy
+        means anything and `check` covers it.  Arrays with fewer than 1000 such elements (the 8 x 3 goldens: the "percentile" is the
+        maximum of two dozen numbers) get one more bit: 2 x factor.  Logged per family (`elementwise`)."""
         got = np.asarray(got, np.float64).ravel(); ref32 = np.asarray(ref32, np.float64).ravel(); truth = np.asarray(truth, np.float64).ravel()
         if self.mode in ("split_bf16", "split_f16"):
             family = family + f"[{self.mode}]"
         assert got.shape == ref32.shape == truth.shape, (family, case, what, got.shape, ref32.shape, truth.shape)
         if not truth.size:
             return 0.0
+        sig = np.abs(truth) >= 1e-3 * float(np.abs(truth).max())
+        if not sig.any():
+            return 0.0
+        got, ref32, truth = got[sig], ref32[sig], truth[sig]
+        if truth.size < 1000:
+            factor = 2.0 * factor
         e_hip = np.abs(got - truth)
         e_ref = np.maximum(np.abs(ref32 - truth), 2.0 * float(np.finfo(np.float32).eps) * np.abs(truth))
         kth = min(truth.size - 1, int(np.ceil(0.999 * truth.size)) - 1)

@@ -647,3 +647,31 @@ def test_f16x2_guard_catches_parameters_replaced_without_calibration():
     gb = tr.check_arith()
     assert tr.steps_done == steps0 + 1 and replays >= 2 and gb["new_skipped"] == replays - 1 and not (gb["flags"] & 4), (replays, gb)
     _oracle_check_of_applied_step(tr, f, snap, steps0, "f16x2_guard_in_graph_replay", f"first layer x 200 without calibration (applied after {replays - 1} redo replays)")
+
+
+def test_saved_activation_decodes_with_the_scale_its_planes_were_written_on():
+    """ADVICE r5 (engine.py: saved_activation): in the f16x2 arithmetic a hidden activation exists only as scaled fp16 planes; they are
+    scaled by the scale in force when they were WRITTEN -- the previous step's after a full step (the update has run since), the current
+    one after a bare forward() or a calibration pass.  Both decode to the fp64 forward of the same input within 1e-5."""
+    f, tr = _guard_trainer(seed=9, B=512)
+    if tr.s16 is None or not tr.split_f16:
+        pytest.skip("plane copies on per-tensor scales belong to the f16x2 arithmetic")
+    lin = tr.linears
+
+    def check(case):
+        P = O.MLPParams([m.weight.detach().cpu().numpy() for m in lin], [m.bias.detach().cpu().numpy() for m in lin])
+        _, cache = O.mlp_forward(P, tr.x.cpu().numpy())
+        for l in range(len(lin) - 1):
+            if tr.acts_out[l] is None:       # planes only
+                PARITY.check("saved_activation_f16x2", case, f"act{l}", tr.saved_activation(l).cpu().numpy(), cache["acts"][l + 1])
+    tr.lr = 0.0                                   # (the parameters the planes were computed with stay the ones the oracle sees)
+    for _ in range(3):
+        tr.step()
+    torch.cuda.synchronize()
+    check("after a full step (planes on the previous scales)")
+    with torch.no_grad():
+        tr.gW.mul_(8.0)                           # the activations grow 8 x: the two scale sets now differ by a power of two
+    tr.step(); torch.cuda.synchronize()           # planes written on the OLD scales, update -> new scales
+    check("after a full step across a scale change")
+    tr.sample(); tr.forward(); torch.cuda.synchronize()
+    check("after a bare forward (planes on the scales in force)")

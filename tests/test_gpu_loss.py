@@ -377,6 +377,36 @@ def test_uniformity_alignment_vs_golden(golden, gname):
         PARITY.check("alignment_goldens", f"a{i:03d} p={p:g}", "dz2", z2.grad.cpu().numpy(), a["out"]["dz2"])
 
 
+def test_alignment_uniformity_loss_is_the_convex_combination(golden):
+    """AlignmentUniformityLoss (reference losses.py:242-250: weights [1 - alpha, alpha]; the reference's own CombinedCLLoss cannot be
+    called with the pair losses and raises) = (1 - alpha) x AlignmentLoss + alpha x UniformityLoss, value and all three gradients, against
+    the reference's goldens of the two parts (G12) combined in fp64."""
+    from cl_ica_amd.losses import AlignmentUniformityLoss
+    G = golden("g12_align_uniform.npz")
+    u, a = G.case("u000"), G.case("a000")
+    p = float(u["meta"]["p"])
+    for alpha in (0.5, 0.2):
+        L = AlignmentUniformityLoss(alpha=alpha, p=p)
+        # inputs: the uniformity golden's (z1, z3) with the alignment golden's z2 where its shape fits (else zeros); expectations: the fp64
+        # oracle of the two parts, which tests/test_oracle_golden.py pins to the reference's G12 outputs
+        z1 = dev(u["in"]["z1"]).requires_grad_(True); z3 = dev(u["in"]["z3"]).requires_grad_(True)
+        z2 = dev(a["in"]["z2"][:z1.shape[0]] if a["in"]["z2"].shape[0] >= z1.shape[0] and a["in"]["z2"].shape[1] == z1.shape[1]
+                 else np.zeros(tuple(z1.shape), np.float32)).requires_grad_(True)
+        tot, per, (al, un) = L(None, None, None, z1, z2, z3)
+        tot.backward()
+        orc_u = O.uniformity_loss(u["in"]["z1"], u["in"]["z3"], p=p)
+        orc_a = O.alignment_loss(u["in"]["z1"], z2.detach().cpu().numpy(), p=p)
+        case = f"alpha={alpha} p={p:g}"
+        PARITY.check("alignment_uniformity", case, "uniformity part", un.item(), orc_u["loss_mean"])
+        PARITY.check("alignment_uniformity", case, "alignment part", al.item(), orc_a["loss_mean"])
+        PARITY.check("alignment_uniformity", case, "loss", tot.item(), (1 - alpha) * orc_a["loss_mean"] + alpha * orc_u["loss_mean"])
+        PARITY.check("alignment_uniformity", case, "dz1", z1.grad.cpu().numpy(), (1 - alpha) * orc_a["dz1"] + alpha * orc_u["dz1"])
+        PARITY.check("alignment_uniformity", case, "dz2", z2.grad.cpu().numpy(), (1 - alpha) * orc_a["dz2"])
+        PARITY.check("alignment_uniformity", case, "dz3", z3.grad.cpu().numpy(), alpha * orc_u["dz3"])
+        if per is not None:
+            PARITY.check("alignment_uniformity", case, "per_item", per.detach().cpu().numpy(), (1 - alpha) * orc_a["loss_i"] + alpha * orc_u["loss_i"])
+
+
 def test_lp_loss_seeded_sweep_vs_oracle():
     """Forty seeded random shapes / parameters around the kernels' internal boundaries (owner tiles of 64, LDS tiles of 128
     rows, on-chip partitions of 16 rows, the planner's split lengths, the 64-coordinate switch to the wide-row kernels)

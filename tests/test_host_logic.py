@@ -401,6 +401,48 @@ def test_lazy_stacking_mechanics_on_cpu():
     assert losses._rolled_rows_of(torch.roll(leaf, 2, 0), leaf) and not losses._rolled_rows_of(torch.roll(leaf * 1, 1, 0), leaf)
 
 
+def test_lazy_finds_an_optimizer_built_later_on_cpu():
+    """the optimizer search used to stop for good after three deferred calls -- an optimizer built AFTER a few
+    evaluation calls (or re-created after a learning-rate change) never got the flush / after-step hooks, and the first pending output
+    that crossed its step raised 'stale' on use.  Now the search is re-armed when the parameters' versions move without a hooked step
+    (and when a pending output goes stale): the late optimizer is found at the next deferred call and its steps flush first."""
+    import torch
+    from cl_ica_amd import lazy
+    net = torch.nn.Sequential(torch.nn.Linear(3, 4), torch.nn.LeakyReLU(), torch.nn.Linear(4, 2))
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = net
+
+        def forward(self, x):
+            return lazy.defer(self, x, lambda xx: self.net(xx), (x.shape[0], 2), list(self.parameters()))
+    m = M()
+    x = torch.randn(4, 3)
+    for _ in range(lazy._SEARCH_TRIES + 2):            # evaluation calls before any optimizer exists: the search runs dry
+        float(m(x).detach().sum())
+    assert m._clica_opt_search[0] >= lazy._SEARCH_TRIES and not m._clica_opt_search[1]
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)       # built later
+    assert opt not in lazy._ATTACHED
+    for q in m.parameters():
+        q.grad = torch.ones_like(q)
+    opt.step()                                          # an un-hooked step: the versions move, HOOK_EPOCH does not
+    a = m(x)                                            # ... which re-arms the search: found now
+    assert opt in lazy._ATTACHED and m._clica_opt_search[1]
+    ref = net(x).detach().clone()
+    opt.step()                                          # hooked: the pending call is flushed with the OLD parameters first
+    assert torch.allclose(lazy.plain(a).detach(), ref) and not torch.allclose(net(x), ref)
+    # a re-created optimizer (learning-rate change): the old hooks die with the old object, the new one is picked up the same way
+    del opt
+    opt2 = torch.optim.SGD(m.parameters(), lr=0.01)
+    opt2.step()
+    b = m(x)
+    assert opt2 in lazy._ATTACHED
+    ref = net(x).detach().clone()
+    opt2.step()
+    assert torch.allclose(lazy.plain(b).detach(), ref)
+
+
 def test_lazy_compute_many_after_step_and_shared_items_on_cpu():
     """Round-4 additions around the drop-in loop, device-free parts: `compute_many` (the stacked call as one multi-output node; None
     falls back to cat + slices), the optimizer post-step hook list, the adjacency test that lets the encoder's backward take the loss

@@ -311,3 +311,51 @@ def test_flat_l2_search_known_answers():
     # the dataset rule (threedident_dataset.py:108-113): z~ snapping onto z's grid point takes its second neighbour
     iz, izt = O.threedident_snap(g, g[[7]] + 0.01, g[[7]] + 0.02)
     assert iz[0] == 7 and izt[0] != 7
+
+
+def test_kitti_pair_pipeline_known_answers():
+    """oracle.kitti_getitem / kitti_collate against HAND-COMPUTED answers of the reference's published semantics (the module itself needs
+    torchvision / matplotlib, absent here, so this half of row N4 is pinned to the text of kitti_masks/dataset.py, not to its execution):
+      * dataset.py:90-95  a flat index addresses sequence s = searchsorted(cumlens, index, side="right") at frame index - cumlens[s - 1]
+                          (so index == cumlens[s - 1] is frame 0 of sequence s, NOT the last frame of s - 1);
+      * dataset.py:97-98  the partner frame is min(start + t, len - 1): clipped to the sequence's last frame, never into the next one;
+      * dataset.py:100-131 masks become uint8 x 255, get a channel axis and come back as float32 in {0, 1};
+      * dataset.py:134-142 custom_collate interleaves: inputs = [first_0, second_0, first_1, second_1, ...], labels likewise."""
+    # three sequences of 3, 2 and 4 frames of 2 x 2 masks; frame f of sequence s is filled with the bit pattern of (10 s + f)
+    lens = [3, 2, 4]
+    data = [[np.array([[(10 * s + f) & 1, ((10 * s + f) >> 1) & 1], [((10 * s + f) >> 2) & 1, ((10 * s + f) >> 3) & 1]], bool) for f in range(n)]
+            for s, n in enumerate(lens)]
+    lat = [[np.array([s, f, 10 * s + f], np.float32) for f in range(n)] for s, n in enumerate(lens)]
+    cum = np.cumsum(lens)                                                   # [3, 5, 9]
+    # index 0: sequence 0 frame 0, t = 1 -> frame 1
+    a, b, la, lb = O.kitti_getitem(data, lat, cum, 0, 1)
+    assert a.shape == (1, 2, 2) and a.dtype == np.float32 and la.tolist() == [0, 0, 0] and lb.tolist() == [0, 1, 1]
+    assert a.ravel().tolist() == [0, 0, 0, 0] and b.ravel().tolist() == [1, 0, 0, 0]
+    # index 2: last frame of sequence 0, t = 5 -> clipped to itself (dataset.py:98), never frame 0 of sequence 1
+    a, b, la, lb = O.kitti_getitem(data, lat, cum, 2, 5)
+    assert la.tolist() == lb.tolist() == [0, 2, 2] and np.array_equal(a, b)
+    # index 3 == cumlens[0]: frame 0 of sequence 1 (side="right", dataset.py:90), t = 1 -> frame 1 of sequence 1
+    a, b, la, lb = O.kitti_getitem(data, lat, cum, 3, 1)
+    assert la.tolist() == [1, 0, 10] and lb.tolist() == [1, 1, 11]
+    assert a.ravel().tolist() == [0, 1, 0, 1] and b.ravel().tolist() == [1, 1, 0, 1]          # 10 = 0b1010, 11 = 0b1011 (bit 0 first)
+    # index 6: sequence 2 frame 1, t = 2 -> frame 3 (the last one, exactly)
+    a, b, la, lb = O.kitti_getitem(data, lat, cum, 6, 2)
+    assert la.tolist() == [2, 1, 21] and lb.tolist() == [2, 3, 23]
+    # collate (dataset.py:134-142): interleaved pairs, labels in the same order
+    s0, s1 = O.kitti_getitem(data, lat, cum, 0, 1), O.kitti_getitem(data, lat, cum, 6, 2)
+    x, y = O.kitti_collate([s0, s1])
+    assert x.shape == (4, 1, 2, 2) and y.shape == (4, 3)
+    assert y[:, 2].tolist() == [0, 1, 21, 23]
+    assert np.array_equal(x[0], s0[0]) and np.array_equal(x[1], s0[1]) and np.array_equal(x[2], s1[0]) and np.array_equal(x[3], s1[1])
+    # the solver then splits the batch back with mu[::2] / mu[1::2] (kitti_masks/solver.py:64-65): anchors 0, 21 and partners 1, 23
+    assert y[::2, 2].tolist() == [0, 21] and y[1::2, 2].tolist() == [1, 23]
+
+
+def test_flat_l2_search_published_faiss_semantics():
+    """faiss.IndexFlatL2 (threedident_dataset.py:69, 104-105; faiss absent: pinned to its published definition) returns the EXACT k smallest
+    SQUARED Euclidean distances in ascending order, ids in add() order, and among equal distances the smaller id first -- hand-computed on
+    a five-row table with two exact ties."""
+    table = np.array([[0.0, 0.0], [3.0, 4.0], [-3.0, 4.0], [6.0, 8.0], [0.0, 5.0]])
+    D, I = O.flat_l2_search(table, np.array([[0.0, 0.0], [0.0, 4.0]]), 4)
+    assert I[0].tolist() == [0, 1, 2, 4] and D[0].tolist() == [0.0, 25.0, 25.0, 25.0]        # three rows at squared distance 25: ids ascending
+    assert I[1].tolist() == [4, 1, 2, 0] and D[1].tolist() == [1.0, 9.0, 9.0, 16.0]           # SQUARED distances (not 1, 3, 3, 4)
