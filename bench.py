@@ -808,7 +808,19 @@ def conv_config_leg(which, device, steps=20, warmup=6, windows=3):
         torch.cuda.synchronize(device)
         ws.append(e0.elapsed_time(e1) * 1e-3)
     el = float(np.median(ws))
-    return {"workload": work, "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": windows,
+    extra = {}
+    if which == "c4":
+        # config 4's step is MIOpen's (ResNet-18 backbone on PyTorch-ROCm, as north_star allows): its `roofline` is a
+        # whole-step estimate -- ResNet-18 at 64 x 64 is (64 / 224)^2 x 1.82 GMAC = 0.149 GMAC per image forward, x 3 for forward + both
+        # backward products, 2 x 1024 images per step -- against the fp32 matrix peak the fp32 NCHW convolutions could reach at best
+        gflop_step = 2.0 * 0.149 * 3.0 * 2048
+        extra["roofline"] = {"kernel": "MIOpen convolution kernels (ResNet-18 backbone; none of this repository's kernels: head, loss and Adam are < 2 % of the step)",
+                             "bound": "mfma", "achieved": round(gflop_step * steps / el / 1e3, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(gflop_step * steps / el / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+                             "what": "WHOLE-STEP ESTIMATE, not a kernel measurement: 1 831 algorithmic GFLOP per step (0.149 GMAC / image forward x 3 x 2048 "
+                                     "images) / step time; the number says how MIOpen's fp32 NCHW path uses the chip, nothing about this repository's kernels",
+                             "traffic": None}
+    return {**extra, "workload": work, "value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "windows": windows,
             "images_per_s": round((2048 if which == "c5" else 2048) * steps / el, 1), "parameters": int(n_params),
             "dtype": ("f32 via f16x2 split in the 16C-deep conv stages (3 fp16 MFMA products of two-piece operands, fp32 accumulate), f32 elsewhere"
                       if which == "c5" and os.environ.get("CLICA_CONV", "hip") != "miopen" and os.environ.get("CLICA_CONV_ARITH", "f16x2") == "f16x2" else "f32"),
@@ -877,11 +889,51 @@ def c5_conv_roofline(device, reps=20, traffic=True):
                                "on the way into LDS, weights in registers), so the launch moves its algorithmic bytes ~once; the streaming version of round 5 "
                                "(every output pixel fetching its own 2 x 2 window: 1.07 GB through the L1) took 148 us") if f16 else "fp32 matrix rate at N = 32",
             "traffic": None, "traffic_source": None}
+    class _A:      # what measure_traffic reads of the headline's arguments (unused by the c5 child command)
+        n, batch_size, p, space_type, native_fp32 = 10, 6144, 2, "box", False
     if traffic:
-        class _A:      # what measure_traffic reads of the headline's arguments (unused by the c5 child command)
-            n, batch_size, p, space_type, native_fp32 = 10, 6144, 2, "box", False
         tb, src = measure_traffic(_A, roof["kernel"], child_args=["--config", "c5", "--steps", "3"])
         roof["traffic"], roof["traffic_source"] = tb, src
+    if f16:
+        # the kernel with the LARGEST share of config 5's step is the streaming kernel `stream16_k<4>` (21 % of GPU time,
+        # profiles/r5_c5_summary.md), and its slowest instance is the second stage's DATA gradient (dO of the 32-channel 16 x 16 stage ->
+        # dO of the 32-channel 32 x 32 stage: 268 MB of stores).  That launch is the config's `roofline`; the tile kernel above rides along.
+        l = 1
+        cout, ho = conv.STAGES[l]; cin, hs = conv.STAGES[l - 1][0], ho + 1
+        dgrid = conv.STAGES[l - 1][1]
+        sd = 3 + (3 - l)
+
+        def launch_dg():
+            _lib.check(lib.clica_conv16_k4s2_dgrad(buf.dO[l].data_ptr(), buf.w16[3 + l - 1].data_ptr(), buf.wscale.data_ptr() + 4 * (3 + l - 1), images, cin, cout,
+                                                   hs, hs, buf.dO[l - 1].data_ptr(), dgrid, dgrid, buf.gate[l - 1].data_ptr(),
+                                                   conv._slots(buf, sd), None, st), "clica_conv16_k4s2_dgrad")
+        for _ in range(5):
+            launch_dg()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(reps):
+            launch_dg()
+        ev[1].record()
+        torch.cuda.synchronize(device)
+        us_d = ev[0].elapsed_time(ev[1]) * 1e3 / reps
+        # algorithmic bytes: dO of this stage read once (padded grid hs x hs, cout channels), dO of the stage below written once
+        # (dgrid x dgrid pixels, cin channels), one gate bit per written element
+        alg_d = int(4 * images * (hs * hs * cout + dgrid * dgrid * cin) + images * dgrid * dgrid * cin // 8)
+        gflop_d = 2.0 * images * hs * hs * (4 * cout) * (4 * cin) / 1e9
+        roof_d = {"kernel": "clica::conv16::stream16_k<4>",
+                  "op": "data gradient of the 32 -> 32 stage (autograd of kitti_masks/model.py:41-56, second Conv2d): dS = dO Wd as a streaming GEMM "
+                        "591 872 x 128 x 128 with the ReLU gate and the scatter into the lower stage's gradient grid in the epilogue",
+                  "bound": "hbm", "achieved": round(alg_d / us_d / 1e3, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(alg_d / us_d / 1e3 / PEAK_HBM_GBS, 4),
+                  "avg_launch_us": round(us_d, 2), "timing": f"HIP events around {reps} isolated launches on the 2048-mask batch's buffers",
+                  "algorithmic_bytes_per_launch": alg_d, "algorithmic_gflop_per_launch": round(gflop_d, 3),
+                  "share": "largest share of the step's GPU time among config 5's kernels (stream16_k<4>: 21 %, profiles/r5_c5_summary.md); this is its slowest instance",
+                  "what_bounds_it": "operand loads with two waves per SIMD (234 registers per wave): the wave waits 0.44 of its cycles, the matrix pipes are 0.18 busy "
+                                    "(tools/c5_pmc_dispatch.sh); the stores alone are 268 MB",
+                  "traffic": None, "traffic_source": None, "forward_tile_kernel": roof}
+        if traffic:
+            tb, src = measure_traffic(_A, roof_d["kernel"], child_args=["--config", "c5", "--steps", "3"])
+            roof_d["traffic"], roof_d["traffic_source"] = tb, (src or "") + " [per-launch average over ALL launches of the symbol in the step: three stages' forward and data gradients]"
+        roof = roof_d
     del net
     conv._POOL.clear()
     torch.cuda.empty_cache()
