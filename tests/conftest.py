@@ -72,7 +72,7 @@ class ParityLog:
             assert err < tol, f"{family}:{case}:{what}: rel err {err:.3e} >= {tol:.1e}" + (f" ({note})" if note else "")
         return err
 
-    def check_elementwise(self, family, case, what, got, ref32, truth, factor=4.0, note=None):
+    def check_elementwise(self, family, case, what, got, ref32, truth, factor=4.0, note=None, scale_floor=0.0):
         """ELEMENT-wise criterion, next to the norm-wise `check`: the HIP result must be no worse against the fp64
         truth than the fp32 REFERENCE itself is, element by element, up to `factor`:
             p99.9 |got - truth|  <=  factor x p99.9 max(|ref32 - truth|, 2 ulp32(truth))
@@ -83,7 +83,10 @@ class ParityLog:
         WHICH elements: those with |truth| >= 1e-3 max|truth| (the set the logged p99.9 figure has always used) -- an element a thousand times
         below its tensor's scale is a cancelling sum of terms at that scale (a saturated row's gradient: alpha g - (1 - alpha) w g with w = 1
         cancels EXACTLY in the reference's formulation and to rounding level, 3e-6 of the scale, in another), only its norm-wise accuracy
-        means anything and `check` covers it.  Arrays with fewer than 1000 such elements (the 8 x 3 goldens: the "percentile" is the
+        means anything and `check` covers it.  `scale_floor` (the summand floors the norm-wise checks use: the size of the terms a loss row or
+        a gradient element is a SUM of) extends both rules to tensors that are cancelling sums as a whole -- a saturated row's loss
+        2 (alpha pos + (1 - alpha) lse) is 1e-3 where pos and lse are 50: an element's resolution is then 8 ulp of the summand scale, and
+        the "significant" set is taken relative to it.  Arrays with fewer than 1000 such elements (the 8 x 3 goldens: the "percentile" is the
         maximum of two dozen numbers) get one more bit: 2 x factor.  Logged per family (`elementwise`)."""
         got = np.asarray(got, np.float64).ravel(); ref32 = np.asarray(ref32, np.float64).ravel(); truth = np.asarray(truth, np.float64).ravel()
         if self.mode in ("split_bf16", "split_f16"):
@@ -91,14 +94,15 @@ class ParityLog:
         assert got.shape == ref32.shape == truth.shape, (family, case, what, got.shape, ref32.shape, truth.shape)
         if not truth.size:
             return 0.0
-        sig = np.abs(truth) >= 1e-3 * float(np.abs(truth).max())
+        sig = np.abs(truth) >= 1e-3 * max(float(np.abs(truth).max()), float(scale_floor))
         if not sig.any():
             return 0.0
         got, ref32, truth = got[sig], ref32[sig], truth[sig]
         if truth.size < 1000:
             factor = 2.0 * factor
         e_hip = np.abs(got - truth)
-        e_ref = np.maximum(np.abs(ref32 - truth), 2.0 * float(np.finfo(np.float32).eps) * np.abs(truth))
+        eps32 = float(np.finfo(np.float32).eps)
+        e_ref = np.maximum(np.abs(ref32 - truth), np.maximum(2.0 * eps32 * np.abs(truth), 8.0 * eps32 * float(scale_floor)))
         kth = min(truth.size - 1, int(np.ceil(0.999 * truth.size)) - 1)
         p_hip = float(np.partition(e_hip, kth)[kth]); p_ref = float(np.partition(e_ref, kth)[kth])
         ratio = p_hip / p_ref if p_ref > 0 else (0.0 if p_hip == 0 else float("inf"))

@@ -670,7 +670,7 @@ def test_saved_activation_decodes_with_the_scale_its_planes_were_written_on():
     torch.cuda.synchronize()
     check("after a full step (planes on the previous scales)")
     with torch.no_grad():
-        tr.gW.mul_(8.0)                           # the activations grow 8 x: the two scale sets now differ by a power of two
+        tr.gW[-1].mul_(8.0)                       # the activations grow 8 x (inside the 64 x headroom): the two scale sets now differ by 2^3
     tr.step(); torch.cuda.synchronize()           # planes written on the OLD scales, update -> new scales
     check("after a full step across a scale change")
     tr.sample(); tr.forward(); torch.cuda.synchronize()
