@@ -549,8 +549,10 @@ def dropin_leg(args, device, steps=40, warmup=8):
     passes, roll inside the graph, loss(...), backward(), optimizer.step(), `.item()` host syncs) and its sampling call
     (:196-200, :328) with `import cl_ica_amd.{losses,encoders,latent_spaces,spaces,invertible_network_utils}` in place of the
     reference's modules; torch autograd drives the HIP kernels through the drop-in modules.  Reported next to the fused engine:
-    `torch_adam` keeps the reference's `torch.optim.Adam` line, `flat_adam` swaps that one line for `cl_ica_amd.optim.Adam`."""
+    `torch_adam` keeps the reference's `torch.optim.Adam` line, `flat_adam` swaps that one line for `cl_ica_amd.optim.Adam`,
+    `captured` additionally wraps the closure once with `cl_ica_amd.capture_train_step` (one graph launch per step)."""
     import contextlib, io, types
+    import cl_ica_amd
     from cl_ica_amd import encoders, invertible_network_utils as inu, lazy, losses, optim, train_mlp
     lazy_on = lazy.enabled()
     n, B = args.n, args.batch_size
@@ -563,7 +565,7 @@ def dropin_leg(args, device, steps=40, warmup=8):
                                          n_iter_cond_thresh=25000 if n <= 10 else 2000).to(device)
     loss = losses.LpSimCLRLoss(p=args.p, tau=1.0, simclr_compatibility_mode=True)
     res = {}
-    for name in ("torch_adam", "flat_adam"):
+    for name in ("torch_adam", "flat_adam", "captured"):
         torch.manual_seed(0)
         f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 50, n * 50, n * 10]).to(device)
         optimizer = torch.optim.Adam(f.parameters(), lr=1e-4) if name == "torch_adam" else optim.Adam(f.parameters(), lr=1e-4)
@@ -581,6 +583,14 @@ def dropin_leg(args, device, steps=40, warmup=8):
             optimizer.step()
             return total_loss_value.item(), [v.item() for v in losses_value]
 
+        if name == "captured":       # the same closure, recorded once into a HIP graph (cl_ica_amd/graphed.py); the call site below is unchanged
+            try:
+                z = latent_space.sample_marginal(B)
+                train_step = cl_ica_amd.capture_train_step(train_step, (z, latent_space.sample_conditional(z, B)), loss, optimizer)
+            except Exception as e:   # noqa: BLE001  (reported, not hidden: the two eager legs above are the fallback a user has)
+                res[name] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                continue
+
         def one():
             z = latent_space.sample_marginal(B)
             return train_step((z, latent_space.sample_conditional(z, B)), loss, optimizer)
@@ -592,11 +602,14 @@ def dropin_leg(args, device, steps=40, warmup=8):
             lv, _ = one()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        res[name] = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "final_loss": lv}
+        ar = encoders.arith_state(f)
+        res[name] = {"value": steps / el, "unit": "steps/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "final_loss": lv,
+                     "encoder_arith": ar["arith"], **({"f16_steps_withheld": ar["skipped"], "f16_flags": ar["flags"]} if "skipped" in ar else {})}
     st = f._structure() if hasattr(f, "_structure") else (None,) * 5 + (False, False)
     fused = encoders._use_fused(st[5], 2 * B if lazy_on else B)
     res["encoder_path"] = (("whole-encoder kernels in the split-bf16 arithmetic (clica_mlp_fwd_split / clica_mlp_dgrad_split / "
-                            "clica_mlp_wgrad_split; weight gradients added into the flat optimizer's gradient arena in place)"
+                            "clica_mlp_wgrad_split, or their f16x2 forms *16 under cl_ica_amd.optim.Adam -- `encoder_arith` of each leg; weight "
+                            "gradients added into the flat optimizer's gradient arena in place)"
                             if encoders._dropin_split(st[6]) else
                             "whole-encoder kernels (clica_mlp_fwd / clica_mlp_dgrad / clica_mlp_wgrad)") if fused else
                            "per-layer GEMM kernels (clica_linear_*): a %d-row encoder call is %d workgroups of 48 rows, below the 128 the "

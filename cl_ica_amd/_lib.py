@@ -200,6 +200,7 @@ SIGNATURES: Dict[str, list] = {
                              C.c_void_p, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],
     "clica_stamp": [C.c_void_p, c_i32, c_i32, C.c_void_p],
+    "clica_publish_host": [C.c_void_p, c_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "clica_clock_probe": [C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_set_tuning": [C.c_char_p, c_i32],
     "clica_abort_capture": [C.c_void_p],

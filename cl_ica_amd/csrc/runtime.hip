@@ -29,6 +29,17 @@ __global__ void stamp_k(unsigned long long* slot, int which, int cap) {
   slot[1 + 2 * (c % (unsigned long long)cap) + which] = t;
   if (!which) slot[0] = c + 1;
 }
+// values[0..n) -> host-visible memory, then a sequence number behind a system-scope release.  See clica_publish_host.
+__global__ void publish_host_k(const float* __restrict__ src, int n, float* host_dst, unsigned int* seq_dev, unsigned int* host_seq) {
+  if ((int)threadIdx.x < n) host_dst[threadIdx.x] = src[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int s = *seq_dev + 1u;
+    *seq_dev = s;
+    __hip_atomic_store(host_seq, s, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 // Shader-clock probe: ONE wave that samples (wall clock, core-clock counter) every `period` wall ticks, n times, and sleeps in between.
 // Launched on a side stream it shares a CU with whatever the main stream runs (16 registers, no LDS: it fits next to the 8-wave
 // workgroups of the encoder kernels), so the cycles it counts between two samples are that XCD's clock over that stretch of time.
@@ -59,6 +70,14 @@ extern "C" int clica_stamp(unsigned long long* slot, int32_t which, int32_t capa
   CLICA_CHECK_ARG(slot != nullptr && capacity >= 1 && (which == 0 || which == 1), "clica_stamp: bad argument");
   hipLaunchKernelGGL(clica::stamp_k, dim3(1), dim3(1), 0, clica::as_stream(stream), slot, (int)which, (int)capacity);
   return clica::launch_status("clica_stamp");
+}
+
+extern "C" int clica_publish_host(const float* src, int32_t n, float* host_dst, uint32_t* seq_dev, uint32_t* host_seq, clica_stream_t stream) {
+  CLICA_CHECK_ARG(src != nullptr && host_dst != nullptr && seq_dev != nullptr && host_seq != nullptr && n >= 1 && n <= 64,
+                  "clica_publish_host: bad argument (1 <= n <= 64)");
+  hipLaunchKernelGGL(clica::publish_host_k, dim3(1), dim3(64), 0, clica::as_stream(stream), src, (int)n, host_dst, (unsigned int*)seq_dev,
+                     (unsigned int*)host_seq);
+  return clica::launch_status("clica_publish_host");
 }
 
 extern "C" int clica_tick(int32_t* counter, clica_stream_t stream) {

@@ -186,26 +186,29 @@ class _SplitPlan:
     _cache = {}
 
     @staticmethod
-    def get(dev, M, shapes):
-        key = (dev, M, shapes)
+    def get(dev, M, shapes, f16=False):
+        key = (dev, M, shapes, f16)
         pl = _SplitPlan._cache.get(key)
         if pl is None:
             if len(_SplitPlan._cache) >= 16:
                 _SplitPlan._cache.clear()
-            pl = _SplitPlan._cache[key] = _SplitPlan(dev, M, shapes)
+            pl = _SplitPlan._cache[key] = _SplitPlan(dev, M, shapes, f16)
         return pl
 
-    def __init__(self, dev, M, shapes):
+    def __init__(self, dev, M, shapes, f16=False):
         import ctypes as C
         from . import _lib
         lib = _lib.load()
         L = len(shapes)
-        self.dev, self.M, self.L, self.shapes = dev, M, L, shapes
+        self.dev, self.M, self.L, self.shapes, self.f16 = dev, M, L, shapes, f16
+        self.a_index = (C.c_int32 * L)(*range(L))                       # positions of layer l's operands in the f16x2 state's scale arrays
+        self.d_index = (C.c_int32 * L)(*[L - 1 - l for l in range(L)])
         self.kinds = kinds = [ops.mlp_wgrad_split_kind(N, K) for N, K in shapes]        # 0: matrix-core weight gradient from planes
         nb = C.c_size_t()
 
         def planes_bytes(width, ones):
-            _lib.check(lib.clica_mlp_planes_bytes(M, width, 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
+            fn = lib.clica_mlp_planes16_bytes if f16 else lib.clica_mlp_planes_bytes       # f16x2: 4 B per element, bf16x3: 6
+            _lib.check(fn(M, width, 1 if ones else 0, C.byref(nb)), "clica_mlp_planes_bytes")
             return nb.value
         _lib.check(lib.clica_mlp_signmask_bytes(M, C.byref(nb)), "clica_mlp_signmask_bytes")
         mask_bytes = nb.value
@@ -251,32 +254,38 @@ class _MLPFusedSplitFn(torch.autograd.Function):
     _ws_cache = {}
 
     @staticmethod
-    def _packed(params_w, key=None):
+    def _packed(params_w, key=None, s16=None, force=False):
+        """`s16`: the encoder's f16x2 context (`_S16Ctx`) or None for the bf16x3 arithmetic -- the two pack formats differ."""
         if key is None:
             key = _MLPFusedFn._weights_key(params_w)
         dev = params_w[0].device
         c = _MLPFusedSplitFn._pack_cache.get(dev)
-        if c is not None and c["key"] == key:
+        if c is not None and c["key"] == key and c["s16"] is s16 and not force:
             return c["packed"], c["packed_t"], key
         ptrs = tuple(k[0] for k in key[1:])
-        if c is not None and c.get("ptrs") == ptrs and c["strides"] == [w.stride() for w in params_w]:
+        if c is not None and c.get("ptrs") == ptrs and c["strides"] == [w.stride() for w in params_w] and c["s16"] is s16:
             # the same parameter tensors with new values (every training step): the argument arrays of the first call still hold
             from . import _lib
-            _lib.check(_lib.load().clica_mlp_pack_split_both(*c["args"], c["packed"].data_ptr(), c["packed_t"].data_ptr(), _lib.stream_ptr()),
-                       "clica_mlp_pack_split_both")
+            if s16 is None:
+                _lib.check(_lib.load().clica_mlp_pack_split_both(*c["args"], c["packed"].data_ptr(), c["packed_t"].data_ptr(), _lib.stream_ptr()),
+                           "clica_mlp_pack_split_both")
+            else:
+                _lib.check(_lib.load().clica_mlp_pack_split16_both(*c["args"], c["packed"].data_ptr(), c["packed_t"].data_ptr(),
+                                                                   s16.state.buf.data_ptr(), _lib.stream_ptr()), "clica_mlp_pack_split16_both")
             c["key"] = key
             return c["packed"], c["packed_t"], key
         import ctypes as C
         shapes = [tuple(w.shape) for w in params_w]
-        reuse = c is not None and c["shapes"] == shapes
+        reuse = c is not None and c["shapes"] == shapes and c["s16"] is s16
         ws = [w.detach() for w in params_w]
-        packed, packed_t = ops.mlp_pack_split_both(ws, c["packed"] if reuse else None, c["packed_t"] if reuse else None)
+        packed, packed_t = ops.mlp_pack_split_both(ws, c["packed"] if reuse else None, c["packed_t"] if reuse else None,
+                                                   state=None if s16 is None else s16.state)
         L = len(ws)
         args = None
         if all(w.dim() == 2 and w.stride(1) == 1 and w.is_cuda and w.dtype == torch.float32 for w in ws):
             args = (L, (C.c_void_p * L)(*[w.data_ptr() for w in ws]), (C.c_int64 * L)(*[w.stride(0) for w in ws]),
                     (C.c_int32 * L)(*[s_[0] for s_ in shapes]), (C.c_int32 * L)(*[s_[1] for s_ in shapes]))
-        _MLPFusedSplitFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t,
+        _MLPFusedSplitFn._pack_cache[dev] = dict(key=key, shapes=shapes, packed=packed, packed_t=packed_t, s16=s16,
                                                  params=[weakref.ref(w) for w in params_w], args=args,
                                                  ptrs=ptrs if args is not None else None, strides=[w.stride() for w in params_w])
         return packed, packed_t, key
@@ -291,7 +300,7 @@ class _MLPFusedSplitFn(torch.autograd.Function):
                 key = _MLPFusedFn._weights_key(ws)
                 if key != c["key"]:
                     with torch.cuda.device(dev):
-                        _MLPFusedSplitFn._packed(ws, key)
+                        _MLPFusedSplitFn._packed(ws, key, s16=c["s16"])
 
     @staticmethod
     def _wgrad_ws(dev, M, shapes):
@@ -313,17 +322,31 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         (x, ldx) = ops._mat("x", x)
         M, dev = x.shape[0], x.device
         pw = params[0::2]
-        packed, _, key = _MLPFusedSplitFn._packed(pw)
-        pl = _SplitPlan.get(dev, M, tuple(tuple(w.shape) for w in pw))
+        s16 = _s16_ctx(params, slope)            # f16x2 (the engine's default arithmetic) when the flat Adam owns these parameters, else bf16x3
+        calibrate = s16 is not None and s16.begin_forward(pw)
+        packed, _, key = _MLPFusedSplitFn._packed(pw, s16=s16, force=calibrate)
+        pl = _SplitPlan.get(dev, M, tuple(tuple(w.shape) for w in pw), s16 is not None)
         arena = torch.empty(pl.f_bytes, dtype=torch.uint8, device=dev)
         y = torch.empty((M, pl.shapes[-1][0]), dtype=torch.float32, device=dev)
         base, VP = arena.data_ptr(), pl.VP
         bias = VP(*[(b if b.is_contiguous() else b.contiguous()).data_ptr() for b in params[1::2]])
         outs = VP(*[None if o is None else base + o for o in pl.f_outs[:-1]], y.data_ptr())
-        _lib.check(_lib.load().clica_mlp_fwd_split(x.data_ptr(), ldx, M, None, 0, 0.0, None, 0, L, bias, outs, pl.f_ldo, pl.N, pl.K,
-                                                   packed.data_ptr(), VP(*[None if o is None else base + o for o in pl.f_masks]),
-                                                   VP(*[None if o is None else base + o for o in pl.f_planes]),
-                                                   float(slope), _lib.stream_ptr()), "clica_mlp_fwd_split")
+        fargs = (x.data_ptr(), ldx, M, None, 0, 0.0, None, 0, L, bias, outs, pl.f_ldo, pl.N, pl.K,
+                 packed.data_ptr(), VP(*[None if o is None else base + o for o in pl.f_masks]),
+                 VP(*[None if o is None else base + o for o in pl.f_planes]), float(slope))
+        if s16 is None:
+            _lib.check(_lib.load().clica_mlp_fwd_split(*fargs, _lib.stream_ptr()), "clica_mlp_fwd_split")
+        else:
+            st_ptr = s16.state.buf.data_ptr()
+            if calibrate:
+                # scales not measured on these parameters yet: this pass (weights packed and activations cut on the scales in force)
+                # records every tensor's fp32 maximum, the update turns them into scales, weights are packed again -- then the real pass
+                _lib.check(_lib.load().clica_mlp_fwd_split16(*fargs, st_ptr, _lib.stream_ptr()), "clica_mlp_fwd_split16")
+                s16.state.update()
+                _MLPFusedSplitFn._packed(pw, s16=s16, force=True)
+                s16.forward_calibrated()
+            _lib.check(_lib.load().clica_mlp_fwd_split16(*fargs, st_ptr, _lib.stream_ptr()), "clica_mlp_fwd_split16")
+        ctx.s16 = s16
         ctx.slope, ctx.L, ctx.plan, ctx.n_in = slope, L, pl, n_in
         ctx.rows = [t.shape[0] for t in xs]
         ctx.pack_key = key
@@ -362,11 +385,13 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         _lib.require_cuda(gy, "grad_output")
         need = ctx.needs_input_grad
         need_x = any(need[2:2 + ctx.n_in])
+        s16 = ctx.s16
+        st = None if s16 is None else s16.state
         cur = _MLPFusedSplitFn._pack_cache.get(dev)
-        if cur is not None and cur["key"] == ctx.pack_key:
+        if cur is not None and cur["key"] == ctx.pack_key and cur["s16"] is s16:
             packed_t = cur["packed_t"]
         else:
-            _, packed_t = ops.mlp_pack_split_both(ws)
+            _, packed_t = ops.mlp_pack_split_both(ws, state=st)
         lib, sp = _lib.load(), _lib.stream_ptr()
         fb = arena.data_ptr()
         barena = torch.empty(pl.b_bytes, dtype=torch.uint8, device=dev)
@@ -377,25 +402,40 @@ class _MLPFusedSplitFn(torch.autograd.Function):
         if L > 1 and need_x and f32_ptr[0] is None:
             dz0 = torch.empty((M, shapes[0][0]), dtype=torch.float32, device=dev)
             f32_ptr[0] = dz0.data_ptr()
+        gy_planes = None
         if L > 1:
             chain, VPc = pl.chain, pl.VPc
-            _lib.check(lib.clica_mlp_dgrad_split(gy.data_ptr(), gy.stride(0), M, L - 1, pl.cN, pl.cK, packed_t.data_ptr(),
-                                                 VPc(*[fb + pl.f_masks[l - 1] for l in chain]),
-                                                 VPc(*[f32_ptr[l - 1] for l in chain]),
-                                                 pl.I64c(*[0 if f32_ptr[l - 1] is None else shapes[l - 1][0] for l in chain]),
-                                                 VPc(*[None if pl.b_planes[l - 1] is None else bb + pl.b_planes[l - 1] for l in chain]),
-                                                 float(slope), sp), "clica_mlp_dgrad_split")
+            cargs = (gy.data_ptr(), gy.stride(0), M, L - 1, pl.cN, pl.cK, packed_t.data_ptr(),
+                     VPc(*[fb + pl.f_masks[l - 1] for l in chain]),
+                     VPc(*[f32_ptr[l - 1] for l in chain]),
+                     pl.I64c(*[0 if f32_ptr[l - 1] is None else shapes[l - 1][0] for l in chain]),
+                     VPc(*[None if pl.b_planes[l - 1] is None else bb + pl.b_planes[l - 1] for l in chain]),
+                     float(slope))
+            if st is None:
+                _lib.check(lib.clica_mlp_dgrad_split(*cargs, sp), "clica_mlp_dgrad_split")
+            else:
+                if s16.begin_backward():
+                    # gradient scales not measured yet: a link cuts its input on the scale in force and measures its OUTPUT in fp32, so
+                    # every un-applied pass + update settles (at least) one more link of the chain (engine.calibrate_scales does the same)
+                    for _ in range(L):
+                        if kinds[L - 1] == 0:
+                            gy_planes = ops.mlp_planes_from_f32(gy, False, out=gy_planes, state=st, tensor=(1, 0))
+                        _lib.check(lib.clica_mlp_dgrad_split16(*cargs, st.buf.data_ptr(), sp), "clica_mlp_dgrad_split16")
+                        st.update()
+                    st.clear_flags()          # (passes on unmeasured scales: whatever they flagged is not a finding)
+                    s16.backward_calibrated()
+                _lib.check(lib.clica_mlp_dgrad_split16(*cargs, st.buf.data_ptr(), sp), "clica_mlp_dgrad_split16")
         keep = [barena]
         # operands of the weight gradients, per layer: planes (kind 0) or fp32 (kind 1)
         dzp, xp, dzf, lddz, xf, ldxf = [None] * L, [None] * L, [None] * L, [0] * L, [None] * L, [0] * L
         for l in range(L):
             if kinds[l] == 0:
                 if l == L - 1:
-                    t = ops.mlp_planes_from_f32(gy, False); keep.append(t); dzp[l] = t.data_ptr()
+                    t = ops.mlp_planes_from_f32(gy, False, out=gy_planes, state=st, tensor=(1, 0)); keep.append(t); dzp[l] = t.data_ptr()
                 else:
                     dzp[l] = bb + pl.b_planes[l]
                 if l == 0:
-                    t = ops.mlp_planes_from_f32(x, True); keep.append(t); xp[l] = t.data_ptr()
+                    t = ops.mlp_planes_from_f32(x, True, state=st, tensor=(0, 0)); keep.append(t); xp[l] = t.data_ptr()
                 else:
                     xp[l] = fb + pl.f_planes[l - 1]
             else:
@@ -411,10 +451,13 @@ class _MLPFusedSplitFn(torch.autograd.Function):
             acc = 0
         wsb = _MLPFusedSplitFn._wgrad_ws(dev, M, shapes)
         VP = pl.VP
-        _lib.check(lib.clica_mlp_wgrad_split(M, L, VP(*dzp), VP(*xp), VP(*dzf), pl.I64(*lddz), VP(*xf), pl.I64(*ldxf),
-                                             VP(*[w.data_ptr() for w in dWs]), pl.I64(*[w.stride(0) for w in dWs]),
-                                             VP(*[b.data_ptr() for b in dbs]), pl.N, pl.K, acc, wsb.data_ptr(), wsb.numel(), sp),
-                   "clica_mlp_wgrad_split")
+        wargs = (M, L, VP(*dzp), VP(*xp), VP(*dzf), pl.I64(*lddz), VP(*xf), pl.I64(*ldxf),
+                 VP(*[w.data_ptr() for w in dWs]), pl.I64(*[w.stride(0) for w in dWs]), VP(*[b.data_ptr() for b in dbs]), pl.N, pl.K, acc)
+        if st is None:
+            _lib.check(lib.clica_mlp_wgrad_split(*wargs, wsb.data_ptr(), wsb.numel(), sp), "clica_mlp_wgrad_split")
+        else:
+            _lib.check(lib.clica_mlp_wgrad_split16(*wargs, st.buf.data_ptr(), pl.a_index, pl.d_index, wsb.data_ptr(), wsb.numel(), sp),
+                       "clica_mlp_wgrad_split16")
         grads = [None] * (2 * L)
         if not in_place:
             for l in range(L):
@@ -430,6 +473,72 @@ class _MLPFusedSplitFn(torch.autograd.Function):
                 off += r
         del keep
         return (None, None, *dxs, *grads)
+
+
+S16_ENABLED = True           # test hook: False keeps the drop-in encoder on the bf16x3 arithmetic (as CLICA_SPLIT_ARITH=bf16 does)
+
+
+class _S16Ctx:
+    """f16x2 arithmetic of ONE drop-in encoder (include/clica.h "f16x2 arithmetic"; the engine's default since round 5): the device state
+    with the per-tensor scales, and what the host knows about them.  Scales follow the data with one step's delay, so they are MEASURED
+    before the first step and after the parameters were written from outside (version counters): the forward runs one un-applied pass +
+    update, the first backward L un-applied chain passes (`_MLPFusedSplitFn`).  From then on the update rides in the flat Adam's launch
+    (cl_ica_amd/optim.py), which also honours THE GUARD: a step whose producers met a value beyond its scale leaves the parameters
+    untouched (counted; `arith_state`)."""
+
+    def __init__(self, n_layers, device, opt):
+        self.state = ops.Split16(n_layers, device)
+        self.opt = weakref.ref(opt)
+        self.versions = None
+        self.fwd_ok = self.bwd_ok = False
+
+    def begin_forward(self, pw) -> bool:
+        """True: this forward has to measure the scales first."""
+        v = sum(w._version for w in pw)
+        if v != self.versions:
+            self.versions, self.fwd_ok, self.bwd_ok = v, False, False
+        return not self.fwd_ok and not torch.cuda.is_current_stream_capturing()
+
+    def forward_calibrated(self):
+        self.fwd_ok = True
+
+    def begin_backward(self) -> bool:
+        return not self.bwd_ok and not torch.cuda.is_current_stream_capturing()
+
+    def backward_calibrated(self):
+        self.bwd_ok = True
+
+
+def _s16_ctx(params, slope):
+    """The f16x2 context of the encoder with these parameters, or None (bf16x3): needs `cl_ica_amd.optim.Adam` over ALL of them -- the
+    launch that applies the step is what the arithmetic's guard acts through --, single rank, <= 8 layers, a LeakyReLU slope in (0, 1)."""
+    import os
+    if not S16_ENABLED or not (0.0 < slope < 1.0) or len(params) > 16 or os.environ.get("CLICA_SPLIT_ARITH", "f16").lower() != "f16":
+        return None
+    opt = None
+    for q in params:
+        r = q.__dict__.get("_clica_flat_opt")
+        o = r() if r is not None else None
+        if o is None or (opt is not None and o is not opt):
+            return None
+        opt = o
+    if opt.world > 1:
+        return None
+    c = params[0].__dict__.get("_clica_s16")
+    if c is None or c.opt() is not opt:
+        c = _S16Ctx(len(params) // 2, params[0].device, opt)
+        params[0].__dict__["_clica_s16"] = c
+    return c if opt._bind_s16(c) else None
+
+
+def arith_state(module) -> dict:
+    """Which arithmetic the whole-encoder kernels of a drop-in encoder run in and, for f16x2, the state of its scales and of the guard
+    (host read + sync: log points, tests): flags (bit 0 overflow seen, bit 1 a step was withheld), `skipped` = steps withheld so far."""
+    lin = [m for m in module if isinstance(m, nn.Linear)]
+    c = lin[0].weight.__dict__.get("_clica_s16") if lin else None
+    if c is None:
+        return dict(arith="bf16x3")
+    return dict(arith="f16x2", **c.state.read(), **{k: v for k, v in c.state.guard().items() if k in ("skipped", "poisoned")})
 
 
 def _after_step():

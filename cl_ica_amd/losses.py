@@ -92,7 +92,13 @@ def _async_item() -> bool:
 
 def _share_items(src, outs):
     if src.is_cuda and torch.cuda.is_current_stream_capturing():
-        return      # tensors of a captured graph are rewritten by every replay: they keep the plain Tensor.item (a cached value would go stale)
+        # tensors of a captured graph are rewritten by every replay: they keep the plain Tensor.item (a cached value would go stale) --
+        # unless cl_ica_amd.capture_train_step is recording, which publishes them to the host from this point of the graph
+        from . import graphed
+        rec = graphed.active_recorder()
+        if rec is not None:
+            rec.publish(src, outs)
+        return
     sh = _SharedScalars(src)
     for k, t in enumerate(outs):
         t.item = functools.partial(sh.item, t, k, t._version)

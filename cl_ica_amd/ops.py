@@ -635,6 +635,16 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
                                           step_dev.data_ptr(), ticket.data_ptr(), stream_ptr()), "clica_adam_step_tick")
 
 
+def publish_host(src: torch.Tensor, host_dst: torch.Tensor, seq_dev: torch.Tensor, host_seq: torch.Tensor):
+    """src (device fp32, <= 64 values) -> host_dst (pinned fp32), then ++seq_dev (device int32) -> host_seq (pinned int32) behind a
+    system-scope release: a host read from the middle of a captured step (clica_publish_host)."""
+    assert src.is_cuda and src.dtype == torch.float32 and src.is_contiguous() and 1 <= src.numel() <= 64
+    assert host_dst.is_pinned() and host_dst.dtype == torch.float32 and host_dst.numel() >= src.numel()
+    assert seq_dev.is_cuda and seq_dev.dtype == torch.int32 and host_seq.is_pinned() and host_seq.dtype == torch.int32
+    check(load().clica_publish_host(src.data_ptr(), src.numel(), host_dst.data_ptr(), seq_dev.data_ptr(), host_seq.data_ptr(), stream_ptr()),
+          "clica_publish_host")
+
+
 def stamp(slot: torch.Tensor, which: int):
     """Device-side begin (0) / end (1) time stamp into `slot` (int64 [1 + 2 * capacity], zeros): usable inside graph capture."""
     check(load().clica_stamp(slot.data_ptr(), int(which), (slot.numel() - 1) // 2, stream_ptr()), "clica_stamp")

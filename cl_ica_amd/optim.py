@@ -11,6 +11,7 @@ Construction re-points every parameter's ``.data`` into a 16-byte aligned slice 
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, Optional
 
 import torch
@@ -53,6 +54,8 @@ class Adam:
             # the drop-in encoder's backward (encoders._MLPFusedFn) adds its dW / db straight into this view (and hands autograd
             # None) when it finds it installed: no per-parameter gradient tensors, no AccumulateGrad launches
             p._clica_grad_view = p.grad
+            p._clica_flat_opt = weakref.ref(self)      # (encoders._s16_ctx: the f16x2 arithmetic needs THIS optimizer to apply the step)
+        self._s16 = None
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
 
@@ -64,6 +67,14 @@ class Adam:
             if p.grad is None or p.grad.data_ptr() != self.grad_arena.data_ptr() + 4 * off:
                 p.grad = self.grad_arena[off:off + p.numel()].view(p.shape)      # someone set it to None / replaced it
                 p._clica_grad_view = p.grad
+
+    def _bind_s16(self, ctx) -> bool:
+        """An encoder's f16x2 context asks to ride in this optimizer's launch (scale update + guard).  One at a time: the launch takes one."""
+        cur = self._s16() if self._s16 is not None else None
+        if cur is None or cur is ctx:
+            self._s16 = weakref.ref(ctx)
+            return True
+        return False
 
     def all_reduce_grads(self):
         """Data parallel: sum the gradient arena over the ranks (the 1/world average is applied inside ``step``)."""
@@ -98,8 +109,16 @@ class Adam:
             raise ValueError("the flat Adam supports exactly one parameter group")
         self._adopt_foreign_grads()
         g = self.param_groups[0]
-        ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
-                      float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world, ticket=self._ticket)
+        s16 = self._s16() if self._s16 is not None else None
+        if s16 is not None:
+            # the encoder runs in the f16x2 arithmetic: its scale update rides in this launch, and a step whose producers met a value
+            # beyond its scale (the guard, include/clica.h) leaves parameters and moments untouched and takes the step count back
+            ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
+                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0, t_offset=1, s16=s16.state)
+            ops.tick(self.step_dev)
+        else:
+            ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
+                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world, ticket=self._ticket)
         lazy.after_step()         # e.g. the encoder's fragment-order weight copies, re-packed now rather than in front of the next forward
         return loss
 

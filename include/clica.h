@@ -709,6 +709,12 @@ int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float*
                          int32_t* step_dev, int32_t* ticket, clica_stream_t stream);
 /* *counter += 1 (single-thread kernel; keeps step/RNG counters on device for graph replay) */
 int clica_tick(int32_t* counter, clica_stream_t stream);
+/* Host reads from the MIDDLE of a captured step (cl_ica_amd/graphed.py: the reference's train_step reads three loss scalars per step,
+ * main_mlp.py:283-285, which become final right after the loss forward).  A one-wave kernel copies src[0..n) (device, n <= 64) to
+ * host_dst (host memory the device can write: hipHostMalloc / a pinned torch tensor), then advances *seq_dev and stores the new value
+ * to *host_seq with a system-scope release.  The host spins on *host_seq reaching the number of replays it has issued and reads the
+ * values while the rest of the graph (backward, optimizer) is still running. */
+int clica_publish_host(const float* src, int32_t n, float* host_dst, uint32_t* seq_dev, uint32_t* host_seq, clica_stream_t stream);
 /* Measurement aid (bench.py): device-side interval stamps that work INSIDE a captured graph, where event records cannot be timed.
  * `slot` = 1 + 2 * capacity device uint64, zero-initialised: a one-thread kernel writes the 100 MHz wall clock (s_memrealtime) to
  * begin (which = 0) / end (which = 1) entry (count % capacity) and the begin stamp advances the count in slot[0].  Launched on the

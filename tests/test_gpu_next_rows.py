@@ -325,6 +325,9 @@ def test_dropin_lazy_stacking_and_symmetric_loss_match_plain_path(B, p, monkeypa
         assert ran == ({"sym_one_sweep": 1} if mode == "fast" else {"generic": 1}), ran
         # .item() of the three scalars: one device copy, the same numbers Tensor.item returns
         assert (tot.item(), pos.item(), neg.item()) == (torch.Tensor.item(tot), torch.Tensor.item(pos), torch.Tensor.item(neg))
+        # the whole-encoder kernels run in the engine's default arithmetic (f16x2) because the flat Adam owns the parameters
+        fused_rows = 2 * B if mode == "fast" else B
+        assert encoders.arith_state(f)["arith"] == ("f16x2" if (fused_rows + 47) // 48 >= 128 else "bf16x3")
         res[mode] = dict(loss=tot.item(), item=item.detach().cpu().numpy(), pos=pos.item(), neg=neg.item(), a=lazy.plain(a).detach().cpu().numpy(),
                          b=b.detach().cpu().numpy(), grads=[q.grad.detach().cpu().numpy().copy() for q in f.parameters()], f=f)
     fam, case = "dropin_lazy_sym", f"B={B} p={p}"
@@ -630,12 +633,19 @@ def test_device_time_stamps_inside_a_graph():
     assert len(ghz) >= 2 and all(0.3 < x < 2.6 for x in ghz), ghz
 
 
-def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
+@pytest.mark.parametrize("flat_arith", ["bf16x3", "f16x2"])
+def test_dropin_flat_adam_in_place_gradient_accumulation(flat_arith, monkeypatch):
     """The reference's train_step structure (two encoder calls per step, main_mlp.py:258-285) on the drop-in modules with
     cl_ica_amd.optim.Adam: the fused encoder backward adds dW / db straight into the optimizer's gradient arena (autograd gets
-    None).  Three steps against the same loop with torch.optim.Adam (ordinary autograd accumulation): parameters agree."""
+    None).  Three steps against the same loop with torch.optim.Adam (ordinary autograd accumulation): parameters agree.
+    `bf16x3`: both sides in the same arithmetic (the flat side's f16x2 switched off) -- the accumulation path alone is under test;
+    `f16x2`: the flat side in its default arithmetic against torch.optim.Adam's bf16x3 -- gradients differ at rounding level, which Adam
+    turns into steps of a fraction of lr for the few elements whose gradient IS at rounding level (measured: 4e-4 of a layer's elements
+    beyond 10 % of lr, the largest at 40 %): all but 1e-3 of the elements within 10 % of
+    lr, none beyond the three steps' total travel."""
     from cl_ica_amd import encoders, losses, optim
     monkeypatch.setattr("cl_ica_amd.encoders.FUSED_MODE", "1")
+    monkeypatch.setattr("cl_ica_amd.encoders.S16_ENABLED", flat_arith == "f16x2")
     n, B = 10, 1536
     loss = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
     outs = {}
@@ -653,6 +663,7 @@ def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
             if kind == "flat":
                 assert all(p.grad.data_ptr() == p._clica_grad_view.data_ptr() for p in f.parameters())
             opt.step()
+        assert encoders.arith_state(f)["arith"] == (flat_arith if kind == "flat" else "bf16x3")
         outs[kind] = [p.detach().clone() for p in f.parameters()] + [tot.detach().clone()]
     # (two Adam implementations, three steps at lr = 1e-3: rounding-level gradient differences move an element by << lr)
     params = list(zip(outs["flat"][:-1], outs["torch"][:-1]))
@@ -662,5 +673,160 @@ def test_dropin_flat_adam_in_place_gradient_accumulation(monkeypatch):
         # normalises to steps of order lr in whatever direction the noise points (measured 1e-5 ... 1.4e-4 between the two runs): bounded by
         # the three steps' total travel instead
         tol = 3e-3 if i == len(params) - 1 else 1e-4
-        assert float((a - b).abs().max()) <= tol, (i, float((a - b).abs().max()))
+        d = (a - b).abs()
+        if flat_arith == "f16x2" and i != len(params) - 1:
+            assert float((d > tol).float().mean()) <= 1e-3 and float(d.max()) <= 2.02 * 1e-3 * 3, (i, float(d.max()), float((d > tol).float().mean()))
+        else:
+            assert float(d.max()) <= tol, (i, float(d.max()))
     assert abs(float(outs["flat"][-1]) - float(outs["torch"][-1])) <= 1e-5 * abs(float(outs["torch"][-1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opt_kind", ["flat", "torch_capturable"])
+def test_captured_train_step_replays_the_reference_closure(opt_kind):
+    """`cl_ica_amd.capture_train_step` records the reference's UNCHANGED train_step closure (main_mlp.py:258-285: two
+    encoder calls, roll, loss, backward, optimizer.step, three `.item()` reads) into a HIP graph.  Two identical encoders are trained on
+    the same batches, one through the closure itself (eager), one through the replaying callable: same returned floats, same parameters
+    after every step (the same kernels run on the same inputs, so to fp32 rounding of nothing: bit-equal), and a batch of another shape
+    goes through the closure itself."""
+    import cl_ica_amd
+    from cl_ica_amd import losses, optim
+    n, B, steps = 10, 1536, 6
+    g = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(steps + 4):
+        x1 = torch.rand(B, n, generator=g).cuda()
+        batches.append((x1, (x1 + 0.05 * torch.randn(B, n, generator=g).cuda()).clamp(0, 1)))
+
+    def make():
+        torch.manual_seed(11)
+        f = build_mlp_n10().cuda()
+        opt = optim.Adam(f.parameters(), lr=1e-3) if opt_kind == "flat" else torch.optim.Adam(f.parameters(), lr=1e-3, capturable=True)
+        L = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
+
+        def train_step(data, loss, optimizer):
+            z1, z2_con_z1 = data
+            z3 = torch.roll(z1, 1, 0)
+            optimizer.zero_grad()
+            z1_rec = f(z1)
+            z2_con_z1_rec = f(z2_con_z1)
+            z3_rec = torch.roll(z1_rec, 1, 0)
+            total_loss_value, _, losses_value = loss(z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec)
+            total_loss_value.backward()
+            optimizer.step()
+            return total_loss_value.item(), [v.item() for v in losses_value]
+        return f, opt, L, train_step
+
+    f_e, opt_e, L_e, step_e = make()
+    f_c, opt_c, L_c, step_c = make()
+    for q_e, q_c in zip(f_e.parameters(), f_c.parameters()):
+        assert torch.equal(q_e, q_c)
+    warm = 3
+    replay = cl_ica_amd.capture_train_step(step_c, batches[0], L_c, opt_c, warmup=warm)
+    assert replay.n_host_scalars == 3 and replay.n_early_scalars == 3      # all three are published from behind the loss forward
+    # the warm-up calls were ordinary steps on batches[0]; the recording itself launched nothing.  Start both sides from the captured
+    # side's state and walk in lockstep
+    f_e.load_state_dict(f_c.state_dict())
+    import copy
+    opt_e.load_state_dict(copy.deepcopy(opt_c.state_dict()))      # (torch's load_state_dict keeps same-device tensors by reference)
+    for k in range(steps):
+        ref = step_e(batches[k + 2], L_e, opt_e)
+        got = replay(batches[k + 2], L_c, opt_c)
+        assert isinstance(got[0], float) and isinstance(got[1], list) and all(isinstance(v, float) for v in got[1])
+        np.testing.assert_allclose(got[0], ref[0], rtol=2e-6, atol=0)
+        np.testing.assert_allclose(got[1], ref[1], rtol=2e-6, atol=0)
+        for q_e, q_c in zip(f_e.parameters(), f_c.parameters()):
+            d = (q_e.detach() - q_c.detach()).abs().max().item()
+            assert d <= 2e-6 * max(1.0, q_e.detach().abs().max().item()), (k, d)
+    PARITY.check("dropin_captured", f"{opt_kind} B={B}", "loss after lockstep steps (replay vs eager closure)", got[0], ref[0])
+    # another batch shape: the closure itself runs (and trains)
+    x1 = torch.rand(333, n, generator=g).cuda()
+    before = [q.detach().clone() for q in f_c.parameters()]
+    out = replay((x1, (x1 + 0.05).clamp(0, 1)), L_c, opt_c)
+    assert isinstance(out[0], float) and any(not torch.equal(b, q.detach()) for b, q in zip(before, f_c.parameters()))
+    # and the graph still replays afterwards
+    out2 = replay(batches[0], L_c, opt_c)
+    assert np.isfinite(out2[0])
+
+
+@pytest.mark.gpu
+def test_dropin_f16x2_arithmetic_under_the_flat_adam_and_its_guard(monkeypatch):
+    """VERDICT r5 item 8 (first half): the drop-in encoder's whole-stack kernels in the engine's f16x2 arithmetic.  It needs the launch that
+    applies the step to honour the arithmetic's guard, so it runs when `cl_ica_amd.optim.Adam` owns the parameters (torch.optim.Adam keeps
+    bf16x3).  (a) first step from fresh parameters -- the scales are measured inside that step's forward / backward --: embeddings, loss
+    and every weight gradient against the fp64 oracle at 1e-5, next to the same step in bf16x3; (b) five steps in each arithmetic give the
+    same losses; (c) a batch 1 000 x larger than the scales know poisons the step ON THE DEVICE: the optimizer launch leaves parameters and
+    moments bit-identical and counts it; the following steps on that data are applied once the scales have followed."""
+    from cl_ica_amd import encoders, losses, optim
+    n, B = 10, 6144
+    g = torch.Generator().manual_seed(21)
+    batches = []
+    for _ in range(8):
+        x1 = torch.rand(B, n, generator=g).cuda()
+        batches.append((x1, (x1 + 0.05 * torch.randn(B, n, generator=g).cuda()).clamp(0, 1)))
+    L = losses.LpSimCLRLoss(p=2, tau=1.0, simclr_compatibility_mode=True)
+
+    def step(f, opt, data):
+        x1, x2 = data
+        opt.zero_grad()
+        a = f(x1); b = f(x2)
+        tot, _, _ = L(None, None, None, a, b, torch.roll(a, 1, 0))
+        tot.backward()
+        grads = [q.grad.detach().clone() for q in f.parameters()]
+        opt.step()
+        return tot.item(), a, b, grads
+
+    runs = {}
+    for arith in ("f16x2", "bf16x3"):
+        monkeypatch.setattr(encoders, "S16_ENABLED", arith == "f16x2")
+        torch.manual_seed(3)
+        f = build_mlp_n10().cuda()
+        opt = optim.Adam(f.parameters(), lr=1e-3)
+        lin = [m for m in f if isinstance(m, torch.nn.Linear)]
+        P = O.MLPParams([m.weight.detach().cpu().numpy().astype(np.float64) for m in lin], [m.bias.detach().cpu().numpy().astype(np.float64) for m in lin])
+        lv, a, b, grads = step(f, opt, batches[0])
+        st = encoders.arith_state(f)
+        assert st["arith"] == arith, st
+        x = np.concatenate([batches[0][0].cpu().numpy(), batches[0][1].cpu().numpy()]).astype(np.float64)
+        y, cache = O.mlp_forward(P, x)
+        ref = O.lp_simclr_loss(y[:B], y[B:], np.roll(y[:B], 1, 0), p=2, compat=True)
+        fam, case = "dropin_f16x2", f"{arith} first step B={B}"
+        from cl_ica_amd import lazy
+        PARITY.check(fam, case, "embeddings z1", lazy.plain(a).detach().cpu().numpy(), y[:B])
+        PARITY.check(fam, case, "embeddings z2", b.detach().cpu().numpy(), y[B:])
+        PARITY.check(fam, case, "loss", lv, ref["loss_mean"])
+        losses_seq = [lv]
+        for k in range(1, 5):
+            losses_seq.append(step(f, opt, batches[k])[0])
+        runs[arith] = dict(f=f, opt=opt, grads=[q.cpu().numpy() for q in grads], losses=losses_seq, state=encoders.arith_state(f))
+    # first-step weight gradients: the two arithmetics against each other (both are checked against fp64 in the engine's tests)
+    for k, (u, v) in enumerate(zip(runs["f16x2"]["grads"][:-1], runs["bf16x3"]["grads"][:-1])):
+        PARITY.check("dropin_f16x2", f"first step B={B}", f"grad{k} f16x2 vs bf16x3", u, v)
+    np.testing.assert_allclose(runs["f16x2"]["losses"], runs["bf16x3"]["losses"], rtol=2e-5)
+    st = runs["f16x2"]["state"]
+    assert st["flags"] == 0 and st["skipped"] == 0 and not st["poisoned"], st
+    assert all(1e-6 < sc < 1e12 and sc != 1.0 for sc in st["scales_d"][:3]), st          # the gradient scales were measured
+    # (c) the guard
+    monkeypatch.setattr(encoders, "S16_ENABLED", True)
+    f, opt = runs["f16x2"]["f"], runs["f16x2"]["opt"]
+    snap = [t.clone() for t in (opt.param_arena, opt.exp_avg, opt.exp_avg_sq)]
+    t0 = int(opt.step_dev.item())
+    big = (batches[5][0] * 1000.0, batches[5][1] * 1000.0)
+    step(f, opt, big)
+    torch.cuda.synchronize()
+    st = encoders.arith_state(f)
+    assert st["skipped"] == 1 and (st["flags"] & 2) and not (st["flags"] & 4), st
+    assert int(opt.step_dev.item()) == t0
+    for u, v in zip(snap, (opt.param_arena, opt.exp_avg, opt.exp_avg_sq)):
+        assert torch.equal(u, v), "a withheld step must leave parameters and moments untouched"
+    tries = 0
+    while int(opt.step_dev.item()) == t0 and tries < 12:
+        step(f, opt, big); tries += 1
+    st = encoders.arith_state(f)
+    assert int(opt.step_dev.item()) == t0 + 1 and st["skipped"] == tries and not (st["flags"] & 4), (tries, st)
+    assert not torch.equal(snap[0], opt.param_arena)
+    # torch.optim.Adam cannot be made to skip a step: the encoder stays on bf16x3 under it
+    f2 = build_mlp_n10().cuda()
+    o2 = torch.optim.Adam(f2.parameters(), lr=1e-3)
+    step(f2, o2, batches[0])
+    assert encoders.arith_state(f2)["arith"] == "bf16x3"
