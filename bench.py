@@ -550,7 +550,9 @@ def dropin_leg(args, device, steps=40, warmup=8):
     (:196-200, :328) with `import cl_ica_amd.{losses,encoders,latent_spaces,spaces,invertible_network_utils}` in place of the
     reference's modules; torch autograd drives the HIP kernels through the drop-in modules.  Reported next to the fused engine:
     `torch_adam` keeps the reference's `torch.optim.Adam` line, `flat_adam` swaps that one line for `cl_ica_amd.optim.Adam`,
-    `captured` additionally wraps the closure once with `cl_ica_amd.capture_train_step` (one graph launch per step)."""
+    `captured` additionally wraps the closure once with `cl_ica_amd.capture_train_step` (one graph launch per step);
+    `torch_adam_captured` does that with `torch.optim.Adam(..., capturable=True)` (the encoder then stays on bf16x3: the f16x2
+    arithmetic needs the flat Adam's launch for its guard)."""
     import contextlib, io, types
     import cl_ica_amd
     from cl_ica_amd import encoders, invertible_network_utils as inu, lazy, losses, optim, train_mlp
@@ -565,10 +567,11 @@ def dropin_leg(args, device, steps=40, warmup=8):
                                          n_iter_cond_thresh=25000 if n <= 10 else 2000).to(device)
     loss = losses.LpSimCLRLoss(p=args.p, tau=1.0, simclr_compatibility_mode=True)
     res = {}
-    for name in ("torch_adam", "flat_adam", "captured"):
+    for name in ("torch_adam", "flat_adam", "torch_adam_captured", "captured"):
         torch.manual_seed(0)
         f = encoders.get_mlp(n_in=n, n_out=n, layers=[n * 10, n * 50, n * 50, n * 50, n * 50, n * 10]).to(device)
-        optimizer = torch.optim.Adam(f.parameters(), lr=1e-4) if name == "torch_adam" else optim.Adam(f.parameters(), lr=1e-4)
+        optimizer = (torch.optim.Adam(f.parameters(), lr=1e-4) if name == "torch_adam" else
+                     torch.optim.Adam(f.parameters(), lr=1e-4, capturable=True) if name == "torch_adam_captured" else optim.Adam(f.parameters(), lr=1e-4))
         h = lambda z: f(g(z))   # noqa: E731
 
         def train_step(data, loss, optimizer):
@@ -583,7 +586,7 @@ def dropin_leg(args, device, steps=40, warmup=8):
             optimizer.step()
             return total_loss_value.item(), [v.item() for v in losses_value]
 
-        if name == "captured":       # the same closure, recorded once into a HIP graph (cl_ica_amd/graphed.py); the call site below is unchanged
+        if name.endswith("captured"):       # the same closure, recorded once into a HIP graph (cl_ica_amd/graphed.py); the call site below is unchanged
             try:
                 z = latent_space.sample_marginal(B)
                 train_step = cl_ica_amd.capture_train_step(train_step, (z, latent_space.sample_conditional(z, B)), loss, optimizer)
