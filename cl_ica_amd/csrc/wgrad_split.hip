@@ -345,12 +345,118 @@ __device__ __forceinline__ void fused_epilogue16(const Prob& g, const f32x16 (&a
   if (g.outS.slots) s16::s16_commit_block_max(g.outS, amax, red, blockIdx.x, gridDim.x);
 }
 
+
+// The f16x2 epilogue SPECIALISED per output combination (round 6).  The generic version above decides direction and the
+// three output formats at run time per accumulator block and clamps every address: ~12 000 instructions and 204 spilled registers behind
+// the 256 x 256 body -- run by all eight waves of a CU at once, with nothing to hide behind.  Here direction and outputs are template
+// parameters, the host guarantees M % 4 == 0 and N % 4 == 0 (row quads and lane quads are whole: one predicate per store, no element
+// fallback), every address is ONE lane base per column block plus a compile-time offset per accumulator block (the plane layout is linear
+// in (i, q) because a wave's row0 is a multiple of 32), and the gate words of a column block are loaded up front, ahead of the stores
+// (the data-gradient epilogue used to wait for the previous block's stores in front of every gate word: vmcnt counts both).
+constexpr int epi_code(bool bwd, bool T, bool N, bool F) { return 16 + (bwd ? 8 : 0) + (T ? 4 : 0) + (N ? 2 : 0) + (F ? 1 : 0); }
+template <int NI, int CODE>
+__device__ __forceinline__ void fused_epilogue16_fast(const Prob& g, const f32x16 (&acc)[NI][2], const int row0, const int col0, int lane) {
+  constexpr bool BWD = (CODE & 8) != 0, HAS_T = (CODE & 4) != 0, HAS_N = (CODE & 2) != 0, HAS_F = (CODE & 1) != 0;
+  asm volatile("" : "+v"(lane));
+  __shared__ float red[8];
+  const int h = lane >> 5, l31 = lane & 31, j4 = lane & 3;
+  const unsigned sel = (j4 & 1) ? 0x03020706u : 0x05040100u;
+  const bool upper = (j4 & 2) != 0;
+  const float unscale = 1.f / (*g.scaleA * *g.scaleB);
+  const float s_out = g.outS.scale ? *g.outS.scale : 1.f;
+  const float slope = g.slope;
+  const bool leaky = g.leaky != 0, slope01 = slope > 0.f && slope < 1.f;
+  const int M = g.M;
+  const int mrow = row0 + 4 * h;                              // first row of this lane's accumulator rows (block (0, 0))
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col0 + j * 32 + l31;
+    const bool col_ok = col < g.N;
+    const float b = (!BWD && g.bias && col_ok) ? g.bias[col] : 0.f;
+    // lane bases (bytes): T-planes: (row = col, feature = mrow); N-planes: (row = mrow + j4, feature = first column of the lane quad)
+    const size_t t_lane = (size_t)(((col & 15) >> 2) * 256 + (col & 3) * 32) + (size_t)(row0 >> 5) * 2048 + (size_t)(8 * h);
+    const int c0 = col & ~3;
+    char* pT = nullptr; const char* pS = nullptr; char* pN = nullptr; float* pF = nullptr;
+    if constexpr (HAS_T) pT = g.outT + (size_t)(col >> 4) * 2048 * g.fuT + t_lane;
+    if constexpr (BWD) pS = g.signT ? g.signT + (size_t)(col >> 4) * 2048 * g.fuS + t_lane : nullptr;
+    const size_t n_step = (size_t)2048 * g.fuN;              // one 16-row group of the N-planes
+    if constexpr (HAS_N) pN = g.outN + (size_t)(row0 >> 4) * n_step + (size_t)(h * 256 + j4 * 32)
+                              + (size_t)(c0 >> 5) * 2048 + (size_t)(((c0 >> 4) & 1) * 128 + (c0 & 15) * 2);
+    if constexpr (HAS_F) pF = g.outF + (int64_t)mrow * g.ldf + col;
+    u32x2 gate[NI][4];
+    if constexpr (BWD) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gate[i][q] = (u32x2){0x3C003C00u, 0x3C003C00u};        // "positive" when there is no gate
+          if (pS && col_ok && mrow + i * 32 + 8 * q < M)
+            gate[i][q] = *reinterpret_cast<const u32x2*>(pS + i * 2048 + (q >> 1) * 128 + (q & 1) * 16);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool ok = col_ok && (mrow + i * 32 + 8 * q < M);    // rows m .. m + 3 exist together (M % 4 == 0)
+        unsigned hb[4], lb[4];
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = acc[i][j][4 * q + e] * unscale;
+          if constexpr (!BWD) {
+            t += b;
+            if (leaky) t = slope01 ? fmaxf(t, t * slope) : (t > 0.f ? t : t * slope);
+          } else {
+            const unsigned w = (e >> 1) ? gate[i][q].y : gate[i][q].x;
+            const unsigned hbits = (e & 1) ? (w >> 16) : (w & 0xFFFFu);
+            const bool pos = (hbits & 0x8000u) == 0u && (hbits & 0x7FFFu) != 0u;
+            t = pos ? t : t * slope;
+          }
+          t = ok ? t : 0.f;
+          v[e] = t;
+          amax = fmaxf(amax, fabsf(t));
+          if constexpr (HAS_T || HAS_N) split16_hi_lo(t * s_out, hb[e], lb[e]);
+        }
+        if constexpr (HAS_T || HAS_N) {
+          const u32x2 ph = (u32x2){hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+          const u32x2 pl = (u32x2){lb[0] | (lb[1] << 16), lb[2] | (lb[3] << 16)};
+          if constexpr (HAS_T) {
+            if (ok) {
+              char* dst = pT + i * 2048 + (q >> 1) * 128 + (q & 1) * 16;
+              *reinterpret_cast<u32x2*>(dst) = ph;
+              *reinterpret_cast<u32x2*>(dst + 1024) = pl;
+            }
+          }
+          if constexpr (HAS_N) {
+            const u32x2 th = quad_transpose16(ph.x, ph.y, sel, upper);      // (all lanes take part)
+            const u32x2 tl = quad_transpose16(pl.x, pl.y, sel, upper);
+            if (ok) {                                                       // (N % 4 == 0: the quad's four columns exist together)
+              char* dst = pN + (size_t)(2 * i + (q >> 1)) * n_step + (q & 1) * 512;
+              *reinterpret_cast<u32x2*>(dst) = th;
+              *reinterpret_cast<u32x2*>(dst + 1024) = tl;
+            }
+          }
+        }
+        if constexpr (HAS_F) {
+          if (ok) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pF[(int64_t)(i * 32 + 8 * q + e) * g.ldf] = v[e];
+          }
+        }
+      }
+    }
+  }
+  if (g.outS.slots) s16::s16_commit_block_max(g.outS, amax, red, blockIdx.x, gridDim.x);
+}
+
 // One work item: output tile (bx, by) of problem g over the row groups of contraction split bz.
 // Eight waves, wave tile 64 x 64 = 2 x 2 accumulator blocks of 32 x 32 (64 registers); per 16-row step a wave reads
 // 2 + 2 unit fragments x 3 planes (24 transposing reads of 512 B) and issues 24 MFMAs (768 matrix cycles).
 // Pipeline: four 36 KB stages; the pieces of step t + 3 are requested during the first half of step t, the fragments of
 // step t + 1 are read during its second half (two register sets, ping-pong), one barrier per step (in the middle).
-template <bool A_WIDE, bool FUSED, int AR>
+template <bool A_WIDE, int FUSED, int AR>
 __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, const int bz) {
   constexpr int NP = WArith<AR>::NP, NPROD = WArith<AR>::NPROD, PIECES = pieces_of<AR>(), STAGE_BYTES = stage_bytes_of<AR>();
   constexpr int NJ = (PIECES + 7) / 8;                       // DMA pieces per wave and step (the last one only for the first PIECES - 8 (NJ - 1) waves)
@@ -487,7 +593,9 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
   // slab epilogue (same layout as the fp32 kernel: accumulator row = (r & 3) + 8 (r >> 2) + 4 h, column = lane & 31)
   const int m0 = by * BM, n0 = bx * BN;
   if constexpr (FUSED) {
-    if constexpr (AR == 0) fused_epilogue<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane); else fused_epilogue16<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    if constexpr (AR == 0) fused_epilogue<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    else if constexpr (FUSED >= 16) fused_epilogue16_fast<2, FUSED>(g, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    else fused_epilogue16<2>(g, acc, m0 + wm * 64, n0 + wn * 64, lane);
     return;
   }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
@@ -526,7 +634,7 @@ __device__ __forceinline__ void body(const Prob& g, const int bx, const int by, 
 // read in H0(t), free behind barrier(t), refilled by the requests of H1(t) with tile t + 3, first needed at barrier(t + 2).
 constexpr int STG2 = 3;
 static_assert((size_t)STG2 * 3 * (UW + UW) * 1024 <= kLdsBytes && (size_t)STG2 * 2 * (UW + UW) * 1024 <= lds_bytes_of<1>(), "the big-tile stages must fit the launch's LDS");
-template <bool FUSED, int AR>
+template <int FUSED, int AR>
 __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int by, const int bz) {
   constexpr int NP = WArith<AR>::NP, NPROD = WArith<AR>::NPROD, PIECES2 = NP * (UW + UW), STAGE2_BYTES = PIECES2 * 1024;
   constexpr int NJ2 = PIECES2 / 8;                            // DMA pieces per wave and step (6 / 4)
@@ -643,7 +751,9 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
 
   const int m0 = by * 256, n0 = bx * 256;
   if constexpr (FUSED) {
-    if constexpr (AR == 0) fused_epilogue<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane); else fused_epilogue16<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    if constexpr (AR == 0) fused_epilogue<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    else if constexpr (FUSED >= 16) fused_epilogue16_fast<4, FUSED>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
+    else fused_epilogue16<4>(g, acc, m0 + wm * 128, n0 + wn * 64, lane);
     return;
   }
   float* Cbase = g.C + (int64_t)bz * g.M * g.ldc;
@@ -698,7 +808,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_split_k(GroupArgs G) {
 // costs more than the big tile's 2/3 bytes per flop save (572 us against 511 us for 768 tiles of 128 x 256).  So ONE full round of big
 // tiles over the first rows_big rows (the first 256 workgroups, one per CU) and the remaining rows as 128 x 256 tiles, picked up as
 // the CUs come free: 286 + 170 us of work per CU instead of 3 x 170.
-template <int AR>
+template <int AR, int EPI = 1>
 __global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
   const Prob& g = G.p[0];
   if (g.a_wide == 3) {
@@ -706,17 +816,17 @@ __global__ __launch_bounds__(THREADS) void gemm_split_k(GroupArgs G) {
     if (b < g.n_big) {
       const int id = xcd_contiguous(b, g.n_big);
       const int by = id / g.gx, bx = id - by * g.gx;
-      body_big<true, AR>(g, bx, by, 0);
+      body_big<EPI, AR>(g, bx, by, 0);
     } else {
       const int id = xcd_contiguous(b - g.n_big, G.total - g.n_big);
       const int by = id / g.gx, bx = id - by * g.gx;
-      body<false, true, AR>(g, bx, g.rows_big / 128 + by, 0);
+      body<false, EPI, AR>(g, bx, g.rows_big / 128 + by, 0);
     }
     return;
   }
   const int id = xcd_contiguous(blockIdx.x, G.total);
   const int by = id / g.gx, bx = id - by * g.gx;
-  if (g.a_wide == 2) body_big<true, AR>(g, bx, by, 0); else if (g.a_wide) body<true, true, AR>(g, bx, by, 0); else body<false, true, AR>(g, bx, by, 0);
+  if (g.a_wide == 2) body_big<EPI, AR>(g, bx, by, 0); else if (g.a_wide) body<true, EPI, AR>(g, bx, by, 0); else body<false, EPI, AR>(g, bx, by, 0);
 }
 
 #ifdef CLICA_WSPLIT_TRACE
@@ -1166,6 +1276,8 @@ extern "C" int clica_mlp_planes_from_f32_t(const float* X, int64_t ldx, int64_t 
   return launch_status("clica_mlp_planes_from_f32_t");
 }
 
+static bool g_epi_specialised = true;       // test / A-B hook: clica_set_tuning("gemm16_epilogue", 0) keeps the generic epilogue
+namespace clica { namespace wsplit { void set_epi_specialised(int on) { g_epi_specialised = on != 0; } } }
 static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, const char* who, bool f16 = false) {
   // 128 x 256 tiles when the output is wide enough, else 256 x 128; with whole rounds of 256 x 256 tiles in front where they fit
   // (mixed tiling, see gemm_split_k)
@@ -1191,6 +1303,27 @@ static int launch_gemm_split(Prob& g, int64_t M, int32_t cols, hipStream_t st, c
   GroupArgs G{};
   G.n = 1; G.p[0] = g; G.first[0] = 0; G.first[1] = G.total = total;
   if (f16) {
+    // the epilogue specialised per direction and output combination where the shape allows it (whole row / lane quads), else the generic one
+    const bool quads = (g.M % 4 == 0) && (g.N % 4 == 0) && g_epi_specialised;
+    const int code = quads ? epi_code(g.epi == 2, g.outT != nullptr, g.outN != nullptr, g.outF != nullptr) : 1;
+#define CLICA_GEMM16_CASE(CODE)                                                                                                          \
+    case CODE: {                                                                                                                         \
+      static bool once_ = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k<1, CODE>),                               \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_of<1>()), true);        \
+      (void)once_;                                                                                                                       \
+      hipLaunchKernelGGL((gemm_split_k<1, CODE>), dim3((unsigned)G.total), dim3(THREADS), lds_bytes_of<1>(), st, G);                     \
+      return launch_status(who);                                                                                                         \
+    }
+    switch (code) {
+      CLICA_GEMM16_CASE(epi_code(false, true, true, false))       // forward inside the wide chain: both plane formats
+      CLICA_GEMM16_CASE(epi_code(false, false, true, true))       // forward, last chain layer: N-planes for the next weight gradient + fp32
+      CLICA_GEMM16_CASE(epi_code(false, false, false, true))      // forward, fp32 only
+      CLICA_GEMM16_CASE(epi_code(true, true, true, false))        // data gradient inside the chain
+      CLICA_GEMM16_CASE(epi_code(true, false, true, true))        // data gradient leaving the chain
+      CLICA_GEMM16_CASE(epi_code(true, false, false, true))
+      default: break;
+    }
+#undef CLICA_GEMM16_CASE
     static bool once16 = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split_k<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes_of<1>()), true);
     (void)once16;
     hipLaunchKernelGGL(gemm_split_k<1>, dim3((unsigned)G.total), dim3(THREADS), lds_bytes_of<1>(), st, G);

@@ -40,7 +40,8 @@ const char* clica_last_error(void);
 /* Test / tuning hook, process-wide (not part of the stable surface): the per-layer Linear entry points and SimCLRLoss choose their body
  * by SHAPE; a test that wants the other product path on a given shape sets it here.  Keys: "skinny" (0: every Linear shape through the MFMA
  * template instead of the vector-ALU kernels for tiny K / N), "gemm_cfg_fwd" / "gemm_cfg_dgrad" / "gemm_cfg_wgrad" (tile configuration id,
- * -1: by shape), "dot_mfma" (0: SimCLRLoss pair sweep at every width), "reset" (all defaults).  Unknown key: CLICA_E_INVALID.  The library
+ * -1: by shape), "dot_mfma" (0: SimCLRLoss pair sweep at every width), "gemm16_epilogue" (0: clica_linear_split_fwd16 / _dgrad16 keep the
+ * generic fused epilogue instead of the one specialised per output combination), "reset" (all defaults).  Unknown key: CLICA_E_INVALID.  The library
  * reads NO tuning switch from the environment (the environment variables it does read are listed in INTEGRATION.md). */
 int clica_set_tuning(const char* key, int32_t value);
 /* After a FAILED stream capture on `stream` (e.g. a collective that cannot be captured): end the capture if the stream is

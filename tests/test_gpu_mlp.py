@@ -871,3 +871,72 @@ def test_linear_split_wide_fwd_dgrad_match_fp64(M, N, K):
     ops.linear_split_dgrad(dzT, wN, None, slope, M, N, K, dx=dx2)
     ref2 = dz.double().cpu().numpy() @ w.double().cpu().numpy()
     assert np.abs(dx2.double().cpu().numpy() - ref2).max() / np.abs(ref2).max() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 400, 2000), (1000, 2000, 400), (8192 + 332, 1996, 48), (512, 132, 260)])
+def test_linear_split16_specialised_epilogues_are_the_generic_one(M, N, K):
+    """the f16x2 forward / data-gradient GEMM of a wide layer (clica_linear_split_fwd16 / _dgrad16, BASELINE config 3)
+    has its epilogue specialised per direction and output combination (gemm_split_k<1, code>: no spills, a third of the instructions).
+    Every combination the engine uses, against the generic epilogue (`clica_set_tuning("gemm16_epilogue", 0)`): plane buffers and fp32
+    copies bit for bit, recorded maxima too; and the fp32 copies against fp64 at 2e-6.  Shapes: interior tiles only, ragged last column
+    tile, mixed 256 x 256 + 128 x 256 tiling with a ragged last row tile, narrow output."""
+    from cl_ica_amd import ops, _lib
+    rng = np.random.default_rng(M + N + K)
+    slope = 0.01
+    dev_ = "cuda"
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev_)
+    w = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(dev_)
+    b = torch.from_numpy(rng.standard_normal(N).astype(np.float32) * 0.1).to(dev_)
+    act = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(dev_)
+    act[0, :5] = 0.0
+    dz = torch.from_numpy((rng.standard_normal((M, N)) * 1e-4).astype(np.float32)).to(dev_)
+    st = ops.Split16(3, x.device)
+
+    def operands():
+        return dict(xT=ops.mlp_planes_from_f32_t(x, state=st, tensor=(0, 1)), wT=ops.mlp_planes_from_f32_t(w, state=st, tensor=(2, 1)),
+                    wN=ops.mlp_planes_from_f32(w, False, state=st, tensor=(2, 1)), dzT=ops.mlp_planes_from_f32_t(dz, state=st, tensor=(1, 1)),
+                    actT=ops.mlp_planes_from_f32_t(act, state=st, tensor=(0, 1)))
+
+    def run(o, combo):
+        T, Nn, F = combo
+        out = {}
+        yT = ops.mlp_planes_alloc(N, M, False, x.device, f16=True) if T else None
+        yN = ops.mlp_planes_from_f32(torch.zeros(M, N, device=x.device), True, state=st, tensor=(0, 2)) if Nn else None
+        y = torch.full((M, N + 3), 7.0, device=x.device) if F else None
+        ops.linear_split_fwd(o["xT"], o["wT"], b, M, N, K, True, slope, yT=yT, yN=yN, yN_ones=True, y=None if y is None else y[:, :N], state=st, layer=1)
+        dxT = ops.mlp_planes_alloc(K, M, False, x.device, f16=True) if T else None
+        dxN = ops.mlp_planes_alloc(M, K, False, x.device, f16=True) if Nn else None
+        dx = torch.full((M, K + 1), 7.0, device=x.device) if F else None
+        ops.linear_split_dgrad(o["dzT"], o["wN"], o["actT"], slope, M, N, K, dxT=dxT, dxN=dxN, dx=None if dx is None else dx[:, :K], state=st, layer=1)
+        torch.cuda.synchronize()
+        return dict(yT=yT, yN=yN, y=y, dxT=dxT, dxN=dxN, dx=dx)
+
+    combos = [(True, True, False), (False, True, True), (False, False, True)]
+    try:
+        o = operands(); run(o, (True, True, True)); st.update()            # first pass on scales of 1: measures every tensor
+        o = operands(); run(o, (True, True, True)); st.update()            # the chain gradient's output settles one update later
+        res = {}
+        for mode in (0, 1):
+            _lib.check(_lib.load().clica_set_tuning(b"gemm16_epilogue", mode), "clica_set_tuning")
+            o = operands()
+            res[mode] = [run(o, c) for c in combos]
+            st.update()
+            res[mode].append(st.read())                                     # the maxima the epilogues recorded, as the scales they lead to
+        sc = res[1][3]
+    finally:
+        _lib.check(_lib.load().clica_set_tuning(b"gemm16_epilogue", 1), "clica_set_tuning")
+    assert sc["flags"] == 0, sc
+    assert res[0][3]["scales_a"] == res[1][3]["scales_a"] and res[0][3]["scales_d"] == res[1][3]["scales_d"]
+    for c, a, g in zip(combos, res[1][:3], res[0][:3]):
+        for k in a:
+            assert (a[k] is None) == (g[k] is None), (c, k)
+            if a[k] is not None:
+                assert torch.equal(a[k], g[k]), f"specialised epilogue differs from the generic one: combo {c}, output {k}"
+    pre = x.double().cpu().numpy() @ w.double().cpu().numpy().T + b.double().cpu().numpy()
+    ref = np.where(pre > 0, pre, slope * pre)
+    gate = np.where(act.cpu().numpy() > 0, 1.0, slope)
+    refd = (dz.double().cpu().numpy() @ w.double().cpu().numpy()) * gate
+    for r in res[1][1:3]:
+        assert np.abs(r["y"][:, :N].double().cpu().numpy() - ref).max() / np.abs(ref).max() < 2e-6
+        assert (r["y"][:, N:] == 7.0).all() and (r["dx"][:, K:] == 7.0).all()
+        assert np.abs(r["dx"][:, :K].double().cpu().numpy() - refd).max() / np.abs(refd).max() < 2e-6
