@@ -117,11 +117,13 @@ __device__ unsigned long long* g_wstrace = nullptr;
 #define WS_DECL unsigned long long ws_ts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define WS_STAMP(ph) do { ws_ts[ph] = __builtin_readcyclecounter(); } while (0)
 #define WS_STEP_STAMP(t, ph) do { if ((t) == 30) WS_STAMP(ph); } while (0)
+#define WS_NOTE(q, v) do { ws_ts[q] = (unsigned long long)(v); } while (0)
 #define WS_FLUSH do { if (g_wstrace && (threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 16; ++q_) g_wstrace[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + q_] = ws_ts[q_]; } } while (0)
 #else
 #define WS_DECL do { } while (0)
 #define WS_STAMP(ph) do { } while (0)
 #define WS_STEP_STAMP(t, ph) do { } while (0)
+#define WS_NOTE(q, v) do { } while (0)
 #define WS_FLUSH do { } while (0)
 #endif
 
@@ -646,6 +648,8 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
   const int wm = wave >> 2, wn = wave & 3, h = lane >> 5, l31 = lane & 31;
   const int g0 = bz * g.gps;
   const int nt = min(g.groups, g0 + g.gps) - g0;
+  WS_DECL;
+  WS_STAMP(0);
   f32x16 acc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -695,6 +699,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
     if (k <= 0) wait_vm<0>(); else if (k == 1) wait_vm<NJ2>(); else wait_vm<2 * NJ2>();
   };
   auto step = [&](const frag_t (&fb)[NP][2], frag_t (&nb)[NP][2], int t) {
+    WS_STEP_STAMP(t, 4);
     load_a(a1, t, 1);
 #pragma unroll
     for (int m = 0; m < NMH; ++m) mfma1(a0, fb, 0, m);
@@ -705,10 +710,13 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
     }
     __builtin_amdgcn_sched_barrier(0);
     const bool next = t + 1 < nt;
+    WS_STEP_STAMP(t, 5);
     if (next) {
       wait_tiles(min(t + 2, nt - 1) - (t + 1));
+      WS_STEP_STAMP(t, 6);
       __syncthreads();
     }
+    WS_STEP_STAMP(t, 7);
     const bool more = t + 3 < nt;
     constexpr int NG = 2 * NP, MPG = NMH / NG;                 // groups of the half: one piece's two fragments (four reads) and MPG MFMAs each (4 / 3)
     static_assert(NG >= NJ2 && NMH % NG == 0, "one DMA request per group");
@@ -734,6 +742,8 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
       if (more && q < NJ2) issue_one(t + 3, q);
       __builtin_amdgcn_sched_barrier(0);
     }
+    WS_STEP_STAMP(t, 8);
+    WS_STEP_STAMP(t - 1, 10);
   };
   // note: a0 of step t + 1 is loaded in H1(t) while H1(t) computes on a1 -- a0 (tile t) is dead behind H0(t)
 #pragma unroll
@@ -744,10 +754,12 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
     }
   wait_tiles(nt > 2 ? 2 : nt - 1);
   __syncthreads();
+  WS_STAMP(1);
   if (nt > 0) { load_a(a0, 0, 0); load_b(b0, 0); }
   int t = 0;
   for (; t + 1 < nt; t += 2) { step(b0, b1, t); step(b1, b0, t + 1); }
   if (t < nt) step(b0, b1, t);
+  WS_STAMP(2);
 
   const int m0 = by * 256, n0 = bx * 256;
   if constexpr (FUSED) {
@@ -776,6 +788,9 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
       }
     }
   }
+  WS_STAMP(3);
+  WS_NOTE(11, 1000 + nt);
+  WS_FLUSH;
 }
 
 __device__ __forceinline__ int xcd_contiguous(int b, int nwg) {     // each XCD walks a contiguous range of the work items

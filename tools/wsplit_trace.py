@@ -29,12 +29,19 @@ t = buf.cpu().numpy().reshape(NWG, 8, 16).astype(np.float64)
 t = t[t[:, 0, 0] > 0]
 print("work items:", len(t))
 t0 = t[:, :, 0].min()
-pro, loop, epi = t[:, :, 1] - t[:, :, 0], t[:, :, 2] - t[:, :, 1], t[:, :, 3] - t[:, :, 2]
-print(f"median cycles per wave: prologue {np.median(pro):.0f}  step loop {np.median(loop):.0f}  epilogue {np.median(epi):.0f}   "
-      f"(86 steps x 768 MFMA cycles per wave = 66048; two waves share a SIMD: 132096 per pair)")
-print(f"start spread: {np.percentile(t[:, :, 0].min(1) - t0, [0, 50, 100]).round().tolist()}   kernel span {t[:, :, 3].max() - t0:.0f} cycles")
-print("step loop by wave id (median):", np.round(np.median(loop, 0)).astype(int).tolist())
-names = {5: "12 MFMAs + DMA requests issued", 6: "vmcnt wait done", 7: "barrier passed", 8: "12 MFMAs + 24 reads issued", 10: "next step starts"}
-print("step 30, cycles since its start (median by wave id):")
-for k, nm in names.items():
-    print(f"  {nm:32s}", np.round(np.median(t[:, :, k] - t[:, :, 4], 0)).astype(int).tolist())
+print(f"kernel span (first entry -> last exit) {t[:, :, 3].max() - t0:.0f} cycles; start spread {np.percentile(t[:, :, 0].min(1) - t0, [0, 50, 100]).round().tolist()}")
+names = {5: "first half's MFMAs + reads issued", 6: "vmcnt wait done", 7: "barrier passed", 8: "second half + DMA requests issued", 10: "next step starts"}
+for label, sel in (("256 x 256 items", t[:, 0, 11] >= 1000), ("256 x 128 / 128 x 256 items", t[:, 0, 11] < 1000)):
+    u = t[sel]
+    if not len(u):
+        continue
+    nt = int(np.median(u[:, 0, 11] % 1000)) if label.startswith("256 x 256") else -1
+    pro, loop, epi = u[:, :, 1] - u[:, :, 0], u[:, :, 2] - u[:, :, 1], u[:, :, 3] - u[:, :, 2]
+    print(f"== {label}: {len(u)}  (steps per item {nt if nt >= 0 else 'n/a'})")
+    print(f"  median cycles per wave: prologue {np.median(pro):.0f}  step loop {np.median(loop):.0f}  epilogue {np.median(epi):.0f};  item exit - kernel start: {np.percentile(u[:, :, 3].max(1) - t0, [0, 50, 100]).round().tolist()}")
+    if nt > 0:
+        print(f"  loop cycles per step {np.median(loop) / nt:.0f}  (MFMA work per SIMD and step: 2 waves x 24 x 32 = 1536 in f16x2, 3072 in bf16x3)")
+    print("  step loop by wave id (median):", np.round(np.median(loop, 0)).astype(int).tolist())
+    print("  step 30, cycles since its start (median by wave id):")
+    for k, nm in names.items():
+        print(f"    {nm:34s}", np.round(np.median(u[:, :, k] - u[:, :, 4], 0)).astype(int).tolist())
