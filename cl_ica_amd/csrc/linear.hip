@@ -1549,7 +1549,7 @@ extern "C" int clica_linear_plan(int32_t op, int64_t M, int64_t N, int64_t K, in
   return CLICA_OK;
 }
 
-namespace clica { namespace lp { void set_dot_mfma(int on); } }      // lp_loss.hip: SimCLRLoss contraction path
+namespace clica { namespace lp { void set_dot_mfma(int on); void set_fused_finalize(int on); } }      // lp_loss.hip: SimCLRLoss contraction path; training forward in one launch
 namespace clica { namespace wsplit { void set_epi_specialised(int on); } }      // wgrad_split.hip: gemm_split_k<1, code> vs the generic epilogue
 extern "C" int clica_set_tuning(const char* key, int32_t value) {
   CLICA_CHECK_ARG(key != nullptr, "clica_set_tuning: key is NULL");
@@ -1560,7 +1560,8 @@ extern "C" int clica_set_tuning(const char* key, int32_t value) {
   else if (!strcmp(key, "gemm_cfg_wgrad")) t.cfg_wgrad = value;
   else if (!strcmp(key, "dot_mfma")) clica::lp::set_dot_mfma(value);
   else if (!strcmp(key, "gemm16_epilogue")) clica::wsplit::set_epi_specialised(value);
-  else if (!strcmp(key, "reset")) { t = gemm::Tuning{-1, -1, -1, true}; clica::lp::set_dot_mfma(1); clica::wsplit::set_epi_specialised(1); }
+  else if (!strcmp(key, "lp_fused_finalize")) clica::lp::set_fused_finalize(value);
+  else if (!strcmp(key, "reset")) { t = gemm::Tuning{-1, -1, -1, true}; clica::lp::set_dot_mfma(1); clica::wsplit::set_epi_specialised(1); clica::lp::set_fused_finalize(1); }
   else { set_error("clica_set_tuning: unknown key '%s'", key); return CLICA_E_INVALID; }
   return CLICA_OK;
 }

@@ -1,52 +1,12 @@
 // C ABI of the Lp InfoNCE loss (include/clica.h) -- planning, workspace carve-up, launches.
 // Kernels: lp_kernels.h; per-exponent instantiations: lp_loss_pk.hip.
 #include "lp_kernels.h"
+#include "lp_finalize.h"
 #include "lp_mfma.h"
 #include "lp_mfma_dev.h"
 
 namespace clica {
 namespace lp {
-
-// ---- positive pair ---------------------------------------------------------------------------
-// returns sum of powers; frac (p<1) branch: (|z1-z2| + 1e-12)^p  (losses.py:439-441)
-__device__ __forceinline__ float pos_sum(const float* a, const float* b, int n, const Params& q, bool frac) {
-  float s = 0.f;
-  for (int k = 0; k < n; ++k) {
-    float d = a[k] - b[k];
-    float t;
-    if (frac) t = fexp2(q.p * flog2(fabsf(d) + 1e-12f));
-    else if (q.p == 2.f) t = d * d;
-    else if (q.p == 1.f) t = fabsf(d);
-    else if (q.p == 3.f) t = fabsf(d) * d * d;
-    else t = fabsf(d) > 0.f ? fexp2(q.p * flog2(fabsf(d))) : 0.f;
-    s += t;
-  }
-  return s;
-}
-
-struct Means {
-  float* blocksums;      // [gridDim.x][3] per-block partial sums
-};
-
-// block tree -> one slot per block; `means_k` (next launch on the stream) sums the slots in index
-// order, so the three means are deterministic and need no atomics or fences.
-__device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const Means& M) {
-  __shared__ float red[3][THREADS / 64];
-  float v[3] = {v0, v1, v2};
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) { red[0][wave] = v[0]; red[1][wave] = v[1]; red[2][wave] = v[2]; }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    float t = 0.f;
-    for (int w = 0; w < THREADS / 64; ++w) t += red[threadIdx.x][w];
-    M.blocksums[blockIdx.x * 3 + threadIdx.x] = t;
-  }
-}
 
 __global__ __launch_bounds__(64) void means_k(const float* __restrict__ blocksums, int nblocks, float inv_count,
                                               float* __restrict__ means) {
@@ -63,65 +23,6 @@ __global__ __launch_bounds__(64) void means_k(const float* __restrict__ blocksum
   if (threadIdx.x == 0) { means[0] = v[0] * inv_count; means[1] = v[1] * inv_count; means[2] = v[2] * inv_count; }
 }
 
-// one row of the coefficient step (shared by bwd_coef_k and the training forward's finalize)
-__device__ __forceinline__ void coef_row(
-    const int64_t i, const int64_t rows, const float* a /* row i of z1 */, const float* b /* row i of z2 */,
-    const Params& q, float tau, float alpha, int compat, int frac, int dot, const float L2,
-    const float* __restrict__ g_mean, const float* __restrict__ g_item,
-    const float* __restrict__ g_pos, const float* __restrict__ g_neg,
-    float* __restrict__ statL, float* __restrict__ statC,
-    float* __restrict__ dz1, int64_t ldd1, float* __restrict__ dz2, int64_t ldd2, float* statC_value = nullptr) {
-  const float inv_rows = 1.f / (float)rows;
-  const float gi = (g_mean ? g_mean[0] : 1.f) * inv_rows + (g_item ? g_item[i] : 0.f);
-  const float A = 2.f * alpha * gi + (g_pos ? g_pos[0] * inv_rows : 0.f);
-  const float C = 2.f * (1.f - alpha) * gi + (g_neg ? g_neg[0] * inv_rows : 0.f);
-  statL[i] = L2;      // row statistic stays in the log2 domain end to end: no ln <-> log2 round trip of a number that is
-                      // ~10^3 in saturated rows (each rounding of it is a 1e-4 relative error on every weight of the row)
-  const float sc = q.xs * C / tau;
-  statC[i] = sc;
-  if (statC_value) *statC_value = sc;       // (the caller's copy: reading statC[i] back is a load behind this thread's own stores -- a vmcnt(0))
-  if (!dz1 && !dz2) return;
-  if (dot) {
-    float pos = 0.f;
-    if (q.posdot) pos = q.posdot[i];
-    else for (int k = 0; k < q.n; ++k) pos += a[k] * b[k];
-    const float dpos = -A / tau + (C / tau) * fexp2(pos * q.kscale - L2);
-    if (q.dpos) { q.dpos[i] = dpos; return; }       // wide rows: dpos_apply_k writes dz1 = dpos z2, dz2 = dpos z1
-    for (int k = 0; k < q.n; ++k) {
-      if (dz1) dz1[i * ldd1 + k] = dpos * b[k];
-      if (dz2) dz2[i * ldd2 + k] = dpos * a[k];
-    }
-    return;
-  }
-  const float sp_ = pos_sum(a, b, q.n, q, frac != 0);
-  const float pos = q.pow ? sp_ : root_of<true>(sp_, q);
-  float cpos = A / tau;
-  if (compat) cpos -= (C / tau) * fexp2(-pos * q.kscale - L2);
-  cpos *= q.pow ? q.p : droot_of<true>(sp_, q);  // includes the factor p
-  for (int k = 0; k < q.n; ++k) {
-    const float d = a[k] - b[k];
-    float dt;
-    if (frac) {
-      const float v = fexp2((q.p - 1.f) * flog2(fabsf(d) + 1e-12f));
-      dt = d > 0.f ? v : (d < 0.f ? -v : 0.f);
-    } else if (q.p == 2.f) dt = d;
-    else if (q.p == 1.f) dt = (d > 0.f ? 1.f : 0.f) - (d < 0.f ? 1.f : 0.f);
-    else if (q.p == 3.f) dt = d * fabsf(d);
-    else {
-      const float ad = fabsf(d);
-      const float v = ad > 0.f ? fexp2((q.p - 1.f) * flog2(ad)) : 0.f;
-      dt = d < 0.f ? -v : v;
-    }
-    const float g = cpos * dt;
-    if (dz1) dz1[i * ldd1 + k] = g;
-    if (dz2) dz2[i * ldd2 + k] = -g;
-  }
-}
-
-constexpr int FIN_ROWS = 64;   // rows per finalize block; the 4 waves split the per-split partials
-// training forward: the finalize thread of a row also does that row's coefficient step (statistics for the pair
-// sweep + the positive-pair gradient, upstream gradient = d(mean loss) = 1), saving the bwd_coef_k launch
-struct TrainOut { float* statL; float* statC; float* dz1; int64_t ldd1; float* dz2; int64_t ldd2; };
 // one rank, p = 2 on the matrix cores (lp_mfma.hip): the finalize block of 64 rows = two pool tiles also writes their feature planes
 // (they carry u_j = C_j 2^-L_j, which this kernel has just computed) -- the separate plane launch of the backward call disappears
 struct FeatOut { lp2::u32x4_t* FP = nullptr; const float* origin = nullptr; float pre2 = 0.f; int64_t pool_tiles = 0; };
@@ -140,87 +41,11 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
   }
   __shared__ float sm[THREADS / FIN_ROWS][FIN_ROWS], ss[THREADS / FIN_ROWS][FIN_ROWS];
   __shared__ float ush[FIN_ROWS];
-  // the block's z1 / z2 rows, staged by all 256 threads (coalesced) while the partials are in flight: the finishing
-  // threads then read their row's coordinates from LDS instead of starting two more dependent global round trips
   constexpr int FIN_MAXN = 64;
   __shared__ float zrows[2][FIN_ROWS * FIN_MAXN];
-  const int lane_row = threadIdx.x & (FIN_ROWS - 1), grp = threadIdx.x / FIN_ROWS;
-  const int64_t i = (int64_t)blockIdx.x * FIN_ROWS + lane_row;
-  const bool staged = q.n <= FIN_MAXN;
-  if (staged) {
-    const int64_t r0 = (int64_t)blockIdx.x * FIN_ROWS;
-    const int cnt = (int)min((int64_t)FIN_ROWS, rows - r0) * q.n;
-    for (int idx = threadIdx.x; idx < cnt; idx += THREADS) {
-      const int r = idx / q.n, k = idx - r * q.n;
-      zrows[0][idx] = z1[(r0 + r) * ld1 + k];
-      zrows[1][idx] = z2[(r0 + r) * ld2 + k];
-    }
-  }
-  float m = -1e30f, s = 0.f;
-  if (i < rows) {
-    // four partials in flight per round (a one-at-a-time loop is a chain of dependent L2 round trips);
-    // missing ones are (m = -1e30, s = 0): they leave the running pair unchanged
-    constexpr int G = THREADS / FIN_ROWS;
-    for (int sp0 = grp; sp0 < nsplit; sp0 += 4 * G) {
-      float2 ps[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int sp = sp0 + u * G;
-        ps[u] = sp < nsplit ? part[(int64_t)sp * rows + i] : make_float2(-1e30f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float mn = fmaxf(m, ps[u].x);
-        s = s * fexp2(m - mn) + ps[u].y * fexp2(ps[u].x - mn);
-        m = mn;
-      }
-    }
-  }
-  sm[grp][lane_row] = m; ss[grp][lane_row] = s;
-  __syncthreads();
-  float v_loss = 0.f, v_pos = 0.f, v_lse = 0.f;
-  if (grp == 0 && i < rows) {
-#pragma unroll
-    for (int w = 1; w < THREADS / FIN_ROWS; ++w) {
-      const float pm = sm[w][lane_row], psum = ss[w][lane_row];
-      const float mn = fmaxf(m, pm);
-      s = s * fexp2(m - mn) + psum * fexp2(pm - mn);
-      m = mn;
-    }
-    float pos, xp;
-    const float* ra = staged ? &zrows[0][lane_row * q.n] : z1 + i * ld1;
-    const float* rb = staged ? &zrows[1][lane_row * q.n] : z2 + i * ld2;
-    if (dot) {   // SimCLRLoss: pos = <z1, z2> and the logit is +pos/tau (losses.py:188-193)
-      pos = 0.f;
-      if (q.posdot) pos = q.posdot[i];
-      else for (int k = 0; k < q.n; ++k) pos += ra[k] * rb[k];
-      xp = pos * q.kscale;
-      pos = -pos;  // loss_pos = -pos/tau (losses.py:192)
-    } else {
-      const float sp_ = pos_sum(ra, rb, q.n, q, frac != 0);
-      pos = q.pow ? sp_ : root_of<true>(sp_, q);
-      xp = -pos * q.kscale;
-    }
-    if (compat) {  // positive pair joins the softmax denominator (losses.py:459-462)
-      const float mn = fmaxf(m, xp);
-      s = s * fexp2(m - mn) + fexp2(xp - mn);
-      m = mn;
-    }
-    const float L2 = m + flog2(s);                // log2-domain log-sum-exp of the scaled logits: THE saved row statistic
-    const float lse_raw = L2 * kLn2;
-    const float lse = compat ? lse_raw : lse_raw - log_b3;   // _logmeanexp, losses.py:506-510
-    const float lp = pos / tau;
-    const float li = 2.f * (alpha * lp + (1.f - alpha) * lse);
-    loss_i[i] = li; pos_i[i] = lp; lse_i[i] = L2;
-    float sc_i = 0.f;
-    if (T.statL)
-      coef_row(i, rows, ra, rb, q, tau, alpha, compat, frac, dot, L2, nullptr, nullptr, nullptr, nullptr, T.statL, T.statC,
-               T.dz1, T.ldd1, T.dz2, T.ldd2, &sc_i);
-    v_loss = li; v_pos = lp; v_lse = lse;
-    if (F.FP) ush[lane_row] = sc_i * fexp2(-L2);            // u_i = C_i 2^-L_i (the value coef_row has just stored in statC[i])
-  } else if (F.FP && grp == 0) {
-    ush[lane_row] = 0.f;
-  }
+  float v_loss, v_pos, v_lse;
+  finalize_rows((int)blockIdx.x, part, nsplit, rows, z1, ld1, z2, ld2, q, tau, alpha, compat, frac, dot, log_b3, loss_i, pos_i, lse_i, T,
+                FinScratch{&sm[0][0], &ss[0][0], zrows[0], zrows[1], FIN_MAXN, F.FP ? ush : nullptr}, v_loss, v_pos, v_lse);
   if (F.FP) {      // (uniform over the launch; `staged` holds: n <= 14)
     static_assert(THREADS == 2 * 128 && FIN_ROWS == 2 * lp2::ROWS, "a finalize block = two pool tiles of 128 feature vectors each");
     __syncthreads();
@@ -234,7 +59,7 @@ __global__ __launch_bounds__(THREADS) void fwd_finalize_k(
       for (int64_t v = (int64_t)gridDim.x * 2 * lp2::FEATVEC + id; v < F.pool_tiles * lp2::FEATVEC; v += THREADS) F.FP[v] = z4;
     }
   }
-  reduce_means(v_loss, v_pos, v_lse, M);
+  reduce_means(v_loss, v_pos, v_lse, M, (int)blockIdx.x);
 }
 
 // ---- backward ------------------------------------------------------------------------------
@@ -585,7 +410,7 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
 
 // ---- training-step pair of entry points: forward with the coefficient step folded into its finalize, symmetric backward
 // with the forward's means folded into its reduction (three launches fewer than fwd + bwd_sym) -------------------------
-struct TrainWs { float* blocksums; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes;
+struct TrainWs { float* blocksums; int* arrive; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes;
                  bool mfma; lp2::Plan P2; lp2::Ws w2; };
 // training-pair forms (bits; all on): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (Params::train),
 // 4 = p = 2 sweeps on the matrix cores where lp_mfma.hip's policy admits them (needs the semantics of bits 1 and 2: the pool contains the anchors)
@@ -593,9 +418,22 @@ static constexpr int train_flags() { return 7; }
 static bool train_mfma_shape(const clica_lp_loss_desc* d) { return (train_flags() & 7) == 7 && lp2::applies(d->n, d->p, d->pow); }
 // (its fallback is the fixed-maximum / folded-coefficient difference sweep)
 static bool train_mfma(const clica_lp_loss_desc* d) { return train_mfma_shape(d) && lp2::applies_to_pool(d->B, d->B3); }
+// clica_set_tuning("lp_fused_finalize", 0): the training forward as sweep + fwd_finalize_k (two launches; test / A-B hook -- same bits)
+static int& fused_finalize_switch() { static int on = 1; return on; }
+namespace clica { namespace lp { void set_fused_finalize(int on) { fused_finalize_switch() = on ? 1 : 0; } } }       // clica_set_tuning (linear.hip)
+static bool launch_fwd_partial_fin(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own, const float* str, int64_t lds,
+                                   int64_t n_str, const Params& q, float2* part, const FinArgs& F, hipStream_t st) {
+  switch (pk) {
+    case 1: return launch_fwd_partial_fin_pk1(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
+    case 2: return launch_fwd_partial_fin_pk2(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
+    case 3: return launch_fwd_partial_fin_pk3(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
+    default: return false;
+  }
+}
 static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols, bool mfma) {
   TrainWs w; char* p = (char*)ws; size_t off = 256;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
+  w.arrive = (int*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * sizeof(int), 256);    // fused finalize: arrival counters (zero between launches)
   w.statL = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
   w.statC = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
   w.strL = (float*)(p + off); off += align_up((size_t)cols * sizeof(float), 256);
@@ -707,6 +545,12 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
     nsplit_f = w.P2.nsplit;
     gate = Gate{w.w2.spread, limit, PF.nsplit};
   } else {
+    // one launch: the last workgroup of every owner tile finishes the tile's rows (lp_finalize.h); two where that form does not exist
+    if (fused_finalize_switch() &&
+        launch_fwd_partial_fin(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part,
+                               FinArgs{z2, ld2, d->tau, d->alpha, d->compat ? 1 : 0, logf((float)cols), loss_i, pos_i, lse_i, Means{w.blocksums},
+                                       TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, w.arrive}, st))
+      return launch_status("clica_lp_loss_fwd_train");
     launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
   }
   Means M{w.blocksums};

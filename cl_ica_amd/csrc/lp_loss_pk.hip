@@ -1,6 +1,7 @@
 // One exponent kind (CLICA_PK = 0 generic, 1, 2, 3; 4 = dot product) of the pairwise-Lp kernels; compiled four
 // times so the 8 padded dims x 3 kernels x 4 kinds instantiate in parallel.
 #include "lp_kernels.h"
+#include "lp_finalize.h"
 #include <stdlib.h>
 #ifndef CLICA_PK
 #error "compile with -DCLICA_PK=0|1|2|3|4"
@@ -67,6 +68,28 @@ void CAT(launch_fwd_partial_pk, CLICA_PK)(const Plan& P, const float* own, int64
       hipLaunchKernelGGL((fwd_partial_k<NP, PK, owners_fwd(NP), true, false, NQ>), grid, block, 0, st, own, ldo, n_own, str, lds,
                          n_str, q, part, part_g, P.chunk);
   })
+}
+
+// The training sweep with the finalize folded in (lp_finalize.h: fwd_partial_fin_k).  Returns false where that form does not exist (rows
+// beyond 16 padded coordinates, the generic exponent, the root form): the caller then launches sweep + fwd_finalize_k.
+bool CAT(launch_fwd_partial_fin_pk, CLICA_PK)(const Plan& P, const float* own, int64_t ldo, int64_t n_own,
+                                              const float* str, int64_t lds, int64_t n_str, const Params& q,
+                                              float2* part, const FinArgs& F, hipStream_t st) {
+  constexpr int PK = CLICA_PK;
+  if constexpr (PK >= 1 && PK <= 3) {
+    if (P.np > 16 || !q.pow || !(q.train & 1)) return false;
+    dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
+    bool done = false;
+    LP_FOR_NP(P.np, {
+      if constexpr (NP <= 16 && HALF * owners_fwd(NP) == FIN_ROWS) {
+        hipLaunchKernelGGL((fwd_partial_fin_k<NP, PK, owners_fwd(NP), false, NQ, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                           n_str, q, part, P.chunk, F);
+        done = true;
+      }
+    })
+    return done;
+  }
+  return false;
 }
 
 void CAT(launch_bwd_pairs_pk, CLICA_PK)(const Plan& P, bool owner_stats, const float* own, int64_t ldo,

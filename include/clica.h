@@ -41,7 +41,8 @@ const char* clica_last_error(void);
  * by SHAPE; a test that wants the other product path on a given shape sets it here.  Keys: "skinny" (0: every Linear shape through the MFMA
  * template instead of the vector-ALU kernels for tiny K / N), "gemm_cfg_fwd" / "gemm_cfg_dgrad" / "gemm_cfg_wgrad" (tile configuration id,
  * -1: by shape), "dot_mfma" (0: SimCLRLoss pair sweep at every width), "gemm16_epilogue" (0: clica_linear_split_fwd16 / _dgrad16 keep the
- * generic fused epilogue instead of the one specialised per output combination), "reset" (all defaults).  Unknown key: CLICA_E_INVALID.  The library
+ * generic fused epilogue instead of the one specialised per output combination), "lp_fused_finalize" (0: clica_lp_loss_fwd_train as sweep +
+ * finalize launch), "reset" (all defaults).  Unknown key: CLICA_E_INVALID.  The library
  * reads NO tuning switch from the environment (the environment variables it does read are listed in INTEGRATION.md). */
 int clica_set_tuning(const char* key, int32_t value);
 /* After a FAILED stream capture on `stream` (e.g. a collective that cannot be captured): end the capture if the stream is
@@ -158,6 +159,10 @@ int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
  * the spread the reference's own training reaches (M ~ 511) the matrix-core gradient measures 6.4e-6 of the 1e-5 budget where the
  * difference sweeps hold 2.1e-6, and the trade buys 13 us of a 350 us step.  CLICA_LP_MFMA / clica_lp_loss_set_matrix_cores: 0 never,
  * 1 the default policy, 2 every pool.
+ * ONE LAUNCH (round 6): on the difference sweeps, rows of <= 16 padded coordinates, p in {1, 2, 3}, fwd_train is a single launch -- the last
+ * workgroup to deliver a partial of a 64-row owner tile finishes that tile's rows (per-tile arrival counters in the workspace, handed over
+ * by agent-scope stores / loads, no fences).  The counters must be ZERO before the first call on a workspace (allocate it zero-filled) and
+ * every launch leaves them zero; results are those of the two-launch form bit for bit (clica_set_tuning("lp_fused_finalize", 0)).
  * clica_lp_loss_train_path reports which launches a call makes:
  * *path = 1 matrix cores with the guarded fallback behind them, 0 VALU sweeps only. */
 int clica_lp_loss_train_workspace_bytes(const clica_lp_loss_desc* d, size_t* bytes);

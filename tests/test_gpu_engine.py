@@ -517,6 +517,38 @@ def test_backward_chain_finishes_dy_itself_equals_the_reduction_launch(monkeypat
             assert a[4]["fallback_steps"] > 0, a[4]          # this case did run on the difference sweeps
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,p,B,space", [(10, 2, 1536, "box"), (10, 1, 1000, "box"), (4, 3, 1024, "box"), (14, 2, 6144, "box"), (10, 2, 1504, "sphere")])
+def test_forward_sweep_finishes_its_rows_itself_equals_the_finalize_launch(n, p, B, space, request):
+    """Single-rank training forward in ONE launch (lp_finalize.h: fwd_partial_fin_k -- the last workgroup of every owner tile merges the
+    tile's partials, forms loss_i / the row statistics / the positive-pair gradient and the block sums of the means) == sweep +
+    fwd_finalize_k (clica_set_tuning("lp_fused_finalize", 0)), bit for bit: the reported scalars of every step, the per-row outputs, dy,
+    every parameter after several steps; eager and in graph replay (the arrival counters must come back to zero by themselves), with a
+    ragged last owner tile (B % 64 != 0) and for the three specialised exponents."""
+    from cl_ica_amd import _lib, encoders
+    from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
+    lib = _lib.load()
+    request.addfinalizer(lambda: _lib.check(lib.clica_set_tuning(b"lp_fused_finalize", 1), "clica_set_tuning"))
+
+    def run(fused: bool, graph: bool):
+        _lib.check(lib.clica_set_tuning(b"lp_fused_finalize", 1 if fused else 0), "clica_set_tuning")
+        torch.manual_seed(11)
+        f = encoders.get_mlp(n, n, [n * 10, n * 50, n * 50, n * 10]).to("cuda")
+        gW = (torch.randn(3, n, n) / n ** 0.5).to("cuda")
+        tr = ContrastiveTrainer(f, gW, SamplerSpec(space=space, n=n, seed=5), batch_size=B, p=p, lr=1e-3, device="cuda")
+        if graph:
+            tr.capture(warmup=2)
+        outs = [tr.step().clone() for _ in range(5)]
+        torch.cuda.synchronize()
+        return torch.stack(outs), tr.loss_out.clone(), tr.dy.clone(), tr.param_arena.clone()
+
+    for graph in (False, True):
+        a, b = run(True, graph), run(False, graph)
+        for x, y, what in zip(a, b, ("scalars", "per-row outputs", "dy", "parameters")):
+            assert torch.isfinite(x).all(), what
+            assert torch.equal(x, y), (what, graph, float((x - y).abs().max()))
+
+
 def _guard_trainer(seed=7, n=10, B=1024, hidden=(100, 500, 500, 100), lr=1e-3):
     from cl_ica_amd import encoders
     from cl_ica_amd.engine import ContrastiveTrainer, SamplerSpec
