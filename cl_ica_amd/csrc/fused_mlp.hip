@@ -1205,6 +1205,11 @@ __device__ __forceinline__ void split_epilogue_fast(const f32x4 (&acc)[RB][CBW],
 // front of an n-wide one -> fp32, both directions), compiled without the other paths: in the generic form every accumulator block
 // carries the branches and the exec-mask code of the copies it does not write (phase trace: epilogue body 8.3 k cycles per 500-wide
 // layer against 3.0 k for the same arithmetic in isolation, tools/proto/epi_probe.hip).  ACT 1 in MODE 1 / 2 is a LeakyReLU layer.
+#ifndef CLICA_SPLIT_PLANE_AUX
+#define CLICA_SPLIT_PLANE_AUX 2      // cache policy of the f16x2 plane-copy stores: 2 = nt (streaming).  Round 6, four interleaved A/B runs on one box: launch 86.3 ->
+                                     // 83.2 us, and the weight-gradient phase that reads the planes 97.7 -> 94.6 us (step +2 %): written back (0), 30 MB of a launch's
+                                     // last layers sit dirty in the L2s until the end-of-kernel write-back.  (sc1 = 16: slower than 0; sc0 | nt = 3, nt | sc1 = 18: as nt or worse.)
+#endif
 template <int ACT, bool BITS, int MODE>
 __device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], unsigned short* planes, const float* bias_row, const float slope, const bool leaky_,
                                                  const unsigned long long mbits, const int N, const int ncb, const int wave, const int lane,
@@ -1275,8 +1280,8 @@ __device__ __forceinline__ void split16_epilogue(const f32x4 (&acc)[RB][CBW], un
         *reinterpret_cast<u32x2*>(dst + PLANE) = pl;
         if (has_pl) {                                  // wave-uniform
           const unsigned po = (unsigned)(r * pl_group_bytes) + pl_cb;
-          __builtin_amdgcn_raw_buffer_store_b64(ph, prsrc, po, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(pl, prsrc, po + 1024u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(ph, prsrc, po, 0, CLICA_SPLIT_PLANE_AUX);
+          __builtin_amdgcn_raw_buffer_store_b64(pl, prsrc, po + 1024u, 0, CLICA_SPLIT_PLANE_AUX);
         }
         if (has_out) {                                 // wave-uniform
           const f32x2 o0 = t[0] * inv2, o1 = t[1] * inv2;

@@ -3,7 +3,7 @@
 #   bash tools/r6_ab.sh <outdir> <tag> [<tag> ...]     tag "default" = the product library, otherwise cl_ica_amd/lib/libclica_hip_<tag>.so
 out=$1; shift
 mkdir -p $out
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
 for tag in "$@"; do
   if [ "$tag" = "default" ]; then unset CLICA_LIB; else export CLICA_LIB=$PWD/cl_ica_amd/lib/libclica_hip_$tag.so; fi
   python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-dropin --no-native-leg --no-secondary --no-traffic --no-dry-leg 2>$out/err_$tag.txt | tail -1 > $out/bench_${tag}_$rep.json
