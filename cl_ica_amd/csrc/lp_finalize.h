@@ -31,7 +31,7 @@ struct Means {
 // block tree -> one slot per block; `means_k` (next launch on the stream) sums the slots in index
 // order, so the three means are deterministic and need no atomics or fences.
 // (`blk`: the finalize block's index -- blockIdx.x of fwd_finalize_k, the owner tile of the fused sweep)
-__device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const Means& M, const int blk) {
+__device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const Means& M, const int blk, const bool coherent = false) {
   __shared__ float red[3][THREADS / 64];
   float v[3] = {v0, v1, v2};
 #pragma unroll
@@ -45,7 +45,8 @@ __device__ __forceinline__ void reduce_means(float v0, float v1, float v2, const
   if (threadIdx.x < 3) {
     float t = 0.f;
     for (int w = 0; w < THREADS / 64; ++w) t += red[threadIdx.x][w];
-    M.blocksums[blk * 3 + threadIdx.x] = t;
+    if (coherent) __hip_atomic_store(&M.blocksums[blk * 3 + threadIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // read by another workgroup of this launch
+    else M.blocksums[blk * 3 + threadIdx.x] = t;
   }
 }
 
@@ -217,9 +218,13 @@ __device__ __forceinline__ void finalize_rows(
 // counter back to zero for the next launch.  The merge order of the partials is finalize_rows' (split index), whoever arrives last: results are those
 // of the two-launch form bit for bit.  Scratch: the sweep's tile buffers (z rows) + 2 KB of its own.
 // Counters: `arrive[tiles]`, all zero before the first launch and between launches (the launch leaves them zero).
+// `means` (generic forward, nullptr in the training pair whose means the backward chain finishes): the LAST tile finisher of the launch
+// (second arrival counter, arrive[gridDim.x]) sums the block sums in means_k's order -- lane l takes slots l, l + 64, ..., then the
+// shuffle tree -- and writes the three means: same bits as the means_k launch.
 struct FinArgs {
   const float* z2; int64_t ld2; float tau, alpha; int compat; float log_b3;
   float* loss_i; float* pos_i; float* lse_i; Means M; TrainOut T; int* arrive;
+  float* means; float inv_count;
 };
 template <int NP, int PK, int R, bool ROOT, int NQ, bool ZMAX>
 __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, false)) void fwd_partial_fin_k(
@@ -250,7 +255,29 @@ __global__ __launch_bounds__(THREADS, fwd_min_waves(NP, false)) void fwd_partial
   finalize_rows<true>((int)blockIdx.x, part, (int)gridDim.y, n_own, own, ldo, F.z2, F.ld2, q, F.tau, F.alpha, F.compat, 0, 0, F.log_b3,
                 F.loss_i, F.pos_i, F.lse_i, F.T, FinScratch{&sm[0][0], &ss[0][0], scratch, scratch + FIN_ROWS * ZMAXN, ZMAXN, nullptr},
                 v_loss, v_pos, v_lse);
-  reduce_means(v_loss, v_pos, v_lse, F.M, (int)blockIdx.x);
+  reduce_means(v_loss, v_pos, v_lse, F.M, (int)blockIdx.x, /*coherent=*/F.means != nullptr);
+  if (!F.means) return;
+  // second level: the last tile finisher sums all block sums (they were agent-scope stores of threads 0..2; wait for their acknowledgement)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int prev = __hip_atomic_fetch_add(&F.arrive[gridDim.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == (int)gridDim.x - 1;
+    if (s_last) __hip_atomic_store(&F.arrive[gridDim.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  float v[3] = {0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] += __hip_atomic_load(&F.M.blocksums[b * 3 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[a] += __shfl_down(v[a], off, 64);
+  }
+  if (threadIdx.x == 0) { F.means[0] = v[0] * F.inv_count; F.means[1] = v[1] * F.inv_count; F.means[2] = v[2] * F.inv_count; }
 }
 
 // per-exponent-kind launchers of the fused form (lp_loss_pk.hip with -DCLICA_PK=k); false: no such form, nothing launched

@@ -234,9 +234,15 @@ __global__ __launch_bounds__(THREADS) void pool_stats_k(int64_t pool_rows, const
 struct FwdWs { float2* part; float* part_g; float* blocksums; size_t bytes; };
 struct BwdWs { float* statL; float* statC; float* partR; float* partC; size_t bytes; };
 
+// Header of every loss workspace: [0, 64) reserved, then the arrival counters of the one-launch forward (lp_finalize.h: one int per
+// 64-row owner tile + one for the means).  ZERO before the first call on a workspace; every launch leaves them zero; nothing else in
+// this file writes the header (the backward / training carves start behind it), so forward and backward calls may share a workspace.
+constexpr size_t kHeaderBytes = 4096;
+constexpr int64_t kArriveMaxTiles = (int64_t)(kHeaderBytes - 64) / 4 - 1;
+static int* header_arrive(void* ws) { return reinterpret_cast<int*>((char*)ws + 64); }
 static FwdWs carve_fwd(void* ws, const Plan& P, int64_t rows, bool rowgrad) {
   FwdWs w; char* p = (char*)ws; size_t off = 0;
-  off += 256;   // reserved header
+  off += kHeaderBytes;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
   w.part = (float2*)(p + off); off += align_up((size_t)P.nsplit * rows * sizeof(float2), 256);
   w.part_g = nullptr;
@@ -249,7 +255,7 @@ static size_t fwd_carve_max(int64_t rows, int64_t cols, int n) {   // plain vs r
   return a > b ? a : b;
 }
 static BwdWs carve_bwd(void* ws, const Plan& PR, const Plan& PC, int64_t rows, int64_t cols) {
-  BwdWs w; char* p = (char*)ws; size_t off = 256;   // keep clear of the forward's ticket word
+  BwdWs w; char* p = (char*)ws; size_t off = kHeaderBytes;   // keep clear of the forward's arrival counters
   w.statL = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
   w.statC = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
   w.partR = (float*)(p + off); off += align_up((size_t)PR.nsplit * rows * PR.np * sizeof(float), 256);
@@ -290,6 +296,18 @@ extern "C" int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t
   return CLICA_OK;
 }
 
+// clica_set_tuning("lp_fused_finalize", 0): the forwards as sweep + fwd_finalize_k (+ means_k) launches (test / A-B hook -- same bits)
+static int& fused_finalize_switch() { static int on = 1; return on; }
+namespace clica { namespace lp { void set_fused_finalize(int on) { fused_finalize_switch() = on ? 1 : 0; } } }       // clica_set_tuning (linear.hip)
+static bool launch_fwd_partial_fin(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own, const float* str, int64_t lds,
+                                   int64_t n_str, const Params& q, float2* part, const FinArgs& F, hipStream_t st) {
+  switch (pk) {
+    case 1: return launch_fwd_partial_fin_pk1(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
+    case 2: return launch_fwd_partial_fin_pk2(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
+    case 3: return launch_fwd_partial_fin_pk3(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
+    default: return false;
+  }
+}
 extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
                                  const float* z1, int64_t ld1, const float* z2, int64_t ld2,
                                  const float* z3, int64_t ld3,
@@ -309,6 +327,13 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, frac);
   hipStream_t st = as_stream(stream);
+  // ONE launch where that form exists (p in {1, 2, 3}, rows of <= 16 padded coordinates, no row gradient, not the p < 1 branch): the last
+  // workgroup of an owner tile finishes its rows, the last finisher the means (lp_finalize.h)
+  if (fused_finalize_switch() && !frac && !rowgrad && P.tiles <= kArriveMaxTiles &&
+      launch_fwd_partial_fin(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part,
+                             FinArgs{z2, ld2, d->tau, d->alpha, d->compat ? 1 : 0, logf((float)cols), loss_i, pos_i, lse_i, Means{w.blocksums},
+                                     TrainOut{}, header_arrive(workspace), means, 1.f / (float)rows}, st))
+    return launch_status("clica_lp_loss_fwd");
   launch_fwd_partial(P, exponent_kind(d->p), rows_p, ldr, rows, cols_p, ldc, cols, q, w.part, w.part_g, st);
   Means M{w.blocksums};
   const int nfin = (int)ceil_div(rows, FIN_ROWS);
@@ -418,20 +443,8 @@ static constexpr int train_flags() { return 7; }
 static bool train_mfma_shape(const clica_lp_loss_desc* d) { return (train_flags() & 7) == 7 && lp2::applies(d->n, d->p, d->pow); }
 // (its fallback is the fixed-maximum / folded-coefficient difference sweep)
 static bool train_mfma(const clica_lp_loss_desc* d) { return train_mfma_shape(d) && lp2::applies_to_pool(d->B, d->B3); }
-// clica_set_tuning("lp_fused_finalize", 0): the training forward as sweep + fwd_finalize_k (two launches; test / A-B hook -- same bits)
-static int& fused_finalize_switch() { static int on = 1; return on; }
-namespace clica { namespace lp { void set_fused_finalize(int on) { fused_finalize_switch() = on ? 1 : 0; } } }       // clica_set_tuning (linear.hip)
-static bool launch_fwd_partial_fin(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own, const float* str, int64_t lds,
-                                   int64_t n_str, const Params& q, float2* part, const FinArgs& F, hipStream_t st) {
-  switch (pk) {
-    case 1: return launch_fwd_partial_fin_pk1(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
-    case 2: return launch_fwd_partial_fin_pk2(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
-    case 3: return launch_fwd_partial_fin_pk3(P, own, ldo, n_own, str, lds, n_str, q, part, F, st);
-    default: return false;
-  }
-}
 static TrainWs carve_train(void* ws, const Plan& PF, const Plan& PR, int64_t rows, int64_t cols, bool mfma) {
-  TrainWs w; char* p = (char*)ws; size_t off = 256;
+  TrainWs w; char* p = (char*)ws; size_t off = kHeaderBytes;
   w.blocksums = (float*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * 3 * sizeof(float), 256);
   w.arrive = (int*)(p + off); off += align_up((size_t)ceil_div(rows, FIN_ROWS) * sizeof(int), 256);    // fused finalize: arrival counters (zero between launches)
   w.statL = (float*)(p + off); off += align_up((size_t)rows * sizeof(float), 256);
@@ -549,7 +562,7 @@ extern "C" int clica_lp_loss_fwd_train(const clica_lp_loss_desc* d,
     if (fused_finalize_switch() &&
         launch_fwd_partial_fin(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part,
                                FinArgs{z2, ld2, d->tau, d->alpha, d->compat ? 1 : 0, logf((float)cols), loss_i, pos_i, lse_i, Means{w.blocksums},
-                                       TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, w.arrive}, st))
+                                       TrainOut{w.statL, w.statC, dz1, ldd1, dz2, ldd2}, w.arrive, nullptr, 0.f}, st))
       return launch_status("clica_lp_loss_fwd_train");
     launch_fwd_partial(PF, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, part, nullptr, st);
   }

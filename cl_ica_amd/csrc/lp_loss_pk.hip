@@ -77,13 +77,20 @@ bool CAT(launch_fwd_partial_fin_pk, CLICA_PK)(const Plan& P, const float* own, i
                                               float2* part, const FinArgs& F, hipStream_t st) {
   constexpr int PK = CLICA_PK;
   if constexpr (PK >= 1 && PK <= 3) {
-    if (P.np > 16 || !q.pow || !(q.train & 1)) return false;
+    if (P.np > 16) return false;
     dim3 grid((unsigned)P.tiles, (unsigned)P.nsplit), block(THREADS);
     bool done = false;
     LP_FOR_NP(P.np, {
       if constexpr (NP <= 16 && HALF * owners_fwd(NP) == FIN_ROWS) {
-        hipLaunchKernelGGL((fwd_partial_fin_k<NP, PK, owners_fwd(NP), false, NQ, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
-                           n_str, q, part, P.chunk, F);
+        if (q.pow && (q.train & 1))        // the training pair's sweep (running maximum known)
+          hipLaunchKernelGGL((fwd_partial_fin_k<NP, PK, owners_fwd(NP), false, NQ, true>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                             n_str, q, part, P.chunk, F);
+        else if (q.pow)                    // generic forward, p-th power (LpSimCLRLoss default)
+          hipLaunchKernelGGL((fwd_partial_fin_k<NP, PK, owners_fwd(NP), false, NQ, false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                             n_str, q, part, P.chunk, F);
+        else                               // generic forward, the norm itself
+          hipLaunchKernelGGL((fwd_partial_fin_k<NP, PK, owners_fwd(NP), true, NQ, false>), grid, block, 0, st, own, ldo, n_own, str, lds,
+                             n_str, q, part, P.chunk, F);
         done = true;
       }
     })

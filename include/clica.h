@@ -89,6 +89,11 @@ int clica_lp_loss_workspace_bytes(const clica_lp_loss_desc* d, size_t* fwd_bytes
  *   rowgrad [B,n] (ld `ldrg`) optional, NULL to skip: sum_j softmax_ij * d neg_ij / d z1_i, accumulated
  *           flash-style inside the same pair sweep.  Handing it to clica_lp_loss_bwd removes the
  *           backward's row pass (one of its two all-pairs sweeps) for ANY upstream gradient.
+ * WORKSPACE: ZERO-FILLED before its first use (round 6).  Its first 4 KB are a header: arrival counters of the one-launch form of this
+ * call (p in {1, 2, 3}, n <= 14, rowgrad == NULL, B <= 64 448: the last workgroup to deliver a partial of a 64-row tile finishes that
+ * tile's rows, the last finisher of the launch writes `means` -- no finalize / means launches, same bits as with them,
+ * clica_set_tuning("lp_fused_finalize", 0)).  Every launch leaves the counters zero and no entry point writes the header otherwise, so
+ * forward, backward and training-pair calls may share one workspace.
  */
 int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
                       const float* z1, int64_t ld1, const float* z2, int64_t ld2,

@@ -820,3 +820,44 @@ def test_p2_train_sweeps_on_matrix_cores_pool_49152():
     g1, g2 = O.lp_symmetric_row_grads(z_all[S], zt_all[S], z_all, lse_nat[S], lse_nat, 2, tau, alpha, local_rows=B)
     PARITY.check(fam, case, "dz1", dz[:B].cpu().numpy()[S], g1)
     PARITY.check(fam, case, "dz2", dz[B:].cpu().numpy()[S], g2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,B3,n", [(1500, 2100, 10), (64, 64, 4), (6144, 6144, 10), (1000, 333, 14)])
+def test_forward_in_one_launch_equals_the_three_launch_form(B, B3, n, request):
+    """clica_lp_loss_fwd as ONE launch (lp_finalize.h: the last workgroup of an owner tile finishes its rows, the last finisher of the launch
+    the three means) == sweep + fwd_finalize_k + means_k (clica_set_tuning("lp_fused_finalize", 0)), bit for bit: loss_i, pos_i, lse_i and
+    the means, for the specialised exponents, both `pow` forms, logsumexp and logmeanexp, ragged tiles, a pool smaller / larger than the
+    batch; called repeatedly on ONE zero-filled workspace shared with the backward call in between (the arrival counters live in the
+    workspace's header: every launch must leave them zero and the backward must keep clear of them)."""
+    import ctypes as C
+    from cl_ica_amd import _lib
+    lib = _lib.load()
+    request.addfinalizer(lambda: _lib.check(lib.clica_set_tuning(b"lp_fused_finalize", 1), "clica_set_tuning"))
+    torch.manual_seed(3)
+    z1 = torch.randn(B, n, device="cuda") * 0.6; z2 = z1 + 0.05 * torch.randn_like(z1); z3 = torch.randn(B3, n, device="cuda") * 0.6
+    for p, pw, compat in ((1, 1, 1), (2, 1, 1), (3, 1, 0), (2, 0, 1), (1, 0, 0)):
+        d = _lib.LpLossDesc(B=B, B3=B3, n=n, p=float(p), tau=0.9, alpha=0.4, compat=compat, pow=pw)
+        fb, bb = C.c_size_t(), C.c_size_t()
+        _lib.check(lib.clica_lp_loss_workspace_bytes(C.byref(d), C.byref(fb), C.byref(bb)), "ws")
+        ws = torch.zeros(max(fb.value, bb.value), dtype=torch.uint8, device="cuda")
+        dz = [torch.empty(B, n, device="cuda"), torch.empty(B, n, device="cuda"), torch.empty(B3, n, device="cuda")]
+        outs = {}
+        for fused in (1, 0, 1):
+            _lib.check(lib.clica_set_tuning(b"lp_fused_finalize", fused), "clica_set_tuning")
+            for rep in range(3):
+                o = torch.full((3 * B + 3,), float("nan"), device="cuda")
+                _lib.check(lib.clica_lp_loss_fwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[:B].data_ptr(),
+                                                 o[B:2 * B].data_ptr(), o[2 * B:3 * B].data_ptr(), o[3 * B:].data_ptr(), None, n,
+                                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "fwd")
+                _lib.check(lib.clica_lp_loss_bwd(C.byref(d), z1.data_ptr(), n, z2.data_ptr(), n, z3.data_ptr(), n, o[2 * B:3 * B].data_ptr(),
+                                                 None, n, None, None, None, None, dz[0].data_ptr(), n, dz[1].data_ptr(), n, dz[2].data_ptr(), n, 0,
+                                                 ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "bwd")
+                torch.cuda.synchronize()
+                assert torch.isfinite(o).all(), (p, pw, compat, fused, rep)
+                outs.setdefault(fused, []).append((o.clone(), dz[0].clone()))
+        ref_o, ref_dz = outs[0][0]
+        for fused, runs in outs.items():
+            for o, g in runs:
+                assert torch.equal(o, ref_o) and torch.equal(g, ref_dz), (p, pw, compat, fused, float((o - ref_o).abs().max()))
+        assert int(ws[64:4096].view(torch.int32).abs().max()) == 0, "the arrival counters must be zero between launches"
