@@ -37,7 +37,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#ifndef CLICA_WSPLIT_ABLATE      // timing ablations (WRONG results): 1 no DMA in the loop, 2 every step re-reads tile 0 (L2-hot), 4 no fragment reads
+#ifndef CLICA_WSPLIT_ABLATE      // timing ablations (WRONG results): 1 no DMA in the loop, 2 every step re-reads tile 0 (L2-hot), 4 no fragment reads (small body), 8 no per-step barrier (256 x 256 body)
 #define CLICA_WSPLIT_ABLATE 0
 #endif
 constexpr int STG = 4;                      // LDS stages of one 16-row step each
@@ -658,6 +658,7 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // six DMA pieces per wave and step: piece pi = wave + 8 j of the stage image [A: 8 units x 3 planes][B: 8 units x 3 planes]
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   const char* src[NJ2]; int stride[NJ2];
 #pragma unroll
   for (int j = 0; j < NJ2; ++j) {
@@ -671,7 +672,6 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
     src[j] = ok ? base + (((int64_t)g0 * fu + u) * NP + plane) * 1024 + lane * 16 : reinterpret_cast<const char*>(g_zero16);
     stride[j] = ok ? fu * NP * planes::kPieceBytes : 0;
   }
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr)smem;
   auto issue_one = [&](int t, int j) { dma_1k(src[j], lds0 + (unsigned)((t % STG2) * STAGE2_BYTES + (wave + 8 * j) * 1024)); src[j] += stride[j]; };
   const int lane_off = h * 512 + ((lane >> 4) & 1) * 128 + (lane & 15) * 8;
   const char* fa_base = smem + lane_off + (wm * 4) * NP * 1024;
@@ -712,12 +712,14 @@ __device__ __forceinline__ void body_big(const Prob& g, const int bx, const int 
     const bool next = t + 1 < nt;
     WS_STEP_STAMP(t, 5);
     if (next) {
-      wait_tiles(min(t + 2, nt - 1) - (t + 1));
+      wait_tiles((CLICA_WSPLIT_ABLATE & 1) ? 0 : min(t + 2, nt - 1) - (t + 1));
       WS_STEP_STAMP(t, 6);
+#if !(CLICA_WSPLIT_ABLATE & 8)
       __syncthreads();
+#endif
     }
     WS_STEP_STAMP(t, 7);
-    const bool more = t + 3 < nt;
+    const bool more = t + 3 < nt && !(CLICA_WSPLIT_ABLATE & 1);
     constexpr int NG = 2 * NP, MPG = NMH / NG;                 // groups of the half: one piece's two fragments (four reads) and MPG MFMAs each (4 / 3)
     static_assert(NG >= NJ2 && NMH % NG == 0, "one DMA request per group");
 #pragma unroll
