@@ -140,6 +140,9 @@ static Params make_params(const clica_lp_loss_desc* d, bool frac) {
   q.pow = d->pow ? 1 : 0; q.n = d->n;
   return q;
 }
+// training-pair forms (bits; all on): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (Params::train),
+// 4 = p = 2 sweeps on the matrix cores where lp_mfma.hip's policy admits them (needs the semantics of bits 1 and 2: the pool contains the anchors)
+static constexpr int train_flags() { return 7; }
 static int exponent_kind(float p) { return p == 1.f ? 1 : (p == 2.f ? 2 : (p == 3.f ? 3 : 0)); }
 
 static void launch_fwd_partial(const Plan& P, int pk, const float* own, int64_t ldo, int64_t n_own,
@@ -326,6 +329,12 @@ extern "C" int clica_lp_loss_fwd(const clica_lp_loss_desc* d,
   FwdWs w = carve_fwd(workspace, P, rows, rowgrad != nullptr);
   if (w.bytes > workspace_bytes) { set_error("clica_lp_loss_fwd: workspace %zu < %zu", workspace_bytes, w.bytes); return CLICA_E_WORKSPACE; }
   Params q = make_params(d, frac);
+  // The negatives ARE the anchors (same buffer: LpSimCLRLoss with z3_rec = roll(z1_rec), main_mlp.py:272): every logit is <= 0 and a
+  // row's own pool entry gives exactly 0 -- the training pair's fixed-maximum sweep applies (Params::train bit 0), as in clica_lp_loss_fwd_train
+  if (!frac && !rowgrad && z3 == z1 && ld3 == ld1 && d->B3 == d->B && d->pow && exponent_kind(d->p) != 0 && (train_flags() & 1)) {
+    q.train = 1;
+    if (exponent_kind(d->p) >= 2) q.pre = powf(q.kscale, 1.f / d->p);
+  }
   hipStream_t st = as_stream(stream);
   // ONE launch where that form exists (p in {1, 2, 3}, rows of <= 16 padded coordinates, no row gradient, not the p < 1 branch): the last
   // workgroup of an owner tile finishes its rows, the last finisher the means (lp_finalize.h)
@@ -427,7 +436,15 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
     hipLaunchKernelGGL(pool_stats_k, dim3((unsigned)ceil_div(cols, THREADS)), dim3(THREADS), 0, st,
                        cols, pool_lse, rows, d->tau, d->alpha, g_mean, g_neg, q.xs, strL, strC);
   }
-  launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, q, w.statL, w.statC, strL, strC, w.partR, st);
+  // the pool contains the owner rows (this entry point's contract): every row statistic is the log2 of a sum >= 1, so the pair sweep
+  // takes the folded coefficient 2^x (u_i + u_j) with one exponential per pair (Params::train bit 1), as clica_lp_loss_bwd_sym_train does
+  Params qs = q;
+  if ((train_flags() & 2) && exponent_kind(d->p) != 0 && d->pow) {
+    qs.train = 2;
+    if (exponent_kind(d->p) >= 2) qs.pre = powf(qs.kscale, 1.f / d->p);
+    qs.gfold = d->p / powf(qs.pre, d->p - 1.f);
+  }
+  launch_bwd_sym(PR, exponent_kind(d->p), z1, ld1, rows, pool, ldp, cols, qs, w.statL, w.statC, strL, strC, w.partR, st);
   hipLaunchKernelGGL(bwd_reduce_k, dim3((unsigned)ceil_div(rows * PR.np, THREADS)), dim3(THREADS), 0, st,
                      (const float*)w.partR, PR.nsplit, rows, PR.np, d->n, dz1, ldd1, 1, MeansJob{nullptr, 0, 0.f, nullptr, -1, nullptr}, Gate{});
   return launch_status("clica_lp_loss_bwd_sym");
@@ -437,9 +454,6 @@ extern "C" int clica_lp_loss_bwd_sym(const clica_lp_loss_desc* d,
 // with the forward's means folded into its reduction (three launches fewer than fwd + bwd_sym) -------------------------
 struct TrainWs { float* blocksums; int* arrive; float* statL; float* statC; float* strL; float* strC; char* scratch; size_t scratch_bytes; size_t bytes;
                  bool mfma; lp2::Plan P2; lp2::Ws w2; };
-// training-pair forms (bits; all on): 1 = fixed-maximum forward sweep, 2 = folded backward coefficient (Params::train),
-// 4 = p = 2 sweeps on the matrix cores where lp_mfma.hip's policy admits them (needs the semantics of bits 1 and 2: the pool contains the anchors)
-static constexpr int train_flags() { return 7; }
 static bool train_mfma_shape(const clica_lp_loss_desc* d) { return (train_flags() & 7) == 7 && lp2::applies(d->n, d->p, d->pow); }
 // (its fallback is the fixed-maximum / folded-coefficient difference sweep)
 static bool train_mfma(const clica_lp_loss_desc* d) { return train_mfma_shape(d) && lp2::applies_to_pool(d->B, d->B3); }
