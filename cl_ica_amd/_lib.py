@@ -198,6 +198,8 @@ SIGNATURES: Dict[str, list] = {
                             C.c_void_p, c_i32, C.c_void_p],
     "clica_adam_step_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                              C.c_void_p, C.c_void_p],
+    "clica_adam_step_s16_tick": [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, c_i32, C.c_void_p],
     "clica_tick": [C.c_void_p, C.c_void_p],
     "clica_stamp": [C.c_void_p, c_i32, c_i32, C.c_void_p],
     "clica_publish_host": [C.c_void_p, c_i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(THREADS) void adam_k(float* __restrict__ p, const f
   // one tensor each -- every producer of the step has finished by stream order, and the next step's pack launch (the first reader of
   // the new scales) comes behind it
   const unsigned nupd = s16_state ? (unsigned)s16::kS16UpdateBlocks : 0u;
-  if (blockIdx.x < nupd) { s16::split16_update_tensor(s16_state, s16_layers, (int)blockIdx.x, step_dev); return; }
+  // (with a fused tick the counter has NOT been advanced yet: a withheld step has nothing to take back, and -- its workgroups returning
+  //  below -- nobody advances it)
+  if (blockIdx.x < nupd) { s16::split16_update_tensor(s16_state, s16_layers, (int)blockIdx.x, ticket ? nullptr : step_dev); return; }
   const unsigned nwork = gridDim.x - nupd, block = blockIdx.x - nupd;
   // the guard (split16.h): a producer of this step cut a tensor that had outgrown its scale -- parameters and moments stay as they are,
   // the update above takes the step counter back and the next replay redoes the step on the scales this one measured
@@ -96,6 +98,16 @@ extern "C" int clica_adam_step_at(float* param, const float* grad, float* exp_av
                                   const int32_t* step_dev, int32_t t_offset, clica_stream_t stream) {
   CLICA_CHECK_ARG(t_offset == 0 || t_offset == 1, "clica_adam_step_at: t_offset must be 0 or 1");
   return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, const_cast<int32_t*>(step_dev), nullptr, t_offset, stream);
+}
+
+// clica_adam_step_tick + the f16x2 encoder arithmetic's scale update in the same launch (the drop-in optimizer's step: update number
+// *step_dev + 1, counter advanced by the launch's last workgroup -- unless the guard withheld the step)
+extern "C" int clica_adam_step_s16_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                                        float lr, float beta1, float beta2, float eps, float grad_scale,
+                                        int32_t* step_dev, int32_t* ticket, void* split16_state, int32_t n_layers, clica_stream_t stream) {
+  CLICA_CHECK_ARG(ticket != nullptr, "clica_adam_step_s16_tick: ticket is NULL");
+  CLICA_CHECK_ARG(split16_state && n_layers >= 1 && n_layers <= 8, "clica_adam_step_s16_tick: bad state / layer count");
+  return adam_launch(param, grad, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, grad_scale, step_dev, ticket, 1, stream, split16_state, n_layers);
 }
 
 // clica_adam_step_at + the f16x2 encoder arithmetic's scale update (clica_split16_update) in the same launch

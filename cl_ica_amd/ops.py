@@ -616,6 +616,14 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
         require_cuda(t, nm)
         if not t.is_contiguous():
             raise ValueError(f"{nm} must be contiguous")
+    if s16 is not None and ticket is not None:     # ... and so does the counter's tick (the drop-in optimizer's step)
+        if t_offset != 1:
+            raise ValueError("adam_step(s16=..., ticket=...): the fused tick advances the counter AFTER the update (t_offset = 1)")
+        check(load().clica_adam_step_s16_tick(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                              param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                              step_dev.data_ptr(), ticket.data_ptr(), s16.buf.data_ptr(), s16.n_layers, stream_ptr()),
+              "clica_adam_step_s16_tick")
+        return True
     if s16 is not None and ticket is None:     # the f16x2 arithmetic's scale update rides in the optimizer launch (clica_adam_step_s16)
         check(load().clica_adam_step_s16(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
                                          param.numel(), float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),

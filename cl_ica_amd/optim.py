@@ -113,9 +113,10 @@ class Adam:
         if s16 is not None:
             # the encoder runs in the f16x2 arithmetic: its scale update rides in this launch, and a step whose producers met a value
             # beyond its scale (the guard, include/clica.h) leaves parameters and moments untouched and takes the step count back
+            # (one launch: update, scale update, guard, and -- its last workgroup -- the counter's tick)
             ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
-                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0, t_offset=1, s16=s16.state)
-            ops.tick(self.step_dev)
+                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0, t_offset=1, s16=s16.state,
+                          ticket=self._ticket)
         else:
             ops.adam_step(self.param_arena, self.grad_arena, self.exp_avg, self.exp_avg_sq, self.step_dev, float(g["lr"]),
                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), grad_scale=1.0 / self.world, ticket=self._ticket)

@@ -718,6 +718,11 @@ int clica_adam_step_s16(float* param, const float* grad, float* exp_avg, float* 
 int clica_adam_step_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                          float lr, float beta1, float beta2, float eps, float grad_scale,
                          int32_t* step_dev, int32_t* ticket, clica_stream_t stream);
+/* clica_adam_step_tick with the f16x2 scale update and guard of clica_adam_step_s16 in the same launch (update number *step_dev + 1; the
+ * launch's last workgroup advances the counter, a step the guard withholds leaves it where it was). */
+int clica_adam_step_s16_tick(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                             float lr, float beta1, float beta2, float eps, float grad_scale,
+                             int32_t* step_dev, int32_t* ticket, void* split16_state, int32_t n_layers, clica_stream_t stream);
 /* *counter += 1 (single-thread kernel; keeps step/RNG counters on device for graph replay) */
 int clica_tick(int32_t* counter, clica_stream_t stream);
 /* Host reads from the MIDDLE of a captured step (cl_ica_amd/graphed.py: the reference's train_step reads three loss scalars per step,
