@@ -139,6 +139,10 @@ SIGNATURES: Dict[str, list] = {
                                 C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                                 C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, c_size,
                                 C.c_void_p],
+    "clica_mlp_wgrad_split16_tail": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
+                                     C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
+                                     C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), c_i32, C.c_void_p, c_size,
+                                     C.c_void_p],
     "clica_mlp_wgrad_split_adam": [c_i64, c_i32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(c_i64),
                                    C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p), C.POINTER(c_i64), C.POINTER(C.c_void_p),
                                    C.POINTER(c_i32), C.POINTER(c_i32), C.c_void_p, C.POINTER(c_i32), C.POINTER(c_i32), C.POINTER(AdamDesc),

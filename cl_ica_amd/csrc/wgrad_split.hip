@@ -1256,6 +1256,17 @@ extern "C" int clica_mlp_wgrad_split16(int64_t M, int32_t n_layers, const void* 
   return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, accumulate, state, a_index, d_index,
                               workspace, workspace_bytes, stream);
 }
+// clica_mlp_wgrad_split16 behind a backward chain that has left the slabs of the n-wide first / last layer itself
+// (clica_mlp_dgrad_split_tail): no tiny-dimension launch -- the drop-in encoder's backward under torch autograd
+extern "C" int clica_mlp_wgrad_split16_tail(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                            const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                            float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                            int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
+                                            int32_t tail_slabs, void* workspace, size_t workspace_bytes, clica_stream_t stream) {
+  CLICA_CHECK_ARG(state && a_index && d_index, "clica_mlp_wgrad_split16_tail: NULL state / index arrays");
+  return mlp_wgrad_split_impl(M, n_layers, dZ_planes, X_planes, dZ, lddz, X, ldx, dW, lddw, db, N, K, accumulate, state, a_index, d_index,
+                              workspace, workspace_bytes, stream, nullptr, tail_slabs ? 1 : 0);
+}
 // Weight gradients AND the optimizer: the trailing reduction launch applies Adam to every element it has just reduced (and carries the
 // f16x2 scale update in front when adam->split16_state is set), so a training step needs no optimizer launch.  state == NULL: bf16x3
 // plane copies (clica_mlp_wgrad_split), else f16x2 (clica_mlp_wgrad_split16).

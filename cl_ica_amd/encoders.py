@@ -240,6 +240,14 @@ class _SplitPlan:
         self.lddw = (C.c_int64 * L)(*[s[1] for s in shapes])
 
 
+def _tail_ok(pl, shapes, kinds) -> bool:
+    """May the backward chain produce the n-wide first / last layer's weight-gradient slabs itself (cached on the plan)?"""
+    ok = bool(len(shapes) >= 3 and kinds[0] == 1 and kinds[-1] == 1 and all(k == 0 for k in kinds[1:-1]) and
+              pl.f_outs[len(shapes) - 2] is not None and ops.mlp_chain_tail_supported(shapes))
+    pl.tail_ok = ok
+    return ok
+
+
 class _MLPFusedSplitFn(torch.autograd.Function):
     """``_MLPFusedFn`` in the split-bf16 arithmetic the training engine uses by default (fp32 results from six bf16 products of
     exact 3-way operand splits: csrc/fused_mlp.hip mlp_split_k, csrc/wgrad_split.hip): forward stack, backward data chain and the
@@ -403,6 +411,7 @@ class _MLPFusedSplitFn(torch.autograd.Function):
             dz0 = torch.empty((M, shapes[0][0]), dtype=torch.float32, device=dev)
             f32_ptr[0] = dz0.data_ptr()
         gy_planes = None
+        use_tail = False
         if L > 1:
             chain, VPc = pl.chain, pl.VPc
             cargs = (gy.data_ptr(), gy.stride(0), M, L - 1, pl.cN, pl.cK, packed_t.data_ptr(),
@@ -424,7 +433,16 @@ class _MLPFusedSplitFn(torch.autograd.Function):
                         st.update()
                     st.clear_flags()          # (passes on unmeasured scales: whatever they flagged is not a finding)
                     s16.backward_calibrated()
-                _lib.check(lib.clica_mlp_dgrad_split16(*cargs, st.buf.data_ptr(), sp), "clica_mlp_dgrad_split16")
+                # the chain also leaves the weight-gradient slabs of the n-wide first / last layer (clica_mlp_dgrad_split_tail: two small
+                # fp32 products over each workgroup's 48 rows behind the last link) -- no tiny-dimension launch in front of the grouped GEMM
+                use_tail = pl.tail_ok if hasattr(pl, "tail_ok") else _tail_ok(pl, shapes, kinds)
+                if use_tail:
+                    wsb_t = _MLPFusedSplitFn._wgrad_ws(dev, M, shapes)
+                    tail = _lib.ChainTail(a_last=fb + pl.f_outs[L - 2], lda=shapes[L - 2][0], x=x.data_ptr(), ldx=x.stride(0), n_layers=L,
+                                          N=pl.N, K=pl.K, wgrad_workspace=wsb_t.data_ptr(), wgrad_workspace_bytes=wsb_t.numel(), dy_parts=None)
+                    _lib.check(lib.clica_mlp_dgrad_split_tail(*cargs, st.buf.data_ptr(), C.byref(tail), sp), "clica_mlp_dgrad_split_tail")
+                else:
+                    _lib.check(lib.clica_mlp_dgrad_split16(*cargs, st.buf.data_ptr(), sp), "clica_mlp_dgrad_split16")
         keep = [barena]
         # operands of the weight gradients, per layer: planes (kind 0) or fp32 (kind 1)
         dzp, xp, dzf, lddz, xf, ldxf = [None] * L, [None] * L, [None] * L, [0] * L, [None] * L, [0] * L
@@ -455,6 +473,9 @@ class _MLPFusedSplitFn(torch.autograd.Function):
                  VP(*[w.data_ptr() for w in dWs]), pl.I64(*[w.stride(0) for w in dWs]), VP(*[b.data_ptr() for b in dbs]), pl.N, pl.K, acc)
         if st is None:
             _lib.check(lib.clica_mlp_wgrad_split(*wargs, wsb.data_ptr(), wsb.numel(), sp), "clica_mlp_wgrad_split")
+        elif L > 1 and use_tail:
+            _lib.check(lib.clica_mlp_wgrad_split16_tail(*wargs, st.buf.data_ptr(), pl.a_index, pl.d_index, 1, wsb.data_ptr(), wsb.numel(), sp),
+                       "clica_mlp_wgrad_split16_tail")
         else:
             _lib.check(lib.clica_mlp_wgrad_split16(*wargs, st.buf.data_ptr(), pl.a_index, pl.d_index, wsb.data_ptr(), wsb.numel(), sp),
                        "clica_mlp_wgrad_split16")

@@ -473,6 +473,15 @@ int clica_mlp_dgrad_split_tail(const float* dY, int64_t lddy, int64_t M, int32_t
                                float* const* out, const int64_t* ldo, void* const* planes, float slope, void* state,
                                const clica_chain_tail* tail, clica_stream_t stream);
 
+/* clica_mlp_wgrad_split16 with `tail_slabs` as in clica_mlp_wgrad_split_adam (the chain call in front was clica_mlp_dgrad_split_tail on the
+ * SAME workspace): the n-wide first / last layer's slabs are already there, no tiny-dimension launch.  No optimizer: what the drop-in
+ * encoder's autograd backward calls. */
+int clica_mlp_wgrad_split16_tail(int64_t M, int32_t n_layers, const void* const* dZ_planes, const void* const* X_planes,
+                                 const float* const* dZ, const int64_t* lddz, const float* const* X, const int64_t* ldx,
+                                 float* const* dW, const int64_t* lddw, float* const* db, const int32_t* N, const int32_t* K,
+                                 int32_t accumulate, const void* state, const int32_t* a_index, const int32_t* d_index,
+                                 int32_t tail_slabs, void* workspace, size_t workspace_bytes, clica_stream_t stream);
+
 /* Weight gradients + optimizer in one call (round 5: the N = 1 training step has no optimizer launch of its own).  The reduction that
  * ends clica_mlp_wgrad_split / _split16 applies torch.optim.Adam's update (main_mlp.py:312, as clica_adam_step_at) to every element
  * it has just reduced; dW[l] (contiguous: lddw[l] = K[l]) and db[l] must be views of ONE gradient arena `grad` that this call covers
