@@ -29,7 +29,7 @@ from typing import Callable, List, Optional
 import torch
 from torch.utils._pytree import tree_map
 
-__all__ = ["LazyOut", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP", "attach", "find_optimizers"]
+__all__ = ["LazyOut", "LazyRoll", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP", "attach", "find_optimizers"]
 
 _META_GETTERS = {"shape", "dtype", "device", "requires_grad", "ndim", "layout", "is_cuda", "is_leaf_placeholder"}
 _META_METHODS = {"dim", "size", "__len__", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "get_device",
@@ -142,24 +142,67 @@ class LazyOut(torch.Tensor):
             with torch._C.DisableTorchFunctionSubclass():      # metadata lives on the wrapper itself: no need to compute anything
                 return func(*args, **kwargs)
 
-        def unwrap(a):
-            return a.materialize() if isinstance(a, LazyOut) else a
+        if name == "roll" and args and type(args[0]) is LazyOut:
+            # z3_rec = torch.roll(z1_rec, 1, 0) (main_mlp.py:272): LpSimCLRLoss never reads the rolled copy (losses.py: _PairLossSymFn), so the
+            # roll itself is deferred as well -- any other consumer gets the real tensor through LazyRoll.materialize()
+            rest = list(args[1:])
+            shifts = kwargs.get("shifts", rest[0] if rest else None)
+            dims = kwargs.get("dims", rest[1] if len(rest) > 1 else None)
+            dims = dims[0] if isinstance(dims, (tuple, list)) and len(dims) == 1 else dims
+            shifts = shifts[0] if isinstance(shifts, (tuple, list)) and len(shifts) == 1 else shifts
+            if isinstance(shifts, int) and dims == 0 and len(args[0].shape) >= 1:
+                return LazyRoll(args[0], shifts)
+
         with torch._C.DisableTorchFunctionSubclass():
-            return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
+            return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
 
     @classmethod
     def __torch_dispatch__(cls, func, types, args=(), kwargs=None):      # anything that slipped past __torch_function__
         kwargs = kwargs or {}
+        return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
 
-        def unwrap(a):
-            return a.materialize() if isinstance(a, LazyOut) else a
-        return func(*tree_map(unwrap, args), **tree_map(unwrap, kwargs))
+
+class LazyRoll(torch.Tensor):
+    """``torch.roll(source, shift, 0)`` of a deferred module output, itself deferred: the reference's ``z3_rec`` (main_mlp.py:272).
+    ``LpSimCLRLoss`` recognises it by ``source`` and never computes it; every other consumer (any torch function, ``plain``) gets the
+    real rolled tensor, computed once with ordinary autograd."""
+
+    @staticmethod
+    def __new__(cls, source, shift: int):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(source.shape), dtype=source.dtype, device=source.device,
+                                                requires_grad=source.requires_grad)
+        r.source, r.shift, r._value = source, int(shift), None
+        return r
+
+    def materialize(self) -> torch.Tensor:
+        if self._value is None:
+            self._value = torch.roll(plain(self.source), self.shift, 0)
+        return self._value
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        name = getattr(func, "__name__", "")
+        if name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in _META_GETTERS or name in _META_METHODS:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
+
+
+def _unwrap(a):
+    return a.materialize() if isinstance(a, (LazyOut, LazyRoll)) else a
 
 
 def plain(t):
     """The plain tensor behind `t` (computing it if it is still pending); anything that is not a LazyOut is returned as is.
     Every entry point of this package that takes embeddings calls this first: a LazyOut must never reach autograd.Function.apply."""
-    return t.materialize() if isinstance(t, LazyOut) else t
+    return t.materialize() if isinstance(t, (LazyOut, LazyRoll)) else t
 
 
 def defer(owner, x: torch.Tensor, compute: Callable[[torch.Tensor], torch.Tensor], out_shape, params, max_items: int = 2,

@@ -329,8 +329,10 @@ class LpSimCLRLoss(CLLoss):
 
     def loss(self, z1, z2_con_z1, z3, z1_rec, z2_con_z1_rec, z3_rec):
         del z1, z2_con_z1, z3   # unused by the reference as well (losses.py:431)
-        rolled = isinstance(z3_rec, RolledRows) and z3_rec.source is z1_rec
-        if isinstance(z3_rec, RolledRows) and not (rolled and _sym_enabled() and float(self.p) >= 1.0 and z1_rec.dim() == 2):
+        # negatives that are the anchors in another order, not computed: RolledRows (callers inside this package) or the deferred
+        # torch.roll of a deferred encoder output (lazy.LazyRoll: the reference's own z3_rec = torch.roll(z1_rec, 1, 0))
+        rolled = isinstance(z3_rec, (RolledRows, lazy.LazyRoll)) and z3_rec.source is z1_rec
+        if isinstance(z3_rec, (RolledRows, lazy.LazyRoll)) and not (rolled and _sym_enabled() and float(self.p) >= 1.0 and z1_rec.dim() == 2):
             z3_rec, rolled = z3_rec.materialize(), False
         z1_rec, z2_con_z1_rec = lazy.plain(z1_rec), lazy.plain(z2_con_z1_rec)
         z3_rec = z1_rec if rolled else lazy.plain(z3_rec)

@@ -367,8 +367,9 @@ def test_lazy_stacking_mechanics_on_cpu():
     b = m(x2)
     assert not isinstance(b, lazy.LazyOut) and calls == [8]                       # one compute over the stack
     av = lazy.plain(a)
-    z3 = torch.roll(a, 1, 0)
-    assert type(z3) is torch.Tensor and losses._rolled_rows_of(z3, av) and not losses._rolled_rows_of(torch.roll(av, 1, 1), av)
+    z3 = torch.roll(a, 1, 0)            # (round 6) deferred as well: a LazyRoll the loss recognises by its source; materialised, the graph shows the roll
+    assert type(z3) is lazy.LazyRoll and z3.source is a and losses._rolled_rows_of(lazy.plain(z3), av)
+    assert losses._rolled_rows_of(torch.roll(av, 1, 0), av) and not losses._rolled_rows_of(torch.roll(av, 1, 1), av)
     assert not losses._rolled_rows_of(torch.roll(b, 1, 0), av)
     ((a * b).sum() + z3.sum()).backward()
     got = [p.grad.clone() for p in m.parameters()]
@@ -594,3 +595,30 @@ def test_bench_self_launch_two_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT_DIR, "bench.py"), "--gpus", "2", "--launch-check"], capture_output=True, text=True,
                        timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_lazy_roll_of_a_deferred_output_on_cpu():
+    """`torch.roll(z1_rec, 1, 0)` of a deferred encoder output (the reference's z3_rec, main_mlp.py:272) is itself deferred: a LazyRoll
+    that remembers its source (LpSimCLRLoss recognises it and never computes it) and gives every other consumer the real rolled tensor,
+    with ordinary autograd behind it; other shifts / dims / a second materialisation behave like torch.roll."""
+    from cl_ica_amd import lazy
+    w = torch.randn(3, 2, requires_grad=True)
+
+    class Owner:
+        pass
+    o = Owner()
+    x1, x2 = torch.randn(4, 3), torch.randn(4, 3)
+    a = lazy.defer(o, x1, lambda x: x @ w, (4, 2), [w])
+    b = lazy.defer(o, x2, lambda x: x @ w, (4, 2), [w])
+    assert type(a) is lazy.LazyOut and type(b) is not lazy.LazyOut
+    r = torch.roll(a, 1, 0)
+    assert type(r) is lazy.LazyRoll and r.source is a and r.shift == 1 and tuple(r.shape) == (4, 2) and r._value is None
+    r2 = a.roll(shifts=2, dims=(0,))
+    assert type(r2) is lazy.LazyRoll and r2.shift == 2
+    assert type(torch.roll(a, 1, 1)) is not lazy.LazyRoll                      # another dimension: the real thing, at once
+    ref = torch.roll(x1 @ w, 1, 0)
+    got = lazy.plain(r)
+    assert type(got) is torch.Tensor and torch.allclose(got, ref) and lazy.plain(r) is got      # computed once
+    assert torch.allclose(r2 + 0.0, torch.roll(x1 @ w, 2, 0))                  # any torch function materialises it
+    (got.sum() * 2.0).backward()
+    torch.testing.assert_close(w.grad, (x1.t() @ torch.full((4, 2), 2.0)))
