@@ -167,9 +167,13 @@ def capture_train_step(train_step: Callable, data, *args, warmup: int = 3, **kwa
     slots: List[torch.Tensor] = []
     rec = _RECORDER = _Recorder(device)
     try:
+        # (the recorded call sees the batch as RollDeferring views of the static buffers: a torch.roll(z1, 1, 0) nobody reads -- the
+        #  reference's z3, main_mlp.py:266 -- then records no launch; anything that does read it gets the rolled tensor)
+        from .lazy import RollDeferring
+        static_view = _tree_map(lambda t: t.as_subclass(RollDeferring) if isinstance(t, torch.Tensor) and not t.requires_grad else t, static)
         with _recording_item(slots):
             with torch.cuda.graph(graph, stream=side):
-                recorded = train_step(static, *args, **kwargs)
+                recorded = train_step(static_view, *args, **kwargs)
                 if slots:                                        # the gather of the host scalars is part of the graph: one D2H copy per replay
                     stacked_dtype = torch.float64 if any(s.dtype == torch.float64 for s in slots) else torch.float32
                     dev_buf = torch.stack([s.to(stacked_dtype) for s in slots])

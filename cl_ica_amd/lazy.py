@@ -29,7 +29,7 @@ from typing import Callable, List, Optional
 import torch
 from torch.utils._pytree import tree_map
 
-__all__ = ["LazyOut", "LazyRoll", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP", "attach", "find_optimizers"]
+__all__ = ["LazyOut", "LazyRoll", "RollDeferring", "defer", "plain", "enabled", "flush_all", "after_step", "AFTER_STEP", "attach", "find_optimizers"]
 
 _META_GETTERS = {"shape", "dtype", "device", "requires_grad", "ndim", "layout", "is_cuda", "is_leaf_placeholder"}
 _META_METHODS = {"dim", "size", "__len__", "ndimension", "numel", "nelement", "is_floating_point", "is_complex", "get_device",
@@ -145,13 +145,9 @@ class LazyOut(torch.Tensor):
         if name == "roll" and args and type(args[0]) is LazyOut:
             # z3_rec = torch.roll(z1_rec, 1, 0) (main_mlp.py:272): LpSimCLRLoss never reads the rolled copy (losses.py: _PairLossSymFn), so the
             # roll itself is deferred as well -- any other consumer gets the real tensor through LazyRoll.materialize()
-            rest = list(args[1:])
-            shifts = kwargs.get("shifts", rest[0] if rest else None)
-            dims = kwargs.get("dims", rest[1] if len(rest) > 1 else None)
-            dims = dims[0] if isinstance(dims, (tuple, list)) and len(dims) == 1 else dims
-            shifts = shifts[0] if isinstance(shifts, (tuple, list)) and len(shifts) == 1 else shifts
-            if isinstance(shifts, int) and dims == 0 and len(args[0].shape) >= 1:
-                return LazyRoll(args[0], shifts)
+            shift = _roll_rows_args(args, kwargs)
+            if shift is not None:
+                return LazyRoll(args[0], shift)
 
         with torch._C.DisableTorchFunctionSubclass():
             return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
@@ -197,6 +193,32 @@ class LazyRoll(torch.Tensor):
 
 def _unwrap(a):
     return a.materialize() if isinstance(a, (LazyOut, LazyRoll)) else a
+
+
+def _roll_rows_args(args, kwargs):
+    """(shift) of a ``roll(x, s, 0)`` call with one integer shift along dim 0, else None."""
+    rest = list(args[1:])
+    shifts = kwargs.get("shifts", rest[0] if rest else None)
+    dims = kwargs.get("dims", rest[1] if len(rest) > 1 else None)
+    dims = dims[0] if isinstance(dims, (tuple, list)) and len(dims) == 1 else dims
+    shifts = shifts[0] if isinstance(shifts, (tuple, list)) and len(shifts) == 1 else shifts
+    return shifts if isinstance(shifts, int) and not isinstance(shifts, bool) and dims == 0 and len(args[0].shape) >= 1 else None
+
+
+class RollDeferring(torch.Tensor):
+    """An ordinary tensor (same storage: ``t.as_subclass(RollDeferring)``) on which ``torch.roll(t, s, 0)`` is deferred (a LazyRoll): what
+    ``capture_train_step`` hands the closure as its batch, so that ``z3 = torch.roll(z1, 1, 0)`` (main_mlp.py:266) -- which the losses of
+    this package never read -- records no launch.  Every other operation runs on the plain tensor and returns plain tensors."""
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if getattr(func, "__name__", "") == "roll" and args and type(args[0]) is RollDeferring:
+            shift = _roll_rows_args(args, kwargs)
+            if shift is not None:
+                return LazyRoll(args[0].as_subclass(torch.Tensor), shift)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
 
 
 def plain(t):

@@ -622,3 +622,17 @@ def test_lazy_roll_of_a_deferred_output_on_cpu():
     assert torch.allclose(r2 + 0.0, torch.roll(x1 @ w, 2, 0))                  # any torch function materialises it
     (got.sum() * 2.0).backward()
     torch.testing.assert_close(w.grad, (x1.t() @ torch.full((4, 2), 2.0)))
+
+
+def test_roll_deferring_view_on_cpu():
+    """lazy.RollDeferring (what capture_train_step hands the recorded closure): same storage as the tensor, roll along dim 0 deferred
+    (LazyRoll on the PLAIN tensor: materialising it must not defer again), everything else plain results."""
+    from cl_ica_amd import lazy
+    t = torch.arange(12.0).reshape(4, 3)
+    v = t.as_subclass(lazy.RollDeferring)
+    assert v.data_ptr() == t.data_ptr() and type(v.to(torch.float32)) is lazy.RollDeferring      # a no-op .to() keeps the view
+    r = torch.roll(v, 1, 0)
+    assert type(r) is lazy.LazyRoll and type(r.source) is torch.Tensor and r._value is None
+    assert torch.equal(lazy.plain(r), torch.roll(t, 1, 0))
+    assert type(v + 1) is torch.Tensor and type(torch.roll(v, 1, 1)) is torch.Tensor and torch.equal(torch.roll(v, 1, 1), torch.roll(t, 1, 1))
+    assert torch.equal(v.roll(-1, 0) * 1.0, torch.roll(t, -1, 0))
